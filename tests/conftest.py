@@ -1,0 +1,45 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    """tests/golden/<name>.npz -> dict of torch tensors (see tests/golden/make_golden.py)."""
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import msda_oracle
+    msda_oracle.build()
+    return msda_oracle
+
+
+def make_problem(B, M, D, Lq, shapes, P, dtype, seed=0, lo=0.0, hi=1.0, device="cpu"):
+    """Random MSDA problem the way the reference's test does it (ops/test.py:33-36)."""
+    g = torch.Generator().manual_seed(seed)
+    shapes = torch.as_tensor(shapes, dtype=torch.long)
+    L = shapes.shape[0]
+    S = int(shapes.prod(1).sum())
+    level_start = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    value = (torch.rand(B, S, M, D, generator=g) * 0.01).to(dtype)
+    loc = (torch.rand(B, Lq, M, L, P, 2, generator=g) * (hi - lo) + lo).to(dtype)
+    attn = torch.rand(B, Lq, M, L, P, generator=g) + 1e-5
+    attn = (attn / attn.sum(-1, keepdim=True).sum(-2, keepdim=True)).to(dtype)
+    grad_out = torch.randn(B, Lq, M * D, generator=g).to(dtype)
+    t = dict(value=value, shapes=shapes, level_start=level_start, loc=loc, attn=attn, grad_out=grad_out)
+    return {k: v.to(device) for k, v in t.items()}
