@@ -1,0 +1,104 @@
+/*
+ * include/monodetr_amd.h -- C ABI of libmonodetr_amd.so (MI355X / gfx950 hot-path kernels).
+ *
+ * This is the drop-in boundary for MonoDETR's native extension.  The reference binds its
+ * CUDA op through pybind11/ATen:
+ *     lib/models/monodetr/ops/src/vision.cpp:13-16         module `MultiScaleDeformableAttention`
+ *     lib/models/monodetr/ops/src/ms_deform_attn.h:20-60   ms_deform_attn_forward / _backward
+ *     lib/models/monodetr/ops/src/cuda/ms_deform_attn_cuda.cu:20-80, :83-153   shapes, asserts, alloc
+ * Here the same two operations are plain `extern "C"` functions taking raw device pointers and
+ * sizes.  No torch/ATen types cross this boundary; the host shim (monodetr_amd/_capi.py) owns
+ * allocation, contiguity checks and the current stream, mirroring what the ATen wrapper did.
+ *
+ * Conventions (all entry points)
+ *   - return 0 on success, a negative MDETR_E_* code on failure; mdetr_last_error() returns a
+ *     thread-local message (the reference only printf'd launch errors, .cuh:948-952).
+ *   - never allocate, free or synchronise; work is enqueued on `stream` (a hipStream_t, may be
+ *     NULL for the default stream) of device ordinal `device`.
+ *   - re-entrant: no global mutable state (forward runs on the main thread, backward on autograd
+ *     worker threads).
+ *   - tensors are dense row-major ("contiguous"), 16-byte aligned base pointers.
+ */
+#ifndef MONODETR_AMD_H
+#define MONODETR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDETR_ABI_VERSION 1
+
+/* element types of the floating-point tensors */
+#define MDETR_F32 0
+#define MDETR_F64 1
+
+#define MDETR_OK            0
+#define MDETR_E_ARG        -1   /* bad size / null pointer / unsupported dtype */
+#define MDETR_E_HIP        -2   /* HIP runtime or launch error (message has the hipError string) */
+#define MDETR_E_ALIGN      -3   /* pointer not 16-byte aligned */
+
+int mdetr_abi_version(void);
+const char *mdetr_last_error(void);
+
+/*
+ * Multi-scale deformable attention, forward.
+ * Replaces ms_deform_attn_cuda_forward (ms_deform_attn_cuda.cu:20-80) and
+ * ms_deformable_im2col_gpu_kernel (ms_deform_im2col_cuda.cuh:237-299).
+ *
+ *   value           [B, S, M, D]            dtype
+ *   spatial_shapes  [L, 2] (H_l, W_l)       int64, DEVICE memory (as in the reference, .cu:67)
+ *   level_start     [L]                     int64, DEVICE memory
+ *   loc             [B, Lq, M, L, P, 2]     dtype, (x, y) normalised to [0,1]
+ *   attn            [B, Lq, M, L, P]        dtype
+ *   out             [B, Lq, M*D]            dtype, fully overwritten (no pre-zeroing needed)
+ *
+ * The reference's im2col_step batch chunking (.cu:50-52) is a launch-size artefact and has no
+ * numerical effect; one launch covers the whole batch here.
+ */
+int mdetr_msda_forward(int dtype,
+                       const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                       const void *loc, const void *attn, void *out,
+                       int B, int S, int M, int D, int L, int Lq, int P,
+                       int device, void *stream);
+
+/*
+ * Multi-scale deformable attention, backward.
+ * Replaces ms_deform_attn_cuda_backward (ms_deform_attn_cuda.cu:83-153) and the col2im kernel
+ * family (ms_deform_im2col_cuda.cuh:301-920).
+ *
+ *   grad_out    [B, Lq, M*D]
+ *   grad_value  [B, S, M, D]           } all three are zero-filled by this call on `stream`
+ *   grad_loc    [B, Lq, M, L, P, 2]    } before accumulation (the reference's at::zeros_like,
+ *   grad_attn   [B, Lq, M, L, P]       } .cu:121-123); the caller may pass uninitialised memory.
+ *
+ * grad_value is accumulated with floating-point atomics: summation order (hence the last bits)
+ * is not deterministic, exactly as in the reference (.cuh:125-152).
+ */
+int mdetr_msda_backward(int dtype,
+                        const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                        const void *loc, const void *attn, const void *grad_out,
+                        void *grad_value, void *grad_loc, void *grad_attn,
+                        int B, int S, int M, int D, int L, int Lq, int P,
+                        int device, void *stream);
+
+/*
+ * Gather indices the kernels use, for bit-exact index parity checks.
+ *   idx [B, Lq, M, L, P, 4] int32 = (in_window, h_low, w_low, corner_mask); zeros when the sample
+ *   is outside the window (.cuh:288).  corner_mask bit0..3 = validity of (low,low) (low,high)
+ *   (high,low) (high,high) per .cuh:56,62,68,74.
+ */
+int mdetr_msda_indices(int dtype, const int64_t *spatial_shapes, const void *loc, int32_t *idx,
+                       int B, int M, int L, int Lq, int P, int device, void *stream);
+
+/*
+ * Which kernel variant a given problem dispatches to: 1 = gfx950 fast path (f32, D == 32),
+ * 0 = generic path (any D, f32/f64).  Pure host logic, no GPU needed.
+ */
+int mdetr_msda_variant(int dtype, int M, int D, int L, int P);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONODETR_AMD_H */

@@ -1,0 +1,70 @@
+"""ctypes binding of libmonodetr_amd.so (C ABI declared in include/monodetr_amd.h).
+
+This is plumbing: it hands raw device pointers, sizes, the device ordinal and the current HIP
+stream to the C ABI and turns negative return codes into ``RuntimeError`` (the reference's ATen
+wrapper raises through AT_ASSERTM / AT_ERROR, ops/src/cuda/ms_deform_attn_cuda.cu:28-52).
+
+There is NO fallback: if the shared library is missing or fails to load, importing symbols from
+here raises.  Build it with ``python -m monodetr_amd.build`` (or ``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmonodetr_amd.so")
+
+MDETR_F32, MDETR_F64 = 0, 1
+ABI_VERSION = 1
+
+_c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/monodetr_amd.h
+SIGNATURES = {
+    "mdetr_abi_version": (_c_int, []),
+    "mdetr_last_error": (ctypes.c_char_p, []),
+    "mdetr_msda_variant": (_c_int, [_c_int] * 5),
+    "mdetr_msda_forward": (_c_int, [_c_int] + [_c_vp] * 6 + [_c_int] * 7 + [_c_int, _c_vp]),
+    "mdetr_msda_backward": (_c_int, [_c_int] + [_c_vp] * 10 + [_c_int] * 7 + [_c_int, _c_vp]),
+    "mdetr_msda_indices": (_c_int, [_c_int] + [_c_vp] * 3 + [_c_int] * 5 + [_c_int, _c_vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """The loaded library (loads on first use). Raises if it is not built -- no fallback."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        "monodetr_amd: %s is missing -- the HIP extension is not built. Run "
+                        "`python -m monodetr_amd.build` (needs hipcc). There is no CPU/PyTorch fallback." % LIB_PATH)
+                handle = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(handle, name)          # AttributeError if the .so is stale
+                    fn.restype, fn.argtypes = res, args
+                got = handle.mdetr_abi_version()
+                if got != ABI_VERSION:
+                    raise RuntimeError("monodetr_amd: ABI version mismatch (lib %d, python %d); rebuild" % (got, ABI_VERSION))
+                _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().mdetr_last_error()
+        raise RuntimeError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def dtype_code(t):
+    import torch
+    if t.dtype == torch.float32:
+        return MDETR_F32
+    if t.dtype == torch.float64:
+        return MDETR_F64
+    # same wording as AT_DISPATCH_FLOATING_TYPES (ms_deform_attn_cuda.cu:64,134)
+    raise RuntimeError('"ms_deform_attn" not implemented for \'%s\'' % str(t.dtype).replace("torch.", ""))

@@ -1,0 +1,56 @@
+"""Build libmonodetr_amd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m monodetr_amd.build [--force] [--save-temps]
+
+The .so lands next to this file (monodetr_amd/libmonodetr_amd.so): git-ignored, but it travels to
+the GPU box with the repo snapshot.  hipcc cross-compiles without a GPU.
+"""
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(HERE, "libmonodetr_amd.so")
+ARCH = "gfx950"
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm); cannot build libmonodetr_amd.so")
+
+
+def build(force=False, save_temps=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-munsafe-fp-atomics", "-Wno-pass-failed", "-I", INCLUDE, "-I", CSRC, "-o", LIB] + sources()
+    if save_temps:
+        tmp = os.path.join(HERE, "build_tmp")
+        os.makedirs(tmp, exist_ok=True)
+        cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True))

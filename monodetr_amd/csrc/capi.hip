@@ -1,0 +1,117 @@
+// monodetr_amd/csrc/capi.hip -- extern "C" entry points of libmonodetr_amd.so (include/monodetr_amd.h).
+// Argument validation + device/stream plumbing + error reporting; kernels live in msda.hip.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/monodetr_amd.h"
+#include "msda.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// Make `device` current for the duration of one call and restore the caller's device afterwards
+// (torch tracks the current device per thread; do not leave it changed).
+struct DeviceScope {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceScope(int device)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device); else prev = -1;
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_common(const char *who, int dtype, int B, int S, int M, int D, int L, int Lq, int P)
+{
+    if (dtype != MDETR_F32 && dtype != MDETR_F64)
+        return fail(MDETR_E_ARG, "%s: unsupported dtype %d (MDETR_F32 / MDETR_F64 only, as AT_DISPATCH_FLOATING_TYPES)", who, dtype);
+    if (B < 0 || S < 0 || M <= 0 || D <= 0 || L <= 0 || Lq < 0 || P <= 0)
+        return fail(MDETR_E_ARG, "%s: bad sizes B=%d S=%d M=%d D=%d L=%d Lq=%d P=%d", who, B, S, M, D, L, Lq, P);
+    if (static_cast<int64_t>(S) * M * D >= (1ll << 31) || static_cast<int64_t>(Lq) * M * L * P * 2 >= (1ll << 31))
+        return fail(MDETR_E_ARG, "%s: one image exceeds 2^31 elements (S*M*D or Lq*M*L*P*2)", who);
+    return MDETR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdetr_abi_version(void) { return MDETR_ABI_VERSION; }
+
+const char *mdetr_last_error(void) { return g_err; }
+
+int mdetr_msda_variant(int dtype, int M, int D, int L, int P)
+{
+    (void)M;
+    return mdetr::msda_fast_path(dtype, D, L, P) ? 1 : 0;
+}
+
+int mdetr_msda_forward(int dtype, const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                       const void *loc, const void *attn, void *out,
+                       int B, int S, int M, int D, int L, int Lq, int P, int device, void *stream)
+{
+    if (int rc = check_common("mdetr_msda_forward", dtype, B, S, M, D, L, Lq, P)) return rc;
+    if (B == 0 || Lq == 0) return MDETR_OK;
+    if (!value || !spatial_shapes || !level_start || !loc || !attn || !out)
+        return fail(MDETR_E_ARG, "mdetr_msda_forward: null pointer");
+    if (!aligned16(value) || !aligned16(loc) || !aligned16(attn) || !aligned16(out))
+        return fail(MDETR_E_ALIGN, "mdetr_msda_forward: value/loc/attn/out must be 16-byte aligned");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_forward: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::msda_forward_launch(dtype, value, spatial_shapes, level_start, loc, attn, out,
+                                                    B, S, M, D, L, Lq, P, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_forward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_msda_backward(int dtype, const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                        const void *loc, const void *attn, const void *grad_out,
+                        void *grad_value, void *grad_loc, void *grad_attn,
+                        int B, int S, int M, int D, int L, int Lq, int P, int device, void *stream)
+{
+    if (int rc = check_common("mdetr_msda_backward", dtype, B, S, M, D, L, Lq, P)) return rc;
+    if (B == 0) return MDETR_OK;
+    if (!value || !spatial_shapes || !level_start || !grad_value || (Lq && (!loc || !attn || !grad_out || !grad_loc || !grad_attn)))
+        return fail(MDETR_E_ARG, "mdetr_msda_backward: null pointer");
+    if (!aligned16(value) || !aligned16(loc) || !aligned16(attn) || !aligned16(grad_out) ||
+        !aligned16(grad_value) || !aligned16(grad_loc) || !aligned16(grad_attn))
+        return fail(MDETR_E_ALIGN, "mdetr_msda_backward: tensors must be 16-byte aligned");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_backward: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::msda_backward_launch(dtype, value, spatial_shapes, level_start, loc, attn, grad_out,
+                                                     grad_value, grad_loc, grad_attn, B, S, M, D, L, Lq, P,
+                                                     static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_backward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_msda_indices(int dtype, const int64_t *spatial_shapes, const void *loc, int32_t *idx,
+                       int B, int M, int L, int Lq, int P, int device, void *stream)
+{
+    if (int rc = check_common("mdetr_msda_indices", dtype, B, 0, M, 1, L, Lq, P)) return rc;
+    if (B == 0 || Lq == 0) return MDETR_OK;
+    if (!spatial_shapes || !loc || !idx) return fail(MDETR_E_ARG, "mdetr_msda_indices: null pointer");
+    if (!aligned16(idx)) return fail(MDETR_E_ALIGN, "mdetr_msda_indices: idx must be 16-byte aligned");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_indices: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::msda_indices_launch(dtype, spatial_shapes, loc, idx, B, M, L, Lq, P,
+                                                    static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_indices: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+}  // extern "C"

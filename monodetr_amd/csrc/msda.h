@@ -1,0 +1,23 @@
+// monodetr_amd/csrc/msda.h -- internal launcher declarations (see msda.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mdetr {
+
+// dtype: 0 = f32, 1 = f64 (MDETR_F32 / MDETR_F64 of include/monodetr_amd.h)
+bool msda_fast_path(int dtype, int D, int L, int P);
+
+hipError_t msda_forward_launch(int dtype, const void *value, const int64_t *shapes, const int64_t *lstart,
+                               const void *loc, const void *attn, void *out,
+                               int B, int S, int M, int D, int L, int Lq, int P, hipStream_t st);
+
+hipError_t msda_backward_launch(int dtype, const void *value, const int64_t *shapes, const int64_t *lstart,
+                                const void *loc, const void *attn, const void *grad_out,
+                                void *grad_value, void *grad_loc, void *grad_attn,
+                                int B, int S, int M, int D, int L, int Lq, int P, hipStream_t st);
+
+hipError_t msda_indices_launch(int dtype, const int64_t *shapes, const void *loc, int32_t *idx,
+                               int B, int M, int L, int Lq, int P, hipStream_t st);
+
+}  // namespace mdetr

@@ -1,0 +1,524 @@
+// monodetr_amd/csrc/msda.hip -- multi-scale deformable attention for MI355X (gfx950, wave64).
+//
+// What it computes (semantics fixed by the reference, /root/reference/lib/models/monodetr/ops):
+//   forward   src/cuda/ms_deform_im2col_cuda.cuh:237-299 + :33-84
+//   backward  src/cuda/ms_deform_im2col_cuda.cuh:301-403 + :87-159 (and the _gm variant :845-920)
+// How it computes it is new.  The reference runs one thread per output scalar (1024-thread blocks
+// forward, D-thread = half-wave blocks backward with serial shared-memory sums).  Here:
+//
+//   fast path (f32, D == 32, the shipped geometry M*D = 256):
+//     - a "pair" is one (b, q, m); its 32 channels are one 128-byte row of `value` per pixel.
+//       8 lanes x float4 cover that row, so a wave64 handles 8 consecutive pairs and every corner
+//       gather is ONE dwordx4 instruction fetching eight full 128-B lines (1 KiB / instruction).
+//     - loc / attn of the 8 pairs are contiguous in memory: one coalesced dwordx4 (+ one
+//       dwordx4 on half the lanes) brings them in, a wave-private LDS slab (padded so the eight
+//       broadcast reads hit distinct banks) hands them to the 8 lanes of each pair.  The reference
+//       re-reads them from global memory in every one of the D channel threads.
+//     - blockIdx -> (image, query chunk) is chosen so all blocks that the dispatcher places on one
+//       XCD (block b -> XCD b % 8) walk the queries of the same image in order: each XCD's private
+//       4 MiB L2 then holds a sliding band of one image's value rows instead of all B images.
+//     - backward: grad_loc / grad_attn are reduced over the 8 lanes of a pair with three DPP adds
+//       (quad_perm, quad_perm, row_half_mirror) -- no barriers, no serial sums -- staged in the LDS
+//       slab and written back coalesced; grad_value goes out as hardware fp32 atomics
+//       (global_atomic_add_f32, executed in L2).
+//   generic path (any D, f32 / f64): one thread per (b, q, m, c), all reductions by atomics, like
+//     the reference's `_gm` kernel.  Used for the reference's gradcheck shapes (D = 30 .. 3096).
+//
+// Pixel coordinate: `loc * size - 0.5` with the product ROUNDED before the subtraction -- the
+// reference's 0.5 is a double literal (.cuh:285-286), so no FMA there -- see pix_coord().
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "msda.h"
+
+namespace mdetr {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// shared arithmetic
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T pix_coord(T loc, int size)
+{
+#pragma clang fp contract(off)
+    const T prod = loc * static_cast<T>(size);
+    return prod - static_cast<T>(0.5);
+}
+
+template <typename T>
+struct Foot {
+    int h_low, w_low;
+    T lh, lw, hh, hw;
+    bool ok1, ok2, ok3, ok4;   // (low,low) (low,high) (high,low) (high,high), false outside window
+    bool inwin;
+};
+
+template <typename T>
+__device__ __forceinline__ Foot<T> footprint(T h_im, T w_im, int H, int W)
+{
+    Foot<T> f;
+    f.inwin = h_im > T(-1) && w_im > T(-1) && h_im < static_cast<T>(H) && w_im < static_cast<T>(W);   // .cuh:288
+    // keep the float->int conversion defined for wild locations: outside the window the values are unused
+    const T hs = f.inwin ? h_im : T(0), ws = f.inwin ? w_im : T(0);
+    const T hf = floor(hs), wf = floor(ws);
+    f.h_low = static_cast<int>(hf);
+    f.w_low = static_cast<int>(wf);
+    f.lh = hs - hf;
+    f.lw = ws - wf;
+    f.hh = T(1) - f.lh;
+    f.hw = T(1) - f.lw;
+    const bool hl = f.h_low >= 0, wl = f.w_low >= 0, hh_ = f.h_low + 1 <= H - 1, wh_ = f.w_low + 1 <= W - 1;
+    f.ok1 = f.inwin && hl && wl;
+    f.ok2 = f.inwin && hl && wh_;
+    f.ok3 = f.inwin && hh_ && wl;
+    f.ok4 = f.inwin && hh_ && wh_;
+    return f;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// sum over the 8 lanes of a pair group; result in all 8 lanes
+__device__ __forceinline__ float sum8(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    return v;
+}
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    // LDS operations of one wave execute in order; this only stops the compiler from moving
+    // the slab reads above the slab writes (and the next round's writes above this round's reads).
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int kWaves = 4;          // 256-thread workgroups
+constexpr int kPairsPerWave = 8;   // 8 lanes x float4 = one 128-B (D = 32) row per pair
+constexpr int kPad = 4;            // floats of padding per pair in the slab (keeps 16-B alignment)
+
+__host__ __device__ constexpr int slab_floats(int LP) { return kPairsPerWave * (2 * LP + kPad) + kPairsPerWave * (LP + kPad); }
+
+// Stage loc / attn (or nothing but geometry) of `nv` pairs starting at global pair `g0` into the
+// wave's slab.  LP % 4 == 0, so a float4 never straddles two pairs.
+template <int TLP>
+__device__ __forceinline__ void stage_pairs(const float *__restrict__ loc, const float *__restrict__ attn,
+                                            float *s_loc, float *s_att, int64_t g0, int nv, int LP_, int lane)
+{
+    const int LP = TLP ? TLP : LP_;
+    const float4 *gl = reinterpret_cast<const float4 *>(loc + g0 * 2 * LP);
+    const float4 *ga = reinterpret_cast<const float4 *>(attn + g0 * LP);
+    const int nl4 = nv * 2 * LP / 4, na4 = nv * LP / 4;
+    for (int i = lane; i < nl4; i += 64) {
+        const float4 v = gl[i];
+        const int f = 4 * i, j = f / (2 * LP), r = f - j * 2 * LP;
+        *reinterpret_cast<float4 *>(s_loc + j * (2 * LP + kPad) + r) = v;
+    }
+    for (int i = lane; i < na4; i += 64) {
+        const float4 v = ga[i];
+        const int f = 4 * i, j = f / LP, r = f - j * LP;
+        *reinterpret_cast<float4 *>(s_att + j * (LP + kPad) + r) = v;
+    }
+}
+
+struct LevelGeom { int H, W; int start; };
+
+__device__ __forceinline__ LevelGeom level_geom(const int64_t *__restrict__ shapes, const int64_t *__restrict__ lstart, int l)
+{
+    LevelGeom g;
+    g.H = static_cast<int>(shapes[2 * l]);          // wave-uniform -> scalar loads
+    g.W = static_cast<int>(shapes[2 * l + 1]);
+    g.start = static_cast<int>(lstart[l]);
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fast path, forward
+// ------------------------------------------------------------------------------------------------
+template <int TL, int TP>
+__global__ __launch_bounds__(kWaves * 64)
+void msda_fwd_d32(const float *__restrict__ value, const int64_t *__restrict__ shapes,
+                  const int64_t *__restrict__ lstart, const float *__restrict__ loc,
+                  const float *__restrict__ attn, float *__restrict__ out,
+                  int B, int S, int M, int L_, int P_, int npairs, int iters)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int L = TL ? TL : L_, P = TP ? TP : P_, LP = L * P;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x % B, chunk = blockIdx.x / B;   // same image on the same XCD (bid % 8)
+    float *s_loc = smem + wave * slab_floats(LP);
+    float *s_att = s_loc + kPairsPerWave * (2 * LP + kPad);
+    const int j = lane >> 3, k = lane & 7;
+    const int64_t img = static_cast<int64_t>(b) * S * M * 32;
+    const int row = M * 32;                                  // floats per pixel
+
+    for (int it = 0; it < iters; ++it) {
+        const int p0 = (chunk * iters + it) * (kWaves * kPairsPerWave) + wave * kPairsPerWave;
+        if (p0 >= npairs) break;                             // wave-uniform
+        const int nv = min(kPairsPerWave, npairs - p0);
+        const int64_t g0 = static_cast<int64_t>(b) * npairs + p0;
+        wave_lds_fence();
+        stage_pairs<TL * TP>(loc, attn, s_loc, s_att, g0, nv, LP, lane);
+        wave_lds_fence();
+        if (j < nv) {
+            const int m = (p0 + j) % M;
+            const float *vb = value + img + m * 32 + k * 4;
+            const float *my_loc = s_loc + j * (2 * LP + kPad);
+            const float *my_att = s_att + j * (LP + kPad);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const LevelGeom g = level_geom(shapes, lstart, l);
+                const float *vl = vb + static_cast<int64_t>(g.start) * row;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const int s = l * P + p;
+                    const float2 xy = *reinterpret_cast<const float2 *>(my_loc + 2 * s);
+                    const float a = my_att[s];
+                    const Foot<float> f = footprint(pix_coord(xy.y, g.H), pix_coord(xy.x, g.W), g.H, g.W);
+                    const int y0 = clampi(f.h_low, 0, g.H - 1), y1 = clampi(f.h_low + 1, 0, g.H - 1);
+                    const int x0 = clampi(f.w_low, 0, g.W - 1), x1 = clampi(f.w_low + 1, 0, g.W - 1);
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 v1 = *reinterpret_cast<const float4 *>(vl + (y0 * g.W + x0) * row);
+                    float4 v2 = *reinterpret_cast<const float4 *>(vl + (y0 * g.W + x1) * row);
+                    float4 v3 = *reinterpret_cast<const float4 *>(vl + (y1 * g.W + x0) * row);
+                    float4 v4 = *reinterpret_cast<const float4 *>(vl + (y1 * g.W + x1) * row);
+                    v1 = f.ok1 ? v1 : z; v2 = f.ok2 ? v2 : z; v3 = f.ok3 ? v3 : z; v4 = f.ok4 ? v4 : z;
+                    const float w1 = f.hh * f.hw, w2 = f.hh * f.lw, w3 = f.lh * f.hw, w4 = f.lh * f.lw;   // .cuh:80
+                    const float wa = f.inwin ? a : 0.f;
+                    acc.x += (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) * wa;                       // .cuh:82,290
+                    acc.y += (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) * wa;
+                    acc.z += (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) * wa;
+                    acc.w += (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w) * wa;
+                }
+            }
+            *reinterpret_cast<float4 *>(out + (g0 + j) * 32 + k * 4) = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fast path, backward
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_add4(float *p, float s, const float4 &t)
+{
+    unsafeAtomicAdd(p + 0, s * t.x);
+    unsafeAtomicAdd(p + 1, s * t.y);
+    unsafeAtomicAdd(p + 2, s * t.z);
+    unsafeAtomicAdd(p + 3, s * t.w);
+}
+
+template <int TL, int TP>
+__global__ __launch_bounds__(kWaves * 64)
+void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ shapes,
+                  const int64_t *__restrict__ lstart, const float *__restrict__ loc,
+                  const float *__restrict__ attn, const float *__restrict__ grad_out,
+                  float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
+                  int B, int S, int M, int L_, int P_, int npairs, int iters)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int L = TL ? TL : L_, P = TP ? TP : P_, LP = L * P;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x % B, chunk = blockIdx.x / B;
+    float *s_loc = smem + wave * slab_floats(LP);
+    float *s_att = s_loc + kPairsPerWave * (2 * LP + kPad);
+    const int j = lane >> 3, k = lane & 7;
+    const int64_t img = static_cast<int64_t>(b) * S * M * 32;
+    const int row = M * 32;
+
+    for (int it = 0; it < iters; ++it) {
+        const int p0 = (chunk * iters + it) * (kWaves * kPairsPerWave) + wave * kPairsPerWave;
+        if (p0 >= npairs) break;
+        const int nv = min(kPairsPerWave, npairs - p0);
+        const int64_t g0 = static_cast<int64_t>(b) * npairs + p0;
+        wave_lds_fence();
+        stage_pairs<TL * TP>(loc, attn, s_loc, s_att, g0, nv, LP, lane);
+        wave_lds_fence();
+        if (j < nv) {
+            const int m = (p0 + j) % M;
+            const int64_t voff = img + m * 32 + k * 4;
+            float *my_loc = s_loc + j * (2 * LP + kPad);
+            float *my_att = s_att + j * (LP + kPad);
+            const float4 go = *reinterpret_cast<const float4 *>(grad_out + (g0 + j) * 32 + k * 4);
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const LevelGeom g = level_geom(shapes, lstart, l);
+                const int64_t loff = voff + static_cast<int64_t>(g.start) * row;
+                const float *vl = value + loff;
+                float *gvl = grad_value + loff;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const int s = l * P + p;
+                    const float2 xy = *reinterpret_cast<const float2 *>(my_loc + 2 * s);
+                    const float a = my_att[s];
+                    const Foot<float> f = footprint(pix_coord(xy.y, g.H), pix_coord(xy.x, g.W), g.H, g.W);
+                    const int y0 = clampi(f.h_low, 0, g.H - 1), y1 = clampi(f.h_low + 1, 0, g.H - 1);
+                    const int x0 = clampi(f.w_low, 0, g.W - 1), x1 = clampi(f.w_low + 1, 0, g.W - 1);
+                    const int o1 = (y0 * g.W + x0) * row, o2 = (y0 * g.W + x1) * row;
+                    const int o3 = (y1 * g.W + x0) * row, o4 = (y1 * g.W + x1) * row;
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 v1 = *reinterpret_cast<const float4 *>(vl + o1);
+                    float4 v2 = *reinterpret_cast<const float4 *>(vl + o2);
+                    float4 v3 = *reinterpret_cast<const float4 *>(vl + o3);
+                    float4 v4 = *reinterpret_cast<const float4 *>(vl + o4);
+                    v1 = f.ok1 ? v1 : z; v2 = f.ok2 ? v2 : z; v3 = f.ok3 ? v3 : z; v4 = f.ok4 ? v4 : z;
+                    const float w1 = f.hh * f.hw, w2 = f.hh * f.lw, w3 = f.lh * f.hw, w4 = f.lh * f.lw;
+                    const float4 tgv = make_float4(go.x * a, go.y * a, go.z * a, go.w * a);      // .cuh:113
+                    if (f.ok1) atomic_add4(gvl + o1, w1, tgv);                                  // .cuh:125
+                    if (f.ok2) atomic_add4(gvl + o2, w2, tgv);                                  // .cuh:134
+                    if (f.ok3) atomic_add4(gvl + o3, w3, tgv);                                  // .cuh:143
+                    if (f.ok4) atomic_add4(gvl + o4, w4, tgv);                                  // .cuh:152
+                    float pa = 0.f, pw = 0.f, ph = 0.f;
+#define MDETR_CH(c)                                                                              \
+                    {                                                                            \
+                        const float gh = -f.hw * v1.c - f.lw * v2.c + f.hw * v3.c + f.lw * v4.c; /* .cuh:123-151 */ \
+                        const float gw = -f.hh * v1.c + f.hh * v2.c - f.lh * v3.c + f.lh * v4.c; \
+                        const float val = w1 * v1.c + w2 * v2.c + w3 * v3.c + w4 * v4.c;         \
+                        pa += go.c * val;                                                        \
+                        pw += gw * tgv.c;                                                        \
+                        ph += gh * tgv.c;                                                        \
+                    }
+                    MDETR_CH(x) MDETR_CH(y) MDETR_CH(z) MDETR_CH(w)
+#undef MDETR_CH
+                    pa = sum8(pa);
+                    pw = sum8(pw) * static_cast<float>(g.W);                                    // .cuh:157
+                    ph = sum8(ph) * static_cast<float>(g.H);                                    // .cuh:158
+                    if (k == 0) {                     // slot s has been read by all 8 lanes (in-order LDS)
+                        *reinterpret_cast<float2 *>(my_loc + 2 * s) = f.inwin ? make_float2(pw, ph) : make_float2(0.f, 0.f);
+                        my_att[s] = f.inwin ? pa : 0.f;
+                    }
+                }
+            }
+        }
+        wave_lds_fence();
+        // coalesced write-back of the slab (mirror of stage_pairs)
+        {
+            float4 *gl = reinterpret_cast<float4 *>(grad_loc + g0 * 2 * LP);
+            float4 *ga = reinterpret_cast<float4 *>(grad_attn + g0 * LP);
+            const int nl4 = nv * 2 * LP / 4, na4 = nv * LP / 4;
+            for (int i = lane; i < nl4; i += 64) {
+                const int fo = 4 * i, jj = fo / (2 * LP), r = fo - jj * 2 * LP;
+                gl[i] = *reinterpret_cast<const float4 *>(s_loc + jj * (2 * LP + kPad) + r);
+            }
+            for (int i = lane; i < na4; i += 64) {
+                const int fo = 4 * i, jj = fo / LP, r = fo - jj * LP;
+                ga[i] = *reinterpret_cast<const float4 *>(s_att + jj * (LP + kPad) + r);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic path (any D, float / double): one thread per (b, q, m, c)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256)
+void msda_fwd_generic(const T *__restrict__ value, const int64_t *__restrict__ shapes,
+                      const int64_t *__restrict__ lstart, const T *__restrict__ loc,
+                      const T *__restrict__ attn, T *__restrict__ out,
+                      int S, int M, int D, int L, int Lq, int P, int64_t n)
+{
+    for (int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; idx < n;
+         idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int c = static_cast<int>(idx % D);
+        const int64_t samp = idx / D;                     // (b*Lq + q)*M + m
+        const int m = static_cast<int>(samp % M);
+        const int64_t b = samp / M / Lq;
+        const int64_t row = static_cast<int64_t>(M) * D;
+        const T *locp = loc + samp * L * P * 2;
+        const T *attp = attn + samp * L * P;
+        T col = 0;
+        for (int l = 0; l < L; ++l) {
+            const int H = static_cast<int>(shapes[2 * l]), W = static_cast<int>(shapes[2 * l + 1]);
+            const T *vb = value + (b * S + lstart[l]) * row + m * D + c;
+            for (int p = 0; p < P; ++p) {
+                const T x = locp[(l * P + p) * 2], y = locp[(l * P + p) * 2 + 1], a = attp[l * P + p];
+                const Foot<T> f = footprint(pix_coord(y, H), pix_coord(x, W), H, W);
+                if (!f.inwin) continue;
+                const int64_t o = (static_cast<int64_t>(f.h_low) * W + f.w_low) * row;
+                const T v1 = f.ok1 ? vb[o] : T(0);
+                const T v2 = f.ok2 ? vb[o + row] : T(0);
+                const T v3 = f.ok3 ? vb[o + W * row] : T(0);
+                const T v4 = f.ok4 ? vb[o + W * row + row] : T(0);
+                col += (f.hh * f.hw * v1 + f.hh * f.lw * v2 + f.lh * f.hw * v3 + f.lh * f.lw * v4) * a;
+            }
+        }
+        out[idx] = col;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void msda_bwd_generic(const T *__restrict__ value, const int64_t *__restrict__ shapes,
+                      const int64_t *__restrict__ lstart, const T *__restrict__ loc,
+                      const T *__restrict__ attn, const T *__restrict__ grad_out,
+                      T *__restrict__ grad_value, T *__restrict__ grad_loc, T *__restrict__ grad_attn,
+                      int S, int M, int D, int L, int Lq, int P, int64_t n)
+{
+    for (int64_t idx = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; idx < n;
+         idx += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int c = static_cast<int>(idx % D);
+        const int64_t samp = idx / D;
+        const int m = static_cast<int>(samp % M);
+        const int64_t b = samp / M / Lq;
+        const int64_t row = static_cast<int64_t>(M) * D;
+        const T *locp = loc + samp * L * P * 2;
+        const T *attp = attn + samp * L * P;
+        T *glocp = grad_loc + samp * L * P * 2;
+        T *gattp = grad_attn + samp * L * P;
+        const T top = grad_out[idx];
+        for (int l = 0; l < L; ++l) {
+            const int H = static_cast<int>(shapes[2 * l]), W = static_cast<int>(shapes[2 * l + 1]);
+            const int64_t base = (b * S + lstart[l]) * row + m * D + c;
+            const T *vb = value + base;
+            T *gvb = grad_value + base;
+            for (int p = 0; p < P; ++p) {
+                const T x = locp[(l * P + p) * 2], y = locp[(l * P + p) * 2 + 1], a = attp[l * P + p];
+                const Foot<T> f = footprint(pix_coord(y, H), pix_coord(x, W), H, W);
+                if (!f.inwin) continue;
+                const int64_t o = (static_cast<int64_t>(f.h_low) * W + f.w_low) * row;
+                const T tgv = top * a;
+                T gh = 0, gw = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+                if (f.ok1) { v1 = vb[o];                 gh -= f.hw * v1; gw -= f.hh * v1; unsafeAtomicAdd(gvb + o,                 f.hh * f.hw * tgv); }
+                if (f.ok2) { v2 = vb[o + row];           gh -= f.lw * v2; gw += f.hh * v2; unsafeAtomicAdd(gvb + o + row,           f.hh * f.lw * tgv); }
+                if (f.ok3) { v3 = vb[o + W * row];       gh += f.hw * v3; gw -= f.lh * v3; unsafeAtomicAdd(gvb + o + W * row,       f.lh * f.hw * tgv); }
+                if (f.ok4) { v4 = vb[o + W * row + row]; gh += f.lw * v4; gw += f.lh * v4; unsafeAtomicAdd(gvb + o + W * row + row, f.lh * f.lw * tgv); }
+                const T val = f.hh * f.hw * v1 + f.hh * f.lw * v2 + f.lh * f.hw * v3 + f.lh * f.lw * v4;
+                unsafeAtomicAdd(gattp + l * P + p, top * val);                        // .cuh:231
+                unsafeAtomicAdd(glocp + (l * P + p) * 2, static_cast<T>(W) * gw * tgv);      // .cuh:232
+                unsafeAtomicAdd(glocp + (l * P + p) * 2 + 1, static_cast<T>(H) * gh * tgv);  // .cuh:233
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void msda_indices_kernel(const int64_t *__restrict__ shapes, const T *__restrict__ loc, int32_t *__restrict__ idx,
+                         int L, int P, int64_t n)
+{
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int l = static_cast<int>((i / P) % L);
+        const int H = static_cast<int>(shapes[2 * l]), W = static_cast<int>(shapes[2 * l + 1]);
+        const Foot<T> f = footprint(pix_coord(loc[2 * i + 1], H), pix_coord(loc[2 * i], W), H, W);
+        int4 o = make_int4(0, 0, 0, 0);
+        if (f.inwin) o = make_int4(1, f.h_low, f.w_low, int(f.ok1) | (int(f.ok2) << 1) | (int(f.ok3) << 2) | (int(f.ok4) << 3));
+        *reinterpret_cast<int4 *>(idx + 4 * i) = o;
+    }
+}
+
+int grid_for(int64_t n, int block)
+{
+    const int64_t g = (n + block - 1) / block;
+    return static_cast<int>(g < 1 ? 1 : (g > 65536 ? 65536 : g));
+}
+
+// how many 32-pair rounds each workgroup walks: keep >= ~8 workgroups per CU in flight on big
+// problems, one round per workgroup on small ones (decoder: 4400 pairs / image)
+int rounds_per_block(int B, int npairs)
+{
+    const int64_t rounds = static_cast<int64_t>(B) * ((npairs + 31) / 32);
+    int it = static_cast<int>(rounds / (256 * 16));
+    return it < 1 ? 1 : (it > 4 ? 4 : it);
+}
+
+}  // namespace
+
+bool msda_fast_path(int dtype, int D, int L, int P)
+{
+    return dtype == 0 && D == 32 && L >= 1 && P >= 1 && (L * P) % 4 == 0 && L * P <= 64;
+}
+
+hipError_t msda_forward_launch(int dtype, const void *value, const int64_t *shapes, const int64_t *lstart,
+                               const void *loc, const void *attn, void *out,
+                               int B, int S, int M, int D, int L, int Lq, int P, hipStream_t st)
+{
+    const int64_t n = static_cast<int64_t>(B) * Lq * M * D;
+    if (n == 0) return hipSuccess;
+    if (msda_fast_path(dtype, D, L, P)) {
+        const int npairs = Lq * M, iters = rounds_per_block(B, npairs);
+        const int chunks = (npairs + 32 * iters - 1) / (32 * iters);
+        const dim3 grid(static_cast<unsigned>(B) * chunks), block(kWaves * 64);
+        const size_t lds = sizeof(float) * kWaves * slab_floats(L * P);
+        auto a = [&](auto kern) {
+            hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const float *>(value), shapes, lstart,
+                               static_cast<const float *>(loc), static_cast<const float *>(attn),
+                               static_cast<float *>(out), B, S, M, L, P, npairs, iters);
+        };
+        if (L == 4 && P == 4) a(msda_fwd_d32<4, 4>); else a(msda_fwd_d32<0, 0>);
+    } else if (dtype == 0) {
+        hipLaunchKernelGGL(msda_fwd_generic<float>, dim3(grid_for(n, 256)), dim3(256), 0, st,
+                           static_cast<const float *>(value), shapes, lstart, static_cast<const float *>(loc),
+                           static_cast<const float *>(attn), static_cast<float *>(out), S, M, D, L, Lq, P, n);
+    } else {
+        hipLaunchKernelGGL(msda_fwd_generic<double>, dim3(grid_for(n, 256)), dim3(256), 0, st,
+                           static_cast<const double *>(value), shapes, lstart, static_cast<const double *>(loc),
+                           static_cast<const double *>(attn), static_cast<double *>(out), S, M, D, L, Lq, P, n);
+    }
+    return hipGetLastError();
+}
+
+hipError_t msda_backward_launch(int dtype, const void *value, const int64_t *shapes, const int64_t *lstart,
+                                const void *loc, const void *attn, const void *grad_out,
+                                void *grad_value, void *grad_loc, void *grad_attn,
+                                int B, int S, int M, int D, int L, int Lq, int P, hipStream_t st)
+{
+    const size_t e = dtype == 0 ? 4 : 8;
+    const int64_t nv = static_cast<int64_t>(B) * S * M * D, ns = static_cast<int64_t>(B) * Lq * M * L * P;
+    hipError_t err;
+    if (nv && (err = hipMemsetAsync(grad_value, 0, nv * e, st)) != hipSuccess) return err;
+    const int64_t n = static_cast<int64_t>(B) * Lq * M * D;
+    if (n == 0 || ns == 0) return hipSuccess;
+    const bool fast = msda_fast_path(dtype, D, L, P);
+    if (!fast) {   // generic path accumulates grad_loc / grad_attn with atomics
+        if ((err = hipMemsetAsync(grad_loc, 0, ns * 2 * e, st)) != hipSuccess) return err;
+        if ((err = hipMemsetAsync(grad_attn, 0, ns * e, st)) != hipSuccess) return err;
+    }
+    if (fast) {
+        const int npairs = Lq * M, iters = rounds_per_block(B, npairs);
+        const int chunks = (npairs + 32 * iters - 1) / (32 * iters);
+        const dim3 grid(static_cast<unsigned>(B) * chunks), block(kWaves * 64);
+        const size_t lds = sizeof(float) * kWaves * slab_floats(L * P);
+        auto a = [&](auto kern) {
+            hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const float *>(value), shapes, lstart,
+                               static_cast<const float *>(loc), static_cast<const float *>(attn),
+                               static_cast<const float *>(grad_out), static_cast<float *>(grad_value),
+                               static_cast<float *>(grad_loc), static_cast<float *>(grad_attn),
+                               B, S, M, L, P, npairs, iters);
+        };
+        if (L == 4 && P == 4) a(msda_bwd_d32<4, 4>); else a(msda_bwd_d32<0, 0>);
+    } else if (dtype == 0) {
+        hipLaunchKernelGGL(msda_bwd_generic<float>, dim3(grid_for(n, 256)), dim3(256), 0, st,
+                           static_cast<const float *>(value), shapes, lstart, static_cast<const float *>(loc),
+                           static_cast<const float *>(attn), static_cast<const float *>(grad_out),
+                           static_cast<float *>(grad_value), static_cast<float *>(grad_loc),
+                           static_cast<float *>(grad_attn), S, M, D, L, Lq, P, n);
+    } else {
+        hipLaunchKernelGGL(msda_bwd_generic<double>, dim3(grid_for(n, 256)), dim3(256), 0, st,
+                           static_cast<const double *>(value), shapes, lstart, static_cast<const double *>(loc),
+                           static_cast<const double *>(attn), static_cast<const double *>(grad_out),
+                           static_cast<double *>(grad_value), static_cast<double *>(grad_loc),
+                           static_cast<double *>(grad_attn), S, M, D, L, Lq, P, n);
+    }
+    return hipGetLastError();
+}
+
+hipError_t msda_indices_launch(int dtype, const int64_t *shapes, const void *loc, int32_t *idx,
+                               int B, int M, int L, int Lq, int P, hipStream_t st)
+{
+    const int64_t n = static_cast<int64_t>(B) * Lq * M * L * P;
+    if (n == 0) return hipSuccess;
+    if (dtype == 0)
+        hipLaunchKernelGGL(msda_indices_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, st, shapes,
+                           static_cast<const float *>(loc), idx, L, P, n);
+    else
+        hipLaunchKernelGGL(msda_indices_kernel<double>, dim3(grid_for(n, 256)), dim3(256), 0, st, shapes,
+                           static_cast<const double *>(loc), idx, L, P, n);
+    return hipGetLastError();
+}
+
+}  // namespace mdetr

@@ -1,0 +1,108 @@
+"""``MSDeformAttn`` -- mirror of lib/models/monodetr/ops/modules/ms_deform_attn.py:69-162.
+
+Same constructor, parameter names (``sampling_offsets``, ``attention_weights``, ``value_proj``,
+``output_proj``), ``_reset_parameters`` initialisation (:106-120), forward signature (:122) and
+numerics; the sampling + aggregation itself is the gfx950 operator behind
+``MSDeformAttnFunction``.  ``MSDeformAttn_cross`` (:164-256, unused by the model) and
+``MultiheadAttention`` (:259-379, imported by depthaware_transformer.py:11 but never
+instantiated) are exported for import compatibility.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..functions import MSDeformAttnFunction
+
+
+def _is_power_of_2(n):
+    if not isinstance(n, int) or n < 0:
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return n != 0 and (n & (n - 1)) == 0
+
+
+def _star_offsets(n_heads, n_levels, n_points):
+    """Bias initialisation of ``sampling_offsets``: one direction per head on the unit square's
+    boundary (max-norm 1), scaled by the point index 1..P (reference :108-114)."""
+    theta = torch.arange(n_heads, dtype=torch.float32) * (2.0 * math.pi / n_heads)
+    d = torch.stack([theta.cos(), theta.sin()], -1)
+    d = d / d.abs().max(-1, keepdim=True)[0]
+    scale = torch.arange(1, n_points + 1, dtype=torch.float32).view(1, 1, n_points, 1)
+    return (d.view(n_heads, 1, 1, 2) * scale).expand(n_heads, n_levels, n_points, 2).reshape(-1)
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4, conditional=False):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("MSDeformAttn: head dimension %d is not a power of 2; the gfx950 fast path "
+                          "needs 32 channels per head, other sizes take the generic kernel." % (d_model // n_heads))
+        self.im2col_step = 64
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        self.conditional = conditional
+        d_value = d_model // 2 if conditional else d_model
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_value, d_value)
+        self.output_proj = nn.Linear(d_value, d_value)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        with torch.no_grad():
+            self.sampling_offsets.weight.zero_()
+            self.sampling_offsets.bias = nn.Parameter(_star_offsets(self.n_heads, self.n_levels, self.n_points))
+            self.attention_weights.weight.zero_()
+            self.attention_weights.bias.zero_()
+            nn.init.xavier_uniform_(self.value_proj.weight)
+            self.value_proj.bias.zero_()
+            nn.init.xavier_uniform_(self.output_proj.weight)
+            self.output_proj.bias.zero_()
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
+                input_level_start_index, input_padding_mask=None):
+        """query [N,Lq,C]; reference_points [N,Lq,L,2] or [N,Lq,L,6] (cx,cy,l,r,t,b);
+        input_flatten [N,S,C]; input_spatial_shapes [L,2] (H,W) int64; input_level_start_index [L];
+        input_padding_mask [N,S] bool (True = padding).  Returns [N,Lq,C]."""
+        N, Lq, _ = query.shape
+        S = input_flatten.shape[1]
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == S
+
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], 0.0)
+        value = value.view(N, S, M, -1)
+
+        offsets = self.sampling_offsets(query).view(N, Lq, M, L, P, 2)
+        weights = F.softmax(self.attention_weights(query).view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+
+        ref = reference_points[:, :, None, :, None, :]
+        if reference_points.shape[-1] == 2:
+            wh = input_spatial_shapes.flip(-1)                                  # (W_l, H_l), :150
+            locations = ref + offsets / wh[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 6:
+            extent = ref[..., 2::2] + ref[..., 3::2]                            # (l+r, t+b), :153-155
+            locations = ref[..., :2] + offsets / P * extent * 0.5
+        else:
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
+                reference_points.shape[-1]))
+
+        out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
+                                         locations, weights, self.im2col_step)
+        return self.output_proj(out)
+
+
+class MSDeformAttn_cross(MSDeformAttn):
+    """Half-width-value variant the reference defines at :164-256 and never instantiates."""
+
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__(d_model, n_levels, n_heads, n_points, conditional=True)
+
+
+# The reference vendors a copy of torch's MultiheadAttention (:259-379) that the model imports but
+# never constructs; the stock module has the same parameters.
+MultiheadAttention = nn.MultiheadAttention

@@ -1,0 +1,115 @@
+"""Drop-in for the reference's extension module ``MultiScaleDeformableAttention``.
+
+The reference builds a pybind11/ATen module with two functions
+(lib/models/monodetr/ops/src/vision.cpp:13-16, ops/src/ms_deform_attn.h:20-60):
+
+    ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
+    ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step)
+
+Same names, argument meaning, return shapes and error behaviour here, implemented by the gfx950
+kernels behind the C ABI (include/monodetr_amd.h).  ``monodetr_amd.install()`` registers this
+module as ``sys.modules['MultiScaleDeformableAttention']`` so ``import MultiScaleDeformableAttention
+as MSDA`` (ops/functions/ms_deform_attn_func.py:18) resolves to it unchanged.
+"""
+import torch
+
+from . import _capi
+
+_NAMES5 = ("value", "spatial_shapes", "level_start_index", "sampling_loc", "attn_weight")
+
+
+def _check_inputs(tensors, names):
+    # ms_deform_attn.h:26-38: CUDA tensors dispatch, anything else is an error
+    if not tensors[0].is_cuda:
+        raise RuntimeError("Not implemented on the CPU")
+    for t, n in zip(tensors, names):                      # ms_deform_attn_cuda.cu:28-38, :93-105
+        if not t.is_contiguous():
+            raise RuntimeError("%s tensor has to be contiguous" % n)
+        if not t.is_cuda:
+            raise RuntimeError("%s must be a CUDA tensor" % n)
+        if t.device != tensors[0].device:
+            raise RuntimeError("%s is on %s but value is on %s" % (n, t.device, tensors[0].device))
+
+
+def _dims(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5:
+        raise RuntimeError("expected value[B,S,M,D], sampling_loc[B,Lq,M,L,P,2], attn_weight[B,Lq,M,L,P]")
+    B, S, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    Lq, P = sampling_loc.shape[1], sampling_loc.shape[4]
+    if tuple(sampling_loc.shape) != (B, Lq, M, L, P, 2) or tuple(attn_weight.shape) != (B, Lq, M, L, P):
+        raise RuntimeError("sampling_loc / attn_weight shapes do not match value / spatial_shapes")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes and level_start_index must be int64 (ms_deform_attn_cuda.cu:67-68)")
+    if tuple(spatial_shapes.shape) != (L, 2) or tuple(level_start_index.shape) != (L,):
+        raise RuntimeError("spatial_shapes must be [L,2] and level_start_index [L]")
+    if sampling_loc.dtype != value.dtype or attn_weight.dtype != value.dtype:
+        raise RuntimeError("value, sampling_loc and attn_weight must share one dtype")
+    step = min(B, int(im2col_step))                       # ms_deform_attn_cuda.cu:50-52
+    if B > 0 and (step <= 0 or B % step != 0):
+        raise RuntimeError("batch(%d) must divide im2col_step(%d)" % (B, step))
+    return B, S, M, D, L, Lq, P
+
+
+def _aligned(t):
+    # the C ABI wants 16-byte aligned bases; contiguous views at odd storage offsets are copied
+    return t if t.data_ptr() % 16 == 0 else t.clone(memory_format=torch.contiguous_format)
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    """-> Tensor [B, Lq, M*D]  (ms_deform_attn_cuda.cu:20-80)."""
+    args = (value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    _check_inputs(args, _NAMES5)
+    B, S, M, D, L, Lq, P = _dims(*args, im2col_step)
+    code = _capi.dtype_code(value)
+    value, sampling_loc, attn_weight = _aligned(value), _aligned(sampling_loc), _aligned(attn_weight)
+    out = torch.empty((B, Lq, M * D), dtype=value.dtype, device=value.device)
+    dev = value.device.index
+    rc = _capi.lib().mdetr_msda_forward(
+        code, value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+        sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(),
+        B, S, M, D, L, Lq, P, dev, _stream(value.device))
+    _capi.check(rc, "mdetr_msda_forward")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight]  (ms_deform_attn_cuda.cu:83-153)."""
+    args = (value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    _check_inputs(args + (grad_output,), _NAMES5 + ("grad_output",))
+    B, S, M, D, L, Lq, P = _dims(*args, im2col_step)
+    if grad_output.dtype != value.dtype or grad_output.numel() != B * Lq * M * D:
+        raise RuntimeError("grad_output must be [B,Lq,M*D] of value's dtype")
+    code = _capi.dtype_code(value)
+    value, sampling_loc, attn_weight, grad_output = (_aligned(t) for t in (value, sampling_loc, attn_weight, grad_output))
+    grad_value = torch.empty_like(value)                  # zero-filled by the C ABI on the stream
+    grad_loc = torch.empty_like(sampling_loc)
+    grad_attn = torch.empty_like(attn_weight)
+    dev = value.device.index
+    rc = _capi.lib().mdetr_msda_backward(
+        code, value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+        sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+        grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
+        B, S, M, D, L, Lq, P, dev, _stream(value.device))
+    _capi.check(rc, "mdetr_msda_backward")
+    return [grad_value, grad_loc, grad_attn]
+
+
+def ms_deform_attn_indices(spatial_shapes, sampling_loc):
+    """int32 [B,Lq,M,L,P,4] = (in_window, h_low, w_low, corner_mask): the gather indices the kernels
+    use, exposed for bit-exact index parity tests (not part of the reference module)."""
+    if not sampling_loc.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")
+    if not sampling_loc.is_contiguous() or not spatial_shapes.is_contiguous():
+        raise RuntimeError("sampling_loc tensor has to be contiguous")
+    B, Lq, M, L, P, _ = sampling_loc.shape
+    idx = torch.empty((B, Lq, M, L, P, 4), dtype=torch.int32, device=sampling_loc.device)
+    rc = _capi.lib().mdetr_msda_indices(
+        _capi.dtype_code(sampling_loc), spatial_shapes.data_ptr(), _aligned(sampling_loc).data_ptr(),
+        idx.data_ptr(), B, M, L, Lq, P, sampling_loc.device.index, _stream(sampling_loc.device))
+    _capi.check(rc, "mdetr_msda_indices")
+    return idx
