@@ -25,7 +25,7 @@ SIGNATURES = {
     "mdetr_last_error": (ctypes.c_char_p, []),
     "mdetr_msda_variant": (_c_int, [_c_int] * 5),
     "mdetr_msda_forward": (_c_int, [_c_int] + [_c_vp] * 6 + [_c_int] * 7 + [_c_int, _c_vp]),
-    "mdetr_msda_backward": (_c_int, [_c_int] + [_c_vp] * 10 + [_c_int] * 7 + [_c_int, _c_vp]),
+    "mdetr_msda_backward": (_c_int, [_c_int] + [_c_vp] * 9 + [_c_int] * 7 + [_c_int, _c_vp]),
     "mdetr_msda_indices": (_c_int, [_c_int] + [_c_vp] * 3 + [_c_int] * 5 + [_c_int, _c_vp]),
 }
 

@@ -28,6 +28,7 @@
 // reference's 0.5 is a double literal (.cuh:285-286), so no FMA there -- see pix_coord().
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "msda.h"
 
@@ -73,6 +74,12 @@ __device__ __forceinline__ Foot<T> footprint(T h_im, T w_im, int H, int W)
     f.ok3 = f.inwin && hh_ && wl;
     f.ok4 = f.inwin && hh_ && wh_;
     return f;
+}
+
+// component-wise select (a whole-float4 ?: is lowered through scratch memory by hipcc)
+__device__ __forceinline__ float4 keep4(bool ok, const float4 &v)
+{
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -133,6 +140,19 @@ __device__ __forceinline__ LevelGeom level_geom(const int64_t *__restrict__ shap
     return g;
 }
 
+// acc += bilinear(v1..v4) * attn for one sample, 4 channels per lane (.cuh:80-82, :290)
+__device__ __forceinline__ void accumulate(float4 &acc, const Foot<float> &f, float a,
+                                           float4 v1, float4 v2, float4 v3, float4 v4)
+{
+    v1 = keep4(f.ok1, v1); v2 = keep4(f.ok2, v2); v3 = keep4(f.ok3, v3); v4 = keep4(f.ok4, v4);
+    const float w1 = f.hh * f.hw, w2 = f.hh * f.lw, w3 = f.lh * f.hw, w4 = f.lh * f.lw;
+    const float wa = f.inwin ? a : 0.f;
+    acc.x += (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) * wa;
+    acc.y += (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) * wa;
+    acc.z += (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) * wa;
+    acc.w += (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w) * wa;
+}
+
 // ------------------------------------------------------------------------------------------------
 // fast path, forward
 // ------------------------------------------------------------------------------------------------
@@ -168,30 +188,48 @@ void msda_fwd_d32(const float *__restrict__ value, const int64_t *__restrict__ s
             const float *my_loc = s_loc + j * (2 * LP + kPad);
             const float *my_att = s_att + j * (LP + kPad);
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (TP != 0) {
+                // compile-time P: issue all 4*P corner gathers of a level before consuming any
 #pragma unroll
-            for (int l = 0; l < L; ++l) {
-                const LevelGeom g = level_geom(shapes, lstart, l);
-                const float *vl = vb + static_cast<int64_t>(g.start) * row;
+                for (int l = 0; l < L; ++l) {
+                    const LevelGeom g = level_geom(shapes, lstart, l);
+                    const float *vl = vb + static_cast<int64_t>(g.start) * row;
+                    Foot<float> f[TP];
+                    float a[TP];
+                    float4 v[TP][4];
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const int s = l * P + p;
-                    const float2 xy = *reinterpret_cast<const float2 *>(my_loc + 2 * s);
-                    const float a = my_att[s];
-                    const Foot<float> f = footprint(pix_coord(xy.y, g.H), pix_coord(xy.x, g.W), g.H, g.W);
-                    const int y0 = clampi(f.h_low, 0, g.H - 1), y1 = clampi(f.h_low + 1, 0, g.H - 1);
-                    const int x0 = clampi(f.w_low, 0, g.W - 1), x1 = clampi(f.w_low + 1, 0, g.W - 1);
-                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                    float4 v1 = *reinterpret_cast<const float4 *>(vl + (y0 * g.W + x0) * row);
-                    float4 v2 = *reinterpret_cast<const float4 *>(vl + (y0 * g.W + x1) * row);
-                    float4 v3 = *reinterpret_cast<const float4 *>(vl + (y1 * g.W + x0) * row);
-                    float4 v4 = *reinterpret_cast<const float4 *>(vl + (y1 * g.W + x1) * row);
-                    v1 = f.ok1 ? v1 : z; v2 = f.ok2 ? v2 : z; v3 = f.ok3 ? v3 : z; v4 = f.ok4 ? v4 : z;
-                    const float w1 = f.hh * f.hw, w2 = f.hh * f.lw, w3 = f.lh * f.hw, w4 = f.lh * f.lw;   // .cuh:80
-                    const float wa = f.inwin ? a : 0.f;
-                    acc.x += (w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x) * wa;                       // .cuh:82,290
-                    acc.y += (w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y) * wa;
-                    acc.z += (w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z) * wa;
-                    acc.w += (w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w) * wa;
+                    for (int p = 0; p < TP; ++p) {
+                        const int s = l * TP + p;
+                        const float2 xy = *reinterpret_cast<const float2 *>(my_loc + 2 * s);
+                        a[p] = my_att[s];
+                        f[p] = footprint(pix_coord(xy.y, g.H), pix_coord(xy.x, g.W), g.H, g.W);
+                        const int y0 = clampi(f[p].h_low, 0, g.H - 1), y1 = clampi(f[p].h_low + 1, 0, g.H - 1);
+                        const int x0 = clampi(f[p].w_low, 0, g.W - 1), x1 = clampi(f[p].w_low + 1, 0, g.W - 1);
+                        v[p][0] = *reinterpret_cast<const float4 *>(vl + (y0 * g.W + x0) * row);
+                        v[p][1] = *reinterpret_cast<const float4 *>(vl + (y0 * g.W + x1) * row);
+                        v[p][2] = *reinterpret_cast<const float4 *>(vl + (y1 * g.W + x0) * row);
+                        v[p][3] = *reinterpret_cast<const float4 *>(vl + (y1 * g.W + x1) * row);
+                    }
+#pragma unroll
+                    for (int p = 0; p < TP; ++p) accumulate(acc, f[p], a[p], v[p][0], v[p][1], v[p][2], v[p][3]);
+                }
+            } else {
+                for (int l = 0; l < L; ++l) {
+                    const LevelGeom g = level_geom(shapes, lstart, l);
+                    const float *vl = vb + static_cast<int64_t>(g.start) * row;
+                    for (int p = 0; p < P; ++p) {
+                        const int s = l * P + p;
+                        const float2 xy = *reinterpret_cast<const float2 *>(my_loc + 2 * s);
+                        const float a = my_att[s];
+                        const Foot<float> f = footprint(pix_coord(xy.y, g.H), pix_coord(xy.x, g.W), g.H, g.W);
+                        const int y0 = clampi(f.h_low, 0, g.H - 1), y1 = clampi(f.h_low + 1, 0, g.H - 1);
+                        const int x0 = clampi(f.w_low, 0, g.W - 1), x1 = clampi(f.w_low + 1, 0, g.W - 1);
+                        const float4 v1 = *reinterpret_cast<const float4 *>(vl + (y0 * g.W + x0) * row);
+                        const float4 v2 = *reinterpret_cast<const float4 *>(vl + (y0 * g.W + x1) * row);
+                        const float4 v3 = *reinterpret_cast<const float4 *>(vl + (y1 * g.W + x0) * row);
+                        const float4 v4 = *reinterpret_cast<const float4 *>(vl + (y1 * g.W + x1) * row);
+                        accumulate(acc, f, a, v1, v2, v3, v4);
+                    }
                 }
             }
             *reinterpret_cast<float4 *>(out + (g0 + j) * 32 + k * 4) = acc;
@@ -210,7 +248,90 @@ __device__ __forceinline__ void atomic_add4(float *p, float s, const float4 &t)
     unsafeAtomicAdd(p + 3, s * t.w);
 }
 
+// Scatter phase of the backward pass with 32 lanes x 1 channel per pair (2 pairs per wave-round):
+// each atomic instruction covers two complete 128-B rows of grad_value.  Reads only the slab
+// (loc / attn) and grad_out -- no value loads, so no vmcnt wait sits between the atomics.
 template <int TL, int TP>
+__device__ __forceinline__ void scatter_rows32(const int64_t *__restrict__ shapes, const int64_t *__restrict__ lstart,
+                                               const float *__restrict__ grad_out, float *__restrict__ grad_value,
+                                               const float *s_loc, const float *s_att, int64_t g0, int p0, int nv,
+                                               int64_t img, int M, int L, int P, int lane)
+{
+    const int LP = L * P, row = M * 32;
+    const int c = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < kPairsPerWave / 2; ++r) {
+        const int jj = 2 * r + half;
+        if (jj < nv) {
+            const int m = (p0 + jj) % M;
+            const float go = grad_out[(g0 + jj) * 32 + c];
+            float *gvb = grad_value + img + m * 32 + c;
+            const float *my_loc = s_loc + jj * (2 * LP + kPad);
+            const float *my_att = s_att + jj * (LP + kPad);
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const LevelGeom g = level_geom(shapes, lstart, l);
+                float *gvl = gvb + static_cast<int64_t>(g.start) * row;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const int s = l * P + p;
+                    const float2 xy = *reinterpret_cast<const float2 *>(my_loc + 2 * s);
+                    const float tgv = go * my_att[s];
+                    const Foot<float> f = footprint(pix_coord(xy.y, g.H), pix_coord(xy.x, g.W), g.H, g.W);
+                    const int o = (f.h_low * g.W + f.w_low) * row;
+                    if (f.ok1) unsafeAtomicAdd(gvl + o, f.hh * f.hw * tgv);
+                    if (f.ok2) unsafeAtomicAdd(gvl + o + row, f.hh * f.lw * tgv);
+                    if (f.ok3) unsafeAtomicAdd(gvl + o + g.W * row, f.lh * f.hw * tgv);
+                    if (f.ok4) unsafeAtomicAdd(gvl + o + g.W * row + row, f.lh * f.lw * tgv);
+                }
+            }
+        }
+    }
+}
+
+// One sample of the backward pass for the 4 channels of this lane: fp32 atomics into grad_value
+// (.cuh:113-152), then d/d(attn), d/d(loc) reduced over the pair's 8 lanes and parked in the slab.
+template <bool ATOMICS>
+__device__ __forceinline__ void scatter_sample(const Foot<float> &f, float a, const float4 &go,
+                                               float4 v1, float4 v2, float4 v3, float4 v4,
+                                               float *gvl, const int (&o)[4], const LevelGeom &g,
+                                               float *my_loc, float *my_att, int s, int k)
+{
+    v1 = keep4(f.ok1, v1); v2 = keep4(f.ok2, v2); v3 = keep4(f.ok3, v3); v4 = keep4(f.ok4, v4);
+    const float w1 = f.hh * f.hw, w2 = f.hh * f.lw, w3 = f.lh * f.hw, w4 = f.lh * f.lw;
+    const float4 tgv = make_float4(go.x * a, go.y * a, go.z * a, go.w * a);      // .cuh:113
+    if constexpr (ATOMICS) {
+        if (f.ok1) atomic_add4(gvl + o[0], w1, tgv);                            // .cuh:125
+        if (f.ok2) atomic_add4(gvl + o[1], w2, tgv);                            // .cuh:134
+        if (f.ok3) atomic_add4(gvl + o[2], w3, tgv);                            // .cuh:143
+        if (f.ok4) atomic_add4(gvl + o[3], w4, tgv);                            // .cuh:152
+    }
+    float pa = 0.f, pw = 0.f, ph = 0.f;
+#define MDETR_CH(c)                                                                              \
+    {                                                                                            \
+        const float gh = -f.hw * v1.c - f.lw * v2.c + f.hw * v3.c + f.lw * v4.c; /* .cuh:123-151 */ \
+        const float gw = -f.hh * v1.c + f.hh * v2.c - f.lh * v3.c + f.lh * v4.c;                 \
+        const float val = w1 * v1.c + w2 * v2.c + w3 * v3.c + w4 * v4.c;                         \
+        pa += go.c * val;                                                                        \
+        pw += gw * tgv.c;                                                                        \
+        ph += gh * tgv.c;                                                                        \
+    }
+    MDETR_CH(x) MDETR_CH(y) MDETR_CH(z) MDETR_CH(w)
+#undef MDETR_CH
+    pa = sum8(pa);
+    pw = sum8(pw) * static_cast<float>(g.W);                                    // .cuh:157
+    ph = sum8(ph) * static_cast<float>(g.H);                                    // .cuh:158
+    if (k == 0) {                     // slot s has been read by all 8 lanes (in-order LDS)
+        *reinterpret_cast<float2 *>(my_loc + 2 * s) = f.inwin ? make_float2(pw, ph) : make_float2(0.f, 0.f);
+        my_att[s] = f.inwin ? pa : 0.f;
+    }
+}
+
+// VAR 0: single phase (gathers, float4-lane atomics and reductions interleaved per sample)
+// VAR 1: per round, a scatter phase with full-row atomics (scatter_rows32) followed by the
+//        gather/reduce phase -- the vmcnt drain the compiler puts between atomics and the next
+//        use of a loaded value then happens once per round instead of once per sample.
+template <int TL, int TP, int VAR>
 __global__ __launch_bounds__(kWaves * 64)
 void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ shapes,
                   const int64_t *__restrict__ lstart, const float *__restrict__ loc,
@@ -237,58 +358,62 @@ void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ s
         wave_lds_fence();
         stage_pairs<TL * TP>(loc, attn, s_loc, s_att, g0, nv, LP, lane);
         wave_lds_fence();
+        if constexpr (VAR == 1)
+            scatter_rows32<TL, TP>(shapes, lstart, grad_out, grad_value, s_loc, s_att, g0, p0, nv, img, M, L, P, lane);
         if (j < nv) {
             const int m = (p0 + j) % M;
             const int64_t voff = img + m * 32 + k * 4;
             float *my_loc = s_loc + j * (2 * LP + kPad);
             float *my_att = s_att + j * (LP + kPad);
             const float4 go = *reinterpret_cast<const float4 *>(grad_out + (g0 + j) * 32 + k * 4);
+            if constexpr (TP != 0) {
 #pragma unroll
-            for (int l = 0; l < L; ++l) {
-                const LevelGeom g = level_geom(shapes, lstart, l);
-                const int64_t loff = voff + static_cast<int64_t>(g.start) * row;
-                const float *vl = value + loff;
-                float *gvl = grad_value + loff;
+                for (int l = 0; l < L; ++l) {
+                    const LevelGeom g = level_geom(shapes, lstart, l);
+                    const int64_t loff = voff + static_cast<int64_t>(g.start) * row;
+                    const float *vl = value + loff;
+                    float *gvl = grad_value + loff;
+                    Foot<float> f[TP];
+                    float a[TP];
+                    int o[TP][4];
+                    float4 v[TP][4];
 #pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const int s = l * P + p;
-                    const float2 xy = *reinterpret_cast<const float2 *>(my_loc + 2 * s);
-                    const float a = my_att[s];
-                    const Foot<float> f = footprint(pix_coord(xy.y, g.H), pix_coord(xy.x, g.W), g.H, g.W);
-                    const int y0 = clampi(f.h_low, 0, g.H - 1), y1 = clampi(f.h_low + 1, 0, g.H - 1);
-                    const int x0 = clampi(f.w_low, 0, g.W - 1), x1 = clampi(f.w_low + 1, 0, g.W - 1);
-                    const int o1 = (y0 * g.W + x0) * row, o2 = (y0 * g.W + x1) * row;
-                    const int o3 = (y1 * g.W + x0) * row, o4 = (y1 * g.W + x1) * row;
-                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                    float4 v1 = *reinterpret_cast<const float4 *>(vl + o1);
-                    float4 v2 = *reinterpret_cast<const float4 *>(vl + o2);
-                    float4 v3 = *reinterpret_cast<const float4 *>(vl + o3);
-                    float4 v4 = *reinterpret_cast<const float4 *>(vl + o4);
-                    v1 = f.ok1 ? v1 : z; v2 = f.ok2 ? v2 : z; v3 = f.ok3 ? v3 : z; v4 = f.ok4 ? v4 : z;
-                    const float w1 = f.hh * f.hw, w2 = f.hh * f.lw, w3 = f.lh * f.hw, w4 = f.lh * f.lw;
-                    const float4 tgv = make_float4(go.x * a, go.y * a, go.z * a, go.w * a);      // .cuh:113
-                    if (f.ok1) atomic_add4(gvl + o1, w1, tgv);                                  // .cuh:125
-                    if (f.ok2) atomic_add4(gvl + o2, w2, tgv);                                  // .cuh:134
-                    if (f.ok3) atomic_add4(gvl + o3, w3, tgv);                                  // .cuh:143
-                    if (f.ok4) atomic_add4(gvl + o4, w4, tgv);                                  // .cuh:152
-                    float pa = 0.f, pw = 0.f, ph = 0.f;
-#define MDETR_CH(c)                                                                              \
-                    {                                                                            \
-                        const float gh = -f.hw * v1.c - f.lw * v2.c + f.hw * v3.c + f.lw * v4.c; /* .cuh:123-151 */ \
-                        const float gw = -f.hh * v1.c + f.hh * v2.c - f.lh * v3.c + f.lh * v4.c; \
-                        const float val = w1 * v1.c + w2 * v2.c + w3 * v3.c + w4 * v4.c;         \
-                        pa += go.c * val;                                                        \
-                        pw += gw * tgv.c;                                                        \
-                        ph += gh * tgv.c;                                                        \
+                    for (int p = 0; p < TP; ++p) {     // all 4*P gathers of the level in flight together
+                        const int s = l * TP + p;
+                        const float2 xy = *reinterpret_cast<const float2 *>(my_loc + 2 * s);
+                        a[p] = my_att[s];
+                        f[p] = footprint(pix_coord(xy.y, g.H), pix_coord(xy.x, g.W), g.H, g.W);
+                        const int y0 = clampi(f[p].h_low, 0, g.H - 1), y1 = clampi(f[p].h_low + 1, 0, g.H - 1);
+                        const int x0 = clampi(f[p].w_low, 0, g.W - 1), x1 = clampi(f[p].w_low + 1, 0, g.W - 1);
+                        o[p][0] = (y0 * g.W + x0) * row; o[p][1] = (y0 * g.W + x1) * row;
+                        o[p][2] = (y1 * g.W + x0) * row; o[p][3] = (y1 * g.W + x1) * row;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) v[p][c] = *reinterpret_cast<const float4 *>(vl + o[p][c]);
                     }
-                    MDETR_CH(x) MDETR_CH(y) MDETR_CH(z) MDETR_CH(w)
-#undef MDETR_CH
-                    pa = sum8(pa);
-                    pw = sum8(pw) * static_cast<float>(g.W);                                    // .cuh:157
-                    ph = sum8(ph) * static_cast<float>(g.H);                                    // .cuh:158
-                    if (k == 0) {                     // slot s has been read by all 8 lanes (in-order LDS)
-                        *reinterpret_cast<float2 *>(my_loc + 2 * s) = f.inwin ? make_float2(pw, ph) : make_float2(0.f, 0.f);
-                        my_att[s] = f.inwin ? pa : 0.f;
+#pragma unroll
+                    for (int p = 0; p < TP; ++p)
+                        scatter_sample<VAR == 0>(f[p], a[p], go, v[p][0], v[p][1], v[p][2], v[p][3], gvl, o[p], g,
+                                       my_loc, my_att, l * TP + p, k);
+                }
+            } else {
+                for (int l = 0; l < L; ++l) {
+                    const LevelGeom g = level_geom(shapes, lstart, l);
+                    const int64_t loff = voff + static_cast<int64_t>(g.start) * row;
+                    const float *vl = value + loff;
+                    float *gvl = grad_value + loff;
+                    for (int p = 0; p < P; ++p) {
+                        const int s = l * P + p;
+                        const float2 xy = *reinterpret_cast<const float2 *>(my_loc + 2 * s);
+                        const float a = my_att[s];
+                        const Foot<float> f = footprint(pix_coord(xy.y, g.H), pix_coord(xy.x, g.W), g.H, g.W);
+                        const int y0 = clampi(f.h_low, 0, g.H - 1), y1 = clampi(f.h_low + 1, 0, g.H - 1);
+                        const int x0 = clampi(f.w_low, 0, g.W - 1), x1 = clampi(f.w_low + 1, 0, g.W - 1);
+                        const int o[4] = {(y0 * g.W + x0) * row, (y0 * g.W + x1) * row, (y1 * g.W + x0) * row, (y1 * g.W + x1) * row};
+                        const float4 v1 = *reinterpret_cast<const float4 *>(vl + o[0]);
+                        const float4 v2 = *reinterpret_cast<const float4 *>(vl + o[1]);
+                        const float4 v3 = *reinterpret_cast<const float4 *>(vl + o[2]);
+                        const float4 v4 = *reinterpret_cast<const float4 *>(vl + o[3]);
+                        scatter_sample<VAR == 0>(f, a, go, v1, v2, v3, v4, gvl, o, g, my_loc, my_att, s, k);
                     }
                 }
             }
@@ -490,7 +615,9 @@ hipError_t msda_backward_launch(int dtype, const void *value, const int64_t *sha
                                static_cast<float *>(grad_loc), static_cast<float *>(grad_attn),
                                B, S, M, L, P, npairs, iters);
         };
-        if (L == 4 && P == 4) a(msda_bwd_d32<4, 4>); else a(msda_bwd_d32<0, 0>);
+        static const int var = [] { const char *e = getenv("MDETR_MSDA_BWD_VARIANT"); return e ? atoi(e) : 1; }();
+        if (L == 4 && P == 4) { if (var == 0) a(msda_bwd_d32<4, 4, 0>); else a(msda_bwd_d32<4, 4, 1>); }
+        else a(msda_bwd_d32<0, 0, 1>);
     } else if (dtype == 0) {
         hipLaunchKernelGGL(msda_bwd_generic<float>, dim3(grid_for(n, 256)), dim3(256), 0, st,
                            static_cast<const float *>(value), shapes, lstart, static_cast<const float *>(loc),

@@ -59,7 +59,7 @@ def test_argument_validation_without_gpu(built_lib):
     assert lib.mdetr_msda_forward(0, None, None, None, None, None, None, 0, 4, 1, 1, 1, 1, 1, 0, None) == 0
     assert lib.mdetr_msda_forward(0, None, None, None, None, None, None, 2, 4, 1, 1, 1, 0, 1, 0, None) == 0
     with pytest.raises(RuntimeError, match="code -1"):
-        _capi.check(lib.mdetr_msda_backward(0, *([None] * 10), 1, 1, 0, 1, 1, 1, 1, 0, None), "bwd")
+        _capi.check(lib.mdetr_msda_backward(0, *([None] * 9), 1, 1, 0, 1, 1, 1, 1, 0, None), "bwd")
 
 
 def test_extension_module_rejects_cpu_tensors_like_the_reference():

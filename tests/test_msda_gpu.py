@@ -145,7 +145,7 @@ def test_full_size_properties_highres(ext):
     """Size-independent properties at BASELINE configs[4] (512x1760, S=18704, Lq=1100), no oracle:
     linearity in value, partition of unity (constant value field + weights summing to 1 -> constant
     output for in-range samples), determinism of the forward, and <grad_out, J v> = <J^T grad_out, v>."""
-    p = make_problem(8, 8, 32, 1100, KITTI_HI, 4, torch.float32, seed=7, lo=0.05, hi=0.95)
+    p = make_problem(8, 8, 32, 1100, KITTI_HI, 4, torch.float32, seed=7, lo=0.07, hi=0.93)   # 0.5/8 < loc < 1 - 0.5/8
     d = dev(p)
     out = run_fwd(ext, d)
     assert torch.equal(out, run_fwd(ext, d))
@@ -216,7 +216,7 @@ def test_autograd_function_fast_path_vs_fp64(ext):
     p = dev(make_problem(2, 8, 32, 80, KITTI, 4, torch.float32, seed=9))
     grads = {}
     for dt in (torch.float32, torch.float64):
-        v, l, a = (p[k].to(dt).requires_grad_(True) for k in ("value", "loc", "attn"))
+        v, l, a = (p[k].to(dt).detach().clone().requires_grad_(True) for k in ("value", "loc", "attn"))
         out = MSDeformAttnFunction.apply(v, p["shapes"], p["level_start"], l, a, 64)
         assert out.shape == (2, 80, 256)
         out.backward(p["grad_out"].to(dt))
