@@ -1,0 +1,37 @@
+"""monodetr_amd -- MI355X-native implementation of MonoDETR's training hot path.
+
+    monodetr_amd.monodetr          mirror of the reference's ``lib/models/monodetr`` package
+    monodetr_amd.msda_ext          mirror of its native extension ``MultiScaleDeformableAttention``
+    monodetr_amd.utils / .losses   the pieces of ``utils`` / ``lib.losses`` the model path imports
+    monodetr_amd.csrc              HIP kernels + C ABI (libmonodetr_amd.so, include/monodetr_amd.h)
+
+``install()`` registers these under the reference's module names so its unchanged
+``tools/train_val.py`` / ``lib/helpers`` import them.
+"""
+import importlib
+import sys
+
+__all__ = ["install", "build_monodetr"]
+
+
+def build_monodetr(cfg):
+    from .monodetr import build_monodetr as _b
+    return _b(cfg)
+
+
+def install(force=False):
+    """Alias this package's modules under the names the reference code imports:
+    ``MultiScaleDeformableAttention`` (ops/functions/ms_deform_attn_func.py:18),
+    ``lib.models.monodetr`` (lib/helpers/model_helper.py:1), ``lib.losses.focal_loss``,
+    ``utils.misc`` / ``utils.box_ops``.  Existing entries are kept unless force=True."""
+    aliases = {
+        "MultiScaleDeformableAttention": ".msda_ext",
+        "lib.models.monodetr": ".monodetr",
+        "lib.losses.focal_loss": ".losses.focal_loss",
+        "utils.misc": ".utils.misc",
+        "utils.box_ops": ".utils.box_ops",
+    }
+    for name, target in aliases.items():
+        if force or name not in sys.modules:
+            sys.modules[name] = importlib.import_module(target, __name__)
+    return sorted(aliases)

@@ -1,0 +1,192 @@
+"""ResNet backbone with frozen BatchNorm -- mirror of lib/models/monodetr/backbone.py
+(``FrozenBatchNorm2d`` :27-64, ``BackboneBase`` :67-90, ``Backbone`` :93-106, ``Joiner`` :109-126,
+``build_backbone`` :129-135).
+
+The reference takes the network from torchvision (``torchvision.models.resnet50`` wrapped in
+``IntermediateLayerGetter``, backbone.py:17-19,82,100-102), which is not a dependency here.  The
+bottleneck ResNet (v1.5: stride on the 3x3 conv) is defined below with the same module names, so
+``backbone.0.body.*`` state_dict keys of published checkpoints load unchanged.
+ImageNet weights are not downloaded at construction (reference :102; there is no network): pass
+``cfg['backbone_weights']`` (a state_dict path) or load a full checkpoint afterwards.
+
+MI355X notes: every BatchNorm is frozen, i.e. an affine map per channel.  ``forward`` folds it into
+the preceding convolution (conv(x, W*s) + t  ==  conv(x, W)*s + t), which removes one full
+read+write pass over every activation of the backbone; gradients still reach W through W*s.
+"""
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..utils.misc import NestedTensor
+from .position_encoding import build_position_encoding
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """BatchNorm2d with fixed statistics and affine parameters (all buffers), eps inside the rsqrt."""
+
+    def __init__(self, n, eps=1e-5):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+        self.eps = eps
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys,
+                              unexpected_keys, error_msgs):
+        state_dict.pop(prefix + 'num_batches_tracked', None)       # reference :44-52
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys,
+                                      unexpected_keys, error_msgs)
+
+    def affine(self):
+        """(scale, shift) with y = x * scale + shift."""
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        return scale, self.bias - self.running_mean * scale
+
+    def forward(self, x):
+        scale, shift = self.affine()
+        return x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+
+
+def conv_bn(x, conv, bn, relu):
+    """conv -> frozen BN (-> ReLU), with the BN folded into the convolution's weight and bias."""
+    if isinstance(bn, FrozenBatchNorm2d) and conv.bias is None:
+        scale, shift = bn.affine()
+        w = conv.weight * scale.to(conv.weight.dtype).view(-1, 1, 1, 1)
+        x = F.conv2d(x, w, shift.to(conv.weight.dtype), conv.stride, conv.padding, conv.dilation, conv.groups)
+    else:
+        x = bn(conv(x))
+    return F.relu(x, inplace=True) if relu else x
+
+
+class Bottleneck(nn.Module):
+    """1x1 reduce -> 3x3 (carries the stride) -> 1x1 expand (x4), residual add, ReLU."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1, norm_layer=FrozenBatchNorm2d):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, dilation, dilation, bias=False)
+        self.bn2 = norm_layer(planes)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
+        self.bn3 = norm_layer(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        skip = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], False)
+        y = conv_bn(x, self.conv1, self.bn1, True)
+        y = conv_bn(y, self.conv2, self.bn2, True)
+        y = conv_bn(y, self.conv3, self.bn3, False)
+        return F.relu(y + skip, inplace=True)
+
+
+class ResNetBody(nn.Module):
+    """Stem + layer1..4 of a bottleneck ResNet; returns the requested stages as an ordered dict
+    {out_name: tensor} (what IntermediateLayerGetter does for the reference, backbone.py:82)."""
+    BLOCKS = {'resnet50': (3, 4, 6, 3), 'resnet101': (3, 4, 23, 3), 'resnet152': (3, 8, 36, 3)}
+
+    def __init__(self, name, return_layers: Dict[str, str], dilation=False, norm_layer=FrozenBatchNorm2d):
+        super().__init__()
+        if name not in self.BLOCKS:
+            raise ValueError("backbone %r: number of channels are hard coded for bottleneck ResNets "
+                             "(reference backbone.py:103)" % name)
+        self.return_layers = dict(return_layers)
+        self.inplanes, self.dilation = 64, 1
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = norm_layer(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        n = self.BLOCKS[name]
+        self.layer1 = self._stage(64, n[0], 1, False, norm_layer)
+        self.layer2 = self._stage(128, n[1], 2, False, norm_layer)
+        self.layer3 = self._stage(256, n[2], 2, False, norm_layer)
+        self.layer4 = self._stage(512, n[3], 2, dilation, norm_layer)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+    def _stage(self, planes, blocks, stride, dilate, norm_layer):
+        prev_dilation = self.dilation
+        if dilate:
+            self.dilation *= stride
+            stride = 1
+        down = None
+        if stride != 1 or self.inplanes != planes * 4:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride, bias=False), norm_layer(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, down, prev_dilation, norm_layer)]
+        self.inplanes = planes * 4
+        layers += [Bottleneck(self.inplanes, planes, dilation=self.dilation, norm_layer=norm_layer) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = self.maxpool(conv_bn(x, self.conv1, self.bn1, True))
+        out = {}
+        for name in ('layer1', 'layer2', 'layer3', 'layer4'):
+            x = getattr(self, name)(x)
+            if name in self.return_layers:
+                out[self.return_layers[name]] = x
+        return out
+
+
+class BackboneBase(nn.Module):
+    def __init__(self, body: nn.Module, train_backbone: bool, return_interm_layers: bool):
+        super().__init__()
+        for name, p in body.named_parameters():             # stem + layer1 always frozen (:71-73)
+            if not train_backbone or not any(s in name for s in ('layer2', 'layer3', 'layer4')):
+                p.requires_grad_(False)
+        if return_interm_layers:
+            self.strides, self.num_channels = [8, 16, 32], [512, 1024, 2048]
+        else:
+            self.strides, self.num_channels = [32], [2048]
+        self.body = body
+
+    def forward(self, images):
+        out = {}
+        for name, x in self.body(images).items():
+            mask = torch.zeros((x.shape[0], x.shape[2], x.shape[3]), dtype=torch.bool, device=x.device)   # :88
+            out[name] = NestedTensor(x, mask)
+        return out
+
+
+class Backbone(BackboneBase):
+    """ResNet backbone with frozen BatchNorm."""
+
+    def __init__(self, name: str, train_backbone: bool, return_interm_layers: bool, dilation: bool, weights=None):
+        layers = {"layer2": "0", "layer3": "1", "layer4": "2"} if return_interm_layers else {"layer4": "0"}
+        body = ResNetBody(name, layers, dilation)
+        if weights is not None:
+            sd = torch.load(weights, map_location="cpu") if isinstance(weights, str) else weights
+            missing, unexpected = body.load_state_dict({k: v for k, v in sd.items() if not k.startswith("fc.")}, strict=False)
+            if missing:
+                raise RuntimeError("backbone weights are missing keys: %s" % missing[:5])
+        super().__init__(body, train_backbone, return_interm_layers)
+        if dilation:
+            self.strides[-1] = self.strides[-1] // 2
+
+
+class Joiner(nn.Sequential):
+    """(backbone, position_embedding) -> (list of NestedTensor features, list of position encodings)."""
+
+    def __init__(self, backbone, position_embedding):
+        super().__init__(backbone, position_embedding)
+        self.strides = backbone.strides
+        self.num_channels = backbone.num_channels
+
+    def forward(self, images):
+        feats = self[0](images)
+        out: List[NestedTensor] = [feats[k] for k in sorted(feats)]
+        pos = [self[1](x).to(x.tensors.dtype) for x in out]
+        return out, pos
+
+
+def build_backbone(cfg):
+    position_embedding = build_position_encoding(cfg)
+    return_interm_layers = cfg['masks'] or cfg['num_feature_levels'] > 1
+    backbone = Backbone(cfg['backbone'], cfg['train_backbone'], return_interm_layers, cfg['dilation'],
+                        weights=cfg.get('backbone_weights'))
+    return Joiner(backbone, position_embedding)

@@ -1,0 +1,361 @@
+"""Depth-aware transformer -- mirror of lib/models/monodetr/depthaware_transformer.py
+(``DepthAwareTransformer`` :68-312, ``VisualEncoderLayer`` :315-354, ``VisualEncoder`` :357-384,
+``DepthAwareDecoderLayer`` :387-515, ``DepthAwareDecoder`` :518-626, ``build_depthaware_transformer``
+:644-660).  Same class names, constructor arguments, parameter names and forward signatures.
+
+What is different underneath (MI355X-first, numerics unchanged):
+  * deformable attention is the gfx950 operator (ops/), dense attention the fused core (attention.py);
+  * activations stay batch-first [B, L, C]; the group fold of the decoder self-attention
+    (reference :480-503: split the 11 query groups and concatenate them along the batch) becomes a
+    free view [B, G*n, C] -> [B*G, n, C]; the hard-coded 50 (:481-482) is n = queries // groups;
+  * level shapes travel as Python ints next to the int64 device tensor, so building reference
+    points does not iterate a CUDA tensor (one device sync per element in the reference, :366);
+    constant per-resolution tensors are cached;
+  * padding masks known to be all-False by construction (utils.misc.no_padding) skip the
+    masked_fill / valid-ratio / key-padding work;
+  * ``sa_v_proj`` is kept as a parameter (checkpoints) but its GEMM, whose result the reference
+    discards (:471 vs :477), is not executed.
+The two-stage / DAB / DINO branches (all off in configs/monodetr.yaml:50-54) are not built.
+"""
+import copy
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import constant_, normal_, xavier_uniform_
+
+from ..utils.misc import inverse_sigmoid, no_padding
+from .attention import MultiheadAttention as FusedMultiheadAttention
+from .ops.modules import MSDeformAttn, MSDeformAttn_cross, MultiheadAttention  # noqa: F401  (reference :11)
+
+
+class MLP(nn.Module):
+    """Linear -> ReLU -> ... -> Linear."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x):
+        for layer in self.layers[:-1]:
+            x = F.relu(layer(x))
+        return self.layers[-1](x)
+
+
+def _get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+def _get_activation_fn(activation):
+    try:
+        return {"relu": F.relu, "gelu": F.gelu, "glu": F.glu}[activation]
+    except KeyError:
+        raise RuntimeError(f"activation should be relu/gelu, not {activation}.")
+
+
+def _shape_list(spatial_shapes):
+    """[(H, W), ...] as Python ints (one host copy if a device tensor is given)."""
+    if torch.is_tensor(spatial_shapes):
+        return [tuple(int(v) for v in hw) for hw in spatial_shapes.tolist()]
+    return [tuple(int(v) for v in hw) for hw in spatial_shapes]
+
+
+class VisualEncoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _get_activation_fn(activation)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    @staticmethod
+    def with_pos_embed(tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def forward_ffn(self, src):
+        ff = self.linear2(self.dropout2(self.activation(self.linear1(src))))
+        return self.norm2(src + self.dropout3(ff))
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+        attn = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
+                              level_start_index, padding_mask)
+        return self.forward_ffn(self.norm1(src + self.dropout1(attn)))
+
+
+class VisualEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+        self._ref_cache = {}
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        """Pixel centres of every level, normalised to [0,1] and rescaled by the valid ratios:
+        [B, S, L, 2] (reference :364-376)."""
+        per_level = []
+        for lvl, (H, W) in enumerate(_shape_list(spatial_shapes)):
+            ys = torch.linspace(0.5, H - 0.5, H, dtype=torch.float32, device=device)
+            xs = torch.linspace(0.5, W - 0.5, W, dtype=torch.float32, device=device)
+            gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+            gy = gy.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * H)
+            gx = gx.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * W)
+            per_level.append(torch.stack((gx, gy), -1))
+        return torch.cat(per_level, 1)[:, :, None] * valid_ratios[:, None]
+
+    def _unpadded_reference_points(self, shapes, B, L, device):
+        key = (tuple(shapes), L, str(device))
+        ref = self._ref_cache.get(key)
+        if ref is None:
+            ones = torch.ones((1, L, 2), dtype=torch.float32, device=device)
+            ref = self._ref_cache[key] = self.get_reference_points(shapes, ones, device)
+        return ref.expand(B, -1, -1, -1)
+
+    def forward(self, src, spatial_shapes, level_start_index, valid_ratios, pos=None, padding_mask=None,
+                ref_token_index=None, ref_token_coord=None, shape_list=None):
+        shapes = shape_list if shape_list is not None else _shape_list(spatial_shapes)
+        if valid_ratios is None:      # no padding anywhere: ratios are identically 1
+            reference_points = self._unpadded_reference_points(shapes, src.shape[0], len(shapes), src.device)
+        else:
+            reference_points = self.get_reference_points(shapes, valid_ratios, src.device)
+        out = src
+        for layer in self.layers:
+            out = layer(out, pos, reference_points, spatial_shapes, level_start_index, padding_mask)
+        return out
+
+
+class DepthAwareDecoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8,
+                 n_points=4, group_num=1):
+        super().__init__()
+        # visual cross attention (deformable)
+        self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        # depth cross attention (dense)
+        self.cross_attn_depth = FusedMultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout_depth = nn.Dropout(dropout)
+        self.norm_depth = nn.LayerNorm(d_model)
+        # inter-query self attention (dense, per query group while training)
+        self.self_attn = FusedMultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        # ffn
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _get_activation_fn(activation)
+        self.dropout3 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.group_num = group_num
+        # content / position projections feeding the self attention
+        self.sa_qcontent_proj = nn.Linear(d_model, d_model)
+        self.sa_qpos_proj = nn.Linear(d_model, d_model)
+        self.sa_kcontent_proj = nn.Linear(d_model, d_model)
+        self.sa_kpos_proj = nn.Linear(d_model, d_model)
+        self.sa_v_proj = nn.Linear(d_model, d_model)      # never contributes (reference :471 vs :477)
+        self.nhead = n_heads
+
+    @staticmethod
+    def with_pos_embed(tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def forward_ffn(self, tgt):
+        ff = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        return self.norm3(tgt + self.dropout4(ff))
+
+    def _self_attention_inputs(self, x):
+        """q = (Wqc + Wqp) x + b, k = (Wkc + Wkp) x + b : the four projections of the reference
+        (:467-474) act on the same input, so they are summed in weight space -- 2 GEMMs, not 4."""
+        wq = self.sa_qcontent_proj.weight + self.sa_qpos_proj.weight
+        bq = self.sa_qcontent_proj.bias + self.sa_qpos_proj.bias
+        wk = self.sa_kcontent_proj.weight + self.sa_kpos_proj.weight
+        bk = self.sa_kcontent_proj.bias + self.sa_kpos_proj.bias
+        q, k = F.linear(x, torch.cat((wq, wk), 0), torch.cat((bq, bk), 0)).split(x.shape[-1], -1)
+        return q, k
+
+    def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
+                src_padding_mask, depth_pos_embed, mask_depth, bs, query_sine_embed=None, is_first=None,
+                depth_pos_embed_ip=None, pos_embeds=None, self_attn_mask=None, query_pos_un=None):
+        """tgt, query_pos [B, Nq, C]; depth_pos_embed [HW/256, B, C] (sequence-first, as the reference
+        passes it); mask_depth [B, HW/256] or None."""
+        B, Nq, C = tgt.shape
+        depth_tokens = depth_pos_embed.transpose(0, 1)
+        # depth cross attention
+        d = self.cross_attn_depth.forward_batch_first(tgt, depth_tokens, depth_tokens, mask_depth)
+        tgt = self.norm_depth(tgt + self.dropout_depth(d))
+        # self attention: keys/queries from content+position, values = tgt itself
+        q, k = self._self_attention_inputs(self.with_pos_embed(tgt, query_pos))
+        v = tgt
+        if self.training and self.group_num > 1:
+            if Nq % self.group_num != 0:
+                raise ValueError("training expects num_queries * group_num queries, got %d for %d groups" % (Nq, self.group_num))
+            n = Nq // self.group_num
+            q, k, v = (t.reshape(B * self.group_num, n, C) for t in (q, k, v))
+        s = self.self_attn.forward_batch_first(q, k, v).reshape(B, Nq, C)
+        tgt = self.norm2(tgt + self.dropout2(s))
+        # deformable cross attention into the visual memory
+        c = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
+                            level_start_index, src_padding_mask)
+        tgt = self.norm1(tgt + self.dropout1(c))
+        return self.forward_ffn(tgt)
+
+
+class DepthAwareDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, return_intermediate=False, d_model=None, use_dab=False,
+                 two_stage_dino=False):
+        super().__init__()
+        if use_dab or two_stage_dino:
+            raise NotImplementedError("use_dab / two_stage_dino are off in configs/monodetr.yaml and not built")
+        self.layers = _get_clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.return_intermediate = return_intermediate
+        # set by MonoDETR for iterative box refinement (reference monodetr.py:129-131)
+        self.bbox_embed = None
+        self.dim_embed = None
+        self.class_embed = None
+        self.use_dab = use_dab
+        self.two_stgae_dino = two_stage_dino
+        # present in every published checkpoint, unused on the default path (reference :541-542)
+        self.query_scale = MLP(d_model, d_model, d_model, 2)
+        self.ref_point_head = MLP(d_model, d_model, 2, 2)
+
+    def forward(self, tgt, reference_points, src, src_spatial_shapes, src_level_start_index, src_valid_ratios,
+                query_pos=None, src_padding_mask=None, depth_pos_embed=None, mask_depth=None, bs=None,
+                depth_pos_embed_ip=None, pos_embeds=None, attn_mask=None):
+        output = tgt
+        bs = src.shape[0]
+        L = src_spatial_shapes.shape[0]
+        hs, refs, dims = [], [], []
+        reference_dims = None
+        for lid, layer in enumerate(self.layers):
+            nd = reference_points.shape[-1]
+            assert nd in (2, 6)
+            if src_valid_ratios is None:
+                ref_in = reference_points[:, :, None].expand(-1, -1, L, -1)
+            else:
+                ref_in = reference_points[:, :, None] * src_valid_ratios.repeat(1, 1, nd // 2)[:, None]
+            output = layer(output, query_pos, ref_in, src, src_spatial_shapes, src_level_start_index,
+                           src_padding_mask, depth_pos_embed, mask_depth, bs, query_sine_embed=None,
+                           is_first=(lid == 0), depth_pos_embed_ip=depth_pos_embed_ip, pos_embeds=pos_embeds,
+                           self_attn_mask=attn_mask, query_pos_un=None)
+            if self.bbox_embed is not None:             # iterative refinement (:602-613)
+                delta = self.bbox_embed[lid](output)
+                if nd == 6:
+                    new_ref = (delta + inverse_sigmoid(reference_points)).sigmoid()
+                else:
+                    new_ref = torch.cat((delta[..., :2] + inverse_sigmoid(reference_points), delta[..., 2:]), -1).sigmoid()
+                reference_points = new_ref.detach()
+            if self.dim_embed is not None:
+                reference_dims = self.dim_embed[lid](output)
+            if self.return_intermediate:
+                hs.append(output)
+                refs.append(reference_points)
+                dims.append(reference_dims)
+        if self.return_intermediate:
+            return torch.stack(hs), torch.stack(refs), torch.stack(dims)
+        return output, reference_points
+
+
+class DepthAwareTransformer(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=1024,
+                 dropout=0.1, activation="relu", return_intermediate_dec=False, num_feature_levels=4,
+                 dec_n_points=4, enc_n_points=4, two_stage=False, two_stage_num_proposals=50, group_num=11,
+                 use_dab=False, two_stage_dino=False):
+        super().__init__()
+        if two_stage or use_dab or two_stage_dino:
+            raise NotImplementedError("two_stage / use_dab / two_stage_dino are off in configs/monodetr.yaml and not built")
+        self.d_model, self.nhead = d_model, nhead
+        self.two_stage, self.two_stage_num_proposals = two_stage, two_stage_num_proposals
+        self.use_dab, self.two_stage_dino, self.group_num = use_dab, two_stage_dino, group_num
+
+        self.encoder = VisualEncoder(
+            VisualEncoderLayer(d_model, dim_feedforward, dropout, activation, num_feature_levels, nhead, enc_n_points),
+            num_encoder_layers)
+        self.decoder = DepthAwareDecoder(
+            DepthAwareDecoderLayer(d_model, dim_feedforward, dropout, activation, num_feature_levels, nhead,
+                                   dec_n_points, group_num=group_num),
+            num_decoder_layers, return_intermediate_dec, d_model, use_dab=use_dab, two_stage_dino=two_stage_dino)
+        self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        self.reference_points = nn.Linear(d_model, 2)
+        self._shape_cache = {}
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        xavier_uniform_(self.reference_points.weight.data, gain=1.0)
+        constant_(self.reference_points.bias.data, 0.)
+        normal_(self.level_embed)
+
+    def get_valid_ratio(self, mask):
+        """Fraction of each image that is not padding, (w, h) per image."""
+        _, H, W = mask.shape
+        vh = torch.sum(~mask[:, :, 0], 1).float() / H
+        vw = torch.sum(~mask[:, 0, :], 1).float() / W
+        return torch.stack([vw, vh], -1)
+
+    def _level_tensors(self, shapes, device):
+        key = (tuple(shapes), str(device))
+        hit = self._shape_cache.get(key)
+        if hit is None:
+            ss = torch.as_tensor(shapes, dtype=torch.long, device=device)
+            hit = self._shape_cache[key] = (ss, torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1])))
+        return hit
+
+    def forward(self, srcs, masks, pos_embeds, query_embed=None, depth_pos_embed=None, depth_pos_embed_ip=None,
+                attn_mask=None):
+        assert query_embed is not None
+        unpadded = all(no_padding(m) for m in masks)
+        shapes = [tuple(s.shape[-2:]) for s in srcs]
+        B, C = srcs[0].shape[:2]
+        # flatten every level to [B, HW, C] and concatenate along the token axis
+        src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1)
+                             for l, p in enumerate(pos_embeds)], 1)
+        spatial_shapes, level_start_index = self._level_tensors(shapes, src_flatten.device)
+        if unpadded:
+            mask_flatten = valid_ratios = mask_depth = None
+        else:
+            mask_flatten = torch.cat([m.flatten(1) for m in masks], 1)
+            valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+            mask_depth = masks[1].flatten(1)
+
+        memory = self.encoder(src_flatten, spatial_shapes, level_start_index, valid_ratios, lvl_pos, mask_flatten,
+                              shape_list=shapes)
+
+        # queries: first half of the embedding is the positional part, second half the content
+        query_pos, tgt = torch.split(query_embed, C, dim=1)
+        reference_points = self.reference_points(query_pos).sigmoid().unsqueeze(0).expand(B, -1, -1)
+        query_pos = query_pos.unsqueeze(0).expand(B, -1, -1)
+        tgt = tgt.unsqueeze(0).expand(B, -1, -1)
+        init_reference_out = reference_points
+
+        depth_tokens = depth_pos_embed.flatten(2).permute(2, 0, 1)
+        depth_tokens_ip = depth_pos_embed_ip.flatten(2).permute(2, 0, 1)
+        hs, inter_references, inter_references_dim = self.decoder(
+            tgt, reference_points, memory, spatial_shapes, level_start_index, valid_ratios, query_pos,
+            mask_flatten, depth_tokens, mask_depth, bs=B, depth_pos_embed_ip=depth_tokens_ip,
+            pos_embeds=pos_embeds, attn_mask=attn_mask)
+        return hs, init_reference_out, inter_references, inter_references_dim, None, None
+
+
+def build_depthaware_transformer(cfg):
+    return DepthAwareTransformer(
+        d_model=cfg['hidden_dim'], dropout=cfg['dropout'], activation="relu", nhead=cfg['nheads'],
+        dim_feedforward=cfg['dim_feedforward'], num_encoder_layers=cfg['enc_layers'],
+        num_decoder_layers=cfg['dec_layers'], return_intermediate_dec=cfg['return_intermediate_dec'],
+        num_feature_levels=cfg['num_feature_levels'], dec_n_points=cfg['dec_n_points'],
+        enc_n_points=cfg['enc_n_points'], two_stage=cfg['two_stage'], two_stage_num_proposals=cfg['num_queries'],
+        use_dab=cfg['use_dab'], two_stage_dino=cfg['two_stage_dino'])
