@@ -67,7 +67,9 @@ class HungarianMatcher(nn.Module):
         sizes = [len(v["boxes"]) for v in targets]
         tgt_ids = torch.cat([v["labels"] for v in targets]).long()
         tgt_boxes = torch.cat([v["boxes_3d"] for v in targets])
-        C = self.cost_matrix(logits.flatten(0, 2).float(), boxes.flatten(0, 2).float(), tgt_ids, tgt_boxes.float())
+        if logits.dtype in (torch.float16, torch.bfloat16):     # autocast heads: score in fp32
+            logits, boxes = logits.float(), boxes.float()
+        C = self.cost_matrix(logits.flatten(0, 2), boxes.flatten(0, 2), tgt_ids, tgt_boxes.to(boxes.dtype))
         C = C.view(Ly, B, Q, -1).cpu().numpy()                                    # the one D2H copy
         return [[(torch.from_numpy(i), torch.from_numpy(j)) for i, j in self.assign(C[l], sizes, group_num)]
                 for l in range(Ly)]

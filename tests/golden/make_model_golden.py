@@ -155,11 +155,36 @@ def main():
                  "backbone.0.body.layer4.2.conv3.weight", "class_embed.2.bias"):
         g = dict(model.named_parameters())[name].grad
         rec["grad/" + name] = g.numpy()
+    # float64 pass: structural parity without fp32 noise.  Every parameter's gradient is recorded
+    # through two scalars (its norm and its projection on a name-seeded random direction).
+    from model_init import grad_fingerprint
+    model.double(); model.zero_grad(set_to_none=True)
+    out = model(images.double(), calibs.double(), targets64(targets), img_sizes)
+    losses = criterion(out, targets64(targets))
+    total = sum(losses[k] * criterion.weight_dict[k] for k in losses if k in criterion.weight_dict)
+    total.backward()
+    rec["f64/total_loss"] = np.asarray(float(total.detach()))
+    for k in ("pred_logits", "pred_boxes", "pred_depth", "pred_3d_dim", "pred_angle"):
+        rec["f64/" + k] = out[k].detach().numpy()
+    for k, v in losses.items():
+        rec["f64/loss/" + k] = np.asarray(float(v))
+    with torch.no_grad():
+        layers = [{k: v for k, v in out.items() if k != "aux_outputs"}] + list(out["aux_outputs"])
+        for li, layer in enumerate(layers):
+            for b, (i, j) in enumerate(criterion.matcher(layer, targets64(targets), group_num=11)):
+                rec[f"f64/match{li}/{b}/src"], rec[f"f64/match{li}/{b}/tgt"] = i.numpy(), j.numpy()
+    fp = grad_fingerprint(model)
+    rec["f64/grad_names"] = np.array(sorted(fp))
+    rec["f64/grad_fp"] = np.array([fp[k] for k in sorted(fp)])
     np.savez_compressed(os.path.join(HERE, "model_kitti_b2.npz"), **rec)
     with open(os.path.join(HERE, "model_state_dict_keys.txt"), "w") as f:
         for k in sorted(keys):
             f.write("%s %s\n" % (k, "x".join(map(str, keys[k]))))
-    print("saved", len(rec), "arrays;", len(keys), "state_dict entries")
+    print("saved", len(rec), "arrays;", len(keys), "state_dict entries; f64 total", float(total))
+
+
+def targets64(targets):
+    return [{k: (v.double() if v.is_floating_point() else v) for k, v in t.items()} for t in targets]
 
 
 if __name__ == "__main__":

@@ -104,3 +104,17 @@ def disable_dropout_(model):
         if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float):
             m.dropout = 0.0
     return model
+
+
+def grad_fingerprint(model):
+    """{param name: (||grad||, <grad, r_name>)} with r_name a name-seeded Gaussian direction: two
+    scalars that pin every parameter's gradient."""
+    fp = {}
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = torch.Generator().manual_seed(_seed("dir:" + name))
+        r = torch.randn(p.shape, generator=g, dtype=torch.float64)
+        gr = p.grad.detach().double().cpu()
+        fp[name] = (float(gr.norm()), float((gr * r).sum()))
+    return fp

@@ -119,10 +119,26 @@ def test_one_training_iteration_gradients_match_reference(built, golden):
     model.zero_grad(set_to_none=True)
     images, calibs, img_sizes, targets = synthetic_batch(2, 384, 1280, seed=7)
     out = model(images, calibs, targets, img_sizes)
-    losses = criterion(out, targets)
+    # losses on the REFERENCE's assignment (near-ties in the matching may legitimately resolve differently)
+    layers = [{k: v for k, v in out.items() if k != "aux_outputs"}] + list(out["aux_outputs"])
+    num_boxes = float(sum(len(t["labels"]) for t in targets) * 11)
+    losses = {}
+    for li, layer in enumerate(layers):
+        tag = "match" if li == 0 else "match_aux%d" % (li - 1)
+        ref_idx = [(golden[f"train/{tag}/{b}/src"], golden[f"train/{tag}/{b}/tgt"]) for b in range(2)]
+        for name in criterion.losses:
+            if li > 0 and name == "depth_map":
+                continue
+            kw = {"log": False} if (li > 0 and name == "labels") else {}
+            ld = criterion.get_loss(name, layer, targets, ref_idx, num_boxes, **kw)
+            losses.update(ld if li == 0 else {"%s_%d" % (k, li - 1): v for k, v in ld.items()})
     total = sum(losses[k] * criterion.weight_dict[k] for k in losses if k in criterion.weight_dict)
     assert torch.isfinite(total)
-    assert abs(float(total) - float(golden["train/total_loss"])) < 1e-3 * abs(float(golden["train/total_loss"]))
+    assert abs(float(total) - float(golden["train/total_loss"])) < 1e-4 * abs(float(golden["train/total_loss"]))
+    # and the criterion's own forward (own matching) gives the same total up to tie noise
+    own = criterion(out, targets)
+    own_total = sum(own[k] * criterion.weight_dict[k] for k in own if k in criterion.weight_dict)
+    assert abs(float(own_total) - float(total)) < 2e-2 * abs(float(total))
     total.backward()
     params = dict(model.named_parameters())
     for k, ref in golden.items():
@@ -130,10 +146,53 @@ def test_one_training_iteration_gradients_match_reference(built, golden):
             continue
         g = params[k[5:]].grad
         assert g is not None, k
-        scale = max(1e-6, ref.abs().max().item())
-        assert (g - ref).abs().max().item() < 2e-3 * scale, (k, (g - ref).abs().max().item(), scale)
+        # fp32 run vs fp32 reference run: rounding noise only (the float64 test below pins structure);
+        # gradients through d/d(sampling location) amplify it most
+        rel = ((g - ref).norm() / ref.norm()).item()
+        assert rel < 1e-2, (k, rel)
     # parameters that never receive a gradient on the default path
     unused = sorted(n for n, p in params.items() if p.requires_grad and p.grad is None)
     assert all(n.startswith("label_enc") or ".sa_v_proj." in n or "decoder.query_scale" in n or "decoder.ref_point_head" in n
                for n in unused), unused
     assert any(".sa_v_proj." in n for n in unused)
+
+
+def test_float64_structural_parity_all_gradients(oracle, golden):
+    """In float64 the mirror and the reference agree to ~1e-10 on outputs, every loss, the matching
+    and the gradient of EVERY parameter (fingerprints: norm + projection on a random direction).
+    This separates structural equality from fp32 rounding noise."""
+    from monodetr_amd.monodetr import build_monodetr
+    from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func as F_
+    from model_init import grad_fingerprint
+    saved = F_.MSDA
+    F_.MSDA = oracle.OracleMSDA
+    try:
+        torch.manual_seed(0)
+        model, criterion = build_monodetr(load_cfg())
+        disable_dropout_(name_seeded_init_(model)).double().train()
+        criterion.train()
+        images, calibs, img_sizes, targets = synthetic_batch(2, 384, 1280, seed=7)
+        t64 = [{k: (v.double() if v.is_floating_point() else v) for k, v in t.items()} for t in targets]
+        out = model(images.double(), calibs.double(), t64, img_sizes)
+        for k in ("pred_logits", "pred_boxes", "pred_depth", "pred_3d_dim", "pred_angle"):
+            assert (out[k] - golden["f64/" + k]).abs().max() < 1e-9 * max(1.0, golden["f64/" + k].abs().max().item()), k
+        layers = [{k: v for k, v in out.items() if k != "aux_outputs"}] + list(out["aux_outputs"])
+        for li, idx in enumerate(criterion.matcher.match_layers(layers, t64, group_num=11)):
+            for b, (i, j) in enumerate(idx):
+                assert torch.equal(i, golden[f"f64/match{li}/{b}/src"]) and torch.equal(j, golden[f"f64/match{li}/{b}/tgt"])
+        losses = criterion(out, t64)
+        for k, v in losses.items():
+            ref = float(golden["f64/loss/" + k])
+            assert abs(float(v) - ref) < 1e-9 * max(1.0, abs(ref)), (k, float(v), ref)
+        total = sum(losses[k] * criterion.weight_dict[k] for k in losses if k in criterion.weight_dict)
+        assert abs(float(total) - float(golden["f64/total_loss"])) < 1e-9 * float(golden["f64/total_loss"])
+        total.backward()
+        fp = grad_fingerprint(model)
+        names = [str(n) for n in golden["f64/grad_names"].tolist()] if hasattr(golden["f64/grad_names"], "tolist") else list(golden["f64/grad_names"])
+        ref_fp = golden["f64/grad_fp"]
+        assert sorted(fp) == sorted(names)
+        for n, (norm, proj) in zip(names, ref_fp.tolist()):
+            assert abs(fp[n][0] - norm) < 1e-7 * norm + 1e-10, (n, fp[n][0], norm)     # +atol: some grads are analytically 0 (key bias)
+            assert abs(fp[n][1] - proj) < 1e-7 * norm + 1e-10, (n, fp[n][1], proj)
+    finally:
+        F_.MSDA = saved
