@@ -98,6 +98,20 @@ int mdetr_msda_indices(int dtype, const int64_t *spatial_shapes, const void *loc
  */
 int mdetr_msda_variant(int dtype, int M, int D, int L, int P);
 
+/*
+ * Optional per-launch kernel timing with HIP events recorded on the launch stream (bench.py's
+ * `roofline` block).  When enabled, every fast-path/generic MSDA kernel launch (the kernel only,
+ * not the zero-fill memsets of the backward) is bracketed by an event pair.
+ *   mdetr_profile_enable(1|0)      start / stop recording (clears previous records when enabling)
+ *   mdetr_profile_read(...)        synchronises the recorded events and aggregates them by
+ *                                  (kind, Lq): kind 0 = msda forward, 1 = msda backward.
+ *                                  Fills up to `cap` rows of {kind, Lq, launches, total_ms} (as
+ *                                  doubles, 4 per row) and returns the number of rows, or < 0.
+ * Recording costs two hipEventRecord calls per launch; it is off by default.
+ */
+int mdetr_profile_enable(int on);
+int mdetr_profile_read(double *rows, int cap);
+
 #ifdef __cplusplus
 }
 #endif

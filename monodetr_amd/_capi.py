@@ -27,6 +27,8 @@ SIGNATURES = {
     "mdetr_msda_forward": (_c_int, [_c_int] + [_c_vp] * 6 + [_c_int] * 7 + [_c_int, _c_vp]),
     "mdetr_msda_backward": (_c_int, [_c_int] + [_c_vp] * 9 + [_c_int] * 7 + [_c_int, _c_vp]),
     "mdetr_msda_indices": (_c_int, [_c_int] + [_c_vp] * 3 + [_c_int] * 5 + [_c_int, _c_vp]),
+    "mdetr_profile_enable": (_c_int, [_c_int]),
+    "mdetr_profile_read": (_c_int, [_c_vp, _c_int]),
 }
 
 _lib = None
@@ -68,3 +70,17 @@ def dtype_code(t):
         return MDETR_F64
     # same wording as AT_DISPATCH_FLOATING_TYPES (ms_deform_attn_cuda.cu:64,134)
     raise RuntimeError('"ms_deform_attn" not implemented for \'%s\'' % str(t.dtype).replace("torch.", ""))
+
+
+def profile_enable(on):
+    check(lib().mdetr_profile_enable(1 if on else 0), "mdetr_profile_enable")
+
+
+def profile_read(cap=64):
+    """[(kind, Lq, launches, total_ms)] of the kernel launches recorded since profile_enable(True);
+    kind 0 = msda forward, 1 = msda backward."""
+    buf = (ctypes.c_double * (4 * cap))()
+    n = lib().mdetr_profile_read(ctypes.cast(buf, ctypes.c_void_p), cap)
+    if n < 0:
+        check(n, "mdetr_profile_read")
+    return [(int(buf[4 * i]), int(buf[4 * i + 1]), int(buf[4 * i + 2]), float(buf[4 * i + 3])) for i in range(n)]

@@ -4,6 +4,12 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "../../include/monodetr_amd.h"
 #include "msda.h"
 
@@ -48,7 +54,73 @@ int check_common(const char *who, int dtype, int B, int S, int M, int D, int L, 
 
 }  // namespace
 
+// ---- optional kernel timing ------------------------------------------------------------------
+namespace mdetr {
+namespace {
+struct Rec { int kind, Lq; hipEvent_t a, b; };
+std::atomic<int> g_prof_on{0};
+std::mutex g_prof_mu;
+std::vector<Rec> g_recs;
+thread_local Rec *t_open = nullptr;
+thread_local Rec t_cur;
+}  // namespace
+
+void profile_begin(int kind, int Lq, hipStream_t st)
+{
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    t_cur = Rec{kind, Lq, nullptr, nullptr};
+    if (hipEventCreate(&t_cur.a) != hipSuccess || hipEventCreate(&t_cur.b) != hipSuccess) return;
+    (void)hipEventRecord(t_cur.a, st);
+    t_open = &t_cur;
+}
+
+void profile_end(hipStream_t st)
+{
+    if (!t_open) return;
+    (void)hipEventRecord(t_cur.b, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_recs.push_back(t_cur);
+    t_open = nullptr;
+}
+}  // namespace mdetr
+
 extern "C" {
+
+int mdetr_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(mdetr::g_prof_mu);
+    if (on) {
+        for (auto &r : mdetr::g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        mdetr::g_recs.clear();
+    }
+    mdetr::g_prof_on.store(on ? 1 : 0);
+    return MDETR_OK;
+}
+
+int mdetr_profile_read(double *rows, int cap)
+{
+    if (!rows || cap < 0) return fail(MDETR_E_ARG, "mdetr_profile_read: bad arguments");
+    std::lock_guard<std::mutex> lk(mdetr::g_prof_mu);
+    std::map<std::pair<int, int>, std::pair<double, double>> agg;     // (kind, Lq) -> (launches, ms)
+    for (auto &r : mdetr::g_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess)
+            return fail(MDETR_E_HIP, "mdetr_profile_read: event query failed");
+        auto &e = agg[{r.kind, r.Lq}];
+        e.first += 1.0;
+        e.second += ms;
+    }
+    int n = 0;
+    for (auto &kv : agg) {
+        if (n >= cap) break;
+        rows[4 * n + 0] = kv.first.first;
+        rows[4 * n + 1] = kv.first.second;
+        rows[4 * n + 2] = kv.second.first;
+        rows[4 * n + 3] = kv.second.second;
+        ++n;
+    }
+    return n;
+}
 
 int mdetr_abi_version(void) { return MDETR_ABI_VERSION; }
 

@@ -20,4 +20,8 @@ hipError_t msda_backward_launch(int dtype, const void *value, const int64_t *sha
 hipError_t msda_indices_launch(int dtype, const int64_t *shapes, const void *loc, int32_t *idx,
                                int B, int M, int L, int Lq, int P, hipStream_t st);
 
+// event-pair profiling of kernel launches (capi.hip owns the storage)
+void profile_begin(int kind, int Lq, hipStream_t st);
+void profile_end(hipStream_t st);
+
 }  // namespace mdetr

@@ -564,6 +564,7 @@ hipError_t msda_forward_launch(int dtype, const void *value, const int64_t *shap
 {
     const int64_t n = static_cast<int64_t>(B) * Lq * M * D;
     if (n == 0) return hipSuccess;
+    struct Scope { hipStream_t s; Scope(int Lq_, hipStream_t s_) : s(s_) { profile_begin(0, Lq_, s_); } ~Scope() { profile_end(s); } } scope(Lq, st);
     if (msda_fast_path(dtype, D, L, P)) {
         const int npairs = Lq * M, iters = rounds_per_block(B, npairs);
         const int chunks = (npairs + 32 * iters - 1) / (32 * iters);
@@ -603,6 +604,7 @@ hipError_t msda_backward_launch(int dtype, const void *value, const int64_t *sha
         if ((err = hipMemsetAsync(grad_loc, 0, ns * 2 * e, st)) != hipSuccess) return err;
         if ((err = hipMemsetAsync(grad_attn, 0, ns * e, st)) != hipSuccess) return err;
     }
+    struct Scope { hipStream_t s; Scope(int Lq_, hipStream_t s_) : s(s_) { profile_begin(1, Lq_, s_); } ~Scope() { profile_end(s); } } scope(Lq, st);
     if (fast) {
         const int npairs = Lq * M, iters = rounds_per_block(B, npairs);
         const int chunks = (npairs + 32 * iters - 1) / (32 * iters);

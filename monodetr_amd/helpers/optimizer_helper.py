@@ -1,0 +1,102 @@
+"""Optimizer factory and the reference's AdamW variant -- mirror of
+lib/helpers/optimizer_helper.py (``build_optimizer`` :7-27, ``AdamW`` :30-129).
+
+Semantics kept exactly (they are NOT torch.optim.AdamW's):
+    m <- b1 m + (1-b1) g ;  v <- b2 v + (1-b2) g^2
+    step = lr * sqrt(1 - b2^t) / (1 - b1^t)
+    p <- p - step * (wd * p + m / (sqrt(v) + eps))            (reference :129)
+i.e. the decoupled decay is scaled by the bias-corrected ``step``, eps is added outside the
+bias correction, parameters whose name contains 'bias' get wd = 0 (:8-16), parameters without a
+gradient are skipped (:79-80).
+
+What changes is how it runs: the reference loops over a few hundred tensors in Python with ~8 tiny
+kernels each (and deprecated ``add_(Number, Tensor)`` overloads, :111-112,129).  Here every update
+is a handful of multi-tensor ``torch._foreach_*`` launches per parameter group, with the scalar
+step size computed on the host (no device sync).
+"""
+import math
+
+import torch
+import torch.optim as optim
+from torch.optim.optimizer import Optimizer
+
+
+def build_optimizer(cfg_optimizer, model):
+    weights, biases = [], []
+    for name, param in model.named_parameters():
+        (biases if 'bias' in name else weights).append(param)
+    parameters = [{'params': biases, 'weight_decay': 0},
+                  {'params': weights, 'weight_decay': cfg_optimizer['weight_decay']}]
+    kind = cfg_optimizer['type']
+    if kind == 'sgd':
+        return optim.SGD(parameters, lr=cfg_optimizer['lr'], momentum=0.9)
+    if kind == 'adam':
+        return optim.Adam(parameters, lr=cfg_optimizer['lr'])
+    if kind == 'adamw':
+        return AdamW(parameters, lr=cfg_optimizer['lr'])
+    raise NotImplementedError("%s optimizer is not supported" % kind)
+
+
+class AdamW(Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if not 0.0 <= lr:
+            raise ValueError("Invalid learning rate: {}".format(lr))
+        if not 0.0 <= eps:
+            raise ValueError("Invalid epsilon value: {}".format(eps))
+        if not 0.0 <= betas[0] < 1.0:
+            raise ValueError("Invalid beta parameter at index 0: {}".format(betas[0]))
+        if not 0.0 <= betas[1] < 1.0:
+            raise ValueError("Invalid beta parameter at index 1: {}".format(betas[1]))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        for group in self.param_groups:
+            group.setdefault('amsgrad', False)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            beta1, beta2 = group['betas']
+            # parameters of one group may have taken different numbers of steps (a parameter that
+            # first gets a gradient later): bucket by step count so the bias correction stays scalar
+            buckets = {}
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError('Adam does not support sparse gradients, please consider SparseAdam instead')
+                st = self.state[p]
+                if len(st) == 0:
+                    st['step'] = 0
+                    st['exp_avg'] = torch.zeros_like(p)
+                    st['exp_avg_sq'] = torch.zeros_like(p)
+                    if group['amsgrad']:
+                        st['max_exp_avg_sq'] = torch.zeros_like(p)
+                st['step'] += 1
+                buckets.setdefault(st['step'], []).append(p)
+            for t, ps in buckets.items():
+                grads = [p.grad for p in ps]
+                m = [self.state[p]['exp_avg'] for p in ps]
+                v = [self.state[p]['exp_avg_sq'] for p in ps]
+                torch._foreach_mul_(m, beta1)
+                torch._foreach_add_(m, grads, alpha=1 - beta1)
+                torch._foreach_mul_(v, beta2)
+                torch._foreach_addcmul_(v, grads, grads, value=1 - beta2)
+                if group['amsgrad']:
+                    vmax = [self.state[p]['max_exp_avg_sq'] for p in ps]
+                    torch._foreach_maximum_(vmax, v)
+                    denom = torch._foreach_sqrt(vmax)
+                else:
+                    denom = torch._foreach_sqrt(v)
+                torch._foreach_add_(denom, group['eps'])
+                step = group['lr'] * math.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
+                upd = torch._foreach_div(m, denom)
+                if group['weight_decay'] != 0:
+                    torch._foreach_add_(upd, ps, alpha=group['weight_decay'])
+                torch._foreach_add_(ps, upd, alpha=-step)
+        return loss

@@ -19,7 +19,10 @@ from .... import msda_ext as MSDA
 
 
 class MSDeformAttnFunction(Function):
+    # under autocast the projections feeding this op are bf16; the op itself computes in fp32
+    # (the reference's extension is fp32/fp64 only, ms_deform_attn_cuda.cu:64, and would raise)
     @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
                 attention_weights, im2col_step):
         ctx.im2col_step = im2col_step
@@ -31,6 +34,7 @@ class MSDeformAttnFunction(Function):
 
     @staticmethod
     @once_differentiable
+    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_output):
         value, shapes, level_start, loc, attn = ctx.saved_tensors
         g_value, g_loc, g_attn = MSDA.ms_deform_attn_backward(
