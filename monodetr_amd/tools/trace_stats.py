@@ -1,0 +1,58 @@
+"""Steady-state per-kernel statistics from a rocprofv3 --kernel-trace CSV.
+
+    python -m monodetr_amd.tools.trace_stats <kernel_trace.csv> --steps K [--out stats.csv] [--top 40]
+
+rocprofv3's own --stats covers the whole process, i.e. also MIOpen's solver search during the first
+warm-up steps (its naive reference convolutions then dominate the table).  This tool keeps only the
+kernels of the LAST K training steps: a step is delimited by the encoder-shaped msda_bwd launches
+(3 per step), so the window starts after the (3*K+1)-th last of them ended.
+"""
+import argparse
+import csv
+import json
+from collections import defaultdict
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("trace")
+    ap.add_argument("--steps", type=int, required=True)
+    ap.add_argument("--out")
+    ap.add_argument("--top", type=int, default=40)
+    a = ap.parse_args()
+    rows = []
+    with open(a.trace) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
+                         int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0)))
+    rows.sort()
+    bwd = [r for r in rows if "msda_bwd_d32" in r[2]]
+    big = max(r[3] for r in bwd)
+    enc = [r for r in bwd if r[3] == big]
+    need = 3 * a.steps
+    assert len(enc) > need, "trace holds %d encoder backward launches, need > %d" % (len(enc), need)
+    t_start = enc[-need - 1][1]              # end of the last kernel of the step before the window
+    t_end = rows[-1][1]
+    win = [r for r in rows if r[0] >= t_start]
+    agg = defaultdict(lambda: [0, 0, 10 ** 18, 0])
+    for s, e, name, _ in win:
+        x = agg[name]
+        x[0] += 1; x[1] += e - s; x[2] = min(x[2], e - s); x[3] = max(x[3], e - s)
+    total = sum(v[1] for v in agg.values())
+    table = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    wall = (t_end - t_start) / 1e6
+    print(json.dumps({"window_ms": round(wall, 2), "ms_per_step_wall": round(wall / a.steps, 2),
+                      "gpu_busy_ms_per_step": round(total / 1e6 / a.steps, 2), "kernels_per_step": round(len(win) / a.steps, 1)}))
+    if a.out:
+        with open(a.out, "w") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "CallsPerStep", "TotalMsPerStep", "AverageUs", "Percentage", "MinUs", "MaxUs"])
+            for name, (n, t, mn, mx) in table:
+                w.writerow([name[:160], round(n / a.steps, 2), round(t / 1e6 / a.steps, 4), round(t / n / 1e3, 2),
+                            round(100.0 * t / total, 2), round(mn / 1e3, 2), round(mx / 1e3, 2)])
+    for name, (n, t, mn, mx) in table[:a.top]:
+        print("%6.2f%% %9.3f ms/step %7.1f calls/step avg %9.1f us  %s" % (100.0 * t / total, t / 1e6 / a.steps, n / a.steps, t / n / 1e3, name[:110]))
+
+
+if __name__ == "__main__":
+    main()
