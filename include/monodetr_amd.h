@@ -84,6 +84,32 @@ int mdetr_msda_backward(int dtype,
                         int device, void *stream);
 
 /*
+ * Backward with the tile-privatised grad_value path.  Same contract as mdetr_msda_backward plus
+ *   spatial_shapes_host / level_start_host   HOST copies of the two int64 arrays (the launch
+ *                                            geometry is planned on the host)
+ *   workspace / workspace_bytes             device scratch of at least
+ *                                            mdetr_msda_backward_workspace_bytes(...) bytes, 256-B aligned
+ * For fp32, D == 32 and Lq == S (self-attention over the pyramid: query q sits at pixel q) grad_value
+ * is accumulated per query tile in LDS as 64-bit fixed point (exact, order-independent) and reduced
+ * without atomics; samples that leave the tile's window, and every other geometry, take the
+ * fp32-atomic path of mdetr_msda_backward.  Passing NULL host arrays or workspace == NULL is allowed
+ * and equivalent to mdetr_msda_backward.  mdetr_msda_backward_workspace_bytes returns 0 when the
+ * geometry does not qualify.
+ */
+int mdetr_msda_backward_ex(int dtype,
+                           const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                           const void *loc, const void *attn, const void *grad_out,
+                           void *grad_value, void *grad_loc, void *grad_attn,
+                           int B, int S, int M, int D, int L, int Lq, int P,
+                           const int64_t *spatial_shapes_host, const int64_t *level_start_host,
+                           void *workspace, int64_t workspace_bytes,
+                           int device, void *stream);
+
+int64_t mdetr_msda_backward_workspace_bytes(int dtype, const int64_t *spatial_shapes_host,
+                                            const int64_t *level_start_host,
+                                            int B, int S, int M, int D, int L, int Lq, int P);
+
+/*
  * Gather indices the kernels use, for bit-exact index parity checks.
  *   idx [B, Lq, M, L, P, 4] int32 = (in_window, h_low, w_low, corner_mask); zeros when the sample
  *   is outside the window (.cuh:288).  corner_mask bit0..3 = validity of (low,low) (low,high)

@@ -171,6 +171,37 @@ int mdetr_msda_backward(int dtype, const void *value, const int64_t *spatial_sha
     return MDETR_OK;
 }
 
+int64_t mdetr_msda_backward_workspace_bytes(int dtype, const int64_t *spatial_shapes_host, const int64_t *level_start_host,
+                                            int B, int S, int M, int D, int L, int Lq, int P)
+{
+    if (dtype != MDETR_F32 || !spatial_shapes_host || !level_start_host) return 0;
+    return mdetr::msda_tiled_workspace_bytes(spatial_shapes_host, level_start_host, B, S, M, D, L, Lq, P);
+}
+
+int mdetr_msda_backward_ex(int dtype, const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                           const void *loc, const void *attn, const void *grad_out,
+                           void *grad_value, void *grad_loc, void *grad_attn,
+                           int B, int S, int M, int D, int L, int Lq, int P,
+                           const int64_t *spatial_shapes_host, const int64_t *level_start_host,
+                           void *workspace, int64_t workspace_bytes, int device, void *stream)
+{
+    if (int rc = check_common("mdetr_msda_backward_ex", dtype, B, S, M, D, L, Lq, P)) return rc;
+    if (B == 0) return MDETR_OK;
+    if (!value || !spatial_shapes || !level_start || !grad_value || (Lq && (!loc || !attn || !grad_out || !grad_loc || !grad_attn)))
+        return fail(MDETR_E_ARG, "mdetr_msda_backward_ex: null pointer");
+    if (!aligned16(value) || !aligned16(loc) || !aligned16(attn) || !aligned16(grad_out) ||
+        !aligned16(grad_value) || !aligned16(grad_loc) || !aligned16(grad_attn) || !aligned16(workspace))
+        return fail(MDETR_E_ALIGN, "mdetr_msda_backward_ex: tensors must be 16-byte aligned");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_backward_ex: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::msda_backward_launch_ex(dtype, value, spatial_shapes, level_start, loc, attn, grad_out,
+                                                        grad_value, grad_loc, grad_attn, B, S, M, D, L, Lq, P,
+                                                        spatial_shapes_host, level_start_host, workspace, workspace_bytes,
+                                                        static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_backward_ex: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
 int mdetr_msda_indices(int dtype, const int64_t *spatial_shapes, const void *loc, int32_t *idx,
                        int B, int M, int L, int Lq, int P, int device, void *stream)
 {

@@ -327,6 +327,7 @@ __device__ __forceinline__ void scatter_sample(const Foot<float> &f, float a, co
     }
 }
 
+// VAR 2: grad_loc / grad_attn only (grad_value comes from the tile-privatised path, msda_tiled.hip)
 // VAR 0: single phase (gathers, float4-lane atomics and reductions interleaved per sample)
 // VAR 1: per round, a scatter phase with full-row atomics (scatter_rows32) followed by the
 //        gather/reduce phase -- the vmcnt drain the compiler puts between atomics and the next
@@ -337,7 +338,7 @@ void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ s
                   const int64_t *__restrict__ lstart, const float *__restrict__ loc,
                   const float *__restrict__ attn, const float *__restrict__ grad_out,
                   float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
-                  int B, int S, int M, int L_, int P_, int npairs, int iters)
+                  int B, int S, int M, int L_, int P_, int npairs, int iters, unsigned *__restrict__ absmax2)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int L = TL ? TL : L_, P = TP ? TP : P_, LP = L * P;
@@ -349,6 +350,7 @@ void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ s
     const int j = lane >> 3, k = lane & 7;
     const int64_t img = static_cast<int64_t>(b) * S * M * 32;
     const int row = M * 32;
+    float amax_g = 0.f, amax_a = 0.f, poison = 0.f;       // VAR 2: max|grad_out|, max|attn| for the tiled scatter's scale
 
     for (int it = 0; it < iters; ++it) {
         const int p0 = (chunk * iters + it) * (kWaves * kPairsPerWave) + wave * kPairsPerWave;
@@ -358,6 +360,12 @@ void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ s
         wave_lds_fence();
         stage_pairs<TL * TP>(loc, attn, s_loc, s_att, g0, nv, LP, lane);
         wave_lds_fence();
+        if constexpr (VAR == 2) {
+            if (j < nv) {
+                const float *ma = s_att + j * (LP + kPad);
+                for (int s = k; s < LP; s += 8) { amax_a = fmaxf(amax_a, fabsf(ma[s])); poison += ma[s] * 0.f; }
+            }
+        }
         if constexpr (VAR == 1)
             scatter_rows32<TL, TP>(shapes, lstart, grad_out, grad_value, s_loc, s_att, g0, p0, nv, img, M, L, P, lane);
         if (j < nv) {
@@ -366,6 +374,10 @@ void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ s
             float *my_loc = s_loc + j * (2 * LP + kPad);
             float *my_att = s_att + j * (LP + kPad);
             const float4 go = *reinterpret_cast<const float4 *>(grad_out + (g0 + j) * 32 + k * 4);
+            if constexpr (VAR == 2) {
+                amax_g = fmaxf(fmaxf(amax_g, fmaxf(fabsf(go.x), fabsf(go.y))), fmaxf(fabsf(go.z), fabsf(go.w)));
+                poison += (go.x + go.y + go.z + go.w) * 0.f;
+            }
             if constexpr (TP != 0) {
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
@@ -431,6 +443,16 @@ void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ s
             for (int i = lane; i < na4; i += 64) {
                 const int fo = 4 * i, jj = fo / LP, r = fo - jj * LP;
                 ga[i] = *reinterpret_cast<const float4 *>(s_att + jj * (LP + kPad) + r);
+            }
+        }
+    }
+    if constexpr (VAR == 2) {
+        if (absmax2) {
+            if (!(poison == 0.f)) amax_g = __builtin_inff();      // NaN / inf somewhere -> scatter takes the atomic path
+            for (int o = 32; o > 0; o >>= 1) { amax_g = fmaxf(amax_g, __shfl_xor(amax_g, o)); amax_a = fmaxf(amax_a, __shfl_xor(amax_a, o)); }
+            if (lane == 0) {
+                atomicMax(absmax2, __builtin_bit_cast(unsigned, amax_g));
+                atomicMax(absmax2 + 1, __builtin_bit_cast(unsigned, amax_a));
             }
         }
     }
@@ -588,10 +610,12 @@ hipError_t msda_forward_launch(int dtype, const void *value, const int64_t *shap
     return hipGetLastError();
 }
 
-hipError_t msda_backward_launch(int dtype, const void *value, const int64_t *shapes, const int64_t *lstart,
-                                const void *loc, const void *attn, const void *grad_out,
-                                void *grad_value, void *grad_loc, void *grad_attn,
-                                int B, int S, int M, int D, int L, int Lq, int P, hipStream_t st)
+hipError_t msda_backward_launch_ex(int dtype, const void *value, const int64_t *shapes, const int64_t *lstart,
+                                   const void *loc, const void *attn, const void *grad_out,
+                                   void *grad_value, void *grad_loc, void *grad_attn,
+                                   int B, int S, int M, int D, int L, int Lq, int P,
+                                   const int64_t *shapes_host, const int64_t *lstart_host,
+                                   void *workspace, int64_t workspace_bytes, hipStream_t st)
 {
     const size_t e = dtype == 0 ? 4 : 8;
     const int64_t nv = static_cast<int64_t>(B) * S * M * D, ns = static_cast<int64_t>(B) * Lq * M * L * P;
@@ -606,6 +630,15 @@ hipError_t msda_backward_launch(int dtype, const void *value, const int64_t *sha
     }
     struct Scope { hipStream_t s; Scope(int Lq_, hipStream_t s_) : s(s_) { profile_begin(1, Lq_, s_); } ~Scope() { profile_end(s); } } scope(Lq, st);
     if (fast) {
+        static const int var_env = [] { const char *ev = getenv("MDETR_MSDA_BWD_VARIANT"); return ev ? atoi(ev) : -1; }();
+        // tile-privatised grad_value (msda_tiled.hip) when the geometry qualifies; the kernel below then
+        // only produces grad_loc / grad_attn (VAR 2)
+        const bool try_tiled = shapes_host && lstart_host && workspace && var_env != 0 && var_env != 1 &&
+                               msda_tiled_workspace_bytes(shapes_host, lstart_host, B, S, M, D, L, Lq, P) > 0 &&
+                               msda_tiled_workspace_bytes(shapes_host, lstart_host, B, S, M, D, L, Lq, P) <= workspace_bytes;
+        unsigned *absmax2 = try_tiled ? static_cast<unsigned *>(workspace) : nullptr;
+        if (try_tiled && (err = hipMemsetAsync(absmax2, 0, 8, st)) != hipSuccess) return err;
+        const int var = try_tiled ? 2 : (var_env == 0 ? 0 : 1);
         const int npairs = Lq * M, iters = rounds_per_block(B, npairs);
         const int chunks = (npairs + 32 * iters - 1) / (32 * iters);
         const dim3 grid(static_cast<unsigned>(B) * chunks), block(kWaves * 64);
@@ -615,11 +648,22 @@ hipError_t msda_backward_launch(int dtype, const void *value, const int64_t *sha
                                static_cast<const float *>(loc), static_cast<const float *>(attn),
                                static_cast<const float *>(grad_out), static_cast<float *>(grad_value),
                                static_cast<float *>(grad_loc), static_cast<float *>(grad_attn),
-                               B, S, M, L, P, npairs, iters);
+                               B, S, M, L, P, npairs, iters, absmax2);
         };
-        static const int var = [] { const char *e = getenv("MDETR_MSDA_BWD_VARIANT"); return e ? atoi(e) : 1; }();
-        if (L == 4 && P == 4) { if (var == 0) a(msda_bwd_d32<4, 4, 0>); else a(msda_bwd_d32<4, 4, 1>); }
-        else a(msda_bwd_d32<0, 0, 1>);
+        if (L == 4 && P == 4) {
+            if (var == 0) a(msda_bwd_d32<4, 4, 0>); else if (var == 1) a(msda_bwd_d32<4, 4, 1>); else a(msda_bwd_d32<4, 4, 2>);
+        } else {
+            if (var == 2) a(msda_bwd_d32<0, 0, 2>); else a(msda_bwd_d32<0, 0, 1>);
+        }
+        if (try_tiled) {
+            // grad_value: tile-privatised scatter (msda_tiled.hip); the gather kernel above produced
+            // grad_loc / grad_attn and max|grad_out|, max|attn| for the fixed-point scale
+            err = msda_tiled_grad_value_launch(shapes_host, lstart_host, static_cast<const float *>(loc),
+                                               static_cast<const float *>(attn), static_cast<const float *>(grad_out),
+                                               static_cast<float *>(grad_value), workspace, workspace_bytes,
+                                               B, S, M, D, L, Lq, P, /*absmax_ready=*/true, st);
+            if (err != hipSuccess) return err;
+        }
     } else if (dtype == 0) {
         hipLaunchKernelGGL(msda_bwd_generic<float>, dim3(grid_for(n, 256)), dim3(256), 0, st,
                            static_cast<const float *>(value), shapes, lstart, static_cast<const float *>(loc),
@@ -634,6 +678,15 @@ hipError_t msda_backward_launch(int dtype, const void *value, const int64_t *sha
                            static_cast<double *>(grad_attn), S, M, D, L, Lq, P, n);
     }
     return hipGetLastError();
+}
+
+hipError_t msda_backward_launch(int dtype, const void *value, const int64_t *shapes, const int64_t *lstart,
+                                const void *loc, const void *attn, const void *grad_out,
+                                void *grad_value, void *grad_loc, void *grad_attn,
+                                int B, int S, int M, int D, int L, int Lq, int P, hipStream_t st)
+{
+    return msda_backward_launch_ex(dtype, value, shapes, lstart, loc, attn, grad_out, grad_value, grad_loc, grad_attn,
+                                   B, S, M, D, L, Lq, P, nullptr, nullptr, nullptr, 0, st);
 }
 
 hipError_t msda_indices_launch(int dtype, const int64_t *shapes, const void *loc, int32_t *idx,

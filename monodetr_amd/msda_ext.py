@@ -60,6 +60,31 @@ def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# Host copies of (spatial_shapes, level_start_index) for launch planning, cached per device tensor
+# (the model reuses one tensor per resolution, so the device->host copy happens once), and one
+# scratch buffer per device for the tile-privatised backward.
+_host_geometry = {}
+_workspaces = {}
+
+
+def _geometry_on_host(spatial_shapes, level_start_index):
+    key = (spatial_shapes.data_ptr(), spatial_shapes._version, level_start_index.data_ptr(),
+           level_start_index._version, spatial_shapes.device)
+    hit = _host_geometry.get(key)
+    if hit is None:
+        if len(_host_geometry) > 64:
+            _host_geometry.clear()
+        hit = _host_geometry[key] = (spatial_shapes.cpu().contiguous(), level_start_index.cpu().contiguous())
+    return hit
+
+
+def _workspace(device, nbytes):
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() < nbytes:
+        ws = _workspaces[device] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
     """-> Tensor [B, Lq, M*D]  (ms_deform_attn_cuda.cu:20-80)."""
     args = (value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
@@ -90,12 +115,27 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
     dev = value.device.index
-    rc = _capi.lib().mdetr_msda_backward(
-        code, value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-        sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
-        grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
-        B, S, M, D, L, Lq, P, dev, _stream(value.device))
-    _capi.check(rc, "mdetr_msda_backward")
+    lib = _capi.lib()
+    ws_bytes = 0
+    if code == _capi.MDETR_F32 and Lq == S and D == 32:        # self-attention over the pyramid: tile path
+        sh_h, st_h = _geometry_on_host(spatial_shapes, level_start_index)
+        ws_bytes = lib.mdetr_msda_backward_workspace_bytes(code, sh_h.data_ptr(), st_h.data_ptr(), B, S, M, D, L, Lq, P)
+    if ws_bytes > 0:
+        ws = _workspace(value.device, ws_bytes)
+        rc = lib.mdetr_msda_backward_ex(
+            code, value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+            grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
+            B, S, M, D, L, Lq, P, sh_h.data_ptr(), st_h.data_ptr(), ws.data_ptr(), ws_bytes,
+            dev, _stream(value.device))
+        _capi.check(rc, "mdetr_msda_backward_ex")
+    else:
+        rc = lib.mdetr_msda_backward(
+            code, value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+            sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+            grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
+            B, S, M, D, L, Lq, P, dev, _stream(value.device))
+        _capi.check(rc, "mdetr_msda_backward")
     return [grad_value, grad_loc, grad_attn]
 
 

@@ -31,7 +31,8 @@ def make(B, Lq, shapes, dist, seed=0, encoder=False):
     value = torch.rand(B, S, M, D, device="cuda", generator=g) * 0.01
     if dist == "uniform":
         loc = torch.rand(B, Lq, M, L, P, 2, device="cuda", generator=g)
-    else:   # "trained-like": reference point + N(0, 4 px) per level
+    else:   # "trained": reference point + N(0, 4 px) per level; "init": the module's
+            # initial star pattern (head direction x point index 1..P px, ms_deform_attn.py:107-114)
         if encoder:
             refs = []
             for (H, W) in shapes:
@@ -42,7 +43,18 @@ def make(B, Lq, shapes, dist, seed=0, encoder=False):
         else:
             ref = torch.rand(B, Lq, 2, device="cuda", generator=g)
         wh = sh.flip(-1).float()
-        loc = ref[:, :, None, None, None, :] + torch.randn(B, Lq, M, L, P, 2, device="cuda", generator=g) * 4.0 / wh[None, None, None, :, None, :]
+        if dist == "init":
+            import math
+            th = torch.arange(M, device="cuda", dtype=torch.float32) * (2.0 * math.pi / M)
+            d = torch.stack([th.cos(), th.sin()], -1)
+            d = d / d.abs().max(-1, keepdim=True)[0]
+            off = d.view(1, 1, M, 1, 1, 2) * torch.arange(1, P + 1, device="cuda").view(1, 1, 1, 1, P, 1)
+            off = off + 0.05 * torch.randn(B, Lq, M, L, P, 2, device="cuda", generator=g)
+        elif dist.startswith("sigma"):
+            off = torch.randn(B, Lq, M, L, P, 2, device="cuda", generator=g) * float(dist[5:])
+        else:
+            off = torch.randn(B, Lq, M, L, P, 2, device="cuda", generator=g) * 4.0
+        loc = ref[:, :, None, None, None, :] + off / wh[None, None, None, :, None, :]
         loc = loc.contiguous()
     attn = torch.softmax(torch.randn(B, Lq, M, L * P, device="cuda", generator=g), -1).view(B, Lq, M, L, P)
     go = torch.randn(B, Lq, M * D, device="cuda", generator=g)

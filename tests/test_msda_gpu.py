@@ -254,3 +254,73 @@ def test_module_forward_backward_gpu(oracle):
     assert (out.double() - want).abs().max() < 1e-3            # north_star bar
     assert (out.double() - want).abs().max() < 2e-5            # what fp32 GEMMs actually give
     assert (src.grad.double() - srcd.grad).abs().max() < 1e-4 * max(1.0, srcd.grad.abs().max().item())
+
+
+# ---------------------------------------------------------------- tile-privatised backward (Lq == S)
+def pyramid_problem(B, shapes, dist, seed, M=8, D=32, P=4):
+    """Self-attention geometry: one query per pyramid pixel; sampling locations = pixel centre +
+    N(0, sigma px) per level ('local'), or uniform over the image ('uniform': every sample leaves the
+    tile windows and takes the fallback atomics), or a mix."""
+    p = make_problem(B, M, D, sum(h * w for h, w in shapes), shapes, P, torch.float32, seed=seed, lo=-0.05, hi=1.05)
+    if dist != "uniform":
+        g = torch.Generator().manual_seed(seed + 1)
+        refs = []
+        for (H, W) in shapes:
+            ys, xs = torch.meshgrid((torch.arange(H) + 0.5) / H, (torch.arange(W) + 0.5) / W, indexing="ij")
+            refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+        ref = torch.cat(refs, 0)
+        wh = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
+        sigma = 2.0 if dist == "local" else 6.0
+        loc = ref[None, :, None, None, None, :] + torch.randn(p["loc"].shape, generator=g) * sigma / wh[None, None, None, :, None, :]
+        if dist == "mixed":                       # a quarter of the samples anywhere in the image
+            far = torch.rand(p["loc"].shape[:-1], generator=g) < 0.25
+            loc = torch.where(far[..., None], p["loc"], loc)
+        p["loc"] = loc.contiguous()
+    return p
+
+
+@pytest.mark.parametrize("shapes,dist", [
+    (KITTI, "local"), (KITTI, "mixed"), (KITTI, "uniform"),
+    ([(12, 40), (6, 20), (3, 10), (2, 5)], "local"),            # every level fits LDS: chunked whole-level windows
+    ([(20, 33), (10, 17), (5, 9)], "mixed"),                    # odd, non-halving pyramid, L = 3
+    (KITTI_HI, "local"),
+])
+def test_tiled_backward_matches_oracle_and_atomic_path(ext, oracle, shapes, dist, monkeypatch):
+    B = 2
+    p = pyramid_problem(B, shapes, dist, seed=len(shapes) * 7 + len(dist))
+    d = dev(p)
+    from monodetr_amd import _capi
+    sh_h, st_h = p["shapes"].contiguous(), p["level_start"].contiguous()
+    S = sh_h.prod(1).sum().item()
+    ws = _capi.lib().mdetr_msda_backward_workspace_bytes(0, sh_h.data_ptr(), st_h.data_ptr(), B, S, 8, 32, len(shapes), S, 4)
+    assert ws > 0, "geometry should qualify for the tile path"
+    gv, gl, ga = run_bwd(ext, d)
+    rv, rl, ra = oracle_bwd(oracle, p, torch.float64)
+    scale = max(1.0, rv.abs().max().item())
+    assert (gv.cpu().double() - rv).abs().max() < 1e-5 * scale
+    assert (ga.cpu().double() - ra).abs().max() < 1e-4 * max(1.0, ra.abs().max().item())
+    # d/d(loc) is discontinuous at cell boundaries: pixel-centre references put a few samples within
+    # fp32 rounding of one, where the fp64 evaluation floors differently.  Compare those against the
+    # fp32 oracle (same rounding as the kernel), everything else against fp64.
+    same_cell = (oracle.indices(p["shapes"], p["loc"]) == oracle.indices(p["shapes"], p["loc"].double())).all(-1)
+    dl = (gl.cpu().double() - rl).abs().amax(-1)
+    assert dl[same_cell].max() < 1e-4 * max(1.0, rl.abs().max().item())
+    assert (~same_cell).sum() < 1e-4 * same_cell.numel()
+    _, rl32, _ = oracle_bwd(oracle, p)
+    assert (gl.cpu() - rl32).abs().max() < 1e-3 * max(1.0, rl32.abs().max().item())
+    if dist == "local":
+        # privatised sums are exact integers (order-independent); only samples that left their window
+        # went through fp32 atomics, so run-to-run differences stay at rounding level
+        gv2, _, _ = run_bwd(ext, d)
+        assert (gv - gv2).abs().max() < 1e-5 * scale
+
+
+def test_tiled_backward_nonfinite_gradients_fall_back(ext, oracle):
+    p = pyramid_problem(1, [(12, 40), (6, 20), (3, 10), (2, 5)], "local", seed=3)
+    p["grad_out"][0, 5, 7] = float("inf")
+    d = dev(p)
+    gv, _, _ = run_bwd(ext, d)
+    rv, _, _ = oracle_bwd(oracle, p)
+    assert torch.equal(torch.isfinite(gv.cpu()), torch.isfinite(rv))
+    fin = torch.isfinite(rv)
+    assert (gv.cpu()[fin] - rv[fin]).abs().max() < 1e-5 * max(1.0, rv[fin].abs().max().item())
