@@ -33,6 +33,7 @@ extern "C" {
 /* element types of the floating-point tensors */
 #define MDETR_F32 0
 #define MDETR_F64 1
+#define MDETR_BF16 2   /* attention entry points only */
 
 #define MDETR_OK            0
 #define MDETR_E_ARG        -1   /* bad size / null pointer / unsupported dtype */
@@ -123,6 +124,35 @@ int mdetr_msda_indices(int dtype, const int64_t *spatial_shapes, const void *loc
  * 0 = generic path (any D, f32/f64).  Pure host logic, no GPU needed.
  */
 int mdetr_msda_variant(int dtype, int M, int D, int L, int P);
+
+/*
+ * Fused dense multi-head attention, head_dim = 32:  out = dropout(softmax(q k^T * scale + mask)) v.
+ * Replaces the QK^T / softmax / dropout / PV core of the three torch.nn.MultiheadAttention calls on
+ * the hot path (depthaware_transformer.py:456-459, :496; depth_predictor/transformer.py:59), which
+ * the reference evaluates with need_weights=True, i.e. with the full [B*H, Lq, Lk] score matrix
+ * (and its head average) in memory.  Scores stay in registers here (bf16 MFMA, fp32 accumulate).
+ *
+ *   dtype            MDETR_F32 or MDETR_BF16: element type of q, k, v, out (and of d_out, dq, dk, dv)
+ *   q                [B, Lq, H*32]  batch stride q_bs, row stride q_rs (elements), innermost contiguous
+ *   k, v             [B, Lk, H*32]  likewise (so slices of a packed in-projection output work)
+ *   key_padding_mask [B, Lk] uint8, nonzero = ignore the key; may be NULL
+ *   out              [B, Lq, H*32]  contiguous
+ *   lse              [B, H, Lq] fp32: log2-domain log-sum-exp of the scaled scores (for backward)
+ *   dropout_p, seed  dropout on the probabilities; the mask is a stateless hash of (seed, b, h, q, k),
+ *                    regenerated identically by the backward
+ * Backward additionally takes out, d_out [B, Lq, H*32] contiguous and a scratch dsum [B, H, Lq] fp32,
+ * and writes dq [B, Lq, H*32], dk, dv [B, Lk, H*32] (contiguous, fully overwritten).
+ */
+int mdetr_attn_forward(int dtype, const void *q, const void *k, const void *v, const uint8_t *key_padding_mask,
+                       void *out, float *lse, int B, int H, int Lq, int Lk,
+                       int64_t q_bs, int64_t k_bs, int64_t v_bs, int q_rs, int k_rs, int v_rs,
+                       float scale, float dropout_p, uint64_t seed, int device, void *stream);
+
+int mdetr_attn_backward(int dtype, const void *q, const void *k, const void *v, const uint8_t *key_padding_mask,
+                        const void *out, const void *d_out, const float *lse, float *dsum,
+                        void *dq, void *dk, void *dv, int B, int H, int Lq, int Lk,
+                        int64_t q_bs, int64_t k_bs, int64_t v_bs, int q_rs, int k_rs, int v_rs,
+                        float scale, float dropout_p, uint64_t seed, int device, void *stream);
 
 /*
  * Optional per-launch kernel timing with HIP events recorded on the launch stream (bench.py's

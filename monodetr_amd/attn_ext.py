@@ -1,0 +1,84 @@
+"""Host binding of the fused attention kernels (C ABI: mdetr_attn_forward / mdetr_attn_backward).
+
+``fused_attention(q, k, v, num_heads, dropout_p, key_padding_mask)`` takes batch-first
+``[B, L, H*32]`` tensors whose last dimension is contiguous (row / batch strides are free, so the
+slices of a packed in-projection output are consumed in place) and returns ``[B, Lq, H*32]``.
+Differentiable; the dropout mask is regenerated in the backward from (seed, b, h, q, k).
+"""
+import torch
+
+from . import _capi
+
+
+def _codes(t):
+    if t.dtype == torch.float32:
+        return _capi.MDETR_F32
+    if t.dtype == torch.bfloat16:
+        return _capi.MDETR_BF16
+    raise RuntimeError("fused attention supports float32 and bfloat16, got %s" % t.dtype)
+
+
+def _strided(t):
+    """[B, L, E] with unit stride in E -> (tensor, batch stride, row stride); copies if it must."""
+    if t.stride(-1) != 1 or (t.data_ptr() % 16) or (t.stride(1) * t.element_size()) % 16 or (t.stride(0) * t.element_size()) % 16:
+        t = t.contiguous()
+    return t, t.stride(0), t.stride(1)
+
+
+class _FusedAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, num_heads, scale, dropout_p, seed, key_padding_mask):
+        assert q.is_cuda, "fused attention runs on the GPU only"
+        B, Lq, E = q.shape
+        Lk = k.shape[1]
+        assert E == num_heads * 32, "head_dim must be 32"
+        assert k.shape == (B, Lk, E) and v.shape == (B, Lk, E) and k.dtype == q.dtype and v.dtype == q.dtype
+        code = _codes(q)
+        q, qb, qr = _strided(q)
+        k, kb, kr = _strided(k)
+        v, vb, vr = _strided(v)
+        kpm = None
+        if key_padding_mask is not None:
+            kpm = key_padding_mask.to(torch.uint8).contiguous()
+            assert kpm.shape == (B, Lk)
+        out = torch.empty((B, Lq, E), dtype=q.dtype, device=q.device)
+        lse = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=q.device)
+        rc = _capi.lib().mdetr_attn_forward(
+            code, q.data_ptr(), k.data_ptr(), v.data_ptr(), kpm.data_ptr() if kpm is not None else None,
+            out.data_ptr(), lse.data_ptr(), B, num_heads, Lq, Lk, qb, kb, vb, qr, kr, vr,
+            float(scale), float(dropout_p), int(seed), q.device.index, torch.cuda.current_stream(q.device).cuda_stream)
+        _capi.check(rc, "mdetr_attn_forward")
+        ctx.save_for_backward(q, k, v, out, lse, kpm if kpm is not None else torch.empty(0, device=q.device))
+        ctx.meta = (code, num_heads, float(scale), float(dropout_p), int(seed), kpm is not None, (qb, kb, vb, qr, kr, vr))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        q, k, v, out, lse, kpm = ctx.saved_tensors
+        code, H, scale, dropout_p, seed, has_kpm, (qb, kb, vb, qr, kr, vr) = ctx.meta
+        B, Lq, E = q.shape
+        Lk = k.shape[1]
+        d_out = d_out.contiguous()
+        if d_out.data_ptr() % 16:
+            d_out = d_out.clone()
+        dq = torch.empty((B, Lq, E), dtype=q.dtype, device=q.device)
+        dk = torch.empty((B, Lk, E), dtype=q.dtype, device=q.device)
+        dv = torch.empty((B, Lk, E), dtype=q.dtype, device=q.device)
+        dsum = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
+        rc = _capi.lib().mdetr_attn_backward(
+            code, q.data_ptr(), k.data_ptr(), v.data_ptr(), kpm.data_ptr() if has_kpm else None,
+            out.data_ptr(), d_out.data_ptr(), lse.data_ptr(), dsum.data_ptr(),
+            dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Lq, Lk, qb, kb, vb, qr, kr, vr,
+            scale, dropout_p, seed, q.device.index, torch.cuda.current_stream(q.device).cuda_stream)
+        _capi.check(rc, "mdetr_attn_backward")
+        return dq, dk, dv, None, None, None, None, None
+
+
+def fused_attention(q, k, v, num_heads, dropout_p=0.0, key_padding_mask=None, scale=None, seed=None):
+    if scale is None:
+        scale = (q.shape[-1] // num_heads) ** -0.5
+    if dropout_p > 0.0 and seed is None:
+        # drawn from torch's CPU generator: reproducible under torch.manual_seed, no device sync
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return _FusedAttention.apply(q, k, v, num_heads, scale, dropout_p, seed or 0, key_padding_mask)

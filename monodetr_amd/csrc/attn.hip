@@ -1,0 +1,475 @@
+// monodetr_amd/csrc/attn.hip -- fused dense multi-head attention (head_dim = 32) on CDNA4 MFMA.
+//
+// Replaces, on MonoDETR's hot path, the three nn.MultiheadAttention cores
+//   depth cross-attention        depthaware_transformer.py:456-459   Lq = 550 (50), Lk = 1920
+//   depth-encoder self-attention depth_predictor/transformer.py:59    Lq = Lk = 1920
+//   decoder (grouped) self-attn  depthaware_transformer.py:496        Lq = Lk = 50, batch = B * 11
+// whose reference path materialises QK^T, softmax, dropout and the head-averaged weights in HBM.
+// Here softmax(q k^T * scale + mask) v runs flash-style: scores never leave registers.
+//
+// Tiling (wave64, `v_mfma_f32_32x32x16_bf16`):
+//   * forward / dQ: one wave owns 32 query rows of one (batch, head); a 256-thread workgroup = 4
+//     waves = 128 queries sharing K/V tiles of 64 keys staged in LDS.  Products are issued
+//     "transposed" (S^T = K Q^T, O^T = V^T P^T, dQ^T = K^T dS^T) so that a lane's column index is
+//     its query: row max / row sum / rescale are lane-local plus ONE exchange with lane^32.
+//   * dK/dV: one wave owns 32 keys, loops over query tiles (S = Q K^T, dP = dO V^T, dV^T = dO^T P,
+//     dK^T = Q^T dS) -- a lane's column index is its key.
+//   * The accumulator (C/D) layout of a 32x32 MFMA -- row = (r&3) + 8(r>>2) + 4(lane>>5), col =
+//     lane&31 -- is fed straight back as the B operand of the next product: the contraction index
+//     is then visited in a permuted ("virtual") order, and the A operand is read from a TRANSPOSED
+//     LDS copy with the same permutation (two 8-byte reads per lane), so no register shuffles.
+//   * inputs fp32 or bf16 (converted to bf16 while staging, fp32 accumulation), exp2-domain online
+//     softmax with the scale folded into Q (or K), dropout on the probabilities from a stateless
+//     counter hash of (seed, b, h, q, k) so forward and backward regenerate the same mask.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "attn.h"
+
+namespace mdetr {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kD = 32;             // head dim
+constexpr int kTile = 64;          // rows of a staged K/V (or Q/dO) tile
+constexpr int kRowPad = 40;        // bf16 per row of a row-major tile (80 B: 16-B aligned, spreads banks)
+constexpr int kTPad = 72;          // bf16 per row of a transposed tile [d][64 rows + 8]
+constexpr float kLog2e = 1.4426950408889634f;
+
+struct AttnArgs {
+    const void *q, *k, *v;         // [B, L, H*32] with row strides (elements); last dim contiguous
+    const uint8_t *kpm;            // [B, Lk] key padding mask (nonzero = ignore) or null
+    int B, H, Lq, Lk;
+    int64_t q_bs, k_bs, v_bs;      // batch strides (elements)
+    int q_rs, k_rs, v_rs;          // row strides (elements)
+    float scale, dropout_p;
+    uint64_t seed;
+};
+
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 zero16()
+{
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// row index (contraction / output row) of accumulator register r for this lane half
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// keep-probability test for dropout: stateless hash of the element coordinates
+__device__ __forceinline__ bool keep_elem(uint64_t seed, int b, int h, int q, int k, unsigned thresh)
+{
+    unsigned x = static_cast<unsigned>(seed) ^ (static_cast<unsigned>(q) * 0x9E3779B1u);
+    x ^= (static_cast<unsigned>(k) + 0x7F4A7C15u) * 0x85EBCA77u;
+    x ^= static_cast<unsigned>(seed >> 32) + static_cast<unsigned>(b * 131 + h) * 0xC2B2AE3Du;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x >= thresh;
+}
+
+template <typename T> __device__ __forceinline__ void load8(const T *p, float (&o)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float *p, float (&o)[8])
+{
+    const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <> __device__ __forceinline__ void load8<__bf16>(const __bf16 *p, float (&o)[8])
+{
+    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = static_cast<float>(v[i]);
+}
+
+template <typename T> __device__ __forceinline__ void store4(T *p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store4<float>(float *p, float a, float b, float c, float d)
+{
+    *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void store4<__bf16>(__bf16 *p, float a, float b, float c, float d)
+{
+    bf16x4 v;
+    v[0] = static_cast<__bf16>(a); v[1] = static_cast<__bf16>(b); v[2] = static_cast<__bf16>(c); v[3] = static_cast<__bf16>(d);
+    *reinterpret_cast<bf16x4 *>(p) = v;
+}
+
+// Stage rows [r0, r0+64) x 32 of a [L, row_stride] matrix into LDS: row-major bf16 copy `rm`
+// ([64][kRowPad]) and/or transposed copy `tr` ([32][kTPad]); rows >= L are zero.  256 threads.
+template <typename T, bool RM, bool TR>
+__device__ __forceinline__ void stage_tile(const T *base, int row_stride, int r0, int L, __bf16 *rm, __bf16 *tr, float mul)
+{
+    const int t = threadIdx.x, row = t >> 2, dc = (t & 3) * 8;
+    float x[8];
+    if (r0 + row < L) load8<T>(base + static_cast<int64_t>(r0 + row) * row_stride + dc, x);
+    else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = 0.f;
+    }
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = static_cast<__bf16>(x[i] * mul);
+    if (RM) *reinterpret_cast<bf16x8 *>(rm + row * kRowPad + dc) = v;
+    if (TR) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tr[(dc + i) * kTPad + row] = v[i];
+    }
+}
+
+// A operand from a row-major tile: lane's row = sub*32 + (lane&31), 8 contiguous columns
+__device__ __forceinline__ bf16x8 frag_rows(const __bf16 *rm, int sub, int kstep, int lane)
+{
+    return *reinterpret_cast<const bf16x8 *>(rm + (sub * 32 + (lane & 31)) * kRowPad + kstep * 16 + (lane >> 5) * 8);
+}
+
+// A operand from a transposed tile [d][rows]: lane's row = d = lane&31; contraction over the tile's
+// rows in the accumulator ("virtual") order: rows base+0..3 and base+8..11, base = sub*32+16*kstep+4*half
+__device__ __forceinline__ bf16x8 frag_cols(const __bf16 *tr, int sub, int kstep, int lane)
+{
+    const __bf16 *p = tr + (lane & 31) * kTPad + sub * 32 + kstep * 16 + (lane >> 5) * 4;
+    const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(p), hi = *reinterpret_cast<const bf16x4 *>(p + 8);
+    bf16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return v;
+}
+
+// B operand from accumulator registers: elements 8*kstep .. 8*kstep+7
+__device__ __forceinline__ bf16x8 frag_acc(const float (&p)[16], int kstep)
+{
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = static_cast<__bf16>(p[8 * kstep + i]);
+    return v;
+}
+
+// B operand from global rows owned by lanes: row = own row (lane&31), columns 16*kstep + 8*half + 0..7
+template <typename T>
+__device__ __forceinline__ void own_row_frags(const T *rowp, bool valid, float mul, int lane, bf16x8 (&f)[2])
+{
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        float x[8];
+        if (valid) load8<T>(rowp + ks * 16 + (lane >> 5) * 8, x);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[ks][i] = static_cast<__bf16>(x[i] * mul);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256)
+void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ lse2)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[kTile * kRowPad];
+    __shared__ __attribute__((aligned(16))) __bf16 Vt[kD * kTPad];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const bool qv = q < a.Lq;
+    const T *Q = static_cast<const T *>(a.q) + b * a.q_bs + h * kD;
+    const T *K = static_cast<const T *>(a.k) + b * a.k_bs + h * kD;
+    const T *V = static_cast<const T *>(a.v) + b * a.v_bs + h * kD;
+
+    bf16x8 qf[2];
+    own_row_frags<T>(Q + static_cast<int64_t>(q) * a.q_rs, qv, a.scale * kLog2e, lane, qf);
+
+    const bool drop = a.dropout_p > 0.f;
+    const unsigned thresh = drop ? static_cast<unsigned>(a.dropout_p * 4294967296.0) : 0u;
+    const float rinv = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
+
+    float m = -__builtin_inff(), l = 0.f;
+    f32x16 acc = zero16();
+
+    for (int k0 = 0; k0 < a.Lk; k0 += kTile) {
+        __syncthreads();
+        stage_tile<T, true, false>(K, a.k_rs, k0, a.Lk, Ks, nullptr, 1.f);
+        stage_tile<T, false, true>(V, a.v_rs, k0, a.Lk, nullptr, Vt, 1.f);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            if (k0 + sub * 32 >= a.Lk) break;                    // block-uniform
+            f32x16 s = zero16();
+            s = mfma(frag_rows(Ks, sub, 0, lane), qf[0], s);     // S^T[key][query]
+            s = mfma(frag_rows(Ks, sub, 1, lane), qf[1], s);
+            float p[16];
+            float mx = m;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + sub * 32 + acc_row(r, half);
+                bool ok = key < a.Lk;
+                if (a.kpm) ok = ok && (a.kpm[static_cast<int64_t>(b) * a.Lk + (ok ? key : 0)] == 0);
+                p[r] = ok ? s[r] : -__builtin_inff();
+                mx = fmaxf(mx, p[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float msafe = mx == -__builtin_inff() ? 0.f : mx;
+            const float alpha = exp2f(m - msafe);               // m = -inf -> 0
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = exp2f(p[r] - msafe);
+                psum += e;
+                p[r] = e;
+                if (drop) {
+                    const int key = k0 + sub * 32 + acc_row(r, half);
+                    p[r] = keep_elem(a.seed, b, h, q, key, thresh) ? e * rinv : 0.f;
+                }
+            }
+            l = l * alpha + psum;
+            m = mx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= alpha;
+            acc = mfma(frag_cols(Vt, sub, 0, lane), frag_acc(p, 0), acc);   // O^T[d][query]
+            acc = mfma(frag_cols(Vt, sub, 1, lane), frag_acc(p, 1), acc);
+        }
+    }
+    l += __shfl_xor(l, 32);
+    if (qv) {
+        const float inv = l > 0.f ? 1.f / l : 0.f;               // fully masked row -> zeros
+        T *o = out + (static_cast<int64_t>(b) * a.Lq + q) * (a.H * kD) + h * kD + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            store4<T>(o + 8 * g, acc[4 * g] * inv, acc[4 * g + 1] * inv, acc[4 * g + 2] * inv, acc[4 * g + 3] * inv);
+        if (half == 0) lse2[(static_cast<int64_t>(b) * a.H + h) * a.Lq + q] = l > 0.f ? m + log2f(l) : -__builtin_inff();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: D = rowsum(dO * O)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256)
+void attn_bwd_prep_kernel(const T *__restrict__ o, const T *__restrict__ d_o, float *__restrict__ dsum, int B, int H, int Lq)
+{
+    // one 8-lane group per (b, q, h): 32 channels as 8 x 4
+    const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    const int64_t item = gid >> 3;
+    const int c = static_cast<int>(gid & 7) * 4;
+    float s = 0.f;
+    const bool ok = item < static_cast<int64_t>(B) * Lq * H;
+    if (ok) {
+        const int64_t off = item * kD + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += static_cast<float>(o[off + i]) * static_cast<float>(d_o[off + i]);
+    }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    if (ok && c == 0) {
+        const int h = static_cast<int>(item % H);
+        const int64_t bq = item / H;
+        const int q = static_cast<int>(bq % Lq), b = static_cast<int>(bq / Lq);
+        dsum[(static_cast<int64_t>(b) * H + h) * Lq + q] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: dQ  (lane = query, loop over key tiles)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256)
+void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float *__restrict__ lse2,
+                        const float *__restrict__ dsum, T *__restrict__ dq)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[kTile * kRowPad];
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[kTile * kRowPad];
+    __shared__ __attribute__((aligned(16))) __bf16 Kt[kD * kTPad];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const bool qv = q < a.Lq;
+    const T *Q = static_cast<const T *>(a.q) + b * a.q_bs + h * kD;
+    const T *K = static_cast<const T *>(a.k) + b * a.k_bs + h * kD;
+    const T *V = static_cast<const T *>(a.v) + b * a.v_bs + h * kD;
+    const int64_t orow = (static_cast<int64_t>(b) * a.Lq + q) * (a.H * kD) + h * kD;
+
+    bf16x8 qf[2], dof[2];
+    own_row_frags<T>(Q + static_cast<int64_t>(q) * a.q_rs, qv, a.scale * kLog2e, lane, qf);
+    own_row_frags<T>(d_o + orow, qv, 1.f, lane, dof);
+    const int64_t stat = (static_cast<int64_t>(b) * a.H + h) * a.Lq + q;
+    const float L2 = qv ? lse2[stat] : 0.f, Dq = qv ? dsum[stat] : 0.f;
+
+    const bool drop = a.dropout_p > 0.f;
+    const unsigned thresh = drop ? static_cast<unsigned>(a.dropout_p * 4294967296.0) : 0u;
+    const float rinv = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
+    f32x16 acc = zero16();
+
+    for (int k0 = 0; k0 < a.Lk; k0 += kTile) {
+        __syncthreads();
+        stage_tile<T, true, true>(K, a.k_rs, k0, a.Lk, Ks, Kt, 1.f);
+        stage_tile<T, true, false>(V, a.v_rs, k0, a.Lk, Vs, nullptr, 1.f);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            if (k0 + sub * 32 >= a.Lk) break;
+            f32x16 s = zero16(), dp = zero16();
+            s = mfma(frag_rows(Ks, sub, 0, lane), qf[0], s);
+            s = mfma(frag_rows(Ks, sub, 1, lane), qf[1], s);
+            dp = mfma(frag_rows(Vs, sub, 0, lane), dof[0], dp);  // dP^T[key][query] = V dO^T
+            dp = mfma(frag_rows(Vs, sub, 1, lane), dof[1], dp);
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + sub * 32 + acc_row(r, half);
+                bool ok = key < a.Lk && L2 != -__builtin_inff();
+                if (a.kpm) ok = ok && (a.kpm[static_cast<int64_t>(b) * a.Lk + (key < a.Lk ? key : 0)] == 0);
+                const float p = ok ? exp2f(s[r] - L2) : 0.f;
+                float g = dp[r];
+                if (drop) g = keep_elem(a.seed, b, h, q, key, thresh) ? g * rinv : 0.f;
+                ds[r] = p * (g - Dq);
+            }
+            acc = mfma(frag_cols(Kt, sub, 0, lane), frag_acc(ds, 0), acc);   // dQ^T[d][query]
+            acc = mfma(frag_cols(Kt, sub, 1, lane), frag_acc(ds, 1), acc);
+        }
+    }
+    if (qv) {
+        T *o = dq + orow + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            store4<T>(o + 8 * g, acc[4 * g] * a.scale, acc[4 * g + 1] * a.scale, acc[4 * g + 2] * a.scale, acc[4 * g + 3] * a.scale);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: dK, dV  (lane = key, loop over query tiles)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256)
+void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const float *__restrict__ lse2,
+                         const float *__restrict__ dsum, T *__restrict__ dk, T *__restrict__ dv)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 Qs[kTile * kRowPad];
+    __shared__ __attribute__((aligned(16))) __bf16 Os[kTile * kRowPad];
+    __shared__ __attribute__((aligned(16))) __bf16 Qt[kD * kTPad];
+    __shared__ __attribute__((aligned(16))) __bf16 Ot[kD * kTPad];
+    __shared__ __attribute__((aligned(16))) float Ls[kTile];
+    __shared__ __attribute__((aligned(16))) float Ds[kTile];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int key = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const bool kv = key < a.Lk;
+    const T *Q = static_cast<const T *>(a.q) + b * a.q_bs + h * kD;
+    const T *K = static_cast<const T *>(a.k) + b * a.k_bs + h * kD;
+    const T *V = static_cast<const T *>(a.v) + b * a.v_bs + h * kD;
+    const T *dO = d_o + static_cast<int64_t>(b) * a.Lq * (a.H * kD) + h * kD;
+    const float *L2b = lse2 + (static_cast<int64_t>(b) * a.H + h) * a.Lq;
+    const float *Db = dsum + (static_cast<int64_t>(b) * a.H + h) * a.Lq;
+
+    bf16x8 kf[2], vf[2];
+    own_row_frags<T>(K + static_cast<int64_t>(key) * a.k_rs, kv, a.scale * kLog2e, lane, kf);
+    own_row_frags<T>(V + static_cast<int64_t>(key) * a.v_rs, kv, 1.f, lane, vf);
+    bool key_ok = kv;
+    if (a.kpm && kv) key_ok = a.kpm[static_cast<int64_t>(b) * a.Lk + key] == 0;
+
+    const bool drop = a.dropout_p > 0.f;
+    const unsigned thresh = drop ? static_cast<unsigned>(a.dropout_p * 4294967296.0) : 0u;
+    const float rinv = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
+    f32x16 acck = zero16(), accv = zero16();
+
+    for (int q0 = 0; q0 < a.Lq; q0 += kTile) {
+        __syncthreads();
+        stage_tile<T, true, true>(Q, a.q_rs, q0, a.Lq, Qs, Qt, 1.f);
+        stage_tile<T, true, true>(dO, a.H * kD, q0, a.Lq, Os, Ot, 1.f);
+        if (threadIdx.x < kTile) {
+            const int qq = q0 + threadIdx.x;
+            Ls[threadIdx.x] = qq < a.Lq ? L2b[qq] : -__builtin_inff();
+            Ds[threadIdx.x] = qq < a.Lq ? Db[qq] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            if (q0 + sub * 32 >= a.Lq) break;
+            f32x16 s = zero16(), dp = zero16();
+            s = mfma(frag_rows(Qs, sub, 0, lane), kf[0], s);     // S[query][key]
+            s = mfma(frag_rows(Qs, sub, 1, lane), kf[1], s);
+            dp = mfma(frag_rows(Os, sub, 0, lane), vf[0], dp);   // dP[query][key] = dO V^T
+            dp = mfma(frag_rows(Os, sub, 1, lane), vf[1], dp);
+            float pd[16], ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qi = sub * 32 + acc_row(r, half), qq = q0 + qi;
+                const float L2 = Ls[qi];
+                const bool ok = key_ok && L2 != -__builtin_inff();
+                const float p = ok ? exp2f(s[r] - L2) : 0.f;
+                float g = dp[r], pk = p;
+                if (drop) {
+                    const bool kp = keep_elem(a.seed, b, h, qq, key, thresh);
+                    g = kp ? g * rinv : 0.f;
+                    pk = kp ? p * rinv : 0.f;
+                }
+                pd[r] = pk;
+                ds[r] = p * (g - Ds[qi]);
+            }
+            accv = mfma(frag_cols(Ot, sub, 0, lane), frag_acc(pd, 0), accv);   // dV^T[d][key] = dO^T P
+            accv = mfma(frag_cols(Ot, sub, 1, lane), frag_acc(pd, 1), accv);
+            acck = mfma(frag_cols(Qt, sub, 0, lane), frag_acc(ds, 0), acck);   // dK^T[d][key] = Q^T dS
+            acck = mfma(frag_cols(Qt, sub, 1, lane), frag_acc(ds, 1), acck);
+        }
+    }
+    if (kv) {
+        const int64_t row = (static_cast<int64_t>(b) * a.Lk + key) * (a.H * kD) + h * kD + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            store4<T>(dk + row + 8 * g, acck[4 * g] * a.scale, acck[4 * g + 1] * a.scale, acck[4 * g + 2] * a.scale, acck[4 * g + 3] * a.scale);
+            store4<T>(dv + row + 8 * g, accv[4 * g], accv[4 * g + 1], accv[4 * g + 2], accv[4 * g + 3]);
+        }
+    }
+}
+
+AttnArgs make_args(const AttnProblem &p)
+{
+    AttnArgs a;
+    a.q = p.q; a.k = p.k; a.v = p.v; a.kpm = p.key_padding_mask;
+    a.B = p.B; a.H = p.H; a.Lq = p.Lq; a.Lk = p.Lk;
+    a.q_bs = p.q_batch_stride; a.k_bs = p.k_batch_stride; a.v_bs = p.v_batch_stride;
+    a.q_rs = p.q_row_stride; a.k_rs = p.k_row_stride; a.v_rs = p.v_row_stride;
+    a.scale = p.scale; a.dropout_p = p.dropout_p; a.seed = p.seed;
+    return a;
+}
+
+}  // namespace
+
+hipError_t attn_forward_launch(const AttnProblem &p, void *out, float *lse2, hipStream_t st)
+{
+    if (p.B == 0 || p.Lq == 0) return hipSuccess;
+    const AttnArgs a = make_args(p);
+    const dim3 grid((p.Lq + 127) / 128, p.H, p.B), block(256);
+    if (p.dtype == 0) hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, 0, st, a, static_cast<float *>(out), lse2);
+    else hipLaunchKernelGGL(attn_fwd_kernel<__bf16>, grid, block, 0, st, a, static_cast<__bf16 *>(out), lse2);
+    return hipGetLastError();
+}
+
+hipError_t attn_backward_launch(const AttnProblem &p, const void *out, const void *d_out, const float *lse2,
+                                float *dsum, void *dq, void *dk, void *dv, hipStream_t st)
+{
+    if (p.B == 0) return hipSuccess;
+    const AttnArgs a = make_args(p);
+    const int64_t items = static_cast<int64_t>(p.B) * p.Lq * p.H;
+    const dim3 gq((p.Lq + 127) / 128, p.H, p.B), gk((p.Lk + 127) / 128, p.H, p.B), block(256);
+    if (p.dtype == 0) {
+        if (items) hipLaunchKernelGGL(attn_bwd_prep_kernel<float>, dim3(static_cast<unsigned>((items * 8 + 255) / 256)), block, 0, st,
+                                      static_cast<const float *>(out), static_cast<const float *>(d_out), dsum, p.B, p.H, p.Lq);
+        if (p.Lq) hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, gq, block, 0, st, a, static_cast<const float *>(d_out), lse2, dsum, static_cast<float *>(dq));
+        if (p.Lk) hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, gk, block, 0, st, a, static_cast<const float *>(d_out), lse2, dsum,
+                                     static_cast<float *>(dk), static_cast<float *>(dv));
+    } else {
+        if (items) hipLaunchKernelGGL(attn_bwd_prep_kernel<__bf16>, dim3(static_cast<unsigned>((items * 8 + 255) / 256)), block, 0, st,
+                                      static_cast<const __bf16 *>(out), static_cast<const __bf16 *>(d_out), dsum, p.B, p.H, p.Lq);
+        if (p.Lq) hipLaunchKernelGGL(attn_bwd_dq_kernel<__bf16>, gq, block, 0, st, a, static_cast<const __bf16 *>(d_out), lse2, dsum, static_cast<__bf16 *>(dq));
+        if (p.Lk) hipLaunchKernelGGL(attn_bwd_dkv_kernel<__bf16>, gk, block, 0, st, a, static_cast<const __bf16 *>(d_out), lse2, dsum,
+                                     static_cast<__bf16 *>(dk), static_cast<__bf16 *>(dv));
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mdetr

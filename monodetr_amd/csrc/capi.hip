@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/monodetr_amd.h"
+#include "attn.h"
 #include "msda.h"
 
 namespace {
@@ -199,6 +200,56 @@ int mdetr_msda_backward_ex(int dtype, const void *value, const int64_t *spatial_
                                                         spatial_shapes_host, level_start_host, workspace, workspace_bytes,
                                                         static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_backward_ex: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+static int attn_check(const char *who, int dtype, const void *q, const void *k, const void *v, int B, int H, int Lq, int Lk,
+                      int q_rs, int k_rs, int v_rs)
+{
+    if (dtype != MDETR_F32 && dtype != MDETR_BF16) return fail(MDETR_E_ARG, "%s: dtype must be MDETR_F32 or MDETR_BF16", who);
+    if (B < 0 || H <= 0 || Lq < 0 || Lk < 0) return fail(MDETR_E_ARG, "%s: bad sizes B=%d H=%d Lq=%d Lk=%d", who, B, H, Lq, Lk);
+    if (B > 65535 || H > 65535) return fail(MDETR_E_ARG, "%s: B and H must be <= 65535 (grid limits)", who);
+    if (B && Lq && Lk && (!q || !k || !v)) return fail(MDETR_E_ARG, "%s: null pointer", who);
+    const int align = dtype == MDETR_F32 ? 4 : 8;      // 16-byte vector loads
+    if (q_rs % align || k_rs % align || v_rs % align) return fail(MDETR_E_ALIGN, "%s: row strides must keep 16-byte alignment", who);
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v)) return fail(MDETR_E_ALIGN, "%s: q/k/v must be 16-byte aligned", who);
+    return MDETR_OK;
+}
+
+int mdetr_attn_forward(int dtype, const void *q, const void *k, const void *v, const uint8_t *key_padding_mask,
+                       void *out, float *lse, int B, int H, int Lq, int Lk,
+                       int64_t q_bs, int64_t k_bs, int64_t v_bs, int q_rs, int k_rs, int v_rs,
+                       float scale, float dropout_p, uint64_t seed, int device, void *stream)
+{
+    if (int rc = attn_check("mdetr_attn_forward", dtype, q, k, v, B, H, Lq, Lk, q_rs, k_rs, v_rs)) return rc;
+    if (B == 0 || Lq == 0) return MDETR_OK;
+    if (!out || !lse || !aligned16(out)) return fail(MDETR_E_ARG, "mdetr_attn_forward: out / lse null or misaligned");
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(MDETR_E_ARG, "mdetr_attn_forward: dropout_p must be in [0, 1)");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_attn_forward: set device %d: %s", device, hipGetErrorString(dev.err));
+    mdetr::AttnProblem p{dtype, q, k, v, key_padding_mask, B, H, Lq, Lk, q_bs, k_bs, v_bs, q_rs, k_rs, v_rs, scale, dropout_p, seed};
+    const hipError_t e = mdetr::attn_forward_launch(p, out, lse, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_attn_forward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_attn_backward(int dtype, const void *q, const void *k, const void *v, const uint8_t *key_padding_mask,
+                        const void *out, const void *d_out, const float *lse, float *dsum,
+                        void *dq, void *dk, void *dv, int B, int H, int Lq, int Lk,
+                        int64_t q_bs, int64_t k_bs, int64_t v_bs, int q_rs, int k_rs, int v_rs,
+                        float scale, float dropout_p, uint64_t seed, int device, void *stream)
+{
+    if (int rc = attn_check("mdetr_attn_backward", dtype, q, k, v, B, H, Lq, Lk, q_rs, k_rs, v_rs)) return rc;
+    if (B == 0) return MDETR_OK;
+    if ((Lq && (!out || !d_out || !lse || !dsum || !dq)) || (Lk && (!dk || !dv)))
+        return fail(MDETR_E_ARG, "mdetr_attn_backward: null pointer");
+    if (!aligned16(out) || !aligned16(d_out) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv))
+        return fail(MDETR_E_ALIGN, "mdetr_attn_backward: tensors must be 16-byte aligned");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_attn_backward: set device %d: %s", device, hipGetErrorString(dev.err));
+    mdetr::AttnProblem p{dtype, q, k, v, key_padding_mask, B, H, Lq, Lk, q_bs, k_bs, v_bs, q_rs, k_rs, v_rs, scale, dropout_p, seed};
+    const hipError_t e = mdetr::attn_backward_launch(p, out, d_out, lse, dsum, dq, dk, dv, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_attn_backward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

@@ -333,7 +333,7 @@ __device__ __forceinline__ void scatter_sample(const Foot<float> &f, float a, co
 //        gather/reduce phase -- the vmcnt drain the compiler puts between atomics and the next
 //        use of a loaded value then happens once per round instead of once per sample.
 template <int TL, int TP, int VAR>
-__global__ __launch_bounds__(kWaves * 64)
+__global__ __launch_bounds__(kWaves * 64, (VAR == 2 ? 4 : 1))      // gather-only variant: keep <= 128 VGPRs (4 waves / SIMD)
 void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ shapes,
                   const int64_t *__restrict__ lstart, const float *__restrict__ loc,
                   const float *__restrict__ attn, const float *__restrict__ grad_out,
@@ -450,9 +450,10 @@ void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ s
         if (absmax2) {
             if (!(poison == 0.f)) amax_g = __builtin_inff();      // NaN / inf somewhere -> scatter takes the atomic path
             for (int o = 32; o > 0; o >>= 1) { amax_g = fmaxf(amax_g, __shfl_xor(amax_g, o)); amax_a = fmaxf(amax_a, __shfl_xor(amax_a, o)); }
-            if (lane == 0) {
-                atomicMax(absmax2, __builtin_bit_cast(unsigned, amax_g));
-                atomicMax(absmax2 + 1, __builtin_bit_cast(unsigned, amax_a));
+            if (lane == 0) {     // same-address atomics serialise in L2: only waves that raise the maximum issue one
+                const unsigned ug = __builtin_bit_cast(unsigned, amax_g), ua = __builtin_bit_cast(unsigned, amax_a);
+                if (ug > __hip_atomic_load(absmax2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(absmax2, ug);
+                if (ua > __hip_atomic_load(absmax2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(absmax2 + 1, ua);
             }
         }
     }
