@@ -18,7 +18,11 @@
 //     lane&31 -- is fed straight back as the B operand of the next product: the contraction index
 //     is then visited in a permuted ("virtual") order, and the A operand is read from a TRANSPOSED
 //     LDS copy with the same permutation (two 8-byte reads per lane), so no register shuffles.
-//   * inputs fp32 or bf16 (converted to bf16 while staging, fp32 accumulation), exp2-domain online
+//   * bf16 inputs: one bf16 MFMA per product step.  fp32 inputs: every operand x is split into
+//     bf16 hi + bf16 lo (lo = bf16(x - hi)) and each product is evaluated as hi*hi + hi*lo + lo*hi
+//     (three MFMAs, the dropped lo*lo term is ~2^-16 relative): fp32-level accuracy at 3/16 of the
+//     cost of the f32-input MFMA, which is what the fp32 model needs to stay within 1e-3 of the
+//     reference.  fp32 accumulation in both modes; exp2-domain online
 //     softmax with the scale folded into Q (or K), dropout on the probabilities from a stateless
 //     counter hash of (seed, b, h, q, k) so forward and backward regenerate the same mask.
 #include <hip/hip_runtime.h>
@@ -52,6 +56,25 @@ struct AttnArgs {
 __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c)
 {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+struct Frag { bf16x8 h, l; };       // operand fragment: hi part (+ lo part in split mode)
+
+template <bool SP>
+__device__ __forceinline__ f32x16 mfmaX(const Frag &a, const Frag &b, f32x16 c)
+{
+    c = mfma(a.h, b.h, c);
+    if (SP) { c = mfma(a.h, b.l, c); c = mfma(a.l, b.h, c); }
+    return c;
+}
+
+struct HiLo { __bf16 h, l; };
+__device__ __forceinline__ HiLo split_bf16(float x)
+{
+    HiLo r;
+    r.h = static_cast<__bf16>(x);
+    r.l = static_cast<__bf16>(x - static_cast<float>(r.h));
+    return r;
 }
 
 __device__ __forceinline__ f32x16 zero16()
@@ -101,9 +124,12 @@ template <> __device__ __forceinline__ void store4<__bf16>(__bf16 *p, float a, f
 }
 
 // Stage rows [r0, r0+64) x 32 of a [L, row_stride] matrix into LDS: row-major bf16 copy `rm`
-// ([64][kRowPad]) and/or transposed copy `tr` ([32][kTPad]); rows >= L are zero.  256 threads.
-template <typename T, bool RM, bool TR>
-__device__ __forceinline__ void stage_tile(const T *base, int row_stride, int r0, int L, __bf16 *rm, __bf16 *tr, float mul)
+// ([64][kRowPad]) and/or transposed copy `tr` ([32][kTPad]); rows >= L are zero.  In split mode the
+// lo parts go to rm + kRmSize / tr + kTrSize.  256 threads.
+constexpr int kRmSize = kTile * kRowPad, kTrSize = kD * kTPad;
+
+template <typename T, bool RM, bool TR, bool SP>
+__device__ __forceinline__ void stage_tile(const T *base, int row_stride, int r0, int L, __bf16 *rm, __bf16 *tr)
 {
     const int t = threadIdx.x, row = t >> 2, dc = (t & 3) * 8;
     float x[8];
@@ -112,45 +138,69 @@ __device__ __forceinline__ void stage_tile(const T *base, int row_stride, int r0
 #pragma unroll
         for (int i = 0; i < 8; ++i) x[i] = 0.f;
     }
-    bf16x8 v;
+    bf16x8 vh, vl;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = static_cast<__bf16>(x[i] * mul);
-    if (RM) *reinterpret_cast<bf16x8 *>(rm + row * kRowPad + dc) = v;
+    for (int i = 0; i < 8; ++i) { const HiLo s2 = split_bf16(x[i]); vh[i] = s2.h; vl[i] = s2.l; }
+    if (RM) {
+        *reinterpret_cast<bf16x8 *>(rm + row * kRowPad + dc) = vh;
+        if (SP) *reinterpret_cast<bf16x8 *>(rm + kRmSize + row * kRowPad + dc) = vl;
+    }
     if (TR) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) tr[(dc + i) * kTPad + row] = v[i];
+        for (int i = 0; i < 8; ++i) {
+            tr[(dc + i) * kTPad + row] = vh[i];
+            if (SP) tr[kTrSize + (dc + i) * kTPad + row] = vl[i];
+        }
     }
 }
 
 // A operand from a row-major tile: lane's row = sub*32 + (lane&31), 8 contiguous columns
-__device__ __forceinline__ bf16x8 frag_rows(const __bf16 *rm, int sub, int kstep, int lane)
+template <bool SP>
+__device__ __forceinline__ Frag frag_rows(const __bf16 *rm, int sub, int kstep, int lane)
 {
-    return *reinterpret_cast<const bf16x8 *>(rm + (sub * 32 + (lane & 31)) * kRowPad + kstep * 16 + (lane >> 5) * 8);
+    const int off = (sub * 32 + (lane & 31)) * kRowPad + kstep * 16 + (lane >> 5) * 8;
+    Frag f;
+    f.h = *reinterpret_cast<const bf16x8 *>(rm + off);
+    if (SP) f.l = *reinterpret_cast<const bf16x8 *>(rm + kRmSize + off);
+    return f;
 }
 
-// A operand from a transposed tile [d][rows]: lane's row = d = lane&31; contraction over the tile's
-// rows in the accumulator ("virtual") order: rows base+0..3 and base+8..11, base = sub*32+16*kstep+4*half
-__device__ __forceinline__ bf16x8 frag_cols(const __bf16 *tr, int sub, int kstep, int lane)
+__device__ __forceinline__ bf16x8 read_cols(const __bf16 *p)
 {
-    const __bf16 *p = tr + (lane & 31) * kTPad + sub * 32 + kstep * 16 + (lane >> 5) * 4;
     const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(p), hi = *reinterpret_cast<const bf16x4 *>(p + 8);
     bf16x8 v;
     v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
     return v;
 }
 
-// B operand from accumulator registers: elements 8*kstep .. 8*kstep+7
-__device__ __forceinline__ bf16x8 frag_acc(const float (&p)[16], int kstep)
+// A operand from a transposed tile [d][rows]: lane's row = d = lane&31; contraction over the tile's
+// rows in the accumulator ("virtual") order: rows base+0..3 and base+8..11, base = sub*32+16*kstep+4*half
+template <bool SP>
+__device__ __forceinline__ Frag frag_cols(const __bf16 *tr, int sub, int kstep, int lane)
 {
-    bf16x8 v;
+    const int off = (lane & 31) * kTPad + sub * 32 + kstep * 16 + (lane >> 5) * 4;
+    Frag f;
+    f.h = read_cols(tr + off);
+    if (SP) f.l = read_cols(tr + kTrSize + off);
+    return f;
+}
+
+// B operand from accumulator registers: elements 8*kstep .. 8*kstep+7
+template <bool SP>
+__device__ __forceinline__ Frag frag_acc(const float (&p)[16], int kstep)
+{
+    Frag f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = static_cast<__bf16>(p[8 * kstep + i]);
-    return v;
+    for (int i = 0; i < 8; ++i) {
+        if (SP) { const HiLo s2 = split_bf16(p[8 * kstep + i]); f.h[i] = s2.h; f.l[i] = s2.l; }
+        else f.h[i] = static_cast<__bf16>(p[8 * kstep + i]);
+    }
+    return f;
 }
 
 // B operand from global rows owned by lanes: row = own row (lane&31), columns 16*kstep + 8*half + 0..7
-template <typename T>
-__device__ __forceinline__ void own_row_frags(const T *rowp, bool valid, float mul, int lane, bf16x8 (&f)[2])
+template <typename T, bool SP>
+__device__ __forceinline__ void own_row_frags(const T *rowp, bool valid, float mul, int lane, Frag (&f)[2])
 {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -161,7 +211,10 @@ __device__ __forceinline__ void own_row_frags(const T *rowp, bool valid, float m
             for (int i = 0; i < 8; ++i) x[i] = 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) f[ks][i] = static_cast<__bf16>(x[i] * mul);
+        for (int i = 0; i < 8; ++i) {
+            if (SP) { const HiLo s2 = split_bf16(x[i] * mul); f[ks].h[i] = s2.h; f[ks].l[i] = s2.l; }
+            else f[ks].h[i] = static_cast<__bf16>(x[i] * mul);
+        }
     }
 }
 
@@ -172,8 +225,9 @@ template <typename T>
 __global__ __launch_bounds__(256)
 void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ lse2)
 {
-    __shared__ __attribute__((aligned(16))) __bf16 Ks[kTile * kRowPad];
-    __shared__ __attribute__((aligned(16))) __bf16 Vt[kD * kTPad];
+    constexpr bool SP = sizeof(T) == 4;                  // fp32 I/O: hi/lo split operands
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[(SP ? 2 : 1) * kRmSize];
+    __shared__ __attribute__((aligned(16))) __bf16 Vt[(SP ? 2 : 1) * kTrSize];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
@@ -182,8 +236,8 @@ void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ 
     const T *K = static_cast<const T *>(a.k) + b * a.k_bs + h * kD;
     const T *V = static_cast<const T *>(a.v) + b * a.v_bs + h * kD;
 
-    bf16x8 qf[2];
-    own_row_frags<T>(Q + static_cast<int64_t>(q) * a.q_rs, qv, a.scale * kLog2e, lane, qf);
+    Frag qf[2];
+    own_row_frags<T, SP>(Q + static_cast<int64_t>(q) * a.q_rs, qv, a.scale * kLog2e, lane, qf);
 
     const bool drop = a.dropout_p > 0.f;
     const unsigned thresh = drop ? static_cast<unsigned>(a.dropout_p * 4294967296.0) : 0u;
@@ -194,15 +248,15 @@ void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ 
 
     for (int k0 = 0; k0 < a.Lk; k0 += kTile) {
         __syncthreads();
-        stage_tile<T, true, false>(K, a.k_rs, k0, a.Lk, Ks, nullptr, 1.f);
-        stage_tile<T, false, true>(V, a.v_rs, k0, a.Lk, nullptr, Vt, 1.f);
+        stage_tile<T, true, false, SP>(K, a.k_rs, k0, a.Lk, Ks, nullptr);
+        stage_tile<T, false, true, SP>(V, a.v_rs, k0, a.Lk, nullptr, Vt);
         __syncthreads();
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             if (k0 + sub * 32 >= a.Lk) break;                    // block-uniform
             f32x16 s = zero16();
-            s = mfma(frag_rows(Ks, sub, 0, lane), qf[0], s);     // S^T[key][query]
-            s = mfma(frag_rows(Ks, sub, 1, lane), qf[1], s);
+            s = mfmaX<SP>(frag_rows<SP>(Ks, sub, 0, lane), qf[0], s);     // S^T[key][query]
+            s = mfmaX<SP>(frag_rows<SP>(Ks, sub, 1, lane), qf[1], s);
             float p[16];
             float mx = m;
 #pragma unroll
@@ -231,8 +285,8 @@ void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ 
             m = mx;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] *= alpha;
-            acc = mfma(frag_cols(Vt, sub, 0, lane), frag_acc(p, 0), acc);   // O^T[d][query]
-            acc = mfma(frag_cols(Vt, sub, 1, lane), frag_acc(p, 1), acc);
+            acc = mfmaX<SP>(frag_cols<SP>(Vt, sub, 0, lane), frag_acc<SP>(p, 0), acc);   // O^T[d][query]
+            acc = mfmaX<SP>(frag_cols<SP>(Vt, sub, 1, lane), frag_acc<SP>(p, 1), acc);
         }
     }
     l += __shfl_xor(l, 32);
@@ -281,9 +335,10 @@ __global__ __launch_bounds__(256)
 void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float *__restrict__ lse2,
                         const float *__restrict__ dsum, T *__restrict__ dq)
 {
-    __shared__ __attribute__((aligned(16))) __bf16 Ks[kTile * kRowPad];
-    __shared__ __attribute__((aligned(16))) __bf16 Vs[kTile * kRowPad];
-    __shared__ __attribute__((aligned(16))) __bf16 Kt[kD * kTPad];
+    constexpr bool SP = sizeof(T) == 4;
+    __shared__ __attribute__((aligned(16))) __bf16 Ks[(SP ? 2 : 1) * kRmSize];
+    __shared__ __attribute__((aligned(16))) __bf16 Vs[(SP ? 2 : 1) * kRmSize];
+    __shared__ __attribute__((aligned(16))) __bf16 Kt[(SP ? 2 : 1) * kTrSize];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
@@ -293,9 +348,9 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
     const T *V = static_cast<const T *>(a.v) + b * a.v_bs + h * kD;
     const int64_t orow = (static_cast<int64_t>(b) * a.Lq + q) * (a.H * kD) + h * kD;
 
-    bf16x8 qf[2], dof[2];
-    own_row_frags<T>(Q + static_cast<int64_t>(q) * a.q_rs, qv, a.scale * kLog2e, lane, qf);
-    own_row_frags<T>(d_o + orow, qv, 1.f, lane, dof);
+    Frag qf[2], dof[2];
+    own_row_frags<T, SP>(Q + static_cast<int64_t>(q) * a.q_rs, qv, a.scale * kLog2e, lane, qf);
+    own_row_frags<T, SP>(d_o + orow, qv, 1.f, lane, dof);
     const int64_t stat = (static_cast<int64_t>(b) * a.H + h) * a.Lq + q;
     const float L2 = qv ? lse2[stat] : 0.f, Dq = qv ? dsum[stat] : 0.f;
 
@@ -306,17 +361,17 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
 
     for (int k0 = 0; k0 < a.Lk; k0 += kTile) {
         __syncthreads();
-        stage_tile<T, true, true>(K, a.k_rs, k0, a.Lk, Ks, Kt, 1.f);
-        stage_tile<T, true, false>(V, a.v_rs, k0, a.Lk, Vs, nullptr, 1.f);
+        stage_tile<T, true, true, SP>(K, a.k_rs, k0, a.Lk, Ks, Kt);
+        stage_tile<T, true, false, SP>(V, a.v_rs, k0, a.Lk, Vs, nullptr);
         __syncthreads();
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             if (k0 + sub * 32 >= a.Lk) break;
             f32x16 s = zero16(), dp = zero16();
-            s = mfma(frag_rows(Ks, sub, 0, lane), qf[0], s);
-            s = mfma(frag_rows(Ks, sub, 1, lane), qf[1], s);
-            dp = mfma(frag_rows(Vs, sub, 0, lane), dof[0], dp);  // dP^T[key][query] = V dO^T
-            dp = mfma(frag_rows(Vs, sub, 1, lane), dof[1], dp);
+            s = mfmaX<SP>(frag_rows<SP>(Ks, sub, 0, lane), qf[0], s);
+            s = mfmaX<SP>(frag_rows<SP>(Ks, sub, 1, lane), qf[1], s);
+            dp = mfmaX<SP>(frag_rows<SP>(Vs, sub, 0, lane), dof[0], dp);  // dP^T[key][query] = V dO^T
+            dp = mfmaX<SP>(frag_rows<SP>(Vs, sub, 1, lane), dof[1], dp);
             float ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -328,8 +383,8 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
                 if (drop) g = keep_elem(a.seed, b, h, q, key, thresh) ? g * rinv : 0.f;
                 ds[r] = p * (g - Dq);
             }
-            acc = mfma(frag_cols(Kt, sub, 0, lane), frag_acc(ds, 0), acc);   // dQ^T[d][query]
-            acc = mfma(frag_cols(Kt, sub, 1, lane), frag_acc(ds, 1), acc);
+            acc = mfmaX<SP>(frag_cols<SP>(Kt, sub, 0, lane), frag_acc<SP>(ds, 0), acc);   // dQ^T[d][query]
+            acc = mfmaX<SP>(frag_cols<SP>(Kt, sub, 1, lane), frag_acc<SP>(ds, 1), acc);
         }
     }
     if (qv) {
@@ -348,10 +403,11 @@ __global__ __launch_bounds__(256)
 void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const float *__restrict__ lse2,
                          const float *__restrict__ dsum, T *__restrict__ dk, T *__restrict__ dv)
 {
-    __shared__ __attribute__((aligned(16))) __bf16 Qs[kTile * kRowPad];
-    __shared__ __attribute__((aligned(16))) __bf16 Os[kTile * kRowPad];
-    __shared__ __attribute__((aligned(16))) __bf16 Qt[kD * kTPad];
-    __shared__ __attribute__((aligned(16))) __bf16 Ot[kD * kTPad];
+    constexpr bool SP = sizeof(T) == 4;
+    __shared__ __attribute__((aligned(16))) __bf16 Qs[(SP ? 2 : 1) * kRmSize];
+    __shared__ __attribute__((aligned(16))) __bf16 Os[(SP ? 2 : 1) * kRmSize];
+    __shared__ __attribute__((aligned(16))) __bf16 Qt[(SP ? 2 : 1) * kTrSize];
+    __shared__ __attribute__((aligned(16))) __bf16 Ot[(SP ? 2 : 1) * kTrSize];
     __shared__ __attribute__((aligned(16))) float Ls[kTile];
     __shared__ __attribute__((aligned(16))) float Ds[kTile];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
@@ -365,9 +421,9 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
     const float *L2b = lse2 + (static_cast<int64_t>(b) * a.H + h) * a.Lq;
     const float *Db = dsum + (static_cast<int64_t>(b) * a.H + h) * a.Lq;
 
-    bf16x8 kf[2], vf[2];
-    own_row_frags<T>(K + static_cast<int64_t>(key) * a.k_rs, kv, a.scale * kLog2e, lane, kf);
-    own_row_frags<T>(V + static_cast<int64_t>(key) * a.v_rs, kv, 1.f, lane, vf);
+    Frag kf[2], vf[2];
+    own_row_frags<T, SP>(K + static_cast<int64_t>(key) * a.k_rs, kv, a.scale * kLog2e, lane, kf);
+    own_row_frags<T, SP>(V + static_cast<int64_t>(key) * a.v_rs, kv, 1.f, lane, vf);
     bool key_ok = kv;
     if (a.kpm && kv) key_ok = a.kpm[static_cast<int64_t>(b) * a.Lk + key] == 0;
 
@@ -378,8 +434,8 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
 
     for (int q0 = 0; q0 < a.Lq; q0 += kTile) {
         __syncthreads();
-        stage_tile<T, true, true>(Q, a.q_rs, q0, a.Lq, Qs, Qt, 1.f);
-        stage_tile<T, true, true>(dO, a.H * kD, q0, a.Lq, Os, Ot, 1.f);
+        stage_tile<T, true, true, SP>(Q, a.q_rs, q0, a.Lq, Qs, Qt);
+        stage_tile<T, true, true, SP>(dO, a.H * kD, q0, a.Lq, Os, Ot);
         if (threadIdx.x < kTile) {
             const int qq = q0 + threadIdx.x;
             Ls[threadIdx.x] = qq < a.Lq ? L2b[qq] : -__builtin_inff();
@@ -390,10 +446,10 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
         for (int sub = 0; sub < 2; ++sub) {
             if (q0 + sub * 32 >= a.Lq) break;
             f32x16 s = zero16(), dp = zero16();
-            s = mfma(frag_rows(Qs, sub, 0, lane), kf[0], s);     // S[query][key]
-            s = mfma(frag_rows(Qs, sub, 1, lane), kf[1], s);
-            dp = mfma(frag_rows(Os, sub, 0, lane), vf[0], dp);   // dP[query][key] = dO V^T
-            dp = mfma(frag_rows(Os, sub, 1, lane), vf[1], dp);
+            s = mfmaX<SP>(frag_rows<SP>(Qs, sub, 0, lane), kf[0], s);     // S[query][key]
+            s = mfmaX<SP>(frag_rows<SP>(Qs, sub, 1, lane), kf[1], s);
+            dp = mfmaX<SP>(frag_rows<SP>(Os, sub, 0, lane), vf[0], dp);   // dP[query][key] = dO V^T
+            dp = mfmaX<SP>(frag_rows<SP>(Os, sub, 1, lane), vf[1], dp);
             float pd[16], ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -410,10 +466,10 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
                 pd[r] = pk;
                 ds[r] = p * (g - Ds[qi]);
             }
-            accv = mfma(frag_cols(Ot, sub, 0, lane), frag_acc(pd, 0), accv);   // dV^T[d][key] = dO^T P
-            accv = mfma(frag_cols(Ot, sub, 1, lane), frag_acc(pd, 1), accv);
-            acck = mfma(frag_cols(Qt, sub, 0, lane), frag_acc(ds, 0), acck);   // dK^T[d][key] = Q^T dS
-            acck = mfma(frag_cols(Qt, sub, 1, lane), frag_acc(ds, 1), acck);
+            accv = mfmaX<SP>(frag_cols<SP>(Ot, sub, 0, lane), frag_acc<SP>(pd, 0), accv);   // dV^T[d][key] = dO^T P
+            accv = mfmaX<SP>(frag_cols<SP>(Ot, sub, 1, lane), frag_acc<SP>(pd, 1), accv);
+            acck = mfmaX<SP>(frag_cols<SP>(Qt, sub, 0, lane), frag_acc<SP>(ds, 0), acck);   // dK^T[d][key] = Q^T dS
+            acck = mfmaX<SP>(frag_cols<SP>(Qt, sub, 1, lane), frag_acc<SP>(ds, 1), acck);
         }
     }
     if (kv) {

@@ -12,27 +12,47 @@ never builds the averaged weights: the QK^T -> softmax -> dropout -> PV core run
 ``attention_core`` is the single entry point of that core (batch-first), so the backend is chosen
 in one place.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ..attn_ext import fused_attention
 
-def attention_core(q, k, v, num_heads, dropout_p=0.0, key_padding_mask=None):
-    """softmax(q k^T / sqrt(d) + mask) v per head.
-    q [B, Lq, E]; k, v [B, Lk, E]; key_padding_mask [B, Lk] bool (True = ignore) or None.
-    Returns [B, Lq, E].  Dropout (if dropout_p > 0) acts on the attention probabilities, as in
-    nn.MultiheadAttention."""
+
+def _sdpa(q, k, v, num_heads, dropout_p, key_padding_mask):
+    """PyTorch evaluation of the same function (CPU tensors; comparator on the GPU)."""
     B, Lq, E = q.shape
     Lk = k.shape[1]
     d = E // num_heads
-    qh = q.view(B, Lq, num_heads, d).transpose(1, 2)
-    kh = k.view(B, Lk, num_heads, d).transpose(1, 2)
-    vh = v.view(B, Lk, num_heads, d).transpose(1, 2)
+    qh = q.reshape(B, Lq, num_heads, d).transpose(1, 2)
+    kh = k.reshape(B, Lk, num_heads, d).transpose(1, 2)
+    vh = v.reshape(B, Lk, num_heads, d).transpose(1, 2)
     mask = None
     if key_padding_mask is not None:
         mask = ~key_padding_mask.view(B, 1, 1, Lk)          # True = attend
     out = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=mask, dropout_p=dropout_p)
     return out.transpose(1, 2).reshape(B, Lq, E)
+
+
+def attention_core(q, k, v, num_heads, dropout_p=0.0, key_padding_mask=None):
+    """softmax(q k^T / sqrt(d) + mask) v per head.
+    q [B, Lq, E]; k, v [B, Lk, E] (last dim contiguous; slices of a packed projection are fine);
+    key_padding_mask [B, Lk] bool (True = ignore) or None.  Returns [B, Lq, E].  Dropout (if
+    dropout_p > 0) acts on the attention probabilities, as in nn.MultiheadAttention.
+
+    GPU tensors with 32 channels per head (the model's geometry) run the gfx950 MFMA kernels of
+    monodetr_amd/csrc/attn.hip -- no fallback: a missing library raises.  CPU tensors (the
+    reference is plain PyTorch there too) and other head sizes use PyTorch's SDPA;
+    MDETR_ATTN_BACKEND=sdpa forces the comparator on the GPU for A/B measurements."""
+    if q.is_cuda and q.shape[-1] == 32 * num_heads and os.environ.get("MDETR_ATTN_BACKEND", "hip") == "hip":
+        if q.dtype not in (torch.float32, torch.bfloat16):
+            q, k, v = q.float(), k.float(), v.float()
+        if k.dtype != q.dtype or v.dtype != q.dtype:
+            k, v = k.to(q.dtype), v.to(q.dtype)
+        return fused_attention(q, k, v, num_heads, dropout_p, key_padding_mask)
+    return _sdpa(q, k, v, num_heads, dropout_p, key_padding_mask)
 
 
 class MultiheadAttention(nn.Module):

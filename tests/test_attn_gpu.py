@@ -59,12 +59,13 @@ def test_forward_backward_vs_fp64(B, H, Lq, Lk, dtype):
     ref = reference(qd, kd, vd, H)
     ref.backward(go.double())
     assert out.dtype == dtype and out.shape == (B, Lq, E)
-    tol = 2e-2
+    # fp32 I/O uses hi/lo split operands (near-fp32 products); bf16 I/O is bf16-level
+    tol, gtol, ftol = (2e-4, 5e-4, 1e-4) if dtype == torch.float32 else (2e-2, 3e-2, 1e-2)
     assert (out.double() - ref).abs().max() < tol * max(1.0, ref.abs().max().item())
     for g, r, name in ((q.grad, qd.grad, "dq"), (k.grad, kd.grad, "dk"), (v.grad, vd.grad, "dv")):
-        assert (g.double() - r).abs().max() < 3e-2 * max(1.0, r.abs().max().item()), name
+        assert (g.double() - r).abs().max() < gtol * max(1.0, r.abs().max().item()), name
         if r.norm() > 1e-3:       # (degenerate single-key problems have exactly zero dq / dk)
-            assert ((g.double() - r).norm() / r.norm()) < 1e-2, name      # relative Frobenius error
+            assert ((g.double() - r).norm() / r.norm()) < ftol, name      # relative Frobenius error
 
 
 def test_strided_inputs_from_packed_projection():
