@@ -77,6 +77,10 @@ __device__ __forceinline__ HiLo split_bf16(float x)
     return r;
 }
 
+// raw v_exp_f32 (exp2f() adds denormal-range fix-ups that cost ~5 extra instructions per element;
+// probabilities below 2^-126 may flush to zero here, which is immaterial for a softmax)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ f32x16 zero16()
 {
     f32x16 z;
@@ -128,16 +132,47 @@ template <> __device__ __forceinline__ void store4<__bf16>(__bf16 *p, float a, f
 // lo parts go to rm + kRmSize / tr + kTrSize.  256 threads.
 constexpr int kRmSize = kTile * kRowPad, kTrSize = kD * kTPad;
 
+// 8 consecutive elements exactly as loaded (conversion is deferred to the LDS store so that the
+// global load of the NEXT tile stays in flight across the compute on the current one)
+template <typename T> struct Raw8;
+template <> struct Raw8<float> { float4 a, b; };
+template <> struct Raw8<__bf16> { bf16x8 v; };
+
+__device__ __forceinline__ void raw_zero(Raw8<float> &r) { r.a = make_float4(0.f, 0.f, 0.f, 0.f); r.b = r.a; }
+__device__ __forceinline__ void raw_zero(Raw8<__bf16> &r)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = static_cast<__bf16>(0.f);
+}
+__device__ __forceinline__ void raw_load(Raw8<float> &r, const float *p) { r.a = *reinterpret_cast<const float4 *>(p); r.b = *reinterpret_cast<const float4 *>(p + 4); }
+__device__ __forceinline__ void raw_load(Raw8<__bf16> &r, const __bf16 *p) { r.v = *reinterpret_cast<const bf16x8 *>(p); }
+__device__ __forceinline__ void raw_floats(const Raw8<float> &r, float (&o)[8])
+{
+    o[0] = r.a.x; o[1] = r.a.y; o[2] = r.a.z; o[3] = r.a.w; o[4] = r.b.x; o[5] = r.b.y; o[6] = r.b.z; o[7] = r.b.w;
+}
+__device__ __forceinline__ void raw_floats(const Raw8<__bf16> &r, float (&o)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = static_cast<float>(r.v[i]);
+}
+
+// this thread's 8 elements of tile rows [r0, r0+64): row = tid/4, columns (tid%4)*8 ..
+template <typename T>
+__device__ __forceinline__ Raw8<T> tile_load(const T *base, int row_stride, int r0, int L)
+{
+    const int row = threadIdx.x >> 2, dc = (threadIdx.x & 3) * 8;
+    Raw8<T> r;
+    if (r0 + row < L) raw_load(r, base + static_cast<int64_t>(r0 + row) * row_stride + dc);
+    else raw_zero(r);
+    return r;
+}
+
 template <typename T, bool RM, bool TR, bool SP>
-__device__ __forceinline__ void stage_tile(const T *base, int row_stride, int r0, int L, __bf16 *rm, __bf16 *tr)
+__device__ __forceinline__ void tile_store(const Raw8<T> &raw, __bf16 *rm, __bf16 *tr)
 {
     const int t = threadIdx.x, row = t >> 2, dc = (t & 3) * 8;
     float x[8];
-    if (r0 + row < L) load8<T>(base + static_cast<int64_t>(r0 + row) * row_stride + dc, x);
-    else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = 0.f;
-    }
+    raw_floats(raw, x);
     bf16x8 vh, vl;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { const HiLo s2 = split_bf16(x[i]); vh[i] = s2.h; vl[i] = s2.l; }
@@ -246,11 +281,16 @@ void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ 
     float m = -__builtin_inff(), l = 0.f;
     f32x16 acc = zero16();
 
+    Raw8<T> rk = tile_load<T>(K, a.k_rs, 0, a.Lk), rv = tile_load<T>(V, a.v_rs, 0, a.Lk);
     for (int k0 = 0; k0 < a.Lk; k0 += kTile) {
+        __syncthreads();                                         // everyone is done reading the previous tile
+        tile_store<T, true, false, SP>(rk, Ks, nullptr);
+        tile_store<T, false, true, SP>(rv, nullptr, Vt);
         __syncthreads();
-        stage_tile<T, true, false, SP>(K, a.k_rs, k0, a.Lk, Ks, nullptr);
-        stage_tile<T, false, true, SP>(V, a.v_rs, k0, a.Lk, nullptr, Vt);
-        __syncthreads();
+        if (k0 + kTile < a.Lk) {                                 // next tile's loads fly during this tile's math
+            rk = tile_load<T>(K, a.k_rs, k0 + kTile, a.Lk);
+            rv = tile_load<T>(V, a.v_rs, k0 + kTile, a.Lk);
+        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             if (k0 + sub * 32 >= a.Lk) break;                    // block-uniform
@@ -269,11 +309,11 @@ void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ 
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float msafe = mx == -__builtin_inff() ? 0.f : mx;
-            const float alpha = exp2f(m - msafe);               // m = -inf -> 0
+            const float alpha = fast_exp2(m - msafe);               // m = -inf -> 0
             float psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(p[r] - msafe);
+                const float e = fast_exp2(p[r] - msafe);
                 psum += e;
                 p[r] = e;
                 if (drop) {
@@ -359,11 +399,16 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
     const float rinv = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
     f32x16 acc = zero16();
 
+    Raw8<T> rk = tile_load<T>(K, a.k_rs, 0, a.Lk), rv = tile_load<T>(V, a.v_rs, 0, a.Lk);
     for (int k0 = 0; k0 < a.Lk; k0 += kTile) {
         __syncthreads();
-        stage_tile<T, true, true, SP>(K, a.k_rs, k0, a.Lk, Ks, Kt);
-        stage_tile<T, true, false, SP>(V, a.v_rs, k0, a.Lk, Vs, nullptr);
+        tile_store<T, true, true, SP>(rk, Ks, Kt);
+        tile_store<T, true, false, SP>(rv, Vs, nullptr);
         __syncthreads();
+        if (k0 + kTile < a.Lk) {
+            rk = tile_load<T>(K, a.k_rs, k0 + kTile, a.Lk);
+            rv = tile_load<T>(V, a.v_rs, k0 + kTile, a.Lk);
+        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             if (k0 + sub * 32 >= a.Lk) break;
@@ -378,7 +423,7 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
                 const int key = k0 + sub * 32 + acc_row(r, half);
                 bool ok = key < a.Lk && L2 != -__builtin_inff();
                 if (a.kpm) ok = ok && (a.kpm[static_cast<int64_t>(b) * a.Lk + (key < a.Lk ? key : 0)] == 0);
-                const float p = ok ? exp2f(s[r] - L2) : 0.f;
+                const float p = ok ? fast_exp2(s[r] - L2) : 0.f;
                 float g = dp[r];
                 if (drop) g = keep_elem(a.seed, b, h, q, key, thresh) ? g * rinv : 0.f;
                 ds[r] = p * (g - Dq);
@@ -432,16 +477,24 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
     const float rinv = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
     f32x16 acck = zero16(), accv = zero16();
 
+    Raw8<T> rq = tile_load<T>(Q, a.q_rs, 0, a.Lq), ro = tile_load<T>(dO, a.H * kD, 0, a.Lq);
+    float rl = -__builtin_inff(), rd = 0.f;
+    if (threadIdx.x < kTile && threadIdx.x < a.Lq) { rl = L2b[threadIdx.x]; rd = Db[threadIdx.x]; }
     for (int q0 = 0; q0 < a.Lq; q0 += kTile) {
         __syncthreads();
-        stage_tile<T, true, true, SP>(Q, a.q_rs, q0, a.Lq, Qs, Qt);
-        stage_tile<T, true, true, SP>(dO, a.H * kD, q0, a.Lq, Os, Ot);
-        if (threadIdx.x < kTile) {
-            const int qq = q0 + threadIdx.x;
-            Ls[threadIdx.x] = qq < a.Lq ? L2b[qq] : -__builtin_inff();
-            Ds[threadIdx.x] = qq < a.Lq ? Db[qq] : 0.f;
-        }
+        tile_store<T, true, true, SP>(rq, Qs, Qt);
+        tile_store<T, true, true, SP>(ro, Os, Ot);
+        if (threadIdx.x < kTile) { Ls[threadIdx.x] = rl; Ds[threadIdx.x] = rd; }
         __syncthreads();
+        if (q0 + kTile < a.Lq) {
+            rq = tile_load<T>(Q, a.q_rs, q0 + kTile, a.Lq);
+            ro = tile_load<T>(dO, a.H * kD, q0 + kTile, a.Lq);
+            if (threadIdx.x < kTile) {
+                const int qq = q0 + kTile + threadIdx.x;
+                rl = qq < a.Lq ? L2b[qq] : -__builtin_inff();
+                rd = qq < a.Lq ? Db[qq] : 0.f;
+            }
+        }
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             if (q0 + sub * 32 >= a.Lq) break;
@@ -456,7 +509,7 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
                 const int qi = sub * 32 + acc_row(r, half), qq = q0 + qi;
                 const float L2 = Ls[qi];
                 const bool ok = key_ok && L2 != -__builtin_inff();
-                const float p = ok ? exp2f(s[r] - L2) : 0.f;
+                const float p = ok ? fast_exp2(s[r] - L2) : 0.f;
                 float g = dp[r], pk = p;
                 if (drop) {
                     const bool kp = keep_elem(a.seed, b, h, qq, key, thresh);
