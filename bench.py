@@ -84,6 +84,9 @@ class TrainStep:
         self.model.to(device)
         if device.type == "cuda":
             self.model.to(memory_format=torch.channels_last)
+        if precision == "bf16":
+            from monodetr_amd.helpers.precision import to_bf16_body
+            to_bf16_body(self.model)
         self.model.train()
         self.criterion.train()
         self.raw_model = self.model
@@ -100,11 +103,13 @@ class TrainStep:
         self.inputs = synthetic_batch(batch, H, W, seed + 1000 * (local_rank + 1), device)
         if device.type == "cuda":
             self.inputs = (self.inputs[0].contiguous(memory_format=torch.channels_last),) + self.inputs[1:]
+        if precision == "bf16":
+            self.inputs = (self.inputs[0].to(torch.bfloat16),) + self.inputs[1:]
 
     def __call__(self):
         images, calibs, img_sizes, targets = self.inputs
         self.optimizer.zero_grad(set_to_none=True)
-        with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.precision == "bf16"):
+        with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.precision == "bf16-autocast"):
             out = self.model(images, calibs, targets, img_sizes, dn_args=None)
             losses = self.criterion(out, targets, None)
         w = self.criterion.weight_dict
@@ -149,7 +154,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
-    ap.add_argument("--precision", default=os.environ.get("MDETR_BENCH_PRECISION", "fp32"), choices=["fp32", "bf16"])
+    ap.add_argument("--precision", default=os.environ.get("MDETR_BENCH_PRECISION", "fp32"), choices=["fp32", "bf16", "bf16-autocast"],
+                    help="bf16 = bf16 model body + fp32 heads + fp32 master weights (helpers/precision.py); "
+                         "bf16-autocast = fp32 parameters under torch.autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=1)
     args = ap.parse_args()

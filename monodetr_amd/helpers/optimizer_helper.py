@@ -12,7 +12,8 @@ gradient are skipped (:79-80).
 What changes is how it runs: the reference loops over a few hundred tensors in Python with ~8 tiny
 kernels each (and deprecated ``add_(Number, Tensor)`` overloads, :111-112,129).  Here every update
 is a handful of multi-tensor ``torch._foreach_*`` launches per parameter group, with the scalar
-step size computed on the host (no device sync).
+step size computed on the host (no device sync).  bf16 parameters (helpers/precision.py) are
+updated through fp32 master copies kept in the optimizer state and rounded back after the step.
 """
 import math
 
@@ -73,16 +74,28 @@ class AdamW(Optimizer):
                 st = self.state[p]
                 if len(st) == 0:
                     st['step'] = 0
-                    st['exp_avg'] = torch.zeros_like(p)
-                    st['exp_avg_sq'] = torch.zeros_like(p)
+                    wide = p.dtype if p.dtype in (torch.float32, torch.float64) else torch.float32
+                    st['exp_avg'] = torch.zeros_like(p, dtype=wide)
+                    st['exp_avg_sq'] = torch.zeros_like(p, dtype=wide)
                     if group['amsgrad']:
-                        st['max_exp_avg_sq'] = torch.zeros_like(p)
+                        st['max_exp_avg_sq'] = torch.zeros_like(p, dtype=wide)
+                    if wide != p.dtype:                   # bf16 / fp16 parameter: fp32 master + staging for the gradient
+                        st['master'] = p.detach().to(wide)
+                        st['grad32'] = torch.zeros_like(p, dtype=wide)
                 st['step'] += 1
                 buckets.setdefault(st['step'], []).append(p)
-            for t, ps in buckets.items():
-                grads = [p.grad for p in ps]
-                m = [self.state[p]['exp_avg'] for p in ps]
-                v = [self.state[p]['exp_avg_sq'] for p in ps]
+            for t, ps_model in buckets.items():
+                # bf16 parameters are updated through their fp32 master copies
+                low = [p for p in ps_model if p.dtype != torch.float32 and p.dtype != torch.float64]
+                ps = [self.state[p]['master'] if p.dtype not in (torch.float32, torch.float64) else p for p in ps_model]
+                grads = [p.grad for p in ps_model]
+                if low:
+                    g32 = [self.state[p]['grad32'] for p in low]
+                    torch._foreach_copy_(g32, [p.grad for p in low])
+                    it = iter(g32)
+                    grads = [next(it) if p.dtype not in (torch.float32, torch.float64) else p.grad for p in ps_model]
+                m = [self.state[p]['exp_avg'] for p in ps_model]
+                v = [self.state[p]['exp_avg_sq'] for p in ps_model]
                 torch._foreach_mul_(m, beta1)
                 torch._foreach_add_(m, grads, alpha=1 - beta1)
                 torch._foreach_mul_(v, beta2)
@@ -99,4 +112,6 @@ class AdamW(Optimizer):
                 if group['weight_decay'] != 0:
                     torch._foreach_add_(upd, ps, alpha=group['weight_decay'])
                 torch._foreach_add_(ps, upd, alpha=-step)
+                if low:
+                    torch._foreach_copy_(low, [self.state[p]['master'] for p in low])
         return loss

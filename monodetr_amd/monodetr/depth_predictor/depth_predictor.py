@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ...utils.misc import no_padding
+from ...utils.misc import at_least_fp32, no_padding
 from .transformer import TransformerEncoder, TransformerEncoderLayer
 
 
@@ -49,13 +49,13 @@ class DepthPredictor(nn.Module):
         src = self.depth_head((s8 + s16 + s32) / 3)
 
         depth_logits = self.depth_classifier(src)
-        weighted_depth = (F.softmax(depth_logits, dim=1) * self.depth_bin_values.reshape(1, -1, 1, 1)).sum(dim=1)
+        weighted_depth = (F.softmax(at_least_fp32(depth_logits), dim=1) * at_least_fp32(self.depth_bin_values).reshape(1, -1, 1, 1)).sum(dim=1)
 
         B, C, H, W = src.shape
         tokens = src.flatten(2).permute(2, 0, 1)
         key_mask = None if no_padding(mask) else mask.flatten(1)
-        enc = self.depth_encoder(tokens, key_mask, pos.flatten(2).permute(2, 0, 1))
-        depth_pos_embed_ip = self.interpolate_depth_embed(weighted_depth)
+        enc = self.depth_encoder(tokens, key_mask, pos.flatten(2).permute(2, 0, 1).to(tokens.dtype))
+        depth_pos_embed_ip = self.interpolate_depth_embed(weighted_depth).to(src.dtype)
         depth_embed = enc.permute(1, 2, 0).reshape(B, C, H, W) + depth_pos_embed_ip
         return depth_logits, depth_embed, weighted_depth, depth_pos_embed_ip
 

@@ -39,6 +39,7 @@ class MLP(nn.Module):
         self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
 
     def forward(self, x):
+        x = x.to(self.layers[0].weight.dtype)       # fp32 heads may sit behind a bf16 body
         for layer in self.layers[:-1]:
             x = F.relu(layer(x))
         return self.layers[-1](x)
@@ -323,7 +324,7 @@ class DepthAwareTransformer(nn.Module):
         # flatten every level to [B, HW, C] and concatenate along the token axis
         src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
         lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1)
-                             for l, p in enumerate(pos_embeds)], 1)
+                             for l, p in enumerate(pos_embeds)], 1).to(src_flatten.dtype)
         spatial_shapes, level_start_index = self._level_tensors(shapes, src_flatten.device)
         if unpadded:
             mask_flatten = valid_ratios = mask_depth = None
@@ -337,9 +338,10 @@ class DepthAwareTransformer(nn.Module):
 
         # queries: first half of the embedding is the positional part, second half the content
         query_pos, tgt = torch.split(query_embed, C, dim=1)
-        reference_points = self.reference_points(query_pos).sigmoid().unsqueeze(0).expand(B, -1, -1)
-        query_pos = query_pos.unsqueeze(0).expand(B, -1, -1)
-        tgt = tgt.unsqueeze(0).expand(B, -1, -1)
+        reference_points = self.reference_points(query_pos.to(self.reference_points.weight.dtype)).sigmoid()
+        reference_points = reference_points.unsqueeze(0).expand(B, -1, -1)
+        query_pos = query_pos.to(memory.dtype).unsqueeze(0).expand(B, -1, -1)
+        tgt = tgt.to(memory.dtype).unsqueeze(0).expand(B, -1, -1)
         init_reference_out = reference_points
 
         depth_tokens = depth_pos_embed.flatten(2).permute(2, 0, 1)

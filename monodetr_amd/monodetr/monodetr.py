@@ -136,11 +136,15 @@ class MonoDETR(nn.Module):
         hs, init_reference, inter_references, inter_references_dim, _, _ = self.depthaware_transformer(
             srcs, masks, pos, query_embeds, depth_pos_embed, depth_pos_embed_ip)
 
+        coords, classes, dims3d, depths, angles = [], [], [], [], []
+        head_dtype = self.class_embed[0].weight.dtype          # heads stay fp32 even behind a bf16 body
+        hs = hs.to(head_dtype)
+        weighted_depth = weighted_depth.to(head_dtype)
+        calibs, img_sizes = calibs.to(head_dtype), img_sizes.to(head_dtype)
         focal = calibs[:, 0, 0].unsqueeze(1)
         img_h = img_sizes[:, 1:2]
-        coords, classes, dims3d, depths, angles = [], [], [], [], []
         for lvl in range(hs.shape[0]):
-            reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
+            reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1]).to(head_dtype)
             box = self.bbox_embed[lvl](hs[lvl])
             if reference.shape[-1] == 6:
                 box = box + reference
@@ -148,7 +152,7 @@ class MonoDETR(nn.Module):
                 assert reference.shape[-1] == 2
                 box = torch.cat((box[..., :2] + reference, box[..., 2:]), -1)
             coord = box.sigmoid()                                  # (cx, cy, l, r, t, b) of the 3D centre / 2D box
-            size3d = inter_references_dim[lvl]
+            size3d = inter_references_dim[lvl].to(head_dtype)
             # depth from geometry: f * H3d / h2d  (:240-242)
             h2d = torch.clamp((coord[:, :, 4] + coord[:, :, 5]) * img_h, min=1.0)
             depth_geo = size3d[:, :, 0] / h2d * focal
@@ -307,8 +311,10 @@ class SetCriterion(nn.Module):
     def forward(self, outputs, targets, mask_dict=None):
         """outputs: the model's dict; targets: list (one per image) of dicts with 'labels', 'boxes',
         'boxes_3d', 'depth', 'size_3d', 'heading_bin', 'heading_res'.  Returns {name: 0-d tensor}."""
-        final = {k: v for k, v in outputs.items() if k != 'aux_outputs'}
-        layers = [final] + list(outputs.get('aux_outputs', []))
+        def widen(d):
+            return {k: (v.float() if torch.is_tensor(v) and v.dtype in (torch.bfloat16, torch.float16) else v) for k, v in d.items()}
+        final = widen({k: v for k, v in outputs.items() if k != 'aux_outputs'})
+        layers = [final] + [widen(a) for a in outputs.get('aux_outputs', [])]
         group_num = self.group_num if self.training else 1
         all_indices = self.matcher.match_layers(layers, targets, group_num=group_num)
 

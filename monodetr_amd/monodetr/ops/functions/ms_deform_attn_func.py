@@ -18,25 +18,35 @@ from torch.autograd.function import once_differentiable
 from .... import msda_ext as MSDA
 
 
+_LOW = (torch.bfloat16, torch.float16)
+
+
 class MSDeformAttnFunction(Function):
-    # under autocast the projections feeding this op are bf16; the op itself computes in fp32
-    # (the reference's extension is fp32/fp64 only, ms_deform_attn_cuda.cu:64, and would raise)
+    # The operator computes in fp32 (the reference's extension is fp32/fp64 only,
+    # ms_deform_attn_cuda.cu:64, and would raise on anything else).  bf16 / fp16 inputs -- under
+    # autocast or in a bf16 model -- are widened on the way in; the output and the gradients come
+    # back in the dtypes of the corresponding inputs.
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
                 attention_weights, im2col_step):
         ctx.im2col_step = im2col_step
+        ctx.in_dtypes = (value.dtype, sampling_locations.dtype, attention_weights.dtype)
+        if value.dtype in _LOW or sampling_locations.dtype in _LOW or attention_weights.dtype in _LOW:
+            value, sampling_locations, attention_weights = value.float(), sampling_locations.float(), attention_weights.float()
+        elif not (value.dtype == sampling_locations.dtype == attention_weights.dtype):
+            wide = torch.promote_types(torch.promote_types(value.dtype, sampling_locations.dtype), attention_weights.dtype)
+            value, sampling_locations, attention_weights = value.to(wide), sampling_locations.to(wide), attention_weights.to(wide)
         out = MSDA.ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
                                           sampling_locations, attention_weights, im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
                               sampling_locations, attention_weights)
-        return out
+        return out.to(ctx.in_dtypes[0]) if ctx.in_dtypes[0] in _LOW else out
 
     @staticmethod
     @once_differentiable
-    @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, grad_output):
         value, shapes, level_start, loc, attn = ctx.saved_tensors
         g_value, g_loc, g_attn = MSDA.ms_deform_attn_backward(
-            value, shapes, level_start, loc, attn, grad_output.contiguous(), ctx.im2col_step)
-        return g_value, None, None, g_loc, g_attn, None
+            value, shapes, level_start, loc, attn, grad_output.to(value.dtype).contiguous(), ctx.im2col_step)
+        dv, dl, da = ctx.in_dtypes
+        return g_value.to(dv), None, None, g_loc.to(dl), g_attn.to(da), None

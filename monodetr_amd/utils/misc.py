@@ -79,3 +79,8 @@ def mark_no_padding(mask):
 
 def no_padding(mask):
     return mask is None or getattr(mask, "_mdetr_no_padding", False)
+
+
+def at_least_fp32(x):
+    """bf16 / fp16 -> fp32; fp32 and fp64 untouched."""
+    return x.float() if x.dtype in (torch.bfloat16, torch.float16) else x

@@ -94,3 +94,37 @@ def test_bf16_autocast_step_runs_and_is_close(built):
             out = model(images, calibs, targets, img_sizes)
     assert torch.isfinite(out["pred_boxes"].float()).all()
     assert (out["pred_boxes"].float() - ref["pred_boxes"]).abs().max() < 0.1       # bf16 end-to-end, sigmoid outputs
+
+
+def test_bf16_body_training_step_matches_fp32_loss():
+    """helpers/precision.py: bf16 body + fp32 heads.  One training step runs, parameters keep their
+    dtypes, and the loss agrees with the fp32 model's to bf16 accuracy."""
+    from monodetr_amd.helpers.optimizer_helper import build_optimizer
+    from monodetr_amd.helpers.precision import to_bf16_body
+    from monodetr_amd.monodetr import build_monodetr
+    images, calibs, img_sizes, targets = synthetic_batch(2, 384, 1280, seed=7, device="cuda")
+    totals = {}
+    for mode in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        model, criterion = build_monodetr(load_cfg(device="cuda"))
+        disable_dropout_(name_seeded_init_(model)).cuda().train()
+        criterion.train()
+        x = images
+        if mode == "bf16":
+            assert to_bf16_body(model) > 100
+            x = images.to(torch.bfloat16)
+        opt = build_optimizer({'type': 'adamw', 'lr': 2e-4, 'weight_decay': 1e-4}, model)
+        out = model(x, calibs, targets, img_sizes)
+        assert out["pred_boxes"].dtype == torch.float32            # heads stay fp32
+        losses = criterion(out, targets)
+        total = sum(losses[k] * criterion.weight_dict[k] for k in losses if k in criterion.weight_dict)
+        total.backward()
+        opt.step()
+        totals[mode] = float(total)
+        if mode == "bf16":
+            p = dict(model.named_parameters())
+            assert p["depthaware_transformer.encoder.layers.0.linear1.weight"].dtype == torch.bfloat16
+            assert p["class_embed.0.weight"].dtype == torch.float32 and p["backbone.0.body.layer2.0.conv1.weight"].dtype == torch.float32
+            assert opt.state[p["depthaware_transformer.encoder.layers.0.linear1.weight"]]["master"].dtype == torch.float32
+            assert all(torch.isfinite(q.grad).all() for q in model.parameters() if q.grad is not None)
+    assert abs(totals["bf16"] - totals["fp32"]) < 0.05 * abs(totals["fp32"]), totals

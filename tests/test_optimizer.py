@@ -33,3 +33,24 @@ def test_state_dict_roundtrip():
     opt2 = build_optimizer({'type': 'adamw', 'lr': 2e-4, 'weight_decay': 1e-4}, make_model())
     opt2.load_state_dict(sd)
     assert opt2.state_dict()['state'][0]['step'] == 1
+
+
+def test_bf16_parameters_use_fp32_master_weights():
+    """A bf16 parameter follows the fp32 trajectory (rounded), instead of stalling on bf16 rounding."""
+    from monodetr_amd.helpers.optimizer_helper import AdamW
+    torch.manual_seed(0)
+    w32 = torch.nn.Parameter(torch.randn(64, 64))
+    w16 = torch.nn.Parameter(w32.detach().to(torch.bfloat16))
+    o32, o16 = AdamW([w32], lr=1e-4, weight_decay=1e-4), AdamW([w16], lr=1e-4, weight_decay=1e-4)
+    start = w32.detach().clone()
+    start16 = w16.detach().float().clone()
+    for step in range(50):
+        g = torch.randn(64, 64, generator=torch.Generator().manual_seed(step)) + 0.5
+        w32.grad, w16.grad = g.clone(), g.to(torch.bfloat16)
+        o32.step(); o16.step()
+    master = o16.state[w16]['master']
+    assert master.dtype == torch.float32 and w16.dtype == torch.bfloat16
+    assert torch.equal(w16.detach(), master.to(torch.bfloat16))
+    # the master tracks the fp32 run closely (gradients differ only by their bf16 rounding)
+    assert ((master - start16) - (w32.detach() - start)).abs().max() < 2e-2 * (w32.detach() - start).abs().max()
+    assert (w32.detach() - start).abs().max() > 1e-3
