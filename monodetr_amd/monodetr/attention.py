@@ -19,6 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..attn_ext import fused_attention
+from .linear import token_linear
 
 
 def _sdpa(q, k, v, num_heads, dropout_p, key_padding_mask):
@@ -73,13 +74,13 @@ class MultiheadAttention(nn.Module):
         E = self.embed_dim
         W, b = self.in_proj_weight, self.in_proj_bias
         if query is key and key is value:
-            return F.linear(query, W, b).split(E, -1)
+            return token_linear(query, W, b).split(E, -1)
         if query is key:                                     # q = k = x + pos, v = x (encoder layers)
-            q, k = F.linear(query, W[:2 * E], b[:2 * E]).split(E, -1)
-            return q, k, F.linear(value, W[2 * E:], b[2 * E:])
+            q, k = token_linear(query, W[:2 * E], b[:2 * E]).split(E, -1)
+            return q, k, token_linear(value, W[2 * E:], b[2 * E:])
         q = F.linear(query, W[:E], b[:E])
         if key is value:
-            k, v = F.linear(key, W[E:], b[E:]).split(E, -1)
+            k, v = token_linear(key, W[E:], b[E:]).split(E, -1)
         else:
             k, v = F.linear(key, W[E:2 * E], b[E:2 * E]), F.linear(value, W[2 * E:], b[2 * E:])
         return q, k, v

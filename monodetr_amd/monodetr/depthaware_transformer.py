@@ -26,6 +26,7 @@ from torch.nn.init import constant_, normal_, xavier_uniform_
 
 from ..utils.misc import inverse_sigmoid, no_padding
 from .attention import MultiheadAttention as FusedMultiheadAttention
+from .linear import token_linear
 from .ops.modules import MSDeformAttn, MSDeformAttn_cross, MultiheadAttention  # noqa: F401  (reference :11)
 
 
@@ -81,7 +82,8 @@ class VisualEncoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, src):
-        ff = self.linear2(self.dropout2(self.activation(self.linear1(src))))
+        h = self.dropout2(self.activation(token_linear(src, self.linear1.weight, self.linear1.bias)))
+        ff = token_linear(h, self.linear2.weight, self.linear2.bias)
         return self.norm2(src + self.dropout3(ff))
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):

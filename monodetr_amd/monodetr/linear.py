@@ -1,0 +1,61 @@
+"""``token_linear``: y = x W^T + b for activations with tens of thousands of token rows.
+
+Forward and the input gradient are ordinary GEMMs (hipBLASLt reaches the memory roofline there:
+~26 us for 81 600 x 256 x 256 bf16).  The WEIGHT gradient dW = dY^T X contracts over the 81 600
+tokens into a 256 x 256 result; the library's NT kernel for that shape runs 16 workgroups deep and
+takes 205-228 us (123 us after TunableOp) -- 27 such GEMMs per training step were the largest single
+GPU item.  Here the token axis is split into C chunks evaluated as one batched GEMM
+([C, N, T/C] x [C, T/C, K], thousands of independent tiles) followed by a sum over C: 35 us.
+Pure library plumbing (torch.bmm -> hipBLASLt); numerics are those of a split-K GEMM.
+"""
+import torch
+import torch.nn.functional as F
+
+_MIN_TOKENS = 4096
+
+
+def _split_count(T):
+    """Chunks along the token axis: a divisor of T giving chunks of ~512-2048 rows."""
+    best = 0
+    for c in (64, 48, 80, 96, 60, 50, 40, 32, 128, 30, 24, 20, 16):
+        if T % c == 0 and T // c >= 256:
+            best = c
+            break
+    return best
+
+
+class _TokenLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dw = db = None
+        x2 = x.reshape(-1, x.shape[-1])
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ weight).view_as(x)
+        T = x2.shape[0]
+        C = _split_count(T)
+        if ctx.needs_input_grad[1]:
+            if C:
+                dw = torch.bmm(dy2.view(C, T // C, -1).transpose(1, 2), x2.view(C, T // C, -1)).sum(0)
+            else:
+                dw = dy2.t() @ x2
+            dw = dw.to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = (dy2.view(C, T // C, -1).sum(1).sum(0) if C else dy2.sum(0)).to(weight.dtype)
+        return dx, dw, db
+
+
+def token_linear(x, weight, bias=None):
+    """F.linear with the split-K weight gradient for big token counts on the GPU; plain F.linear otherwise."""
+    if x.is_cuda and x.dtype == weight.dtype and x.numel() // x.shape[-1] >= _MIN_TOKENS and torch.is_grad_enabled() \
+            and not torch.is_autocast_enabled():
+        return _TokenLinear.apply(x, weight, bias)
+    return F.linear(x, weight, bias)

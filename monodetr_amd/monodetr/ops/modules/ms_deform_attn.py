@@ -15,6 +15,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..functions import MSDeformAttnFunction
+from ...linear import token_linear
 
 
 def _is_power_of_2(n):
@@ -72,13 +73,13 @@ class MSDeformAttn(nn.Module):
         M, L, P = self.n_heads, self.n_levels, self.n_points
         assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == S
 
-        value = self.value_proj(input_flatten)
+        value = token_linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, S, M, -1)
 
-        offsets = self.sampling_offsets(query).view(N, Lq, M, L, P, 2)
-        weights = F.softmax(self.attention_weights(query).view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+        offsets = token_linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias).view(N, Lq, M, L, P, 2)
+        weights = F.softmax(token_linear(query, self.attention_weights.weight, self.attention_weights.bias).view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
 
         ref = reference_points[:, :, None, :, None, :]
         if reference_points.shape[-1] == 2:
@@ -93,7 +94,7 @@ class MSDeformAttn(nn.Module):
 
         out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
                                          locations, weights, self.im2col_step)
-        return self.output_proj(out)
+        return token_linear(out, self.output_proj.weight, self.output_proj.bias)
 
 
 class MSDeformAttn_cross(MSDeformAttn):
