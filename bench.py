@@ -200,14 +200,39 @@ def main():
         elapsed = float(t)
     assert torch.isfinite(loss).item(), "training loss is not finite"
 
-    kernels = []
-    for kind, Lq, launches, total_ms in _capi.profile_read():
+    # ---- per-kernel timings from the HIP events recorded by the C ABI during the timed steps --------
+    names = {0: "msda_fwd_d32", 1: "msda_bwd_d32", 2: "msda_scatter_tiles", 3: "msda_reduce_tiles",
+             4: "attn_fwd_kernel", 5: "attn_bwd(prep+dq+dkv)"}
+    kernels, by_key = [], {}
+    for kind, key, launches, total_ms in _capi.profile_read():
         avg = total_ms / max(launches, 1)
-        byts = msda_algorithmic_bytes(args.batch, Lq, kind == 1)
-        kernels.append({"kernel": ("msda_bwd_d32" if kind else "msda_fwd_d32"), "Lq": Lq, "launches": launches,
-                        "avg_ms": round(avg, 4), "algorithmic_MB": round(byts / 1e6, 1),
-                        "achieved_GBps": round(byts / avg / 1e6, 1), "frac": round(byts / avg / 1e6 / 8000.0, 4)})
-    dom = max(kernels, key=lambda k: k["avg_ms"] * k["launches"]) if kernels else None
+        row = {"kernel": names.get(kind, str(kind)), "launches": launches, "avg_ms": round(avg, 4)}
+        if kind <= 3:
+            row["Lq"] = key
+            if kind == 0:
+                byts = msda_algorithmic_bytes(args.batch, key, False)
+                row.update(algorithmic_MB=round(byts / 1e6, 1), achieved_GBps=round(byts / avg / 1e6, 1),
+                           frac=round(byts / avg / 1e6 / 8000.0, 4))
+        else:
+            Lq, Lk = key // 4096, key % 4096
+            flops = 4.0 * args.batch * 8 * Lq * Lk * 32 * (1.0 if kind == 4 else 2.5)
+            row.update(Lq=Lq, Lk=Lk, TFLOPs=round(flops / avg / 1e9, 1))
+        kernels.append(row)
+        by_key[(kind, key)] = avg
+    # MSDA backward as an operator = gather kernel (+ scatter_tiles + reduce_tiles on the encoder shape)
+    ops = []
+    for (kind, key), avg in by_key.items():
+        if kind == 1:
+            parts = [avg] + [by_key[(k2, key)] for k2 in (2, 3) if (k2, key) in by_key]
+            byts = msda_algorithmic_bytes(args.batch, key, True)
+            ops.append({"op": "msda_backward", "Lq": key, "kernels_in_op": len(parts), "ms": round(sum(parts), 4),
+                        "algorithmic_MB": round(byts / 1e6, 1), "achieved_GBps": round(byts / sum(parts) / 1e6, 1),
+                        "frac": round(byts / sum(parts) / 1e6 / 8000.0, 4)})
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "msda_pmc_traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath))
+    dom = max(ops, key=lambda o: o["ms"]) if ops else None
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -225,10 +250,12 @@ def main():
             "final_loss": round(float(loss), 4),
         }
         if dom is not None:
-            line["roofline"] = {"kernel": "%s(Lq=%d)" % (dom["kernel"], dom["Lq"]), "bound": "hbm",
-                                "achieved": dom["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
-                                "frac": dom["frac"], "traffic": None,
-                                "avg_launch_ms": dom["avg_ms"], "algorithmic_bytes": int(dom["algorithmic_MB"] * 1e6)}
+            # dominant hand-written operator: MSDA backward at the encoder shape (gather + tile scatter + reduce)
+            line["roofline"] = {"kernel": "msda_backward(Lq=%d): msda_bwd_d32 + msda_scatter_tiles + msda_reduce_tiles" % dom["Lq"],
+                                "bound": "hbm", "achieved": dom["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
+                                "frac": dom["frac"], "traffic": traffic.get("msda_backward_Lq%d" % dom["Lq"]),
+                                "avg_launch_ms": dom["ms"], "algorithmic_bytes": int(dom["algorithmic_MB"] * 1e6)}
+            line["ops"] = ops
             line["kernels"] = kernels
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_steps)

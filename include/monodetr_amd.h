@@ -160,7 +160,10 @@ int mdetr_attn_backward(int dtype, const void *q, const void *k, const void *v, 
  * not the zero-fill memsets of the backward) is bracketed by an event pair.
  *   mdetr_profile_enable(1|0)      start / stop recording (clears previous records when enabling)
  *   mdetr_profile_read(...)        synchronises the recorded events and aggregates them by
- *                                  (kind, Lq): kind 0 = msda forward, 1 = msda backward.
+ *                                  (kind, key): kind 0 = msda forward, 1 = msda backward gather kernel
+ *                                  (msda_bwd_d32 / generic), 2 = msda_scatter_tiles, 3 = msda_reduce_tiles
+ *                                  with key = Lq; kind 4 = attention forward, 5 = attention backward
+ *                                  (prep + dq + dkv) with key = Lq * 4096 + Lk.
  *                                  Fills up to `cap` rows of {kind, Lq, launches, total_ms} (as
  *                                  doubles, 4 per row) and returns the number of rows, or < 0.
  * Recording costs two hipEventRecord calls per launch; it is off by default.

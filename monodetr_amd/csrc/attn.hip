@@ -29,6 +29,7 @@
 #include <stdint.h>
 
 #include "attn.h"
+#include "msda.h"
 
 namespace mdetr {
 namespace {
@@ -553,8 +554,10 @@ hipError_t attn_forward_launch(const AttnProblem &p, void *out, float *lse2, hip
     if (p.B == 0 || p.Lq == 0) return hipSuccess;
     const AttnArgs a = make_args(p);
     const dim3 grid((p.Lq + 127) / 128, p.H, p.B), block(256);
+    profile_begin(4, p.Lq * 4096 + (p.Lk < 4096 ? p.Lk : 4095), st);
     if (p.dtype == 0) hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, 0, st, a, static_cast<float *>(out), lse2);
     else hipLaunchKernelGGL(attn_fwd_kernel<__bf16>, grid, block, 0, st, a, static_cast<__bf16 *>(out), lse2);
+    profile_end(st);
     return hipGetLastError();
 }
 
@@ -565,6 +568,8 @@ hipError_t attn_backward_launch(const AttnProblem &p, const void *out, const voi
     const AttnArgs a = make_args(p);
     const int64_t items = static_cast<int64_t>(p.B) * p.Lq * p.H;
     const dim3 gq((p.Lq + 127) / 128, p.H, p.B), gk((p.Lk + 127) / 128, p.H, p.B), block(256);
+    struct Scope { hipStream_t s; Scope(int key, hipStream_t s_) : s(s_) { profile_begin(5, key, s_); } ~Scope() { profile_end(s); } }
+        scope(p.Lq * 4096 + (p.Lk < 4096 ? p.Lk : 4095), st);
     if (p.dtype == 0) {
         if (items) hipLaunchKernelGGL(attn_bwd_prep_kernel<float>, dim3(static_cast<unsigned>((items * 8 + 255) / 256)), block, 0, st,
                                       static_cast<const float *>(out), static_cast<const float *>(d_out), dsum, p.B, p.H, p.Lq);

@@ -629,7 +629,6 @@ hipError_t msda_backward_launch_ex(int dtype, const void *value, const int64_t *
         if ((err = hipMemsetAsync(grad_loc, 0, ns * 2 * e, st)) != hipSuccess) return err;
         if ((err = hipMemsetAsync(grad_attn, 0, ns * e, st)) != hipSuccess) return err;
     }
-    struct Scope { hipStream_t s; Scope(int Lq_, hipStream_t s_) : s(s_) { profile_begin(1, Lq_, s_); } ~Scope() { profile_end(s); } } scope(Lq, st);
     if (fast) {
         static const int var_env = [] { const char *ev = getenv("MDETR_MSDA_BWD_VARIANT"); return ev ? atoi(ev) : -1; }();
         // tile-privatised grad_value (msda_tiled.hip) when the geometry qualifies; the kernel below then
@@ -651,11 +650,13 @@ hipError_t msda_backward_launch_ex(int dtype, const void *value, const int64_t *
                                static_cast<float *>(grad_loc), static_cast<float *>(grad_attn),
                                B, S, M, L, P, npairs, iters, absmax2);
         };
+        profile_begin(1, Lq, st);
         if (L == 4 && P == 4) {
             if (var == 0) a(msda_bwd_d32<4, 4, 0>); else if (var == 1) a(msda_bwd_d32<4, 4, 1>); else a(msda_bwd_d32<4, 4, 2>);
         } else {
             if (var == 2) a(msda_bwd_d32<0, 0, 2>); else a(msda_bwd_d32<0, 0, 1>);
         }
+        profile_end(st);
         if (try_tiled) {
             // grad_value: tile-privatised scatter (msda_tiled.hip); the gather kernel above produced
             // grad_loc / grad_attn and max|grad_out|, max|attn| for the fixed-point scale
@@ -666,11 +667,13 @@ hipError_t msda_backward_launch_ex(int dtype, const void *value, const int64_t *
             if (err != hipSuccess) return err;
         }
     } else if (dtype == 0) {
+        profile_begin(1, Lq, st);
         hipLaunchKernelGGL(msda_bwd_generic<float>, dim3(grid_for(n, 256)), dim3(256), 0, st,
                            static_cast<const float *>(value), shapes, lstart, static_cast<const float *>(loc),
                            static_cast<const float *>(attn), static_cast<const float *>(grad_out),
                            static_cast<float *>(grad_value), static_cast<float *>(grad_loc),
                            static_cast<float *>(grad_attn), S, M, D, L, Lq, P, n);
+        profile_end(st);
     } else {
         hipLaunchKernelGGL(msda_bwd_generic<double>, dim3(grid_for(n, 256)), dim3(256), 0, st,
                            static_cast<const double *>(value), shapes, lstart, static_cast<const double *>(loc),

@@ -435,10 +435,14 @@ hipError_t msda_tiled_grad_value_launch(const int64_t *shapes_h, const int64_t *
         attr_set = true;
     }
     const unsigned nblocks = static_cast<unsigned>(B) * M * pl.blk0[L];
+    profile_begin(2, Lq, st);
     hipLaunchKernelGGL(msda_scatter_tiles, dim3(nblocks), dim3(kThreads), lds, st, pl, loc, attn, grad_out, grad_value,
                        absmax2, scratch);
+    profile_end(st);
     const int64_t nrows = static_cast<int64_t>(B) * S * M;
+    profile_begin(3, Lq, st);
     hipLaunchKernelGGL(msda_reduce_tiles, dim3(static_cast<unsigned>((nrows * 8 + 255) / 256)), dim3(256), 0, st, pl, scratch, grad_value);
+    profile_end(st);
     return hipGetLastError();
 }
 
