@@ -155,6 +155,24 @@ int mdetr_attn_backward(int dtype, const void *q, const void *k, const void *v, 
                         float scale, float dropout_p, uint64_t seed, int device, void *stream);
 
 /*
+ * Batched linear sum assignment (Hungarian matching) on the device.  Replaces the host loop of
+ * scipy.optimize.linear_sum_assignment calls in HungarianMatcher.forward (matcher.py:87-103: one
+ * device->host copy and 3 x B x 11 solver calls per iteration).
+ *
+ *   cost         fp32; element (problem-image li = layer*images + b, query q, target t) at
+ *                cost[li*img_stride + q*q_stride + t*t_stride]           (device)
+ *   num_targets  [images] int32: valid targets of each image, <= kmax    (device)
+ *   assign       [layers, images, groups, kmax] int32 (device): for problem (l, b, g) and target t <
+ *                num_targets[b], the index in [g*n, (g+1)*n) of the query matched to it; -1 elsewhere
+ *   n            queries per group (<= 64), kmax <= n
+ * Each (l, b, g) is an independent min-cost matching of all targets of image b to distinct queries
+ * of group g, solved exactly in float64 (shortest augmenting paths, one wave64 per problem).
+ */
+int mdetr_lsa_forward(const float *cost, const int32_t *num_targets, int32_t *assign,
+                      int layers, int images, int groups, int n, int kmax,
+                      int64_t img_stride, int64_t q_stride, int64_t t_stride, int device, void *stream);
+
+/*
  * Optional per-launch kernel timing with HIP events recorded on the launch stream (bench.py's
  * `roofline` block).  When enabled, every fast-path/generic MSDA kernel launch (the kernel only,
  * not the zero-fill memsets of the backward) is bracketed by an event pair.

@@ -12,6 +12,7 @@
 
 #include "../../include/monodetr_amd.h"
 #include "attn.h"
+#include "lsa.h"
 #include "msda.h"
 
 namespace {
@@ -250,6 +251,22 @@ int mdetr_attn_backward(int dtype, const void *q, const void *k, const void *v, 
     mdetr::AttnProblem p{dtype, q, k, v, key_padding_mask, B, H, Lq, Lk, q_bs, k_bs, v_bs, q_rs, k_rs, v_rs, scale, dropout_p, seed};
     const hipError_t e = mdetr::attn_backward_launch(p, out, d_out, lse, dsum, dq, dk, dv, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_attn_backward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_lsa_forward(const float *cost, const int32_t *num_targets, int32_t *assign,
+                      int layers, int images, int groups, int n, int kmax,
+                      int64_t img_stride, int64_t q_stride, int64_t t_stride, int device, void *stream)
+{
+    if (layers < 0 || images < 0 || groups < 0 || n <= 0 || n > 64 || kmax < 0 || kmax > n)
+        return fail(MDETR_E_ARG, "mdetr_lsa_forward: need 0 < n <= 64 and 0 <= kmax <= n (n=%d kmax=%d)", n, kmax);
+    if (layers == 0 || images == 0 || groups == 0 || kmax == 0) return MDETR_OK;
+    if (!cost || !num_targets || !assign) return fail(MDETR_E_ARG, "mdetr_lsa_forward: null pointer");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_lsa_forward: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::lsa_launch(cost, num_targets, assign, layers, images, groups, n, kmax,
+                                           img_stride, q_stride, t_stride, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_lsa_forward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

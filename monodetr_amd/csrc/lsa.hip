@@ -1,0 +1,123 @@
+// monodetr_amd/csrc/lsa.hip -- batched linear sum assignment (Hungarian matching) on the GPU.
+//
+// The reference matches predictions to ground truth on the HOST: it copies the cost matrix to the
+// CPU and calls scipy.optimize.linear_sum_assignment once per (decoder layer, image, query group)
+// -- 3 x 8 x 11 = 264 calls and a device->host sync per training iteration
+// (lib/models/monodetr/matcher.py:87-103).  Here one wave64 solves one assignment problem with the
+// shortest-augmenting-path (Jonker-Volgenant / "Hungarian with potentials") algorithm:
+//   * rows = the k <= 64 ground-truth objects of an image, columns = the n <= 64 queries of a group;
+//     lane j owns column j (its potential v_j, slack minv_j, predecessor way_j, assigned row p_j);
+//   * the per-step argmin over the free columns is a 6-step butterfly over the wave;
+//   * all arithmetic in float64, as scipy does on the same fp32 costs, so the optimum is the same
+//     (when the optimum is not unique either solver may return any optimal assignment).
+// Problems are tiny (<= 50 x 50); all of them run concurrently, no host involvement, graph-capturable.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lsa.h"
+
+namespace mdetr {
+namespace {
+
+constexpr int kMaxDim = 64;
+constexpr int kWavesPerBlock = 4;
+
+struct MinLoc { double v; int j; };
+
+__device__ __forceinline__ MinLoc wave_argmin(double v, int j)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(v, o);
+        const int oj = __shfl_xor(j, o);
+        if (ov < v || (ov == v && oj < j)) { v = ov; j = oj; }
+    }
+    return {v, j};
+}
+
+// cost(problem, target t, query column j) = C[base + j * q_stride + t * t_stride]
+__global__ __launch_bounds__(kWavesPerBlock * 64)
+void lsa_kernel(const float *__restrict__ C, const int *__restrict__ num_targets, int *__restrict__ assign,
+                int num_problems, int groups, int n, int kmax,
+                int64_t img_stride, int64_t q_stride, int64_t t_stride, int images_per_layer)
+{
+    // per wave: costs [kmax][65] fp32 (exact in fp64 on read) + row potentials u[64] fp64
+    extern __shared__ __attribute__((aligned(16))) unsigned char lsa_smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int prob = blockIdx.x * kWavesPerBlock + wave;
+    if (prob >= num_problems) return;                                 // wave-uniform
+    // problem -> (layer*image, group)
+    const int g = prob % groups, li = prob / groups;                  // li = layer * images_per_layer + image
+    const int image = li % images_per_layer;
+    int k = num_targets[image];
+    k = k < 0 ? 0 : (k > kmax ? kmax : k);
+    int *out = assign + static_cast<int64_t>(prob) * kmax;
+    for (int t = lane; t < kmax; t += 64) out[t] = -1;
+    if (k == 0) return;
+
+    const size_t per_wave = static_cast<size_t>(kmax) * (kMaxDim + 1) * sizeof(float) + kMaxDim * sizeof(double);
+    double *u = reinterpret_cast<double *>(lsa_smem + wave * per_wave);
+    float (*a)[kMaxDim + 1] = reinterpret_cast<float (*)[kMaxDim + 1]>(lsa_smem + wave * per_wave + kMaxDim * sizeof(double));
+    const float *Cp = C + static_cast<int64_t>(li) * img_stride + static_cast<int64_t>(g) * n * q_stride;
+    for (int t = 0; t < k; ++t)
+        a[t][lane] = lane < n ? Cp[lane * q_stride + t * t_stride] : 0.f;
+    if (lane < kMaxDim) u[lane] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const double INF = 1e300;
+    const bool col = lane < n;
+    double v = 0.0;
+    int p = -1;                                                       // row assigned to this column
+    for (int i = 0; i < k; ++i) {
+        double minv = INF;
+        int way = -2;                                                 // -1 = reached from the dummy column
+        bool used = false;
+        int j0 = -1;                                                  // current column (-1 = dummy column holding row i)
+        while (true) {
+            if (lane == j0) used = true;
+            const int i0 = j0 < 0 ? i : __shfl(p, j0);
+            const double ui0 = u[i0];
+            double cand = INF;
+            if (col && !used) {
+                const double cur = static_cast<double>(a[i0][lane]) - ui0 - v;
+                if (cur < minv) { minv = cur; way = j0; }
+                cand = minv;
+            }
+            const MinLoc m = wave_argmin(cand, lane);
+            const double delta = m.v;
+            // potentials: rows of used columns (distinct rows) and the dummy column's row i
+            if (used) { u[p] += delta; v -= delta; }
+            else minv -= delta;
+            if (lane == 0) u[i] += delta;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            j0 = m.j;
+            if (__shfl(p, j0) < 0) break;                             // free column reached
+        }
+        // augment along the alternating path back to the dummy column
+        while (j0 >= 0) {
+            const int j1 = __shfl(way, j0);
+            const int pj1 = j1 < 0 ? i : __shfl(p, j1);
+            if (lane == j0) p = pj1;
+            j0 = j1;
+        }
+    }
+    if (col && p >= 0) out[p] = g * n + lane;
+}
+
+}  // namespace
+
+hipError_t lsa_launch(const float *cost, const int *num_targets, int *assign, int layers, int images, int groups,
+                      int n, int kmax, int64_t img_stride, int64_t q_stride, int64_t t_stride, hipStream_t st)
+{
+    const int num_problems = layers * images * groups;
+    if (num_problems == 0 || kmax == 0) return hipSuccess;
+    const dim3 grid((num_problems + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * 64);
+    const size_t lds = kWavesPerBlock * (static_cast<size_t>(kmax) * (kMaxDim + 1) * sizeof(float) + kMaxDim * sizeof(double));
+    hipLaunchKernelGGL(lsa_kernel, grid, block, lds, st, cost, num_targets, assign, num_problems, groups, n, kmax,
+                       img_stride, q_stride, t_stride, images);
+    return hipGetLastError();
+}
+
+}  // namespace mdetr
