@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MDETR_ABI_VERSION 1
+#define MDETR_ABI_VERSION 2
 
 /* element types of the floating-point tensors */
 #define MDETR_F32 0
@@ -140,19 +140,22 @@ int mdetr_msda_variant(int dtype, int M, int D, int L, int P);
  *   lse              [B, H, Lq] fp32: log2-domain log-sum-exp of the scaled scores (for backward)
  *   dropout_p, seed  dropout on the probabilities; the mask is a stateless hash of (seed, b, h, q, k),
  *                    regenerated identically by the backward
+ *   seed_dev         optional DEVICE pointer to a uint64 added to `seed` when the kernel runs: lets a
+ *                    captured hipGraph draw a fresh mask on every replay (the host scalar is frozen at
+ *                    capture time); NULL = use `seed` alone
  * Backward additionally takes out, d_out [B, Lq, H*32] contiguous and a scratch dsum [B, H, Lq] fp32,
  * and writes dq [B, Lq, H*32], dk, dv [B, Lk, H*32] (contiguous, fully overwritten).
  */
 int mdetr_attn_forward(int dtype, const void *q, const void *k, const void *v, const uint8_t *key_padding_mask,
                        void *out, float *lse, int B, int H, int Lq, int Lk,
                        int64_t q_bs, int64_t k_bs, int64_t v_bs, int q_rs, int k_rs, int v_rs,
-                       float scale, float dropout_p, uint64_t seed, int device, void *stream);
+                       float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev, int device, void *stream);
 
 int mdetr_attn_backward(int dtype, const void *q, const void *k, const void *v, const uint8_t *key_padding_mask,
                         const void *out, const void *d_out, const float *lse, float *dsum,
                         void *dq, void *dk, void *dv, int B, int H, int Lq, int Lk,
                         int64_t q_bs, int64_t k_bs, int64_t v_bs, int q_rs, int k_rs, int v_rs,
-                        float scale, float dropout_p, uint64_t seed, int device, void *stream);
+                        float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev, int device, void *stream);
 
 /*
  * Batched linear sum assignment (Hungarian matching) on the device.  Replaces the host loop of

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmonodetr_amd.so")
 
 MDETR_F32, MDETR_F64, MDETR_BF16 = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -30,9 +30,9 @@ SIGNATURES = {
     "mdetr_msda_backward_workspace_bytes": (ctypes.c_int64, [_c_int, _c_vp, _c_vp] + [_c_int] * 7),
     "mdetr_msda_indices": (_c_int, [_c_int] + [_c_vp] * 3 + [_c_int] * 5 + [_c_int, _c_vp]),
     "mdetr_attn_forward": (_c_int, [_c_int] + [_c_vp] * 6 + [_c_int] * 4 + [ctypes.c_int64] * 3 + [_c_int] * 3
-                           + [ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _c_int, _c_vp]),
+                           + [ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),
     "mdetr_attn_backward": (_c_int, [_c_int] + [_c_vp] * 11 + [_c_int] * 4 + [ctypes.c_int64] * 3 + [_c_int] * 3
-                            + [ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _c_int, _c_vp]),
+                            + [ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),
     "mdetr_lsa_forward": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [ctypes.c_int64] * 3 + [_c_int, _c_vp]),
     "mdetr_profile_enable": (_c_int, [_c_int]),
     "mdetr_profile_read": (_c_int, [_c_vp, _c_int]),

@@ -25,9 +25,24 @@ def _strided(t):
     return t, t.stride(0), t.stride(1)
 
 
+_seed_state = {}
+
+
+def _next_seed(device):
+    """Device-resident dropout counter: returns a snapshot tensor (int64 [1]) for this call and
+    advances the counter, all with device ops -- so a captured hipGraph draws a new mask on every
+    replay.  Initialised once from torch's CPU generator (reproducible under torch.manual_seed)."""
+    st = _seed_state.get(device)
+    if st is None:
+        st = _seed_state[device] = torch.randint(0, 2 ** 40, (1,), dtype=torch.int64).to(device)
+    snap = st.clone()
+    st.add_(1)
+    return snap
+
+
 class _FusedAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, num_heads, scale, dropout_p, seed, key_padding_mask):
+    def forward(ctx, q, k, v, num_heads, scale, dropout_p, seed, key_padding_mask, seed_dev=None):
         assert q.is_cuda, "fused attention runs on the GPU only"
         B, Lq, E = q.shape
         Lk = k.shape[1]
@@ -46,8 +61,10 @@ class _FusedAttention(torch.autograd.Function):
         rc = _capi.lib().mdetr_attn_forward(
             code, q.data_ptr(), k.data_ptr(), v.data_ptr(), kpm.data_ptr() if kpm is not None else None,
             out.data_ptr(), lse.data_ptr(), B, num_heads, Lq, Lk, qb, kb, vb, qr, kr, vr,
-            float(scale), float(dropout_p), int(seed), q.device.index, torch.cuda.current_stream(q.device).cuda_stream)
+            float(scale), float(dropout_p), int(seed), seed_dev.data_ptr() if seed_dev is not None else None,
+            q.device.index, torch.cuda.current_stream(q.device).cuda_stream)
         _capi.check(rc, "mdetr_attn_forward")
+        ctx.seed_dev = seed_dev
         ctx.save_for_backward(q, k, v, out, lse, kpm if kpm is not None else torch.empty(0, device=q.device))
         ctx.meta = (code, num_heads, float(scale), float(dropout_p), int(seed), kpm is not None, (qb, kb, vb, qr, kr, vr))
         return out
@@ -70,15 +87,16 @@ class _FusedAttention(torch.autograd.Function):
             code, q.data_ptr(), k.data_ptr(), v.data_ptr(), kpm.data_ptr() if has_kpm else None,
             out.data_ptr(), d_out.data_ptr(), lse.data_ptr(), dsum.data_ptr(),
             dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Lq, Lk, qb, kb, vb, qr, kr, vr,
-            scale, dropout_p, seed, q.device.index, torch.cuda.current_stream(q.device).cuda_stream)
+            scale, dropout_p, seed, ctx.seed_dev.data_ptr() if ctx.seed_dev is not None else None,
+            q.device.index, torch.cuda.current_stream(q.device).cuda_stream)
         _capi.check(rc, "mdetr_attn_backward")
-        return dq, dk, dv, None, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None, None
 
 
 def fused_attention(q, k, v, num_heads, dropout_p=0.0, key_padding_mask=None, scale=None, seed=None):
     if scale is None:
         scale = (q.shape[-1] // num_heads) ** -0.5
+    seed_dev = None
     if dropout_p > 0.0 and seed is None:
-        # drawn from torch's CPU generator: reproducible under torch.manual_seed, no device sync
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-    return _FusedAttention.apply(q, k, v, num_heads, scale, dropout_p, seed or 0, key_padding_mask)
+        seed_dev = _next_seed(q.device)          # explicit `seed` (tests) keeps the host-scalar path
+    return _FusedAttention.apply(q, k, v, num_heads, scale, dropout_p, seed or 0, key_padding_mask, seed_dev)

@@ -14,6 +14,7 @@ struct AttnProblem {
     int q_row_stride, k_row_stride, v_row_stride;
     float scale, dropout_p;
     uint64_t seed;
+    const uint64_t *seed_dev;        // optional device word added to `seed` (graph-replay-safe dropout), or null
 };
 
 hipError_t attn_forward_launch(const AttnProblem &p, void *out, float *lse2, hipStream_t st);

@@ -52,6 +52,7 @@ struct AttnArgs {
     int q_rs, k_rs, v_rs;          // row strides (elements)
     float scale, dropout_p;
     uint64_t seed;
+    const uint64_t *seed_dev;
 };
 
 __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c)
@@ -276,6 +277,7 @@ void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ 
     own_row_frags<T, SP>(Q + static_cast<int64_t>(q) * a.q_rs, qv, a.scale * kLog2e, lane, qf);
 
     const bool drop = a.dropout_p > 0.f;
+    const uint64_t seed_eff = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
     const unsigned thresh = drop ? static_cast<unsigned>(a.dropout_p * 4294967296.0) : 0u;
     const float rinv = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
 
@@ -319,7 +321,7 @@ void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ 
                 p[r] = e;
                 if (drop) {
                     const int key = k0 + sub * 32 + acc_row(r, half);
-                    p[r] = keep_elem(a.seed, b, h, q, key, thresh) ? e * rinv : 0.f;
+                    p[r] = keep_elem(seed_eff, b, h, q, key, thresh) ? e * rinv : 0.f;
                 }
             }
             l = l * alpha + psum;
@@ -396,6 +398,7 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
     const float L2 = qv ? lse2[stat] : 0.f, Dq = qv ? dsum[stat] : 0.f;
 
     const bool drop = a.dropout_p > 0.f;
+    const uint64_t seed_eff = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
     const unsigned thresh = drop ? static_cast<unsigned>(a.dropout_p * 4294967296.0) : 0u;
     const float rinv = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
     f32x16 acc = zero16();
@@ -426,7 +429,7 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
                 if (a.kpm) ok = ok && (a.kpm[static_cast<int64_t>(b) * a.Lk + (key < a.Lk ? key : 0)] == 0);
                 const float p = ok ? fast_exp2(s[r] - L2) : 0.f;
                 float g = dp[r];
-                if (drop) g = keep_elem(a.seed, b, h, q, key, thresh) ? g * rinv : 0.f;
+                if (drop) g = keep_elem(seed_eff, b, h, q, key, thresh) ? g * rinv : 0.f;
                 ds[r] = p * (g - Dq);
             }
             acc = mfmaX<SP>(frag_cols<SP>(Kt, sub, 0, lane), frag_acc<SP>(ds, 0), acc);   // dQ^T[d][query]
@@ -474,6 +477,7 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
     if (a.kpm && kv) key_ok = a.kpm[static_cast<int64_t>(b) * a.Lk + key] == 0;
 
     const bool drop = a.dropout_p > 0.f;
+    const uint64_t seed_eff = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
     const unsigned thresh = drop ? static_cast<unsigned>(a.dropout_p * 4294967296.0) : 0u;
     const float rinv = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
     f32x16 acck = zero16(), accv = zero16();
@@ -513,7 +517,7 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
                 const float p = ok ? fast_exp2(s[r] - L2) : 0.f;
                 float g = dp[r], pk = p;
                 if (drop) {
-                    const bool kp = keep_elem(a.seed, b, h, qq, key, thresh);
+                    const bool kp = keep_elem(seed_eff, b, h, qq, key, thresh);
                     g = kp ? g * rinv : 0.f;
                     pk = kp ? p * rinv : 0.f;
                 }
@@ -543,7 +547,7 @@ AttnArgs make_args(const AttnProblem &p)
     a.B = p.B; a.H = p.H; a.Lq = p.Lq; a.Lk = p.Lk;
     a.q_bs = p.q_batch_stride; a.k_bs = p.k_batch_stride; a.v_bs = p.v_batch_stride;
     a.q_rs = p.q_row_stride; a.k_rs = p.k_row_stride; a.v_rs = p.v_row_stride;
-    a.scale = p.scale; a.dropout_p = p.dropout_p; a.seed = p.seed;
+    a.scale = p.scale; a.dropout_p = p.dropout_p; a.seed = p.seed; a.seed_dev = p.seed_dev;
     return a;
 }
 

@@ -220,7 +220,7 @@ static int attn_check(const char *who, int dtype, const void *q, const void *k, 
 int mdetr_attn_forward(int dtype, const void *q, const void *k, const void *v, const uint8_t *key_padding_mask,
                        void *out, float *lse, int B, int H, int Lq, int Lk,
                        int64_t q_bs, int64_t k_bs, int64_t v_bs, int q_rs, int k_rs, int v_rs,
-                       float scale, float dropout_p, uint64_t seed, int device, void *stream)
+                       float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev, int device, void *stream)
 {
     if (int rc = attn_check("mdetr_attn_forward", dtype, q, k, v, B, H, Lq, Lk, q_rs, k_rs, v_rs)) return rc;
     if (B == 0 || Lq == 0) return MDETR_OK;
@@ -228,7 +228,7 @@ int mdetr_attn_forward(int dtype, const void *q, const void *k, const void *v, c
     if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(MDETR_E_ARG, "mdetr_attn_forward: dropout_p must be in [0, 1)");
     DeviceScope dev(device);
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_attn_forward: set device %d: %s", device, hipGetErrorString(dev.err));
-    mdetr::AttnProblem p{dtype, q, k, v, key_padding_mask, B, H, Lq, Lk, q_bs, k_bs, v_bs, q_rs, k_rs, v_rs, scale, dropout_p, seed};
+    mdetr::AttnProblem p{dtype, q, k, v, key_padding_mask, B, H, Lq, Lk, q_bs, k_bs, v_bs, q_rs, k_rs, v_rs, scale, dropout_p, seed, seed_dev};
     const hipError_t e = mdetr::attn_forward_launch(p, out, lse, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_attn_forward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
@@ -238,7 +238,7 @@ int mdetr_attn_backward(int dtype, const void *q, const void *k, const void *v, 
                         const void *out, const void *d_out, const float *lse, float *dsum,
                         void *dq, void *dk, void *dv, int B, int H, int Lq, int Lk,
                         int64_t q_bs, int64_t k_bs, int64_t v_bs, int q_rs, int k_rs, int v_rs,
-                        float scale, float dropout_p, uint64_t seed, int device, void *stream)
+                        float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev, int device, void *stream)
 {
     if (int rc = attn_check("mdetr_attn_backward", dtype, q, k, v, B, H, Lq, Lk, q_rs, k_rs, v_rs)) return rc;
     if (B == 0) return MDETR_OK;
@@ -248,7 +248,7 @@ int mdetr_attn_backward(int dtype, const void *q, const void *k, const void *v, 
         return fail(MDETR_E_ALIGN, "mdetr_attn_backward: tensors must be 16-byte aligned");
     DeviceScope dev(device);
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_attn_backward: set device %d: %s", device, hipGetErrorString(dev.err));
-    mdetr::AttnProblem p{dtype, q, k, v, key_padding_mask, B, H, Lq, Lk, q_bs, k_bs, v_bs, q_rs, k_rs, v_rs, scale, dropout_p, seed};
+    mdetr::AttnProblem p{dtype, q, k, v, key_padding_mask, B, H, Lq, Lk, q_bs, k_bs, v_bs, q_rs, k_rs, v_rs, scale, dropout_p, seed, seed_dev};
     const hipError_t e = mdetr::attn_backward_launch(p, out, d_out, lse, dsum, dq, dk, dv, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_attn_backward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;

@@ -29,7 +29,12 @@ def integer_corners(gt_boxes2d, downsample_factor=1):
     return torch.cat((torch.floor(b[:, :2]), torch.ceil(b[:, 2:])), 1).long()
 
 
-def image_index(num_gt_per_img, device):
+def image_index(num_gt_per_img, device, num_images=None):
+    """Image index of every box.  `num_gt_per_img` is the reference's per-image list of counts, or an
+    int K meaning "every image has exactly K (padded) slots" -- the static-shape form, which needs
+    `num_images` and involves no data-dependent sizes."""
+    if isinstance(num_gt_per_img, int):
+        return torch.arange(num_images, device=device).repeat_interleave(num_gt_per_img)
     counts = torch.as_tensor(num_gt_per_img, device=device)
     return torch.repeat_interleave(torch.arange(len(num_gt_per_img), device=device), counts)
 
@@ -42,7 +47,7 @@ def compute_fg_mask(gt_boxes2d, shape, num_gt_per_img, downsample_factor=1, devi
         return fg
     cover = box_cover(integer_corners(gt_boxes2d, downsample_factor), H, W)
     fg = torch.zeros((B, H, W), dtype=torch.int32, device=device).index_add_(
-        0, image_index(num_gt_per_img, device), cover.to(torch.int32)) > 0
+        0, image_index(num_gt_per_img, device, B), cover.to(torch.int32)) > 0
     return fg
 
 

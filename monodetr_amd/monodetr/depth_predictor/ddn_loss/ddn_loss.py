@@ -19,16 +19,18 @@ class DDNLoss(nn.Module):
         self.alpha, self.gamma = alpha, gamma
         self.loss_func = FocalLoss(alpha=self.alpha, gamma=self.gamma, reduction="none")
 
-    def build_target_depth_from_3dcenter(self, depth_logits, gt_boxes2d, gt_center_depth, num_gt_per_img):
+    def build_target_depth_from_3dcenter(self, depth_logits, gt_boxes2d, gt_center_depth, num_gt_per_img, valid=None):
         B, _, H, W = depth_logits.shape
         maps = torch.zeros((B, H, W), device=depth_logits.device, dtype=depth_logits.dtype)
         if gt_boxes2d.shape[0] == 0:
             return maps
         cover = box_cover(integer_corners(gt_boxes2d), H, W)                       # [K, H, W]
+        if valid is not None:
+            cover = cover & valid.view(-1, 1, 1)
         depth = gt_center_depth.to(maps.dtype).view(-1, 1, 1)
         painted = torch.where(cover, depth, torch.full_like(depth, float("inf")).expand_as(cover))
         nearest = torch.full((B, H, W), float("inf"), device=maps.device, dtype=maps.dtype)
-        nearest.index_reduce_(0, image_index(num_gt_per_img, maps.device), painted, "amin")
+        nearest.index_reduce_(0, image_index(num_gt_per_img, maps.device, B), painted, "amin")
         return torch.where(torch.isinf(nearest), maps, nearest)
 
     def bin_depths(self, depth_map, mode="LID", depth_min=1e-3, depth_max=60, num_bins=80, target=False):
@@ -47,10 +49,11 @@ class DDNLoss(nn.Module):
             indices = torch.where(bad, torch.full_like(indices, num_bins), indices).type(torch.int64)
         return indices
 
-    def forward(self, depth_logits, gt_boxes2d, num_gt_per_img, gt_center_depth):
+    def forward(self, depth_logits, gt_boxes2d, num_gt_per_img, gt_center_depth, valid=None):
         """depth_logits [B, D+1, H, W]; gt_boxes2d [K, 4] xyxy in depth-map pixels (all images
-        concatenated); num_gt_per_img list; gt_center_depth [K]."""
+        concatenated); num_gt_per_img: list of per-image counts, or an int K for the padded static form
+        (then `valid` [B*K] marks the real boxes and padded boxes are all-zero); gt_center_depth [K]."""
         target = self.bin_depths(self.build_target_depth_from_3dcenter(
-            depth_logits, gt_boxes2d, gt_center_depth, num_gt_per_img), target=True)
+            depth_logits, gt_boxes2d, gt_center_depth, num_gt_per_img, valid), target=True)
         return self.balancer(loss=self.loss_func(depth_logits, target), gt_boxes2d=gt_boxes2d,
                              num_gt_per_img=num_gt_per_img)

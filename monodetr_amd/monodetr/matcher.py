@@ -75,6 +75,62 @@ class HungarianMatcher(nn.Module):
                 for l in range(Ly)]
 
     @torch.no_grad()
+    def cost_padded(self, logits, boxes, gt):
+        """logits [L,B,Q,C], boxes [L,B,Q,6], padded ground truth -> cost [L,B,Q,K] (same terms as
+        `cost_matrix`, evaluated per image against that image's K target slots only)."""
+        if logits.dtype in (torch.float16, torch.bfloat16):
+            logits, boxes = logits.float(), boxes.float()
+        L, B, Q, _ = logits.shape
+        K = gt["valid"].shape[1]
+        prob = logits.sigmoid()
+        alpha, gamma = 0.25, 2.0
+        neg = (1 - alpha) * (prob ** gamma) * (-(1 - prob + 1e-8).log())
+        pos = alpha * ((1 - prob) ** gamma) * (-(prob + 1e-8).log())
+        lab = gt["labels"][None, :, None, :].expand(L, B, Q, K)
+        c_class = (pos - neg).gather(-1, lab)
+        tb = gt["boxes_3d"].to(boxes.dtype)[None, :, None, :, :]                     # [1,B,1,K,6]
+        pb = boxes[:, :, :, None, :]                                                 # [L,B,Q,1,6]
+        c_center = (pb[..., 0:2] - tb[..., 0:2]).abs().sum(-1)
+        c_bbox = (pb[..., 2:6] - tb[..., 2:6]).abs().sum(-1)
+        p_xyxy, t_xyxy = box_cxcylrtb_to_xyxy(pb), box_cxcylrtb_to_xyxy(tb)
+        wh = (torch.min(p_xyxy[..., 2:], t_xyxy[..., 2:]) - torch.max(p_xyxy[..., :2], t_xyxy[..., :2])).clamp(min=0)
+        inter = wh[..., 0] * wh[..., 1]
+        area_p = (p_xyxy[..., 2] - p_xyxy[..., 0]) * (p_xyxy[..., 3] - p_xyxy[..., 1])
+        area_t = (t_xyxy[..., 2] - t_xyxy[..., 0]) * (t_xyxy[..., 3] - t_xyxy[..., 1])
+        union = area_p + area_t - inter
+        hw = (torch.max(p_xyxy[..., 2:], t_xyxy[..., 2:]) - torch.min(p_xyxy[..., :2], t_xyxy[..., :2])).clamp(min=0)
+        hull = hw[..., 0] * hw[..., 1]
+        c_giou = -(inter / union - (hull - union) / hull)
+        return self.cost_bbox * c_bbox + self.cost_3dcenter * c_center + self.cost_class * c_class + self.cost_giou * c_giou
+
+    @torch.no_grad()
+    def assign_padded(self, layer_outputs, gt, group_num=11):
+        """Assignment of every decoder layer in static shape: [L, B, G, K] int64, the matched query of
+        each target slot (-1 for padded slots).  On the GPU the problems are solved by the device
+        Hungarian kernel (csrc/lsa.hip) with no host synchronisation; on CPU tensors by scipy, as the
+        reference does everywhere."""
+        logits = torch.stack([o["pred_logits"] for o in layer_outputs])
+        boxes = torch.stack([o["pred_boxes"] for o in layer_outputs])
+        L, B, Q, _ = logits.shape
+        K = gt["valid"].shape[1]
+        C = self.cost_padded(logits, boxes, gt)
+        n = Q // group_num
+        if C.is_cuda and n <= 64 and K <= n:
+            from ..lsa_ext import batched_assignment
+            return batched_assignment(C.float(), gt["num"], group_num).long()
+        Ch = C.double().cpu().numpy()
+        sizes = gt["num_host"] if gt.get("num_host") is not None else gt["num"].tolist()
+        out = -np.ones((L, B, group_num, K), dtype=np.int64)
+        for l in range(L):
+            for b in range(B):
+                k = int(sizes[b])
+                for g in range(group_num):
+                    if k:
+                        r, c = linear_sum_assignment(Ch[l, b, g * n:(g + 1) * n, :k])
+                        out[l, b, g, c] = r + g * n
+        return torch.from_numpy(out).to(C.device)
+
+    @torch.no_grad()
     def forward(self, outputs, targets, group_num=11):
         """outputs: {'pred_logits' [B,Q,C], 'pred_boxes' [B,Q,6]}; targets: list of dicts with 'labels',
         'boxes', 'boxes_3d'.  Returns a list (one per image) of (index_i, index_j)."""

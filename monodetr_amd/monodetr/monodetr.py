@@ -181,27 +181,88 @@ class MonoDETR(nn.Module):
                                          outputs_angle[:-1], outputs_depth[:-1])]
 
 
-class _Matched:
-    """Index triple of one decoder layer's assignment: image, query and (global) target index of
-    every matched pair, plus the ground truth gathered in that order."""
+# ---- ground truth in static shape ----------------------------------------------------------------
+_DUMMY_BOX3D = (0.5, 0.5, 0.1, 0.1, 0.1, 0.1)       # benign stand-in for padded slots (keeps every formula finite)
 
-    def __init__(self, indices, gt, device):
-        offs = gt["offsets"]
-        img = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
-        qry = torch.cat([src for src, _ in indices])
-        tgt = torch.cat([j + offs[i] for i, (_, j) in enumerate(indices)])
-        packed = torch.stack((img, qry, tgt)).to(device, non_blocking=True)       # one H2D copy
-        self.img, self.qry, self.tgt = packed[0], packed[1], packed[2]
-        self.idx = (self.img, self.qry)
+
+def pad_targets(targets, kmax=None):
+    """list (one per image) of target dicts -> dict of [B, K, ...] tensors padded to K = kmax (default:
+    the largest image), plus `valid` [B, K] bool and `num` [B] int32.  Padded slots hold harmless
+    values and are masked out of every loss.  This is the only place where the ragged list is
+    touched; everything downstream has shapes that do not depend on the number of objects, which is
+    what lets the criterion run without host synchronisation (and inside a hipGraph)."""
+    B = len(targets)
+    sizes = [int(t["labels"].shape[0]) for t in targets]
+    K = max(max(sizes) if sizes else 0, 1) if kmax is None else int(kmax)
+    assert all(s <= K for s in sizes), "an image has more objects than kmax"
+    dev = targets[0]["labels"].device
+    fdt = targets[0]["boxes_3d"].dtype
+
+    def padded(key, shape, dtype, fill):
+        out = torch.empty((B, K) + shape, dtype=dtype, device=dev)
+        out[...] = torch.as_tensor(fill, dtype=dtype, device=dev)
+        for b, t in enumerate(targets):
+            if sizes[b] and key in t:
+                out[b, :sizes[b]] = t[key].reshape((sizes[b],) + shape).to(dtype)
+        return out
+
+    gt = {
+        "labels": padded("labels", (), torch.int64, 0),
+        "boxes": padded("boxes", (4,), fdt, (0.0, 0.0, 0.0, 0.0)),
+        "boxes_3d": padded("boxes_3d", (6,), fdt, _DUMMY_BOX3D),
+        "depth": padded("depth", (), fdt, 1.0),
+        "size_3d": padded("size_3d", (3,), fdt, (1.0, 1.0, 1.0)),
+        "heading_bin": padded("heading_bin", (), torch.int64, 0),
+        "heading_res": padded("heading_res", (), fdt, 0.0),
+    }
+    num = torch.tensor(sizes, dtype=torch.int32)
+    gt["valid"] = (torch.arange(K)[None, :] < num[:, None]).to(dev)
+    gt["num"] = num.to(dev)
+    gt["num_host"] = sizes
+    return gt
+
+
+def assignment_from_indices(indices, gt, Q, group_num):
+    """Reference-style matcher output (per image (query idx, target idx)) -> [B, G, K] int64, -1 = none."""
+    B, K = gt["valid"].shape
+    n = Q // group_num
+    a = torch.full((B, group_num, K), -1, dtype=torch.int64)
+    for b, (src, tgt) in enumerate(indices):
+        src, tgt = src.to("cpu", torch.int64), tgt.to("cpu", torch.int64)
+        if src.numel():
+            a[b, torch.div(src, n, rounding_mode="floor"), tgt] = src
+    return a.to(gt["valid"].device)
+
+
+class _Pairs:
+    """All (image, group, target-slot) pairs of one decoder layer in static shape [B, G, K]: the matched
+    query index (0 for unmatched / padded slots), the validity mask, and helpers to gather."""
+
+    def __init__(self, assign, gt):
         self.gt = gt
+        self.ok = (assign >= 0) & gt["valid"][:, None, :]
+        self.q = assign.clamp(min=0)
+        B, G, K = assign.shape
+        self.b = torch.arange(B, device=assign.device).view(B, 1, 1).expand(B, G, K)
 
-    def target(self, key):
-        return self.gt[key][self.tgt]
+    def pred(self, x):                        # x [B, Q, D] -> [B, G, K, D]
+        return x[self.b, self.q]
+
+    def target(self, key):                    # gt[key] [B, K, ...] -> broadcast over groups [B, G, K, ...]
+        t = self.gt[key]
+        return t[:, None].expand((t.shape[0], self.q.shape[1]) + tuple(t.shape[1:]))
+
+    def msum(self, x):                        # sum of x [B, G, K] over valid pairs
+        return torch.where(self.ok, x, torch.zeros((), dtype=x.dtype, device=x.device)).sum()
 
 
 class SetCriterion(nn.Module):
     """Hungarian matching of predictions to ground truth, then the eight MonoDETR losses on the
-    matched pairs, for the last decoder layer and (auxiliary) every earlier one."""
+    matched pairs, for the last decoder layer and (auxiliary) every earlier one.
+
+    Everything after `pad_targets` is shape-static: pairs are [B, G, K] with a validity mask, the
+    assignment comes from the device solver on the GPU (scipy on CPU tensors), `num_boxes` may stay a
+    device scalar.  Accepts the reference's list-of-dicts targets or an already padded dict."""
 
     def __init__(self, num_classes, matcher, weight_dict, focal_alpha, losses, group_num=11):
         super().__init__()
@@ -213,130 +274,123 @@ class SetCriterion(nn.Module):
         self.ddn_loss = DDNLoss()
         self.group_num = group_num
 
-    # ---- ground truth, concatenated once per call ------------------------------------------------
-    @staticmethod
-    def _gather_targets(targets):
-        sizes = [len(t["labels"]) for t in targets]
-        gt = {k: torch.cat([t[k] for t in targets], 0)
-              for k in ("labels", "boxes", "boxes_3d", "depth", "size_3d", "heading_bin", "heading_res") if k in targets[0]}
-        gt["sizes"] = sizes
-        gt["offsets"] = [0] + list(torch.tensor(sizes).cumsum(0).tolist())[:-1]
-        return gt
-
-    def _matched(self, indices, targets, outputs, gt=None):
-        gt = gt if gt is not None else self._gather_targets(targets)
-        return _Matched(indices, gt, outputs["pred_logits"].device)
-
-    # ---- individual losses (reference :320-458); `m` is a _Matched -----------------------------
-    def loss_labels(self, outputs, targets, indices, num_boxes, log=True, m=None):
-        m = m or self._matched(indices, targets, outputs)
+    # ---- individual losses (reference :320-458) on a _Pairs ---------------------------------------
+    def _labels(self, outputs, pr, num_boxes, log=True):
         logits = outputs['pred_logits']
-        labels_o = m.target("labels").reshape(-1).long()
-        classes = torch.full(logits.shape[:2], self.num_classes, dtype=torch.int64, device=logits.device)
-        classes[m.idx] = labels_o
-        onehot = F.one_hot(classes, self.num_classes + 1)[..., :-1].to(logits.dtype)
-        losses = {'loss_ce': sigmoid_focal_loss(logits, onehot, num_boxes, alpha=self.focal_alpha, gamma=2) * logits.shape[1]}
+        B, Q, C = logits.shape
+        labels = pr.target("labels")
+        # scatter the matched labels; unmatched / padded pairs go to a dummy (Q-th) query that is dropped
+        classes = torch.full((B, Q + 1), self.num_classes, dtype=torch.int64, device=logits.device)
+        classes.scatter_(1, torch.where(pr.ok, pr.q, torch.full_like(pr.q, Q)).reshape(B, -1), labels.reshape(B, -1))
+        onehot = F.one_hot(classes[:, :Q], self.num_classes + 1)[..., :-1].to(logits.dtype)
+        losses = {'loss_ce': sigmoid_focal_loss(logits, onehot, num_boxes, alpha=self.focal_alpha, gamma=2) * Q}
         if log:
-            losses['class_error'] = 100 - accuracy(logits[m.idx], labels_o)[0]
+            with torch.no_grad():
+                hit = (pr.pred(logits).argmax(-1) == labels) & pr.ok
+                nmatch = pr.ok.sum()
+                acc = torch.where(nmatch > 0, hit.sum() * 100.0 / nmatch.clamp(min=1), torch.zeros((), device=logits.device))
+            losses['class_error'] = 100 - acc
         return losses
 
     @torch.no_grad()
-    def loss_cardinality(self, outputs, targets, indices, num_boxes, m=None):
+    def _cardinality(self, outputs, pr, num_boxes):
         logits = outputs['pred_logits']
-        sizes = m.gt["sizes"] if m is not None else [len(v["labels"]) for v in targets]
-        tgt_lengths = torch.as_tensor(sizes, device=logits.device)
         card_pred = (logits.argmax(-1) != logits.shape[-1] - 1).sum(1)
-        return {'cardinality_error': F.l1_loss(card_pred.float(), tgt_lengths.float())}
+        return {'cardinality_error': F.l1_loss(card_pred.float(), pr.gt["num"].float())}
 
-    def loss_3dcenter(self, outputs, targets, indices, num_boxes, m=None):
-        m = m or self._matched(indices, targets, outputs)
-        src = outputs['pred_boxes'][:, :, 0:2][m.idx]
-        return {'loss_center': F.l1_loss(src, m.target('boxes_3d')[:, 0:2], reduction='none').sum() / num_boxes}
+    def _center(self, outputs, pr, num_boxes):
+        d = (pr.pred(outputs['pred_boxes'])[..., 0:2] - pr.target('boxes_3d')[..., 0:2]).abs().sum(-1)
+        return {'loss_center': pr.msum(d) / num_boxes}
 
-    def loss_boxes(self, outputs, targets, indices, num_boxes, m=None):
-        m = m or self._matched(indices, targets, outputs)
-        src, tgt = outputs['pred_boxes'][m.idx], m.target('boxes_3d')
-        giou = box_ops.elementwise_giou(box_ops.box_cxcylrtb_to_xyxy(src), box_ops.box_cxcylrtb_to_xyxy(tgt))
-        return {'loss_bbox': F.l1_loss(src[:, 2:6], tgt[:, 2:6], reduction='none').sum() / num_boxes,
-                'loss_giou': (1 - giou).sum() / num_boxes}
+    def _boxes(self, outputs, pr, num_boxes):
+        src, tgt = pr.pred(outputs['pred_boxes']), pr.target('boxes_3d')
+        src = torch.where(pr.ok[..., None], src, tgt)                # padded pairs: identical boxes, finite GIoU
+        l1 = (src[..., 2:6] - tgt[..., 2:6]).abs().sum(-1)
+        giou = box_ops.elementwise_giou(box_ops.box_cxcylrtb_to_xyxy(src).reshape(-1, 4),
+                                        box_ops.box_cxcylrtb_to_xyxy(tgt).reshape(-1, 4)).view_as(l1)
+        return {'loss_bbox': pr.msum(l1) / num_boxes, 'loss_giou': pr.msum(1 - giou) / num_boxes}
 
-    def loss_depths(self, outputs, targets, indices, num_boxes, m=None):
-        m = m or self._matched(indices, targets, outputs)
-        src = outputs['pred_depth'][m.idx]
-        tgt = m.target('depth').reshape(-1)
-        mu, log_var = src[:, 0], src[:, 1]                     # Laplacian aleatoric uncertainty (:398-399)
+    def _depths(self, outputs, pr, num_boxes):
+        src, tgt = pr.pred(outputs['pred_depth']), pr.target('depth')
+        mu, log_var = src[..., 0], src[..., 1]                      # Laplacian aleatoric uncertainty (:398-399)
+        log_var = torch.where(pr.ok, log_var, torch.zeros_like(log_var))
         loss = 1.4142 * torch.exp(-log_var) * torch.abs(mu - tgt) + log_var
-        return {'loss_depth': loss.sum() / num_boxes}
+        return {'loss_depth': pr.msum(loss) / num_boxes}
 
-    def loss_dims(self, outputs, targets, indices, num_boxes, m=None):
-        m = m or self._matched(indices, targets, outputs)
-        src, tgt = outputs['pred_3d_dim'][m.idx], m.target('size_3d')
-        rel = torch.abs(src - tgt) / tgt.detach()              # dimension-aware L1 (:410-416)
-        with torch.no_grad():
-            comp = F.l1_loss(src, tgt) / rel.mean()
-        return {'loss_dim': (rel * comp).sum() / num_boxes}
+    def _dims(self, outputs, pr, num_boxes):
+        src, tgt = pr.pred(outputs['pred_3d_dim']), pr.target('size_3d')
+        diff = torch.abs(src - tgt)
+        rel = diff / tgt.detach()                                   # dimension-aware L1 (:410-416)
+        ok3 = pr.ok[..., None].expand_as(diff)
+        zero = torch.zeros((), dtype=diff.dtype, device=diff.device)
+        with torch.no_grad():                                       # mean |d| / mean relative |d| over the matched pairs
+            comp = torch.where(ok3, diff, zero).sum() / torch.where(ok3, rel, zero).sum().clamp(min=1e-12)
+        return {'loss_dim': torch.where(ok3, rel * comp, zero).sum() / num_boxes}
 
-    def loss_angles(self, outputs, targets, indices, num_boxes, m=None):
-        m = m or self._matched(indices, targets, outputs)
-        pred = outputs['pred_angle'][m.idx].view(-1, 24)
-        bins = m.target('heading_bin').view(-1).long()
-        res = m.target('heading_res').view(-1)
-        cls_loss = F.cross_entropy(pred[:, 0:12], bins, reduction='none')
-        pred_res = pred[:, 12:24].gather(1, bins.view(-1, 1)).squeeze(1)       # residual of the true bin
-        return {'loss_angle': (cls_loss + F.l1_loss(pred_res, res, reduction='none')).sum() / num_boxes}
+    def _angles(self, outputs, pr, num_boxes):
+        pred = pr.pred(outputs['pred_angle'])                        # [B, G, K, 24]
+        bins, res = pr.target('heading_bin'), pr.target('heading_res')
+        cls_loss = F.cross_entropy(pred[..., 0:12].reshape(-1, 12), bins.reshape(-1), reduction='none').view_as(res)
+        pred_res = pred[..., 12:24].gather(-1, bins[..., None]).squeeze(-1)       # residual of the true bin
+        return {'loss_angle': pr.msum(cls_loss + (pred_res - res).abs()) / num_boxes}
 
-    def loss_depth_map(self, outputs, targets, indices, num_boxes, m=None):
+    def _depth_map(self, outputs, pr, num_boxes):
         logits = outputs['pred_depth_map_logits']
-        gt = m.gt if m is not None else self._gather_targets(targets)
+        gt = pr.gt
         H, W = logits.shape[-2:]
         scale = torch.tensor([W, H, W, H], dtype=gt["boxes"].dtype, device=gt["boxes"].device)   # 80,24,80,24 at 384x1280
         boxes = box_ops.box_cxcywh_to_xyxy(gt["boxes"] * scale)
-        return {"loss_depth_map": self.ddn_loss(logits, boxes, gt["sizes"], gt["depth"].squeeze(dim=1))}
+        boxes = torch.where(gt["valid"][..., None], boxes, torch.zeros_like(boxes))              # padded slots cover nothing
+        return {"loss_depth_map": self.ddn_loss(logits, boxes.reshape(-1, 4), gt["valid"].shape[1], gt["depth"].reshape(-1),
+                                                valid=gt["valid"].reshape(-1))}
 
-    def _get_src_permutation_idx(self, indices):
-        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
-        return batch_idx, torch.cat([src for (src, _) in indices])
+    _LOSSES = {'labels': '_labels', 'cardinality': '_cardinality', 'boxes': '_boxes', 'depths': '_depths',
+               'dims': '_dims', 'angles': '_angles', 'center': '_center', 'depth_map': '_depth_map'}
 
-    def _get_tgt_permutation_idx(self, indices):
-        batch_idx = torch.cat([torch.full_like(tgt, i) for i, (_, tgt) in enumerate(indices)])
-        return batch_idx, torch.cat([tgt for (_, tgt) in indices])
+    def _get(self, loss, outputs, pr, num_boxes, **kwargs):
+        assert loss in self._LOSSES, f'do you really want to compute {loss} loss?'
+        return getattr(self, self._LOSSES[loss])(outputs, pr, num_boxes, **kwargs)
 
     def get_loss(self, loss, outputs, targets, indices, num_boxes, **kwargs):
-        loss_map = {'labels': self.loss_labels, 'cardinality': self.loss_cardinality, 'boxes': self.loss_boxes,
-                    'depths': self.loss_depths, 'dims': self.loss_dims, 'angles': self.loss_angles,
-                    'center': self.loss_3dcenter, 'depth_map': self.loss_depth_map}
-        assert loss in loss_map, f'do you really want to compute {loss} loss?'
-        return loss_map[loss](outputs, targets, indices, num_boxes, **kwargs)
+        """Reference signature (:466-481): `indices` is the matcher's list of (query idx, target idx)."""
+        gt = targets if isinstance(targets, dict) else pad_targets(targets)
+        Q = outputs['pred_logits'].shape[1]
+        G = self.group_num if Q % self.group_num == 0 and Q // self.group_num * self.group_num == Q and self.training else 1
+        assign = assignment_from_indices(indices, gt, Q, G)
+        return self._get(loss, _widen(outputs), _Pairs(assign, gt), num_boxes, **kwargs)
 
     def forward(self, outputs, targets, mask_dict=None):
         """outputs: the model's dict; targets: list (one per image) of dicts with 'labels', 'boxes',
-        'boxes_3d', 'depth', 'size_3d', 'heading_bin', 'heading_res'.  Returns {name: 0-d tensor}."""
-        def widen(d):
-            return {k: (v.float() if torch.is_tensor(v) and v.dtype in (torch.bfloat16, torch.float16) else v) for k, v in d.items()}
-        final = widen({k: v for k, v in outputs.items() if k != 'aux_outputs'})
-        layers = [final] + [widen(a) for a in outputs.get('aux_outputs', [])]
+        'boxes_3d', 'depth', 'size_3d', 'heading_bin', 'heading_res' -- or the dict `pad_targets`
+        makes of it.  Returns {name: 0-d tensor}."""
+        final = _widen({k: v for k, v in outputs.items() if k != 'aux_outputs'})
+        layers = [final] + [_widen(a) for a in outputs.get('aux_outputs', [])]
         group_num = self.group_num if self.training else 1
-        all_indices = self.matcher.match_layers(layers, targets, group_num=group_num)
+        gt = targets if isinstance(targets, dict) else pad_targets(targets)
+        assign = self.matcher.assign_padded(layers, gt, group_num)           # [L, B, G, K], -1 = none
 
-        num_boxes = sum(len(t["labels"]) for t in targets) * group_num
-        if is_dist_avail_and_initialized():
-            nb = torch.as_tensor([num_boxes], dtype=torch.float, device=final["pred_logits"].device)
-            torch.distributed.all_reduce(nb)
-            num_boxes = torch.clamp(nb / get_world_size(), min=1)[0]          # stays on device: no sync
-        else:
-            num_boxes = max(float(num_boxes), 1.0)
+        if gt.get("num_host") is not None and not is_dist_avail_and_initialized():
+            num_boxes = max(float(sum(gt["num_host"]) * group_num), 1.0)
+        else:                                                               # stays on the device: no sync
+            nb = gt["num"].sum().to(torch.float32) * group_num
+            if is_dist_avail_and_initialized():
+                torch.distributed.all_reduce(nb)
+            num_boxes = torch.clamp(nb / get_world_size(), min=1)
 
-        gt = self._gather_targets(targets)
         losses = {}
-        for li, (layer_out, indices) in enumerate(zip(layers, all_indices)):
-            m = _Matched(indices, gt, final["pred_logits"].device)
+        for li, layer_out in enumerate(layers):
+            pr = _Pairs(assign[li], gt)
             for loss in self.losses:
                 if li > 0 and loss == 'depth_map':       # depth-map loss only on the final layer (:521-523)
                     continue
                 kwargs = {'log': False} if (li > 0 and loss == 'labels') else {}
-                ld = self.get_loss(loss, layer_out, targets, indices, num_boxes, m=m, **kwargs)
+                ld = self._get(loss, layer_out, pr, num_boxes, **kwargs)
                 losses.update(ld if li == 0 else {k + f'_{li - 1}': v for k, v in ld.items()})
         return losses
+
+
+def _widen(d):
+    return {k: (v.float() if torch.is_tensor(v) and v.dtype in (torch.bfloat16, torch.float16) else v) for k, v in d.items()}
 
 
 def build(cfg):
