@@ -75,7 +75,7 @@ def synthetic_batch(B, H, W, seed, device):
 class TrainStep:
     """model + criterion + optimizer on one device; __call__ runs one full training iteration."""
 
-    def __init__(self, device, batch, precision, seed=444, ddp=False, local_rank=0, size=(384, 1280)):
+    def __init__(self, device, batch, precision, seed=444, ddp=False, local_rank=0, size=(384, 1280), graph=False):
         from monodetr_amd.helpers.optimizer_helper import build_optimizer
         from monodetr_amd.monodetr import build_monodetr
         torch.manual_seed(seed)                               # same initial weights on every rank
@@ -96,7 +96,9 @@ class TrainStep:
             # receive gradients on the default path; bucket views avoid a grad copy
             self.model = DDP(self.model, device_ids=[local_rank], static_graph=True, gradient_as_bucket_view=True,
                              bucket_cap_mb=64)
-        self.optimizer = build_optimizer(OPT_CFG, self.raw_model)
+        self.optimizer = build_optimizer(dict(OPT_CFG, capturable=graph), self.raw_model)
+        self.graph = None
+        self.want_graph = graph
         self.precision = precision
         self.device = device
         H, W = size
@@ -106,7 +108,40 @@ class TrainStep:
         if precision == "bf16":
             self.inputs = (self.inputs[0].to(torch.bfloat16),) + self.inputs[1:]
 
+        if device.type == "cuda":
+            # the ragged per-image target lists are padded to KITTI's max_objs = 50 once, outside the step
+            # (the data loader's job: lib/datasets/kitti/kitti_dataset.py pads to max_objs the same way)
+            from monodetr_amd.monodetr.monodetr import pad_targets
+            padded = pad_targets(self.inputs[3], kmax=50)
+            if graph:
+                padded["num_host"] = None                    # normaliser computed on the device: replays must not bake it in
+            self.inputs = self.inputs[:3] + (padded,)
+
+    def capture(self, eager_steps=3):
+        """Record one whole training iteration (forward, criterion with on-device matching, backward,
+        optimizer) into a hipGraph; __call__ then replays it with one launch.  Warm-up and capture
+        share one side stream: autograd binds each parameter's AccumulateGrad node to the stream of
+        its first use, and a capture on any other stream would leave those nodes outside the graph."""
+        side = self.stream = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(eager_steps):                     # optimizer state, workspaces, geometry caches, MIOpen plans
+                self._step()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self.graph = torch.cuda.CUDAGraph()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph, stream=side):      # same stream as the warm-up: autograd's AccumulateGrad nodes are bound to it
+            self.loss = self._step()
+        return self
+
     def __call__(self):
+        if self.graph is not None:
+            self.graph.replay()
+            return self.loss
+        return self._step()
+
+    def _step(self):
         images, calibs, img_sizes, targets = self.inputs
         self.optimizer.zero_grad(set_to_none=True)
         with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.precision == "bf16-autocast"):
@@ -157,6 +192,10 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("MDETR_BENCH_PRECISION", "fp32"), choices=["fp32", "bf16", "bf16-autocast"],
                     help="bf16 = bf16 model body + fp32 heads + fp32 master weights (helpers/precision.py); "
                          "bf16-autocast = fp32 parameters under torch.autocast")
+    ap.add_argument("--graph", default=os.environ.get("MDETR_BENCH_GRAPH", "off"), choices=["on", "off"],
+                    help="on = replay the whole training iteration as one hipGraph (single GPU, experimental: see "
+                         "DESIGN.md 7 -- verified in fp32, worth <1%% once the host syncs were gone; bf16 replays are "
+                         "not reliable on this ROCm build)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=1)
     args = ap.parse_args()
@@ -178,14 +217,19 @@ def main():
 
     from monodetr_amd import _capi
     _capi.lib()                                                     # fail loudly if the HIP library is missing
-    step = TrainStep(device, args.batch, args.precision, ddp=world > 1, local_rank=local_rank)
+    use_graph = args.graph == "on"
+    if use_graph and world > 1:
+        raise SystemExit("--graph on is a single-GPU mode (the RCCL all-reduce of DDP is not captured)")
+    step = TrainStep(device, args.batch, args.precision, ddp=world > 1, local_rank=local_rank, graph=use_graph)
+    if use_graph:
+        step.capture()                                              # untimed: part of start-up, like model build
 
     for _ in range(args.warmup):
         step()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    _capi.profile_enable(True)
+    _capi.profile_enable(not use_graph)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -194,6 +238,18 @@ def main():
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
     _capi.profile_enable(False)
+    loss = loss.clone()
+    kernel_timing = "HIP events around every launch of the timed steps"
+    if use_graph:
+        # events cannot be recorded inside a replayed graph: time the same kernels, same inputs, in a few
+        # eager iterations right after the timed region
+        _capi.profile_enable(True)
+        with torch.cuda.stream(step.stream):                        # autograd's AccumulateGrad nodes live on this stream
+            for _ in range(3):
+                step._step()
+        torch.cuda.synchronize()
+        _capi.profile_enable(False)
+        kernel_timing = "HIP events around every launch of 3 eager iterations run right after the timed graph replays"
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -246,7 +302,8 @@ def main():
             "config": {"workload": "full MonoDETR training step (ResNet-50 + depth predictor + 3 enc / 3 dec layers, "
                                    "550 train queries, 4 levels, criterion + AdamW), BASELINE configs[2]/[3] shape",
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "image": "3x384x1280",
-                       "precision": args.precision, "parallelism": "dp%d" % world},
+                       "precision": args.precision, "parallelism": "dp%d" % world,
+                       "launch": "one hipGraph replay per iteration" if use_graph else "eager"},
             "final_loss": round(float(loss), 4),
         }
         if dom is not None:
@@ -255,6 +312,7 @@ def main():
                                 "bound": "hbm", "achieved": dom["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
                                 "frac": dom["frac"], "traffic": traffic.get("msda_backward_Lq%d" % dom["Lq"]),
                                 "avg_launch_ms": dom["ms"], "algorithmic_bytes": int(dom["algorithmic_MB"] * 1e6)}
+            line["roofline"]["timing"] = kernel_timing
             line["ops"] = ops
             line["kernels"] = kernels
         if world == 1 and not args.no_cpu_baseline:

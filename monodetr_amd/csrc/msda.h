@@ -36,6 +36,12 @@ hipError_t msda_tiled_grad_value_launch(const int64_t *shapes_h, const int64_t *
 hipError_t msda_indices_launch(int dtype, const int64_t *shapes, const void *loc, int32_t *idx,
                                int B, int M, int L, int Lq, int P, hipStream_t st);
 
+// Zero `bytes` bytes at p with a store kernel.  Used instead of hipMemsetAsync: inside a captured
+// hipGraph the memset NODE of a large, freshly mapped buffer was observed to leave stale data after
+// the process mapped more device memory between replays (gradients of the first MSDA backward of a
+// replay came back ~1e9); kernel nodes are not affected.
+hipError_t zero_fill_launch(void *p, int64_t bytes, hipStream_t st);
+
 // event-pair profiling of kernel launches (capi.hip owns the storage)
 void profile_begin(int kind, int Lq, hipStream_t st);
 void profile_end(hipStream_t st);

@@ -611,6 +611,34 @@ hipError_t msda_forward_launch(int dtype, const void *value, const int64_t *shap
     return hipGetLastError();
 }
 
+namespace {
+__global__ __launch_bounds__(256)
+void zero_fill_kernel(uint4 *__restrict__ body, int64_t n16, unsigned char *__restrict__ head, int head_bytes,
+                      unsigned char *__restrict__ tail, int tail_bytes)
+{
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    for (int64_t i = t; i < n16; i += stride) body[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (t < head_bytes) head[t] = 0;
+    if (t < tail_bytes) tail[t] = 0;
+}
+}  // namespace
+
+hipError_t zero_fill_launch(void *p, int64_t bytes, hipStream_t st)
+{
+    if (bytes <= 0) return hipSuccess;
+    unsigned char *b = static_cast<unsigned char *>(p);
+    int head = static_cast<int>((16 - (reinterpret_cast<uintptr_t>(b) & 15)) & 15);
+    if (head > bytes) head = static_cast<int>(bytes);
+    const int64_t n16 = (bytes - head) / 16;
+    const int tail = static_cast<int>(bytes - head - n16 * 16);
+    int64_t blocks = (n16 + 256 * 4 - 1) / (256 * 4);                // ~4 stores per thread
+    blocks = blocks < 1 ? 1 : (blocks > 256 * 32 ? 256 * 32 : blocks);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st,
+                       reinterpret_cast<uint4 *>(b + head), n16, b, head, b + head + n16 * 16, tail);
+    return hipGetLastError();
+}
+
 hipError_t msda_backward_launch_ex(int dtype, const void *value, const int64_t *shapes, const int64_t *lstart,
                                    const void *loc, const void *attn, const void *grad_out,
                                    void *grad_value, void *grad_loc, void *grad_attn,
@@ -621,13 +649,13 @@ hipError_t msda_backward_launch_ex(int dtype, const void *value, const int64_t *
     const size_t e = dtype == 0 ? 4 : 8;
     const int64_t nv = static_cast<int64_t>(B) * S * M * D, ns = static_cast<int64_t>(B) * Lq * M * L * P;
     hipError_t err;
-    if (nv && (err = hipMemsetAsync(grad_value, 0, nv * e, st)) != hipSuccess) return err;
+    if (nv && (err = zero_fill_launch(grad_value, nv * e, st)) != hipSuccess) return err;
     const int64_t n = static_cast<int64_t>(B) * Lq * M * D;
     if (n == 0 || ns == 0) return hipSuccess;
     const bool fast = msda_fast_path(dtype, D, L, P);
     if (!fast) {   // generic path accumulates grad_loc / grad_attn with atomics
-        if ((err = hipMemsetAsync(grad_loc, 0, ns * 2 * e, st)) != hipSuccess) return err;
-        if ((err = hipMemsetAsync(grad_attn, 0, ns * e, st)) != hipSuccess) return err;
+        if ((err = zero_fill_launch(grad_loc, ns * 2 * e, st)) != hipSuccess) return err;
+        if ((err = zero_fill_launch(grad_attn, ns * e, st)) != hipSuccess) return err;
     }
     if (fast) {
         static const int var_env = [] { const char *ev = getenv("MDETR_MSDA_BWD_VARIANT"); return ev ? atoi(ev) : -1; }();
@@ -637,7 +665,7 @@ hipError_t msda_backward_launch_ex(int dtype, const void *value, const int64_t *
                                msda_tiled_workspace_bytes(shapes_host, lstart_host, B, S, M, D, L, Lq, P) > 0 &&
                                msda_tiled_workspace_bytes(shapes_host, lstart_host, B, S, M, D, L, Lq, P) <= workspace_bytes;
         unsigned *absmax2 = try_tiled ? static_cast<unsigned *>(workspace) : nullptr;
-        if (try_tiled && (err = hipMemsetAsync(absmax2, 0, 8, st)) != hipSuccess) return err;
+        if (try_tiled && (err = zero_fill_launch(absmax2, 8, st)) != hipSuccess) return err;
         const int var = try_tiled ? 2 : (var_env == 0 ? 0 : 1);
         const int npairs = Lq * M, iters = rounds_per_block(B, npairs);
         const int chunks = (npairs + 32 * iters - 1) / (32 * iters);

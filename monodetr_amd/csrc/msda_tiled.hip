@@ -423,7 +423,7 @@ hipError_t msda_tiled_grad_value_launch(const int64_t *shapes_h, const int64_t *
     float *scratch = reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + 256);
     hipError_t err = hipSuccess;
     if (!absmax_ready) {
-        if ((err = hipMemsetAsync(absmax2, 0, 8, st)) != hipSuccess) return err;
+        if ((err = zero_fill_launch(absmax2, 8, st)) != hipSuccess) return err;
         const int64_t n_go = static_cast<int64_t>(B) * Lq * M * D, n_at = static_cast<int64_t>(B) * Lq * M * L * P;
         hipLaunchKernelGGL(absmax2_kernel, dim3(1024), dim3(256), 0, st, grad_out, n_go, attn, n_at, absmax2);
     }

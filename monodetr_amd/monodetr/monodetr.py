@@ -338,8 +338,8 @@ class SetCriterion(nn.Module):
         logits = outputs['pred_depth_map_logits']
         gt = pr.gt
         H, W = logits.shape[-2:]
-        scale = torch.tensor([W, H, W, H], dtype=gt["boxes"].dtype, device=gt["boxes"].device)   # 80,24,80,24 at 384x1280
-        boxes = box_ops.box_cxcywh_to_xyxy(gt["boxes"] * scale)
+        b = gt["boxes"]                                              # x (80, 24, 80, 24) at 384x1280, no host->device copy
+        boxes = box_ops.box_cxcywh_to_xyxy(torch.stack((b[..., 0] * W, b[..., 1] * H, b[..., 2] * W, b[..., 3] * H), -1))
         boxes = torch.where(gt["valid"][..., None], boxes, torch.zeros_like(boxes))              # padded slots cover nothing
         return {"loss_depth_map": self.ddn_loss(logits, boxes.reshape(-1, 4), gt["valid"].shape[1], gt["depth"].reshape(-1),
                                                 valid=gt["valid"].reshape(-1))}

@@ -54,3 +54,19 @@ def test_bf16_parameters_use_fp32_master_weights():
     # the master tracks the fp32 run closely (gradients differ only by their bf16 rounding)
     assert ((master - start16) - (w32.detach() - start)).abs().max() < 2e-2 * (w32.detach() - start).abs().max()
     assert (w32.detach() - start).abs().max() > 1e-3
+
+
+def test_capturable_mode_matches_host_step_size():
+    """capturable=True (device-resident step count and step size) follows the same trajectory."""
+    from monodetr_amd.helpers.optimizer_helper import build_optimizer
+    g = load_golden("optimizer_adamw")
+    model = make_model()
+    opt = build_optimizer({'type': 'adamw', 'lr': 2e-4, 'weight_decay': 1e-4, 'capturable': True}, model)
+    for step in range(6):
+        make_grads(model, step)
+        opt.step()
+    for n, p in model.named_parameters():
+        ref = g["step5/%s" % n]
+        # the step size is rounded to fp32 on the device: relative 6e-8 of an update of order lr
+        assert (p.detach() - ref).abs().max() < 1e-9, n
+    assert max(float(t) for t in opt.param_groups[0]['step_dev'].values()) == 6.0
