@@ -158,6 +158,20 @@ int mdetr_attn_backward(int dtype, const void *q, const void *k, const void *v, 
                         float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev, int device, void *stream);
 
 /*
+ * Column sums of a tall row-major matrix, accumulated in fp32: out[j] = sum_i x[i * ld + j].
+ * Not an entry point of the reference's extension: it is the bias gradient of the model's token-wise
+ * linear layers (db = sum over the 81 600 tokens of dY; torch's autograd computes it with a generic
+ * reduction -- reference call sites: every nn.Linear applied to the flattened feature pyramid, e.g.
+ * lib/models/monodetr/ops/modules/ms_deform_attn.py:80-83 and depthaware_transformer.py:331-333).
+ *   dtype      MDETR_F32 (cols % 4 == 0) or MDETR_BF16 (cols % 8 == 0); x and ld * sizeof(T) 16-byte aligned
+ *   out        fp32 [cols] (overwritten);  workspace  >= mdetr_column_sum_workspace_bytes(rows, cols)
+ * Deterministic (two passes in a fixed order, no atomics).
+ */
+int64_t mdetr_column_sum_workspace_bytes(int64_t rows, int cols);
+int mdetr_column_sum(int dtype, const void *x, float *out, void *workspace, int64_t workspace_bytes,
+                     int64_t rows, int cols, int64_t ld, int device, void *stream);
+
+/*
  * Batched linear sum assignment (Hungarian matching) on the device.  Replaces the host loop of
  * scipy.optimize.linear_sum_assignment calls in HungarianMatcher.forward (matcher.py:87-103: one
  * device->host copy and 3 x B x 11 solver calls per iteration).

@@ -1,0 +1,31 @@
+"""``column_sum(x)``: fp32 column sums of a tall 2-D tensor on the GPU (csrc/colsum.hip) -- the bias
+gradient of the token-wise linear layers.  CUDA tensors only; callers keep their own torch expression
+for everything else."""
+import torch
+
+from . import _capi
+
+_workspaces = {}
+
+
+def supported(x):
+    return (x.is_cuda and x.dim() == 2 and x.dtype in (torch.float32, torch.bfloat16) and x.stride(1) == 1
+            and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0
+            and (x.stride(0) * x.element_size()) % 16 == 0 and x.data_ptr() % 16 == 0 and x.shape[0] > 0)
+
+
+def column_sum(x):
+    """x [T, N] (f32 / bf16, unit column stride) -> fp32 [N]."""
+    if not supported(x):
+        raise RuntimeError("column_sum: needs a CUDA f32/bf16 matrix with 16-byte aligned rows")
+    T, N = x.shape
+    lib = _capi.lib()
+    need = lib.mdetr_column_sum_workspace_bytes(T, N)
+    ws = _workspaces.get(x.device)
+    if ws is None or ws.numel() < need:
+        ws = _workspaces[x.device] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    rc = lib.mdetr_column_sum(_capi.MDETR_BF16 if x.dtype == torch.bfloat16 else _capi.MDETR_F32, x.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                              T, N, x.stride(0), x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+    _capi.check(rc, "mdetr_column_sum")
+    return out

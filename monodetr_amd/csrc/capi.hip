@@ -12,6 +12,7 @@
 
 #include "../../include/monodetr_amd.h"
 #include "attn.h"
+#include "colsum.h"
 #include "lsa.h"
 #include "msda.h"
 
@@ -267,6 +268,30 @@ int mdetr_lsa_forward(const float *cost, const int32_t *num_targets, int32_t *as
     const hipError_t e = mdetr::lsa_launch(cost, num_targets, assign, layers, images, groups, n, kmax,
                                            img_stride, q_stride, t_stride, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_lsa_forward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int64_t mdetr_column_sum_workspace_bytes(int64_t rows, int cols)
+{
+    if (rows < 0 || cols < 0) return -1;
+    return mdetr::colsum_workspace_bytes(rows, cols);
+}
+
+int mdetr_column_sum(int dtype, const void *x, float *out, void *workspace, int64_t workspace_bytes,
+                     int64_t rows, int cols, int64_t ld, int device, void *stream)
+{
+    if (rows < 0 || cols < 0 || ld < cols) return fail(MDETR_E_ARG, "mdetr_column_sum: bad shape rows=%lld cols=%d ld=%lld",
+                                                      static_cast<long long>(rows), cols, static_cast<long long>(ld));
+    if (cols == 0) return MDETR_OK;
+    if (!out || !workspace || (rows > 0 && !x)) return fail(MDETR_E_ARG, "mdetr_column_sum: null pointer");
+    if (!mdetr::colsum_supported(dtype, cols, ld, x))
+        return fail(MDETR_E_ARG, "mdetr_column_sum: needs f32 (cols %% 4 == 0) or bf16 (cols %% 8 == 0), 16-byte aligned rows");
+    if (workspace_bytes < mdetr::colsum_workspace_bytes(rows, cols))
+        return fail(MDETR_E_ARG, "mdetr_column_sum: workspace too small");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_column_sum: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::colsum_launch(dtype, x, out, workspace, rows, cols, ld, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_column_sum: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

@@ -1,0 +1,140 @@
+// monodetr_amd/csrc/colsum.hip -- column sums of a tall row-major matrix (fp32 accumulation).
+//
+// The bias gradient of a token-wise linear layer is db[j] = sum_t dY[t, j] with T = 81 600 token rows
+// and 256 .. 1024 columns (27 such reductions per MonoDETR training step).  The framework's generic
+// reduction runs them at 0.2 - 0.6 TB/s (up to 260 us each); this is a pure HBM stream:
+//   stage 1: a block owns kRowsPerBlock consecutive rows; a thread owns one 16-byte column vector and
+//            every (256 / vectors-per-row)-th row, keeps VEC fp32 partial sums in registers, the row
+//            lanes are combined through LDS, one fp32 partial row per block goes to the workspace;
+//   stage 2: the partial rows are added in a fixed order (deterministic, no atomics).
+// Algorithmic bytes = rows * cols * sizeof(T) (read once).
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "colsum.h"
+
+namespace mdetr {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kRowsPerBlock = 256;
+
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void add(float *acc, const uint4 &v)
+    {
+        acc[0] += __uint_as_float(v.x); acc[1] += __uint_as_float(v.y);
+        acc[2] += __uint_as_float(v.z); acc[3] += __uint_as_float(v.w);
+    }
+};
+template <> struct Vec16<__hip_bfloat16> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void add(float *acc, const uint4 &v)
+    {
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                      // bf16 -> fp32 is a 16-bit shift
+            acc[2 * i] += __uint_as_float(w[i] << 16);
+            acc[2 * i + 1] += __uint_as_float(w[i] & 0xFFFF0000u);
+        }
+    }
+};
+
+// CT = column vectors handled per block row pass (power of two <= 256); row lanes = 256 / CT
+template <typename T>
+__global__ __launch_bounds__(kThreads)
+void colsum_partial_kernel(const T *__restrict__ x, float *__restrict__ partial, int64_t rows, int cols, int64_t ld, int CT)
+{
+    constexpr int VEC = Vec16<T>::N;
+    __shared__ float red[kThreads * VEC];
+    const int cvs = cols / VEC;
+    const int lane_c = threadIdx.x % CT, lane_r = threadIdx.x / CT, RL = kThreads / CT;
+    const int cv = blockIdx.y * CT + lane_c;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.x) * kRowsPerBlock;
+    const int64_t r1 = r0 + kRowsPerBlock < rows ? r0 + kRowsPerBlock : rows;
+    float acc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+    if (cv < cvs) {
+        const T *p = x + static_cast<int64_t>(cv) * VEC;
+        int64_t r = r0 + lane_r;
+        for (; r + 3 * RL < r1; r += 4 * RL) {             // four independent loads in flight
+            const uint4 a = *reinterpret_cast<const uint4 *>(p + r * ld);
+            const uint4 b = *reinterpret_cast<const uint4 *>(p + (r + RL) * ld);
+            const uint4 c = *reinterpret_cast<const uint4 *>(p + (r + 2 * RL) * ld);
+            const uint4 d = *reinterpret_cast<const uint4 *>(p + (r + 3 * RL) * ld);
+            Vec16<T>::add(acc, a); Vec16<T>::add(acc, b); Vec16<T>::add(acc, c); Vec16<T>::add(acc, d);
+        }
+        for (; r < r1; r += RL) Vec16<T>::add(acc, *reinterpret_cast<const uint4 *>(p + r * ld));
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[(lane_r * CT + lane_c) * VEC + i] = acc[i];
+    __syncthreads();
+    // thread t < CT * VEC sums scalar column (t) of this tile over the row lanes, in lane order
+    for (int t = threadIdx.x; t < CT * VEC; t += kThreads) {
+        float s = 0.f;
+        for (int l = 0; l < RL; ++l) s += red[l * CT * VEC + t];
+        const int col = blockIdx.y * CT * VEC + t;
+        if (col < cols) partial[static_cast<int64_t>(blockIdx.x) * cols + col] = s;
+    }
+}
+
+__global__ __launch_bounds__(kThreads)
+void colsum_final_kernel(const float *__restrict__ partial, float *__restrict__ out, int nblk, int cols)
+{
+    const int col = blockIdx.x * kThreads + threadIdx.x;
+    if (col >= cols) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) {
+        s0 += partial[static_cast<int64_t>(b) * cols + col];
+        s1 += partial[static_cast<int64_t>(b + 1) * cols + col];
+        s2 += partial[static_cast<int64_t>(b + 2) * cols + col];
+        s3 += partial[static_cast<int64_t>(b + 3) * cols + col];
+    }
+    for (; b < nblk; ++b) s0 += partial[static_cast<int64_t>(b) * cols + col];
+    out[col] = (s0 + s1) + (s2 + s3);
+}
+
+}  // namespace
+
+int64_t colsum_workspace_bytes(int64_t rows, int cols)
+{
+    const int64_t nblk = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
+    return nblk * cols * static_cast<int64_t>(sizeof(float));
+}
+
+bool colsum_supported(int dtype, int cols, int64_t ld, const void *x)
+{
+    const int vec = dtype == 2 ? 8 : 4, esz = dtype == 2 ? 2 : 4;
+    return (dtype == 0 || dtype == 2) && cols > 0 && cols % vec == 0 && (ld * esz) % 16 == 0 &&
+           (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+}
+
+hipError_t colsum_launch(int dtype, const void *x, float *out, void *workspace, int64_t rows, int cols, int64_t ld,
+                         hipStream_t st)
+{
+    if (cols == 0) return hipSuccess;
+    const int64_t nblk = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
+    float *partial = static_cast<float *>(workspace);
+    if (nblk > 0) {
+        const int vec = dtype == 2 ? 8 : 4;
+        const int cvs = cols / vec;
+        int CT = 1;
+        while (CT * 2 <= cvs && CT * 2 <= kThreads) CT *= 2;
+        const dim3 grid(static_cast<unsigned>(nblk), static_cast<unsigned>((cvs + CT - 1) / CT));
+        if (dtype == 2)
+            hipLaunchKernelGGL(colsum_partial_kernel<__hip_bfloat16>, grid, dim3(kThreads), 0, st,
+                               static_cast<const __hip_bfloat16 *>(x), partial, rows, cols, ld, CT);
+        else
+            hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(kThreads), 0, st,
+                               static_cast<const float *>(x), partial, rows, cols, ld, CT);
+    }
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
+                       partial, out, static_cast<int>(nblk), cols);
+    return hipGetLastError();
+}
+
+}  // namespace mdetr

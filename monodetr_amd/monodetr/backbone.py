@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..utils.misc import NestedTensor
+from .linear import pointwise_conv, pointwise_eligible
 from .position_encoding import build_position_encoding
 
 
@@ -76,7 +77,10 @@ def conv_bn(x, conv, bn, relu):
         else:
             w = (conv.weight * scale.to(conv.weight.dtype).view(-1, 1, 1, 1)).to(dt)
             b = shift.to(dt)
-        x = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if pointwise_eligible(x, conv.kernel_size, conv.stride, conv.padding, conv.groups) and x.dtype == w.dtype:
+            x = pointwise_conv(x, w, b)
+        else:
+            x = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
     else:
         x = bn(conv(x))
     return F.relu(x, inplace=True) if relu else x

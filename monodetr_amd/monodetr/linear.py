@@ -10,6 +10,9 @@ Pure library plumbing (torch.bmm -> hipBLASLt); numerics are those of a split-K 
 """
 import torch
 import torch.nn.functional as F
+from torch import nn
+
+from .. import colsum_ext
 
 _MIN_TOKENS = 4096
 
@@ -49,7 +52,10 @@ class _TokenLinear(torch.autograd.Function):
                 dw = dy2.t() @ x2
             dw = dw.to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = (dy2.view(C, T // C, -1).sum(1).sum(0) if C else dy2.sum(0)).to(weight.dtype)
+            if dy2.is_cuda and colsum_ext.supported(dy2):
+                db = colsum_ext.column_sum(dy2).to(weight.dtype)        # csrc/colsum.hip: one HBM pass, fp32 accumulation
+            else:
+                db = (dy2.view(C, T // C, -1).sum(1).sum(0) if C else dy2.sum(0)).to(weight.dtype)
         return dx, dw, db
 
 
@@ -59,3 +65,29 @@ def token_linear(x, weight, bias=None):
             and not torch.is_autocast_enabled():
         return _TokenLinear.apply(x, weight, bias)
     return F.linear(x, weight, bias)
+
+
+def pointwise_eligible(x, kernel_size, stride, padding, groups):
+    return (x.is_cuda and tuple(kernel_size) == (1, 1) and tuple(stride) == (1, 1) and tuple(padding) == (0, 0)
+            and groups == 1 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def pointwise_conv(x, weight, bias=None):
+    """1x1 stride-1 convolution of a channels_last activation == a linear layer over its B*H*W tokens:
+    the [B,H,W,C] permutation is a view, the GEMMs go to hipBLASLt (which runs these memory-bound
+    shapes near the HBM roofline) and the weight gradient takes `token_linear`'s split-K path; MIOpen's
+    implicit-GEMM kernels plus their cast / zero-fill helpers took 2-3x as long on the same shapes."""
+    B, C, H, W = x.shape
+    y = token_linear(x.permute(0, 2, 3, 1).reshape(B * H * W, C), weight.reshape(weight.shape[0], C), bias)
+    return y.view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+class PointwiseConv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters, same state_dict keys) whose forward takes `pointwise_conv` when the
+    input qualifies and nn.Conv2d's otherwise."""
+
+    def forward(self, x):
+        if pointwise_eligible(x, self.kernel_size, self.stride, self.padding, self.groups) \
+                and x.dtype == self.weight.dtype and not torch.is_autocast_enabled():
+            return pointwise_conv(x, self.weight, self.bias)
+        return super().forward(x)

@@ -109,8 +109,12 @@ class HungarianMatcher(nn.Module):
         each target slot (-1 for padded slots).  On the GPU the problems are solved by the device
         Hungarian kernel (csrc/lsa.hip) with no host synchronisation; on CPU tensors by scipy, as the
         reference does everywhere."""
-        logits = torch.stack([o["pred_logits"] for o in layer_outputs])
-        boxes = torch.stack([o["pred_boxes"] for o in layer_outputs])
+        return self.assign_stacked(torch.stack([o["pred_logits"] for o in layer_outputs]),
+                                   torch.stack([o["pred_boxes"] for o in layer_outputs]), gt, group_num)
+
+    @torch.no_grad()
+    def assign_stacked(self, logits, boxes, gt, group_num=11):
+        """`assign_padded` on already layer-stacked predictions: logits [L,B,Q,C], boxes [L,B,Q,6]."""
         L, B, Q, _ = logits.shape
         K = gt["valid"].shape[1]
         C = self.cost_padded(logits, boxes, gt)

@@ -33,6 +33,7 @@ from .backbone import build_backbone
 from .depth_predictor import DepthPredictor
 from .depth_predictor.ddn_loss import DDNLoss
 from .depthaware_transformer import MLP, build_depthaware_transformer
+from .linear import PointwiseConv2d
 from .matcher import build_matcher
 
 
@@ -74,7 +75,7 @@ class MonoDETR(nn.Module):
         self.query_embed = nn.Embedding(num_queries * group_num, hidden_dim * 2)
 
         def proj(cin, k, stride):
-            return nn.Sequential(nn.Conv2d(cin, hidden_dim, kernel_size=k, stride=stride, padding=k // 2),
+            return nn.Sequential(PointwiseConv2d(cin, hidden_dim, kernel_size=k, stride=stride, padding=k // 2),
                                  nn.GroupNorm(32, hidden_dim))
         if num_feature_levels > 1:
             projs = [proj(c, 1, 1) for c in backbone.num_channels]
@@ -136,42 +137,50 @@ class MonoDETR(nn.Module):
         hs, init_reference, inter_references, inter_references_dim, _, _ = self.depthaware_transformer(
             srcs, masks, pos, query_embeds, depth_pos_embed, depth_pos_embed_ip)
 
-        coords, classes, dims3d, depths, angles = [], [], [], [], []
+        # Prediction heads (:222-262).  The per-level MLPs have their own weights; everything after them
+        # is evaluated once on level-stacked [L, B, Q, .] tensors instead of once per decoder level.
         head_dtype = self.class_embed[0].weight.dtype          # heads stay fp32 even behind a bf16 body
         hs = hs.to(head_dtype)
+        L = hs.shape[0]
         weighted_depth = weighted_depth.to(head_dtype)
         calibs, img_sizes = calibs.to(head_dtype), img_sizes.to(head_dtype)
-        focal = calibs[:, 0, 0].unsqueeze(1)
-        img_h = img_sizes[:, 1:2]
-        for lvl in range(hs.shape[0]):
-            reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1]).to(head_dtype)
-            box = self.bbox_embed[lvl](hs[lvl])
-            if reference.shape[-1] == 6:
-                box = box + reference
-            else:
-                assert reference.shape[-1] == 2
-                box = torch.cat((box[..., :2] + reference, box[..., 2:]), -1)
-            coord = box.sigmoid()                                  # (cx, cy, l, r, t, b) of the 3D centre / 2D box
-            size3d = inter_references_dim[lvl].to(head_dtype)
-            # depth from geometry: f * H3d / h2d  (:240-242)
-            h2d = torch.clamp((coord[:, :, 4] + coord[:, :, 5]) * img_h, min=1.0)
-            depth_geo = size3d[:, :, 0] / h2d * focal
-            depth_reg = self.depth_embed[lvl](hs[lvl])
-            # depth read from the predicted depth map at the (detached) 3D centre (:248-253)
-            centre = ((coord[..., :2] - 0.5) * 2).unsqueeze(2).detach()
-            depth_map = F.grid_sample(weighted_depth.unsqueeze(1), centre, mode='bilinear', align_corners=True).squeeze(1)
-            depth_ave = torch.cat([((1. / (depth_reg[:, :, 0:1].sigmoid() + 1e-6) - 1.) + depth_geo.unsqueeze(-1) + depth_map) / 3,
-                                   depth_reg[:, :, 1:2]], -1)
-            coords.append(coord)
-            classes.append(self.class_embed[lvl](hs[lvl]))
-            dims3d.append(size3d)
-            depths.append(depth_ave)
-            angles.append(self.angle_embed[lvl](hs[lvl]))
+        focal = calibs[:, 0, 0].view(1, -1, 1)
+        img_h = img_sizes[:, 1].view(1, -1, 1)
+        # level 0 refines the initial reference, level l > 0 the reference left by level l-1 (:226-236).  A
+        # 2-component reference only shifts (cx, cy): padded with zeros it adds nothing to (l, r, t, b)
+        first = inverse_sigmoid(init_reference.to(head_dtype))
+        if first.shape[-1] == 2:
+            first = F.pad(first, (0, 4))
+        later = inverse_sigmoid(inter_references[:L - 1].to(head_dtype))
+        if later.shape[-1] == 2:
+            later = F.pad(later, (0, 4))
+        reference = torch.cat((first[None], later), 0)
+        box = torch.stack([self.bbox_embed[lvl](hs[lvl]) for lvl in range(L)]) + reference
+        coord = box.sigmoid()                                      # (cx, cy, l, r, t, b) of the 3D centre / 2D box
+        size3d = inter_references_dim[:L].to(head_dtype)
+        # depth from geometry: f * H3d / h2d  (:240-242)
+        h2d = torch.clamp((coord[..., 4] + coord[..., 5]) * img_h, min=1.0)
+        depth_geo = size3d[..., 0] / h2d * focal
+        depth_reg = torch.stack([self.depth_embed[lvl](hs[lvl]) for lvl in range(L)])
+        # depth read from the predicted depth map at the (detached) 3D centre (:248-253): one bilinear
+        # lookup for the queries of all levels
+        B, Q = coord.shape[1], coord.shape[2]
+        centre = ((coord[..., :2] - 0.5) * 2).detach().permute(1, 0, 2, 3).reshape(B, L * Q, 1, 2)
+        depth_map = F.grid_sample(weighted_depth.unsqueeze(1), centre, mode='bilinear', align_corners=True)
+        depth_map = depth_map.view(B, L, Q).permute(1, 0, 2)
+        depth_ave = torch.cat([((1. / (depth_reg[..., 0:1].sigmoid() + 1e-6) - 1.) + depth_geo.unsqueeze(-1)
+                                + depth_map.unsqueeze(-1)) / 3, depth_reg[..., 1:2]], -1)
+        classes = torch.stack([self.class_embed[lvl](hs[lvl]) for lvl in range(L)])
+        angles = torch.stack([self.angle_embed[lvl](hs[lvl]) for lvl in range(L)])
 
-        out = {'pred_logits': classes[-1], 'pred_boxes': coords[-1], 'pred_3d_dim': dims3d[-1],
-               'pred_depth': depths[-1], 'pred_angle': angles[-1], 'pred_depth_map_logits': depth_logits}
+        out = {'pred_logits': classes[-1], 'pred_boxes': coord[-1], 'pred_3d_dim': size3d[-1],
+               'pred_depth': depth_ave[-1], 'pred_angle': angles[-1], 'pred_depth_map_logits': depth_logits}
         if self.aux_loss:
-            out['aux_outputs'] = self._set_aux_loss(classes, coords, dims3d, angles, depths)
+            out['aux_outputs'] = self._set_aux_loss(classes, coord, size3d, angles, depth_ave)
+            # level-stacked views of the same predictions for the criterion (levels 0 .. L-1; not part of
+            # the reference's dict)
+            out['_levels'] = {'pred_logits': classes, 'pred_boxes': coord, 'pred_3d_dim': size3d,
+                              'pred_depth': depth_ave, 'pred_angle': angles}
         return out
 
     @torch.jit.unused
@@ -235,32 +244,37 @@ def assignment_from_indices(indices, gt, Q, group_num):
 
 
 class _Pairs:
-    """All (image, group, target-slot) pairs of one decoder layer in static shape [B, G, K]: the matched
-    query index (0 for unmatched / padded slots), the validity mask, and helpers to gather."""
+    """All (decoder layer, image, group, target-slot) pairs in static shape [L, B, G, K]: the matched
+    query index (0 for unmatched / padded slots), the validity mask, and helpers to gather.  The L
+    decoder layers are evaluated together: every loss below is one pass over [L, ...] tensors that
+    ends in a per-layer vector [L], instead of L passes of the same ~230 tiny kernels."""
 
     def __init__(self, assign, gt):
         self.gt = gt
-        self.ok = (assign >= 0) & gt["valid"][:, None, :]
+        self.ok = (assign >= 0) & gt["valid"][None, :, None, :]
         self.q = assign.clamp(min=0)
-        B, G, K = assign.shape
-        self.b = torch.arange(B, device=assign.device).view(B, 1, 1).expand(B, G, K)
 
-    def pred(self, x):                        # x [B, Q, D] -> [B, G, K, D]
-        return x[self.b, self.q]
+    def pred(self, x):                        # x [L, B, Q, D] -> [L, B, G, K, D]
+        # gather, not x[l, b, q]: the backward of advanced indexing is a sort-based index_put (164 us per
+        # call on MI355X); gather's backward is a scatter_add
+        L, B, G, K = self.q.shape
+        D = x.shape[-1]
+        return x.gather(2, self.q.reshape(L, B, G * K, 1).expand(L, B, G * K, D)).view(L, B, G, K, D)
 
-    def target(self, key):                    # gt[key] [B, K, ...] -> broadcast over groups [B, G, K, ...]
+    def target(self, key):                    # gt[key] [B, K, ...] -> broadcast over layers and groups [L, B, G, K, ...]
         t = self.gt[key]
-        return t[:, None].expand((t.shape[0], self.q.shape[1]) + tuple(t.shape[1:]))
+        L, B, G, K = self.q.shape
+        return t[None, :, None].expand((L, B, G) + tuple(t.shape[1:]))
 
-    def msum(self, x):                        # sum of x [B, G, K] over valid pairs
-        return torch.where(self.ok, x, torch.zeros((), dtype=x.dtype, device=x.device)).sum()
+    def msum(self, x):                        # x [L, B, G, K] -> [L]: sum over the valid pairs of each layer
+        return torch.where(self.ok, x, torch.zeros((), dtype=x.dtype, device=x.device)).flatten(1).sum(1)
 
 
 class SetCriterion(nn.Module):
     """Hungarian matching of predictions to ground truth, then the eight MonoDETR losses on the
     matched pairs, for the last decoder layer and (auxiliary) every earlier one.
 
-    Everything after `pad_targets` is shape-static: pairs are [B, G, K] with a validity mask, the
+    Everything after `pad_targets` is shape-static: pairs are [L, B, G, K] with a validity mask, the
     assignment comes from the device solver on the GPU (scipy on CPU tensors), `num_boxes` may stay a
     device scalar.  Accepts the reference's list-of-dicts targets or an already padded dict."""
 
@@ -274,29 +288,32 @@ class SetCriterion(nn.Module):
         self.ddn_loss = DDNLoss()
         self.group_num = group_num
 
-    # ---- individual losses (reference :320-458) on a _Pairs ---------------------------------------
+    # ---- individual losses (reference :320-458); `outputs` values are layer-stacked [L, B, Q, D], every
+    # ---- returned entry is a per-layer vector [L] ------------------------------------------------------
     def _labels(self, outputs, pr, num_boxes, log=True):
         logits = outputs['pred_logits']
-        B, Q, C = logits.shape
+        L, B, Q, C = logits.shape
         labels = pr.target("labels")
         # scatter the matched labels; unmatched / padded pairs go to a dummy (Q-th) query that is dropped
-        classes = torch.full((B, Q + 1), self.num_classes, dtype=torch.int64, device=logits.device)
-        classes.scatter_(1, torch.where(pr.ok, pr.q, torch.full_like(pr.q, Q)).reshape(B, -1), labels.reshape(B, -1))
-        onehot = F.one_hot(classes[:, :Q], self.num_classes + 1)[..., :-1].to(logits.dtype)
-        losses = {'loss_ce': sigmoid_focal_loss(logits, onehot, num_boxes, alpha=self.focal_alpha, gamma=2) * Q}
+        classes = torch.full((L, B, Q + 1), self.num_classes, dtype=torch.int64, device=logits.device)
+        classes.scatter_(2, torch.where(pr.ok, pr.q, torch.full_like(pr.q, Q)).reshape(L, B, -1), labels.reshape(L, B, -1))
+        onehot = F.one_hot(classes[..., :Q], self.num_classes + 1)[..., :-1].to(logits.dtype)
+        losses = {'loss_ce': sigmoid_focal_loss(logits, onehot, num_boxes, alpha=self.focal_alpha, gamma=2,
+                                                per_layer=True) * Q}
         if log:
             with torch.no_grad():
                 hit = (pr.pred(logits).argmax(-1) == labels) & pr.ok
-                nmatch = pr.ok.sum()
-                acc = torch.where(nmatch > 0, hit.sum() * 100.0 / nmatch.clamp(min=1), torch.zeros((), device=logits.device))
+                nmatch = pr.ok.flatten(1).sum(1)
+                acc = torch.where(nmatch > 0, hit.flatten(1).sum(1) * 100.0 / nmatch.clamp(min=1),
+                                  torch.zeros((), device=logits.device))
             losses['class_error'] = 100 - acc
         return losses
 
     @torch.no_grad()
     def _cardinality(self, outputs, pr, num_boxes):
         logits = outputs['pred_logits']
-        card_pred = (logits.argmax(-1) != logits.shape[-1] - 1).sum(1)
-        return {'cardinality_error': F.l1_loss(card_pred.float(), pr.gt["num"].float())}
+        card_pred = (logits.argmax(-1) != logits.shape[-1] - 1).sum(2)              # [L, B]
+        return {'cardinality_error': (card_pred.float() - pr.gt["num"].float()[None]).abs().mean(1)}
 
     def _center(self, outputs, pr, num_boxes):
         d = (pr.pred(outputs['pred_boxes'])[..., 0:2] - pr.target('boxes_3d')[..., 0:2]).abs().sum(-1)
@@ -323,51 +340,69 @@ class SetCriterion(nn.Module):
         rel = diff / tgt.detach()                                   # dimension-aware L1 (:410-416)
         ok3 = pr.ok[..., None].expand_as(diff)
         zero = torch.zeros((), dtype=diff.dtype, device=diff.device)
-        with torch.no_grad():                                       # mean |d| / mean relative |d| over the matched pairs
-            comp = torch.where(ok3, diff, zero).sum() / torch.where(ok3, rel, zero).sum().clamp(min=1e-12)
-        return {'loss_dim': torch.where(ok3, rel * comp, zero).sum() / num_boxes}
+        rel_ok = torch.where(ok3, rel, zero)
+        with torch.no_grad():                                       # mean |d| / mean relative |d| over the matched pairs of a layer
+            comp = torch.where(ok3, diff, zero).flatten(1).sum(1) / rel_ok.flatten(1).sum(1).clamp(min=1e-12)
+        return {'loss_dim': rel_ok.flatten(1).sum(1) * comp / num_boxes}
 
     def _angles(self, outputs, pr, num_boxes):
-        pred = pr.pred(outputs['pred_angle'])                        # [B, G, K, 24]
+        pred = pr.pred(outputs['pred_angle'])                        # [L, B, G, K, 24]
         bins, res = pr.target('heading_bin'), pr.target('heading_res')
         cls_loss = F.cross_entropy(pred[..., 0:12].reshape(-1, 12), bins.reshape(-1), reduction='none').view_as(res)
         pred_res = pred[..., 12:24].gather(-1, bins[..., None]).squeeze(-1)       # residual of the true bin
         return {'loss_angle': pr.msum(cls_loss + (pred_res - res).abs()) / num_boxes}
 
     def _depth_map(self, outputs, pr, num_boxes):
+        """Final layer only (:521-523): `outputs['pred_depth_map_logits']` is not layer-stacked; returns [1]."""
         logits = outputs['pred_depth_map_logits']
         gt = pr.gt
         H, W = logits.shape[-2:]
         b = gt["boxes"]                                              # x (80, 24, 80, 24) at 384x1280, no host->device copy
         boxes = box_ops.box_cxcywh_to_xyxy(torch.stack((b[..., 0] * W, b[..., 1] * H, b[..., 2] * W, b[..., 3] * H), -1))
         boxes = torch.where(gt["valid"][..., None], boxes, torch.zeros_like(boxes))              # padded slots cover nothing
-        return {"loss_depth_map": self.ddn_loss(logits, boxes.reshape(-1, 4), gt["valid"].shape[1], gt["depth"].reshape(-1),
-                                                valid=gt["valid"].reshape(-1))}
+        loss = self.ddn_loss(logits, boxes.reshape(-1, 4), gt["valid"].shape[1], gt["depth"].reshape(-1),
+                             valid=gt["valid"].reshape(-1))
+        return {"loss_depth_map": loss.reshape(1)}
 
     _LOSSES = {'labels': '_labels', 'cardinality': '_cardinality', 'boxes': '_boxes', 'depths': '_depths',
                'dims': '_dims', 'angles': '_angles', 'center': '_center', 'depth_map': '_depth_map'}
+    _STACKED = ('pred_logits', 'pred_boxes', 'pred_3d_dim', 'pred_depth', 'pred_angle')
 
     def _get(self, loss, outputs, pr, num_boxes, **kwargs):
         assert loss in self._LOSSES, f'do you really want to compute {loss} loss?'
         return getattr(self, self._LOSSES[loss])(outputs, pr, num_boxes, **kwargs)
 
     def get_loss(self, loss, outputs, targets, indices, num_boxes, **kwargs):
-        """Reference signature (:466-481): `indices` is the matcher's list of (query idx, target idx)."""
+        """Reference signature (:466-481): one layer's `outputs`, `indices` the matcher's list of
+        (query idx, target idx); returns {name: 0-d tensor}."""
         gt = targets if isinstance(targets, dict) else pad_targets(targets)
         Q = outputs['pred_logits'].shape[1]
         G = self.group_num if Q % self.group_num == 0 and Q // self.group_num * self.group_num == Q and self.training else 1
         assign = assignment_from_indices(indices, gt, Q, G)
-        return self._get(loss, _widen(outputs), _Pairs(assign, gt), num_boxes, **kwargs)
+        one = {k: (v[None] if k in self._STACKED else v) for k, v in _widen(outputs).items() if torch.is_tensor(v)}
+        return {k: v[0] for k, v in self._get(loss, one, _Pairs(assign[None], gt), num_boxes, **kwargs).items()}
 
     def forward(self, outputs, targets, mask_dict=None):
         """outputs: the model's dict; targets: list (one per image) of dicts with 'labels', 'boxes',
         'boxes_3d', 'depth', 'size_3d', 'heading_bin', 'heading_res' -- or the dict `pad_targets`
-        makes of it.  Returns {name: 0-d tensor}."""
-        final = _widen({k: v for k, v in outputs.items() if k != 'aux_outputs'})
-        layers = [final] + [_widen(a) for a in outputs.get('aux_outputs', [])]
+        makes of it.  Returns {name: 0-d tensor}, auxiliary layers suffixed _0, _1, ... (:511-530)."""
+        final = _widen({k: v for k, v in outputs.items() if k not in ('aux_outputs', '_levels')})
+        if '_levels' in outputs:
+            # the model's own level-stacked predictions [L, B, Q, D] (levels 0 .. L-1, the final layer last)
+            stacked = _widen(outputs['_levels'])
+            L = stacked['pred_logits'].shape[0]
+            names = [str(i) for i in range(L - 1)] + [None]                  # suffix of every level, None = final
+        else:
+            layers = [final] + [_widen(a) for a in outputs.get('aux_outputs', [])]
+            L = len(layers)
+            stacked = {k: torch.stack([lay[k] for lay in layers]) for k in self._STACKED}     # final layer first
+            names = [None] + [str(i) for i in range(L - 1)]
+        last = names.index(None)
+        if 'pred_depth_map_logits' in final:
+            stacked['pred_depth_map_logits'] = final['pred_depth_map_logits']
         group_num = self.group_num if self.training else 1
         gt = targets if isinstance(targets, dict) else pad_targets(targets)
-        assign = self.matcher.assign_padded(layers, gt, group_num)           # [L, B, G, K], -1 = none
+        assign = self.matcher.assign_stacked(stacked['pred_logits'], stacked['pred_boxes'], gt, group_num)   # [L, B, G, K]
 
         if gt.get("num_host") is not None and not is_dist_avail_and_initialized():
             num_boxes = max(float(sum(gt["num_host"]) * group_num), 1.0)
@@ -377,15 +412,18 @@ class SetCriterion(nn.Module):
                 torch.distributed.all_reduce(nb)
             num_boxes = torch.clamp(nb / get_world_size(), min=1)
 
-        losses = {}
-        for li, layer_out in enumerate(layers):
-            pr = _Pairs(assign[li], gt)
-            for loss in self.losses:
-                if li > 0 and loss == 'depth_map':       # depth-map loss only on the final layer (:521-523)
+        pr = _Pairs(assign, gt)
+        losses, aux = {}, {}
+        for loss in self.losses:
+            for name, vec in self._get(loss, stacked, pr, num_boxes).items():
+                parts = vec.unbind(0)
+                # auxiliary layers: no depth-map loss (:521-523) and no class_error (log=False, :524-526)
+                if name in ('loss_depth_map', 'class_error'):
+                    losses[name] = parts[0] if name == 'loss_depth_map' else parts[last]
                     continue
-                kwargs = {'log': False} if (li > 0 and loss == 'labels') else {}
-                ld = self._get(loss, layer_out, pr, num_boxes, **kwargs)
-                losses.update(ld if li == 0 else {k + f'_{li - 1}': v for k, v in ld.items()})
+                losses[name] = parts[last]
+                aux.update({f'{name}_{names[i]}': parts[i] for i in range(L) if i != last})
+        losses.update(aux)
         return losses
 
 

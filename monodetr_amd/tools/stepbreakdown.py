@@ -27,7 +27,7 @@ def main():
     for _ in range(a.iters):
         step.optimizer.zero_grad(set_to_none=True)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.precision == "bf16"):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.precision == "bf16-autocast"):
             out = step.model(images, calibs, targets, img_sizes)
             torch.cuda.synchronize(); t1 = time.perf_counter()
             losses = step.criterion(out, targets)
@@ -42,6 +42,26 @@ def main():
         acc["forward"] += t1 - t0; acc["criterion"] += t2 - t1; acc["backward"] += t3 - t2; acc["optimizer"] += t4 - t3
         acc["criterion_host_only"] += t1b - t1
     print(json.dumps({k: round(v / a.iters * 1e3, 2) for k, v in acc.items()}))
+    # host enqueue time of each phase (no synchronisation inside the step): if their sum is close to the
+    # step's wall time the step is launch-bound, not GPU-bound
+    host = dict(forward=0.0, criterion=0.0, backward=0.0, optimizer=0.0, wall=0.0)
+    for _ in range(a.iters):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        step.optimizer.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=a.precision == "bf16-autocast"):
+            out = step.model(images, calibs, targets, img_sizes)
+            t1 = time.perf_counter()
+            losses = step.criterion(out, targets)
+        t2 = time.perf_counter()
+        total = sum(losses[k] * w[k] for k in losses if k in w)
+        total.backward()
+        t3 = time.perf_counter()
+        step.optimizer.step()
+        t4 = time.perf_counter()
+        torch.cuda.synchronize(); t5 = time.perf_counter()
+        host["forward"] += t1 - t0; host["criterion"] += t2 - t1; host["backward"] += t3 - t2
+        host["optimizer"] += t4 - t3; host["wall"] += t5 - t0
+    print(json.dumps({"host_enqueue_ms": {k: round(v / a.iters * 1e3, 2) for k, v in host.items()}}))
 
 
 if __name__ == "__main__":

@@ -196,3 +196,66 @@ def test_float64_structural_parity_all_gradients(oracle, golden):
             assert abs(fp[n][1] - proj) < 1e-7 * norm + 1e-10, (n, fp[n][1], proj)
     finally:
         F_.MSDA = saved
+
+
+def test_separable_bilinear_resize_matches_interpolate():
+    """The GPU path of the depth predictor's 2x upsampling (two matrix products) == F.interpolate."""
+    import torch.nn.functional as F
+    from monodetr_amd.monodetr.depth_predictor.depth_predictor import _bilinear_resize_matmul
+    torch.manual_seed(0)
+    for shape, size in (((2, 16, 12, 40), (24, 80)), ((1, 8, 5, 7), (11, 13)), ((2, 4, 6, 6), (6, 6))):
+        x = torch.randn(shape, dtype=torch.float64).contiguous(memory_format=torch.channels_last).requires_grad_()
+        ref = F.interpolate(x, size=size, mode='bilinear')
+        got = _bilinear_resize_matmul(x, size)
+        assert got.shape == ref.shape and (got - ref).abs().max() < 1e-12
+        g = torch.randn_like(ref)
+        gr, = torch.autograd.grad(ref, x, g)
+        gg, = torch.autograd.grad(got, x, g)
+        assert (gr - gg).abs().max() < 1e-12
+
+
+def test_hat_weight_embedding_interpolation_matches_two_lookups():
+    """interpolate_1d (hat weights x table) == embed(floor)*(1-frac) + embed(floor+1)*frac, values and gradients."""
+    from monodetr_amd.monodetr.depth_predictor.depth_predictor import DepthPredictor
+    torch.manual_seed(1)
+    embed = torch.nn.Embedding(61, 16).double()
+    coord = (torch.rand(3, 5, 7, dtype=torch.float64) * 60).requires_grad_()
+    with torch.no_grad():
+        coord[0, 0, 0], coord[0, 0, 1], coord[0, 0, 2] = 60.0, 0.0, 17.0       # table end, start, an exact integer
+    got = DepthPredictor.interpolate_1d(None, coord, embed)
+    lo = coord.floor()
+    frac = (coord - lo).unsqueeze(-1)
+    lo = lo.long()
+    hi = (lo + 1).clamp(max=60)
+    ref = embed(lo) * (1 - frac) + embed(hi) * frac
+    assert (got - ref).abs().max() < 1e-12
+    g = torch.randn_like(ref)
+    gr = torch.autograd.grad(ref, (coord, embed.weight), g)
+    gg = torch.autograd.grad(got, (coord, embed.weight), g)
+    inner = (coord.detach() != coord.detach().floor())                          # the kink at integers has no unique slope
+    assert ((gr[0] - gg[0]).abs() * inner).max() < 1e-10 and (gr[1] - gg[1]).abs().max() < 1e-10
+
+
+def test_pointwise_conv_matches_conv2d():
+    """1x1 stride-1 convolution as a token GEMM (the GPU path of the backbone / projections) == F.conv2d,
+    values and gradients, including the split-K weight-gradient path of _TokenLinear."""
+    import torch.nn.functional as F
+    from monodetr_amd.monodetr.linear import _TokenLinear, pointwise_conv
+    torch.manual_seed(2)
+    x = torch.randn(2, 24, 32, 80, dtype=torch.float64).contiguous(memory_format=torch.channels_last).requires_grad_()
+    w = torch.randn(40, 24, 1, 1, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(40, dtype=torch.float64, requires_grad=True)
+    ref = F.conv2d(x, w, b)
+    got = pointwise_conv(x, w, b)
+    assert got.shape == ref.shape and (got - ref).abs().max() < 1e-12
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    g = torch.randn_like(ref)
+    ref_grads = torch.autograd.grad(ref, (x, w, b), g)
+    for a, c in zip(ref_grads, torch.autograd.grad(got, (x, w, b), g)):
+        assert (a - c).abs().max() < 1e-10
+    # the split-K autograd function itself (5120 tokens -> 20 chunks of 256)
+    t = x.permute(0, 2, 3, 1).reshape(-1, 24)
+    y = _TokenLinear.apply(t, w.reshape(40, 24), b)
+    gy = g.permute(0, 2, 3, 1).reshape(-1, 40)
+    for a, c in zip(ref_grads, torch.autograd.grad(y, (x, w, b), gy)):
+        assert (a - c).abs().max() < 1e-10
