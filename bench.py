@@ -1,13 +1,15 @@
 """bench.py -- MonoDETR training throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp32|bf16] [--batch 8]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|fp32] [--batch 8]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic input: MonoDETR forward in train
 mode (550 queries) -> SetCriterion (Hungarian matching + 8 losses x 3 decoder layers) -> backward ->
 the reference's AdamW step, at B = 8 images per GPU, 3 x 384 x 1280, random-init weights, inputs
-resident in HBM.  One process per GPU; for N > 1 the image batch is sharded (weak scaling) and
+resident in HBM.  Default precision is BASELINE.json configs[2]'s: bf16 (bf16 model body, fp32
+prediction heads, fp32 master weights, the MSDA operator itself in fp32); --precision fp32 runs the
+reference's own all-fp32 arithmetic.  One process per GPU; for N > 1 the image batch is sharded (weak scaling) and
 gradients are all-reduced over RCCL/xGMI by DistributedDataParallel.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
@@ -147,8 +149,7 @@ class TrainStep:
         with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.precision == "bf16-autocast"):
             out = self.model(images, calibs, targets, img_sizes, dn_args=None)
             losses = self.criterion(out, targets, None)
-        w = self.criterion.weight_dict
-        total = sum(losses[k] * w[k] for k in losses if k in w)     # trainer_helper.py:141-143
+        total = self.criterion.weighted_total(losses)               # trainer_helper.py:141-143, one dot product
         total.backward()
         self.optimizer.step()
         return total
@@ -189,7 +190,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
-    ap.add_argument("--precision", default=os.environ.get("MDETR_BENCH_PRECISION", "fp32"), choices=["fp32", "bf16", "bf16-autocast"],
+    ap.add_argument("--precision", default=os.environ.get("MDETR_BENCH_PRECISION", "bf16"), choices=["fp32", "bf16", "bf16-autocast"],
                     help="bf16 = bf16 model body + fp32 heads + fp32 master weights (helpers/precision.py); "
                          "bf16-autocast = fp32 parameters under torch.autocast")
     ap.add_argument("--graph", default=os.environ.get("MDETR_BENCH_GRAPH", "off"), choices=["on", "off"],
@@ -300,7 +301,8 @@ def main():
             "dtype": "f32" if args.precision == "fp32" else "bf16",
             "data": "synthetic (N(0,1) images 3x384x1280, 1-8 synthetic cars per image), random-init weights",
             "config": {"workload": "full MonoDETR training step (ResNet-50 + depth predictor + 3 enc / 3 dec layers, "
-                                   "550 train queries, 4 levels, criterion + AdamW), BASELINE configs[2]/[3] shape",
+                                   "550 train queries, 4 levels, criterion + AdamW) = BASELINE configs[2] (1 GPU) / "
+                                   "configs[3] (DDP)",
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "image": "3x384x1280",
                        "precision": args.precision, "parallelism": "dp%d" % world,
                        "launch": "one hipGraph replay per iteration" if use_graph else "eager"},

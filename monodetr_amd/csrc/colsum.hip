@@ -81,21 +81,33 @@ void colsum_partial_kernel(const T *__restrict__ x, float *__restrict__ partial,
     }
 }
 
+// 16 columns x 16 row slices per block: slice s adds partial rows s, s+16, ... (four loads in flight),
+// the slices are combined through LDS in slice order
 __global__ __launch_bounds__(kThreads)
 void colsum_final_kernel(const float *__restrict__ partial, float *__restrict__ out, int nblk, int cols)
 {
-    const int col = blockIdx.x * kThreads + threadIdx.x;
-    if (col >= cols) return;
+    __shared__ float red[16][17];
+    const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + c;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 3 < nblk; b += 4) {
-        s0 += partial[static_cast<int64_t>(b) * cols + col];
-        s1 += partial[static_cast<int64_t>(b + 1) * cols + col];
-        s2 += partial[static_cast<int64_t>(b + 2) * cols + col];
-        s3 += partial[static_cast<int64_t>(b + 3) * cols + col];
+    if (col < cols) {
+        int b = sl;
+        for (; b + 48 < nblk; b += 64) {
+            s0 += partial[static_cast<int64_t>(b) * cols + col];
+            s1 += partial[static_cast<int64_t>(b + 16) * cols + col];
+            s2 += partial[static_cast<int64_t>(b + 32) * cols + col];
+            s3 += partial[static_cast<int64_t>(b + 48) * cols + col];
+        }
+        for (; b < nblk; b += 16) s0 += partial[static_cast<int64_t>(b) * cols + col];
     }
-    for (; b < nblk; ++b) s0 += partial[static_cast<int64_t>(b) * cols + col];
-    out[col] = (s0 + s1) + (s2 + s3);
+    red[sl][c] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && col < cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) s += red[l][c];
+        out[col] = s;
+    }
 }
 
 }  // namespace
@@ -118,7 +130,8 @@ hipError_t colsum_launch(int dtype, const void *x, float *out, void *workspace, 
 {
     if (cols == 0) return hipSuccess;
     const int64_t nblk = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
-    float *partial = static_cast<float *>(workspace);
+    // a single row block: its partial row IS the result
+    float *partial = nblk == 1 ? out : static_cast<float *>(workspace);
     if (nblk > 0) {
         const int vec = dtype == 2 ? 8 : 4;
         const int cvs = cols / vec;
@@ -132,7 +145,8 @@ hipError_t colsum_launch(int dtype, const void *x, float *out, void *workspace, 
             hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(kThreads), 0, st,
                                static_cast<const float *>(x), partial, rows, cols, ld, CT);
     }
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
+    if (nblk == 1) return hipGetLastError();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 15) / 16), dim3(kThreads), 0, st,
                        partial, out, static_cast<int>(nblk), cols);
     return hipGetLastError();
 }

@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..utils.misc import NestedTensor
+from ..utils.misc import NestedTensor, mark_no_padding
 from .linear import pointwise_conv, pointwise_eligible
 from .position_encoding import build_position_encoding
 
@@ -60,13 +60,69 @@ class FrozenBatchNorm2d(nn.Module):
         return x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
 
 
+class _FoldAll(torch.autograd.Function):
+    """folded_i = (W_i * scale_i).to(dt) for every trainable convolution of the backbone in two
+    multi-tensor launches (and two more in the backward: dW_i = dfolded_i.to(W dtype) * scale_i)
+    instead of two small kernels per convolution each way.  `scales` are the frozen-BN scales expanded
+    to the weights' shapes and strides, which is what keeps torch._foreach_* on its fused path."""
+
+    @staticmethod
+    def forward(ctx, scales, dt, *weights):
+        ctx.scales, ctx.wdtype = scales, weights[0].dtype
+        ctx.like = weights
+        out = torch._foreach_mul(list(weights), scales)
+        if dt != ctx.wdtype:
+            low = [torch.empty_like(w, dtype=dt) for w in weights]
+            torch._foreach_copy_(low, out)
+            out = low
+        return tuple(out)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        grads = [g if g is not None else torch.zeros_like(w, dtype=ctx.wdtype) for g, w in zip(grads, ctx.like)]
+        if grads[0].dtype != ctx.wdtype or any(g.dtype != ctx.wdtype for g in grads):
+            wide = [torch.empty_like(w) for w in ctx.like]
+            torch._foreach_copy_(wide, grads)
+            grads = wide
+            torch._foreach_mul_(grads, ctx.scales)
+        else:
+            grads = torch._foreach_mul(grads, ctx.scales)
+        return (None, None) + tuple(grads)
+
+
+def prefold(pairs, dt):
+    """Fold the frozen BN of every trainable (conv, bn) pair into its weight for THIS forward pass and
+    park the result on the conv module (`conv_bn` consumes it)."""
+    if not pairs:
+        return
+    key = tuple(bn.affine()[0].data_ptr() for _, bn in pairs) + tuple(c.weight.data_ptr() for c, _ in pairs) + (dt,)
+    cache = pairs[0][0].__dict__.get("_prefold_cache")
+    if cache is None or cache[0] != key:
+        scales, shifts = [], []
+        with torch.no_grad():
+            for conv, bn in pairs:
+                scale, shift = bn.affine()
+                full = torch.empty_like(conv.weight)
+                full.copy_(scale.to(conv.weight.dtype).view(-1, 1, 1, 1).expand_as(conv.weight))
+                scales.append(full)
+                shifts.append(shift.to(dt))
+        cache = pairs[0][0].__dict__["_prefold_cache"] = (key, scales, shifts)
+    folded = _FoldAll.apply(cache[1], dt, *[conv.weight for conv, _ in pairs])
+    for (conv, _), w, b in zip(pairs, folded, cache[2]):
+        conv.__dict__["_prefolded"] = (w, b)
+
+
 def conv_bn(x, conv, bn, relu):
     """conv -> frozen BN (-> ReLU), with the BN folded into the convolution's weight and bias.
     For frozen convolutions (stem, layer1) the folded weight itself is cached."""
     if isinstance(bn, FrozenBatchNorm2d) and conv.bias is None:
         scale, shift = bn.affine()
         dt = x.dtype if x.dtype in (torch.bfloat16, torch.float16) and not torch.is_autocast_enabled() else conv.weight.dtype
-        if not conv.weight.requires_grad:
+        pre = conv.__dict__.pop("_prefolded", None)
+        if pre is not None and pre[0].dtype == dt:
+            w, b = pre
+        elif not conv.weight.requires_grad:
             key = (conv.weight.data_ptr(), conv.weight._version, bn._affine_key, dt)
             if getattr(conv, "_folded_key", None) != key:
                 with torch.no_grad():
@@ -75,8 +131,14 @@ def conv_bn(x, conv, bn, relu):
                 conv._folded_key = key
             w, b = conv._folded
         else:
-            w = (conv.weight * scale.to(conv.weight.dtype).view(-1, 1, 1, 1)).to(dt)
-            b = shift.to(dt)
+            # trainable convolution: the fold is part of the autograd graph (dW = dW_folded * scale); the
+            # casts of the frozen (scale, shift) pair are cached per dtype
+            cast = getattr(bn, "_affine_cast", None)
+            if cast is None or cast[0] != (bn._affine_key, conv.weight.dtype, dt):
+                cast = bn._affine_cast = ((bn._affine_key, conv.weight.dtype, dt),
+                                          scale.to(conv.weight.dtype).view(-1, 1, 1, 1), shift.to(dt))
+            w = (conv.weight * cast[1]).to(dt)
+            b = cast[2]
         if pointwise_eligible(x, conv.kernel_size, conv.stride, conv.padding, conv.groups) and x.dtype == w.dtype:
             x = pointwise_conv(x, w, b)
         else:
@@ -121,6 +183,7 @@ class ResNetBody(nn.Module):
             raise ValueError("backbone %r: number of channels are hard coded for bottleneck ResNets "
                              "(reference backbone.py:103)" % name)
         self.return_layers = dict(return_layers)
+        self.prefold = None               # None = on CUDA tensors only; True / False to force (tests)
         self.inplanes, self.dilation = 64, 1
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = norm_layer(64)
@@ -148,7 +211,24 @@ class ResNetBody(nn.Module):
         layers += [Bottleneck(self.inplanes, planes, dilation=self.dilation, norm_layer=norm_layer) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
+    def _trainable_pairs(self):
+        pairs = []
+        for m in self.modules():
+            if isinstance(m, Bottleneck):
+                cands = [(m.conv1, m.bn1), (m.conv2, m.bn2), (m.conv3, m.bn3)]
+                if m.downsample is not None:
+                    cands.append((m.downsample[0], m.downsample[1]))
+                pairs += [(c, b) for c, b in cands if c.weight.requires_grad and c.bias is None
+                          and isinstance(b, FrozenBatchNorm2d)]
+        return pairs
+
     def forward(self, x):
+        use = self.prefold if self.prefold is not None else x.is_cuda
+        if use and torch.is_grad_enabled() and not torch.is_autocast_enabled():
+            dt = x.dtype if x.dtype in (torch.bfloat16, torch.float16) else None
+            pairs = self._trainable_pairs()
+            if pairs:
+                prefold(pairs, dt if dt is not None else pairs[0][0].weight.dtype)
         x = self.maxpool(conv_bn(x, self.conv1, self.bn1, True))
         out = {}
         for name in ('layer1', 'layer2', 'layer3', 'layer4'):
@@ -169,11 +249,16 @@ class BackboneBase(nn.Module):
         else:
             self.strides, self.num_channels = [32], [2048]
         self.body = body
+        self._masks = {}
 
     def forward(self, images):
         out = {}
         for name, x in self.body(images).items():
-            mask = torch.zeros((x.shape[0], x.shape[2], x.shape[3]), dtype=torch.bool, device=x.device)   # :88
+            # all-False padding mask (:88), tagged so that consumers need not inspect it; one tensor per shape
+            key = (x.shape[0], x.shape[2], x.shape[3], x.device)
+            mask = self._masks.get(key)
+            if mask is None:
+                mask = self._masks[key] = mark_no_padding(torch.zeros(key[:3], dtype=torch.bool, device=x.device))
             out[name] = NestedTensor(x, mask)
         return out
 

@@ -47,7 +47,12 @@ class _TokenLinear(torch.autograd.Function):
         C = _split_count(T)
         if ctx.needs_input_grad[1]:
             if C:
-                dw = torch.bmm(dy2.view(C, T // C, -1).transpose(1, 2), x2.view(C, T // C, -1)).sum(0)
+                parts = torch.bmm(dy2.view(C, T // C, -1).transpose(1, 2), x2.view(C, T // C, -1))    # [C, N, K]
+                flat = parts.view(C, -1)
+                if colsum_ext.supported(flat):       # sum over the C chunks in one streaming pass (csrc/colsum.hip)
+                    dw = colsum_ext.column_sum(flat).view(parts.shape[1], parts.shape[2])
+                else:
+                    dw = parts.sum(0)
             else:
                 dw = dy2.t() @ x2
             dw = dw.to(weight.dtype)

@@ -382,6 +382,19 @@ class SetCriterion(nn.Module):
         one = {k: (v[None] if k in self._STACKED else v) for k, v in _widen(outputs).items() if torch.is_tensor(v)}
         return {k: v[0] for k, v in self._get(loss, one, _Pairs(assign[None], gt), num_boxes, **kwargs).items()}
 
+    def weighted_total(self, losses):
+        """sum_k weight_dict[k] * losses[k] over the weighted entries -- what the reference's trainer
+        computes in a Python loop (lib/helpers/trainer_helper.py:141-143: ~24 multiplies and adds on 0-d
+        tensors, each a kernel launch, and as many again in the backward) -- as one stack and one dot
+        product."""
+        keys = [k for k in losses if k in self.weight_dict]
+        vec = torch.stack([losses[k] for k in keys])
+        cache = self.__dict__.get("_weight_vec")
+        if cache is None or cache[0] != (tuple(keys), vec.dtype, vec.device):
+            w = torch.tensor([float(self.weight_dict[k]) for k in keys], dtype=vec.dtype, device=vec.device)
+            cache = self.__dict__["_weight_vec"] = ((tuple(keys), vec.dtype, vec.device), w)
+        return torch.dot(vec, cache[1])
+
     def forward(self, outputs, targets, mask_dict=None):
         """outputs: the model's dict; targets: list (one per image) of dicts with 'labels', 'boxes',
         'boxes_3d', 'depth', 'size_3d', 'heading_bin', 'heading_res' -- or the dict `pad_targets`

@@ -5,6 +5,8 @@ import math
 import torch
 from torch import nn
 
+from ..utils.misc import no_padding
+
 
 class PositionEmbeddingSine(nn.Module):
     """2-D sine/cosine encoding over the un-padded extent of each image: ``num_pos_feats`` channels
@@ -17,10 +19,23 @@ class PositionEmbeddingSine(nn.Module):
             raise ValueError("normalize should be True if scale is passed")
         self.num_pos_feats, self.temperature, self.normalize = num_pos_feats, temperature, normalize
         self.scale = 2 * math.pi if scale is None else scale
+        self._cache = {}
 
     def forward(self, tensor_list):
+        """The encoding depends on the mask only.  Masks tagged all-False by construction
+        (utils.misc.mark_no_padding -- every mask this model builds) give the same tensor for a given
+        shape on every call, so it is computed once (~22 kernels per pyramid level otherwise)."""
         mask = tensor_list.mask
         assert mask is not None
+        if not no_padding(mask):
+            return self._encode(mask)
+        key = (tuple(mask.shape), mask.device)
+        pos = self._cache.get(key)
+        if pos is None:
+            pos = self._cache[key] = self._encode(mask)
+        return pos
+
+    def _encode(self, mask):
         valid = ~mask
         y = valid.cumsum(1, dtype=torch.float32)
         x = valid.cumsum(2, dtype=torch.float32)

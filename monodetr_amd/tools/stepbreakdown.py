@@ -34,7 +34,7 @@ def main():
             t1b = time.perf_counter()
         torch.cuda.synchronize(); t2 = time.perf_counter()
         w = step.criterion.weight_dict
-        total = sum(losses[k] * w[k] for k in losses if k in w)
+        total = step.criterion.weighted_total(losses)
         total.backward()
         torch.cuda.synchronize(); t3 = time.perf_counter()
         step.optimizer.step()
@@ -53,7 +53,7 @@ def main():
             t1 = time.perf_counter()
             losses = step.criterion(out, targets)
         t2 = time.perf_counter()
-        total = sum(losses[k] * w[k] for k in losses if k in w)
+        total = step.criterion.weighted_total(losses)
         total.backward()
         t3 = time.perf_counter()
         step.optimizer.step()

@@ -138,6 +138,7 @@ def test_one_training_iteration_gradients_match_reference(built, golden):
     # and the criterion's own forward (own matching) gives the same total up to tie noise
     own = criterion(out, targets)
     own_total = sum(own[k] * criterion.weight_dict[k] for k in own if k in criterion.weight_dict)
+    assert abs(float(criterion.weighted_total(own)) - float(own_total)) <= 1e-5 * abs(float(own_total))   # one-dot form
     assert abs(float(own_total) - float(total)) < 2e-2 * abs(float(total))
     total.backward()
     params = dict(model.named_parameters())
@@ -259,3 +260,29 @@ def test_pointwise_conv_matches_conv2d():
     gy = g.permute(0, 2, 3, 1).reshape(-1, 40)
     for a, c in zip(ref_grads, torch.autograd.grad(y, (x, w, b), gy)):
         assert (a - c).abs().max() < 1e-10
+
+
+def test_multi_tensor_bn_fold_matches_per_conv_fold():
+    """ResNetBody with the frozen-BN fold done for all trainable convolutions at once (the GPU path)
+    == the per-convolution fold: same features, same weight gradients."""
+    from monodetr_amd.monodetr.backbone import Backbone
+    torch.manual_seed(3)
+    bb = Backbone('resnet50', True, True, False).double()
+    for m in bb.modules():                                  # non-trivial frozen statistics
+        if m.__class__.__name__ == 'FrozenBatchNorm2d':
+            m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.2, 0.2)
+            m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(1, 3, 64, 96, dtype=torch.float64)
+    res = {}
+    for flag in (False, True):
+        bb.body.prefold = flag
+        bb.zero_grad(set_to_none=True)
+        feats = bb(x)
+        sum(f.tensors.square().mean() for f in feats.values()).backward()
+        res[flag] = ([f.tensors.detach().clone() for f in feats.values()],
+                     {n: p.grad.clone() for n, p in bb.named_parameters() if p.grad is not None})
+    assert len(res[True][1]) == len(res[False][1]) > 30
+    for a, b in zip(res[False][0], res[True][0]):
+        assert (a - b).abs().max() < 1e-12
+    for n, g in res[False][1].items():
+        assert (g - res[True][1][n]).abs().max() <= 1e-12 * max(1.0, g.abs().max()), n
