@@ -286,3 +286,40 @@ def test_multi_tensor_bn_fold_matches_per_conv_fold():
         assert (a - b).abs().max() < 1e-12
     for n, g in res[False][1].items():
         assert (g - res[True][1][n]).abs().max() <= 1e-12 * max(1.0, g.abs().max()), n
+
+
+def test_criterion_input_forms_agree(built):
+    """The criterion's three input forms give the same losses: (a) the model's dict with its
+    level-stacked `_levels` views, (b) the reference-shaped dict (final layer + aux_outputs list, as the
+    reference model returns it), (c) either of them with targets already padded to KITTI's 50 slots."""
+    from monodetr_amd.monodetr.monodetr import pad_targets
+    model, criterion = built
+    model.train(); criterion.train()
+    images, calibs, sizes, targets = synthetic_batch(2, 96, 320, 7, torch.device("cpu"))
+    with torch.no_grad():
+        out = model(images, calibs, targets, sizes)
+    assert "_levels" in out and len(out["aux_outputs"]) == 2
+    a = criterion(out, targets)
+    b = criterion({k: v for k, v in out.items() if k != "_levels"}, targets)
+    c = criterion(out, pad_targets(targets, kmax=50))
+    assert set(a) == set(b) == set(c) and len(a) == 26
+    for k in a:
+        assert a[k].dim() == 0
+        assert abs(float(a[k]) - float(b[k])) <= 1e-6 * max(1.0, abs(float(a[k]))), k
+        assert abs(float(a[k]) - float(c[k])) <= 1e-6 * max(1.0, abs(float(a[k]))), k
+
+
+def test_criterion_with_an_image_without_objects(built):
+    """An image with zero ground-truth objects contributes nothing and breaks nothing (the reference
+    handles it through empty index tensors; here through all-invalid padded slots)."""
+    model, criterion = built
+    model.train(); criterion.train()
+    images, calibs, sizes, targets = synthetic_batch(2, 96, 320, 11, torch.device("cpu"))
+    targets[1] = {k: v[:0] for k, v in targets[1].items()}
+    out = model(images, calibs, targets, sizes)
+    losses = criterion(out, targets)
+    total = criterion.weighted_total(losses)
+    assert torch.isfinite(total)
+    total.backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    model.zero_grad(set_to_none=True)
