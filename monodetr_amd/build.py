@@ -40,8 +40,12 @@ def hipcc():
 def build(force=False, save_temps=False, verbose=False):
     if not force and not _stale():
         return LIB
+    # -amdgpu-mfma-vgpr-form: MFMA accumulators live in ordinary VGPRs (unified register file on
+    # gfx90a+).  Without it hipcc parks them in AGPRs and pays a v_accvgpr_read/write per element every
+    # time the softmax touches a score: 14-19 % of the attention kernels' VALU instructions.
     cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-munsafe-fp-atomics", "-Wno-pass-failed", "-I", INCLUDE, "-I", CSRC, "-o", LIB] + sources()
+           "-munsafe-fp-atomics", "-mllvm", "-amdgpu-mfma-vgpr-form", "-Wno-pass-failed",
+           "-I", INCLUDE, "-I", CSRC, "-o", LIB] + sources()
     if save_temps:
         tmp = os.path.join(HERE, "build_tmp")
         os.makedirs(tmp, exist_ok=True)

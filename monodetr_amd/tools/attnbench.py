@@ -29,6 +29,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--dropout", type=float, default=0.0, help="attention dropout probability (the model trains with 0.1)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     H, E = 8, 256
@@ -39,11 +40,11 @@ def main():
         flops = 4.0 * B * H * Lq * Lk * 32
 
         def hip_f():
-            return fused_attention(q, k, v, H)
+            return fused_attention(q, k, v, H, dropout_p=a.dropout)
 
         def sdpa_f():
             qh, kh, vh = (t.view(B, -1, H, 32).transpose(1, 2) for t in (q, k, v))
-            return F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B, Lq, E)
+            return F.scaled_dot_product_attention(qh, kh, vh, dropout_p=a.dropout).transpose(1, 2).reshape(B, Lq, E)
 
         row = {}
         for tag, f in (("hip", hip_f), ("sdpa", sdpa_f)):
@@ -53,7 +54,7 @@ def main():
             row[tag] = dict(fwd_ms=round(tf, 4), bwd_ms=round(tb, 4), fwd_TFLOPs=round(flops / tf / 1e9, 1),
                             bwd_TFLOPs=round(2.5 * flops / tb / 1e9, 1))
         res[name] = row
-    print(json.dumps(dict(dtype=a.dtype, **res)))
+    print(json.dumps(dict(dtype=a.dtype, dropout=a.dropout, **res)))
 
 
 if __name__ == "__main__":

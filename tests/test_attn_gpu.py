@@ -31,10 +31,11 @@ def keep_mask(seed, B, H, Lq, Lk, p):
     h = torch.arange(H).view(1, H, 1, 1)
     q = torch.arange(Lq).view(1, 1, Lq, 1)
     k = torch.arange(Lk).view(1, 1, 1, Lk)
-    x = (seed & M) ^ ((q * 0x9E3779B1) & M)
-    x = x ^ (((k + 0x7F4A7C15) & M) * 0x85EBCA77 & M)
-    x = x ^ ((((seed >> 32) & M) + ((b * 131 + h) * 0xC2B2AE3D & M)) & M)
-    x = x ^ (x >> 16); x = (x * 0x7FEB352D) & M; x = x ^ (x >> 15); x = (x * 0x846CA68B) & M; x = x ^ (x >> 16)
+    qterm = ((q * 0x9E3779B1) & M) ^ (seed & M) ^ ((((seed >> 32) & M) + ((b * 131 + h) * 0xC2B2AE3D & M)) & M)
+    kterm = (((k + 0x7F4A7C15) & M) * 0x85EBCA77) & M
+    x = qterm ^ kterm
+    x = x ^ (x >> 15)
+    x = (x * 0x2C1B3C6D) & M
     return x >= int(p * 4294967296.0)
 
 
