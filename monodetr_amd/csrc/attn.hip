@@ -443,11 +443,16 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
             dp = mfmaX<SP>(frag_rows<SP>(Vs, sub, 0, lane), dof[0], dp);  // dP^T[key][query] = V dO^T
             dp = mfmaX<SP>(frag_rows<SP>(Vs, sub, 1, lane), dof[1], dp);
             float ds[16];
+            const bool plain = !a.kpm && k0 + sub * 32 + 32 <= a.Lk;   // block-uniform: whole sub-tile valid, no mask
+            const bool row_ok = L2 != -__builtin_inff();
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + sub * 32 + acc_row(r, half);
-                bool ok = key < a.Lk && L2 != -__builtin_inff();
-                if (a.kpm) ok = ok && (a.kpm[static_cast<int64_t>(b) * a.Lk + (key < a.Lk ? key : 0)] == 0);
+                bool ok = row_ok;
+                if (!plain) {
+                    ok = ok && key < a.Lk;
+                    if (a.kpm) ok = ok && (a.kpm[static_cast<int64_t>(b) * a.Lk + (key < a.Lk ? key : 0)] == 0);
+                }
                 const float p = ok ? fast_exp2(s[r] - L2) : 0.f;
                 float g = dp[r];
                 if (drop) g = keep_elem(qterm, drop_kterm(key), thresh) ? g * rinv : 0.f;

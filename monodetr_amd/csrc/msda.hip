@@ -238,6 +238,130 @@ void msda_fwd_d32(const float *__restrict__ value, const int64_t *__restrict__ s
 }
 
 // ------------------------------------------------------------------------------------------------
+// fast path, forward, "sample record" form (L * P == 16)
+// ------------------------------------------------------------------------------------------------
+// In msda_fwd_d32 each of the 8 lanes of a pair recomputes the pair's 16 footprints (coordinates,
+// floor, window tests, corner addresses): ~1460 VALU instructions per round, a quarter of them
+// selects, ~100 quarter-rate integer multiplies -- PMC (profiles/r01h_pmc_msda.json): the kernel
+// issues VALU 38 % of its wave cycles and parks on memory only 38 %.  Here every (pair, sample)
+// footprint is computed ONCE, by one lane: a round has 8 x 16 = 128 samples = 2 per lane, whose
+// (x, y) and attention weight are read straight from global memory (consecutive lanes, consecutive
+// samples: coalesced), and published as a 32-byte LDS record {4 byte offsets, 4 bilinear weights}
+// (+ the attention weight in a side array); the 8 lanes of a pair then read each record as a
+// broadcast and only gather and accumulate.  A lane's sample slot -- hence its level geometry -- is
+// the same in every round, so H, W and the level start are loaded once per kernel.
+//
+// Exactness: a corner outside the map gets weight 0 and the address of a corner of the same sample
+// that IS inside (so the product is 0 x a value the reference also reads -- identical even for
+// non-finite values); a sample with no corner inside (or outside the window, .cuh:288) is flagged in
+// bit 0 of its first offset and its contribution is replaced by 0, as the reference skips it.
+struct alignas(16) SampleRec { int off[4]; float w[4]; };
+constexpr int kRecStride = 17;     // records per pair (16 + 1): the 8 pairs a wave reads in one instruction start 8 banks apart
+
+template <int TL, int TP>
+__global__ __launch_bounds__(kWaves * 64)
+void msda_fwd_rec(const float *__restrict__ value, const int64_t *__restrict__ shapes,
+                  const int64_t *__restrict__ lstart, const float *__restrict__ loc,
+                  const float *__restrict__ attn, float *__restrict__ out,
+                  int B, int S, int M, int npairs, int iters)
+{
+    constexpr int LP = TL * TP;
+    static_assert(LP == 16, "one record slot per lane and half-round");
+    __shared__ SampleRec s_rec[kWaves][kPairsPerWave * kRecStride];
+    __shared__ float s_att[kWaves][kPairsPerWave * kRecStride];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x % B, chunk = blockIdx.x / B;   // same image on the same XCD (bid % 8)
+    SampleRec *wrec = s_rec[wave];
+    float *watt = s_att[wave];
+    const int j = lane >> 3, k = lane & 7;
+    const char *vimg = reinterpret_cast<const char *>(value + static_cast<int64_t>(b) * S * M * 32) + k * 16;
+
+    // producer role: sample slot s = lane % 16 of pairs lane / 16 and 4 + lane / 16
+    const int ps = lane & 15, pl = ps / TP;
+    const int H = static_cast<int>(shapes[2 * pl]), W = static_cast<int>(shapes[2 * pl + 1]);
+    const int start = static_cast<int>(lstart[pl]);
+    const int dx = M * 128, dy = W * dx;                    // bytes to the next pixel / next row
+
+    for (int it = 0; it < iters; ++it) {
+        const int p0 = (chunk * iters + it) * (kWaves * kPairsPerWave) + wave * kPairsPerWave;
+        if (p0 >= npairs) break;                             // wave-uniform
+        const int nv = min(kPairsPerWave, npairs - p0);
+        const int64_t g0 = static_cast<int64_t>(b) * npairs + p0;
+        float2 xy[2];
+        float at[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int pj = 4 * hf + (lane >> 4);
+            const int64_t gs = (g0 + (pj < nv ? pj : 0)) * LP + ps;
+            xy[hf] = reinterpret_cast<const float2 *>(loc)[gs];
+            at[hf] = attn[gs];
+        }
+        wave_lds_fence();                                    // the previous round's records have been consumed
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int pj = 4 * hf + (lane >> 4);
+            const Foot<float> f = footprint(pix_coord(xy[hf].y, H), pix_coord(xy[hf].x, W), H, W);
+            const int m = (p0 + pj) % M;
+            const int o1 = ((start + f.h_low * W + f.w_low) * M + m) * 128;
+            const int o2 = o1 + dx, o3 = o1 + dy, o4 = o3 + dx;
+            const bool any = f.ok1 || f.ok2 || f.ok3 || f.ok4;
+            const int fb = f.ok1 ? o1 : (f.ok2 ? o2 : (f.ok3 ? o3 : o4));
+            SampleRec r;
+            r.off[0] = any ? (f.ok1 ? o1 : fb) : 1;          // bit 0 = "contributes nothing"
+            r.off[1] = any ? (f.ok2 ? o2 : fb) : 0;
+            r.off[2] = any ? (f.ok3 ? o3 : fb) : 0;
+            r.off[3] = any ? (f.ok4 ? o4 : fb) : 0;
+            r.w[0] = f.ok1 ? f.hh * f.hw : 0.f;
+            r.w[1] = f.ok2 ? f.hh * f.lw : 0.f;
+            r.w[2] = f.ok3 ? f.lh * f.hw : 0.f;
+            r.w[3] = f.ok4 ? f.lh * f.lw : 0.f;
+            if (pj < nv) {
+                SampleRec *dst = wrec + pj * kRecStride + ps;
+                *reinterpret_cast<int4 *>(dst->off) = make_int4(r.off[0], r.off[1], r.off[2], r.off[3]);
+                *reinterpret_cast<float4 *>(dst->w) = make_float4(r.w[0], r.w[1], r.w[2], r.w[3]);
+                watt[pj * kRecStride + ps] = f.inwin ? at[hf] : 0.f;
+            }
+        }
+        wave_lds_fence();
+        if (j < nv) {
+            const SampleRec *pr = wrec + j * kRecStride;
+            const float *pa = watt + j * kRecStride;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int l = 0; l < TL; ++l) {
+                int4 o[TP];
+                float4 w[TP], v[TP][4];
+                float a[TP];
+#pragma unroll
+                for (int p = 0; p < TP; ++p) {               // all 4*P gathers of a level are issued before any is consumed
+                    o[p] = *reinterpret_cast<const int4 *>(pr[l * TP + p].off);
+                    w[p] = *reinterpret_cast<const float4 *>(pr[l * TP + p].w);
+                    a[p] = pa[l * TP + p];
+                    v[p][0] = *reinterpret_cast<const float4 *>(vimg + (o[p].x & ~1));
+                    v[p][1] = *reinterpret_cast<const float4 *>(vimg + o[p].y);
+                    v[p][2] = *reinterpret_cast<const float4 *>(vimg + o[p].z);
+                    v[p][3] = *reinterpret_cast<const float4 *>(vimg + o[p].w);
+                }
+#pragma unroll
+                for (int p = 0; p < TP; ++p) {
+                    const bool skip = (o[p].x & 1) != 0;
+                    const float cx = w[p].x * v[p][0].x + w[p].y * v[p][1].x + w[p].z * v[p][2].x + w[p].w * v[p][3].x;
+                    const float cy = w[p].x * v[p][0].y + w[p].y * v[p][1].y + w[p].z * v[p][2].y + w[p].w * v[p][3].y;
+                    const float cz = w[p].x * v[p][0].z + w[p].y * v[p][1].z + w[p].z * v[p][2].z + w[p].w * v[p][3].z;
+                    const float cw = w[p].x * v[p][0].w + w[p].y * v[p][1].w + w[p].z * v[p][2].w + w[p].w * v[p][3].w;
+                    acc.x += (skip ? 0.f : cx) * a[p];
+                    acc.y += (skip ? 0.f : cy) * a[p];
+                    acc.z += (skip ? 0.f : cz) * a[p];
+                    acc.w += (skip ? 0.f : cw) * a[p];
+                }
+            }
+            *reinterpret_cast<float4 *>(out + (g0 + j) * 32 + k * 4) = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fast path, backward
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void atomic_add4(float *p, float s, const float4 &t)
@@ -598,7 +722,13 @@ hipError_t msda_forward_launch(int dtype, const void *value, const int64_t *shap
                                static_cast<const float *>(loc), static_cast<const float *>(attn),
                                static_cast<float *>(out), B, S, M, L, P, npairs, iters);
         };
-        if (L == 4 && P == 4) a(msda_fwd_d32<4, 4>); else a(msda_fwd_d32<0, 0>);
+        static const bool legacy = [] { const char *ev = getenv("MDETR_MSDA_FWD_LEGACY"); return ev && atoi(ev) != 0; }();
+        if (L == 4 && P == 4 && !legacy)
+            hipLaunchKernelGGL((msda_fwd_rec<4, 4>), grid, block, 0, st, static_cast<const float *>(value), shapes, lstart,
+                               static_cast<const float *>(loc), static_cast<const float *>(attn),
+                               static_cast<float *>(out), B, S, M, npairs, iters);
+        else if (L == 4 && P == 4) a(msda_fwd_d32<4, 4>);
+        else a(msda_fwd_d32<0, 0>);
     } else if (dtype == 0) {
         hipLaunchKernelGGL(msda_fwd_generic<float>, dim3(grid_for(n, 256)), dim3(256), 0, st,
                            static_cast<const float *>(value), shapes, lstart, static_cast<const float *>(loc),
