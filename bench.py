@@ -187,8 +187,12 @@ def cpu_baseline(steps=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--prime", type=int, default=12,
+                    help="untimed start-up iterations before the W warm-up steps (MIOpen solver search, hipBLASLt "
+                         "kernel selection, allocator pool growth, clock ramp: the first ~15 iterations of a process "
+                         "run 10-25 %% slower than its steady state)")
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--precision", default=os.environ.get("MDETR_BENCH_PRECISION", "bf16"), choices=["fp32", "bf16", "bf16-autocast"],
                     help="bf16 = bf16 model body + fp32 heads + fp32 master weights (helpers/precision.py); "
@@ -225,6 +229,8 @@ def main():
     if use_graph:
         step.capture()                                              # untimed: part of start-up, like model build
 
+    for _ in range(args.prime):                                     # process start-up, like the model build
+        step()
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -258,7 +264,7 @@ def main():
     assert torch.isfinite(loss).item(), "training loss is not finite"
 
     # ---- per-kernel timings from the HIP events recorded by the C ABI during the timed steps --------
-    names = {0: "msda_fwd_d32", 1: "msda_bwd_d32", 2: "msda_scatter_tiles", 3: "msda_reduce_tiles",
+    names = {0: "msda_fwd_rec", 1: "msda_bwd_d32", 2: "msda_scatter_tiles", 3: "msda_reduce_tiles",
              4: "attn_fwd_kernel", 5: "attn_bwd(prep+dq+dkv)"}
     kernels, by_key = [], {}
     for kind, key, launches, total_ms in _capi.profile_read():
@@ -304,7 +310,7 @@ def main():
                                    "550 train queries, 4 levels, criterion + AdamW) = BASELINE configs[2] (1 GPU) / "
                                    "configs[3] (DDP)",
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "image": "3x384x1280",
-                       "precision": args.precision, "parallelism": "dp%d" % world,
+                       "precision": args.precision, "parallelism": "dp%d" % world, "prime_steps": args.prime,
                        "launch": "one hipGraph replay per iteration" if use_graph else "eager"},
             "final_loss": round(float(loss), 4),
         }
