@@ -155,6 +155,31 @@ class TrainStep:
         return total
 
 
+def bind_to_gpu_numa_node(local_rank):
+    """Pin this process (and the threads it creates later: autograd workers, RCCL proxies) to the CPUs
+    of the NUMA node the GPU hangs off -- what `numactl --cpunodebind` does per rank in a production
+    launch.  The bf16 step is launch-bound, and launches issued from the far socket are slower and
+    noisier.  Returns (node, previous affinity) or None when the topology cannot be read."""
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bus = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bus).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        before = os.sched_getaffinity(0)
+        cpus &= before
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node, before
+    except (OSError, ValueError, AttributeError):
+        return None
+
+
 def msda_algorithmic_bytes(B, Lq, backward, S=10200, M=8, D=32, L=4, P=4, e=4):
     """value + loc + attn + out (forward); + grad_value + grad_loc + grad_attn (backward)."""
     fwd = e * B * (S * M * D + Lq * M * L * P * 3 + Lq * M * D)
@@ -215,7 +240,16 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    bound = None if os.environ.get("MDETR_BENCH_NO_NUMA_BIND") == "1" else bind_to_gpu_numa_node(local_rank)
+    # MDETR_BENCH_FORCE_DDP=1: take the N > 1 code path (process group, DDP wrapper, RCCL all-reduce,
+    # barriers) with a single rank -- the only way to exercise it on a 1-GPU box
+    force_ddp = os.environ.get("MDETR_BENCH_FORCE_DDP", "0") == "1"
+    if force_ddp and world == 1:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    dist_on = world > 1 or force_ddp
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", device_id=device)      # RCCL on ROCm
@@ -225,7 +259,7 @@ def main():
     use_graph = args.graph == "on"
     if use_graph and world > 1:
         raise SystemExit("--graph on is a single-GPU mode (the RCCL all-reduce of DDP is not captured)")
-    step = TrainStep(device, args.batch, args.precision, ddp=world > 1, local_rank=local_rank, graph=use_graph)
+    step = TrainStep(device, args.batch, args.precision, ddp=dist_on, local_rank=local_rank, graph=use_graph)
     if use_graph:
         step.capture()                                              # untimed: part of start-up, like model build
 
@@ -233,7 +267,7 @@ def main():
         step()
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     _capi.profile_enable(not use_graph)
@@ -241,7 +275,7 @@ def main():
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
     _capi.profile_enable(False)
@@ -257,7 +291,7 @@ def main():
         torch.cuda.synchronize()
         _capi.profile_enable(False)
         kernel_timing = "HIP events around every launch of 3 eager iterations run right after the timed graph replays"
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
@@ -323,10 +357,13 @@ def main():
             line["roofline"]["timing"] = kernel_timing
             line["ops"] = ops
             line["kernels"] = kernels
+        line["config"]["cpu_affinity"] = "NUMA node %d of the GPU" % bound[0] if bound else "unbound"
         if world == 1 and not args.no_cpu_baseline:
+            if bound:
+                os.sched_setaffinity(0, bound[1])                   # the CPU baseline gets every core again
             line["cpu_baseline"] = cpu_baseline(args.cpu_steps)
         print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 
