@@ -92,12 +92,18 @@ class TrainStep:
         self.model.train()
         self.criterion.train()
         self.raw_model = self.model
-        if ddp:
+        self.grad_sync = None
+        if ddp == "ddp":
             from torch.nn.parallel import DistributedDataParallel as DDP
             # static_graph: label_enc / sa_v_proj / decoder.query_scale / decoder.ref_point_head never
             # receive gradients on the default path; bucket views avoid a grad copy
             self.model = DDP(self.model, device_ids=[local_rank], static_graph=True, gradient_as_bucket_view=True,
                              bucket_cap_mb=64)
+        elif ddp:
+            # default N > 1 path: one flat all-reduce per dtype after the backward (helpers/dist_helper.py)
+            from monodetr_amd.helpers.dist_helper import FlatGradSync, broadcast_parameters
+            broadcast_parameters(self.raw_model)
+            self.grad_sync = FlatGradSync(self.raw_model.parameters())
         self.optimizer = build_optimizer(dict(OPT_CFG, capturable=graph), self.raw_model)
         self.graph = None
         self.want_graph = graph
@@ -151,6 +157,8 @@ class TrainStep:
             losses = self.criterion(out, targets, None)
         total = self.criterion.weighted_total(losses)               # trainer_helper.py:141-143, one dot product
         total.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.sync()
         self.optimizer.step()
         return total
 
@@ -259,7 +267,7 @@ def main():
     use_graph = args.graph == "on"
     if use_graph and world > 1:
         raise SystemExit("--graph on is a single-GPU mode (the RCCL all-reduce of DDP is not captured)")
-    step = TrainStep(device, args.batch, args.precision, ddp=dist_on, local_rank=local_rank, graph=use_graph)
+    step = TrainStep(device, args.batch, args.precision, ddp=(os.environ.get("MDETR_BENCH_SYNC", "flat") if dist_on else False), local_rank=local_rank, graph=use_graph)
     if use_graph:
         step.capture()                                              # untimed: part of start-up, like model build
 
@@ -344,7 +352,8 @@ def main():
                                    "550 train queries, 4 levels, criterion + AdamW) = BASELINE configs[2] (1 GPU) / "
                                    "configs[3] (DDP)",
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "image": "3x384x1280",
-                       "precision": args.precision, "parallelism": "dp%d" % world, "prime_steps": args.prime,
+                       "precision": args.precision, "parallelism": "dp%d" % world,
+                       "grad_sync": (os.environ.get("MDETR_BENCH_SYNC", "flat") if dist_on else "none"), "prime_steps": args.prime,
                        "launch": "one hipGraph replay per iteration" if use_graph else "eager"},
             "final_loss": round(float(loss), 4),
         }

@@ -81,7 +81,36 @@ def _worker(rank, world, port, out_dir):
         dist.all_gather(gathered, flat)
         same = all(torch.equal(gathered[0], g) for g in gathered[1:])
         unused = sorted(n for n, p in model.named_parameters() if p.requires_grad and p.grad is None)
-        torch.save(dict(worst=worst, same=same, unused=unused, n_grads=len(got)), os.path.join(out_dir, "r%d.pt" % rank))
+
+        # bench.py's default N > 1 path: FlatGradSync (one flat all-reduce per dtype after the backward),
+        # including a bf16 group and a deliberately perturbed start that broadcast_parameters must repair
+        from monodetr_amd.helpers.dist_helper import FlatGradSync, broadcast_parameters
+        model, criterion = fresh()
+        if rank == 1:
+            with torch.no_grad():
+                next(model.parameters()).add_(1.0)
+        broadcast_parameters(model)
+        sync = FlatGradSync(model.parameters())
+        opt = build_optimizer({'type': 'adamw', 'lr': 2e-4, 'weight_decay': 1e-4}, model)
+        opt.zero_grad(set_to_none=True)
+        loss_of(model, criterion, batch).backward()
+        sync.sync()
+        got2 = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        assert sorted(got2) == sorted(avg)
+        worst_flat = max(((got2[n] - avg[n]).abs().max() / (avg[n].abs().max() + 1e-12)).item() for n in avg)
+        opt.step()
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        same_flat = all(torch.equal(gathered[0], g) for g in gathered[1:])
+        # mixed dtypes: a bf16 and an fp32 tensor go through separate flat buffers
+        a = torch.nn.Parameter(torch.full((5,), float(rank + 1)))
+        b = torch.nn.Parameter(torch.full((3, 2), float(rank + 1), dtype=torch.bfloat16))
+        a.grad, b.grad = torch.full((5,), float(rank + 1)), torch.full((3, 2), float(2 * rank + 2), dtype=torch.bfloat16)
+        FlatGradSync([a, b]).sync()
+        mixed_ok = bool((a.grad == (1 + world) / 2).all()) and bool((b.grad.float() == (1 + world)).all())
+        torch.save(dict(worst=worst, same=same, unused=unused, n_grads=len(got), worst_flat=worst_flat, same_flat=same_flat,
+                        mixed_ok=mixed_ok), os.path.join(out_dir, "r%d.pt" % rank))
     finally:
         dist.destroy_process_group()
 
@@ -94,6 +123,7 @@ def test_two_rank_ddp_step_matches_manual_gradient_average(tmp_path):
         res = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
         assert res["same"], "ranks diverged after the optimizer step"
         assert res["worst"] < 1e-4, res["worst"]
+        assert res["same_flat"] and res["worst_flat"] < 1e-4 and res["mixed_ok"], res
         assert res["n_grads"] > 300
         assert all(n.startswith("label_enc") or ".sa_v_proj." in n or "decoder.query_scale" in n or "decoder.ref_point_head" in n
                    for n in res["unused"]), res["unused"]
