@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$PWD; O=$R/gpurun_out/attn; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/attn; mkdir -p $O
 python -m pytest tests/test_attn_gpu.py -x -q 2>&1 | tail -1
 for d in 0.0 0.1; do python -m monodetr_amd.tools.attnbench --dtype bf16 --dropout $d 2>/dev/null | tail -1; done
 python -m monodetr_amd.tools.attnbench --dtype fp32 --dropout 0.1 2>/dev/null | tail -1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # end-of-round evidence: GPU tests, smoke, bench lines, steady-state kernel stats + rocprofv3 --stats, op benches
-R=$PWD; O=$R/gpurun_out/final; mkdir -p $O; T=${1:-r01h}
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/final; mkdir -p $O; T=${1:-r01h}
 python -m pytest tests -m gpu -q 2>&1 | tail -2 > $O/${T}_pytest_gpu.log; cat $O/${T}_pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 python bench.py > $O/${T}_bench_bf16.json 2> $O/bench_bf16.err; cut -c1-200 $O/${T}_bench_bf16.json

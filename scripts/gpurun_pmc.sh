@@ -1,6 +1,6 @@
 #!/bin/bash
 # one PMC pass per counter set over the MSDA and attention op benches (run through gpurun)
-R=$PWD; O=$R/gpurun_out/pmc; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/pmc; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R
 rocprofv3 -L 2>/dev/null | grep -o -E "\b(SQ|TCC|TCP|TA|GRBM)_[A-Za-z0-9_]+" | sort -u > $O/counter_names.txt
 i=0
