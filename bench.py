@@ -104,7 +104,10 @@ class TrainStep:
             from monodetr_amd.helpers.dist_helper import FlatGradSync, broadcast_parameters
             broadcast_parameters(self.raw_model)
             self.grad_sync = FlatGradSync(self.raw_model.parameters())
-        self.optimizer = build_optimizer(dict(OPT_CFG, capturable=graph), self.raw_model)
+        # MDETR_FUSED_ADAMW=1: one-launch-per-group HIP AdamW (helpers/optimizer_helper.FusedAdamW); off until
+        # its kernel has had its first GPU validation (tests/test_pending_gpu.py)
+        self.optimizer = build_optimizer(dict(OPT_CFG, capturable=graph, fused=os.environ.get("MDETR_FUSED_ADAMW") == "1"),
+                                         self.raw_model)
         self.graph = None
         self.want_graph = graph
         self.precision = precision

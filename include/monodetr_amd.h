@@ -158,6 +158,23 @@ int mdetr_attn_backward(int dtype, const void *q, const void *k, const void *v, 
                         float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev, int device, void *stream);
 
 /*
+ * One step of the reference's AdamW (lib/helpers/optimizer_helper.py:69-129 -- not torch.optim.AdamW: the
+ * decoupled decay is scaled by the bias-corrected step, eps is added outside the bias correction) over a
+ * FLAT parameter group, in one launch:
+ *     m <- b1 m + (1-b1) g ;  v <- b2 v + (1-b2) g^2 ;  p <- p - step (wd p + m / (sqrt(v) + eps))
+ *   param_dtype   MDETR_F32: param == master, fp32 gradient;  MDETR_BF16: bf16 param and gradient, the
+ *                 update runs on the fp32 `master` copy and the rounded result is written to `param`
+ *   n_no_decay    elements [0, n_no_decay) use weight decay 0 (the reference gives 'bias' parameters
+ *                 wd = 0, :8-16); the caller lays the group out with those first
+ *   step_size     lr * sqrt(1 - b2^t) / (1 - b1^t), computed by the caller;  step_size_dev, if not
+ *                 NULL, is a device fp32 scalar used instead (graph-replay-safe step count)
+ * All five arrays hold n elements and are 16-byte aligned.  exp_avg / exp_avg_sq / master are fp32.
+ */
+int mdetr_adamw_step(int param_dtype, void *param, float *master, const void *grad, float *exp_avg, float *exp_avg_sq,
+                     int64_t n, int64_t n_no_decay, float beta1, float beta2, float eps, float weight_decay,
+                     float step_size, const float *step_size_dev, int device, void *stream);
+
+/*
  * Column sums of a tall row-major matrix, accumulated in fp32: out[j] = sum_i x[i * ld + j].
  * Not an entry point of the reference's extension: it is the bias gradient of the model's token-wise
  * linear layers (db = sum over the 81 600 tokens of dY; torch's autograd computes it with a generic

@@ -12,6 +12,7 @@
 
 #include "../../include/monodetr_amd.h"
 #include "attn.h"
+#include "adamw.h"
 #include "colsum.h"
 #include "lsa.h"
 #include "msda.h"
@@ -268,6 +269,28 @@ int mdetr_lsa_forward(const float *cost, const int32_t *num_targets, int32_t *as
     const hipError_t e = mdetr::lsa_launch(cost, num_targets, assign, layers, images, groups, n, kmax,
                                            img_stride, q_stride, t_stride, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_lsa_forward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_adamw_step(int param_dtype, void *param, float *master, const void *grad, float *exp_avg, float *exp_avg_sq,
+                     int64_t n, int64_t n_no_decay, float beta1, float beta2, float eps, float weight_decay,
+                     float step_size, const float *step_size_dev, int device, void *stream)
+{
+    if (param_dtype != MDETR_F32 && param_dtype != MDETR_BF16)
+        return fail(MDETR_E_ARG, "mdetr_adamw_step: parameter dtype must be f32 or bf16");
+    if (n < 0 || n_no_decay < 0 || n_no_decay > n) return fail(MDETR_E_ARG, "mdetr_adamw_step: bad sizes");
+    if (n == 0) return MDETR_OK;
+    if (!param || !master || !grad || !exp_avg || !exp_avg_sq) return fail(MDETR_E_ARG, "mdetr_adamw_step: null pointer");
+    if (param_dtype == MDETR_F32 && static_cast<void *>(master) != param)
+        return fail(MDETR_E_ARG, "mdetr_adamw_step: an f32 parameter is its own master copy");
+    if (!aligned16(param) || !aligned16(master) || !aligned16(grad) || !aligned16(exp_avg) || !aligned16(exp_avg_sq))
+        return fail(MDETR_E_ALIGN, "mdetr_adamw_step: buffers must be 16-byte aligned");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_adamw_step: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::adamw_launch(param_dtype, param, master, grad, exp_avg, exp_avg_sq, n, n_no_decay,
+                                             beta1, beta2, eps, weight_decay, step_size, step_size_dev,
+                                             static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_adamw_step: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

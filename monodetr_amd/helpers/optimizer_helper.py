@@ -39,7 +39,8 @@ def build_optimizer(cfg_optimizer, model):
     if kind == 'adam':
         return optim.Adam(parameters, lr=cfg_optimizer['lr'])
     if kind == 'adamw':
-        return AdamW(parameters, lr=cfg_optimizer['lr'], capturable=bool(cfg_optimizer.get('capturable', False)))
+        cls = FusedAdamW if cfg_optimizer.get('fused', False) else AdamW
+        return cls(parameters, lr=cfg_optimizer['lr'], capturable=bool(cfg_optimizer.get('capturable', False)))
     raise NotImplementedError("%s optimizer is not supported" % kind)
 
 
@@ -62,6 +63,18 @@ class AdamW(Optimizer):
         for group in self.param_groups:
             group.setdefault('amsgrad', False)
             group.setdefault('capturable', False)
+
+    def load_state_dict(self, state_dict):
+        """torch's loader casts every floating-point state tensor to its parameter's dtype, which would
+        round the fp32 moments and master copy of a bf16 parameter to bf16: put the tensors back as saved."""
+        from itertools import chain
+        super().load_state_dict(state_dict)
+        saved_ids = chain.from_iterable(g['params'] for g in state_dict['param_groups'])
+        own = chain.from_iterable(g['params'] for g in self.param_groups)
+        for pid, p in zip(saved_ids, own):
+            for k, v in state_dict['state'].get(pid, {}).items():
+                if torch.is_tensor(v) and v.is_floating_point() and k != 'step':
+                    self.state[p][k] = v.detach().clone().to(device=p.device)
 
     def _device_step_size(self, group, device, first_step):
         """lr * sqrt(1 - b2^t) / (1 - b1^t) as a device scalar.  t lives on the device, one counter
@@ -144,3 +157,149 @@ class AdamW(Optimizer):
                 if low:
                     torch._foreach_copy_(low, [self.state[p]['master'] for p in low])
         return loss
+
+
+class FusedAdamW(AdamW):
+    """The same update as :class:`AdamW` with ONE kernel launch per (parameter group, dtype)
+    (csrc/adamw.hip through ``mdetr_adamw_step``) instead of ~40 multi-tensor launches per group.
+
+    At the first ``step()`` the parameters that receive gradients are re-homed into one flat buffer per
+    (group, dtype) -- each ``p.data`` becomes a view with its original shape and strides, segments
+    start on 256-byte boundaries -- together with flat fp32 ``exp_avg`` / ``exp_avg_sq`` (and fp32
+    master copies of bf16 parameters); ``state[p]`` holds views of those, so ``state_dict()`` keeps the
+    reference's per-parameter layout.  Each step copies the gradients into a flat staging buffer with one
+    multi-tensor copy and launches the update.  CUDA parameters only; amsgrad, sparse gradients and CPU
+    parameters take the parent's path.  """
+
+    _PAD = 64                                    # elements: 256 B for fp32 segments, 128 B for bf16
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._flat = None
+        self._lib = None                         # tests substitute a host build of the same kernel arithmetic
+        self._allow_cpu = False
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)      # AdamW.load_state_dict: keeps the saved dtypes
+        self._flat = None                        # loaded state tensors are not views of the flat buffers: rebuild
+
+    def _eligible(self):
+        for group in self.param_groups:
+            if group['amsgrad']:
+                return False
+            for p in group['params']:
+                if p.grad is not None and ((not p.is_cuda and not self._allow_cpu) or p.grad.is_sparse
+                                           or p.dtype not in (torch.float32, torch.bfloat16)):
+                    return False
+        return True
+
+    @staticmethod
+    def _dense(t):
+        return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
+
+    def _signature(self):
+        return tuple(tuple(id(p) for p in g['params'] if p.grad is not None) for g in self.param_groups)
+
+    @torch.no_grad()
+    def _build_flat(self):
+        flat = []
+        for gi, group in enumerate(self.param_groups):
+            # one flat buffer per (dtype, number of steps already taken): a parameter that first receives a
+            # gradient later has its own bias correction, as in the parent class
+            by_dtype = {}
+            for p in group['params']:
+                if p.grad is not None:
+                    by_dtype.setdefault((p.dtype, int(self.state[p].get('step', 0))), []).append(p)
+            for (dtype, _), plist in by_dtype.items():
+                offs, total = [], 0
+                for p in plist:
+                    offs.append(total)
+                    total += -(-p.numel() // self._PAD) * self._PAD
+                dev = plist[0].device
+                buf = dict(group=gi, dtype=dtype, params=plist, n=total,
+                           param=torch.zeros(total, dtype=dtype, device=dev),
+                           grad=torch.zeros(total, dtype=dtype, device=dev),
+                           exp_avg=torch.zeros(total, dtype=torch.float32, device=dev),
+                           exp_avg_sq=torch.zeros(total, dtype=torch.float32, device=dev))
+                buf['master'] = buf['param'] if dtype == torch.float32 else torch.zeros(total, dtype=torch.float32, device=dev)
+                grad_views, steps = [], set()
+                for p, off in zip(plist, offs):
+                    if not self._dense(p.data):
+                        p.data = p.data.contiguous()
+                    shape, stride, n = tuple(p.shape), tuple(p.stride()), p.numel()
+
+                    def view(t, off=off, shape=shape, stride=stride):
+                        return t.as_strided(shape, stride, off)
+                    st = self.state[p]
+                    view(buf['param']).copy_(p.data)
+                    if dtype != torch.float32:
+                        view(buf['master']).copy_(st['master'] if 'master' in st else p.data)
+                    if 'exp_avg' in st:                         # carry an existing state over (load_state_dict, late switch)
+                        view(buf['exp_avg']).copy_(st['exp_avg'])
+                        view(buf['exp_avg_sq']).copy_(st['exp_avg_sq'])
+                    p.data = view(buf['param'])
+                    st['exp_avg'], st['exp_avg_sq'] = view(buf['exp_avg']), view(buf['exp_avg_sq'])
+                    if dtype != torch.float32:
+                        st['master'] = view(buf['master'])
+                        st.pop('grad32', None)
+                    st.setdefault('step', 0)
+                    steps.add(int(st['step']))
+                    grad_views.append(view(buf['grad']))
+                if len(steps) != 1:
+                    raise RuntimeError("FusedAdamW: the parameters of a flat group must have taken the same number of steps")
+                buf['grad_views'], buf['step'] = grad_views, steps.pop()
+                flat.append(buf)
+        self._flat = (self._signature(), flat)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if not self._eligible():
+            return super().step(closure)
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self._flat is None or self._flat[0] != self._signature():
+            self._build_flat()
+        from .. import _capi
+        lib = self._lib if self._lib is not None else _capi.lib()
+        for buf in self._flat[1]:
+            group = self.param_groups[buf['group']]
+            beta1, beta2 = group['betas']
+            grads = []
+            for p in buf['params']:
+                g = p.grad
+                grads.append(g if g.stride() == p.stride() else torch.empty_like(p).copy_(g))
+            torch._foreach_copy_(buf['grad_views'], grads)
+            buf['step'] += 1
+            t = buf['step']
+            for p in buf['params']:
+                self.state[p]['step'] = t
+            step_dev = None
+            if group['capturable']:
+                group['calls'] = group.get('calls', 0)            # the device counters are keyed like the parent's
+                step_dev = self._fused_step_size(group, buf, t)
+            step = float(group['lr']) * math.sqrt(1 - beta2 ** t) / (1 - beta1 ** t) if step_dev is None else 0.0
+            dev = buf['param'].device
+            rc = lib.mdetr_adamw_step(
+                _capi.MDETR_BF16 if buf['dtype'] == torch.bfloat16 else _capi.MDETR_F32,
+                buf['param'].data_ptr(), buf['master'].data_ptr(), buf['grad'].data_ptr(),
+                buf['exp_avg'].data_ptr(), buf['exp_avg_sq'].data_ptr(), buf['n'],
+                buf['n'] if group['weight_decay'] == 0 else 0, beta1, beta2, group['eps'], group['weight_decay'],
+                step, step_dev.data_ptr() if step_dev is not None else None,
+                dev.index if dev.type == "cuda" else -1,
+                torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None)
+            if rc != 0:
+                _capi.check(rc, "mdetr_adamw_step")
+        return loss
+
+    def _fused_step_size(self, group, buf, first_step):
+        """Device-resident bias-corrected step size of one flat buffer (capturable mode)."""
+        beta1, beta2 = group['betas']
+        t = buf.get('step_dev')
+        if t is None:
+            t = buf['step_dev'] = torch.full((), float(first_step - 1), dtype=torch.float64, device=buf['param'].device)
+        t.add_(1.0)
+        lr = group['lr']
+        lr = lr.to(device=t.device, dtype=torch.float64) if torch.is_tensor(lr) else float(lr)
+        return (lr * torch.sqrt(1.0 - torch.pow(beta2, t)) / (1.0 - torch.pow(beta1, t))).to(torch.float32)

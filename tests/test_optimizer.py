@@ -70,3 +70,93 @@ def test_capturable_mode_matches_host_step_size():
         # the step size is rounded to fp32 on the device: relative 6e-8 of an update of order lr
         assert (p.detach() - ref).abs().max() < 1e-9, n
     assert max(float(t) for t in opt.param_groups[0]['step_dev'].values()) == 6.0
+
+
+def _fused(params_or_model, **kw):
+    """FusedAdamW wired to the HOST build of the kernel arithmetic (tests/native) so that the flat
+    layout logic and the update formula run on CPU tensors."""
+    import native_host
+    from monodetr_amd.helpers.optimizer_helper import FusedAdamW, build_optimizer
+    if isinstance(params_or_model, torch.nn.Module):
+        opt = build_optimizer({'type': 'adamw', 'lr': 2e-4, 'weight_decay': 1e-4, 'fused': True, **kw}, params_or_model)
+    else:
+        opt = FusedAdamW(params_or_model, **kw)
+    assert isinstance(opt, FusedAdamW)
+    opt._lib, opt._allow_cpu = native_host.lib(), True
+    return opt
+
+
+def test_fused_adamw_matches_reference_steps_fp32():
+    """One launch per (group, dtype) over flat buffers == six recorded steps of the reference's AdamW
+    (fp32 arithmetic against the fp64 recording: 1e-6 relative)."""
+    g = load_golden("optimizer_adamw")
+    shadow, model = make_model(), make_model().float()          # the recorded gradients are float64 draws
+    opt = _fused(model)
+    for step in range(6):
+        make_grads(shadow, step)
+        for ps, p in zip(shadow.parameters(), model.parameters()):
+            p.grad = None if ps.grad is None else ps.grad.float()
+        opt.step()
+    for n, p in model.named_parameters():
+        ref = torch.as_tensor(g["step5/%s" % n]).float()
+        assert (p.detach() - ref).abs().max() <= 2e-6 * max(1.0, ref.abs().max().item()), n
+    # the parameters are now views of one flat buffer per (group, dtype, cohort): 2 groups x {from step 0, 'late' from step 2}
+    flat = opt._flat[1]
+    assert len(flat) == 4 and all(b["param"].data_ptr() <= p.data_ptr() < b['param'].data_ptr() + 4 * b['n']
+                                  for b in flat for p in b['params'])
+    sd = opt.state_dict()
+    assert sd['state'][0]['exp_avg'].shape == opt.param_groups[0]['params'][0].shape
+
+
+def test_fused_adamw_equals_foreach_adamw_on_mixed_layouts_and_dtypes():
+    """Same trajectory as the multi-tensor AdamW for fp32 + bf16 parameters, a channels_last 4-d weight,
+    odd sizes (padding) and a parameter that never gets a gradient; then a state_dict round trip."""
+    from monodetr_amd.helpers.optimizer_helper import AdamW
+    torch.manual_seed(5)
+
+    def make():
+        torch.manual_seed(5)
+        w4 = torch.nn.Parameter(torch.randn(6, 5, 3, 3).contiguous(memory_format=torch.channels_last))
+        b1 = torch.nn.Parameter(torch.randn(7))
+        wl = torch.nn.Parameter(torch.randn(33, 17).to(torch.bfloat16))
+        bl = torch.nn.Parameter(torch.randn(33).to(torch.bfloat16))
+        unused = torch.nn.Parameter(torch.randn(4))
+        groups = [{'params': [b1, bl, unused], 'weight_decay': 0}, {'params': [w4, wl], 'weight_decay': 1e-2}]
+        return [w4, b1, wl, bl, unused], groups
+
+    pa, ga = make()
+    pb, gb = make()
+    oa, ob = AdamW(ga, lr=1e-3), _fused(gb, lr=1e-3)
+    for step in range(5):
+        gen = torch.Generator().manual_seed(100 + step)
+        for x, y in zip(pa[:4], pb[:4]):
+            g = torch.randn(x.shape, generator=gen)
+            if x.dim() == 4:
+                g = g.contiguous(memory_format=torch.channels_last)
+            x.grad, y.grad = g.to(x.dtype), g.to(y.dtype).clone()
+        oa.step(); ob.step()
+    for x, y in zip(pa, pb):
+        assert x.stride() == y.stride()
+        tol = 1e-6 if x.dtype == torch.float32 else 1e-2
+        assert (x.detach().float() - y.detach().float()).abs().max() <= tol * max(1.0, x.detach().float().abs().max().item())
+    # fp32 master copies of the bf16 parameters agree much more closely than the rounded model copies
+    assert (oa.state[pa[2]]['master'] - ob.state[pb[2]]['master']).abs().max() < 1e-5
+    assert ob.state[pb[2]]['master'].dtype == torch.float32 and torch.equal(pb[2].detach(), ob.state[pb[2]]['master'].to(torch.bfloat16))
+    assert pb[4].grad is None and 'exp_avg' not in ob.state[pb[4]]
+    # state_dict round trip into a fresh fused optimizer continues the same trajectory
+    pc, gc = make()
+    oc = _fused(gc, lr=1e-3)
+    with torch.no_grad():
+        for y, z in zip(pb, pc):
+            z.copy_(y)
+    import copy
+    oc.load_state_dict(copy.deepcopy(ob.state_dict()))          # as read back from a checkpoint file
+    gen = torch.Generator().manual_seed(999)
+    for y, z in zip(pb[:4], pc[:4]):
+        g = torch.randn(y.shape, generator=gen)
+        if y.dim() == 4:
+            g = g.contiguous(memory_format=torch.channels_last)
+        y.grad, z.grad = g.to(y.dtype), g.to(z.dtype).clone()
+    ob.step(); oc.step()
+    for y, z in zip(pb[:4], pc[:4]):
+        assert torch.equal(y.detach(), z.detach())
