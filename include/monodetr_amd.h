@@ -158,6 +158,40 @@ int mdetr_attn_backward(int dtype, const void *q, const void *k, const void *v, 
                         float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev, int device, void *stream);
 
 /*
+ * MonoDETR's matched-pair losses for all decoder levels at once (lib/models/monodetr/monodetr.py:320-458:
+ * loss_labels / loss_cardinality / loss_3dcenter / loss_boxes / loss_depths / loss_dims / loss_angles, called per
+ * level by SetCriterion.forward :490-532), one launch forward and one backward.
+ *   predictions, level-stacked fp32:  logits [L,B,Q,C], boxes [L,B,Q,6] (cx,cy,l,r,t,b), dims [L,B,Q,3],
+ *                                     depths [L,B,Q,2] (mean, log-variance), angles [L,B,Q,24]
+ *   assign  int32 [L,B,G,K]   matched query of target slot k in query group g, or -1 (mdetr_lsa_forward's output)
+ *   ground truth padded to K slots per image:  labels, heading_bin int64 [B,K]; boxes3d [B,K,6]; depth [B,K];
+ *                                     size3d [B,K,3]; heading_res [B,K]; valid uint8 [B,K]; num int32 [B]
+ *   num_boxes / num_boxes_dev         the normaliser (:503-508), host value or device scalar (non-NULL wins)
+ *   out     fp32 [9, L]: loss_ce, loss_center, loss_bbox, loss_giou, loss_depth, loss_dim, loss_angle,
+ *           class_error, cardinality_error per level;   comp fp32 [L]: the dimension-aware L1's detached factor
+ *   workspace  >= mdetr_pair_losses_workspace_bytes(L, B) bytes, ZERO before the first call; every forward
+ *           call leaves it zero again
+ * backward: grad_out fp32 [9, L] (rows 0-6 are read) -> gradients of the five prediction tensors, every element
+ * written (zeros for unmatched queries).  Q % G == 0, C <= 8, K <= 64.
+ */
+int64_t mdetr_pair_losses_workspace_bytes(int L, int B);
+int mdetr_pair_losses_forward(const float *logits, const float *boxes, const float *dims, const float *depths,
+                              const float *angles, const int32_t *assign, const int64_t *labels, const float *boxes3d,
+                              const float *depth, const float *size3d, const int64_t *heading_bin,
+                              const float *heading_res, const uint8_t *valid, const int32_t *num,
+                              int L, int B, int Q, int C, int G, int K, float focal_alpha,
+                              float num_boxes, const float *num_boxes_dev, float *out, float *comp, void *workspace,
+                              int device, void *stream);
+int mdetr_pair_losses_backward(const float *logits, const float *boxes, const float *dims, const float *depths,
+                               const float *angles, const int32_t *assign, const int64_t *labels, const float *boxes3d,
+                               const float *depth, const float *size3d, const int64_t *heading_bin,
+                               const float *heading_res, const uint8_t *valid,
+                               int L, int B, int Q, int C, int G, int K, float focal_alpha,
+                               float num_boxes, const float *num_boxes_dev, const float *grad_out, const float *comp,
+                               float *g_logits, float *g_boxes, float *g_dims, float *g_depths, float *g_angles,
+                               int device, void *stream);
+
+/*
  * One step of the reference's AdamW (lib/helpers/optimizer_helper.py:69-129 -- not torch.optim.AdamW: the
  * decoupled decay is scaled by the bias-corrected step, eps is added outside the bias correction) over a
  * FLAT parameter group, in one launch:

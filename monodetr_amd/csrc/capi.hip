@@ -15,6 +15,7 @@
 #include "adamw.h"
 #include "colsum.h"
 #include "lsa.h"
+#include "pair_losses.h"
 #include "msda.h"
 
 namespace {
@@ -269,6 +270,66 @@ int mdetr_lsa_forward(const float *cost, const int32_t *num_targets, int32_t *as
     const hipError_t e = mdetr::lsa_launch(cost, num_targets, assign, layers, images, groups, n, kmax,
                                            img_stride, q_stride, t_stride, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_lsa_forward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+static int pair_losses_args(const char *who, int L, int B, int Q, int C, int G, int K)
+{
+    if (L <= 0 || B <= 0 || Q <= 0 || C <= 0 || C > mdetr::kMaxClasses || G <= 0 || Q % G != 0 || K <= 0 || K > 64)
+        return fail(MDETR_E_ARG, "%s: bad shape L=%d B=%d Q=%d C=%d G=%d K=%d", who, L, B, Q, C, G, K);
+    return MDETR_OK;
+}
+
+int64_t mdetr_pair_losses_workspace_bytes(int L, int B)
+{
+    return L <= 0 || B <= 0 ? -1 : mdetr::pair_losses_workspace_bytes(L, B);
+}
+
+int mdetr_pair_losses_forward(const float *logits, const float *boxes, const float *dims, const float *depths,
+                              const float *angles, const int32_t *assign, const int64_t *labels, const float *boxes3d,
+                              const float *depth, const float *size3d, const int64_t *heading_bin,
+                              const float *heading_res, const uint8_t *valid, const int32_t *num,
+                              int L, int B, int Q, int C, int G, int K, float focal_alpha,
+                              float num_boxes, const float *num_boxes_dev, float *out, float *comp, void *workspace,
+                              int device, void *stream)
+{
+    if (int rc = pair_losses_args("mdetr_pair_losses_forward", L, B, Q, C, G, K)) return rc;
+    if (!logits || !boxes || !dims || !depths || !angles || !assign || !labels || !boxes3d || !depth || !size3d ||
+        !heading_bin || !heading_res || !valid || !num || !out || !comp || !workspace)
+        return fail(MDETR_E_ARG, "mdetr_pair_losses_forward: null pointer");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_pair_losses_forward: set device %d: %s", device, hipGetErrorString(dev.err));
+    const mdetr::PairLossDims d{L, B, Q, C, G, K, focal_alpha};
+    const mdetr::PairLossIn in{logits, boxes, dims, depths, angles, assign, reinterpret_cast<const long long *>(labels),
+                               reinterpret_cast<const long long *>(heading_bin), boxes3d, depth, size3d, heading_res, valid};
+    const hipError_t e = mdetr::pair_losses_forward_launch(d, in, num, num_boxes, num_boxes_dev, out, comp, workspace,
+                                                           static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_pair_losses_forward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_pair_losses_backward(const float *logits, const float *boxes, const float *dims, const float *depths,
+                               const float *angles, const int32_t *assign, const int64_t *labels, const float *boxes3d,
+                               const float *depth, const float *size3d, const int64_t *heading_bin,
+                               const float *heading_res, const uint8_t *valid,
+                               int L, int B, int Q, int C, int G, int K, float focal_alpha,
+                               float num_boxes, const float *num_boxes_dev, const float *grad_out, const float *comp,
+                               float *g_logits, float *g_boxes, float *g_dims, float *g_depths, float *g_angles,
+                               int device, void *stream)
+{
+    if (int rc = pair_losses_args("mdetr_pair_losses_backward", L, B, Q, C, G, K)) return rc;
+    if (!logits || !boxes || !dims || !depths || !angles || !assign || !labels || !boxes3d || !depth || !size3d ||
+        !heading_bin || !heading_res || !valid || !grad_out || !comp || !g_logits || !g_boxes || !g_dims || !g_depths || !g_angles)
+        return fail(MDETR_E_ARG, "mdetr_pair_losses_backward: null pointer");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_pair_losses_backward: set device %d: %s", device, hipGetErrorString(dev.err));
+    const mdetr::PairLossDims d{L, B, Q, C, G, K, focal_alpha};
+    const mdetr::PairLossIn in{logits, boxes, dims, depths, angles, assign, reinterpret_cast<const long long *>(labels),
+                               reinterpret_cast<const long long *>(heading_bin), boxes3d, depth, size3d, heading_res, valid};
+    const hipError_t e = mdetr::pair_losses_backward_launch(d, in, grad_out, comp, num_boxes, num_boxes_dev, g_logits,
+                                                            g_boxes, g_dims, g_depths, g_angles,
+                                                            static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_pair_losses_backward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

@@ -287,6 +287,11 @@ class SetCriterion(nn.Module):
         self.focal_alpha = focal_alpha
         self.ddn_loss = DDNLoss()
         self.group_num = group_num
+        # MDETR_FUSED_LOSSES=1: all matched-pair losses of all levels in one HIP launch each way
+        # (csrc/pair_losses.hip).  Off until the kernel has had its first GPU validation
+        # (tests/test_pending_gpu.py); its arithmetic is validated on the CPU (tests/test_fused_losses_cpu.py).
+        import os
+        self.fused_pair_losses = os.environ.get("MDETR_FUSED_LOSSES") == "1"
 
     # ---- individual losses (reference :320-458); `outputs` values are layer-stacked [L, B, Q, D], every
     # ---- returned entry is a per-layer vector [L] ------------------------------------------------------
@@ -427,8 +432,23 @@ class SetCriterion(nn.Module):
 
         pr = _Pairs(assign, gt)
         losses, aux = {}, {}
-        for loss in self.losses:
-            for name, vec in self._get(loss, stacked, pr, num_boxes).items():
+        per_loss = []
+        if self.fused_pair_losses and all(k in self._LOSSES for k in self.losses):
+            # every per-pair loss of every level in one launch (pair_losses_ext); the depth-map loss stays below
+            from ..pair_losses_ext import fused_pair_losses
+            rows = fused_pair_losses(stacked, assign, gt, num_boxes, self.focal_alpha)
+            wanted = {'labels': ('loss_ce', 'class_error'), 'cardinality': ('cardinality_error',),
+                      'center': ('loss_center',), 'boxes': ('loss_bbox', 'loss_giou'), 'depths': ('loss_depth',),
+                      'dims': ('loss_dim',), 'angles': ('loss_angle',)}
+            for loss in self.losses:
+                if loss == 'depth_map':
+                    per_loss.append(self._get(loss, stacked, pr, num_boxes))
+                else:
+                    per_loss.append({name: rows[name] for name in wanted[loss]})
+        else:
+            per_loss = [self._get(loss, stacked, pr, num_boxes) for loss in self.losses]
+        for ld in per_loss:
+            for name, vec in ld.items():
                 parts = vec.unbind(0)
                 # auxiliary layers: no depth-map loss (:521-523) and no class_error (log=False, :524-526)
                 if name in ('loss_depth_map', 'class_error'):

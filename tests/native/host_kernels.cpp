@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "../../monodetr_amd/csrc/adamw_math.h"
+#include "../../monodetr_amd/csrc/pair_losses_math.h"
 
 namespace {
 
@@ -44,6 +45,68 @@ int mdetr_adamw_step(int param_dtype, void *param, float *master, const void *gr
         const float q = mdetr::adamw_element(master[i], g, m, v, c, i < n_no_decay ? 0.f : weight_decay, step);
         exp_avg[i] = m; exp_avg_sq[i] = v; master[i] = q;
         if (param_dtype == 2) static_cast<uint16_t *>(param)[i] = f32_to_bf16(q);
+    }
+    return 0;
+}
+
+// same argument lists as mdetr_pair_losses_forward / _backward (include/monodetr_amd.h), serial loops over the rows
+int64_t mdetr_pair_losses_workspace_bytes(int L, int B) { return 16 + 0 * (L + B); }
+
+int mdetr_pair_losses_forward(const float *logits, const float *boxes, const float *dims, const float *depths,
+                              const float *angles, const int32_t *assign, const int64_t *labels, const float *boxes3d,
+                              const float *depth, const float *size3d, const int64_t *heading_bin,
+                              const float *heading_res, const uint8_t *valid, const int32_t *num,
+                              int L, int B, int Q, int C, int G, int K, float focal_alpha,
+                              float num_boxes, const float *num_boxes_dev, float *out, float *comp, void *workspace,
+                              int device, void *stream)
+{
+    (void)workspace; (void)device; (void)stream;
+    using namespace mdetr;
+    const PairLossDims d{L, B, Q, C, G, K, focal_alpha};
+    const PairLossIn in{logits, boxes, dims, depths, angles, assign, reinterpret_cast<const long long *>(labels),
+                        reinterpret_cast<const long long *>(heading_bin), boxes3d, depth, size3d, heading_res, valid};
+    const float nb = num_boxes_dev ? *num_boxes_dev : num_boxes;
+    for (int l = 0; l < L; ++l) {
+        float acc[kPairLossRows + 3] = {0};
+        float card_err = 0.f;
+        for (int b = 0; b < B; ++b) {
+            int fg = 0;
+            for (int q = 0; q < Q; ++q) fg += pl_row_forward(d, in, l, b, q, acc) ? 1 : 0;
+            const float diff = static_cast<float>(fg) - static_cast<float>(num[b]);
+            card_err += diff < 0.f ? -diff : diff;
+        }
+        const float s_rel = acc[kPairLossRows], cf = acc[kLossDim] / (s_rel > 1e-12f ? s_rel : 1e-12f);
+        comp[l] = cf;
+        for (int r = 0; r < kNumWeighted; ++r) out[r * L + l] = acc[r] / nb;
+        out[kLossDim * L + l] = s_rel * cf / nb;
+        const float hits = acc[kPairLossRows + 1], nmatch = acc[kPairLossRows + 2];
+        out[kClassError * L + l] = 100.f - (nmatch > 0.f ? hits * 100.f / nmatch : 0.f);
+        out[kCardinality * L + l] = card_err / static_cast<float>(B);
+    }
+    return 0;
+}
+
+int mdetr_pair_losses_backward(const float *logits, const float *boxes, const float *dims, const float *depths,
+                               const float *angles, const int32_t *assign, const int64_t *labels, const float *boxes3d,
+                               const float *depth, const float *size3d, const int64_t *heading_bin,
+                               const float *heading_res, const uint8_t *valid,
+                               int L, int B, int Q, int C, int G, int K, float focal_alpha,
+                               float num_boxes, const float *num_boxes_dev, const float *grad_out, const float *comp,
+                               float *g_logits, float *g_boxes, float *g_dims, float *g_depths, float *g_angles,
+                               int device, void *stream)
+{
+    (void)device; (void)stream;
+    using namespace mdetr;
+    const PairLossDims d{L, B, Q, C, G, K, focal_alpha};
+    const PairLossIn in{logits, boxes, dims, depths, angles, assign, reinterpret_cast<const long long *>(labels),
+                        reinterpret_cast<const long long *>(heading_bin), boxes3d, depth, size3d, heading_res, valid};
+    const float inv = 1.f / (num_boxes_dev ? *num_boxes_dev : num_boxes);
+    for (int l = 0; l < L; ++l) {
+        float w[kNumWeighted];
+        for (int i = 0; i < kNumWeighted; ++i) w[i] = grad_out[i * L + l] * inv;
+        for (int b = 0; b < B; ++b)
+            for (int q = 0; q < Q; ++q)
+                pl_row_backward(d, in, l, b, q, w, comp[l], g_logits, g_boxes, g_dims, g_depths, g_angles);
     }
     return 0;
 }

@@ -20,7 +20,8 @@ def lib():
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", SRC, "-o", OUT])
         from monodetr_amd import _capi
         L = ctypes.CDLL(OUT)
-        for name in ("mdetr_adamw_step",):
+        for name in ("mdetr_adamw_step", "mdetr_pair_losses_workspace_bytes", "mdetr_pair_losses_forward",
+                     "mdetr_pair_losses_backward"):
             res, args = _capi.SIGNATURES[name]
             getattr(L, name).restype, getattr(L, name).argtypes = res, args
         _lib = L

@@ -1,0 +1,97 @@
+"""The fused matched-pair losses (csrc/pair_losses_math.h, the arithmetic of csrc/pair_losses.hip) against
+the PyTorch criterion and its autograd, on the CPU through the host build of the same functions
+(tests/native).  Values: all 26 loss entries; gradients: w.r.t. all five prediction tensors of all levels."""
+import pytest
+import torch
+
+import native_host
+from model_init import load_cfg
+
+
+def _problem(L, B, Q, K, G, seed, empty_image=True):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.rand(*s, generator=g)          # noqa: E731
+    n = lambda *s: torch.randn(*s, generator=g)         # noqa: E731
+    preds = {
+        'pred_logits': n(L, B, Q, 3),
+        'pred_boxes': torch.cat((0.2 + 0.6 * r(L, B, Q, 2), 0.02 + 0.2 * r(L, B, Q, 4)), -1),
+        'pred_3d_dim': 0.5 + 2.5 * r(L, B, Q, 3),
+        'pred_depth': torch.cat((5 + 40 * r(L, B, Q, 1), n(L, B, Q, 1)), -1),
+        'pred_angle': n(L, B, Q, 24),
+    }
+    num = torch.randint(1, K + 1, (B,), generator=g)
+    if empty_image:
+        num[-1] = 0
+    gt = {
+        'labels': torch.randint(0, 3, (B, K), generator=g),
+        'boxes': torch.cat((0.2 + 0.6 * r(B, K, 2), 0.05 + 0.2 * r(B, K, 2)), -1),
+        'boxes_3d': torch.cat((0.2 + 0.6 * r(B, K, 2), 0.02 + 0.2 * r(B, K, 4)), -1),
+        'depth': 5 + 40 * r(B, K),
+        'size_3d': 0.8 + 2 * r(B, K, 3),
+        'heading_bin': torch.randint(0, 12, (B, K), generator=g),
+        'heading_res': 0.3 * n(B, K),
+        'valid': torch.arange(K)[None, :] < num[:, None],
+        'num': num.to(torch.int32),
+        'num_host': [int(v) for v in num],
+    }
+    return preds, gt
+
+
+@pytest.fixture()
+def criterion():
+    from monodetr_amd import pair_losses_ext
+    from monodetr_amd.monodetr import build_monodetr
+    torch.manual_seed(0)
+    cfg = load_cfg()
+    _, crit = build_monodetr(cfg)
+    crit.train()
+    pair_losses_ext._backend = native_host.lib()
+    yield crit
+    pair_losses_ext._backend = None
+
+
+@pytest.mark.parametrize("L,B,Q,K,G,seed", [(3, 4, 110, 7, 11, 0), (3, 2, 550, 50, 11, 1), (1, 3, 20, 5, 1, 2)])
+def test_fused_pair_losses_match_the_criterion(criterion, L, B, Q, K, G, seed):
+    preds, gt = _problem(L, B, Q, K, G, seed)
+    criterion.group_num = G
+    outputs = {k: v[-1] for k, v in preds.items()}
+    outputs['pred_depth_map_logits'] = torch.randn(B, 81, 6, 20, generator=torch.Generator().manual_seed(seed + 7))
+    outputs['aux_outputs'] = [{k: v[i] for k, v in preds.items()} for i in range(L - 1)]
+
+    def run(fused):
+        criterion.fused_pair_losses = fused
+        leaves = {k: v.clone().requires_grad_(True) for k, v in preds.items()}
+        out = dict(outputs, _levels=leaves)
+        losses = criterion(out, gt)
+        total = criterion.weighted_total(losses)
+        total.backward()
+        return losses, {k: v.grad for k, v in leaves.items()}
+
+    ref_losses, ref_grads = run(False)
+    got_losses, got_grads = run(True)
+    assert set(ref_losses) == set(got_losses)
+    for k in ref_losses:
+        a, b = float(ref_losses[k]), float(got_losses[k])
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (k, a, b)
+    for k in ref_grads:
+        scale = ref_grads[k].abs().max().item()
+        assert scale > 0
+        assert (ref_grads[k] - got_grads[k]).abs().max().item() <= 2e-5 * scale + 1e-9, k
+
+
+def test_fused_pair_losses_with_a_device_normaliser_and_no_targets(criterion):
+    """num_boxes as a tensor (the multi-GPU form) and a batch without any object (every loss but the focal
+    background term is zero, gradients finite)."""
+    from monodetr_amd.pair_losses_ext import fused_pair_losses
+    preds, gt = _problem(2, 2, 22, 4, 11, 5, empty_image=False)
+    gt['valid'][:] = False
+    gt['num'][:] = 0
+    assign = torch.full((2, 2, 11, 4), -1, dtype=torch.int64)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in preds.items()}
+    rows = fused_pair_losses(leaves, assign, gt, torch.tensor(1.0), 0.25)
+    for name in ('loss_center', 'loss_bbox', 'loss_giou', 'loss_depth', 'loss_dim', 'loss_angle'):
+        assert float(rows[name].abs().sum()) == 0.0
+    assert (rows['class_error'] == 100).all() and (rows['loss_ce'] > 0).all()
+    sum(rows[k].sum() for k in ('loss_ce', 'loss_bbox', 'loss_dim')).backward()
+    assert all(torch.isfinite(v.grad).all() for v in leaves.values())
+    assert float(leaves['pred_boxes'].grad.abs().sum()) == 0.0

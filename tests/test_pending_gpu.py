@@ -76,3 +76,39 @@ def test_training_step_with_fused_adamw_matches_default():
     assert type(step.optimizer).__name__ == "FusedAdamW"
     for a, b in zip(traj[False], traj[True]):
         assert abs(a - b) <= 2e-2 * abs(a), traj
+
+
+def test_fused_pair_losses_kernel_matches_the_criterion():
+    """csrc/pair_losses.hip (launch glue, reductions, last-block finalisation, workspace self-cleaning)
+    against the PyTorch criterion on the GPU: all loss entries and the gradients of the five prediction
+    tensors, twice in a row (the second call runs on the workspace the first one left behind)."""
+    from test_fused_losses_cpu import _problem
+    from model_init import load_cfg
+    from monodetr_amd.monodetr import build_monodetr
+    torch.manual_seed(0)
+    _, criterion = build_monodetr(load_cfg())
+    criterion.train().cuda()
+    for (L, B, Q, K, G, seed) in ((3, 8, 550, 50, 11, 1), (3, 4, 110, 7, 11, 0)):
+        preds, gt = _problem(L, B, Q, K, G, seed)
+        preds = {k: v.cuda() for k, v in preds.items()}
+        gt = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in gt.items()}
+        criterion.group_num = G
+        outputs = {k: v[-1] for k, v in preds.items()}
+        outputs['pred_depth_map_logits'] = torch.randn(B, 81, 6, 20, device="cuda")
+        outputs['aux_outputs'] = [{k: v[i] for k, v in preds.items()} for i in range(L - 1)]
+
+        def run(fused):
+            criterion.fused_pair_losses = fused
+            leaves = {k: v.clone().requires_grad_(True) for k, v in preds.items()}
+            losses = criterion(dict(outputs, _levels=leaves), gt)
+            criterion.weighted_total(losses).backward()
+            return losses, {k: v.grad for k, v in leaves.items()}
+
+        ref_losses, ref_grads = run(False)
+        for _ in range(2):
+            got_losses, got_grads = run(True)
+            for k in ref_losses:
+                a, b = float(ref_losses[k]), float(got_losses[k])
+                assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (k, a, b)
+            for k in ref_grads:
+                assert (ref_grads[k] - got_grads[k]).abs().max().item() <= 1e-4 * ref_grads[k].abs().max().item() + 1e-9, k
