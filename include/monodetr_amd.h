@@ -192,6 +192,27 @@ int mdetr_pair_losses_backward(const float *logits, const float *boxes, const fl
                                int device, void *stream);
 
 /*
+ * MonoDETR's depth-map loss (lib/models/monodetr/depth_predictor/ddn_loss/ddn_loss.py:103-127 with
+ * balancer.py:26-50 and focalloss.py:58-129; called from monodetr.py:443-458) in one launch each way.
+ *   logits   fp32 [B, C, H, W] depth-bin logits (C = bins + 1) in any dense layout: element strides sb, sc, sh, sw
+ *   boxes    fp32 [B, K, 4] ground-truth 2D boxes (cx, cy, w, h) normalised to the image, padded to K slots
+ *   depth    fp32 [B, K] object centre depths;   valid uint8 [B, K]
+ *   out      fp32 [1]: sum over pixels of weight * focal / (B H W), weight = fg_weight inside any valid box
+ *            (nearest object gives the target bin, linear-increasing discretisation between depth_min and
+ *            depth_max), bg_weight elsewhere (target = the extra last bin)
+ *   workspace  16 bytes, ZERO before the first call; every forward call leaves it zero again
+ * backward: grad_out fp32 [1] -> grad_logits, same layout as logits, every element written.
+ */
+int mdetr_ddn_loss_forward(const float *logits, const float *boxes, const float *depth, const uint8_t *valid,
+                           int B, int C, int H, int W, int K, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                           float alpha, float fg_weight, float bg_weight, float depth_min, float depth_max,
+                           float *out, void *workspace, int device, void *stream);
+int mdetr_ddn_loss_backward(const float *logits, const float *boxes, const float *depth, const uint8_t *valid,
+                            int B, int C, int H, int W, int K, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                            float alpha, float fg_weight, float bg_weight, float depth_min, float depth_max,
+                            const float *grad_out, float *grad_logits, int device, void *stream);
+
+/*
  * One step of the reference's AdamW (lib/helpers/optimizer_helper.py:69-129 -- not torch.optim.AdamW: the
  * decoupled decay is scaled by the bias-corrected step, eps is added outside the bias correction) over a
  * FLAT parameter group, in one launch:

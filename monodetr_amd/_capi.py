@@ -34,6 +34,8 @@ SIGNATURES = {
     "mdetr_attn_backward": (_c_int, [_c_int] + [_c_vp] * 11 + [_c_int] * 4 + [ctypes.c_int64] * 3 + [_c_int] * 3
                             + [ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),
     "mdetr_lsa_forward": (_c_int, [_c_vp] * 3 + [_c_int] * 5 + [ctypes.c_int64] * 3 + [_c_int, _c_vp]),
+    "mdetr_ddn_loss_forward": (_c_int, [_c_vp] * 4 + [_c_int] * 5 + [ctypes.c_int64] * 4 + [ctypes.c_float] * 5 + [_c_vp, _c_vp, _c_int, _c_vp]),
+    "mdetr_ddn_loss_backward": (_c_int, [_c_vp] * 4 + [_c_int] * 5 + [ctypes.c_int64] * 4 + [ctypes.c_float] * 5 + [_c_vp, _c_vp, _c_int, _c_vp]),
     "mdetr_pair_losses_workspace_bytes": (ctypes.c_int64, [_c_int, _c_int]),
     "mdetr_pair_losses_forward": (_c_int, [_c_vp] * 14 + [_c_int] * 6 + [ctypes.c_float, ctypes.c_float] + [_c_vp] * 4 + [_c_int, _c_vp]),
     "mdetr_pair_losses_backward": (_c_int, [_c_vp] * 13 + [_c_int] * 6 + [ctypes.c_float, ctypes.c_float] + [_c_vp] * 8 + [_c_int, _c_vp]),

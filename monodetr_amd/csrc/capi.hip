@@ -14,6 +14,7 @@
 #include "attn.h"
 #include "adamw.h"
 #include "colsum.h"
+#include "ddn_loss.h"
 #include "lsa.h"
 #include "pair_losses.h"
 #include "msda.h"
@@ -270,6 +271,53 @@ int mdetr_lsa_forward(const float *cost, const int32_t *num_targets, int32_t *as
     const hipError_t e = mdetr::lsa_launch(cost, num_targets, assign, layers, images, groups, n, kmax,
                                            img_stride, q_stride, t_stride, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_lsa_forward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+static int ddn_args(const char *who, int B, int C, int H, int W, int K)
+{
+    if (B <= 0 || C < 2 || H <= 0 || W <= 0 || K < 0)
+        return fail(MDETR_E_ARG, "%s: bad shape B=%d C=%d H=%d W=%d K=%d", who, B, C, H, W, K);
+    return MDETR_OK;
+}
+
+static mdetr::DdnDims ddn_dims(int B, int C, int H, int W, int K, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                               float alpha, float fg_weight, float bg_weight, float depth_min, float depth_max)
+{
+    return mdetr::DdnDims{B, C, H, W, K, sb, sc, sh, sw, alpha, fg_weight, bg_weight, depth_min, depth_max};
+}
+
+int mdetr_ddn_loss_forward(const float *logits, const float *boxes, const float *depth, const uint8_t *valid,
+                           int B, int C, int H, int W, int K, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                           float alpha, float fg_weight, float bg_weight, float depth_min, float depth_max,
+                           float *out, void *workspace, int device, void *stream)
+{
+    if (int rc = ddn_args("mdetr_ddn_loss_forward", B, C, H, W, K)) return rc;
+    if (!logits || !out || !workspace || (K > 0 && (!boxes || !depth || !valid)))
+        return fail(MDETR_E_ARG, "mdetr_ddn_loss_forward: null pointer");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_ddn_loss_forward: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::ddn_loss_forward_launch(
+        ddn_dims(B, C, H, W, K, sb, sc, sh, sw, alpha, fg_weight, bg_weight, depth_min, depth_max), logits, boxes, depth,
+        valid, out, workspace, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_ddn_loss_forward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_ddn_loss_backward(const float *logits, const float *boxes, const float *depth, const uint8_t *valid,
+                            int B, int C, int H, int W, int K, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                            float alpha, float fg_weight, float bg_weight, float depth_min, float depth_max,
+                            const float *grad_out, float *grad_logits, int device, void *stream)
+{
+    if (int rc = ddn_args("mdetr_ddn_loss_backward", B, C, H, W, K)) return rc;
+    if (!logits || !grad_out || !grad_logits || (K > 0 && (!boxes || !depth || !valid)))
+        return fail(MDETR_E_ARG, "mdetr_ddn_loss_backward: null pointer");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_ddn_loss_backward: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::ddn_loss_backward_launch(
+        ddn_dims(B, C, H, W, K, sb, sc, sh, sw, alpha, fg_weight, bg_weight, depth_min, depth_max), logits, boxes, depth,
+        valid, grad_out, grad_logits, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_ddn_loss_backward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

@@ -361,6 +361,11 @@ class SetCriterion(nn.Module):
         """Final layer only (:521-523): `outputs['pred_depth_map_logits']` is not layer-stacked; returns [1]."""
         logits = outputs['pred_depth_map_logits']
         gt = pr.gt
+        if self.fused_pair_losses:                                   # one launch each way (ddn_loss_ext)
+            from ..ddn_loss_ext import fused_ddn_loss
+            bal = self.ddn_loss.balancer
+            return {"loss_depth_map": fused_ddn_loss(logits, gt["boxes"], gt["depth"], gt["valid"], self.ddn_loss.alpha,
+                                                     bal.fg_weight, bal.bg_weight).reshape(1)}
         H, W = logits.shape[-2:]
         b = gt["boxes"]                                              # x (80, 24, 80, 24) at 384x1280, no host->device copy
         boxes = box_ops.box_cxcywh_to_xyxy(torch.stack((b[..., 0] * W, b[..., 1] * H, b[..., 2] * W, b[..., 3] * H), -1))

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "../../monodetr_amd/csrc/adamw_math.h"
+#include "../../monodetr_amd/csrc/ddn_loss_math.h"
 #include "../../monodetr_amd/csrc/pair_losses_math.h"
 
 namespace {
@@ -46,6 +47,53 @@ int mdetr_adamw_step(int param_dtype, void *param, float *master, const void *gr
         exp_avg[i] = m; exp_avg_sq[i] = v; master[i] = q;
         if (param_dtype == 2) static_cast<uint16_t *>(param)[i] = f32_to_bf16(q);
     }
+    return 0;
+}
+
+// same argument lists as mdetr_ddn_loss_forward / _backward, serial loops over the pixels
+static mdetr::DdnDims host_ddn_dims(int B, int C, int H, int W, int K, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                                    float alpha, float fg_weight, float bg_weight, float depth_min, float depth_max)
+{
+    return mdetr::DdnDims{B, C, H, W, K, sb, sc, sh, sw, alpha, fg_weight, bg_weight, depth_min, depth_max};
+}
+
+int mdetr_ddn_loss_forward(const float *logits, const float *boxes, const float *depth, const uint8_t *valid,
+                           int B, int C, int H, int W, int K, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                           float alpha, float fg_weight, float bg_weight, float depth_min, float depth_max,
+                           float *out, void *workspace, int device, void *stream)
+{
+    (void)workspace; (void)device; (void)stream;
+    const mdetr::DdnDims d = host_ddn_dims(B, C, H, W, K, sb, sc, sh, sw, alpha, fg_weight, bg_weight, depth_min, depth_max);
+    double sum = 0.0;
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                bool fg;
+                const int t = mdetr::ddn_target(d, boxes + static_cast<int64_t>(b) * K * 4, depth + static_cast<int64_t>(b) * K,
+                                                valid + static_cast<int64_t>(b) * K, x, y, fg);
+                sum += mdetr::ddn_pixel(d, logits + b * sb + y * sh + x * sw, t, 0.f, nullptr) * (fg ? fg_weight : bg_weight);
+            }
+    out[0] = static_cast<float>(sum / (static_cast<double>(B) * H * W));
+    return 0;
+}
+
+int mdetr_ddn_loss_backward(const float *logits, const float *boxes, const float *depth, const uint8_t *valid,
+                            int B, int C, int H, int W, int K, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                            float alpha, float fg_weight, float bg_weight, float depth_min, float depth_max,
+                            const float *grad_out, float *grad_logits, int device, void *stream)
+{
+    (void)device; (void)stream;
+    const mdetr::DdnDims d = host_ddn_dims(B, C, H, W, K, sb, sc, sh, sw, alpha, fg_weight, bg_weight, depth_min, depth_max);
+    const float n = static_cast<float>(static_cast<int64_t>(B) * H * W);
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                bool fg;
+                const int t = mdetr::ddn_target(d, boxes + static_cast<int64_t>(b) * K * 4, depth + static_cast<int64_t>(b) * K,
+                                                valid + static_cast<int64_t>(b) * K, x, y, fg);
+                const int64_t off = b * sb + y * sh + x * sw;
+                mdetr::ddn_pixel(d, logits + off, t, grad_out[0] * (fg ? fg_weight : bg_weight) / n, grad_logits + off);
+            }
     return 0;
 }
 

@@ -39,15 +39,15 @@ def _problem(L, B, Q, K, G, seed, empty_image=True):
 
 @pytest.fixture()
 def criterion():
-    from monodetr_amd import pair_losses_ext
+    from monodetr_amd import ddn_loss_ext, pair_losses_ext
     from monodetr_amd.monodetr import build_monodetr
     torch.manual_seed(0)
     cfg = load_cfg()
     _, crit = build_monodetr(cfg)
     crit.train()
-    pair_losses_ext._backend = native_host.lib()
+    pair_losses_ext._backend = ddn_loss_ext._backend = native_host.lib()
     yield crit
-    pair_losses_ext._backend = None
+    pair_losses_ext._backend = ddn_loss_ext._backend = None
 
 
 @pytest.mark.parametrize("L,B,Q,K,G,seed", [(3, 4, 110, 7, 11, 0), (3, 2, 550, 50, 11, 1), (1, 3, 20, 5, 1, 2)])
@@ -95,3 +95,45 @@ def test_fused_pair_losses_with_a_device_normaliser_and_no_targets(criterion):
     sum(rows[k].sum() for k in ('loss_ce', 'loss_bbox', 'loss_dim')).backward()
     assert all(torch.isfinite(v.grad).all() for v in leaves.values())
     assert float(leaves['pred_boxes'].grad.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("layout", ["contiguous", "channels_last"])
+def test_fused_ddn_loss_matches_the_pytorch_ddn_loss(layout):
+    """csrc/ddn_loss_math.h (host build) == DDNLoss (box painting, LID bins, focal loss with the +1e-6 one-hot,
+    fg/bg balancer): value and the gradient w.r.t. all depth logits; boxes that leave the image, overlap
+    (nearest object wins), an image without objects, padded slots."""
+    from monodetr_amd import ddn_loss_ext
+    from monodetr_amd.monodetr.depth_predictor.ddn_loss import DDNLoss
+    from monodetr_amd.utils import box_ops
+    ddn_loss_ext._backend = native_host.lib()
+    try:
+        g = torch.Generator().manual_seed(3)
+        B, C, H, W, K = 3, 81, 24, 80, 6
+        logits = torch.randn(B, C, H, W, generator=g)
+        if layout == "channels_last":
+            logits = logits.contiguous(memory_format=torch.channels_last)
+        boxes = torch.cat((torch.rand(B, K, 2, generator=g), 0.05 + 0.5 * torch.rand(B, K, 2, generator=g)), -1)
+        boxes[0, 0] = torch.tensor([0.02, 0.5, 0.3, 0.4])              # sticks out on the left: negative corner wraps
+        boxes[0, 1] = boxes[0, 2]                                       # identical boxes, different depths
+        depth = 2 + 55 * torch.rand(B, K, generator=g)
+        depth[1, 0] = 75.0                                              # beyond depth_max -> the extra bin
+        num = torch.tensor([K, 3, 0])
+        valid = torch.arange(K)[None, :] < num[:, None]
+
+        ref_mod = DDNLoss()
+        za = logits.clone().requires_grad_(True)
+        b = boxes
+        xyxy = box_ops.box_cxcywh_to_xyxy(torch.stack((b[..., 0] * W, b[..., 1] * H, b[..., 2] * W, b[..., 3] * H), -1))
+        xyxy = torch.where(valid[..., None], xyxy, torch.zeros_like(xyxy))
+        ref = ref_mod(za, xyxy.reshape(-1, 4), K, depth.reshape(-1), valid=valid.reshape(-1))
+        (ref * 1.7).backward()
+
+        zb = logits.clone().requires_grad_(True)
+        got = ddn_loss_ext.fused_ddn_loss(zb, boxes, depth, valid, ref_mod.alpha, ref_mod.balancer.fg_weight,
+                                          ref_mod.balancer.bg_weight)
+        (got * 1.7).backward()
+        assert abs(float(ref) - float(got)) <= 2e-6 * abs(float(ref))
+        assert zb.grad.stride() == zb.stride()
+        assert (za.grad - zb.grad).abs().max() <= 2e-5 * za.grad.abs().max()
+    finally:
+        ddn_loss_ext._backend = None

@@ -112,3 +112,33 @@ def test_fused_pair_losses_kernel_matches_the_criterion():
                 assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (k, a, b)
             for k in ref_grads:
                 assert (ref_grads[k] - got_grads[k]).abs().max().item() <= 1e-4 * ref_grads[k].abs().max().item() + 1e-9, k
+
+
+@pytest.mark.parametrize("layout", ["contiguous", "channels_last"])
+def test_fused_ddn_loss_kernel_matches_the_pytorch_ddn_loss(layout):
+    """csrc/ddn_loss.hip against DDNLoss on the GPU at the training shape (8 x 81 x 24 x 80, 50 slots):
+    value and gradient, twice in a row (workspace self-cleaning)."""
+    from monodetr_amd.ddn_loss_ext import fused_ddn_loss
+    from monodetr_amd.monodetr.depth_predictor.ddn_loss import DDNLoss
+    from monodetr_amd.utils import box_ops
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W, K = 8, 81, 24, 80, 50
+    logits = torch.randn(B, C, H, W, generator=g).cuda()
+    if layout == "channels_last":
+        logits = logits.contiguous(memory_format=torch.channels_last)
+    boxes = torch.cat((torch.rand(B, K, 2, generator=g), 0.05 + 0.4 * torch.rand(B, K, 2, generator=g)), -1).cuda()
+    depth = (2 + 60 * torch.rand(B, K, generator=g)).cuda()
+    num = torch.randint(0, 9, (B,), generator=g)
+    valid = (torch.arange(K)[None, :] < num[:, None]).cuda()
+    ref_mod = DDNLoss()
+    za = logits.clone().requires_grad_(True)
+    xyxy = box_ops.box_cxcywh_to_xyxy(torch.stack((boxes[..., 0] * W, boxes[..., 1] * H, boxes[..., 2] * W, boxes[..., 3] * H), -1))
+    xyxy = torch.where(valid[..., None], xyxy, torch.zeros_like(xyxy))
+    ref = ref_mod(za, xyxy.reshape(-1, 4), K, depth.reshape(-1), valid=valid.reshape(-1))
+    ref.backward()
+    for _ in range(2):
+        zb = logits.clone().requires_grad_(True)
+        got = fused_ddn_loss(zb, boxes, depth, valid, ref_mod.alpha, ref_mod.balancer.fg_weight, ref_mod.balancer.bg_weight)
+        got.backward()
+        assert abs(float(ref) - float(got)) <= 1e-5 * abs(float(ref))
+        assert (za.grad - zb.grad).abs().max() <= 1e-4 * za.grad.abs().max()
