@@ -192,6 +192,18 @@ int mdetr_pair_losses_backward(const float *logits, const float *boxes, const fl
                                int device, void *stream);
 
 /*
+ * mdetr_lsa_forward with the matching cost evaluated inside the kernel (matcher.py:55-84) instead of read from a
+ * cost matrix:  cost(q, t) = w_bbox L1(l,r,t,b) + w_center L1(cx,cy) + w_class (pos - neg focal cost at label_t)
+ * - w_giou GIoU, from level-stacked predictions logits fp32 [layers, images, groups*n, num_classes], boxes fp32
+ * [layers, images, groups*n, 6] and the padded ground truth labels int64 [images, kmax], boxes3d fp32
+ * [images, kmax, 6].  Same output as mdetr_lsa_forward.
+ */
+int mdetr_lsa_forward_fused(const float *logits, const float *boxes, const int64_t *labels, const float *boxes3d,
+                            const int32_t *num_targets, int32_t *assign, int layers, int images, int groups, int n,
+                            int kmax, int num_classes, float w_class, float w_bbox, float w_center, float w_giou,
+                            float focal_alpha, int device, void *stream);
+
+/*
  * MonoDETR's depth-map loss (lib/models/monodetr/depth_predictor/ddn_loss/ddn_loss.py:103-127 with
  * balancer.py:26-50 and focalloss.py:58-129; called from monodetr.py:443-458) in one launch each way.
  *   logits   fp32 [B, C, H, W] depth-bin logits (C = bins + 1) in any dense layout: element strides sb, sc, sh, sw

@@ -427,6 +427,25 @@ int mdetr_column_sum(int dtype, const void *x, float *out, void *workspace, int6
     return MDETR_OK;
 }
 
+int mdetr_lsa_forward_fused(const float *logits, const float *boxes, const int64_t *labels, const float *boxes3d,
+                            const int32_t *num_targets, int32_t *assign, int layers, int images, int groups, int n,
+                            int kmax, int num_classes, float w_class, float w_bbox, float w_center, float w_giou,
+                            float focal_alpha, int device, void *stream)
+{
+    if (layers < 0 || images < 0 || groups < 0 || n <= 0 || n > 64 || kmax < 0 || kmax > n || num_classes <= 0)
+        return fail(MDETR_E_ARG, "mdetr_lsa_forward_fused: need 0 < n <= 64, 0 <= kmax <= n, num_classes > 0 (n=%d kmax=%d)", n, kmax);
+    if (layers == 0 || images == 0 || groups == 0 || kmax == 0) return MDETR_OK;
+    if (!logits || !boxes || !labels || !boxes3d || !num_targets || !assign)
+        return fail(MDETR_E_ARG, "mdetr_lsa_forward_fused: null pointer");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_lsa_forward_fused: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::lsa_fused_launch(logits, boxes, labels, boxes3d, num_targets, assign, layers, images, groups,
+                                                 n, kmax, num_classes, w_class, w_bbox, w_center, w_giou, focal_alpha,
+                                                 static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_lsa_forward_fused: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
 int mdetr_msda_indices(int dtype, const int64_t *spatial_shapes, const void *loc, int32_t *idx,
                        int B, int M, int L, int Lq, int P, int device, void *stream)
 {

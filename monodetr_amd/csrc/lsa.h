@@ -10,4 +10,12 @@ namespace mdetr {
 hipError_t lsa_launch(const float *cost, const int *num_targets, int *assign, int layers, int images, int groups,
                       int n, int kmax, int64_t img_stride, int64_t q_stride, int64_t t_stride, hipStream_t st);
 
+// same problems, with the matching cost evaluated in the kernel (matcher.py:55-84) from level-stacked
+// predictions logits [layers*images, groups*n, num_classes], boxes [.., 6] and the padded ground truth
+// labels [images, kmax] (int64), boxes3d [images, kmax, 6]
+hipError_t lsa_fused_launch(const float *logits, const float *boxes, const int64_t *labels, const float *boxes3d,
+                            const int *num_targets, int *assign, int layers, int images, int groups, int n, int kmax,
+                            int num_classes, float w_class, float w_bbox, float w_center, float w_giou, float alpha,
+                            hipStream_t st);
+
 }  // namespace mdetr

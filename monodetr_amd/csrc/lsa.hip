@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "lsa.h"
+#include "pair_losses_math.h"
 
 namespace mdetr {
 namespace {
@@ -35,11 +36,23 @@ __device__ __forceinline__ MinLoc wave_argmin(double v, int j)
     return {v, j};
 }
 
-// cost(problem, target t, query column j) = C[base + j * q_stride + t * t_stride]
+// inputs of the fused form: the cost is evaluated in the kernel from the predictions and the padded ground
+// truth (pl_match_cost, pair_losses_math.h) instead of being read from a cost matrix built by ~45
+// framework kernels
+struct LsaFused {
+    const float *logits, *boxes;       // [L*B, Q, C], [L*B, Q, 6]
+    const long long *labels;           // [B, kmax]
+    const float *boxes3d;              // [B, kmax, 6]
+    int num_classes;
+    MatchWeights w;
+};
+
+// cost(problem, target t, query column j) = C[base + j * q_stride + t * t_stride]   (FUSED: computed)
+template <bool FUSED>
 __global__ __launch_bounds__(kWavesPerBlock * 64)
 void lsa_kernel(const float *__restrict__ C, const int *__restrict__ num_targets, int *__restrict__ assign,
                 int num_problems, int groups, int n, int kmax,
-                int64_t img_stride, int64_t q_stride, int64_t t_stride, int images_per_layer)
+                int64_t img_stride, int64_t q_stride, int64_t t_stride, int images_per_layer, const LsaFused fz)
 {
     // per wave: costs [kmax][65] fp32 (exact in fp64 on read) + row potentials u[64] fp64
     extern __shared__ __attribute__((aligned(16))) unsigned char lsa_smem[];
@@ -58,9 +71,18 @@ void lsa_kernel(const float *__restrict__ C, const int *__restrict__ num_targets
     const size_t per_wave = static_cast<size_t>(kmax) * (kMaxDim + 1) * sizeof(float) + kMaxDim * sizeof(double);
     double *u = reinterpret_cast<double *>(lsa_smem + wave * per_wave);
     float (*a)[kMaxDim + 1] = reinterpret_cast<float (*)[kMaxDim + 1]>(lsa_smem + wave * per_wave + kMaxDim * sizeof(double));
-    const float *Cp = C + static_cast<int64_t>(li) * img_stride + static_cast<int64_t>(g) * n * q_stride;
-    for (int t = 0; t < k; ++t)
-        a[t][lane] = lane < n ? Cp[lane * q_stride + t * t_stride] : 0.f;
+    if (FUSED) {
+        const int64_t row = (static_cast<int64_t>(li) * groups + g) * n + (lane < n ? lane : 0);   // (l, b, query)
+        const float *lg = fz.logits + row * fz.num_classes, *bx = fz.boxes + row * 6;
+        for (int t = 0; t < k; ++t) {
+            const int64_t tk = static_cast<int64_t>(image) * kmax + t;
+            a[t][lane] = lane < n ? pl_match_cost(lg, bx, static_cast<int>(fz.labels[tk]), fz.boxes3d + tk * 6, fz.w) : 0.f;
+        }
+    } else {
+        const float *Cp = C + static_cast<int64_t>(li) * img_stride + static_cast<int64_t>(g) * n * q_stride;
+        for (int t = 0; t < k; ++t)
+            a[t][lane] = lane < n ? Cp[lane * q_stride + t * t_stride] : 0.f;
+    }
     if (lane < kMaxDim) u[lane] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -115,8 +137,24 @@ hipError_t lsa_launch(const float *cost, const int *num_targets, int *assign, in
     if (num_problems == 0 || kmax == 0) return hipSuccess;
     const dim3 grid((num_problems + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * 64);
     const size_t lds = kWavesPerBlock * (static_cast<size_t>(kmax) * (kMaxDim + 1) * sizeof(float) + kMaxDim * sizeof(double));
-    hipLaunchKernelGGL(lsa_kernel, grid, block, lds, st, cost, num_targets, assign, num_problems, groups, n, kmax,
-                       img_stride, q_stride, t_stride, images);
+    hipLaunchKernelGGL(lsa_kernel<false>, grid, block, lds, st, cost, num_targets, assign, num_problems, groups, n, kmax,
+                       img_stride, q_stride, t_stride, images, LsaFused{});
+    return hipGetLastError();
+}
+
+hipError_t lsa_fused_launch(const float *logits, const float *boxes, const int64_t *labels, const float *boxes3d,
+                            const int *num_targets, int *assign, int layers, int images, int groups, int n, int kmax,
+                            int num_classes, float w_class, float w_bbox, float w_center, float w_giou, float alpha,
+                            hipStream_t st)
+{
+    const int num_problems = layers * images * groups;
+    if (num_problems == 0 || kmax == 0) return hipSuccess;
+    const dim3 grid((num_problems + kWavesPerBlock - 1) / kWavesPerBlock), block(kWavesPerBlock * 64);
+    const size_t lds = kWavesPerBlock * (static_cast<size_t>(kmax) * (kMaxDim + 1) * sizeof(float) + kMaxDim * sizeof(double));
+    const LsaFused fz{logits, boxes, reinterpret_cast<const long long *>(labels), boxes3d, num_classes,
+                      MatchWeights{w_class, w_bbox, w_center, w_giou, alpha}};
+    hipLaunchKernelGGL(lsa_kernel<true>, grid, block, lds, st, nullptr, num_targets, assign, num_problems, groups, n, kmax,
+                       0, 0, 0, images, fz);
     return hipGetLastError();
 }
 

@@ -134,6 +134,34 @@ MDETR_HD void pl_giou(const float *src6, const float *tgt6, float &loss, float *
     g6[5] = -gx[3];
 }
 
+// GIoU value only (the matcher's cost term)
+MDETR_HD float pl_giou_value(const float *src6, const float *tgt6)
+{
+    float s[4], t[4];
+    pl_xyxy(src6, s);
+    pl_xyxy(tgt6, t);
+    const float iw = pl_max(pl_min(s[2], t[2]) - pl_max(s[0], t[0]), 0.f), ih = pl_max(pl_min(s[3], t[3]) - pl_max(s[1], t[1]), 0.f);
+    const float inter = iw * ih;
+    const float uni = (s[2] - s[0]) * (s[3] - s[1]) + (t[2] - t[0]) * (t[3] - t[1]) - inter;
+    const float hw = pl_max(pl_max(s[2], t[2]) - pl_min(s[0], t[0]), 0.f), hh = pl_max(pl_max(s[3], t[3]) - pl_min(s[1], t[1]), 0.f);
+    const float hull = hw * hh;
+    return inter / uni - (hull - uni) / hull;
+}
+
+struct MatchWeights { float w_class, w_bbox, w_center, w_giou, alpha; };
+
+// Hungarian matching cost of (query, target) -- lib/models/monodetr/matcher.py:55-84:
+//   w_bbox * L1(l,r,t,b) + w_center * L1(cx,cy) + w_class * (pos - neg focal cost at the target label) - w_giou * GIoU
+MDETR_HD float pl_match_cost(const float *logits, const float *box6, int label, const float *tgt6, const MatchWeights &w)
+{
+    const float p = 1.f / (1.f + pl_exp(-logits[label]));
+    const float neg = (1.f - w.alpha) * (p * p) * (-pl_log(1.f - p + 1e-8f));
+    const float pos = w.alpha * ((1.f - p) * (1.f - p)) * (-pl_log(p + 1e-8f));
+    const float c_center = pl_abs(box6[0] - tgt6[0]) + pl_abs(box6[1] - tgt6[1]);
+    const float c_bbox = pl_abs(box6[2] - tgt6[2]) + pl_abs(box6[3] - tgt6[3]) + pl_abs(box6[4] - tgt6[4]) + pl_abs(box6[5] - tgt6[5]);
+    return w.w_bbox * c_bbox + w.w_center * c_center + w.w_class * (pos - neg) + w.w_giou * (-pl_giou_value(box6, tgt6));
+}
+
 struct PairLossDims {
     int L, B, Q, C, G, K;          // levels, images, queries, classes, groups, target slots
     float alpha;                   // focal alpha

@@ -22,3 +22,30 @@ def batched_assignment(cost, num_targets, groups):
         torch.cuda.current_stream(cost.device).cuda_stream)
     _capi.check(rc, "mdetr_lsa_forward")
     return assign
+
+
+_backend = None               # tests substitute the host build (tests/native): same cost arithmetic, serial solver
+
+
+def batched_assignment_fused(logits, boxes, gt, groups, weights, focal_alpha=0.25):
+    """Assignment straight from level-stacked predictions (logits [L,B,Q,C], boxes [L,B,Q,6]) and the padded
+    ground truth: the cost of matcher.py:55-84 is evaluated inside the solver kernel.  weights = (class, bbox,
+    3dcenter, giou).  Returns [L, B, G, K] int32 like `batched_assignment`."""
+    L, B, Q, C = logits.shape
+    K = gt["valid"].shape[1]
+    n = Q // groups
+    assert n * groups == Q and n <= 64 and K <= n, "need Q = groups * n with n <= 64 and Kmax <= n"
+    dev = logits.device
+    lg, bx = logits.float().contiguous(), boxes.float().contiguous()
+    labels, b3d = gt["labels"].to(torch.int64).contiguous(), gt["boxes_3d"].float().contiguous()
+    num = gt["num"].to(device=dev, dtype=torch.int32).contiguous()
+    assign = torch.empty((L, B, groups, K), dtype=torch.int32, device=dev)
+    lib = _backend if _backend is not None else _capi.lib()
+    rc = lib.mdetr_lsa_forward_fused(
+        lg.data_ptr(), bx.data_ptr(), labels.data_ptr(), b3d.data_ptr(), num.data_ptr(), assign.data_ptr(),
+        L, B, groups, n, K, C, float(weights[0]), float(weights[1]), float(weights[2]), float(weights[3]),
+        float(focal_alpha), dev.index if dev.type == "cuda" else -1,
+        torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None)
+    if rc != 0:
+        _capi.check(rc, "mdetr_lsa_forward_fused")
+    return assign

@@ -9,6 +9,8 @@ reference does (scipy ``linear_sum_assignment``, :96); what changes is the traff
 ``match_layers`` scores all decoder layers in one batched device computation and makes ONE
 device->host copy per iteration instead of one per layer.
 """
+import os
+
 import numpy as np
 import torch
 from scipy.optimize import linear_sum_assignment
@@ -22,6 +24,9 @@ class HungarianMatcher(nn.Module):
         super().__init__()
         self.cost_class, self.cost_3dcenter, self.cost_bbox, self.cost_giou = cost_class, cost_3dcenter, cost_bbox, cost_giou
         assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
+        # MDETR_FUSED_LOSSES=1: matching cost evaluated inside the device solver (off until its first GPU
+        # validation, like the fused losses: tests/test_pending_gpu.py)
+        self.fused_cost = os.environ.get("MDETR_FUSED_LOSSES") == "1"
 
     @torch.no_grad()
     def cost_matrix(self, pred_logits, pred_boxes, tgt_ids, tgt_boxes):
@@ -117,8 +122,13 @@ class HungarianMatcher(nn.Module):
         """`assign_padded` on already layer-stacked predictions: logits [L,B,Q,C], boxes [L,B,Q,6]."""
         L, B, Q, _ = logits.shape
         K = gt["valid"].shape[1]
-        C = self.cost_padded(logits, boxes, gt)
         n = Q // group_num
+        if self.fused_cost and n <= 64 and K <= n and n * group_num == Q:
+            # the cost is evaluated inside the solver kernel: no cost matrix, one launch (lsa_ext)
+            from ..lsa_ext import batched_assignment_fused
+            return batched_assignment_fused(logits, boxes, gt, group_num, (self.cost_class, self.cost_bbox,
+                                            self.cost_3dcenter, self.cost_giou)).long()
+        C = self.cost_padded(logits, boxes, gt)
         if C.is_cuda and n <= 64 and K <= n:
             from ..lsa_ext import batched_assignment
             return batched_assignment(C.float(), gt["num"], group_num).long()

@@ -50,6 +50,72 @@ int mdetr_adamw_step(int param_dtype, void *param, float *master, const void *gr
     return 0;
 }
 
+// mdetr_lsa_forward_fused: the kernel's cost arithmetic (pl_match_cost) + a serial version of its
+// shortest-augmenting-path solver (float64 on the fp32 costs, smallest column index on ties)
+int mdetr_lsa_forward_fused(const float *logits, const float *boxes, const int64_t *labels, const float *boxes3d,
+                            const int32_t *num_targets, int32_t *assign, int layers, int images, int groups, int n,
+                            int kmax, int num_classes, float w_class, float w_bbox, float w_center, float w_giou,
+                            float focal_alpha, int device, void *stream)
+{
+    (void)device; (void)stream;
+    const mdetr::MatchWeights mw{w_class, w_bbox, w_center, w_giou, focal_alpha};
+    const double INF = 1e300;
+    for (int li = 0; li < layers * images; ++li)
+        for (int g = 0; g < groups; ++g) {
+            const int image = li % images;
+            int k = num_targets[image];
+            k = k < 0 ? 0 : (k > kmax ? kmax : k);
+            int32_t *out = assign + (static_cast<int64_t>(li) * groups + g) * kmax;
+            for (int t = 0; t < kmax; ++t) out[t] = -1;
+            if (k == 0) continue;
+            double a[64][64], u[64] = {0}, v[64] = {0};
+            int p[64];
+            for (int j = 0; j < n; ++j) {
+                p[j] = -1;
+                const int64_t row = (static_cast<int64_t>(li) * groups + g) * n + j;
+                for (int t = 0; t < k; ++t) {
+                    const int64_t tk = static_cast<int64_t>(image) * kmax + t;
+                    a[t][j] = static_cast<double>(mdetr::pl_match_cost(logits + row * num_classes, boxes + row * 6,
+                                                                       static_cast<int>(labels[tk]), boxes3d + tk * 6, mw));
+                }
+            }
+            for (int i = 0; i < k; ++i) {
+                double minv[64];
+                int way[64];
+                bool used[64];
+                for (int j = 0; j < n; ++j) { minv[j] = INF; way[j] = -2; used[j] = false; }
+                int j0 = -1;
+                while (true) {
+                    if (j0 >= 0) used[j0] = true;
+                    const int i0 = j0 < 0 ? i : p[j0];
+                    double delta = INF;
+                    int j1 = -1;
+                    for (int j = 0; j < n; ++j) {
+                        if (used[j]) continue;
+                        const double cur = a[i0][j] - u[i0] - v[j];
+                        if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+                        if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+                    }
+                    for (int j = 0; j < n; ++j) {
+                        if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
+                        else minv[j] -= delta;
+                    }
+                    u[i] += delta;
+                    j0 = j1;
+                    if (p[j0] < 0) break;
+                }
+                while (j0 >= 0) {
+                    const int jp = way[j0];
+                    p[j0] = jp < 0 ? i : p[jp];
+                    j0 = jp;
+                }
+            }
+            for (int j = 0; j < n; ++j)
+                if (p[j] >= 0) out[p[j]] = g * n + j;
+        }
+    return 0;
+}
+
 // same argument lists as mdetr_ddn_loss_forward / _backward, serial loops over the pixels
 static mdetr::DdnDims host_ddn_dims(int B, int C, int H, int W, int K, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
                                     float alpha, float fg_weight, float bg_weight, float depth_min, float depth_max)

@@ -39,15 +39,15 @@ def _problem(L, B, Q, K, G, seed, empty_image=True):
 
 @pytest.fixture()
 def criterion():
-    from monodetr_amd import ddn_loss_ext, pair_losses_ext
+    from monodetr_amd import ddn_loss_ext, lsa_ext, pair_losses_ext
     from monodetr_amd.monodetr import build_monodetr
     torch.manual_seed(0)
     cfg = load_cfg()
     _, crit = build_monodetr(cfg)
     crit.train()
-    pair_losses_ext._backend = ddn_loss_ext._backend = native_host.lib()
+    pair_losses_ext._backend = ddn_loss_ext._backend = lsa_ext._backend = native_host.lib()
     yield crit
-    pair_losses_ext._backend = ddn_loss_ext._backend = None
+    pair_losses_ext._backend = ddn_loss_ext._backend = lsa_ext._backend = None
 
 
 @pytest.mark.parametrize("L,B,Q,K,G,seed", [(3, 4, 110, 7, 11, 0), (3, 2, 550, 50, 11, 1), (1, 3, 20, 5, 1, 2)])
@@ -59,7 +59,7 @@ def test_fused_pair_losses_match_the_criterion(criterion, L, B, Q, K, G, seed):
     outputs['aux_outputs'] = [{k: v[i] for k, v in preds.items()} for i in range(L - 1)]
 
     def run(fused):
-        criterion.fused_pair_losses = fused
+        criterion.fused_pair_losses = criterion.matcher.fused_cost = fused      # matching, pair losses, depth-map loss
         leaves = {k: v.clone().requires_grad_(True) for k, v in preds.items()}
         out = dict(outputs, _levels=leaves)
         losses = criterion(out, gt)
@@ -137,3 +137,39 @@ def test_fused_ddn_loss_matches_the_pytorch_ddn_loss(layout):
         assert (za.grad - zb.grad).abs().max() <= 2e-5 * za.grad.abs().max()
     finally:
         ddn_loss_ext._backend = None
+
+
+def test_fused_matching_cost_and_serial_solver_match_scipy_on_the_pytorch_cost():
+    """pl_match_cost (the cost evaluated inside the device solver) against matcher.cost_padded, through the
+    host build: the assignments equal scipy's on the PyTorch cost matrix (total cost equal where an optimum
+    is not unique)."""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    from monodetr_amd import lsa_ext
+    from monodetr_amd.monodetr import build_monodetr
+    lsa_ext._backend = native_host.lib()
+    try:
+        _, crit = build_monodetr(load_cfg())
+        m = crit.matcher
+        for (L, B, Q, K, G, seed) in ((3, 4, 550, 50, 11, 0), (2, 3, 110, 7, 11, 1), (1, 2, 64, 64, 1, 2)):
+            preds, gt = _problem(L, B, Q, K, G, seed)
+            cost = m.cost_padded(preds['pred_logits'], preds['pred_boxes'], gt).double().numpy()
+            got = lsa_ext.batched_assignment_fused(preds['pred_logits'], preds['pred_boxes'], gt, G,
+                                                   (m.cost_class, m.cost_bbox, m.cost_3dcenter, m.cost_giou)).numpy()
+            n = Q // G
+            for l in range(L):
+                for b in range(B):
+                    k = int(gt['num'][b])
+                    for g in range(G):
+                        a = got[l, b, g]
+                        assert (a[k:] == -1).all()
+                        if k == 0:
+                            continue
+                        sub = cost[l, b, g * n:(g + 1) * n, :k]
+                        r, c = linear_sum_assignment(sub)
+                        mine = a[:k] - g * n
+                        assert len(set(mine.tolist())) == k and mine.min() >= 0 and mine.max() < n
+                        ref_total, my_total = sub[r, c].sum(), sub[mine, np.arange(k)].sum()
+                        assert abs(ref_total - my_total) <= 1e-5 * max(1.0, abs(ref_total))
+    finally:
+        lsa_ext._backend = None

@@ -142,3 +142,35 @@ def test_fused_ddn_loss_kernel_matches_the_pytorch_ddn_loss(layout):
         got.backward()
         assert abs(float(ref) - float(got)) <= 1e-5 * abs(float(ref))
         assert (za.grad - zb.grad).abs().max() <= 1e-4 * za.grad.abs().max()
+
+
+def test_fused_cost_solver_kernel_matches_scipy():
+    """csrc/lsa.hip with the cost evaluated in the kernel against scipy on the PyTorch cost matrix (equal
+    total cost per problem; assignments are permutations of the group's queries)."""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    from test_fused_losses_cpu import _problem
+    from model_init import load_cfg
+    from monodetr_amd.lsa_ext import batched_assignment_fused
+    from monodetr_amd.monodetr import build_monodetr
+    _, crit = build_monodetr(load_cfg())
+    m = crit.matcher
+    for (L, B, Q, K, G, seed) in ((3, 8, 550, 50, 11, 0), (2, 3, 110, 7, 11, 1), (1, 2, 64, 64, 1, 2)):
+        preds, gt = _problem(L, B, Q, K, G, seed)
+        cost = m.cost_padded(preds['pred_logits'], preds['pred_boxes'], gt).double().numpy()
+        gtc = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in gt.items()}
+        got = batched_assignment_fused(preds['pred_logits'].cuda(), preds['pred_boxes'].cuda(), gtc, G,
+                                       (m.cost_class, m.cost_bbox, m.cost_3dcenter, m.cost_giou)).cpu().numpy()
+        n = Q // G
+        for l in range(L):
+            for b in range(B):
+                k = int(gt['num'][b])
+                for g in range(G):
+                    a = got[l, b, g]
+                    assert (a[k:] == -1).all()
+                    if k:
+                        sub = cost[l, b, g * n:(g + 1) * n, :k]
+                        r, c = linear_sum_assignment(sub)
+                        mine = a[:k] - g * n
+                        assert len(set(mine.tolist())) == k and mine.min() >= 0 and mine.max() < n
+                        assert abs(sub[r, c].sum() - sub[mine, np.arange(k)].sum()) <= 1e-5 * max(1.0, abs(sub[r, c].sum()))
