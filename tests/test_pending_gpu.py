@@ -174,3 +174,23 @@ def test_fused_cost_solver_kernel_matches_scipy():
                         mine = a[:k] - g * n
                         assert len(set(mine.tolist())) == k and mine.min() >= 0 and mine.max() < n
                         assert abs(sub[r, c].sum() - sub[mine, np.arange(k)].sum()) <= 1e-5 * max(1.0, abs(sub[r, c].sum()))
+
+
+def test_training_step_with_fused_criterion_matches_default():
+    """Three full training iterations (bf16 body, dropout off) with MDETR_FUSED_LOSSES=1 (fused matching cost,
+    pair losses, depth-map loss): the loss trajectory follows the default one."""
+    import bench
+    from model_init import disable_dropout_
+    dev = torch.device("cuda", 0)
+    traj = {}
+    for fused in (False, True):
+        os.environ["MDETR_FUSED_LOSSES"] = "1" if fused else "0"
+        try:
+            step = bench.TrainStep(dev, 2, "bf16", size=(96, 320))
+        finally:
+            os.environ.pop("MDETR_FUSED_LOSSES", None)
+        assert step.criterion.fused_pair_losses == fused and step.criterion.matcher.fused_cost == fused
+        disable_dropout_(step.raw_model)
+        traj[fused] = [float(step()) for _ in range(3)]
+    for a, b in zip(traj[False], traj[True]):
+        assert abs(a - b) <= 2e-2 * abs(a), traj
