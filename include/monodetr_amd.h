@@ -6,8 +6,9 @@
  *     lib/models/monodetr/ops/src/vision.cpp:13-16         module `MultiScaleDeformableAttention`
  *     lib/models/monodetr/ops/src/ms_deform_attn.h:20-60   ms_deform_attn_forward / _backward
  *     lib/models/monodetr/ops/src/cuda/ms_deform_attn_cuda.cu:20-80, :83-153   shapes, asserts, alloc
- * Here the same two operations are plain `extern "C"` functions taking raw device pointers and
- * sizes.  No torch/ATen types cross this boundary; the host shim (monodetr_amd/_capi.py) owns
+ * Here the same two operations -- and the other hand-written kernels of the training step (dense
+ * attention, Hungarian matching, the criterion's losses, column sums, AdamW) -- are plain `extern "C"`
+ * functions taking raw device pointers and sizes.  No torch/ATen types cross this boundary; the host shim (monodetr_amd/_capi.py) owns
  * allocation, contiguity checks and the current stream, mirroring what the ATen wrapper did.
  *
  * Conventions (all entry points)
@@ -15,8 +16,9 @@
  *     thread-local message (the reference only printf'd launch errors, .cuh:948-952).
  *   - never allocate, free or synchronise; work is enqueued on `stream` (a hipStream_t, may be
  *     NULL for the default stream) of device ordinal `device`.
- *   - re-entrant: no global mutable state (forward runs on the main thread, backward on autograd
- *     worker threads).
+ *   - re-entrant: the compute entry points keep no mutable state of their own (forward runs on the main
+ *     thread, backward on autograd worker threads); scratch they need is passed in as `workspace`.
+ *     The only process-wide state is the opt-in profiling store (mdetr_profile_*), guarded by a mutex.
  *   - tensors are dense row-major ("contiguous"), 16-byte aligned base pointers.
  */
 #ifndef MONODETR_AMD_H
@@ -33,7 +35,7 @@ extern "C" {
 /* element types of the floating-point tensors */
 #define MDETR_F32 0
 #define MDETR_F64 1
-#define MDETR_BF16 2   /* attention entry points only */
+#define MDETR_BF16 2   /* attention, column-sum and AdamW entry points */
 
 #define MDETR_OK            0
 #define MDETR_E_ARG        -1   /* bad size / null pointer / unsupported dtype */
