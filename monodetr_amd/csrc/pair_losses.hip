@@ -78,7 +78,7 @@ void pair_losses_fwd_kernel(const PairLossDims d, const PairLossIn in, const int
     if (!last) return;
     __threadfence();
     // finalise: one thread per level
-    if (threadIdx.x < d.L) {
+    if (static_cast<int>(threadIdx.x) < d.L) {
         const int lv = threadIdx.x;
         float s[kAcc];                                                  // agent-scope loads: the sums were built by
         for (int i = 0; i < kAcc; ++i)                                  // atomics issued from other XCDs

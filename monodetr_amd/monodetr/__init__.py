@@ -1,6 +1,10 @@
-"""Mirror of lib/models/monodetr: ``build_monodetr(cfg) -> (model, criterion)`` (__init__.py:1-5)."""
-from .monodetr import build
+"""Model package with the reference's entry point: ``build_monodetr(cfg) -> (model, criterion)``
+(lib/models/monodetr/__init__.py), where ``cfg`` is the ``model:`` section of configs/monodetr.yaml."""
+from . import monodetr as _impl
+
+__all__ = ["build_monodetr"]
 
 
 def build_monodetr(cfg):
-    return build(cfg)
+    model, criterion = _impl.build(cfg)
+    return model, criterion
