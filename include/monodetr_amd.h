@@ -244,6 +244,18 @@ int mdetr_adamw_step(int param_dtype, void *param, float *master, const void *gr
                      float step_size, const float *step_size_dev, int device, void *stream);
 
 /*
+ * y[T, N] = x[T, K] * weight[N, K]^T + bias (+ ReLU) for tall token matrices in bf16, with the weight held in
+ * LDS (the GEMM behind every nn.Linear applied to the flattened feature pyramid: ops/modules/ms_deform_attn.py:
+ * 80-83, depthaware_transformer.py:331-333; the input gradient is the same product with weight^T).
+ *   x      bf16 [T, K], row stride ldx elements (ldx % 8 == 0, 16-byte aligned base)
+ *   weight bf16 [N, K] row-major, 16-byte aligned;  bias bf16 [N] or NULL
+ *   y      bf16 [T, N], row stride ldy elements (ldy % 4 == 0, 8-byte aligned base)
+ *   K in {128, 256}, N % 8 == 0, fp32 accumulation on the matrix cores
+ */
+int mdetr_token_linear(const void *x, const void *weight, const void *bias, void *y, int64_t T, int N, int K,
+                       int64_t ldx, int64_t ldy, int relu, int device, void *stream);
+
+/*
  * Column sums of a tall row-major matrix, accumulated in fp32: out[j] = sum_i x[i * ld + j].
  * Not an entry point of the reference's extension: it is the bias gradient of the model's token-wise
  * linear layers (db = sum over the 81 600 tokens of dY; torch's autograd computes it with a generic

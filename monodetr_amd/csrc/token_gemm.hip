@@ -1,0 +1,204 @@
+// monodetr_amd/csrc/token_gemm.hip -- y[T, N] = x[T, K] W^T + b  (+ ReLU) for tall token matrices, bf16,
+// with the WEIGHT RESIDENT IN LDS.
+//
+// Why: the transformer's linear layers act on T = 81 600 tokens with K = 256 (21 forward + 21
+// input-gradient products per training step).  Such a product is 10.7 GFLOP against 84 MB of
+// compulsory traffic -- memory-bound, floor ~10 us at 8 TB/s -- and the library kernel hipBLASLt picks
+// (MT64x64x128) takes 41 us = 2 TB/s (profiles/r01h_bench_bf16_steady_kernel_stats.csv).  A 256 x 256
+// bf16 weight is 128 KiB: it fits the 160 KiB LDS of a CU whole.
+//
+// Layout of the computation (the fragment conventions are those of attn.hip, validated there):
+//   * a workgroup = 4 waves loads W[n0 : n0 + NB*32, 0:K] once into LDS, row-major, rows padded by 8 bf16
+//     (264 elements = 132 dwords = 4 mod 64: the 16 rows of a ds_read_b128 lane group hit 16 distinct
+//     4-bank slots);
+//   * each wave then walks 32-token tiles (grid-stride): the tile's 32 x K inputs are fetched with
+//     coalesced 16-byte loads into registers, four K-slabs of 64, and passed through a wave-private LDS
+//     slab [32][72] so that a lane can read ITS token's 8 contiguous k values as the B operand;
+//     the next tile's slab s is requested right after slab s of the current tile has been written to
+//     LDS, so a whole tile of loads (16 KiB per wave) is in flight during the matrix work;
+//   * products are issued transposed, Y^T[n][token] = W[n][:] . X[token][:]  (A = weight rows from
+//     LDS, B = the lane's token), with v_mfma_f32_32x32x16_bf16: a lane's accumulator then holds four
+//     consecutive output features of ITS token per register quad -> 8-byte stores, bias / ReLU applied
+//     in registers.
+// Algorithmic bytes = 2 (T K + T N) + 2 N K; MFMA work is 4-5x below the memory time at these shapes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "token_gemm.h"
+
+namespace mdetr {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kWavesG = 4;
+constexpr int kSlabK = 64;                 // k values per slab
+constexpr int kSlabPad = kSlabK + 8;       // 72 bf16 = 36 dwords per slab row (conflict-free b128 reads, see above)
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// accumulator register r of a lane holds row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31 of the
+// 32 x 32 result (attn.hip acc_row)
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// K = contraction length (multiple of 64), NB = number of 32-wide output blocks held by a workgroup
+template <int K, int NB, bool RELU>
+__global__ __launch_bounds__(kWavesG * 64)
+void token_gemm_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, const __bf16 *__restrict__ bias,
+                       __bf16 *__restrict__ y, int64_t T, int N, int64_t ldx, int64_t ldy)
+{
+    constexpr int KP = K + 8;                                    // padded weight row
+    constexpr int NS = K / kSlabK;                               // slabs per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16 *Ws = reinterpret_cast<__bf16 *>(smem_raw);           // [NB*32][KP]
+    __bf16 *slabs = Ws + NB * 32 * KP;                           // [4 waves][32][kSlabPad]
+    float *bias_s = reinterpret_cast<float *>(slabs + kWavesG * 32 * kSlabPad);   // [NB*32]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    const int n0 = blockIdx.y * NB * 32;
+
+    // ---- weight (and bias) into LDS, once: 16-byte chunks, consecutive threads -> consecutive chunks of a row
+    for (int c = threadIdx.x; c < NB * 32 * (K / 8); c += kWavesG * 64) {
+        const int row = c / (K / 8), col = (c - row * (K / 8)) * 8;
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = static_cast<__bf16>(0.f);
+        if (n0 + row < N) v = *reinterpret_cast<const bf16x8 *>(w + static_cast<int64_t>(n0 + row) * K + col);
+        *reinterpret_cast<bf16x8 *>(Ws + row * KP + col) = v;
+    }
+    for (int c = threadIdx.x; c < NB * 32; c += kWavesG * 64)
+        bias_s[c] = (bias && n0 + c < N) ? static_cast<float>(bias[n0 + c]) : 0.f;
+    __syncthreads();
+
+    __bf16 *slab = slabs + wave * 32 * kSlabPad;
+    const int64_t tiles = (T + 31) / 32;
+    const int64_t wave_id = static_cast<int64_t>(blockIdx.x) * kWavesG + wave, wave_n = static_cast<int64_t>(gridDim.x) * kWavesG;
+
+    // staging map of one slab (32 rows x 64 k = 256 chunks of 16 B): chunk c = lane + 64 j -> row c / 8, piece c % 8
+    bf16x8 stage[NS][4];
+    auto request = [&](int64_t tile, int s) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = lane + 64 * j, row = c >> 3, piece = c & 7;
+            const int64_t t = tile * 32 + row;
+            bf16x8 v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = static_cast<__bf16>(0.f);
+            if (t < T) v = *reinterpret_cast<const bf16x8 *>(x + t * ldx + s * kSlabK + piece * 8);
+            stage[s][j] = v;
+        }
+    };
+
+    int64_t tile = wave_id;
+    if (tile < tiles) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) request(tile, s);
+    }
+    for (; tile < tiles; tile += wave_n) {
+        f32x16 acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+        const int64_t next = tile + wave_n;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            wave_sync();                                         // the previous slab's fragment reads are done
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = lane + 64 * j, row = c >> 3, piece = c & 7;
+                *reinterpret_cast<bf16x8 *>(slab + row * kSlabPad + piece * 8) = stage[s][j];
+            }
+            if (next < tiles) request(next, s);                  // next tile's slab s: in flight during the products below
+            wave_sync();
+#pragma unroll
+            for (int ks = 0; ks < kSlabK / 16; ++ks) {
+                // B operand: this lane's token (row lane & 31 of the slab), 8 contiguous k
+                const bf16x8 xb = *reinterpret_cast<const bf16x8 *>(slab + (lane & 31) * kSlabPad + ks * 16 + half * 8);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    // A operand: weight row n = 32 b + (lane & 31), the same 8 k values of the global K axis
+                    const bf16x8 wa = *reinterpret_cast<const bf16x8 *>(Ws + (b * 32 + (lane & 31)) * KP + s * kSlabK + ks * 16 + half * 8);
+                    acc[b] = mfma_bf16(wa, xb, acc[b]);          // Y^T[n][token]
+                }
+            }
+        }
+        // ---- epilogue: lane = token (lane & 31); register quad g holds features 32 b + 8 g + 4 half + 0..3
+        const int64_t t = tile * 32 + (lane & 31);
+        if (t < T) {
+            __bf16 *yr = y + t * ldy + n0 + 4 * half;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nn = b * 32 + 8 * g + 4 * half;     // first of the four features, relative to n0
+                    if (n0 + nn < N) {                            // N is a multiple of 4: a quad is in or out as a whole
+                        bf16x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float v = acc[b][4 * g + i] + bias_s[nn + i];
+                            if (RELU) v = v > 0.f ? v : 0.f;
+                            o[i] = static_cast<__bf16>(v);
+                        }
+                        *reinterpret_cast<bf16x4 *>(yr + b * 32 + 8 * g) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int K, int NB, bool RELU>
+hipError_t launch(const void *x, const void *w, const void *bias, void *y, int64_t T, int N, int64_t ldx, int64_t ldy,
+                  hipStream_t st)
+{
+    constexpr size_t lds = static_cast<size_t>(NB) * 32 * (K + 8) * 2 + kWavesG * 32 * kSlabPad * 2 + NB * 32 * 4;
+    static_assert(lds <= 160 * 1024, "weight block does not fit the LDS");
+    auto kern = token_gemm_kernel<K, NB, RELU>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int64_t tiles = (T + 31) / 32;
+    int64_t gx = (tiles + kWavesG - 1) / kWavesG;
+    const int ny = (N + NB * 32 - 1) / (NB * 32);
+    const int64_t cap = 256 / ny > 0 ? 256 / ny : 1;              // one workgroup per CU holds the weight: <= 256 in total
+    if (gx > cap) gx = cap;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(ny)), dim3(kWavesG * 64), lds, st,
+                       static_cast<const __bf16 *>(x), static_cast<const __bf16 *>(w), static_cast<const __bf16 *>(bias),
+                       static_cast<__bf16 *>(y), T, N, ldx, ldy);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool token_gemm_supported(int64_t T, int N, int K, int64_t ldx, int64_t ldy, const void *x, const void *w, const void *y)
+{
+    const auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return T > 0 && (K == 256 || K == 128) && N > 0 && N % 8 == 0 && ldx % 8 == 0 && ldy % 4 == 0 && ldx >= K && ldy >= N &&
+           al(x) && al(w) && (reinterpret_cast<uintptr_t>(y) & 7) == 0;
+}
+
+hipError_t token_gemm_launch(const void *x, const void *w, const void *bias, void *y, int64_t T, int N, int K,
+                             int64_t ldx, int64_t ldy, bool relu, hipStream_t st)
+{
+    if (K == 256) {
+        if (N <= 128) return relu ? launch<256, 4, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch<256, 4, false>(x, w, bias, y, T, N, ldx, ldy, st);
+        return relu ? launch<256, 8, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch<256, 8, false>(x, w, bias, y, T, N, ldx, ldy, st);
+    }
+    return relu ? launch<128, 8, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch<128, 8, false>(x, w, bias, y, T, N, ldx, ldy, st);
+}
+
+}  // namespace mdetr

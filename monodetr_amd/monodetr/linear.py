@@ -8,6 +8,8 @@ GPU item.  Here the token axis is split into C chunks evaluated as one batched G
 ([C, N, T/C] x [C, T/C, K], thousands of independent tiles) followed by a sum over C: 35 us.
 Pure library plumbing (torch.bmm -> hipBLASLt); numerics are those of a split-K GEMM.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -15,6 +17,10 @@ from torch import nn
 from .. import colsum_ext
 
 _MIN_TOKENS = 4096
+# MDETR_TOKEN_GEMM=1: forward and input-gradient products of K in {128, 256} bf16 layers through the
+# LDS-resident-weight kernel (csrc/token_gemm.hip).  Off until its first GPU validation
+# (tests/test_pending_gpu.py); the library GEMM is the default.
+_TOKEN_GEMM = os.environ.get("MDETR_TOKEN_GEMM") == "1"
 
 
 def _split_count(T):
@@ -32,6 +38,11 @@ class _TokenLinear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if _TOKEN_GEMM:
+            from .. import token_gemm_ext
+            x2 = x.reshape(-1, x.shape[-1])
+            if token_gemm_ext.supported(x2, weight):
+                return token_gemm_ext.token_gemm(x2, weight, bias).view(x.shape[:-1] + (weight.shape[0],))
         return F.linear(x, weight, bias)
 
     @staticmethod
@@ -42,7 +53,14 @@ class _TokenLinear(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         dy2 = dy.reshape(-1, dy.shape[-1])
         if ctx.needs_input_grad[0]:
-            dx = (dy2 @ weight).view_as(x)
+            dx = None
+            if _TOKEN_GEMM:
+                from .. import token_gemm_ext
+                wt = weight.t().contiguous()                        # [K_in, N]: dX = dY (W^T)^T, contraction over N
+                if dy2.is_contiguous() and token_gemm_ext.supported(dy2, wt):
+                    dx = token_gemm_ext.token_gemm(dy2, wt).view_as(x)
+            if dx is None:
+                dx = (dy2 @ weight).view_as(x)
         T = x2.shape[0]
         C = _split_count(T)
         if ctx.needs_input_grad[1]:
