@@ -28,15 +28,22 @@ def _strided(t):
 _seed_state = {}
 
 
+_WEYL = 0x9E3779B97F4A7C15 - (1 << 64)      # 64-bit golden-ratio increment as a signed int64
+
+
 def _next_seed(device):
     """Device-resident dropout counter: returns a snapshot tensor (int64 [1]) for this call and
     advances the counter, all with device ops -- so a captured hipGraph draws a new mask on every
-    replay.  Initialised once from torch's CPU generator (reproducible under torch.manual_seed)."""
+    replay.  Initialised once from torch's CPU generator (reproducible under torch.manual_seed).
+    The counter advances by the 64-bit golden ratio (a Weyl sequence), not by 1: the kernels' hash mixes
+    the seed with a single multiply, and masks drawn from seeds that differ only in their lowest bit are
+    correlated (-0.11); golden-ratio steps flip about half of the bits and give uncorrelated masks
+    (tests/test_dropout_hash_cpu.py)."""
     st = _seed_state.get(device)
     if st is None:
-        st = _seed_state[device] = torch.randint(0, 2 ** 40, (1,), dtype=torch.int64).to(device)
+        st = _seed_state[device] = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
     snap = st.clone()
-    st.add_(1)
+    st.add_(_WEYL)                             # wraps modulo 2^64
     return snap
 
 
