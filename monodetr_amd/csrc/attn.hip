@@ -102,6 +102,9 @@ __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (
 // 33 M elements: drop rate 0.1000, neighbour correlations along q, k, head and batch < 3e-4 (noise
 // level), per-row / per-column counts binomial.  The previous two-multiply finaliser plus per-element
 // coordinate multiplies cost one third of the forward kernel's time at p = 0.1.
+// Caveat: the seed enters by XOR only, so two seeds that differ in just their lowest bits give correlated
+// masks (-0.11 for seed, seed + 1); callers must step seeds by a constant that flips many bits --
+// attn_ext._next_seed uses the 64-bit golden ratio (tests/test_dropout_hash_cpu.py).
 __device__ __forceinline__ unsigned drop_qterm(uint64_t seed, int b, int h, int q)
 {
     return (static_cast<unsigned>(q) * 0x9E3779B1u) ^ static_cast<unsigned>(seed) ^
