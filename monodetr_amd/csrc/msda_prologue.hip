@@ -1,0 +1,152 @@
+// monodetr_amd/csrc/msda_prologue.hip -- softmax over a head's L*P samples + sampling-location arithmetic of
+// MSDeformAttn.forward in one launch (and their gradients in one more), straight from the two projection
+// outputs to the fp32 `sampling_locations` / `attention_weights` the sampling operator consumes.
+//
+// The module does this with a softmax, a divide, an add and -- in a bf16 model -- casts on [B, Lq, M, L, P(, 2)]
+// tensors (10-20 M elements at the encoder shape): 5 launches forward and 5-7 backward per MSDA call, and in
+// bf16 the locations are rounded to 8 bits of mantissa on the way.  Here one thread owns one (image, query,
+// head): its 2 LP offsets and LP logits are contiguous, consecutive threads are consecutive heads of a query
+// (coalesced), everything is evaluated in fp32 (msda_prologue_math.h).  HBM-bound: algorithmic bytes =
+// B Lq M LP (3 e_io + 12) forward.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "msda_prologue.h"
+#include "msda_prologue_math.h"
+
+namespace mdetr {
+namespace {
+
+template <typename T> __device__ __forceinline__ float ldf(const T *p);
+template <> __device__ __forceinline__ float ldf<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float ldf<__hip_bfloat16>(const __hip_bfloat16 *p) { return __bfloat162float(*p); }
+template <typename T> __device__ __forceinline__ void stf(T *p, float v);
+template <> __device__ __forceinline__ void stf<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<__hip_bfloat16>(__hip_bfloat16 *p, float v) { *p = __float2bfloat16(v); }
+
+// TLP = L * P known at compile time (16 for MonoDETR: the per-sample arrays stay in registers) or 0 (any LP <= 64)
+template <typename T, int TLP>
+__global__ __launch_bounds__(256)
+void prologue_fwd_kernel(const PrologueDims d, const T *__restrict__ offsets, const T *__restrict__ logits,
+                         const T *__restrict__ ref, const int64_t *__restrict__ shapes, float *__restrict__ loc,
+                         float *__restrict__ attn)
+{
+    const int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;              // (b, q, m)
+    const int64_t total = static_cast<int64_t>(d.B) * d.Lq * d.M;
+    if (u >= total) return;
+    const int64_t bq = u / d.M;
+    const int b = static_cast<int>(bq / d.Lq), q = static_cast<int>(bq - static_cast<int64_t>(b) * d.Lq);
+    constexpr int CAP = TLP ? TLP : kPrologueMaxLP;
+    const int LP = TLP ? TLP : d.L * d.P;
+    float lg[CAP], at[CAP];
+#pragma unroll
+    for (int i = 0; i < (TLP ? TLP : 1); ++i) if (TLP) lg[i] = ldf<T>(logits + u * LP + i);
+    if (!TLP) for (int i = 0; i < LP; ++i) lg[i] = ldf<T>(logits + u * LP + i);
+    pro_softmax(lg, LP, at);
+#pragma unroll
+    for (int i = 0; i < (TLP ? TLP : 1); ++i) if (TLP) attn[u * LP + i] = at[i];
+    if (!TLP) for (int i = 0; i < LP; ++i) attn[u * LP + i] = at[i];
+    for (int l = 0; l < d.L; ++l) {
+        float rl[6];
+        const T *rp = ref + b * d.rsb + q * d.rsq + l * d.rsl;
+        for (int r = 0; r < d.R; ++r) rl[r] = ldf<T>(rp + r);
+        const float wh[2] = {static_cast<float>(shapes[2 * l + 1]), static_cast<float>(shapes[2 * l])};   // (W_l, H_l)
+        for (int p = 0; p < d.P; ++p)
+            for (int c = 0; c < 2; ++c) {
+                const int64_t i = (u * LP + l * d.P + p) * 2 + c;
+                loc[i] = pro_location(ldf<T>(offsets + i), rl, d.R, c, wh[c], d.P);
+            }
+    }
+}
+
+template <typename T, int TLP>
+__global__ __launch_bounds__(256)
+void prologue_bwd_kernel(const PrologueDims d, const T *__restrict__ offsets, const T *__restrict__ ref,
+                         const int64_t *__restrict__ shapes, const float *__restrict__ attn,
+                         const float *__restrict__ g_loc, const float *__restrict__ g_attn, T *__restrict__ g_offsets,
+                         T *__restrict__ g_logits, float *__restrict__ g_ref)
+{
+    const int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t total = static_cast<int64_t>(d.B) * d.Lq * d.M;
+    if (u >= total) return;
+    const int64_t bq = u / d.M;
+    const int b = static_cast<int>(bq / d.Lq), q = static_cast<int>(bq - static_cast<int64_t>(b) * d.Lq);
+    constexpr int CAP = TLP ? TLP : kPrologueMaxLP;
+    const int LP = TLP ? TLP : d.L * d.P;
+    float at[CAP], ga[CAP], gl[CAP];
+#pragma unroll
+    for (int i = 0; i < (TLP ? TLP : 1); ++i) if (TLP) { at[i] = attn[u * LP + i]; ga[i] = g_attn[u * LP + i]; }
+    if (!TLP) for (int i = 0; i < LP; ++i) { at[i] = attn[u * LP + i]; ga[i] = g_attn[u * LP + i]; }
+    pro_softmax_backward(at, ga, LP, gl);
+#pragma unroll
+    for (int i = 0; i < (TLP ? TLP : 1); ++i) if (TLP) stf<T>(g_logits + u * LP + i, gl[i]);
+    if (!TLP) for (int i = 0; i < LP; ++i) stf<T>(g_logits + u * LP + i, gl[i]);
+    for (int l = 0; l < d.L; ++l) {
+        float rl[6], gr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const T *rp = ref + b * d.rsb + q * d.rsq + l * d.rsl;
+        for (int r = 0; r < d.R; ++r) rl[r] = ldf<T>(rp + r);
+        const float wh[2] = {static_cast<float>(shapes[2 * l + 1]), static_cast<float>(shapes[2 * l])};
+        for (int p = 0; p < d.P; ++p)
+            for (int c = 0; c < 2; ++c) {
+                const int64_t i = (u * LP + l * d.P + p) * 2 + c;
+                const float off = d.R == 2 ? 0.f : ldf<T>(offsets + i);
+                stf<T>(g_offsets + i, pro_location_backward(g_loc[i], off, rl, d.R, c, wh[c], d.P, g_ref ? gr : nullptr));
+            }
+        if (g_ref) {
+            float *out = g_ref + ((static_cast<int64_t>(b) * d.Lq + q) * d.L + l) * d.R;
+            for (int r = 0; r < d.R; ++r) unsafeAtomicAdd(out + r, gr[r]);                 // summed over the M heads
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t msda_prologue_forward_launch(int io_dtype, const PrologueDims &d, const void *offsets, const void *logits,
+                                        const void *ref, const int64_t *shapes, float *loc, float *attn, hipStream_t st)
+{
+    const int64_t total = static_cast<int64_t>(d.B) * d.Lq * d.M;
+    if (total == 0) return hipSuccess;
+    const dim3 grid(static_cast<unsigned>((total + 255) / 256)), block(256);
+    const bool lp16 = d.L * d.P == 16;
+    auto go = [&](auto kern, auto *tag) {
+        using T = std::remove_pointer_t<decltype(tag)>;
+        hipLaunchKernelGGL(kern, grid, block, 0, st, d, static_cast<const T *>(offsets), static_cast<const T *>(logits),
+                           static_cast<const T *>(ref), shapes, loc, attn);
+    };
+    if (io_dtype == 2) {
+        if (lp16) go(prologue_fwd_kernel<__hip_bfloat16, 16>, static_cast<__hip_bfloat16 *>(nullptr));
+        else go(prologue_fwd_kernel<__hip_bfloat16, 0>, static_cast<__hip_bfloat16 *>(nullptr));
+    } else {
+        if (lp16) go(prologue_fwd_kernel<float, 16>, static_cast<float *>(nullptr));
+        else go(prologue_fwd_kernel<float, 0>, static_cast<float *>(nullptr));
+    }
+    return hipGetLastError();
+}
+
+hipError_t msda_prologue_backward_launch(int io_dtype, const PrologueDims &d, const void *offsets, const void *ref,
+                                         const int64_t *shapes, const float *attn, const float *g_loc, const float *g_attn,
+                                         void *g_offsets, void *g_logits, float *g_ref, hipStream_t st)
+{
+    const int64_t total = static_cast<int64_t>(d.B) * d.Lq * d.M;
+    if (total == 0) return hipSuccess;
+    const dim3 grid(static_cast<unsigned>((total + 255) / 256)), block(256);
+    const bool lp16 = d.L * d.P == 16;
+    auto go = [&](auto kern, auto *tag) {
+        using T = std::remove_pointer_t<decltype(tag)>;
+        hipLaunchKernelGGL(kern, grid, block, 0, st, d, static_cast<const T *>(offsets), static_cast<const T *>(ref), shapes,
+                           attn, g_loc, g_attn, static_cast<T *>(g_offsets), static_cast<T *>(g_logits), g_ref);
+    };
+    if (io_dtype == 2) {
+        if (lp16) go(prologue_bwd_kernel<__hip_bfloat16, 16>, static_cast<__hip_bfloat16 *>(nullptr));
+        else go(prologue_bwd_kernel<__hip_bfloat16, 0>, static_cast<__hip_bfloat16 *>(nullptr));
+    } else {
+        if (lp16) go(prologue_bwd_kernel<float, 16>, static_cast<float *>(nullptr));
+        else go(prologue_bwd_kernel<float, 0>, static_cast<float *>(nullptr));
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mdetr

@@ -8,6 +8,7 @@ numerics; the sampling + aggregation itself is the gfx950 operator behind
 instantiated) are exported for import compatibility.
 """
 import math
+import os
 import warnings
 
 import torch
@@ -16,7 +17,12 @@ from torch import nn
 
 from ..functions import MSDeformAttnFunction
 from ...linear import token_linear
+from .... import msda_prologue_ext
 
+
+# MDETR_MSDA_PROLOGUE=1: fused softmax + sampling-location kernel (off until its first GPU validation,
+# tests/test_pending_gpu.py)
+_FUSED_PROLOGUE = os.environ.get("MDETR_MSDA_PROLOGUE") == "1"
 
 _checked_shapes = set()
 
@@ -93,18 +99,22 @@ class MSDeformAttn(nn.Module):
         value = value.view(N, S, M, -1)
 
         offsets = token_linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias).view(N, Lq, M, L, P, 2)
-        weights = F.softmax(token_linear(query, self.attention_weights.weight, self.attention_weights.bias).view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
-
-        ref = reference_points[:, :, None, :, None, :]
-        if reference_points.shape[-1] == 2:
-            wh = input_spatial_shapes.flip(-1)                                  # (W_l, H_l), :150
-            locations = ref + offsets / wh[None, None, None, :, None, :]
-        elif reference_points.shape[-1] == 6:
-            extent = ref[..., 2::2] + ref[..., 3::2]                            # (l+r, t+b), :153-155
-            locations = ref[..., :2] + offsets / P * extent * 0.5
-        else:
+        logits = token_linear(query, self.attention_weights.weight, self.attention_weights.bias).view(N, Lq, M, L * P)
+        if reference_points.shape[-1] not in (2, 6):
             raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
                 reference_points.shape[-1]))
+        if _FUSED_PROLOGUE and msda_prologue_ext.supported(offsets, logits, reference_points):
+            # softmax + sampling-location arithmetic in one fp32 launch (csrc/msda_prologue.hip)
+            locations, weights = msda_prologue_ext.msda_prologue(offsets, logits, reference_points, input_spatial_shapes)
+        else:
+            weights = F.softmax(logits, -1).view(N, Lq, M, L, P)
+            ref = reference_points[:, :, None, :, None, :]
+            if reference_points.shape[-1] == 2:
+                wh = input_spatial_shapes.flip(-1)                                  # (W_l, H_l), :150
+                locations = ref + offsets / wh[None, None, None, :, None, :]
+            else:
+                extent = ref[..., 2::2] + ref[..., 3::2]                            # (l+r, t+b), :153-155
+                locations = ref[..., :2] + offsets / P * extent * 0.5
 
         out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
                                          locations, weights, self.im2col_step)

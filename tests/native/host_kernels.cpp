@@ -6,6 +6,7 @@
 
 #include "../../monodetr_amd/csrc/adamw_math.h"
 #include "../../monodetr_amd/csrc/ddn_loss_math.h"
+#include "../../monodetr_amd/csrc/msda_prologue_math.h"
 #include "../../monodetr_amd/csrc/pair_losses_math.h"
 
 namespace {
@@ -47,6 +48,78 @@ int mdetr_adamw_step(int param_dtype, void *param, float *master, const void *gr
         exp_avg[i] = m; exp_avg_sq[i] = v; master[i] = q;
         if (param_dtype == 2) static_cast<uint16_t *>(param)[i] = f32_to_bf16(q);
     }
+    return 0;
+}
+
+// mdetr_msda_prologue_forward / _backward: serial loops over the (image, query, head) units
+static float host_ld(int dt, const void *p, int64_t i)
+{
+    return dt == 2 ? bf16_to_f32(static_cast<const uint16_t *>(p)[i]) : static_cast<const float *>(p)[i];
+}
+static void host_st(int dt, void *p, int64_t i, float v)
+{
+    if (dt == 2) static_cast<uint16_t *>(p)[i] = f32_to_bf16(v); else static_cast<float *>(p)[i] = v;
+}
+
+int mdetr_msda_prologue_forward(int io_dtype, const void *offsets, const void *logits, const void *ref,
+                                const int64_t *spatial_shapes, float *sampling_loc, float *attn_weight,
+                                int B, int Lq, int M, int L, int P, int R, int64_t ref_sb, int64_t ref_sq, int64_t ref_sl,
+                                int device, void *stream)
+{
+    (void)device; (void)stream;
+    const int LP = L * P;
+    for (int b = 0; b < B; ++b)
+        for (int q = 0; q < Lq; ++q)
+            for (int m = 0; m < M; ++m) {
+                const int64_t u = (static_cast<int64_t>(b) * Lq + q) * M + m;
+                float lg[64], at[64];
+                for (int i = 0; i < LP; ++i) lg[i] = host_ld(io_dtype, logits, u * LP + i);
+                mdetr::pro_softmax(lg, LP, at);
+                for (int i = 0; i < LP; ++i) attn_weight[u * LP + i] = at[i];
+                for (int l = 0; l < L; ++l) {
+                    float rl[6];
+                    for (int r = 0; r < R; ++r) rl[r] = host_ld(io_dtype, ref, b * ref_sb + q * ref_sq + l * ref_sl + r);
+                    const float wh[2] = {static_cast<float>(spatial_shapes[2 * l + 1]), static_cast<float>(spatial_shapes[2 * l])};
+                    for (int p = 0; p < P; ++p)
+                        for (int c = 0; c < 2; ++c) {
+                            const int64_t i = (u * LP + l * P + p) * 2 + c;
+                            sampling_loc[i] = mdetr::pro_location(host_ld(io_dtype, offsets, i), rl, R, c, wh[c], P);
+                        }
+                }
+            }
+    return 0;
+}
+
+int mdetr_msda_prologue_backward(int io_dtype, const void *offsets, const void *ref, const int64_t *spatial_shapes,
+                                 const float *attn_weight, const float *grad_loc, const float *grad_attn,
+                                 void *grad_offsets, void *grad_logits, float *grad_ref,
+                                 int B, int Lq, int M, int L, int P, int R, int64_t ref_sb, int64_t ref_sq, int64_t ref_sl,
+                                 int device, void *stream)
+{
+    (void)device; (void)stream;
+    const int LP = L * P;
+    if (grad_ref) memset(grad_ref, 0, sizeof(float) * static_cast<size_t>(B) * Lq * L * R);
+    for (int b = 0; b < B; ++b)
+        for (int q = 0; q < Lq; ++q)
+            for (int m = 0; m < M; ++m) {
+                const int64_t u = (static_cast<int64_t>(b) * Lq + q) * M + m;
+                float gl[64];
+                mdetr::pro_softmax_backward(attn_weight + u * LP, grad_attn + u * LP, LP, gl);
+                for (int i = 0; i < LP; ++i) host_st(io_dtype, grad_logits, u * LP + i, gl[i]);
+                for (int l = 0; l < L; ++l) {
+                    float rl[6], gr[6] = {0, 0, 0, 0, 0, 0};
+                    for (int r = 0; r < R; ++r) rl[r] = host_ld(io_dtype, ref, b * ref_sb + q * ref_sq + l * ref_sl + r);
+                    const float wh[2] = {static_cast<float>(spatial_shapes[2 * l + 1]), static_cast<float>(spatial_shapes[2 * l])};
+                    for (int p = 0; p < P; ++p)
+                        for (int c = 0; c < 2; ++c) {
+                            const int64_t i = (u * LP + l * P + p) * 2 + c;
+                            const float off = R == 2 ? 0.f : host_ld(io_dtype, offsets, i);
+                            host_st(io_dtype, grad_offsets, i, mdetr::pro_location_backward(grad_loc[i], off, rl, R, c, wh[c], P, grad_ref ? gr : nullptr));
+                        }
+                    if (grad_ref)
+                        for (int r = 0; r < R; ++r) grad_ref[((static_cast<int64_t>(b) * Lq + q) * L + l) * R + r] += gr[r];
+                }
+            }
     return 0;
 }
 

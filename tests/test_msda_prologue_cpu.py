@@ -1,0 +1,95 @@
+"""The fused MSDA prologue (csrc/msda_prologue_math.h: softmax over L*P + sampling-location arithmetic) against
+the module's PyTorch formulation (ms_deform_attn.py:139-160) and its autograd, on the CPU through the host build:
+2- and 6-component reference points, reference points as an expanded (broadcast) view, fp32 and bf16 I/O."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import native_host
+
+
+def torch_prologue(offsets, logits, ref, shapes, P):
+    B, Lq, M, L = offsets.shape[:4]
+    weights = F.softmax(logits.float(), -1).view(B, Lq, M, L, P)
+    r = ref.float()[:, :, None, :, None, :]
+    off = offsets.float()
+    if ref.shape[-1] == 2:
+        wh = shapes.flip(-1).float()
+        loc = r + off / wh[None, None, None, :, None, :]
+    else:
+        extent = r[..., 2::2] + r[..., 3::2]
+        loc = r[..., :2] + off / P * extent * 0.5
+    return loc, weights
+
+
+@pytest.fixture()
+def backend():
+    from monodetr_amd import msda_prologue_ext
+    msda_prologue_ext._backend = native_host.lib()
+    yield msda_prologue_ext
+    msda_prologue_ext._backend = None
+
+
+@pytest.mark.parametrize("R,expanded,dtype,LP", [(2, False, torch.float32, (4, 4)), (6, True, torch.float32, (4, 4)),
+                                                 (6, False, torch.float32, (3, 2)), (2, False, torch.bfloat16, (4, 4)),
+                                                 (6, True, torch.bfloat16, (4, 4))])
+def test_prologue_matches_module_formulas_and_autograd(backend, R, expanded, dtype, LP):
+    L, P = LP
+    B, Lq, M = 2, 37, 8
+    g = torch.Generator().manual_seed(R + L)
+    shapes = torch.tensor([(48, 160), (24, 80), (12, 40), (6, 20)][:L], dtype=torch.int64)
+    offsets = (torch.randn(B, Lq, M, L, P, 2, generator=g) * 3).to(dtype).requires_grad_(True)
+    logits = torch.randn(B, Lq, M, L * P, generator=g).to(dtype).requires_grad_(True)
+    if expanded:
+        base = torch.rand(B, Lq, R, generator=g).to(dtype).requires_grad_(True)
+        ref = base[:, :, None].expand(-1, -1, L, -1)
+    else:
+        base = torch.rand(B, Lq, L, R, generator=g).to(dtype).requires_grad_(True)
+        ref = base
+    g_loc = torch.randn(B, Lq, M, L, P, 2, generator=g)
+    g_att = torch.randn(B, Lq, M, L, P, generator=g)
+
+    loc_r, att_r = torch_prologue(offsets, logits, ref, shapes, P)
+    ref_grads = torch.autograd.grad([loc_r, att_r], [offsets, logits, base], [g_loc, g_att])
+    loc, att = backend.msda_prologue(offsets, logits, ref, shapes)
+    got_grads = torch.autograd.grad([loc, att], [offsets, logits, base], [g_loc, g_att])
+
+    assert loc.dtype == att.dtype == torch.float32
+    assert (loc - loc_r).abs().max() < 1e-6 and (att - att_r).abs().max() < 1e-6       # both evaluate in fp32
+    tol = 1e-5 if dtype == torch.float32 else 2e-2                                       # bf16 gradients are rounded once
+    for a, b in zip(ref_grads, got_grads):
+        assert a.shape == b.shape and a.dtype == b.dtype
+        assert (a.float() - b.float()).abs().max() <= tol * max(1.0, a.float().abs().max().item())
+
+
+def test_module_with_the_fused_prologue_matches_default(backend, oracle):
+    """MSDeformAttn.forward with MDETR_MSDA_PROLOGUE on == off (fp32), outputs and all parameter gradients."""
+    from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func as F_
+    from monodetr_amd.monodetr.ops.modules import ms_deform_attn as mod
+    saved = F_.MSDA
+    F_.MSDA = oracle.OracleMSDA
+    try:
+        torch.manual_seed(0)
+        m = mod.MSDeformAttn(256, 4, 8, 4)
+        with torch.no_grad():
+            m.sampling_offsets.weight.normal_(0, 0.02); m.attention_weights.weight.normal_(0, 0.1)
+        shapes = torch.tensor([(12, 20), (6, 10), (3, 5), (2, 3)], dtype=torch.int64)
+        start = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+        S = int(shapes.prod(1).sum())
+        src = torch.randn(2, S, 256)
+        query = torch.randn(2, 9, 256)
+        refp = torch.rand(2, 9, 6)[:, :, None].expand(-1, -1, 4, -1) * 0.5 + 0.1
+        res = {}
+        for flag in (False, True):
+            mod._FUSED_PROLOGUE = flag
+            m.zero_grad(set_to_none=True)
+            out = m(query, refp, src, shapes, start)
+            out.square().sum().backward()
+            res[flag] = (out.detach(), {n: p.grad.clone() for n, p in m.named_parameters()})
+        mod._FUSED_PROLOGUE = False
+        assert (res[False][0] - res[True][0]).abs().max() < 1e-5
+        for n, gr in res[False][1].items():
+            assert (gr - res[True][1][n]).abs().max() <= 1e-4 * max(1.0, gr.abs().max().item()), n
+    finally:
+        F_.MSDA = saved
+        mod._FUSED_PROLOGUE = False

@@ -239,3 +239,34 @@ def test_token_linear_layer_with_the_token_gemm_matches_default():
             linear._TOKEN_GEMM = False
     for a, c in zip(res[False], res[True]):
         assert ((a - c).norm() / a.norm()).item() < 6e-3
+
+
+@pytest.mark.parametrize("R,Lq,dtype", [(2, 10200, torch.float32), (2, 10200, torch.bfloat16), (6, 550, torch.float32),
+                                        (6, 550, torch.bfloat16)])
+def test_msda_prologue_kernel_matches_module_formulas(R, Lq, dtype):
+    """csrc/msda_prologue.hip at the encoder (R = 2) and decoder (R = 6, broadcast reference points) shapes against
+    the module's PyTorch formulation evaluated in fp32, values and gradients."""
+    from test_msda_prologue_cpu import torch_prologue
+    from monodetr_amd.msda_prologue_ext import msda_prologue
+    B, M, L, P = 8, 8, 4, 4
+    g = torch.Generator().manual_seed(R)
+    shapes = torch.tensor([(48, 160), (24, 80), (12, 40), (6, 20)], dtype=torch.int64).cuda()
+    offsets = (torch.randn(B, Lq, M, L, P, 2, generator=g) * 3).to(dtype).cuda().requires_grad_(True)
+    logits = torch.randn(B, Lq, M, L * P, generator=g).to(dtype).cuda().requires_grad_(True)
+    if R == 6:
+        base = torch.rand(B, Lq, R, generator=g).to(dtype).cuda().requires_grad_(True)
+        ref = base[:, :, None].expand(-1, -1, L, -1)
+    else:
+        base = torch.rand(B, Lq, L, R, generator=g).to(dtype).cuda().requires_grad_(True)
+        ref = base
+    g_loc = torch.randn(B, Lq, M, L, P, 2, generator=g).cuda()
+    g_att = torch.randn(B, Lq, M, L, P, generator=g).cuda()
+    loc_r, att_r = torch_prologue(offsets, logits, ref, shapes, P)
+    ref_grads = torch.autograd.grad([loc_r, att_r], [offsets, logits, base], [g_loc, g_att])
+    loc, att = msda_prologue(offsets, logits, ref, shapes)
+    got_grads = torch.autograd.grad([loc, att], [offsets, logits, base], [g_loc, g_att])
+    assert (loc - loc_r).abs().max() < 1e-5 and (att - att_r).abs().max() < 1e-6
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    for a, b in zip(ref_grads, got_grads):
+        assert a.shape == b.shape and a.dtype == b.dtype
+        assert (a.float() - b.float()).abs().max() <= tol * max(1.0, a.float().abs().max().item())
