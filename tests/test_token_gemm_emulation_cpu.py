@@ -77,7 +77,8 @@ def emulate(x, ldx, T, w, bias, N, K, NB, relu, grid_x):
 
 
 @pytest.mark.parametrize("T,K,N,NB,relu,grid_x", [(70, 128, 64, 8, False, 1), (45, 256, 40, 4, True, 2),
-                                                  (33, 128, 264, 8, False, 1), (96, 256, 256, 8, False, 1)])
+                                                  (33, 128, 264, 8, False, 1), (96, 256, 256, 8, False, 1),
+                                                  (40, 512, 136, 4, True, 1)])
 def test_token_gemm_index_arithmetic(T, K, N, NB, relu, grid_x):
     rng = np.random.default_rng(T + N)
     ldx = K + 16
