@@ -27,7 +27,7 @@ from torch import nn
 
 from ..losses.focal_loss import sigmoid_focal_loss
 from ..utils import box_ops
-from ..utils.misc import (NestedTensor, accuracy, get_world_size, inverse_sigmoid,
+from ..utils.misc import (NestedTensor, get_world_size, inverse_sigmoid,
                           is_dist_avail_and_initialized, mark_no_padding)
 from .backbone import build_backbone
 from .depth_predictor import DepthPredictor
