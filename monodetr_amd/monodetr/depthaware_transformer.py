@@ -82,7 +82,10 @@ class VisualEncoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, src):
-        h = self.dropout2(self.activation(token_linear(src, self.linear1.weight, self.linear1.bias)))
+        if self.activation is F.relu:                       # ReLU can ride in the GEMM epilogue (linear.token_linear)
+            h = self.dropout2(token_linear(src, self.linear1.weight, self.linear1.bias, relu=True))
+        else:
+            h = self.dropout2(self.activation(token_linear(src, self.linear1.weight, self.linear1.bias)))
         ff = token_linear(h, self.linear2.weight, self.linear2.bias)
         return self.norm2(src + self.dropout3(ff))
 

@@ -35,20 +35,33 @@ def _split_count(T):
 
 class _TokenLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
+    def forward(ctx, x, weight, bias, fused_relu=False):
+        """fused_relu is only ever True on the token-GEMM path (ReLU in the kernel's epilogue)."""
         ctx.has_bias = bias is not None
+        ctx.fused_relu = False
         if _TOKEN_GEMM:
             from .. import token_gemm_ext
             x2 = x.reshape(-1, x.shape[-1])
             if token_gemm_ext.supported(x2, weight):
-                return token_gemm_ext.token_gemm(x2, weight, bias).view(x.shape[:-1] + (weight.shape[0],))
+                y = token_gemm_ext.token_gemm(x2, weight, bias, relu=fused_relu).view(x.shape[:-1] + (weight.shape[0],))
+                if fused_relu:
+                    ctx.fused_relu = True
+                    ctx.save_for_backward(x, weight, y)
+                else:
+                    ctx.save_for_backward(x, weight)
+                return y
+        assert not fused_relu
+        ctx.save_for_backward(x, weight)
         return F.linear(x, weight, bias)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        if ctx.fused_relu:
+            x, weight, y = ctx.saved_tensors
+            dy = dy * (y > 0)                                        # ReLU of the epilogue
+        else:
+            x, weight = ctx.saved_tensors
         dx = dw = db = None
         x2 = x.reshape(-1, x.shape[-1])
         dy2 = dy.reshape(-1, dy.shape[-1])
@@ -79,15 +92,27 @@ class _TokenLinear(torch.autograd.Function):
                 db = colsum_ext.column_sum(dy2).to(weight.dtype)        # csrc/colsum.hip: one HBM pass, fp32 accumulation
             else:
                 db = (dy2.view(C, T // C, -1).sum(1).sum(0) if C else dy2.sum(0)).to(weight.dtype)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def token_linear(x, weight, bias=None):
-    """F.linear with the split-K weight gradient for big token counts on the GPU; plain F.linear otherwise."""
+def _kernel_relu(x, weight):
+    if not _TOKEN_GEMM:
+        return False
+    from .. import token_gemm_ext
+    return token_gemm_ext.supported(x.reshape(-1, x.shape[-1]), weight)
+
+
+def token_linear(x, weight, bias=None, relu=False):
+    """F.linear (followed by ReLU if `relu`) with the split-K weight gradient for big token counts on the GPU;
+    plain F.linear otherwise.  With the token-GEMM kernel enabled the ReLU runs in its epilogue."""
     if x.is_cuda and x.dtype == weight.dtype and x.numel() // x.shape[-1] >= _MIN_TOKENS and torch.is_grad_enabled() \
             and not torch.is_autocast_enabled():
-        return _TokenLinear.apply(x, weight, bias)
-    return F.linear(x, weight, bias)
+        if relu and _kernel_relu(x, weight):
+            return _TokenLinear.apply(x, weight, bias, True)
+        y = _TokenLinear.apply(x, weight, bias, False)
+    else:
+        y = F.linear(x, weight, bias)
+    return F.relu(y) if relu else y
 
 
 def pointwise_eligible(x, kernel_size, stride, padding, groups):

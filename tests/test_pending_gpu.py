@@ -229,16 +229,17 @@ def test_token_linear_layer_with_the_token_gemm_matches_default():
     w = (torch.randn(256, 256, device="cuda") / 16).to(torch.bfloat16).requires_grad_(True)
     b = torch.randn(256, device="cuda").to(torch.bfloat16).requires_grad_(True)
     g = torch.randn(8, 10200, 256, device="cuda").to(torch.bfloat16)
-    res = {}
-    for flag in (False, True):
-        linear._TOKEN_GEMM = flag
-        try:
-            y = linear.token_linear(x, w, b)
-            res[flag] = (y.detach().float(),) + tuple(t.float() for t in torch.autograd.grad(y, (x, w, b), g))
-        finally:
-            linear._TOKEN_GEMM = False
-    for a, c in zip(res[False], res[True]):
-        assert ((a - c).norm() / a.norm()).item() < 6e-3
+    for relu in (False, True):                                      # relu=True: ReLU in the kernel's epilogue
+        res = {}
+        for flag in (False, True):
+            linear._TOKEN_GEMM = flag
+            try:
+                y = linear.token_linear(x, w, b, relu=relu)
+                res[flag] = (y.detach().float(),) + tuple(t.float() for t in torch.autograd.grad(y, (x, w, b), g))
+            finally:
+                linear._TOKEN_GEMM = False
+        for a, c in zip(res[False], res[True]):
+            assert ((a - c).norm() / a.norm()).item() < 6e-3
 
 
 @pytest.mark.parametrize("R,Lq,dtype", [(2, 10200, torch.float32), (2, 10200, torch.bfloat16), (6, 550, torch.float32),
