@@ -173,11 +173,26 @@ __device__ __forceinline__ void raw_floats(const Raw8<__bf16> &r, float (&o)[8])
     for (int i = 0; i < 8; ++i) o[i] = static_cast<float>(r.v[i]);
 }
 
+// Staging map: which (row, 8-element chunk) of the 64 x 32 tile thread t loads and stores.
+//   default : row = t / 4, chunk = t % 4 (four consecutive threads cover a row's 64 bytes);
+//   remap   : row = (t & 15) + 16 (t >> 6), chunk = (t >> 4) & 3 -- the same 64 chunks per wave-level load (the
+//             global side is unchanged), but inside a 32-lane store group only two chunk values occur, 16 banks
+//             apart, so both the transposing 2-byte stores and the 16-byte row-major stores become conflict-free
+//             in the LDS bank model (tests/test_lds_bank_model_cpu.py; they are 2-way today, the remaining 23 % of
+//             conflict cycles).  Compile with -DMDETR_ATTN_STAGE_REMAP=1 to try it: off until it has run on a GPU.
+#ifndef MDETR_ATTN_STAGE_REMAP
+#define MDETR_ATTN_STAGE_REMAP 0
+#endif
+
 // this thread's 8 elements of tile rows [r0, r0+64): row = tid/4, columns (tid%4)*8 ..
 template <typename T>
 __device__ __forceinline__ Raw8<T> tile_load(const T *base, int row_stride, int r0, int L)
 {
+#if MDETR_ATTN_STAGE_REMAP
+    const int row = (threadIdx.x & 15) + 16 * (threadIdx.x >> 6), dc = ((threadIdx.x >> 4) & 3) * 8;
+#else
     const int row = threadIdx.x >> 2, dc = (threadIdx.x & 3) * 8;
+#endif
     Raw8<T> r;
     if (r0 + row < L) raw_load(r, base + static_cast<int64_t>(r0 + row) * row_stride + dc);
     else raw_zero(r);
@@ -187,7 +202,11 @@ __device__ __forceinline__ Raw8<T> tile_load(const T *base, int row_stride, int 
 template <typename T, bool RM, bool TR, bool SP>
 __device__ __forceinline__ void tile_store(const Raw8<T> &raw, __bf16 *rm, __bf16 *tr)
 {
+#if MDETR_ATTN_STAGE_REMAP
+    const int t = threadIdx.x, row = (t & 15) + 16 * (t >> 6), dc = ((t >> 4) & 3) * 8;
+#else
     const int t = threadIdx.x, row = t >> 2, dc = (t & 3) * 8;
+#endif
     float x[8];
     raw_floats(raw, x);
     bf16x8 vh, vl;
