@@ -194,6 +194,24 @@ int mdetr_pair_losses_backward(const float *logits, const float *boxes, const fl
                                int device, void *stream);
 
 /*
+ * Mixed-precision variant of mdetr_msda_forward / mdetr_msda_backward_ex for a bf16 model body: `value`, `out` and
+ * `grad_out` are bf16 (64-byte rows), sampling locations, attention weights and all three gradient outputs are
+ * fp32, accumulation is fp32 throughout.  The reference's operator is fp32/fp64 only (ms_deform_attn_cuda.cu:64) and
+ * a bf16 model has to widen `value` (42 -> 84 MB at the encoder shape) and narrow `out` around every call; this
+ * variant reads and writes the model's tensors directly.  D = 32, L = P = 4 only.  Workspace and host geometry as
+ * for mdetr_msda_backward_ex (mdetr_msda_backward_workspace_bytes with MDETR_F32).
+ */
+int mdetr_msda_forward_bf16(const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                            const float *loc, const float *attn, void *out,
+                            int B, int S, int M, int D, int L, int Lq, int P, int device, void *stream);
+int mdetr_msda_backward_bf16(const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                             const float *loc, const float *attn, const void *grad_out,
+                             float *grad_value, float *grad_loc, float *grad_attn,
+                             int B, int S, int M, int D, int L, int Lq, int P,
+                             const int64_t *spatial_shapes_host, const int64_t *level_start_host,
+                             void *workspace, int64_t workspace_bytes, int device, void *stream);
+
+/*
  * The arithmetic MSDeformAttn.forward performs between its projections and the sampling operator
  * (lib/models/monodetr/ops/modules/ms_deform_attn.py:139-160), one launch each way, evaluated in fp32:
  *     attn_weight  = softmax over the L*P samples of a head (logits [B, Lq, M, L*P])

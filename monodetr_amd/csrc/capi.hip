@@ -445,6 +445,50 @@ int mdetr_column_sum(int dtype, const void *x, float *out, void *workspace, int6
     return MDETR_OK;
 }
 
+int mdetr_msda_forward_bf16(const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                            const float *loc, const float *attn, void *out,
+                            int B, int S, int M, int D, int L, int Lq, int P, int device, void *stream)
+{
+    if (int rc = check_common("mdetr_msda_forward_bf16", MDETR_F32, B, S, M, D, L, Lq, P)) return rc;
+    if (D != 32 || L != 4 || P != 4) return fail(MDETR_E_ARG, "mdetr_msda_forward_bf16: D = 32, L = P = 4 only (D=%d L=%d P=%d)", D, L, P);
+    if (B == 0 || Lq == 0) return MDETR_OK;
+    if (!value || !spatial_shapes || !level_start || !loc || !attn || !out)
+        return fail(MDETR_E_ARG, "mdetr_msda_forward_bf16: null pointer");
+    if (!aligned16(value) || !aligned16(loc) || !aligned16(attn) || !aligned16(out))
+        return fail(MDETR_E_ALIGN, "mdetr_msda_forward_bf16: value/loc/attn/out must be 16-byte aligned");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_forward_bf16: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::msda_forward_bf16_launch(value, spatial_shapes, level_start, loc, attn, out,
+                                                         B, S, M, D, L, Lq, P, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_forward_bf16: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_msda_backward_bf16(const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                             const float *loc, const float *attn, const void *grad_out,
+                             float *grad_value, float *grad_loc, float *grad_attn,
+                             int B, int S, int M, int D, int L, int Lq, int P,
+                             const int64_t *spatial_shapes_host, const int64_t *level_start_host,
+                             void *workspace, int64_t workspace_bytes, int device, void *stream)
+{
+    if (int rc = check_common("mdetr_msda_backward_bf16", MDETR_F32, B, S, M, D, L, Lq, P)) return rc;
+    if (D != 32 || L != 4 || P != 4) return fail(MDETR_E_ARG, "mdetr_msda_backward_bf16: D = 32, L = P = 4 only (D=%d L=%d P=%d)", D, L, P);
+    if (!grad_value || !grad_loc || !grad_attn) return fail(MDETR_E_ARG, "mdetr_msda_backward_bf16: null output pointer");
+    if (B > 0 && Lq > 0 && (!value || !spatial_shapes || !level_start || !loc || !attn || !grad_out))
+        return fail(MDETR_E_ARG, "mdetr_msda_backward_bf16: null pointer");
+    if (!aligned16(value) || !aligned16(loc) || !aligned16(attn) || !aligned16(grad_out) || !aligned16(grad_value) ||
+        !aligned16(grad_loc) || !aligned16(grad_attn))
+        return fail(MDETR_E_ALIGN, "mdetr_msda_backward_bf16: all tensors must be 16-byte aligned");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_backward_bf16: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::msda_backward_bf16_launch(value, spatial_shapes, level_start, loc, attn, grad_out, grad_value,
+                                                          grad_loc, grad_attn, B, S, M, D, L, Lq, P, spatial_shapes_host,
+                                                          level_start_host, workspace, workspace_bytes,
+                                                          static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_backward_bf16: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
 static int prologue_args(const char *who, int io_dtype, int B, int Lq, int M, int L, int P, int R)
 {
     if (io_dtype != MDETR_F32 && io_dtype != MDETR_BF16) return fail(MDETR_E_ARG, "%s: dtype must be f32 or bf16", who);

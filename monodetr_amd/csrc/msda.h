@@ -1,9 +1,35 @@
 // monodetr_amd/csrc/msda.h -- internal launcher declarations (see msda.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
 #include <stdint.h>
 
 namespace mdetr {
+
+// Element types of `value` / `out` / `grad_out` on the fast path: float, or bf16 for a bf16 model body
+// (rows of 32 channels = 64 bytes, a lane's 4 channels = one 8-byte access; arithmetic stays fp32).
+template <typename E> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int kBytes = 4;
+    static __device__ __forceinline__ float load1(const float *p) { return *p; }
+    static __device__ __forceinline__ float4 load4(const char *p) { return *reinterpret_cast<const float4 *>(p); }
+    static __device__ __forceinline__ void store4(char *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
+};
+template <> struct Elem<__hip_bfloat16> {
+    static constexpr int kBytes = 2;
+    static __device__ __forceinline__ float load1(const __hip_bfloat16 *p) { return __bfloat162float(*p); }
+    static __device__ __forceinline__ float4 load4(const char *p)
+    {
+        const uint2 u = *reinterpret_cast<const uint2 *>(p);                    // bf16 -> fp32 is a 16-bit shift
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
+                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+    }
+    static __device__ __forceinline__ void store4(char *p, const float4 &v)
+    {
+        __hip_bfloat16 h[4] = {__float2bfloat16(v.x), __float2bfloat16(v.y), __float2bfloat16(v.z), __float2bfloat16(v.w)};
+        *reinterpret_cast<uint2 *>(p) = *reinterpret_cast<const uint2 *>(h);
+    }
+};
 
 // dtype: 0 = f32, 1 = f64 (MDETR_F32 / MDETR_F64 of include/monodetr_amd.h)
 bool msda_fast_path(int dtype, int D, int L, int P);
@@ -26,12 +52,26 @@ hipError_t msda_backward_launch_ex(int dtype, const void *value, const int64_t *
                                    const int64_t *shapes_host, const int64_t *lstart_host,
                                    void *workspace, int64_t workspace_bytes, hipStream_t st);
 
+// Mixed-precision operator for a bf16 model body: `value`, `out` and `grad_out` in bf16, sampling locations,
+// attention weights and every gradient output in fp32 (fp32 accumulation throughout).  D = 32, L = P = 4 only;
+// other shapes return hipErrorNotSupported (the caller widens to fp32 and takes the ordinary path).
+hipError_t msda_forward_bf16_launch(const void *value, const int64_t *shapes, const int64_t *lstart,
+                                    const float *loc, const float *attn, void *out,
+                                    int B, int S, int M, int D, int L, int Lq, int P, hipStream_t st);
+hipError_t msda_backward_bf16_launch(const void *value, const int64_t *shapes, const int64_t *lstart,
+                                     const float *loc, const float *attn, const void *grad_out,
+                                     float *grad_value, float *grad_loc, float *grad_attn,
+                                     int B, int S, int M, int D, int L, int Lq, int P,
+                                     const int64_t *shapes_host, const int64_t *lstart_host,
+                                     void *workspace, int64_t workspace_bytes, hipStream_t st);
+
 int64_t msda_tiled_workspace_bytes(const int64_t *shapes_h, const int64_t *start_h, int B, int S, int M, int D, int L, int Lq, int P);
 
 hipError_t msda_tiled_grad_value_launch(const int64_t *shapes_h, const int64_t *start_h,
-                                        const float *loc, const float *attn, const float *grad_out, float *grad_value,
+                                        const float *loc, const float *attn, const void *grad_out, float *grad_value,
                                         void *workspace, int64_t workspace_bytes,
-                                        int B, int S, int M, int D, int L, int Lq, int P, bool absmax_ready, hipStream_t st);
+                                        int B, int S, int M, int D, int L, int Lq, int P, bool absmax_ready, hipStream_t st,
+                                        int grad_out_dtype = 0 /* 0 = f32, 2 = bf16 (needs absmax_ready) */);
 
 hipError_t msda_indices_launch(int dtype, const int64_t *shapes, const void *loc, int32_t *idx,
                                int B, int M, int L, int Lq, int P, hipStream_t st);

@@ -258,13 +258,14 @@ void msda_fwd_d32(const float *__restrict__ value, const int64_t *__restrict__ s
 struct alignas(16) SampleRec { int off[4]; float w[4]; };
 constexpr int kRecStride = 17;     // records per pair (16 + 1): the 8 pairs a wave reads in one instruction start 8 banks apart
 
-template <int TL, int TP>
+template <int TL, int TP, typename VT = float, typename OT = float>
 __global__ __launch_bounds__(kWaves * 64)
-void msda_fwd_rec(const float *__restrict__ value, const int64_t *__restrict__ shapes,
+void msda_fwd_rec(const VT *__restrict__ value, const int64_t *__restrict__ shapes,
                   const int64_t *__restrict__ lstart, const float *__restrict__ loc,
-                  const float *__restrict__ attn, float *__restrict__ out,
+                  const float *__restrict__ attn, OT *__restrict__ out,
                   int B, int S, int M, int npairs, int iters)
 {
+    constexpr int kRowBytes = 32 * Elem<VT>::kBytes;       // one head's 32 channels of a pixel
     constexpr int LP = TL * TP;
     static_assert(LP == 16, "one record slot per lane and half-round");
     __shared__ SampleRec s_rec[kWaves][kPairsPerWave * kRecStride];
@@ -275,13 +276,13 @@ void msda_fwd_rec(const float *__restrict__ value, const int64_t *__restrict__ s
     SampleRec *wrec = s_rec[wave];
     float *watt = s_att[wave];
     const int j = lane >> 3, k = lane & 7;
-    const char *vimg = reinterpret_cast<const char *>(value + static_cast<int64_t>(b) * S * M * 32) + k * 16;
+    const char *vimg = reinterpret_cast<const char *>(value + static_cast<int64_t>(b) * S * M * 32) + k * (4 * Elem<VT>::kBytes);
 
     // producer role: sample slot s = lane % 16 of pairs lane / 16 and 4 + lane / 16
     const int ps = lane & 15, pl = ps / TP;
     const int H = static_cast<int>(shapes[2 * pl]), W = static_cast<int>(shapes[2 * pl + 1]);
     const int start = static_cast<int>(lstart[pl]);
-    const int dx = M * 128, dy = W * dx;                    // bytes to the next pixel / next row
+    const int dx = M * kRowBytes, dy = W * dx;              // bytes to the next pixel / next row
 
     for (int it = 0; it < iters; ++it) {
         const int p0 = (chunk * iters + it) * (kWaves * kPairsPerWave) + wave * kPairsPerWave;
@@ -303,7 +304,7 @@ void msda_fwd_rec(const float *__restrict__ value, const int64_t *__restrict__ s
             const int pj = 4 * hf + (lane >> 4);
             const Foot<float> f = footprint(pix_coord(xy[hf].y, H), pix_coord(xy[hf].x, W), H, W);
             const int m = (p0 + pj) % M;
-            const int o1 = ((start + f.h_low * W + f.w_low) * M + m) * 128;
+            const int o1 = ((start + f.h_low * W + f.w_low) * M + m) * kRowBytes;
             const int o2 = o1 + dx, o3 = o1 + dy, o4 = o3 + dx;
             const bool any = f.ok1 || f.ok2 || f.ok3 || f.ok4;
             const int fb = f.ok1 ? o1 : (f.ok2 ? o2 : (f.ok3 ? o3 : o4));
@@ -338,10 +339,10 @@ void msda_fwd_rec(const float *__restrict__ value, const int64_t *__restrict__ s
                     o[p] = *reinterpret_cast<const int4 *>(pr[l * TP + p].off);
                     w[p] = *reinterpret_cast<const float4 *>(pr[l * TP + p].w);
                     a[p] = pa[l * TP + p];
-                    v[p][0] = *reinterpret_cast<const float4 *>(vimg + (o[p].x & ~1));
-                    v[p][1] = *reinterpret_cast<const float4 *>(vimg + o[p].y);
-                    v[p][2] = *reinterpret_cast<const float4 *>(vimg + o[p].z);
-                    v[p][3] = *reinterpret_cast<const float4 *>(vimg + o[p].w);
+                    v[p][0] = Elem<VT>::load4(vimg + (o[p].x & ~1));
+                    v[p][1] = Elem<VT>::load4(vimg + o[p].y);
+                    v[p][2] = Elem<VT>::load4(vimg + o[p].z);
+                    v[p][3] = Elem<VT>::load4(vimg + o[p].w);
                 }
 #pragma unroll
                 for (int p = 0; p < TP; ++p) {
@@ -356,7 +357,7 @@ void msda_fwd_rec(const float *__restrict__ value, const int64_t *__restrict__ s
                     acc.w += (skip ? 0.f : cw) * a[p];
                 }
             }
-            *reinterpret_cast<float4 *>(out + (g0 + j) * 32 + k * 4) = acc;
+            Elem<OT>::store4(reinterpret_cast<char *>(out + (g0 + j) * 32 + k * 4), acc);
         }
     }
 }
@@ -375,9 +376,9 @@ __device__ __forceinline__ void atomic_add4(float *p, float s, const float4 &t)
 // Scatter phase of the backward pass with 32 lanes x 1 channel per pair (2 pairs per wave-round):
 // each atomic instruction covers two complete 128-B rows of grad_value.  Reads only the slab
 // (loc / attn) and grad_out -- no value loads, so no vmcnt wait sits between the atomics.
-template <int TL, int TP>
+template <int TL, int TP, typename GT = float>
 __device__ __forceinline__ void scatter_rows32(const int64_t *__restrict__ shapes, const int64_t *__restrict__ lstart,
-                                               const float *__restrict__ grad_out, float *__restrict__ grad_value,
+                                               const GT *__restrict__ grad_out, float *__restrict__ grad_value,
                                                const float *s_loc, const float *s_att, int64_t g0, int p0, int nv,
                                                int64_t img, int M, int L, int P, int lane)
 {
@@ -388,7 +389,7 @@ __device__ __forceinline__ void scatter_rows32(const int64_t *__restrict__ shape
         const int jj = 2 * r + half;
         if (jj < nv) {
             const int m = (p0 + jj) % M;
-            const float go = grad_out[(g0 + jj) * 32 + c];
+            const float go = Elem<GT>::load1(grad_out + (g0 + jj) * 32 + c);
             float *gvb = grad_value + img + m * 32 + c;
             const float *my_loc = s_loc + jj * (2 * LP + kPad);
             const float *my_att = s_att + jj * (LP + kPad);
@@ -456,11 +457,11 @@ __device__ __forceinline__ void scatter_sample(const Foot<float> &f, float a, co
 // VAR 1: per round, a scatter phase with full-row atomics (scatter_rows32) followed by the
 //        gather/reduce phase -- the vmcnt drain the compiler puts between atomics and the next
 //        use of a loaded value then happens once per round instead of once per sample.
-template <int TL, int TP, int VAR>
+template <int TL, int TP, int VAR, typename VT = float, typename GT = float>
 __global__ __launch_bounds__(kWaves * 64, (VAR == 2 ? 4 : 1))      // gather-only variant: keep <= 128 VGPRs (4 waves / SIMD)
-void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ shapes,
+void msda_bwd_d32(const VT *__restrict__ value, const int64_t *__restrict__ shapes,
                   const int64_t *__restrict__ lstart, const float *__restrict__ loc,
-                  const float *__restrict__ attn, const float *__restrict__ grad_out,
+                  const float *__restrict__ attn, const GT *__restrict__ grad_out,
                   float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
                   int B, int S, int M, int L_, int P_, int npairs, int iters, unsigned *__restrict__ absmax2)
 {
@@ -491,13 +492,13 @@ void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ s
             }
         }
         if constexpr (VAR == 1)
-            scatter_rows32<TL, TP>(shapes, lstart, grad_out, grad_value, s_loc, s_att, g0, p0, nv, img, M, L, P, lane);
+            scatter_rows32<TL, TP, GT>(shapes, lstart, grad_out, grad_value, s_loc, s_att, g0, p0, nv, img, M, L, P, lane);
         if (j < nv) {
             const int m = (p0 + j) % M;
             const int64_t voff = img + m * 32 + k * 4;
             float *my_loc = s_loc + j * (2 * LP + kPad);
             float *my_att = s_att + j * (LP + kPad);
-            const float4 go = *reinterpret_cast<const float4 *>(grad_out + (g0 + j) * 32 + k * 4);
+            const float4 go = Elem<GT>::load4(reinterpret_cast<const char *>(grad_out + (g0 + j) * 32 + k * 4));
             if constexpr (VAR == 2) {
                 amax_g = fmaxf(fmaxf(amax_g, fmaxf(fabsf(go.x), fabsf(go.y))), fmaxf(fabsf(go.z), fabsf(go.w)));
                 poison += (go.x + go.y + go.z + go.w) * 0.f;
@@ -507,7 +508,7 @@ void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ s
                 for (int l = 0; l < L; ++l) {
                     const LevelGeom g = level_geom(shapes, lstart, l);
                     const int64_t loff = voff + static_cast<int64_t>(g.start) * row;
-                    const float *vl = value + loff;
+                    const VT *vl = value + loff;
                     float *gvl = grad_value + loff;
                     Foot<float> f[TP];
                     float a[TP];
@@ -524,7 +525,7 @@ void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ s
                         o[p][0] = (y0 * g.W + x0) * row; o[p][1] = (y0 * g.W + x1) * row;
                         o[p][2] = (y1 * g.W + x0) * row; o[p][3] = (y1 * g.W + x1) * row;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) v[p][c] = *reinterpret_cast<const float4 *>(vl + o[p][c]);
+                        for (int c = 0; c < 4; ++c) v[p][c] = Elem<VT>::load4(reinterpret_cast<const char *>(vl + o[p][c]));
                     }
 #pragma unroll
                     for (int p = 0; p < TP; ++p)
@@ -535,7 +536,7 @@ void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ s
                 for (int l = 0; l < L; ++l) {
                     const LevelGeom g = level_geom(shapes, lstart, l);
                     const int64_t loff = voff + static_cast<int64_t>(g.start) * row;
-                    const float *vl = value + loff;
+                    const VT *vl = value + loff;
                     float *gvl = grad_value + loff;
                     for (int p = 0; p < P; ++p) {
                         const int s = l * P + p;
@@ -545,10 +546,10 @@ void msda_bwd_d32(const float *__restrict__ value, const int64_t *__restrict__ s
                         const int y0 = clampi(f.h_low, 0, g.H - 1), y1 = clampi(f.h_low + 1, 0, g.H - 1);
                         const int x0 = clampi(f.w_low, 0, g.W - 1), x1 = clampi(f.w_low + 1, 0, g.W - 1);
                         const int o[4] = {(y0 * g.W + x0) * row, (y0 * g.W + x1) * row, (y1 * g.W + x0) * row, (y1 * g.W + x1) * row};
-                        const float4 v1 = *reinterpret_cast<const float4 *>(vl + o[0]);
-                        const float4 v2 = *reinterpret_cast<const float4 *>(vl + o[1]);
-                        const float4 v3 = *reinterpret_cast<const float4 *>(vl + o[2]);
-                        const float4 v4 = *reinterpret_cast<const float4 *>(vl + o[3]);
+                        const float4 v1 = Elem<VT>::load4(reinterpret_cast<const char *>(vl + o[0]));
+                        const float4 v2 = Elem<VT>::load4(reinterpret_cast<const char *>(vl + o[1]));
+                        const float4 v3 = Elem<VT>::load4(reinterpret_cast<const char *>(vl + o[2]));
+                        const float4 v4 = Elem<VT>::load4(reinterpret_cast<const char *>(vl + o[3]));
                         scatter_sample<VAR == 0>(f, a, go, v1, v2, v3, v4, gvl, o, g, my_loc, my_att, s, k);
                     }
                 }
@@ -838,6 +839,60 @@ hipError_t msda_backward_launch_ex(int dtype, const void *value, const int64_t *
                            static_cast<const double *>(attn), static_cast<const double *>(grad_out),
                            static_cast<double *>(grad_value), static_cast<double *>(grad_loc),
                            static_cast<double *>(grad_attn), S, M, D, L, Lq, P, n);
+    }
+    return hipGetLastError();
+}
+
+// ---- mixed-precision operator (bf16 value / out / grad_out, fp32 everything else): D = 32, L = P = 4 ------------
+hipError_t msda_forward_bf16_launch(const void *value, const int64_t *shapes, const int64_t *lstart,
+                                    const float *loc, const float *attn, void *out,
+                                    int B, int S, int M, int D, int L, int Lq, int P, hipStream_t st)
+{
+    if (D != 32 || L != 4 || P != 4) return hipErrorNotSupported;
+    if (static_cast<int64_t>(B) * Lq * M == 0) return hipSuccess;
+    struct Scope { hipStream_t s; Scope(int Lq_, hipStream_t s_) : s(s_) { profile_begin(0, Lq_, s_); } ~Scope() { profile_end(s); } } scope(Lq, st);
+    const int npairs = Lq * M, iters = rounds_per_block(B, npairs);
+    const int chunks = (npairs + 32 * iters - 1) / (32 * iters);
+    hipLaunchKernelGGL((msda_fwd_rec<4, 4, __hip_bfloat16, __hip_bfloat16>), dim3(static_cast<unsigned>(B) * chunks), dim3(kWaves * 64), 0, st,
+                       static_cast<const __hip_bfloat16 *>(value), shapes, lstart, loc, attn,
+                       static_cast<__hip_bfloat16 *>(out), B, S, M, npairs, iters);
+    return hipGetLastError();
+}
+
+hipError_t msda_backward_bf16_launch(const void *value, const int64_t *shapes, const int64_t *lstart,
+                                     const float *loc, const float *attn, const void *grad_out,
+                                     float *grad_value, float *grad_loc, float *grad_attn,
+                                     int B, int S, int M, int D, int L, int Lq, int P,
+                                     const int64_t *shapes_host, const int64_t *lstart_host,
+                                     void *workspace, int64_t workspace_bytes, hipStream_t st)
+{
+    if (D != 32 || L != 4 || P != 4) return hipErrorNotSupported;
+    const int64_t nv = static_cast<int64_t>(B) * S * M * D;
+    hipError_t err;
+    if (nv && (err = zero_fill_launch(grad_value, nv * 4, st)) != hipSuccess) return err;
+    if (static_cast<int64_t>(B) * Lq * M == 0) return hipSuccess;
+    const bool try_tiled = shapes_host && lstart_host && workspace &&
+                           msda_tiled_workspace_bytes(shapes_host, lstart_host, B, S, M, D, L, Lq, P) > 0 &&
+                           msda_tiled_workspace_bytes(shapes_host, lstart_host, B, S, M, D, L, Lq, P) <= workspace_bytes;
+    unsigned *absmax2 = try_tiled ? static_cast<unsigned *>(workspace) : nullptr;
+    if (try_tiled && (err = zero_fill_launch(absmax2, 8, st)) != hipSuccess) return err;
+    const int npairs = Lq * M, iters = rounds_per_block(B, npairs);
+    const int chunks = (npairs + 32 * iters - 1) / (32 * iters);
+    const dim3 grid(static_cast<unsigned>(B) * chunks), block(kWaves * 64);
+    const size_t lds = sizeof(float) * kWaves * slab_floats(L * P);
+    auto a = [&](auto kern) {
+        hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<const __hip_bfloat16 *>(value), shapes, lstart, loc, attn,
+                           static_cast<const __hip_bfloat16 *>(grad_out), grad_value, grad_loc, grad_attn,
+                           B, S, M, L, P, npairs, iters, absmax2);
+    };
+    profile_begin(1, Lq, st);
+    if (try_tiled) a(msda_bwd_d32<4, 4, 2, __hip_bfloat16, __hip_bfloat16>);
+    else a(msda_bwd_d32<4, 4, 1, __hip_bfloat16, __hip_bfloat16>);
+    profile_end(st);
+    if (try_tiled) {
+        err = msda_tiled_grad_value_launch(shapes_host, lstart_host, loc, attn, grad_out, grad_value, workspace, workspace_bytes,
+                                           B, S, M, D, L, Lq, P, /*absmax_ready=*/true, st, /*grad_out_dtype=*/2);
+        if (err != hipSuccess) return err;
     }
     return hipGetLastError();
 }

@@ -189,9 +189,10 @@ __device__ __forceinline__ void accumulate_sample(const unsigned *rr, float g, u
     }
 }
 
+template <typename GT>
 __global__ __launch_bounds__(kThreads)
 void msda_scatter_tiles(const TilePlan pl, const float *__restrict__ loc, const float *__restrict__ attn,
-                        const float *__restrict__ grad_out, float *__restrict__ grad_value,
+                        const GT *__restrict__ grad_out, float *__restrict__ grad_value,
                         const unsigned *__restrict__ absmax2, float *__restrict__ scratch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -272,7 +273,7 @@ void msda_scatter_tiles(const TilePlan pl, const float *__restrict__ loc, const 
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int q = static_cast<int>(hrec[(t * 4) * kRecDwords]);
-                g[t] = grad_out[(pair_base + static_cast<int64_t>(q) * pl.M) * kCH + c];   // q = 0 for padding records
+                g[t] = Elem<GT>::load1(grad_out + (pair_base + static_cast<int64_t>(q) * pl.M) * kCH + c);   // q = 0 for padding records
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -286,7 +287,7 @@ void msda_scatter_tiles(const TilePlan pl, const float *__restrict__ loc, const 
             for (int j = 0; j < 32; ++j) {
                 if (half * 32 + j < nloc) {
                     const int q = static_cast<int>(hrec[j * kRecDwords]);
-                    const float gq = grad_out[(pair_base + static_cast<int64_t>(q) * pl.M) * kCH + c];
+                    const float gq = Elem<GT>::load1(grad_out + (pair_base + static_cast<int64_t>(q) * pl.M) * kCH + c);
                     accumulate_sample(hrec + j * kRecDwords, gq, win, gv_level, pl.M * kCH, c, scale);
                 }
             }
@@ -411,10 +412,12 @@ int64_t msda_tiled_workspace_bytes(const int64_t *shapes_h, const int64_t *start
 // grad_value must already be zero-filled on `st`.  Returns hipErrorNotSupported when the geometry
 // does not qualify (caller falls back to the atomic path).
 hipError_t msda_tiled_grad_value_launch(const int64_t *shapes_h, const int64_t *start_h,
-                                        const float *loc, const float *attn, const float *grad_out, float *grad_value,
+                                        const float *loc, const float *attn, const void *grad_out, float *grad_value,
                                         void *workspace, int64_t workspace_bytes,
-                                        int B, int S, int M, int D, int L, int Lq, int P, bool absmax_ready, hipStream_t st)
+                                        int B, int S, int M, int D, int L, int Lq, int P, bool absmax_ready, hipStream_t st,
+                                        int grad_out_dtype)
 {
+    if (grad_out_dtype != 0 && !absmax_ready) return hipErrorNotSupported;   // the fp32 absmax pre-pass is not templated
     TilePlan pl;
     if (D != kCH || !build_plan(pl, shapes_h, start_h, B, S, M, L, Lq, P)) return hipErrorNotSupported;
     const int64_t need = 256 + static_cast<int64_t>(B) * M * pl.scr_per_bm * 4;
@@ -425,19 +428,25 @@ hipError_t msda_tiled_grad_value_launch(const int64_t *shapes_h, const int64_t *
     if (!absmax_ready) {
         if ((err = zero_fill_launch(absmax2, 8, st)) != hipSuccess) return err;
         const int64_t n_go = static_cast<int64_t>(B) * Lq * M * D, n_at = static_cast<int64_t>(B) * Lq * M * L * P;
-        hipLaunchKernelGGL(absmax2_kernel, dim3(1024), dim3(256), 0, st, grad_out, n_go, attn, n_at, absmax2);
+        hipLaunchKernelGGL(absmax2_kernel, dim3(1024), dim3(256), 0, st, static_cast<const float *>(grad_out), n_go, attn, n_at, absmax2);
     }
     const size_t lds = static_cast<size_t>(pl.max_cells) * kCH * 8 + static_cast<size_t>(kWavesT) * 64 * kRecDwords * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(msda_scatter_tiles), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static bool attr_set[2] = {false, false};
+    const int which = grad_out_dtype == 2 ? 1 : 0;
+    if (!attr_set[which]) {
+        err = which ? hipFuncSetAttribute(reinterpret_cast<const void *>(msda_scatter_tiles<__hip_bfloat16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                    : hipFuncSetAttribute(reinterpret_cast<const void *>(msda_scatter_tiles<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (err != hipSuccess) return err;
-        attr_set = true;
+        attr_set[which] = true;
     }
     const unsigned nblocks = static_cast<unsigned>(B) * M * pl.blk0[L];
     profile_begin(2, Lq, st);
-    hipLaunchKernelGGL(msda_scatter_tiles, dim3(nblocks), dim3(kThreads), lds, st, pl, loc, attn, grad_out, grad_value,
-                       absmax2, scratch);
+    if (which)
+        hipLaunchKernelGGL(msda_scatter_tiles<__hip_bfloat16>, dim3(nblocks), dim3(kThreads), lds, st, pl, loc, attn,
+                           static_cast<const __hip_bfloat16 *>(grad_out), grad_value, absmax2, scratch);
+    else
+        hipLaunchKernelGGL(msda_scatter_tiles<float>, dim3(nblocks), dim3(kThreads), lds, st, pl, loc, attn,
+                           static_cast<const float *>(grad_out), grad_value, absmax2, scratch);
     profile_end(st);
     const int64_t nrows = static_cast<int64_t>(B) * S * M;
     profile_begin(3, Lq, st);

@@ -11,6 +11,8 @@ dispatcher does (ops/src/ms_deform_attn.h:38).  The reference's debug helper
 ``ms_deform_attn_core_pytorch`` (:41-61) is deliberately not re-exported from the product package;
 its restatement lives in oracle/msda_torch_ref.py (test infrastructure).
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -19,6 +21,10 @@ from .... import msda_ext as MSDA
 
 
 _LOW = (torch.bfloat16, torch.float16)
+# MDETR_MSDA_BF16=1: a bf16 model's value / output / grad_output go through the mixed-precision kernels as they are
+# (include/monodetr_amd.h, mdetr_msda_forward_bf16) instead of being widened to fp32 around the call.  Off until the
+# kernels have run on the GPU.
+_NATIVE_BF16 = os.environ.get("MDETR_MSDA_BF16") == "1"
 
 
 class MSDeformAttnFunction(Function):
@@ -31,6 +37,14 @@ class MSDeformAttnFunction(Function):
                 attention_weights, im2col_step):
         ctx.im2col_step = im2col_step
         ctx.in_dtypes = (value.dtype, sampling_locations.dtype, attention_weights.dtype)
+        ctx.native_bf16 = _NATIVE_BF16 and MSDA.bf16_supported(value, sampling_locations)
+        if ctx.native_bf16:
+            value, sampling_locations, attention_weights = value.contiguous(), sampling_locations.float(), attention_weights.float()
+            out = MSDA.ms_deform_attn_forward_bf16(value, value_spatial_shapes, value_level_start_index,
+                                                   sampling_locations, attention_weights)
+            ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
+                                  sampling_locations, attention_weights)
+            return out
         if value.dtype in _LOW or sampling_locations.dtype in _LOW or attention_weights.dtype in _LOW:
             value, sampling_locations, attention_weights = value.float(), sampling_locations.float(), attention_weights.float()
         elif not (value.dtype == sampling_locations.dtype == attention_weights.dtype):
@@ -46,7 +60,11 @@ class MSDeformAttnFunction(Function):
     @once_differentiable
     def backward(ctx, grad_output):
         value, shapes, level_start, loc, attn = ctx.saved_tensors
+        dv, dl, da = ctx.in_dtypes
+        if ctx.native_bf16:
+            g_value, g_loc, g_attn = MSDA.ms_deform_attn_backward_bf16(
+                value, shapes, level_start, loc, attn, grad_output.to(torch.bfloat16).contiguous())
+            return g_value.to(dv), None, None, g_loc.to(dl), g_attn.to(da), None
         g_value, g_loc, g_attn = MSDA.ms_deform_attn_backward(
             value, shapes, level_start, loc, attn, grad_output.to(value.dtype).contiguous(), ctx.im2col_step)
-        dv, dl, da = ctx.in_dtypes
         return g_value.to(dv), None, None, g_loc.to(dl), g_attn.to(da), None

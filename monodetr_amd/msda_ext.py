@@ -139,6 +139,73 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return [grad_value, grad_loc, grad_attn]
 
 
+def _dims_mixed(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
+    if value.dtype != torch.bfloat16 or sampling_loc.dtype != torch.float32 or attn_weight.dtype != torch.float32:
+        raise RuntimeError("bf16 variant: value must be bfloat16, sampling_loc and attn_weight float32")
+    if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5:
+        raise RuntimeError("expected value[B,S,M,D], sampling_loc[B,Lq,M,L,P,2], attn_weight[B,Lq,M,L,P]")
+    B, S, M, D = value.shape
+    L = spatial_shapes.shape[0]
+    Lq, P = sampling_loc.shape[1], sampling_loc.shape[4]
+    if tuple(sampling_loc.shape) != (B, Lq, M, L, P, 2) or tuple(attn_weight.shape) != (B, Lq, M, L, P):
+        raise RuntimeError("sampling_loc / attn_weight shapes do not match value / spatial_shapes")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes and level_start_index must be int64 (ms_deform_attn_cuda.cu:67-68)")
+    if tuple(spatial_shapes.shape) != (L, 2) or tuple(level_start_index.shape) != (L,):
+        raise RuntimeError("spatial_shapes must be [L,2] and level_start_index [L]")
+    return B, S, M, D, L, Lq, P
+
+
+def bf16_supported(value, sampling_loc):
+    """Shapes the mixed-precision kernels cover (D = 32, L = P = 4 -- the model's configuration)."""
+    return (value.is_cuda and value.dtype == torch.bfloat16 and value.dim() == 4 and value.shape[3] == 32
+            and sampling_loc.dim() == 6 and sampling_loc.shape[3] == 4 and sampling_loc.shape[4] == 4)
+
+
+def ms_deform_attn_forward_bf16(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
+    """bf16 ``value`` in, bf16 ``[B, Lq, M*D]`` out; fp32 sampling locations / weights; fp32 accumulation.
+    Not part of the reference module (its kernels are fp32/fp64 only): include/monodetr_amd.h, mdetr_msda_forward_bf16."""
+    args = (value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    _check_inputs(args, _NAMES5)
+    B, S, M, D, L, Lq, P = _dims_mixed(*args)
+    value, sampling_loc, attn_weight = _aligned(value), _aligned(sampling_loc), _aligned(attn_weight)
+    out = torch.empty((B, Lq, M * D), dtype=torch.bfloat16, device=value.device)
+    rc = _capi.lib().mdetr_msda_forward_bf16(
+        value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+        sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(),
+        B, S, M, D, L, Lq, P, value.device.index, _stream(value.device))
+    _capi.check(rc, "mdetr_msda_forward_bf16")
+    return out
+
+
+def ms_deform_attn_backward_bf16(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight], all fp32, from bf16 ``value`` / ``grad_output``."""
+    args = (value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    _check_inputs(args + (grad_output,), _NAMES5 + ("grad_output",))
+    B, S, M, D, L, Lq, P = _dims_mixed(*args)
+    if grad_output.dtype != torch.bfloat16 or grad_output.numel() != B * Lq * M * D:
+        raise RuntimeError("grad_output must be bfloat16 [B,Lq,M*D]")
+    value, sampling_loc, attn_weight, grad_output = (_aligned(t) for t in (value, sampling_loc, attn_weight, grad_output))
+    grad_value = torch.empty(value.shape, dtype=torch.float32, device=value.device)   # zero-filled by the C ABI
+    grad_loc = torch.empty_like(sampling_loc)
+    grad_attn = torch.empty_like(attn_weight)
+    lib = _capi.lib()
+    ws_bytes, ws_ptr, sh_ptr, st_ptr = 0, 0, 0, 0
+    if Lq == S:
+        sh_h, st_h = _geometry_on_host(spatial_shapes, level_start_index)
+        ws_bytes = lib.mdetr_msda_backward_workspace_bytes(_capi.MDETR_F32, sh_h.data_ptr(), st_h.data_ptr(),
+                                                           B, S, M, D, L, Lq, P)
+        if ws_bytes > 0:
+            ws_ptr, sh_ptr, st_ptr = _workspace(value.device, ws_bytes).data_ptr(), sh_h.data_ptr(), st_h.data_ptr()
+    rc = lib.mdetr_msda_backward_bf16(
+        value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+        sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+        grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
+        B, S, M, D, L, Lq, P, sh_ptr, st_ptr, ws_ptr, ws_bytes, value.device.index, _stream(value.device))
+    _capi.check(rc, "mdetr_msda_backward_bf16")
+    return [grad_value, grad_loc, grad_attn]
+
+
 def ms_deform_attn_indices(spatial_shapes, sampling_loc):
     """int32 [B,Lq,M,L,P,4] = (in_window, h_low, w_low, corner_mask): the gather indices the kernels
     use, exposed for bit-exact index parity tests (not part of the reference module)."""

@@ -271,3 +271,70 @@ def test_msda_prologue_kernel_matches_module_formulas(R, Lq, dtype):
     for a, b in zip(ref_grads, got_grads):
         assert a.shape == b.shape and a.dtype == b.dtype
         assert (a.float() - b.float()).abs().max() <= tol * max(1.0, a.float().abs().max().item())
+
+
+def _msda_problem(B, Lq, M, shapes, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    sh = torch.tensor(shapes, dtype=torch.int64, device="cuda")
+    start = torch.cat([sh.new_zeros(1), (sh[:, 0] * sh[:, 1]).cumsum(0)[:-1]])
+    S = int((sh[:, 0] * sh[:, 1]).sum())
+    Lq = S if Lq is None else Lq
+    value = torch.randn(B, S, M, 32, generator=g, device="cuda").to(torch.bfloat16)
+    loc = torch.rand(B, Lq, M, 4, 4, 2, generator=g, device="cuda") * 1.3 - 0.15      # some samples leave the map
+    attn = torch.softmax(torch.randn(B, Lq, M, 16, generator=g, device="cuda"), -1).view(B, Lq, M, 4, 4)
+    grad_out = torch.randn(B, Lq, M * 32, generator=g, device="cuda").to(torch.bfloat16)
+    return value, sh, start, loc, attn, grad_out
+
+
+@pytest.mark.parametrize("B,Lq,M,shapes", [
+    (2, None, 8, [(12, 40), (6, 20), (3, 10), (2, 5)]),         # self-attention: tile-privatised grad_value
+    (2, 50, 8, [(12, 40), (6, 20), (3, 10), (2, 5)]),           # decoder-like cross attention: atomics
+    (8, None, 8, [(48, 160), (24, 80), (12, 40), (6, 20)]),     # the encoder shape of the benchmark
+    (1, 3, 1, [(1, 1), (2, 3), (1, 7), (5, 1)]),                # degenerate maps, ragged tail
+])
+def test_msda_bf16_kernels_match_the_fp32_kernels_on_rounded_inputs(B, Lq, M, shapes):
+    """The mixed-precision operator computes exactly what the fp32 operator computes on the widened bf16 tensors;
+    the only differences are the final rounding of `out` to bf16 and the fp32 summation order."""
+    from monodetr_amd import msda_ext
+    value, sh, start, loc, attn, grad_out = _msda_problem(B, Lq, M, shapes, 3)
+    out = msda_ext.ms_deform_attn_forward_bf16(value, sh, start, loc, attn)
+    ref = msda_ext.ms_deform_attn_forward(value.float(), sh, start, loc, attn, 64)
+    assert out.dtype == torch.bfloat16 and out.shape == ref.shape
+    assert torch.equal(out, ref.to(torch.bfloat16)) or (out.float() - ref).abs().max() <= 2 ** -8 * ref.abs().max()
+    gv, gl, ga = msda_ext.ms_deform_attn_backward_bf16(value, sh, start, loc, attn, grad_out)
+    rv, rl, ra = msda_ext.ms_deform_attn_backward(value.float(), sh, start, loc, attn, grad_out.float(), 64)
+    for got, want in ((gv, rv), (gl, rl), (ga, ra)):
+        assert got.dtype == torch.float32 and got.shape == want.shape
+        assert (got - want).abs().max() <= 1e-3 * max(1.0, want.abs().max().item())
+
+
+def test_msda_function_with_native_bf16_matches_the_widening_path(monkeypatch):
+    from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func as F
+    value, sh, start, loc, attn, grad_out = _msda_problem(2, None, 8, [(12, 40), (6, 20), (3, 10), (2, 5)], 4)
+    res = {}
+    for native in (False, True):
+        monkeypatch.setattr(F, "_NATIVE_BF16", native)
+        v = value.clone().requires_grad_(True)
+        l = loc.to(torch.bfloat16).requires_grad_(True)
+        a = attn.to(torch.bfloat16).requires_grad_(True)
+        out = F.MSDeformAttnFunction.apply(v, sh, start, l, a, 64)
+        out.backward(grad_out)
+        res[native] = (out.detach(), v.grad, l.grad, a.grad)
+    for x, y in zip(res[False], res[True]):
+        assert x.dtype == y.dtype == torch.bfloat16
+        assert (x.float() - y.float()).abs().max() <= 2 ** -7 * max(1.0, x.float().abs().max().item())
+
+
+def test_training_step_with_bf16_msda_matches_default(monkeypatch):
+    import bench
+    from model_init import disable_dropout_
+    from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func as F
+    dev = torch.device("cuda", 0)
+    traj = {}
+    for native in (False, True):
+        monkeypatch.setattr(F, "_NATIVE_BF16", native)
+        step = bench.TrainStep(dev, 2, "bf16", size=(96, 320))
+        disable_dropout_(step.raw_model)
+        traj[native] = [float(step()) for _ in range(3)]
+    for a, b in zip(traj[False], traj[True]):
+        assert abs(a - b) <= 2e-2 * abs(a), traj
