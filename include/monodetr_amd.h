@@ -297,6 +297,38 @@ int mdetr_token_linear(const void *x, const void *weight, const void *bias, void
                        int64_t ldx, int64_t ldy, int relu, int device, void *stream);
 
 /*
+ * Training image path of the input pipeline on the device: what
+ * lib/datasets/kitti/kitti_dataset.py:127-163 does per sample on a CPU worker -- photometric distortion
+ * (lib/datasets/kitti/pd.py:376-398) with its uint8 cast, horizontal flip, PIL's affine warp with bilinear
+ * resampling to out_w x out_h, / 255, (x - mean) / std, HWC -> CHW -- computed for a whole batch in one launch
+ * from the decoded RGB8 images, bit-identical to that chain.  The random decisions are made on the host by the
+ * caller (in the reference's order, monodetr_amd/datasets/kitti_dataset.py) and arrive in the descriptors.
+ *   pixels   device, uint8: the batch's decoded images back to back, each H x W x 3 (RGB, rows of 3 W bytes)
+ *   images   device, MdetrKittiImage[n_images] (8-byte aligned)
+ *   out      device, [n_images, 3, out_h, out_w] MDETR_F32 or MDETR_BF16 (bf16 = the float32 result rounded to
+ *            nearest even), 16-byte aligned, out_w % 4 == 0
+ *   mean, std   host pointers to 3 floats each (kitti_dataset.py:79-80)
+ */
+#define MDETR_KITTI_FLIP 1u            /* Image.FLIP_LEFT_RIGHT before the warp */
+#define MDETR_KITTI_DISTORT 2u         /* the photometric chain runs (even with every stage idle it re-quantises) */
+#define MDETR_KITTI_CONTRAST_FIRST 4u  /* contrast before the HSV stages (pd.py:392-395), else after */
+#define MDETR_KITTI_BRIGHTNESS 8u
+#define MDETR_KITTI_CONTRAST 16u
+#define MDETR_KITTI_SATURATION 32u
+#define MDETR_KITTI_HUE 64u
+typedef struct MdetrKittiImage {
+    int64_t pixel_offset;   /* byte offset of this image in `pixels` */
+    int32_t width, height;
+    uint32_t flags;         /* MDETR_KITTI_* */
+    uint32_t perm;          /* lighting noise: output channel c = distorted channel (perm >> 2c) & 3; identity 0x24 */
+    float brightness, contrast, saturation, hue;
+    double inv[6];          /* PIL's AFFINE data: source = inv * (output pixel centre, 1) */
+} MdetrKittiImage;
+int mdetr_kitti_preprocess(const uint8_t *pixels, const MdetrKittiImage *images, int n_images, void *out,
+                           int out_dtype, int out_h, int out_w, const float *mean, const float *std,
+                           int device, void *stream);
+
+/*
  * Column sums of a tall row-major matrix, accumulated in fp32: out[j] = sum_i x[i * ld + j].
  * Not an entry point of the reference's extension: it is the bias gradient of the model's token-wise
  * linear layers (db = sum over the 81 600 tokens of dY; torch's autograd computes it with a generic

@@ -23,13 +23,19 @@ def install(force=False):
     """Alias this package's modules under the names the reference code imports:
     ``MultiScaleDeformableAttention`` (ops/functions/ms_deform_attn_func.py:18),
     ``lib.models.monodetr`` (lib/helpers/model_helper.py:1), ``lib.losses.focal_loss``,
-    ``utils.misc`` / ``utils.box_ops``.  Existing entries are kept unless force=True."""
+    ``utils.misc`` / ``utils.box_ops``, and the input pipeline ``lib.helpers.dataloader_helper`` /
+    ``lib.datasets.kitti.kitti_dataset`` (lib/helpers/dataloader_helper.py:4, tools/train_val.py).
+    Existing entries are kept unless force=True."""
     aliases = {
         "MultiScaleDeformableAttention": ".msda_ext",
         "lib.models.monodetr": ".monodetr",
         "lib.losses.focal_loss": ".losses.focal_loss",
         "utils.misc": ".utils.misc",
         "utils.box_ops": ".utils.box_ops",
+        "lib.helpers.dataloader_helper": ".helpers.dataloader_helper",
+        "lib.datasets.utils": ".datasets.utils",
+        "lib.datasets.kitti.kitti_utils": ".datasets.kitti.kitti_utils",
+        "lib.datasets.kitti.kitti_dataset": ".datasets.kitti.kitti_dataset",
     }
     for name, target in aliases.items():
         if force or name not in sys.modules:

@@ -43,6 +43,7 @@ SIGNATURES = {
     "mdetr_token_linear": (_c_int, [_c_vp] * 4 + [ctypes.c_int64, _c_int, _c_int, ctypes.c_int64, ctypes.c_int64, _c_int, _c_int, _c_vp]),
     "mdetr_column_sum_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, _c_int]),
     "mdetr_column_sum": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, ctypes.c_int64, ctypes.c_int64, _c_int, ctypes.c_int64, _c_int, _c_vp]),
+    "mdetr_kitti_preprocess": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_vp]),
     "mdetr_msda_forward_bf16": (_c_int, [_c_vp] * 6 + [_c_int] * 7 + [_c_int, _c_vp]),
     "mdetr_msda_backward_bf16": (_c_int, [_c_vp] * 9 + [_c_int] * 7 + [_c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_vp]),
     "mdetr_msda_prologue_forward": (_c_int, [_c_int] + [_c_vp] * 6 + [_c_int] * 6 + [ctypes.c_int64] * 3 + [_c_int, _c_vp]),

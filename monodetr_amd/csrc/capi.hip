@@ -15,6 +15,7 @@
 #include "adamw.h"
 #include "colsum.h"
 #include "ddn_loss.h"
+#include "kitti_prep.h"
 #include "lsa.h"
 #include "pair_losses.h"
 #include "token_gemm.h"
@@ -442,6 +443,29 @@ int mdetr_column_sum(int dtype, const void *x, float *out, void *workspace, int6
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_column_sum: set device %d: %s", device, hipGetErrorString(dev.err));
     const hipError_t e = mdetr::colsum_launch(dtype, x, out, workspace, rows, cols, ld, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_column_sum: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_kitti_preprocess(const uint8_t *pixels, const MdetrKittiImage *images, int n_images, void *out,
+                           int out_dtype, int out_h, int out_w, const float *mean, const float *std,
+                           int device, void *stream)
+{
+    if (n_images < 0 || out_h < 0 || out_w < 0) return fail(MDETR_E_ARG, "mdetr_kitti_preprocess: negative size");
+    if (out_dtype != MDETR_F32 && out_dtype != MDETR_BF16)
+        return fail(MDETR_E_ARG, "mdetr_kitti_preprocess: out_dtype %d (MDETR_F32 or MDETR_BF16)", out_dtype);
+    if (out_w % 4 != 0) return fail(MDETR_E_ARG, "mdetr_kitti_preprocess: out_w = %d must be a multiple of 4", out_w);
+    if (!mean || !std) return fail(MDETR_E_ARG, "mdetr_kitti_preprocess: null mean / std");
+    if (n_images == 0 || out_h == 0 || out_w == 0) return MDETR_OK;
+    if (!pixels || !images || !out) return fail(MDETR_E_ARG, "mdetr_kitti_preprocess: null pointer");
+    if (!aligned16(out) || reinterpret_cast<uintptr_t>(images) % 8 != 0)
+        return fail(MDETR_E_ALIGN, "mdetr_kitti_preprocess: out must be 16-byte, images 8-byte aligned");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_kitti_preprocess: set device %d: %s", device, hipGetErrorString(dev.err));
+    mdetr::KittiNorm norm;
+    for (int c = 0; c < 3; ++c) { norm.mean[c] = mean[c]; norm.stdv[c] = std[c]; }
+    const hipError_t e = mdetr::kitti_prep_launch(pixels, images, n_images, out, out_dtype, out_h, out_w, norm,
+                                                  static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_kitti_preprocess: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

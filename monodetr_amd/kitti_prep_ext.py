@@ -1,0 +1,59 @@
+"""``preprocess_batch``: the training image path of the input pipeline on the device, one launch per batch
+(csrc/kitti_prep.hip through ``mdetr_kitti_preprocess``): photometric distortion, flip, PIL-exact affine/bilinear warp,
+normalisation and HWC -> CHW of ``lib/datasets/kitti/kitti_dataset.py:127-163``, from decoded RGB8 images.
+
+``DESCRIPTOR`` is the numpy dtype of ``MdetrKittiImage`` (include/monodetr_amd.h); the host side of the pipeline
+(``monodetr_amd/datasets``) fills one record per image."""
+import numpy as np
+import torch
+
+from . import _capi
+
+_backend = None               # tests substitute the host build of the same arithmetic (tests/native)
+
+FLIP, DISTORT, CONTRAST_FIRST, BRIGHTNESS, CONTRAST, SATURATION, HUE = 1, 2, 4, 8, 16, 32, 64
+IDENTITY_PERM = 0x24
+
+DESCRIPTOR = np.dtype([('pixel_offset', '<i8'), ('width', '<i4'), ('height', '<i4'), ('flags', '<u4'), ('perm', '<u4'),
+                       ('brightness', '<f4'), ('contrast', '<f4'), ('saturation', '<f4'), ('hue', '<f4'),
+                       ('inv', '<f8', (6,))], align=True)
+assert DESCRIPTOR.itemsize == 88
+
+_MEAN = (0.485, 0.456, 0.406)          # kitti_dataset.py:79-80
+_STD = (0.229, 0.224, 0.225)
+
+
+def _lib():
+    return _backend if _backend is not None else _capi.lib()
+
+
+def preprocess_batch(pixels, descriptors, out_hw=(384, 1280), dtype=torch.float32, mean=_MEAN, std=_STD, out=None):
+    """pixels: uint8 1-D tensor (all images of the batch back to back); descriptors: uint8 tensor viewing
+    ``DESCRIPTOR`` records [n * 88] on the same device -> [n, 3, H, W] ``dtype`` tensor on that device.
+    Runs on the current stream; no synchronisation."""
+    if pixels.dtype != torch.uint8 or descriptors.dtype != torch.uint8 or not pixels.is_contiguous() or not descriptors.is_contiguous():
+        raise RuntimeError("pixels and descriptors must be contiguous uint8 tensors")
+    if pixels.device != descriptors.device:
+        raise RuntimeError("pixels is on %s but descriptors on %s" % (pixels.device, descriptors.device))
+    if descriptors.numel() % DESCRIPTOR.itemsize != 0:
+        raise RuntimeError("descriptors must hold whole %d-byte records" % DESCRIPTOR.itemsize)
+    if not pixels.is_cuda and _backend is None:
+        raise RuntimeError("Not implemented on the CPU")
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("output dtype must be float32 or bfloat16")
+    n = descriptors.numel() // DESCRIPTOR.itemsize
+    H, W = out_hw
+    if out is None:
+        out = torch.empty((n, 3, H, W), dtype=dtype, device=pixels.device)
+    elif tuple(out.shape) != (n, 3, H, W) or out.dtype != dtype or not out.is_contiguous() or out.device != pixels.device:
+        raise RuntimeError("out must be a contiguous [n,3,H,W] tensor of the requested dtype on the pixels' device")
+    m = np.asarray(mean, dtype=np.float32)
+    s = np.asarray(std, dtype=np.float32)
+    cuda = pixels.is_cuda
+    rc = _lib().mdetr_kitti_preprocess(
+        pixels.data_ptr(), descriptors.data_ptr(), n, out.data_ptr(),
+        _capi.MDETR_F32 if dtype == torch.float32 else _capi.MDETR_BF16, H, W, m.ctypes.data, s.ctypes.data,
+        pixels.device.index if cuda else -1, torch.cuda.current_stream(pixels.device).cuda_stream if cuda else None)
+    if rc != 0:
+        _capi.check(rc, "mdetr_kitti_preprocess")
+    return out

@@ -262,6 +262,37 @@ def project_rect_to_img(p2, pts):
     return (q[:, 0:2].T / hom[:, 2]).T
 
 
+def flip_p2(p2, img_size):
+    """Calibration.flip (kitti_utils.py:286-326): P2 of the mirrored image, re-fitted by SVD through 8 points."""
+    cu, cv, fu, fv = p2[0, 2], p2[1, 2], p2[0, 0], p2[1, 1]
+    tx, ty = p2[0, 3] / (-fu), p2[1, 3] / (-fv)
+    wsize, hsize = 4, 2
+    p2ds = np.concatenate([np.expand_dims(np.tile(np.expand_dims(np.linspace(0, img_size[0], wsize), 0), [hsize, 1]), -1),
+                           np.expand_dims(np.tile(np.expand_dims(np.linspace(0, img_size[1], hsize), 1), [1, wsize]), -1),
+                           np.linspace(2, 78, wsize * hsize).reshape(hsize, wsize, 1)], -1).reshape(-1, 3)
+    u, v, d = p2ds[:, 0:1], p2ds[:, 1:2], p2ds[:, 2:3]
+    x = ((u - cu) * d) / fu + tx
+    y = ((v - cv) * d) / fv + ty
+    p3ds = np.concatenate((x.reshape(-1, 1), y.reshape(-1, 1), d.reshape(-1, 1)), axis=1)
+    p3ds[:, 0] *= -1
+    p2ds[:, 0] = img_size[0] - p2ds[:, 0]
+    m = np.zeros([wsize * hsize, 2, 7])
+    m[:, 0, 0] = p3ds[:, 0]
+    m[:, 0, 1] = m[:, 1, 2] = p3ds[:, 2]
+    m[:, 1, 0] = p3ds[:, 1]
+    m[:, 0, 3] = m[:, 1, 4] = 1
+    m[:, :, -2] = -p2ds[:, :2]
+    m[:, :, -1] = (-p2ds[:, :2] * p3ds[:, 2:3])
+    sol = np.linalg.svd(m.reshape(-1, 7))[-1][-1]
+    sol /= sol[-1]
+    new = np.zeros([4, 3]).astype(np.float32)
+    new[0, 0] = new[1, 1] = sol[0]
+    new[2, 0:2] = sol[1:3]
+    new[3, :] = sol[3:6]
+    new[-1, -1] = p2[-1, -1]
+    return new.T
+
+
 def ry_to_alpha(p2, ry, u):
     """Calibration.ry2alpha (kitti_utils.py:276-284)."""
     alpha = ry - np.arctan2(u - p2[0, 2], p2[0, 0])
@@ -282,11 +313,16 @@ def angle_to_class(angle, bins=12):
 
 
 def encode_targets(objects, p2, img_size, flip, trans, crop_scale, writelist=('Car',), clip_2d=False,
-                   depth_scale='normal', resolution=RESOLUTION):
-    """kitti_dataset.py:173-312 with aug_calib off (the shipped config): the 13 target arrays of one sample.
-    `objects` are LabelLine objects; they are modified in place by the flip exactly as the reference does."""
+                   depth_scale='normal', resolution=RESOLUTION, aug_calib=False):
+    """kitti_dataset.py:173-312: the 13 target arrays of one sample (aug_calib is off in the shipped config).
+    `objects` are LabelLine objects; they are modified in place by the flip exactly as the reference does.
+    Returns (targets, P2) -- P2 changes when aug_calib re-fits it for a flipped image."""
     if flip:                                                                       # :177-190
+        if aug_calib:
+            p2 = flip_p2(p2, img_size)
         for o in objects:
+            if aug_calib:
+                o.pos[0] *= -1
             x1, x2 = o.box2d[0], o.box2d[2]
             o.box2d[0], o.box2d[2] = img_size[0] - x2, img_size[0] - x1
             o.alpha = np.pi - o.alpha
@@ -318,7 +354,7 @@ def encode_targets(objects, p2, img_size, flip, trans, crop_scale, writelist=('C
         center_2d = np.array([(bbox[0] + bbox[2]) / 2, (bbox[1] + bbox[3]) / 2], dtype=np.float32)
         c3 = (o.pos + [0, -o.h / 2, 0]).reshape(-1, 3)
         c3 = project_rect_to_img(p2, c3)[0]
-        if flip:
+        if flip and not aug_calib:
             c3[0] = img_size[0] - c3[0]
         c3 = warp_point(c3.reshape(-1), trans)
         if c3[0] < 0 or c3[0] >= resolution[0] or c3[1] < 0 or c3[1] >= resolution[1]:
@@ -358,11 +394,11 @@ def encode_targets(objects, p2, img_size, flip, trans, crop_scale, writelist=('C
         if o.truncation <= 0.5 and o.occlusion <= 2:
             t['mask_2d'][i] = 1
         t['calibs'][i] = p2
-    return t
+    return t, p2
 
 
 def training_sample(img_u8, label_lines, calib_lines, aug_pd=True, aug_crop=True, random_flip=0.5, random_crop=0.5,
-                    scale=0.05, shift=0.05, augment=True):
+                    scale=0.05, shift=0.05, augment=True, aug_calib=False):
     """One `__getitem__` of the train split: (inputs [3,384,1280] float32, P2, targets dict, params dict)."""
     img_u8 = np.asarray(img_u8)
     img_size = np.array([img_u8.shape[1], img_u8.shape[0]])
@@ -378,5 +414,5 @@ def training_sample(img_u8, label_lines, calib_lines, aug_pd=True, aug_crop=True
     inputs = warp_and_normalise(img_u8, flip, trans_inv)
     p2 = read_p2(calib_lines)
     objects = [LabelLine(l) for l in label_lines]
-    targets = encode_targets(objects, p2, img_size, flip, trans, crop_scale)
+    targets, p2 = encode_targets(objects, p2, img_size, flip, trans, crop_scale, aug_calib=aug_calib)
     return inputs, p2, targets, params

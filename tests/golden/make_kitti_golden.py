@@ -28,7 +28,8 @@ sys.dont_write_bytecode = True
 from oracle import kitti_pipeline as okp          # noqa: E402
 import kitti_synth                                # noqa: E402
 
-SEEDS = [444, 445, 446, 447, 448, 449, 450, 451, 452, 453, 454, 455]
+SEEDS = [444, 445, 446, 447, 448, 449, 450, 451, 452, 453, 454, 455, 456, 457, 458, 459]
+N_TRAIN, N_VAL = 10, 2          # then: train split with aug_calib (P2 re-fitted for flipped images)
 
 
 def install_stubs():
@@ -65,10 +66,11 @@ def main():
                'scale': 0.05, 'shift': 0.05, 'writelist': ['Car'], 'depth_scale': 'normal'}
         train = KITTI_Dataset('train', cfg)
         val = KITTI_Dataset('val', cfg)
+        train_calib = KITTI_Dataset('train', dict(cfg, aug_calib=True, random_flip=0.8))
         out['seeds'] = np.array(SEEDS)
         for n, seed in enumerate(SEEDS):
             item = n % len(ids)
-            ds = val if n >= 10 else train                           # the last two samples: no augmentation
+            ds = train if n < N_TRAIN else (val if n < N_TRAIN + N_VAL else train_calib)
             np.random.seed(seed)
             inputs, p2, targets, info = ds[item]
             inputs = np.ascontiguousarray(inputs, dtype=np.float32)

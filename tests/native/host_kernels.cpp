@@ -6,6 +6,7 @@
 
 #include "../../monodetr_amd/csrc/adamw_math.h"
 #include "../../monodetr_amd/csrc/ddn_loss_math.h"
+#include "../../monodetr_amd/csrc/kitti_prep_math.h"
 #include "../../monodetr_amd/csrc/msda_prologue_math.h"
 #include "../../monodetr_amd/csrc/pair_losses_math.h"
 
@@ -295,6 +296,28 @@ int mdetr_pair_losses_backward(const float *logits, const float *boxes, const fl
             for (int q = 0; q < Q; ++q)
                 pl_row_backward(d, in, l, b, q, w, comp[l], g_logits, g_boxes, g_dims, g_depths, g_angles);
     }
+    return 0;
+}
+
+// same argument list as mdetr_kitti_preprocess; `pixels`, `images` and `out` are host memory here
+int mdetr_kitti_preprocess(const uint8_t *pixels, const MdetrKittiImage *images, int n_images, void *out,
+                           int out_dtype, int out_h, int out_w, const float *mean, const float *std,
+                           int device, void *stream)
+{
+    (void)device; (void)stream;
+    using namespace mdetr;
+    const int64_t plane = static_cast<int64_t>(out_h) * out_w;
+    for (int n = 0; n < n_images; ++n)
+        for (int oy = 0; oy < out_h; ++oy)
+            for (int ox = 0; ox < out_w; ++ox) {
+                float px[3];
+                kp_pixel(images[n], pixels + images[n].pixel_offset, ox, oy, mean, std, px);
+                for (int c = 0; c < 3; ++c) {
+                    const int64_t at = (static_cast<int64_t>(n) * 3 + c) * plane + static_cast<int64_t>(oy) * out_w + ox;
+                    if (out_dtype == 0) static_cast<float *>(out)[at] = px[c];
+                    else static_cast<uint16_t *>(out)[at] = f32_to_bf16(px[c]);
+                }
+            }
     return 0;
 }
 

@@ -22,7 +22,7 @@ def lib():
         L = ctypes.CDLL(OUT)
         for name in ("mdetr_adamw_step", "mdetr_pair_losses_workspace_bytes", "mdetr_pair_losses_forward",
                      "mdetr_pair_losses_backward", "mdetr_ddn_loss_forward", "mdetr_ddn_loss_backward", "mdetr_lsa_forward_fused", "mdetr_msda_prologue_forward",
-                     "mdetr_msda_prologue_backward"):
+                     "mdetr_msda_prologue_backward", "mdetr_kitti_preprocess"):
             res, args = _capi.SIGNATURES[name]
             getattr(L, name).restype, getattr(L, name).argtypes = res, args
         _lib = L

@@ -38,7 +38,8 @@ def test_oracle_reproduces_the_reference_dataset_class_sample_for_sample(tree):
         pre = 's%02d_' % n
         img, labels, calib = load_raw(root, ids[int(g[pre + 'item'])])
         np.random.seed(int(seed))
-        inputs, p2, targets, params = okp.training_sample(img, labels, calib, augment=n < 10)
+        inputs, p2, targets, params = okp.training_sample(img, labels, calib, augment=not 10 <= n < 12, aug_calib=n >= 12,
+                                                          random_flip=0.8 if n >= 12 else 0.5)
         n_aug += params['pd'] is not None and params['flip']
         inputs = np.ascontiguousarray(inputs, dtype=np.float32)
         assert inputs.shape == (3, 384, 1280)
@@ -94,3 +95,152 @@ def test_uint8_cast_is_the_wrapping_c_cast_the_reference_relies_on():
     with np.errstate(invalid='ignore'):
         assert np.array_equal(x.astype(np.uint8), x.astype(np.int32).astype(np.uint8))
     assert list(x.astype(np.int32).astype(np.uint8)) == [44, 253, 255, 0, 0, 255]
+
+
+# ---- product host side + the kernel arithmetic (host build) ------------------------------------------------------
+CFG = {'type': 'KITTI', 'aug_pd': True, 'aug_crop': True, 'random_flip': 0.5, 'random_crop': 0.5, 'scale': 0.05,
+       'shift': 0.05, 'writelist': ['Car'], 'depth_scale': 'normal', 'train_split': 'train', 'test_split': 'val',
+       'batch_size': 3}
+
+
+@pytest.fixture()
+def host_backend():
+    import native_host
+    from monodetr_amd import kitti_prep_ext
+    kitti_prep_ext._backend = native_host.lib()
+    yield kitti_prep_ext
+    kitti_prep_ext._backend = None
+
+
+def run_host(prep, image, dtype=None):
+    import torch
+    from monodetr_amd.helpers.dataloader_helper import pack_images
+    packed, n = pack_images([image])
+    head = n * prep.DESCRIPTOR.itemsize
+    return prep.preprocess_batch(packed[head:], packed[:head], dtype=dtype or torch.float32)
+
+
+def test_dataset_and_kernel_arithmetic_reproduce_the_reference_sample_for_sample(tree, host_backend):
+    """The product path -- KITTI_Dataset's draws / descriptor / targets on the host and the device kernel's
+    per-pixel arithmetic (here: its host build) -- against the fixture recorded from the reference class:
+    images bit-exact (SHA-256), every target array equal."""
+    from monodetr_amd.datasets.kitti import KITTI_Dataset
+    root, ids = tree
+    g = np.load(GOLD)
+    cfg = dict(CFG, root_dir=root)
+    train, val = KITTI_Dataset('train', cfg), KITTI_Dataset('val', cfg)
+    train_calib = KITTI_Dataset('train', dict(cfg, aug_calib=True, random_flip=0.8))
+    seen_flags, refits = 0, 0
+    for n, seed in enumerate(g['seeds']):
+        pre = 's%02d_' % n
+        np.random.seed(int(seed))
+        image, p2, targets, info = (train if n < 10 else (val if n < 12 else train_calib))[int(g[pre + 'item'])]
+        seen_flags |= int(image['descriptor']['flags'][0])
+        refits += n >= 12 and bool(image['descriptor']['flags'][0] & 1)
+        out = run_host(host_backend, image)[0].numpy()
+        assert np.array_equal(out[:, 5::24, 7::40], g[pre + 'sub'])
+        assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).digest() == g[pre + 'sha256'].tobytes()
+        assert np.array_equal(p2, g[pre + 'p2']) and np.array_equal(info['img_size'], g[pre + 'img_size'])
+        for k in TARGET_KEYS:
+            want = g[pre + 't_' + k]
+            assert targets[k].dtype == want.dtype and np.array_equal(targets[k], want), (n, k)
+    assert seen_flags == 127                                            # every stage of the chain was exercised
+    assert refits >= 2                                                  # aug_calib: P2 re-fitted for flipped images
+
+
+@pytest.mark.parametrize("flags_off", [0, 8, 16, 32, 64, 4, 2])
+def test_kernel_arithmetic_matches_the_oracle_for_each_stage_combination(host_backend, flags_off):
+    """Stage by stage (one switched off at a time, both contrast positions, every channel permutation, extreme
+    parameters that drive values through the uint8 wrap-around) on a small image, vs the numpy/PIL oracle."""
+    prep = host_backend
+    rs = np.random.RandomState(flags_off)
+    img = kitti_synth.synth_image(rs, 200, 90)
+    for trial in range(6):
+        d = np.zeros(1, dtype=prep.DESCRIPTOR)
+        flags = 127 & ~flags_off
+        if trial % 2:
+            flags ^= prep.CONTRAST_FIRST
+        perm = okp.PERMS[trial]
+        pd = {'brightness': rs.uniform(-32, 32), 'contrast': rs.uniform(0.5, 1.5), 'saturation': rs.uniform(0.5, 1.5),
+              'hue': rs.uniform(-18, 18), 'perm': perm, 'contrast_first': bool(flags & prep.CONTRAST_FIRST)}
+        if trial == 5:
+            pd.update(brightness=32.0, contrast=1.5, hue=18.0)
+        for name, bit in (('brightness', 8), ('contrast', 16), ('saturation', 32), ('hue', 64)):
+            d[name] = pd[name]
+            if not flags & bit:
+                pd[name] = None
+        inv = np.array([[0.16 + 0.01 * trial, 0.004, -3.0 + trial], [-0.003, 0.23, -2.5]])
+        d['width'], d['height'], d['flags'], d['inv'] = 200, 90, flags, inv.reshape(-1)
+        d['perm'] = perm[0] | (perm[1] << 2) | (perm[2] << 4)
+        src = okp.apply_photometric(img, pd) if flags & prep.DISTORT else img
+        want = okp.warp_and_normalise(src, bool(flags & prep.FLIP), inv)
+        got = run_host(prep, {'pixels': img, 'descriptor': d})[0].numpy()
+        assert np.array_equal(got, want), (flags, trial)
+
+
+def test_bf16_output_is_the_rounded_float32_output(host_backend):
+    import torch
+    rs = np.random.RandomState(3)
+    img = kitti_synth.synth_image(rs, 160, 80)
+    d = np.zeros(1, dtype=host_backend.DESCRIPTOR)
+    d['width'], d['height'], d['perm'], d['inv'] = 160, 80, host_backend.IDENTITY_PERM, [0.125, 0, 0, 0, 0.2083, 0]
+    f32 = run_host(host_backend, {'pixels': img, 'descriptor': d})
+    bf = run_host(host_backend, {'pixels': img, 'descriptor': d}, dtype=torch.bfloat16)
+    assert bf.dtype == torch.bfloat16 and torch.equal(bf, f32.to(torch.bfloat16))
+
+
+def test_loader_batches_like_the_reference_loader(tree, host_backend):
+    """build_dataloader: the 4-tuple of the reference's loop (trainer_helper.py:122), ragged image sizes in one
+    batch, workers, and the test split's repeated image."""
+    import torch
+    from monodetr_amd.helpers.dataloader_helper import build_dataloader
+    root, ids = tree
+    cfg = dict(CFG, root_dir=root)
+    train, val = build_dataloader(cfg, workers=0, device='cpu')
+    assert len(train) == 2 and len(val) == 2
+    batches = list(val)                                                 # no augmentation, no shuffling: deterministic
+    inputs, calibs, targets, info = batches[0]
+    assert inputs.shape == (3, 3, 384, 1280) and inputs.dtype == torch.float32
+    assert calibs.shape == (3, 3, 4) and targets['boxes_3d'].shape == (3, 50, 6) and targets['labels'].dtype == torch.int8
+    assert info['img_id'].tolist() == [int(i) for i in ids[:3]] and info['img_size'].shape == (3, 2)
+    for b in range(3):                                                  # each image equals its single-sample result
+        image, _, t, _ = val.dataset[b]
+        assert torch.equal(inputs[b], run_host(host_backend, image)[0])
+        assert np.array_equal(targets['depth'][b].numpy(), t['depth'])
+    # worker processes: same batches
+    _, val2 = build_dataloader(cfg, workers=2, device='cpu')
+    for (a, _, ta, _), (b, _, tb, _) in zip(batches, val2):
+        assert torch.equal(a, b) and torch.equal(ta['boxes'], tb['boxes'])
+    # test split
+    from monodetr_amd.datasets.kitti import KITTI_Dataset
+    from monodetr_amd.helpers.dataloader_helper import DeviceLoader, collate_packed
+    dl = torch.utils.data.DataLoader(KITTI_Dataset('test', dict(cfg, root_dir=root)) if os.path.isdir(os.path.join(root, 'testing'))
+                                     else _as_test_split(KITTI_Dataset('val', cfg)), batch_size=2, collate_fn=collate_packed)
+    x, calib, again, info = next(iter(DeviceLoader(dl, 'cpu')))
+    assert again is x and x.shape == (2, 3, 384, 1280)
+
+
+def _as_test_split(ds):
+    ds.split = 'test'                                                   # same files, the test split's return convention
+    return ds
+
+
+def test_product_refuses_to_run_without_the_device_library():
+    import torch
+    from monodetr_amd import kitti_prep_ext
+    assert kitti_prep_ext._backend is None
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        kitti_prep_ext.preprocess_batch(torch.zeros(30, dtype=torch.uint8), torch.zeros(88, dtype=torch.uint8))
+
+
+def test_install_aliases_the_reference_module_names_of_the_pipeline():
+    import subprocess
+    import sys
+    code = ("import monodetr_amd; monodetr_amd.install();"
+            "from lib.helpers.dataloader_helper import build_dataloader;"
+            "from lib.datasets.kitti.kitti_dataset import KITTI_Dataset;"
+            "from lib.datasets.kitti.kitti_utils import Calibration, get_affine_transform, affine_transform, get_objects_from_label;"
+            "from lib.datasets.utils import angle2class, class2angle; print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and r.stdout.strip() == 'ok', r.stderr

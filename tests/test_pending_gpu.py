@@ -338,3 +338,75 @@ def test_training_step_with_bf16_msda_matches_default(monkeypatch):
         traj[native] = [float(step()) for _ in range(3)]
     for a, b in zip(traj[False], traj[True]):
         assert abs(a - b) <= 2e-2 * abs(a), traj
+
+
+# ---- input pipeline on the device ----------------------------------------------------------------
+def _kitti_batch(n, seed, distort=True):
+    import numpy as np
+    import kitti_synth
+    from monodetr_amd import kitti_prep_ext as prep
+    from oracle import kitti_pipeline as okp
+    rs = np.random.RandomState(seed)
+    images, want = [], []
+    for k in range(n):
+        w, h = kitti_synth.SIZES[(seed + k) % 4]
+        img = kitti_synth.synth_image(rs, w, h)
+        np.random.seed(1000 * seed + k)
+        d = np.zeros(1, dtype=prep.DESCRIPTOR)
+        d['width'], d['height'], d['perm'] = w, h, prep.IDENTITY_PERM
+        src = img
+        if distort:
+            from monodetr_amd.datasets.kitti.kitti_dataset import draw_photometric
+            state = np.random.get_state()
+            draw_photometric(d[0])
+            np.random.set_state(state)
+            src = okp.apply_photometric(img, okp.draw_photometric())
+        flip, center, crop_size, _ = okp.draw_geometry(np.array([w, h]), scale=0.4, shift=0.1)
+        if flip:
+            d['flags'] |= prep.FLIP
+        _, inv = okp.affine_pair(center, crop_size)
+        d['inv'] = inv.reshape(-1)
+        images.append({'pixels': img, 'descriptor': d})
+        want.append(okp.warp_and_normalise(src, flip, inv))
+    return images, np.stack(want)
+
+
+@pytest.mark.parametrize("n,distort", [(1, False), (3, True), (8, True)])
+def test_kitti_preprocess_kernel_is_bit_identical_to_the_reference_chain(n, distort):
+    import numpy as np
+    from monodetr_amd import kitti_prep_ext as prep
+    from monodetr_amd.helpers.dataloader_helper import pack_images
+    images, want = _kitti_batch(n, 11 + n, distort)
+    packed, _ = pack_images(images)
+    dev = packed.cuda()
+    head = n * prep.DESCRIPTOR.itemsize
+    out = prep.preprocess_batch(dev[head:], dev[:head])
+    assert out.shape == (n, 3, 384, 1280)
+    assert np.array_equal(out.cpu().numpy(), want)                      # bit-exact, float32
+    bf = prep.preprocess_batch(dev[head:], dev[:head], dtype=torch.bfloat16)
+    assert torch.equal(bf, out.to(torch.bfloat16))
+
+
+def test_device_loader_yields_the_reference_loop_tuple(tmp_path):
+    import numpy as np
+    import kitti_synth
+    from monodetr_amd.helpers.dataloader_helper import build_dataloader
+    from oracle import kitti_pipeline as okp
+    from PIL import Image
+    root = str(tmp_path)
+    ids = kitti_synth.make_tree(root, n_images=5, seed=9)
+    cfg = {'type': 'KITTI', 'root_dir': root, 'aug_pd': True, 'aug_crop': True, 'train_split': 'train', 'test_split': 'val',
+           'batch_size': 2, 'scale': 0.05, 'shift': 0.05, 'writelist': ['Car']}
+    train, val = build_dataloader(cfg, workers=2)
+    seen = 0
+    for inputs, calibs, targets, info in val:                            # 3 batches (2, 2, 1), prefetch one ahead
+        assert inputs.is_cuda and inputs.shape[1:] == (3, 384, 1280) and calibs.shape[1:] == (3, 4)
+        for b, img_id in enumerate(info['img_id'].tolist()):
+            img = np.array(Image.open('%s/training/image_2/%06d.png' % (root, img_id)))
+            size = np.array([img.shape[1], img.shape[0]])
+            _, inv = okp.affine_pair(size / 2, size)
+            assert np.array_equal(inputs[b].cpu().numpy(), okp.warp_and_normalise(img, False, inv))
+            seen += 1
+    assert seen == 5
+    n = sum(x.shape[0] for x, _, _, _ in train)                          # augmented, shuffled: runs and is finite
+    assert n == 5 and all(torch.isfinite(x).all() for x, _, _, _ in train)
