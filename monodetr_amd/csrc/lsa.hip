@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mdetr_wave.h>
+
 #include "lsa.h"
 #include "pair_losses_math.h"
 
@@ -55,7 +57,7 @@ void lsa_kernel(const float *__restrict__ C, const int *__restrict__ num_targets
                 int64_t img_stride, int64_t q_stride, int64_t t_stride, int images_per_layer, const LsaFused fz)
 {
     // per wave: costs [kmax][65] fp32 (exact in fp64 on read) + row potentials u[64] fp64
-    extern __shared__ __attribute__((aligned(16))) unsigned char lsa_smem[];
+    MDETR_DYNAMIC_LDS(unsigned char, lsa_smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int prob = blockIdx.x * kWavesPerBlock + wave;
     if (prob >= num_problems) return;                                 // wave-uniform

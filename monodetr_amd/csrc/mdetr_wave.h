@@ -1,0 +1,27 @@
+// monodetr_amd/csrc/mdetr_wave.h -- the wave-level vocabulary of the MFMA kernels written after round 1's GPU budget:
+// bf16 / fp32 fragment vector types, the 32x32x16 bf16 matrix instruction, the wave-private LDS hand-over barrier
+// and the dynamic-LDS declaration.  Included as <mdetr_wave.h> so that the CPU emulation build
+// (tests/native/hipshim, tests/native_emul.py) can substitute its own implementation of exactly these pieces and
+// run the unmodified kernel source on the host.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// D = A B + C on one wave: lane l supplies A[l & 31][8 (l >> 5) + 0..7] and B[8 (l >> 5) + 0..7][l & 31];
+// accumulator register r of lane l is D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31]  (validated in attn.hip)
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// orders a wave's LDS writes before its subsequent LDS reads (wave-private buffers: no workgroup barrier needed)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+#define MDETR_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]

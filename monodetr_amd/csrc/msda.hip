@@ -30,6 +30,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mdetr_wave.h>
+
 #include "msda.h"
 
 namespace mdetr {
@@ -163,7 +165,7 @@ void msda_fwd_d32(const float *__restrict__ value, const int64_t *__restrict__ s
                   const float *__restrict__ attn, float *__restrict__ out,
                   int B, int S, int M, int L_, int P_, int npairs, int iters)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    MDETR_DYNAMIC_LDS(float, smem);
     const int L = TL ? TL : L_, P = TP ? TP : P_, LP = L * P;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -465,7 +467,7 @@ void msda_bwd_d32(const VT *__restrict__ value, const int64_t *__restrict__ shap
                   float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
                   int B, int S, int M, int L_, int P_, int npairs, int iters, unsigned *__restrict__ absmax2)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    MDETR_DYNAMIC_LDS(float, smem);
     const int L = TL ? TL : L_, P = TP ? TP : P_, LP = L * P;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -30,6 +30,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <mdetr_wave.h>
+
 #include "msda.h"
 
 namespace mdetr {
@@ -195,7 +197,7 @@ void msda_scatter_tiles(const TilePlan pl, const float *__restrict__ loc, const 
                         const GT *__restrict__ grad_out, float *__restrict__ grad_value,
                         const unsigned *__restrict__ absmax2, float *__restrict__ scratch)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    MDETR_DYNAMIC_LDS(unsigned char, smem_raw);
     unsigned long long *win = reinterpret_cast<unsigned long long *>(smem_raw);
     unsigned *recs = reinterpret_cast<unsigned *>(smem_raw + static_cast<size_t>(pl.max_cells) * kCH * 8);
 

@@ -24,32 +24,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mdetr_wave.h>
+
 #include "token_gemm.h"
 
 namespace mdetr {
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
 constexpr int kWavesG = 4;
 constexpr int kSlabK = 64;                 // k values per slab
 constexpr int kSlabPad = kSlabK + 8;       // 72 bf16 = 36 dwords per slab row (conflict-free b128 reads, see above)
 
-__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
 // accumulator register r of a lane holds row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31 of the
-// 32 x 32 result (attn.hip acc_row)
-
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
+// 32 x 32 result (mdetr_wave.h, attn.hip acc_row)
 
 // K = contraction length (multiple of 64), NB = number of 32-wide output blocks held by a workgroup
 template <int K, int NB, bool RELU>
@@ -59,7 +46,7 @@ void token_gemm_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ 
 {
     constexpr int KP = K + 8;                                    // padded weight row
     constexpr int NS = K / kSlabK;                               // slabs per tile
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    MDETR_DYNAMIC_LDS(unsigned char, smem_raw);
     __bf16 *Ws = reinterpret_cast<__bf16 *>(smem_raw);           // [NB*32][KP]
     __bf16 *slabs = Ws + NB * 32 * KP;                           // [4 waves][32][kSlabPad]
     float *bias_s = reinterpret_cast<float *>(slabs + kWavesG * 32 * kSlabPad);   // [NB*32]

@@ -1,0 +1,57 @@
+// tests/native/hipshim/mdetr_wave.h -- TEST INFRASTRUCTURE: CPU stand-in for monodetr_amd/csrc/mdetr_wave.h (found
+// first on the include path of the emulation build).  Fragment vectors are small structs; the matrix instruction is
+// emulated as a wave-collective exchange with the operand / accumulator layout documented (and GPU-validated through
+// attn.hip) in the real header: products of bf16 values are exact in fp32, accumulation is fp32 in k order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+
+#define __bf16 hipshim_bf16
+struct hipshim_bf16 {
+    uint16_t bits;
+    hipshim_bf16() = default;
+    explicit hipshim_bf16(float f) : bits(__float2bfloat16(f).bits) {}
+    explicit operator float() const { __hip_bfloat16 h; h.bits = bits; return __bfloat162float(h); }
+};
+
+template <typename T, int N> struct alignas(sizeof(T) * N) hipshim_vec {
+    T v[N];
+    T &operator[](int i) { return v[i]; }
+    const T &operator[](int i) const { return v[i]; }
+};
+typedef hipshim_vec<__bf16, 8> bf16x8;
+typedef hipshim_vec<__bf16, 4> bf16x4;
+struct f32x16 {
+    float v[16];
+    float &operator[](int i) { return v[i]; }
+    const float &operator[](int i) const { return v[i]; }
+};
+
+namespace hipshim {
+extern float mfma_a[1024][8], mfma_b[1024][8];
+unsigned char *dynamic_lds();
+}  // namespace hipshim
+
+inline f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c)
+{
+    const int me = threadIdx.x, base = hipshim::lane_base(), lane = me - base;
+    for (int i = 0; i < 8; ++i) {
+        hipshim::mfma_a[me][i] = static_cast<float>(a[i]);
+        hipshim::mfma_b[me][i] = static_cast<float>(b[i]);
+    }
+    hipshim::sync_wave();
+    const int col = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k)
+            acc += hipshim::mfma_a[base + row + 32 * (k >> 3)][k & 7] * hipshim::mfma_b[base + col + 32 * (k >> 3)][k & 7];
+        c[r] = acc;
+    }
+    hipshim::sync_wave();
+    return c;
+}
+
+inline void wave_sync() { hipshim::sync_wave(); }
+
+#define MDETR_DYNAMIC_LDS(type, name) type *name = reinterpret_cast<type *>(hipshim::dynamic_lds())

@@ -4,6 +4,7 @@ the PyTorch criterion and its autograd, on the CPU through the host build of the
 import pytest
 import torch
 
+import backends
 import native_host
 from model_init import load_cfg
 
@@ -37,15 +38,15 @@ def _problem(L, B, Q, K, G, seed, empty_image=True):
     return preds, gt
 
 
-@pytest.fixture()
-def criterion():
+@pytest.fixture(params=backends.BACKENDS)
+def criterion(request):
     from monodetr_amd import ddn_loss_ext, lsa_ext, pair_losses_ext
     from monodetr_amd.monodetr import build_monodetr
     torch.manual_seed(0)
     cfg = load_cfg()
     _, crit = build_monodetr(cfg)
     crit.train()
-    pair_losses_ext._backend = ddn_loss_ext._backend = lsa_ext._backend = native_host.lib()
+    pair_losses_ext._backend = ddn_loss_ext._backend = lsa_ext._backend = backends.get(request.param)
     yield crit
     pair_losses_ext._backend = ddn_loss_ext._backend = lsa_ext._backend = None
 
@@ -97,15 +98,16 @@ def test_fused_pair_losses_with_a_device_normaliser_and_no_targets(criterion):
     assert float(leaves['pred_boxes'].grad.abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("backend", backends.BACKENDS)
 @pytest.mark.parametrize("layout", ["contiguous", "channels_last"])
-def test_fused_ddn_loss_matches_the_pytorch_ddn_loss(layout):
+def test_fused_ddn_loss_matches_the_pytorch_ddn_loss(layout, backend):
     """csrc/ddn_loss_math.h (host build) == DDNLoss (box painting, LID bins, focal loss with the +1e-6 one-hot,
     fg/bg balancer): value and the gradient w.r.t. all depth logits; boxes that leave the image, overlap
     (nearest object wins), an image without objects, padded slots."""
     from monodetr_amd import ddn_loss_ext
     from monodetr_amd.monodetr.depth_predictor.ddn_loss import DDNLoss
     from monodetr_amd.utils import box_ops
-    ddn_loss_ext._backend = native_host.lib()
+    ddn_loss_ext._backend = backends.get(backend)
     try:
         g = torch.Generator().manual_seed(3)
         B, C, H, W, K = 3, 81, 24, 80, 6
@@ -139,15 +141,17 @@ def test_fused_ddn_loss_matches_the_pytorch_ddn_loss(layout):
         ddn_loss_ext._backend = None
 
 
-def test_fused_matching_cost_and_serial_solver_match_scipy_on_the_pytorch_cost():
-    """pl_match_cost (the cost evaluated inside the device solver) against matcher.cost_padded, through the
-    host build: the assignments equal scipy's on the PyTorch cost matrix (total cost equal where an optimum
-    is not unique)."""
+@pytest.mark.parametrize("backend", backends.BACKENDS)
+def test_fused_matching_cost_and_solver_match_scipy_on_the_pytorch_cost(backend):
+    """pl_match_cost (the cost evaluated inside the device solver) against matcher.cost_padded: the assignments
+    equal scipy's on the PyTorch cost matrix (total cost equal where an optimum is not unique).  "host": a serial
+    copy of the solver around the shared cost arithmetic; "emul": the real lsa.hip kernel (wave argmin, LDS duals)
+    with the fused cost, on the HIP-on-CPU shim."""
     import numpy as np
     from scipy.optimize import linear_sum_assignment
     from monodetr_amd import lsa_ext
     from monodetr_amd.monodetr import build_monodetr
-    lsa_ext._backend = native_host.lib()
+    lsa_ext._backend = backends.get(backend)
     try:
         _, crit = build_monodetr(load_cfg())
         m = crit.matcher

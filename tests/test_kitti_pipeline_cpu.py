@@ -103,11 +103,11 @@ CFG = {'type': 'KITTI', 'aug_pd': True, 'aug_crop': True, 'random_flip': 0.5, 'r
        'batch_size': 3}
 
 
-@pytest.fixture()
-def host_backend():
-    import native_host
+@pytest.fixture(params=["host", "emul"])
+def host_backend(request):
+    import backends
     from monodetr_amd import kitti_prep_ext
-    kitti_prep_ext._backend = native_host.lib()
+    kitti_prep_ext._backend = backends.get(request.param)
     yield kitti_prep_ext
     kitti_prep_ext._backend = None
 

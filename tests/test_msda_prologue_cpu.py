@@ -5,6 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+import backends
 import native_host
 
 
@@ -22,10 +23,10 @@ def torch_prologue(offsets, logits, ref, shapes, P):
     return loc, weights
 
 
-@pytest.fixture()
-def backend():
+@pytest.fixture(params=backends.BACKENDS)
+def backend(request):
     from monodetr_amd import msda_prologue_ext
-    msda_prologue_ext._backend = native_host.lib()
+    msda_prologue_ext._backend = backends.get(request.param)
     yield msda_prologue_ext
     msda_prologue_ext._backend = None
 

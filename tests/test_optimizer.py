@@ -1,4 +1,5 @@
 """AdamW mirror vs six recorded steps of the reference's AdamW (tests/golden/optimizer_adamw.npz)."""
+import pytest
 import torch
 
 from conftest import load_golden
@@ -72,26 +73,28 @@ def test_capturable_mode_matches_host_step_size():
     assert max(float(t) for t in opt.param_groups[0]['step_dev'].values()) == 6.0
 
 
-def _fused(params_or_model, **kw):
-    """FusedAdamW wired to the HOST build of the kernel arithmetic (tests/native) so that the flat
-    layout logic and the update formula run on CPU tensors."""
-    import native_host
+def _fused(params_or_model, backend="host", **kw):
+    """FusedAdamW wired to a CPU stand-in for the library (tests/backends.py: the host build of the kernel
+    arithmetic, or the real adamw.hip on the HIP-on-CPU shim) so that the flat layout logic and the update
+    run on CPU tensors."""
+    import backends
     from monodetr_amd.helpers.optimizer_helper import FusedAdamW, build_optimizer
     if isinstance(params_or_model, torch.nn.Module):
         opt = build_optimizer({'type': 'adamw', 'lr': 2e-4, 'weight_decay': 1e-4, 'fused': True, **kw}, params_or_model)
     else:
         opt = FusedAdamW(params_or_model, **kw)
     assert isinstance(opt, FusedAdamW)
-    opt._lib, opt._allow_cpu = native_host.lib(), True
+    opt._lib, opt._allow_cpu = backends.get(backend), True
     return opt
 
 
-def test_fused_adamw_matches_reference_steps_fp32():
+@pytest.mark.parametrize("backend", ["host", "emul"])
+def test_fused_adamw_matches_reference_steps_fp32(backend):
     """One launch per (group, dtype) over flat buffers == six recorded steps of the reference's AdamW
     (fp32 arithmetic against the fp64 recording: 1e-6 relative)."""
     g = load_golden("optimizer_adamw")
     shadow, model = make_model(), make_model().float()          # the recorded gradients are float64 draws
-    opt = _fused(model)
+    opt = _fused(model, backend)
     for step in range(6):
         make_grads(shadow, step)
         for ps, p in zip(shadow.parameters(), model.parameters()):
@@ -108,7 +111,8 @@ def test_fused_adamw_matches_reference_steps_fp32():
     assert sd['state'][0]['exp_avg'].shape == opt.param_groups[0]['params'][0].shape
 
 
-def test_fused_adamw_equals_foreach_adamw_on_mixed_layouts_and_dtypes():
+@pytest.mark.parametrize("backend", ["host", "emul"])
+def test_fused_adamw_equals_foreach_adamw_on_mixed_layouts_and_dtypes(backend):
     """Same trajectory as the multi-tensor AdamW for fp32 + bf16 parameters, a channels_last 4-d weight,
     odd sizes (padding) and a parameter that never gets a gradient; then a state_dict round trip."""
     from monodetr_amd.helpers.optimizer_helper import AdamW
@@ -126,7 +130,7 @@ def test_fused_adamw_equals_foreach_adamw_on_mixed_layouts_and_dtypes():
 
     pa, ga = make()
     pb, gb = make()
-    oa, ob = AdamW(ga, lr=1e-3), _fused(gb, lr=1e-3)
+    oa, ob = AdamW(ga, lr=1e-3), _fused(gb, backend, lr=1e-3)
     for step in range(5):
         gen = torch.Generator().manual_seed(100 + step)
         for x, y in zip(pa[:4], pb[:4]):
@@ -145,7 +149,7 @@ def test_fused_adamw_equals_foreach_adamw_on_mixed_layouts_and_dtypes():
     assert pb[4].grad is None and 'exp_avg' not in ob.state[pb[4]]
     # state_dict round trip into a fresh fused optimizer continues the same trajectory
     pc, gc = make()
-    oc = _fused(gc, lr=1e-3)
+    oc = _fused(gc, backend, lr=1e-3)
     with torch.no_grad():
         for y, z in zip(pb, pc):
             z.copy_(y)
