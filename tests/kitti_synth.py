@@ -25,12 +25,12 @@ def synth_image(rs, w, h):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
-def synth_label_lines(rs, w, h, n):
+def synth_label_lines(rs, w, h, n, occ_choices=None):
     lines = []
     for _ in range(n):
         cls = CLASSES[rs.randint(len(CLASSES))]
         trunc = -1 if cls == 'DontCare' else round(float(rs.choice([0, 0, 0.1, 0.3, 0.6])), 2)
-        occ = -1 if cls == 'DontCare' else int(rs.randint(0, 4))
+        occ = -1 if cls == 'DontCare' else (int(rs.randint(0, 4)) if occ_choices is None else int(rs.choice(occ_choices)))
         z = float(rs.uniform(1.0, 75.0))
         x = float(rs.uniform(-0.5, 0.5) * z * 1.2)
         y = float(rs.uniform(1.2, 2.0))
@@ -59,7 +59,7 @@ def synth_calib_lines(rs):
             fmt('Tr_velo_to_cam', rt), fmt('Tr_imu_to_velo', rt)]
 
 
-def make_tree(root, n_images=6, seed=7):
+def make_tree(root, n_images=6, seed=7, images=True, occ_choices=None):
     """Writes root/{ImageSets/train.txt, training/{image_2,label_2,calib}/%06d.*}; returns the list of ids."""
     rs = np.random.RandomState(seed)
     for d in ('ImageSets', 'training/image_2', 'training/label_2', 'training/calib'):
@@ -68,10 +68,11 @@ def make_tree(root, n_images=6, seed=7):
     for k in range(n_images):
         idx = 3 * k + 1
         w, h = SIZES[k % len(SIZES)]
-        Image.fromarray(synth_image(rs, w, h)).save(os.path.join(root, 'training/image_2/%06d.png' % idx))
+        if images:
+            Image.fromarray(synth_image(rs, w, h)).save(os.path.join(root, 'training/image_2/%06d.png' % idx))
         n = 0 if k == 4 else int(rs.randint(1, 9))                    # one image without objects
         with open(os.path.join(root, 'training/label_2/%06d.txt' % idx), 'w') as f:
-            f.write('\n'.join(synth_label_lines(rs, w, h, n)) + ('\n' if n else ''))
+            f.write('\n'.join(synth_label_lines(rs, w, h, n, occ_choices)) + ('\n' if n else ''))
         with open(os.path.join(root, 'training/calib/%06d.txt' % idx), 'w') as f:
             f.write('\n'.join(synth_calib_lines(rs)) + '\n')
         ids.append('%06d' % idx)
