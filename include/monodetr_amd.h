@@ -329,6 +329,41 @@ int mdetr_kitti_preprocess(const uint8_t *pixels, const MdetrKittiImage *images,
                            int device, void *stream);
 
 /*
+ * KITTI evaluation: rotated-box overlaps on the device, the serial statistics on the host.
+ *
+ * mdetr_rotate_iou_eval replaces rotate_iou_gpu_eval (lib/datasets/kitti/kitti_eval_python/rotate_iou.py:262-330);
+ * mdetr_box3d_overlap_eval additionally folds in d3_box_overlap_kernel (eval.py:195-228).  Both are SEGMENTED: frame f
+ * owns boxes [box_start[f], box_start[f+1]) and query boxes [qbox_start[f], qbox_start[f+1]) and its row-major
+ * [n_f, k_f] block of `out` starts at out_start[f] (out_start[n_frames] = total number of pairs), so one launch covers
+ * a whole split and only within-frame pairs are computed (the reference evaluates all pairs of 50-frame parts).
+ *   boxes / qboxes   device; float [., 5] (x, y, dx, dy, angle)  resp.  double [., 7] (x, y, z, l, h, w, ry; camera)
+ *   *_start          device int64 [n_frames + 1]
+ *   criterion        -1 IoU, 0 / 1 intersection over the query box's / the box's area (volume), 2 intersection
+ *   out[n, k]        overlap of box n with query box k, evaluated as devRotateIoUEval(query box, box) (:293-296)
+ */
+int mdetr_rotate_iou_eval(const float *boxes, const float *qboxes, const int64_t *box_start, const int64_t *qbox_start,
+                          const int64_t *out_start, int n_frames, int64_t total_pairs, int criterion, float *out,
+                          int device, void *stream);
+int mdetr_box3d_overlap_eval(const double *boxes, const double *qboxes, const int64_t *box_start, const int64_t *qbox_start,
+                             const int64_t *out_start, int n_frames, int64_t total_pairs, int criterion, double *out,
+                             int device, void *stream);
+/*
+ * HOST function (no device work): precision / recall accumulation of one (class, difficulty, metric, overlap) cell of
+ * eval_class (eval.py:563-620) -- compute_statistics_jit over all frames, get_thresholds, fused_compute_statistics.
+ *   overlaps     frame f: [nd_f, ng_f] row-major at ov_start[f] (detections x ground truths)
+ *   gt_datas     [sum ng, 5] (bbox, alpha);  dt_datas [sum nd, 6] (bbox, alpha, score);  *_start int64 [n_frames + 1]
+ *   ignored_*    int64 per box: 0 counts, 1 neutral, -1 other class (clean_data, eval.py:30-82)
+ *   dontcares    [sum ndc, 4]
+ *   pr           out, [n_thresholds, 4] = tp, fp, fn, orientation similarity per recall threshold
+ *   thresholds   out, [n_thresholds] (<= max_thresholds, 41 in the reference)
+ */
+int mdetr_kitti_pr_curve(const double *overlaps, const int64_t *ov_start, const double *gt_datas, const double *dt_datas,
+                         const int64_t *gt_start, const int64_t *dt_start, const int64_t *ignored_gt,
+                         const int64_t *ignored_det, const double *dontcares, const int64_t *dc_start, int n_frames,
+                         int metric, double min_overlap, int64_t num_valid_gt, int compute_aos, int max_thresholds,
+                         double *pr, double *thresholds, int *n_thresholds);
+
+/*
  * Column sums of a tall row-major matrix, accumulated in fp32: out[j] = sum_i x[i * ld + j].
  * Not an entry point of the reference's extension: it is the bias gradient of the model's token-wise
  * linear layers (db = sum over the 81 600 tokens of dY; torch's autograd computes it with a generic

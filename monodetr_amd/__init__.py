@@ -33,6 +33,12 @@ def install(force=False):
         "utils.misc": ".utils.misc",
         "utils.box_ops": ".utils.box_ops",
         "lib.helpers.dataloader_helper": ".helpers.dataloader_helper",
+        "lib.helpers.decode_helper": ".helpers.decode_helper",
+        "lib.helpers.tester_helper": ".helpers.tester_helper",
+        "lib.helpers.save_helper": ".helpers.save_helper",
+        "lib.datasets.kitti.kitti_eval_python.eval": ".datasets.kitti.kitti_eval_python.eval",
+        "lib.datasets.kitti.kitti_eval_python.kitti_common": ".datasets.kitti.kitti_eval_python.kitti_common",
+        "lib.datasets.kitti.kitti_eval_python.rotate_iou": ".datasets.kitti.kitti_eval_python.rotate_iou",
         "lib.datasets.utils": ".datasets.utils",
         "lib.datasets.kitti.kitti_utils": ".datasets.kitti.kitti_utils",
         "lib.datasets.kitti.kitti_dataset": ".datasets.kitti.kitti_dataset",

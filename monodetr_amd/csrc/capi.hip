@@ -18,6 +18,7 @@
 #include "kitti_prep.h"
 #include "lsa.h"
 #include "pair_losses.h"
+#include "rotate_iou.h"
 #include "token_gemm.h"
 #include "msda.h"
 #include "msda_prologue.h"
@@ -443,6 +444,43 @@ int mdetr_column_sum(int dtype, const void *x, float *out, void *workspace, int6
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_column_sum: set device %d: %s", device, hipGetErrorString(dev.err));
     const hipError_t e = mdetr::colsum_launch(dtype, x, out, workspace, rows, cols, ld, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_column_sum: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+static int riou_args(const char *fn, const void *boxes, const void *qboxes, const int64_t *box_start, const int64_t *qbox_start,
+                     const int64_t *out_start, int n_frames, int64_t total_pairs, int criterion, const void *out)
+{
+    if (n_frames < 0 || total_pairs < 0) return fail(MDETR_E_ARG, "%s: negative size", fn);
+    if (criterion < -1 || criterion > 2) return fail(MDETR_E_ARG, "%s: criterion %d (expected -1, 0, 1 or 2)", fn, criterion);
+    if (total_pairs > 0 && (!boxes || !qboxes || !box_start || !qbox_start || !out_start || !out)) return fail(MDETR_E_ARG, "%s: null pointer", fn);
+    return MDETR_OK;
+}
+
+int mdetr_rotate_iou_eval(const float *boxes, const float *qboxes, const int64_t *box_start, const int64_t *qbox_start,
+                          const int64_t *out_start, int n_frames, int64_t total_pairs, int criterion, float *out,
+                          int device, void *stream)
+{
+    if (int rc = riou_args("mdetr_rotate_iou_eval", boxes, qboxes, box_start, qbox_start, out_start, n_frames, total_pairs, criterion, out)) return rc;
+    if (total_pairs == 0) return MDETR_OK;
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_rotate_iou_eval: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::rotate_iou_launch(boxes, qboxes, box_start, qbox_start, out_start, n_frames, total_pairs, criterion, out,
+                                                  static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_rotate_iou_eval: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_box3d_overlap_eval(const double *boxes, const double *qboxes, const int64_t *box_start, const int64_t *qbox_start,
+                             const int64_t *out_start, int n_frames, int64_t total_pairs, int criterion, double *out,
+                             int device, void *stream)
+{
+    if (int rc = riou_args("mdetr_box3d_overlap_eval", boxes, qboxes, box_start, qbox_start, out_start, n_frames, total_pairs, criterion, out)) return rc;
+    if (total_pairs == 0) return MDETR_OK;
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_box3d_overlap_eval: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::box3d_overlap_launch(boxes, qboxes, box_start, qbox_start, out_start, n_frames, total_pairs, criterion, out,
+                                                     static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_box3d_overlap_eval: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

@@ -11,7 +11,7 @@ the worker), this one returns the DECODED image and an 88-byte descriptor of wha
 
 ``helpers/dataloader_helper.py`` batches those, ships 1.4 MB instead of 5.9 MB per image over PCIe and produces the
 reference's ``inputs`` tensor on the GPU in one kernel launch (bit-identical, ``csrc/kitti_prep.hip``).
-``KITTI_Dataset.eval`` (KITTI AP) is not part of this path.
+``KITTI_Dataset.eval`` runs the official evaluation of ``kitti_eval_python`` (device overlaps, native statistics).
 """
 import os
 
@@ -122,6 +122,26 @@ class KITTI_Dataset(data.Dataset):
 
     def __len__(self):
         return len(self.idx_list)
+
+    def eval(self, results_dir, logger):
+        """Official KITTI evaluation of the result files in ``results_dir`` against this split's labels; logs the
+        report per class of the write-list and returns the car 3-D AP|R40 at moderate difficulty
+        (kitti_dataset.py:101-116)."""
+        from .kitti_eval_python import kitti_common as kitti
+        from .kitti_eval_python.eval import get_official_eval_result
+        logger.info("==> Loading detections and GTs...")
+        img_ids = [int(i) for i in self.idx_list]
+        dt_annos = kitti.get_label_annos(results_dir)
+        gt_annos = kitti.get_label_annos(self.label_dir, img_ids)
+        test_id = {'Car': 0, 'Pedestrian': 1, 'Cyclist': 2}
+        logger.info('==> Evaluating (official) ...')
+        car_moderate = 0
+        for category in self.writelist:
+            results_str, results_dict, mAP3d_R40 = get_official_eval_result(gt_annos, dt_annos, test_id[category])
+            if category == 'Car':
+                car_moderate = mAP3d_R40
+            logger.info(results_str)
+        return car_moderate
 
     # ---- one sample --------------------------------------------------------------------------
     def __getitem__(self, item):

@@ -18,3 +18,4 @@ env MDETR_FUSED_LOSSES=1 MDETR_FUSED_ADAMW=1 MDETR_MSDA_PROLOGUE=1 python bench.
 python -m monodetr_amd.tools.prepbench 2>&1 | tail -1 | tee $O/prepbench_fp32.json
 python -m monodetr_amd.tools.prepbench --dtype bf16 2>&1 | tail -1 | tee $O/prepbench_bf16.json
 python tests/prep_cpu_baseline.py | tee $O/prep_cpu_baseline.json
+python -m monodetr_amd.tools.evalbench 2>&1 | tail -1 | tee $O/evalbench.json

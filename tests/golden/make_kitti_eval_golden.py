@@ -43,6 +43,12 @@ def install_stubs():
     sys.modules['skimage'], sys.modules['skimage.io'] = sk, sk.io
     cv2 = types.ModuleType('cv2')
     sys.modules.setdefault('cv2', cv2)
+    tv = types.ModuleType('torchvision')
+    tv.ops = types.ModuleType('torchvision.ops')
+    tv.ops.boxes = types.ModuleType('torchvision.ops.boxes')
+    tv.ops.boxes.box_area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    for name, mod in (('torchvision', tv), ('torchvision.ops', tv.ops), ('torchvision.ops.boxes', tv.ops.boxes)):
+        sys.modules.setdefault(name, mod)
 
 
 def sample_boxes(rs, n):
@@ -101,6 +107,17 @@ def main():
         out['car_3d_precision'], out['car_3d_recall'] = ret['precision'], ret['recall']
         ret = ref_eval.eval_class(gt, dt, [0], [0, 1, 2], 0, np.array([[[0.7], [0.7], [0.7]], [[0.7], [0.5], [0.5]]]), compute_aos=True)
         out['car_bbox_precision'], out['car_bbox_aos'] = ret['precision'], ret['orientation']
+    # ---- decode path: lib/helpers/decode_helper.py (extract_dets_from_outputs, decode_detections) ----
+    from lib.helpers.decode_helper import decode_detections, extract_dets_from_outputs
+    from lib.datasets.kitti.kitti_utils import Calibration
+    outputs, p2, info = kitti_synth_dets.decode_problem()
+    dets = extract_dets_from_outputs(outputs, K=50, topk=50).numpy()
+    out['decode_dets'] = dets.copy()
+    calibs = [Calibration({'P2': p, 'R0': np.eye(3, dtype=np.float32), 'Tr_velo2cam': np.zeros((3, 4), dtype=np.float32)}) for p in p2]
+    res = decode_detections(dets.copy(), info, calibs, np.zeros((3, 3), dtype=np.float32), 0.2)
+    for img_id, preds in res.items():
+        out['decode_img%d' % img_id] = np.array(preds, dtype=np.float64).reshape(-1, 14)
+        print('decoded', img_id, len(preds))
     np.savez_compressed(os.path.join(HERE, 'kitti_eval.npz'), **out)
     print('wrote', os.path.join(HERE, 'kitti_eval.npz'))
 

@@ -38,3 +38,18 @@ def make_results(root, ids, out_dir, seed=3):
                 rs.uniform(1.3, 1.9), rs.uniform(1.4, 1.8), rs.uniform(3, 4.5), x, rs.uniform(1.3, 1.9), z, rs.uniform(-3, 3), rs.uniform(0.05, 0.7)))
         with open(os.path.join(out_dir, '%s.txt' % idx), 'w') as fh:
             fh.write('\n'.join(out) + ('\n' if out else ''))
+
+
+def decode_problem():
+    """Random head outputs of two images + their calibration, shared with the tests."""
+    import torch
+    g = torch.Generator().manual_seed(11)
+    B, Q = 2, 50
+    boxes = torch.cat([torch.rand(B, Q, 2, generator=g) * 0.6 + 0.2, torch.rand(B, Q, 4, generator=g) * 0.08 + 0.01], -1)
+    outputs = {'pred_logits': torch.randn(B, Q, 3, generator=g) * 1.5 - 2.5, 'pred_boxes': boxes,
+               'pred_angle': torch.randn(B, Q, 24, generator=g), 'pred_3d_dim': torch.rand(B, Q, 3, generator=g) * 2 + 1,
+               'pred_depth': torch.cat([torch.rand(B, Q, 1, generator=g) * 50 + 3, torch.randn(B, Q, 1, generator=g)], -1)}
+    p2 = [np.array([[721.54, 0, 609.56, 44.857], [0, 721.54, 172.85, 0.2164], [0, 0, 1, 0.002746]], dtype=np.float32),
+          np.array([[707.05, 0, 604.08, 45.757], [0, 707.05, 180.51, -0.3454], [0, 0, 1, 0.004981]], dtype=np.float32)]
+    info = {'img_id': np.array([1, 4]), 'img_size': np.array([[1242, 375], [1224, 370]])}
+    return outputs, p2, info

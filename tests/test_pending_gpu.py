@@ -410,3 +410,53 @@ def test_device_loader_yields_the_reference_loop_tuple(tmp_path):
     assert seen == 5
     n = sum(x.shape[0] for x, _, _, _ in train)                          # augmented, shuffled: runs and is finite
     assert n == 5 and all(torch.isfinite(x).all() for x, _, _, _ in train)
+
+
+# ---- KITTI evaluation on the device ---------------------------------------------------------------
+def test_rotated_overlap_kernels_match_the_oracle_on_the_gpu():
+    import numpy as np
+    from monodetr_amd.datasets.kitti.kitti_eval_python import rotate_iou
+    from oracle import kitti_eval as oke
+    rs = np.random.RandomState(5)
+    frames_b, frames_q = [], []
+    for f in range(7):
+        n, k = [(5, 9), (0, 3), (12, 1), (3, 0), (8, 8), (1, 1), (20, 17)][f]
+        mk = lambda m: np.stack([rs.uniform(-4, 4, m), rs.uniform(8, 16, m), rs.uniform(1.4, 4.5, m), rs.uniform(1.4, 4.5, m), rs.uniform(-3.2, 3.2, m)], 1)
+        frames_b.append(mk(n)); frames_q.append(mk(k))
+    frames_q[5] = frames_b[5].copy()                                    # identical boxes
+    for crit in (-1, 0, 1, 2):
+        got = rotate_iou.segmented_rotate_iou(frames_b, frames_q, crit)
+        for b, q, o in zip(frames_b, frames_q, got):
+            assert o.shape == (len(b), len(q)) and o.dtype == np.float32
+            assert np.array_equal(o, oke.rotate_iou(b.astype(np.float32), q.astype(np.float32), crit))      # float32, same operations
+    b7 = [np.concatenate([b[:, :1], rs.uniform(1.2, 2, (len(b), 1)), b[:, 1:2], b[:, 2:3], rs.uniform(1.3, 2, (len(b), 1)), b[:, 3:]], 1) for b in frames_b]
+    q7 = [np.concatenate([q[:, :1], rs.uniform(1.2, 2, (len(q), 1)), q[:, 1:2], q[:, 2:3], rs.uniform(1.3, 2, (len(q), 1)), q[:, 3:]], 1) for q in frames_q]
+    for crit in (-1, 0, 1):
+        got = rotate_iou.segmented_box3d_overlap(b7, q7, crit)
+        for b, q, o in zip(b7, q7, got):
+            assert np.array_equal(o, oke.d3_box_overlap(b, q, crit).reshape(len(b), len(q)))
+    one = rotate_iou.rotate_iou_gpu_eval(frames_b[6], frames_q[6])
+    assert one.dtype == np.float64 and np.array_equal(one.astype(np.float32), got_first(frames_b[6], frames_q[6]))
+
+
+def got_first(b, q):
+    from oracle import kitti_eval as oke
+    return oke.rotate_iou(b.astype('float32'), q.astype('float32'), -1)
+
+
+def test_official_evaluation_on_the_gpu_matches_the_recorded_reference_report(tmp_path):
+    import numpy as np
+    import kitti_synth
+    import kitti_synth_dets
+    from monodetr_amd.datasets.kitti.kitti_eval_python import eval as kitti_eval
+    from monodetr_amd.datasets.kitti.kitti_eval_python import kitti_common
+    root = str(tmp_path)
+    ids = kitti_synth.make_tree(root, n_images=40, seed=21, images=False, occ_choices=[0, 0, 0, 1, 2, 3])
+    kitti_synth_dets.make_results(root, ids, os.path.join(root, 'results'), seed=3)
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'kitti_eval.npz'))
+    dt = kitti_common.get_label_annos(os.path.join(root, 'results'))
+    gt = kitti_common.get_label_annos(os.path.join(root, 'training', 'label_2'), [int(i) for i in ids])
+    for cls in (0, 1, 2):
+        text, ret, moderate = kitti_eval.get_official_eval_result(gt, dt, cls)
+        assert text == str(g['cls%d_text' % cls])
+        assert abs(moderate - float(g['cls%d_ap3d_r40_moderate' % cls])) < 1e-12
