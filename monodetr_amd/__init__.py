@@ -33,6 +33,11 @@ def install(force=False):
         "utils.misc": ".utils.misc",
         "utils.box_ops": ".utils.box_ops",
         "lib.helpers.dataloader_helper": ".helpers.dataloader_helper",
+        "lib.helpers.model_helper": ".helpers.model_helper",
+        "lib.helpers.utils_helper": ".helpers.utils_helper",
+        "lib.helpers.scheduler_helper": ".helpers.scheduler_helper",
+        "lib.helpers.trainer_helper": ".helpers.trainer_helper",
+        "lib.helpers.optimizer_helper": ".helpers.optimizer_helper",
         "lib.helpers.decode_helper": ".helpers.decode_helper",
         "lib.helpers.tester_helper": ".helpers.tester_helper",
         "lib.helpers.save_helper": ".helpers.save_helper",

@@ -64,6 +64,7 @@ class DeviceLoader:
     def __init__(self, loader, device, dtype=torch.float32, out_hw=(384, 1280)):
         self.loader, self.device, self.dtype, self.out_hw = loader, torch.device(device), dtype, out_hw
         self.dataset = loader.dataset
+        self.sampler = loader.sampler
         self._stream = None
 
     def __len__(self):
@@ -109,15 +110,21 @@ class DeviceLoader:
         return batch
 
 
-def build_dataloader(cfg, workers=4, device=None, dtype=torch.float32):
+def build_dataloader(cfg, workers=4, device=None, dtype=torch.float32, world_size=1, rank=0):
+    """``(train_loader, test_loader)`` as the reference's function; ``world_size`` / ``rank`` shard the TRAINING split
+    across data-parallel processes (``DistributedSampler``; the caller advances ``loader.sampler.set_epoch``)."""
     if cfg['type'] != 'KITTI':
         raise NotImplementedError("%s dataset is not supported" % cfg['type'])
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
     loaders = []
     for split, shuffle in ((cfg['train_split'], True), (cfg['test_split'], False)):
-        dl = DataLoader(dataset=KITTI_Dataset(split=split, cfg=cfg), batch_size=cfg['batch_size'], num_workers=workers,
-                        worker_init_fn=my_worker_init_fn, shuffle=shuffle, pin_memory=False, drop_last=False,
+        dataset = KITTI_Dataset(split=split, cfg=cfg)
+        sampler = None
+        if shuffle and world_size > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world_size, rank=rank, shuffle=True)
+        dl = DataLoader(dataset=dataset, batch_size=cfg['batch_size'], num_workers=workers, worker_init_fn=my_worker_init_fn,
+                        shuffle=shuffle and sampler is None, sampler=sampler, pin_memory=False, drop_last=False,
                         collate_fn=collate_packed)
         loaders.append(DeviceLoader(dl, device, dtype))
     return loaders[0], loaders[1]

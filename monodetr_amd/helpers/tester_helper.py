@@ -53,7 +53,7 @@ class Tester(object):
             outputs = self.model(inputs, calibs, targets, img_sizes, dn_args=0)
             model_time += time.time() - start
             dets = extract_dets_from_outputs(outputs=outputs, K=self.max_objs, topk=self.cfg['topk'])
-            dets = dets.detach().cpu().numpy()
+            dets = dets.detach().float().cpu().numpy()
             frame_calibs = [dataset.get_calib(int(index)) for index in info['img_id']]
             info_np = {key: val.detach().cpu().numpy() for key, val in info.items()}
             results.update(decode_detections(dets=dets, info=info_np, calibs=frame_calibs, cls_mean_size=dataset.cls_mean_size,

@@ -1,0 +1,122 @@
+"""``Trainer`` -- mirror of ``lib/helpers/trainer_helper.py``: same constructor, ``train()``, ``train_one_epoch()``,
+checkpoint naming, resume / pretrain handling and best-result bookkeeping, around the iteration ``bench.py`` times.
+
+What differs from the reference loop (trainer_helper.py:116-173), and why:
+  * targets go from the collated batch to the criterion's static-shape form on the device
+    (``pad_targets_from_batch``) instead of ragged per-image lists -- no host synchronisation;
+  * the loss values are logged every ``log_every`` iterations from ONE device-to-host copy; the reference calls
+    ``.item()`` on each of the ~26 entries every iteration (26 synchronisations per step);
+  * with more than one process (torchrun, one per GPU) gradients are averaged by one flat all-reduce per dtype
+    (``dist_helper.FlatGradSync``) after the backward pass; the reference uses ``nn.DataParallel``
+    (tools/train_val.py:55).
+``prepare_targets`` is kept for callers that want the reference's ragged lists.
+"""
+import os
+
+import numpy as np
+import torch
+
+from ..monodetr.monodetr import pad_targets_from_batch
+from .save_helper import get_checkpoint_state, load_checkpoint, save_checkpoint
+
+
+class Trainer(object):
+    def __init__(self, cfg, model, optimizer, train_loader, test_loader, lr_scheduler, warmup_lr_scheduler, logger, loss,
+                 model_name, log_every=30):
+        self.cfg, self.model, self.optimizer = cfg, model, optimizer
+        self.train_loader, self.test_loader = train_loader, test_loader
+        self.lr_scheduler, self.warmup_lr_scheduler = lr_scheduler, warmup_lr_scheduler
+        self.logger, self.detr_loss, self.model_name = logger, loss, model_name
+        self.epoch, self.best_result, self.best_epoch = 0, 0, 0
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.output_dir = os.path.join('./' + cfg['save_path'], model_name)
+        self.tester = None
+        self.log_every = log_every
+        self.grad_sync = None
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            from .dist_helper import FlatGradSync, broadcast_parameters
+            broadcast_parameters(self.model)
+            self.grad_sync = FlatGradSync(self.model.parameters())
+
+        if cfg.get('pretrain_model'):
+            assert os.path.exists(cfg['pretrain_model'])
+            load_checkpoint(model=self.model, optimizer=None, filename=cfg['pretrain_model'], map_location=self.device, logger=self.logger)
+        if cfg.get('resume_model', None):
+            path = os.path.join(self.output_dir, "checkpoint.pth")
+            assert os.path.exists(path)
+            self.epoch, self.best_result, self.best_epoch = load_checkpoint(
+                model=self.model.to(self.device), optimizer=self.optimizer, filename=path, map_location=self.device, logger=self.logger)
+            self.lr_scheduler.last_epoch = self.epoch - 1
+            self.logger.info("Loading Checkpoint... Best Result:{}, Best Epoch:{}".format(self.best_result, self.best_epoch))
+
+    def _is_main(self):
+        return not (torch.distributed.is_available() and torch.distributed.is_initialized()) or torch.distributed.get_rank() == 0
+
+    def _save(self, name, best_result, best_epoch):
+        if self._is_main():
+            os.makedirs(self.output_dir, exist_ok=True)
+            save_checkpoint(get_checkpoint_state(self.model, self.optimizer, self.epoch, best_result, best_epoch),
+                            os.path.join(self.output_dir, name))
+
+    def train(self):
+        best_result, best_epoch = self.best_result, self.best_epoch
+        for epoch in range(self.epoch, self.cfg['max_epoch']):
+            np.random.seed(np.random.get_state()[1][0] + epoch)          # a different augmentation stream per epoch
+            if hasattr(getattr(self.train_loader, 'sampler', None), 'set_epoch'):
+                self.train_loader.sampler.set_epoch(epoch)                # data-parallel shards reshuffle together
+            self.train_one_epoch(epoch)
+            self.epoch += 1
+            if self.warmup_lr_scheduler is not None and epoch < 5:
+                self.warmup_lr_scheduler.step()
+            else:
+                self.lr_scheduler.step()
+            if (self.epoch % self.cfg['save_frequency']) == 0:
+                self._save('checkpoint_epoch_%d' % self.epoch if self.cfg['save_all'] else 'checkpoint', best_result, best_epoch)
+                if self.tester is not None:
+                    self.logger.info("Test Epoch {}".format(self.epoch))
+                    self.tester.inference()
+                    cur_result = self.tester.evaluate()
+                    if cur_result > best_result:
+                        best_result, best_epoch = cur_result, self.epoch
+                        self._save('checkpoint_best', best_result, best_epoch)
+                    self.logger.info("Best Result:{}, epoch:{}".format(best_result, best_epoch))
+        self.logger.info("Best Result:{}, epoch:{}".format(best_result, best_epoch))
+        self.best_result, self.best_epoch = best_result, best_epoch
+        return None
+
+    def train_step(self, inputs, calibs, targets, info=None):
+        """One iteration on a collated batch; returns the dict of unweighted loss tensors (on the device)."""
+        inputs, calibs = inputs.to(self.device, non_blocking=True), calibs.to(self.device, non_blocking=True)
+        targets = {k: v.to(self.device, non_blocking=True) for k, v in targets.items()}
+        img_sizes = targets['img_size']
+        if self.cfg.get("use_dn"):
+            raise NotImplementedError("denoising queries (use_dn) are off in configs/monodetr.yaml and not mirrored")
+        gt = pad_targets_from_batch(targets)
+        self.optimizer.zero_grad()
+        outputs = self.model(inputs, calibs, gt, img_sizes, dn_args=None)
+        losses = self.detr_loss(outputs, gt, None)
+        weights = self.detr_loss.weight_dict
+        total = sum(losses[k] * weights[k] for k in losses if k in weights)
+        total.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.sync()
+        self.optimizer.step()
+        return losses
+
+    def train_one_epoch(self, epoch):
+        torch.set_grad_enabled(True)
+        self.model.train()
+        weights = self.detr_loss.weight_dict
+        for batch_idx, (inputs, calibs, targets, info) in enumerate(self.train_loader):
+            losses = self.train_step(inputs, calibs, targets, info)
+            if batch_idx % self.log_every == 0 and self._is_main():
+                keys = [k for k in losses if k in weights]
+                vals = torch.stack([losses[k].detach().float() * weights[k] for k in keys]).cpu().tolist()     # one copy
+                self.logger.info("epoch %d iter %d  loss_detr: %.2f  %s" % (
+                    epoch, batch_idx, sum(vals), ", ".join("%s: %.2f" % kv for kv in zip(keys, vals) if not kv[0][-1].isdigit())))
+
+    def prepare_targets(self, targets, batch_size):
+        """The reference's ragged form: one dict per image holding the objects kept by ``mask_2d``."""
+        keys = ('labels', 'boxes', 'calibs', 'depth', 'size_3d', 'heading_bin', 'heading_res', 'boxes_3d')
+        mask = targets['mask_2d']
+        return [{k: v[b][mask[b]] for k, v in targets.items() if k in keys} for b in range(batch_size)]

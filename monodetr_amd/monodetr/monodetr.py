@@ -231,6 +231,38 @@ def pad_targets(targets, kmax=None):
     return gt
 
 
+def pad_targets_from_batch(targets):
+    """The loader's collated targets (``[B, 50, ...]`` tensors + ``mask_2d``, kitti_dataset.py:299-312) -> the padded
+    dict of ``pad_targets`` with K = 50, WITHOUT leaving the device: where the reference's trainer builds ragged
+    per-image lists with boolean indexing (``val[bz][mask[bz]]``, trainer_helper.py:175-186: one host
+    synchronisation per image and key), the kept objects are moved to the front of each row by a stable sort of
+    the mask, in the same order, and the rest of the row becomes padding."""
+    mask = targets["mask_2d"].bool()
+    B, K = mask.shape
+    order = torch.argsort((~mask).to(torch.int8), dim=1, stable=True)            # kept slots first, original order
+    num = mask.sum(1).to(torch.int32)
+    valid = torch.arange(K, device=mask.device)[None, :] < num[:, None]
+    fdt = targets["boxes_3d"].dtype
+
+    def take(key, dtype, fill):
+        t = targets[key]
+        t = t.reshape(B, K, -1)
+        t = torch.gather(t, 1, order[..., None].expand(-1, -1, t.shape[-1])).to(dtype)
+        pad = torch.as_tensor(fill, dtype=dtype, device=t.device).expand_as(t)
+        return torch.where(valid[..., None], t, pad)
+
+    return {
+        "labels": take("labels", torch.int64, 0)[..., 0],
+        "boxes": take("boxes", fdt, (0.0, 0.0, 0.0, 0.0)),
+        "boxes_3d": take("boxes_3d", fdt, _DUMMY_BOX3D),
+        "depth": take("depth", fdt, 1.0)[..., 0],
+        "size_3d": take("size_3d", fdt, (1.0, 1.0, 1.0)),
+        "heading_bin": take("heading_bin", torch.int64, 0)[..., 0],
+        "heading_res": take("heading_res", fdt, 0.0)[..., 0],
+        "valid": valid, "num": num, "num_host": None,
+    }
+
+
 def assignment_from_indices(indices, gt, Q, group_num):
     """Reference-style matcher output (per image (query idx, target idx)) -> [B, G, K] int64, -1 = none."""
     B, K = gt["valid"].shape

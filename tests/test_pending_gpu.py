@@ -460,3 +460,36 @@ def test_official_evaluation_on_the_gpu_matches_the_recorded_reference_report(tm
         text, ret, moderate = kitti_eval.get_official_eval_result(gt, dt, cls)
         assert text == str(g['cls%d_text' % cls])
         assert abs(moderate - float(g['cls%d_ap3d_r40_moderate' % cls])) < 1e-12
+
+
+# ---- the whole pipeline: loader -> training -> checkpoint -> inference -> result files -> official evaluation --------
+def test_train_val_entry_point_end_to_end(tmp_path, monkeypatch):
+    import yaml
+    import kitti_synth
+    from model_init import MODEL_CFG
+    from monodetr_amd.tools import train_val
+    monkeypatch.chdir(tmp_path)
+    root = str(tmp_path / 'kitti')
+    ids = kitti_synth.make_tree(root, n_images=4, seed=5, occ_choices=[0, 0, 1])
+    cfg = {
+        'random_seed': 444, 'model_name': 'monodetr',
+        'dataset': {'type': 'KITTI', 'root_dir': root, 'train_split': 'train', 'test_split': 'val', 'batch_size': 2, 'use_3d_center': True,
+                    'writelist': ['Car'], 'aug_pd': True, 'aug_crop': True, 'random_flip': 0.5, 'random_crop': 0.5, 'scale': 0.05,
+                    'shift': 0.05, 'depth_scale': 'normal'},
+        'model': dict(MODEL_CFG, device='cuda'),
+        'optimizer': {'type': 'adamw', 'lr': 2e-4, 'weight_decay': 1e-4},
+        'lr_scheduler': {'type': 'step', 'warmup': False, 'decay_rate': 0.1, 'decay_list': [125, 165]},
+        'trainer': {'max_epoch': 2, 'gpu_ids': '0', 'save_frequency': 1, 'save_path': 'outputs/', 'save_all': False, 'use_dn': False,
+                    'precision': 'bf16'},
+        'tester': {'type': 'KITTI', 'mode': 'single', 'checkpoint': 2, 'threshold': 0.0, 'topk': 50},
+    }
+    path = str(tmp_path / 'cfg.yaml')
+    yaml.safe_dump(cfg, open(path, 'w'))
+    train_val.main(['--config', path])
+    out = tmp_path / 'outputs' / 'monodetr'
+    assert (out / 'checkpoint.pth').exists() and (out / 'checkpoint_best.pth').exists()
+    files = sorted(os.listdir(out / 'outputs' / 'data'))
+    assert files == ['%s.txt' % i for i in ids]
+    line = open(out / 'outputs' / 'data' / files[0]).readline().split(' ')
+    assert len(line) == 16 and line[0] in ('Pedestrian', 'Car', 'Cyclist')
+    train_val.main(['--config', path, '-e'])                            # evaluation only, from checkpoint_best.pth
