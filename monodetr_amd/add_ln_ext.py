@@ -1,0 +1,97 @@
+"""``residual_layernorm(a, b, norm, dropout)``: ``norm(a + dropout(b))`` in one launch each way
+(csrc/add_ln.hip through ``mdetr_add_layernorm_forward / _backward``) -- the model's ten residual sites.
+The dropout decision is a hash of (device-resident seed, element index); no mask tensor exists."""
+import os
+
+import torch
+import torch.nn.functional as F
+
+from . import _capi
+from .attn_ext import _next_seed
+
+_backend = None               # tests substitute the CPU emulation of the same kernel source (tests/native_emul.py)
+# MDETR_FUSED_LN=1 routes the residual sites through the kernel; off until it has run on a GPU
+ENABLED = os.environ.get("MDETR_FUSED_LN") == "1"
+
+
+def _lib():
+    return _backend if _backend is not None else _capi.lib()
+
+
+def supported(a, b, norm):
+    return ((a.is_cuda or _backend is not None) and a.dtype in (torch.float32, torch.bfloat16) and b.dtype == a.dtype
+            and a.shape == b.shape and a.shape[-1] in (128, 256, 512) and len(norm.normalized_shape) == 1
+            and norm.normalized_shape[0] == a.shape[-1] and norm.elementwise_affine and norm.bias is not None)
+
+
+def _dev(t):
+    cuda = t.is_cuda
+    return (t.device.index if cuda else -1), (torch.cuda.current_stream(t.device).cuda_stream if cuda else None)
+
+
+def _column_sum_f32(x):
+    """fp32 [rows, n] -> [n] (the partial gamma / beta sums; at most 1024 rows)."""
+    if x.is_cuda and _backend is None:
+        from .colsum_ext import column_sum
+        return column_sum(x)
+    return x.sum(0)
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, gamma, beta, eps, p, seed, seed_dev):
+        shape = a.shape
+        C = shape[-1]
+        a2, b2 = a.reshape(-1, C).contiguous(), b.reshape(-1, C).contiguous()
+        rows = a2.shape[0]
+        g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
+        y, s = torch.empty_like(a2), torch.empty_like(a2)
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=a.device)
+        io = _capi.MDETR_BF16 if a.dtype == torch.bfloat16 else _capi.MDETR_F32
+        dev, stream = _dev(a2)
+        rc = _lib().mdetr_add_layernorm_forward(io, a2.data_ptr(), b2.data_ptr(), g32.data_ptr(), b32.data_ptr(), y.data_ptr(), s.data_ptr(),
+                                                stats.data_ptr(), rows, C, float(eps), float(p), int(seed),
+                                                seed_dev.data_ptr() if seed_dev is not None else None, dev, stream)
+        if rc != 0:
+            _capi.check(rc, "mdetr_add_layernorm_forward")
+        ctx.save_for_backward(s, g32, stats)
+        ctx.seed_dev = seed_dev
+        ctx.meta = (io, rows, C, float(p), int(seed), shape, gamma.dtype, beta.dtype)
+        return y.view(shape)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        s, g32, stats = ctx.saved_tensors
+        io, rows, C, p, seed, shape, g_dtype, b_dtype = ctx.meta
+        dy2 = dy.reshape(-1, C).contiguous()
+        da, db = torch.empty_like(s), torch.empty_like(s)
+        lib = _lib()
+        nb = lib.mdetr_add_layernorm_partial_rows(rows)
+        partial = torch.empty((nb, 2 * C), dtype=torch.float32, device=s.device)
+        dev, stream = _dev(s)
+        rc = lib.mdetr_add_layernorm_backward(io, dy2.data_ptr(), s.data_ptr(), g32.data_ptr(), stats.data_ptr(), da.data_ptr(), db.data_ptr(),
+                                              partial.data_ptr(), rows, C, p, seed,
+                                              ctx.seed_dev.data_ptr() if ctx.seed_dev is not None else None, dev, stream)
+        if rc != 0:
+            _capi.check(rc, "mdetr_add_layernorm_backward")
+        sums = _column_sum_f32(partial)
+        return da.view(shape), db.view(shape), sums[:C].to(g_dtype), sums[C:].to(b_dtype), None, None, None, None
+
+
+def fused_add_layernorm(a, b, gamma, beta, eps=1e-5, dropout_p=0.0, seed=None):
+    """LayerNorm(a + dropout(b)) over the last dimension (128, 256 or 512 wide); ``seed`` fixes the mask (tests),
+    otherwise every call draws a fresh device-resident seed."""
+    seed_dev = None
+    if dropout_p > 0.0 and seed is None:
+        seed_dev = _next_seed(a.device)
+    return _AddLayerNorm.apply(a, b, gamma, beta, eps, dropout_p, seed or 0, seed_dev)
+
+
+def residual_layernorm(a, b, norm, dropout):
+    """``norm(a + dropout(b))`` for an ``nn.LayerNorm`` and an ``nn.Dropout`` module -- the fused kernel when
+    ``MDETR_FUSED_LN=1`` and the shapes allow, the three framework operators otherwise."""
+    if ENABLED and supported(a, b, norm):
+        p = dropout.p if (dropout is not None and dropout.training) else 0.0
+        return fused_add_layernorm(a, b, norm.weight, norm.bias, norm.eps, p)
+    return norm(a + (dropout(b) if dropout is not None else b))

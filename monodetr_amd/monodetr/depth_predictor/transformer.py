@@ -7,6 +7,7 @@ import copy
 import torch.nn.functional as F
 from torch import nn
 
+from ...add_ln_ext import residual_layernorm
 from ..attention import MultiheadAttention
 
 
@@ -36,9 +37,9 @@ class TransformerEncoderLayer(nn.Module):
 
     def forward(self, src, src_key_padding_mask, pos):
         qk = src if pos is None else src + pos
-        src = self.norm1(src + self.dropout1(self.self_attn(qk, qk, src, key_padding_mask=src_key_padding_mask)[0]))
+        src = residual_layernorm(src, self.self_attn(qk, qk, src, key_padding_mask=src_key_padding_mask)[0], self.norm1, self.dropout1)
         ff = self.linear2(self.dropout(self.activation(self.linear1(src))))
-        return self.norm2(src + self.dropout2(ff))
+        return residual_layernorm(src, ff, self.norm2, self.dropout2)
 
 
 class TransformerEncoder(nn.Module):

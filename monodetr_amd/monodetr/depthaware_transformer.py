@@ -24,6 +24,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
+from ..add_ln_ext import residual_layernorm
 from ..utils.misc import inverse_sigmoid, no_padding
 from .attention import MultiheadAttention as FusedMultiheadAttention
 from .linear import token_linear
@@ -87,12 +88,12 @@ class VisualEncoderLayer(nn.Module):
         else:
             h = self.dropout2(self.activation(token_linear(src, self.linear1.weight, self.linear1.bias)))
         ff = token_linear(h, self.linear2.weight, self.linear2.bias)
-        return self.norm2(src + self.dropout3(ff))
+        return residual_layernorm(src, ff, self.norm2, self.dropout3)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         attn = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
                               level_start_index, padding_mask)
-        return self.forward_ffn(self.norm1(src + self.dropout1(attn)))
+        return self.forward_ffn(residual_layernorm(src, attn, self.norm1, self.dropout1))
 
 
 class VisualEncoder(nn.Module):
@@ -175,7 +176,7 @@ class DepthAwareDecoderLayer(nn.Module):
 
     def forward_ffn(self, tgt):
         ff = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
-        return self.norm3(tgt + self.dropout4(ff))
+        return residual_layernorm(tgt, ff, self.norm3, self.dropout4)
 
     def _self_attention_inputs(self, x):
         """q = (Wqc + Wqp) x + b, k = (Wkc + Wkp) x + b : the four projections of the reference
@@ -196,7 +197,7 @@ class DepthAwareDecoderLayer(nn.Module):
         depth_tokens = depth_pos_embed.transpose(0, 1)
         # depth cross attention
         d = self.cross_attn_depth.forward_batch_first(tgt, depth_tokens, depth_tokens, mask_depth)
-        tgt = self.norm_depth(tgt + self.dropout_depth(d))
+        tgt = residual_layernorm(tgt, d, self.norm_depth, self.dropout_depth)
         # self attention: keys/queries from content+position, values = tgt itself
         q, k = self._self_attention_inputs(self.with_pos_embed(tgt, query_pos))
         v = tgt
@@ -206,11 +207,11 @@ class DepthAwareDecoderLayer(nn.Module):
             n = Nq // self.group_num
             q, k, v = (t.reshape(B * self.group_num, n, C) for t in (q, k, v))
         s = self.self_attn.forward_batch_first(q, k, v).reshape(B, Nq, C)
-        tgt = self.norm2(tgt + self.dropout2(s))
+        tgt = residual_layernorm(tgt, s, self.norm2, self.dropout2)
         # deformable cross attention into the visual memory
         c = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
                             level_start_index, src_padding_mask)
-        tgt = self.norm1(tgt + self.dropout1(c))
+        tgt = residual_layernorm(tgt, c, self.norm1, self.dropout1)
         return self.forward_ffn(tgt)
 
 

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(ROOT, "monodetr_amd", "csrc")
 SHIM = os.path.join(HERE, "native", "hipshim")
 OUT = os.path.join(HERE, "native", "_build", "libemul.so")
-KERNELS = ["capi", "pair_losses", "ddn_loss", "adamw", "msda_prologue", "kitti_prep", "colsum", "token_gemm", "msda", "msda_tiled", "lsa", "rotate_iou", "kitti_stats"]
+KERNELS = ["capi", "pair_losses", "ddn_loss", "adamw", "msda_prologue", "kitti_prep", "colsum", "token_gemm", "msda", "msda_tiled", "lsa", "rotate_iou", "kitti_stats", "add_ln"]
 
 _lib = None
 

@@ -493,3 +493,46 @@ def test_train_val_entry_point_end_to_end(tmp_path, monkeypatch):
     line = open(out / 'outputs' / 'data' / files[0]).readline().split(' ')
     assert len(line) == 16 and line[0] in ('Pedestrian', 'Car', 'Cyclist')
     train_val.main(['--config', path, '-e'])                            # evaluation only, from checkpoint_best.pth
+
+
+# ---- fused residual + dropout + LayerNorm ----------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,C,dtype,p", [(81600, 256, torch.bfloat16, 0.1), (4400, 256, torch.float32, 0.0), (15360, 256, torch.float32, 0.1),
+                                            (77, 128, torch.bfloat16, 0.0), (33, 512, torch.float32, 0.2)])
+def test_fused_add_layernorm_kernel_matches_the_framework_operators(rows, C, dtype, p):
+    from monodetr_amd import add_ln_ext
+    from test_add_ln_emulated_cpu import keep_mask
+    g = torch.Generator(device="cuda").manual_seed(rows + C)
+    a = torch.randn(rows, C, generator=g, device="cuda").to(dtype).requires_grad_(True)
+    b = (torch.randn(rows, C, generator=g, device="cuda") * 0.7 + 0.2).to(dtype).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g, device="cuda")).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g, device="cuda")).requires_grad_(True)
+    dy = torch.randn(rows, C, generator=g, device="cuda").to(dtype)
+    y = add_ln_ext.fused_add_layernorm(a, b, gamma, beta, 1e-5, p, seed=987654321)
+    y.backward(dy)
+    got = (y.detach(), a.grad.clone(), b.grad.clone(), gamma.grad.clone(), beta.grad.clone())
+    for t in (a, b, gamma, beta):
+        t.grad = None
+    keep = keep_mask(987654321, rows * C, p).view(rows, C).cuda() if p > 0 else torch.ones(rows, C, device="cuda")
+    s = (a.float() + b.float() * keep / (1 - p)).to(dtype)
+    ref = torch.nn.functional.layer_norm(s.float(), (C,), gamma, beta, 1e-5).to(dtype)
+    ref.backward(dy)
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5
+    for name, x, w in zip(("y", "da", "db", "dgamma", "dbeta"), got, (ref.detach(), a.grad, b.grad, gamma.grad, beta.grad)):
+        scale = max(1.0, w.float().abs().max().item())
+        lim = tol * scale * (30 if name in ("dgamma", "dbeta") and dtype == torch.bfloat16 else 1)      # sums of 81 600 bf16-rounded terms
+        assert (x.float() - w.float()).abs().max().item() <= lim, name
+
+
+def test_training_step_with_fused_layernorm_matches_default(monkeypatch):
+    import bench
+    from model_init import disable_dropout_
+    from monodetr_amd import add_ln_ext
+    dev = torch.device("cuda", 0)
+    traj = {}
+    for on in (False, True):
+        monkeypatch.setattr(add_ln_ext, "ENABLED", on)
+        step = bench.TrainStep(dev, 2, "bf16", size=(96, 320))
+        disable_dropout_(step.raw_model)
+        traj[on] = [float(step()) for _ in range(3)]
+    for a, b in zip(traj[False], traj[True]):
+        assert abs(a - b) <= 2e-2 * abs(a), traj

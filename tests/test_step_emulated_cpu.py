@@ -1,5 +1,5 @@
 """One complete training iteration with EVERY GPU-pending switch on -- fused criterion (pair losses, depth-map loss,
-in-solver matching cost), MSDA prologue, fused AdamW -- and the MSDA operator itself, all running the real kernel
+in-solver matching cost), MSDA prologue, fused residual LayerNorm, fused AdamW -- and the MSDA operator itself, all running the real kernel
 sources on the HIP-on-CPU shim (tests/native_emul.py), against the default path of the same model with the oracle as
 the operator (the configuration tests/test_model_cpu.py pins to the reference's classes).
 
@@ -51,16 +51,16 @@ class EmulMSDA:
 
 
 def run_step(oracle, pending, assignment=None):
-    from monodetr_amd import ddn_loss_ext, lsa_ext, msda_prologue_ext, pair_losses_ext
+    from monodetr_amd import add_ln_ext, ddn_loss_ext, lsa_ext, msda_prologue_ext, pair_losses_ext
     from monodetr_amd.helpers.optimizer_helper import AdamW, FusedAdamW
     from monodetr_amd.monodetr import build_monodetr
     from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func as F_
     from monodetr_amd.monodetr.ops.modules import ms_deform_attn as M_
-    exts = (pair_losses_ext, ddn_loss_ext, lsa_ext, msda_prologue_ext)
-    saved = (F_.MSDA, M_._FUSED_PROLOGUE)
+    exts = (pair_losses_ext, ddn_loss_ext, lsa_ext, msda_prologue_ext, add_ln_ext)
+    saved = (F_.MSDA, M_._FUSED_PROLOGUE, add_ln_ext.ENABLED)
     try:
         F_.MSDA = EmulMSDA if pending else oracle.OracleMSDA
-        M_._FUSED_PROLOGUE = pending
+        M_._FUSED_PROLOGUE = add_ln_ext.ENABLED = pending
         for e in exts:
             e._backend = native_emul.lib() if pending else None
         torch.manual_seed(0)
@@ -96,7 +96,7 @@ def run_step(oracle, pending, assignment=None):
         params = {n: p.detach().clone() for n, p in model.named_parameters()}
         return {k: float(v.detach()) for k, v in losses.items()}, float(total.detach()), grads, params, rec
     finally:
-        F_.MSDA, M_._FUSED_PROLOGUE = saved
+        F_.MSDA, M_._FUSED_PROLOGUE, add_ln_ext.ENABLED = saved
         for e in exts:
             e._backend = None
 
