@@ -135,3 +135,68 @@ def test_schedule_and_seeding_helpers():
     a = (np.random.rand(), torch.rand(1).item())
     set_random_seed(444)
     assert a == (np.random.rand(), torch.rand(1).item())
+
+
+def _dp_worker(rank, world, port, root, out_dir):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    sys.path.insert(0, here)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.chdir(out_dir)
+    torch.set_num_threads(2)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import backends
+        from monodetr_amd import kitti_prep_ext
+        from monodetr_amd.helpers.dataloader_helper import build_dataloader
+        from monodetr_amd.helpers.optimizer_helper import build_optimizer
+        from monodetr_amd.helpers.scheduler_helper import build_lr_scheduler
+        from monodetr_amd.helpers.trainer_helper import Trainer
+        kitti_prep_ext._backend = backends.get("host")
+        cfg_data = {'type': 'KITTI', 'root_dir': root, 'aug_pd': True, 'aug_crop': True, 'train_split': 'train', 'test_split': 'val',
+                    'batch_size': 2, 'writelist': ['Car'], 'scale': 0.05, 'shift': 0.05}
+        train_loader, test_loader = build_dataloader(cfg_data, workers=0, device='cpu', world_size=world, rank=rank)
+        torch.manual_seed(rank)                                          # different starts: the trainer must broadcast rank 0's
+        model, loss = _Model(), _Loss()
+        opt = build_optimizer({'type': 'adamw', 'lr': 1e-2, 'weight_decay': 0.0}, model)
+        sched, _ = build_lr_scheduler({'warmup': False, 'decay_rate': 0.1, 'decay_list': [5]}, opt, last_epoch=-1)
+        cfg = {'max_epoch': 2, 'save_frequency': 1, 'save_all': True, 'save_path': 'out/', 'use_dn': False}
+        tr = Trainer(cfg, model, opt, train_loader, test_loader, sched, None, logging.getLogger('dp%d' % rank), loss, 'm')
+        assert tr.grad_sync is not None
+        seen = []
+        inner = train_loader.loader.dataset.__getitem__.__func__
+
+        def spy(self, item):
+            seen.append(int(item))
+            return inner(self, item)
+        type(train_loader.loader.dataset).__getitem__ = spy
+        tr.train()
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        torch.distributed.all_gather(gathered, flat)
+        torch.save({'same': all(torch.equal(gathered[0], g) for g in gathered[1:]), 'seen': seen}, os.path.join(out_dir, 'r%d.pt' % rank))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_trainer_data_parallel_two_ranks_gloo(tmp_path):
+    """torchrun-style N = 2 on CPU: each rank trains on its shard of every epoch (DistributedSampler), gradients are
+    averaged by the flat all-reduce, the ranks stay bit-identical, rank 0 alone writes checkpoints."""
+    import socket
+    import torch.multiprocessing as mp
+    root = str(tmp_path / 'kitti')
+    kitti_synth.make_tree(root, n_images=6, seed=5)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / 'run')
+    os.makedirs(out)
+    mp.spawn(_dp_worker, args=(2, port, root, out), nprocs=2, join=True)
+    res = [torch.load(os.path.join(out, 'r%d.pt' % r)) for r in range(2)]
+    assert res[0]['same'] and res[1]['same']
+    per_epoch = [sorted(res[0]['seen'][:3] + res[1]['seen'][:3]), sorted(res[0]['seen'][3:] + res[1]['seen'][3:])]
+    assert per_epoch == [[0, 1, 2, 3, 4, 5]] * 2                         # shards are disjoint and cover the split, every epoch
+    assert res[0]['seen'][:3] != res[0]['seen'][3:] or res[1]['seen'][:3] != res[1]['seen'][3:]      # reshuffled between epochs
+    assert sorted(os.listdir(os.path.join(out, 'out', 'm'))) == ['checkpoint_epoch_1.pth', 'checkpoint_epoch_2.pth']
