@@ -26,6 +26,15 @@ def _strided(t):
 
 
 _seed_state = {}
+_backend = None               # tests substitute the CPU emulation of the same kernel source (tests/native_emul.py)
+
+
+def _lib():
+    return _backend if _backend is not None else _capi.lib()
+
+
+def _where(t):
+    return (t.device.index, torch.cuda.current_stream(t.device).cuda_stream) if t.is_cuda else (-1, None)
 
 
 _WEYL = 0x9E3779B97F4A7C15 - (1 << 64)      # 64-bit golden-ratio increment as a signed int64
@@ -50,7 +59,7 @@ def _next_seed(device):
 class _FusedAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, num_heads, scale, dropout_p, seed, key_padding_mask, seed_dev=None):
-        assert q.is_cuda, "fused attention runs on the GPU only"
+        assert q.is_cuda or _backend is not None, "fused attention runs on the GPU only"
         B, Lq, E = q.shape
         Lk = k.shape[1]
         assert E == num_heads * 32, "head_dim must be 32"
@@ -65,11 +74,11 @@ class _FusedAttention(torch.autograd.Function):
             assert kpm.shape == (B, Lk)
         out = torch.empty((B, Lq, E), dtype=q.dtype, device=q.device)
         lse = torch.empty((B, num_heads, Lq), dtype=torch.float32, device=q.device)
-        rc = _capi.lib().mdetr_attn_forward(
+        rc = _lib().mdetr_attn_forward(
             code, q.data_ptr(), k.data_ptr(), v.data_ptr(), kpm.data_ptr() if kpm is not None else None,
             out.data_ptr(), lse.data_ptr(), B, num_heads, Lq, Lk, qb, kb, vb, qr, kr, vr,
             float(scale), float(dropout_p), int(seed), seed_dev.data_ptr() if seed_dev is not None else None,
-            q.device.index, torch.cuda.current_stream(q.device).cuda_stream)
+            *_where(q))
         _capi.check(rc, "mdetr_attn_forward")
         ctx.seed_dev = seed_dev
         ctx.save_for_backward(q, k, v, out, lse, kpm if kpm is not None else torch.empty(0, device=q.device))
@@ -90,12 +99,12 @@ class _FusedAttention(torch.autograd.Function):
         dk = torch.empty((B, Lk, E), dtype=q.dtype, device=q.device)
         dv = torch.empty((B, Lk, E), dtype=q.dtype, device=q.device)
         dsum = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
-        rc = _capi.lib().mdetr_attn_backward(
+        rc = _lib().mdetr_attn_backward(
             code, q.data_ptr(), k.data_ptr(), v.data_ptr(), kpm.data_ptr() if has_kpm else None,
             out.data_ptr(), d_out.data_ptr(), lse.data_ptr(), dsum.data_ptr(),
             dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, H, Lq, Lk, qb, kb, vb, qr, kr, vr,
             scale, dropout_p, seed, ctx.seed_dev.data_ptr() if ctx.seed_dev is not None else None,
-            q.device.index, torch.cuda.current_stream(q.device).cuda_stream)
+            *_where(q))
         _capi.check(rc, "mdetr_attn_backward")
         return dq, dk, dv, None, None, None, None, None, None
 

@@ -28,15 +28,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mdetr_wave.h>
+
 #include "attn.h"
 #include "msda.h"
 
 namespace mdetr {
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kD = 32;             // head dim
 constexpr int kTile = 64;          // rows of a staged K/V (or Q/dO) tile
@@ -56,10 +54,7 @@ struct AttnArgs {
     const uint64_t *seed_dev;
 };
 
-__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return mfma_bf16(a, b, c); }      // mdetr_wave.h
 
 struct Frag { bf16x8 h, l; };       // operand fragment: hi part (+ lo part in split mode)
 

@@ -101,6 +101,19 @@ template <typename T> inline T __shfl_down(T v, int delta, int width = 64)
     return __shfl(v, src < width ? src : lane % width, width);
 }
 
+// wave votes: every live lane of the wave takes part
+inline int __any(int pred)
+{
+    const int me = threadIdx.x, base = hipshim::lane_base(), n = hipshim::live_lanes();
+    hipshim::exchange[me] = pred != 0;
+    hipshim::sync_wave();
+    int r = 0;
+    for (int l = 0; l < n; ++l) r |= static_cast<int>(hipshim::exchange[base + l]);
+    hipshim::sync_wave();
+    return r;
+}
+inline int __all(int pred) { return !__any(!pred); }
+
 template <typename T, typename U> inline T atomicAdd(T *p, U v) { const T old = *p; *p = old + static_cast<T>(v); return old; }
 template <typename T, typename U> inline T unsafeAtomicAdd(T *p, U v) { return atomicAdd(p, v); }
 template <typename T> inline T atomicMax(T *p, T v) { const T old = *p; if (v > old) *p = v; return old; }
@@ -115,7 +128,8 @@ using std::min;
 inline void __builtin_amdgcn_fence(int, const char *) {}
 inline void __builtin_amdgcn_wave_barrier() { hipshim::sync_wave(); }        // lanes run one after another here: a real rendezvous
 inline void __builtin_amdgcn_s_barrier() { hipshim::sync_block(); }
-inline int __builtin_amdgcn_readfirstlane(int v) { return v; }                // only used on wave-uniform values
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }                // only used on wave-uniform values
 // v_mov_b32 with a DPP modifier, all rows / banks enabled, bound_ctrl: quad_perm, row_shl / row_shr, row_mirror,
 // row_half_mirror (the controls the sources use); a row is 16 lanes.  Invalid source lanes read 0 (bound_ctrl).
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)

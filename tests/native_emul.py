@@ -1,4 +1,4 @@
-"""Builds the repository's own .hip sources -- capi.hip and the kernels that have not met a GPU yet -- with g++
+"""Builds the repository's own .hip sources -- capi.hip and every kernel file -- with g++
 against tests/native/hipshim (a minimal HIP-on-the-CPU: fibers for the threads of a block, barriers, wave shuffles)
 and exposes the resulting library through ctypes with the C ABI's signatures.  Unlike tests/native_host.py (which
 re-implements the launch loops around the shared *_math.h arithmetic) this runs the REAL kernels, launchers and
@@ -13,30 +13,56 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(ROOT, "monodetr_amd", "csrc")
 SHIM = os.path.join(HERE, "native", "hipshim")
 OUT = os.path.join(HERE, "native", "_build", "libemul.so")
-KERNELS = ["capi", "pair_losses", "ddn_loss", "adamw", "msda_prologue", "kitti_prep", "colsum", "token_gemm", "msda", "msda_tiled", "lsa", "rotate_iou", "kitti_stats", "add_ln"]
+KERNELS = ["capi", "pair_losses", "ddn_loss", "adamw", "msda_prologue", "kitti_prep", "colsum", "token_gemm", "msda", "msda_tiled", "lsa", "rotate_iou", "kitti_stats", "add_ln", "attn"]
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        os.makedirs(os.path.dirname(OUT), exist_ok=True)
-        srcs = [os.path.join(CSRC, k + ".hip") for k in KERNELS]
-        extra = [os.path.join(SHIM, "runtime.cpp"), os.path.join(SHIM, "stubs.cpp")]
-        deps = srcs + extra + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
-            [os.path.join(SHIM, "hip", f) for f in os.listdir(os.path.join(SHIM, "hip"))] + [os.path.join(SHIM, "mdetr_wave.h")] + [os.path.join(ROOT, "include", "monodetr_amd.h")]
-        if not os.path.exists(OUT) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps):
-            cmd = ["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-ffp-contract=off", "-I", SHIM, "-I", os.path.join(ROOT, "include"),
-                   "-I", CSRC, "-o", OUT]
-            for s in srcs:
-                cmd += ["-x", "c++", s]
-            cmd += ["-x", "none"] + extra
-            subprocess.check_call(cmd)
-        from monodetr_amd import _capi
-        L = ctypes.CDLL(OUT)
-        for name, (res, args) in _capi.SIGNATURES.items():
-            fn = getattr(L, name)
-            fn.restype, fn.argtypes = res, args
-        _lib = L
-    return _lib
+def lib(defines=()):
+    """The emulated library; ``defines`` (e.g. ("MDETR_ATTN_STAGE_REMAP=1",)) selects a compile-time variant, built
+    into its own file."""
+    key = tuple(defines)
+    if key not in _libs:
+        out = OUT if not key else OUT.replace(".so", "_" + "_".join(d.replace("=", "-") for d in key) + ".so")
+        _libs[key] = _build(out, key)
+    return _libs[key]
+
+
+def _compile(job):
+    src, obj, defines = job
+    cmd = ["g++", "-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-I", SHIM, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+           "-c", "-o", obj] + ["-D" + d for d in defines] + (["-x", "c++"] if src.endswith(".hip") else []) + [src]
+    subprocess.check_call(cmd)
+
+
+def _build(OUT, defines):
+    """One object per source (compiled in parallel, cached by modification time), then one link.  A compile-time
+    variant recompiles only the sources that mention one of its macros."""
+    from concurrent.futures import ThreadPoolExecutor
+    bdir = os.path.dirname(OUT)
+    os.makedirs(bdir, exist_ok=True)
+    srcs = [os.path.join(CSRC, k + ".hip") for k in KERNELS] + [os.path.join(SHIM, "runtime.cpp")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+        [os.path.join(SHIM, "hip", f) for f in os.listdir(os.path.join(SHIM, "hip"))] + [os.path.join(SHIM, "mdetr_wave.h"),
+                                                                                         os.path.join(ROOT, "include", "monodetr_amd.h")]
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    macros = [d.split("=")[0] for d in defines]
+    jobs, objs = [], []
+    for src in srcs:
+        affected = [d for d, m in zip(defines, macros) if m in open(src).read()]
+        tag = "".join("_" + d.replace("=", "-") for d in affected)
+        obj = os.path.join(bdir, "emul_" + os.path.basename(src).replace(".", "_") + tag + ".o")
+        objs.append(obj)
+        if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            jobs.append((src, obj, affected))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as pool:
+            list(pool.map(_compile, jobs))
+    if jobs or not os.path.exists(OUT):
+        subprocess.check_call(["g++", "-shared", "-o", OUT] + objs)
+    from monodetr_amd import _capi
+    L = ctypes.CDLL(OUT)
+    for name, (res, args) in _capi.SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    return L
