@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(ROOT, "monodetr_amd", "csrc")
 SHIM = os.path.join(HERE, "native", "hipshim")
-OUT = os.path.join(HERE, "native", "_build", "libemul.so")
+OUT = os.path.join(HERE, "native", "_build", "libemul_asan.so" if os.environ.get("MDETR_EMUL_ASAN") == "1" else "libemul.so")
 KERNELS = ["capi", "pair_losses", "ddn_loss", "adamw", "msda_prologue", "kitti_prep", "colsum", "token_gemm", "msda", "msda_tiled", "lsa", "rotate_iou", "kitti_stats", "add_ln", "attn"]
 
 _libs = {}
@@ -28,9 +28,13 @@ def lib(defines=()):
     return _libs[key]
 
 
+SANITIZE = os.environ.get("MDETR_EMUL_ASAN") == "1"       # AddressSanitizer build: run the interpreter with LD_PRELOAD=libasan.so
+_SAN = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g"] if SANITIZE else []
+
+
 def _compile(job):
     src, obj, defines = job
-    cmd = ["g++", "-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-I", SHIM, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+    cmd = ["g++", "-std=c++17", "-O1", "-fPIC", "-ffp-contract=off"] + _SAN + [ "-I", SHIM, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
            "-c", "-o", obj] + ["-D" + d for d in defines] + (["-x", "c++"] if src.endswith(".hip") else []) + [src]
     subprocess.check_call(cmd)
 
@@ -51,7 +55,7 @@ def _build(OUT, defines):
     for src in srcs:
         affected = [d for d, m in zip(defines, macros) if m in open(src).read()]
         tag = "".join("_" + d.replace("=", "-") for d in affected)
-        obj = os.path.join(bdir, "emul_" + os.path.basename(src).replace(".", "_") + tag + ".o")
+        obj = os.path.join(bdir, ("asan_" if SANITIZE else "emul_") + os.path.basename(src).replace(".", "_") + tag + ".o")
         objs.append(obj)
         if not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
             jobs.append((src, obj, affected))
@@ -59,7 +63,7 @@ def _build(OUT, defines):
         with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as pool:
             list(pool.map(_compile, jobs))
     if jobs or not os.path.exists(OUT):
-        subprocess.check_call(["g++", "-shared", "-o", OUT] + objs)
+        subprocess.check_call(["g++", "-shared", "-o", OUT] + _SAN + objs)
     from monodetr_amd import _capi
     L = ctypes.CDLL(OUT)
     for name, (res, args) in _capi.SIGNATURES.items():
