@@ -63,15 +63,29 @@ void run_block(int nthreads)
         makecontext(&fibers[t].ctx, entry, 0);
         fibers[t].state = READY;
     }
+    // Lane order between synchronisation points: ascending by default; HIPSHIM_ORDER=reverse or =shuffle runs the lanes
+    // in another order, which exposes a missing barrier (a consumer running before its producer) as a wrong result.
+    std::vector<int> order(nthreads);
+    for (int t = 0; t < nthreads; ++t) order[t] = t;
+    static const char *mode = getenv("HIPSHIM_ORDER");
+    static unsigned lcg = 12345u;
     for (;;) {
+        if (mode && mode[0] == 'r') for (int t = 0; t < nthreads; ++t) order[t] = nthreads - 1 - t;
+        if (mode && mode[0] == 's')
+            for (int t = nthreads - 1; t > 0; --t) {
+                lcg = lcg * 1664525u + 1013904223u;
+                std::swap(order[t], order[(lcg >> 8) % (t + 1)]);
+            }
         bool ran = false;
-        for (int t = 0; t < nthreads; ++t)
+        for (int i = 0; i < nthreads; ++i) {
+            const int t = order[i];
             if (fibers[t].state == READY) {
                 current = t;
                 threadIdx = dim3(static_cast<unsigned>(t));
                 swapcontext(&scheduler, &fibers[t].ctx);
                 ran = true;
             }
+        }
         bool released = false, all_done = true, all_block = true;
         for (int w = 0; w * 64 < nthreads; ++w) {                      // wave-level release
             int live = 0, waiting = 0;
