@@ -378,6 +378,10 @@ def main():
             line["ops"] = ops
             line["kernels"] = kernels
         line["config"]["cpu_affinity"] = "NUMA node %d of the GPU" % bound[0] if bound else "unbound"
+        # optional kernels switched on through the environment; empty = the default path
+        line["config"]["switches"] = sorted(k for k, v in os.environ.items() if k.startswith("MDETR_") and v == "1" and
+                                            k in ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_TOKEN_GEMM",
+                                                  "MDETR_MSDA_BF16", "MDETR_FUSED_LN"))
         if world == 1 and not args.no_cpu_baseline:
             if bound:
                 os.sched_setaffinity(0, bound[1])                   # the CPU baseline gets every core again
