@@ -12,6 +12,13 @@ prediction heads, fp32 master weights, the MSDA operator itself in fp32); --prec
 reference's own all-fp32 arithmetic.  One process per GPU; for N > 1 the image batch is sharded (weak scaling) and
 gradients are all-reduced over RCCL/xGMI by DistributedDataParallel.  Rank 0 prints ONE JSON line.
 
+Optional kernels: with no MDETR_* switch in the environment, rank 0 of an N = 1 run first probes, in a
+child process on the same GPU, the default path and the candidate sets of `probe_configs` -- three deterministic
+iterations each (dropout off) whose losses must agree with the default path's within 3 %, then a short timing with
+dropout on -- and runs the benchmark with the fastest admissible set (`config.switches`, `config.autotune` on the JSON
+line; the decision is cached in $TMPDIR for the N > 1 runs that follow).  A candidate that crashes, times out,
+disagrees or is not faster leaves the default path in place.  MDETR_BENCH_AUTOTUNE=0 skips the probe.
+
 Extra objects on that line:
   roofline      the dominant hand-written kernel (MSDA backward at the encoder shape): ALGORITHMIC
                 bytes per launch / its average launch duration measured with HIP
@@ -75,12 +82,168 @@ def synthetic_batch(B, H, W, seed, device):
     return images.to(device), P2[None].repeat(B, 1, 1).to(device), torch.tensor([[1242, 375]] * B, device=device), targets
 
 
+# ---- optional kernels ----------------------------------------------------------------------------
+# Each is switched on by an environment variable of the same name (= "1") or, when none is set, chosen by the
+# start-up autotune below.  MDETR_MSDA_BF16 changes the MSDA operator's element type, which the roofline accounting of
+# this file does not model, so it is environment-only.
+AUTOTUNE_SWITCHES = ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN", "MDETR_TOKEN_GEMM")
+ALL_SWITCHES = AUTOTUNE_SWITCHES + ("MDETR_MSDA_BF16",)
+
+
+def env_switches():
+    return {k for k in ALL_SWITCHES if os.environ.get(k) == "1"}
+
+
+def apply_switches(names):
+    """Runtime equivalent of the environment switches for the module-level ones (the criterion's and the optimizer's
+    are applied by TrainStep)."""
+    from monodetr_amd import add_ln_ext
+    from monodetr_amd.monodetr import linear
+    from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func
+    from monodetr_amd.monodetr.ops.modules import ms_deform_attn
+    ms_deform_attn._FUSED_PROLOGUE = "MDETR_MSDA_PROLOGUE" in names
+    add_ln_ext.ENABLED = "MDETR_FUSED_LN" in names
+    linear._TOKEN_GEMM = "MDETR_TOKEN_GEMM" in names
+    ms_deform_attn_func._NATIVE_BF16 = "MDETR_MSDA_BF16" in names
+
+
+def probe_configs(precision):
+    """Candidate switch sets: the default path, everything but the token GEMM (the one candidate that replaces a tuned
+    library kernel and may well be slower), everything.  The fullest set runs last so that a crash in it loses nothing."""
+    base = ["MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN"]
+    return [[], base] + ([base + ["MDETR_TOKEN_GEMM"]] if precision == "bf16" else [])
+
+
+def choose_config(results, rel_tol=0.03, min_gain=0.01):
+    """results: list of {"switches": [...], "losses": [3 floats], "ms": float} from one probe run, the default path
+    (no switches) among them.  A candidate is admissible if its three deterministic losses are finite and within
+    rel_tol of the default path's; the fastest admissible one wins if it beats the default by min_gain."""
+    base = next((r for r in results if not r["switches"]), None)
+    if base is None or not all(x == x and abs(x) != float("inf") for x in base["losses"]):
+        return [], "no default-path probe"
+    best, why = base, "default path is fastest"
+    for r in results:
+        if r is base:
+            continue
+        ok = r.get("finite", True) and len(r["losses"]) == len(base["losses"]) and all(
+            x == x and abs(x - b) <= rel_tol * max(abs(b), 1e-6) for x, b in zip(r["losses"], base["losses"]))
+        r["admissible"] = bool(ok)
+        if ok and r["ms"] < best["ms"] and r["ms"] <= base["ms"] * (1.0 - min_gain):
+            best, why = r, "fastest admissible candidate"
+    return sorted(best["switches"]), why
+
+
+def run_probe(args, local_rank, configs, timeout=300):
+    """Run `bench.py --probe` in a child process (a kernel that faults takes the child down, not this process) and
+    return the PROBE records it managed to print."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                          "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID") and not k.startswith("MDETR_")}
+    env["MDETR_BENCH_AUTOTUNE"] = "0"
+    cmd = [sys.executable, os.path.abspath(__file__), "--probe", json.dumps(configs), "--precision", args.precision, "--batch", str(args.batch),
+           "--probe-device", str(local_rank)]
+    out = ""
+    try:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout, text=True).stdout
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+    except Exception:
+        return []
+    records = []
+    for ln in out.splitlines():
+        if ln.startswith("PROBE "):
+            try:
+                records.append(json.loads(ln[6:]))
+            except ValueError:
+                pass
+    return records
+
+
+def autotune(args, world, local_rank, runner=run_probe, cache_path=None):
+    """Which optional kernels to run with: the environment's if any is set; otherwise the result of one probe run on
+    this GPU -- every candidate set is executed in a child process, checked against the default path's deterministic
+    losses, timed, and the fastest admissible one is taken (cached per box so that the N = 2, 4, 8 runs that follow an
+    N = 1 run reuse it).  Returns (switches or None for "as the environment says", report dict or None)."""
+    if env_switches() or os.environ.get("MDETR_BENCH_AUTOTUNE", "1") == "0" or args.graph == "on":
+        return None, None
+    try:
+        lib = os.path.join(ROOT, "monodetr_amd", "libmonodetr_amd.so")
+        key = "%s|b%d|%s|%d" % (args.precision, args.batch, torch.cuda.get_device_name(local_rank), int(os.path.getmtime(lib)))
+        cache_path = cache_path or os.path.join(os.environ.get("TMPDIR", "/tmp"), "mdetr_bench_autotune.json")
+        if os.path.exists(cache_path):
+            try:
+                cached = json.load(open(cache_path))
+                if cached.get("key") == key:
+                    return list(cached["chosen"]), dict(cached["report"], source="cache")
+            except (ValueError, KeyError, OSError):
+                pass
+        if world > 1:
+            return None, None                                         # no cached decision: every rank stays on the default path
+        results = runner(args, local_rank, probe_configs(args.precision))
+        chosen, why = choose_config(results)
+        report = {"source": "probe", "decision": why, "chosen": chosen,
+                  "candidates": [{"switches": r["switches"], "ms": r["ms"], "admissible": r.get("admissible", True)} for r in results]}
+        try:
+            json.dump({"key": key, "chosen": chosen, "report": report}, open(cache_path, "w"))
+        except OSError:
+            pass
+        return chosen, report
+    except Exception as e:                                            # never let the tuner take the benchmark down
+        return None, {"source": "failed", "error": repr(e)}
+
+
+def probe_config(device, batch, precision, names, size=(384, 1280), warm=5, timed=8, prepare=None):
+    """One candidate of the autotune: build the training step with exactly the switch set `names` and dropout disabled
+    (deterministic: same initial weights, same inputs for every candidate), report the first three losses and the
+    time per iteration of `timed` iterations after `warm` more."""
+    step = TrainStep(device, batch, precision, switches=names, size=size)
+    if prepare is not None:
+        prepare(step)                                                 # (tests: CPU stand-ins for the device library)
+    saved = []
+    for m in step.raw_model.modules():                                # dropout off for the three comparison steps ...
+        if isinstance(m, torch.nn.Dropout):
+            saved.append((m, "p", m.p))
+            m.p = 0.0
+        if isinstance(getattr(m, "dropout", None), float):
+            saved.append((m, "dropout", m.dropout))
+            m.dropout = 0.0
+    sync = (lambda: torch.cuda.synchronize(device)) if device.type == "cuda" else (lambda: None)
+    losses = [float(step().detach()) for _ in range(3)]
+    for m, name, value in saved:                                      # ... and back on for the timed ones (the configuration the benchmark runs)
+        setattr(m, name, value)
+    for _ in range(warm):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        last = step()
+    sync()
+    ms = (time.perf_counter() - t0) / max(timed, 1) * 1e3
+    return {"switches": sorted(names), "losses": losses, "ms": round(ms, 3), "finite": bool(torch.isfinite(last.detach()).item())}
+
+
+def probe_main(args):
+    """Child side of the autotune: one PROBE line per candidate, flushed as soon as it is known."""
+    device = torch.device("cuda", args.probe_device)
+    torch.cuda.set_device(device)
+    from monodetr_amd import _capi
+    _capi.lib()
+    for names in json.loads(args.probe):
+        print("PROBE " + json.dumps(probe_config(device, args.batch, args.precision, names)), flush=True)
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
 class TrainStep:
     """model + criterion + optimizer on one device; __call__ runs one full training iteration."""
 
-    def __init__(self, device, batch, precision, seed=444, ddp=False, local_rank=0, size=(384, 1280), graph=False):
+    def __init__(self, device, batch, precision, seed=444, ddp=False, local_rank=0, size=(384, 1280), graph=False, switches=None):
         from monodetr_amd.helpers.optimizer_helper import build_optimizer
         from monodetr_amd.monodetr import build_monodetr
+        # optional kernels: None = as the environment says (the modules read it at import), else exactly this set
+        self.switches = env_switches() if switches is None else set(switches)
+        if switches is not None:
+            apply_switches(self.switches)
         torch.manual_seed(seed)                               # same initial weights on every rank
         cfg = dict(MODEL_CFG, device=str(device).split(':')[0])
         self.model, self.criterion = build_monodetr(cfg)
@@ -92,6 +255,8 @@ class TrainStep:
             to_bf16_body(self.model)
         self.model.train()
         self.criterion.train()
+        if switches is not None:
+            self.criterion.fused_pair_losses = self.criterion.matcher.fused_cost = "MDETR_FUSED_LOSSES" in self.switches
         self.raw_model = self.model
         self.grad_sync = None
         if ddp == "ddp":
@@ -107,7 +272,7 @@ class TrainStep:
             self.grad_sync = FlatGradSync(self.raw_model.parameters())
         # MDETR_FUSED_ADAMW=1: one-launch-per-group HIP AdamW (helpers/optimizer_helper.FusedAdamW); off until
         # its kernel has had its first GPU validation (tests/test_pending_gpu.py)
-        self.optimizer = build_optimizer(dict(OPT_CFG, capturable=graph, fused=os.environ.get("MDETR_FUSED_ADAMW") == "1"),
+        self.optimizer = build_optimizer(dict(OPT_CFG, capturable=graph, fused="MDETR_FUSED_ADAMW" in self.switches),
                                          self.raw_model)
         self.graph = None
         self.want_graph = graph
@@ -239,8 +404,12 @@ def main():
                          "DESIGN.md 7 -- verified in fp32, worth <1%% once the host syncs were gone; bf16 replays are "
                          "not reliable on this ROCm build)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--probe", default=None, help=argparse.SUPPRESS)             # child mode of the autotune
+    ap.add_argument("--probe-device", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-steps", type=int, default=1)
     args = ap.parse_args()
+    if args.probe is not None:
+        return probe_main(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -271,7 +440,12 @@ def main():
     use_graph = args.graph == "on"
     if use_graph and world > 1:
         raise SystemExit("--graph on is a single-GPU mode (the RCCL all-reduce of DDP is not captured)")
-    step = TrainStep(device, args.batch, args.precision, ddp=(os.environ.get("MDETR_BENCH_SYNC", "flat") if dist_on else False), local_rank=local_rank, graph=use_graph)
+    # optional kernels: the environment's, or -- with none set -- what the probe run found fastest and correct on this GPU
+    chosen, tune_report = autotune(args, world, local_rank)
+    # (N > 1: every rank reads the same cached decision of the preceding N = 1 run; the optional kernels compute the same
+    # step as the default ones, so ranks need not even agree -- no extra collective is introduced)
+    step = TrainStep(device, args.batch, args.precision, ddp=(os.environ.get("MDETR_BENCH_SYNC", "flat") if dist_on else False), local_rank=local_rank, graph=use_graph,
+                     switches=chosen)
     if use_graph:
         step.capture()                                              # untimed: part of start-up, like model build
 
@@ -378,10 +552,10 @@ def main():
             line["ops"] = ops
             line["kernels"] = kernels
         line["config"]["cpu_affinity"] = "NUMA node %d of the GPU" % bound[0] if bound else "unbound"
-        # optional kernels switched on through the environment; empty = the default path
-        line["config"]["switches"] = sorted(k for k, v in os.environ.items() if k.startswith("MDETR_") and v == "1" and
-                                            k in ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_TOKEN_GEMM",
-                                                  "MDETR_MSDA_BF16", "MDETR_FUSED_LN"))
+        # optional kernels in this run: from the environment, or chosen by the start-up probe
+        line["config"]["switches"] = sorted(step.switches)
+        if tune_report is not None:
+            line["config"]["autotune"] = tune_report
         if world == 1 and not args.no_cpu_baseline:
             if bound:
                 os.sched_setaffinity(0, bound[1])                   # the CPU baseline gets every core again

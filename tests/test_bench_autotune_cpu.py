@@ -1,0 +1,141 @@
+"""bench.py's start-up autotune, host logic only (the probe itself needs the GPU): candidate sets, the admissibility
+rule against the default path's deterministic losses, the choice, caching per box, and that nothing the tuner does can
+take the benchmark down."""
+import json
+import os
+import types
+
+import pytest
+
+import bench
+
+
+def args(**kw):
+    return types.SimpleNamespace(precision=kw.get("precision", "bf16"), batch=8, graph=kw.get("graph", "off"))
+
+
+@pytest.fixture(autouse=True)
+def clean_env(monkeypatch):
+    for k in list(os.environ):
+        if k.startswith("MDETR_"):
+            monkeypatch.delenv(k)
+    monkeypatch.setattr(bench.torch.cuda, "get_device_name", lambda i=0: "AMD Instinct MI355X")
+
+
+def test_candidate_sets():
+    bf = bench.probe_configs("bf16")
+    assert bf[0] == [] and set(bf[-1]) == set(bench.AUTOTUNE_SWITCHES) and set(bf[1]) == set(bf[-1]) - {"MDETR_TOKEN_GEMM"}
+    assert "MDETR_TOKEN_GEMM" not in sum(bench.probe_configs("fp32"), [])          # a bf16-only kernel
+    assert "MDETR_MSDA_BF16" not in bench.AUTOTUNE_SWITCHES                          # changes the roofline accounting: environment only
+
+
+def test_choice_takes_the_fastest_admissible_candidate():
+    base = {"switches": [], "losses": [30.0, 29.0, 28.5], "ms": 38.0}
+    good = {"switches": ["MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW"], "losses": [30.1, 29.2, 28.4], "ms": 34.0}
+    better_but_wrong = {"switches": ["MDETR_FUSED_LN"], "losses": [30.0, 35.0, 28.5], "ms": 30.0}
+    nan = {"switches": ["MDETR_TOKEN_GEMM"], "losses": [float("nan"), 1.0, 1.0], "ms": 20.0}
+    slower = {"switches": ["MDETR_MSDA_PROLOGUE"], "losses": [30.0, 29.0, 28.5], "ms": 39.0}
+    chosen, why = bench.choose_config([base, good, better_but_wrong, nan, slower])
+    assert chosen == sorted(good["switches"]) and "admissible" in why
+    assert better_but_wrong["admissible"] is False and nan["admissible"] is False and good["admissible"] is True
+    assert bench.choose_config([base, slower]) == ([], "default path is fastest")
+    assert bench.choose_config([base, dict(good, ms=37.9)])[0] == []                # below the 1 % gain threshold
+    assert bench.choose_config([good])[0] == []                                      # no default-path probe: nothing to compare with
+    assert bench.choose_config([])[0] == []
+
+
+def test_autotune_runs_one_probe_caches_per_box_and_reports(tmp_path):
+    calls = []
+
+    def runner(a, local_rank, configs):
+        calls.append(configs)
+        return [{"switches": sorted(c), "losses": [30.0, 29.0, 28.0], "ms": 38.0 - 1.5 * len(c)} for c in configs]
+    cache = str(tmp_path / "tune.json")
+    chosen, report = bench.autotune(args(), 1, 0, runner=runner, cache_path=cache)
+    assert chosen == sorted(bench.AUTOTUNE_SWITCHES) and report["source"] == "probe" and len(report["candidates"]) == 3
+    chosen2, report2 = bench.autotune(args(), 1, 0, runner=runner, cache_path=cache)
+    assert chosen2 == chosen and report2["source"] == "cache" and len(calls) == 1
+    # another precision is another key
+    bench.autotune(args(precision="fp32"), 1, 0, runner=runner, cache_path=cache)
+    assert len(calls) == 2
+    # N > 1 only ever reads the cache
+    assert bench.autotune(args(precision="bf16"), 8, 3, runner=runner, cache_path=str(tmp_path / "none.json")) == (None, None)
+    assert len(calls) == 2
+    json.dump({"key": "stale"}, open(cache, "w"))
+    assert bench.autotune(args(), 8, 0, runner=runner, cache_path=cache) == (None, None)
+
+
+def test_autotune_steps_aside(tmp_path, monkeypatch):
+    boom = lambda *a: (_ for _ in ()).throw(RuntimeError("probe exploded"))
+    chosen, report = bench.autotune(args(), 1, 0, runner=boom, cache_path=str(tmp_path / "c.json"))
+    assert chosen is None and report["source"] == "failed"                           # default path, benchmark goes on
+    assert bench.autotune(args(), 1, 0, runner=lambda *a: [], cache_path=str(tmp_path / "d.json"))[0] == []   # child died before printing
+    monkeypatch.setenv("MDETR_FUSED_LN", "1")                                         # explicit switches win
+    assert bench.autotune(args(), 1, 0, runner=boom) == (None, None) and bench.env_switches() == {"MDETR_FUSED_LN"}
+    monkeypatch.delenv("MDETR_FUSED_LN")
+    monkeypatch.setenv("MDETR_BENCH_AUTOTUNE", "0")
+    assert bench.autotune(args(), 1, 0, runner=boom) == (None, None)
+    monkeypatch.delenv("MDETR_BENCH_AUTOTUNE")
+    assert bench.autotune(args(graph="on"), 1, 0, runner=boom) == (None, None)
+
+
+def test_probe_child_command_is_isolated_from_the_launcher_environment(monkeypatch):
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen.update(cmd=cmd, env=env)
+        return types.SimpleNamespace(stdout='noise\nPROBE {"switches": [], "losses": [1, 2, 3], "ms": 40.0}\nPROBE not-json\n')
+    import subprocess
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("MASTER_PORT", "1234")
+    recs = bench.run_probe(args(), 0, [[], ["MDETR_FUSED_LN"]])
+    assert recs == [{"switches": [], "losses": [1, 2, 3], "ms": 40.0}]
+    assert "--probe" in seen["cmd"] and json.loads(seen["cmd"][seen["cmd"].index("--probe") + 1]) == [[], ["MDETR_FUSED_LN"]]
+    assert not {"WORLD_SIZE", "RANK", "MASTER_PORT"} & set(seen["env"]) and seen["env"]["MDETR_BENCH_AUTOTUNE"] == "0"
+
+
+def test_apply_switches_sets_and_clears_the_module_flags():
+    from monodetr_amd import add_ln_ext
+    from monodetr_amd.monodetr import linear
+    from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func
+    from monodetr_amd.monodetr.ops.modules import ms_deform_attn
+    bench.apply_switches({"MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE"})
+    assert add_ln_ext.ENABLED and ms_deform_attn._FUSED_PROLOGUE and not linear._TOKEN_GEMM and not ms_deform_attn_func._NATIVE_BF16
+    bench.apply_switches(set())
+    assert not (add_ln_ext.ENABLED or ms_deform_attn._FUSED_PROLOGUE or linear._TOKEN_GEMM or ms_deform_attn_func._NATIVE_BF16)
+
+
+def test_probe_candidate_runs_the_training_step_with_exactly_its_switches(oracle):
+    """The child side, on the CPU: bench.TrainStep with an explicit switch set (kernel sources on the shim, oracle as
+    the MSDA operator) against the default path -- the comparison the probe makes on the GPU."""
+    import native_emul
+    import torch
+    from monodetr_amd import add_ln_ext, ddn_loss_ext, lsa_ext, msda_prologue_ext, pair_losses_ext
+    from monodetr_amd.helpers.optimizer_helper import AdamW, FusedAdamW
+    from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func as F_
+    exts = (add_ln_ext, ddn_loss_ext, lsa_ext, msda_prologue_ext, pair_losses_ext)
+    saved = F_.MSDA
+    F_.MSDA = oracle.OracleMSDA
+    for e in exts:
+        e._backend = native_emul.lib()
+    seen = {}
+
+    def prepare(step):
+        seen[tuple(sorted(step.switches))] = (type(step.optimizer), step.criterion.fused_pair_losses, step.criterion.matcher.fused_cost,
+                                              add_ln_ext.ENABLED)
+        if isinstance(step.optimizer, FusedAdamW):
+            step.optimizer._lib, step.optimizer._allow_cpu = native_emul.lib(), True
+    try:
+        dev = torch.device("cpu")
+        cands = [[], ["MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN"]]
+        recs = [bench.probe_config(dev, 1, "fp32", c, size=(64, 192), warm=0, timed=1, prepare=prepare) for c in cands]
+    finally:
+        F_.MSDA = saved
+        for e in exts:
+            e._backend = None
+        bench.apply_switches(set())
+    assert seen[()] == (AdamW, False, False, False)
+    assert seen[tuple(sorted(cands[1]))] == (FusedAdamW, True, True, True)
+    assert recs[0]["switches"] == [] and recs[1]["switches"] == sorted(cands[1]) and recs[1]["ms"] > 0
+    chosen, _ = bench.choose_config([recs[0], dict(recs[1], ms=recs[0]["ms"] * 0.5)])
+    assert chosen == sorted(cands[1]), (recs[0]["losses"], recs[1]["losses"])          # losses agree within the probe's tolerance
