@@ -142,13 +142,17 @@ def run_probe(args, local_rank, configs, timeout=300):
     env["MDETR_BENCH_AUTOTUNE"] = "0"
     cmd = [sys.executable, os.path.abspath(__file__), "--probe", json.dumps(configs), "--precision", args.precision, "--batch", str(args.batch),
            "--probe-device", str(local_rank)]
-    out = ""
+    out, err = "", ""
+    text = lambda b: b.decode(errors="replace") if isinstance(b, bytes) else (b or "")
     try:
-        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout, text=True).stdout
+        done = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+        out, err = done.stdout, done.stderr
     except subprocess.TimeoutExpired as e:
-        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
-    except Exception:
+        out, err = text(e.stdout), text(e.stderr) + "\n[probe timed out after %d s]" % timeout
+    except Exception as e:
+        run_probe.stderr_tail = repr(e)
         return []
+    run_probe.stderr_tail = (err or "")[-600:]                        # kept for the report when a candidate did not finish
     records = []
     for ln in out.splitlines():
         if ln.startswith("PROBE "):
@@ -181,8 +185,12 @@ def autotune(args, world, local_rank, runner=run_probe, cache_path=None):
             return None, None                                         # no cached decision: every rank stays on the default path
         results = runner(args, local_rank, probe_configs(args.precision))
         chosen, why = choose_config(results)
+        configs = probe_configs(args.precision)
         report = {"source": "probe", "decision": why, "chosen": chosen,
                   "candidates": [{"switches": r["switches"], "ms": r["ms"], "admissible": r.get("admissible", True)} for r in results]}
+        if len(results) < len(configs):                               # a candidate took the child down: say how
+            report["unfinished"] = [sorted(c) for c in configs[len(results):]]
+            report["child_stderr_tail"] = getattr(runner, "stderr_tail", "")
         try:
             json.dump({"key": key, "chosen": chosen, "report": report}, open(cache_path, "w"))
         except OSError:

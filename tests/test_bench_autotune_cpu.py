@@ -84,7 +84,7 @@ def test_probe_child_command_is_isolated_from_the_launcher_environment(monkeypat
 
     def fake_run(cmd, env=None, **kw):
         seen.update(cmd=cmd, env=env)
-        return types.SimpleNamespace(stdout='noise\nPROBE {"switches": [], "losses": [1, 2, 3], "ms": 40.0}\nPROBE not-json\n')
+        return types.SimpleNamespace(stderr='warn', stdout='noise\nPROBE {"switches": [], "losses": [1, 2, 3], "ms": 40.0}\nPROBE not-json\n')
     import subprocess
     monkeypatch.setattr(subprocess, "run", fake_run)
     monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("MASTER_PORT", "1234")
