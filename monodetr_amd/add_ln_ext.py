@@ -24,6 +24,12 @@ def supported(a, b, norm):
             and norm.normalized_shape[0] == a.shape[-1] and norm.elementwise_affine and norm.bias is not None)
 
 
+def _rows(t, C):
+    """[rows, C] contiguous with a 16-byte aligned base (views at odd storage offsets are copied)."""
+    t = t.reshape(-1, C).contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 def _dev(t):
     cuda = t.is_cuda
     return (t.device.index if cuda else -1), (torch.cuda.current_stream(t.device).cuda_stream if cuda else None)
@@ -42,7 +48,7 @@ class _AddLayerNorm(torch.autograd.Function):
     def forward(ctx, a, b, gamma, beta, eps, p, seed, seed_dev):
         shape = a.shape
         C = shape[-1]
-        a2, b2 = a.reshape(-1, C).contiguous(), b.reshape(-1, C).contiguous()
+        a2, b2 = _rows(a, C), _rows(b, C)
         rows = a2.shape[0]
         g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
         y, s = torch.empty_like(a2), torch.empty_like(a2)
@@ -64,7 +70,7 @@ class _AddLayerNorm(torch.autograd.Function):
     def backward(ctx, dy):
         s, g32, stats = ctx.saved_tensors
         io, rows, C, p, seed, shape, g_dtype, b_dtype = ctx.meta
-        dy2 = dy.reshape(-1, C).contiguous()
+        dy2 = _rows(dy, C)
         da, db = torch.empty_like(s), torch.empty_like(s)
         lib = _lib()
         nb = lib.mdetr_add_layernorm_partial_rows(rows)
