@@ -17,7 +17,7 @@ def _io_code(dtype):
 
 
 def supported(offsets, logits, reference_points):
-    return (offsets.dtype in (torch.float32, torch.bfloat16) and logits.dtype == offsets.dtype
+    return ((offsets.is_cuda or _backend is not None) and offsets.dtype in (torch.float32, torch.bfloat16) and logits.dtype == offsets.dtype
             and reference_points.shape[-1] in (2, 6) and reference_points.stride(-1) == 1)
 
 
