@@ -62,3 +62,28 @@ def test_token_gemm_rejects_unsupported_shapes_through_the_c_abi():
     y = torch.zeros(8, 8, dtype=torch.bfloat16)
     rc = L.mdetr_token_linear(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), 8, 8, 96, 96, 8, 0, 0, None)
     assert rc != 0 and b"K" in ctypes.string_at(L.mdetr_last_error())
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_token_linear_autograd_function_with_the_emulated_kernel(relu, monkeypatch):
+    """The autograd integration the model uses (monodetr/linear.py _TokenLinear): forward through the kernel (ReLU in
+    its epilogue), input gradient through the kernel with the transposed weight, weight / bias gradients in torch."""
+    from monodetr_amd import token_gemm_ext
+    from monodetr_amd.monodetr import linear
+    monkeypatch.setattr(token_gemm_ext, "_backend", native_emul.lib())
+    monkeypatch.setattr(linear, "_TOKEN_GEMM", True)
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(2, 150, 256, generator=g) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(128, 256, generator=g) * 0.1).to(torch.bfloat16).requires_grad_(True)
+    b = torch.randn(128, generator=g).to(torch.bfloat16).requires_grad_(True)
+    dy = torch.randn(2, 150, 128, generator=g).to(torch.bfloat16)
+    y = linear._TokenLinear.apply(x, w, b, relu)
+    y.backward(dy)
+    got = (y.detach(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+    x.grad = w.grad = b.grad = None
+    ref = torch.nn.functional.linear(x.float(), w.float(), b.float())
+    ref = ref.clamp(min=0) if relu else ref
+    ref.backward(dy.float())
+    for name, a, r in zip(("y", "dx", "dw", "db"), got, (ref.detach(), x.grad, w.grad, b.grad)):
+        assert a.dtype == torch.bfloat16
+        assert (a.float() - r.float()).abs().max() <= 3e-2 * max(1.0, r.float().abs().max().item()), name
