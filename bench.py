@@ -84,10 +84,10 @@ def synthetic_batch(B, H, W, seed, device):
 
 # ---- optional kernels ----------------------------------------------------------------------------
 # Each is switched on by an environment variable of the same name (= "1") or, when none is set, chosen by the
-# start-up autotune below.  MDETR_MSDA_BF16 changes the MSDA operator's element type, which the roofline accounting of
-# this file does not model, so it is environment-only.
-AUTOTUNE_SWITCHES = ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN", "MDETR_TOKEN_GEMM")
-ALL_SWITCHES = AUTOTUNE_SWITCHES + ("MDETR_MSDA_BF16",)
+# start-up autotune below.  (MDETR_MSDA_BF16 changes the MSDA operator's element types; the roofline accounting
+# follows it: msda_algorithmic_bytes(mixed=True), and the PMC traffic figure recorded for the fp32 operator is dropped.)
+AUTOTUNE_SWITCHES = ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN", "MDETR_MSDA_BF16", "MDETR_TOKEN_GEMM")
+ALL_SWITCHES = AUTOTUNE_SWITCHES
 
 
 def env_switches():
@@ -108,10 +108,13 @@ def apply_switches(names):
 
 
 def probe_configs(precision):
-    """Candidate switch sets: the default path, everything but the token GEMM (the one candidate that replaces a tuned
-    library kernel and may well be slower), everything.  The fullest set runs last so that a crash in it loses nothing."""
+    """Candidate switch sets, nested: the default path; the fused criterion / optimizer / prologue / LayerNorm kernels;
+    + the bf16-native MSDA; + the token GEMM (the one candidate that replaces a tuned library kernel and may well be
+    slower).  The fullest set runs last so that a crash in it loses nothing.  The last two exist for a bf16 body only."""
     base = ["MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN"]
-    return [[], base] + ([base + ["MDETR_TOKEN_GEMM"]] if precision == "bf16" else [])
+    if precision != "bf16":
+        return [[], base]
+    return [[], base, base + ["MDETR_MSDA_BF16"], base + ["MDETR_MSDA_BF16", "MDETR_TOKEN_GEMM"]]
 
 
 def choose_config(results, rel_tol=0.03, min_gain=0.01):
@@ -133,7 +136,7 @@ def choose_config(results, rel_tol=0.03, min_gain=0.01):
     return sorted(best["switches"]), why
 
 
-def run_probe(args, local_rank, configs, timeout=300):
+def run_probe(args, local_rank, configs, timeout=330):
     """Run `bench.py --probe` in a child process (a kernel that faults takes the child down, not this process) and
     return the PROBE records it managed to print."""
     import subprocess
@@ -365,10 +368,14 @@ def bind_to_gpu_numa_node(local_rank):
         return None
 
 
-def msda_algorithmic_bytes(B, Lq, backward, S=10200, M=8, D=32, L=4, P=4, e=4):
-    """value + loc + attn + out (forward); + grad_value + grad_loc + grad_attn (backward)."""
-    fwd = e * B * (S * M * D + Lq * M * L * P * 3 + Lq * M * D)
-    return fwd + e * B * (S * M * D + Lq * M * L * P * 3) if backward else fwd
+def msda_algorithmic_bytes(B, Lq, backward, S=10200, M=8, D=32, L=4, P=4, e=4, mixed=False):
+    """value + loc + attn + out (forward); + grad_value + grad_loc + grad_attn (backward), `e` bytes per
+    element.  mixed = the bf16-native operator (MDETR_MSDA_BF16): value / out / grad_out are 2-byte, sampling
+    locations, weights and all three gradients stay 4-byte."""
+    ev = 2 if mixed else e
+    samples = B * Lq * M * L * P * 3
+    fwd = ev * B * S * M * D + e * samples + ev * B * Lq * M * D
+    return fwd + e * (B * S * M * D + samples) if backward else fwd
 
 
 def cpu_baseline(steps=1):
@@ -502,13 +509,14 @@ def main():
     names = {0: "msda_fwd_rec", 1: "msda_bwd_d32", 2: "msda_scatter_tiles", 3: "msda_reduce_tiles",
              4: "attn_fwd_kernel", 5: "attn_bwd(prep+dq+dkv)"}
     kernels, by_key = [], {}
+    msda_mixed = "MDETR_MSDA_BF16" in step.switches               # bf16-native operator: 2-byte value / out / grad_out
     for kind, key, launches, total_ms in _capi.profile_read():
         avg = total_ms / max(launches, 1)
         row = {"kernel": names.get(kind, str(kind)), "launches": launches, "avg_ms": round(avg, 4)}
         if kind <= 3:
             row["Lq"] = key
             if kind == 0:
-                byts = msda_algorithmic_bytes(args.batch, key, False)
+                byts = msda_algorithmic_bytes(args.batch, key, False, mixed=msda_mixed)
                 row.update(algorithmic_MB=round(byts / 1e6, 1), achieved_GBps=round(byts / avg / 1e6, 1),
                            frac=round(byts / avg / 1e6 / 8000.0, 4))
         else:
@@ -522,7 +530,7 @@ def main():
     for (kind, key), avg in by_key.items():
         if kind == 1:
             parts = [avg] + [by_key[(k2, key)] for k2 in (2, 3) if (k2, key) in by_key]
-            byts = msda_algorithmic_bytes(args.batch, key, True)
+            byts = msda_algorithmic_bytes(args.batch, key, True, mixed=msda_mixed)
             ops.append({"op": "msda_backward", "Lq": key, "kernels_in_op": len(parts), "ms": round(sum(parts), 4),
                         "algorithmic_MB": round(byts / 1e6, 1), "achieved_GBps": round(byts / sum(parts) / 1e6, 1),
                         "frac": round(byts / sum(parts) / 1e6 / 8000.0, 4)})
@@ -554,7 +562,7 @@ def main():
             # dominant hand-written operator: MSDA backward at the encoder shape (gather + tile scatter + reduce)
             line["roofline"] = {"kernel": "msda_backward(Lq=%d): msda_bwd_d32 + msda_scatter_tiles + msda_reduce_tiles" % dom["Lq"],
                                 "bound": "hbm", "achieved": dom["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
-                                "frac": dom["frac"], "traffic": traffic.get("msda_backward_Lq%d" % dom["Lq"]),
+                                "frac": dom["frac"], "traffic": None if msda_mixed else traffic.get("msda_backward_Lq%d" % dom["Lq"]),
                                 "avg_launch_ms": dom["ms"], "algorithmic_bytes": int(dom["algorithmic_MB"] * 1e6)}
             line["roofline"]["timing"] = kernel_timing
             line["ops"] = ops

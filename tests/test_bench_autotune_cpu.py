@@ -24,9 +24,11 @@ def clean_env(monkeypatch):
 
 def test_candidate_sets():
     bf = bench.probe_configs("bf16")
-    assert bf[0] == [] and set(bf[-1]) == set(bench.AUTOTUNE_SWITCHES) and set(bf[1]) == set(bf[-1]) - {"MDETR_TOKEN_GEMM"}
-    assert "MDETR_TOKEN_GEMM" not in sum(bench.probe_configs("fp32"), [])          # a bf16-only kernel
-    assert "MDETR_MSDA_BF16" not in bench.AUTOTUNE_SWITCHES                          # changes the roofline accounting: environment only
+    assert bf[0] == [] and set(bf[-1]) == set(bench.AUTOTUNE_SWITCHES) and all(set(a) < set(b) for a, b in zip(bf, bf[1:]))   # nested
+    assert not {"MDETR_TOKEN_GEMM", "MDETR_MSDA_BF16"} & set(sum(bench.probe_configs("fp32"), []))                          # bf16-body kernels
+    # the roofline accounting follows the operator's element types
+    f32, mixed = bench.msda_algorithmic_bytes(8, 10200, True), bench.msda_algorithmic_bytes(8, 10200, True, mixed=True)
+    assert f32 - mixed == 2 * 8 * 10200 * 8 * 32 * 2                                        # value and grad_out at half width
 
 
 def test_choice_takes_the_fastest_admissible_candidate():
@@ -52,7 +54,7 @@ def test_autotune_runs_one_probe_caches_per_box_and_reports(tmp_path):
         return [{"switches": sorted(c), "losses": [30.0, 29.0, 28.0], "ms": 38.0 - 1.5 * len(c)} for c in configs]
     cache = str(tmp_path / "tune.json")
     chosen, report = bench.autotune(args(), 1, 0, runner=runner, cache_path=cache)
-    assert chosen == sorted(bench.AUTOTUNE_SWITCHES) and report["source"] == "probe" and len(report["candidates"]) == 3
+    assert chosen == sorted(bench.AUTOTUNE_SWITCHES) and report["source"] == "probe" and len(report["candidates"]) == 4
     chosen2, report2 = bench.autotune(args(), 1, 0, runner=runner, cache_path=cache)
     assert chosen2 == chosen and report2["source"] == "cache" and len(calls) == 1
     # another precision is another key
@@ -103,6 +105,9 @@ def test_apply_switches_sets_and_clears_the_module_flags():
     assert add_ln_ext.ENABLED and ms_deform_attn._FUSED_PROLOGUE and not linear._TOKEN_GEMM and not ms_deform_attn_func._NATIVE_BF16
     bench.apply_switches(set())
     assert not (add_ln_ext.ENABLED or ms_deform_attn._FUSED_PROLOGUE or linear._TOKEN_GEMM or ms_deform_attn_func._NATIVE_BF16)
+    bench.apply_switches({"MDETR_MSDA_BF16"})
+    assert ms_deform_attn_func._NATIVE_BF16
+    bench.apply_switches(set())
 
 
 def test_probe_candidate_runs_the_training_step_with_exactly_its_switches(oracle):

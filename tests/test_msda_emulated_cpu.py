@@ -117,3 +117,59 @@ def test_emulated_bf16_kernels_match_the_fp32_kernels_on_widened_tensors(B, M, L
                                       p["level_start"].data_ptr() if n else None, ws.data_ptr() if n else None, n, 0, None))
     rv, rl, ra = bwd(wide, tiled=bool(n))
     assert close(gv, rv, 1e-6) and close(gl, rl, 1e-6) and close(ga, ra, 1e-6)
+
+
+class _EmulModule:
+    """The extension-module object as MSDeformAttnFunction sees it, backed by the emulated C ABI (CPU tensors)."""
+
+    @staticmethod
+    def bf16_supported(value, loc):
+        return value.dtype == torch.bfloat16 and value.shape[3] == 32 and loc.shape[3] == 4 and loc.shape[4] == 4
+
+    @staticmethod
+    def ms_deform_attn_forward(value, shapes, start, loc, attn, im2col_step):
+        return fwd(dict(value=value, shapes=shapes, level_start=start, loc=loc, attn=attn))
+
+    @staticmethod
+    def ms_deform_attn_backward(value, shapes, start, loc, attn, grad_out, im2col_step):
+        return list(bwd(dict(value=value, shapes=shapes, level_start=start, loc=loc, attn=attn, grad_out=grad_out)))
+
+    @staticmethod
+    def ms_deform_attn_forward_bf16(value, shapes, start, loc, attn):
+        L = native_emul.lib()
+        B, S, M, D = value.shape
+        Lq = loc.shape[1]
+        out = torch.empty(B, Lq, M * D, dtype=torch.bfloat16)
+        _check(L.mdetr_msda_forward_bf16(value.data_ptr(), shapes.data_ptr(), start.data_ptr(), loc.data_ptr(), attn.data_ptr(),
+                                         out.data_ptr(), B, S, M, D, 4, Lq, 4, 0, None))
+        return out
+
+    @staticmethod
+    def ms_deform_attn_backward_bf16(value, shapes, start, loc, attn, grad_out):
+        L = native_emul.lib()
+        B, S, M, D = value.shape
+        Lq = loc.shape[1]
+        gv, gl, ga = torch.empty(B, S, M, D), torch.empty_like(loc), torch.empty_like(attn)
+        _check(L.mdetr_msda_backward_bf16(value.data_ptr(), shapes.data_ptr(), start.data_ptr(), loc.data_ptr(), attn.data_ptr(),
+                                          grad_out.data_ptr(), gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, S, M, D, 4, Lq, 4,
+                                          None, None, None, 0, 0, None))
+        return [gv, gl, ga]
+
+
+def test_autograd_function_with_native_bf16_matches_the_widening_path(monkeypatch):
+    """MSDeformAttnFunction as a bf16 model calls it (bf16 value, locations and weights): MDETR_MSDA_BF16 on vs off."""
+    from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func as F
+    monkeypatch.setattr(F, "MSDA", _EmulModule)
+    p = make_problem(2, 8, 32, 50, SMALL, 4, torch.float32, seed=6, lo=-0.1, hi=1.1)
+    res = {}
+    for native in (False, True):
+        monkeypatch.setattr(F, "_NATIVE_BF16", native)
+        v = (p["value"] * 100).to(torch.bfloat16).requires_grad_(True)
+        l = p["loc"].to(torch.bfloat16).requires_grad_(True)
+        a = p["attn"].to(torch.bfloat16).requires_grad_(True)
+        out = F.MSDeformAttnFunction.apply(v, p["shapes"], p["level_start"], l, a, 64)
+        out.backward(p["grad_out"].to(torch.bfloat16))
+        res[native] = (out.detach(), v.grad, l.grad, a.grad)
+    for x, y in zip(res[False], res[True]):
+        assert x.dtype == y.dtype == torch.bfloat16
+        assert (x.float() - y.float()).abs().max() <= 2 ** -7 * max(1.0, x.float().abs().max().item())
