@@ -121,9 +121,13 @@ def choose_config(results, rel_tol=0.03, min_gain=0.01):
     """results: list of {"switches": [...], "losses": [3 floats], "ms": float} from one probe run, the default path
     (no switches) among them.  A candidate is admissible if its three deterministic losses are finite and within
     rel_tol of the default path's; the fastest admissible one wins if it beats the default by min_gain."""
-    base = next((r for r in results if not r["switches"]), None)
-    if base is None or not all(x == x and abs(x) != float("inf") for x in base["losses"]):
+    bases = [r for r in results if not r["switches"]]
+    if not bases or not all(x == x and abs(x) != float("inf") for x in bases[0]["losses"]):
         return [], "no default-path probe"
+    # the default path is probed first and again last (the first candidate of a process also pays for library warm-up):
+    # its reference time is the better of the two
+    base = dict(bases[0], ms=min(r["ms"] for r in bases))
+    results = [base] + [r for r in results if r["switches"]]
     best, why = base, "default path is fastest"
     for r in results:
         if r is base:
@@ -186,9 +190,9 @@ def autotune(args, world, local_rank, runner=run_probe, cache_path=None):
                 pass
         if world > 1:
             return None, None                                         # no cached decision: every rank stays on the default path
-        results = runner(args, local_rank, probe_configs(args.precision))
+        results = runner(args, local_rank, probe_configs(args.precision) + [[]])
         chosen, why = choose_config(results)
-        configs = probe_configs(args.precision)
+        configs = probe_configs(args.precision) + [[]]
         report = {"source": "probe", "decision": why, "chosen": chosen,
                   "candidates": [{"switches": r["switches"], "ms": r["ms"], "admissible": r.get("admissible", True)} for r in results]}
         if len(results) < len(configs):                               # a candidate took the child down: say how
