@@ -208,9 +208,9 @@ def autotune(args, world, local_rank, runner=run_probe, cache_path=None):
 
 
 def probe_config(device, batch, precision, names, size=(384, 1280), warm=5, timed=8, prepare=None):
-    """One candidate of the autotune: build the training step with exactly the switch set `names` and dropout disabled
-    (deterministic: same initial weights, same inputs for every candidate), report the first three losses and the
-    time per iteration of `timed` iterations after `warm` more."""
+    """One candidate of the autotune: build the training step with exactly the switch set `names`; three iterations
+    with dropout disabled (deterministic: same initial weights, same inputs for every candidate) give the losses to
+    compare, then -- dropout back on, the configuration the benchmark runs -- `warm` + `timed` iterations give the time."""
     step = TrainStep(device, batch, precision, switches=names, size=size)
     if prepare is not None:
         prepare(step)                                                 # (tests: CPU stand-ins for the device library)
