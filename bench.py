@@ -108,13 +108,15 @@ def apply_switches(names):
 
 
 def probe_configs(precision):
-    """Candidate switch sets, nested: the default path; the fused criterion / optimizer / prologue / LayerNorm kernels;
-    + the bf16-native MSDA; + the token GEMM (the one candidate that replaces a tuned library kernel and may well be
-    slower).  The fullest set runs last so that a crash in it loses nothing.  The last two exist for a bf16 body only."""
-    base = ["MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN"]
+    """Candidate switch sets, nested so that a set which fails still leaves the smaller ones standing: the default path;
+    the criterion / optimizer kernels; + the model-side prologue and LayerNorm kernels; + the bf16-native MSDA; + the
+    token GEMM (the one candidate that replaces a tuned library kernel and may well be slower).  The fullest set runs
+    last so that a crash in it loses nothing.  The last two exist for a bf16 body only."""
+    loss_side = ["MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW"]
+    base = loss_side + ["MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN"]
     if precision != "bf16":
-        return [[], base]
-    return [[], base, base + ["MDETR_MSDA_BF16"], base + ["MDETR_MSDA_BF16", "MDETR_TOKEN_GEMM"]]
+        return [[], loss_side, base]
+    return [[], loss_side, base, base + ["MDETR_MSDA_BF16"], base + ["MDETR_MSDA_BF16", "MDETR_TOKEN_GEMM"]]
 
 
 def choose_config(results, rel_tol=0.03, min_gain=0.01):
@@ -140,7 +142,7 @@ def choose_config(results, rel_tol=0.03, min_gain=0.01):
     return sorted(best["switches"]), why
 
 
-def run_probe(args, local_rank, configs, timeout=330):
+def run_probe(args, local_rank, configs, timeout=360):
     """Run `bench.py --probe` in a child process (a kernel that faults takes the child down, not this process) and
     return the PROBE records it managed to print."""
     import subprocess
