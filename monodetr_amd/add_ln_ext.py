@@ -14,6 +14,19 @@ _backend = None               # tests substitute the CPU emulation of the same k
 ENABLED = os.environ.get("MDETR_FUSED_LN") == "1"
 
 
+_seed_counter = None
+
+
+def _host_seed():
+    """A new 64-bit seed per call: a Weyl sequence started from torch's CPU generator (reproducible under
+    torch.manual_seed), as attn_ext._next_seed does on the device."""
+    global _seed_counter
+    if _seed_counter is None:
+        _seed_counter = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
+    _seed_counter = (_seed_counter + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    return _seed_counter
+
+
 def _lib():
     return _backend if _backend is not None else _capi.lib()
 
@@ -90,7 +103,10 @@ def fused_add_layernorm(a, b, gamma, beta, eps=1e-5, dropout_p=0.0, seed=None):
     otherwise every call draws a fresh device-resident seed."""
     seed_dev = None
     if dropout_p > 0.0 and seed is None:
-        seed_dev = _next_seed(a.device)
+        if a.is_cuda and torch.cuda.is_current_stream_capturing():
+            seed_dev = _next_seed(a.device)                 # a replayed graph needs a seed that lives on the device
+        else:
+            seed = _host_seed()                             # eager: a host integer costs no launch
     return _AddLayerNorm.apply(a, b, gamma, beta, eps, dropout_p, seed or 0, seed_dev)
 
 
