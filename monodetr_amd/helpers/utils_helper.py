@@ -1,28 +1,34 @@
-"""Logger and seeding -- mirror of ``lib/helpers/utils_helper.py`` (seed, seed^2, seed^3, seed^4 for Python / numpy /
-torch CPU / torch device generators, so that a run is comparable with a reference run of the same ``random_seed``)."""
+"""Seeding and logging for the training script -- mirror of ``lib/helpers/utils_helper.py``.
+
+``set_random_seed(s)`` seeds Python with s, numpy with s^2, torch's CPU generator with s^3 and the device generators
+with s^4 -- the reference's scheme, so a run here draws the same augmentations and initial weights as a reference run
+with the same ``random_seed``.  (The reference also forces cuDNN into deterministic mode; MIOpen has no such switch.)
+"""
 import logging
 import random
 
 import numpy as np
 import torch
 
-
-def create_logger(log_file, rank=0):
-    fmt = '%(asctime)s  %(levelname)5s  %(message)s'
-    level = logging.INFO if rank == 0 else logging.ERROR
-    logging.basicConfig(level=level, format=fmt, filename=log_file)
-    logger = logging.getLogger(__name__)
-    if not any(isinstance(h, logging.StreamHandler) and not isinstance(h, logging.FileHandler) for h in logger.handlers):
-        console = logging.StreamHandler()
-        console.setLevel(level)
-        console.setFormatter(logging.Formatter(fmt))
-        logger.addHandler(console)
-    return logger
+_FORMAT = '%(asctime)s  %(levelname)5s  %(message)s'
 
 
 def set_random_seed(seed):
-    random.seed(seed)
-    np.random.seed(seed ** 2)
-    torch.manual_seed(seed ** 3)
+    for seeder, power in ((random.seed, 1), (np.random.seed, 2), (torch.manual_seed, 3)):
+        seeder(seed ** power)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed ** 4)
+
+
+def create_logger(log_file, rank=0):
+    """File + console logger; ranks other than 0 only report errors."""
+    level = logging.INFO if rank == 0 else logging.ERROR
+    logging.basicConfig(level=level, format=_FORMAT, filename=log_file)
+    logger = logging.getLogger(__name__)
+    has_console = any(type(h) is logging.StreamHandler for h in logger.handlers)
+    if not has_console:
+        console = logging.StreamHandler()
+        console.setFormatter(logging.Formatter(_FORMAT))
+        console.setLevel(level)
+        logger.addHandler(console)
+    return logger
