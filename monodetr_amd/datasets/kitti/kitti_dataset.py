@@ -57,52 +57,39 @@ def draw_photometric(desc):
 
 
 class KITTI_Dataset(data.Dataset):
+    # configuration keys of the `dataset:` section and their defaults (kitti_dataset.py:24-84)
+    _OPTIONS = (('use_3d_center', True), ('bbox2d_type', 'anno'), ('meanshape', False), ('class_merging', False),
+                ('use_dontcare', False), ('aug_pd', False), ('aug_crop', False), ('aug_calib', False), ('random_flip', 0.5),
+                ('random_crop', 0.5), ('scale', 0.4), ('shift', 0.1), ('depth_scale', 'normal'), ('clip_2d', False))
+    _MEAN_SIZE = ((1.76255119, 0.66068622, 0.84422524),            # h, w, l of Pedestrian / Car / Cyclist (meanshape)
+                  (1.52563191462, 1.62856739989, 3.88311640418),
+                  (1.73698127, 0.59706367, 1.76282397))
+
     def __init__(self, split, cfg):
-        self.root_dir = cfg.get('root_dir')
-        self.split = split
-        self.num_classes, self.max_objs = 3, 50
-        self.class_name = ['Pedestrian', 'Car', 'Cyclist']
-        self.cls2id = {'Pedestrian': 0, 'Car': 1, 'Cyclist': 2}
-        self.resolution = np.array([1280, 384])                    # W, H
-        self.use_3d_center = cfg.get('use_3d_center', True)
-        self.writelist = list(cfg.get('writelist', ['Car']))
-        self.bbox2d_type = cfg.get('bbox2d_type', 'anno')
+        assert split in ['train', 'val', 'trainval', 'test']
+        self.split, self.root_dir = split, cfg.get('root_dir')
+        for key, default in self._OPTIONS:
+            setattr(self, key, cfg.get(key, default))
         assert self.bbox2d_type in ['anno', 'proj']
-        self.meanshape = cfg.get('meanshape', False)
-        self.class_merging = cfg.get('class_merging', False)
-        self.use_dontcare = cfg.get('use_dontcare', False)
+        self.num_classes, self.max_objs, self.downsample = 3, 50, 32
+        self.class_name = ['Pedestrian', 'Car', 'Cyclist']
+        self.cls2id = {name: i for i, name in enumerate(self.class_name)}
+        self.resolution = np.array([1280, 384])                    # W, H
+        self.writelist = list(cfg.get('writelist', ['Car']))
         if self.class_merging:
             self.writelist.extend(['Van', 'Truck'])
         if self.use_dontcare:
             self.writelist.extend(['DontCare'])
 
-        assert self.split in ['train', 'val', 'trainval', 'test']
-        with open(os.path.join(self.root_dir, 'ImageSets', self.split + '.txt')) as f:
+        with open(os.path.join(self.root_dir, 'ImageSets', split + '.txt')) as f:
             self.idx_list = [x.strip() for x in f.readlines()]
         self.data_dir = os.path.join(self.root_dir, 'testing' if split == 'test' else 'training')
-        self.image_dir = os.path.join(self.data_dir, 'image_2')
-        self.calib_dir = os.path.join(self.data_dir, 'calib')
-        self.label_dir = os.path.join(self.data_dir, 'label_2')
-
+        self.image_dir, self.calib_dir, self.label_dir = (os.path.join(self.data_dir, d) for d in ('image_2', 'calib', 'label_2'))
         self.data_augmentation = split in ['train', 'trainval']
-        self.aug_pd = cfg.get('aug_pd', False)
-        self.aug_crop = cfg.get('aug_crop', False)
-        self.aug_calib = cfg.get('aug_calib', False)
-        self.random_flip = cfg.get('random_flip', 0.5)
-        self.random_crop = cfg.get('random_crop', 0.5)
-        self.scale = cfg.get('scale', 0.4)
-        self.shift = cfg.get('shift', 0.1)
-        self.depth_scale = cfg.get('depth_scale', 'normal')
 
         self.mean = np.array([0.485, 0.456, 0.406], dtype=np.float32)
         self.std = np.array([0.229, 0.224, 0.225], dtype=np.float32)
-        self.cls_mean_size = np.array([[1.76255119, 0.66068622, 0.84422524],
-                                       [1.52563191462, 1.62856739989, 3.88311640418],
-                                       [1.73698127, 0.59706367, 1.76282397]])
-        if not self.meanshape:
-            self.cls_mean_size = np.zeros_like(self.cls_mean_size, dtype=np.float32)
-        self.downsample = 32
-        self.clip_2d = cfg.get('clip_2d', False)
+        self.cls_mean_size = np.array(self._MEAN_SIZE) if self.meanshape else np.zeros((3, 3), dtype=np.float32)
 
     # ---- files -------------------------------------------------------------------------------
     def get_image(self, idx):
