@@ -262,6 +262,8 @@ class TrainStep:
         if switches is not None:
             apply_switches(self.switches)
         torch.manual_seed(seed)                               # same initial weights on every rank
+        if os.environ.get("MDETR_BENCH_MIOPEN_FIND") == "1":       # experiment: let MIOpen time its solvers per convolution shape
+            torch.backends.cudnn.benchmark = True
         cfg = dict(MODEL_CFG, device=str(device).split(':')[0])
         self.model, self.criterion = build_monodetr(cfg)
         self.model.to(device)
