@@ -53,6 +53,8 @@ class Tester(object):
         inputs, calibs, targets, info = batch
         dataset = self.dataloader.dataset
         inputs, calibs = inputs.to(self.device), calibs.to(self.device)
+        if inputs.is_cuda:
+            inputs = inputs.contiguous(memory_format=torch.channels_last)
         started = time.time()
         outputs = self.model(inputs, calibs, targets, info['img_size'].to(self.device), dn_args=0)
         spent = time.time() - started

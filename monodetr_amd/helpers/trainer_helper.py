@@ -87,6 +87,8 @@ class Trainer(object):
     def train_step(self, inputs, calibs, targets, info=None):
         """One iteration on a collated batch; returns the dict of unweighted loss tensors (on the device)."""
         inputs, calibs = inputs.to(self.device, non_blocking=True), calibs.to(self.device, non_blocking=True)
+        if inputs.is_cuda:
+            inputs = inputs.contiguous(memory_format=torch.channels_last)
         targets = {k: v.to(self.device, non_blocking=True) for k, v in targets.items()}
         img_sizes = targets['img_size']
         if self.cfg.get("use_dn"):

@@ -63,6 +63,8 @@ def build_run(cfg, proc):
                                                  world_size=proc.world, rank=proc.rank)
     model, criterion = model_helper.build_model(cfg['model'])
     model, criterion = model.to(proc.device), criterion.to(proc.device)
+    if proc.on_gpu:
+        model.to(memory_format=torch.channels_last)                 # MIOpen's fast path; feature maps then flatten to tokens as views
     if bf16:
         from monodetr_amd.helpers.precision import to_bf16_body
         to_bf16_body(model)
