@@ -305,7 +305,8 @@ int mdetr_token_linear(const void *x, const void *weight, const void *bias, void
  * caller (in the reference's order, monodetr_amd/datasets/kitti_dataset.py) and arrive in the descriptors.
  *   pixels   device, uint8: the batch's decoded images back to back, each H x W x 3 (RGB, rows of 3 W bytes)
  *   images   device, MdetrKittiImage[n_images] (8-byte aligned)
- *   out      device, [n_images, 3, out_h, out_w] MDETR_F32 or MDETR_BF16 (bf16 = the float32 result rounded to
+ *   out      device, [n_images, 3, out_h, out_w] (channels_last = 0) or [n_images, out_h, out_w, 3] (= 1: the
+ *            memory of a torch channels_last tensor), MDETR_F32 or MDETR_BF16 (bf16 = the float32 result rounded to
  *            nearest even), 16-byte aligned, out_w % 4 == 0
  *   mean, std   host pointers to 3 floats each (kitti_dataset.py:79-80)
  */
@@ -325,7 +326,7 @@ typedef struct MdetrKittiImage {
     double inv[6];          /* PIL's AFFINE data: source = inv * (output pixel centre, 1) */
 } MdetrKittiImage;
 int mdetr_kitti_preprocess(const uint8_t *pixels, const MdetrKittiImage *images, int n_images, void *out,
-                           int out_dtype, int out_h, int out_w, const float *mean, const float *std,
+                           int out_dtype, int out_h, int out_w, int channels_last, const float *mean, const float *std,
                            int device, void *stream);
 
 /*

@@ -533,7 +533,7 @@ int mdetr_box3d_overlap_eval(const double *boxes, const double *qboxes, const in
 }
 
 int mdetr_kitti_preprocess(const uint8_t *pixels, const MdetrKittiImage *images, int n_images, void *out,
-                           int out_dtype, int out_h, int out_w, const float *mean, const float *std,
+                           int out_dtype, int out_h, int out_w, int channels_last, const float *mean, const float *std,
                            int device, void *stream)
 {
     if (n_images < 0 || out_h < 0 || out_w < 0) return fail(MDETR_E_ARG, "mdetr_kitti_preprocess: negative size");
@@ -549,7 +549,7 @@ int mdetr_kitti_preprocess(const uint8_t *pixels, const MdetrKittiImage *images,
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_kitti_preprocess: set device %d: %s", device, hipGetErrorString(dev.err));
     mdetr::KittiNorm norm;
     for (int c = 0; c < 3; ++c) { norm.mean[c] = mean[c]; norm.stdv[c] = std[c]; }
-    const hipError_t e = mdetr::kitti_prep_launch(pixels, images, n_images, out, out_dtype, out_h, out_w, norm,
+    const hipError_t e = mdetr::kitti_prep_launch(pixels, images, n_images, out, out_dtype, out_h, out_w, norm, channels_last != 0,
                                                   static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_kitti_preprocess: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;

@@ -37,7 +37,7 @@ template <> __device__ __forceinline__ void store_px4<__hip_bfloat16>(__hip_bflo
 template <typename O>
 __global__ __launch_bounds__(kThreads)
 void kitti_prep_kernel(const uint8_t *__restrict__ pixels, const MdetrKittiImage *__restrict__ images, int n_images,
-                       O *__restrict__ out, int out_h, int out_w, KittiNorm norm)
+                       O *__restrict__ out, int out_h, int out_w, KittiNorm norm, int channels_last)
 {
     const int n = blockIdx.x % n_images;                      // image -> XCD (blockIdx % 8) when n_images == 8
     const int tile = blockIdx.x / n_images;
@@ -55,6 +55,15 @@ void kitti_prep_kernel(const uint8_t *__restrict__ pixels, const MdetrKittiImage
         r[0][i] = px[0]; r[1][i] = px[1]; r[2][i] = px[2];
     }
     const int64_t plane = static_cast<int64_t>(out_h) * out_w;
+    if (channels_last) {                                      // [n][y][x][c]: the thread's 4 pixels are 12 consecutive values
+        float v[3][kPix];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v[i / kPix][i % kPix] = r[i % 3][i / 3];
+        O *o = out + (static_cast<int64_t>(n) * plane + static_cast<int64_t>(oy) * out_w + ox0) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) store_px4<O>(o + c * kPix, v[c]);
+        return;
+    }
     O *o = out + static_cast<int64_t>(n) * 3 * plane + static_cast<int64_t>(oy) * out_w + ox0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) store_px4<O>(o + c * plane, r[c]);
@@ -63,7 +72,7 @@ void kitti_prep_kernel(const uint8_t *__restrict__ pixels, const MdetrKittiImage
 }  // namespace
 
 hipError_t kitti_prep_launch(const uint8_t *pixels, const MdetrKittiImage *images, int n_images, void *out,
-                             int out_dtype, int out_h, int out_w, KittiNorm norm, hipStream_t st)
+                             int out_dtype, int out_h, int out_w, KittiNorm norm, int channels_last, hipStream_t st)
 {
     if (n_images == 0 || out_h == 0 || out_w == 0) return hipSuccess;
     const int64_t groups = static_cast<int64_t>(out_w / kPix) * out_h;
@@ -71,10 +80,10 @@ hipError_t kitti_prep_launch(const uint8_t *pixels, const MdetrKittiImage *image
     const dim3 grid(static_cast<unsigned>(tiles * n_images)), block(kThreads);
     if (out_dtype == 0)
         hipLaunchKernelGGL(kitti_prep_kernel<float>, grid, block, 0, st, pixels, images, n_images,
-                           static_cast<float *>(out), out_h, out_w, norm);
+                           static_cast<float *>(out), out_h, out_w, norm, channels_last);
     else
         hipLaunchKernelGGL(kitti_prep_kernel<__hip_bfloat16>, grid, block, 0, st, pixels, images, n_images,
-                           static_cast<__hip_bfloat16 *>(out), out_h, out_w, norm);
+                           static_cast<__hip_bfloat16 *>(out), out_h, out_w, norm, channels_last);
     return hipGetLastError();
 }
 

@@ -90,7 +90,7 @@ class DeviceLoader:
 
     def _run(self, packed, n):
         head = n * prep.DESCRIPTOR.itemsize
-        return prep.preprocess_batch(packed[head:], packed[:head], self.out_hw, self.dtype)
+        return prep.preprocess_batch(packed[head:], packed[:head], self.out_hw, self.dtype, channels_last=self.device.type == 'cuda')
 
     def __iter__(self):
         pending = None

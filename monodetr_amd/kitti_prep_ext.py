@@ -27,9 +27,11 @@ def _lib():
     return _backend if _backend is not None else _capi.lib()
 
 
-def preprocess_batch(pixels, descriptors, out_hw=(384, 1280), dtype=torch.float32, mean=_MEAN, std=_STD, out=None):
+def preprocess_batch(pixels, descriptors, out_hw=(384, 1280), dtype=torch.float32, mean=_MEAN, std=_STD, out=None,
+                     channels_last=False):
     """pixels: uint8 1-D tensor (all images of the batch back to back); descriptors: uint8 tensor viewing
     ``DESCRIPTOR`` records [n * 88] on the same device -> [n, 3, H, W] ``dtype`` tensor on that device.
+    ``channels_last`` lays the result out as torch's channels_last memory format (what the convolutions want).
     Runs on the current stream; no synchronisation."""
     if pixels.dtype != torch.uint8 or descriptors.dtype != torch.uint8 or not pixels.is_contiguous() or not descriptors.is_contiguous():
         raise RuntimeError("pixels and descriptors must be contiguous uint8 tensors")
@@ -43,16 +45,17 @@ def preprocess_batch(pixels, descriptors, out_hw=(384, 1280), dtype=torch.float3
         raise RuntimeError("output dtype must be float32 or bfloat16")
     n = descriptors.numel() // DESCRIPTOR.itemsize
     H, W = out_hw
+    fmt = torch.channels_last if channels_last else torch.contiguous_format
     if out is None:
-        out = torch.empty((n, 3, H, W), dtype=dtype, device=pixels.device)
-    elif tuple(out.shape) != (n, 3, H, W) or out.dtype != dtype or not out.is_contiguous() or out.device != pixels.device:
-        raise RuntimeError("out must be a contiguous [n,3,H,W] tensor of the requested dtype on the pixels' device")
+        out = torch.empty((n, 3, H, W), dtype=dtype, device=pixels.device, memory_format=fmt)
+    elif tuple(out.shape) != (n, 3, H, W) or out.dtype != dtype or not out.is_contiguous(memory_format=fmt) or out.device != pixels.device:
+        raise RuntimeError("out must be a dense [n,3,H,W] tensor of the requested dtype and memory format on the pixels' device")
     m = np.asarray(mean, dtype=np.float32)
     s = np.asarray(std, dtype=np.float32)
     cuda = pixels.is_cuda
     rc = _lib().mdetr_kitti_preprocess(
         pixels.data_ptr(), descriptors.data_ptr(), n, out.data_ptr(),
-        _capi.MDETR_F32 if dtype == torch.float32 else _capi.MDETR_BF16, H, W, m.ctypes.data, s.ctypes.data,
+        _capi.MDETR_F32 if dtype == torch.float32 else _capi.MDETR_BF16, H, W, 1 if channels_last else 0, m.ctypes.data, s.ctypes.data,
         pixels.device.index if cuda else -1, torch.cuda.current_stream(pixels.device).cuda_stream if cuda else None)
     if rc != 0:
         _capi.check(rc, "mdetr_kitti_preprocess")

@@ -46,14 +46,14 @@ def main():
     head = n * prep.DESCRIPTOR.itemsize
     staged = packed.pin_memory()
     dev = staged.cuda()
-    out = torch.empty((n, 3, 384, 1280), dtype=dt, device="cuda")
+    out = torch.empty((n, 3, 384, 1280), dtype=dt, device="cuda", memory_format=torch.channels_last)
 
     def kernel():
-        prep.preprocess_batch(dev[head:], dev[:head], dtype=dt, out=out)
+        prep.preprocess_batch(dev[head:], dev[:head], dtype=dt, out=out, channels_last=True)
 
     def with_copy():
         d = staged.to("cuda", non_blocking=True)
-        prep.preprocess_batch(d[head:], d[:head], dtype=dt, out=out)
+        prep.preprocess_batch(d[head:], d[:head], dtype=dt, out=out, channels_last=True)
 
     res = {}
     for tag, fn in (("kernel", kernel), ("h2d+kernel", with_copy)):

@@ -301,7 +301,7 @@ int mdetr_pair_losses_backward(const float *logits, const float *boxes, const fl
 
 // same argument list as mdetr_kitti_preprocess; `pixels`, `images` and `out` are host memory here
 int mdetr_kitti_preprocess(const uint8_t *pixels, const MdetrKittiImage *images, int n_images, void *out,
-                           int out_dtype, int out_h, int out_w, const float *mean, const float *std,
+                           int out_dtype, int out_h, int out_w, int channels_last, const float *mean, const float *std,
                            int device, void *stream)
 {
     (void)device; (void)stream;
@@ -313,7 +313,8 @@ int mdetr_kitti_preprocess(const uint8_t *pixels, const MdetrKittiImage *images,
                 float px[3];
                 kp_pixel(images[n], pixels + images[n].pixel_offset, ox, oy, mean, std, px);
                 for (int c = 0; c < 3; ++c) {
-                    const int64_t at = (static_cast<int64_t>(n) * 3 + c) * plane + static_cast<int64_t>(oy) * out_w + ox;
+                    const int64_t at = channels_last ? (static_cast<int64_t>(n) * plane + static_cast<int64_t>(oy) * out_w + ox) * 3 + c
+                                                     : (static_cast<int64_t>(n) * 3 + c) * plane + static_cast<int64_t>(oy) * out_w + ox;
                     if (out_dtype == 0) static_cast<float *>(out)[at] = px[c];
                     else static_cast<uint16_t *>(out)[at] = f32_to_bf16(px[c]);
                 }

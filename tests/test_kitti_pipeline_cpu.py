@@ -244,3 +244,23 @@ def test_install_aliases_the_reference_module_names_of_the_pipeline():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and r.stdout.strip() == 'ok', r.stderr
+
+
+def test_channels_last_output_holds_the_same_values(host_backend):
+    import torch
+    from monodetr_amd.helpers.dataloader_helper import pack_images
+    rs = np.random.RandomState(8)
+    images = []
+    for k, (w, h) in enumerate([(200, 90), (161, 77)]):
+        d = np.zeros(1, dtype=host_backend.DESCRIPTOR)
+        d['width'], d['height'], d['flags'], d['perm'] = w, h, 127, [0x24, 0x06][k]
+        d['brightness'], d['contrast'], d['saturation'], d['hue'] = 11.0, 1.2, 0.8, -7.0
+        d['inv'] = [w / 128.0, 0.01, -1, 0.002, h / 48.0, -0.5]
+        images.append({'pixels': kitti_synth.synth_image(rs, w, h), 'descriptor': d})
+    packed, n = pack_images(images)
+    head = n * host_backend.DESCRIPTOR.itemsize
+    for dtype in (torch.float32, torch.bfloat16):
+        a = host_backend.preprocess_batch(packed[head:], packed[:head], out_hw=(48, 128), dtype=dtype)
+        b = host_backend.preprocess_batch(packed[head:], packed[:head], out_hw=(48, 128), dtype=dtype, channels_last=True)
+        assert b.shape == a.shape and b.is_contiguous(memory_format=torch.channels_last) and not b.is_contiguous()
+        assert torch.equal(a, b)
