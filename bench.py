@@ -196,7 +196,8 @@ def autotune(args, world, local_rank, runner=run_probe, cache_path=None):
         chosen, why = choose_config(results)
         configs = probe_configs(args.precision) + [[]]
         report = {"source": "probe", "decision": why, "chosen": chosen,
-                  "candidates": [{"switches": r["switches"], "ms": r["ms"], "admissible": r.get("admissible", True)} for r in results]}
+                  "candidates": [dict({"switches": r["switches"], "ms": r["ms"], "admissible": r.get("admissible", True)},
+                                      **({"error": r["error"]} if "error" in r else {})) for r in results]}
         if len(results) < len(configs):                               # a candidate took the child down: say how
             report["unfinished"] = [sorted(c) for c in configs[len(results):]]
             report["child_stderr_tail"] = getattr(runner, "stderr_tail", "")
@@ -246,7 +247,11 @@ def probe_main(args):
     from monodetr_amd import _capi
     _capi.lib()
     for names in json.loads(args.probe):
-        print("PROBE " + json.dumps(probe_config(device, args.batch, args.precision, names)), flush=True)
+        try:
+            record = probe_config(device, args.batch, args.precision, names)
+        except Exception as e:                                        # a refused call (not a fault): this candidate is out, the rest go on
+            record = {"switches": sorted(names), "losses": [float("nan")] * 3, "ms": 1e9, "finite": False, "error": repr(e)[:300]}
+        print("PROBE " + json.dumps(record), flush=True)
         gc.collect()
         torch.cuda.empty_cache()
 
