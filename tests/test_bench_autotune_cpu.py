@@ -147,3 +147,44 @@ def test_probe_candidate_runs_the_training_step_with_exactly_its_switches(oracle
     chosen, _ = bench.choose_config([recs[0], dict(recs[1], ms=recs[0]["ms"] * 0.5)])
     assert chosen == sorted(cands[1]), (recs[0]["losses"], recs[1]["losses"])          # losses agree within the probe's tolerance
     assert all(abs(a - b) <= 0.01 * abs(b) for a, b in zip(recs[1]["losses"], recs[0]["losses"]))      # (3 % allowed; bf16 body, two optimizer steps in)
+
+
+def test_bench_main_composes_its_json_line(monkeypatch, capsys):
+    """bench.main() from argument parsing to the JSON line with the GPU mocked away (a stand-in step, canned kernel
+    timings): catches slips in the line's bookkeeping -- switches, probe report, roofline bytes following the operator's
+    element types -- without a GPU."""
+    import sys
+    import torch
+    from monodetr_amd import _capi
+
+    class Step:
+        def __init__(self, *a, switches=None, **k):
+            self.switches, self.raw_model = set(switches or []), torch.nn.Linear(1, 1)
+
+        def __call__(self):
+            return torch.tensor(1.5)
+
+    def no_topology(i):
+        raise AttributeError
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
+    monkeypatch.setattr(torch.cuda, "get_device_properties", no_topology)
+    monkeypatch.setattr(_capi, "lib", lambda: None)
+    monkeypatch.setattr(_capi, "profile_enable", lambda on: None)
+    monkeypatch.setattr(_capi, "profile_read", lambda: [(0, 10200, 3, 0.7), (1, 10200, 3, 3.0), (2, 10200, 3, 2.1), (3, 10200, 3, 0.3),
+                                                        (1, 550, 3, 0.6), (4, 1920 * 4096 + 1920, 3, 0.4)])
+    monkeypatch.setattr(bench, "TrainStep", Step)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--prime", "1", "--no-cpu-baseline"])
+    for chosen in (["MDETR_MSDA_BF16", "MDETR_FUSED_LN"], None):
+        monkeypatch.setattr(bench, "autotune", lambda *a, **k: (chosen, {"source": "probe", "chosen": chosen} if chosen else None))
+        bench.main()
+        line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+        assert line["metric"].startswith("training images/sec") and line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 0
+        assert line["config"]["switches"] == sorted(chosen or []) and ("autotune" in line["config"]) == bool(chosen)
+        roof = line["roofline"]
+        assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / 8000.0) < 1e-3
+        if chosen:
+            assert roof["traffic"] is None and roof["algorithmic_bytes"] == 417800000         # bf16 value / out / grad_out
+        else:
+            assert roof["algorithmic_bytes"] == 501400000
