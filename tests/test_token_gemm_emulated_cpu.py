@@ -28,7 +28,9 @@ def run(x, w, bias, relu, ldy=None):
     (97, 128, 264, False, False),       # K = 128; N = 264: two column blocks, the second with 8 live features
     (33, 512, 136, True, True),         # K = 512, NB = 4, two column blocks
     (1, 256, 8, False, True),           # one token, one quad pair
-    (2100, 256, 256, True, True),       # more tiles than waves in flight: 66 tiles, grid-stride + prefetch of the next tile
+    (2100, 256, 256, True, True),       # 66 tiles over 17 workgroups
+    (33000, 128, 16, True, True),       # 1032 tiles > 4 waves x 256 workgroups (the launch cap): waves wrap to a second tile,
+                                        # with the next tile's loads requested across the wrap
 ])
 def test_token_gemm_source_on_the_cpu_shim_matches_linear(T, K, N, relu, use_bias):
     g = torch.Generator().manual_seed(T + K + N)
