@@ -1,0 +1,83 @@
+"""Op-level timing of the kernels written after round 1's GPU budget against the framework operators
+they replace, at the encoder's token count (81 600 x 256, bf16), with algorithmic bytes -> fraction of the 8 TB/s HBM
+roofline.
+
+    python -m monodetr_amd.tools.fusedbench [--iters 30]
+"""
+import argparse
+import json
+
+import torch
+import torch.nn.functional as F
+
+HBM = 8.0e12
+
+
+def timeit(fn, iters):
+    for _ in range(5):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def row(ms, byts, **extra):
+    return dict(ms=round(ms, 4), GBps=round(byts / ms / 1e6, 1), frac=round(byts / (ms * 1e-3) / HBM, 4), **extra)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=30)
+    a = ap.parse_args()
+    dev, T, C, e = "cuda", 81600, 256, 2
+    res = {}
+
+    # ---- residual + dropout + LayerNorm ----------------------------------------------------------------------------
+    from monodetr_amd import add_ln_ext
+    x = torch.randn(T, C, device=dev).to(torch.bfloat16).requires_grad_(True)
+    r = torch.randn(T, C, device=dev).to(torch.bfloat16).requires_grad_(True)
+    norm = torch.nn.LayerNorm(C).to(dev).to(torch.bfloat16)
+    drop = torch.nn.Dropout(0.1)
+    dy = torch.randn(T, C, device=dev).to(torch.bfloat16)
+    fused_f = lambda: add_ln_ext.fused_add_layernorm(x, r, norm.weight, norm.bias, norm.eps, 0.1)
+    torch_f = lambda: norm(x + drop(r))
+    for tag, f in (("fused", fused_f), ("framework", torch_f)):
+        y = f()
+        bwd = lambda: torch.autograd.grad(y, (x, r, norm.weight, norm.bias), dy, retain_graph=True)
+        res["add_ln_fwd_" + tag] = row(timeit(f, a.iters), 4 * T * C * e)
+        res["add_ln_bwd_" + tag] = row(timeit(bwd, a.iters), 4 * T * C * e)
+
+    # ---- token GEMM ------------------------------------------------------------------------------------------------
+    from monodetr_amd import token_gemm_ext
+    w = (torch.randn(C, C, device=dev) * 0.05).to(torch.bfloat16)
+    b = torch.randn(C, device=dev).to(torch.bfloat16)
+    xt = x.detach()
+    byts = e * (T * C + T * C + C * C)
+    res["token_gemm_256x256"] = row(timeit(lambda: token_gemm_ext.token_gemm(xt, w, b), a.iters), byts, TFLOPs=None)
+    res["library_gemm_256x256"] = row(timeit(lambda: F.linear(xt, w, b), a.iters), byts)
+    res["token_gemm_256x256_relu"] = row(timeit(lambda: token_gemm_ext.token_gemm(xt, w, b, relu=True), a.iters), byts)
+    res["library_gemm_256x256_relu"] = row(timeit(lambda: F.relu(F.linear(xt, w, b)), a.iters), byts)
+    w128 = (torch.randn(128, C, device=dev) * 0.05).to(torch.bfloat16)
+    byts = e * (T * C + T * 128 + 128 * C)
+    res["token_gemm_256x128"] = row(timeit(lambda: token_gemm_ext.token_gemm(xt, w128), a.iters), byts)
+    res["library_gemm_256x128"] = row(timeit(lambda: F.linear(xt, w128), a.iters), byts)
+
+    # ---- fused AdamW -----------------------------------------------------------------------------------------------
+    from monodetr_amd.helpers.optimizer_helper import AdamW, FusedAdamW
+    for tag, cls in (("fused", FusedAdamW), ("foreach", AdamW)):
+        params = [torch.nn.Parameter(torch.randn(256, 256, device=dev)) for _ in range(140)] + [torch.nn.Parameter(torch.randn(2048, 1024, device=dev)) for _ in range(12)]
+        for p in params:
+            p.grad = torch.randn_like(p)
+        opt = cls([{'params': params, 'weight_decay': 1e-4}], lr=2e-4)
+        opt.step()
+        n = sum(p.numel() for p in params)
+        res["adamw_" + tag] = row(timeit(opt.step, a.iters), 28 * n, parameters=n)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

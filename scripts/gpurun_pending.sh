@@ -22,3 +22,4 @@ python -m monodetr_amd.tools.prepbench --dtype bf16 2>&1 | tail -1 | tee $O/prep
 python tests/prep_cpu_baseline.py | tee $O/prep_cpu_baseline.json
 python -m monodetr_amd.tools.evalbench 2>&1 | tail -1 | tee $O/evalbench.json
 rm -f ${TMPDIR:-/tmp}/mdetr_bench_autotune.json; python bench.py --no-cpu-baseline 2>$O/bench_autotune.err | tee $O/bench_autotune.json | val "start-up probe (default invocation)"
+python -m monodetr_amd.tools.fusedbench 2>&1 | tail -1 | tee $O/fusedbench.json
