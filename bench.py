@@ -14,8 +14,8 @@ gradients are all-reduced over RCCL/xGMI by DistributedDataParallel.  Rank 0 pri
 
 Optional kernels: with no MDETR_* switch in the environment, rank 0 of an N = 1 run first probes, in a
 child process on the same GPU, the default path and the candidate sets of `probe_configs` -- three deterministic
-iterations each (dropout off) whose losses must agree with the default path's within 3 %, then a short timing with
-dropout on -- and runs the benchmark with the fastest admissible set (`config.switches`, `config.autotune` on the JSON
+iterations each (dropout off) whose losses (3 %) and first-iteration gradient norms (6 %) must agree with the default
+path's, then a short timing with dropout on -- and runs the benchmark with the fastest admissible set (`config.switches`, `config.autotune` on the JSON
 line; the decision is cached in $TMPDIR for the N > 1 runs that follow).  A candidate that crashes, times out,
 disagrees or is not faster leaves the default path in place.  MDETR_BENCH_AUTOTUNE=0 skips the probe.
 
@@ -122,7 +122,8 @@ def probe_configs(precision):
 def choose_config(results, rel_tol=0.03, min_gain=0.01):
     """results: list of {"switches": [...], "losses": [3 floats], "ms": float} from one probe run, the default path
     (no switches) among them.  A candidate is admissible if its three deterministic losses are finite and within
-    rel_tol of the default path's; the fastest admissible one wins if it beats the default by min_gain."""
+    rel_tol of the default path's and the summed gradient norms of its first iteration within 2 rel_tol; the fastest
+    admissible one wins if it beats the default by min_gain."""
     bases = [r for r in results if not r["switches"]]
     if not bases or not all(x == x and abs(x) != float("inf") for x in bases[0]["losses"]):
         return [], "no default-path probe"
@@ -136,6 +137,9 @@ def choose_config(results, rel_tol=0.03, min_gain=0.01):
             continue
         ok = r.get("finite", True) and len(r["losses"]) == len(base["losses"]) and all(
             x == x and abs(x - b) <= rel_tol * max(abs(b), 1e-6) for x, b in zip(r["losses"], base["losses"]))
+        if ok and "grad_norm" in r and "grad_norm" in base:           # first-iteration gradients agree as well
+            g, gb = r["grad_norm"], base["grad_norm"]
+            ok = g == g and abs(g - gb) <= 2 * rel_tol * max(abs(gb), 1e-6)
         r["admissible"] = bool(ok)
         if ok and r["ms"] < best["ms"] and r["ms"] <= base["ms"] * (1.0 - min_gain):
             best, why = r, "fastest admissible candidate"
@@ -226,7 +230,10 @@ def probe_config(device, batch, precision, names, size=(384, 1280), warm=5, time
             saved.append((m, "dropout", m.dropout))
             m.dropout = 0.0
     sync = (lambda: torch.cuda.synchronize(device)) if device.type == "cuda" else (lambda: None)
-    losses = [float(step().detach()) for _ in range(3)]
+    losses = [float(step().detach())]
+    with torch.no_grad():                                             # gradients of the first iteration, summarised: sum of per-tensor norms
+        grad_norm = float(sum(p.grad.float().norm() for p in step.raw_model.parameters() if p.grad is not None))
+    losses += [float(step().detach()) for _ in range(2)]
     for m, name, value in saved:                                      # ... and back on for the timed ones (the configuration the benchmark runs)
         setattr(m, name, value)
     for _ in range(warm):
@@ -237,7 +244,8 @@ def probe_config(device, batch, precision, names, size=(384, 1280), warm=5, time
         last = step()
     sync()
     ms = (time.perf_counter() - t0) / max(timed, 1) * 1e3
-    return {"switches": sorted(names), "losses": losses, "ms": round(ms, 3), "finite": bool(torch.isfinite(last.detach()).item())}
+    return {"switches": sorted(names), "losses": losses, "grad_norm": grad_norm, "ms": round(ms, 3),
+            "finite": bool(torch.isfinite(last.detach()).item())}
 
 
 def probe_main(args):

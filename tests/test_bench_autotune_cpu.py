@@ -43,6 +43,9 @@ def test_choice_takes_the_fastest_admissible_candidate():
     assert bench.choose_config([base, slower]) == ([], "default path is fastest")
     assert bench.choose_config([base, dict(good, ms=37.9)])[0] == []                # below the 1 % gain threshold
     assert bench.choose_config([good])[0] == []                                      # no default-path probe: nothing to compare with
+    # first-iteration gradients must agree too
+    assert bench.choose_config([dict(base, grad_norm=100.0), dict(good, grad_norm=103.0)])[0] == sorted(good["switches"])
+    assert bench.choose_config([dict(base, grad_norm=100.0), dict(good, grad_norm=120.0)])[0] == []
     # the default path is timed first and last; the better time is the reference
     assert bench.choose_config([base, dict(good, ms=36.5), dict(base, ms=36.0)])[0] == []
     assert bench.choose_config([])[0] == []
@@ -146,6 +149,7 @@ def test_probe_candidate_runs_the_training_step_with_exactly_its_switches(oracle
     assert recs[0]["switches"] == [] and recs[1]["switches"] == sorted(cands[1]) and recs[1]["ms"] > 0
     chosen, _ = bench.choose_config([recs[0], dict(recs[1], ms=recs[0]["ms"] * 0.5)])
     assert chosen == sorted(cands[1]), (recs[0]["losses"], recs[1]["losses"])          # losses agree within the probe's tolerance
+    assert abs(recs[1]["grad_norm"] - recs[0]["grad_norm"]) <= 0.02 * recs[0]["grad_norm"]
     assert all(abs(a - b) <= 0.01 * abs(b) for a, b in zip(recs[1]["losses"], recs[0]["losses"]))      # (3 % allowed; bf16 body, two optimizer steps in)
 
 
