@@ -368,7 +368,8 @@ int mdetr_kitti_pr_curve(const double *overlaps, const int64_t *ov_start, const 
  * y = LayerNorm(a + dropout(b)) over the last dimension, one pass each way -- the ten residual sites of the model
  * (lib/models/monodetr/depthaware_transformer.py:331-353, :431-435, :456-510; depth_predictor/transformer.py:57-65),
  * which the reference runs as nn.Dropout, an addition and nn.LayerNorm.
- *   io_dtype   MDETR_F32 or MDETR_BF16: a, b, y, s (and dy, da, db); gamma / beta / stats fp32; fp32 arithmetic
+ *   io_dtype   MDETR_F32 or MDETR_BF16: a, b, y, s (and dy, da, db); stats fp32; fp32 arithmetic
+ *   param_dtype  MDETR_F32 or MDETR_BF16: gamma, beta (a bf16 model body keeps them in bf16)
  *   a, b       [rows, cols] contiguous, cols in {128, 256, 512}, 16-byte aligned; b may be NULL (plain LayerNorm)
  *   s          out, a + dropout(b) as the backward reads it (may be NULL when b is NULL: the backward then takes a)
  *   stats      out, fp32 [rows, 2] = (mean, 1 / sqrt(var + eps))
@@ -378,11 +379,11 @@ int mdetr_kitti_pr_curve(const double *overlaps, const int64_t *ov_start, const 
  *   partial    fp32 [mdetr_add_layernorm_partial_rows(rows), 2 * cols]: columns [0, cols) sum dy * xhat (d gamma),
  *              [cols, 2 cols) sum dy (d beta); the caller finishes them with mdetr_column_sum
  */
-int mdetr_add_layernorm_forward(int io_dtype, const void *a, const void *b, const float *gamma, const float *beta, void *y,
+int mdetr_add_layernorm_forward(int io_dtype, int param_dtype, const void *a, const void *b, const void *gamma, const void *beta, void *y,
                                 void *s, float *stats, int64_t rows, int cols, float eps, float dropout_p, uint64_t seed,
                                 const uint64_t *seed_dev, int device, void *stream);
 int64_t mdetr_add_layernorm_partial_rows(int64_t rows);
-int mdetr_add_layernorm_backward(int io_dtype, const void *dy, const void *s, const float *gamma, const float *stats,
+int mdetr_add_layernorm_backward(int io_dtype, int param_dtype, const void *dy, const void *s, const void *gamma, const float *stats,
                                  void *da, void *db, float *partial, int64_t rows, int cols, float dropout_p,
                                  uint64_t seed, const uint64_t *seed_dev, int device, void *stream);
 

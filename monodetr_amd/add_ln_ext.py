@@ -63,38 +63,44 @@ class _AddLayerNorm(torch.autograd.Function):
         C = shape[-1]
         a2, b2 = _rows(a, C), _rows(b, C)
         rows = a2.shape[0]
-        g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
+        if gamma.dtype == beta.dtype and gamma.dtype in (torch.float32, torch.bfloat16):
+            gp, bp = gamma.contiguous(), beta.contiguous()           # read as they are: no cast launches
+        else:
+            gp, bp = gamma.float().contiguous(), beta.float().contiguous()
+        pcode = _capi.MDETR_BF16 if gp.dtype == torch.bfloat16 else _capi.MDETR_F32
         y, s = torch.empty_like(a2), torch.empty_like(a2)
         stats = torch.empty((rows, 2), dtype=torch.float32, device=a.device)
         io = _capi.MDETR_BF16 if a.dtype == torch.bfloat16 else _capi.MDETR_F32
         dev, stream = _dev(a2)
-        rc = _lib().mdetr_add_layernorm_forward(io, a2.data_ptr(), b2.data_ptr(), g32.data_ptr(), b32.data_ptr(), y.data_ptr(), s.data_ptr(),
+        rc = _lib().mdetr_add_layernorm_forward(io, pcode, a2.data_ptr(), b2.data_ptr(), gp.data_ptr(), bp.data_ptr(), y.data_ptr(), s.data_ptr(),
                                                 stats.data_ptr(), rows, C, float(eps), float(p), int(seed),
                                                 seed_dev.data_ptr() if seed_dev is not None else None, dev, stream)
         if rc != 0:
             _capi.check(rc, "mdetr_add_layernorm_forward")
-        ctx.save_for_backward(s, g32, stats)
+        ctx.save_for_backward(s, gp, stats)
         ctx.seed_dev = seed_dev
-        ctx.meta = (io, rows, C, float(p), int(seed), shape, gamma.dtype, beta.dtype)
+        ctx.meta = (io, pcode, rows, C, float(p), int(seed), shape, gamma.dtype, beta.dtype)
         return y.view(shape)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        s, g32, stats = ctx.saved_tensors
-        io, rows, C, p, seed, shape, g_dtype, b_dtype = ctx.meta
+        s, gp, stats = ctx.saved_tensors
+        io, pcode, rows, C, p, seed, shape, g_dtype, b_dtype = ctx.meta
         dy2 = _rows(dy, C)
         da, db = torch.empty_like(s), torch.empty_like(s)
         lib = _lib()
         nb = lib.mdetr_add_layernorm_partial_rows(rows)
         partial = torch.empty((nb, 2 * C), dtype=torch.float32, device=s.device)
         dev, stream = _dev(s)
-        rc = lib.mdetr_add_layernorm_backward(io, dy2.data_ptr(), s.data_ptr(), g32.data_ptr(), stats.data_ptr(), da.data_ptr(), db.data_ptr(),
+        rc = lib.mdetr_add_layernorm_backward(io, pcode, dy2.data_ptr(), s.data_ptr(), gp.data_ptr(), stats.data_ptr(), da.data_ptr(), db.data_ptr(),
                                               partial.data_ptr(), rows, C, p, seed,
                                               ctx.seed_dev.data_ptr() if ctx.seed_dev is not None else None, dev, stream)
         if rc != 0:
             _capi.check(rc, "mdetr_add_layernorm_backward")
         sums = _column_sum_f32(partial)
+        if g_dtype == b_dtype:
+            sums = sums.to(g_dtype)                                 # one cast for both
         return da.view(shape), db.view(shape), sums[:C].to(g_dtype), sums[C:].to(b_dtype), None, None, None, None
 
 

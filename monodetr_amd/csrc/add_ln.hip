@@ -58,10 +58,10 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-template <typename T, int E>
+template <typename T, typename PT, int E>
 __global__ __launch_bounds__(kWavesLn * 64)
-void add_ln_fwd_kernel(const T *__restrict__ a, const T *__restrict__ b, const float *__restrict__ gamma,
-                       const float *__restrict__ beta, T *__restrict__ y, T *__restrict__ s, float *__restrict__ stats,
+void add_ln_fwd_kernel(const T *__restrict__ a, const T *__restrict__ b, const PT *__restrict__ gamma,
+                       const PT *__restrict__ beta, T *__restrict__ y, T *__restrict__ s, float *__restrict__ stats,
                        int64_t rows, float eps, uint32_t thresh, float keep_scale, uint64_t seed,
                        const uint64_t *__restrict__ seed_dev)
 {
@@ -97,14 +97,14 @@ void add_ln_fwd_kernel(const T *__restrict__ a, const T *__restrict__ b, const f
     const float rstd = 1.0f / sqrtf(wave_sum(sq) * (1.0f / C) + eps);
     float o[E];
 #pragma unroll
-    for (int i = 0; i < E; ++i) o[i] = (v[i] - mean) * rstd * gamma[lane * E + i] + beta[lane * E + i];
+    for (int i = 0; i < E; ++i) o[i] = (v[i] - mean) * rstd * ld1<PT>(gamma + lane * E + i) + ld1<PT>(beta + lane * E + i);
     store_row<T, E>(y + at, o);
     if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 
-template <typename T, int E>
+template <typename T, typename PT, int E>
 __global__ __launch_bounds__(kWavesLn * 64)
-void add_ln_bwd_kernel(const T *__restrict__ dy, const T *__restrict__ s, const float *__restrict__ gamma,
+void add_ln_bwd_kernel(const T *__restrict__ dy, const T *__restrict__ s, const PT *__restrict__ gamma,
                        const float *__restrict__ stats, T *__restrict__ da, T *__restrict__ db,
                        float *__restrict__ partial, int64_t rows, uint32_t thresh, float keep_scale, uint64_t seed,
                        const uint64_t *__restrict__ seed_dev)
@@ -115,7 +115,7 @@ void add_ln_bwd_kernel(const T *__restrict__ dy, const T *__restrict__ s, const 
     const uint64_t sd = seed + (seed_dev ? *seed_dev : 0ull);
     float g[E], acc_g[E], acc_b[E];
 #pragma unroll
-    for (int i = 0; i < E; ++i) { g[i] = gamma[lane * E + i]; acc_g[i] = 0.f; acc_b[i] = 0.f; }
+    for (int i = 0; i < E; ++i) { g[i] = ld1<PT>(gamma + lane * E + i); acc_g[i] = 0.f; acc_b[i] = 0.f; }
     for (int64_t row = static_cast<int64_t>(blockIdx.x) * kWavesLn + wave; row < rows; row += static_cast<int64_t>(gridDim.x) * kWavesLn) {
         const int64_t at = row * C + lane * E;
         const float mean = stats[2 * row], rstd = stats[2 * row + 1];
@@ -154,26 +154,28 @@ void add_ln_bwd_kernel(const T *__restrict__ dy, const T *__restrict__ s, const 
         partial[static_cast<int64_t>(blockIdx.x) * 2 * C + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
-template <typename T, int E>
-hipError_t launch_fwd(const AddLnProblem &p, const void *a, const void *b, const float *gamma, const float *beta, void *y, void *s,
+template <typename T, typename PT, int E>
+hipError_t launch_fwd(const AddLnProblem &p, const void *a, const void *b, const void *gamma, const void *beta, void *y, void *s,
                       float *stats, hipStream_t st)
 {
     const uint32_t thresh = b ? ln_threshold(p.dropout_p) : 0u;
     const float scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
-    hipLaunchKernelGGL((add_ln_fwd_kernel<T, E>), dim3(static_cast<unsigned>((p.rows + kWavesLn - 1) / kWavesLn)), dim3(kWavesLn * 64), 0, st,
-                       static_cast<const T *>(a), static_cast<const T *>(b), gamma, beta, static_cast<T *>(y), static_cast<T *>(s), stats,
+    hipLaunchKernelGGL((add_ln_fwd_kernel<T, PT, E>), dim3(static_cast<unsigned>((p.rows + kWavesLn - 1) / kWavesLn)), dim3(kWavesLn * 64), 0, st,
+                       static_cast<const T *>(a), static_cast<const T *>(b), static_cast<const PT *>(gamma), static_cast<const PT *>(beta),
+                       static_cast<T *>(y), static_cast<T *>(s), stats,
                        p.rows, p.eps, thresh, scale, p.seed, p.seed_dev);
     return hipGetLastError();
 }
 
-template <typename T, int E>
-hipError_t launch_bwd(const AddLnProblem &p, const void *dy, const void *s, const float *gamma, const float *stats, void *da, void *db,
+template <typename T, typename PT, int E>
+hipError_t launch_bwd(const AddLnProblem &p, const void *dy, const void *s, const void *gamma, const float *stats, void *da, void *db,
                       float *partial, hipStream_t st)
 {
     const uint32_t thresh = db ? ln_threshold(p.dropout_p) : 0u;
     const float scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
-    hipLaunchKernelGGL((add_ln_bwd_kernel<T, E>), dim3(static_cast<unsigned>(add_ln_partial_rows(p.rows))), dim3(kWavesLn * 64), 0, st,
-                       static_cast<const T *>(dy), static_cast<const T *>(s), gamma, stats, static_cast<T *>(da), static_cast<T *>(db), partial,
+    hipLaunchKernelGGL((add_ln_bwd_kernel<T, PT, E>), dim3(static_cast<unsigned>(add_ln_partial_rows(p.rows))), dim3(kWavesLn * 64), 0, st,
+                       static_cast<const T *>(dy), static_cast<const T *>(s), static_cast<const PT *>(gamma), stats, static_cast<T *>(da),
+                       static_cast<T *>(db), partial,
                        p.rows, thresh, scale, p.seed, p.seed_dev);
     return hipGetLastError();
 }
@@ -186,28 +188,44 @@ int64_t add_ln_partial_rows(int64_t rows)
     return blocks < 1 ? 1 : (blocks > kMaxBwdBlocks ? kMaxBwdBlocks : blocks);
 }
 
-hipError_t add_ln_forward_launch(const AddLnProblem &p, const void *a, const void *b, const float *gamma, const float *beta,
+template <int E>
+hipError_t dispatch_fwd(const AddLnProblem &p, const void *a, const void *b, const void *gamma, const void *beta, void *y, void *s,
+                        float *stats, hipStream_t st)
+{
+    using BF = __hip_bfloat16;
+    if (p.io_dtype == 2) return p.param_dtype == 2 ? launch_fwd<BF, BF, E>(p, a, b, gamma, beta, y, s, stats, st) : launch_fwd<BF, float, E>(p, a, b, gamma, beta, y, s, stats, st);
+    return p.param_dtype == 2 ? launch_fwd<float, BF, E>(p, a, b, gamma, beta, y, s, stats, st) : launch_fwd<float, float, E>(p, a, b, gamma, beta, y, s, stats, st);
+}
+
+template <int E>
+hipError_t dispatch_bwd(const AddLnProblem &p, const void *dy, const void *s, const void *gamma, const float *stats, void *da, void *db,
+                        float *partial, hipStream_t st)
+{
+    using BF = __hip_bfloat16;
+    if (p.io_dtype == 2) return p.param_dtype == 2 ? launch_bwd<BF, BF, E>(p, dy, s, gamma, stats, da, db, partial, st) : launch_bwd<BF, float, E>(p, dy, s, gamma, stats, da, db, partial, st);
+    return p.param_dtype == 2 ? launch_bwd<float, BF, E>(p, dy, s, gamma, stats, da, db, partial, st) : launch_bwd<float, float, E>(p, dy, s, gamma, stats, da, db, partial, st);
+}
+
+hipError_t add_ln_forward_launch(const AddLnProblem &p, const void *a, const void *b, const void *gamma, const void *beta,
                                  void *y, void *s, float *stats, hipStream_t st)
 {
     if (p.rows == 0) return hipSuccess;
-    const bool bf = p.io_dtype == 2;
     switch (p.cols) {
-    case 128: return bf ? launch_fwd<__hip_bfloat16, 2>(p, a, b, gamma, beta, y, s, stats, st) : launch_fwd<float, 2>(p, a, b, gamma, beta, y, s, stats, st);
-    case 256: return bf ? launch_fwd<__hip_bfloat16, 4>(p, a, b, gamma, beta, y, s, stats, st) : launch_fwd<float, 4>(p, a, b, gamma, beta, y, s, stats, st);
-    case 512: return bf ? launch_fwd<__hip_bfloat16, 8>(p, a, b, gamma, beta, y, s, stats, st) : launch_fwd<float, 8>(p, a, b, gamma, beta, y, s, stats, st);
+    case 128: return dispatch_fwd<2>(p, a, b, gamma, beta, y, s, stats, st);
+    case 256: return dispatch_fwd<4>(p, a, b, gamma, beta, y, s, stats, st);
+    case 512: return dispatch_fwd<8>(p, a, b, gamma, beta, y, s, stats, st);
     default: return hipErrorNotSupported;
     }
 }
 
-hipError_t add_ln_backward_launch(const AddLnProblem &p, const void *dy, const void *s, const float *gamma, const float *stats,
+hipError_t add_ln_backward_launch(const AddLnProblem &p, const void *dy, const void *s, const void *gamma, const float *stats,
                                   void *da, void *db, float *partial, hipStream_t st)
 {
     if (p.rows == 0) return hipSuccess;
-    const bool bf = p.io_dtype == 2;
     switch (p.cols) {
-    case 128: return bf ? launch_bwd<__hip_bfloat16, 2>(p, dy, s, gamma, stats, da, db, partial, st) : launch_bwd<float, 2>(p, dy, s, gamma, stats, da, db, partial, st);
-    case 256: return bf ? launch_bwd<__hip_bfloat16, 4>(p, dy, s, gamma, stats, da, db, partial, st) : launch_bwd<float, 4>(p, dy, s, gamma, stats, da, db, partial, st);
-    case 512: return bf ? launch_bwd<__hip_bfloat16, 8>(p, dy, s, gamma, stats, da, db, partial, st) : launch_bwd<float, 8>(p, dy, s, gamma, stats, da, db, partial, st);
+    case 128: return dispatch_bwd<2>(p, dy, s, gamma, stats, da, db, partial, st);
+    case 256: return dispatch_bwd<4>(p, dy, s, gamma, stats, da, db, partial, st);
+    case 512: return dispatch_bwd<8>(p, dy, s, gamma, stats, da, db, partial, st);
     default: return hipErrorNotSupported;
     }
 }

@@ -448,27 +448,28 @@ int mdetr_column_sum(int dtype, const void *x, float *out, void *workspace, int6
     return MDETR_OK;
 }
 
-static int add_ln_args(const char *fn, int io_dtype, int64_t rows, int cols, float dropout_p)
+static int add_ln_args(const char *fn, int io_dtype, int param_dtype, int64_t rows, int cols, float dropout_p)
 {
     if (io_dtype != MDETR_F32 && io_dtype != MDETR_BF16) return fail(MDETR_E_ARG, "%s: io_dtype %d (MDETR_F32 or MDETR_BF16)", fn, io_dtype);
+    if (param_dtype != MDETR_F32 && param_dtype != MDETR_BF16) return fail(MDETR_E_ARG, "%s: param_dtype %d (MDETR_F32 or MDETR_BF16)", fn, param_dtype);
     if (rows < 0) return fail(MDETR_E_ARG, "%s: negative row count", fn);
     if (cols != 128 && cols != 256 && cols != 512) return fail(MDETR_E_ARG, "%s: cols = %d (128, 256 or 512)", fn, cols);
     if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(MDETR_E_ARG, "%s: dropout_p = %g outside [0, 1)", fn, static_cast<double>(dropout_p));
     return MDETR_OK;
 }
 
-int mdetr_add_layernorm_forward(int io_dtype, const void *a, const void *b, const float *gamma, const float *beta, void *y,
+int mdetr_add_layernorm_forward(int io_dtype, int param_dtype, const void *a, const void *b, const void *gamma, const void *beta, void *y,
                                 void *s, float *stats, int64_t rows, int cols, float eps, float dropout_p, uint64_t seed,
                                 const uint64_t *seed_dev, int device, void *stream)
 {
-    if (int rc = add_ln_args("mdetr_add_layernorm_forward", io_dtype, rows, cols, dropout_p)) return rc;
+    if (int rc = add_ln_args("mdetr_add_layernorm_forward", io_dtype, param_dtype, rows, cols, dropout_p)) return rc;
     if (rows == 0) return MDETR_OK;
     if (!a || !gamma || !beta || !y || !stats) return fail(MDETR_E_ARG, "mdetr_add_layernorm_forward: null pointer");
     if (!aligned16(a) || !aligned16(b) || !aligned16(y) || !aligned16(s))
         return fail(MDETR_E_ALIGN, "mdetr_add_layernorm_forward: a, b, y, s must be 16-byte aligned");
     DeviceScope dev(device);
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_add_layernorm_forward: set device %d: %s", device, hipGetErrorString(dev.err));
-    const mdetr::AddLnProblem p{io_dtype, rows, cols, eps, dropout_p, seed, seed_dev};
+    const mdetr::AddLnProblem p{io_dtype, param_dtype, rows, cols, eps, dropout_p, seed, seed_dev};
     const hipError_t e = mdetr::add_ln_forward_launch(p, a, b, gamma, beta, y, s, stats, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_add_layernorm_forward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
@@ -476,18 +477,18 @@ int mdetr_add_layernorm_forward(int io_dtype, const void *a, const void *b, cons
 
 int64_t mdetr_add_layernorm_partial_rows(int64_t rows) { return mdetr::add_ln_partial_rows(rows); }
 
-int mdetr_add_layernorm_backward(int io_dtype, const void *dy, const void *s, const float *gamma, const float *stats,
+int mdetr_add_layernorm_backward(int io_dtype, int param_dtype, const void *dy, const void *s, const void *gamma, const float *stats,
                                  void *da, void *db, float *partial, int64_t rows, int cols, float dropout_p,
                                  uint64_t seed, const uint64_t *seed_dev, int device, void *stream)
 {
-    if (int rc = add_ln_args("mdetr_add_layernorm_backward", io_dtype, rows, cols, dropout_p)) return rc;
+    if (int rc = add_ln_args("mdetr_add_layernorm_backward", io_dtype, param_dtype, rows, cols, dropout_p)) return rc;
     if (!partial) return fail(MDETR_E_ARG, "mdetr_add_layernorm_backward: null partial buffer");
     if (rows > 0 && (!dy || !s || !gamma || !stats || !da)) return fail(MDETR_E_ARG, "mdetr_add_layernorm_backward: null pointer");
     if (!aligned16(dy) || !aligned16(s) || !aligned16(da) || !aligned16(db))
         return fail(MDETR_E_ALIGN, "mdetr_add_layernorm_backward: dy, s, da, db must be 16-byte aligned");
     DeviceScope dev(device);
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_add_layernorm_backward: set device %d: %s", device, hipGetErrorString(dev.err));
-    const mdetr::AddLnProblem p{io_dtype, rows, cols, 0.f, dropout_p, seed, seed_dev};
+    const mdetr::AddLnProblem p{io_dtype, param_dtype, rows, cols, 0.f, dropout_p, seed, seed_dev};
     hipError_t e = hipSuccess;
     if (rows == 0) e = mdetr::zero_fill_launch(partial, static_cast<int64_t>(2) * cols * 4, static_cast<hipStream_t>(stream));
     else e = mdetr::add_ln_backward_launch(p, dy, s, gamma, stats, da, db, partial, static_cast<hipStream_t>(stream));

@@ -81,3 +81,23 @@ def test_residual_layernorm_helper_and_module_integration(ext, monkeypatch):
     assert not torch.equal(y1, y2) and (y1 - ref).abs().max() > 1e-3     # masks differ between calls
     odd = torch.randn(2, 50, 96)
     assert torch.equal(ext.residual_layernorm(odd, odd, torch.nn.LayerNorm(96), None), torch.nn.LayerNorm(96)(odd + odd))   # unsupported width: fallback
+
+
+def test_bf16_affine_parameters_are_read_without_casts(ext):
+    """A bf16 model body keeps LayerNorm's weight and bias in bf16: the kernel reads them as they are and the gradients
+    come back in bf16."""
+    g = torch.Generator().manual_seed(5)
+    rows, C = 300, 256
+    a = torch.randn(rows, C, generator=g).to(torch.bfloat16).requires_grad_(True)
+    b = torch.randn(rows, C, generator=g).to(torch.bfloat16).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(torch.bfloat16).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).to(torch.bfloat16).requires_grad_(True)
+    dy = torch.randn(rows, C, generator=g).to(torch.bfloat16)
+    y = ext.fused_add_layernorm(a, b, gamma, beta, 1e-5, 0.0)
+    y.backward(dy)
+    assert gamma.grad.dtype == beta.grad.dtype == torch.bfloat16
+    a2, b2, g2, be2 = (t.detach().float().requires_grad_(True) for t in (a, b, gamma, beta))
+    ref = F.layer_norm((a2 + b2).to(torch.bfloat16).float(), (C,), g2, be2, 1e-5)
+    ref.backward(dy.float())
+    for got, want in ((y, ref), (a.grad, a2.grad), (gamma.grad, g2.grad), (beta.grad, be2.grad)):
+        assert (got.float() - want.detach().float()).abs().max() <= 3e-2 * max(1.0, want.abs().max().item())
