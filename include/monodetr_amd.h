@@ -217,18 +217,19 @@ int mdetr_msda_backward_bf16(const void *value, const int64_t *spatial_shapes, c
  *     attn_weight  = softmax over the L*P samples of a head (logits [B, Lq, M, L*P])
  *     sampling_loc = ref + offsets / (W_l, H_l)                          (R == 2 reference components)
  *                  = ref[:2] + offsets / P * (ref[2]+ref[3], ref[4]+ref[5]) * 0.5      (R == 6)
- *   io_dtype   MDETR_F32 or MDETR_BF16: dtype of offsets [B,Lq,M,L,P,2], logits, ref and of grad_offsets / grad_logits
+ *   io_dtype   MDETR_F32 or MDETR_BF16: dtype of offsets [B,Lq,M,L,P,2], logits and of grad_offsets / grad_logits
+ *   ref_dtype  MDETR_F32 or MDETR_BF16: dtype of ref (a bf16 model body keeps its reference points in fp32)
  *   ref        [B, Lq, L, R] with element strides (ref_sb, ref_sq, ref_sl) -- 0 for a broadcast axis -- and a
  *              contiguous last dimension;  spatial_shapes int64 [L, 2] (H, W) on the device
  *   outputs    sampling_loc fp32 [B,Lq,M,L,P,2], attn_weight fp32 [B,Lq,M,L,P]: what mdetr_msda_forward consumes
  * backward: grad_loc / grad_attn (fp32, from mdetr_msda_backward) -> grad_offsets, grad_logits (io_dtype) and, if
  * grad_ref != NULL, grad_ref fp32 [B, Lq, L, R] dense (zero-filled here, then accumulated over the M heads).
  */
-int mdetr_msda_prologue_forward(int io_dtype, const void *offsets, const void *logits, const void *ref,
+int mdetr_msda_prologue_forward(int io_dtype, int ref_dtype, const void *offsets, const void *logits, const void *ref,
                                 const int64_t *spatial_shapes, float *sampling_loc, float *attn_weight,
                                 int B, int Lq, int M, int L, int P, int R, int64_t ref_sb, int64_t ref_sq, int64_t ref_sl,
                                 int device, void *stream);
-int mdetr_msda_prologue_backward(int io_dtype, const void *offsets, const void *ref, const int64_t *spatial_shapes,
+int mdetr_msda_prologue_backward(int io_dtype, int ref_dtype, const void *offsets, const void *ref, const int64_t *spatial_shapes,
                                  const float *attn_weight, const float *grad_loc, const float *grad_attn,
                                  void *grad_offsets, void *grad_logits, float *grad_ref,
                                  int B, int Lq, int M, int L, int P, int R, int64_t ref_sb, int64_t ref_sq, int64_t ref_sl,

@@ -52,8 +52,8 @@ SIGNATURES = {
     "mdetr_kitti_preprocess": (_c_int, [_c_vp, _c_vp, _c_int, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_int, _c_vp]),
     "mdetr_msda_forward_bf16": (_c_int, [_c_vp] * 6 + [_c_int] * 7 + [_c_int, _c_vp]),
     "mdetr_msda_backward_bf16": (_c_int, [_c_vp] * 9 + [_c_int] * 7 + [_c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_vp]),
-    "mdetr_msda_prologue_forward": (_c_int, [_c_int] + [_c_vp] * 6 + [_c_int] * 6 + [ctypes.c_int64] * 3 + [_c_int, _c_vp]),
-    "mdetr_msda_prologue_backward": (_c_int, [_c_int] + [_c_vp] * 9 + [_c_int] * 6 + [ctypes.c_int64] * 3 + [_c_int, _c_vp]),
+    "mdetr_msda_prologue_forward": (_c_int, [_c_int, _c_int] + [_c_vp] * 6 + [_c_int] * 6 + [ctypes.c_int64] * 3 + [_c_int, _c_vp]),
+    "mdetr_msda_prologue_backward": (_c_int, [_c_int, _c_int] + [_c_vp] * 9 + [_c_int] * 6 + [ctypes.c_int64] * 3 + [_c_int, _c_vp]),
     "mdetr_lsa_forward_fused": (_c_int, [_c_vp] * 6 + [_c_int] * 6 + [ctypes.c_float] * 5 + [_c_int, _c_vp]),
     "mdetr_profile_enable": (_c_int, [_c_int]),
     "mdetr_profile_read": (_c_int, [_c_vp, _c_int]),

@@ -608,31 +608,33 @@ static int prologue_args(const char *who, int io_dtype, int B, int Lq, int M, in
     return MDETR_OK;
 }
 
-int mdetr_msda_prologue_forward(int io_dtype, const void *offsets, const void *logits, const void *ref,
+int mdetr_msda_prologue_forward(int io_dtype, int ref_dtype, const void *offsets, const void *logits, const void *ref,
                                 const int64_t *spatial_shapes, float *sampling_loc, float *attn_weight,
                                 int B, int Lq, int M, int L, int P, int R, int64_t ref_sb, int64_t ref_sq, int64_t ref_sl,
                                 int device, void *stream)
 {
     if (int rc = prologue_args("mdetr_msda_prologue_forward", io_dtype, B, Lq, M, L, P, R)) return rc;
+    if (ref_dtype != MDETR_F32 && ref_dtype != MDETR_BF16) return fail(MDETR_E_ARG, "mdetr_msda_prologue_forward: ref_dtype %d", ref_dtype);
     if (B == 0 || Lq == 0) return MDETR_OK;
     if (!offsets || !logits || !ref || !spatial_shapes || !sampling_loc || !attn_weight)
         return fail(MDETR_E_ARG, "mdetr_msda_prologue_forward: null pointer");
     DeviceScope dev(device);
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_prologue_forward: set device %d: %s", device, hipGetErrorString(dev.err));
     const mdetr::PrologueDims d{B, Lq, M, L, P, R, ref_sb, ref_sq, ref_sl};
-    const hipError_t e = mdetr::msda_prologue_forward_launch(io_dtype, d, offsets, logits, ref, spatial_shapes, sampling_loc,
+    const hipError_t e = mdetr::msda_prologue_forward_launch(io_dtype, ref_dtype, d, offsets, logits, ref, spatial_shapes, sampling_loc,
                                                              attn_weight, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_prologue_forward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 
-int mdetr_msda_prologue_backward(int io_dtype, const void *offsets, const void *ref, const int64_t *spatial_shapes,
+int mdetr_msda_prologue_backward(int io_dtype, int ref_dtype, const void *offsets, const void *ref, const int64_t *spatial_shapes,
                                  const float *attn_weight, const float *grad_loc, const float *grad_attn,
                                  void *grad_offsets, void *grad_logits, float *grad_ref,
                                  int B, int Lq, int M, int L, int P, int R, int64_t ref_sb, int64_t ref_sq, int64_t ref_sl,
                                  int device, void *stream)
 {
     if (int rc = prologue_args("mdetr_msda_prologue_backward", io_dtype, B, Lq, M, L, P, R)) return rc;
+    if (ref_dtype != MDETR_F32 && ref_dtype != MDETR_BF16) return fail(MDETR_E_ARG, "mdetr_msda_prologue_backward: ref_dtype %d", ref_dtype);
     if (B == 0 || Lq == 0) return MDETR_OK;
     if (!offsets || !ref || !spatial_shapes || !attn_weight || !grad_loc || !grad_attn || !grad_offsets || !grad_logits)
         return fail(MDETR_E_ARG, "mdetr_msda_prologue_backward: null pointer");
@@ -642,7 +644,7 @@ int mdetr_msda_prologue_backward(int io_dtype, const void *offsets, const void *
     hipError_t e = hipSuccess;
     if (grad_ref) e = mdetr::zero_fill_launch(grad_ref, static_cast<int64_t>(B) * Lq * L * R * 4, static_cast<hipStream_t>(stream));
     if (e == hipSuccess)
-        e = mdetr::msda_prologue_backward_launch(io_dtype, d, offsets, ref, spatial_shapes, attn_weight, grad_loc, grad_attn,
+        e = mdetr::msda_prologue_backward_launch(io_dtype, ref_dtype, d, offsets, ref, spatial_shapes, attn_weight, grad_loc, grad_attn,
                                                  grad_offsets, grad_logits, grad_ref, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_prologue_backward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;

@@ -10,11 +10,11 @@ struct PrologueDims {
     int64_t rsb, rsq, rsl;               // element strides of the reference points [B, Lq, L, R] (last dim contiguous)
 };
 
-// io_dtype: 0 = f32, 2 = bf16 (offsets, logits, reference points and the returned g_offsets / g_logits)
-hipError_t msda_prologue_forward_launch(int io_dtype, const PrologueDims &d, const void *offsets, const void *logits,
+// io_dtype: 0 = f32, 2 = bf16 (offsets, logits and the returned g_offsets / g_logits); ref_dtype: the reference points'
+hipError_t msda_prologue_forward_launch(int io_dtype, int ref_dtype, const PrologueDims &d, const void *offsets, const void *logits,
                                         const void *ref, const int64_t *shapes, float *loc, float *attn, hipStream_t st);
 // g_ref: fp32 [B, Lq, L, R] dense, accumulated with atomics -- the caller zero-fills it; NULL = not needed
-hipError_t msda_prologue_backward_launch(int io_dtype, const PrologueDims &d, const void *offsets, const void *ref,
+hipError_t msda_prologue_backward_launch(int io_dtype, int ref_dtype, const PrologueDims &d, const void *offsets, const void *ref,
                                          const int64_t *shapes, const float *attn, const float *g_loc, const float *g_attn,
                                          void *g_offsets, void *g_logits, float *g_ref, hipStream_t st);
 

@@ -28,10 +28,10 @@ template <> __device__ __forceinline__ void stf<float>(float *p, float v) { *p =
 template <> __device__ __forceinline__ void stf<__hip_bfloat16>(__hip_bfloat16 *p, float v) { *p = __float2bfloat16(v); }
 
 // TLP = L * P known at compile time (16 for MonoDETR: the per-sample arrays stay in registers) or 0 (any LP <= 64)
-template <typename T, int TLP>
+template <typename T, typename RT, int TLP>
 __global__ __launch_bounds__(256)
 void prologue_fwd_kernel(const PrologueDims d, const T *__restrict__ offsets, const T *__restrict__ logits,
-                         const T *__restrict__ ref, const int64_t *__restrict__ shapes, float *__restrict__ loc,
+                         const RT *__restrict__ ref, const int64_t *__restrict__ shapes, float *__restrict__ loc,
                          float *__restrict__ attn)
 {
     const int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;              // (b, q, m)
@@ -51,8 +51,8 @@ void prologue_fwd_kernel(const PrologueDims d, const T *__restrict__ offsets, co
     if (!TLP) for (int i = 0; i < LP; ++i) attn[u * LP + i] = at[i];
     for (int l = 0; l < d.L; ++l) {
         float rl[6];
-        const T *rp = ref + b * d.rsb + q * d.rsq + l * d.rsl;
-        for (int r = 0; r < d.R; ++r) rl[r] = ldf<T>(rp + r);
+        const RT *rp = ref + b * d.rsb + q * d.rsq + l * d.rsl;
+        for (int r = 0; r < d.R; ++r) rl[r] = ldf<RT>(rp + r);
         const float wh[2] = {static_cast<float>(shapes[2 * l + 1]), static_cast<float>(shapes[2 * l])};   // (W_l, H_l)
         for (int p = 0; p < d.P; ++p)
             for (int c = 0; c < 2; ++c) {
@@ -62,9 +62,9 @@ void prologue_fwd_kernel(const PrologueDims d, const T *__restrict__ offsets, co
     }
 }
 
-template <typename T, int TLP>
+template <typename T, typename RT, int TLP>
 __global__ __launch_bounds__(256)
-void prologue_bwd_kernel(const PrologueDims d, const T *__restrict__ offsets, const T *__restrict__ ref,
+void prologue_bwd_kernel(const PrologueDims d, const T *__restrict__ offsets, const RT *__restrict__ ref,
                          const int64_t *__restrict__ shapes, const float *__restrict__ attn,
                          const float *__restrict__ g_loc, const float *__restrict__ g_attn, T *__restrict__ g_offsets,
                          T *__restrict__ g_logits, float *__restrict__ g_ref)
@@ -86,8 +86,8 @@ void prologue_bwd_kernel(const PrologueDims d, const T *__restrict__ offsets, co
     if (!TLP) for (int i = 0; i < LP; ++i) stf<T>(g_logits + u * LP + i, gl[i]);
     for (int l = 0; l < d.L; ++l) {
         float rl[6], gr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const T *rp = ref + b * d.rsb + q * d.rsq + l * d.rsl;
-        for (int r = 0; r < d.R; ++r) rl[r] = ldf<T>(rp + r);
+        const RT *rp = ref + b * d.rsb + q * d.rsq + l * d.rsl;
+        for (int r = 0; r < d.R; ++r) rl[r] = ldf<RT>(rp + r);
         const float wh[2] = {static_cast<float>(shapes[2 * l + 1]), static_cast<float>(shapes[2 * l])};
         for (int p = 0; p < d.P; ++p)
             for (int c = 0; c < 2; ++c) {
@@ -104,49 +104,62 @@ void prologue_bwd_kernel(const PrologueDims d, const T *__restrict__ offsets, co
 
 }  // namespace
 
-hipError_t msda_prologue_forward_launch(int io_dtype, const PrologueDims &d, const void *offsets, const void *logits,
-                                        const void *ref, const int64_t *shapes, float *loc, float *attn, hipStream_t st)
+// reference points may stay fp32 while the projections' outputs are bf16 (a bf16 model body keeps its coordinates in fp32)
+template <typename T, typename RT>
+hipError_t launch_fwd(const PrologueDims &d, const void *offsets, const void *logits, const void *ref, const int64_t *shapes,
+                      float *loc, float *attn, dim3 grid, hipStream_t st)
 {
-    const int64_t total = static_cast<int64_t>(d.B) * d.Lq * d.M;
-    if (total == 0) return hipSuccess;
-    const dim3 grid(static_cast<unsigned>((total + 255) / 256)), block(256);
-    const bool lp16 = d.L * d.P == 16;
-    auto go = [&](auto kern, auto *tag) {
-        using T = std::remove_pointer_t<decltype(tag)>;
-        hipLaunchKernelGGL(kern, grid, block, 0, st, d, static_cast<const T *>(offsets), static_cast<const T *>(logits),
-                           static_cast<const T *>(ref), shapes, loc, attn);
-    };
-    if (io_dtype == 2) {
-        if (lp16) go(prologue_fwd_kernel<__hip_bfloat16, 16>, static_cast<__hip_bfloat16 *>(nullptr));
-        else go(prologue_fwd_kernel<__hip_bfloat16, 0>, static_cast<__hip_bfloat16 *>(nullptr));
-    } else {
-        if (lp16) go(prologue_fwd_kernel<float, 16>, static_cast<float *>(nullptr));
-        else go(prologue_fwd_kernel<float, 0>, static_cast<float *>(nullptr));
-    }
+    if (d.L * d.P == 16)
+        hipLaunchKernelGGL((prologue_fwd_kernel<T, RT, 16>), grid, dim3(256), 0, st, d, static_cast<const T *>(offsets),
+                           static_cast<const T *>(logits), static_cast<const RT *>(ref), shapes, loc, attn);
+    else
+        hipLaunchKernelGGL((prologue_fwd_kernel<T, RT, 0>), grid, dim3(256), 0, st, d, static_cast<const T *>(offsets),
+                           static_cast<const T *>(logits), static_cast<const RT *>(ref), shapes, loc, attn);
     return hipGetLastError();
 }
 
-hipError_t msda_prologue_backward_launch(int io_dtype, const PrologueDims &d, const void *offsets, const void *ref,
+template <typename T, typename RT>
+hipError_t launch_bwd(const PrologueDims &d, const void *offsets, const void *ref, const int64_t *shapes, const float *attn,
+                      const float *g_loc, const float *g_attn, void *g_offsets, void *g_logits, float *g_ref, dim3 grid, hipStream_t st)
+{
+    if (d.L * d.P == 16)
+        hipLaunchKernelGGL((prologue_bwd_kernel<T, RT, 16>), grid, dim3(256), 0, st, d, static_cast<const T *>(offsets),
+                           static_cast<const RT *>(ref), shapes, attn, g_loc, g_attn, static_cast<T *>(g_offsets),
+                           static_cast<T *>(g_logits), g_ref);
+    else
+        hipLaunchKernelGGL((prologue_bwd_kernel<T, RT, 0>), grid, dim3(256), 0, st, d, static_cast<const T *>(offsets),
+                           static_cast<const RT *>(ref), shapes, attn, g_loc, g_attn, static_cast<T *>(g_offsets),
+                           static_cast<T *>(g_logits), g_ref);
+    return hipGetLastError();
+}
+
+hipError_t msda_prologue_forward_launch(int io_dtype, int ref_dtype, const PrologueDims &d, const void *offsets, const void *logits,
+                                        const void *ref, const int64_t *shapes, float *loc, float *attn, hipStream_t st)
+{
+    using BF = __hip_bfloat16;
+    const int64_t total = static_cast<int64_t>(d.B) * d.Lq * d.M;
+    if (total == 0) return hipSuccess;
+    const dim3 grid(static_cast<unsigned>((total + 255) / 256));
+    if (io_dtype == 2)
+        return ref_dtype == 2 ? launch_fwd<BF, BF>(d, offsets, logits, ref, shapes, loc, attn, grid, st)
+                              : launch_fwd<BF, float>(d, offsets, logits, ref, shapes, loc, attn, grid, st);
+    return ref_dtype == 2 ? launch_fwd<float, BF>(d, offsets, logits, ref, shapes, loc, attn, grid, st)
+                          : launch_fwd<float, float>(d, offsets, logits, ref, shapes, loc, attn, grid, st);
+}
+
+hipError_t msda_prologue_backward_launch(int io_dtype, int ref_dtype, const PrologueDims &d, const void *offsets, const void *ref,
                                          const int64_t *shapes, const float *attn, const float *g_loc, const float *g_attn,
                                          void *g_offsets, void *g_logits, float *g_ref, hipStream_t st)
 {
+    using BF = __hip_bfloat16;
     const int64_t total = static_cast<int64_t>(d.B) * d.Lq * d.M;
     if (total == 0) return hipSuccess;
-    const dim3 grid(static_cast<unsigned>((total + 255) / 256)), block(256);
-    const bool lp16 = d.L * d.P == 16;
-    auto go = [&](auto kern, auto *tag) {
-        using T = std::remove_pointer_t<decltype(tag)>;
-        hipLaunchKernelGGL(kern, grid, block, 0, st, d, static_cast<const T *>(offsets), static_cast<const T *>(ref), shapes,
-                           attn, g_loc, g_attn, static_cast<T *>(g_offsets), static_cast<T *>(g_logits), g_ref);
-    };
-    if (io_dtype == 2) {
-        if (lp16) go(prologue_bwd_kernel<__hip_bfloat16, 16>, static_cast<__hip_bfloat16 *>(nullptr));
-        else go(prologue_bwd_kernel<__hip_bfloat16, 0>, static_cast<__hip_bfloat16 *>(nullptr));
-    } else {
-        if (lp16) go(prologue_bwd_kernel<float, 16>, static_cast<float *>(nullptr));
-        else go(prologue_bwd_kernel<float, 0>, static_cast<float *>(nullptr));
-    }
-    return hipGetLastError();
+    const dim3 grid(static_cast<unsigned>((total + 255) / 256));
+    if (io_dtype == 2)
+        return ref_dtype == 2 ? launch_bwd<BF, BF>(d, offsets, ref, shapes, attn, g_loc, g_attn, g_offsets, g_logits, g_ref, grid, st)
+                              : launch_bwd<BF, float>(d, offsets, ref, shapes, attn, g_loc, g_attn, g_offsets, g_logits, g_ref, grid, st);
+    return ref_dtype == 2 ? launch_bwd<float, BF>(d, offsets, ref, shapes, attn, g_loc, g_attn, g_offsets, g_logits, g_ref, grid, st)
+                          : launch_bwd<float, float>(d, offsets, ref, shapes, attn, g_loc, g_attn, g_offsets, g_logits, g_ref, grid, st);
 }
 
 }  // namespace mdetr

@@ -51,7 +51,8 @@ class _FusedDdnLoss(torch.autograd.Function):
         z = ctx.keep[0]
         dev = z.device
         grad = torch.empty_like(z)                       # same strides as z (dense)
-        rc = _lib().mdetr_ddn_loss_backward(*ctx.args, grad_out.reshape(1).float().contiguous().data_ptr(), grad.data_ptr(),
+        g = grad_out.reshape(1).float().contiguous()                 # a named tensor: it must outlive the call that reads its pointer
+        rc = _lib().mdetr_ddn_loss_backward(*ctx.args, g.data_ptr(), grad.data_ptr(),
                                             dev.index if dev.type == "cuda" else -1,
                                             torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None)
         if rc != 0:

@@ -28,21 +28,22 @@ class _Prologue(torch.autograd.Function):
         R = ref.shape[-1]
         io = offsets.dtype
         off, lg = offsets.contiguous(), logits.contiguous()
-        refc = ref if ref.dtype == io else ref.to(io)
+        refc = ref if ref.dtype in (torch.float32, torch.bfloat16) else ref.float()     # read in its own dtype: fp32 coordinates stay fp32
         if refc.stride(-1) != 1:
             refc = refc.contiguous()
+        rcode = _io_code(refc.dtype)
         dev = off.device
         loc = torch.empty((B, Lq, M, L, P, 2), dtype=torch.float32, device=dev)
         attn = torch.empty((B, Lq, M, L, P), dtype=torch.float32, device=dev)
         geom = (B, Lq, M, L, P, R, refc.stride(0), refc.stride(1), refc.stride(2))
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
-        rc = _lib().mdetr_msda_prologue_forward(_io_code(io), off.data_ptr(), lg.data_ptr(), refc.data_ptr(),
+        rc = _lib().mdetr_msda_prologue_forward(_io_code(io), rcode, off.data_ptr(), lg.data_ptr(), refc.data_ptr(),
                                                 spatial_shapes.data_ptr(), loc.data_ptr(), attn.data_ptr(), *geom,
                                                 dev.index if dev.type == "cuda" else -1, stream)
         if rc != 0:
             _capi.check(rc, "mdetr_msda_prologue_forward")
         ctx.save_for_backward(off, refc, spatial_shapes, attn)
-        ctx.geom, ctx.io, ctx.ref_dtype = geom, io, ref.dtype
+        ctx.geom, ctx.io, ctx.ref_dtype, ctx.rcode = geom, io, ref.dtype, rcode
         ctx.ref_shape = tuple(ref.shape)
         ctx.mark_non_differentiable(spatial_shapes)
         return loc, attn
@@ -57,9 +58,10 @@ class _Prologue(torch.autograd.Function):
         g_lg = torch.empty((B, Lq, M, L * P), dtype=ctx.io, device=dev)
         g_ref = torch.empty((B, Lq, L, R), dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
+        gl, ga = g_loc.contiguous().float(), g_attn.contiguous().float()      # named: they must outlive the call that reads their pointers
         rc = _lib().mdetr_msda_prologue_backward(
-            _io_code(ctx.io), off.data_ptr(), refc.data_ptr(), shapes.data_ptr(), attn.data_ptr(),
-            g_loc.contiguous().float().data_ptr(), g_attn.contiguous().float().data_ptr(), g_off.data_ptr(), g_lg.data_ptr(),
+            _io_code(ctx.io), ctx.rcode, off.data_ptr(), refc.data_ptr(), shapes.data_ptr(), attn.data_ptr(),
+            gl.data_ptr(), ga.data_ptr(), g_off.data_ptr(), g_lg.data_ptr(),
             g_ref.data_ptr() if g_ref is not None else None, *ctx.geom, dev.index if dev.type == "cuda" else -1, stream)
         if rc != 0:
             _capi.check(rc, "mdetr_msda_prologue_backward")

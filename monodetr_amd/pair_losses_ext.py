@@ -73,9 +73,10 @@ class _FusedPairLosses(torch.autograd.Function):
         dev = t[0].device
         grads = [torch.empty_like(x) for x in t[:5]]
         nb_host, nb_dev = ctx.nb
+        go = grad_out.contiguous().float()                           # named: it must outlive the call that reads its pointer
         rc = _lib().mdetr_pair_losses_backward(
             *[x.data_ptr() for x in t], L, B, Q, C, G, K, ctx.alpha, nb_host,
-            nb_dev.data_ptr() if nb_dev is not None else None, grad_out.contiguous().float().data_ptr(),
+            nb_dev.data_ptr() if nb_dev is not None else None, go.data_ptr(),
             ctx.comp.data_ptr(), *[g.data_ptr() for g in grads], dev.index if dev.type == "cuda" else -1, _stream(dev))
         if rc != 0:
             _capi.check(rc, "mdetr_pair_losses_backward")

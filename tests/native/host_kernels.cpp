@@ -62,7 +62,7 @@ static void host_st(int dt, void *p, int64_t i, float v)
     if (dt == 2) static_cast<uint16_t *>(p)[i] = f32_to_bf16(v); else static_cast<float *>(p)[i] = v;
 }
 
-int mdetr_msda_prologue_forward(int io_dtype, const void *offsets, const void *logits, const void *ref,
+int mdetr_msda_prologue_forward(int io_dtype, int ref_dtype, const void *offsets, const void *logits, const void *ref,
                                 const int64_t *spatial_shapes, float *sampling_loc, float *attn_weight,
                                 int B, int Lq, int M, int L, int P, int R, int64_t ref_sb, int64_t ref_sq, int64_t ref_sl,
                                 int device, void *stream)
@@ -79,7 +79,7 @@ int mdetr_msda_prologue_forward(int io_dtype, const void *offsets, const void *l
                 for (int i = 0; i < LP; ++i) attn_weight[u * LP + i] = at[i];
                 for (int l = 0; l < L; ++l) {
                     float rl[6];
-                    for (int r = 0; r < R; ++r) rl[r] = host_ld(io_dtype, ref, b * ref_sb + q * ref_sq + l * ref_sl + r);
+                    for (int r = 0; r < R; ++r) rl[r] = host_ld(ref_dtype, ref, b * ref_sb + q * ref_sq + l * ref_sl + r);
                     const float wh[2] = {static_cast<float>(spatial_shapes[2 * l + 1]), static_cast<float>(spatial_shapes[2 * l])};
                     for (int p = 0; p < P; ++p)
                         for (int c = 0; c < 2; ++c) {
@@ -91,7 +91,7 @@ int mdetr_msda_prologue_forward(int io_dtype, const void *offsets, const void *l
     return 0;
 }
 
-int mdetr_msda_prologue_backward(int io_dtype, const void *offsets, const void *ref, const int64_t *spatial_shapes,
+int mdetr_msda_prologue_backward(int io_dtype, int ref_dtype, const void *offsets, const void *ref, const int64_t *spatial_shapes,
                                  const float *attn_weight, const float *grad_loc, const float *grad_attn,
                                  void *grad_offsets, void *grad_logits, float *grad_ref,
                                  int B, int Lq, int M, int L, int P, int R, int64_t ref_sb, int64_t ref_sq, int64_t ref_sl,
@@ -109,7 +109,7 @@ int mdetr_msda_prologue_backward(int io_dtype, const void *offsets, const void *
                 for (int i = 0; i < LP; ++i) host_st(io_dtype, grad_logits, u * LP + i, gl[i]);
                 for (int l = 0; l < L; ++l) {
                     float rl[6], gr[6] = {0, 0, 0, 0, 0, 0};
-                    for (int r = 0; r < R; ++r) rl[r] = host_ld(io_dtype, ref, b * ref_sb + q * ref_sq + l * ref_sl + r);
+                    for (int r = 0; r < R; ++r) rl[r] = host_ld(ref_dtype, ref, b * ref_sb + q * ref_sq + l * ref_sl + r);
                     const float wh[2] = {static_cast<float>(spatial_shapes[2 * l + 1]), static_cast<float>(spatial_shapes[2 * l])};
                     for (int p = 0; p < P; ++p)
                         for (int c = 0; c < 2; ++c) {

@@ -94,3 +94,21 @@ def test_module_with_the_fused_prologue_matches_default(backend, oracle):
     finally:
         F_.MSDA = saved
         mod._FUSED_PROLOGUE = False
+
+
+def test_fp32_reference_points_stay_fp32_with_bf16_projections(backend):
+    """A bf16 model body keeps its reference points in fp32 (coordinates in bf16 would be quantised to ~1/256 of the
+    image): the kernel reads them as they are, so the locations differ from the all-fp32 formula only through the
+    bf16 offsets."""
+    g = torch.Generator().manual_seed(9)
+    B, Lq, M, L, P = 2, 9, 8, 4, 4
+    shapes = torch.tensor([[48, 160], [24, 80], [12, 40], [6, 20]])
+    off = torch.randn(B, Lq, M, L, P, 2, generator=g).to(torch.bfloat16)
+    lg = torch.randn(B, Lq, M, L * P, generator=g).to(torch.bfloat16)
+    ref = (torch.rand(B, Lq, L, 2, generator=g) * 0.9 + 0.05).requires_grad_(True)            # fp32, values that bf16 cannot hold
+    loc, w = backend.msda_prologue(off, lg, ref, shapes)
+    want = ref.detach()[:, :, None, :, None, :] + off.float() / shapes.flip(-1)[None, None, None, :, None, :]
+    assert (loc - want).abs().max() < 1e-6                                                    # bf16-rounded refs would be off by ~2e-3
+    assert (ref.detach().to(torch.bfloat16).float() - ref.detach()).abs().max() > 1e-3
+    loc.sum().backward()
+    assert ref.grad.dtype == torch.float32 and torch.allclose(ref.grad, torch.full_like(ref.grad, M * P * 2.0 / 2), atol=1e-4)
