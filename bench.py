@@ -86,7 +86,8 @@ def synthetic_batch(B, H, W, seed, device):
 # Each is switched on by an environment variable of the same name (= "1") or, when none is set, chosen by the
 # start-up autotune below.  (MDETR_MSDA_BF16 changes the MSDA operator's element types; the roofline accounting
 # follows it: msda_algorithmic_bytes(mixed=True), and the PMC traffic figure recorded for the fp32 operator is dropped.)
-AUTOTUNE_SWITCHES = ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN", "MDETR_MSDA_BF16", "MDETR_TOKEN_GEMM")
+AUTOTUNE_SWITCHES = ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN", "MDETR_MSDA_BF16", "MDETR_TOKEN_GEMM",
+                     "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU")
 ALL_SWITCHES = AUTOTUNE_SWITCHES
 
 
@@ -97,26 +98,35 @@ def env_switches():
 def apply_switches(names):
     """Runtime equivalent of the environment switches for the module-level ones (the criterion's and the optimizer's
     are applied by TrainStep)."""
-    from monodetr_amd import add_ln_ext
+    from monodetr_amd import add_ln_ext, bias_act_ext
     from monodetr_amd.monodetr import linear
     from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func
     from monodetr_amd.monodetr.ops.modules import ms_deform_attn
     ms_deform_attn._FUSED_PROLOGUE = "MDETR_MSDA_PROLOGUE" in names
     add_ln_ext.ENABLED = "MDETR_FUSED_LN" in names
     linear._TOKEN_GEMM = "MDETR_TOKEN_GEMM" in names
+    linear._GEMM_RELU = "MDETR_GEMM_RELU" in names
+    bias_act_ext.ENABLED = "MDETR_FUSED_EPILOGUE" in names
     ms_deform_attn_func._NATIVE_BF16 = "MDETR_MSDA_BF16" in names
 
 
 def probe_configs(precision):
     """Candidate switch sets, nested so that a set which fails still leaves the smaller ones standing: the default path;
-    the criterion / optimizer kernels; + the model-side prologue and LayerNorm kernels; + the bf16-native MSDA; + the
-    token GEMM (the one candidate that replaces a tuned library kernel and may well be slower).  The fullest set runs
-    last so that a crash in it loses nothing.  The last two exist for a bf16 body only."""
+    the criterion / optimizer kernels; + the model-side prologue and LayerNorm kernels; + the bf16-native MSDA (bf16 body
+    only); + the fused convolution / FFN tails; + ReLU in the library GEMM's epilogue; + the token GEMM (bf16 only; the
+    one candidate that replaces a tuned library kernel and may well be slower).  The fullest set runs last so that a
+    crash in it loses nothing."""
     loss_side = ["MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW"]
     base = loss_side + ["MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN"]
-    if precision != "bf16":
-        return [[], loss_side, base]
-    return [[], loss_side, base, base + ["MDETR_MSDA_BF16"], base + ["MDETR_MSDA_BF16", "MDETR_TOKEN_GEMM"]]
+    sets = [[], loss_side, base]
+    if precision == "bf16":
+        base = base + ["MDETR_MSDA_BF16"]
+        sets.append(base)
+    tails = base + ["MDETR_FUSED_EPILOGUE"]
+    sets += [tails, tails + ["MDETR_GEMM_RELU"]]
+    if precision == "bf16":
+        sets.append(tails + ["MDETR_GEMM_RELU", "MDETR_TOKEN_GEMM"])
+    return sets
 
 
 def choose_config(results, rel_tol=0.03, min_gain=0.01):
@@ -146,7 +156,7 @@ def choose_config(results, rel_tol=0.03, min_gain=0.01):
     return sorted(best["switches"]), why
 
 
-def run_probe(args, local_rank, configs, timeout=360):
+def run_probe(args, local_rank, configs, timeout=420):
     """Run `bench.py --probe` in a child process (a kernel that faults takes the child down, not this process) and
     return the PROBE records it managed to print."""
     import subprocess

@@ -403,6 +403,27 @@ int mdetr_column_sum(int dtype, const void *x, float *out, void *workspace, int6
                      int64_t rows, int cols, int64_t ld, int device, void *stream);
 
 /*
+ * y = dropout(relu(x + bias[col] + skip)) over a [rows, cols] channels-last activation in one pass, and its backward --
+ * the tails the reference runs as separate operators after a convolution / linear layer: frozen-BN shift + ReLU after the
+ * bottleneck's 3x3 convolution and "out += identity; relu(out)" after its expansion (lib/models/monodetr/backbone.py:100-102
+ * -> torchvision resnet Bottleneck.forward), ReLU + Dropout between the two FFN layers (depthaware_transformer.py:334-337,
+ * :431-435; depth_predictor/transformer.py:57-65).
+ *   io_dtype   MDETR_F32 (cols % 4 == 0) or MDETR_BF16 (cols % 8 == 0): x, skip, y (and dy, dx); fp32 arithmetic, one rounding
+ *   bias       [cols] fp32, or bf16 with a bf16 activation (bias_dtype); NULL = none.  skip [rows, cols]; NULL = none
+ *   y          out; may be x itself (in place).  All tensors contiguous and 16-byte aligned
+ *   relu       0 / 1 (NaN passes through, as clamp_min)
+ *   dropout    p in [0, 1): element (row, col) is kept iff a hash of (seed [+ *seed_dev], row * cols + col) >= p * 2^32 and
+ *              scaled by 1 / (1 - p) (the decision function of mdetr_add_layernorm_forward); no mask is stored
+ * backward (relu = 1): dx = y > 0 ? dy * scale : 0 with scale = 1 / (1 - p) -- y > 0 holds exactly where the
+ * pre-activation was positive and the element was kept, so neither the mask nor the hash is needed; dx may be dy itself.
+ */
+int mdetr_bias_act_forward(int io_dtype, int bias_dtype, const void *x, const void *bias, const void *skip, void *y,
+                           int64_t rows, int cols, int relu, float dropout_p, uint64_t seed, const uint64_t *seed_dev,
+                           int device, void *stream);
+int mdetr_bias_act_backward(int io_dtype, const void *dy, const void *y, void *dx, int64_t rows, int cols, float scale,
+                            int device, void *stream);
+
+/*
  * Batched linear sum assignment (Hungarian matching) on the device.  Replaces the host loop of
  * scipy.optimize.linear_sum_assignment calls in HungarianMatcher.forward (matcher.py:87-103: one
  * device->host copy and 3 x B x 11 solver calls per iteration).

@@ -46,6 +46,8 @@ SIGNATURES = {
     "mdetr_add_layernorm_forward": (_c_int, [_c_int, _c_int] + [_c_vp] * 7 + [ctypes.c_int64, _c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),
     "mdetr_add_layernorm_partial_rows": (ctypes.c_int64, [ctypes.c_int64]),
     "mdetr_add_layernorm_backward": (_c_int, [_c_int, _c_int] + [_c_vp] * 7 + [ctypes.c_int64, _c_int, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),
+    "mdetr_bias_act_forward": (_c_int, [_c_int, _c_int] + [_c_vp] * 4 + [ctypes.c_int64, _c_int, _c_int, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),
+    "mdetr_bias_act_backward": (_c_int, [_c_int] + [_c_vp] * 3 + [ctypes.c_int64, _c_int, ctypes.c_float, _c_int, _c_vp]),
     "mdetr_rotate_iou_eval": (_c_int, [_c_vp] * 5 + [_c_int, ctypes.c_int64, _c_int, _c_vp, _c_int, _c_vp]),
     "mdetr_box3d_overlap_eval": (_c_int, [_c_vp] * 5 + [_c_int, ctypes.c_int64, _c_int, _c_vp, _c_int, _c_vp]),
     "mdetr_kitti_pr_curve": (_c_int, [_c_vp] * 10 + [_c_int, _c_int, ctypes.c_double, ctypes.c_int64, _c_int, _c_int, _c_vp, _c_vp, _c_vp]),

@@ -14,6 +14,7 @@
 #include "attn.h"
 #include "adamw.h"
 #include "add_ln.h"
+#include "bias_act.h"
 #include "colsum.h"
 #include "ddn_loss.h"
 #include "kitti_prep.h"
@@ -445,6 +446,43 @@ int mdetr_column_sum(int dtype, const void *x, float *out, void *workspace, int6
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_column_sum: set device %d: %s", device, hipGetErrorString(dev.err));
     const hipError_t e = mdetr::colsum_launch(dtype, x, out, workspace, rows, cols, ld, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_column_sum: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_bias_act_forward(int io_dtype, int bias_dtype, const void *x, const void *bias, const void *skip, void *y,
+                           int64_t rows, int cols, int relu, float dropout_p, uint64_t seed, const uint64_t *seed_dev,
+                           int device, void *stream)
+{
+    if (rows < 0) return fail(MDETR_E_ARG, "mdetr_bias_act_forward: negative row count");
+    if (!mdetr::bias_act_supported(io_dtype, bias ? bias_dtype : MDETR_F32, cols))
+        return fail(MDETR_E_ARG, "mdetr_bias_act_forward: io_dtype %d / bias_dtype %d / cols %d (f32: cols %% 4 == 0; bf16: cols %% 8 == 0, "
+                                 "bf16 bias only with a bf16 activation)", io_dtype, bias_dtype, cols);
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(MDETR_E_ARG, "mdetr_bias_act_forward: dropout_p = %g outside [0, 1)", static_cast<double>(dropout_p));
+    if (rows == 0) return MDETR_OK;
+    if (!x || !y) return fail(MDETR_E_ARG, "mdetr_bias_act_forward: null pointer");
+    if (!aligned16(x) || !aligned16(y) || !aligned16(skip) || !aligned16(bias))
+        return fail(MDETR_E_ALIGN, "mdetr_bias_act_forward: x, bias, skip, y must be 16-byte aligned");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_bias_act_forward: set device %d: %s", device, hipGetErrorString(dev.err));
+    const mdetr::BiasActProblem p{io_dtype, bias ? bias_dtype : MDETR_F32, rows, cols, relu ? 1 : 0, dropout_p, seed, seed_dev};
+    const hipError_t e = mdetr::bias_act_forward_launch(p, x, bias, skip, y, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_bias_act_forward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_bias_act_backward(int io_dtype, const void *dy, const void *y, void *dx, int64_t rows, int cols, float scale,
+                            int device, void *stream)
+{
+    if (rows < 0) return fail(MDETR_E_ARG, "mdetr_bias_act_backward: negative row count");
+    if (!mdetr::bias_act_supported(io_dtype, MDETR_F32, cols))
+        return fail(MDETR_E_ARG, "mdetr_bias_act_backward: io_dtype %d / cols %d (f32: cols %% 4 == 0; bf16: cols %% 8 == 0)", io_dtype, cols);
+    if (rows == 0) return MDETR_OK;
+    if (!dy || !y || !dx) return fail(MDETR_E_ARG, "mdetr_bias_act_backward: null pointer");
+    if (!aligned16(dy) || !aligned16(y) || !aligned16(dx)) return fail(MDETR_E_ALIGN, "mdetr_bias_act_backward: dy, y, dx must be 16-byte aligned");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_bias_act_backward: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::bias_act_backward_launch(io_dtype, dy, y, dx, rows, cols, scale, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_bias_act_backward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

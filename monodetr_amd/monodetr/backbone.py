@@ -20,7 +20,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..utils.misc import NestedTensor, mark_no_padding
-from .linear import pointwise_conv, pointwise_eligible
+from .. import bias_act_ext
+from .linear import pointwise_conv, pointwise_eligible, pointwise_relu_fusable
 from .position_encoding import build_position_encoding
 
 
@@ -140,7 +141,16 @@ def conv_bn(x, conv, bn, relu):
             w = (conv.weight * cast[1]).to(dt)
             b = cast[2]
         if pointwise_eligible(x, conv.kernel_size, conv.stride, conv.padding, conv.groups) and x.dtype == w.dtype:
+            if relu and pointwise_relu_fusable(x, w, b):
+                return pointwise_conv(x, w, b, relu=True)            # ReLU in the GEMM's epilogue
             x = pointwise_conv(x, w, b)
+        elif relu and bias_act_ext.ENABLED and (x.is_cuda or bias_act_ext._backend is not None):
+            # the shift and the ReLU in one pass behind the library convolution (csrc/bias_act.hip) instead of the
+            # library's own bias kernel plus a clamp
+            x = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if bias_act_ext.supported(x, b):
+                return bias_act_ext.bias_act(x, b, None, relu=True)
+            x = x + b.view(1, -1, 1, 1)
         else:
             x = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
     else:
@@ -169,6 +179,8 @@ class Bottleneck(nn.Module):
         y = conv_bn(x, self.conv1, self.bn1, True)
         y = conv_bn(y, self.conv2, self.bn2, True)
         y = conv_bn(y, self.conv3, self.bn3, False)
+        if bias_act_ext.ENABLED and bias_act_ext.supported(y, None, skip):
+            return bias_act_ext.bias_act(y, None, skip, relu=True)   # "+ identity" and the ReLU in one pass
         return F.relu(y + skip, inplace=True)
 
 

@@ -9,6 +9,7 @@ from torch import nn
 
 from ...add_ln_ext import residual_layernorm
 from ..attention import MultiheadAttention
+from ..linear import ffn_hidden
 
 
 def _get_clones(module, N):
@@ -38,7 +39,7 @@ class TransformerEncoderLayer(nn.Module):
     def forward(self, src, src_key_padding_mask, pos):
         qk = src if pos is None else src + pos
         src = residual_layernorm(src, self.self_attn(qk, qk, src, key_padding_mask=src_key_padding_mask)[0], self.norm1, self.dropout1)
-        ff = self.linear2(self.dropout(self.activation(self.linear1(src))))
+        ff = self.linear2(ffn_hidden(src, self.linear1, self.dropout, self.activation, tokenwise=False))
         return residual_layernorm(src, ff, self.norm2, self.dropout2)
 
 

@@ -27,7 +27,7 @@ from torch.nn.init import constant_, normal_, xavier_uniform_
 from ..add_ln_ext import residual_layernorm
 from ..utils.misc import inverse_sigmoid, no_padding
 from .attention import MultiheadAttention as FusedMultiheadAttention
-from .linear import token_linear
+from .linear import ffn_hidden, token_linear
 from .ops.modules import MSDeformAttn, MSDeformAttn_cross, MultiheadAttention  # noqa: F401  (reference :11)
 
 
@@ -83,10 +83,7 @@ class VisualEncoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, src):
-        if self.activation is F.relu:                       # ReLU can ride in the GEMM epilogue (linear.token_linear)
-            h = self.dropout2(token_linear(src, self.linear1.weight, self.linear1.bias, relu=True))
-        else:
-            h = self.dropout2(self.activation(token_linear(src, self.linear1.weight, self.linear1.bias)))
+        h = ffn_hidden(src, self.linear1, self.dropout2, self.activation)       # ReLU (+ Dropout) fused behind the GEMM where possible
         ff = token_linear(h, self.linear2.weight, self.linear2.bias)
         return residual_layernorm(src, ff, self.norm2, self.dropout3)
 
@@ -175,7 +172,7 @@ class DepthAwareDecoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, tgt):
-        ff = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        ff = self.linear2(ffn_hidden(tgt, self.linear1, self.dropout3, self.activation, tokenwise=False))
         return residual_layernorm(tgt, ff, self.norm3, self.dropout4)
 
     def _self_attention_inputs(self, x):

@@ -21,6 +21,9 @@ _MIN_TOKENS = 4096
 # LDS-resident-weight kernel (csrc/token_gemm.hip).  Off until its first GPU validation
 # (tests/test_pending_gpu.py); the library GEMM is the default.
 _TOKEN_GEMM = os.environ.get("MDETR_TOKEN_GEMM") == "1"
+# MDETR_GEMM_RELU=1: "linear -> ReLU" as one library GEMM with the RELU_BIAS epilogue (torch._addmm_activation ->
+# hipBLASLt) instead of a GEMM and an elementwise pass.  Off until timed on a GPU.
+_GEMM_RELU = os.environ.get("MDETR_GEMM_RELU") == "1"
 
 
 def _split_count(T):
@@ -36,7 +39,7 @@ def _split_count(T):
 class _TokenLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, fused_relu=False):
-        """fused_relu is only ever True on the token-GEMM path (ReLU in the kernel's epilogue)."""
+        """fused_relu: ReLU in the epilogue of the token-GEMM kernel or, failing that, of the library GEMM."""
         ctx.has_bias = bias is not None
         ctx.fused_relu = False
         if _TOKEN_GEMM:
@@ -50,7 +53,12 @@ class _TokenLinear(torch.autograd.Function):
                 else:
                     ctx.save_for_backward(x, weight)
                 return y
-        assert not fused_relu
+        if fused_relu:                                               # library GEMM, RELU_BIAS epilogue
+            x2 = x.reshape(-1, x.shape[-1])
+            y = torch._addmm_activation(bias, x2, weight.t()).view(x.shape[:-1] + (weight.shape[0],))
+            ctx.fused_relu = True
+            ctx.save_for_backward(x, weight, y)
+            return y
         ctx.save_for_backward(x, weight)
         return F.linear(x, weight, bias)
 
@@ -59,7 +67,7 @@ class _TokenLinear(torch.autograd.Function):
     def backward(ctx, dy):
         if ctx.fused_relu:
             x, weight, y = ctx.saved_tensors
-            dy = dy * (y > 0)                                        # ReLU of the epilogue
+            dy = torch.ops.aten.threshold_backward(dy, y, 0.0)       # ReLU of the epilogue: dy where y > 0, one launch
         else:
             x, weight = ctx.saved_tensors
         dx = dw = db = None
@@ -95,11 +103,13 @@ class _TokenLinear(torch.autograd.Function):
         return dx, dw, db, None
 
 
-def _kernel_relu(x, weight):
-    if not _TOKEN_GEMM:
-        return False
-    from .. import token_gemm_ext
-    return token_gemm_ext.supported(x.reshape(-1, x.shape[-1]), weight)
+def _kernel_relu(x, weight, bias=None):
+    """Can the ReLU ride in the GEMM's epilogue?  (the token-GEMM kernel, or the library's RELU_BIAS epilogue)"""
+    if _TOKEN_GEMM:
+        from .. import token_gemm_ext
+        if token_gemm_ext.supported(x.reshape(-1, x.shape[-1]), weight):
+            return True
+    return _GEMM_RELU and bias is not None and bias.dim() == 1 and bias.is_contiguous()
 
 
 def token_linear(x, weight, bias=None, relu=False):
@@ -107,7 +117,7 @@ def token_linear(x, weight, bias=None, relu=False):
     plain F.linear otherwise.  With the token-GEMM kernel enabled the ReLU runs in its epilogue."""
     if x.is_cuda and x.dtype == weight.dtype and x.numel() // x.shape[-1] >= _MIN_TOKENS and torch.is_grad_enabled() \
             and not torch.is_autocast_enabled():
-        if relu and _kernel_relu(x, weight):
+        if relu and _kernel_relu(x, weight, bias):
             return _TokenLinear.apply(x, weight, bias, True)
         y = _TokenLinear.apply(x, weight, bias, False)
     else:
@@ -120,14 +130,44 @@ def pointwise_eligible(x, kernel_size, stride, padding, groups):
             and groups == 1 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))
 
 
-def pointwise_conv(x, weight, bias=None):
+def pointwise_conv(x, weight, bias=None, relu=False):
     """1x1 stride-1 convolution of a channels_last activation == a linear layer over its B*H*W tokens:
     the [B,H,W,C] permutation is a view, the GEMMs go to hipBLASLt (which runs these memory-bound
     shapes near the HBM roofline) and the weight gradient takes `token_linear`'s split-K path; MIOpen's
-    implicit-GEMM kernels plus their cast / zero-fill helpers took 2-3x as long on the same shapes."""
+    implicit-GEMM kernels plus their cast / zero-fill helpers took 2-3x as long on the same shapes.
+    `relu`: followed by a ReLU (in the GEMM's epilogue where `token_linear` can put it there)."""
     B, C, H, W = x.shape
-    y = token_linear(x.permute(0, 2, 3, 1).reshape(B * H * W, C), weight.reshape(weight.shape[0], C), bias)
+    y = token_linear(x.permute(0, 2, 3, 1).reshape(B * H * W, C), weight.reshape(weight.shape[0], C), bias, relu=relu)
     return y.view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def pointwise_relu_fusable(x, weight, bias):
+    """Would `pointwise_conv(..., relu=True)` run the ReLU inside the GEMM?  (callers that apply an in-place ReLU
+    themselves otherwise)"""
+    C = x.shape[1]
+    return (x.numel() // C >= _MIN_TOKENS and torch.is_grad_enabled() and not torch.is_autocast_enabled()
+            and _kernel_relu(x.permute(0, 2, 3, 1).reshape(-1, C), weight.reshape(weight.shape[0], C), bias))
+
+
+def ffn_hidden(x, lin, dropout, activation=F.relu, tokenwise=True):
+    """``dropout(activation(lin(x)))`` -- the first half of an FFN (depthaware_transformer.py:334-337, :431-435;
+    depth_predictor/transformer.py:57-65).  ``tokenwise``: the GEMM through `token_linear` (the encoder's 81 600 token
+    rows) instead of the module call.  With MDETR_FUSED_EPILOGUE=1 ReLU and Dropout are one pass behind the GEMM
+    (csrc/bias_act.hip); otherwise the ReLU rides in the GEMM's epilogue when one of the GEMM switches allows it."""
+    from .. import bias_act_ext
+    p = dropout.p if (dropout is not None and dropout.training) else 0.0
+    first = (lambda relu: token_linear(x, lin.weight, lin.bias, relu=relu)) if tokenwise else \
+        (lambda relu: F.relu(lin(x)) if relu else lin(x))
+    if activation is not F.relu:
+        h = activation(first(False))
+    elif bias_act_ext.ENABLED and p > 0.0 and torch.is_grad_enabled():
+        h = first(False)
+        if bias_act_ext.supported(h):
+            return bias_act_ext.bias_act(h, None, None, relu=True, dropout_p=p)
+        h = F.relu(h)
+    else:
+        h = first(True)
+    return dropout(h) if dropout is not None else h
 
 
 class PointwiseConv2d(nn.Conv2d):

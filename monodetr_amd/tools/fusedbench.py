@@ -61,6 +61,25 @@ def main():
     res["library_gemm_256x256"] = row(timeit(lambda: F.linear(xt, w, b), a.iters), byts)
     res["token_gemm_256x256_relu"] = row(timeit(lambda: token_gemm_ext.token_gemm(xt, w, b, relu=True), a.iters), byts)
     res["library_gemm_256x256_relu"] = row(timeit(lambda: F.relu(F.linear(xt, w, b)), a.iters), byts)
+    res["library_gemm_256x256_relu_epilogue"] = row(timeit(lambda: torch._addmm_activation(b, xt, w.t()), a.iters), byts)   # MDETR_GEMM_RELU
+
+    # ---- convolution / FFN tails (csrc/bias_act.hip) -----------------------------------------------------------------
+    from monodetr_amd import bias_act_ext
+    for tag, shape in (("layer1_3x3_tail", (8, 64, 96, 320)), ("layer1_residual_tail", (8, 256, 96, 320)), ("layer3_residual_tail", (8, 1024, 24, 80))):
+        act = torch.randn(shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        skip = torch.randn(shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if "residual" in tag else None
+        shift = torch.randn(shape[1], device=dev).to(torch.bfloat16) if skip is None else None
+        n = act.numel() * e
+        res["bias_act_" + tag + "_fused"] = row(timeit(lambda: bias_act_ext.bias_act(act, shift, skip, relu=True), a.iters), n * (3 if skip is not None else 2))
+        if skip is None:
+            res["bias_act_" + tag + "_framework"] = row(timeit(lambda: F.relu_(act + shift.view(1, -1, 1, 1)), a.iters), n * 2)
+        else:
+            res["bias_act_" + tag + "_framework"] = row(timeit(lambda: F.relu_(act + skip), a.iters), n * 3)
+    h = torch.randn(T, C, device=dev).to(torch.bfloat16).requires_grad_(True)
+    for tag, f in (("fused", lambda: bias_act_ext.bias_act(h, None, None, relu=True, dropout_p=0.1)), ("framework", lambda: F.dropout(F.relu(h), 0.1, True))):
+        y = f()
+        res["ffn_relu_dropout_fwd_" + tag] = row(timeit(f, a.iters), 2 * T * C * e)
+        res["ffn_relu_dropout_bwd_" + tag] = row(timeit(lambda: torch.autograd.grad(y, (h,), dy, retain_graph=True), a.iters), 3 * T * C * e)
     w128 = (torch.randn(128, C, device=dev) * 0.05).to(torch.bfloat16)
     byts = e * (T * C + T * 128 + 128 * C)
     res["token_gemm_256x128"] = row(timeit(lambda: token_gemm_ext.token_gemm(xt, w128), a.iters), byts)

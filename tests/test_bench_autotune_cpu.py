@@ -59,7 +59,7 @@ def test_autotune_runs_one_probe_caches_per_box_and_reports(tmp_path):
         return [{"switches": sorted(c), "losses": [30.0, 29.0, 28.0], "ms": 38.0 - 1.5 * len(c)} for c in configs]
     cache = str(tmp_path / "tune.json")
     chosen, report = bench.autotune(args(), 1, 0, runner=runner, cache_path=cache)
-    assert chosen == sorted(bench.AUTOTUNE_SWITCHES) and report["source"] == "probe" and len(report["candidates"]) == 6 and calls[0][0] == calls[0][-1] == []
+    assert chosen == sorted(bench.AUTOTUNE_SWITCHES) and report["source"] == "probe" and len(report["candidates"]) == 8 and calls[0][0] == calls[0][-1] == []
     chosen2, report2 = bench.autotune(args(), 1, 0, runner=runner, cache_path=cache)
     assert chosen2 == chosen and report2["source"] == "cache" and len(calls) == 1
     # another precision is another key

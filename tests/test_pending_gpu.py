@@ -536,3 +536,82 @@ def test_training_step_with_fused_layernorm_matches_default(monkeypatch):
         traj[on] = [float(step()) for _ in range(3)]
     for a, b in zip(traj[False], traj[True]):
         assert abs(a - b) <= 2e-2 * abs(a), traj
+
+
+# ---- fused convolution / FFN tails (csrc/bias_act.hip) and ReLU in the library GEMM's epilogue ------------------------
+@pytest.mark.parametrize("shape,dtype,bias_dtype,use_skip,p", [
+    ((8, 64, 96, 320), torch.bfloat16, torch.bfloat16, False, 0.0),      # layer1 3x3 tail at the benchmark size
+    ((8, 256, 96, 320), torch.bfloat16, None, True, 0.0),                # layer1 residual tail (126 MB per tensor)
+    ((8, 2048, 12, 40), torch.float32, torch.float32, True, 0.0),
+    ((3, 24, 7, 5), torch.float32, torch.float32, True, 0.0),            # 6 vectors per row: bias re-read per vector
+    ((8, 10200, 256), torch.bfloat16, None, False, 0.1),                 # encoder FFN: ReLU + Dropout
+    ((1920, 8, 256), torch.float32, None, False, 0.1),
+])
+def test_bias_act_kernel_matches_the_framework_operators(shape, dtype, bias_dtype, use_skip, p):
+    from monodetr_amd import bias_act_ext
+    from test_add_ln_emulated_cpu import keep_mask
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    cl = len(shape) == 4
+    C = shape[1] if cl else shape[-1]
+
+    def make():
+        t = torch.randn(shape, generator=g, device="cuda").to(dtype)
+        return t.contiguous(memory_format=torch.channels_last) if cl else t
+
+    x, skip = make().requires_grad_(True), (make().requires_grad_(True) if use_skip else None)
+    bias = (torch.randn(C, generator=g, device="cuda") * 0.5).to(bias_dtype) if bias_dtype is not None else None
+    dy = make()
+    y = bias_act_ext.bias_act(x, bias, skip, relu=True, dropout_p=p, seed=24680)
+    assert y.stride() == x.stride()
+    y.backward(dy)
+    pre = x.detach().float() + (bias.float().view((1, C, 1, 1) if cl else (C,)) if bias is not None else 0.0) + (skip.detach().float() if use_skip else 0.0)
+    if p > 0:
+        keep = keep_mask(24680, x.numel(), p).view(shape).cuda()
+        scale = torch.tensor(1.0 / (1.0 - p), dtype=torch.float32, device="cuda")
+    else:
+        keep, scale = torch.ones((), device="cuda"), torch.ones((), device="cuda")
+    assert torch.equal(y.detach(), (torch.relu(pre) * scale * keep).to(dtype))
+    want = torch.where((pre > 0) & (keep > 0), dy.float() * scale, torch.zeros((), device="cuda")).to(dtype)
+    assert torch.equal(x.grad, want)
+    if use_skip:
+        assert torch.equal(skip.grad, want)
+
+
+def test_library_gemm_relu_epilogue_matches_linear_then_relu_on_the_gpu(monkeypatch):
+    from monodetr_amd.monodetr import linear
+    torch.manual_seed(2)
+    for dtype, T, K, N in ((torch.bfloat16, 81600, 256, 256), (torch.float32, 4400, 256, 256), (torch.bfloat16, 245760, 256, 64)):
+        x = torch.randn(T, K, device="cuda").to(dtype).requires_grad_(True)
+        w = (torch.randn(N, K, device="cuda") / 16).to(dtype).requires_grad_(True)
+        b = torch.randn(N, device="cuda").to(dtype).requires_grad_(True)
+        dy = torch.randn(T, N, device="cuda").to(dtype)
+        monkeypatch.setattr(linear, "_GEMM_RELU", True)
+        y = linear.token_linear(x, w, b, relu=True)
+        assert y.grad_fn is not None and "TokenLinear" in type(y.grad_fn).__name__
+        y.backward(dy)
+        got = [y.detach(), x.grad.clone(), w.grad.clone(), b.grad.clone()]
+        x.grad = w.grad = b.grad = None
+        monkeypatch.setattr(linear, "_GEMM_RELU", False)
+        ref = linear.token_linear(x, w, b, relu=True)
+        ref.backward(dy)
+        tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+        for name, a, r in zip(("y", "dx", "dw", "db"), got, [ref.detach(), x.grad, w.grad, b.grad]):
+            assert (a.float() - r.float()).abs().max().item() <= tol * max(1.0, r.float().abs().max().item()), (dtype, name)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_training_step_with_fused_tails_matches_default(monkeypatch, precision):
+    import bench
+    from model_init import disable_dropout_
+    dev = torch.device("cuda", 0)
+    traj = {}
+    try:
+        for names in ((), ("MDETR_FUSED_EPILOGUE",), ("MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU")):
+            step = bench.TrainStep(dev, 2, precision, size=(96, 320), switches=names)
+            disable_dropout_(step.raw_model)
+            traj[names] = [float(step()) for _ in range(3)]
+    finally:
+        bench.apply_switches(set())
+    for names, t in traj.items():
+        for a, b in zip(traj[()], t):
+            assert abs(a - b) <= (2e-2 if precision == "bf16" else 2e-4) * abs(a), traj
