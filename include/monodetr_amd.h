@@ -292,7 +292,7 @@ int mdetr_adamw_step(int param_dtype, void *param, float *master, const void *gr
  *   x      bf16 [T, K], row stride ldx elements (ldx % 8 == 0, 16-byte aligned base)
  *   weight bf16 [N, K] row-major, 16-byte aligned;  bias bf16 [N] or NULL
  *   y      bf16 [T, N], row stride ldy elements (ldy % 4 == 0, 8-byte aligned base)
- *   K in {128, 256, 512}, N % 8 == 0, fp32 accumulation on the matrix cores
+ *   K in {64, 128, 256, 512}, N % 8 == 0, fp32 accumulation on the matrix cores
  */
 int mdetr_token_linear(const void *x, const void *weight, const void *bias, void *y, int64_t T, int N, int K,
                        int64_t ldx, int64_t ldy, int relu, int device, void *stream);

@@ -417,7 +417,7 @@ int mdetr_token_linear(const void *x, const void *weight, const void *bias, void
     if (T == 0) return MDETR_OK;
     if (!x || !weight || !y) return fail(MDETR_E_ARG, "mdetr_token_linear: null pointer");
     if (!mdetr::token_gemm_supported(T, N, K, ldx, ldy, x, weight, y))
-        return fail(MDETR_E_ARG, "mdetr_token_linear: needs bf16, K in {128, 256, 512}, N %% 8 == 0, 16-byte aligned x / weight rows");
+        return fail(MDETR_E_ARG, "mdetr_token_linear: needs bf16, K in {64, 128, 256, 512}, N %% 8 == 0, 16-byte aligned x / weight rows");
     DeviceScope dev(device);
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_token_linear: set device %d: %s", device, hipGetErrorString(dev.err));
     const hipError_t e = mdetr::token_gemm_launch(x, weight, bias, y, T, N, K, ldx, ldy, relu != 0, static_cast<hipStream_t>(stream));

@@ -5,7 +5,7 @@
 
 namespace mdetr {
 
-// bf16 only; K in {128, 256, 512}; N % 8 == 0; x rows 16-byte aligned (ldx % 8 == 0), y rows 8-byte aligned
+// bf16 only; K in {64, 128, 256, 512}; N % 8 == 0; x rows 16-byte aligned (ldx % 8 == 0), y rows 8-byte aligned
 bool token_gemm_supported(int64_t T, int N, int K, int64_t ldx, int64_t ldy, const void *x, const void *w, const void *y);
 hipError_t token_gemm_launch(const void *x, const void *w, const void *bias, void *y, int64_t T, int N, int K,
                              int64_t ldx, int64_t ldy, bool relu, hipStream_t st);

@@ -174,7 +174,7 @@ hipError_t launch(const void *x, const void *w, const void *bias, void *y, int64
 bool token_gemm_supported(int64_t T, int N, int K, int64_t ldx, int64_t ldy, const void *x, const void *w, const void *y)
 {
     const auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    return T > 0 && (K == 512 || K == 256 || K == 128) && N > 0 && N % 8 == 0 && ldx % 8 == 0 && ldy % 4 == 0 && ldx >= K && ldy >= N &&
+    return T > 0 && (K == 512 || K == 256 || K == 128 || K == 64) && N > 0 && N % 8 == 0 && ldx % 8 == 0 && ldy % 4 == 0 && ldx >= K && ldy >= N &&
            al(x) && al(w) && (reinterpret_cast<uintptr_t>(y) & 7) == 0;
 }
 
@@ -187,6 +187,8 @@ hipError_t token_gemm_launch(const void *x, const void *w, const void *bias, voi
         if (N <= 128) return relu ? launch<256, 4, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch<256, 4, false>(x, w, bias, y, T, N, ldx, ldy, st);
         return relu ? launch<256, 8, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch<256, 8, false>(x, w, bias, y, T, N, ldx, ldy, st);
     }
+    if (K == 64)           // the backbone's 64 -> 256 expansions (245 760 tokens in layer1): one slab per tile
+        return relu ? launch<64, 8, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch<64, 8, false>(x, w, bias, y, T, N, ldx, ldy, st);
     return relu ? launch<128, 8, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch<128, 8, false>(x, w, bias, y, T, N, ldx, ldy, st);
 }
 

@@ -17,7 +17,7 @@ from torch import nn
 from .. import colsum_ext
 
 _MIN_TOKENS = 4096
-# MDETR_TOKEN_GEMM=1: forward and input-gradient products of K in {128, 256, 512} bf16 layers through the
+# MDETR_TOKEN_GEMM=1: forward and input-gradient products of K in {64, 128, 256, 512} bf16 layers through the
 # LDS-resident-weight kernel (csrc/token_gemm.hip).  Off until its first GPU validation
 # (tests/test_pending_gpu.py); the library GEMM is the default.
 _TOKEN_GEMM = os.environ.get("MDETR_TOKEN_GEMM") == "1"

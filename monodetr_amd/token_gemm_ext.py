@@ -1,5 +1,5 @@
 """``token_gemm(x, weight, bias, relu)``: y = x W^T + b (+ ReLU) in bf16 with the weight resident in LDS
-(csrc/token_gemm.hip through ``mdetr_token_linear``).  CUDA bf16 only, K in {128, 256, 512}; callers check
+(csrc/token_gemm.hip through ``mdetr_token_linear``).  CUDA bf16 only, K in {64, 128, 256, 512}; callers check
 ``supported`` and keep the library GEMM for everything else."""
 import torch
 
@@ -17,7 +17,7 @@ def supported(x2, weight, n_out=None):
     K = x2.shape[1]
     N = weight.shape[0] if n_out is None else n_out
     return ((x2.is_cuda or _backend is not None) and x2.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x2.dim() == 2
-            and K in (128, 256, 512) and weight.shape[1] == K and N % 8 == 0 and x2.stride(1) == 1
+            and K in (64, 128, 256, 512) and weight.shape[1] == K and N % 8 == 0 and x2.stride(1) == 1
             and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0 and weight.is_contiguous()
             and weight.data_ptr() % 16 == 0 and x2.shape[0] > 0)
 

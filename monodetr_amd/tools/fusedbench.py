@@ -85,6 +85,17 @@ def main():
     res["token_gemm_256x128"] = row(timeit(lambda: token_gemm_ext.token_gemm(xt, w128), a.iters), byts)
     res["library_gemm_256x128"] = row(timeit(lambda: F.linear(xt, w128), a.iters), byts)
 
+    # the backbone's layer1 expansions / reductions as token GEMMs (245 760 tokens)
+    T1 = 8 * 96 * 320
+    x64, x256 = torch.randn(T1, 64, device=dev).to(torch.bfloat16), torch.randn(T1, 256, device=dev).to(torch.bfloat16)
+    w_up, w_dn = (torch.randn(256, 64, device=dev) * 0.1).to(torch.bfloat16), (torch.randn(64, 256, device=dev) * 0.05).to(torch.bfloat16)
+    b_up, b_dn = torch.randn(256, device=dev).to(torch.bfloat16), torch.randn(64, device=dev).to(torch.bfloat16)
+    byts = e * (T1 * 64 + T1 * 256 + 64 * 256)
+    res["token_gemm_layer1_64to256"] = row(timeit(lambda: token_gemm_ext.token_gemm(x64, w_up, b_up), a.iters), byts)
+    res["library_gemm_layer1_64to256"] = row(timeit(lambda: F.linear(x64, w_up, b_up), a.iters), byts)
+    res["token_gemm_layer1_256to64_relu"] = row(timeit(lambda: token_gemm_ext.token_gemm(x256, w_dn, b_dn, relu=True), a.iters), byts)
+    res["library_gemm_layer1_256to64_relu"] = row(timeit(lambda: F.relu_(F.linear(x256, w_dn, b_dn)), a.iters), byts)
+
     # ---- fused AdamW -----------------------------------------------------------------------------------------------
     from monodetr_amd.helpers.optimizer_helper import AdamW, FusedAdamW
     for tag, cls in (("fused", FusedAdamW), ("foreach", AdamW)):

@@ -199,7 +199,7 @@ def test_training_step_with_fused_criterion_matches_default():
 @pytest.mark.parametrize("T,K,N,relu,bias", [(81600, 256, 256, False, True), (81600, 256, 1024, True, True),
                                              (81600, 256, 128, False, True), (4400, 256, 256, False, False),
                                              (61440, 128, 512, False, True), (61440, 512, 128, True, True), (1000, 256, 384, False, True),
-                                             (33, 256, 8, False, True)])
+                                             (33, 256, 8, False, True), (245760, 64, 256, False, True), (245760, 256, 64, True, True)])
 def test_token_gemm_matches_the_library_gemm(T, K, N, relu, bias):
     """csrc/token_gemm.hip (weight resident in LDS, MFMA 32x32x16 bf16) against F.linear evaluated in fp32 on the
     same bf16 inputs; ragged T (tile tail), N below / above one weight block, strided x."""

@@ -28,6 +28,8 @@ def run(x, w, bias, relu, ldy=None):
     (97, 128, 264, False, False),       # K = 128; N = 264: two column blocks, the second with 8 live features
     (33, 512, 136, True, True),         # K = 512, NB = 4, two column blocks
     (1, 256, 8, False, True),           # one token, one quad pair
+    (170, 64, 256, True, True),         # K = 64: a single slab per tile (the backbone's 64 -> 256 expansions)
+    (70, 64, 72, False, False),
     (2100, 256, 256, True, True),       # 66 tiles over 17 workgroups
     (33000, 128, 16, True, True),       # 1032 tiles > 4 waves x 256 workgroups (the launch cap): waves wrap to a second tile,
                                         # with the next tile's loads requested across the wrap
