@@ -114,8 +114,10 @@ __device__ __forceinline__ uint4 ba_element(const uint4 &xv, const uint4 &sv, bo
     return Io16<T>::pack(f);
 }
 
-// FIXED: the grid stride is a multiple of cvs, so a lane's column vector never changes
-template <typename T, typename BT, bool FIXED>
+// FIXED: the grid stride is a multiple of cvs, so a lane's column vector never changes.  SKIP: a residual operand
+// (a template parameter: a run-time choice between a load and a constant becomes a select of ADDRESSES, i.e. flat
+// loads from a scratch copy of the constant)
+template <typename T, typename BT, bool FIXED, bool SKIP>
 __global__ __launch_bounds__(kThreadsBa)
 void bias_act_fwd_kernel(const T *x, const BT *__restrict__ bias, const T *skip, T *y, BaParams p)
 {
@@ -126,16 +128,17 @@ void bias_act_fwd_kernel(const T *x, const BT *__restrict__ bias, const T *skip,
     const uint4 *xp = reinterpret_cast<const uint4 *>(x);
     const uint4 *sp = reinterpret_cast<const uint4 *>(skip);
     uint4 *yp = reinterpret_cast<uint4 *>(y);
-    const bool has_skip = skip != nullptr;
+    constexpr bool has_skip = SKIP;
     float bv[N];
     if (FIXED) load_bias<T, BT>(bias, static_cast<int>(v % p.cvs), bv);
-    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
     for (; v + 3 * stride < p.nvec; v += 4 * stride) {         // four independent 16-byte loads per tensor in flight
         uint4 a[4], s[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) a[k] = xp[v + k * stride];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] = has_skip ? sp[v + k * stride] : zero;
+        for (int k = 0; k < 4; ++k) {
+            if constexpr (SKIP) s[k] = sp[v + k * stride]; else s[k] = make_uint4(0u, 0u, 0u, 0u);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (!FIXED) load_bias<T, BT>(bias, static_cast<int>((v + k * stride) % p.cvs), bv);
@@ -145,7 +148,8 @@ void bias_act_fwd_kernel(const T *x, const BT *__restrict__ bias, const T *skip,
     for (; v < p.nvec; v += stride) {
         if (!FIXED) load_bias<T, BT>(bias, static_cast<int>(v % p.cvs), bv);
         const uint4 a = xp[v];
-        const uint4 s = has_skip ? sp[v] : zero;
+        uint4 s = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (SKIP) s = sp[v];
         yp[v] = ba_element<T>(a, s, has_skip, bv, v, p, sd);
     }
 }
@@ -209,12 +213,14 @@ hipError_t fwd_launch(const BiasActProblem &q, const void *x, const void *bias, 
     p.seed_dev = q.seed_dev;
     const int grid = grid_for(p.nvec, p.cvs);
     const bool fixed = (static_cast<int64_t>(grid) * kThreadsBa) % p.cvs == 0;
-    if (fixed)
-        hipLaunchKernelGGL((bias_act_fwd_kernel<T, BT, true>), dim3(grid), dim3(kThreadsBa), 0, st, static_cast<const T *>(x),
-                           static_cast<const BT *>(bias), static_cast<const T *>(skip), static_cast<T *>(y), p);
-    else
-        hipLaunchKernelGGL((bias_act_fwd_kernel<T, BT, false>), dim3(grid), dim3(kThreadsBa), 0, st, static_cast<const T *>(x),
-                           static_cast<const BT *>(bias), static_cast<const T *>(skip), static_cast<T *>(y), p);
+    const T *xs = static_cast<const T *>(x), *ss = static_cast<const T *>(skip);
+    const BT *bs = static_cast<const BT *>(bias);
+    T *ys = static_cast<T *>(y);
+    const dim3 g(grid), b(kThreadsBa);
+    if (fixed && skip)       hipLaunchKernelGGL((bias_act_fwd_kernel<T, BT, true, true>), g, b, 0, st, xs, bs, ss, ys, p);
+    else if (fixed)          hipLaunchKernelGGL((bias_act_fwd_kernel<T, BT, true, false>), g, b, 0, st, xs, bs, ss, ys, p);
+    else if (skip)           hipLaunchKernelGGL((bias_act_fwd_kernel<T, BT, false, true>), g, b, 0, st, xs, bs, ss, ys, p);
+    else                     hipLaunchKernelGGL((bias_act_fwd_kernel<T, BT, false, false>), g, b, 0, st, xs, bs, ss, ys, p);
     return hipGetLastError();
 }
 

@@ -98,7 +98,14 @@ void lsa_kernel(const float *__restrict__ C, const int *__restrict__ num_targets
         int way = -2;                                                 // -1 = reached from the dummy column
         bool used = false;
         int j0 = -1;                                                  // current column (-1 = dummy column holding row i)
-        while (true) {
+        // Every pass marks one more column as used, so a free column is reached within i + 1 <= n passes -- for
+        // finite costs.  With NaN / inf costs (diverged predictions) the candidates stop being ordered: the argmin can
+        // return a used column again or differ between lanes, and nothing then guarantees that an unbounded search
+        // ends -- on the GPU that is a hung queue, not a wrong number.  Both loops of a row are therefore bounded by
+        // n + 1 trips; a row whose search does not reach a free column stays unmatched (the result is meaningless
+        // for such input, but the kernel returns and the output is still a matching).
+        bool reached = false;
+        for (int pass = 0; pass <= n; ++pass) {
             if (lane == j0) used = true;
             const int i0 = j0 < 0 ? i : __shfl(p, j0);
             const double ui0 = u[i0];
@@ -117,10 +124,11 @@ void lsa_kernel(const float *__restrict__ C, const int *__restrict__ num_targets
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             j0 = m.j;
-            if (__shfl(p, j0) < 0) break;                             // free column reached
+            if (__shfl(p, j0) < 0) { reached = true; break; }         // free column reached
         }
+        if (!reached) continue;                                       // wave-uniform (j0 and p[j0] are)
         // augment along the alternating path back to the dummy column
-        while (j0 >= 0) {
+        for (int hop = 0; hop <= n && j0 >= 0; ++hop) {
             const int j1 = __shfl(way, j0);
             const int pj1 = j1 < 0 ? i : __shfl(p, j1);
             if (lane == j0) p = pj1;

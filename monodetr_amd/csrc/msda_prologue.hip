@@ -12,6 +12,7 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 
+#include <initializer_list>
 #include <type_traits>
 
 #include "msda_prologue.h"
@@ -102,6 +103,120 @@ void prologue_bwd_kernel(const PrologueDims d, const T *__restrict__ offsets, co
     }
 }
 
+// ---- L = P = 4 (the model's configuration), 16-byte aligned tensors: the unit's 16 logits / 32 offsets / 16 weights /
+// ---- 32 locations move as 16-byte lane accesses (2-8 per tensor instead of 16-32 scalar ones, each of which touches 64
+// ---- different cache lines per wave), every array index is a compile-time constant (registers, no scratch)
+template <typename T, int N> __device__ __forceinline__ void load_vec(const T *p, float (&v)[N])
+{
+    constexpr int E = 16 / sizeof(T);                              // elements per 16-byte access
+    static_assert(N % E == 0, "whole 16-byte accesses");
+    struct alignas(16) Pack { T e[E]; };
+#pragma unroll
+    for (int k = 0; k < N / E; ++k) {
+        const Pack t = *reinterpret_cast<const Pack *>(p + k * E);
+#pragma unroll
+        for (int i = 0; i < E; ++i) v[k * E + i] = ldf<T>(&t.e[i]);
+    }
+}
+template <typename T, int N> __device__ __forceinline__ void store_vec(T *p, const float (&v)[N])
+{
+    constexpr int E = 16 / sizeof(T);
+    static_assert(N % E == 0, "whole 16-byte accesses");
+    struct alignas(16) Pack { T e[E]; };
+#pragma unroll
+    for (int k = 0; k < N / E; ++k) {
+        Pack t;
+#pragma unroll
+        for (int i = 0; i < E; ++i) stf<T>(&t.e[i], v[k * E + i]);
+        *reinterpret_cast<Pack *>(p + k * E) = t;
+    }
+}
+
+template <typename RT> __device__ __forceinline__ void load_ref(const RT *rp, int R, float (&rl)[6])
+{
+#pragma unroll
+    for (int r = 0; r < 6; ++r) rl[r] = r < R ? ldf<RT>(rp + r) : 0.f;
+}
+
+template <typename T, typename RT>
+__global__ __launch_bounds__(256)
+void prologue_fwd_vec44(const PrologueDims d, const T *__restrict__ offsets, const T *__restrict__ logits,
+                        const RT *__restrict__ ref, const int64_t *__restrict__ shapes, float *__restrict__ loc,
+                        float *__restrict__ attn)
+{
+    const int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;              // (b, q, m)
+    if (u >= static_cast<int64_t>(d.B) * d.Lq * d.M) return;
+    const int64_t bq = u / d.M;
+    const int b = static_cast<int>(bq / d.Lq), q = static_cast<int>(bq - static_cast<int64_t>(b) * d.Lq);
+    float lg[16], at[16], off[32], lc[32];
+    load_vec<T, 16>(logits + u * 16, lg);
+    load_vec<T, 32>(offsets + u * 32, off);
+    pro_softmax(lg, 16, at);
+    store_vec<float, 16>(attn + u * 16, at);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        float rl[6];
+        load_ref<RT>(ref + b * d.rsb + q * d.rsq + l * d.rsl, d.R, rl);
+        const float wh[2] = {static_cast<float>(shapes[2 * l + 1]), static_cast<float>(shapes[2 * l])};   // (W_l, H_l)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) lc[(l * 4 + p) * 2 + c] = pro_location(off[(l * 4 + p) * 2 + c], rl, d.R, c, wh[c], 4);
+    }
+    store_vec<float, 32>(loc + u * 32, lc);
+}
+
+template <typename T, typename RT>
+__global__ __launch_bounds__(256)
+void prologue_bwd_vec44(const PrologueDims d, const T *__restrict__ offsets, const RT *__restrict__ ref,
+                        const int64_t *__restrict__ shapes, const float *__restrict__ attn,
+                        const float *__restrict__ g_loc, const float *__restrict__ g_attn, T *__restrict__ g_offsets,
+                        T *__restrict__ g_logits, float *__restrict__ g_ref)
+{
+    const int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (u >= static_cast<int64_t>(d.B) * d.Lq * d.M) return;
+    const int64_t bq = u / d.M;
+    const int b = static_cast<int>(bq / d.Lq), q = static_cast<int>(bq - static_cast<int64_t>(b) * d.Lq);
+    float at[16], ga[16], gl[16], glc[32], off[32], go[32];
+    load_vec<float, 16>(attn + u * 16, at);
+    load_vec<float, 16>(g_attn + u * 16, ga);
+    load_vec<float, 32>(g_loc + u * 32, glc);
+    if (d.R != 2) load_vec<T, 32>(offsets + u * 32, off);          // the 2-component form does not read the offsets
+    else {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) off[i] = 0.f;
+    }
+    pro_softmax_backward(at, ga, 16, gl);
+    store_vec<T, 16>(g_logits + u * 16, gl);
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        float rl[6], gr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        load_ref<RT>(ref + b * d.rsb + q * d.rsq + l * d.rsl, d.R, rl);
+        const float wh[2] = {static_cast<float>(shapes[2 * l + 1]), static_cast<float>(shapes[2 * l])};
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int i = (l * 4 + p) * 2 + c;
+                go[i] = pro_location_backward(glc[i], off[i], rl, d.R, c, wh[c], 4, gr);    // (a select with nullptr would put gr in scratch)
+            }
+        if (g_ref) {
+            float *out = g_ref + ((static_cast<int64_t>(b) * d.Lq + q) * d.L + l) * d.R;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+                if (r < d.R) unsafeAtomicAdd(out + r, gr[r]);                             // summed over the M heads
+        }
+    }
+    store_vec<T, 32>(g_offsets + u * 32, go);
+}
+
+bool aligned16_all(std::initializer_list<const void *> ps)
+{
+    for (const void *p : ps)
+        if (reinterpret_cast<uintptr_t>(p) & 15u) return false;
+    return true;
+}
+
 }  // namespace
 
 // reference points may stay fp32 while the projections' outputs are bf16 (a bf16 model body keeps its coordinates in fp32)
@@ -109,7 +224,10 @@ template <typename T, typename RT>
 hipError_t launch_fwd(const PrologueDims &d, const void *offsets, const void *logits, const void *ref, const int64_t *shapes,
                       float *loc, float *attn, dim3 grid, hipStream_t st)
 {
-    if (d.L * d.P == 16)
+    if (d.L == 4 && d.P == 4 && aligned16_all({offsets, logits, loc, attn}))
+        hipLaunchKernelGGL((prologue_fwd_vec44<T, RT>), grid, dim3(256), 0, st, d, static_cast<const T *>(offsets),
+                           static_cast<const T *>(logits), static_cast<const RT *>(ref), shapes, loc, attn);
+    else if (d.L * d.P == 16)
         hipLaunchKernelGGL((prologue_fwd_kernel<T, RT, 16>), grid, dim3(256), 0, st, d, static_cast<const T *>(offsets),
                            static_cast<const T *>(logits), static_cast<const RT *>(ref), shapes, loc, attn);
     else
@@ -122,7 +240,11 @@ template <typename T, typename RT>
 hipError_t launch_bwd(const PrologueDims &d, const void *offsets, const void *ref, const int64_t *shapes, const float *attn,
                       const float *g_loc, const float *g_attn, void *g_offsets, void *g_logits, float *g_ref, dim3 grid, hipStream_t st)
 {
-    if (d.L * d.P == 16)
+    if (d.L == 4 && d.P == 4 && aligned16_all({offsets, attn, g_loc, g_attn, g_offsets, g_logits}))
+        hipLaunchKernelGGL((prologue_bwd_vec44<T, RT>), grid, dim3(256), 0, st, d, static_cast<const T *>(offsets),
+                           static_cast<const RT *>(ref), shapes, attn, g_loc, g_attn, static_cast<T *>(g_offsets),
+                           static_cast<T *>(g_logits), g_ref);
+    else if (d.L * d.P == 16)
         hipLaunchKernelGGL((prologue_bwd_kernel<T, RT, 16>), grid, dim3(256), 0, st, d, static_cast<const T *>(offsets),
                            static_cast<const RT *>(ref), shapes, attn, g_loc, g_attn, static_cast<T *>(g_offsets),
                            static_cast<T *>(g_logits), g_ref);

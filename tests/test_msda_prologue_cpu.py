@@ -112,3 +112,44 @@ def test_fp32_reference_points_stay_fp32_with_bf16_projections(backend):
     assert (ref.detach().to(torch.bfloat16).float() - ref.detach()).abs().max() > 1e-3
     loc.sum().backward()
     assert ref.grad.dtype == torch.float32 and torch.allclose(ref.grad, torch.full_like(ref.grad, M * P * 2.0 / 2), atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R", [2, 6])
+def test_vector_and_scalar_kernels_agree_bit_for_bit(dtype, R):
+    """L = P = 4 with 16-byte aligned tensors takes the 16-byte-access kernels (prologue_*_vec44); the same call on
+    pointers that are off by one element takes the element-wise ones.  Same arithmetic, so the same bits -- on the
+    HIP-on-CPU shim, through the C ABI."""
+    import native_emul
+    lib = native_emul.lib()
+    g = torch.Generator().manual_seed(R)
+    B, Lq, M, L, P = 2, 21, 8, 4, 4
+    shapes = torch.tensor([[48, 160], [24, 80], [12, 40], [6, 20]], dtype=torch.int64)
+    code = 2 if dtype == torch.bfloat16 else 0
+    n = B * Lq * M * L * P
+
+    def padded(t):                                   # (aligned copy, copy displaced by one element)
+        buf = torch.zeros(t.numel() + 16, dtype=t.dtype)
+        a, b = buf[:t.numel()], torch.zeros(t.numel() + 16, dtype=t.dtype)[1:t.numel() + 1]
+        a.copy_(t.reshape(-1)); b.copy_(t.reshape(-1))
+        assert a.data_ptr() % 16 == 0 and b.data_ptr() % 16 != 0
+        return a, b
+
+    off = padded((torch.randn(2 * n, generator=g) * 3).to(dtype))
+    lg = padded(torch.randn(n, generator=g).to(dtype))
+    ref = (torch.rand(B, Lq, L, R, generator=g) * 0.8 + 0.1).contiguous()
+    g_loc, g_att = padded(torch.randn(2 * n, generator=g)), padded(torch.randn(n, generator=g))
+    geom = (B, Lq, M, L, P, R, ref.stride(0), ref.stride(1), ref.stride(2))
+    out = []
+    for k in (0, 1):
+        loc, att = padded(torch.zeros(2 * n))[k], padded(torch.zeros(n))[k]
+        assert lib.mdetr_msda_prologue_forward(code, 0, off[k].data_ptr(), lg[k].data_ptr(), ref.data_ptr(), shapes.data_ptr(),
+                                               loc.data_ptr(), att.data_ptr(), *geom, -1, None) == 0
+        g_off, g_lg = padded(torch.zeros(2 * n, dtype=dtype))[k], padded(torch.zeros(n, dtype=dtype))[k]
+        g_ref = torch.empty(B, Lq, L, R)
+        assert lib.mdetr_msda_prologue_backward(code, 0, off[k].data_ptr(), ref.data_ptr(), shapes.data_ptr(), att.data_ptr(),
+                                                g_loc[k].data_ptr(), g_att[k].data_ptr(), g_off.data_ptr(), g_lg.data_ptr(),
+                                                g_ref.data_ptr(), *geom, -1, None) == 0
+        out.append((loc.clone(), att.clone(), g_off.clone(), g_lg.clone(), g_ref))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
