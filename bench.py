@@ -111,29 +111,35 @@ def apply_switches(names):
 
 
 def probe_configs(precision):
-    """Candidate switch sets, nested so that a set which fails still leaves the smaller ones standing: the default path;
-    the criterion / optimizer kernels; + the model-side prologue and LayerNorm kernels; + the bf16-native MSDA (bf16 body
-    only); + the fused convolution / FFN tails; + ReLU in the library GEMM's epilogue; + the token GEMM (bf16 only; the
-    one candidate that replaces a tuned library kernel and may well be slower).  The fullest set runs last so that a
-    crash in it loses nothing."""
-    loss_side = ["MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW"]
-    base = loss_side + ["MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN"]
-    sets = [[], loss_side, base]
-    if precision == "bf16":
-        base = base + ["MDETR_MSDA_BF16"]
-        sets.append(base)
-    tails = base + ["MDETR_FUSED_EPILOGUE"]
-    sets += [tails, tails + ["MDETR_GEMM_RELU"]]
-    if precision == "bf16":
-        sets.append(tails + ["MDETR_GEMM_RELU", "MDETR_TOKEN_GEMM"])
-    return sets
+    """Candidate switch sets, nested and growing by ONE kernel family per level, so that a family which faults or
+    disagrees costs only itself and what is stacked on top of it: the default path; + the fused criterion; + the flat
+    AdamW; + the residual LayerNorm kernel; + the MSDA prologue; + the bf16-native MSDA (bf16 body only); + the fused
+    convolution / FFN tails; + ReLU in the library GEMM's epilogue; + the token GEMM (bf16 only; the one candidate
+    that replaces a tuned library kernel and may well be slower).  The fullest set runs last so that a crash in it
+    loses nothing."""
+    order = ["MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE", "MDETR_MSDA_BF16",
+             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_TOKEN_GEMM"]
+    if precision != "bf16":
+        order = [k for k in order if k not in ("MDETR_MSDA_BF16", "MDETR_TOKEN_GEMM")]
+    return [order[:i] for i in range(len(order) + 1)]
+
+
+def admissible(r, base, rel_tol=0.03):
+    """Does candidate record `r` compute the same training step as the default-path record `base`?  Its three
+    deterministic losses must be finite and within rel_tol of the default path's, and the summed gradient norms of its
+    first iteration within 2 rel_tol."""
+    ok = r.get("finite", True) and "error" not in r and len(r["losses"]) == len(base["losses"]) and all(
+        x == x and abs(x - b) <= rel_tol * max(abs(b), 1e-6) for x, b in zip(r["losses"], base["losses"]))
+    if ok and "grad_norm" in r and "grad_norm" in base:               # first-iteration gradients agree as well
+        g, gb = r["grad_norm"], base["grad_norm"]
+        ok = g == g and abs(g - gb) <= 2 * rel_tol * max(abs(gb), 1e-6)
+    return bool(ok)
 
 
 def choose_config(results, rel_tol=0.03, min_gain=0.01):
     """results: list of {"switches": [...], "losses": [3 floats], "ms": float} from one probe run, the default path
-    (no switches) among them.  A candidate is admissible if its three deterministic losses are finite and within
-    rel_tol of the default path's and the summed gradient norms of its first iteration within 2 rel_tol; the fastest
-    admissible one wins if it beats the default by min_gain."""
+    (no switches) among them.  The fastest admissible candidate (see `admissible`) wins if it beats the default by
+    min_gain."""
     bases = [r for r in results if not r["switches"]]
     if not bases or not all(x == x and abs(x) != float("inf") for x in bases[0]["losses"]):
         return [], "no default-path probe"
@@ -145,44 +151,84 @@ def choose_config(results, rel_tol=0.03, min_gain=0.01):
     for r in results:
         if r is base:
             continue
-        ok = r.get("finite", True) and len(r["losses"]) == len(base["losses"]) and all(
-            x == x and abs(x - b) <= rel_tol * max(abs(b), 1e-6) for x, b in zip(r["losses"], base["losses"]))
-        if ok and "grad_norm" in r and "grad_norm" in base:           # first-iteration gradients agree as well
-            g, gb = r["grad_norm"], base["grad_norm"]
-            ok = g == g and abs(g - gb) <= 2 * rel_tol * max(abs(gb), 1e-6)
-        r["admissible"] = bool(ok)
+        ok = admissible(r, base, rel_tol)
+        r["admissible"] = ok
         if ok and r["ms"] < best["ms"] and r["ms"] <= base["ms"] * (1.0 - min_gain):
             best, why = r, "fastest admissible candidate"
     return sorted(best["switches"]), why
 
 
-def run_probe(args, local_rank, configs, timeout=420):
-    """Run `bench.py --probe` in a child process (a kernel that faults takes the child down, not this process) and
-    return the PROBE records it managed to print."""
+def _probe_child(args, local_rank, spec, timeout):
+    """One `bench.py --probe` child (a kernel that faults takes the child down, not this process).  Returns
+    (PROBE records, families announced by PROBE-TRY lines, stderr tail)."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
                                                           "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID") and not k.startswith("MDETR_")}
     env["MDETR_BENCH_AUTOTUNE"] = "0"
-    cmd = [sys.executable, os.path.abspath(__file__), "--probe", json.dumps(configs), "--precision", args.precision, "--batch", str(args.batch),
+    cmd = [sys.executable, os.path.abspath(__file__), "--probe", json.dumps(spec), "--precision", args.precision, "--batch", str(args.batch),
            "--probe-device", str(local_rank)]
     out, err = "", ""
     text = lambda b: b.decode(errors="replace") if isinstance(b, bytes) else (b or "")
     try:
-        done = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+        done = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=max(timeout, 1), text=True)
         out, err = done.stdout, done.stderr
     except subprocess.TimeoutExpired as e:
         out, err = text(e.stdout), text(e.stderr) + "\n[probe timed out after %d s]" % timeout
     except Exception as e:
-        run_probe.stderr_tail = repr(e)
-        return []
-    run_probe.stderr_tail = (err or "")[-600:]                        # kept for the report when a candidate did not finish
-    records = []
+        return [], [], repr(e)
+    records, tried = parse_probe_output(out)
+    return records, tried, (err or "")[-600:]
+
+
+def parse_probe_output(out):
+    """stdout of a probe child -> (PROBE records, families announced by PROBE-TRY lines)."""
+    records, tried = [], []
     for ln in out.splitlines():
-        if ln.startswith("PROBE "):
+        if ln.startswith("PROBE-TRY "):
+            tried.append(ln[10:].strip())
+        elif ln.startswith("PROBE "):
             try:
                 records.append(json.loads(ln[6:]))
             except ValueError:
                 pass
+    return records, tried
+
+
+def run_probe(args, local_rank, configs, timeout=480, child=_probe_child, launches=4):
+    """The probe proper.  `configs` is the nested list of `probe_configs` (+ a final []); its last non-empty entry gives
+    the ORDER in which the kernel families are tried.  The child accumulates greedily: family k is run on top of the
+    families accepted so far and kept if the step still agrees with the default path (`admissible`) and is not slower,
+    so a family that disagrees costs only itself.  A family that takes the child down (fault, hang -> time-out) is
+    recorded as such and a new child continues with the families after it (at most `launches` children, one shared
+    time budget).  Returns every PROBE record; the caller picks with `choose_config`."""
+    order = list(max(configs, key=len)) if configs else []
+    deadline = time.monotonic() + timeout
+    records, state, remaining = [], {"good": [], "good_ms": None, "base": None}, order
+    run_probe.stderr_tail = ""
+    for _ in range(launches):
+        left = deadline - time.monotonic()
+        if left <= 5:
+            break
+        # a healthy child needs a minute or two; a hung one must not eat the whole budget
+        recs, tried, err = child(args, local_rank, dict(state, order=remaining), min(left, 300))
+        run_probe.stderr_tail = err
+        records += recs
+        for r in recs:                                                # replay the child's accept rule
+            if not r["switches"] and state["base"] is None:
+                state["base"], state["good_ms"] = r, r["ms"]
+            elif r.get("accepted"):
+                state["good"], state["good_ms"] = state["good"] + [r["family"]], min(state["good_ms"] or r["ms"], r["ms"])
+        if any(r.get("final") for r in recs) or state["base"] is None:
+            break                                                     # complete -- or not even the default path ran
+        done = {r.get("family") for r in recs}
+        crashed = next((f for f in tried if f not in done), None)
+        if crashed is None or crashed not in remaining:
+            break                                                     # ended outside a family (closing default run, cut short): nothing more to learn
+        records.append({"switches": sorted(state["good"] + [crashed]), "family": crashed, "losses": [float("nan")] * 3, "ms": 1e9,
+                        "finite": False, "error": "the probe child did not survive this family: " + err[-200:]})
+        remaining = remaining[remaining.index(crashed) + 1:]
+        if not remaining:
+            break
     return records
 
 
@@ -211,9 +257,9 @@ def autotune(args, world, local_rank, runner=run_probe, cache_path=None):
         configs = probe_configs(args.precision) + [[]]
         report = {"source": "probe", "decision": why, "chosen": chosen,
                   "candidates": [dict({"switches": r["switches"], "ms": r["ms"], "admissible": r.get("admissible", True)},
-                                      **({"error": r["error"]} if "error" in r else {})) for r in results]}
-        if len(results) < len(configs):                               # a candidate took the child down: say how
-            report["unfinished"] = [sorted(c) for c in configs[len(results):]]
+                                      **{k: r[k] for k in ("error", "family", "accepted") if k in r}) for r in results]}
+        if not any(r.get("final") for r in results) and len(results) < len(configs):     # the probe did not run to its end: say how
+            report["incomplete"] = True
             report["child_stderr_tail"] = getattr(runner, "stderr_tail", "")
         try:
             json.dump({"key": key, "chosen": chosen, "report": report}, open(cache_path, "w"))
@@ -258,20 +304,51 @@ def probe_config(device, batch, precision, names, size=(384, 1280), warm=5, time
             "finite": bool(torch.isfinite(last.detach()).item())}
 
 
-def probe_main(args):
-    """Child side of the autotune: one PROBE line per candidate, flushed as soon as it is known."""
-    device = torch.device("cuda", args.probe_device)
-    torch.cuda.set_device(device)
-    from monodetr_amd import _capi
-    _capi.lib()
-    for names in json.loads(args.probe):
-        try:
-            record = probe_config(device, args.batch, args.precision, names)
-        except Exception as e:                                        # a refused call (not a fault): this candidate is out, the rest go on
-            record = {"switches": sorted(names), "losses": [float("nan")] * 3, "ms": 1e9, "finite": False, "error": repr(e)[:300]}
+def probe_main(args, run=None):
+    """Child side of the autotune: one PROBE line per candidate, flushed as soon as it is known.  `--probe` carries
+    either a plain list of switch sets (each is run as given) or {"order", "good", "good_ms", "base"}: the greedy
+    accumulation described at `run_probe`."""
+    if run is None:
+        device = torch.device("cuda", args.probe_device)
+        torch.cuda.set_device(device)
+        from monodetr_amd import _capi
+        _capi.lib()
+
+        def run(names):
+            try:
+                return probe_config(device, args.batch, args.precision, names)
+            except Exception as e:                                    # a refused call (not a fault): this candidate is out, the rest go on
+                return {"switches": sorted(names), "losses": [float("nan")] * 3, "ms": 1e9, "finite": False, "error": repr(e)[:300]}
+            finally:
+                gc.collect()
+                if torch.cuda.is_available():
+                    torch.cuda.empty_cache()
+
+    def emit(record):
         print("PROBE " + json.dumps(record), flush=True)
-        gc.collect()
-        torch.cuda.empty_cache()
+
+    spec = json.loads(args.probe)
+    if isinstance(spec, list):
+        for names in spec:
+            emit(run(names))
+        return
+    good, good_ms, base = list(spec.get("good") or []), spec.get("good_ms"), spec.get("base")
+    if base is None:
+        base = run([])
+        emit(base)
+        good_ms = base["ms"]
+    else:
+        run([])                                                       # a follow-up child: pay this process's library warm-up outside the comparison
+    for fam in spec["order"]:
+        print("PROBE-TRY " + fam, flush=True)                         # the parent learns which family was in flight if this process dies
+        rec = run(good + [fam])
+        rec["family"] = fam
+        rec["admissible"] = admissible(rec, base)
+        rec["accepted"] = bool(rec["admissible"] and rec["ms"] <= (good_ms or rec["ms"]) * 1.02)
+        emit(rec)
+        if rec["accepted"]:
+            good, good_ms = good + [fam], min(good_ms or rec["ms"], rec["ms"])
+    emit(dict(run([]), final=True))                                   # the default path again, now with warm libraries
 
 
 class TrainStep:

@@ -59,7 +59,7 @@ def test_autotune_runs_one_probe_caches_per_box_and_reports(tmp_path):
         return [{"switches": sorted(c), "losses": [30.0, 29.0, 28.0], "ms": 38.0 - 1.5 * len(c)} for c in configs]
     cache = str(tmp_path / "tune.json")
     chosen, report = bench.autotune(args(), 1, 0, runner=runner, cache_path=cache)
-    assert chosen == sorted(bench.AUTOTUNE_SWITCHES) and report["source"] == "probe" and len(report["candidates"]) == 8 and calls[0][0] == calls[0][-1] == []
+    assert chosen == sorted(bench.AUTOTUNE_SWITCHES) and report["source"] == "probe" and len(report["candidates"]) == 10 and calls[0][0] == calls[0][-1] == []
     chosen2, report2 = bench.autotune(args(), 1, 0, runner=runner, cache_path=cache)
     assert chosen2 == chosen and report2["source"] == "cache" and len(calls) == 1
     # another precision is another key
@@ -97,7 +97,8 @@ def test_probe_child_command_is_isolated_from_the_launcher_environment(monkeypat
     monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("MASTER_PORT", "1234")
     recs = bench.run_probe(args(), 0, [[], ["MDETR_FUSED_LN"]])
     assert recs == [{"switches": [], "losses": [1, 2, 3], "ms": 40.0}]
-    assert "--probe" in seen["cmd"] and json.loads(seen["cmd"][seen["cmd"].index("--probe") + 1]) == [[], ["MDETR_FUSED_LN"]]
+    assert "--probe" in seen["cmd"] and json.loads(seen["cmd"][seen["cmd"].index("--probe") + 1]) == \
+        {"good": [], "good_ms": None, "base": None, "order": ["MDETR_FUSED_LN"]}
     assert not {"WORLD_SIZE", "RANK", "MASTER_PORT"} & set(seen["env"]) and seen["env"]["MDETR_BENCH_AUTOTUNE"] == "0"
 
 
@@ -192,3 +193,75 @@ def test_bench_main_composes_its_json_line(monkeypatch, capsys):
             assert roof["traffic"] is None and roof["algorithmic_bytes"] == 417800000         # bf16 value / out / grad_out
         else:
             assert roof["algorithmic_bytes"] == 501400000
+
+
+def _scripted_child(behaviour, log):
+    """A stand-in for the probe child process that runs the REAL child loop (bench.probe_main) around a scripted
+    `run`: behaviour[family] in {"ok" (faster), "slow", "wrong" (losses off), "raise" (refused call), "die" (the process
+    is lost)}."""
+    import contextlib
+    import io
+
+    class Died(BaseException):
+        pass
+
+    def child(a, local_rank, spec, timeout):
+        log.append(dict(spec))
+
+        def run(names):
+            kinds = [behaviour.get(n, "ok") for n in names]
+            if "die" in kinds:
+                raise Died()
+            if "raise" in kinds:
+                return {"switches": sorted(names), "losses": [float("nan")] * 3, "ms": 1e9, "finite": False, "error": "RuntimeError('refused')"}
+            losses = [30.0, 29.0, 28.0] if "wrong" not in kinds else [30.0, 35.0, 41.0]
+            ms = 40.0 - 1.0 * sum(k == "ok" for k in kinds) + 3.0 * sum(k == "slow" for k in kinds)
+            return {"switches": sorted(names), "losses": losses, "grad_norm": 100.0, "ms": ms, "finite": True}
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            try:
+                bench.probe_main(types.SimpleNamespace(probe=json.dumps(spec)), run=run)
+            except Died:
+                pass
+        recs, tried = bench.parse_probe_output(buf.getvalue())
+        return recs, tried, "stderr of the child"
+    return child
+
+
+def test_greedy_probe_drops_only_the_family_that_disagrees_or_dies():
+    order = bench.probe_configs("bf16")[-1]
+    configs = bench.probe_configs("bf16") + [[]]
+    # every family fine: the fullest set is reached and chosen
+    log = []
+    recs = bench.run_probe(args(), 0, configs, child=_scripted_child({}, log))
+    assert len(log) == 1 and len(recs) == len(order) + 2 and recs[-1].get("final")
+    assert bench.choose_config(recs)[0] == sorted(order)
+    # one family computes something else, one is slower, one refuses: each costs only itself
+    bad = {"MDETR_FUSED_LN": "wrong", "MDETR_MSDA_BF16": "slow", "MDETR_GEMM_RELU": "raise"}
+    recs = bench.run_probe(args(), 0, configs, child=_scripted_child(bad, log))
+    chosen, why = bench.choose_config(recs)
+    assert chosen == sorted(set(order) - set(bad)) and why == "fastest admissible candidate"
+    by_family = {r.get("family"): r for r in recs}
+    assert not by_family["MDETR_FUSED_LN"]["admissible"] and not by_family["MDETR_FUSED_LN"]["accepted"]
+    assert by_family["MDETR_MSDA_BF16"]["admissible"] and not by_family["MDETR_MSDA_BF16"]["accepted"]
+    assert "MDETR_FUSED_LN" not in by_family["MDETR_MSDA_PROLOGUE"]["switches"]           # tried on top of the accepted ones only
+    # a family that takes the child down: recorded, and a second child carries on after it with the accepted set
+    log.clear()
+    recs = bench.run_probe(args(), 0, configs, child=_scripted_child({"MDETR_MSDA_PROLOGUE": "die"}, log))
+    assert len(log) == 2 and log[1]["good"] == ["MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN"]
+    assert log[1]["order"] == order[order.index("MDETR_MSDA_PROLOGUE") + 1:] and log[1]["base"]["switches"] == []
+    died = [r for r in recs if "did not survive" in r.get("error", "")]
+    assert len(died) == 1 and died[0]["family"] == "MDETR_MSDA_PROLOGUE"
+    assert bench.choose_config(recs)[0] == sorted(set(order) - {"MDETR_MSDA_PROLOGUE"})
+    # the default path itself dies: nothing to compare with, the benchmark keeps its defaults
+    log.clear()
+
+    def dead(a, local_rank, spec, timeout):
+        log.append(spec)
+        return [], [], "Memory access fault"
+    assert bench.run_probe(args(), 0, configs, child=dead) == [] and len(log) == 1
+    assert bench.choose_config([]) == ([], "no default-path probe")
+    # a child that keeps dying is given up on after a few launches
+    log.clear()
+    recs = bench.run_probe(args(), 0, configs, child=_scripted_child({k: "die" for k in order}, log))
+    assert len(log) == 4 and bench.choose_config(recs)[0] == []
