@@ -151,5 +151,7 @@ def test_vector_and_scalar_kernels_agree_bit_for_bit(dtype, R):
                                                 g_loc[k].data_ptr(), g_att[k].data_ptr(), g_off.data_ptr(), g_lg.data_ptr(),
                                                 g_ref.data_ptr(), *geom, -1, None) == 0
         out.append((loc.clone(), att.clone(), g_off.clone(), g_lg.clone(), g_ref))
-    for a, b in zip(*out):
+    for a, b in zip(out[0][:4], out[1][:4]):
         assert torch.equal(a, b)
+    # grad_ref is a float atomic sum over the M heads of a query: the same terms, in lane order
+    assert (out[0][4] - out[1][4]).abs().max().item() <= 1e-5 * max(1.0, out[0][4].abs().max().item())
