@@ -144,6 +144,8 @@ def pointwise_conv(x, weight, bias=None, relu=False):
 def pointwise_relu_fusable(x, weight, bias):
     """Would `pointwise_conv(..., relu=True)` run the ReLU inside the GEMM?  (callers that apply an in-place ReLU
     themselves otherwise)"""
+    if not (_TOKEN_GEMM or _GEMM_RELU):                              # the default path pays nothing for the question
+        return False
     C = x.shape[1]
     return (x.numel() // C >= _MIN_TOKENS and torch.is_grad_enabled() and not torch.is_autocast_enabled()
             and _kernel_relu(x.permute(0, 2, 3, 1).reshape(-1, C), weight.reshape(weight.shape[0], C), bias))
