@@ -87,7 +87,7 @@ def synthetic_batch(B, H, W, seed, device):
 # start-up autotune below.  (MDETR_MSDA_BF16 changes the MSDA operator's element types; the roofline accounting
 # follows it: msda_algorithmic_bytes(mixed=True), and the PMC traffic figure recorded for the fp32 operator is dropped.)
 AUTOTUNE_SWITCHES = ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN", "MDETR_MSDA_BF16", "MDETR_TOKEN_GEMM",
-                     "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU")
+                     "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3")
 ALL_SWITCHES = AUTOTUNE_SWITCHES
 
 
@@ -98,7 +98,7 @@ def env_switches():
 def apply_switches(names):
     """Runtime equivalent of the environment switches for the module-level ones (the criterion's and the optimizer's
     are applied by TrainStep)."""
-    from monodetr_amd import add_ln_ext, bias_act_ext
+    from monodetr_amd import add_ln_ext, bias_act_ext, conv3x3_ext
     from monodetr_amd.monodetr import linear
     from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func
     from monodetr_amd.monodetr.ops.modules import ms_deform_attn
@@ -107,6 +107,7 @@ def apply_switches(names):
     linear._TOKEN_GEMM = "MDETR_TOKEN_GEMM" in names
     linear._GEMM_RELU = "MDETR_GEMM_RELU" in names
     bias_act_ext.ENABLED = "MDETR_FUSED_EPILOGUE" in names
+    conv3x3_ext.ENABLED = "MDETR_CONV3X3" in names
     ms_deform_attn_func._NATIVE_BF16 = "MDETR_MSDA_BF16" in names
 
 
@@ -114,13 +115,13 @@ def probe_configs(precision):
     """Candidate switch sets, nested and growing by ONE kernel family per level, so that a family which faults or
     disagrees costs only itself and what is stacked on top of it: the default path; + the fused criterion; + the flat
     AdamW; + the residual LayerNorm kernel; + the MSDA prologue; + the bf16-native MSDA (bf16 body only); + the fused
-    convolution / FFN tails; + ReLU in the library GEMM's epilogue; + the token GEMM (bf16 only; the one candidate
-    that replaces a tuned library kernel and may well be slower).  The fullest set runs last so that a crash in it
+    convolution / FFN tails; + ReLU in the library GEMM's epilogue; + the 3x3 convolution and the token GEMM (bf16 only; the
+    candidates that replace tuned library kernels and may well be slower).  The fullest set runs last so that a crash in it
     loses nothing."""
     order = ["MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE", "MDETR_MSDA_BF16",
-             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_TOKEN_GEMM"]
+             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_TOKEN_GEMM"]
     if precision != "bf16":
-        order = [k for k in order if k not in ("MDETR_MSDA_BF16", "MDETR_TOKEN_GEMM")]
+        order = [k for k in order if k not in ("MDETR_MSDA_BF16", "MDETR_CONV3X3", "MDETR_TOKEN_GEMM")]
     return [order[:i] for i in range(len(order) + 1)]
 
 

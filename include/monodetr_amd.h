@@ -403,6 +403,20 @@ int mdetr_column_sum(int dtype, const void *x, float *out, void *workspace, int6
                      int64_t rows, int cols, int64_t ld, int device, void *stream);
 
 /*
+ * 3x3 / stride 1 / pad 1 convolution of a channels-last bf16 activation on the matrix cores (implicit GEMM, im2col in LDS),
+ * with a per-channel shift (the folded frozen BatchNorm) and an optional ReLU in the epilogue -- Bottleneck.conv2 -> bn2 -> relu
+ * of the ResNet body (lib/models/monodetr/backbone.py:100-102 -> torchvision resnet), which the reference hands to cuDNN.
+ *   x      bf16 [B, H, W, C], C % 64 == 0 (a channels_last [B, C, H, W] tensor), 16-byte aligned
+ *   w      bf16 [N, 3, 3, C], N % 32 == 0 (a channels_last [N, C, 3, 3] weight), 16-byte aligned
+ *   shift  fp32 [N] or NULL;  relu 0 / 1
+ *   y      bf16 [B, H, W, N], 8-byte aligned;  y = act(conv(x, w) + shift), fp32 accumulation, one rounding
+ * The input gradient of the same convolution is this entry point on grad_y with the weight transformed to
+ * w'[c, t, s, n] = w[n, 2 - t, 2 - s, c] (taps mirrored, channel axes swapped), shift = NULL, relu = 0.
+ */
+int mdetr_conv3x3_forward(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N,
+                          int relu, int device, void *stream);
+
+/*
  * y = dropout(relu(x + bias[col] + skip)) over a [rows, cols] channels-last activation in one pass, and its backward --
  * the tails the reference runs as separate operators after a convolution / linear layer: frozen-BN shift + ReLU after the
  * bottleneck's 3x3 convolution and "out += identity; relu(out)" after its expansion (lib/models/monodetr/backbone.py:100-102

@@ -46,6 +46,7 @@ SIGNATURES = {
     "mdetr_add_layernorm_forward": (_c_int, [_c_int, _c_int] + [_c_vp] * 7 + [ctypes.c_int64, _c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),
     "mdetr_add_layernorm_partial_rows": (ctypes.c_int64, [ctypes.c_int64]),
     "mdetr_add_layernorm_backward": (_c_int, [_c_int, _c_int] + [_c_vp] * 7 + [ctypes.c_int64, _c_int, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),
+    "mdetr_conv3x3_forward": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_int, _c_vp]),
     "mdetr_bias_act_forward": (_c_int, [_c_int, _c_int] + [_c_vp] * 4 + [ctypes.c_int64, _c_int, _c_int, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),
     "mdetr_bias_act_backward": (_c_int, [_c_int] + [_c_vp] * 3 + [ctypes.c_int64, _c_int, ctypes.c_float, _c_int, _c_vp]),
     "mdetr_rotate_iou_eval": (_c_int, [_c_vp] * 5 + [_c_int, ctypes.c_int64, _c_int, _c_vp, _c_int, _c_vp]),

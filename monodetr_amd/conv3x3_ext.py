@@ -1,0 +1,83 @@
+"""``conv3x3(x, weight, shift, relu)``: 3x3 / stride 1 / pad 1 convolution of a channels_last bf16 activation with the folded
+frozen-BN shift and the ReLU in its epilogue (csrc/conv3x3.hip through ``mdetr_conv3x3_forward``): forward and input gradient
+run on the kernel, the weight gradient stays with the library."""
+import os
+
+import torch
+
+from . import _capi
+
+_backend = None               # tests substitute the CPU emulation of the same kernel source (tests/native_emul.py)
+# MDETR_CONV3X3=1 routes the backbone's stride-1 3x3 convolutions through the kernel; off until it has run on a GPU
+ENABLED = os.environ.get("MDETR_CONV3X3") == "1"
+
+
+def _lib():
+    return _backend if _backend is not None else _capi.lib()
+
+
+def supported(x, weight, stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=1):
+    """x [B, C, H, W] channels_last bf16, weight [N, C, 3, 3] bf16; stride 1, padding 1, no dilation / groups."""
+    return ((x.is_cuda or _backend is not None) and x.dim() == 4 and weight.dim() == 4 and x.dtype == torch.bfloat16
+            and weight.dtype == torch.bfloat16 and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1)
+            and tuple(padding) == (1, 1) and tuple(dilation) == (1, 1) and groups == 1 and weight.shape[1] == x.shape[1]
+            and x.shape[1] % 64 == 0 and weight.shape[0] % 32 == 0 and x.numel() > 0
+            and x.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0)
+
+
+def _ohwi(weight):
+    """[N, C, 3, 3] -> contiguous [N, 3, 3, C] (a view when the weight is channels_last already)."""
+    w = weight.permute(0, 2, 3, 1).contiguous()
+    return w if w.data_ptr() % 16 == 0 else w.clone()
+
+
+def _launch(x_cl, w_ohwi, shift, relu):
+    """x_cl [B, C, H, W] channels_last, w_ohwi [N, 3, 3, C] contiguous -> y [B, N, H, W] channels_last."""
+    B, C, H, W = x_cl.shape
+    N = w_ohwi.shape[0]
+    y = torch.empty((B, N, H, W), dtype=torch.bfloat16, device=x_cl.device, memory_format=torch.channels_last)
+    cuda = x_cl.is_cuda
+    rc = _lib().mdetr_conv3x3_forward(x_cl.data_ptr(), w_ohwi.data_ptr(), shift.data_ptr() if shift is not None else None, y.data_ptr(),
+                                      B, H, W, C, N, 1 if relu else 0, x_cl.device.index if cuda else -1,
+                                      torch.cuda.current_stream(x_cl.device).cuda_stream if cuda else None)
+    if rc != 0:
+        _capi.check(rc, "mdetr_conv3x3_forward")
+    return y
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, shift, relu):
+        w = _ohwi(weight)
+        sh = None if shift is None else shift.float().contiguous()
+        y = _launch(x, w, sh, relu)
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x, weight, w, *((y,) if relu else ()))
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, weight, w = ctx.saved_tensors[:3]
+        if ctx.relu:
+            dy = torch.ops.aten.threshold_backward(dy, ctx.saved_tensors[3], 0.0)
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # dX = conv(dY, w') with w'[c, t, s, n] = w[n, 2 - t, 2 - s, c]: the same kernel, taps mirrored, channel axes swapped
+            if dy.shape[1] % 64 == 0 and x.shape[1] % 32 == 0 and dy.data_ptr() % 16 == 0:
+                dx = _launch(dy, w.flip(1, 2).permute(3, 1, 2, 0).contiguous(), None, False)
+            else:
+                dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (True, False, False))[0]
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
+        return dx, dw, None, None
+
+
+def conv3x3(x, weight, shift=None, relu=False):
+    """act(conv2d(x, weight, padding=1) + shift[None, :, None, None]); ``shift`` [N] without gradient (a frozen-BN shift)."""
+    if not supported(x, weight):
+        raise RuntimeError("conv3x3: needs a CUDA bf16 channels_last activation with C % 64 == 0 and a bf16 [N, C, 3, 3] weight with N % 32 == 0")
+    if shift is not None and shift.requires_grad:
+        raise RuntimeError("conv3x3: the shift is a constant of the epilogue (no gradient)")
+    return _Conv3x3.apply(x, weight, shift, relu)

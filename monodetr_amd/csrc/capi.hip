@@ -16,6 +16,7 @@
 #include "add_ln.h"
 #include "bias_act.h"
 #include "colsum.h"
+#include "conv3x3.h"
 #include "ddn_loss.h"
 #include "kitti_prep.h"
 #include "lsa.h"
@@ -446,6 +447,21 @@ int mdetr_column_sum(int dtype, const void *x, float *out, void *workspace, int6
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_column_sum: set device %d: %s", device, hipGetErrorString(dev.err));
     const hipError_t e = mdetr::colsum_launch(dtype, x, out, workspace, rows, cols, ld, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_column_sum: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_conv3x3_forward(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N,
+                          int relu, int device, void *stream)
+{
+    if (B < 0 || H < 0 || W < 0 || C <= 0 || N <= 0) return fail(MDETR_E_ARG, "mdetr_conv3x3_forward: bad sizes B=%d H=%d W=%d C=%d N=%d", B, H, W, C, N);
+    if (B == 0 || H == 0 || W == 0) return MDETR_OK;
+    if (!x || !w || !y) return fail(MDETR_E_ARG, "mdetr_conv3x3_forward: null pointer");
+    if (!mdetr::conv3x3_supported(B, H, W, C, N, x, w, y))
+        return fail(MDETR_E_ARG, "mdetr_conv3x3_forward: needs C %% 64 == 0, N %% 32 == 0, 16-byte aligned x / w, 8-byte aligned y (C=%d N=%d)", C, N);
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv3x3_forward: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::conv3x3_launch(x, w, shift, y, B, H, W, C, N, relu != 0, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv3x3_forward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

@@ -1,0 +1,13 @@
+// monodetr_amd/csrc/conv3x3.h -- internal launcher declarations (see conv3x3.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mdetr {
+
+// bf16 only; x [B, H, W, C] with C % 64 == 0, w [N, 3, 3, C] with N % 32 == 0, y [B, H, W, N]; x / w 16-byte, y 8-byte aligned
+bool conv3x3_supported(int B, int H, int W, int C, int N, const void *x, const void *w, const void *y);
+hipError_t conv3x3_launch(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N, bool relu,
+                          hipStream_t st);
+
+}  // namespace mdetr

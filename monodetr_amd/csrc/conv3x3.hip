@@ -1,0 +1,173 @@
+// monodetr_amd/csrc/conv3x3.hip -- 3x3 / stride 1 / pad 1 convolution of a channels-last bf16 activation as an implicit
+// GEMM on the matrix cores, im2col done in LDS, with the frozen-BN shift and the ReLU in the epilogue.
+//
+// The ResNet-50 body has 13 such convolutions (torchvision Bottleneck.conv2 behind lib/models/monodetr/backbone.py:100-102;
+// 18.1 GFLOP each at B = 8, whatever the stage), forward and -- with the taps mirrored and the channel axes swapped --
+// input gradient.  MIOpen's implicit-GEMM kernels take 64-70 us for one of them in profiles/r01h (~ 270 TFLOP/s, 11 % of
+// the dense bf16 rate) and leave shift, ReLU and casts to separate passes.
+//
+//   y[b, r, c, n] = act( shift[n] + sum_{t, s, k} x[b, r + t - 1, c + s - 1, k] * w[n, t, s, k] )
+//   x [B, H, W, C] (C % 64 == 0), w [N, 3, 3, C] (the channels_last layout of an [N, C, 3, 3] weight), y [B, H, W, N]
+//
+// A workgroup (4 waves) owns 4 output rows x 32 columns x NB*32 output channels of one image; wave i owns row i, lane & 31 a
+// column.  Per 64-channel slab of the input the (4 + 2) x (32 + 2) pixel halo is staged in LDS once -- zero outside the
+// image: this IS the padding -- and serves all nine taps as shifted reads: tap (t, s) of output pixel (i, j) is halo pixel
+// (i + t, j + s).  The weights of one tap row (3 taps x NB*32 channels x 64 k) follow through LDS.  Products are issued
+// transposed, Y^T[n][pixel] = W[n][:] . X[pixel][:], with v_mfma_f32_32x32x16_bf16 (fragment conventions of token_gemm.hip /
+// attn.hip, validated there): a lane's accumulator quad holds four consecutive output channels of ITS pixel, so shift, ReLU and
+// the bf16 rounding happen in registers and leave as 8-byte stores.  LDS rows are padded to 72 bf16 (36 dwords: the 16 rows
+// of a ds_read_b128 lane group fall on distinct bank quads).
+// Algorithmic bytes = 2 B H W (C + N) + 18 N C;  flops = 18 B H W C N.  MFMA-bound by design; this first version is
+// single-buffered (a barrier pair per tap row), i.e. its ceiling is the LDS fill, not the matrix cores.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mdetr_wave.h>
+
+#include "conv3x3.h"
+
+namespace mdetr {
+namespace {
+
+constexpr int kWavesC = 4;               // = output rows per workgroup
+constexpr int kTileW = 32;               // output columns per workgroup (one per lane & 31)
+constexpr int kSlab = 64;                // input channels per LDS slab
+constexpr int kPad = kSlab + 8;          // 72 bf16 per LDS row
+constexpr int kHaloH = kWavesC + 2, kHaloW = kTileW + 2;
+
+struct ConvDims {
+    int B, H, W, C, N;
+    int tiles_x, tiles_y;                // column / row tiles per image
+};
+
+template <int NB, bool RELU>
+__global__ __launch_bounds__(kWavesC * 64)
+void conv3x3_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, const float *__restrict__ shift,
+                    __bf16 *__restrict__ y, const ConvDims d)
+{
+    MDETR_DYNAMIC_LDS(unsigned char, conv_smem);
+    __bf16 *halo = reinterpret_cast<__bf16 *>(conv_smem);                    // [kHaloH][kHaloW][kPad]
+    __bf16 *wts = halo + kHaloH * kHaloW * kPad;                            // [3 taps][NB*32][kPad]
+    float *shift_s = reinterpret_cast<float *>(wts + 3 * NB * 32 * kPad);    // [NB*32]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+    int t = blockIdx.x;
+    const int tx = t % d.tiles_x; t /= d.tiles_x;
+    const int ty = t % d.tiles_y; const int b = t / d.tiles_y;
+    const int r0 = ty * kWavesC, c0 = tx * kTileW, n0 = blockIdx.y * NB * 32;
+    const __bf16 *xb = x + static_cast<int64_t>(b) * d.H * d.W * d.C;
+
+    for (int i = threadIdx.x; i < NB * 32; i += kWavesC * 64) shift_s[i] = (shift && n0 + i < d.N) ? shift[n0 + i] : 0.f;
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+
+    for (int k0 = 0; k0 < d.C; k0 += kSlab) {
+        __syncthreads();                                                    // the previous slab's reads are done
+        // ---- halo of this channel slab: (4 + 2) x (32 + 2) pixels x 64 channels in 16-byte pieces, zero outside the image
+        for (int p = threadIdx.x; p < kHaloH * kHaloW * (kSlab / 8); p += kWavesC * 64) {
+            const int piece = p & 7, pix = p >> 3;
+            const int hr = pix / kHaloW, hc = pix - hr * kHaloW;
+            const int r = r0 + hr - 1, c = c0 + hc - 1;
+            bf16x8 v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = static_cast<__bf16>(0.f);
+            if (r >= 0 && r < d.H && c >= 0 && c < d.W)
+                v = *reinterpret_cast<const bf16x8 *>(xb + (static_cast<int64_t>(r) * d.W + c) * d.C + k0 + piece * 8);
+            *reinterpret_cast<bf16x8 *>(halo + pix * kPad + piece * 8) = v;
+        }
+        for (int tr = 0; tr < 3; ++tr) {
+            if (tr) __syncthreads();                                        // the previous tap row's weight reads are done
+            // ---- weights of tap row tr: [s][n][64 k] <- w[n0 + n][tr][s][k0 .. k0 + 64)
+            for (int p = threadIdx.x; p < 3 * NB * 32 * (kSlab / 8); p += kWavesC * 64) {
+                const int piece = p & 7, row = p >> 3;                      // row = s * NB*32 + n
+                const int s = row / (NB * 32), n = row - s * (NB * 32);
+                bf16x8 v;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = static_cast<__bf16>(0.f);
+                if (n0 + n < d.N)
+                    v = *reinterpret_cast<const bf16x8 *>(w + ((static_cast<int64_t>(n0 + n) * 3 + tr) * 3 + s) * d.C + k0 + piece * 8);
+                *reinterpret_cast<bf16x8 *>(wts + row * kPad + piece * 8) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const __bf16 *hp = halo + ((wave + tr) * kHaloW + col + s) * kPad;      // input pixel of tap (tr, s) for this lane's output pixel
+#pragma unroll
+                for (int ks = 0; ks < kSlab / 16; ++ks) {
+                    const bf16x8 xv = *reinterpret_cast<const bf16x8 *>(hp + ks * 16 + half * 8);       // B operand: this lane's pixel, 8 k
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wts + (s * NB * 32 + nb * 32 + col) * kPad + ks * 16 + half * 8);
+                        acc[nb] = mfma_bf16(wv, xv, acc[nb]);               // Y^T[n][pixel]
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane = pixel (row wave, column lane & 31); register quad g of block nb = channels 32 nb + 8 g + 4 half + 0..3
+    const int r = r0 + wave, c = c0 + col;
+    if (r < d.H && c < d.W) {
+        __bf16 *yp = y + ((static_cast<int64_t>(b) * d.H + r) * d.W + c) * d.N + n0 + 4 * half;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nn = nb * 32 + 8 * g + 4 * half;
+                if (n0 + nn < d.N) {                                        // N % 32 == 0: a quad is in or out as a whole
+                    bf16x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[nb][4 * g + i] + shift_s[nn + i];
+                        if (RELU) v = v > 0.f ? v : 0.f;
+                        o[i] = static_cast<__bf16>(v);
+                    }
+                    *reinterpret_cast<bf16x4 *>(yp + nb * 32 + 8 * g) = o;
+                }
+            }
+    }
+}
+
+template <int NB, bool RELU>
+hipError_t launch(const void *x, const void *w, const float *shift, void *y, const ConvDims &d, hipStream_t st)
+{
+    constexpr size_t lds = static_cast<size_t>(kHaloH) * kHaloW * kPad * 2 + 3 * NB * 32 * kPad * 2 + NB * 32 * 4;
+    static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
+    auto kern = conv3x3_kernel<NB, RELU>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const dim3 grid(static_cast<unsigned>(d.B * d.tiles_x * d.tiles_y), static_cast<unsigned>((d.N + NB * 32 - 1) / (NB * 32)));
+    hipLaunchKernelGGL(kern, grid, dim3(kWavesC * 64), lds, st, static_cast<const __bf16 *>(x), static_cast<const __bf16 *>(w), shift,
+                       static_cast<__bf16 *>(y), d);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool conv3x3_supported(int B, int H, int W, int C, int N, const void *x, const void *w, const void *y)
+{
+    const auto al = [](const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+    return B > 0 && H > 0 && W > 0 && C > 0 && C % 64 == 0 && N > 0 && N % 32 == 0 && al(x, 16) && al(w, 16) && al(y, 8) &&
+           static_cast<int64_t>(B) * ((H + 3) / 4) * ((W + 31) / 32) < (1ll << 31);
+}
+
+hipError_t conv3x3_launch(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N, bool relu,
+                          hipStream_t st)
+{
+    ConvDims d{B, H, W, C, N, (W + kTileW - 1) / kTileW, (H + kWavesC - 1) / kWavesC};
+    // 128 output channels per workgroup where the layer has them (the halo is then read once per 128 channels); 64 for the
+    // 64-channel stage
+    if (N >= 128) return relu ? launch<4, true>(x, w, shift, y, d, st) : launch<4, false>(x, w, shift, y, d, st);
+    if (N >= 64) return relu ? launch<2, true>(x, w, shift, y, d, st) : launch<2, false>(x, w, shift, y, d, st);
+    return relu ? launch<1, true>(x, w, shift, y, d, st) : launch<1, false>(x, w, shift, y, d, st);
+}
+
+}  // namespace mdetr

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..utils.misc import NestedTensor, mark_no_padding
-from .. import bias_act_ext
+from .. import bias_act_ext, conv3x3_ext
 from .linear import pointwise_conv, pointwise_eligible, pointwise_relu_fusable
 from .position_encoding import build_position_encoding
 
@@ -144,6 +144,10 @@ def conv_bn(x, conv, bn, relu):
             if relu and pointwise_relu_fusable(x, w, b):
                 return pointwise_conv(x, w, b, relu=True)            # ReLU in the GEMM's epilogue
             x = pointwise_conv(x, w, b)
+        elif conv3x3_ext.ENABLED and conv3x3_ext.supported(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
+            # stride-1 3x3: implicit GEMM with LDS im2col, shift and ReLU in its epilogue (csrc/conv3x3.hip); forward and
+            # input gradient on the kernel, weight gradient with the library
+            return conv3x3_ext.conv3x3(x, w, shift, relu=relu)
         elif relu and bias_act_ext.ENABLED and (x.is_cuda or bias_act_ext._backend is not None):
             # the shift and the ReLU in one pass behind the library convolution (csrc/bias_act.hip) instead of the
             # library's own bias kernel plus a clamp

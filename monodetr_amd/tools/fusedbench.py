@@ -96,6 +96,20 @@ def main():
     res["token_gemm_layer1_256to64_relu"] = row(timeit(lambda: token_gemm_ext.token_gemm(x256, w_dn, b_dn, relu=True), a.iters), byts)
     res["library_gemm_layer1_256to64_relu"] = row(timeit(lambda: F.relu_(F.linear(x256, w_dn, b_dn)), a.iters), byts)
 
+    # ---- 3x3 convolutions of the backbone: csrc/conv3x3.hip (shift + ReLU inside) vs the library convolution + its tail ----
+    from monodetr_amd import conv3x3_ext
+    for tag, (Cc, Hc, Wc) in (("layer1", (64, 96, 320)), ("layer2", (128, 48, 160)), ("layer3", (256, 24, 80)), ("layer4", (512, 12, 40))):
+        xc = torch.randn(8, Cc, Hc, Wc, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wc = (torch.randn(Cc, Cc, 3, 3, device=dev) / (3.0 * Cc ** 0.5)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        sh = torch.randn(Cc, device=dev)
+        shb = sh.to(torch.bfloat16)
+        flops = 18.0 * 8 * Hc * Wc * Cc * Cc
+        byts = e * (2 * 8 * Hc * Wc * Cc + 9 * Cc * Cc)
+        for name, f in (("conv3x3_" + tag + "_kernel", lambda: conv3x3_ext._launch(xc, conv3x3_ext._ohwi(wc), sh, True)),
+                        ("conv3x3_" + tag + "_library", lambda: F.relu_(F.conv2d(xc, wc, shb, padding=1)))):
+            ms = timeit(f, a.iters)
+            res[name] = dict(row(ms, byts), TFLOPs=round(flops / ms / 1e9, 1), frac_mfma=round(flops / (ms * 1e-3) / 2.5e15, 4))
+
     # ---- fused AdamW -----------------------------------------------------------------------------------------------
     from monodetr_amd.helpers.optimizer_helper import AdamW, FusedAdamW
     for tag, cls in (("fused", FusedAdamW), ("foreach", AdamW)):

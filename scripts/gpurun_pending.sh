@@ -17,9 +17,10 @@ run "MDETR_FUSED_LN=1"
 run "MDETR_FUSED_EPILOGUE=1"
 run "MDETR_GEMM_RELU=1"
 run "MDETR_FUSED_EPILOGUE=1 MDETR_GEMM_RELU=1"
+run "MDETR_CONV3X3=1"
 run "MDETR_BENCH_MIOPEN_FIND=1"
 run "MDETR_BENCH_TUNABLEOP=1"
-run "MDETR_FUSED_LOSSES=1 MDETR_FUSED_ADAMW=1 MDETR_MSDA_PROLOGUE=1 MDETR_TOKEN_GEMM=1 MDETR_MSDA_BF16=1 MDETR_FUSED_LN=1 MDETR_FUSED_EPILOGUE=1 MDETR_GEMM_RELU=1"
+run "MDETR_FUSED_LOSSES=1 MDETR_FUSED_ADAMW=1 MDETR_MSDA_PROLOGUE=1 MDETR_TOKEN_GEMM=1 MDETR_MSDA_BF16=1 MDETR_FUSED_LN=1 MDETR_FUSED_EPILOGUE=1 MDETR_GEMM_RELU=1 MDETR_CONV3X3=1"
 env MDETR_BENCH_AUTOTUNE=0 MDETR_FUSED_LOSSES=1 MDETR_FUSED_ADAMW=1 MDETR_MSDA_PROLOGUE=1 python bench.py --precision fp32 --no-cpu-baseline 2>/dev/null | val "fp32, fused losses + adamw + prologue"
 python -m monodetr_amd.tools.prepbench 2>&1 | tail -1 | tee $O/prepbench_fp32.json
 python -m monodetr_amd.tools.prepbench --dtype bf16 2>&1 | tail -1 | tee $O/prepbench_bf16.json

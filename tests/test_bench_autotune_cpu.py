@@ -25,7 +25,7 @@ def clean_env(monkeypatch):
 def test_candidate_sets():
     bf = bench.probe_configs("bf16")
     assert bf[0] == [] and set(bf[-1]) == set(bench.AUTOTUNE_SWITCHES) and all(set(a) < set(b) for a, b in zip(bf, bf[1:]))   # nested
-    assert not {"MDETR_TOKEN_GEMM", "MDETR_MSDA_BF16"} & set(sum(bench.probe_configs("fp32"), []))                          # bf16-body kernels
+    assert not {"MDETR_TOKEN_GEMM", "MDETR_MSDA_BF16", "MDETR_CONV3X3"} & set(sum(bench.probe_configs("fp32"), []))                          # bf16-body kernels
     # the roofline accounting follows the operator's element types
     f32, mixed = bench.msda_algorithmic_bytes(8, 10200, True), bench.msda_algorithmic_bytes(8, 10200, True, mixed=True)
     assert f32 - mixed == 2 * 8 * 10200 * 8 * 32 * 2                                        # value and grad_out at half width
@@ -59,7 +59,7 @@ def test_autotune_runs_one_probe_caches_per_box_and_reports(tmp_path):
         return [{"switches": sorted(c), "losses": [30.0, 29.0, 28.0], "ms": 38.0 - 1.5 * len(c)} for c in configs]
     cache = str(tmp_path / "tune.json")
     chosen, report = bench.autotune(args(), 1, 0, runner=runner, cache_path=cache)
-    assert chosen == sorted(bench.AUTOTUNE_SWITCHES) and report["source"] == "probe" and len(report["candidates"]) == 10 and calls[0][0] == calls[0][-1] == []
+    assert chosen == sorted(bench.AUTOTUNE_SWITCHES) and report["source"] == "probe" and len(report["candidates"]) == 11 and calls[0][0] == calls[0][-1] == []
     chosen2, report2 = bench.autotune(args(), 1, 0, runner=runner, cache_path=cache)
     assert chosen2 == chosen and report2["source"] == "cache" and len(calls) == 1
     # another precision is another key

@@ -1,0 +1,104 @@
+"""csrc/conv3x3.hip -- implicit-GEMM 3x3 convolution (LDS im2col, MFMA, shift + ReLU epilogue) -- with its launcher and
+C-ABI entry on the HIP-on-CPU shim, through the product's autograd wrapper (monodetr_amd/conv3x3_ext.py), against
+F.conv2d evaluated in fp32 on the same bf16 inputs: ragged tiles (H % 4, W % 32), several channel slabs, every
+output-block variant, borders (the zero halo is the padding), the input gradient through the mirrored-tap weights."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import native_emul
+
+
+@pytest.fixture()
+def ext():
+    from monodetr_amd import conv3x3_ext
+    conv3x3_ext._backend = native_emul.lib()
+    yield conv3x3_ext
+    conv3x3_ext._backend = None
+
+
+def close(got, want, what):
+    err = (got.float() - want.float()).abs().max().item()
+    assert err <= 1.2e-2 * max(1.0, want.float().abs().max().item()), (what, err)      # bf16 output: half an ulp of the largest value + accumulation order
+
+
+@pytest.mark.parametrize("B,H,W,C,N,relu,use_shift", [
+    (2, 5, 37, 64, 64, True, True),          # NB = 2; two column tiles (the second 5 wide), two row tiles (the second 1 high)
+    (1, 4, 32, 128, 128, False, True),       # exactly one tile, two channel slabs, NB = 4
+    (1, 9, 40, 64, 160, True, False),        # NB = 4 with a second output block of 32 live channels; W = 40 as layer4
+    (3, 3, 3, 64, 32, True, True),           # NB = 1; an image smaller than the tile: every tap crosses a border
+    (1, 6, 80, 192, 96, False, False),       # three slabs, N = 96: NB = 2, two output blocks (the second half empty)
+])
+def test_conv3x3_matches_conv2d(ext, B, H, W, C, N, relu, use_shift):
+    g = torch.Generator().manual_seed(B * 1000 + H * W + C + N)
+    x = torch.randn(B, C, H, W, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(N, C, 3, 3, generator=g) / (3.0 * C ** 0.5)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    shift = torch.randn(N, generator=g) * 0.5 if use_shift else None
+    dy = torch.randn(B, N, H, W, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert ext.supported(x, w)
+    y = ext.conv3x3(x, w, shift, relu=relu)
+    assert y.shape == (B, N, H, W) and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(dy)
+    got = (y.detach(), x.grad.clone(), w.grad.clone())
+    x.grad = w.grad = None
+    ref = F.conv2d(x.float(), w.float(), shift, padding=1)
+    ref = F.relu(ref) if relu else ref
+    # the wrapper's backward sees the bf16-rounded output (ReLU mask) and bf16 gradients: mirror that
+    mask = (y.detach() > 0) if relu else torch.ones_like(ref, dtype=torch.bool)
+    gx, gw = torch.autograd.grad(F.conv2d(x.float(), w.float(), None, padding=1), (x, w), dy.float() * mask)
+    close(got[0], ref, "y")
+    close(got[1], gx, "dx")
+    close(got[2], gw, "dw")
+
+
+def test_refusals_and_fallback_of_the_input_gradient(ext):
+    x = torch.randn(1, 64, 4, 4).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(32, 64, 3, 3).to(torch.bfloat16)
+    assert ext.supported(x, w)
+    assert not ext.supported(x.float(), w.float()) and not ext.supported(x, w, stride=(2, 2)) and not ext.supported(x, w, padding=(0, 0))
+    assert not ext.supported(x.contiguous(), w)                                   # NCHW-contiguous
+    assert not ext.supported(torch.randn(1, 48, 4, 4).to(torch.bfloat16).contiguous(memory_format=torch.channels_last), w[:, :48].contiguous())
+    with pytest.raises(RuntimeError):
+        ext.conv3x3(x.float(), w.float())
+    with pytest.raises(RuntimeError):
+        ext.conv3x3(x, w, torch.zeros(32, requires_grad=True))
+    # N = 32 is not a multiple of 64: the input gradient (a convolution with C and N swapped) takes the library
+    xr = x.clone().requires_grad_(True)
+    y = ext.conv3x3(xr, w, None, relu=False)
+    y.float().square().sum().backward()
+    xf = x.float().requires_grad_(True)
+    F.conv2d(xf, w.float(), None, padding=1).to(torch.bfloat16).float().square().sum().backward()
+    close(xr.grad, xf.grad, "dx through the library")
+    lib = native_emul.lib()
+    assert lib.mdetr_conv3x3_forward(x.data_ptr(), w.data_ptr(), None, x.data_ptr(), 1, 4, 4, 48, 32, 0, -1, None) != 0       # C % 64
+    assert lib.mdetr_conv3x3_forward(x.data_ptr(), w.data_ptr(), None, x.data_ptr(), 1, 4, 4, 64, 40, 0, -1, None) != 0       # N % 32
+    assert lib.mdetr_conv3x3_forward(None, None, None, None, 0, 4, 4, 64, 32, 0, -1, None) == 0                                # empty batch
+
+
+def test_bottleneck_takes_the_kernel_for_its_3x3_and_agrees_with_the_library_path(ext):
+    """The call site (backbone.conv_bn): a bf16 channels_last bottleneck, kernel on vs off -- output, input gradient and
+    every weight gradient."""
+    from monodetr_amd.monodetr.backbone import Bottleneck, FrozenBatchNorm2d
+    torch.manual_seed(5)
+    block = Bottleneck(256, 64).to(memory_format=torch.channels_last)
+    for m in block.modules():
+        if isinstance(m, FrozenBatchNorm2d):
+            m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.3); m.running_mean.normal_(0, 0.3); m.running_var.uniform_(0.5, 2.0)
+    block = block.to(torch.bfloat16)
+    x = torch.randn(2, 256, 6, 40).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(2, 256, 6, 40).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    calls, real, res = [], ext.conv3x3, {}
+    for on in (False, True):
+        ext.ENABLED = on
+        ext.conv3x3 = lambda *a, **k: (calls.append(on), real(*a, **k))[1]
+        try:
+            xi = x.clone().requires_grad_(True)
+            block.zero_grad()
+            y = block(xi)
+            y.backward(dy)
+            res[on] = [y.detach(), xi.grad] + [p.grad.clone() for p in block.parameters()]
+        finally:
+            ext.ENABLED, ext.conv3x3 = False, real
+    assert calls == [True]                                           # conv2 only: conv1 / conv3 are 1x1
+    for a, b in zip(res[False], res[True]):
+        close(b, a, "bottleneck")

@@ -615,3 +615,42 @@ def test_training_step_with_fused_tails_matches_default(monkeypatch, precision):
     for names, t in traj.items():
         for a, b in zip(traj[()], t):
             assert abs(a - b) <= (2e-2 if precision == "bf16" else 2e-4) * abs(a), traj
+
+
+# ---- implicit-GEMM 3x3 convolution (csrc/conv3x3.hip) ----------------------------------------------------------------
+@pytest.mark.parametrize("B,H,W,C,N,relu", [(8, 96, 320, 64, 64, True), (8, 48, 160, 128, 128, True), (8, 24, 80, 256, 256, True),
+                                             (8, 12, 40, 512, 512, False), (2, 13, 45, 64, 96, True)])
+def test_conv3x3_kernel_matches_the_library_convolution(B, H, W, C, N, relu):
+    from monodetr_amd import conv3x3_ext
+    g = torch.Generator(device="cuda").manual_seed(C + N + H)
+    x = torch.randn(B, C, H, W, generator=g, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(N, C, 3, 3, generator=g, device="cuda") / (3.0 * C ** 0.5)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    shift = torch.randn(N, generator=g, device="cuda") * 0.5
+    dy = torch.randn(B, N, H, W, generator=g, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = conv3x3_ext.conv3x3(x, w, shift, relu=relu)
+    y.backward(dy)
+    got = (y.detach(), x.grad.clone(), w.grad.clone())
+    x.grad = w.grad = None
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), shift, padding=1)            # fp32 on the same bf16 inputs
+    ref = torch.relu(ref) if relu else ref
+    mask = (y.detach() > 0) if relu else torch.ones_like(ref, dtype=torch.bool)
+    gx, gw = torch.autograd.grad(torch.nn.functional.conv2d(x.float(), w.float(), None, padding=1), (x, w), dy.float() * mask)
+    for name, a, r in zip(("y", "dx", "dw"), got, (ref, gx, gw)):
+        lim = 1.2e-2 * max(1.0, r.abs().max().item()) * (4 if name == "dw" else 1)      # dw: the library's bf16 split-K sums
+        assert (a.float() - r).abs().max().item() <= lim, name
+
+
+def test_training_step_with_the_conv3x3_kernel_matches_default():
+    import bench
+    from model_init import disable_dropout_
+    dev = torch.device("cuda", 0)
+    traj = {}
+    try:
+        for names in ((), ("MDETR_CONV3X3",)):
+            step = bench.TrainStep(dev, 2, "bf16", size=(96, 320), switches=names)
+            disable_dropout_(step.raw_model)
+            traj[names] = [float(step()) for _ in range(3)]
+    finally:
+        bench.apply_switches(set())
+    for a, b in zip(traj[()], traj[("MDETR_CONV3X3",)]):
+        assert abs(a - b) <= 2e-2 * abs(a), traj
