@@ -17,8 +17,9 @@
 // attn.hip, validated there): a lane's accumulator quad holds four consecutive output channels of ITS pixel, so shift, ReLU and
 // the bf16 rounding happen in registers and leave as 8-byte stores.  LDS rows are padded to 72 bf16 (36 dwords: the 16 rows
 // of a ds_read_b128 lane group fall on distinct bank quads).
-// Algorithmic bytes = 2 B H W (C + N) + 18 N C;  flops = 18 B H W C N.  MFMA-bound by design; this first version is
-// single-buffered (a barrier pair per tap row), i.e. its ceiling is the LDS fill, not the matrix cores.
+// The next stage's global loads are staged in registers while the current stage's products run (one LDS buffer).
+// Algorithmic bytes = 2 B H W (C + N) + 18 N C;  flops = 18 B H W C N.  MFMA-bound by design (LDS-read-bound in this first
+// version: 5 ds_read_b128 per 4 MFMAs).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -64,45 +65,78 @@ void conv3x3_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
 
-    for (int k0 = 0; k0 < d.C; k0 += kSlab) {
-        __syncthreads();                                                    // the previous slab's reads are done
-        // ---- halo of this channel slab: (4 + 2) x (32 + 2) pixels x 64 channels in 16-byte pieces, zero outside the image
-        for (int p = threadIdx.x; p < kHaloH * kHaloW * (kSlab / 8); p += kWavesC * 64) {
-            const int piece = p & 7, pix = p >> 3;
+    // Staging registers: the NEXT stage's weights (and, at a slab boundary, halo) are requested from global memory before
+    // the current stage's products are issued and written to LDS after them, so a whole stage of loads is in flight during
+    // the matrix work (one LDS buffer, two barriers per stage).  Stage q = (slab q / 3, tap row q % 3).
+    constexpr int WP = 3 * NB * 32 * (kSlab / 8) / (kWavesC * 64);          // weight pieces per thread (3 NB)
+    constexpr int HP = (kHaloH * kHaloW * (kSlab / 8) + kWavesC * 64 - 1) / (kWavesC * 64);     // halo pieces per thread (7)
+    bf16x8 wreg[WP], hreg[HP];
+    auto fetch_w = [&](int k0, int tr) {                                    // [s][n][64 k] <- w[n0 + n][tr][s][k0 .. k0 + 64)
+#pragma unroll
+        for (int j = 0; j < WP; ++j) {
+            const int p = threadIdx.x + j * kWavesC * 64, piece = p & 7, row = p >> 3;      // row = s * NB*32 + n
+            const int s = row / (NB * 32), n = row - s * (NB * 32);
+            bf16x8 v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = static_cast<__bf16>(0.f);
+            if (n0 + n < d.N)
+                v = *reinterpret_cast<const bf16x8 *>(w + ((static_cast<int64_t>(n0 + n) * 3 + tr) * 3 + s) * d.C + k0 + piece * 8);
+            wreg[j] = v;
+        }
+    };
+    auto fetch_h = [&](int k0) {                                            // (4 + 2) x (32 + 2) pixels x 64 channels, zero outside the image
+#pragma unroll
+        for (int j = 0; j < HP; ++j) {
+            const int p = threadIdx.x + j * kWavesC * 64, piece = p & 7, pix = p >> 3;
             const int hr = pix / kHaloW, hc = pix - hr * kHaloW;
             const int r = r0 + hr - 1, c = c0 + hc - 1;
             bf16x8 v;
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = static_cast<__bf16>(0.f);
-            if (r >= 0 && r < d.H && c >= 0 && c < d.W)
+            if (pix < kHaloH * kHaloW && r >= 0 && r < d.H && c >= 0 && c < d.W)
                 v = *reinterpret_cast<const bf16x8 *>(xb + (static_cast<int64_t>(r) * d.W + c) * d.C + k0 + piece * 8);
-            *reinterpret_cast<bf16x8 *>(halo + pix * kPad + piece * 8) = v;
+            hreg[j] = v;
         }
-        for (int tr = 0; tr < 3; ++tr) {
-            if (tr) __syncthreads();                                        // the previous tap row's weight reads are done
-            // ---- weights of tap row tr: [s][n][64 k] <- w[n0 + n][tr][s][k0 .. k0 + 64)
-            for (int p = threadIdx.x; p < 3 * NB * 32 * (kSlab / 8); p += kWavesC * 64) {
-                const int piece = p & 7, row = p >> 3;                      // row = s * NB*32 + n
-                const int s = row / (NB * 32), n = row - s * (NB * 32);
-                bf16x8 v;
+    };
+    auto store_w = [&]() {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = static_cast<__bf16>(0.f);
-                if (n0 + n < d.N)
-                    v = *reinterpret_cast<const bf16x8 *>(w + ((static_cast<int64_t>(n0 + n) * 3 + tr) * 3 + s) * d.C + k0 + piece * 8);
-                *reinterpret_cast<bf16x8 *>(wts + row * kPad + piece * 8) = v;
-            }
-            __syncthreads();
+        for (int j = 0; j < WP; ++j) {
+            const int p = threadIdx.x + j * kWavesC * 64;
+            *reinterpret_cast<bf16x8 *>(wts + (p >> 3) * kPad + (p & 7) * 8) = wreg[j];
+        }
+    };
+    auto store_h = [&]() {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const __bf16 *hp = halo + ((wave + tr) * kHaloW + col + s) * kPad;      // input pixel of tap (tr, s) for this lane's output pixel
+        for (int j = 0; j < HP; ++j) {
+            const int p = threadIdx.x + j * kWavesC * 64;
+            if (p < kHaloH * kHaloW * (kSlab / 8)) *reinterpret_cast<bf16x8 *>(halo + (p >> 3) * kPad + (p & 7) * 8) = hreg[j];
+        }
+    };
+
+    const int stages = d.C / kSlab * 3;
+    fetch_h(0);
+    fetch_w(0, 0);
+    for (int q = 0; q < stages; ++q) {
+        const int tr = q % 3;
+        __syncthreads();                                                    // the previous stage's LDS reads are done
+        if (tr == 0) store_h();
+        store_w();
+        if (q + 1 < stages) {                                               // in flight during the products below
+            const int nq = q + 1, ntr = nq % 3, nk0 = nq / 3 * kSlab;
+            if (ntr == 0) fetch_h(nk0);
+            fetch_w(nk0, ntr);
+        }
+        __syncthreads();
 #pragma unroll
-                for (int ks = 0; ks < kSlab / 16; ++ks) {
-                    const bf16x8 xv = *reinterpret_cast<const bf16x8 *>(hp + ks * 16 + half * 8);       // B operand: this lane's pixel, 8 k
+        for (int s = 0; s < 3; ++s) {
+            const __bf16 *hp = halo + ((wave + tr) * kHaloW + col + s) * kPad;          // input pixel of tap (tr, s) for this lane's output pixel
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wts + (s * NB * 32 + nb * 32 + col) * kPad + ks * 16 + half * 8);
-                        acc[nb] = mfma_bf16(wv, xv, acc[nb]);               // Y^T[n][pixel]
-                    }
+            for (int ks = 0; ks < kSlab / 16; ++ks) {
+                const bf16x8 xv = *reinterpret_cast<const bf16x8 *>(hp + ks * 16 + half * 8);           // B operand: this lane's pixel, 8 k
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wts + (s * NB * 32 + nb * 32 + col) * kPad + ks * 16 + half * 8);
+                    acc[nb] = mfma_bf16(wv, xv, acc[nb]);                   // Y^T[n][pixel]
                 }
             }
         }
