@@ -39,6 +39,9 @@ constexpr int kHaloH = kWavesC + 2, kHaloW = kTileW + 2;
 struct ConvDims {
     int B, H, W, C, N;
     int tiles_x, tiles_y;                // column / row tiles per image
+    int tiles;                           // B * tiles_x * tiles_y
+    int ngroups;                         // output-channel groups of NB*32
+    int xcd_per;                         // 8 / ngroups when that is whole (XCD-aware numbering below), else 0
 };
 
 template <int NB, bool RELU>
@@ -51,10 +54,22 @@ void conv3x3_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, 
     __bf16 *wts = halo + kHaloH * kHaloW * kPad;                            // [3 taps][NB*32][kPad]
     float *shift_s = reinterpret_cast<float *>(wts + 3 * NB * 32 * kPad);    // [NB*32]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
-    int t = blockIdx.x;
+    // Workgroup id -> (output-channel group, pixel tile).  The dispatcher deals consecutive workgroups round-robin to the 8
+    // XCDs, each with its own L2: with ngroups in {1, 2, 4, 8} the group is made a function of id % 8, so an XCD only ever
+    // touches the weights of 8 / ngroups ... of ONE group (1.2 MB of the 4.7 MB at 512 channels) instead of all of them.
+    int group, t;
+    if (d.xcd_per > 0) {
+        const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+        group = xcd % d.ngroups;
+        t = within * d.xcd_per + xcd / d.ngroups;
+    } else {
+        group = blockIdx.x % d.ngroups;
+        t = blockIdx.x / d.ngroups;
+    }
+    if (t >= d.tiles) return;                                               // padding of the XCD numbering (whole workgroup, before any barrier)
     const int tx = t % d.tiles_x; t /= d.tiles_x;
     const int ty = t % d.tiles_y; const int b = t / d.tiles_y;
-    const int r0 = ty * kWavesC, c0 = tx * kTileW, n0 = blockIdx.y * NB * 32;
+    const int r0 = ty * kWavesC, c0 = tx * kTileW, n0 = group * NB * 32;
     const __bf16 *xb = x + static_cast<int64_t>(b) * d.H * d.W * d.C;
 
     for (int i = threadIdx.x; i < NB * 32; i += kWavesC * 64) shift_s[i] = (shift && n0 + i < d.N) ? shift[n0 + i] : 0.f;
@@ -178,9 +193,13 @@ hipError_t launch(const void *x, const void *w, const float *shift, void *y, con
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const dim3 grid(static_cast<unsigned>(d.B * d.tiles_x * d.tiles_y), static_cast<unsigned>((d.N + NB * 32 - 1) / (NB * 32)));
-    hipLaunchKernelGGL(kern, grid, dim3(kWavesC * 64), lds, st, static_cast<const __bf16 *>(x), static_cast<const __bf16 *>(w), shift,
-                       static_cast<__bf16 *>(y), d);
+    ConvDims g = d;
+    g.tiles = d.B * d.tiles_x * d.tiles_y;
+    g.ngroups = (d.N + NB * 32 - 1) / (NB * 32);
+    g.xcd_per = (g.ngroups <= 8 && 8 % g.ngroups == 0) ? 8 / g.ngroups : 0;
+    const int64_t blocks = g.xcd_per ? 8ll * ((g.tiles + g.xcd_per - 1) / g.xcd_per) : static_cast<int64_t>(g.tiles) * g.ngroups;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kWavesC * 64), lds, st, static_cast<const __bf16 *>(x),
+                       static_cast<const __bf16 *>(w), shift, static_cast<__bf16 *>(y), g);
     return hipGetLastError();
 }
 
@@ -190,13 +209,13 @@ bool conv3x3_supported(int B, int H, int W, int C, int N, const void *x, const v
 {
     const auto al = [](const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
     return B > 0 && H > 0 && W > 0 && C > 0 && C % 64 == 0 && N > 0 && N % 32 == 0 && al(x, 16) && al(w, 16) && al(y, 8) &&
-           static_cast<int64_t>(B) * ((H + 3) / 4) * ((W + 31) / 32) < (1ll << 31);
+           static_cast<int64_t>(B) * ((H + 3) / 4) * ((W + 31) / 32) * ((N + 31) / 32) < (1ll << 30);
 }
 
 hipError_t conv3x3_launch(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N, bool relu,
                           hipStream_t st)
 {
-    ConvDims d{B, H, W, C, N, (W + kTileW - 1) / kTileW, (H + kWavesC - 1) / kWavesC};
+    ConvDims d{B, H, W, C, N, (W + kTileW - 1) / kTileW, (H + kWavesC - 1) / kWavesC, 0, 0, 0};
     // 128 output channels per workgroup where the layer has them (the halo is then read once per 128 channels); 64 for the
     // 64-channel stage
     if (N >= 128) return relu ? launch<4, true>(x, w, shift, y, d, st) : launch<4, false>(x, w, shift, y, d, st);

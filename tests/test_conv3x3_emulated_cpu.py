@@ -28,6 +28,8 @@ def close(got, want, what):
     (1, 9, 40, 64, 160, True, False),        # NB = 4 with a second output block of 32 live channels; W = 40 as layer4
     (3, 3, 3, 64, 32, True, True),           # NB = 1; an image smaller than the tile: every tap crosses a border
     (1, 6, 80, 192, 96, False, False),       # three slabs, N = 96: NB = 2, two output blocks (the second half empty)
+    (1, 4, 8, 64, 384, False, True),         # three output-channel groups: not a divisor of 8, the plain workgroup numbering
+    (1, 9, 32, 64, 512, True, True),         # four groups x three pixel tiles: the XCD numbering is padded to 16 workgroups
 ])
 def test_conv3x3_matches_conv2d(ext, B, H, W, C, N, relu, use_shift):
     g = torch.Generator().manual_seed(B * 1000 + H * W + C + N)
