@@ -452,6 +452,21 @@ class TrainStep:
         return total
 
 
+def time_default_path(device, args, prime=8, warm=6, timed=20):
+    """images/sec of the default path (no optional kernel) -- what `value` would be without the start-up probe."""
+    step = TrainStep(device, args.batch, args.precision, switches=())
+    for _ in range(prime + warm):
+        step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        step()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / timed
+    return {"value": round(args.batch / dt, 2), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3), "steps": timed,
+            "warmup": prime + warm, "switches": []}
+
+
 def bind_to_gpu_numa_node(local_rank):
     """Pin this process (and the threads it creates later: autograd workers, RCCL proxies) to the CPUs
     of the NUMA node the GPU hangs off -- what `numactl --cpunodebind` does per rank in a production
@@ -697,6 +712,13 @@ def main():
         line["config"]["switches"] = sorted(step.switches)
         if tune_report is not None:
             line["config"]["autotune"] = tune_report
+        if world == 1 and chosen and not use_graph:
+            # the probe switched optional kernels on: time the GPU-validated default path as well, in this process and the
+            # same way (shorter), so that the line carries both numbers
+            try:
+                line["default_path"] = time_default_path(device, args)
+            except Exception as e:                                  # must not cost the measured line
+                line["default_path"] = {"value": None, "error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             if bound:
                 os.sched_setaffinity(0, bound[1])                   # the CPU baseline gets every core again

@@ -189,7 +189,9 @@ def test_bench_main_composes_its_json_line(monkeypatch, capsys):
         assert line["config"]["switches"] == sorted(chosen or []) and ("autotune" in line["config"]) == bool(chosen)
         roof = line["roofline"]
         assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / 8000.0) < 1e-3
+        assert ("default_path" in line) == bool(chosen)                 # the GPU-validated configuration is timed beside a probed one
         if chosen:
+            assert line["default_path"]["value"] > 0 and line["default_path"]["switches"] == [] and line["default_path"]["steps"] == 20
             assert roof["traffic"] is None and roof["algorithmic_bytes"] == 417800000         # bf16 value / out / grad_out
         else:
             assert roof["algorithmic_bytes"] == 501400000
