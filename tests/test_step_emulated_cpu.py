@@ -51,16 +51,16 @@ class EmulMSDA:
 
 
 def run_step(oracle, pending, assignment=None):
-    from monodetr_amd import add_ln_ext, ddn_loss_ext, lsa_ext, msda_prologue_ext, pair_losses_ext
+    from monodetr_amd import add_ln_ext, bias_act_ext, ddn_loss_ext, lsa_ext, msda_prologue_ext, pair_losses_ext
     from monodetr_amd.helpers.optimizer_helper import AdamW, FusedAdamW
     from monodetr_amd.monodetr import build_monodetr
     from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func as F_
     from monodetr_amd.monodetr.ops.modules import ms_deform_attn as M_
-    exts = (pair_losses_ext, ddn_loss_ext, lsa_ext, msda_prologue_ext, add_ln_ext)
+    exts = (pair_losses_ext, ddn_loss_ext, lsa_ext, msda_prologue_ext, add_ln_ext, bias_act_ext)
     saved = (F_.MSDA, M_._FUSED_PROLOGUE, add_ln_ext.ENABLED)
     try:
         F_.MSDA = EmulMSDA if pending else oracle.OracleMSDA
-        M_._FUSED_PROLOGUE = add_ln_ext.ENABLED = pending
+        M_._FUSED_PROLOGUE = add_ln_ext.ENABLED = bias_act_ext.ENABLED = pending
         for e in exts:
             e._backend = native_emul.lib() if pending else None
         torch.manual_seed(0)
@@ -87,6 +87,12 @@ def run_step(oracle, pending, assignment=None):
 
         criterion.matcher.assign_stacked = matching
         images, calibs, img_sizes, targets = synthetic_batch(1, 64, 192, seed=11, max_objs=5)
+        if pending:                                                   # channels_last, as on the GPU: the backbone's tails then take csrc/bias_act.hip
+            model.to(memory_format=torch.channels_last)
+            images = images.contiguous(memory_format=torch.channels_last)
+            calls = []
+            real = bias_act_ext.bias_act
+            bias_act_ext.bias_act = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
         out = model(images, calibs, targets, img_sizes)
         losses = criterion(out, targets)
         total = sum(losses[k] * criterion.weight_dict[k] for k in losses if k in criterion.weight_dict)
@@ -94,9 +100,14 @@ def run_step(oracle, pending, assignment=None):
         grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
         opt.step()
         params = {n: p.detach().clone() for n, p in model.named_parameters()}
+        if pending:
+            assert len(calls) == 1 + 32 + 16, len(calls)              # stem + conv1 / conv2 of the 16 bottlenecks (no GEMM path on the CPU) + their residual tails
         return {k: float(v.detach()) for k, v in losses.items()}, float(total.detach()), grads, params, rec
     finally:
+        if pending:
+            bias_act_ext.bias_act = real
         F_.MSDA, M_._FUSED_PROLOGUE, add_ln_ext.ENABLED = saved
+        bias_act_ext.ENABLED = False
         for e in exts:
             e._backend = None
 
