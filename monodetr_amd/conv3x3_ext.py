@@ -52,6 +52,7 @@ class _Conv3x3(torch.autograd.Function):
         sh = None if shift is None else shift.float().contiguous()
         y = _launch(x, w, sh, relu)
         ctx.relu = bool(relu)
+        ctx.shift_dtype = None if shift is None else shift.dtype
         ctx.save_for_backward(x, weight, w, *((y,) if relu else ()))
         return y
 
@@ -71,13 +72,32 @@ class _Conv3x3(torch.autograd.Function):
                 dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (True, False, False))[0]
         if ctx.needs_input_grad[1]:
             dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
-        return dx, dw, None, None
+        ds = None
+        if ctx.shift_dtype is not None and ctx.needs_input_grad[2]:
+            # a trainable shift (a convolution bias): its gradient is the column sum of dY over the B*H*W pixels
+            dy2 = dy.permute(0, 2, 3, 1).reshape(-1, dy.shape[1])
+            if dy2.is_cuda and _backend is None:
+                from .colsum_ext import column_sum, supported as colsum_ok
+                ds = column_sum(dy2) if colsum_ok(dy2) else dy2.float().sum(0)
+            else:
+                ds = dy2.float().sum(0)
+            ds = ds.to(ctx.shift_dtype)
+        return dx, dw, ds, None
 
 
 def conv3x3(x, weight, shift=None, relu=False):
-    """act(conv2d(x, weight, padding=1) + shift[None, :, None, None]); ``shift`` [N] without gradient (a frozen-BN shift)."""
+    """act(conv2d(x, weight, padding=1) + shift[None, :, None, None]); ``shift`` [N]: a frozen-BN shift or a trainable bias."""
     if not supported(x, weight):
         raise RuntimeError("conv3x3: needs a CUDA bf16 channels_last activation with C % 64 == 0 and a bf16 [N, C, 3, 3] weight with N % 32 == 0")
-    if shift is not None and shift.requires_grad:
-        raise RuntimeError("conv3x3: the shift is a constant of the epilogue (no gradient)")
     return _Conv3x3.apply(x, weight, shift, relu)
+
+
+class Conv3x3(torch.nn.Conv2d):
+    """nn.Conv2d (same parameters, same state_dict keys) whose forward takes the kernel when MDETR_CONV3X3=1 and the call
+    qualifies (3x3 / stride 1 / pad 1, bf16 channels_last, C % 64 == 0, N % 32 == 0), and nn.Conv2d's otherwise."""
+
+    def forward(self, x):
+        if ENABLED and x.dtype == self.weight.dtype and not torch.is_autocast_enabled() \
+                and supported(x, self.weight, self.stride, self.padding, self.dilation, self.groups) and self.padding_mode == "zeros":
+            return conv3x3(x, self.weight, self.bias, relu=False)
+        return super().forward(x)

@@ -10,6 +10,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ...utils.misc import at_least_fp32, no_padding
+from ...conv3x3_ext import Conv3x3
 from ..linear import PointwiseConv2d
 from .transformer import TransformerEncoder, TransformerEncoderLayer
 
@@ -71,8 +72,8 @@ class DepthPredictor(nn.Module):
         self.proj = _conv_gn(d, d, 1)
         self.upsample = _conv_gn(d, d, 1)
         self.depth_head = nn.Sequential(
-            nn.Conv2d(d, d, kernel_size=(3, 3), padding=1), nn.GroupNorm(32, num_channels=d), nn.ReLU(),
-            nn.Conv2d(d, d, kernel_size=(3, 3), padding=1), nn.GroupNorm(32, num_channels=d), nn.ReLU())
+            Conv3x3(d, d, kernel_size=(3, 3), padding=1), nn.GroupNorm(32, num_channels=d), nn.ReLU(),
+            Conv3x3(d, d, kernel_size=(3, 3), padding=1), nn.GroupNorm(32, num_channels=d), nn.ReLU())
         self.depth_classifier = PointwiseConv2d(d, nbins + 1, kernel_size=(1, 1))
         self.depth_encoder = TransformerEncoder(TransformerEncoderLayer(d, nhead=8, dim_feedforward=256, dropout=0.1), 1)
         self.depth_pos_embed = nn.Embedding(int(dmax) + 1, 256)

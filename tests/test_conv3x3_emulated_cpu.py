@@ -62,8 +62,6 @@ def test_refusals_and_fallback_of_the_input_gradient(ext):
     assert not ext.supported(torch.randn(1, 48, 4, 4).to(torch.bfloat16).contiguous(memory_format=torch.channels_last), w[:, :48].contiguous())
     with pytest.raises(RuntimeError):
         ext.conv3x3(x.float(), w.float())
-    with pytest.raises(RuntimeError):
-        ext.conv3x3(x, w, torch.zeros(32, requires_grad=True))
     # N = 32 is not a multiple of 64: the input gradient (a convolution with C and N swapped) takes the library
     xr = x.clone().requires_grad_(True)
     y = ext.conv3x3(xr, w, None, relu=False)
@@ -104,3 +102,34 @@ def test_bottleneck_takes_the_kernel_for_its_3x3_and_agrees_with_the_library_pat
     assert calls == [True]                                           # conv2 only: conv1 / conv3 are 1x1
     for a, b in zip(res[False], res[True]):
         close(b, a, "bottleneck")
+
+
+def test_conv_module_with_a_trainable_bias_as_in_the_depth_head(ext):
+    """conv3x3_ext.Conv3x3 (the depth predictor's 3x3 convolutions: nn.Conv2d with a bias, GroupNorm behind it): kernel on
+    vs the library, output and the three gradients; same parameters and state_dict keys as nn.Conv2d."""
+    torch.manual_seed(2)
+    conv = ext.Conv3x3(64, 64, kernel_size=(3, 3), padding=1).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    assert isinstance(conv, torch.nn.Conv2d) and set(conv.state_dict()) == {"weight", "bias"}
+    x = torch.randn(2, 64, 7, 33).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(2, 64, 7, 33).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for on in (False, True):
+        ext.ENABLED = on
+        try:
+            xi = x.clone().requires_grad_(True)
+            conv.zero_grad()
+            y = conv(xi)
+            assert (type(y.grad_fn).__name__ == "_Conv3x3Backward") == on
+            y.backward(dy)
+            res[on] = (y.detach(), xi.grad, conv.weight.grad.clone(), conv.bias.grad.clone())
+        finally:
+            ext.ENABLED = False
+    for name, a, b in zip(("y", "dx", "dw", "db"), res[False], res[True]):
+        assert a.dtype == b.dtype and a.shape == b.shape
+        close(b, a, name)
+    # calls that do not qualify stay with the library even when the switch is on
+    ext.ENABLED = True
+    try:
+        assert type(conv(x.contiguous()).grad_fn).__name__ != "_Conv3x3Backward"              # NCHW-contiguous input
+    finally:
+        ext.ENABLED = False
