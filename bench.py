@@ -244,15 +244,20 @@ def autotune(args, world, local_rank, runner=run_probe, cache_path=None):
         lib = os.path.join(ROOT, "monodetr_amd", "libmonodetr_amd.so")
         key = "%s|b%d|%s|%d" % (args.precision, args.batch, torch.cuda.get_device_name(local_rank), int(os.path.getmtime(lib)))
         cache_path = cache_path or os.path.join(os.environ.get("TMPDIR", "/tmp"), "mdetr_bench_autotune.json")
-        if os.path.exists(cache_path):
-            try:
-                cached = json.load(open(cache_path))
-                if cached.get("key") == key:
-                    return list(cached["chosen"]), dict(cached["report"], source="cache")
-            except (ValueError, KeyError, OSError):
-                pass
-        if world > 1:
-            return None, None                                         # no cached decision: every rank stays on the default path
+        # N > 1: a rank takes the decision of the preceding N = 1 run on this box if there is one (same GPU model, same
+        # library: the key), else its own earlier decision, else it probes its own GPU -- no communication, and ranks need
+        # not agree (the optional kernels compute the same step).  That keeps the N = 1, 2, 4, 8 values comparable even when
+        # the cache of the N = 1 run is not there.
+        own_path = cache_path if world == 1 else "%s.rank%d" % (cache_path, local_rank)
+        for path in dict.fromkeys((cache_path, own_path)):
+            if os.path.exists(path):
+                try:
+                    cached = json.load(open(path))
+                    if cached.get("key") == key:
+                        return list(cached["chosen"]), dict(cached["report"], source="cache")
+                except (ValueError, KeyError, OSError):
+                    pass
+        cache_path = own_path
         results = runner(args, local_rank, probe_configs(args.precision) + [[]])
         chosen, why = choose_config(results)
         configs = probe_configs(args.precision) + [[]]
@@ -572,7 +577,9 @@ def main():
     if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=device)      # RCCL on ROCm
+        import datetime
+        # (a generous collective time-out: with no cached probe decision the ranks probe their GPUs before the first collective)
+        torch.distributed.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=30))      # RCCL on ROCm
 
     from monodetr_amd import _capi
     _capi.lib()                                                     # fail loudly if the HIP library is missing
@@ -581,8 +588,8 @@ def main():
         raise SystemExit("--graph on is a single-GPU mode (the RCCL all-reduce of DDP is not captured)")
     # optional kernels: the environment's, or -- with none set -- what the probe run found fastest and correct on this GPU
     chosen, tune_report = autotune(args, world, local_rank)
-    # (N > 1: every rank reads the same cached decision of the preceding N = 1 run; the optional kernels compute the same
-    # step as the default ones, so ranks need not even agree -- no extra collective is introduced)
+    # (N > 1: every rank reads the cached decision of the preceding N = 1 run -- or, without one, probes its own GPU; the
+    # optional kernels compute the same step as the default ones, so ranks need not even agree and no collective is added)
     step = TrainStep(device, args.batch, args.precision, ddp=(os.environ.get("MDETR_BENCH_SYNC", "flat") if dist_on else False), local_rank=local_rank, graph=use_graph,
                      switches=chosen)
     if use_graph:

@@ -62,14 +62,19 @@ def test_autotune_runs_one_probe_caches_per_box_and_reports(tmp_path):
     assert chosen == sorted(bench.AUTOTUNE_SWITCHES) and report["source"] == "probe" and len(report["candidates"]) == 11 and calls[0][0] == calls[0][-1] == []
     chosen2, report2 = bench.autotune(args(), 1, 0, runner=runner, cache_path=cache)
     assert chosen2 == chosen and report2["source"] == "cache" and len(calls) == 1
+    # N > 1: the N = 1 run's decision if it is there ...
+    chosen3, report3 = bench.autotune(args(precision="bf16"), 8, 3, runner=runner, cache_path=cache)
+    assert chosen3 == chosen and report3["source"] == "cache" and len(calls) == 1
     # another precision is another key
     bench.autotune(args(precision="fp32"), 1, 0, runner=runner, cache_path=cache)
     assert len(calls) == 2
-    # N > 1 only ever reads the cache
-    assert bench.autotune(args(precision="bf16"), 8, 3, runner=runner, cache_path=str(tmp_path / "none.json")) == (None, None)
-    assert len(calls) == 2
+    # ... else the rank probes its own GPU and remembers the outcome under its own name
+    none = str(tmp_path / "none.json")
+    chosen4, report4 = bench.autotune(args(precision="bf16"), 8, 3, runner=runner, cache_path=none)
+    assert chosen4 == chosen and report4["source"] == "probe" and len(calls) == 3 and os.path.exists(none + ".rank3") and not os.path.exists(none)
+    assert bench.autotune(args(precision="bf16"), 8, 3, runner=runner, cache_path=none)[1]["source"] == "cache" and len(calls) == 3
     json.dump({"key": "stale"}, open(cache, "w"))
-    assert bench.autotune(args(), 8, 0, runner=runner, cache_path=cache) == (None, None)
+    assert bench.autotune(args(), 8, 0, runner=runner, cache_path=cache)[1]["source"] == "probe" and len(calls) == 4
 
 
 def test_autotune_steps_aside(tmp_path, monkeypatch):
