@@ -654,3 +654,24 @@ def test_training_step_with_the_conv3x3_kernel_matches_default():
         bench.apply_switches(set())
     for a, b in zip(traj[()], traj[("MDETR_CONV3X3",)]):
         assert abs(a - b) <= 2e-2 * abs(a), traj
+
+
+def test_conv3x3_module_with_a_trainable_bias_matches_the_library(monkeypatch):
+    """conv3x3_ext.Conv3x3 as the depth head uses it (bias with a gradient, no ReLU), kernel on vs off."""
+    from monodetr_amd import conv3x3_ext
+    torch.manual_seed(4)
+    conv = conv3x3_ext.Conv3x3(256, 256, kernel_size=(3, 3), padding=1).cuda().to(torch.bfloat16).to(memory_format=torch.channels_last)
+    x = torch.randn(8, 256, 24, 80, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(8, 256, 24, 80, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(conv3x3_ext, "ENABLED", on)
+        xi = x.clone().requires_grad_(True)
+        conv.zero_grad()
+        y = conv(xi)
+        assert (type(y.grad_fn).__name__ == "_Conv3x3Backward") == on
+        y.backward(dy)
+        res[on] = (y.detach(), xi.grad, conv.weight.grad.clone(), conv.bias.grad.clone())
+    for name, a, b in zip(("y", "dx", "dw", "db"), res[False], res[True]):
+        lim = 2e-2 * max(1.0, a.float().abs().max().item()) * (4 if name in ("dw", "db") else 1)       # bf16 sums over 15 360 pixels
+        assert (a.float() - b.float()).abs().max().item() <= lim, name
