@@ -318,12 +318,12 @@ class DepthAwareTransformer(nn.Module):
             hit = self._shape_cache[key] = (ss, torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1])))
         return hit
 
-    def forward(self, srcs, masks, pos_embeds, query_embed=None, depth_pos_embed=None, depth_pos_embed_ip=None,
-                attn_mask=None):
-        assert query_embed is not None
+    def encode(self, srcs, masks, pos_embeds):
+        """Flatten + concatenate the pyramid and run the visual encoder (depthaware_transformer.py:208-229 of the
+        reference): returns (memory [B, S, C], spatial_shapes, level_start_index, valid_ratios, mask_flatten, mask_depth).
+        Also the whole of BASELINE configs[1] after the backbone (`bench.py --config 2`)."""
         unpadded = all(no_padding(m) for m in masks)
         shapes = [tuple(s.shape[-2:]) for s in srcs]
-        B, C = srcs[0].shape[:2]
         # flatten every level to [B, HW, C] and concatenate along the token axis
         src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
         lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1)
@@ -338,6 +338,13 @@ class DepthAwareTransformer(nn.Module):
 
         memory = self.encoder(src_flatten, spatial_shapes, level_start_index, valid_ratios, lvl_pos, mask_flatten,
                               shape_list=shapes)
+        return memory, spatial_shapes, level_start_index, valid_ratios, mask_flatten, mask_depth
+
+    def forward(self, srcs, masks, pos_embeds, query_embed=None, depth_pos_embed=None, depth_pos_embed_ip=None,
+                attn_mask=None):
+        assert query_embed is not None
+        B, C = srcs[0].shape[:2]
+        memory, spatial_shapes, level_start_index, valid_ratios, mask_flatten, mask_depth = self.encode(srcs, masks, pos_embeds)
 
         # queries: first half of the embedding is the positional part, second half the content
         query_pos, tgt = torch.split(query_embed, C, dim=1)

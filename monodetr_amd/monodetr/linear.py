@@ -19,7 +19,7 @@ from .. import colsum_ext
 _MIN_TOKENS = 4096
 # MDETR_TOKEN_GEMM=1: forward and input-gradient products of K in {64, 128, 256, 512} bf16 layers through the
 # LDS-resident-weight kernel (csrc/token_gemm.hip).  Off until its first GPU validation
-# (tests/test_pending_gpu.py); the library GEMM is the default.
+# (tests/test_fused_gpu.py); the library GEMM is the default.
 _TOKEN_GEMM = os.environ.get("MDETR_TOKEN_GEMM") == "1"
 # MDETR_GEMM_RELU=1: "linear -> ReLU" as one library GEMM with the RELU_BIAS epilogue (torch._addmm_activation ->
 # hipBLASLt) instead of a GEMM and an elementwise pass.  Off until timed on a GPU.

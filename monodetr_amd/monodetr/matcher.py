@@ -25,7 +25,7 @@ class HungarianMatcher(nn.Module):
         self.cost_class, self.cost_3dcenter, self.cost_bbox, self.cost_giou = cost_class, cost_3dcenter, cost_bbox, cost_giou
         assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
         # MDETR_FUSED_LOSSES=1: matching cost evaluated inside the device solver (off until its first GPU
-        # validation, like the fused losses: tests/test_pending_gpu.py)
+        # validation, like the fused losses: tests/test_fused_gpu.py)
         self.fused_cost = os.environ.get("MDETR_FUSED_LOSSES") == "1"
 
     @torch.no_grad()

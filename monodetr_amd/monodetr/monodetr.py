@@ -114,9 +114,9 @@ class MonoDETR(nn.Module):
             self.depth_embed = nn.ModuleList([depth_embed for _ in range(num_pred)])
             self.depthaware_transformer.decoder.bbox_embed = None
 
-    def forward(self, images, calibs, targets, img_sizes, dn_args=None):
-        """images [B,3,H,W]; calibs [B,3,4] (only the focal length calibs[:,0,0] is read); img_sizes
-        [B,2] (w,h); targets / dn_args unused on the default path.  Returns the prediction dict."""
+    def pyramid(self, images):
+        """Backbone + input projections (monodetr.py:156-178 of the reference): (srcs, masks, pos), one entry per
+        feature level."""
         features, pos = self.backbone(images)
         srcs, masks = [], []
         for l, feat in enumerate(features):
@@ -130,6 +130,12 @@ class MonoDETR(nn.Module):
             pos.append(self.backbone[1](NestedTensor(src, mask)).to(src.dtype))
             srcs.append(src)
             masks.append(mask)
+        return srcs, masks, pos
+
+    def forward(self, images, calibs, targets, img_sizes, dn_args=None):
+        """images [B,3,H,W]; calibs [B,3,4] (only the focal length calibs[:,0,0] is read); img_sizes
+        [B,2] (w,h); targets / dn_args unused on the default path.  Returns the prediction dict."""
+        srcs, masks, pos = self.pyramid(images)
 
         query_embeds = self.query_embed.weight if self.training else self.query_embed.weight[:self.num_queries]
 
@@ -321,7 +327,7 @@ class SetCriterion(nn.Module):
         self.group_num = group_num
         # MDETR_FUSED_LOSSES=1: all matched-pair losses of all levels in one HIP launch each way
         # (csrc/pair_losses.hip).  Off until the kernel has had its first GPU validation
-        # (tests/test_pending_gpu.py); its arithmetic is validated on the CPU (tests/test_fused_losses_cpu.py).
+        # (tests/test_fused_gpu.py); its arithmetic is validated on the CPU (tests/test_fused_losses_cpu.py).
         import os
         self.fused_pair_losses = os.environ.get("MDETR_FUSED_LOSSES") == "1"
 
@@ -442,9 +448,19 @@ class SetCriterion(nn.Module):
         'boxes_3d', 'depth', 'size_3d', 'heading_bin', 'heading_res' -- or the dict `pad_targets`
         makes of it.  Returns {name: 0-d tensor}, auxiliary layers suffixed _0, _1, ... (:511-530)."""
         final = _widen({k: v for k, v in outputs.items() if k not in ('aux_outputs', '_levels')})
-        if '_levels' in outputs:
+        levels = outputs.get('_levels')
+        if levels is not None:
+            # `_levels` is level-first [L, B, Q, D]; a caller that gathers replica outputs along dim 0
+            # (nn.DataParallel, what the reference's tools/train_val.py:55 wraps the model in) turns it into
+            # [n*L, B/n, ...] while pred_* become [B, ...]: use it only when it still describes this batch
+            ref = final['pred_logits']
+            n_aux = len(outputs.get('aux_outputs', []))
+            if not all(v.dim() == final[k].dim() + 1 and v.shape[0] == n_aux + 1 and v.shape[1:] == final[k].shape
+                       for k, v in levels.items() if k in final) or 'pred_logits' not in levels or ref.dim() != 3:
+                levels = None
+        if levels is not None:
             # the model's own level-stacked predictions [L, B, Q, D] (levels 0 .. L-1, the final layer last)
-            stacked = _widen(outputs['_levels'])
+            stacked = _widen(levels)
             L = stacked['pred_logits'].shape[0]
             names = [str(i) for i in range(L - 1)] + [None]                  # suffix of every level, None = final
         else:

@@ -21,7 +21,7 @@ from .... import msda_prologue_ext
 
 
 # MDETR_MSDA_PROLOGUE=1: fused softmax + sampling-location kernel (off until its first GPU validation,
-# tests/test_pending_gpu.py)
+# tests/test_fused_gpu.py)
 _FUSED_PROLOGUE = os.environ.get("MDETR_MSDA_PROLOGUE") == "1"
 
 _checked_shapes = set()

@@ -1,16 +1,14 @@
-"""GPU tests of kernels written after this round's GPU budget was spent.  Their arithmetic is validated
-on the CPU through a host build of the same device functions (tests/native, tests/test_optimizer.py,
-tests/test_fused_losses_cpu.py); these tests exercise the HIP launch glue and are skipped unless
-MDETR_TEST_PENDING=1, so that an unvalidated kernel cannot turn the GPU suite red.  First thing to run
-next round:   MDETR_TEST_PENDING=1 python -m pytest tests/test_pending_gpu.py -q
-The features they cover are OFF by default for the same reason."""
+"""GPU tests of the optional kernel families (fused criterion, flat AdamW, residual LayerNorm, MSDA prologue, bf16-native
+MSDA, convolution / FFN tails, library GEMM + ReLU epilogue, 3x3 convolution, token GEMM), the input pipeline kernel and the
+evaluation kernels: each family against the framework operators / the default path it replaces.  First GPU run: round 2
+(profiles/r02a_pytest_fused_gpu.log, 56 of 57 green; the 57th was this file's own end-to-end configuration).  A family
+may be listed in bench.COMMITTED_SWITCHES only while its tests here are green."""
 import os
 
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("MDETR_TEST_PENDING") != "1", reason="pending first GPU validation")]
+pytestmark = [pytest.mark.gpu]
 
 
 def test_fused_adamw_kernel_matches_foreach_adamw():
@@ -479,7 +477,7 @@ def test_train_val_entry_point_end_to_end(tmp_path, monkeypatch):
         'model': dict(MODEL_CFG, device='cuda'),
         'optimizer': {'type': 'adamw', 'lr': 2e-4, 'weight_decay': 1e-4},
         'lr_scheduler': {'type': 'step', 'warmup': False, 'decay_rate': 0.1, 'decay_list': [125, 165]},
-        'trainer': {'max_epoch': 2, 'gpu_ids': '0', 'save_frequency': 1, 'save_path': 'outputs/', 'save_all': False, 'use_dn': False,
+        'trainer': {'max_epoch': 2, 'gpu_ids': '0', 'save_frequency': 1, 'save_path': 'outputs/', 'save_all': True, 'use_dn': False,
                     'precision': 'bf16'},
         'tester': {'type': 'KITTI', 'mode': 'single', 'checkpoint': 2, 'threshold': 0.0, 'topk': 50},
     }
@@ -487,12 +485,14 @@ def test_train_val_entry_point_end_to_end(tmp_path, monkeypatch):
     yaml.safe_dump(cfg, open(path, 'w'))
     train_val.main(['--config', path])
     out = tmp_path / 'outputs' / 'monodetr'
-    assert (out / 'checkpoint.pth').exists() and (out / 'checkpoint_best.pth').exists()
+    # (checkpoint_best.pth is written only when the validation AP rises above 0, trainer_helper.py:100-107 -- not after two
+    # epochs from random weights: the run keeps every epoch and the tester is pointed at the last one)
+    assert (out / 'checkpoint_epoch_1.pth').exists() and (out / 'checkpoint_epoch_2.pth').exists()
     files = sorted(os.listdir(out / 'outputs' / 'data'))
     assert files == ['%s.txt' % i for i in ids]
     line = open(out / 'outputs' / 'data' / files[0]).readline().split(' ')
     assert len(line) == 16 and line[0] in ('Pedestrian', 'Car', 'Cyclist')
-    train_val.main(['--config', path, '-e'])                            # evaluation only, from checkpoint_best.pth
+    train_val.main(['--config', path, '-e'])                            # evaluation only, from checkpoint_epoch_2.pth
 
 
 # ---- fused residual + dropout + LayerNorm ----------------------------------------------------------------------------

@@ -309,6 +309,31 @@ def test_criterion_input_forms_agree(built):
         assert abs(float(a[k]) - float(c[k])) <= 1e-6 * max(1.0, abs(float(a[k]))), k
 
 
+def test_criterion_survives_a_dataparallel_style_gather(built):
+    """nn.DataParallel (the reference's multi-GPU mode, tools/train_val.py:55) gathers every tensor of the output dict
+    along dim 0.  The level-first `_levels` views then no longer describe the batch ([n*L, B/n, ...]); the criterion has
+    to notice and restack the reference-shaped entries instead."""
+    model, criterion = built
+    model.train(); criterion.train()
+    images, calibs, sizes, targets = synthetic_batch(2, 96, 320, 7, torch.device("cpu"))
+    with torch.no_grad():
+        whole = model(images, calibs, targets, sizes)
+        parts = [model(images[i:i + 1], calibs[i:i + 1], targets[i:i + 1], sizes[i:i + 1]) for i in range(2)]
+
+    def cat(objs):                                       # what torch.nn.parallel.gather does, minus the device copies
+        if isinstance(objs[0], torch.Tensor):
+            return torch.cat(objs, 0)
+        if isinstance(objs[0], dict):
+            return {k: cat([o[k] for o in objs]) for k in objs[0]}
+        return [cat(list(o)) for o in zip(*objs)]
+    gathered = cat(parts)
+    assert gathered["_levels"]["pred_logits"].shape[0] == 2 * whole["_levels"]["pred_logits"].shape[0]
+    a = criterion(whole, targets)
+    b = criterion(gathered, targets)
+    for k in a:
+        assert abs(float(a[k]) - float(b[k])) <= 2e-5 * max(1.0, abs(float(a[k]))), k
+
+
 def test_criterion_with_an_image_without_objects(built):
     """An image with zero ground-truth objects contributes nothing and breaks nothing (the reference
     handles it through empty index tensors; here through all-invalid padded slots)."""
