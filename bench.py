@@ -258,10 +258,11 @@ class TrainStep:
         return total
 
 
-def time_default_path(device, args, prime=8, warm=6, timed=20):
-    """images/sec of the default path (no optional kernel) -- what `value` would be without the start-up probe."""
-    step = TrainStep(device, args.batch, args.precision, switches=())
-    for _ in range(prime + warm):
+def time_variant(device, args, precision, switches, prime=10, timed=20, **kw):
+    """images/sec of another variant of the same step (the default path without optional kernels; the all-fp32 path),
+    timed in this process the same way as the headline, only shorter."""
+    step = TrainStep(device, args.batch, precision, switches=switches, **kw)
+    for _ in range(prime):
         step()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -269,8 +270,11 @@ def time_default_path(device, args, prime=8, warm=6, timed=20):
         step()
     torch.cuda.synchronize(device)
     dt = (time.perf_counter() - t0) / timed
+    del step
+    gc.collect()
+    torch.cuda.empty_cache()
     return {"value": round(args.batch / dt, 2), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3), "steps": timed,
-            "warmup": prime + warm, "switches": []}
+            "warmup": prime, "precision": precision, "switches": sorted(switches)}
 
 
 def bind_to_gpu_numa_node(local_rank):
@@ -308,27 +312,97 @@ def msda_algorithmic_bytes(B, Lq, backward, S=10200, M=8, D=32, L=4, P=4, e=4, m
     return fwd + e * (B * S * M * D + samples) if backward else fwd
 
 
-def cpu_baseline(steps=1):
-    """The same training iteration at batch 1 on the host cores (PyTorch CPU + the CPU oracle for
-    MSDA).  This is the reported baseline, not the product path."""
+def _cpu_model_name():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_msda_op_baseline(warm=3, timed=10, budget_s=40.0):
+    """BASELINE.md section 3.  The reference's CPU path for the operator is `ms_deform_attn_core_pytorch`
+    (ops/functions/ms_deform_attn_func.py:41-61: one F.grid_sample per level + weighted sum); /root/reference does not
+    exist on the GPU box, so its port oracle/msda_torch_ref.msda_grid_sample is timed: fp32, every host core, inputs as
+    ops/test.py:33-36 (seed 3, value = rand * 0.01, loc = rand, attn = rand + 1e-5 normalised), 3 warm-up + 10 timed calls,
+    forward alone and forward + backward (autograd), encoder (Lq = S = 10 200) and decoder-train (Lq = 550) shapes at B = 8.
+    GB/s on the ALGORITHMIC bytes of SURVEY.md 8d.  The timed count shrinks if a shape would overrun `budget_s`."""
+    from oracle.msda_torch_ref import msda_grid_sample                # checker, used only in this leg
+    B, M, D, P = 8, 8, 32, 4
+    shapes = LEVELS
+    S = sum(h * w for h, w in shapes)
+    rows = {}
+    for tag, Lq in (("encoder_Lq10200", S), ("decoder_Lq550", 550)):
+        torch.manual_seed(3)
+        value = (torch.rand(B, S, M, D) * 0.01).requires_grad_(True)
+        loc = torch.rand(B, Lq, M, len(shapes), P, 2).requires_grad_(True)
+        attn = torch.rand(B, Lq, M, len(shapes), P) + 1e-5
+        attn = (attn / attn.sum(-1, keepdim=True).sum(-2, keepdim=True)).requires_grad_(True)
+        gout = torch.rand(B, Lq, M * D)
+
+        def fwd():
+            with torch.no_grad():
+                return msda_grid_sample(value, shapes, loc, attn)
+
+        def fwd_bwd():
+            out = msda_grid_sample(value, shapes, loc, attn)
+            torch.autograd.grad(out, (value, loc, attn), gout)
+
+        for name, fn, backward in (("fwd", fwd, False), ("fwd_bwd", fwd_bwd, True)):
+            t0 = time.perf_counter()
+            fn()
+            first = time.perf_counter() - t0
+            n_warm = warm - 1 if first * (warm + timed) < budget_s else 0
+            n_timed = timed if first * (warm + timed) < budget_s else max(2, int(budget_s / 2 / max(first, 1e-3)))
+            for _ in range(n_warm):
+                fn()
+            t0 = time.perf_counter()
+            for _ in range(n_timed):
+                fn()
+            dt = (time.perf_counter() - t0) / n_timed
+            byts = msda_algorithmic_bytes(B, Lq, False) + (msda_algorithmic_bytes(B, Lq, True) if backward else 0)
+            rows["%s_%s" % (tag, name)] = {"ms_per_call": round(dt * 1e3, 2), "GBps_algorithmic": round(byts / dt / 1e9, 2), "warmup": n_warm + 1, "timed": n_timed}
+    return rows
+
+
+def cpu_baseline(steps=1, batch=2):
+    """The reported CPU baseline (kind "port": /root/reference cannot travel to the GPU box; its arithmetic is pinned to
+    the reference's by tests/test_oracle_golden.py and tests/test_model_cpu.py).  Two parts: the operator-level protocol of
+    BASELINE.md section 3 (`msda_op`), and the whole training iteration at batch `batch` with PyTorch CPU ops and the C
+    oracle as the MSDA operator (OpenMP over (image, head)) -> `value` in the metric's unit."""
     from oracle import msda_oracle                                   # checker, used only in this leg
     from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func as F_
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    torch.set_num_threads(cores)
     msda_oracle.build()
     saved = F_.MSDA
     F_.MSDA = msda_oracle.OracleMSDA
     try:
-        step = TrainStep(torch.device("cpu"), 1, "fp32", switches=())   # the optional GPU kernels have no business here
+        step = TrainStep(torch.device("cpu"), batch, "fp32", switches=())   # the optional GPU kernels have no business here
         step()                                                       # warm-up (allocations, oneDNN primitives)
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         dt = (time.perf_counter() - t0) / steps
+        del step
     finally:
         F_.MSDA = saved
-    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d training iteration(s) at batch 1 (3x384x1280, fp32) after 1 warm-up, PyTorch CPU ops + "
-                      "oracle MSDA (OpenMP over the batch only)" % steps,
-            "s_per_iter": round(dt, 3)}
+    out = {"value": round(batch / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port", "cpu": _cpu_model_name(),
+           "sample": "%d training iteration(s) at batch %d (3x384x1280, fp32) after 1 warm-up: PyTorch CPU ops + the C oracle as the "
+                     "MSDA operator; msda_op = BASELINE.md section 3 protocol on oracle/msda_torch_ref (port of "
+                     "ms_deform_attn_core_pytorch), B=8, 3 warm-up + 10 timed" % (steps, batch),
+           "s_per_iter": round(dt, 3)}
+    try:
+        out["msda_op"] = cpu_msda_op_baseline()
+    except Exception as e:                                           # the op-level leg must not cost the whole-step figure
+        out["msda_op"] = {"error": repr(e)[:200]}
+    return out
 
 
 def main():
@@ -349,12 +423,23 @@ def main():
                          "DESIGN.md 7 -- verified in fp32, worth <1%% once the host syncs were gone; bf16 replays are "
                          "not reliable on this ROCm build)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--probe", default=None, help=argparse.SUPPRESS)             # child mode of the autotune
-    ap.add_argument("--probe-device", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--no-variants", action="store_true", help="skip the fp32_path / default_path / rccl_1rank side measurements")
     ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5],
+                    help="BASELINE.json configs, 1-based: 3 (default) = full MonoDETR step B=8 384x1280 (configs[2], and configs[3] "
+                         "with --gpus N); 2 = ResNet-50 + input projections + MSDeformAttn encoder only, fp32 (configs[1]); "
+                         "5 = full step at 512x1760 with 100 queries, bf16 (configs[4])")
     args = ap.parse_args()
-    if args.probe is not None:
-        return probe_main(args)
+    size, queries, part = (384, 1280), 50, "full"
+    if args.config == 2:
+        part = "encoder"
+        if "--precision" not in sys.argv and "MDETR_BENCH_PRECISION" not in os.environ:
+            args.precision = "fp32"
+    elif args.config == 5:
+        size, queries = (512, 1760), 100
+    levels = [((size[0] // s + (size[0] % s > 0)), (size[1] // s + (size[1] % s > 0))) for s in (8, 16, 32)]
+    levels.append(((levels[-1][0] - 1) // 2 + 1, (levels[-1][1] - 1) // 2 + 1))       # 3x3 stride-2 pad-1 level
+    S_tokens = sum(h * w for h, w in levels)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -379,7 +464,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
-        # (a generous collective time-out: with no cached probe decision the ranks probe their GPUs before the first collective)
+        # (a generous collective time-out: MIOpen / hipBLASLt start-up differs by minutes between ranks on a cold box)
         torch.distributed.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=30))      # RCCL on ROCm
 
     from monodetr_amd import _capi
@@ -387,16 +472,14 @@ def main():
     use_graph = args.graph == "on"
     if use_graph and world > 1:
         raise SystemExit("--graph on is a single-GPU mode (the RCCL all-reduce of DDP is not captured)")
-    # optional kernels: the environment's, or -- with none set -- what the probe run found fastest and correct on this GPU
-    chosen, tune_report = autotune(args, world, local_rank)
-    # (N > 1: every rank reads the cached decision of the preceding N = 1 run -- or, without one, probes its own GPU; the
-    # optional kernels compute the same step as the default ones, so ranks need not even agree and no collective is added)
+    # optional kernel families: the committed list (or the environment's MDETR_*=1 for an A/B run) -- the same on every rank
+    chosen, switch_source = committed_switches(args.precision)
     step = TrainStep(device, args.batch, args.precision, ddp=(os.environ.get("MDETR_BENCH_SYNC", "flat") if dist_on else False), local_rank=local_rank, graph=use_graph,
-                     switches=chosen)
+                     switches=chosen, size=size, queries=queries, part=part)
     if use_graph:
         step.capture()                                              # untimed: part of start-up, like model build
 
-    # experiment (scripts/gpurun_pending.sh): let PyTorch's TunableOp time the library's GEMM solutions per shape during
+    # experiment: let PyTorch's TunableOp time the library's GEMM solutions per shape during
     # the start-up iterations and freeze the choice before anything is measured -- the decoder-sized products
     # ([4 400, 256] x [256, 256] and smaller) take 10-26 us each in `r01h` with the heuristic's macro-tiles
     tunable = os.environ.get("MDETR_BENCH_TUNABLEOP") == "1" and hasattr(torch.cuda, "tunable")
@@ -463,7 +546,7 @@ def main():
         if kind <= 3:
             row["Lq"] = key
             if kind == 0:
-                byts = msda_algorithmic_bytes(args.batch, key, False, mixed=msda_mixed)
+                byts = msda_algorithmic_bytes(args.batch, key, False, S=S_tokens, mixed=msda_mixed)
                 row.update(algorithmic_MB=round(byts / 1e6, 1), achieved_GBps=round(byts / avg / 1e6, 1),
                            frac=round(byts / avg / 1e6 / 8000.0, 4))
         else:
@@ -477,7 +560,7 @@ def main():
     for (kind, key), avg in by_key.items():
         if kind == 1:
             parts = [avg] + [by_key[(k2, key)] for k2 in (2, 3) if (k2, key) in by_key]
-            byts = msda_algorithmic_bytes(args.batch, key, True, mixed=msda_mixed)
+            byts = msda_algorithmic_bytes(args.batch, key, True, S=S_tokens, mixed=msda_mixed)
             ops.append({"op": "msda_backward", "Lq": key, "kernels_in_op": len(parts), "ms": round(sum(parts), 4),
                         "algorithmic_MB": round(byts / 1e6, 1), "achieved_GBps": round(byts / sum(parts) / 1e6, 1),
                         "frac": round(byts / sum(parts) / 1e6 / 8000.0, 4)})
@@ -489,17 +572,23 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        img = "3x%dx%d" % size
+        workload = {
+            3: "full MonoDETR training step (ResNet-50 + depth predictor + 3 enc / 3 dec layers, 550 train queries, 4 levels, "
+               "criterion + AdamW) = BASELINE configs[2] (1 GPU) / configs[3] (DDP)",
+            2: "ResNet-50 + input projections + MSDeformAttn encoder only (forward, mean-square objective on the encoder memory, "
+               "backward, AdamW over the parameters involved) = BASELINE configs[1]",
+            5: "full MonoDETR training step at 512x1760, 100 (x 11 groups = 1100 train) queries, S = %d tokens = BASELINE configs[4]" % S_tokens,
+        }[args.config]
         line = {
-            "metric": "training images/sec at B=8 per GPU, KITTI 384x1280",
+            "metric": "training images/sec at B=8 per GPU, KITTI %dx%d" % size,
             "value": round(args.batch * world / (elapsed / args.steps), 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16",
-            "data": "synthetic (N(0,1) images 3x384x1280, 1-8 synthetic cars per image), random-init weights",
-            "config": {"workload": "full MonoDETR training step (ResNet-50 + depth predictor + 3 enc / 3 dec layers, "
-                                   "550 train queries, 4 levels, criterion + AdamW) = BASELINE configs[2] (1 GPU) / "
-                                   "configs[3] (DDP)",
-                       "global_batch": args.batch * world, "per_gpu_batch": args.batch, "image": "3x384x1280",
+            "data": "synthetic (N(0,1) images %s, 1-8 synthetic cars per image), random-init weights" % img,
+            "config": {"workload": workload, "baseline_config": args.config,
+                       "global_batch": args.batch * world, "per_gpu_batch": args.batch, "image": img, "queries": queries,
                        "precision": args.precision, "parallelism": "dp%d" % world,
                        "grad_sync": (os.environ.get("MDETR_BENCH_SYNC", "flat") if dist_on else "none"), "prime_steps": args.prime,
                        "launch": "one hipGraph replay per iteration" if use_graph else "eager",
@@ -510,23 +599,43 @@ def main():
             # dominant hand-written operator: MSDA backward at the encoder shape (gather + tile scatter + reduce)
             line["roofline"] = {"kernel": "msda_backward(Lq=%d): msda_bwd_d32 + msda_scatter_tiles + msda_reduce_tiles" % dom["Lq"],
                                 "bound": "hbm", "achieved": dom["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
-                                "frac": dom["frac"], "traffic": None if msda_mixed else traffic.get("msda_backward_Lq%d" % dom["Lq"]),
+                                "frac": dom["frac"], "traffic": traffic.get("msda_backward%s_Lq%d" % ("_bf16" if msda_mixed else "", dom["Lq"])),
                                 "avg_launch_ms": dom["ms"], "algorithmic_bytes": int(dom["algorithmic_MB"] * 1e6)}
             line["roofline"]["timing"] = kernel_timing
             line["ops"] = ops
             line["kernels"] = kernels
         line["config"]["cpu_affinity"] = "NUMA node %d of the GPU" % bound[0] if bound else "unbound"
-        # optional kernels in this run: from the environment, or chosen by the start-up probe
+        # optional kernel families in this run: the committed list, or the environment's for an A/B run
         line["config"]["switches"] = sorted(step.switches)
-        if tune_report is not None:
-            line["config"]["autotune"] = tune_report
-        if world == 1 and chosen and not use_graph:
-            # the probe switched optional kernels on: time the GPU-validated default path as well, in this process and the
-            # same way (shorter), so that the line carries both numbers
+        line["config"]["switch_source"] = switch_source
+        side = world == 1 and not use_graph and not args.no_variants and not force_ddp
+        del step
+        gc.collect()
+        torch.cuda.empty_cache()
+        if side and args.precision != "fp32":
+            # the reference's own arithmetic (all fp32), same step, same process, same timing method (shorter)
             try:
-                line["default_path"] = time_default_path(device, args)
+                line["fp32_path"] = time_variant(device, args, "fp32", committed_switches("fp32")[0], size=size, queries=queries, part=part)
             except Exception as e:                                  # must not cost the measured line
+                line["fp32_path"] = {"value": None, "error": repr(e)[:200]}
+        if side and chosen:
+            # the same step without any optional kernel family
+            try:
+                line["default_path"] = time_variant(device, args, args.precision, (), size=size, queries=queries, part=part)
+            except Exception as e:
                 line["default_path"] = {"value": None, "error": repr(e)[:200]}
+        if side and args.config == 3:
+            # the N > 1 code path with one rank: process group over RCCL, parameter broadcast, flat gradient all-reduce
+            try:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29533")
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                import datetime
+                torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=device, timeout=datetime.timedelta(minutes=5))
+                line["rccl_1rank"] = time_variant(device, args, args.precision, chosen, ddp="flat")
+                torch.distributed.destroy_process_group()
+            except Exception as e:
+                line["rccl_1rank"] = {"value": None, "error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             if bound:
                 os.sched_setaffinity(0, bound[1])                   # the CPU baseline gets every core again

@@ -104,9 +104,11 @@ int FN(msda_oracle_forward)(const REAL *value, const int64_t *shapes, const int6
 }
 
 /* grad_out [B,Lq,M*D] -> grad_value [B,S,M,D], grad_loc (shape of loc), grad_attn (shape of attn).
- * All three outputs are fully (re)written; no pre-zeroing needed.  Parallel over the batch
- * only: grad_value scatter inside one image stays sequential in (q,m,l,p,c) order, so the
- * oracle is deterministic (the reference's atomics are not). */
+ * All three outputs are fully (re)written; no pre-zeroing needed.  Parallel over (image, head):
+ * heads write disjoint channels of grad_value, and inside one (image, head) the scatter stays
+ * sequential in (q,l,p,c) order -- every address sees its contributions in the same order as a
+ * fully serial (q,m,l,p,c) loop, so the oracle is deterministic and thread-count independent
+ * (the reference's atomics are not). */
 int FN(msda_oracle_backward)(const REAL *value, const int64_t *shapes, const int64_t *level_start,
                              const REAL *loc, const REAL *attn, const REAL *grad_out,
                              REAL *grad_value, REAL *grad_loc, REAL *grad_attn,
@@ -114,10 +116,10 @@ int FN(msda_oracle_backward)(const REAL *value, const int64_t *shapes, const int
 {
     const int64_t qid_stride = (int64_t)M * D;
     memset(grad_value, 0, sizeof(REAL) * (size_t)B * S * M * D);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < B; ++b) {
-        for (int q = 0; q < Lq; ++q) {
-            for (int m = 0; m < M; ++m) {
+        for (int m = 0; m < M; ++m) {
+            for (int q = 0; q < Lq; ++q) {
                 const int64_t samp = ((int64_t)b * Lq + q) * M + m;
                 const REAL *g = grad_out + samp * D;
                 const REAL *locp = loc + samp * L * P * 2;

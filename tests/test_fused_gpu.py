@@ -56,6 +56,28 @@ def test_fused_adamw_kernel_matches_foreach_adamw():
         assert (y.detach().float() - z.detach().float()).abs().max() <= 1e-5 * max(1.0, y.detach().float().abs().max().item())
 
 
+def test_fused_adamw_vs_recorded_reference_steps():
+    """adamw.hip on the GPU against six recorded steps of the REFERENCE's own optimizer (lib/helpers/optimizer_helper.py:
+    69-129; tests/golden/optimizer_adamw.npz recorded in fp64 by tests/golden/make_optimizer_golden.py): fp32 arithmetic
+    against the fp64 recording, 1e-6 of the parameter scale; a parameter that receives its first gradient at step 2 included."""
+    from conftest import load_golden
+    from optimizer_problem import make_grads, make_model
+    from monodetr_amd.helpers.optimizer_helper import FusedAdamW, build_optimizer
+    g = load_golden("optimizer_adamw")
+    shadow, model = make_model(), make_model().float().cuda()
+    opt = build_optimizer({'type': 'adamw', 'lr': 2e-4, 'weight_decay': 1e-4, 'fused': True}, model)
+    assert isinstance(opt, FusedAdamW)
+    for step in range(6):
+        make_grads(shadow, step)
+        for ps, p in zip(shadow.parameters(), model.parameters()):
+            p.grad = None if ps.grad is None else ps.grad.float().cuda()
+        opt.step()
+        if step in (0, 5):
+            for n, p in model.named_parameters():
+                ref = torch.as_tensor(g["step%d/%s" % (step, n)])
+                assert (p.detach().cpu().double() - ref).abs().max() <= 1e-6 * max(1.0, ref.abs().max().item()), (step, n)
+
+
 def test_training_step_with_fused_adamw_matches_default():
     """Three full training iterations (bf16 body, dropout off): the loss trajectory with the fused
     optimizer follows the default one."""

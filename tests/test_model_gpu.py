@@ -128,3 +128,76 @@ def test_bf16_body_training_step_matches_fp32_loss():
             assert opt.state[p["depthaware_transformer.encoder.layers.0.linear1.weight"]]["master"].dtype == torch.float32
             assert all(torch.isfinite(q.grad).all() for q in model.parameters() if q.grad is not None)
     assert abs(totals["bf16"] - totals["fp32"]) < 0.05 * abs(totals["fp32"]), totals
+
+
+def _loss_on_reference_assignment(model, criterion, golden, x, calibs, targets, img_sizes):
+    out = model(x, calibs, targets, img_sizes)
+    layers = [{k: v for k, v in out.items() if k not in ("aux_outputs", "_levels")}] + list(out["aux_outputs"])
+    losses = {}
+    for li, layer in enumerate(layers):
+        ref_idx = [(golden[f"f64/match{li}/{b}/src"], golden[f"f64/match{li}/{b}/tgt"]) for b in range(2)]
+        for name in criterion.losses:
+            if li > 0 and name == "depth_map":
+                continue
+            kw = {"log": False} if (li > 0 and name == "labels") else {}
+            ld = criterion.get_loss(name, layer, targets, ref_idx, float(11 * 11), **kw)
+            losses.update(ld if li == 0 else {"%s_%d" % (k, li - 1): v for k, v in ld.items()})
+    total = sum(losses[k] * criterion.weight_dict[k] for k in losses if k in criterion.weight_dict)
+    return out, total
+
+
+@pytest.mark.parametrize("switches", ["default", "committed"])
+def test_bf16_body_outputs_and_gradients_vs_fp32(switches):
+    """BASELINE configs[2] is a bf16 configuration; this is its parity bar.  The bf16 body (helpers/precision.py: bf16
+    input projections / depth predictor / encoder / decoder, fp32 backbone parameters, heads, criterion) against (a) the
+    fp32 golden outputs recorded from the REFERENCE's classes: every prediction within 2e-2 of its scale, and (b) the fp32
+    model's gradients on the same (recorded) assignment: cosine >= 0.99 for every parameter tensor whose gradient is not
+    negligible, and the total loss within 1 %.  Run on the default path and with the committed optional kernel families
+    (bench.COMMITTED_SWITCHES['bf16']) -- the configuration bench.py measures."""
+    import bench
+    from monodetr_amd.helpers.precision import to_bf16_body
+    from monodetr_amd.monodetr import build_monodetr
+    golden = load_golden("model_kitti_b2")
+    images, calibs, img_sizes, targets = synthetic_batch(2, 384, 1280, seed=7, device="cuda")
+    grads, totals, outs = {}, {}, {}
+    try:
+        for mode in ("fp32", "bf16"):
+            names = set(bench.COMMITTED_SWITCHES[mode]) if switches == "committed" else set()
+            names -= {"MDETR_FUSED_ADAMW"}                              # no optimizer step here
+            bench.apply_switches(names)
+            torch.manual_seed(0)
+            model, criterion = build_monodetr(load_cfg(device="cuda"))
+            disable_dropout_(name_seeded_init_(model)).cuda().to(memory_format=torch.channels_last).train()
+            criterion.train()
+            criterion.fused_pair_losses = criterion.matcher.fused_cost = False      # per-layer get_loss on the recorded assignment
+            x = images.contiguous(memory_format=torch.channels_last)
+            if mode == "bf16":
+                to_bf16_body(model)
+                x = x.to(torch.bfloat16)
+            out, total = _loss_on_reference_assignment(model, criterion, golden, x, calibs, targets, img_sizes)
+            total.backward()
+            grads[mode] = {n: p.grad.detach().float().flatten() for n, p in model.named_parameters() if p.grad is not None}
+            totals[mode], outs[mode] = float(total), {k: v.detach().float() for k, v in out.items() if torch.is_tensor(v)}
+            del model, criterion, out, total
+    finally:
+        bench.apply_switches(set())
+    for k in ("pred_logits", "pred_boxes", "pred_3d_dim", "pred_depth", "pred_angle", "pred_depth_map_logits"):
+        ref = golden[f"train/{k}"]
+        err = (outs["bf16"][k].cpu() - ref).abs().max().item()
+        assert err <= 2e-2 * max(1.0, ref.abs().max().item()), (k, err, ref.abs().max().item())
+    assert abs(totals["bf16"] - totals["fp32"]) <= 1e-2 * abs(totals["fp32"]), totals
+    assert abs(totals["fp32"] - float(golden["f64/total_loss"])) < 1e-3 * float(golden["f64/total_loss"])
+    assert sorted(grads["bf16"]) == sorted(grads["fp32"])
+    biggest = max(float(g.norm()) for g in grads["fp32"].values())
+    worst = []
+    for n, g32 in grads["fp32"].items():
+        g16 = grads["bf16"][n]
+        n32 = float(g32.norm())
+        if n32 < 1e-6 * biggest:
+            continue
+        cos = float(torch.dot(g32, g16) / (n32 * float(g16.norm()) + 1e-30))
+        worst.append((cos, n, n32))
+    worst.sort()
+    print("lowest gradient cosines (bf16 body vs fp32):", worst[:5])
+    assert len(worst) > 250
+    assert worst[0][0] >= 0.99, worst[:8]

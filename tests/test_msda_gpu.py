@@ -141,6 +141,32 @@ def test_full_size_encoder_and_decoder_shapes(ext, oracle):
         assert (ga.cpu() - ra).abs().max() < 1e-4 * max(1.0, ra.abs().max().item())
 
 
+def test_bf16_native_full_encoder_shape_vs_oracle(ext, oracle):
+    """The bf16-native operator (bf16 value / out / grad_out; fp32 locations, weights, accumulation, gradients) at the
+    benchmark's encoder shape B=8, S=Lq=10200 -- and the decoder's Lq=550 -- against the ORACLE (reference semantics
+    .cuh:237-403) evaluated in fp32 on the same bf16-rounded tensors.  out: the oracle's value rounded to bf16, at most one
+    bf16 ulp apart (summation order); gradients: 2e-5 / 1e-4 of scale as for the fp32 operator; gather indices bit-exact."""
+    for Lq in (10200, 550):
+        p = make_problem(8, 8, 32, Lq, KITTI, 4, torch.float32, seed=Lq + 1, lo=-0.05, hi=1.05)
+        p["value"] = p["value"].to(torch.bfloat16).float()
+        p["grad_out"] = p["grad_out"].to(torch.bfloat16).float()
+        d = dev(p)
+        vb, gb = d["value"].to(torch.bfloat16), d["grad_out"].to(torch.bfloat16)
+        out = ext.ms_deform_attn_forward_bf16(vb, d["shapes"], d["level_start"], d["loc"], d["attn"])
+        ref32 = oracle_fwd(oracle, p)
+        assert out.dtype == torch.bfloat16
+        err = (out.float().cpu() - ref32).abs()
+        assert (err <= 2.0 ** -8 * ref32.abs() + 1e-9).all()                # one bf16 ulp of the oracle's value
+        assert (out.cpu() == ref32.to(torch.bfloat16)).float().mean() > 0.999
+        assert torch.equal(ext.ms_deform_attn_indices(d["shapes"], d["loc"]).cpu(), oracle.indices(p["shapes"], p["loc"]))
+        gv, gl, ga = ext.ms_deform_attn_backward_bf16(vb, d["shapes"], d["level_start"], d["loc"], d["attn"], gb)
+        rv, rl, ra = oracle_bwd(oracle, p)
+        assert gv.dtype == gl.dtype == ga.dtype == torch.float32
+        assert (gv.cpu() - rv).abs().max() < 2e-5 * max(1.0, rv.abs().max().item())
+        assert (gl.cpu() - rl).abs().max() < 1e-4 * max(1.0, rl.abs().max().item())
+        assert (ga.cpu() - ra).abs().max() < 1e-4 * max(1.0, ra.abs().max().item())
+
+
 def test_full_size_properties_highres(ext):
     """Size-independent properties at BASELINE configs[4] (512x1760, S=18704, Lq=1100), no oracle:
     linearity in value, partition of unity (constant value field + weights summing to 1 -> constant
