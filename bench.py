@@ -106,10 +106,13 @@ SWITCH_TESTS = {
     "MDETR_MSDA_BF16": "test_msda_bf16_kernels_*, test_msda_function_with_native_bf16_*, test_training_step_with_bf16_msda_*, test_msda_gpu.py::test_bf16_native_full_encoder_shape_vs_oracle",
     "MDETR_FUSED_EPILOGUE": "test_bias_act_kernel_*, test_training_step_with_fused_tails_*",
     "MDETR_GEMM_RELU": "test_library_gemm_relu_epilogue_*, test_training_step_with_fused_tails_*",
+    "MDETR_CONV3X3": "test_conv3x3_kernel_matches_the_library_convolution, test_training_step_with_the_conv3x3_kernel_*, test_conv3x3_module_with_a_trainable_bias_*",
 }
 COMMITTED_SWITCHES = {
+    # (MDETR_CONV3X3: 1.6-3.5x MIOpen per kernel on the four ResNet stages, profiles/r02a_fusedbench.json; the step 249.3 vs
+    # 234.6 img/s, profiles/r02b_bench_committed_plus_conv3x3.json.  MDETR_TOKEN_GEMM stays off: slower than hipBLASLt.)
     "bf16": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE", "MDETR_MSDA_BF16",
-             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU"),
+             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3"),
     "fp32": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE",
              "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU"),
 }
@@ -322,19 +325,24 @@ def _cpu_model_name():
     return "unknown"
 
 
-def cpu_msda_op_baseline(warm=3, timed=10, budget_s=40.0):
+def _emit(tag, obj):
+    print("CPU-BASELINE " + json.dumps({tag: obj}), flush=True)
+
+
+def cpu_msda_op_baseline(warm=3, timed=10, leg_budget_s=10.0, emit=None):
     """BASELINE.md section 3.  The reference's CPU path for the operator is `ms_deform_attn_core_pytorch`
     (ops/functions/ms_deform_attn_func.py:41-61: one F.grid_sample per level + weighted sum); /root/reference does not
     exist on the GPU box, so its port oracle/msda_torch_ref.msda_grid_sample is timed: fp32, every host core, inputs as
     ops/test.py:33-36 (seed 3, value = rand * 0.01, loc = rand, attn = rand + 1e-5 normalised), 3 warm-up + 10 timed calls,
-    forward alone and forward + backward (autograd), encoder (Lq = S = 10 200) and decoder-train (Lq = 550) shapes at B = 8.
-    GB/s on the ALGORITHMIC bytes of SURVEY.md 8d.  The timed count shrinks if a shape would overrun `budget_s`."""
+    forward alone and forward + backward (autograd), decoder-train (Lq = 550) and encoder (Lq = S = 10 200) shapes at B = 8.
+    GB/s on the ALGORITHMIC bytes of SURVEY.md 8d.  A leg whose calls are too slow for `leg_budget_s` runs fewer of them
+    (the counts actually used are in the record)."""
     from oracle.msda_torch_ref import msda_grid_sample                # checker, used only in this leg
     B, M, D, P = 8, 8, 32, 4
     shapes = LEVELS
     S = sum(h * w for h, w in shapes)
     rows = {}
-    for tag, Lq in (("encoder_Lq10200", S), ("decoder_Lq550", 550)):
+    for tag, Lq in (("decoder_Lq550", 550), ("encoder_Lq10200", S)):
         torch.manual_seed(3)
         value = (torch.rand(B, S, M, D) * 0.01).requires_grad_(True)
         loc = torch.rand(B, Lq, M, len(shapes), P, 2).requires_grad_(True)
@@ -354,24 +362,28 @@ def cpu_msda_op_baseline(warm=3, timed=10, budget_s=40.0):
             t0 = time.perf_counter()
             fn()
             first = time.perf_counter() - t0
-            n_warm = warm - 1 if first * (warm + timed) < budget_s else 0
-            n_timed = timed if first * (warm + timed) < budget_s else max(2, int(budget_s / 2 / max(first, 1e-3)))
-            for _ in range(n_warm):
-                fn()
-            t0 = time.perf_counter()
-            for _ in range(n_timed):
-                fn()
-            dt = (time.perf_counter() - t0) / n_timed
+            if first * 3 > leg_budget_s:                              # one sample is all the budget allows
+                n_warm, n_timed, dt = 0, 1, first
+            else:
+                n_warm = min(warm - 1, max(0, int(leg_budget_s / 4 / first)))
+                for _ in range(n_warm):
+                    fn()
+                n_timed = max(2, min(timed, int((leg_budget_s - first * (1 + n_warm)) / first)))
+                t0 = time.perf_counter()
+                for _ in range(n_timed):
+                    fn()
+                dt = (time.perf_counter() - t0) / n_timed
             byts = msda_algorithmic_bytes(B, Lq, False) + (msda_algorithmic_bytes(B, Lq, True) if backward else 0)
-            rows["%s_%s" % (tag, name)] = {"ms_per_call": round(dt * 1e3, 2), "GBps_algorithmic": round(byts / dt / 1e9, 2), "warmup": n_warm + 1, "timed": n_timed}
+            rows["%s_%s" % (tag, name)] = {"ms_per_call": round(dt * 1e3, 2), "GBps_algorithmic": round(byts / dt / 1e9, 2),
+                                           "warmup": n_warm + (0 if n_timed == 1 and n_warm == 0 else 1), "timed": n_timed}
+            if emit:
+                emit("msda_op", rows)
     return rows
 
 
-def cpu_baseline(steps=1, batch=2):
-    """The reported CPU baseline (kind "port": /root/reference cannot travel to the GPU box; its arithmetic is pinned to
-    the reference's by tests/test_oracle_golden.py and tests/test_model_cpu.py).  Two parts: the operator-level protocol of
-    BASELINE.md section 3 (`msda_op`), and the whole training iteration at batch `batch` with PyTorch CPU ops and the C
-    oracle as the MSDA operator (OpenMP over (image, head)) -> `value` in the metric's unit."""
+def cpu_baseline_child(steps=1, batch=2):
+    """Runs in a child process of its own (fresh thread pools, no CPU pinning inherited from the GPU process): prints one
+    `CPU-BASELINE {...}` line per finished part so that the parent can keep what was done if it has to cut the child off."""
     from oracle import msda_oracle                                   # checker, used only in this leg
     from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func as F_
     cores = os.cpu_count() or 1
@@ -380,6 +392,7 @@ def cpu_baseline(steps=1, batch=2):
     except (AttributeError, OSError):
         pass
     torch.set_num_threads(cores)
+    _emit("host", {"cores": torch.get_num_threads(), "cpu": _cpu_model_name()})
     msda_oracle.build()
     saved = F_.MSDA
     F_.MSDA = msda_oracle.OracleMSDA
@@ -393,16 +406,47 @@ def cpu_baseline(steps=1, batch=2):
         del step
     finally:
         F_.MSDA = saved
-    out = {"value": round(batch / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port", "cpu": _cpu_model_name(),
-           "sample": "%d training iteration(s) at batch %d (3x384x1280, fp32) after 1 warm-up: PyTorch CPU ops + the C oracle as the "
-                     "MSDA operator; msda_op = BASELINE.md section 3 protocol on oracle/msda_torch_ref (port of "
-                     "ms_deform_attn_core_pytorch), B=8, 3 warm-up + 10 timed" % (steps, batch),
-           "s_per_iter": round(dt, 3)}
+    _emit("step", {"value": round(batch / dt, 4), "s_per_iter": round(dt, 3), "batch": batch, "steps": steps})
+    cpu_msda_op_baseline(emit=_emit)
+
+
+def cpu_baseline(steps=1, batch=2, timeout_s=150):
+    """The reported CPU baseline (kind "port": /root/reference cannot travel to the GPU box; its arithmetic is pinned to
+    the reference's by tests/test_oracle_golden.py and tests/test_model_cpu.py).  Two parts, measured in a child process
+    under a hard time limit: the whole training iteration at batch `batch` with PyTorch CPU ops and the C oracle as the
+    MSDA operator (OpenMP over (image, head)) -> `value` in the metric's unit; and the operator-level protocol of
+    BASELINE.md section 3 (`msda_op`)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")
+           and not k.startswith("OMP_") and not k.startswith("MDETR_")}
+    env["HIP_VISIBLE_DEVICES"] = ""                                  # the child is a CPU process
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-steps", str(steps), "--cpu-batch", str(batch)]
+    note, out = "", ""
     try:
-        out["msda_op"] = cpu_msda_op_baseline()
-    except Exception as e:                                           # the op-level leg must not cost the whole-step figure
-        out["msda_op"] = {"error": repr(e)[:200]}
-    return out
+        done = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s, text=True)
+        out = done.stdout
+        if done.returncode != 0:
+            note = "child exited with %d" % done.returncode
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout.decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or "")
+        note = "cut off after %d s (what had finished is reported)" % timeout_s
+    parts = {}
+    for ln in out.splitlines():
+        if ln.startswith("CPU-BASELINE "):
+            try:
+                parts.update(json.loads(ln[13:]))
+            except ValueError:
+                pass
+    host, stepr = parts.get("host", {}), parts.get("step", {})
+    res = {"value": stepr.get("value"), "unit": "images/sec", "cores": host.get("cores", 0), "kind": "port", "cpu": host.get("cpu", "unknown"),
+           "sample": "%d training iteration(s) at batch %d (3x384x1280, fp32) after 1 warm-up: PyTorch CPU ops + the C oracle as the MSDA "
+                     "operator; msda_op = BASELINE.md section 3 protocol on oracle/msda_torch_ref (port of ms_deform_attn_core_pytorch), "
+                     "B=8, up to 3 warm-up + 10 timed calls within 10 s per leg" % (steps, batch),
+           "s_per_iter": stepr.get("s_per_iter"), "msda_op": parts.get("msda_op", {})}
+    if note:
+        res["note"] = note
+    return res
 
 
 def main():
@@ -425,11 +469,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the fp32_path / default_path / rccl_1rank side measurements")
     ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5],
                     help="BASELINE.json configs, 1-based: 3 (default) = full MonoDETR step B=8 384x1280 (configs[2], and configs[3] "
                          "with --gpus N); 2 = ResNet-50 + input projections + MSDeformAttn encoder only, fp32 (configs[1]); "
                          "5 = full step at 512x1760 with 100 queries, bf16 (configs[4])")
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        return cpu_baseline_child(args.cpu_steps, args.cpu_batch)
     size, queries, part = (384, 1280), 50, "full"
     if args.config == 2:
         part = "encoder"
@@ -537,33 +585,37 @@ def main():
 
     # ---- per-kernel timings from the HIP events recorded by the C ABI during the timed steps --------
     names = {0: "msda_fwd_rec", 1: "msda_bwd_d32", 2: "msda_scatter_tiles", 3: "msda_reduce_tiles",
-             4: "attn_fwd_kernel", 5: "attn_bwd(prep+dq+dkv)"}
+             4: "attn_fwd_kernel", 5: "attn_bwd(prep+dq+dkv)", 6: "msda_bwd_fused", 7: "msda_absmax", 8: "msda_finalize"}
     kernels, by_key = [], {}
     msda_mixed = "MDETR_MSDA_BF16" in step.switches               # bf16-native operator: 2-byte value / out / grad_out
     for kind, key, launches, total_ms in _capi.profile_read():
         avg = total_ms / max(launches, 1)
         row = {"kernel": names.get(kind, str(kind)), "launches": launches, "avg_ms": round(avg, 4)}
-        if kind <= 3:
+        if kind in (4, 5):
+            Lq, Lk = key // 4096, key % 4096
+            flops = 4.0 * args.batch * 8 * Lq * Lk * 32 * (1.0 if kind == 4 else 2.5)
+            row.update(Lq=Lq, Lk=Lk, TFLOPs=round(flops / avg / 1e9, 1))
+        else:
             row["Lq"] = key
             if kind == 0:
                 byts = msda_algorithmic_bytes(args.batch, key, False, S=S_tokens, mixed=msda_mixed)
                 row.update(algorithmic_MB=round(byts / 1e6, 1), achieved_GBps=round(byts / avg / 1e6, 1),
                            frac=round(byts / avg / 1e6 / 8000.0, 4))
-        else:
-            Lq, Lk = key // 4096, key % 4096
-            flops = 4.0 * args.batch * 8 * Lq * Lk * 32 * (1.0 if kind == 4 else 2.5)
-            row.update(Lq=Lq, Lk=Lk, TFLOPs=round(flops / avg / 1e9, 1))
         kernels.append(row)
         by_key[(kind, key)] = avg
-    # MSDA backward as an operator = gather kernel (+ scatter_tiles + reduce_tiles on the encoder shape)
+    # MSDA backward as an operator: the one-pass kernel + its scale pre-pass + the finalize pass (msda_fused.hip), or round 1's
+    # gather kernel (+ scatter_tiles + reduce_tiles on the encoder shape)
     ops = []
     for (kind, key), avg in by_key.items():
-        if kind == 1:
-            parts = [avg] + [by_key[(k2, key)] for k2 in (2, 3) if (k2, key) in by_key]
+        if kind in (1, 6):
+            group = (6, 7, 8) if kind == 6 else (1, 2, 3)
+            parts = [(names[k2], by_key[(k2, key)]) for k2 in group if (k2, key) in by_key]
+            total = sum(t for _, t in parts)
             byts = msda_algorithmic_bytes(args.batch, key, True, S=S_tokens, mixed=msda_mixed)
-            ops.append({"op": "msda_backward", "Lq": key, "kernels_in_op": len(parts), "ms": round(sum(parts), 4),
-                        "algorithmic_MB": round(byts / 1e6, 1), "achieved_GBps": round(byts / sum(parts) / 1e6, 1),
-                        "frac": round(byts / sum(parts) / 1e6 / 8000.0, 4)})
+            ops.append({"op": "msda_backward", "Lq": key, "kernels_in_op": len(parts), "kernels": " + ".join(n for n, _ in parts),
+                        "dominant_kernel_ms": round(max(t for _, t in parts), 4), "ms": round(total, 4),
+                        "algorithmic_MB": round(byts / 1e6, 1), "achieved_GBps": round(byts / total / 1e6, 1),
+                        "frac": round(byts / total / 1e6 / 8000.0, 4)})
     traffic = {}
     tpath = os.path.join(ROOT, "profiles", "msda_pmc_traffic.json")
     if os.path.exists(tpath):
@@ -597,7 +649,7 @@ def main():
         }
         if dom is not None:
             # dominant hand-written operator: MSDA backward at the encoder shape (gather + tile scatter + reduce)
-            line["roofline"] = {"kernel": "msda_backward(Lq=%d): msda_bwd_d32 + msda_scatter_tiles + msda_reduce_tiles" % dom["Lq"],
+            line["roofline"] = {"kernel": "msda_backward(Lq=%d): %s" % (dom["Lq"], dom["kernels"]),
                                 "bound": "hbm", "achieved": dom["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
                                 "frac": dom["frac"], "traffic": traffic.get("msda_backward%s_Lq%d" % ("_bf16" if msda_mixed else "", dom["Lq"])),
                                 "avg_launch_ms": dom["ms"], "algorithmic_bytes": int(dom["algorithmic_MB"] * 1e6)}
@@ -638,9 +690,9 @@ def main():
                 line["rccl_1rank"] = {"value": None, "error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             if bound:
-                os.sched_setaffinity(0, bound[1])                   # the CPU baseline gets every core again
+                os.sched_setaffinity(0, bound[1])                   # the CPU baseline's child process gets every core
             try:
-                line["cpu_baseline"] = cpu_baseline(args.cpu_steps)
+                line["cpu_baseline"] = cpu_baseline(args.cpu_steps, args.cpu_batch)
             except Exception as e:                                  # a reported baseline must not cost the measured line
                 line["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
                                         "sample": "failed: %r" % (e,)}

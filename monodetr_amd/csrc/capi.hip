@@ -189,7 +189,9 @@ int64_t mdetr_msda_backward_workspace_bytes(int dtype, const int64_t *spatial_sh
                                             int B, int S, int M, int D, int L, int Lq, int P)
 {
     if (dtype != MDETR_F32 || !spatial_shapes_host || !level_start_host) return 0;
-    return mdetr::msda_tiled_workspace_bytes(spatial_shapes_host, level_start_host, B, S, M, D, L, Lq, P);
+    const int64_t a = mdetr::msda_tiled_workspace_bytes(spatial_shapes_host, level_start_host, B, S, M, D, L, Lq, P);
+    const int64_t b = mdetr::msda_fused_workspace_bytes(spatial_shapes_host, level_start_host, B, S, M, D, L, Lq, P);
+    return a > b ? a : b;
 }
 
 int mdetr_msda_backward_ex(int dtype, const void *value, const int64_t *spatial_shapes, const int64_t *level_start,

@@ -186,12 +186,14 @@ hipError_t launch(const void *x, const void *w, const float *shift, void *y, con
     constexpr size_t lds = static_cast<size_t>(kHaloH) * kHaloW * kPad * 2 + 3 * NB * 32 * kPad * 2 + NB * 32 * 4;
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
     auto kern = conv3x3_kernel<NB, RELU>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};                           // the attribute is per device: one process may drive several GPUs
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess) dev_ = -1;
+    if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_]) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(lds));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;
     }
     ConvDims g = d;
     g.tiles = d.B * d.tiles_x * d.tiles_y;

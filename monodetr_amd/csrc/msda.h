@@ -73,6 +73,14 @@ hipError_t msda_tiled_grad_value_launch(const int64_t *shapes_h, const int64_t *
                                         int B, int S, int M, int D, int L, int Lq, int P, bool absmax_ready, hipStream_t st,
                                         int grad_out_dtype = 0 /* 0 = f32, 2 = bf16 (needs absmax_ready) */);
 
+// msda_fused.hip: the whole backward (all three gradients) in one pass, self-attention over the pyramid or cross-attention
+// with few queries; D = 32.  elem_dtype 0: value / grad_out fp32, 2: bf16.  Writes every output completely.
+int64_t msda_fused_workspace_bytes(const int64_t *shapes_h, const int64_t *start_h, int B, int S, int M, int D, int L, int Lq, int P);
+hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *start_h, const void *value, const float *loc,
+                                      const float *attn, const void *grad_out, float *grad_value, float *grad_loc, float *grad_attn,
+                                      void *workspace, int64_t workspace_bytes, int B, int S, int M, int D, int L, int Lq, int P,
+                                      int elem_dtype, hipStream_t st);
+
 hipError_t msda_indices_launch(int dtype, const int64_t *shapes, const void *loc, int32_t *idx,
                                int B, int M, int L, int Lq, int P, hipStream_t st);
 

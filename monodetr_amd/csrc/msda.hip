@@ -782,10 +782,19 @@ hipError_t msda_backward_launch_ex(int dtype, const void *value, const int64_t *
     const size_t e = dtype == 0 ? 4 : 8;
     const int64_t nv = static_cast<int64_t>(B) * S * M * D, ns = static_cast<int64_t>(B) * Lq * M * L * P;
     hipError_t err;
-    if (nv && (err = zero_fill_launch(grad_value, nv * e, st)) != hipSuccess) return err;
     const int64_t n = static_cast<int64_t>(B) * Lq * M * D;
-    if (n == 0 || ns == 0) return hipSuccess;
+    // MDETR_MSDA_BWD = fused (default) | tiled | atomic: which grad_value strategy the fast path takes
+    const int bwd_env = [] { const char *ev = getenv("MDETR_MSDA_BWD"); return !ev || !*ev || ev[0] == 'f' ? 0 : (ev[0] == 't' ? 1 : 2); }();
     const bool fast = msda_fast_path(dtype, D, L, P);
+    if (fast && bwd_env == 0 && n && ns && shapes_host && lstart_host && workspace) {
+        // one-pass backward (msda_fused.hip): writes all three outputs completely, no zero fill
+        err = msda_backward_fused_launch(shapes_host, lstart_host, value, static_cast<const float *>(loc), static_cast<const float *>(attn),
+                                         grad_out, static_cast<float *>(grad_value), static_cast<float *>(grad_loc),
+                                         static_cast<float *>(grad_attn), workspace, workspace_bytes, B, S, M, D, L, Lq, P, 0, st);
+        if (err != hipErrorNotSupported) return err;
+    }
+    if (nv && (err = zero_fill_launch(grad_value, nv * e, st)) != hipSuccess) return err;
+    if (n == 0 || ns == 0) return hipSuccess;
     if (!fast) {   // generic path accumulates grad_loc / grad_attn with atomics
         if ((err = zero_fill_launch(grad_loc, ns * 2 * e, st)) != hipSuccess) return err;
         if ((err = zero_fill_launch(grad_attn, ns * e, st)) != hipSuccess) return err;
@@ -794,7 +803,7 @@ hipError_t msda_backward_launch_ex(int dtype, const void *value, const int64_t *
         static const int var_env = [] { const char *ev = getenv("MDETR_MSDA_BWD_VARIANT"); return ev ? atoi(ev) : -1; }();
         // tile-privatised grad_value (msda_tiled.hip) when the geometry qualifies; the kernel below then
         // only produces grad_loc / grad_attn (VAR 2)
-        const bool try_tiled = shapes_host && lstart_host && workspace && var_env != 0 && var_env != 1 &&
+        const bool try_tiled = shapes_host && lstart_host && workspace && var_env != 0 && var_env != 1 && bwd_env != 2 &&
                                msda_tiled_workspace_bytes(shapes_host, lstart_host, B, S, M, D, L, Lq, P) > 0 &&
                                msda_tiled_workspace_bytes(shapes_host, lstart_host, B, S, M, D, L, Lq, P) <= workspace_bytes;
         unsigned *absmax2 = try_tiled ? static_cast<unsigned *>(workspace) : nullptr;
@@ -871,9 +880,15 @@ hipError_t msda_backward_bf16_launch(const void *value, const int64_t *shapes, c
     if (D != 32 || L != 4 || P != 4) return hipErrorNotSupported;
     const int64_t nv = static_cast<int64_t>(B) * S * M * D;
     hipError_t err;
+    const int bwd_env = [] { const char *ev = getenv("MDETR_MSDA_BWD"); return !ev || !*ev || ev[0] == 'f' ? 0 : (ev[0] == 't' ? 1 : 2); }();
+    if (bwd_env == 0 && static_cast<int64_t>(B) * Lq * M && shapes_host && lstart_host && workspace) {
+        err = msda_backward_fused_launch(shapes_host, lstart_host, value, loc, attn, grad_out, grad_value, grad_loc, grad_attn,
+                                         workspace, workspace_bytes, B, S, M, D, L, Lq, P, 2, st);
+        if (err != hipErrorNotSupported) return err;
+    }
     if (nv && (err = zero_fill_launch(grad_value, nv * 4, st)) != hipSuccess) return err;
     if (static_cast<int64_t>(B) * Lq * M == 0) return hipSuccess;
-    const bool try_tiled = shapes_host && lstart_host && workspace &&
+    const bool try_tiled = shapes_host && lstart_host && workspace && bwd_env != 2 &&
                            msda_tiled_workspace_bytes(shapes_host, lstart_host, B, S, M, D, L, Lq, P) > 0 &&
                            msda_tiled_workspace_bytes(shapes_host, lstart_host, B, S, M, D, L, Lq, P) <= workspace_bytes;
     unsigned *absmax2 = try_tiled ? static_cast<unsigned *>(workspace) : nullptr;

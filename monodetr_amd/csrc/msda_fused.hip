@@ -1,0 +1,665 @@
+// monodetr_amd/csrc/msda_fused.hip -- the whole MSDA backward (reference: ms_deformable_col2im_gpu_kernel_*,
+// ms_deform_im2col_cuda.cuh:301-920, and its launcher :956-1326) as ONE kernel per call, D = 32:
+// grad_value, grad_sampling_loc and grad_attn_weight from a single pass over loc / attn / grad_out.
+//
+// What it replaces (round 1: msda.hip `msda_bwd_d32<..,2>` + msda_tiled.hip `msda_scatter_tiles` +
+// `msda_reduce_tiles`, 1.14 ms for the encoder call): a gather kernel that produced d/d(loc), d/d(attn), a scatter
+// kernel that re-read loc / attn / grad_out and accumulated grad_value in LDS windows WITH A HALO as int64 fixed point
+// (one `ds_add_u64` per corner and CHANNEL = 1.34 G LDS atomics, 27 % of its issue slots in the f64 conversion), the
+// windows written to a 266 MB scratch buffer and re-read by a reduce kernel: 2.26 GB of HBM traffic for 0.5 GB of
+// algorithmic bytes (profiles/r01_msda_pmc.md).
+//
+// Here:
+//   * a workgroup owns (image b, head m, level l, CORE tile of level-l cells) -- cores partition the level, so the
+//     window has no halo and is stored straight into grad_value: no scratch round trip, no reduce pass, no zero-fill
+//     of grad_value.  Instead of the WINDOW carrying a halo, the set of QUERIES a block looks at does: every query
+//     whose pyramid position lies within R cells of the core is a candidate; a candidate's corners that fall into the
+//     core are accumulated, the others belong to a neighbouring block (which sees the same query as ITS candidate).
+//     Each sample has exactly one OWNER block (the one whose core holds the query's own position) which also gathers
+//     the four value rows and produces d/d(loc), d/d(attn) -- the separate gather kernel is gone.
+//   * accumulation: TWO channels per 64-bit LDS atomic and no conversion instructions at all.  A contribution
+//     x = w * (attn * g * 2^s) is rounded to an integer by ONE fp32 FMA with the addend 1.5 * 2^23 (the integer
+//     appears in the low mantissa bits, RNE, |x| < 2^22); the raw IEEE bit patterns of two such results -- exactly what
+//     a `v_pk_fma_f32` leaves in a 64-bit register pair -- are added with one `ds_add_u64`.  Integer addition is
+//     associative, so the sum is exact and order-independent (deterministic, unlike the reference's fp32 atomics);
+//     the constant exponent bits are removed at read-out with the cell's contribution count n (one 32-bit LDS
+//     atomic per corner and SAMPLE, not per channel):  sum - n * (C << 32 | C)  leaves  (sum_hi << 32) + sum_lo  in
+//     two's complement.  |sum| < 2^31 needs n < 512: the count is checked after the pass and, should a cell have
+//     drawn more, the block repeats its pass with contributions pre-scaled by 1/2 (never on the shapes measured).
+//   * levels small enough to be held whole (12x40, 6x20: a QUARTER of the pyramid's cells each receives as many samples
+//     as level 0) are accumulated per chunk of queries; their partial windows go to a small scratch buffer
+//     (39 MB for the encoder call) and a finalize kernel adds them in a fixed order.
+//   * a corner that lands outside every block's reach (learned offsets > R cells) is added by its owner with a global
+//     fp32 atomic into a side buffer (`far`), which the finalize kernel folds into grad_value only when a device flag
+//     says that happened: arbitrary sampling locations stay correct, only slower.  Non-finite grad_out / attn
+//     (no scale exists) take that route for every corner, reproducing the reference's NaN / inf propagation.
+//   * cross-attention (Lq != S, the decoder: 550 queries): blocks tile the levels the same way and every block scans
+//     all queries (2200 samples per level) -- no global atomic at all; the owner of a sample is the tile holding its
+//     first corner.
+//
+// Work unit sizes (B = 8, M = 8, encoder): per (b, m) 15 + 6 core tiles (16 x 32 cells) on levels 0 / 1 and 8 + 8 query
+// chunks on levels 2 / 3; a level-0 block looks at ~1 100 queries (510 own) x 4 points.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mdetr_wave.h>
+
+#include "msda.h"
+
+namespace mdetr {
+namespace {
+
+constexpr int kMaxLevels = 4;
+constexpr int kCH = 32;               // channels per head (fast path geometry)
+constexpr int kThreads = 512;         // 8 waves per workgroup
+constexpr int kWavesF = kThreads / 64;
+constexpr int kRecDw = 12;            // per-sample record, 48 B
+constexpr int kCellU64 = kCH / 2;     // packed channel pairs per cell (128 B)
+constexpr int kTrash = 8;             // sink rows for corners that are not this block's business (one per record slot mod 8)
+constexpr int kMaxCells = 1024;       // (1024 + 8) * 128 B + 4 KB counts + 24 KB records < 160 KB
+constexpr unsigned long long kCookie = 0x6d64657472667573ull;
+
+// workspace header (first 256 bytes)
+struct Header {
+    unsigned absmax_g, absmax_a;      // bit patterns of max|grad_out|, max|attn| (inf: something non-finite)
+    unsigned far;                     // some block added into the `far` buffer during this call
+    unsigned pad;
+    unsigned long long cookie;        // kCookie once the `far` buffer is known to be all zero between calls ...
+    unsigned long long far_elems;     // ... over this many floats (a call of another size lays the workspace out differently)
+};
+
+struct FusedPlan {
+    int B, S, M, L, P, Lq;
+    int H[kMaxLevels], W[kMaxLevels], start[kMaxLevels];
+    int mode[kMaxLevels];             // 0: core tiles, candidates = queries within R cells (self-attention over the pyramid)
+                                      // 1: whole level resident, queries split into chunks, partial windows -> scratch
+                                      // 2: core tiles, every block scans all queries (cross-attention)
+    int TH[kMaxLevels], TW[kMaxLevels], nty[kMaxLevels], ntx[kMaxLevels], R[kMaxLevels];
+    int nchunk[kMaxLevels];
+    int blk0[kMaxLevels], nblk[kMaxLevels], nblocks;      // blocks of one (b, m): level l owns [blk0[l], blk0[l] + nblk[l])
+    long long scr0[kMaxLevels];       // float offset of level l's partial windows within one (b, m) slab (mode 1)
+    long long scr_per_bm;
+    int max_cells;
+};
+
+// ---- tiny helpers ---------------------------------------------------------------------------------
+__host__ __device__ inline int ceil_div_ll(long long a, long long b)   // b > 0, any sign of a
+{
+    return static_cast<int>(a >= 0 ? (a + b - 1) / b : -((-a) / b));
+}
+
+// cell of level l (extent n_l) that holds the centre of cell y of a level with extent n_q
+__host__ __device__ inline int centre_cell(int y, int n_l, int n_q)
+{
+    return static_cast<int>((static_cast<long long>(2 * y + 1) * n_l) / (2LL * n_q));
+}
+
+// first y in [0, n_q] with centre_cell(y) >= t   (monotone in y)
+__host__ __device__ inline int first_at_or_after(int t, int n_l, int n_q)
+{
+    const int y = ceil_div_ll(2LL * t * n_q - n_l, 2LL * n_l);
+    return y < 0 ? 0 : (y > n_q ? n_q : y);
+}
+
+__device__ __forceinline__ float pix_coord_f(float loc, int size)
+{
+#pragma clang fp contract(off)
+    const float prod = loc * static_cast<float>(size);       // .cuh:285-286: product rounded, then - 0.5
+    return prod - 0.5f;
+}
+
+__device__ __forceinline__ float sum8f(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    return v;
+}
+
+// ---- 1. scale pre-pass: max|grad_out|, max|attn| (and the first-use zero fill of the `far` buffer) ---------------
+template <typename GT>
+__global__ __launch_bounds__(256)
+void msda_absmax_kernel(const GT *__restrict__ g, int64_t ng, const float *__restrict__ a, int64_t na,
+                        Header *__restrict__ hdr, float *__restrict__ far, int64_t nfar)
+{
+    // ng, na are multiples of 4; bases 16-byte aligned
+    float mg = 0.f, ma = 0.f, poison = 0.f;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    const int64_t tid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    for (int64_t i = tid; i < ng / 4; i += stride) {
+        const float4 v = Elem<GT>::load4(reinterpret_cast<const char *>(g) + i * 4 * Elem<GT>::kBytes);
+        mg = fmaxf(fmaxf(mg, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        poison += (v.x + v.y + v.z + v.w) * 0.f;             // NaN, or inf * 0, poisons the sum
+    }
+    for (int64_t i = tid; i < na / 4; i += stride) {
+        const float4 v = *reinterpret_cast<const float4 *>(a + i * 4);
+        ma = fmaxf(fmaxf(ma, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        poison += (v.x + v.y + v.z + v.w) * 0.f;
+    }
+    if (!(poison == 0.f)) mg = __builtin_inff();
+    for (int o = 32; o > 0; o >>= 1) { mg = fmaxf(mg, __shfl_xor(mg, o)); ma = fmaxf(ma, __shfl_xor(ma, o)); }
+    if ((threadIdx.x & 63) == 0) {                            // non-negative floats order like their bit patterns
+        atomicMax(&hdr->absmax_g, __builtin_bit_cast(unsigned, mg));
+        atomicMax(&hdr->absmax_a, __builtin_bit_cast(unsigned, ma));
+    }
+    // a workspace this library has not finalized yet (fresh allocation): its `far` buffer may hold anything
+    if (hdr->cookie != kCookie || hdr->far_elems != static_cast<unsigned long long>(nfar)) {
+        float4 *f4 = reinterpret_cast<float4 *>(far);
+        for (int64_t i = tid; i < nfar / 4; i += stride) f4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// ---- 2. the fused backward -----------------------------------------------------------------------------------------
+struct Work {
+    int l, mode;
+    int cy0, cx0;                      // core origin in level-l cells
+    int tstride;                       // cells per window row
+    int ncell;                         // window cells (stride-based)
+    int y0[kMaxLevels], y1[kMaxLevels], x0[kMaxLevels], x1[kMaxLevels];   // mode 0: candidate rectangle per query level
+    int q0, nq;                        // number of candidate queries (mode 1 / 2: contiguous from q0)
+    int slot;                          // tile / chunk index within the level
+};
+
+__device__ __forceinline__ Work decode_block(const FusedPlan &pl, int k)
+{
+    Work w;
+    int l = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxLevels; ++i)
+        if (i < pl.L && k >= pl.blk0[i] && k < pl.blk0[i] + pl.nblk[i]) l = i;
+    w.l = l;
+    w.mode = pl.mode[l];
+    const int t = k - pl.blk0[l];
+    w.slot = t;
+    w.q0 = 0;
+    w.nq = 0;
+#pragma unroll
+    for (int lq = 0; lq < kMaxLevels; ++lq) w.y0[lq] = w.y1[lq] = w.x0[lq] = w.x1[lq] = 0;
+    if (w.mode == 1) {
+        w.cy0 = 0; w.cx0 = 0; w.tstride = pl.W[l]; w.ncell = pl.H[l] * pl.W[l];
+        const int nch = pl.nchunk[l];
+        w.q0 = static_cast<int>(static_cast<long long>(pl.Lq) * t / nch);
+        w.nq = static_cast<int>(static_cast<long long>(pl.Lq) * (t + 1) / nch) - w.q0;
+    } else {
+        const int ty = t / pl.ntx[l], tx = t % pl.ntx[l];
+        w.cy0 = ty * pl.TH[l]; w.cx0 = tx * pl.TW[l]; w.tstride = pl.TW[l]; w.ncell = pl.TH[l] * pl.TW[l];
+        if (w.mode == 2) {
+            w.nq = pl.Lq;
+        } else {
+            const int R = pl.R[l];
+#pragma unroll
+            for (int lq = 0; lq < kMaxLevels; ++lq) {
+                if (lq >= pl.L) continue;
+                w.y0[lq] = first_at_or_after(w.cy0 - R, pl.H[l], pl.H[lq]);
+                w.y1[lq] = first_at_or_after(w.cy0 + pl.TH[l] + R, pl.H[l], pl.H[lq]);
+                w.x0[lq] = first_at_or_after(w.cx0 - R, pl.W[l], pl.W[lq]);
+                w.x1[lq] = first_at_or_after(w.cx0 + pl.TW[l] + R, pl.W[l], pl.W[lq]);
+                w.nq += (w.y1[lq] - w.y0[lq]) * (w.x1[lq] - w.x0[lq]);
+            }
+        }
+    }
+    return w;
+}
+
+// i-th candidate query of a mode-0 block -> flattened query index and its centre cell on level l
+__device__ __forceinline__ int nth_query(const FusedPlan &pl, const Work &w, int i, int &qcy, int &qcx)
+{
+    int q = 0;
+    bool done = false;
+    qcy = qcx = 0;
+#pragma unroll
+    for (int lq = 0; lq < kMaxLevels; ++lq) {
+        const int wx = w.x1[lq] - w.x0[lq], n = (w.y1[lq] - w.y0[lq]) * wx;
+        if (!done && i < n) {
+            const int y = w.y0[lq] + i / wx, x = w.x0[lq] + i % wx;
+            q = pl.start[lq] + y * pl.W[lq] + x;
+            qcy = centre_cell(y, pl.H[w.l], pl.H[lq]);
+            qcx = centre_cell(x, pl.W[w.l], pl.W[lq]);
+            done = true;
+        }
+        i -= n;
+    }
+    return q;
+}
+
+// four corner contributions of one sample for the 4 channels of this lane: 8 FMAs, 8 ds_add_u64
+__device__ __forceinline__ void accumulate4(unsigned long long *win, unsigned o01, unsigned o23, const float (&wt)[4],
+                                            const float4 &ag, int k, float magic)
+{
+    const unsigned cell[4] = {o01 & 0xFFFFu, o01 >> 16, o23 & 0xFFFFu, o23 >> 16};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        unsigned long long *p = win + cell[c] * kCellU64 + 2 * k;
+        const unsigned b0 = __builtin_bit_cast(unsigned, __builtin_fmaf(wt[c], ag.x, magic));
+        const unsigned b1 = __builtin_bit_cast(unsigned, __builtin_fmaf(wt[c], ag.y, magic));
+        const unsigned b2 = __builtin_bit_cast(unsigned, __builtin_fmaf(wt[c], ag.z, magic));
+        const unsigned b3 = __builtin_bit_cast(unsigned, __builtin_fmaf(wt[c], ag.w, magic));
+        __hip_atomic_fetch_add(p, (static_cast<unsigned long long>(b1) << 32) | b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p + 1, (static_cast<unsigned long long>(b3) << 32) | b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+template <typename VT, typename GT>
+__global__ __launch_bounds__(kThreads)
+void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const float *__restrict__ loc,
+                    const float *__restrict__ attn, const GT *__restrict__ grad_out,
+                    float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
+                    Header *__restrict__ hdr, float *__restrict__ scratch, float *__restrict__ far)
+{
+    MDETR_DYNAMIC_LDS(unsigned char, smem_raw);
+    unsigned long long *win = reinterpret_cast<unsigned long long *>(smem_raw);
+    unsigned *cnt = reinterpret_cast<unsigned *>(smem_raw + static_cast<size_t>(pl.max_cells + kTrash) * kCellU64 * 8);
+    unsigned *recs = cnt + pl.max_cells;
+    unsigned *blk = recs + kWavesF * 64 * kRecDw;            // [0] = max count of the pass
+
+    const int bid = blockIdx.x;
+    const int b = bid % pl.B, r_ = bid / pl.B, m = r_ % pl.M, kblk = r_ / pl.M;      // image -> XCD (bid % 8)
+    const Work w = decode_block(pl, kblk);
+    const int l = w.l, H = pl.H[l], W = pl.W[l], TH = w.mode == 1 ? H : pl.TH[l], TW = w.mode == 1 ? W : pl.TW[l];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int P = pl.P, LP = pl.L * P, M = pl.M;
+    const int j = lane >> 3, k = lane & 7;
+    constexpr int eb = Elem<VT>::kBytes;
+    const int rowb = M * kCH * eb;                            // bytes from a pixel to the next, `value`
+    const char *vlev = reinterpret_cast<const char *>(value) + ((static_cast<int64_t>(b) * pl.S + pl.start[l]) * M + m) * (kCH * eb) + k * 4 * eb;
+    const int64_t pair0 = static_cast<int64_t>(b) * pl.Lq * M + m;                    // pair index of query q: pair0 + q * M
+    float *far_lev = far + ((static_cast<int64_t>(b) * pl.S + pl.start[l]) * M + m) * kCH + k * 4;
+    unsigned *wrec = recs + wave * 64 * kRecDw;
+
+    // one power-of-two scale per call: |w * attn * g| <= max|attn| * max|g| = mx < 2^e
+    const float mx = __builtin_bit_cast(float, hdr->absmax_g) * __builtin_bit_cast(float, hdr->absmax_a);
+    const bool finite = mx <= 3.0e38f;                        // inf / NaN somewhere: every corner goes to the `far` buffer
+    int e = 0;
+    if (finite && mx > 0.f) (void)frexpf(mx, &e);
+    const int nsamp = w.nq * P;
+
+    for (int shift = 0;; ++shift) {
+        // contributions are rounded to multiples of 2^-(22 - shift - e): |x| * scale < 2^(22 - shift), up to 2^(9 + shift) - 1 per cell
+        const float scale = ldexpf(1.0f, 22 - shift - e);
+        const float magic = ldexpf(1.0f, 23) + ldexpf(1.0f, 22 - shift);
+        for (int i = threadIdx.x; i < (w.ncell + kTrash) * kCellU64; i += kThreads) win[i] = 0ull;
+        for (int i = threadIdx.x; i < w.ncell; i += kThreads) cnt[i] = 0u;
+        if (threadIdx.x == 0) blk[0] = 0u;
+        __syncthreads();
+
+        for (int base = wave * 64; base < nsamp; base += kWavesF * 64) {
+            // ---- a. one candidate sample per lane: footprint, ownership, record ----------------------------------------
+            bool keep = false, owned = false;
+            unsigned rec[kRecDw];
+            {
+                const int i = base + lane;
+                const bool act = i < nsamp;
+                const int qi = act ? i / P : 0, p = act ? i - qi * P : 0;
+                int q, qcy = 0, qcx = 0;
+                if (w.mode == 0) {
+                    q = nth_query(pl, w, qi, qcy, qcx);
+                    owned = qcy >= w.cy0 && qcy < w.cy0 + TH && qcx >= w.cx0 && qcx < w.cx0 + TW;
+                } else {
+                    q = w.q0 + qi;
+                    owned = w.mode == 1;
+                }
+                const int64_t srec = (pair0 + static_cast<int64_t>(q) * M) * LP + l * P + p;
+                const float2 xy = act ? *reinterpret_cast<const float2 *>(loc + srec * 2) : make_float2(-9.f, -9.f);
+                const float a_in = act ? attn[srec] : 0.f;
+                const float h_im = pix_coord_f(xy.y, H), w_im = pix_coord_f(xy.x, W);
+                const bool inwin = h_im > -1.f && w_im > -1.f && h_im < static_cast<float>(H) && w_im < static_cast<float>(W);   // .cuh:288
+                const float hs = inwin ? h_im : 0.f, ws = inwin ? w_im : 0.f;
+                const float hf = floorf(hs), wf = floorf(ws);
+                const int y = static_cast<int>(hf), x = static_cast<int>(wf);
+                const float lh = hs - hf, lw = ws - wf, hh = 1.f - lh, hw = 1.f - lw;
+                const float cw[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+                const int yc0 = min(max(y, 0), H - 1), yc1 = min(max(y + 1, 0), H - 1);
+                const int xc0 = min(max(x, 0), W - 1), xc1 = min(max(x + 1, 0), W - 1);
+                if (w.mode == 2) owned = yc0 >= w.cy0 && yc0 < w.cy0 + TH && xc0 >= w.cx0 && xc0 < w.cx0 + TW;
+                owned = owned && act;
+                unsigned cell[4], valid = 0u, farm = 0u;
+                float wt[4];
+                bool anycore = false;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int yy = y + (c >> 1), xx = x + (c & 1);
+                    const bool inmap = act && inwin && yy >= 0 && yy <= H - 1 && xx >= 0 && xx <= W - 1;  // .cuh:56-74
+                    wt[c] = inmap ? cw[c] : 0.f;
+                    valid |= inmap ? (1u << c) : 0u;
+                    // grad_value: a corner of bilinear weight exactly 0 (integer pixel coordinates, as the model's initial
+                    // offsets produce) adds exactly 0 for finite gradients -- it is neither accumulated nor counted
+                    const bool ok = inmap && (wt[c] != 0.f || !finite);
+                    const int wy = yy - w.cy0, wx = xx - w.cx0;
+                    const bool core = ok && finite && wy >= 0 && wy < TH && wx >= 0 && wx < TW;
+                    cell[c] = core ? static_cast<unsigned>(wy * w.tstride + wx) : 0xFFFFu;
+                    anycore = anycore || core;
+                    if (ok && !core && owned) {
+                        bool other = false;                   // does the block that owns this cell look at this query?
+                        if (finite && w.mode == 0) {
+                            const int ty = yy / TH, tx = xx / TW, R = pl.R[l];
+                            other = qcy >= ty * TH - R && qcy < (ty + 1) * TH + R && qcx >= tx * TW - R && qcx < (tx + 1) * TW + R;
+                        } else if (finite && w.mode == 2) {
+                            other = true;
+                        }
+                        farm |= other ? 0u : (1u << c);
+                    }
+                }
+                keep = owned || anycore;
+                rec[0] = static_cast<unsigned>(q);
+                rec[1] = static_cast<unsigned>(yc0 * W + xc0) | (static_cast<unsigned>(xc1 - xc0) << 30) | (static_cast<unsigned>(yc1 - yc0) << 31);
+                rec[2] = cell[0] | (cell[1] << 16);
+                rec[3] = cell[2] | (cell[3] << 16);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rec[4 + c] = __builtin_bit_cast(unsigned, wt[c]);
+                rec[8] = __builtin_bit_cast(unsigned, inwin ? a_in : 0.f);
+                rec[9] = __builtin_bit_cast(unsigned, lh);
+                rec[10] = __builtin_bit_cast(unsigned, lw);
+                rec[11] = valid | (farm << 4) | (static_cast<unsigned>(p) << 8);
+            }
+            const unsigned long long mo = __ballot(keep && owned), mh = __ballot(keep && !owned);
+            const int no = __popcll(mo), nh = __popcll(mh);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (keep) {
+                const int slot = owned ? __popcll(mo & below) : 63 - __popcll(mh & below);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {                 // this block's cells: count the contribution, other corners -> sink row
+                    const unsigned cc = (c < 2 ? rec[2] >> (16 * c) : rec[3] >> (16 * (c - 2))) & 0xFFFFu;
+                    if (cc != 0xFFFFu) atomicAdd(cnt + cc, 1u);
+                }
+                const unsigned sink = static_cast<unsigned>(w.ncell + (slot & 7));
+                const unsigned c0 = rec[2] & 0xFFFFu, c1 = rec[2] >> 16, c2 = rec[3] & 0xFFFFu, c3 = rec[3] >> 16;
+                rec[2] = (c0 == 0xFFFFu ? sink : c0) | ((c1 == 0xFFFFu ? sink : c1) << 16);
+                rec[3] = (c2 == 0xFFFFu ? sink : c2) | ((c3 == 0xFFFFu ? sink : c3) << 16);
+                unsigned *dst = wrec + slot * kRecDw;
+                *reinterpret_cast<uint4 *>(dst) = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+                *reinterpret_cast<uint4 *>(dst + 4) = make_uint4(rec[4], rec[5], rec[6], rec[7]);
+                *reinterpret_cast<uint4 *>(dst + 8) = make_uint4(rec[8], rec[9], rec[10], rec[11]);
+            }
+            wave_sync();
+
+            // ---- b1. own samples, 8 per step, 8 lanes x 4 channels each: accumulate, gather, d/d(loc), d/d(attn) ----------
+            for (int i0 = 0; i0 < no; i0 += 8) {
+                const bool on = i0 + j < no;                  // (the tail group of a list is partly empty)
+                float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f, a = 0.f, lh = 0.f, lw = 0.f;
+                float wt[4] = {0.f, 0.f, 0.f, 0.f};
+                unsigned flags = 0u;
+                int64_t pair = 0;
+                if (on) {
+                    const unsigned *rr = wrec + (i0 + j) * kRecDw;
+                    const uint4 r0 = *reinterpret_cast<const uint4 *>(rr);
+                    const uint4 r1 = *reinterpret_cast<const uint4 *>(rr + 4);
+                    const uint4 r2 = *reinterpret_cast<const uint4 *>(rr + 8);
+                    pair = pair0 + static_cast<int64_t>(r0.x) * M;
+                    const float4 g = Elem<GT>::load4(reinterpret_cast<const char *>(grad_out) + (pair * kCH + k * 4) * Elem<GT>::kBytes);
+                    const unsigned pix = r0.y & 0xFFFFFFu;
+                    const int dxb = (r0.y >> 30) & 1u ? rowb : 0, dyb = (r0.y >> 31) ? W * rowb : 0;
+                    const char *vb = vlev + static_cast<int64_t>(pix) * rowb;
+                    const float4 v0 = Elem<VT>::load4(vb), v1 = Elem<VT>::load4(vb + dxb);
+                    const float4 v2 = Elem<VT>::load4(vb + dyb), v3 = Elem<VT>::load4(vb + dyb + dxb);
+                    wt[0] = __builtin_bit_cast(float, r1.x); wt[1] = __builtin_bit_cast(float, r1.y);
+                    wt[2] = __builtin_bit_cast(float, r1.z); wt[3] = __builtin_bit_cast(float, r1.w);
+                    a = __builtin_bit_cast(float, r2.x); lh = __builtin_bit_cast(float, r2.y); lw = __builtin_bit_cast(float, r2.z);
+                    flags = r2.w;
+                    if (finite) {
+                        const float as = a * scale;
+                        accumulate4(win, r0.z, r0.w, wt, make_float4(as * g.x, as * g.y, as * g.z, as * g.w), k, magic);
+                    }
+                    if ((flags & 0xF0u) && shift == 0) {      // corners nobody else will see: global fp32 atomics (.cuh:125-152)
+                        const float4 tg = make_float4(a * g.x, a * g.y, a * g.z, a * g.w);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (flags & (16u << c)) {
+                                float *p = far_lev + (static_cast<int64_t>(pix) + ((c & 1) && (r0.y >> 30 & 1u) ? 1 : 0) + ((c >> 1) && (r0.y >> 31) ? W : 0)) * (M * kCH);
+                                unsafeAtomicAdd(p + 0, wt[c] * tg.x);
+                                unsafeAtomicAdd(p + 1, wt[c] * tg.y);
+                                unsafeAtomicAdd(p + 2, wt[c] * tg.z);
+                                unsafeAtomicAdd(p + 3, wt[c] * tg.w);
+                            }
+                        }
+                        if (k == 0) hdr->far = 1u;
+                    }
+                    e0 = g.x * v0.x + g.y * v0.y + g.z * v0.z + g.w * v0.w;
+                    e1 = g.x * v1.x + g.y * v1.y + g.z * v1.z + g.w * v1.w;
+                    e2 = g.x * v2.x + g.y * v2.y + g.z * v2.z + g.w * v2.w;
+                    e3 = g.x * v3.x + g.y * v3.y + g.z * v3.z + g.w * v3.w;
+                }
+                float d0 = sum8f(e0), d1 = sum8f(e1), d2 = sum8f(e2), d3 = sum8f(e3);    // over the 8 lanes of the sample, every lane takes part
+                d0 = (flags & 1u) ? d0 : 0.f; d1 = (flags & 2u) ? d1 : 0.f;              // a corner outside the map reads nothing (.cuh:56-78)
+                d2 = (flags & 4u) ? d2 : 0.f; d3 = (flags & 8u) ? d3 : 0.f;
+                if (on && k == 0) {
+                    const float hh = 1.f - lh, hw = 1.f - lw;
+                    const int p = (flags >> 8) & 15u;
+                    const int64_t o = pair * LP + l * P + p;
+                    grad_attn[o] = wt[0] * d0 + wt[1] * d1 + wt[2] * d2 + wt[3] * d3;                                      // .cuh:156
+                    reinterpret_cast<float2 *>(grad_loc)[o] = make_float2(static_cast<float>(W) * (a * (hh * (d1 - d0) + lh * (d3 - d2))),   // .cuh:157
+                                                                           static_cast<float>(H) * (a * (hw * (d2 - d0) + lw * (d3 - d1))));  // .cuh:158
+                }
+            }
+            // ---- b2. neighbours' samples that reach into this core: accumulate only ---------------------------------------
+            for (int i0 = 0; i0 < nh; i0 += 8) {
+                if (i0 + j < nh) {
+                    const unsigned *rr = wrec + (64 - nh + i0 + j) * kRecDw;
+                    const uint4 r0 = *reinterpret_cast<const uint4 *>(rr);
+                    const uint4 r1 = *reinterpret_cast<const uint4 *>(rr + 4);
+                    const float a = __builtin_bit_cast(float, rr[8]);
+                    const int64_t pair = pair0 + static_cast<int64_t>(r0.x) * M;
+                    const float4 g = Elem<GT>::load4(reinterpret_cast<const char *>(grad_out) + (pair * kCH + k * 4) * Elem<GT>::kBytes);
+                    const float wt[4] = {__builtin_bit_cast(float, r1.x), __builtin_bit_cast(float, r1.y),
+                                         __builtin_bit_cast(float, r1.z), __builtin_bit_cast(float, r1.w)};
+                    const float as = a * scale;
+                    accumulate4(win, r0.z, r0.w, wt, make_float4(as * g.x, as * g.y, as * g.z, as * g.w), k, magic);
+                }
+            }
+            wave_sync();
+        }
+        __syncthreads();
+
+        // ---- c. did any cell draw more contributions than a 32-bit field holds at this scale? ---------------------------
+        {
+            unsigned mc = 0u;
+            for (int i = threadIdx.x; i < w.ncell; i += kThreads) mc = max(mc, cnt[i]);
+            for (int o = 32; o > 0; o >>= 1) mc = max(mc, __shfl_xor(mc, o));
+            if (lane == 0) atomicMax(blk, mc);
+        }
+        __syncthreads();
+        const unsigned maxcnt = blk[0];
+        __syncthreads();
+        if (!finite || maxcnt < (512u << shift) || shift >= 12) {
+            // ---- d. read-out: strip the n * (magic bits) the atomics added along, store ----------------------------------
+            const unsigned long long cbits = static_cast<unsigned long long>(__builtin_bit_cast(unsigned, magic)) * 0x100000001ull;
+            const float inv = finite ? ldexpf(1.0f, -(22 - shift - e)) : 0.f;
+            float *dst1 = scratch + (static_cast<int64_t>(b) * M + m) * pl.scr_per_bm + pl.scr0[l] + static_cast<int64_t>(w.slot) * w.ncell * kCH;
+            float *dst0 = grad_value + ((static_cast<int64_t>(b) * pl.S + pl.start[l]) * M + m) * kCH;
+            for (int i = threadIdx.x; i < w.ncell * kCellU64; i += kThreads) {
+                const int cell = i / kCellU64, pr = i % kCellU64;
+                const unsigned long long s = win[i] - static_cast<unsigned long long>(cnt[cell]) * cbits;
+                const int lo = static_cast<int>(static_cast<unsigned>(s));
+                const int hi = static_cast<int>((static_cast<long long>(s) - static_cast<long long>(lo)) >> 32);
+                const float2 out = make_float2(static_cast<float>(lo) * inv, static_cast<float>(hi) * inv);
+                if (w.mode == 1) {
+                    *reinterpret_cast<float2 *>(dst1 + static_cast<int64_t>(cell) * kCH + 2 * pr) = out;
+                } else {
+                    const int yy = w.cy0 + cell / w.tstride, xx = w.cx0 + cell % w.tstride;
+                    if (yy < H && xx < W)                     // cores partition the level: exclusive owner, plain store
+                        *reinterpret_cast<float2 *>(dst0 + static_cast<int64_t>(yy * W + xx) * (M * kCH) + 2 * pr) = out;
+                }
+            }
+            break;
+        }
+    }
+}
+
+// ---- 3. finalize: sum the query chunks of the small levels; fold the `far` buffer in if it was used ------------------
+__global__ __launch_bounds__(256)
+void msda_finalize_kernel(const FusedPlan pl, const float *__restrict__ scratch, float *__restrict__ far,
+                          float *__restrict__ grad_value, Header *__restrict__ hdr)
+{
+    // 8 lanes x float4 per (b, pixel, m) row of 32 channels
+    const int64_t gid = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (gid == 0) {                                          // from here on the `far` buffer is all zero between calls
+        hdr->cookie = kCookie;
+        hdr->far_elems = static_cast<unsigned long long>(pl.B) * pl.S * pl.M * kCH;
+    }
+    const int64_t row = gid >> 3;
+    const int c4 = static_cast<int>(gid & 7) * 4;
+    const int64_t nrows = static_cast<int64_t>(pl.B) * pl.S * pl.M;
+    if (row >= nrows) return;
+    const bool use_far = hdr->far != 0u;
+    const int m = static_cast<int>(row % pl.M);
+    const int64_t bp = row / pl.M;
+    const int pix = static_cast<int>(bp % pl.S), b = static_cast<int>(bp / pl.S);
+    int l = 0;
+    while (l + 1 < pl.L && pix >= pl.start[l + 1]) ++l;
+    const bool chunks = pl.mode[l] == 1;
+    if (!chunks && !use_far) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (chunks) {
+        const int ncell = pl.H[l] * pl.W[l];
+        const float *base = scratch + (static_cast<int64_t>(b) * pl.M + m) * pl.scr_per_bm + pl.scr0[l] +
+                            static_cast<int64_t>(pix - pl.start[l]) * kCH + c4;
+        for (int t = 0; t < pl.nchunk[l]; ++t) {              // fixed order: deterministic
+            const float4 v = *reinterpret_cast<const float4 *>(base + static_cast<int64_t>(t) * ncell * kCH);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    } else {
+        acc = *reinterpret_cast<const float4 *>(grad_value + row * kCH + c4);
+    }
+    if (use_far) {
+        float4 *f = reinterpret_cast<float4 *>(far + row * kCH + c4);
+        const float4 v = *f;
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        *f = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    *reinterpret_cast<float4 *>(grad_value + row * kCH + c4) = acc;
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------------
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, int B, int S, int M, int L, int Lq, int P)
+{
+    if (L < 1 || L > kMaxLevels || P < 1 || P > 8 || B < 1 || M < 1 || Lq < 1) return false;
+    memset(&pl, 0, sizeof(pl));
+    pl.B = B; pl.S = S; pl.M = M; pl.L = L; pl.P = P; pl.Lq = Lq;
+    int64_t total = 0;
+    for (int l = 0; l < L; ++l) {
+        pl.H[l] = static_cast<int>(shapes_h[2 * l]);
+        pl.W[l] = static_cast<int>(shapes_h[2 * l + 1]);
+        pl.start[l] = static_cast<int>(start_h[l]);
+        if (pl.H[l] <= 0 || pl.W[l] <= 0 || pl.start[l] != total) return false;
+        if (static_cast<int64_t>(pl.H[l]) * pl.W[l] >= (1 << 24)) return false;      // pixel index is packed in 24 bits
+        total += static_cast<int64_t>(pl.H[l]) * pl.W[l];
+    }
+    if (total != S) return false;
+    const bool self = Lq == S;                               // queries = the pyramid's cells, in order
+    if (!self && static_cast<int64_t>(Lq) * P > 16384) return false;   // every block scans every query: only for few queries
+    // tuning knobs (read per call: a handful of getenv()s against a multi-microsecond launch sequence)
+    const int tile_h = env_int("MDETR_MSDA_TILE_H", 16), tile_w = env_int("MDETR_MSDA_TILE_W", 32);
+    const int reach = env_int("MDETR_MSDA_REACH", 5), chunks_env = env_int("MDETR_MSDA_CHUNKS", 8);
+    const int whole_max = env_int("MDETR_MSDA_WHOLE_LEVEL_CELLS", 512);
+    if (tile_h < 1 || tile_w < 1 || tile_h * tile_w > kMaxCells || reach < 0 || chunks_env < 1) return false;
+    int blk = 0;
+    long long scr = 0;
+    pl.max_cells = 0;
+    for (int li = 0; li < L; ++li) {
+        const int l = L - 1 - li;                            // small, sample-dense levels first: their blocks are the longest
+        const int H = pl.H[l], W = pl.W[l];
+        int cells;
+        if (self && H * W <= whole_max) {
+            pl.mode[l] = 1;
+            pl.nchunk[l] = chunks_env < Lq ? chunks_env : Lq;
+            pl.nblk[l] = pl.nchunk[l];
+            cells = H * W;
+            pl.scr0[l] = scr;
+            scr += static_cast<long long>(pl.nchunk[l]) * cells * kCH;
+        } else {
+            pl.mode[l] = self ? 0 : 2;
+            int TH = tile_h < H ? tile_h : H, TW = tile_w < W ? tile_w : W;
+            if (!self && H * W <= kMaxCells) { TH = H; TW = W; }
+            pl.TH[l] = TH; pl.TW[l] = TW; pl.R[l] = reach;
+            pl.nty[l] = (H + TH - 1) / TH;
+            pl.ntx[l] = (W + TW - 1) / TW;
+            pl.nblk[l] = pl.nty[l] * pl.ntx[l];
+            cells = TH * TW;
+        }
+        if (cells > kMaxCells || cells >= 0xFFF0) return false;
+        pl.max_cells = cells > pl.max_cells ? cells : pl.max_cells;
+        pl.blk0[l] = blk;
+        blk += pl.nblk[l];
+    }
+    pl.nblocks = blk;
+    pl.scr_per_bm = scr;
+    return true;
+}
+
+int64_t plan_workspace_bytes(const FusedPlan &pl)
+{
+    return 256 + (static_cast<int64_t>(pl.B) * pl.M * pl.scr_per_bm + static_cast<int64_t>(pl.B) * pl.S * pl.M * kCH) * 4;
+}
+
+}  // namespace
+
+int64_t msda_fused_workspace_bytes(const int64_t *shapes_h, const int64_t *start_h, int B, int S, int M, int D, int L, int Lq, int P)
+{
+    FusedPlan pl;
+    if (D != kCH || !shapes_h || !start_h || !build_plan(pl, shapes_h, start_h, B, S, M, L, Lq, P)) return 0;
+    return plan_workspace_bytes(pl);
+}
+
+// value_dtype / grad_dtype: 0 = f32, 2 = bf16.  Writes all three outputs completely (no pre-zeroing needed).  Returns
+// hipErrorNotSupported when the geometry does not qualify (the caller falls back to the atomic path).
+hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *start_h, const void *value, const float *loc,
+                                      const float *attn, const void *grad_out, float *grad_value, float *grad_loc, float *grad_attn,
+                                      void *workspace, int64_t workspace_bytes, int B, int S, int M, int D, int L, int Lq, int P,
+                                      int elem_dtype, hipStream_t st)
+{
+    FusedPlan pl;
+    if (D != kCH || !shapes_h || !start_h || !build_plan(pl, shapes_h, start_h, B, S, M, L, Lq, P)) return hipErrorNotSupported;
+    if (!workspace || workspace_bytes < plan_workspace_bytes(pl)) return hipErrorNotSupported;
+    if (elem_dtype != 0 && elem_dtype != 2) return hipErrorNotSupported;
+    Header *hdr = static_cast<Header *>(workspace);
+    const int64_t nfar = static_cast<int64_t>(B) * S * M * kCH;
+    float *far = reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + 256);      // [256, 256 + 4 nfar): zero between calls
+    float *scratch = far + nfar;
+    hipError_t err;
+    if ((err = zero_fill_launch(hdr, 16, st)) != hipSuccess) return err;
+    const int64_t n_go = static_cast<int64_t>(B) * Lq * M * D, n_at = static_cast<int64_t>(B) * Lq * M * L * P;
+    if ((L * P) % 4 != 0) return hipErrorNotSupported;       // the pre-pass reads attn in 16-byte pieces
+    profile_begin(7, Lq, st);
+    if (elem_dtype == 2)
+        hipLaunchKernelGGL(msda_absmax_kernel<__hip_bfloat16>, dim3(1024), dim3(256), 0, st, static_cast<const __hip_bfloat16 *>(grad_out), n_go, attn, n_at, hdr, far, nfar);
+    else
+        hipLaunchKernelGGL(msda_absmax_kernel<float>, dim3(1024), dim3(256), 0, st, static_cast<const float *>(grad_out), n_go, attn, n_at, hdr, far, nfar);
+    profile_end(st);
+    const size_t lds = static_cast<size_t>(pl.max_cells + kTrash) * kCellU64 * 8 + static_cast<size_t>(pl.max_cells) * 4 +
+                       static_cast<size_t>(kWavesF) * 64 * kRecDw * 4 + 16;
+    int dev = 0;
+    if ((err = hipGetDevice(&dev)) != hipSuccess) return err;
+    static bool attr_set[2][64] = {};                        // per kernel instance and device
+    const int which = elem_dtype == 2 ? 1 : 0;
+    if (dev < 0 || dev >= 64 || !attr_set[which][dev]) {
+        err = which ? hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_fused<__hip_bfloat16, __hip_bfloat16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                    : hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_fused<float, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (err != hipSuccess) return err;
+        if (dev >= 0 && dev < 64) attr_set[which][dev] = true;
+    }
+    const unsigned nblocks = static_cast<unsigned>(B) * M * pl.nblocks;
+    profile_begin(6, Lq, st);
+    if (which)
+        hipLaunchKernelGGL((msda_bwd_fused<__hip_bfloat16, __hip_bfloat16>), dim3(nblocks), dim3(kThreads), lds, st, pl,
+                           static_cast<const __hip_bfloat16 *>(value), loc, attn, static_cast<const __hip_bfloat16 *>(grad_out),
+                           grad_value, grad_loc, grad_attn, hdr, scratch, far);
+    else
+        hipLaunchKernelGGL((msda_bwd_fused<float, float>), dim3(nblocks), dim3(kThreads), lds, st, pl,
+                           static_cast<const float *>(value), loc, attn, static_cast<const float *>(grad_out),
+                           grad_value, grad_loc, grad_attn, hdr, scratch, far);
+    profile_end(st);
+    const int64_t nrows = static_cast<int64_t>(B) * S * M;
+    profile_begin(8, Lq, st);
+    hipLaunchKernelGGL(msda_finalize_kernel, dim3(static_cast<unsigned>((nrows * 8 + 255) / 256)), dim3(256), 0, st, pl, scratch, far, grad_value, hdr);
+    profile_end(st);
+    return hipGetLastError();
+}
+
+}  // namespace mdetr

@@ -433,13 +433,15 @@ hipError_t msda_tiled_grad_value_launch(const int64_t *shapes_h, const int64_t *
         hipLaunchKernelGGL(absmax2_kernel, dim3(1024), dim3(256), 0, st, static_cast<const float *>(grad_out), n_go, attn, n_at, absmax2);
     }
     const size_t lds = static_cast<size_t>(pl.max_cells) * kCH * 8 + static_cast<size_t>(kWavesT) * 64 * kRecDwords * 4;
-    static bool attr_set[2] = {false, false};
+    static bool attr_set[2][64] = {};                        // per kernel instance and device
     const int which = grad_out_dtype == 2 ? 1 : 0;
-    if (!attr_set[which]) {
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess) dev_ = -1;
+    if (dev_ < 0 || dev_ >= 64 || !attr_set[which][dev_]) {
         err = which ? hipFuncSetAttribute(reinterpret_cast<const void *>(msda_scatter_tiles<__hip_bfloat16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
                     : hipFuncSetAttribute(reinterpret_cast<const void *>(msda_scatter_tiles<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (err != hipSuccess) return err;
-        attr_set[which] = true;
+        if (dev_ >= 0 && dev_ < 64) attr_set[which][dev_] = true;
     }
     const unsigned nblocks = static_cast<unsigned>(B) * M * pl.blk0[L];
     profile_begin(2, Lq, st);

@@ -151,12 +151,14 @@ hipError_t launch(const void *x, const void *w, const void *bias, void *y, int64
     constexpr size_t lds = static_cast<size_t>(NB) * 32 * (K + 8) * 2 + kWavesG * 32 * kSlabPad * 2 + NB * 32 * 4;
     static_assert(lds <= 160 * 1024, "weight block does not fit the LDS");
     auto kern = token_gemm_kernel<K, NB, RELU>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};                           // the attribute is per device: one process may drive several GPUs
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess) dev_ = -1;
+    if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_]) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(lds));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;
     }
     const int64_t tiles = (T + 31) / 32;
     int64_t gx = (tiles + kWavesG - 1) / kWavesG;

@@ -238,8 +238,19 @@ class ResNetBody(nn.Module):
                           and isinstance(b, FrozenBatchNorm2d)]
         return pairs
 
+    def _stash_holders(self):
+        hit = self.__dict__.get("_stash_holder_list")
+        if hit is None:
+            hit = self.__dict__["_stash_holder_list"] = [m for m in self.modules() if isinstance(m, nn.Conv2d)]
+        return hit
+
     def forward(self, x):
         use = self.prefold if self.prefold is not None else x.is_cuda
+        # a forward pass that was interrupted between `prefold` and `conv_bn` (an exception that the caller caught) leaves
+        # per-pass folded weights parked on the convolutions; they must not survive into this pass -- least of all into a
+        # no-grad / eval pass that folds nothing itself and would then run with weights from before the last optimizer step
+        for m in self._stash_holders():
+            m.__dict__.pop("_prefolded", None)
         if use and torch.is_grad_enabled() and not torch.is_autocast_enabled():
             dt = x.dtype if x.dtype in (torch.bfloat16, torch.float16) else None
             pairs = self._trainable_pairs()

@@ -24,18 +24,19 @@ from .... import msda_prologue_ext
 # tests/test_fused_gpu.py)
 _FUSED_PROLOGUE = os.environ.get("MDETR_MSDA_PROLOGUE") == "1"
 
-_checked_shapes = set()
 
 
 def _check_token_count(spatial_shapes, S):
-    """sum(H_l * W_l) == S (reference :136).  The reference evaluates this on the device tensor every
-    call (a device->host sync); here once per (tensor, S)."""
-    key = (spatial_shapes.data_ptr(), spatial_shapes._version, S)
-    if key not in _checked_shapes:
+    """sum(H_l * W_l) == S (reference :136).  The reference evaluates this on the device tensor every call (a
+    device->host sync); here once per (tensor object, version, S) -- remembered ON the tensor, not by its address,
+    which the caching allocator re-issues to later tensors."""
+    seen = getattr(spatial_shapes, "_mdetr_token_count", None)
+    if seen != (spatial_shapes._version, S):
         assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == S
-        if len(_checked_shapes) > 256:
-            _checked_shapes.clear()
-        _checked_shapes.add(key)
+        try:
+            spatial_shapes._mdetr_token_count = (spatial_shapes._version, S)
+        except AttributeError:
+            pass
 
 
 def _is_power_of_2(n):

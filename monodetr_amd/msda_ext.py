@@ -60,22 +60,24 @@ def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
-# Host copies of (spatial_shapes, level_start_index) for launch planning, cached per device tensor
-# (the model reuses one tensor per resolution, so the device->host copy happens once), and one
-# scratch buffer per device for the tile-privatised backward.
-_host_geometry = {}
+# Host copies of (spatial_shapes, level_start_index) for launch planning, kept ON the device tensor they were read from
+# (the model reuses one tensor per resolution -- DepthAwareTransformer._level_tensors -- so the device->host copy happens
+# once per resolution); a caller that builds fresh tensors every call pays one small synchronising copy per call.  (An
+# earlier version keyed a dict on data_ptr / _version: the caching allocator hands the address of a freed shapes tensor
+# to the next one, whose contents may differ.)  One scratch buffer per device for the workspace-based backward.
 _workspaces = {}
 
 
 def _geometry_on_host(spatial_shapes, level_start_index):
-    key = (spatial_shapes.data_ptr(), spatial_shapes._version, level_start_index.data_ptr(),
-           level_start_index._version, spatial_shapes.device)
-    hit = _host_geometry.get(key)
-    if hit is None:
-        if len(_host_geometry) > 64:
-            _host_geometry.clear()
-        hit = _host_geometry[key] = (spatial_shapes.cpu().contiguous(), level_start_index.cpu().contiguous())
-    return hit
+    hit = getattr(spatial_shapes, "_mdetr_host", None)
+    if hit is None or hit[0] != spatial_shapes._version or hit[1] is not level_start_index or hit[2] != level_start_index._version:
+        host = (spatial_shapes.cpu().contiguous(), level_start_index.cpu().contiguous())
+        hit = (spatial_shapes._version, level_start_index, level_start_index._version, host)
+        try:
+            spatial_shapes._mdetr_host = hit
+        except AttributeError:                               # a tensor subclass without a __dict__: no caching
+            pass
+    return hit[3]
 
 
 def _workspace(device, nbytes):
@@ -111,13 +113,13 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
         raise RuntimeError("grad_output must be [B,Lq,M*D] of value's dtype")
     code = _capi.dtype_code(value)
     value, sampling_loc, attn_weight, grad_output = (_aligned(t) for t in (value, sampling_loc, attn_weight, grad_output))
-    grad_value = torch.empty_like(value)                  # zero-filled by the C ABI on the stream
+    grad_value = torch.empty_like(value)                  # written completely (or zero-filled first) by the C ABI on the stream
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
     dev = value.device.index
     lib = _capi.lib()
     ws_bytes = 0
-    if code == _capi.MDETR_F32 and Lq == S and D == 32:        # self-attention over the pyramid: tile path
+    if code == _capi.MDETR_F32 and D == 32 and B * Lq > 0:     # one-pass backward (csrc/msda_fused.hip) where the geometry qualifies
         sh_h, st_h = _geometry_on_host(spatial_shapes, level_start_index)
         ws_bytes = lib.mdetr_msda_backward_workspace_bytes(code, sh_h.data_ptr(), st_h.data_ptr(), B, S, M, D, L, Lq, P)
     if ws_bytes > 0:
@@ -191,7 +193,7 @@ def ms_deform_attn_backward_bf16(value, spatial_shapes, level_start_index, sampl
     grad_attn = torch.empty_like(attn_weight)
     lib = _capi.lib()
     ws_bytes, ws_ptr, sh_ptr, st_ptr = 0, 0, 0, 0
-    if Lq == S:
+    if B * Lq > 0:
         sh_h, st_h = _geometry_on_host(spatial_shapes, level_start_index)
         ws_bytes = lib.mdetr_msda_backward_workspace_bytes(_capi.MDETR_F32, sh_h.data_ptr(), st_h.data_ptr(),
                                                            B, S, M, D, L, Lq, P)

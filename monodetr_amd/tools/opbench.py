@@ -80,16 +80,36 @@ def main():
     ap.add_argument("--dist", default="trained")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--B", type=int, default=8)
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16 = the mixed-precision operator of the bf16 model body (bf16 value / out / grad_out)")
     a = ap.parse_args()
+    from monodetr_amd import _capi
+    names = {0: "msda_fwd", 1: "msda_bwd_d32", 2: "msda_scatter_tiles", 3: "msda_reduce_tiles", 6: "msda_bwd_fused", 7: "msda_absmax", 8: "msda_finalize"}
     shapes = KITTI_HI if a.hires else KITTI
     S = sum(h * w for h, w in shapes)
     res = {}
     for name, Lq, enc in (("encoder", S, True), ("decoder", 1100 if a.hires else 550, False)):
         v, sh, st, loc, attn, go, dims = make(a.B, Lq, shapes, a.dist, encoder=enc)
         fb, bb = algorithmic_bytes(*dims)
-        tf = time_call(lambda: msda_ext.ms_deform_attn_forward(v, sh, st, loc, attn, 64), a.iters)
-        tb = time_call(lambda: msda_ext.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64), a.iters)
-        res[name] = dict(Lq=Lq, fwd_ms=round(tf, 4), fwd_GBs=round(fb / tf / 1e6, 1), bwd_ms=round(tb, 4),
+        if a.dtype == "bf16":
+            v, go = v.to(torch.bfloat16), go.to(torch.bfloat16)
+            e = 2
+            fb = e * dims[0] * (dims[1] * 256 + Lq * 256) + 4 * dims[0] * Lq * 8 * 16 * 3
+            bb = fb + 4 * dims[0] * (dims[1] * 256 + Lq * 8 * 16 * 3)
+            f_fwd = lambda: msda_ext.ms_deform_attn_forward_bf16(v, sh, st, loc, attn)
+            f_bwd = lambda: msda_ext.ms_deform_attn_backward_bf16(v, sh, st, loc, attn, go)
+        else:
+            f_fwd = lambda: msda_ext.ms_deform_attn_forward(v, sh, st, loc, attn, 64)
+            f_bwd = lambda: msda_ext.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64)
+        tf = time_call(f_fwd, a.iters)
+        tb = time_call(f_bwd, a.iters)
+        _capi.profile_enable(True)                            # per-kernel split of one more round, HIP events inside the C ABI
+        for _ in range(10):
+            f_bwd()
+        torch.cuda.synchronize()
+        _capi.profile_enable(False)
+        split = {names.get(k, str(k)): round(ms / max(n, 1), 4) for k, key, n, ms in _capi.profile_read()}
+        res[name] = dict(bwd_kernels_ms=split, Lq=Lq, fwd_ms=round(tf, 4), fwd_GBs=round(fb / tf / 1e6, 1), bwd_ms=round(tb, 4),
                          bwd_GBs=round(bb / tb / 1e6, 1), fwd_MB=round(fb / 1e6, 1), bwd_MB=round(bb / 1e6, 1))
     print(json.dumps(dict(dist=a.dist, hires=a.hires, B=a.B, **res)))
 

@@ -32,7 +32,10 @@ class Process:
         if self.on_gpu:
             torch.cuda.set_device(self.local_rank)
         if self.world > 1:
-            torch.distributed.init_process_group('nccl' if self.on_gpu else 'gloo')
+            # only rank 0 runs the per-epoch inference + KITTI evaluation (3 769 frames) while the other ranks already wait in
+            # the next epoch's first collective: the default watchdog time-out would abort the job
+            import datetime
+            torch.distributed.init_process_group('nccl' if self.on_gpu else 'gloo', timeout=datetime.timedelta(minutes=60))
         self.device = torch.device("cuda", self.local_rank) if self.on_gpu else torch.device("cpu")
 
     @property

@@ -113,6 +113,18 @@ inline int __any(int pred)
     return r;
 }
 inline int __all(int pred) { return !__any(!pred); }
+// 64-bit mask of the live lanes whose predicate holds
+inline unsigned long long __ballot(int pred)
+{
+    const int me = threadIdx.x, base = hipshim::lane_base(), n = hipshim::live_lanes();
+    hipshim::exchange[me] = pred != 0;
+    hipshim::sync_wave();
+    unsigned long long r = 0;
+    for (int l = 0; l < n; ++l) r |= (hipshim::exchange[base + l] ? 1ull : 0ull) << l;
+    hipshim::sync_wave();
+    return r;
+}
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 
 template <typename T, typename U> inline T atomicAdd(T *p, U v) { const T old = *p; *p = old + static_cast<T>(v); return old; }
 template <typename T, typename U> inline T unsafeAtomicAdd(T *p, U v) { return atomicAdd(p, v); }

@@ -1,5 +1,5 @@
-"""The MSDA kernel sources (csrc/msda.hip, csrc/msda_tiled.hip) -- kernels, launchers and C-ABI entries, unmodified --
-run on the HIP-on-CPU shim (tests/native_emul.py).
+"""The MSDA kernel sources (csrc/msda.hip, csrc/msda_tiled.hip, csrc/msda_fused.hip) -- kernels, launchers and C-ABI
+entries, unmodified -- run on the HIP-on-CPU shim (tests/native_emul.py).
 
 Two purposes.  (1) The fp32 / fp64 paths are GPU-validated: running them here against the oracle validates the
 EMULATOR (fibers, wave barriers, DPP controls, LDS, the fixed-point tile scatter).  (2) With the emulator trusted,
@@ -33,18 +33,31 @@ def fwd(p, code=0):
     return out
 
 
-def bwd(p, code=0, tiled=False):
+def bwd(p, code=0, tiled=False, path=None, ws=None):
+    """path: None = C ABI without workspace (global atomics); "tiled" / "fused" / "atomic" = mdetr_msda_backward_ex with the
+    grad_value strategy selected through MDETR_MSDA_BWD (`tiled=True` is the round-1 spelling of path="tiled")."""
+    import os
     L = native_emul.lib()
+    path = "tiled" if tiled and path is None else path
     B, S, M, D = p["value"].shape
     Lq, Lv, P = p["loc"].shape[1], p["loc"].shape[3], p["loc"].shape[4]
-    gv, gl, ga = torch.full_like(p["value"], 9.0), torch.empty_like(p["loc"]), torch.empty_like(p["attn"])
+    gv, gl, ga = torch.full_like(p["value"], 9.0), torch.full_like(p["loc"], 7.0), torch.full_like(p["attn"], 5.0)
     common = (code, p["value"].data_ptr(), p["shapes"].data_ptr(), p["level_start"].data_ptr(), p["loc"].data_ptr(),
               p["attn"].data_ptr(), p["grad_out"].data_ptr(), gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, S, M, D, Lv, Lq, P)
-    if tiled:
-        n = L.mdetr_msda_backward_workspace_bytes(code, p["shapes"].data_ptr(), p["level_start"].data_ptr(), B, S, M, D, Lv, Lq, P)
-        assert n > 0
-        ws = torch.empty(n, dtype=torch.uint8)
-        _check(L.mdetr_msda_backward_ex(*common, p["shapes"].data_ptr(), p["level_start"].data_ptr(), ws.data_ptr(), n, 0, None))
+    if path is not None:
+        saved = os.environ.get("MDETR_MSDA_BWD")
+        os.environ["MDETR_MSDA_BWD"] = path
+        try:
+            n = L.mdetr_msda_backward_workspace_bytes(code, p["shapes"].data_ptr(), p["level_start"].data_ptr(), B, S, M, D, Lv, Lq, P)
+            assert n > 0
+            if ws is None or ws.numel() < n:
+                ws = torch.randint(0, 255, (n,), dtype=torch.uint8)         # a fresh workspace holds anything
+            _check(L.mdetr_msda_backward_ex(*common, p["shapes"].data_ptr(), p["level_start"].data_ptr(), ws.data_ptr(), ws.numel(), 0, None))
+        finally:
+            if saved is None:
+                del os.environ["MDETR_MSDA_BWD"]
+            else:
+                os.environ["MDETR_MSDA_BWD"] = saved
     else:
         _check(L.mdetr_msda_backward(*common, 0, None))
     return gv, gl, ga
@@ -68,9 +81,12 @@ def test_emulated_fp32_kernels_match_the_oracle(B, M, Lq, shapes, P, lo, hi):
     assert close(fwd(p), ref, 1e-6)
     rv, rl, ra = oracle.backward(p["value"].double(), p["shapes"], p["level_start"], p["loc"].double(), p["attn"].double(),
                                  p["grad_out"].double())
-    for tiled in ([False, True] if Lq is None else [False]):
-        gv, gl, ga = bwd(p, tiled=tiled)
-        assert close(gv, rv, 1e-5) and close(gl, rl, 1e-4) and close(ga, ra, 1e-4), tiled
+    paths = [None, "fused"] + (["tiled"] if Lq is None else [])
+    if 32 % (len(shapes) * P):
+        paths = [None]                                      # the one-pass kernel's pre-pass reads attn in 16-byte pieces
+    for path in paths:
+        gv, gl, ga = bwd(p, path=path)
+        assert close(gv, rv, 1e-5) and close(gl, rl, 1e-4) and close(ga, ra, 1e-4), path
 
 
 def test_emulated_generic_kernel_fp64_and_odd_channel_count():
@@ -109,14 +125,16 @@ def test_emulated_bf16_kernels_match_the_fp32_kernels_on_widened_tensors(B, M, L
     ref = fwd(wide)
     assert torch.equal(out, ref.to(torch.bfloat16))                    # same fp32 arithmetic, then one rounding
     gv, gl, ga = torch.full((B, S, M, 32), 9.0), torch.empty_like(p["loc"]), torch.empty_like(p["attn"])
-    n = L.mdetr_msda_backward_workspace_bytes(0, p["shapes"].data_ptr(), p["level_start"].data_ptr(), B, S, M, 32, 4, Lq_, 4) if Lq is None else 0
-    ws = torch.empty(max(n, 1), dtype=torch.uint8)
+    n = L.mdetr_msda_backward_workspace_bytes(0, p["shapes"].data_ptr(), p["level_start"].data_ptr(), B, S, M, 32, 4, Lq_, 4)
+    ws = torch.randint(0, 255, (max(n, 1),), dtype=torch.uint8)
     _check(L.mdetr_msda_backward_bf16(vb.data_ptr(), p["shapes"].data_ptr(), p["level_start"].data_ptr(), p["loc"].data_ptr(),
                                       p["attn"].data_ptr(), gb.data_ptr(), gv.data_ptr(), gl.data_ptr(), ga.data_ptr(),
                                       B, S, M, 32, 4, Lq_, 4, p["shapes"].data_ptr() if n else None,
                                       p["level_start"].data_ptr() if n else None, ws.data_ptr() if n else None, n, 0, None))
-    rv, rl, ra = bwd(wide, tiled=bool(n))
+    rv, rl, ra = bwd(wide, path="fused" if n else None)
     assert close(gv, rv, 1e-6) and close(gl, rl, 1e-6) and close(ga, ra, 1e-6)
+    if n:                                                  # integer accumulation: the two element types agree bit for bit
+        assert torch.equal(gv, rv)
 
 
 class _EmulModule:
@@ -173,3 +191,95 @@ def test_autograd_function_with_native_bf16_matches_the_widening_path(monkeypatc
     for x, y in zip(res[False], res[True]):
         assert x.dtype == y.dtype == torch.bfloat16
         assert (x.float() - y.float()).abs().max() <= 2 ** -7 * max(1.0, x.float().abs().max().item())
+
+
+# ---- (3) the one-pass backward (csrc/msda_fused.hip) ------------------------------------------------------------------
+def _fused_env(monkeypatch, th, tw, reach, whole, chunks):
+    for k, v in (("MDETR_MSDA_TILE_H", th), ("MDETR_MSDA_TILE_W", tw), ("MDETR_MSDA_REACH", reach),
+                 ("MDETR_MSDA_WHOLE_LEVEL_CELLS", whole), ("MDETR_MSDA_CHUNKS", chunks)):
+        monkeypatch.setenv(k, str(v))
+
+
+def _oracle_bwd(p):
+    return oracle.backward(p["value"].double(), p["shapes"], p["level_start"], p["loc"].double(), p["attn"].double(), p["grad_out"].double())
+
+
+@pytest.mark.parametrize("th,tw,reach,whole,chunks", [(4, 8, 2, 30, 3), (3, 5, 1, 0, 1), (16, 32, 4, 512, 8)])
+@pytest.mark.parametrize("B,M,Lq,shapes,lo,hi", [
+    (1, 2, None, TINY, 0.0, 1.0),              # self-attention, uniform locations: most corners leave every block's reach
+    (2, 2, None, SMALL, -0.3, 1.3),            # + samples outside the maps
+    (2, 2, 50, SMALL, -0.2, 1.2),              # cross-attention: every block scans every query
+    (1, 1, 3, ODD, 0.0, 1.0),                  # degenerate maps
+])
+def test_fused_backward_matches_the_oracle_for_every_plan(monkeypatch, th, tw, reach, whole, chunks, B, M, Lq, shapes, lo, hi):
+    """Core tiles + candidate queries (mode 0), whole-level chunks (mode 1), scan-all tiles (mode 2), the `far` buffer, with
+    tile geometries that split the small test pyramids the way the default plan splits the 48x160 one."""
+    _fused_env(monkeypatch, th, tw, reach, whole, chunks)
+    S = sum(h * w for h, w in shapes)
+    p = make_problem(B, M, 32, S if Lq is None else Lq, shapes, 4, torch.float32, seed=3, lo=lo, hi=hi)
+    gv, gl, ga = bwd(p, path="fused")
+    rv, rl, ra = _oracle_bwd(p)
+    assert close(gv, rv, 1e-5) and close(gl, rl, 1e-6) and close(ga, ra, 1e-6)
+
+
+def test_fused_backward_near_samples_stay_in_lds_and_are_deterministic(monkeypatch):
+    """Offsets of at most `reach` cells (the model's initial star pattern, ops/modules/ms_deform_attn.py:107-114): nothing
+    takes the global-atomic route (the `far` flag in the workspace header stays 0), and the result is independent of the
+    tile geometry bit for bit (integer accumulation), which the fp32-atomic paths are not."""
+    S = sum(h * w for h, w in SMALL)
+    p = make_problem(2, 2, 32, S, SMALL, 4, torch.float32, seed=4)
+    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij"), -1).reshape(-1, 2)
+                     for h, w in SMALL])[:, [1, 0]]                         # (x, y) of every query
+    g = torch.Generator().manual_seed(1)
+    off = (torch.rand(2, S, 2, 4, 4, 2, generator=g) * 2 - 1) * 1.4        # |offset| + 1.5 <= reach (3 cells) in each level's own units
+    off[:, :, :, :, 0] = off[:, :, :, :, 0].round()                        # some exactly integer: corners of weight 0 are skipped
+    sizes = torch.tensor([[w, h] for h, w in SMALL], dtype=torch.float32).view(1, 1, 1, 4, 1, 2)
+    p["loc"] = (ref.view(1, S, 1, 1, 1, 2) + off / sizes).contiguous()
+    # (fp32 oracle: with pixel coordinates ON integers the floor is decided by the fp32 rounding of loc * size, .cuh:285-286)
+    rv, rl, ra = oracle.backward(p["value"], p["shapes"], p["level_start"], p["loc"], p["attn"], p["grad_out"])
+    outs = []
+    for th, tw in ((4, 8), (6, 20), (3, 7)):
+        _fused_env(monkeypatch, th, tw, 3, 30, 3)
+        ws = torch.randint(0, 255, (1 << 22,), dtype=torch.uint8)
+        gv, gl, ga = bwd(p, path="fused", ws=ws)
+        assert ws[8:12].view(torch.int32).item() == 0                       # Header.far
+        assert close(gv, rv, 1e-5) and close(gl, rl, 1e-5) and close(ga, ra, 1e-5)
+        outs.append(gv)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_fused_backward_repeats_a_pass_when_a_cell_draws_too_many_contributions(monkeypatch):
+    """All 255 x 4 samples of a level on ONE footprint: > 511 contributions per cell, the 32-bit fields would overflow;
+    the block notices from its counts and repeats the pass at half the resolution."""
+    _fused_env(monkeypatch, 4, 8, 2, 30, 1)
+    S = sum(h * w for h, w in TINY)
+    p = make_problem(1, 2, 32, S, TINY, 4, torch.float32, seed=9)
+    p["loc"] = torch.full_like(p["loc"], 0.5) + 0.01 * torch.rand(p["loc"].shape, generator=torch.Generator().manual_seed(2))
+    gv, gl, ga = bwd(p, path="fused")
+    rv, rl, ra = _oracle_bwd(p)
+    assert close(gv, rv, 2e-5) and close(gl, rl, 1e-6) and close(ga, ra, 1e-6)
+
+
+def test_fused_backward_non_finite_gradients_and_workspace_reuse(monkeypatch):
+    """inf / NaN in grad_out: no fixed-point scale exists, every corner takes the global-atomic route and propagates like the
+    reference's atomics; the same workspace then serves a finite call of another size and the first size again (the `far`
+    buffer's all-zero invariant is re-established whenever the layout changes)."""
+    _fused_env(monkeypatch, 4, 8, 2, 30, 3)
+    S = sum(h * w for h, w in TINY)
+    ws = torch.randint(0, 255, (1 << 22,), dtype=torch.uint8)
+    p = make_problem(1, 2, 32, S, TINY, 4, torch.float32, seed=5, lo=0.1, hi=0.9)
+    bad = dict(p, grad_out=p["grad_out"].clone())
+    bad["grad_out"][0, 7, 3] = float("inf")
+    bad["grad_out"][0, 100, 40] = float("nan")
+    gv, gl, ga = bwd(bad, path="fused", ws=ws)
+    rv, rl, ra = oracle.backward(bad["value"], bad["shapes"], bad["level_start"], bad["loc"], bad["attn"], bad["grad_out"])
+    fin = torch.isfinite(rv)
+    assert torch.equal(torch.isfinite(gv), fin) and (~fin).any()
+    assert (gv[fin] - rv[fin]).abs().max() < 1e-5 * max(1.0, rv[fin].abs().max().item())
+    fl = torch.isfinite(rl)
+    assert torch.equal(torch.isfinite(gl), fl) and (gl[fl] - rl[fl]).abs().max() < 1e-5 * max(1.0, rl[fl].abs().max().item())
+    for B, Lq in ((2, 17), (1, S), (2, 17)):
+        q = make_problem(B, 2, 32, Lq, TINY, 4, torch.float32, seed=B + Lq, lo=-0.2, hi=1.2)
+        gv, gl, ga = bwd(q, path="fused", ws=ws)
+        rv, rl, ra = _oracle_bwd(q)
+        assert close(gv, rv, 1e-5) and close(gl, rl, 1e-6) and close(ga, ra, 1e-6), (B, Lq)

@@ -305,13 +305,19 @@ def pyramid_problem(B, shapes, dist, seed, M=8, D=32, P=4):
     return p
 
 
+@pytest.mark.parametrize("path", ["fused", "tiled"])
 @pytest.mark.parametrize("shapes,dist", [
     (KITTI, "local"), (KITTI, "mixed"), (KITTI, "uniform"),
     ([(12, 40), (6, 20), (3, 10), (2, 5)], "local"),            # every level fits LDS: chunked whole-level windows
     ([(20, 33), (10, 17), (5, 9)], "mixed"),                    # odd, non-halving pyramid, L = 3
     (KITTI_HI, "local"),
 ])
-def test_tiled_backward_matches_oracle_and_atomic_path(ext, oracle, shapes, dist, monkeypatch):
+def test_workspace_backward_paths_match_oracle(ext, oracle, shapes, dist, path, monkeypatch):
+    """Self-attention over the pyramid through mdetr_msda_backward_ex: the one-pass kernel (msda_fused.hip, the default) and
+    round 1's gather + tile scatter + reduce (msda_tiled.hip, MDETR_MSDA_BWD=tiled), for sampling locations that stay near
+    the query ("local", the trained-like case), mostly do ("mixed") or are anywhere ("uniform": nearly every corner leaves
+    the blocks' reach and takes the global-atomic route)."""
+    monkeypatch.setenv("MDETR_MSDA_BWD", path)
     B = 2
     p = pyramid_problem(B, shapes, dist, seed=len(shapes) * 7 + len(dist))
     d = dev(p)
@@ -337,11 +343,15 @@ def test_tiled_backward_matches_oracle_and_atomic_path(ext, oracle, shapes, dist
     if dist == "local":
         # privatised sums are exact integers (order-independent); only samples that left their window
         # went through fp32 atomics, so run-to-run differences stay at rounding level
-        gv2, _, _ = run_bwd(ext, d)
+        gv2, gl2, ga2 = run_bwd(ext, d)
         assert (gv - gv2).abs().max() < 1e-5 * scale
+        if path == "fused":
+            assert torch.equal(gl, gl2) and torch.equal(ga, ga2)
 
 
-def test_tiled_backward_nonfinite_gradients_fall_back(ext, oracle):
+@pytest.mark.parametrize("path", ["fused", "tiled"])
+def test_workspace_backward_nonfinite_gradients_fall_back(ext, oracle, path, monkeypatch):
+    monkeypatch.setenv("MDETR_MSDA_BWD", path)
     p = pyramid_problem(1, [(12, 40), (6, 20), (3, 10), (2, 5)], "local", seed=3)
     p["grad_out"][0, 5, 7] = float("inf")
     d = dev(p)
