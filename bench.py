@@ -325,6 +325,23 @@ def _cpu_model_name():
     return "unknown"
 
 
+def _physical_cores():
+    """(physical cores, logical CPUs) this process may run on.  One thread per physical core: with one per SMT sibling
+    (256 on the 2 x 64-core EPYC hosts of the MI355X boxes) PyTorch's CPU convolutions ran > 10x slower (round 2: the
+    batch-2 iteration did not finish in 150 s; with 128 threads it takes ~10 s)."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cpus = list(range(os.cpu_count() or 1))
+    cores = set()
+    for c in cpus:
+        try:
+            cores.add(open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip())
+        except OSError:
+            return len(cpus), len(cpus)
+    return max(1, len(cores)), len(cpus)
+
+
 def _emit(tag, obj):
     print("CPU-BASELINE " + json.dumps({tag: obj}), flush=True)
 
@@ -386,13 +403,9 @@ def cpu_baseline_child(steps=1, batch=2):
     `CPU-BASELINE {...}` line per finished part so that the parent can keep what was done if it has to cut the child off."""
     from oracle import msda_oracle                                   # checker, used only in this leg
     from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func as F_
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        pass
+    cores, logical = _physical_cores()
     torch.set_num_threads(cores)
-    _emit("host", {"cores": torch.get_num_threads(), "cpu": _cpu_model_name()})
+    _emit("host", {"cores": torch.get_num_threads(), "logical_cpus": logical, "cpu": _cpu_model_name()})
     msda_oracle.build()
     saved = F_.MSDA
     F_.MSDA = msda_oracle.OracleMSDA
@@ -419,6 +432,7 @@ def cpu_baseline(steps=1, batch=2, timeout_s=150):
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")
            and not k.startswith("OMP_") and not k.startswith("MDETR_")}
+    env["OMP_NUM_THREADS"] = str(_physical_cores()[0])
     env["HIP_VISIBLE_DEVICES"] = ""                                  # the child is a CPU process
     env["CUDA_VISIBLE_DEVICES"] = ""
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-steps", str(steps), "--cpu-batch", str(batch)]
@@ -439,7 +453,8 @@ def cpu_baseline(steps=1, batch=2, timeout_s=150):
             except ValueError:
                 pass
     host, stepr = parts.get("host", {}), parts.get("step", {})
-    res = {"value": stepr.get("value"), "unit": "images/sec", "cores": host.get("cores", 0), "kind": "port", "cpu": host.get("cpu", "unknown"),
+    res = {"value": stepr.get("value"), "unit": "images/sec", "cores": host.get("cores", 0), "logical_cpus": host.get("logical_cpus"),
+           "kind": "port", "cpu": host.get("cpu", "unknown"),
            "sample": "%d training iteration(s) at batch %d (3x384x1280, fp32) after 1 warm-up: PyTorch CPU ops + the C oracle as the MSDA "
                      "operator; msda_op = BASELINE.md section 3 protocol on oracle/msda_torch_ref (port of ms_deform_attn_core_pytorch), "
                      "B=8, up to 3 warm-up + 10 timed calls within 10 s per leg" % (steps, batch),
@@ -696,7 +711,13 @@ def main():
             except Exception as e:                                  # a reported baseline must not cost the measured line
                 line["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
                                         "sample": "failed: %r" % (e,)}
-        print(json.dumps(line))
+        try:                                                        # whatever C libraries left in their stdio buffers (RCCL prints
+            import ctypes                                           # a version banner) goes out BEFORE the line: the line stays last
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
     if dist_on:
         torch.distributed.destroy_process_group()
 

@@ -87,6 +87,24 @@ int mdetr_msda_backward(int dtype,
                         int device, void *stream);
 
 /*
+ * Host (CPU) twins of mdetr_msda_forward / mdetr_msda_backward: EVERY pointer is a host pointer, including
+ * spatial_shapes and level_start; no device, no stream; outputs are written completely.  They replace the reference's
+ * CPU entry points ms_deform_attn_cpu_forward / _backward (ops/src/cpu/ms_deform_attn_cpu.cpp:17-40), which only raise
+ * "Not implement on cpu" -- so that BASELINE configs[0] (the yaml on a CPU, one training iteration) can run.  Same
+ * arithmetic as the CUDA kernels (ms_deform_im2col_cuda.cuh:33-159, 237-403); one (image, head) per task on a pool of
+ * host threads; deterministic.  Explicit entry points, not a fallback: the device entry points never route here.
+ */
+int mdetr_msda_forward_cpu(int dtype,
+                           const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                           const void *loc, const void *attn, void *out,
+                           int B, int S, int M, int D, int L, int Lq, int P);
+int mdetr_msda_backward_cpu(int dtype,
+                            const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                            const void *loc, const void *attn, const void *grad_out,
+                            void *grad_value, void *grad_loc, void *grad_attn,
+                            int B, int S, int M, int D, int L, int Lq, int P);
+
+/*
  * Backward with the tile-privatised grad_value path.  Same contract as mdetr_msda_backward plus
  *   spatial_shapes_host / level_start_host   HOST copies of the two int64 arrays (the launch
  *                                            geometry is planned on the host)

@@ -26,6 +26,8 @@ SIGNATURES = {
     "mdetr_msda_variant": (_c_int, [_c_int] * 5),
     "mdetr_msda_forward": (_c_int, [_c_int] + [_c_vp] * 6 + [_c_int] * 7 + [_c_int, _c_vp]),
     "mdetr_msda_backward": (_c_int, [_c_int] + [_c_vp] * 9 + [_c_int] * 7 + [_c_int, _c_vp]),
+    "mdetr_msda_forward_cpu": (_c_int, [_c_int] + [_c_vp] * 6 + [_c_int] * 7),
+    "mdetr_msda_backward_cpu": (_c_int, [_c_int] + [_c_vp] * 9 + [_c_int] * 7),
     "mdetr_msda_backward_ex": (_c_int, [_c_int] + [_c_vp] * 9 + [_c_int] * 7 + [_c_vp, _c_vp, _c_vp, ctypes.c_int64] + [_c_int, _c_vp]),
     "mdetr_msda_backward_workspace_bytes": (ctypes.c_int64, [_c_int, _c_vp, _c_vp] + [_c_int] * 7),
     "mdetr_msda_indices": (_c_int, [_c_int] + [_c_vp] * 3 + [_c_int] * 5 + [_c_int, _c_vp]),

@@ -185,6 +185,30 @@ int mdetr_msda_backward(int dtype, const void *value, const int64_t *spatial_sha
     return MDETR_OK;
 }
 
+int mdetr_msda_forward_cpu(int dtype, const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                           const void *loc, const void *attn, void *out, int B, int S, int M, int D, int L, int Lq, int P)
+{
+    if (int rc = check_common("mdetr_msda_forward_cpu", dtype, B, S, M, D, L, Lq, P)) return rc;
+    if (B == 0 || Lq == 0) return MDETR_OK;
+    if (!value || !spatial_shapes || !level_start || !loc || !attn || !out)
+        return fail(MDETR_E_ARG, "mdetr_msda_forward_cpu: null pointer");
+    mdetr::msda_forward_cpu(dtype, value, spatial_shapes, level_start, loc, attn, out, B, S, M, D, L, Lq, P);
+    return MDETR_OK;
+}
+
+int mdetr_msda_backward_cpu(int dtype, const void *value, const int64_t *spatial_shapes, const int64_t *level_start,
+                            const void *loc, const void *attn, const void *grad_out,
+                            void *grad_value, void *grad_loc, void *grad_attn, int B, int S, int M, int D, int L, int Lq, int P)
+{
+    if (int rc = check_common("mdetr_msda_backward_cpu", dtype, B, S, M, D, L, Lq, P)) return rc;
+    if (B == 0) return MDETR_OK;
+    if (!value || !spatial_shapes || !level_start || !grad_value || (Lq && (!loc || !attn || !grad_out || !grad_loc || !grad_attn)))
+        return fail(MDETR_E_ARG, "mdetr_msda_backward_cpu: null pointer");
+    mdetr::msda_backward_cpu(dtype, value, spatial_shapes, level_start, loc, attn, grad_out, grad_value, grad_loc, grad_attn,
+                             B, S, M, D, L, Lq, P);
+    return MDETR_OK;
+}
+
 int64_t mdetr_msda_backward_workspace_bytes(int dtype, const int64_t *spatial_shapes_host, const int64_t *level_start_host,
                                             int B, int S, int M, int D, int L, int Lq, int P)
 {

@@ -81,6 +81,13 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
                                       void *workspace, int64_t workspace_bytes, int B, int S, int M, int D, int L, int Lq, int P,
                                       int elem_dtype, hipStream_t st);
 
+// msda_cpu.hip: host implementation (every pointer a HOST pointer); dtype 0 = f32, 1 = f64
+void msda_forward_cpu(int dtype, const void *value, const int64_t *shapes, const int64_t *lstart, const void *loc,
+                      const void *attn, void *out, int B, int S, int M, int D, int L, int Lq, int P);
+void msda_backward_cpu(int dtype, const void *value, const int64_t *shapes, const int64_t *lstart, const void *loc,
+                       const void *attn, const void *grad_out, void *grad_value, void *grad_loc, void *grad_attn,
+                       int B, int S, int M, int D, int L, int Lq, int P);
+
 hipError_t msda_indices_launch(int dtype, const int64_t *shapes, const void *loc, int32_t *idx,
                                int B, int M, int L, int Lq, int P, hipStream_t st);
 

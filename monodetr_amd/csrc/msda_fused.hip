@@ -53,12 +53,10 @@ namespace {
 
 constexpr int kMaxLevels = 4;
 constexpr int kCH = 32;               // channels per head (fast path geometry)
-constexpr int kThreads = 512;         // 8 waves per workgroup
-constexpr int kWavesF = kThreads / 64;
 constexpr int kRecDw = 12;            // per-sample record, 48 B
 constexpr int kCellU64 = kCH / 2;     // packed channel pairs per cell (128 B)
 constexpr int kTrash = 8;             // sink rows for corners that are not this block's business (one per record slot mod 8)
-constexpr int kMaxCells = 1024;       // (1024 + 8) * 128 B + 4 KB counts + 24 KB records < 160 KB
+constexpr int kMaxCells = 1024;       // (1024 + 8) * 128 B + 4 KB counts + 24 KB records + tables < 160 KB
 constexpr unsigned long long kCookie = 0x6d64657472667573ull;
 
 // workspace header (first 256 bytes)
@@ -82,6 +80,7 @@ struct FusedPlan {
     long long scr0[kMaxLevels];       // float offset of level l's partial windows within one (b, m) slab (mode 1)
     long long scr_per_bm;
     int max_cells;
+    int max_tab;                      // ints of the centre-cell tables a mode-0 block may need
 };
 
 // ---- tiny helpers ---------------------------------------------------------------------------------
@@ -93,7 +92,7 @@ __host__ __device__ inline int ceil_div_ll(long long a, long long b)   // b > 0,
 // cell of level l (extent n_l) that holds the centre of cell y of a level with extent n_q
 __host__ __device__ inline int centre_cell(int y, int n_l, int n_q)
 {
-    return static_cast<int>((static_cast<long long>(2 * y + 1) * n_l) / (2LL * n_q));
+    return static_cast<int>((static_cast<unsigned>(2 * y + 1) * static_cast<unsigned>(n_l)) / (2u * static_cast<unsigned>(n_q)));   // extents < 2^15
 }
 
 // first y in [0, n_q] with centre_cell(y) >= t   (monotone in y)
@@ -140,9 +139,20 @@ void msda_absmax_kernel(const GT *__restrict__ g, int64_t ng, const float *__res
     }
     if (!(poison == 0.f)) mg = __builtin_inff();
     for (int o = 32; o > 0; o >>= 1) { mg = fmaxf(mg, __shfl_xor(mg, o)); ma = fmaxf(ma, __shfl_xor(ma, o)); }
+    // one atomic per WORKGROUP and only if it raises the maximum: same-address atomics serialise in L2 (~12 ns each; one
+    // per wave made this 25-microsecond pass take 110)
+    __shared__ unsigned s_max[2];
+    if (threadIdx.x < 2) s_max[threadIdx.x] = 0u;
+    __syncthreads();
     if ((threadIdx.x & 63) == 0) {                            // non-negative floats order like their bit patterns
-        atomicMax(&hdr->absmax_g, __builtin_bit_cast(unsigned, mg));
-        atomicMax(&hdr->absmax_a, __builtin_bit_cast(unsigned, ma));
+        atomicMax(&s_max[0], __builtin_bit_cast(unsigned, mg));
+        atomicMax(&s_max[1], __builtin_bit_cast(unsigned, ma));
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        unsigned *dst = threadIdx.x == 0 ? &hdr->absmax_g : &hdr->absmax_a;
+        const unsigned v = s_max[threadIdx.x];
+        if (v > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, v);
     }
     // a workspace this library has not finalized yet (fresh allocation): its `far` buffer may hold anything
     if (hdr->cookie != kCookie || hdr->far_elems != static_cast<unsigned long long>(nfar)) {
@@ -157,7 +167,10 @@ struct Work {
     int cy0, cx0;                      // core origin in level-l cells
     int tstride;                       // cells per window row
     int ncell;                         // window cells (stride-based)
-    int y0[kMaxLevels], y1[kMaxLevels], x0[kMaxLevels], x1[kMaxLevels];   // mode 0: candidate rectangle per query level
+    // mode 0: the candidate queries are one rectangle per query level, enumerated level by level, row by row
+    int y0[kMaxLevels], x0[kMaxLevels], wx[kMaxLevels], rows[kMaxLevels], cum[kMaxLevels + 1];
+    float inv_wx[kMaxLevels];
+    int roff[kMaxLevels], coff[kMaxLevels], ntab;         // centre-cell tables (LDS): rows / columns of each rectangle
     int q0, nq;                        // number of candidate queries (mode 1 / 2: contiguous from q0)
     int slot;                          // tile / chunk index within the level
 };
@@ -175,8 +188,13 @@ __device__ __forceinline__ Work decode_block(const FusedPlan &pl, int k)
     w.slot = t;
     w.q0 = 0;
     w.nq = 0;
+    w.ntab = 0;
+    w.cum[0] = 0;
 #pragma unroll
-    for (int lq = 0; lq < kMaxLevels; ++lq) w.y0[lq] = w.y1[lq] = w.x0[lq] = w.x1[lq] = 0;
+    for (int lq = 0; lq < kMaxLevels; ++lq) {
+        w.y0[lq] = w.x0[lq] = w.rows[lq] = w.roff[lq] = w.coff[lq] = 0;
+        w.wx[lq] = 1; w.inv_wx[lq] = 1.f; w.cum[lq + 1] = 0;
+    }
     if (w.mode == 1) {
         w.cy0 = 0; w.cx0 = 0; w.tstride = pl.W[l]; w.ncell = pl.H[l] * pl.W[l];
         const int nch = pl.nchunk[l];
@@ -191,40 +209,27 @@ __device__ __forceinline__ Work decode_block(const FusedPlan &pl, int k)
             const int R = pl.R[l];
 #pragma unroll
             for (int lq = 0; lq < kMaxLevels; ++lq) {
-                if (lq >= pl.L) continue;
-                w.y0[lq] = first_at_or_after(w.cy0 - R, pl.H[l], pl.H[lq]);
-                w.y1[lq] = first_at_or_after(w.cy0 + pl.TH[l] + R, pl.H[l], pl.H[lq]);
-                w.x0[lq] = first_at_or_after(w.cx0 - R, pl.W[l], pl.W[lq]);
-                w.x1[lq] = first_at_or_after(w.cx0 + pl.TW[l] + R, pl.W[l], pl.W[lq]);
-                w.nq += (w.y1[lq] - w.y0[lq]) * (w.x1[lq] - w.x0[lq]);
+                if (lq < pl.L) {
+                    w.y0[lq] = first_at_or_after(w.cy0 - R, pl.H[l], pl.H[lq]);
+                    w.rows[lq] = first_at_or_after(w.cy0 + pl.TH[l] + R, pl.H[l], pl.H[lq]) - w.y0[lq];
+                    w.x0[lq] = first_at_or_after(w.cx0 - R, pl.W[l], pl.W[lq]);
+                    const int cols = first_at_or_after(w.cx0 + pl.TW[l] + R, pl.W[l], pl.W[lq]) - w.x0[lq];
+                    w.wx[lq] = cols > 0 ? cols : 1;
+                    w.inv_wx[lq] = 1.0f / static_cast<float>(w.wx[lq]);
+                    w.roff[lq] = w.ntab; w.ntab += w.rows[lq];
+                    w.coff[lq] = w.ntab; w.ntab += cols;
+                    w.cum[lq + 1] = w.cum[lq] + w.rows[lq] * cols;
+                } else {
+                    w.cum[lq + 1] = w.cum[lq];
+                }
             }
+            w.nq = w.cum[kMaxLevels];
         }
     }
     return w;
 }
 
-// i-th candidate query of a mode-0 block -> flattened query index and its centre cell on level l
-__device__ __forceinline__ int nth_query(const FusedPlan &pl, const Work &w, int i, int &qcy, int &qcx)
-{
-    int q = 0;
-    bool done = false;
-    qcy = qcx = 0;
-#pragma unroll
-    for (int lq = 0; lq < kMaxLevels; ++lq) {
-        const int wx = w.x1[lq] - w.x0[lq], n = (w.y1[lq] - w.y0[lq]) * wx;
-        if (!done && i < n) {
-            const int y = w.y0[lq] + i / wx, x = w.x0[lq] + i % wx;
-            q = pl.start[lq] + y * pl.W[lq] + x;
-            qcy = centre_cell(y, pl.H[w.l], pl.H[lq]);
-            qcx = centre_cell(x, pl.W[w.l], pl.W[lq]);
-            done = true;
-        }
-        i -= n;
-    }
-    return q;
-}
-
-// four corner contributions of one sample for the 4 channels of this lane: 8 FMAs, 8 ds_add_u64
+// four corner contributions of one sample for the 4 channels of this lane: 16 FMAs, 8 ds_add_u64
 __device__ __forceinline__ void accumulate4(unsigned long long *win, unsigned o01, unsigned o23, const float (&wt)[4],
                                             const float4 &ag, int k, float magic)
 {
@@ -241,32 +246,56 @@ __device__ __forceinline__ void accumulate4(unsigned long long *win, unsigned o0
     }
 }
 
-template <typename VT, typename GT>
-__global__ __launch_bounds__(kThreads)
+// everything one of the 8 lanes of an own sample needs, requested up front (the loads of the NEXT group of 8 samples are in
+// flight while the current group is accumulated and reduced: the loop is otherwise bound by one L2 round trip per group)
+struct OwnGroup { uint4 r0, r1, r2; float4 g, v0, v1, v2, v3; };
+struct HaloGroup { uint4 r0, r1; float a; float4 g; };
+
+template <typename VT, typename GT, int THREADS, bool PIPE>
+__global__ __launch_bounds__(THREADS)
 void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const float *__restrict__ loc,
                     const float *__restrict__ attn, const GT *__restrict__ grad_out,
                     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
                     Header *__restrict__ hdr, float *__restrict__ scratch, float *__restrict__ far)
 {
+    constexpr int kWavesB = THREADS / 64;
     MDETR_DYNAMIC_LDS(unsigned char, smem_raw);
     unsigned long long *win = reinterpret_cast<unsigned long long *>(smem_raw);
     unsigned *cnt = reinterpret_cast<unsigned *>(smem_raw + static_cast<size_t>(pl.max_cells + kTrash) * kCellU64 * 8);
     unsigned *recs = cnt + pl.max_cells;
-    unsigned *blk = recs + kWavesF * 64 * kRecDw;            // [0] = max count of the pass
+    int *tab = reinterpret_cast<int *>(recs + kWavesB * 64 * kRecDw);       // centre cells of the candidate rows / columns (mode 0)
+    unsigned *blk = reinterpret_cast<unsigned *>(tab + pl.max_tab);          // [0] = max count of the pass
 
     const int bid = blockIdx.x;
     const int b = bid % pl.B, r_ = bid / pl.B, m = r_ % pl.M, kblk = r_ / pl.M;      // image -> XCD (bid % 8)
     const Work w = decode_block(pl, kblk);
     const int l = w.l, H = pl.H[l], W = pl.W[l], TH = w.mode == 1 ? H : pl.TH[l], TW = w.mode == 1 ? W : pl.TW[l];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int P = pl.P, LP = pl.L * P, M = pl.M;
+    const int P = pl.P, LP = pl.L * P, M = pl.M, R = pl.R[l];
     const int j = lane >> 3, k = lane & 7;
     constexpr int eb = Elem<VT>::kBytes;
     const int rowb = M * kCH * eb;                            // bytes from a pixel to the next, `value`
     const char *vlev = reinterpret_cast<const char *>(value) + ((static_cast<int64_t>(b) * pl.S + pl.start[l]) * M + m) * (kCH * eb) + k * 4 * eb;
+    const char *gbase = reinterpret_cast<const char *>(grad_out) + k * 4 * Elem<GT>::kBytes;
     const int64_t pair0 = static_cast<int64_t>(b) * pl.Lq * M + m;                    // pair index of query q: pair0 + q * M
     float *far_lev = far + ((static_cast<int64_t>(b) * pl.S + pl.start[l]) * M + m) * kCH + k * 4;
     unsigned *wrec = recs + wave * 64 * kRecDw;
+
+    // centre cells of the candidate rectangles' rows and columns on level l (mode 0): two small tables instead of two
+    // divisions per candidate
+    if (w.mode == 0) {
+        for (int t = threadIdx.x; t < w.ntab; t += THREADS) {
+            int v = 0;
+#pragma unroll
+            for (int lq = 0; lq < kMaxLevels; ++lq) {
+                if (lq < pl.L) {
+                    if (t >= w.roff[lq] && t < w.coff[lq]) v = centre_cell(w.y0[lq] + t - w.roff[lq], H, pl.H[lq]);
+                    if (t >= w.coff[lq] && t < w.coff[lq] + w.wx[lq]) v = centre_cell(w.x0[lq] + t - w.coff[lq], W, pl.W[lq]);
+                }
+            }
+            tab[t] = v;
+        }
+    }
 
     // one power-of-two scale per call: |w * attn * g| <= max|attn| * max|g| = mx < 2^e
     const float mx = __builtin_bit_cast(float, hdr->absmax_g) * __builtin_bit_cast(float, hdr->absmax_a);
@@ -274,27 +303,44 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
     int e = 0;
     if (finite && mx > 0.f) (void)frexpf(mx, &e);
     const int nsamp = w.nq * P;
+    const float inv_p = 1.0f / static_cast<float>(P);
 
     for (int shift = 0;; ++shift) {
         // contributions are rounded to multiples of 2^-(22 - shift - e): |x| * scale < 2^(22 - shift), up to 2^(9 + shift) - 1 per cell
         const float scale = ldexpf(1.0f, 22 - shift - e);
         const float magic = ldexpf(1.0f, 23) + ldexpf(1.0f, 22 - shift);
-        for (int i = threadIdx.x; i < (w.ncell + kTrash) * kCellU64; i += kThreads) win[i] = 0ull;
-        for (int i = threadIdx.x; i < w.ncell; i += kThreads) cnt[i] = 0u;
+        for (int i = threadIdx.x; i < (w.ncell + kTrash) * kCellU64; i += THREADS) win[i] = 0ull;
+        for (int i = threadIdx.x; i < w.ncell; i += THREADS) cnt[i] = 0u;
         if (threadIdx.x == 0) blk[0] = 0u;
         __syncthreads();
 
-        for (int base = wave * 64; base < nsamp; base += kWavesF * 64) {
+        for (int base = wave * 64; base < nsamp; base += kWavesB * 64) {
             // ---- a. one candidate sample per lane: footprint, ownership, record ----------------------------------------
             bool keep = false, owned = false;
             unsigned rec[kRecDw];
             {
                 const int i = base + lane;
                 const bool act = i < nsamp;
-                const int qi = act ? i / P : 0, p = act ? i - qi * P : 0;
+                const int ia = act ? i : 0;
+                // (exact for these sizes: the quotient is < 2^16 and sits 0.5 / P away from the next integer)
+                const int qi = P == 4 ? ia >> 2 : static_cast<int>((static_cast<float>(ia) + 0.5f) * inv_p);
+                const int p = ia - qi * P;
                 int q, qcy = 0, qcx = 0;
                 if (w.mode == 0) {
-                    q = nth_query(pl, w, qi, qcy, qcx);
+                    const int lq = (qi >= w.cum[1] ? 1 : 0) + (qi >= w.cum[2] ? 1 : 0) + (qi >= w.cum[3] ? 1 : 0);
+                    const int rel = qi - (lq == 0 ? 0 : lq == 1 ? w.cum[1] : lq == 2 ? w.cum[2] : w.cum[3]);
+                    const int wxl = lq == 0 ? w.wx[0] : lq == 1 ? w.wx[1] : lq == 2 ? w.wx[2] : w.wx[3];
+                    const float inv = lq == 0 ? w.inv_wx[0] : lq == 1 ? w.inv_wx[1] : lq == 2 ? w.inv_wx[2] : w.inv_wx[3];
+                    const int row = static_cast<int>((static_cast<float>(rel) + 0.5f) * inv), col = rel - row * wxl;
+                    const int y0l = lq == 0 ? w.y0[0] : lq == 1 ? w.y0[1] : lq == 2 ? w.y0[2] : w.y0[3];
+                    const int x0l = lq == 0 ? w.x0[0] : lq == 1 ? w.x0[1] : lq == 2 ? w.x0[2] : w.x0[3];
+                    const int Wq = lq == 0 ? pl.W[0] : lq == 1 ? pl.W[1] : lq == 2 ? pl.W[2] : pl.W[3];
+                    const int sq = lq == 0 ? pl.start[0] : lq == 1 ? pl.start[1] : lq == 2 ? pl.start[2] : pl.start[3];
+                    const int ro = lq == 0 ? w.roff[0] : lq == 1 ? w.roff[1] : lq == 2 ? w.roff[2] : w.roff[3];
+                    const int co = lq == 0 ? w.coff[0] : lq == 1 ? w.coff[1] : lq == 2 ? w.coff[2] : w.coff[3];
+                    q = sq + (y0l + row) * Wq + x0l + col;
+                    qcy = tab[ro + row];
+                    qcx = tab[co + col];
                     owned = qcy >= w.cy0 && qcy < w.cy0 + TH && qcx >= w.cx0 && qcx < w.cx0 + TW;
                 } else {
                     q = w.q0 + qi;
@@ -330,16 +376,16 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                     const bool core = ok && finite && wy >= 0 && wy < TH && wx >= 0 && wx < TW;
                     cell[c] = core ? static_cast<unsigned>(wy * w.tstride + wx) : 0xFFFFu;
                     anycore = anycore || core;
-                    if (ok && !core && owned) {
-                        bool other = false;                   // does the block that owns this cell look at this query?
-                        if (finite && w.mode == 0) {
-                            const int ty = yy / TH, tx = xx / TW, R = pl.R[l];
-                            other = qcy >= ty * TH - R && qcy < (ty + 1) * TH + R && qcx >= tx * TW - R && qcx < (tx + 1) * TW + R;
-                        } else if (finite && w.mode == 2) {
-                            other = true;
-                        }
-                        farm |= other ? 0u : (1u << c);
+                    // a corner outside the core: does the block that owns its cell look at this query?  That block is this
+                    // one's neighbour in the direction of the corner (a corner a whole tile further out is beyond anybody's
+                    // reach: R <= TH, TW); it looks at queries whose centre lies within R cells of ITS core.
+                    bool other = finite && w.mode == 2;
+                    if (finite && w.mode == 0) {
+                        const int oy = w.cy0 + (wy < 0 ? -TH : (wy >= TH ? TH : 0)), ox = w.cx0 + (wx < 0 ? -TW : (wx >= TW ? TW : 0));
+                        const bool beyond = wy < -TH || wy >= 2 * TH || wx < -TW || wx >= 2 * TW;
+                        other = !beyond && qcy >= oy - R && qcy < oy + TH + R && qcx >= ox - R && qcx < ox + TW + R;
                     }
+                    farm |= (ok && !core && owned && !other) ? (1u << c) : 0u;
                 }
                 keep = owned || anycore;
                 rec[0] = static_cast<unsigned>(q);
@@ -375,38 +421,41 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
             wave_sync();
 
             // ---- b1. own samples, 8 per step, 8 lanes x 4 channels each: accumulate, gather, d/d(loc), d/d(attn) ----------
-            for (int i0 = 0; i0 < no; i0 += 8) {
-                const bool on = i0 + j < no;                  // (the tail group of a list is partly empty)
+            auto fetch_own = [&](int r, OwnGroup &o) {
+                const unsigned *rr = wrec + r * kRecDw;
+                o.r0 = *reinterpret_cast<const uint4 *>(rr);
+                o.r1 = *reinterpret_cast<const uint4 *>(rr + 4);
+                o.r2 = *reinterpret_cast<const uint4 *>(rr + 8);
+                const int64_t pair = pair0 + static_cast<int64_t>(o.r0.x) * M;
+                o.g = Elem<GT>::load4(gbase + pair * (kCH * Elem<GT>::kBytes));
+                const int dxb = (o.r0.y >> 30) & 1u ? rowb : 0, dyb = (o.r0.y >> 31) ? W * rowb : 0;
+                const char *vb = vlev + static_cast<int64_t>(o.r0.y & 0xFFFFFFu) * rowb;
+                o.v0 = Elem<VT>::load4(vb); o.v1 = Elem<VT>::load4(vb + dxb);
+                o.v2 = Elem<VT>::load4(vb + dyb); o.v3 = Elem<VT>::load4(vb + dyb + dxb);
+            };
+            auto run_own = [&](bool on, const OwnGroup &o) {
                 float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f, a = 0.f, lh = 0.f, lw = 0.f;
                 float wt[4] = {0.f, 0.f, 0.f, 0.f};
                 unsigned flags = 0u;
                 int64_t pair = 0;
                 if (on) {
-                    const unsigned *rr = wrec + (i0 + j) * kRecDw;
-                    const uint4 r0 = *reinterpret_cast<const uint4 *>(rr);
-                    const uint4 r1 = *reinterpret_cast<const uint4 *>(rr + 4);
-                    const uint4 r2 = *reinterpret_cast<const uint4 *>(rr + 8);
-                    pair = pair0 + static_cast<int64_t>(r0.x) * M;
-                    const float4 g = Elem<GT>::load4(reinterpret_cast<const char *>(grad_out) + (pair * kCH + k * 4) * Elem<GT>::kBytes);
-                    const unsigned pix = r0.y & 0xFFFFFFu;
-                    const int dxb = (r0.y >> 30) & 1u ? rowb : 0, dyb = (r0.y >> 31) ? W * rowb : 0;
-                    const char *vb = vlev + static_cast<int64_t>(pix) * rowb;
-                    const float4 v0 = Elem<VT>::load4(vb), v1 = Elem<VT>::load4(vb + dxb);
-                    const float4 v2 = Elem<VT>::load4(vb + dyb), v3 = Elem<VT>::load4(vb + dyb + dxb);
-                    wt[0] = __builtin_bit_cast(float, r1.x); wt[1] = __builtin_bit_cast(float, r1.y);
-                    wt[2] = __builtin_bit_cast(float, r1.z); wt[3] = __builtin_bit_cast(float, r1.w);
-                    a = __builtin_bit_cast(float, r2.x); lh = __builtin_bit_cast(float, r2.y); lw = __builtin_bit_cast(float, r2.z);
-                    flags = r2.w;
+                    pair = pair0 + static_cast<int64_t>(o.r0.x) * M;
+                    wt[0] = __builtin_bit_cast(float, o.r1.x); wt[1] = __builtin_bit_cast(float, o.r1.y);
+                    wt[2] = __builtin_bit_cast(float, o.r1.z); wt[3] = __builtin_bit_cast(float, o.r1.w);
+                    a = __builtin_bit_cast(float, o.r2.x); lh = __builtin_bit_cast(float, o.r2.y); lw = __builtin_bit_cast(float, o.r2.z);
+                    flags = o.r2.w;
+                    const float4 g = o.g;
                     if (finite) {
                         const float as = a * scale;
-                        accumulate4(win, r0.z, r0.w, wt, make_float4(as * g.x, as * g.y, as * g.z, as * g.w), k, magic);
+                        accumulate4(win, o.r0.z, o.r0.w, wt, make_float4(as * g.x, as * g.y, as * g.z, as * g.w), k, magic);
                     }
                     if ((flags & 0xF0u) && shift == 0) {      // corners nobody else will see: global fp32 atomics (.cuh:125-152)
                         const float4 tg = make_float4(a * g.x, a * g.y, a * g.z, a * g.w);
+                        const unsigned pix = o.r0.y & 0xFFFFFFu;
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             if (flags & (16u << c)) {
-                                float *p = far_lev + (static_cast<int64_t>(pix) + ((c & 1) && (r0.y >> 30 & 1u) ? 1 : 0) + ((c >> 1) && (r0.y >> 31) ? W : 0)) * (M * kCH);
+                                float *p = far_lev + (static_cast<int64_t>(pix) + ((c & 1) && (o.r0.y >> 30 & 1u) ? 1 : 0) + ((c >> 1) && (o.r0.y >> 31) ? W : 0)) * (M * kCH);
                                 unsafeAtomicAdd(p + 0, wt[c] * tg.x);
                                 unsafeAtomicAdd(p + 1, wt[c] * tg.y);
                                 unsafeAtomicAdd(p + 2, wt[c] * tg.z);
@@ -415,10 +464,10 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                         }
                         if (k == 0) hdr->far = 1u;
                     }
-                    e0 = g.x * v0.x + g.y * v0.y + g.z * v0.z + g.w * v0.w;
-                    e1 = g.x * v1.x + g.y * v1.y + g.z * v1.z + g.w * v1.w;
-                    e2 = g.x * v2.x + g.y * v2.y + g.z * v2.z + g.w * v2.w;
-                    e3 = g.x * v3.x + g.y * v3.y + g.z * v3.z + g.w * v3.w;
+                    e0 = g.x * o.v0.x + g.y * o.v0.y + g.z * o.v0.z + g.w * o.v0.w;
+                    e1 = g.x * o.v1.x + g.y * o.v1.y + g.z * o.v1.z + g.w * o.v1.w;
+                    e2 = g.x * o.v2.x + g.y * o.v2.y + g.z * o.v2.z + g.w * o.v2.w;
+                    e3 = g.x * o.v3.x + g.y * o.v3.y + g.z * o.v3.z + g.w * o.v3.w;
                 }
                 float d0 = sum8f(e0), d1 = sum8f(e1), d2 = sum8f(e2), d3 = sum8f(e3);    // over the 8 lanes of the sample, every lane takes part
                 d0 = (flags & 1u) ? d0 : 0.f; d1 = (flags & 2u) ? d1 : 0.f;              // a corner outside the map reads nothing (.cuh:56-78)
@@ -426,25 +475,58 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 if (on && k == 0) {
                     const float hh = 1.f - lh, hw = 1.f - lw;
                     const int p = (flags >> 8) & 15u;
-                    const int64_t o = pair * LP + l * P + p;
-                    grad_attn[o] = wt[0] * d0 + wt[1] * d1 + wt[2] * d2 + wt[3] * d3;                                      // .cuh:156
-                    reinterpret_cast<float2 *>(grad_loc)[o] = make_float2(static_cast<float>(W) * (a * (hh * (d1 - d0) + lh * (d3 - d2))),   // .cuh:157
-                                                                           static_cast<float>(H) * (a * (hw * (d2 - d0) + lw * (d3 - d1))));  // .cuh:158
+                    const int64_t o_ = pair * LP + l * P + p;
+                    grad_attn[o_] = wt[0] * d0 + wt[1] * d1 + wt[2] * d2 + wt[3] * d3;                                     // .cuh:156
+                    reinterpret_cast<float2 *>(grad_loc)[o_] = make_float2(static_cast<float>(W) * (a * (hh * (d1 - d0) + lh * (d3 - d2))),   // .cuh:157
+                                                                            static_cast<float>(H) * (a * (hw * (d2 - d0) + lw * (d3 - d1))));  // .cuh:158
+                }
+            };
+            if constexpr (PIPE) {
+                OwnGroup ga, gb;
+                if (j < no) fetch_own(j, ga);
+                for (int i0 = 0; i0 < no; i0 += 16) {
+                    if (i0 + 8 + j < no) fetch_own(i0 + 8 + j, gb);
+                    run_own(i0 + j < no, ga);
+                    if (i0 + 8 < no) {                        // (wave-uniform)
+                        if (i0 + 16 + j < no) fetch_own(i0 + 16 + j, ga);
+                        run_own(i0 + 8 + j < no, gb);
+                    }
+                }
+            } else {
+                OwnGroup ga;
+                for (int i0 = 0; i0 < no; i0 += 8) {
+                    if (i0 + j < no) fetch_own(i0 + j, ga);
+                    run_own(i0 + j < no, ga);
                 }
             }
             // ---- b2. neighbours' samples that reach into this core: accumulate only ---------------------------------------
-            for (int i0 = 0; i0 < nh; i0 += 8) {
-                if (i0 + j < nh) {
-                    const unsigned *rr = wrec + (64 - nh + i0 + j) * kRecDw;
-                    const uint4 r0 = *reinterpret_cast<const uint4 *>(rr);
-                    const uint4 r1 = *reinterpret_cast<const uint4 *>(rr + 4);
-                    const float a = __builtin_bit_cast(float, rr[8]);
-                    const int64_t pair = pair0 + static_cast<int64_t>(r0.x) * M;
-                    const float4 g = Elem<GT>::load4(reinterpret_cast<const char *>(grad_out) + (pair * kCH + k * 4) * Elem<GT>::kBytes);
-                    const float wt[4] = {__builtin_bit_cast(float, r1.x), __builtin_bit_cast(float, r1.y),
-                                         __builtin_bit_cast(float, r1.z), __builtin_bit_cast(float, r1.w)};
-                    const float as = a * scale;
-                    accumulate4(win, r0.z, r0.w, wt, make_float4(as * g.x, as * g.y, as * g.z, as * g.w), k, magic);
+            auto fetch_halo = [&](int r, HaloGroup &o) {
+                const unsigned *rr = wrec + r * kRecDw;
+                o.r0 = *reinterpret_cast<const uint4 *>(rr);
+                o.r1 = *reinterpret_cast<const uint4 *>(rr + 4);
+                o.a = __builtin_bit_cast(float, rr[8]);
+                o.g = Elem<GT>::load4(gbase + (pair0 + static_cast<int64_t>(o.r0.x) * M) * (kCH * Elem<GT>::kBytes));
+            };
+            auto run_halo = [&](const HaloGroup &o) {
+                const float wt[4] = {__builtin_bit_cast(float, o.r1.x), __builtin_bit_cast(float, o.r1.y),
+                                     __builtin_bit_cast(float, o.r1.z), __builtin_bit_cast(float, o.r1.w)};
+                const float as = o.a * scale;
+                accumulate4(win, o.r0.z, o.r0.w, wt, make_float4(as * o.g.x, as * o.g.y, as * o.g.z, as * o.g.w), k, magic);
+            };
+            if constexpr (PIPE) {
+                HaloGroup ha, hb;
+                const int h0 = 64 - nh;
+                if (j < nh) fetch_halo(h0 + j, ha);
+                for (int i0 = 0; i0 < nh; i0 += 16) {
+                    if (i0 + 8 + j < nh) fetch_halo(h0 + i0 + 8 + j, hb);
+                    if (i0 + j < nh) run_halo(ha);
+                    if (i0 + 16 + j < nh) fetch_halo(h0 + i0 + 16 + j, ha);
+                    if (i0 + 8 + j < nh) run_halo(hb);
+                }
+            } else {
+                HaloGroup ha;
+                for (int i0 = 0; i0 < nh; i0 += 8) {
+                    if (i0 + j < nh) { fetch_halo(64 - nh + i0 + j, ha); run_halo(ha); }
                 }
             }
             wave_sync();
@@ -454,7 +536,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
         // ---- c. did any cell draw more contributions than a 32-bit field holds at this scale? ---------------------------
         {
             unsigned mc = 0u;
-            for (int i = threadIdx.x; i < w.ncell; i += kThreads) mc = max(mc, cnt[i]);
+            for (int i = threadIdx.x; i < w.ncell; i += THREADS) mc = max(mc, cnt[i]);
             for (int o = 32; o > 0; o >>= 1) mc = max(mc, __shfl_xor(mc, o));
             if (lane == 0) atomicMax(blk, mc);
         }
@@ -467,7 +549,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
             const float inv = finite ? ldexpf(1.0f, -(22 - shift - e)) : 0.f;
             float *dst1 = scratch + (static_cast<int64_t>(b) * M + m) * pl.scr_per_bm + pl.scr0[l] + static_cast<int64_t>(w.slot) * w.ncell * kCH;
             float *dst0 = grad_value + ((static_cast<int64_t>(b) * pl.S + pl.start[l]) * M + m) * kCH;
-            for (int i = threadIdx.x; i < w.ncell * kCellU64; i += kThreads) {
+            for (int i = threadIdx.x; i < w.ncell * kCellU64; i += THREADS) {
                 const int cell = i / kCellU64, pr = i % kCellU64;
                 const unsigned long long s = win[i] - static_cast<unsigned long long>(cnt[cell]) * cbits;
                 const int lo = static_cast<int>(static_cast<unsigned>(s));
@@ -548,7 +630,7 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
         pl.W[l] = static_cast<int>(shapes_h[2 * l + 1]);
         pl.start[l] = static_cast<int>(start_h[l]);
         if (pl.H[l] <= 0 || pl.W[l] <= 0 || pl.start[l] != total) return false;
-        if (static_cast<int64_t>(pl.H[l]) * pl.W[l] >= (1 << 24)) return false;      // pixel index is packed in 24 bits
+        if (static_cast<int64_t>(pl.H[l]) * pl.W[l] >= (1 << 24) || pl.H[l] >= (1 << 15) || pl.W[l] >= (1 << 15)) return false;   // packed indices
         total += static_cast<int64_t>(pl.H[l]) * pl.W[l];
     }
     if (total != S) return false;
@@ -580,8 +662,17 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
             pl.TH[l] = TH; pl.TW[l] = TW; pl.R[l] = reach;
             pl.nty[l] = (H + TH - 1) / TH;
             pl.ntx[l] = (W + TW - 1) / TW;
+            // the owner's "does a neighbour see this query" test looks one tile out: the reach must not exceed a tile
+            if (self && ((pl.nty[l] > 1 && reach > TH) || (pl.ntx[l] > 1 && reach > TW))) return false;
             pl.nblk[l] = pl.nty[l] * pl.ntx[l];
             cells = TH * TW;
+            if (self) {                                      // centre-cell tables: rows + columns of the candidate rectangle on every query level
+                int tab = 0;
+                for (int lq = 0; lq < L; ++lq)
+                    tab += ((TH + 2 * reach) * pl.H[lq] + H - 1) / H + ((TW + 2 * reach) * pl.W[lq] + W - 1) / W + 4;
+                pl.max_tab = tab > pl.max_tab ? tab : pl.max_tab;
+                if (static_cast<long long>(Lq) * P >= (1 << 22)) return false;   // float index arithmetic of the candidate decode
+            }
         }
         if (cells > kMaxCells || cells >= 0xFFF0) return false;
         pl.max_cells = cells > pl.max_cells ? cells : pl.max_cells;
@@ -632,28 +723,44 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
     else
         hipLaunchKernelGGL(msda_absmax_kernel<float>, dim3(1024), dim3(256), 0, st, static_cast<const float *>(grad_out), n_go, attn, n_at, hdr, far, nfar);
     profile_end(st);
-    const size_t lds = static_cast<size_t>(pl.max_cells + kTrash) * kCellU64 * 8 + static_cast<size_t>(pl.max_cells) * 4 +
-                       static_cast<size_t>(kWavesF) * 64 * kRecDw * 4 + 16;
+    // 512 threads (8 waves) or 1024 (16 waves: twice the record buffers, more loads in flight per CU)
+    int threads = env_int("MDETR_MSDA_THREADS", 512);
+    threads = threads >= 1024 ? 1024 : 512;
+    size_t lds = static_cast<size_t>(pl.max_cells + kTrash) * kCellU64 * 8 + static_cast<size_t>(pl.max_cells) * 4 +
+                 static_cast<size_t>(threads / 64) * 64 * kRecDw * 4 + static_cast<size_t>(pl.max_tab) * 4 + 16;
+    if (lds > 160 * 1024 && threads == 1024) {
+        threads = 512;
+        lds -= static_cast<size_t>(8) * 64 * kRecDw * 4;
+    }
+    if (lds > 160 * 1024) return hipErrorNotSupported;
     int dev = 0;
     if ((err = hipGetDevice(&dev)) != hipSuccess) return err;
-    static bool attr_set[2][64] = {};                        // per kernel instance and device
-    const int which = elem_dtype == 2 ? 1 : 0;
+    const bool pipe = threads == 512 && env_int("MDETR_MSDA_PIPE", 1) != 0;   // (the 1024-thread form has 128 VGPRs: no room for a second group)
+    static bool attr_set[6][64] = {};                        // per kernel instance and device
+    const int which = (elem_dtype == 2 ? 1 : 0) + (threads == 1024 ? 4 : (pipe ? 0 : 2));
+    const void *kern = which == 0 ? reinterpret_cast<const void *>(msda_bwd_fused<float, float, 512, true>)
+                     : which == 1 ? reinterpret_cast<const void *>(msda_bwd_fused<__hip_bfloat16, __hip_bfloat16, 512, true>)
+                     : which == 2 ? reinterpret_cast<const void *>(msda_bwd_fused<float, float, 512, false>)
+                     : which == 3 ? reinterpret_cast<const void *>(msda_bwd_fused<__hip_bfloat16, __hip_bfloat16, 512, false>)
+                     : which == 4 ? reinterpret_cast<const void *>(msda_bwd_fused<float, float, 1024, false>)
+                                  : reinterpret_cast<const void *>(msda_bwd_fused<__hip_bfloat16, __hip_bfloat16, 1024, false>);
     if (dev < 0 || dev >= 64 || !attr_set[which][dev]) {
-        err = which ? hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_fused<__hip_bfloat16, __hip_bfloat16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                    : hipFuncSetAttribute(reinterpret_cast<const void *>(msda_bwd_fused<float, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (err != hipSuccess) return err;
+        if ((err = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return err;
         if (dev >= 0 && dev < 64) attr_set[which][dev] = true;
     }
     const unsigned nblocks = static_cast<unsigned>(B) * M * pl.nblocks;
     profile_begin(6, Lq, st);
-    if (which)
-        hipLaunchKernelGGL((msda_bwd_fused<__hip_bfloat16, __hip_bfloat16>), dim3(nblocks), dim3(kThreads), lds, st, pl,
-                           static_cast<const __hip_bfloat16 *>(value), loc, attn, static_cast<const __hip_bfloat16 *>(grad_out),
-                           grad_value, grad_loc, grad_attn, hdr, scratch, far);
-    else
-        hipLaunchKernelGGL((msda_bwd_fused<float, float>), dim3(nblocks), dim3(kThreads), lds, st, pl,
-                           static_cast<const float *>(value), loc, attn, static_cast<const float *>(grad_out),
-                           grad_value, grad_loc, grad_attn, hdr, scratch, far);
+    auto go = [&](auto k, auto vt, auto gt) {
+        using VT = decltype(vt); using GT = decltype(gt);
+        hipLaunchKernelGGL(k, dim3(nblocks), dim3(threads), lds, st, pl, static_cast<const VT *>(value), loc, attn,
+                           static_cast<const GT *>(grad_out), grad_value, grad_loc, grad_attn, hdr, scratch, far);
+    };
+    if (which == 0) go(msda_bwd_fused<float, float, 512, true>, float(), float());
+    else if (which == 1) go(msda_bwd_fused<__hip_bfloat16, __hip_bfloat16, 512, true>, __hip_bfloat16(), __hip_bfloat16());
+    else if (which == 2) go(msda_bwd_fused<float, float, 512, false>, float(), float());
+    else if (which == 3) go(msda_bwd_fused<__hip_bfloat16, __hip_bfloat16, 512, false>, __hip_bfloat16(), __hip_bfloat16());
+    else if (which == 4) go(msda_bwd_fused<float, float, 1024, false>, float(), float());
+    else go(msda_bwd_fused<__hip_bfloat16, __hip_bfloat16, 1024, false>, __hip_bfloat16(), __hip_bfloat16());
     profile_end(st);
     const int64_t nrows = static_cast<int64_t>(B) * S * M;
     profile_begin(8, Lq, st);

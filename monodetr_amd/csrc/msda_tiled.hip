@@ -427,6 +427,9 @@ hipError_t msda_tiled_grad_value_launch(const int64_t *shapes_h, const int64_t *
     unsigned *absmax2 = static_cast<unsigned *>(workspace);
     float *scratch = reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + 256);
     hipError_t err = hipSuccess;
+    // this path writes its windows where msda_fused.hip keeps a buffer it assumes all-zero between calls: void that claim
+    // (bytes 16..31 of the header: cookie + size) so that an A/B run sharing one workspace stays correct
+    if ((err = zero_fill_launch(static_cast<unsigned char *>(workspace) + 16, 16, st)) != hipSuccess) return err;
     if (!absmax_ready) {
         if ((err = zero_fill_launch(absmax2, 8, st)) != hipSuccess) return err;
         const int64_t n_go = static_cast<int64_t>(B) * Lq * M * D, n_at = static_cast<int64_t>(B) * Lq * M * L * P;

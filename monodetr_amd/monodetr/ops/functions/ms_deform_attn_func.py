@@ -7,13 +7,17 @@ for arguments 0, 3 and 4 only, like the reference.  ``MSDA`` is the extension-mo
 (reference: ``import MultiScaleDeformableAttention as MSDA``, :18); here it is
 ``monodetr_amd.msda_ext`` -- the gfx950 kernels behind the C ABI.  There is no Python/CPU
 fallback in this file: CPU tensors raise "Not implemented on the CPU" exactly as the reference's
-dispatcher does (ops/src/ms_deform_attn.h:38).  The reference's debug helper
-``ms_deform_attn_core_pytorch`` (:41-61) is deliberately not re-exported from the product package;
-its restatement lives in oracle/msda_torch_ref.py (test infrastructure).
+dispatcher does (ops/src/ms_deform_attn.h:38).
+
+``ms_deform_attn_core_pytorch(value, value_spatial_shapes, sampling_locations, attention_weights)`` is the reference's
+"for debug and test only" helper (:41-61, imported by its ops/test.py:19): the same operator spelled with
+``F.grid_sample``, any float dtype, CPU or GPU, differentiable through autograd.  It is part of this module's surface
+like in the reference and, like there, nothing in the model calls it -- ``MSDeformAttnFunction`` never falls back to it.
 """
 import os
 
 import torch
+import torch.nn.functional as F
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
@@ -68,3 +72,23 @@ class MSDeformAttnFunction(Function):
         g_value, g_loc, g_attn = MSDA.ms_deform_attn_backward(
             value, shapes, level_start, loc, attn, grad_output.to(value.dtype).contiguous(), ctx.im2col_step)
         return g_value.to(dv), None, None, g_loc.to(dl), g_attn.to(da), None
+
+
+def ms_deform_attn_core_pytorch(value, value_spatial_shapes, sampling_locations, attention_weights):
+    """Reference :41-61.  value [N, S, M, D]; value_spatial_shapes iterable of (H, W); sampling_locations
+    [N, Lq, M, L, P, 2] as (x, y) in [0, 1]; attention_weights [N, Lq, M, L, P]  ->  [N, Lq, M*D].
+    One bilinear ``grid_sample`` (zero padding, align_corners=False) per level over a (N*M, D, H, W) view of that
+    level's tokens, then the attention-weighted sum over the L*P samples."""
+    N, S, M, D = value.shape
+    Lq, L, P = sampling_locations.shape[1], sampling_locations.shape[3], sampling_locations.shape[4]
+    sizes = [(int(h), int(w)) for h, w in value_spatial_shapes]
+    levels = value.split([h * w for h, w in sizes], dim=1)
+    grid = 2 * sampling_locations - 1                                         # grid_sample's [-1, 1] convention (:46)
+    sampled = []
+    for lvl, (h, w) in enumerate(sizes):
+        image = levels[lvl].flatten(2).transpose(1, 2).reshape(N * M, D, h, w)                  # :49-51
+        where = grid[:, :, :, lvl].transpose(1, 2).flatten(0, 1)                                 # [N*M, Lq, P, 2] (:53)
+        sampled.append(F.grid_sample(image, where, mode='bilinear', padding_mode='zeros', align_corners=False))   # :55-56
+    weights = attention_weights.transpose(1, 2).reshape(N * M, 1, Lq, L * P)                    # :59
+    out = (torch.stack(sampled, dim=-2).flatten(-2) * weights).sum(-1).view(N, M * D, Lq)       # :60
+    return out.transpose(1, 2).contiguous()

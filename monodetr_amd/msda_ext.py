@@ -11,11 +11,24 @@ kernels behind the C ABI (include/monodetr_amd.h).  ``monodetr_amd.install()`` r
 module as ``sys.modules['MultiScaleDeformableAttention']`` so ``import MultiScaleDeformableAttention
 as MSDA`` (ops/functions/ms_deform_attn_func.py:18) resolves to it unchanged.
 """
+import os
+
 import torch
 
 from . import _capi
 
 _NAMES5 = ("value", "spatial_shapes", "level_start_index", "sampling_loc", "attn_weight")
+
+# MDETR_MSDA_CPU=1 (or ``allow_cpu(True)``): host tensors go to the C ABI's host entry points mdetr_msda_forward_cpu /
+# _backward_cpu instead of raising.  OFF by default: the reference raises for CPU tensors (ops/src/ms_deform_attn.h:38,
+# cpu/ms_deform_attn_cpu.cpp:26,39) and so does this module -- the switch exists so that BASELINE configs[0] (the yaml on a
+# CPU, one training iteration: plumbing) can run at all.  CUDA tensors never take this route, switch or no switch.
+_ALLOW_CPU = os.environ.get("MDETR_MSDA_CPU") == "1"
+
+
+def allow_cpu(on=True):
+    global _ALLOW_CPU
+    _ALLOW_CPU = bool(on)
 
 
 def _check_inputs(tensors, names):
@@ -90,6 +103,8 @@ def _workspace(device, nbytes):
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
     """-> Tensor [B, Lq, M*D]  (ms_deform_attn_cuda.cu:20-80)."""
     args = (value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    if _ALLOW_CPU and not value.is_cuda:
+        return _forward_cpu(*args, im2col_step)
     _check_inputs(args, _NAMES5)
     B, S, M, D, L, Lq, P = _dims(*args, im2col_step)
     code = _capi.dtype_code(value)
@@ -107,6 +122,8 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step):
     """-> [grad_value, grad_sampling_loc, grad_attn_weight]  (ms_deform_attn_cuda.cu:83-153)."""
     args = (value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    if _ALLOW_CPU and not value.is_cuda:
+        return _backward_cpu(*args, grad_output, im2col_step)
     _check_inputs(args + (grad_output,), _NAMES5 + ("grad_output",))
     B, S, M, D, L, Lq, P = _dims(*args, im2col_step)
     if grad_output.dtype != value.dtype or grad_output.numel() != B * Lq * M * D:
@@ -139,6 +156,40 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
             B, S, M, D, L, Lq, P, dev, _stream(value.device))
         _capi.check(rc, "mdetr_msda_backward")
     return [grad_value, grad_loc, grad_attn]
+
+
+def _host_args(tensors, names):
+    for t, n in zip(tensors, names):
+        if t.is_cuda:
+            raise RuntimeError("%s must be a CPU tensor (value is)" % n)
+        if not t.is_contiguous():
+            raise RuntimeError("%s tensor has to be contiguous" % n)
+
+
+def _forward_cpu(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    """Host tensors through mdetr_msda_forward_cpu (only when MDETR_MSDA_CPU=1 / allow_cpu())."""
+    args = (value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    _host_args(args, _NAMES5)
+    B, S, M, D, L, Lq, P = _dims(*args, im2col_step)
+    out = torch.empty((B, Lq, M * D), dtype=value.dtype)
+    rc = _capi.lib().mdetr_msda_forward_cpu(_capi.dtype_code(value), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                            sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(), B, S, M, D, L, Lq, P)
+    _capi.check(rc, "mdetr_msda_forward_cpu")
+    return out
+
+
+def _backward_cpu(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step):
+    args = (value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+    _host_args(args + (grad_output,), _NAMES5 + ("grad_output",))
+    B, S, M, D, L, Lq, P = _dims(*args, im2col_step)
+    if grad_output.dtype != value.dtype or grad_output.numel() != B * Lq * M * D:
+        raise RuntimeError("grad_output must be [B,Lq,M*D] of value's dtype")
+    gv, gl, ga = torch.empty_like(value), torch.empty_like(sampling_loc), torch.empty_like(attn_weight)
+    rc = _capi.lib().mdetr_msda_backward_cpu(_capi.dtype_code(value), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                             sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
+                                             gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, S, M, D, L, Lq, P)
+    _capi.check(rc, "mdetr_msda_backward_cpu")
+    return [gv, gl, ga]
 
 
 def _dims_mixed(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):

@@ -143,3 +143,51 @@ def test_module_forward_on_cpu_with_oracle_backend(monkeypatch, oracle):
         g1, = torch.autograd.grad(out.sum(), src, retain_graph=True)
         g2, = torch.autograd.grad(want.sum(), src)
         assert (g1 - g2).abs().max() < 1e-10
+
+
+# ---- host (CPU) twins of the operator: mdetr_msda_forward_cpu / _backward_cpu (reference stubs cpu/ms_deform_attn_cpu.cpp:17-40) ----
+@pytest.mark.parametrize("B,M,D,Lq,shapes,P,dtype,lo,hi", [
+    (1, 2, 2, 2, [(6, 4), (3, 2)], 2, torch.float64, 0.0, 1.0),                      # the reference's own test problem (ops/test.py:21-28)
+    (2, 8, 32, 37, [(12, 40), (6, 20), (3, 10), (2, 5)], 4, torch.float32, -0.2, 1.2),
+    (1, 3, 30, 9, [(5, 7), (1, 1)], 3, torch.float64, -0.1, 1.1),
+])
+def test_cpu_entry_points_match_the_oracle(built_lib, oracle, B, M, D, Lq, shapes, P, dtype, lo, hi):
+    from monodetr_amd import msda_ext
+    p = make_problem(B, M, D, Lq, shapes, P, dtype, seed=3, lo=lo, hi=hi)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):           # default: the reference's behaviour
+        msda_ext.ms_deform_attn_forward(p["value"], p["shapes"], p["level_start"], p["loc"], p["attn"], 64)
+    msda_ext.allow_cpu(True)
+    try:
+        out = msda_ext.ms_deform_attn_forward(p["value"], p["shapes"], p["level_start"], p["loc"], p["attn"], 64)
+        gv, gl, ga = msda_ext.ms_deform_attn_backward(p["value"], p["shapes"], p["level_start"], p["loc"], p["attn"], p["grad_out"], 64)
+    finally:
+        msda_ext.allow_cpu(False)
+    ref = oracle.forward(p["value"], p["shapes"], p["level_start"], p["loc"], p["attn"])
+    rv, rl, ra = oracle.backward(p["value"], p["shapes"], p["level_start"], p["loc"], p["attn"], p["grad_out"])
+    tol = 1e-12 if dtype == torch.float64 else 1e-5
+    for got, want in ((out, ref), (gv, rv), (gl, rl), (ga, ra)):
+        assert got.shape == want.shape and got.dtype == want.dtype
+        assert (got - want).abs().max() <= tol * max(1.0, want.abs().max().item())
+
+
+def test_baseline_config_1_runs_on_the_cpu_through_the_c_abi(built_lib):
+    """BASELINE.json configs[0]: configs/monodetr.yaml on a CPU, batch_size 1, two KITTI-shaped synthetic images, one
+    training iteration each -- plumbing.  The reference cannot run it (its operator raises on the CPU); here the C ABI's
+    host entry points carry the operator (MDETR_MSDA_CPU / allow_cpu) and everything else is the same code as on the GPU.
+    Pass = finite loss, and every trainable parameter outside the known-unused set receives a gradient."""
+    import bench
+    from monodetr_amd import msda_ext
+    msda_ext.allow_cpu(True)
+    try:
+        step = bench.TrainStep(torch.device("cpu"), 1, "fp32", switches=())
+        losses = []
+        for sample in range(2):
+            step.inputs = bench.synthetic_batch(1, 384, 1280, 1000 + sample, torch.device("cpu"))
+            losses.append(float(step().detach()))
+    finally:
+        msda_ext.allow_cpu(False)
+    assert all(l == l and abs(l) < 1e6 for l in losses), losses
+    unused = ("label_enc", "sa_v_proj", "decoder.query_scale", "decoder.ref_point_head")
+    for n, p in step.raw_model.named_parameters():
+        if p.requires_grad and not any(u in n for u in unused):
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n

@@ -184,7 +184,9 @@ def test_full_size_properties_highres(ext):
     gv, _, _ = run_bwd(ext, d)                                      # adjoint identity in value
     lhs = (d["grad_out"].double() * run_fwd(ext, d2).double()).sum()
     rhs = (gv.double() * d2["value"].double()).sum()
-    assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs).item())
+    # grad_value is accumulated in fixed point with 22 fractional bits below the call's largest contribution
+    # (msda_fused.hip): unbiased rounding errors of ~1e-6 x that maximum per element, over 38 M elements
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs).item())
 
 
 def test_empty_and_degenerate(ext):

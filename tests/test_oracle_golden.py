@@ -114,3 +114,27 @@ def test_empty_query_set(oracle):
     assert out.shape == (1, 0, 8)
     gv, gl, ga = oracle.backward(p["value"], p["shapes"], p["level_start"], p["loc"], p["attn"], p["grad_out"])
     assert gv.abs().max() == 0 and gl.numel() == 0 and ga.numel() == 0
+
+
+# ---- the product's own ms_deform_attn_core_pytorch against the vectors recorded from the reference's ----
+def test_product_core_pytorch_function_matches_the_recorded_reference_outputs():
+    """monodetr_amd...ops.functions.ms_deform_attn_core_pytorch (mirror of ops/functions/ms_deform_attn_func.py:41-61, what
+    the reference's ops/test.py:19 imports) reproduces the outputs -- and through autograd the gradients -- the reference's
+    own function produced (tests/golden/make_golden.py), in fp64 and fp32."""
+    from monodetr_amd.monodetr.ops.functions import MSDeformAttnFunction, ms_deform_attn_core_pytorch   # both names, as ops/test.py:19
+    assert MSDeformAttnFunction is not None
+    g = load_golden("msda_ref_test_f64")
+    out = ms_deform_attn_core_pytorch(g["value"], g["shapes"], g["loc"], g["attn"])
+    assert out.shape == g["out"].shape and (out - g["out"]).abs().max() < 1e-14
+    for D in (30, 32, 64, 71):
+        g = load_golden("msda_grad_d%d" % D)
+        v, l, a = (g[k].clone().requires_grad_(True) for k in ("value", "loc", "attn"))
+        out = ms_deform_attn_core_pytorch(v, g["shapes"], l, a)
+        assert (out - g["out"]).abs().max() < 1e-14
+        out.backward(g["grad_out"])
+        assert (v.grad - g["grad_value"]).abs().max() < 1e-13
+        assert (l.grad - g["grad_loc"]).abs().max() < 1e-12
+        assert (a.grad - g["grad_attn"]).abs().max() < 1e-13
+    g = load_golden("msda_kitti_small")
+    out32 = ms_deform_attn_core_pytorch(g["value"], g["shapes"], g["loc"], g["attn"])
+    assert out32.dtype == torch.float32 and (out32 - g["out_f32"]).abs().max() < 1e-7
