@@ -186,10 +186,11 @@ class TrainStep:
             self.model = DDP(self.model, device_ids=[local_rank], static_graph=True, gradient_as_bucket_view=True,
                              bucket_cap_mb=64)
         elif ddp:
-            # default N > 1 path: one flat all-reduce per dtype after the backward (helpers/dist_helper.py)
-            from monodetr_amd.helpers.dist_helper import FlatGradSync, broadcast_parameters
+            # default N > 1 path: one flat all-reduce per dtype after the backward; "bucketed": the same exchange in
+            # ~32 MB buckets issued from gradient hooks while the backward is still running (helpers/dist_helper.py)
+            from monodetr_amd.helpers.dist_helper import BucketedGradSync, FlatGradSync, broadcast_parameters
             broadcast_parameters(self.raw_model)
-            self.grad_sync = FlatGradSync(self.raw_model.parameters())
+            self.grad_sync = (BucketedGradSync if ddp == "bucketed" else FlatGradSync)(self.raw_model.parameters())
         # MDETR_FUSED_ADAMW=1: one-launch-per-group HIP AdamW (helpers/optimizer_helper.FusedAdamW); off until
         # its kernel has had its first GPU validation (tests/test_fused_gpu.py)
         self.optimizer = build_optimizer(dict(OPT_CFG, capturable=graph, fused="MDETR_FUSED_ADAMW" in self.switches),

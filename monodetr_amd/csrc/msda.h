@@ -11,12 +11,22 @@ namespace mdetr {
 template <typename E> struct Elem;
 template <> struct Elem<float> {
     static constexpr int kBytes = 4;
+    typedef float4 Raw;                                   // 4 channels as loaded; widen() when consumed (keeps batches of loads compact)
+    static __device__ __forceinline__ Raw loadr(const char *p) { return *reinterpret_cast<const float4 *>(p); }
+    static __device__ __forceinline__ float4 widen(const Raw &r) { return r; }
     static __device__ __forceinline__ float load1(const float *p) { return *p; }
     static __device__ __forceinline__ float4 load4(const char *p) { return *reinterpret_cast<const float4 *>(p); }
     static __device__ __forceinline__ void store4(char *p, const float4 &v) { *reinterpret_cast<float4 *>(p) = v; }
 };
 template <> struct Elem<__hip_bfloat16> {
     static constexpr int kBytes = 2;
+    typedef uint2 Raw;
+    static __device__ __forceinline__ Raw loadr(const char *p) { return *reinterpret_cast<const uint2 *>(p); }
+    static __device__ __forceinline__ float4 widen(const Raw &u)
+    {
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
+                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+    }
     static __device__ __forceinline__ float load1(const __hip_bfloat16 *p) { return __bfloat162float(*p); }
     static __device__ __forceinline__ float4 load4(const char *p)
     {

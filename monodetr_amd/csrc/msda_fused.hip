@@ -44,6 +44,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include <mdetr_wave.h>
 
 #include "msda.h"
@@ -246,13 +248,8 @@ __device__ __forceinline__ void accumulate4(unsigned long long *win, unsigned o0
     }
 }
 
-// everything one of the 8 lanes of an own sample needs, requested up front (the loads of the NEXT group of 8 samples are in
-// flight while the current group is accumulated and reduced: the loop is otherwise bound by one L2 round trip per group)
-struct OwnGroup { uint4 r0, r1, r2; float4 g, v0, v1, v2, v3; };
-struct HaloGroup { uint4 r0, r1; float a; float4 g; };
-
-template <typename VT, typename GT, int THREADS, bool PIPE>
-__global__ __launch_bounds__(THREADS)
+template <typename VT, typename GT, int THREADS, int GMAX>
+__global__ __launch_bounds__(THREADS, (THREADS == 512 && GMAX <= 4 && sizeof(VT) == 2) ? 4 : 2)
 void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const float *__restrict__ loc,
                     const float *__restrict__ attn, const GT *__restrict__ grad_out,
                     float *__restrict__ grad_value, float *__restrict__ grad_loc, float *__restrict__ grad_attn,
@@ -264,7 +261,8 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
     unsigned *cnt = reinterpret_cast<unsigned *>(smem_raw + static_cast<size_t>(pl.max_cells + kTrash) * kCellU64 * 8);
     unsigned *recs = cnt + pl.max_cells;
     int *tab = reinterpret_cast<int *>(recs + kWavesB * 64 * kRecDw);       // centre cells of the candidate rows / columns (mode 0)
-    unsigned *blk = reinterpret_cast<unsigned *>(tab + pl.max_tab);          // [0] = max count of the pass
+    int *lv = tab + pl.max_tab;                                              // 4 x 8 ints: the candidate rectangle of each query level
+    unsigned *blk = reinterpret_cast<unsigned *>(lv + 32);                   // [0] = max count of the pass
 
     const int bid = blockIdx.x;
     const int b = bid % pl.B, r_ = bid / pl.B, m = r_ % pl.M, kblk = r_ / pl.M;      // image -> XCD (bid % 8)
@@ -284,6 +282,15 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
     // centre cells of the candidate rectangles' rows and columns on level l (mode 0): two small tables instead of two
     // divisions per candidate
     if (w.mode == 0) {
+        if (threadIdx.x < kMaxLevels) {
+            const int lq = threadIdx.x;
+#define MDETR_SEL4(arr) (lq == 0 ? arr[0] : lq == 1 ? arr[1] : lq == 2 ? arr[2] : arr[3])
+            int *L8 = lv + lq * 8;
+            L8[0] = MDETR_SEL4(w.cum); L8[1] = MDETR_SEL4(w.wx); L8[2] = __builtin_bit_cast(int, MDETR_SEL4(w.inv_wx));
+            L8[3] = MDETR_SEL4(w.y0); L8[4] = MDETR_SEL4(w.x0); L8[5] = MDETR_SEL4(pl.W); L8[6] = MDETR_SEL4(pl.start);
+            L8[7] = MDETR_SEL4(w.roff) | (MDETR_SEL4(w.coff) << 16);
+#undef MDETR_SEL4
+        }
         for (int t = threadIdx.x; t < w.ntab; t += THREADS) {
             int v = 0;
 #pragma unroll
@@ -314,41 +321,48 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
         if (threadIdx.x == 0) blk[0] = 0u;
         __syncthreads();
 
+        // candidate decode + the loads of its location / weight, issued one step AHEAD of their use (the loop is bound by
+        // memory round trips, not by arithmetic: everything that can be in flight early is)
+        struct Cand { int q, p, qcy, qcx; bool act, owned; float2 xy; float a; };
+        auto decode = [&](int base_, Cand &c) {
+            const int i = base_ + lane;
+            c.act = i < nsamp;
+            const int ia = c.act ? i : 0;
+            // (exact for these sizes: the quotient is < 2^20 and sits 0.5 / P away from the next integer)
+            const int qi = P == 4 ? ia >> 2 : static_cast<int>((static_cast<float>(ia) + 0.5f) * inv_p);
+            c.p = ia - qi * P;
+            c.qcy = c.qcx = 0;
+            if (w.mode == 0) {
+                const int lq = (qi >= w.cum[1] ? 1 : 0) + (qi >= w.cum[2] ? 1 : 0) + (qi >= w.cum[3] ? 1 : 0);
+                const int *L8 = lv + lq * 8;                  // this query level's rectangle (LDS; a step rarely straddles two levels)
+                const int rel = qi - L8[0], wxl = L8[1], y0l = L8[3], x0l = L8[4], Wq = L8[5], sq = L8[6], ro = L8[7] & 0xFFFF, co = L8[7] >> 16;
+                const float inv = __builtin_bit_cast(float, L8[2]);
+                const int row = static_cast<int>((static_cast<float>(rel) + 0.5f) * inv), col = rel - row * wxl;
+                c.q = sq + (y0l + row) * Wq + x0l + col;
+                c.qcy = tab[ro + row];
+                c.qcx = tab[co + col];
+                c.owned = c.qcy >= w.cy0 && c.qcy < w.cy0 + TH && c.qcx >= w.cx0 && c.qcx < w.cx0 + TW;
+            } else {
+                c.q = w.q0 + qi;
+                c.owned = w.mode == 1;
+            }
+            const int64_t srec = (pair0 + static_cast<int64_t>(c.q) * M) * LP + l * P + c.p;
+            c.xy = c.act ? *reinterpret_cast<const float2 *>(loc + srec * 2) : make_float2(-9.f, -9.f);
+            c.a = c.act ? attn[srec] : 0.f;
+        };
+
+        Cand cur;
+        if (wave * 64 < nsamp) decode(wave * 64, cur);
         for (int base = wave * 64; base < nsamp; base += kWavesB * 64) {
             // ---- a. one candidate sample per lane: footprint, ownership, record ----------------------------------------
             bool keep = false, owned = false;
             unsigned rec[kRecDw];
             {
-                const int i = base + lane;
-                const bool act = i < nsamp;
-                const int ia = act ? i : 0;
-                // (exact for these sizes: the quotient is < 2^16 and sits 0.5 / P away from the next integer)
-                const int qi = P == 4 ? ia >> 2 : static_cast<int>((static_cast<float>(ia) + 0.5f) * inv_p);
-                const int p = ia - qi * P;
-                int q, qcy = 0, qcx = 0;
-                if (w.mode == 0) {
-                    const int lq = (qi >= w.cum[1] ? 1 : 0) + (qi >= w.cum[2] ? 1 : 0) + (qi >= w.cum[3] ? 1 : 0);
-                    const int rel = qi - (lq == 0 ? 0 : lq == 1 ? w.cum[1] : lq == 2 ? w.cum[2] : w.cum[3]);
-                    const int wxl = lq == 0 ? w.wx[0] : lq == 1 ? w.wx[1] : lq == 2 ? w.wx[2] : w.wx[3];
-                    const float inv = lq == 0 ? w.inv_wx[0] : lq == 1 ? w.inv_wx[1] : lq == 2 ? w.inv_wx[2] : w.inv_wx[3];
-                    const int row = static_cast<int>((static_cast<float>(rel) + 0.5f) * inv), col = rel - row * wxl;
-                    const int y0l = lq == 0 ? w.y0[0] : lq == 1 ? w.y0[1] : lq == 2 ? w.y0[2] : w.y0[3];
-                    const int x0l = lq == 0 ? w.x0[0] : lq == 1 ? w.x0[1] : lq == 2 ? w.x0[2] : w.x0[3];
-                    const int Wq = lq == 0 ? pl.W[0] : lq == 1 ? pl.W[1] : lq == 2 ? pl.W[2] : pl.W[3];
-                    const int sq = lq == 0 ? pl.start[0] : lq == 1 ? pl.start[1] : lq == 2 ? pl.start[2] : pl.start[3];
-                    const int ro = lq == 0 ? w.roff[0] : lq == 1 ? w.roff[1] : lq == 2 ? w.roff[2] : w.roff[3];
-                    const int co = lq == 0 ? w.coff[0] : lq == 1 ? w.coff[1] : lq == 2 ? w.coff[2] : w.coff[3];
-                    q = sq + (y0l + row) * Wq + x0l + col;
-                    qcy = tab[ro + row];
-                    qcx = tab[co + col];
-                    owned = qcy >= w.cy0 && qcy < w.cy0 + TH && qcx >= w.cx0 && qcx < w.cx0 + TW;
-                } else {
-                    q = w.q0 + qi;
-                    owned = w.mode == 1;
-                }
-                const int64_t srec = (pair0 + static_cast<int64_t>(q) * M) * LP + l * P + p;
-                const float2 xy = act ? *reinterpret_cast<const float2 *>(loc + srec * 2) : make_float2(-9.f, -9.f);
-                const float a_in = act ? attn[srec] : 0.f;
+                const bool act = cur.act;
+                const int q = cur.q, p = cur.p, qcy = cur.qcy, qcx = cur.qcx;
+                owned = cur.owned;
+                const float2 xy = cur.xy;
+                const float a_in = cur.a;
                 const float h_im = pix_coord_f(xy.y, H), w_im = pix_coord_f(xy.x, W);
                 const bool inwin = h_im > -1.f && w_im > -1.f && h_im < static_cast<float>(H) && w_im < static_cast<float>(W);   // .cuh:288
                 const float hs = inwin ? h_im : 0.f, ws = inwin ? w_im : 0.f;
@@ -360,7 +374,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 const int xc0 = min(max(x, 0), W - 1), xc1 = min(max(x + 1, 0), W - 1);
                 if (w.mode == 2) owned = yc0 >= w.cy0 && yc0 < w.cy0 + TH && xc0 >= w.cx0 && xc0 < w.cx0 + TW;
                 owned = owned && act;
-                unsigned cell[4], valid = 0u, farm = 0u;
+                unsigned cell[4], valid = 0u, stray = 0u;
                 float wt[4];
                 bool anycore = false;
 #pragma unroll
@@ -376,16 +390,23 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                     const bool core = ok && finite && wy >= 0 && wy < TH && wx >= 0 && wx < TW;
                     cell[c] = core ? static_cast<unsigned>(wy * w.tstride + wx) : 0xFFFFu;
                     anycore = anycore || core;
-                    // a corner outside the core: does the block that owns its cell look at this query?  That block is this
-                    // one's neighbour in the direction of the corner (a corner a whole tile further out is beyond anybody's
-                    // reach: R <= TH, TW); it looks at queries whose centre lies within R cells of ITS core.
-                    bool other = finite && w.mode == 2;
-                    if (finite && w.mode == 0) {
+                    stray |= (ok && !core && owned) ? (1u << c) : 0u;
+                }
+                // an own sample's corner outside the core: does the block that owns its cell look at this query?  That block is
+                // this one's neighbour in the direction of the corner (a corner a whole tile further out is beyond anybody's
+                // reach: R <= TH, TW); it looks at queries whose centre lies within R cells of ITS core.  (Rare: skipped
+                // altogether when no lane of the wave has such a corner.)
+                unsigned farm = stray;
+                if (finite && w.mode == 2) farm = 0u;         // every other block scans every query
+                if (finite && w.mode == 0 && __any(stray != 0u)) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int wy = y + (c >> 1) - w.cy0, wx = x + (c & 1) - w.cx0;
                         const int oy = w.cy0 + (wy < 0 ? -TH : (wy >= TH ? TH : 0)), ox = w.cx0 + (wx < 0 ? -TW : (wx >= TW ? TW : 0));
                         const bool beyond = wy < -TH || wy >= 2 * TH || wx < -TW || wx >= 2 * TW;
-                        other = !beyond && qcy >= oy - R && qcy < oy + TH + R && qcx >= ox - R && qcx < ox + TW + R;
+                        const bool other = !beyond && qcy >= oy - R && qcy < oy + TH + R && qcx >= ox - R && qcx < ox + TW + R;
+                        farm &= other ? ~(1u << c) : ~0u;
                     }
-                    farm |= (ok && !core && owned && !other) ? (1u << c) : 0u;
                 }
                 keep = owned || anycore;
                 rec[0] = static_cast<unsigned>(q);
@@ -399,6 +420,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 rec[10] = __builtin_bit_cast(unsigned, lw);
                 rec[11] = valid | (farm << 4) | (static_cast<unsigned>(p) << 8);
             }
+            if (base + kWavesB * 64 < nsamp) decode(base + kWavesB * 64, cur);           // next step's loads go out now
             const unsigned long long mo = __ballot(keep && owned), mh = __ballot(keep && !owned);
             const int no = __popcll(mo), nh = __popcll(mh);
             const unsigned long long below = (1ull << lane) - 1ull;
@@ -420,42 +442,34 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
             }
             wave_sync();
 
-            // ---- b1. own samples, 8 per step, 8 lanes x 4 channels each: accumulate, gather, d/d(loc), d/d(attn) ----------
-            auto fetch_own = [&](int r, OwnGroup &o) {
-                const unsigned *rr = wrec + r * kRecDw;
-                o.r0 = *reinterpret_cast<const uint4 *>(rr);
-                o.r1 = *reinterpret_cast<const uint4 *>(rr + 4);
-                o.r2 = *reinterpret_cast<const uint4 *>(rr + 8);
-                const int64_t pair = pair0 + static_cast<int64_t>(o.r0.x) * M;
-                o.g = Elem<GT>::load4(gbase + pair * (kCH * Elem<GT>::kBytes));
-                const int dxb = (o.r0.y >> 30) & 1u ? rowb : 0, dyb = (o.r0.y >> 31) ? W * rowb : 0;
-                const char *vb = vlev + static_cast<int64_t>(o.r0.y & 0xFFFFFFu) * rowb;
-                o.v0 = Elem<VT>::load4(vb); o.v1 = Elem<VT>::load4(vb + dxb);
-                o.v2 = Elem<VT>::load4(vb + dyb); o.v3 = Elem<VT>::load4(vb + dyb + dxb);
-            };
-            auto run_own = [&](bool on, const OwnGroup &o) {
+            // ---- b1. own samples, 8 per group (8 lanes x 4 channels each), up to NG groups per batch: every load of the batch
+            //          is requested before the first group is consumed ----------------------------------------------------------
+            auto run_own = [&](bool on, int r, const float4 &g, const float4 &v0, const float4 &v1, const float4 &v2, const float4 &v3) {
                 float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f, a = 0.f, lh = 0.f, lw = 0.f;
                 float wt[4] = {0.f, 0.f, 0.f, 0.f};
                 unsigned flags = 0u;
                 int64_t pair = 0;
                 if (on) {
-                    pair = pair0 + static_cast<int64_t>(o.r0.x) * M;
-                    wt[0] = __builtin_bit_cast(float, o.r1.x); wt[1] = __builtin_bit_cast(float, o.r1.y);
-                    wt[2] = __builtin_bit_cast(float, o.r1.z); wt[3] = __builtin_bit_cast(float, o.r1.w);
-                    a = __builtin_bit_cast(float, o.r2.x); lh = __builtin_bit_cast(float, o.r2.y); lw = __builtin_bit_cast(float, o.r2.z);
-                    flags = o.r2.w;
-                    const float4 g = o.g;
+                    const unsigned *rr = wrec + r * kRecDw;
+                    const uint4 r0 = *reinterpret_cast<const uint4 *>(rr);
+                    const uint4 r1 = *reinterpret_cast<const uint4 *>(rr + 4);
+                    const uint4 r2 = *reinterpret_cast<const uint4 *>(rr + 8);
+                    pair = pair0 + static_cast<int64_t>(r0.x) * M;
+                    wt[0] = __builtin_bit_cast(float, r1.x); wt[1] = __builtin_bit_cast(float, r1.y);
+                    wt[2] = __builtin_bit_cast(float, r1.z); wt[3] = __builtin_bit_cast(float, r1.w);
+                    a = __builtin_bit_cast(float, r2.x); lh = __builtin_bit_cast(float, r2.y); lw = __builtin_bit_cast(float, r2.z);
+                    flags = r2.w;
                     if (finite) {
                         const float as = a * scale;
-                        accumulate4(win, o.r0.z, o.r0.w, wt, make_float4(as * g.x, as * g.y, as * g.z, as * g.w), k, magic);
+                        accumulate4(win, r0.z, r0.w, wt, make_float4(as * g.x, as * g.y, as * g.z, as * g.w), k, magic);
                     }
                     if ((flags & 0xF0u) && shift == 0) {      // corners nobody else will see: global fp32 atomics (.cuh:125-152)
                         const float4 tg = make_float4(a * g.x, a * g.y, a * g.z, a * g.w);
-                        const unsigned pix = o.r0.y & 0xFFFFFFu;
+                        const unsigned pix = r0.y & 0xFFFFFFu;
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             if (flags & (16u << c)) {
-                                float *p = far_lev + (static_cast<int64_t>(pix) + ((c & 1) && (o.r0.y >> 30 & 1u) ? 1 : 0) + ((c >> 1) && (o.r0.y >> 31) ? W : 0)) * (M * kCH);
+                                float *p = far_lev + (static_cast<int64_t>(pix) + ((c & 1) && (r0.y >> 30 & 1u) ? 1 : 0) + ((c >> 1) && (r0.y >> 31) ? W : 0)) * (M * kCH);
                                 unsafeAtomicAdd(p + 0, wt[c] * tg.x);
                                 unsafeAtomicAdd(p + 1, wt[c] * tg.y);
                                 unsafeAtomicAdd(p + 2, wt[c] * tg.z);
@@ -464,10 +478,10 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                         }
                         if (k == 0) hdr->far = 1u;
                     }
-                    e0 = g.x * o.v0.x + g.y * o.v0.y + g.z * o.v0.z + g.w * o.v0.w;
-                    e1 = g.x * o.v1.x + g.y * o.v1.y + g.z * o.v1.z + g.w * o.v1.w;
-                    e2 = g.x * o.v2.x + g.y * o.v2.y + g.z * o.v2.z + g.w * o.v2.w;
-                    e3 = g.x * o.v3.x + g.y * o.v3.y + g.z * o.v3.z + g.w * o.v3.w;
+                    e0 = g.x * v0.x + g.y * v0.y + g.z * v0.z + g.w * v0.w;
+                    e1 = g.x * v1.x + g.y * v1.y + g.z * v1.z + g.w * v1.w;
+                    e2 = g.x * v2.x + g.y * v2.y + g.z * v2.z + g.w * v2.w;
+                    e3 = g.x * v3.x + g.y * v3.y + g.z * v3.z + g.w * v3.w;
                 }
                 float d0 = sum8f(e0), d1 = sum8f(e1), d2 = sum8f(e2), d3 = sum8f(e3);    // over the 8 lanes of the sample, every lane takes part
                 d0 = (flags & 1u) ? d0 : 0.f; d1 = (flags & 2u) ? d1 : 0.f;              // a corner outside the map reads nothing (.cuh:56-78)
@@ -481,53 +495,70 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                                                                             static_cast<float>(H) * (a * (hw * (d2 - d0) + lw * (d3 - d1))));  // .cuh:158
                 }
             };
-            if constexpr (PIPE) {
-                OwnGroup ga, gb;
-                if (j < no) fetch_own(j, ga);
-                for (int i0 = 0; i0 < no; i0 += 16) {
-                    if (i0 + 8 + j < no) fetch_own(i0 + 8 + j, gb);
-                    run_own(i0 + j < no, ga);
-                    if (i0 + 8 < no) {                        // (wave-uniform)
-                        if (i0 + 16 + j < no) fetch_own(i0 + 16 + j, ga);
-                        run_own(i0 + 8 + j < no, gb);
-                    }
+            // a batch of exactly NG groups (the last one possibly ragged): straight-line code, lanes beyond the list re-read its
+            // last record and are masked at the use
+            auto own_batch = [&](auto ngc, int i0) {
+                constexpr int NG = decltype(ngc)::value;
+                typename Elem<GT>::Raw rg[NG];
+                typename Elem<VT>::Raw rv[NG][4];
+#pragma unroll
+                for (int t = 0; t < NG; ++t) {
+                    const int r = min(i0 + 8 * t + j, no - 1);
+                    const uint2 h = *reinterpret_cast<const uint2 *>(wrec + r * kRecDw);
+                    rg[t] = Elem<GT>::loadr(gbase + (pair0 + static_cast<int64_t>(h.x) * M) * (kCH * Elem<GT>::kBytes));
+                    const int dxb = (h.y >> 30) & 1u ? rowb : 0, dyb = (h.y >> 31) ? W * rowb : 0;
+                    const char *vb = vlev + static_cast<int64_t>(h.y & 0xFFFFFFu) * rowb;
+                    rv[t][0] = Elem<VT>::loadr(vb); rv[t][1] = Elem<VT>::loadr(vb + dxb);
+                    rv[t][2] = Elem<VT>::loadr(vb + dyb); rv[t][3] = Elem<VT>::loadr(vb + dyb + dxb);
                 }
-            } else {
-                OwnGroup ga;
-                for (int i0 = 0; i0 < no; i0 += 8) {
-                    if (i0 + j < no) fetch_own(i0 + j, ga);
-                    run_own(i0 + j < no, ga);
+#pragma unroll
+                for (int t = 0; t < NG; ++t) {
+                    const int r = i0 + 8 * t + j;
+                    run_own(r < no, min(r, no - 1), Elem<GT>::widen(rg[t]), Elem<VT>::widen(rv[t][0]), Elem<VT>::widen(rv[t][1]),
+                            Elem<VT>::widen(rv[t][2]), Elem<VT>::widen(rv[t][3]));
+                }
+            };
+            for (int i0 = 0; i0 < no; i0 += 8 * GMAX) {
+                const int ng = min(GMAX, (no - i0 + 7) >> 3);                             // wave-uniform
+                if (ng == 1) own_batch(std::integral_constant<int, 1>(), i0);
+                else if (ng == 2) own_batch(std::integral_constant<int, 2>(), i0);
+                else if (ng == 3) own_batch(std::integral_constant<int, 3>(), i0);
+                else if (GMAX <= 4 || ng == 4) own_batch(std::integral_constant<int, 4>(), i0);
+                else if constexpr (GMAX > 4) {
+                    if (ng <= 6) { own_batch(std::integral_constant<int, 4>(), i0); own_batch(std::integral_constant<int, 2>(), i0 + 32); }
+                    else own_batch(std::integral_constant<int, GMAX>(), i0);
                 }
             }
             // ---- b2. neighbours' samples that reach into this core: accumulate only ---------------------------------------
-            auto fetch_halo = [&](int r, HaloGroup &o) {
-                const unsigned *rr = wrec + r * kRecDw;
-                o.r0 = *reinterpret_cast<const uint4 *>(rr);
-                o.r1 = *reinterpret_cast<const uint4 *>(rr + 4);
-                o.a = __builtin_bit_cast(float, rr[8]);
-                o.g = Elem<GT>::load4(gbase + (pair0 + static_cast<int64_t>(o.r0.x) * M) * (kCH * Elem<GT>::kBytes));
-            };
-            auto run_halo = [&](const HaloGroup &o) {
-                const float wt[4] = {__builtin_bit_cast(float, o.r1.x), __builtin_bit_cast(float, o.r1.y),
-                                     __builtin_bit_cast(float, o.r1.z), __builtin_bit_cast(float, o.r1.w)};
-                const float as = o.a * scale;
-                accumulate4(win, o.r0.z, o.r0.w, wt, make_float4(as * o.g.x, as * o.g.y, as * o.g.z, as * o.g.w), k, magic);
-            };
-            if constexpr (PIPE) {
-                HaloGroup ha, hb;
+            auto halo_batch = [&](auto ngc, int i0) {
+                constexpr int NG = decltype(ngc)::value;
+                typename Elem<GT>::Raw rg[NG];
                 const int h0 = 64 - nh;
-                if (j < nh) fetch_halo(h0 + j, ha);
-                for (int i0 = 0; i0 < nh; i0 += 16) {
-                    if (i0 + 8 + j < nh) fetch_halo(h0 + i0 + 8 + j, hb);
-                    if (i0 + j < nh) run_halo(ha);
-                    if (i0 + 16 + j < nh) fetch_halo(h0 + i0 + 16 + j, ha);
-                    if (i0 + 8 + j < nh) run_halo(hb);
+#pragma unroll
+                for (int t = 0; t < NG; ++t) {
+                    const int r = h0 + min(i0 + 8 * t + j, nh - 1);
+                    rg[t] = Elem<GT>::loadr(gbase + (pair0 + static_cast<int64_t>(wrec[r * kRecDw]) * M) * (kCH * Elem<GT>::kBytes));
                 }
-            } else {
-                HaloGroup ha;
-                for (int i0 = 0; i0 < nh; i0 += 8) {
-                    if (i0 + j < nh) { fetch_halo(64 - nh + i0 + j, ha); run_halo(ha); }
+#pragma unroll
+                for (int t = 0; t < NG; ++t) {
+                    if (i0 + 8 * t + j < nh) {
+                        const unsigned *rr = wrec + (h0 + i0 + 8 * t + j) * kRecDw;
+                        const uint4 r0 = *reinterpret_cast<const uint4 *>(rr);
+                        const uint4 r1 = *reinterpret_cast<const uint4 *>(rr + 4);
+                        const float wt[4] = {__builtin_bit_cast(float, r1.x), __builtin_bit_cast(float, r1.y),
+                                             __builtin_bit_cast(float, r1.z), __builtin_bit_cast(float, r1.w)};
+                        const float as = __builtin_bit_cast(float, rr[8]) * scale;
+                        const float4 g = Elem<GT>::widen(rg[t]);
+                        accumulate4(win, r0.z, r0.w, wt, make_float4(as * g.x, as * g.y, as * g.z, as * g.w), k, magic);
+                    }
                 }
+            };
+            for (int i0 = 0; i0 < nh; i0 += 32) {
+                const int ng = min(4, (nh - i0 + 7) >> 3);
+                if (ng == 1) halo_batch(std::integral_constant<int, 1>(), i0);
+                else if (ng == 2) halo_batch(std::integral_constant<int, 2>(), i0);
+                else if (ng == 3) halo_batch(std::integral_constant<int, 3>(), i0);
+                else halo_batch(std::integral_constant<int, 4>(), i0);
             }
             wave_sync();
         }
@@ -725,9 +756,9 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
     profile_end(st);
     // 512 threads (8 waves) or 1024 (16 waves: twice the record buffers, more loads in flight per CU)
     int threads = env_int("MDETR_MSDA_THREADS", 512);
-    threads = threads >= 1024 ? 1024 : 512;
+    threads = (threads >= 1024 && elem_dtype == 2) ? 1024 : 512;   // (16 waves leave 128 VGPRs: the fp32 form's load batches do not fit)
     size_t lds = static_cast<size_t>(pl.max_cells + kTrash) * kCellU64 * 8 + static_cast<size_t>(pl.max_cells) * 4 +
-                 static_cast<size_t>(threads / 64) * 64 * kRecDw * 4 + static_cast<size_t>(pl.max_tab) * 4 + 16;
+                 static_cast<size_t>(threads / 64) * 64 * kRecDw * 4 + static_cast<size_t>(pl.max_tab) * 4 + 128 + 16;
     if (lds > 160 * 1024 && threads == 1024) {
         threads = 512;
         lds -= static_cast<size_t>(8) * 64 * kRecDw * 4;
@@ -735,15 +766,17 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
     if (lds > 160 * 1024) return hipErrorNotSupported;
     int dev = 0;
     if ((err = hipGetDevice(&dev)) != hipSuccess) return err;
-    const bool pipe = threads == 512 && env_int("MDETR_MSDA_PIPE", 1) != 0;   // (the 1024-thread form has 128 VGPRs: no room for a second group)
+    // groups of 8 own samples whose loads are in flight together: 4 (<= 128 VGPRs: two 512-thread workgroups per CU when
+    // the LDS allows) or 8 (bf16 only, one workgroup per CU)
+    int groups = env_int("MDETR_MSDA_GROUPS", 4);
+    groups = (groups >= 8 && elem_dtype == 2 && threads == 512) ? 8 : 4;
     static bool attr_set[6][64] = {};                        // per kernel instance and device
-    const int which = (elem_dtype == 2 ? 1 : 0) + (threads == 1024 ? 4 : (pipe ? 0 : 2));
-    const void *kern = which == 0 ? reinterpret_cast<const void *>(msda_bwd_fused<float, float, 512, true>)
-                     : which == 1 ? reinterpret_cast<const void *>(msda_bwd_fused<__hip_bfloat16, __hip_bfloat16, 512, true>)
-                     : which == 2 ? reinterpret_cast<const void *>(msda_bwd_fused<float, float, 512, false>)
-                     : which == 3 ? reinterpret_cast<const void *>(msda_bwd_fused<__hip_bfloat16, __hip_bfloat16, 512, false>)
-                     : which == 4 ? reinterpret_cast<const void *>(msda_bwd_fused<float, float, 1024, false>)
-                                  : reinterpret_cast<const void *>(msda_bwd_fused<__hip_bfloat16, __hip_bfloat16, 1024, false>);
+    const int which = (elem_dtype == 2 ? 1 : 0) + (threads == 1024 ? 4 : (groups == 8 ? 2 : 0));
+    typedef __hip_bfloat16 bf;
+    const void *kern = which == 0 ? reinterpret_cast<const void *>(msda_bwd_fused<float, float, 512, 4>)
+                     : which == 1 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 512, 4>)
+                     : which == 3 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 512, 8>)
+                                  : reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 1024, 4>);
     if (dev < 0 || dev >= 64 || !attr_set[which][dev]) {
         if ((err = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return err;
         if (dev >= 0 && dev < 64) attr_set[which][dev] = true;
@@ -755,12 +788,10 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
         hipLaunchKernelGGL(k, dim3(nblocks), dim3(threads), lds, st, pl, static_cast<const VT *>(value), loc, attn,
                            static_cast<const GT *>(grad_out), grad_value, grad_loc, grad_attn, hdr, scratch, far);
     };
-    if (which == 0) go(msda_bwd_fused<float, float, 512, true>, float(), float());
-    else if (which == 1) go(msda_bwd_fused<__hip_bfloat16, __hip_bfloat16, 512, true>, __hip_bfloat16(), __hip_bfloat16());
-    else if (which == 2) go(msda_bwd_fused<float, float, 512, false>, float(), float());
-    else if (which == 3) go(msda_bwd_fused<__hip_bfloat16, __hip_bfloat16, 512, false>, __hip_bfloat16(), __hip_bfloat16());
-    else if (which == 4) go(msda_bwd_fused<float, float, 1024, false>, float(), float());
-    else go(msda_bwd_fused<__hip_bfloat16, __hip_bfloat16, 1024, false>, __hip_bfloat16(), __hip_bfloat16());
+    if (which == 0) go(msda_bwd_fused<float, float, 512, 4>, float(), float());
+    else if (which == 1) go(msda_bwd_fused<bf, bf, 512, 4>, bf(), bf());
+    else if (which == 3) go(msda_bwd_fused<bf, bf, 512, 8>, bf(), bf());
+    else go(msda_bwd_fused<bf, bf, 1024, 4>, bf(), bf());
     profile_end(st);
     const int64_t nrows = static_cast<int64_t>(B) * S * M;
     profile_begin(8, Lq, st);

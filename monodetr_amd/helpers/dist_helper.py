@@ -49,3 +49,84 @@ class FlatGradSync:
             dist.all_reduce(flat, group=self.group)                   # SUM (gloo has no AVG); RCCL ring over xGMI on the GPU
             flat.mul_(1.0 / self.world)
             torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+
+
+class BucketedGradSync:
+    """The overlapped form of the same exchange ("bucketed and overlapped with backward"): parameters are
+    grouped, in the order their gradients become ready, into buckets of ~``bucket_mb`` per dtype; a post-accumulate hook
+    on each parameter counts its bucket down, and the bucket's all-reduce is issued (asynchronously, on the process
+    group's own stream) the moment its last gradient exists -- while the backward pass of the earlier layers is still
+    running.  ``sync()`` after ``backward()`` waits for the outstanding reductions and copies the averages back.
+
+    The first iteration is a discovery pass (one flat exchange, like ``FlatGradSync``) that records which parameters
+    receive gradients and in which order; buckets are laid out from that.  Same requirement as ``FlatGradSync``: the
+    set of parameters with gradients is the same on every rank and in every iteration.
+
+    When to prefer which: on ONE node the flat exchange costs 8 launches and ~1-2 ms of un-overlapped xGMI time at the end
+    of a ~30 ms step; this form hides that time at the price of one Python hook per parameter (345) and ~3 launches per
+    bucket.  ``bench.py`` selects with MDETR_BENCH_SYNC=flat|bucketed|ddp."""
+
+    def __init__(self, params, world_size=None, group=None, bucket_mb=32.0):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.world = world_size if world_size is not None else dist.get_world_size(group)
+        self.bucket_bytes = int(bucket_mb * (1 << 20))
+        self.buckets = None                      # list of dicts {params, pending, work, flat}
+        self._order = []                         # discovery: parameters in the order their gradients appeared
+        self._of = {}
+        self._flat = FlatGradSync(self.params, self.world, group)
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._hook)
+
+    def _hook(self, p):
+        if self.buckets is None:
+            self._order.append(p)
+            return
+        b = self._of.get(id(p))
+        if b is None:
+            return
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    @torch.no_grad()
+    def _launch(self, b):
+        grads = [p.grad for p in b["params"]]
+        b["flat"] = torch.cat([g.reshape(-1) for g in grads])
+        b["work"] = dist.all_reduce(b["flat"], group=self.group, async_op=True)
+
+    def _build(self):
+        seen, ordered = set(), []
+        for p in self._order:                    # gradient-ready order of the discovery pass (accumulated grads fire once)
+            if id(p) not in seen and p.grad is not None:
+                seen.add(id(p))
+                ordered.append(p)
+        self.buckets, open_by_dtype = [], {}
+        for p in ordered:
+            b = open_by_dtype.get(p.grad.dtype)
+            if b is None or b["bytes"] >= self.bucket_bytes:
+                b = open_by_dtype[p.grad.dtype] = {"params": [], "bytes": 0, "pending": 0, "work": None, "flat": None}
+                self.buckets.append(b)
+            b["params"].append(p)
+            b["bytes"] += p.grad.numel() * p.grad.element_size()
+            self._of[id(p)] = b
+        for b in self.buckets:
+            b["pending"] = len(b["params"])
+
+    @torch.no_grad()
+    def sync(self):
+        if self.buckets is None:                 # discovery iteration: plain flat exchange
+            self._flat.sync()
+            self._build()
+            return
+        for b in self.buckets:
+            if b["work"] is None:                # a bucket whose hooks did not all fire (should not happen on a static graph)
+                if any(p.grad is None for p in b["params"]):
+                    raise RuntimeError("BucketedGradSync: the set of parameters with gradients changed between iterations")
+                self._launch(b)
+        for b in self.buckets:
+            b["work"].wait()
+            flat = b["flat"].mul_(1.0 / self.world)
+            grads = [p.grad for p in b["params"]]
+            torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+            b["work"], b["flat"], b["pending"] = None, None, len(b["params"])

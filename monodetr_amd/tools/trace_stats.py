@@ -4,7 +4,7 @@
 
 rocprofv3's own --stats covers the whole process, i.e. also MIOpen's solver search during the first
 warm-up steps (its naive reference convolutions then dominate the table).  This tool keeps only the
-kernels of the LAST K training steps: a step is delimited by the encoder-shaped msda_bwd launches
+kernels of the LAST K training steps: a step is delimited by the encoder-shaped msda_bwd_fused (or msda_bwd_d32) launches
 (3 per step), so the window starts after the (3*K+1)-th last of them ended.
 """
 import argparse
@@ -53,7 +53,7 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
                          int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0)))
     rows.sort()
-    bwd = [r for r in rows if "msda_bwd_d32" in r[2]]
+    bwd = [r for r in rows if "msda_bwd_fused" in r[2]] or [r for r in rows if "msda_bwd_d32" in r[2]]
     big = max(r[3] for r in bwd)
     enc = [r for r in bwd if r[3] == big]
     need = 3 * a.steps

@@ -109,8 +109,40 @@ def _worker(rank, world, port, out_dir):
         a.grad, b.grad = torch.full((5,), float(rank + 1)), torch.full((3, 2), float(2 * rank + 2), dtype=torch.bfloat16)
         FlatGradSync([a, b]).sync()
         mixed_ok = bool((a.grad == (1 + world) / 2).all()) and bool((b.grad.float() == (1 + world)).all())
+        # the overlapped form: discovery iteration (flat), then an iteration whose buckets are reduced from gradient hooks
+        from monodetr_amd.helpers.dist_helper import BucketedGradSync
+        model, criterion = fresh()
+        broadcast_parameters(model)
+        bsync = BucketedGradSync(model.parameters(), bucket_mb=8.0)
+        worst_bucketed, n_buckets = 0.0, 0
+        for it in range(2):                                           # (same batch, same weights: the same gradients are expected twice)
+            for p_ in model.parameters():
+                p_.grad = None
+            loss_of(model, criterion, batch).backward()
+            bsync.sync()
+            got3 = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+            assert sorted(got3) == sorted(avg)
+            worst_bucketed = max(worst_bucketed, max(((got3[n] - avg[n]).abs().max() / (avg[n].abs().max() + 1e-12)).item() for n in avg))
+            n_buckets = len(bsync.buckets)
+
+        # bench.py's own step object on the N > 1 path (gloo here, RCCL on the GPUs), both exchanges: ranks hold identical
+        # parameters after two iterations, and every rank runs the same committed switch list
+        import bench
+        same_bench = {}
+        for mode in ("flat", "bucketed"):
+            step = bench.TrainStep(torch.device("cpu"), 1, "fp32", ddp=mode, local_rank=rank, size=(96, 320), switches=())
+            for _ in range(2):
+                step()
+            flat = torch.cat([p.detach().reshape(-1) for p in step.raw_model.parameters()])
+            gathered = [torch.empty_like(flat) for _ in range(world)]
+            dist.all_gather(gathered, flat)
+            same_bench[mode] = all(torch.equal(gathered[0], g) for g in gathered[1:])
+        lists = [None] * world
+        dist.all_gather_object(lists, sorted(bench.committed_switches("bf16")[0]))
+        same_switches = all(l == lists[0] for l in lists)
         torch.save(dict(worst=worst, same=same, unused=unused, n_grads=len(got), worst_flat=worst_flat, same_flat=same_flat,
-                        mixed_ok=mixed_ok), os.path.join(out_dir, "r%d.pt" % rank))
+                        mixed_ok=mixed_ok, worst_bucketed=worst_bucketed, n_buckets=n_buckets, same_bench=same_bench,
+                        same_switches=same_switches), os.path.join(out_dir, "r%d.pt" % rank))
     finally:
         dist.destroy_process_group()
 
@@ -124,6 +156,8 @@ def test_two_rank_ddp_step_matches_manual_gradient_average(tmp_path):
         assert res["same"], "ranks diverged after the optimizer step"
         assert res["worst"] < 1e-4, res["worst"]
         assert res["same_flat"] and res["worst_flat"] < 1e-4 and res["mixed_ok"], res
+        assert res["worst_bucketed"] < 1e-4 and res["n_buckets"] >= 3, res
+        assert res["same_bench"] == {"flat": True, "bucketed": True} and res["same_switches"], res
         assert res["n_grads"] > 300
         assert all(n.startswith("label_enc") or ".sa_v_proj." in n or "decoder.query_scale" in n or "decoder.ref_point_head" in n
                    for n in res["unused"]), res["unused"]

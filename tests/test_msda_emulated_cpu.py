@@ -285,12 +285,13 @@ def test_fused_backward_non_finite_gradients_and_workspace_reuse(monkeypatch):
         assert close(gv, rv, 1e-5) and close(gl, rl, 1e-6) and close(ga, ra, 1e-6), (B, Lq)
 
 
-@pytest.mark.parametrize("threads,pipe", [(512, 0), (1024, 0)])
-def test_fused_backward_kernel_variants(monkeypatch, threads, pipe):
-    """The launch variants behind MDETR_MSDA_THREADS / MDETR_MSDA_PIPE (16-wave workgroups; no second group in flight)."""
+@pytest.mark.parametrize("threads,groups", [(512, 8), (1024, 4)])
+def test_fused_backward_kernel_variants(monkeypatch, threads, groups):
+    """The launch variants behind MDETR_MSDA_THREADS / MDETR_MSDA_GROUPS (16-wave workgroups; 8 sample groups in flight -- the
+    bf16 form only: the fp32 call below runs the 4-group kernel)."""
     _fused_env(monkeypatch, 4, 8, 2, 30, 3)
     monkeypatch.setenv("MDETR_MSDA_THREADS", str(threads))
-    monkeypatch.setenv("MDETR_MSDA_PIPE", str(pipe))
+    monkeypatch.setenv("MDETR_MSDA_GROUPS", str(groups))
     S = sum(h * w for h, w in SMALL)
     for Lq in (S, 50):
         p = make_problem(2, 2, 32, Lq, SMALL, 4, torch.float32, seed=3, lo=-0.2, hi=1.2)
