@@ -17,6 +17,7 @@ import numpy as np
 
 from .... import _capi
 from .rotate_iou import segmented_box3d_overlap, segmented_rotate_iou
+from .rotate_iou import self_check as rotate_iou_self_check
 
 N_SAMPLE_PTS = 41
 CLASS_NAMES = ['car', 'pedestrian', 'cyclist', 'van', 'person_sitting', 'truck']
@@ -79,6 +80,7 @@ def calculate_overlaps(gt_annos, dt_annos, metric):
     if metric not in (1, 2):
         raise ValueError("unknown metric")
     dts, gts = [_boxes_for(d, metric) for d in dt_annos], [_boxes_for(g, metric) for g in gt_annos]
+    rotate_iou_self_check()                                  # known-answer test of the overlap kernel, once per process
     fn = segmented_rotate_iou if metric == 1 else segmented_box3d_overlap
     return [o.astype(np.float64) for o in fn(dts, gts, -1)]
 

@@ -64,3 +64,29 @@ def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1, device_id=0):
     if boxes.shape[0] == 0 or query_boxes.shape[0] == 0:
         return np.zeros((boxes.shape[0], query_boxes.shape[0]), dtype=np.float32)
     return segmented_rotate_iou([boxes], [query_boxes], criterion, device_id)[0].astype(boxes.dtype)
+
+
+# ---- known-answer self check ---------------------------------------------------------------------------------------
+# A defect here would silently change the AP that picks checkpoint_best.  Before the first evaluation of a process the
+# kernel computes 4 x 3 overlaps under the three criteria the evaluation uses; the float32 bit patterns must equal the
+# table below, which tests/test_kitti_eval_cpu.py holds to the restatement of the reference's device functions
+# (oracle/kitti_eval.py, pinned on the fixture recorded from the reference's rotate_iou.py).
+_KAT_BOXES = np.array([[0, 0, 4, 2, 0.0], [1, 1, 3, 3, 0.5], [10, -2, 2.5, 1.5, -1.2], [0.3, 0.2, 4, 2, 3.0]], dtype=np.float32)
+_KAT_QUERY = np.array([[0, 0, 4, 2, 0.0], [0.5, 0.25, 2, 4, 0.3], [9.5, -2.2, 2, 2, 0.4]], dtype=np.float32)
+_KAT_BITS = {
+    -1: [1065353216, 1052080449, 0, 1050640856, 1055091924, 0, 0, 0, 1056588329, 1060655630, 1053012594, 0],
+    0: [1065353216, 1057356788, 0, 1057044538, 1059541364, 0, 0, 0, 1059248056, 1062622065, 1057854693, 0],
+    1: [1065353216, 1057356788, 0, 1055242571, 1058322990, 0, 0, 0, 1059959526, 1062622065, 1057854693, 0],
+}
+_self_checked = set()
+
+
+def self_check(device_id=0):
+    key = (_backend is not None, device_id)
+    if key in _self_checked:
+        return
+    for criterion, want in _KAT_BITS.items():
+        got = rotate_iou_gpu_eval(_KAT_BOXES, _KAT_QUERY, criterion, device_id).astype(np.float32).view(np.uint32).reshape(-1).tolist()
+        if got != want:
+            raise RuntimeError("mdetr_rotate_iou_eval failed its known-answer check (criterion %d): the evaluation must not be trusted" % criterion)
+    _self_checked.add(key)

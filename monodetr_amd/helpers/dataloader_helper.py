@@ -71,6 +71,7 @@ class DeviceLoader:
         return len(self.loader)
 
     def _upload(self, batch):
+        prep.self_check(self.device)                          # known-answer test of the image kernel, once per device
         packed, n = batch[0]
         if self.device.type != 'cuda':
             if prep._backend is None:

@@ -60,3 +60,43 @@ def preprocess_batch(pixels, descriptors, out_hw=(384, 1280), dtype=torch.float3
     if rc != 0:
         _capi.check(rc, "mdetr_kitti_preprocess")
     return out
+
+
+# ---- known-answer self check ---------------------------------------------------------------------------------------
+# A defect in the device image path would not crash: it would silently feed the network wrong pixels.  The first batch a
+# DeviceLoader uploads on a device is therefore preceded by one tiny launch of the same kernel on a fixed 48 x 36 image
+# with every stage of the chain switched on (flip, brightness, saturation, hue, contrast-last, channel permutation, a
+# non-trivial affine map), whose float32 output must hash to the value below.  tests/test_kitti_pipeline_cpu.py holds that
+# constant to the numpy / PIL oracle of the reference chain (oracle/kitti_pipeline.py, itself pinned on the fixture
+# recorded from the reference's KITTI_Dataset).
+_SELF_CHECK_SHA256 = "038e0608be770aea8ba68b60d368f5aba58f0791ea6e2574f21fc50fdab98d9a"
+_self_checked = set()
+
+
+def self_check_inputs():
+    v = np.arange(36 * 48 * 3, dtype=np.uint32)
+    img = ((v * np.uint32(2654435761)) >> np.uint32(13)).astype(np.uint8).reshape(36, 48, 3)
+    d = np.zeros(1, dtype=DESCRIPTOR)
+    d['width'], d['height'] = 48, 36
+    d['flags'] = FLIP | DISTORT | BRIGHTNESS | CONTRAST | SATURATION | HUE
+    d['perm'] = 1 | (2 << 2) | (0 << 4)
+    d['brightness'], d['contrast'], d['saturation'], d['hue'] = 11.5, 1.25, 0.75, -9.0
+    d['inv'] = np.array([1.17, 0.031, -1.4, -0.027, 1.43, -0.8])
+    return img, d
+
+
+def self_check(device):
+    """Once per device and process; raises if the kernel's output for the known input is not the known answer."""
+    import hashlib
+    device = torch.device(device)
+    if device in _self_checked:
+        return
+    img, d = self_check_inputs()
+    px = torch.from_numpy(img.reshape(-1).copy()).to(device)
+    ds = torch.from_numpy(d.view(np.uint8).reshape(-1).copy()).to(device)
+    out = preprocess_batch(px, ds, out_hw=(24, 40))
+    got = hashlib.sha256(out.cpu().contiguous().numpy().tobytes()).hexdigest()
+    if got != _SELF_CHECK_SHA256:
+        raise RuntimeError("mdetr_kitti_preprocess failed its known-answer check on %s (got %s): the device image path "
+                           "must not be trusted" % (device, got[:16]))
+    _self_checked.add(device)

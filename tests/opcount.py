@@ -52,13 +52,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--top", type=int, default=40)
-    ap.add_argument("--op", default=None, help="also list the forward source lines of this operator, e.g. _to_copy")
+    ap.add_argument("--op", default=None, help="also list the source lines of these operators (comma separated), e.g. _to_copy,add.Tensor")
+    ap.add_argument("--device", default="cpu", help="cuda: the real step (committed switch list, B = 8, 384 x 1280) on the GPU")
     a = ap.parse_args()
-    from oracle import msda_oracle
-    from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func as F_
-    msda_oracle.build()
-    F_.MSDA = msda_oracle.OracleMSDA
-    step = bench.TrainStep(torch.device("cpu"), 2, a.precision, size=(96, 320))
+    if a.device == "cuda":
+        step = bench.TrainStep(torch.device("cuda", 0), 8, a.precision, switches=bench.committed_switches(a.precision)[0])
+        for _ in range(3):
+            step._step()
+    else:
+        from oracle import msda_oracle
+        from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func as F_
+        msda_oracle.build()
+        F_.MSDA = msda_oracle.OracleMSDA
+        step = bench.TrainStep(torch.device("cpu"), 2, a.precision, size=(96, 320))
     step._step()                                   # caches
     images, calibs, img_sizes, targets = step.inputs
     c = Counter()
@@ -67,8 +73,7 @@ def main():
         out = step.model(images, calibs, targets, img_sizes, dn_args=None)
         c.phase = "criterion"
         losses = step.criterion(out, targets, None)
-        w = step.criterion.weight_dict
-        total = sum(losses[k] * w[k] for k in losses if k in w)
+        total = step.criterion.weighted_total(losses)
         c.phase = "backward"
         total.backward()
         c.phase = "optimizer"
@@ -81,9 +86,9 @@ def main():
         print("\n== %s: top source lines" % ph)
         for (p, site), n in sorted(((k, v) for k, v in c.by_site.items() if k[0] == ph), key=lambda kv: -kv[1])[:a.top]:
             print("%5d  %s" % (n, site))
-    if a.op:
-        print("\n== source lines of %s" % a.op)
-        for (p, site, op), n in sorted(((k, v) for k, v in c.by_site_op.items() if a.op in k[2]), key=lambda kv: -kv[1])[:a.top]:
+    for opname in (a.op.split(",") if a.op else []):
+        print("\n== source lines of %s" % opname)
+        for (p, site, op), n in sorted(((k, v) for k, v in c.by_site_op.items() if opname in k[2]), key=lambda kv: -kv[1])[:a.top]:
             print("%5d  %-10s %s" % (n, p, site))
     for ph in ("forward", "criterion", "backward", "optimizer"):
         print("\n== %s: top operators" % ph)

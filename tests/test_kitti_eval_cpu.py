@@ -147,3 +147,24 @@ def test_detection_decoding_matches_the_reference_helpers(tmp_path):
     assert set(back[0]['name']) <= {'Pedestrian', 'Car', 'Cyclist'}
     assert np.allclose(back[0]['score'], [round(p[-1], 2) for p in res[1]], atol=0.006)
     assert np.allclose(back[0]['dimensions'][:, [1, 2, 0]], [[round(v, 2) for v in p[6:9]] for p in res[1]], atol=0.006)   # file order h, w, l
+
+
+def test_overlap_kernel_self_check_table_is_what_the_reference_functions_compute(emulated_overlaps):
+    """The known-answer test that precedes the first evaluation of a process (rotate_iou.self_check): its table equals the
+    restatement of the reference's device functions bit for bit, the kernel source reproduces it, and a kernel that
+    computes anything else is refused."""
+    from monodetr_amd.datasets.kitti.kitti_eval_python import rotate_iou as R
+    for crit, want in R._KAT_BITS.items():
+        ref = oke.rotate_iou(R._KAT_BOXES, R._KAT_QUERY, crit).astype(np.float32)
+        assert ref.view(np.uint32).reshape(-1).tolist() == want, crit
+    R._self_checked.clear()
+    R.self_check(0)
+    saved = R._KAT_BITS[0][1]
+    R._KAT_BITS[0][1] ^= 1
+    R._self_checked.clear()
+    try:
+        with pytest.raises(RuntimeError, match="known-answer"):
+            R.self_check(0)
+    finally:
+        R._KAT_BITS[0][1] = saved
+        R._self_checked.clear()

@@ -264,3 +264,27 @@ def test_channels_last_output_holds_the_same_values(host_backend):
         b = host_backend.preprocess_batch(packed[head:], packed[:head], out_hw=(48, 128), dtype=dtype, channels_last=True)
         assert b.shape == a.shape and b.is_contiguous(memory_format=torch.channels_last) and not b.is_contiguous()
         assert torch.equal(a, b)
+
+
+def test_self_check_constant_is_what_the_reference_chain_computes(host_backend):
+    """The known-answer test the DeviceLoader runs before its first batch (kitti_prep_ext.self_check): its constant is the
+    hash of what the numpy / PIL oracle of the reference chain produces for the fixed input, the kernel arithmetic
+    reproduces it, and a kernel that computes anything else is refused."""
+    import torch
+    prep = host_backend
+    img, d = prep.self_check_inputs()
+    pd = {'brightness': 11.5, 'contrast': 1.25, 'saturation': 0.75, 'hue': -9.0, 'perm': (1, 2, 0), 'contrast_first': False}
+    want = okp.warp_and_normalise(okp.apply_photometric(img, pd), True, np.array(d['inv'][0]).reshape(2, 3), resolution=(40, 24))
+    assert hashlib.sha256(np.ascontiguousarray(want[None]).tobytes()).hexdigest() == prep._SELF_CHECK_SHA256
+    prep._self_checked.clear()
+    prep.self_check("cpu")                                   # (through the substituted backend)
+    assert torch.device("cpu") in prep._self_checked
+    prep._self_checked.clear()
+    saved = prep._SELF_CHECK_SHA256
+    prep._SELF_CHECK_SHA256 = "00" * 32
+    try:
+        with pytest.raises(RuntimeError, match="known-answer"):
+            prep.self_check("cpu")
+    finally:
+        prep._SELF_CHECK_SHA256 = saved
+        prep._self_checked.clear()
