@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDETR_ABI_VERSION 2
+#define MDETR_ABI_VERSION 3
 
 /* element types of the floating-point tensors */
 #define MDETR_F32 0
@@ -419,6 +419,10 @@ int mdetr_add_layernorm_backward(int io_dtype, int param_dtype, const void *dy, 
 int64_t mdetr_column_sum_workspace_bytes(int64_t rows, int cols);
 int mdetr_column_sum(int dtype, const void *x, float *out, void *workspace, int64_t workspace_bytes,
                      int64_t rows, int cols, int64_t ld, int device, void *stream);
+/* The same reduction with the result written in `out_dtype` (MDETR_F32, or MDETR_BF16: the fp32 sum rounded once) -- the
+ * gradient of a bf16 parameter then needs no separate cast launch. */
+int mdetr_column_sum_to(int dtype, const void *x, void *out, int out_dtype, void *workspace, int64_t workspace_bytes,
+                        int64_t rows, int cols, int64_t ld, int device, void *stream);
 
 /*
  * 3x3 / stride 1 / pad 1 convolution of a channels-last bf16 activation on the matrix cores (implicit GEMM, im2col in LDS),

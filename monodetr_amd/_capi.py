@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmonodetr_amd.so")
 
 MDETR_F32, MDETR_F64, MDETR_BF16 = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -45,6 +45,7 @@ SIGNATURES = {
     "mdetr_token_linear": (_c_int, [_c_vp] * 4 + [ctypes.c_int64, _c_int, _c_int, ctypes.c_int64, ctypes.c_int64, _c_int, _c_int, _c_vp]),
     "mdetr_column_sum_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, _c_int]),
     "mdetr_column_sum": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, ctypes.c_int64, ctypes.c_int64, _c_int, ctypes.c_int64, _c_int, _c_vp]),
+    "mdetr_column_sum_to": (_c_int, [_c_int, _c_vp, _c_vp, _c_int, _c_vp, ctypes.c_int64, ctypes.c_int64, _c_int, ctypes.c_int64, _c_int, _c_vp]),
     "mdetr_add_layernorm_forward": (_c_int, [_c_int, _c_int] + [_c_vp] * 7 + [ctypes.c_int64, _c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),
     "mdetr_add_layernorm_partial_rows": (ctypes.c_int64, [ctypes.c_int64]),
     "mdetr_add_layernorm_backward": (_c_int, [_c_int, _c_int] + [_c_vp] * 7 + [ctypes.c_int64, _c_int, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),

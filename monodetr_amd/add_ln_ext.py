@@ -48,12 +48,12 @@ def _dev(t):
     return (t.device.index if cuda else -1), (torch.cuda.current_stream(t.device).cuda_stream if cuda else None)
 
 
-def _column_sum_f32(x):
-    """fp32 [rows, n] -> [n] (the partial gamma / beta sums; at most 1024 rows)."""
+def _column_sum_f32(x, out_dtype=torch.float32):
+    """fp32 [rows, n] -> [n] (the partial gamma / beta sums; at most 1024 rows), written as ``out_dtype``."""
     if x.is_cuda and _backend is None:
         from .colsum_ext import column_sum
-        return column_sum(x)
-    return x.sum(0)
+        return column_sum(x, out_dtype if out_dtype in (torch.float32, torch.bfloat16) else torch.float32)
+    return x.sum(0).to(out_dtype)
 
 
 class _AddLayerNorm(torch.autograd.Function):
@@ -98,9 +98,7 @@ class _AddLayerNorm(torch.autograd.Function):
                                               ctx.seed_dev.data_ptr() if ctx.seed_dev is not None else None, dev, stream)
         if rc != 0:
             _capi.check(rc, "mdetr_add_layernorm_backward")
-        sums = _column_sum_f32(partial)
-        if g_dtype == b_dtype:
-            sums = sums.to(g_dtype)                                 # one cast for both
+        sums = _column_sum_f32(partial, g_dtype if g_dtype == b_dtype else torch.float32)   # written in the parameters' dtype
         return da.view(shape), db.view(shape), sums[:C].to(g_dtype), sums[C:].to(b_dtype), None, None, None, None
 
 

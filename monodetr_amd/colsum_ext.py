@@ -14,8 +14,9 @@ def supported(x):
             and (x.stride(0) * x.element_size()) % 16 == 0 and x.data_ptr() % 16 == 0 and x.shape[0] > 0)
 
 
-def column_sum(x):
-    """x [T, N] (f32 / bf16, unit column stride) -> fp32 [N]."""
+def column_sum(x, out_dtype=torch.float32):
+    """x [T, N] (f32 / bf16, unit column stride) -> [N] column sums, accumulated in fp32 and written as ``out_dtype``
+    (float32 or bfloat16: one rounding, no separate cast launch)."""
     if not supported(x):
         raise RuntimeError("column_sum: needs a CUDA f32/bf16 matrix with 16-byte aligned rows")
     T, N = x.shape
@@ -24,8 +25,11 @@ def column_sum(x):
     ws = _workspaces.get(x.device)
     if ws is None or ws.numel() < need:
         ws = _workspaces[x.device] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
-    out = torch.empty(N, dtype=torch.float32, device=x.device)
-    rc = lib.mdetr_column_sum(_capi.MDETR_BF16 if x.dtype == torch.bfloat16 else _capi.MDETR_F32, x.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
-                              T, N, x.stride(0), x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
-    _capi.check(rc, "mdetr_column_sum")
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("column_sum: out_dtype must be float32 or bfloat16")
+    out = torch.empty(N, dtype=out_dtype, device=x.device)
+    code = lambda dt: _capi.MDETR_BF16 if dt == torch.bfloat16 else _capi.MDETR_F32
+    rc = lib.mdetr_column_sum_to(code(x.dtype), x.data_ptr(), out.data_ptr(), code(out_dtype), ws.data_ptr(), ws.numel(),
+                                 T, N, x.stride(0), x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+    _capi.check(rc, "mdetr_column_sum_to")
     return out

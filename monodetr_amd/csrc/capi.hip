@@ -458,22 +458,35 @@ int64_t mdetr_column_sum_workspace_bytes(int64_t rows, int cols)
     return mdetr::colsum_workspace_bytes(rows, cols);
 }
 
+static int column_sum_impl(const char *who, int dtype, const void *x, void *out, int out_dtype, void *workspace, int64_t workspace_bytes,
+                           int64_t rows, int cols, int64_t ld, int device, void *stream)
+{
+    if (rows < 0 || cols < 0 || ld < cols) return fail(MDETR_E_ARG, "%s: bad shape rows=%lld cols=%d ld=%lld", who,
+                                                      static_cast<long long>(rows), cols, static_cast<long long>(ld));
+    if (out_dtype != MDETR_F32 && out_dtype != MDETR_BF16) return fail(MDETR_E_ARG, "%s: out_dtype must be MDETR_F32 or MDETR_BF16", who);
+    if (cols == 0) return MDETR_OK;
+    if (!out || !workspace || (rows > 0 && !x)) return fail(MDETR_E_ARG, "%s: null pointer", who);
+    if (!mdetr::colsum_supported(dtype, cols, ld, x))
+        return fail(MDETR_E_ARG, "%s: needs f32 (cols %% 4 == 0) or bf16 (cols %% 8 == 0), 16-byte aligned rows", who);
+    if (workspace_bytes < mdetr::colsum_workspace_bytes(rows, cols))
+        return fail(MDETR_E_ARG, "%s: workspace too small", who);
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "%s: set device %d: %s", who, device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::colsum_launch(dtype, x, out, workspace, rows, cols, ld, static_cast<hipStream_t>(stream), out_dtype);
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "%s: launch failed: %s", who, hipGetErrorString(e));
+    return MDETR_OK;
+}
+
 int mdetr_column_sum(int dtype, const void *x, float *out, void *workspace, int64_t workspace_bytes,
                      int64_t rows, int cols, int64_t ld, int device, void *stream)
 {
-    if (rows < 0 || cols < 0 || ld < cols) return fail(MDETR_E_ARG, "mdetr_column_sum: bad shape rows=%lld cols=%d ld=%lld",
-                                                      static_cast<long long>(rows), cols, static_cast<long long>(ld));
-    if (cols == 0) return MDETR_OK;
-    if (!out || !workspace || (rows > 0 && !x)) return fail(MDETR_E_ARG, "mdetr_column_sum: null pointer");
-    if (!mdetr::colsum_supported(dtype, cols, ld, x))
-        return fail(MDETR_E_ARG, "mdetr_column_sum: needs f32 (cols %% 4 == 0) or bf16 (cols %% 8 == 0), 16-byte aligned rows");
-    if (workspace_bytes < mdetr::colsum_workspace_bytes(rows, cols))
-        return fail(MDETR_E_ARG, "mdetr_column_sum: workspace too small");
-    DeviceScope dev(device);
-    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_column_sum: set device %d: %s", device, hipGetErrorString(dev.err));
-    const hipError_t e = mdetr::colsum_launch(dtype, x, out, workspace, rows, cols, ld, static_cast<hipStream_t>(stream));
-    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_column_sum: launch failed: %s", hipGetErrorString(e));
-    return MDETR_OK;
+    return column_sum_impl("mdetr_column_sum", dtype, x, out, MDETR_F32, workspace, workspace_bytes, rows, cols, ld, device, stream);
+}
+
+int mdetr_column_sum_to(int dtype, const void *x, void *out, int out_dtype, void *workspace, int64_t workspace_bytes,
+                        int64_t rows, int cols, int64_t ld, int device, void *stream)
+{
+    return column_sum_impl("mdetr_column_sum_to", dtype, x, out, out_dtype, workspace, workspace_bytes, rows, cols, ld, device, stream);
 }
 
 int mdetr_conv3x3_forward(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N,

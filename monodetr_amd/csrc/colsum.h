@@ -8,7 +8,8 @@ namespace mdetr {
 // dtype: 0 = f32, 2 = bf16 (MDETR_F32 / MDETR_BF16 of include/monodetr_amd.h)
 bool colsum_supported(int dtype, int cols, int64_t ld, const void *x);
 int64_t colsum_workspace_bytes(int64_t rows, int cols);
-hipError_t colsum_launch(int dtype, const void *x, float *out, void *workspace, int64_t rows, int cols, int64_t ld,
-                         hipStream_t st);
+// out_dtype: 0 = fp32 `out`, 2 = bf16 `out` (the fp32 sum rounded once)
+hipError_t colsum_launch(int dtype, const void *x, void *out, void *workspace, int64_t rows, int cols, int64_t ld,
+                         hipStream_t st, int out_dtype = 0);
 
 }  // namespace mdetr

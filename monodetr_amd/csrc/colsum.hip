@@ -83,8 +83,9 @@ void colsum_partial_kernel(const T *__restrict__ x, float *__restrict__ partial,
 
 // 16 columns x 16 row slices per block: slice s adds partial rows s, s+16, ... (four loads in flight),
 // the slices are combined through LDS in slice order
+template <typename OT>
 __global__ __launch_bounds__(kThreads)
-void colsum_final_kernel(const float *__restrict__ partial, float *__restrict__ out, int nblk, int cols)
+void colsum_final_kernel(const float *__restrict__ partial, OT *__restrict__ out, int nblk, int cols)
 {
     __shared__ float red[16][17];
     const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
@@ -106,7 +107,7 @@ void colsum_final_kernel(const float *__restrict__ partial, float *__restrict__ 
         float s = 0.f;
 #pragma unroll
         for (int l = 0; l < 16; ++l) s += red[l][c];
-        out[col] = s;
+        out[col] = static_cast<OT>(s);                      // one rounding of the fp32 sum (a bf16 gradient needs no cast launch)
     }
 }
 
@@ -125,13 +126,13 @@ bool colsum_supported(int dtype, int cols, int64_t ld, const void *x)
            (reinterpret_cast<uintptr_t>(x) & 15) == 0;
 }
 
-hipError_t colsum_launch(int dtype, const void *x, float *out, void *workspace, int64_t rows, int cols, int64_t ld,
-                         hipStream_t st)
+hipError_t colsum_launch(int dtype, const void *x, void *out, void *workspace, int64_t rows, int cols, int64_t ld,
+                         hipStream_t st, int out_dtype)
 {
     if (cols == 0) return hipSuccess;
     const int64_t nblk = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
-    // a single row block: its partial row IS the result
-    float *partial = nblk == 1 ? out : static_cast<float *>(workspace);
+    // a single row block: its partial row IS the (fp32) result
+    float *partial = (nblk == 1 && out_dtype == 0) ? static_cast<float *>(out) : static_cast<float *>(workspace);
     if (nblk > 0) {
         const int vec = dtype == 2 ? 8 : 4;
         const int cvs = cols / vec;
@@ -145,9 +146,13 @@ hipError_t colsum_launch(int dtype, const void *x, float *out, void *workspace, 
             hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(kThreads), 0, st,
                                static_cast<const float *>(x), partial, rows, cols, ld, CT);
     }
-    if (nblk == 1) return hipGetLastError();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 15) / 16), dim3(kThreads), 0, st,
-                       partial, out, static_cast<int>(nblk), cols);
+    if (nblk == 1 && out_dtype == 0) return hipGetLastError();
+    if (out_dtype == 2)
+        hipLaunchKernelGGL(colsum_final_kernel<__hip_bfloat16>, dim3((cols + 15) / 16), dim3(kThreads), 0, st,
+                           partial, static_cast<__hip_bfloat16 *>(out), static_cast<int>(nblk), cols);
+    else
+        hipLaunchKernelGGL(colsum_final_kernel<float>, dim3((cols + 15) / 16), dim3(kThreads), 0, st,
+                           partial, static_cast<float *>(out), static_cast<int>(nblk), cols);
     return hipGetLastError();
 }
 

@@ -650,7 +650,7 @@ int env_int(const char *name, int dflt)
     return v && *v ? atoi(v) : dflt;
 }
 
-bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, int B, int S, int M, int L, int Lq, int P)
+bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, int B, int S, int M, int L, int Lq, int P, int elem_dtype = 2)
 {
     if (L < 1 || L > kMaxLevels || P < 1 || P > 8 || B < 1 || M < 1 || Lq < 1) return false;
     memset(&pl, 0, sizeof(pl));
@@ -667,9 +667,12 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
     if (total != S) return false;
     const bool self = Lq == S;                               // queries = the pyramid's cells, in order
     if (!self && static_cast<int64_t>(Lq) * P > 16384) return false;   // every block scans every query: only for few queries
-    // tuning knobs (read per call: a handful of getenv()s against a multi-microsecond launch sequence)
-    const int tile_h = env_int("MDETR_MSDA_TILE_H", 16), tile_w = env_int("MDETR_MSDA_TILE_W", 32);
-    const int reach = env_int("MDETR_MSDA_REACH", 5), chunks_env = env_int("MDETR_MSDA_CHUNKS", 8);
+    // tuning knobs (read per call: a handful of getenv()s against a multi-microsecond launch sequence).  Defaults from the
+    // sweep on MI355X at the encoder shape (profiles/r02f_opbench_*.json): 16 x 40 core tiles, reach 5 cells (the model's
+    // initial offsets reach 4 px on every level), whole-level windows up to 512 cells split into 12 query chunks.
+    // (the fp32 form runs 8 waves per workgroup and prefers bigger tiles: 24 x 40, 0.88 ms vs 0.95 at 16 x 32)
+    const int tile_h = env_int("MDETR_MSDA_TILE_H", elem_dtype == 2 ? 16 : 24), tile_w = env_int("MDETR_MSDA_TILE_W", 40);
+    const int reach = env_int("MDETR_MSDA_REACH", 5), chunks_env = env_int("MDETR_MSDA_CHUNKS", 12);
     const int whole_max = env_int("MDETR_MSDA_WHOLE_LEVEL_CELLS", 512);
     if (tile_h < 1 || tile_w < 1 || tile_h * tile_w > kMaxCells || reach < 0 || chunks_env < 1) return false;
     int blk = 0;
@@ -737,7 +740,7 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
                                       int elem_dtype, hipStream_t st)
 {
     FusedPlan pl;
-    if (D != kCH || !shapes_h || !start_h || !build_plan(pl, shapes_h, start_h, B, S, M, L, Lq, P)) return hipErrorNotSupported;
+    if (D != kCH || !shapes_h || !start_h || !build_plan(pl, shapes_h, start_h, B, S, M, L, Lq, P, elem_dtype)) return hipErrorNotSupported;
     if (!workspace || workspace_bytes < plan_workspace_bytes(pl)) return hipErrorNotSupported;
     if (elem_dtype != 0 && elem_dtype != 2) return hipErrorNotSupported;
     Header *hdr = static_cast<Header *>(workspace);
@@ -755,7 +758,7 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
         hipLaunchKernelGGL(msda_absmax_kernel<float>, dim3(1024), dim3(256), 0, st, static_cast<const float *>(grad_out), n_go, attn, n_at, hdr, far, nfar);
     profile_end(st);
     // 512 threads (8 waves) or 1024 (16 waves: twice the record buffers, more loads in flight per CU)
-    int threads = env_int("MDETR_MSDA_THREADS", 512);
+    int threads = env_int("MDETR_MSDA_THREADS", 1024);          // (bf16: 0.74 ms at 16 waves vs 0.96 at 8, same tile)
     threads = (threads >= 1024 && elem_dtype == 2) ? 1024 : 512;   // (16 waves leave 128 VGPRs: the fp32 form's load batches do not fit)
     size_t lds = static_cast<size_t>(pl.max_cells + kTrash) * kCellU64 * 8 + static_cast<size_t>(pl.max_cells) * 4 +
                  static_cast<size_t>(threads / 64) * 64 * kRecDw * 4 + static_cast<size_t>(pl.max_tab) * 4 + 128 + 16;

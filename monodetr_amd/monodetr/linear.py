@@ -88,16 +88,16 @@ class _TokenLinear(torch.autograd.Function):
             if C:
                 parts = torch.bmm(dy2.view(C, T // C, -1).transpose(1, 2), x2.view(C, T // C, -1))    # [C, N, K]
                 flat = parts.view(C, -1)
-                if colsum_ext.supported(flat):       # sum over the C chunks in one streaming pass (csrc/colsum.hip)
-                    dw = colsum_ext.column_sum(flat).view(parts.shape[1], parts.shape[2])
+                if colsum_ext.supported(flat) and weight.dtype in (torch.float32, torch.bfloat16):
+                    # sum over the C chunks in one streaming pass (csrc/colsum.hip), written in the parameter's dtype
+                    dw = colsum_ext.column_sum(flat, weight.dtype).view(parts.shape[1], parts.shape[2])
                 else:
-                    dw = parts.sum(0)
+                    dw = parts.sum(0).to(weight.dtype)
             else:
-                dw = dy2.t() @ x2
-            dw = dw.to(weight.dtype)
+                dw = (dy2.t() @ x2).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            if dy2.is_cuda and colsum_ext.supported(dy2):
-                db = colsum_ext.column_sum(dy2).to(weight.dtype)        # csrc/colsum.hip: one HBM pass, fp32 accumulation
+            if dy2.is_cuda and colsum_ext.supported(dy2) and weight.dtype in (torch.float32, torch.bfloat16):
+                db = colsum_ext.column_sum(dy2, weight.dtype)       # csrc/colsum.hip: one HBM pass, fp32 accumulation, one rounding
             else:
                 db = (dy2.view(C, T // C, -1).sum(1).sum(0) if C else dy2.sum(0)).to(weight.dtype)
         return dx, dw, db, None
