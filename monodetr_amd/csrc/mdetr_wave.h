@@ -17,6 +17,13 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// two packed fp32 lanes: element-wise fma / mul on this type select v_pk_fma_f32 / v_pk_mul_f32 (one issue slot for two
+// channels; the plain-float spelling compiles to two scalar FMAs)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 make_f32x2(float x, float y) { f32x2 r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 mul2(f32x2 a, f32x2 b) { return a * b; }
+
 // orders a wave's LDS writes before its subsequent LDS reads (wave-private buffers: no workgroup barrier needed)
 __device__ __forceinline__ void wave_sync()
 {

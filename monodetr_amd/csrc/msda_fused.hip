@@ -78,7 +78,10 @@ struct FusedPlan {
                                       // 2: core tiles, every block scans all queries (cross-attention)
     int TH[kMaxLevels], TW[kMaxLevels], nty[kMaxLevels], ntx[kMaxLevels], R[kMaxLevels];
     int nchunk[kMaxLevels];
-    int blk0[kMaxLevels], nblk[kMaxLevels], nblocks;      // blocks of one (b, m): level l owns [blk0[l], blk0[l] + nblk[l])
+    // blocks of one (b, m): level l owns blk0[l] + i * bstride[l], i < nblk[l].  Whole-level (chunked) levels with the same
+    // chunk count are interleaved (bstride > 1): chunk t of one level and chunk t of the next read the same loc / attn /
+    // grad_out lines of the same queries and then run side by side on one XCD, where the second reader hits L2.
+    int blk0[kMaxLevels], nblk[kMaxLevels], bstride[kMaxLevels], nblocks;
     long long scr0[kMaxLevels];       // float offset of level l's partial windows within one (b, m) slab (mode 1)
     long long scr_per_bm;
     int max_cells;
@@ -182,11 +185,15 @@ __device__ __forceinline__ Work decode_block(const FusedPlan &pl, int k)
     Work w;
     int l = 0;
 #pragma unroll
-    for (int i = 0; i < kMaxLevels; ++i)
-        if (i < pl.L && k >= pl.blk0[i] && k < pl.blk0[i] + pl.nblk[i]) l = i;
+    for (int i = 0; i < kMaxLevels; ++i) {
+        if (i < pl.L && k >= pl.blk0[i]) {
+            const int d = k - pl.blk0[i], st = pl.bstride[i];
+            if (d % st == 0 && d / st < pl.nblk[i]) l = i;
+        }
+    }
     w.l = l;
     w.mode = pl.mode[l];
-    const int t = k - pl.blk0[l];
+    const int t = (k - pl.blk0[l]) / pl.bstride[l];
     w.slot = t;
     w.q0 = 0;
     w.nq = 0;
@@ -231,20 +238,20 @@ __device__ __forceinline__ Work decode_block(const FusedPlan &pl, int k)
     return w;
 }
 
-// four corner contributions of one sample for the 4 channels of this lane: 16 FMAs, 8 ds_add_u64
+// four corner contributions of one sample for the 4 channels of this lane: 8 packed FMAs, 8 ds_add_u64 (the 64-bit
+// register pair a packed FMA leaves behind IS the atomic's operand)
 __device__ __forceinline__ void accumulate4(unsigned long long *win, unsigned o01, unsigned o23, const float (&wt)[4],
                                             const float4 &ag, int k, float magic)
 {
     const unsigned cell[4] = {o01 & 0xFFFFu, o01 >> 16, o23 & 0xFFFFu, o23 >> 16};
+    const f32x2 ag01 = make_f32x2(ag.x, ag.y), ag23 = make_f32x2(ag.z, ag.w), mg = make_f32x2(magic, magic);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         unsigned long long *p = win + cell[c] * kCellU64 + 2 * k;
-        const unsigned b0 = __builtin_bit_cast(unsigned, __builtin_fmaf(wt[c], ag.x, magic));
-        const unsigned b1 = __builtin_bit_cast(unsigned, __builtin_fmaf(wt[c], ag.y, magic));
-        const unsigned b2 = __builtin_bit_cast(unsigned, __builtin_fmaf(wt[c], ag.z, magic));
-        const unsigned b3 = __builtin_bit_cast(unsigned, __builtin_fmaf(wt[c], ag.w, magic));
-        __hip_atomic_fetch_add(p, (static_cast<unsigned long long>(b1) << 32) | b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(p + 1, (static_cast<unsigned long long>(b3) << 32) | b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const f32x2 wc = make_f32x2(wt[c], wt[c]);
+        const f32x2 r01 = fma2(wc, ag01, mg), r23 = fma2(wc, ag23, mg);
+        __hip_atomic_fetch_add(p, __builtin_bit_cast(unsigned long long, r01), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(p + 1, __builtin_bit_cast(unsigned long long, r23), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
@@ -478,10 +485,12 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                         }
                         if (k == 0) hdr->far = 1u;
                     }
-                    e0 = g.x * v0.x + g.y * v0.y + g.z * v0.z + g.w * v0.w;
-                    e1 = g.x * v1.x + g.y * v1.y + g.z * v1.z + g.w * v1.w;
-                    e2 = g.x * v2.x + g.y * v2.y + g.z * v2.z + g.w * v2.w;
-                    e3 = g.x * v3.x + g.y * v3.y + g.z * v3.z + g.w * v3.w;
+                    // four 4-channel dot products as packed pairs: (e0, e1) and (e2, e3) share their FMAs
+                    f32x2 p01 = mul2(make_f32x2(g.x, g.x), make_f32x2(v0.x, v1.x)), p23 = mul2(make_f32x2(g.x, g.x), make_f32x2(v2.x, v3.x));
+                    p01 = fma2(make_f32x2(g.y, g.y), make_f32x2(v0.y, v1.y), p01); p23 = fma2(make_f32x2(g.y, g.y), make_f32x2(v2.y, v3.y), p23);
+                    p01 = fma2(make_f32x2(g.z, g.z), make_f32x2(v0.z, v1.z), p01); p23 = fma2(make_f32x2(g.z, g.z), make_f32x2(v2.z, v3.z), p23);
+                    p01 = fma2(make_f32x2(g.w, g.w), make_f32x2(v0.w, v1.w), p01); p23 = fma2(make_f32x2(g.w, g.w), make_f32x2(v2.w, v3.w), p23);
+                    e0 = p01.x; e1 = p01.y; e2 = p23.x; e3 = p23.y;
                 }
                 float d0 = sum8f(e0), d1 = sum8f(e1), d2 = sum8f(e2), d3 = sum8f(e3);    // over the 8 lanes of the sample, every lane takes part
                 d0 = (flags & 1u) ? d0 : 0.f; d1 = (flags & 2u) ? d1 : 0.f;              // a corner outside the map reads nothing (.cuh:56-78)
@@ -710,6 +719,20 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
         }
         if (cells > kMaxCells || cells >= 0xFFF0) return false;
         pl.max_cells = cells > pl.max_cells ? cells : pl.max_cells;
+        pl.bstride[l] = 1;
+    }
+    // block numbering: the chunked levels first (their blocks are the longest), interleaved chunk by chunk; then the tiled
+    // levels, coarsest first
+    int n1 = 0, first_chunks = 0;
+    for (int l = L - 1; l >= 0; --l)
+        if (pl.mode[l] == 1) { if (!n1) first_chunks = pl.nchunk[l]; if (pl.nchunk[l] == first_chunks) ++n1; }
+    int j = 0;
+    for (int l = L - 1; l >= 0; --l) {
+        if (pl.mode[l] == 1 && pl.nchunk[l] == first_chunks) { pl.blk0[l] = blk + j; pl.bstride[l] = n1; ++j; }
+    }
+    blk += n1 * first_chunks;
+    for (int l = L - 1; l >= 0; --l) {
+        if (pl.mode[l] == 1 && pl.nchunk[l] == first_chunks) continue;
         pl.blk0[l] = blk;
         blk += pl.nblk[l];
     }

@@ -52,6 +52,12 @@ inline f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c)
     return c;
 }
 
+// two packed fp32 lanes (the real header: ext_vector_type(2) -> v_pk_fma_f32 / v_pk_mul_f32)
+struct f32x2 { float x, y; };
+inline f32x2 make_f32x2(float x, float y) { return {x, y}; }
+inline f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+inline f32x2 mul2(f32x2 a, f32x2 b) { return {a.x * b.x, a.y * b.y}; }
+
 inline void wave_sync() { hipshim::sync_wave(); }
 
 #define MDETR_DYNAMIC_LDS(type, name) type *name = reinterpret_cast<type *>(hipshim::dynamic_lds())
