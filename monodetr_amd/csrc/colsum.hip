@@ -43,9 +43,11 @@ template <> struct Vec16<__hip_bfloat16> {
 };
 
 // CT = column vectors handled per block row pass (power of two <= 256); row lanes = 256 / CT
-template <typename T>
+// PT = float: one partial row per block into the workspace; PT = bf16: only for a single row block, whose partial row IS
+// the result (rounded once)
+template <typename T, typename PT = float>
 __global__ __launch_bounds__(kThreads)
-void colsum_partial_kernel(const T *__restrict__ x, float *__restrict__ partial, int64_t rows, int cols, int64_t ld, int CT)
+void colsum_partial_kernel(const T *__restrict__ x, PT *__restrict__ partial, int64_t rows, int cols, int64_t ld, int CT)
 {
     constexpr int VEC = Vec16<T>::N;
     __shared__ float red[kThreads * VEC];
@@ -77,7 +79,7 @@ void colsum_partial_kernel(const T *__restrict__ x, float *__restrict__ partial,
         float s = 0.f;
         for (int l = 0; l < RL; ++l) s += red[l * CT * VEC + t];
         const int col = blockIdx.y * CT * VEC + t;
-        if (col < cols) partial[static_cast<int64_t>(blockIdx.x) * cols + col] = s;
+        if (col < cols) partial[static_cast<int64_t>(blockIdx.x) * cols + col] = static_cast<PT>(s);
     }
 }
 
@@ -131,22 +133,31 @@ hipError_t colsum_launch(int dtype, const void *x, void *out, void *workspace, i
 {
     if (cols == 0) return hipSuccess;
     const int64_t nblk = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
-    // a single row block: its partial row IS the (fp32) result
-    float *partial = (nblk == 1 && out_dtype == 0) ? static_cast<float *>(out) : static_cast<float *>(workspace);
+    // a single row block: its partial row IS the result, in either output type
+    float *partial = nblk == 1 ? static_cast<float *>(out) : static_cast<float *>(workspace);
     if (nblk > 0) {
         const int vec = dtype == 2 ? 8 : 4;
         const int cvs = cols / vec;
         int CT = 1;
         while (CT * 2 <= cvs && CT * 2 <= kThreads) CT *= 2;
         const dim3 grid(static_cast<unsigned>(nblk), static_cast<unsigned>((cvs + CT - 1) / CT));
-        if (dtype == 2)
-            hipLaunchKernelGGL(colsum_partial_kernel<__hip_bfloat16>, grid, dim3(kThreads), 0, st,
+        if (nblk == 1 && out_dtype == 2) {
+            __hip_bfloat16 *o = static_cast<__hip_bfloat16 *>(out);
+            if (dtype == 2)
+                hipLaunchKernelGGL((colsum_partial_kernel<__hip_bfloat16, __hip_bfloat16>), grid, dim3(kThreads), 0, st,
+                                   static_cast<const __hip_bfloat16 *>(x), o, rows, cols, ld, CT);
+            else
+                hipLaunchKernelGGL((colsum_partial_kernel<float, __hip_bfloat16>), grid, dim3(kThreads), 0, st,
+                                   static_cast<const float *>(x), o, rows, cols, ld, CT);
+        } else if (dtype == 2) {
+            hipLaunchKernelGGL((colsum_partial_kernel<__hip_bfloat16, float>), grid, dim3(kThreads), 0, st,
                                static_cast<const __hip_bfloat16 *>(x), partial, rows, cols, ld, CT);
-        else
-            hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(kThreads), 0, st,
+        } else {
+            hipLaunchKernelGGL((colsum_partial_kernel<float, float>), grid, dim3(kThreads), 0, st,
                                static_cast<const float *>(x), partial, rows, cols, ld, CT);
+        }
     }
-    if (nblk == 1 && out_dtype == 0) return hipGetLastError();
+    if (nblk == 1) return hipGetLastError();
     if (out_dtype == 2)
         hipLaunchKernelGGL(colsum_final_kernel<__hip_bfloat16>, dim3((cols + 15) / 16), dim3(kThreads), 0, st,
                            partial, static_cast<__hip_bfloat16 *>(out), static_cast<int>(nblk), cols);

@@ -37,3 +37,16 @@ def test_column_sum_strided_rows_and_token_linear_bias_grad():
     got = torch.autograd.grad(token_linear(inp, w, b), (inp, w, b), g)
     for a, c in zip(ref, got):
         assert (a - c).abs().max() <= 2e-3 * a.abs().max()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(81600, 256), (64, 65536), (200, 48), (4400, 128)])
+def test_column_sum_written_as_bf16_is_the_rounded_fp32_sum(dtype, shape):
+    """mdetr_column_sum_to(..., MDETR_BF16): the gradient of a bf16 parameter without a cast launch -- exactly the fp32
+    result rounded once, for the one-block case (rows <= 256: the split-K weight gradients) and the two-pass case."""
+    from monodetr_amd.colsum_ext import column_sum
+    torch.manual_seed(shape[0] * 3 + shape[1])
+    x = (torch.randn(shape, device="cuda") + 0.1).to(dtype)
+    f32 = column_sum(x)
+    b16 = column_sum(x, torch.bfloat16)
+    assert b16.dtype == torch.bfloat16 and torch.equal(b16, f32.to(torch.bfloat16))
