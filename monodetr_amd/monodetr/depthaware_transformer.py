@@ -47,6 +47,27 @@ class MLP(nn.Module):
         return self.layers[-1](x)
 
 
+def fused_first_layers(x, heads):
+    """The first Linear of several heads that read the same tensor as ONE GEMM (weights concatenated along the output
+    axis): `heads` are MLPs or plain nn.Linear modules.  Returns the per-head slices of the result (pre-activation).  The
+    prediction heads are five tiny fp32 products per decoder level on the same [B * Q, 256] tensor; separately each costs a
+    25-40 microsecond library launch three times over (forward, input gradient, weight gradient)."""
+    firsts = [h.layers[0] if isinstance(h, MLP) else h for h in heads]
+    x = x.to(firsts[0].weight.dtype)                # fp32 heads may sit behind a bf16 body: one cast for all of them
+    y = F.linear(x, torch.cat([l.weight for l in firsts], 0), torch.cat([l.bias for l in firsts], 0))
+    return y.split([l.out_features for l in firsts], -1)
+
+
+def mlp_rest(mlp, h):
+    """The remainder of MLP.forward given the output `h` of its first Linear."""
+    if mlp.num_layers == 1:
+        return h
+    x = F.relu(h)
+    for layer in mlp.layers[1:-1]:
+        x = F.relu(layer(x))
+    return mlp.layers[-1](x)
+
+
 def _get_clones(module, N):
     return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
 
@@ -239,6 +260,7 @@ class DepthAwareDecoder(nn.Module):
         L = src_spatial_shapes.shape[0]
         hs, refs, dims = [], [], []
         reference_dims = None
+        head_out = self.__dict__["head_outputs"] = []      # per level (box delta, depth, angle, class logits) when the heads are fused
         for lid, layer in enumerate(self.layers):
             nd = reference_points.shape[-1]
             assert nd in (2, 6)
@@ -250,14 +272,27 @@ class DepthAwareDecoder(nn.Module):
                            src_padding_mask, depth_pos_embed, mask_depth, bs, query_sine_embed=None,
                            is_first=(lid == 0), depth_pos_embed_ip=depth_pos_embed_ip, pos_embeds=pos_embeds,
                            self_attn_mask=attn_mask, query_pos_un=None)
-            if self.bbox_embed is not None:             # iterative refinement (:602-613)
+            fused = self.__dict__.get("fused_heads")      # (class_embed, depth_embed, angle_embed) lists, set by MonoDETR
+            if fused is not None and self.bbox_embed is not None and self.dim_embed is not None:
+                # every head that reads this level's output, first layers as one GEMM; the box and size heads are
+                # finished here (the refinement needs them), the rest is handed to MonoDETR.forward -- which would
+                # otherwise evaluate bbox_embed a second time on the same tensor (reference monodetr.py:226-236)
+                cls, dep, ang = (f[lid] for f in fused)
+                parts = fused_first_layers(output, [self.bbox_embed[lid], self.dim_embed[lid], dep, ang, cls])
+                delta = mlp_rest(self.bbox_embed[lid], parts[0])
+                head_out.append((delta, mlp_rest(dep, parts[2]), mlp_rest(ang, parts[3]),
+                                 mlp_rest(cls, parts[4]) if isinstance(cls, MLP) else parts[4]))
+            elif self.bbox_embed is not None:
                 delta = self.bbox_embed[lid](output)
+            if self.bbox_embed is not None:             # iterative refinement (:602-613)
                 if nd == 6:
                     new_ref = (delta + inverse_sigmoid(reference_points)).sigmoid()
                 else:
                     new_ref = torch.cat((delta[..., :2] + inverse_sigmoid(reference_points), delta[..., 2:]), -1).sigmoid()
                 reference_points = new_ref.detach()
-            if self.dim_embed is not None:
+            if fused is not None and self.bbox_embed is not None and self.dim_embed is not None:
+                reference_dims = mlp_rest(self.dim_embed[lid], parts[1])
+            elif self.dim_embed is not None:
                 reference_dims = self.dim_embed[lid](output)
             if self.return_intermediate:
                 hs.append(output)

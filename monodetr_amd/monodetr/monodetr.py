@@ -105,6 +105,7 @@ class MonoDETR(nn.Module):
             self.depthaware_transformer.decoder.dim_embed = self.dim_embed_3d
             self.angle_embed = _get_clones(angle_embed, num_pred)
             self.depth_embed = _get_clones(depth_embed, num_pred)
+            self.fuse_heads = True          # the decoder evaluates all five heads of a level together (see forward)
         else:
             nn.init.constant_(bbox_embed.layers[-1].bias.data[2:], -2.0)
             self.class_embed = nn.ModuleList([class_embed for _ in range(num_pred)])
@@ -113,6 +114,7 @@ class MonoDETR(nn.Module):
             self.angle_embed = nn.ModuleList([angle_embed for _ in range(num_pred)])
             self.depth_embed = nn.ModuleList([depth_embed for _ in range(num_pred)])
             self.depthaware_transformer.decoder.bbox_embed = None
+            self.fuse_heads = False
 
     def pyramid(self, images):
         """Backbone + input projections (monodetr.py:156-178 of the reference): (srcs, masks, pos), one entry per
@@ -140,6 +142,11 @@ class MonoDETR(nn.Module):
         query_embeds = self.query_embed.weight if self.training else self.query_embed.weight[:self.num_queries]
 
         depth_logits, depth_pos_embed, weighted_depth, depth_pos_embed_ip = self.depth_predictor(srcs, masks[1], pos[1])
+        # the decoder evaluates the five heads that read a level's output together (first layers as one GEMM).  The head
+        # lists are handed over per forward, through the decoder's __dict__: not registered sub-modules (the state_dict
+        # keeps the reference's key names), and THIS replica's modules when a DataParallel wrapper has replicated the model
+        self.depthaware_transformer.decoder.__dict__["fused_heads"] = \
+            (self.class_embed, self.depth_embed, self.angle_embed) if self.fuse_heads else None
         hs, init_reference, inter_references, inter_references_dim, _, _ = self.depthaware_transformer(
             srcs, masks, pos, query_embeds, depth_pos_embed, depth_pos_embed_ip)
 
@@ -161,13 +168,15 @@ class MonoDETR(nn.Module):
         if later.shape[-1] == 2:
             later = F.pad(later, (0, 4))
         reference = torch.cat((first[None], later), 0)
-        box = torch.stack([self.bbox_embed[lvl](hs[lvl]) for lvl in range(L)]) + reference
+        head_out = self.depthaware_transformer.decoder.__dict__.get("head_outputs") or []
+        fused = len(head_out) == L                             # the decoder already evaluated the heads (fused first layers)
+        box = torch.stack([head_out[lvl][0] if fused else self.bbox_embed[lvl](hs[lvl]) for lvl in range(L)]) + reference
         coord = box.sigmoid()                                      # (cx, cy, l, r, t, b) of the 3D centre / 2D box
         size3d = inter_references_dim[:L].to(head_dtype)
         # depth from geometry: f * H3d / h2d  (:240-242)
         h2d = torch.clamp((coord[..., 4] + coord[..., 5]) * img_h, min=1.0)
         depth_geo = size3d[..., 0] / h2d * focal
-        depth_reg = torch.stack([self.depth_embed[lvl](hs[lvl]) for lvl in range(L)])
+        depth_reg = torch.stack([head_out[lvl][1] if fused else self.depth_embed[lvl](hs[lvl]) for lvl in range(L)])
         # depth read from the predicted depth map at the (detached) 3D centre (:248-253): one bilinear
         # lookup for the queries of all levels
         B, Q = coord.shape[1], coord.shape[2]
@@ -176,8 +185,9 @@ class MonoDETR(nn.Module):
         depth_map = depth_map.view(B, L, Q).permute(1, 0, 2)
         depth_ave = torch.cat([((1. / (depth_reg[..., 0:1].sigmoid() + 1e-6) - 1.) + depth_geo.unsqueeze(-1)
                                 + depth_map.unsqueeze(-1)) / 3, depth_reg[..., 1:2]], -1)
-        classes = torch.stack([self.class_embed[lvl](hs[lvl]) for lvl in range(L)])
-        angles = torch.stack([self.angle_embed[lvl](hs[lvl]) for lvl in range(L)])
+        classes = torch.stack([head_out[lvl][3] if fused else self.class_embed[lvl](hs[lvl]) for lvl in range(L)])
+        angles = torch.stack([head_out[lvl][2] if fused else self.angle_embed[lvl](hs[lvl]) for lvl in range(L)])
+        self.depthaware_transformer.decoder.__dict__["head_outputs"] = []     # do not keep the graph alive past this forward
 
         out = {'pred_logits': classes[-1], 'pred_boxes': coord[-1], 'pred_3d_dim': size3d[-1],
                'pred_depth': depth_ave[-1], 'pred_angle': angles[-1], 'pred_depth_map_logits': depth_logits}
