@@ -28,7 +28,17 @@ Extra objects on that line:
                 events on the launch stream during the timed steps, against 8 TB/s HBM.
   kernels       the same for every MSDA launch shape (forward/backward x encoder/decoder).
   fp32_path     the same step in the reference's own arithmetic (all fp32), timed in this process after the
-                bf16 line (shorter: 10 + 20 iterations).
+                bf16 line (shorter: 10 + 20 iterations), launched the same way as the headline.
+  eager_path    the headline's step with eager launches instead of graph replay (~1 900 launches per iteration;
+                host-CPU dependent), default_path = no optional kernel family at all (eager), rccl_1rank = the N > 1
+                code path with one rank (RCCL process group, flat gradient all-reduce between the two graphs).
+
+Launch mode (`config.launch`): by default the iteration is replayed from hipGraphs captured during start-up -- every
+kernel of the step runs, on the same static synthetic batch the eager loop would use; only the ~1 900 host-side launches
+per iteration are gone (--graph off measures those too).  Inside a replayed graph no HIP event can be recorded around a
+single kernel, so `roofline` / `kernels` time the same kernels in three eager iterations run right after the timed
+region (`roofline.timing` says so); the rocprofv3 kernel trace of the same command (profiles/) sees the replayed
+kernels themselves.
   cpu_baseline  BASELINE.md section 3: the reference's CPU path for the operator -- `ms_deform_attn_core_pytorch`
                 (ops/functions/ms_deform_attn_func.py:41-61), here its port oracle/msda_torch_ref.py since the reference
                 tree does not travel -- on all host cores, fp32, 3 warm-up + 10 timed, forward and forward+backward at
@@ -94,7 +104,7 @@ def synthetic_batch(B, H, W, seed, device):
 # with the COMMITTED list below.  (MDETR_MSDA_BF16 changes the MSDA operator's element types; the roofline accounting
 # follows it: msda_algorithmic_bytes(mixed=True).)
 AUTOTUNE_SWITCHES = ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN", "MDETR_MSDA_BF16", "MDETR_TOKEN_GEMM",
-                     "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3")
+                     "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM")
 ALL_SWITCHES = AUTOTUNE_SWITCHES
 # The measured configuration.  family -> the GPU tests that hold it to the default path / the framework operators
 # (all in tests/test_fused_gpu.py unless a file is named); a family without green tests is not listed.
@@ -106,15 +116,17 @@ SWITCH_TESTS = {
     "MDETR_MSDA_BF16": "test_msda_bf16_kernels_*, test_msda_function_with_native_bf16_*, test_training_step_with_bf16_msda_*, test_msda_gpu.py::test_bf16_native_full_encoder_shape_vs_oracle",
     "MDETR_FUSED_EPILOGUE": "test_bias_act_kernel_*, test_training_step_with_fused_tails_*",
     "MDETR_GEMM_RELU": "test_library_gemm_relu_epilogue_*, test_training_step_with_fused_tails_*",
+    "MDETR_GROUP_NORM": "test_group_norm_kernel_*, test_training_step_with_the_group_norm_kernel_*",
     "MDETR_CONV3X3": "test_conv3x3_kernel_matches_the_library_convolution, test_training_step_with_the_conv3x3_kernel_*, test_conv3x3_module_with_a_trainable_bias_*",
 }
 COMMITTED_SWITCHES = {
     # (MDETR_CONV3X3: 1.6-3.5x MIOpen per kernel on the four ResNet stages, profiles/r02a_fusedbench.json; the step 249.3 vs
-    # 234.6 img/s, profiles/r02b_bench_committed_plus_conv3x3.json.  MDETR_TOKEN_GEMM stays off: slower than hipBLASLt.)
+    # 234.6 img/s, profiles/r02b_bench_committed_plus_conv3x3.json.  MDETR_TOKEN_GEMM stays off: slower than hipBLASLt.
+    # MDETR_GROUP_NORM: 328.9 vs 308.7 img/s under graph replay, profiles/r02m_bench_with_gn.json.)
     "bf16": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE", "MDETR_MSDA_BF16",
-             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3"),
+             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM"),
     "fp32": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE",
-             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU"),
+             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_GROUP_NORM"),
 }
 COMMITTED_SWITCHES["bf16-autocast"] = COMMITTED_SWITCHES["fp32"]
 
@@ -134,7 +146,7 @@ def env_switches():
 def apply_switches(names):
     """Runtime equivalent of the environment switches for the module-level ones (the criterion's and the optimizer's
     are applied by TrainStep)."""
-    from monodetr_amd import add_ln_ext, bias_act_ext, conv3x3_ext
+    from monodetr_amd import add_ln_ext, bias_act_ext, conv3x3_ext, group_norm_ext
     from monodetr_amd.monodetr import linear
     from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func
     from monodetr_amd.monodetr.ops.modules import ms_deform_attn
@@ -144,6 +156,7 @@ def apply_switches(names):
     linear._GEMM_RELU = "MDETR_GEMM_RELU" in names
     bias_act_ext.ENABLED = "MDETR_FUSED_EPILOGUE" in names
     conv3x3_ext.ENABLED = "MDETR_CONV3X3" in names
+    group_norm_ext.ENABLED = "MDETR_GROUP_NORM" in names
     ms_deform_attn_func._NATIVE_BF16 = "MDETR_MSDA_BF16" in names
 
 
@@ -185,17 +198,18 @@ class TrainStep:
             # receive gradients on the default path; bucket views avoid a grad copy
             self.model = DDP(self.model, device_ids=[local_rank], static_graph=True, gradient_as_bucket_view=True,
                              bucket_cap_mb=64)
-        elif ddp:
+        elif ddp and torch.distributed.is_initialized():
             # default N > 1 path: one flat all-reduce per dtype after the backward; "bucketed": the same exchange in
             # ~32 MB buckets issued from gradient hooks while the backward is still running (helpers/dist_helper.py)
             from monodetr_amd.helpers.dist_helper import BucketedGradSync, FlatGradSync, broadcast_parameters
             broadcast_parameters(self.raw_model)
             self.grad_sync = (BucketedGradSync if ddp == "bucketed" else FlatGradSync)(self.raw_model.parameters())
+        self.pending_sync = ddp if (ddp and ddp != "ddp" and self.grad_sync is None) else None   # attach_process_group() later
         # MDETR_FUSED_ADAMW=1: one-launch-per-group HIP AdamW (helpers/optimizer_helper.FusedAdamW); off until
         # its kernel has had its first GPU validation (tests/test_fused_gpu.py)
         self.optimizer = build_optimizer(dict(OPT_CFG, capturable=graph, fused="MDETR_FUSED_ADAMW" in self.switches),
                                          self.raw_model)
-        self.graph = None
+        self.graph = self.graph_opt = self.sync_plan = None
         self.want_graph = graph
         self.precision = precision
         self.device = device
@@ -219,7 +233,21 @@ class TrainStep:
         """Record one whole training iteration (forward, criterion with on-device matching, backward,
         optimizer) into a hipGraph; __call__ then replays it with one launch.  Warm-up and capture
         share one side stream: autograd binds each parameter's AccumulateGrad node to the stream of
-        its first use, and a capture on any other stream would leave those nodes outside the graph."""
+        its first use, and a capture on any other stream would leave those nodes outside the graph.
+
+        With a gradient exchange (N > 1: ``FlatGradSync``) the iteration becomes TWO graphs with the exchange between them,
+        issued eagerly: [zero_grad, forward, criterion, backward] -> all-reduce of the flat gradient (RCCL, 8 launches) ->
+        [optimizer step].  The collectives stay outside any capture; the gradients live at fixed addresses in the graphs'
+        shared memory pool, so the eager exchange reads and rewrites them in place."""
+        if (self.grad_sync is not None and type(self.grad_sync).__name__ != "FlatGradSync") or self.pending_sync not in (None, "flat"):
+            raise RuntimeError("graph replay needs the flat gradient exchange (MDETR_BENCH_SYNC=flat)")
+        if self.grad_sync is not None:
+            # a live RCCL process group and stream capture do not mix on this stack: its watchdog thread polls events while
+            # the capture is under way and aborts the process ("operation not permitted on an event last recorded in a
+            # capturing stream", profiles/r02m).  Capture first, create the process group afterwards: attach_process_group().
+            raise RuntimeError("capture before the process group exists (TrainStep built before init_process_group)")
+        if self.model is not self.raw_model:
+            raise RuntimeError("graph replay is not available under the DistributedDataParallel wrapper")
         side = self.stream = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -227,19 +255,89 @@ class TrainStep:
                 self._step()
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
-        self.graph = torch.cuda.CUDAGraph()
+        graph, graph_opt = torch.cuda.CUDAGraph(), None
         self.optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph, stream=side):      # same stream as the warm-up: autograd's AccumulateGrad nodes are bound to it
-            self.loss = self._step()
+        if self.pending_sync is None:
+            with torch.cuda.graph(graph, stream=side):       # same stream as the warm-up: autograd's AccumulateGrad nodes are bound to it
+                self.loss = self._step()
+        else:
+            from monodetr_amd.helpers.dist_helper import static_plan
+            with torch.cuda.graph(graph, stream=side):
+                self.loss = self._forward_backward()
+            # the gradients now sit at the addresses the captured backward writes to: every later exchange gathers from THOSE
+            # into persistent flat buffers, reduces there, and the captured optimizer reads the reduced slices
+            self.sync_plan = static_plan(self.raw_model.parameters())
+            for ps, src, flat, views in self.sync_plan:
+                for p_, v in zip(ps, views):
+                    p_.grad = v
+            graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_opt, stream=side, pool=graph.pool()):
+                self.optimizer.step()
+        torch.cuda.synchronize(self.device)
+        self.graph, self.graph_opt = graph, graph_opt
         return self
+
+    def try_capture(self):
+        """capture(), or the eager step if the capture fails.  With a pending gradient exchange the decision becomes final in
+        attach_process_group() (every rank must take the same one)."""
+        self.capture_error = ""
+        try:
+            self.capture()
+        except Exception as e:                               # noqa: BLE001 -- whatever the runtime objects to: measure eagerly instead
+            self.capture_error = repr(e)[:160]
+            self.graph = self.graph_opt = self.sync_plan = None
+            torch.cuda.synchronize(self.device)
+            print("bench: graph capture not used (%s): eager launches" % self.capture_error, file=sys.stderr, flush=True)
+        return self.launch_mode()
+
+    def launch_mode(self):
+        if self.graph is None:
+            return "eager" + (" (graph capture failed: %s)" % self.capture_error if getattr(self, "capture_error", "") else "")
+        return ("one hipGraph replay per iteration" if self.graph_opt is None else
+                "two hipGraph replays per iteration (forward + backward | optimizer) around the eager RCCL gradient all-reduce")
+
+    def attach_process_group(self):
+        """The N > 1 half of the construction, once torch.distributed is up: rank 0's parameters and optimizer state to
+        everybody, the gradient exchange (gathering from the captured backward's gradient tensors if the step replays
+        graphs), and one decision for all ranks: graphs only if every rank captured them."""
+        from monodetr_amd.helpers.dist_helper import BucketedGradSync, FlatGradSync, broadcast_parameters
+        if self.pending_sync is None:
+            return self.launch_mode()
+        flag = torch.tensor([1 if self.graph is not None else 0], device=self.device, dtype=torch.int32)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if int(flag) == 0 and self.graph is not None:
+            self.capture_error = "capture failed on another rank"
+            self.graph = self.graph_opt = self.sync_plan = None
+        broadcast_parameters(self.raw_model, extra=[t for st in self.optimizer.state.values() for t in st.values() if torch.is_tensor(t)] +
+                             [t for b in (getattr(self.optimizer, "_flat", None) or (None, []))[1] for t in b.values() if torch.is_tensor(t)])
+        self.grad_sync = (BucketedGradSync if self.pending_sync == "bucketed" else FlatGradSync)(self.raw_model.parameters())
+        if self.graph is not None:
+            self.grad_sync._static = self.sync_plan
+        self.pending_sync = None
+        return self.launch_mode()
 
     def __call__(self):
         if self.graph is not None:
             self.graph.replay()
+            if self.graph_opt is not None:
+                self.grad_sync.sync()
+                self.graph_opt.replay()
             return self.loss
         return self._step()
 
-    def _step(self):
+    def eager_iteration(self):
+        """One eagerly launched iteration of a step that normally replays graphs (kernel timing after the timed region):
+        fresh gradient tensors, so the exchange must gather from them, not from the captured backward's."""
+        static = None
+        if self.grad_sync is not None and getattr(self.grad_sync, "_static", None) is not None:
+            static, self.grad_sync._static = self.grad_sync._static, None
+        try:
+            return self._step()
+        finally:
+            if static is not None:
+                self.grad_sync._static = static
+
+    def _forward_backward(self):
         images, calibs, img_sizes, targets = self.inputs
         self.optimizer.zero_grad(set_to_none=True)
         if self.part == "encoder":
@@ -247,25 +345,33 @@ class TrainStep:
             memory = self.raw_model.depthaware_transformer.encode(srcs, masks, pos)[0]
             total = memory.float().square().mean()
             total.backward()
-            if self.grad_sync is not None:
-                self.grad_sync.sync()
-            self.optimizer.step()
             return total
         with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.precision == "bf16-autocast"):
             out = self.model(images, calibs, targets, img_sizes, dn_args=None)
             losses = self.criterion(out, targets, None)
         total = self.criterion.weighted_total(losses)               # trainer_helper.py:141-143, one dot product
         total.backward()
+        return total
+
+    def _step(self):
+        total = self._forward_backward()
         if self.grad_sync is not None:
             self.grad_sync.sync()
         self.optimizer.step()
         return total
 
 
-def time_variant(device, args, precision, switches, prime=10, timed=20, **kw):
+def time_variant(device, args, precision, switches, prime=10, timed=20, pg_init=None, **kw):
     """images/sec of another variant of the same step (the default path without optional kernels; the all-fp32 path),
-    timed in this process the same way as the headline, only shorter."""
+    timed in this process the same way as the headline, only shorter.  pg_init: creates the process group of a variant
+    with a gradient exchange -- before the step is built when it launches eagerly, after its graphs are captured otherwise."""
+    if pg_init is not None and not kw.get("graph"):
+        pg_init()
     step = TrainStep(device, args.batch, precision, switches=switches, **kw)
+    launch = step.try_capture() if kw.get("graph") else "eager"
+    if pg_init is not None and kw.get("graph"):
+        pg_init()
+        launch = step.attach_process_group()
     for _ in range(prime):
         step()
     torch.cuda.synchronize(device)
@@ -278,7 +384,7 @@ def time_variant(device, args, precision, switches, prime=10, timed=20, **kw):
     gc.collect()
     torch.cuda.empty_cache()
     return {"value": round(args.batch / dt, 2), "unit": "images/sec", "ms_per_step": round(dt * 1e3, 3), "steps": timed,
-            "warmup": prime, "precision": precision, "switches": sorted(switches)}
+            "warmup": prime, "precision": precision, "switches": sorted(switches), "launch": launch}
 
 
 def bind_to_gpu_numa_node(local_rank):
@@ -478,10 +584,11 @@ def main():
     ap.add_argument("--precision", default=os.environ.get("MDETR_BENCH_PRECISION", "bf16"), choices=["fp32", "bf16", "bf16-autocast"],
                     help="bf16 = bf16 model body + fp32 heads + fp32 master weights (helpers/precision.py); "
                          "bf16-autocast = fp32 parameters under torch.autocast")
-    ap.add_argument("--graph", default=os.environ.get("MDETR_BENCH_GRAPH", "off"), choices=["on", "off"],
-                    help="on = replay the whole training iteration as one hipGraph (single GPU, experimental: see "
-                         "DESIGN.md 7 -- verified in fp32, worth <1%% once the host syncs were gone; bf16 replays are "
-                         "not reliable on this ROCm build)")
+    ap.add_argument("--graph", default=os.environ.get("MDETR_BENCH_GRAPH", "auto"), choices=["auto", "on", "off"],
+                    help="auto (default) = replay the training iteration from hipGraphs -- one graph on a single GPU, two "
+                         "(forward + backward | optimizer) around the eager RCCL all-reduce with N > 1 -- and fall back to eager "
+                         "launches if the capture fails on any rank; on = the same without the fall-back; off = eager launches "
+                         "(~1 900 per iteration: the step time then depends on the host CPU, 224-261 img/s across boxes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the fp32_path / default_path / rccl_1rank side measurements")
     ap.add_argument("--cpu-steps", type=int, default=1)
@@ -524,24 +631,40 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
     dist_on = world > 1 or force_ddp
-    if dist_on:
+    sync_mode = os.environ.get("MDETR_BENCH_SYNC", "flat") if dist_on else False
+    want_graph = args.graph != "off" and sync_mode in (False, "flat")
+    if args.graph == "on" and not want_graph:
+        raise SystemExit("--graph on needs the flat gradient exchange (MDETR_BENCH_SYNC=flat), not %r" % (sync_mode,))
+
+    def init_process_group():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
-        # (a generous collective time-out: MIOpen / hipBLASLt start-up differs by minutes between ranks on a cold box)
+        # (a generous collective time-out: MIOpen / hipBLASLt start-up and the graph capture differ by minutes between ranks
+        # on a cold box)
         torch.distributed.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=30))      # RCCL on ROCm
+    # graph replay with N > 1: the step is built and captured BEFORE the process group exists (TrainStep.capture)
+    if dist_on and not want_graph:
+        init_process_group()
 
     from monodetr_amd import _capi
     _capi.lib()                                                     # fail loudly if the HIP library is missing
-    use_graph = args.graph == "on"
-    if use_graph and world > 1:
-        raise SystemExit("--graph on is a single-GPU mode (the RCCL all-reduce of DDP is not captured)")
     # optional kernel families: the committed list (or the environment's MDETR_*=1 for an A/B run) -- the same on every rank
     chosen, switch_source = committed_switches(args.precision)
-    step = TrainStep(device, args.batch, args.precision, ddp=(os.environ.get("MDETR_BENCH_SYNC", "flat") if dist_on else False), local_rank=local_rank, graph=use_graph,
+    step = TrainStep(device, args.batch, args.precision, ddp=sync_mode, local_rank=local_rank, graph=want_graph,
                      switches=chosen, size=size, queries=queries, part=part)
-    if use_graph:
-        step.capture()                                              # untimed: part of start-up, like model build
+    launch_mode = "eager"
+    if want_graph:                                                  # untimed: part of start-up, like model build
+        if args.graph == "on":
+            step.capture()
+            launch_mode = ("one hipGraph replay per iteration" if step.graph_opt is None else
+                           "two hipGraph replays per iteration (forward + backward | optimizer) around the eager RCCL gradient all-reduce")
+        else:
+            launch_mode = step.try_capture()
+        if dist_on:
+            init_process_group()
+            launch_mode = step.attach_process_group()
+    use_graph = step.graph is not None
 
     # experiment: let PyTorch's TunableOp time the library's GEMM solutions per shape during
     # the start-up iterations and freeze the choice before anything is measured -- the decoder-sized products
@@ -589,7 +712,7 @@ def main():
         _capi.profile_enable(True)
         with torch.cuda.stream(step.stream):                        # autograd's AccumulateGrad nodes live on this stream
             for _ in range(3):
-                step._step()
+                step.eager_iteration()
         torch.cuda.synchronize()
         _capi.profile_enable(False)
         kernel_timing = "HIP events around every launch of 3 eager iterations run right after the timed graph replays"
@@ -659,7 +782,7 @@ def main():
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "image": img, "queries": queries,
                        "precision": args.precision, "parallelism": "dp%d" % world,
                        "grad_sync": (os.environ.get("MDETR_BENCH_SYNC", "flat") if dist_on else "none"), "prime_steps": args.prime,
-                       "launch": "one hipGraph replay per iteration" if use_graph else "eager",
+                       "launch": launch_mode,
                        **({"gemm_selection": "TunableOp during start-up"} if tunable else {})},
             "final_loss": round(float(loss), 4),
         }
@@ -676,18 +799,25 @@ def main():
         # optional kernel families in this run: the committed list, or the environment's for an A/B run
         line["config"]["switches"] = sorted(step.switches)
         line["config"]["switch_source"] = switch_source
-        side = world == 1 and not use_graph and not args.no_variants and not force_ddp
+        side = world == 1 and not args.no_variants and not force_ddp
         del step
         gc.collect()
         torch.cuda.empty_cache()
         if side and args.precision != "fp32":
             # the reference's own arithmetic (all fp32), same step, same process, same timing method (shorter)
             try:
-                line["fp32_path"] = time_variant(device, args, "fp32", committed_switches("fp32")[0], size=size, queries=queries, part=part)
+                line["fp32_path"] = time_variant(device, args, "fp32", committed_switches("fp32")[0], size=size, queries=queries, part=part,
+                                                 graph=use_graph)
             except Exception as e:                                  # must not cost the measured line
                 line["fp32_path"] = {"value": None, "error": repr(e)[:200]}
+        if side and use_graph:
+            # the headline's step launched eagerly (what `value` was before graph replay became the default)
+            try:
+                line["eager_path"] = time_variant(device, args, args.precision, chosen, size=size, queries=queries, part=part)
+            except Exception as e:
+                line["eager_path"] = {"value": None, "error": repr(e)[:200]}
         if side and chosen:
-            # the same step without any optional kernel family
+            # the same step without any optional kernel family (eager: its matcher synchronises with the host)
             try:
                 line["default_path"] = time_variant(device, args, args.precision, (), size=size, queries=queries, part=part)
             except Exception as e:
@@ -699,8 +829,9 @@ def main():
                 os.environ.setdefault("MASTER_PORT", "29533")
                 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
                 import datetime
-                torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=device, timeout=datetime.timedelta(minutes=5))
-                line["rccl_1rank"] = time_variant(device, args, args.precision, chosen, ddp="flat")
+                one_rank = lambda: torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=device,   # noqa: E731
+                                                                        timeout=datetime.timedelta(minutes=5))
+                line["rccl_1rank"] = time_variant(device, args, args.precision, chosen, ddp="flat", graph=use_graph, pg_init=one_rank)
                 torch.distributed.destroy_process_group()
             except Exception as e:
                 line["rccl_1rank"] = {"value": None, "error": repr(e)[:200]}

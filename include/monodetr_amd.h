@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDETR_ABI_VERSION 3
+#define MDETR_ABI_VERSION 4
 
 /* element types of the floating-point tensors */
 #define MDETR_F32 0
@@ -458,6 +458,27 @@ int mdetr_bias_act_forward(int io_dtype, int bias_dtype, const void *x, const vo
                            int device, void *stream);
 int mdetr_bias_act_backward(int io_dtype, const void *dy, const void *y, void *dx, int64_t rows, int cols, float scale,
                             int device, void *stream);
+
+/*
+ * GroupNorm (+ ReLU) of a channels-last activation with 8 channels per group -- nn.GroupNorm(32, 256) after every input
+ * projection (lib/models/monodetr/monodetr.py:77-99) and in the depth predictor's conv + GN (+ ReLU) stages
+ * (depth_predictor/depth_predictor.py:30-56).  x, y, dy, dx: [n, hw, c] (NCHW tensors in channels_last memory format),
+ * contiguous, 16-byte aligned, io_dtype MDETR_F32 / MDETR_BF16; gamma, beta: [c] in param_dtype (bf16 only with a bf16
+ * activation); c == 8 * groups, c / 8 a power of two <= 256.  fp32 arithmetic; moments by pairwise (Chan) combination;
+ * deterministic (no atomics).
+ *   forward    y = (x - mean_g) * rstd_g * gamma + beta, then max(0, .) if relu; stats [n, groups, 2] fp32 (mean, rstd) out
+ *   backward   dx; dparams [2, c] in param_dtype = (dgamma row, dbeta row).  The ReLU mask is recomputed from x, gamma, beta
+ *              and stats with the forward's expression -- no output needs to be kept
+ *   workspace  mdetr_group_norm_workspace_bytes(n, hw, c, groups) bytes of device memory, contents irrelevant (0 = shape not
+ *              supported)
+ */
+int64_t mdetr_group_norm_workspace_bytes(int n, int64_t hw, int c, int groups);
+int mdetr_group_norm_forward(int io_dtype, int param_dtype, const void *x, const void *gamma, const void *beta, void *y, float *stats,
+                             void *workspace, int64_t workspace_bytes, int n, int64_t hw, int c, int groups, float eps, int relu,
+                             int device, void *stream);
+int mdetr_group_norm_backward(int io_dtype, int param_dtype, const void *dy, const void *x, const void *gamma, const void *beta,
+                              const float *stats, void *dx, void *dparams, void *workspace, int64_t workspace_bytes,
+                              int n, int64_t hw, int c, int groups, int relu, int device, void *stream);
 
 /*
  * Batched linear sum assignment (Hungarian matching) on the device.  Replaces the host loop of

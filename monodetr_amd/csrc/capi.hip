@@ -16,6 +16,7 @@
 #include "add_ln.h"
 #include "bias_act.h"
 #include "colsum.h"
+#include "group_norm.h"
 #include "conv3x3.h"
 #include "ddn_loss.h"
 #include "kitti_prep.h"
@@ -538,6 +539,61 @@ int mdetr_bias_act_backward(int io_dtype, const void *dy, const void *y, void *d
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_bias_act_backward: set device %d: %s", device, hipGetErrorString(dev.err));
     const hipError_t e = mdetr::bias_act_backward_launch(io_dtype, dy, y, dx, rows, cols, scale, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_bias_act_backward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int64_t mdetr_group_norm_workspace_bytes(int n, int64_t hw, int c, int groups)
+{
+    return mdetr::group_norm_workspace_bytes(n, hw, c, groups);
+}
+
+static int group_norm_args(const char *fn, int io_dtype, int param_dtype, int n, int64_t hw, int c, int groups, int64_t workspace_bytes)
+{
+    if (n < 0 || hw < 0) return fail(MDETR_E_ARG, "%s: negative size", fn);
+    if (!mdetr::group_norm_supported(io_dtype, param_dtype, c, groups) || (io_dtype == MDETR_F32 && param_dtype == MDETR_BF16))
+        return fail(MDETR_E_ARG, "%s: io_dtype %d / param_dtype %d / c %d / groups %d (f32 or bf16; bf16 parameters only with a bf16 activation; "
+                                 "c == 8 * groups, c / 8 a power of two <= 256)", fn, io_dtype, param_dtype, c, groups);
+    if (n > 0 && hw > 0 && workspace_bytes < mdetr::group_norm_workspace_bytes(n, hw, c, groups))
+        return fail(MDETR_E_ARG, "%s: workspace of %lld bytes, need %lld", fn, static_cast<long long>(workspace_bytes),
+                    static_cast<long long>(mdetr::group_norm_workspace_bytes(n, hw, c, groups)));
+    return MDETR_OK;
+}
+
+int mdetr_group_norm_forward(int io_dtype, int param_dtype, const void *x, const void *gamma, const void *beta, void *y, float *stats,
+                             void *workspace, int64_t workspace_bytes, int n, int64_t hw, int c, int groups, float eps, int relu,
+                             int device, void *stream)
+{
+    if (int rc = group_norm_args("mdetr_group_norm_forward", io_dtype, param_dtype, n, hw, c, groups, workspace_bytes)) return rc;
+    if (n == 0 || hw == 0) return MDETR_OK;
+    if (!x || !gamma || !beta || !y || !stats || !workspace) return fail(MDETR_E_ARG, "mdetr_group_norm_forward: null pointer");
+    if (!aligned16(x) || !aligned16(y) || !aligned16(gamma) || !aligned16(beta) || !aligned16(workspace))
+        return fail(MDETR_E_ALIGN, "mdetr_group_norm_forward: x, y, gamma, beta, workspace must be 16-byte aligned");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_group_norm_forward: set device %d: %s", device, hipGetErrorString(dev.err));
+    const mdetr::GroupNormProblem p{io_dtype, param_dtype, n, hw, c, groups, eps, relu ? 1 : 0};
+    const hipError_t e = mdetr::group_norm_forward_launch(p, x, gamma, beta, y, stats, workspace, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_group_norm_forward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_group_norm_backward(int io_dtype, int param_dtype, const void *dy, const void *x, const void *gamma, const void *beta,
+                              const float *stats, void *dx, void *dparams, void *workspace, int64_t workspace_bytes,
+                              int n, int64_t hw, int c, int groups, int relu, int device, void *stream)
+{
+    if (int rc = group_norm_args("mdetr_group_norm_backward", io_dtype, param_dtype, n, hw, c, groups, workspace_bytes)) return rc;
+    if (!dparams) return fail(MDETR_E_ARG, "mdetr_group_norm_backward: null dparams");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_group_norm_backward: set device %d: %s", device, hipGetErrorString(dev.err));
+    if (n == 0 || hw == 0) {
+        const hipError_t e = mdetr::zero_fill_launch(dparams, static_cast<int64_t>(2) * c * (param_dtype == MDETR_BF16 ? 2 : 4), static_cast<hipStream_t>(stream));
+        return e == hipSuccess ? MDETR_OK : fail(MDETR_E_HIP, "mdetr_group_norm_backward: zero fill failed: %s", hipGetErrorString(e));
+    }
+    if (!dy || !x || !gamma || !beta || !stats || !dx || !workspace) return fail(MDETR_E_ARG, "mdetr_group_norm_backward: null pointer");
+    if (!aligned16(dy) || !aligned16(x) || !aligned16(dx) || !aligned16(gamma) || !aligned16(beta) || !aligned16(dparams) || !aligned16(workspace))
+        return fail(MDETR_E_ALIGN, "mdetr_group_norm_backward: dy, x, dx, gamma, beta, dparams, workspace must be 16-byte aligned");
+    const mdetr::GroupNormProblem p{io_dtype, param_dtype, n, hw, c, groups, 0.f, relu ? 1 : 0};
+    const hipError_t e = mdetr::group_norm_backward_launch(p, dy, x, gamma, beta, stats, dx, dparams, workspace, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_group_norm_backward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

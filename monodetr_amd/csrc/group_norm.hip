@@ -1,0 +1,321 @@
+// monodetr_amd/csrc/group_norm.hip -- GroupNorm (+ ReLU) of a CHANNELS-LAST activation, 8 channels per group.
+//
+// The reference normalises every 256-channel map it projects with nn.GroupNorm(32, 256): the four input projections
+// (lib/models/monodetr/monodetr.py:77-99) and the depth predictor's five conv + GN (+ ReLU) stages
+// (depth_predictor/depth_predictor.py:30-56).  The framework's GroupNorm works on NCHW-contiguous memory; between this
+// repository's channels-last convolutions every call pays a layout copy in, moments, fused-parameter and elementwise
+// kernels, a copy out and a separate ReLU (6 launches, ~68 us at [8, 256, 24, 80] bf16; ~82 us backward) for 7.9 MB of
+// data that fits in L2.  Here: a group of 8 channels IS one 16-byte vector of a pixel's row, so a thread owns (group,
+// row lane) and streams rows:
+//   forward   1. moments per (image, row chunk, group): Chan-combined (count, mean, M2) -- no E[x^2] - E[x]^2 cancellation;
+//             2. combine the chunks, y = (x - mean) * rstd * gamma + beta, optional ReLU; mean / rstd kept for the backward.
+//   backward  1. per (image, chunk, group): a = sum dy gamma, b = sum dy gamma xhat; per channel: sum dy xhat, sum dy
+//                (the ReLU mask is recomputed from x: no saved output);
+//             2. dx = rstd * (dy gamma - (a + xhat b) / m);
+//             3. the per-channel partial rows are added by colsum.hip in a fixed order: dgamma, dbeta.
+// Everything is deterministic (no atomics).  Algorithmic bytes: forward 2 * N * HW * C * e (read + write; the second read
+// of x hits L2), backward 3 * N * HW * C * e.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "colsum.h"
+#include "group_norm.h"
+
+namespace mdetr {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxChunks = 32;
+
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float *p, float (&v)[8])
+    {
+        const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float *p, const float (&v)[8])
+    {
+        *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4 *>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct Vec8<__hip_bfloat16> {
+    static __device__ __forceinline__ void load(const __hip_bfloat16 *p, float (&v)[8])
+    {
+        const uint4 u = *reinterpret_cast<const uint4 *>(p);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+        }
+    }
+    static __device__ __forceinline__ unsigned short rne(float f)   // fp32 -> bf16, round to nearest even (NaN stays NaN)
+    {
+        const unsigned u = __float_as_uint(f);
+        if ((u & 0x7FFFFFFFu) > 0x7F800000u) return static_cast<unsigned short>((u >> 16) | 0x40u);
+        return static_cast<unsigned short>((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    }
+    static __device__ __forceinline__ void store(__hip_bfloat16 *p, const float (&v)[8])
+    {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = static_cast<unsigned>(rne(v[2 * i])) | (static_cast<unsigned>(rne(v[2 * i + 1])) << 16);
+        *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+struct Moments { float n, mean, m2; };
+// Chan et al.: moments of the union of two samples
+__device__ __forceinline__ Moments combine(const Moments &a, const Moments &b)
+{
+    const float n = a.n + b.n;
+    if (n == 0.f) return a;
+    const float d = b.mean - a.mean, f = b.n / n;
+    return {n, a.mean + d * f, a.m2 + b.m2 + d * d * a.n * f};
+}
+
+struct Dims { int n; int64_t hw; int c, gl, rl, chunk_rows, nchunks; float eps; };
+
+// thread -> (group lane = 16-byte vector of the row, row lane)
+#define MDETR_GN_LANES() \
+    const int gl = threadIdx.x % d.gl, rl = threadIdx.x / d.gl; \
+    const int chunk = blockIdx.x, img = blockIdx.y; \
+    const int64_t r0 = static_cast<int64_t>(chunk) * d.chunk_rows; \
+    const int64_t r1 = r0 + d.chunk_rows < d.hw ? r0 + d.chunk_rows : d.hw; \
+    const int64_t img_off = static_cast<int64_t>(img) * d.hw * d.c + gl * 8
+
+template <typename T>
+__global__ __launch_bounds__(kThreads)
+void gn_fwd_moments(const Dims d, const T *__restrict__ x, float *__restrict__ partial)
+{
+    __shared__ float red[3][kThreads];
+    MDETR_GN_LANES();
+    Moments m = {0.f, 0.f, 0.f};
+    for (int64_t r = r0 + rl; r < r1; r += d.rl) {
+        float v[8];
+        Vec8<T>::load(x + img_off + r * d.c, v);
+        const float rm = ((v[0] + v[1]) + (v[2] + v[3]) + ((v[4] + v[5]) + (v[6] + v[7]))) * 0.125f;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q += (v[i] - rm) * (v[i] - rm);
+        m = combine(m, Moments{8.f, rm, q});
+    }
+    red[0][threadIdx.x] = m.n; red[1][threadIdx.x] = m.mean; red[2][threadIdx.x] = m.m2;
+    __syncthreads();
+    if (rl == 0) {
+        for (int l = 1; l < d.rl; ++l) {                       // fixed order: deterministic
+            const int t = l * d.gl + gl;
+            m = combine(m, Moments{red[0][t], red[1][t], red[2][t]});
+        }
+        float *o = partial + ((static_cast<int64_t>(img) * d.nchunks + chunk) * d.gl + gl) * 3;
+        o[0] = m.n; o[1] = m.mean; o[2] = m.m2;
+    }
+}
+
+template <typename T, typename PT, bool RELU>
+__global__ __launch_bounds__(kThreads)
+void gn_fwd_apply(const Dims d, const T *__restrict__ x, const float *__restrict__ partial, const PT *__restrict__ gamma,
+                  const PT *__restrict__ beta, T *__restrict__ y, float *__restrict__ stats)
+{
+    MDETR_GN_LANES();
+    Moments m = {0.f, 0.f, 0.f};
+    for (int k = 0; k < d.nchunks; ++k) {
+        const float *p = partial + ((static_cast<int64_t>(img) * d.nchunks + k) * d.gl + gl) * 3;
+        m = combine(m, Moments{p[0], p[1], p[2]});
+    }
+    const float mean = m.mean, rstd = 1.0f / sqrtf(m.m2 / m.n + d.eps);
+    if (chunk == 0 && rl == 0) {
+        stats[(static_cast<int64_t>(img) * d.gl + gl) * 2] = mean;
+        stats[(static_cast<int64_t>(img) * d.gl + gl) * 2 + 1] = rstd;
+    }
+    float g[8], b[8];
+    Vec8<PT>::load(gamma + gl * 8, g);
+    Vec8<PT>::load(beta + gl * 8, b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { g[i] *= rstd; b[i] -= mean * g[i]; }      // y = x * (gamma rstd) + (beta - mean gamma rstd)
+    for (int64_t r = r0 + rl; r < r1; r += d.rl) {
+        float v[8];
+        Vec8<T>::load(x + img_off + r * d.c, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[i] = v[i] * g[i] + b[i];
+            if (RELU) v[i] = v[i] > 0.f ? v[i] : 0.f;
+        }
+        Vec8<T>::store(y + img_off + r * d.c, v);
+    }
+}
+
+// the forward's pre-activation, bit for bit (same expression): the ReLU mask needs its sign
+template <bool RELU>
+__device__ __forceinline__ bool gn_active(float xv, float gs, float bs) { return !RELU || xv * gs + bs > 0.f; }
+
+template <typename T, typename PT, bool RELU>
+__global__ __launch_bounds__(kThreads)
+void gn_bwd_sums(const Dims d, const T *__restrict__ dy, const T *__restrict__ x, const float *__restrict__ stats,
+                 const PT *__restrict__ gamma, const PT *__restrict__ beta, float *__restrict__ ab, float *__restrict__ gb)
+{
+    __shared__ float red[18][kThreads];
+    MDETR_GN_LANES();
+    const float mean = stats[(static_cast<int64_t>(img) * d.gl + gl) * 2], rstd = stats[(static_cast<int64_t>(img) * d.gl + gl) * 2 + 1];
+    float g[8], gs[8], bs[8];
+    Vec8<PT>::load(gamma + gl * 8, g);
+    Vec8<PT>::load(beta + gl * 8, bs);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { gs[i] = g[i] * rstd; bs[i] -= mean * gs[i]; }
+    float dg[8], db[8], a = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dg[i] = db[i] = 0.f;
+    for (int64_t r = r0 + rl; r < r1; r += d.rl) {
+        float v[8], e[8];
+        Vec8<T>::load(x + img_off + r * d.c, v);
+        Vec8<T>::load(dy + img_off + r * d.c, e);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float dd = gn_active<RELU>(v[i], gs[i], bs[i]) ? e[i] : 0.f;
+            const float xh = (v[i] - mean) * rstd;
+            dg[i] += dd * xh; db[i] += dd;
+            a += dd * g[i]; b += dd * g[i] * xh;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[i][threadIdx.x] = dg[i]; red[8 + i][threadIdx.x] = db[i]; }
+    red[16][threadIdx.x] = a; red[17][threadIdx.x] = b;
+    __syncthreads();
+    if (rl == 0) {
+        for (int l = 1; l < d.rl; ++l) {
+            const int t = l * d.gl + gl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { dg[i] += red[i][t]; db[i] += red[8 + i][t]; }
+            a += red[16][t]; b += red[17][t];
+        }
+        const int64_t row = static_cast<int64_t>(img) * d.nchunks + chunk;
+        ab[(row * d.gl + gl) * 2] = a;
+        ab[(row * d.gl + gl) * 2 + 1] = b;
+        Vec8<float>::store(gb + row * 2 * d.c + gl * 8, dg);
+        Vec8<float>::store(gb + row * 2 * d.c + d.c + gl * 8, db);
+    }
+}
+
+template <typename T, typename PT, bool RELU>
+__global__ __launch_bounds__(kThreads)
+void gn_bwd_apply(const Dims d, const T *__restrict__ dy, const T *__restrict__ x, const float *__restrict__ stats,
+                  const PT *__restrict__ gamma, const PT *__restrict__ beta, const float *__restrict__ ab, T *__restrict__ dx)
+{
+    MDETR_GN_LANES();
+    const float mean = stats[(static_cast<int64_t>(img) * d.gl + gl) * 2], rstd = stats[(static_cast<int64_t>(img) * d.gl + gl) * 2 + 1];
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < d.nchunks; ++k) {
+        const float *p = ab + ((static_cast<int64_t>(img) * d.nchunks + k) * d.gl + gl) * 2;
+        a += p[0]; b += p[1];
+    }
+    const float inv_m = 1.0f / (static_cast<float>(d.hw) * 8.f);
+    a *= inv_m; b *= inv_m;
+    float g[8], gs[8], bs[8];
+    Vec8<PT>::load(gamma + gl * 8, g);
+    Vec8<PT>::load(beta + gl * 8, bs);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { gs[i] = g[i] * rstd; bs[i] -= mean * gs[i]; }
+    for (int64_t r = r0 + rl; r < r1; r += d.rl) {
+        float v[8], e[8];
+        Vec8<T>::load(x + img_off + r * d.c, v);
+        Vec8<T>::load(dy + img_off + r * d.c, e);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float dd = gn_active<RELU>(v[i], gs[i], bs[i]) ? e[i] : 0.f;
+            const float xh = (v[i] - mean) * rstd;
+            e[i] = rstd * (dd * g[i] - (a + xh * b));
+        }
+        Vec8<T>::store(dx + img_off + r * d.c, e);
+    }
+}
+
+Dims make_dims(const GroupNormProblem &p)
+{
+    Dims d;
+    d.n = p.n; d.hw = p.hw; d.c = p.c; d.gl = p.c / 8; d.rl = kThreads / d.gl; d.eps = p.eps;
+    int64_t rows = (p.hw + kMaxChunks - 1) / kMaxChunks;
+    if (rows < 64) rows = 64;
+    rows = (rows + d.rl - 1) / d.rl * d.rl;
+    d.chunk_rows = static_cast<int>(rows);
+    d.nchunks = static_cast<int>((p.hw + rows - 1) / rows);
+    return d;
+}
+
+struct Workspace { float *moments, *ab, *gb; void *colsum; };
+Workspace carve(const GroupNormProblem &p, const Dims &d, void *ws)
+{
+    float *f = static_cast<float *>(ws);
+    const int64_t rows = static_cast<int64_t>(p.n) * d.nchunks;
+    Workspace w;
+    w.moments = f;                                   // rows * gl * 3 (forward) -- the backward reuses the space for ab
+    w.ab = f;                                        // rows * gl * 2
+    w.gb = f + ((rows * d.gl * 3 + 3) & ~static_cast<int64_t>(3));   // rows * 2 c
+    w.colsum = w.gb + rows * 2 * p.c;
+    return w;
+}
+
+}  // namespace
+
+bool group_norm_supported(int io_dtype, int param_dtype, int c, int groups)
+{
+    if ((io_dtype != 0 && io_dtype != 2) || (param_dtype != 0 && param_dtype != 2)) return false;
+    if (groups <= 0 || c != groups * 8) return false;
+    const int gl = c / 8;
+    return gl >= 1 && gl <= kThreads && (kThreads % gl) == 0;
+}
+
+int64_t group_norm_workspace_bytes(int n, int64_t hw, int c, int groups)
+{
+    if (n <= 0 || hw <= 0 || !group_norm_supported(0, 0, c, groups)) return 0;
+    GroupNormProblem p{0, 0, n, hw, c, groups, 0.f, 0};
+    const Dims d = make_dims(p);
+    const int64_t rows = static_cast<int64_t>(n) * d.nchunks;
+    return (((rows * d.gl * 3 + 3) & ~static_cast<int64_t>(3)) + rows * 2 * c) * 4 + colsum_workspace_bytes(rows, 2 * c) + 64;
+}
+
+hipError_t group_norm_forward_launch(const GroupNormProblem &p, const void *x, const void *gamma, const void *beta, void *y,
+                                     float *stats, void *workspace, hipStream_t st)
+{
+    const Dims d = make_dims(p);
+    const Workspace w = carve(p, d, workspace);
+    const dim3 grid(static_cast<unsigned>(d.nchunks), static_cast<unsigned>(p.n));
+    typedef __hip_bfloat16 bf;
+    if (p.io_dtype == 2) hipLaunchKernelGGL(gn_fwd_moments<bf>, grid, dim3(kThreads), 0, st, d, static_cast<const bf *>(x), w.moments);
+    else hipLaunchKernelGGL(gn_fwd_moments<float>, grid, dim3(kThreads), 0, st, d, static_cast<const float *>(x), w.moments);
+#define MDETR_GN_FWD(T, PT, R) hipLaunchKernelGGL((gn_fwd_apply<T, PT, R>), grid, dim3(kThreads), 0, st, d, static_cast<const T *>(x), \
+        w.moments, static_cast<const PT *>(gamma), static_cast<const PT *>(beta), static_cast<T *>(y), stats)
+    if (p.io_dtype == 2 && p.param_dtype == 2) { if (p.relu) MDETR_GN_FWD(bf, bf, true); else MDETR_GN_FWD(bf, bf, false); }
+    else if (p.io_dtype == 2) { if (p.relu) MDETR_GN_FWD(bf, float, true); else MDETR_GN_FWD(bf, float, false); }
+    else if (p.param_dtype == 0) { if (p.relu) MDETR_GN_FWD(float, float, true); else MDETR_GN_FWD(float, float, false); }
+    else return hipErrorNotSupported;                 // fp32 activation with bf16 parameters: not a combination the model produces
+#undef MDETR_GN_FWD
+    return hipGetLastError();
+}
+
+hipError_t group_norm_backward_launch(const GroupNormProblem &p, const void *dy, const void *x, const void *gamma, const void *beta,
+                                      const float *stats, void *dx, void *dparams, void *workspace, hipStream_t st)
+{
+    const Dims d = make_dims(p);
+    const Workspace w = carve(p, d, workspace);
+    const dim3 grid(static_cast<unsigned>(d.nchunks), static_cast<unsigned>(p.n));
+    typedef __hip_bfloat16 bf;
+#define MDETR_GN_BWD(T, PT, R) do { \
+        hipLaunchKernelGGL((gn_bwd_sums<T, PT, R>), grid, dim3(kThreads), 0, st, d, static_cast<const T *>(dy), static_cast<const T *>(x), stats, \
+                           static_cast<const PT *>(gamma), static_cast<const PT *>(beta), w.ab, w.gb); \
+        hipLaunchKernelGGL((gn_bwd_apply<T, PT, R>), grid, dim3(kThreads), 0, st, d, static_cast<const T *>(dy), static_cast<const T *>(x), stats, \
+                           static_cast<const PT *>(gamma), static_cast<const PT *>(beta), w.ab, static_cast<T *>(dx)); } while (0)
+    if (p.io_dtype == 2 && p.param_dtype == 2) { if (p.relu) MDETR_GN_BWD(bf, bf, true); else MDETR_GN_BWD(bf, bf, false); }
+    else if (p.io_dtype == 2) { if (p.relu) MDETR_GN_BWD(bf, float, true); else MDETR_GN_BWD(bf, float, false); }
+    else if (p.param_dtype == 0) { if (p.relu) MDETR_GN_BWD(float, float, true); else MDETR_GN_BWD(float, float, false); }
+    else return hipErrorNotSupported;
+#undef MDETR_GN_BWD
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int64_t rows = static_cast<int64_t>(p.n) * d.nchunks;
+    return colsum_launch(0, w.gb, dparams, w.colsum, rows, 2 * p.c, 2 * p.c, st, p.param_dtype);
+}
+
+}  // namespace mdetr

@@ -20,9 +20,18 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c)
 // two packed fp32 lanes: element-wise fma / mul on this type select v_pk_fma_f32 / v_pk_mul_f32 (one issue slot for two
 // channels; the plain-float spelling compiles to two scalar FMAs)
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;      // 16 bytes as one register quad (arrays of it stay in registers)
 __device__ __forceinline__ f32x2 make_f32x2(float x, float y) { f32x2 r; r.x = x; r.y = y; return r; }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 mul2(f32x2 a, f32x2 b) { return a * b; }
+
+// c + a.lo * b.lo + a.hi * b.hi on two PACKED bf16 pairs (the 32-bit words as they sit in memory), fp32 accumulate:
+// v_dot2c_f32_bf16 -- a dot product over bf16 data without widening either operand first
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+__device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float c)
+{
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+}
 
 // orders a wave's LDS writes before its subsequent LDS reads (wave-private buffers: no workgroup barrier needed)
 __device__ __forceinline__ void wave_sync()

@@ -57,6 +57,8 @@ constexpr int kMaxLevels = 4;
 constexpr int kCH = 32;               // channels per head (fast path geometry)
 constexpr int kRecDw = 12;            // per-sample record, 48 B
 constexpr int kCellU64 = kCH / 2;     // packed channel pairs per cell (128 B)
+constexpr int kCellStride = kCellU64 + 1;   // 64-bit LDS slots from a cell to the next: one slot of padding rotates consecutive
+                                            // cells across the banks (at 128 B every cell would start on bank 0 or 32)
 constexpr int kTrash = 8;             // sink rows for corners that are not this block's business (one per record slot mod 8)
 constexpr int kMaxCells = 1024;       // (1024 + 8) * 128 B + 4 KB counts + 24 KB records + tables < 160 KB
 constexpr unsigned long long kCookie = 0x6d64657472667573ull;
@@ -121,6 +123,81 @@ __device__ __forceinline__ float sum8f(float v)
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
     return v;
 }
+
+__device__ __forceinline__ float sum4f(float v)            // over the 4 lanes of a quad
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    return v;
+}
+template <int LPS> __device__ __forceinline__ float sum_sample(float v) { return LPS == 8 ? sum8f(v) : sum4f(v); }
+
+// The CPL = 32 / LPS channels ONE lane owns of a 32-channel row (LPS lanes per sample), as they sit in memory: loaded with one
+// 16-byte (or 8-byte) request, widened only where fp32 values are needed.
+template <typename E, int CPL> struct LaneRaw;
+template <> struct LaneRaw<float, 4> {
+    typedef f32x4 T;
+    static __device__ __forceinline__ T load(const char *p) { return *reinterpret_cast<const f32x4 *>(p); }
+    static __device__ __forceinline__ void widen(const T &r, float (&f)[4]) { f[0] = r.x; f[1] = r.y; f[2] = r.z; f[3] = r.w; }
+};
+template <> struct LaneRaw<__hip_bfloat16, 4> {
+    typedef uint2 T;
+    static __device__ __forceinline__ T load(const char *p) { return *reinterpret_cast<const uint2 *>(p); }
+    static __device__ __forceinline__ unsigned word(const T &r, int i) { return i == 0 ? r.x : r.y; }
+    static __device__ __forceinline__ void widen(const T &r, float (&f)[4])
+    {
+        f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xFFFF0000u);
+        f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xFFFF0000u);
+    }
+};
+template <> struct LaneRaw<__hip_bfloat16, 8> {
+    typedef uint4 T;
+    static __device__ __forceinline__ T load(const char *p) { return *reinterpret_cast<const uint4 *>(p); }
+    static __device__ __forceinline__ unsigned word(const T &r, int i) { return i == 0 ? r.x : i == 1 ? r.y : i == 2 ? r.z : r.w; }
+    static __device__ __forceinline__ void widen(const T &r, float (&f)[8])
+    {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned u = word(r, i);
+            f[2 * i] = __uint_as_float(u << 16);
+            f[2 * i + 1] = __uint_as_float(u & 0xFFFF0000u);
+        }
+    }
+};
+
+// the four corner dot products e[c] = sum_i g[i] * v_c[i] over this lane's channels
+template <typename GT, typename VT, int CPL> struct CornerDots {
+    // packed pairs: (e0, e1) and (e2, e3) share their FMAs
+    static __device__ __forceinline__ void run(const typename LaneRaw<GT, CPL>::T &, const float (&g)[CPL],
+                                               const typename LaneRaw<VT, CPL>::T (&v)[4], float (&e)[4])
+    {
+        float f0[CPL], f1[CPL], f2[CPL], f3[CPL];            // (four separate arrays: a 2-D one is not promoted to registers)
+        LaneRaw<VT, CPL>::widen(v[0], f0); LaneRaw<VT, CPL>::widen(v[1], f1);
+        LaneRaw<VT, CPL>::widen(v[2], f2); LaneRaw<VT, CPL>::widen(v[3], f3);
+        f32x2 p01 = mul2(make_f32x2(g[0], g[0]), make_f32x2(f0[0], f1[0])), p23 = mul2(make_f32x2(g[0], g[0]), make_f32x2(f2[0], f3[0]));
+#pragma unroll
+        for (int i = 1; i < CPL; ++i) {
+            p01 = fma2(make_f32x2(g[i], g[i]), make_f32x2(f0[i], f1[i]), p01);
+            p23 = fma2(make_f32x2(g[i], g[i]), make_f32x2(f2[i], f3[i]), p23);
+        }
+        e[0] = p01.x; e[1] = p01.y; e[2] = p23.x; e[3] = p23.y;
+    }
+};
+template <int CPL> struct CornerDots<__hip_bfloat16, __hip_bfloat16, CPL> {
+    // both operands bf16: v_dot2c_f32_bf16 on the words as loaded (products exact in fp32, fp32 accumulation) -- no widening
+    static __device__ __forceinline__ void run(const typename LaneRaw<__hip_bfloat16, CPL>::T &graw, const float (&)[CPL],
+                                               const typename LaneRaw<__hip_bfloat16, CPL>::T (&v)[4], float (&e)[4])
+    {
+        typedef LaneRaw<__hip_bfloat16, CPL> R;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL / 2; ++i) acc = dot2_bf16(R::word(graw, i), R::word(v[c], i), acc);
+            e[c] = acc;
+        }
+    }
+};
 
 // ---- 1. scale pre-pass: max|grad_out|, max|attn| (and the first-use zero fill of the `far` buffer) ---------------
 template <typename GT>
@@ -238,24 +315,34 @@ __device__ __forceinline__ Work decode_block(const FusedPlan &pl, int k)
     return w;
 }
 
-// four corner contributions of one sample for the 4 channels of this lane: 8 packed FMAs, 8 ds_add_u64 (the 64-bit
-// register pair a packed FMA leaves behind IS the atomic's operand)
-__device__ __forceinline__ void accumulate4(unsigned long long *win, unsigned o01, unsigned o23, const float (&wt)[4],
-                                            const float4 &ag, int k, float magic)
+// four corner contributions of one sample for the CPL channels of this lane: per corner CPL / 2 packed FMAs and as many
+// ds_add_u64 (the 64-bit register pair a packed FMA leaves behind IS the atomic's operand)
+template <int CPL>
+__device__ __forceinline__ void accumulate(unsigned long long *win, unsigned o01, unsigned o23, const float (&wt)[4],
+                                           const float (&ag)[CPL], int k, float magic)
 {
     const unsigned cell[4] = {o01 & 0xFFFFu, o01 >> 16, o23 & 0xFFFFu, o23 >> 16};
-    const f32x2 ag01 = make_f32x2(ag.x, ag.y), ag23 = make_f32x2(ag.z, ag.w), mg = make_f32x2(magic, magic);
+    const f32x2 mg = make_f32x2(magic, magic);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        unsigned long long *p = win + cell[c] * kCellU64 + 2 * k;
+        unsigned long long *p = win + cell[c] * kCellStride + (CPL / 2) * k;
         const f32x2 wc = make_f32x2(wt[c], wt[c]);
-        const f32x2 r01 = fma2(wc, ag01, mg), r23 = fma2(wc, ag23, mg);
-        __hip_atomic_fetch_add(p, __builtin_bit_cast(unsigned long long, r01), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(p + 1, __builtin_bit_cast(unsigned long long, r23), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int pr = 0; pr < CPL / 2; ++pr) {
+            const f32x2 r = fma2(wc, make_f32x2(ag[2 * pr], ag[2 * pr + 1]), mg);
+            __hip_atomic_fetch_add(p + pr, __builtin_bit_cast(unsigned long long, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
 }
 
-template <typename VT, typename GT, int THREADS, int GMAX>
+// LDS carve-up (bytes), shared by the kernel and the launcher
+__host__ __device__ inline size_t lds_win_bytes(int max_cells) { return (static_cast<size_t>(max_cells + kTrash) * kCellStride * 8 + 15) & ~static_cast<size_t>(15); }
+__host__ __device__ inline size_t lds_cnt_bytes(int max_cells) { return (static_cast<size_t>(max_cells) * 4 + 15) & ~static_cast<size_t>(15); }
+
+// LPS lanes per sample (each owning CPL = 32 / LPS channels), GMAX groups of 64 / LPS own samples with their loads in flight
+// together.  bf16: LPS = 4 -- 16 samples per wave pass instead of 8 halves every per-sample instruction (record reads, cell
+// addresses, the lane reduction, the d/d(loc) arithmetic) and the dot products run on the packed words.
+template <typename VT, typename GT, int THREADS, int GMAX, int LPS>
 __global__ __launch_bounds__(THREADS, (THREADS == 512 && GMAX <= 4 && sizeof(VT) == 2) ? 4 : 2)
 void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const float *__restrict__ loc,
                     const float *__restrict__ attn, const GT *__restrict__ grad_out,
@@ -263,10 +350,13 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                     Header *__restrict__ hdr, float *__restrict__ scratch, float *__restrict__ far)
 {
     constexpr int kWavesB = THREADS / 64;
+    constexpr int CPL = kCH / LPS, SPG = 64 / LPS;            // channels per lane, samples per group (one wave pass)
+    typedef LaneRaw<VT, CPL> RV;
+    typedef LaneRaw<GT, CPL> RG;
     MDETR_DYNAMIC_LDS(unsigned char, smem_raw);
     unsigned long long *win = reinterpret_cast<unsigned long long *>(smem_raw);
-    unsigned *cnt = reinterpret_cast<unsigned *>(smem_raw + static_cast<size_t>(pl.max_cells + kTrash) * kCellU64 * 8);
-    unsigned *recs = cnt + pl.max_cells;
+    unsigned *cnt = reinterpret_cast<unsigned *>(smem_raw + lds_win_bytes(pl.max_cells));
+    unsigned *recs = reinterpret_cast<unsigned *>(smem_raw + lds_win_bytes(pl.max_cells) + lds_cnt_bytes(pl.max_cells));
     int *tab = reinterpret_cast<int *>(recs + kWavesB * 64 * kRecDw);       // centre cells of the candidate rows / columns (mode 0)
     int *lv = tab + pl.max_tab;                                              // 4 x 8 ints: the candidate rectangle of each query level
     unsigned *blk = reinterpret_cast<unsigned *>(lv + 32);                   // [0] = max count of the pass
@@ -277,13 +367,15 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
     const int l = w.l, H = pl.H[l], W = pl.W[l], TH = w.mode == 1 ? H : pl.TH[l], TW = w.mode == 1 ? W : pl.TW[l];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int P = pl.P, LP = pl.L * P, M = pl.M, R = pl.R[l];
-    const int j = lane >> 3, k = lane & 7;
+    const int j = lane / LPS, k = lane % LPS;
     constexpr int eb = Elem<VT>::kBytes;
     const int rowb = M * kCH * eb;                            // bytes from a pixel to the next, `value`
-    const char *vlev = reinterpret_cast<const char *>(value) + ((static_cast<int64_t>(b) * pl.S + pl.start[l]) * M + m) * (kCH * eb) + k * 4 * eb;
-    const char *gbase = reinterpret_cast<const char *>(grad_out) + k * 4 * Elem<GT>::kBytes;
-    const int64_t pair0 = static_cast<int64_t>(b) * pl.Lq * M + m;                    // pair index of query q: pair0 + q * M
-    float *far_lev = far + ((static_cast<int64_t>(b) * pl.S + pl.start[l]) * M + m) * kCH + k * 4;
+    const char *vlev = reinterpret_cast<const char *>(value) + ((static_cast<int64_t>(b) * pl.S + pl.start[l]) * M + m) * (kCH * eb) + k * CPL * eb;
+    const char *gbase = reinterpret_cast<const char *>(grad_out) + k * CPL * Elem<GT>::kBytes;
+    // index arithmetic in 32 bits (the plan guarantees B * Lq * M * L * P < 2^28 and byte offsets into grad_out / one image's
+    // value below 2^31): pair index of query q = pair0u + q * M
+    const unsigned pair0u = static_cast<unsigned>(b) * static_cast<unsigned>(pl.Lq) * M + m;
+    float *far_lev = far + ((static_cast<int64_t>(b) * pl.S + pl.start[l]) * M + m) * kCH + k * CPL;
     unsigned *wrec = recs + wave * 64 * kRecDw;
 
     // centre cells of the candidate rectangles' rows and columns on level l (mode 0): two small tables instead of two
@@ -323,7 +415,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
         // contributions are rounded to multiples of 2^-(22 - shift - e): |x| * scale < 2^(22 - shift), up to 2^(9 + shift) - 1 per cell
         const float scale = ldexpf(1.0f, 22 - shift - e);
         const float magic = ldexpf(1.0f, 23) + ldexpf(1.0f, 22 - shift);
-        for (int i = threadIdx.x; i < (w.ncell + kTrash) * kCellU64; i += THREADS) win[i] = 0ull;
+        for (int i = threadIdx.x; i < (w.ncell + kTrash) * kCellStride; i += THREADS) win[i] = 0ull;
         for (int i = threadIdx.x; i < w.ncell; i += THREADS) cnt[i] = 0u;
         if (threadIdx.x == 0) blk[0] = 0u;
         __syncthreads();
@@ -348,12 +440,12 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 c.q = sq + (y0l + row) * Wq + x0l + col;
                 c.qcy = tab[ro + row];
                 c.qcx = tab[co + col];
-                c.owned = c.qcy >= w.cy0 && c.qcy < w.cy0 + TH && c.qcx >= w.cx0 && c.qcx < w.cx0 + TW;
+                c.owned = static_cast<unsigned>(c.qcy - w.cy0) < static_cast<unsigned>(TH) && static_cast<unsigned>(c.qcx - w.cx0) < static_cast<unsigned>(TW);
             } else {
                 c.q = w.q0 + qi;
                 c.owned = w.mode == 1;
             }
-            const int64_t srec = (pair0 + static_cast<int64_t>(c.q) * M) * LP + l * P + c.p;
+            const unsigned srec = (pair0u + static_cast<unsigned>(c.q) * M) * LP + l * P + c.p;
             c.xy = c.act ? *reinterpret_cast<const float2 *>(loc + srec * 2) : make_float2(-9.f, -9.f);
             c.a = c.act ? attn[srec] : 0.f;
         };
@@ -379,23 +471,29 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 const float cw[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
                 const int yc0 = min(max(y, 0), H - 1), yc1 = min(max(y + 1, 0), H - 1);
                 const int xc0 = min(max(x, 0), W - 1), xc1 = min(max(x + 1, 0), W - 1);
-                if (w.mode == 2) owned = yc0 >= w.cy0 && yc0 < w.cy0 + TH && xc0 >= w.cx0 && xc0 < w.cx0 + TW;
+                if (w.mode == 2) owned = static_cast<unsigned>(yc0 - w.cy0) < static_cast<unsigned>(TH) && static_cast<unsigned>(xc0 - w.cx0) < static_cast<unsigned>(TW);
                 owned = owned && act;
+                // per axis: inside the map (.cuh:56-74), inside this block's core (one unsigned compare each)
+                const int wy0 = y - w.cy0, wx0 = x - w.cx0;
+                const bool aw = act && inwin;
+                const bool my[2] = {aw && static_cast<unsigned>(y) < static_cast<unsigned>(H), aw && static_cast<unsigned>(y + 1) < static_cast<unsigned>(H)};
+                const bool mx[2] = {static_cast<unsigned>(x) < static_cast<unsigned>(W), static_cast<unsigned>(x + 1) < static_cast<unsigned>(W)};
+                const bool ky[2] = {finite && static_cast<unsigned>(wy0) < static_cast<unsigned>(TH), finite && static_cast<unsigned>(wy0 + 1) < static_cast<unsigned>(TH)};
+                const bool kx[2] = {static_cast<unsigned>(wx0) < static_cast<unsigned>(TW), static_cast<unsigned>(wx0 + 1) < static_cast<unsigned>(TW)};
+                const int cell0 = wy0 * w.tstride + wx0;
                 unsigned cell[4], valid = 0u, stray = 0u;
                 float wt[4];
                 bool anycore = false;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int yy = y + (c >> 1), xx = x + (c & 1);
-                    const bool inmap = act && inwin && yy >= 0 && yy <= H - 1 && xx >= 0 && xx <= W - 1;  // .cuh:56-74
+                    const bool inmap = my[c >> 1] && mx[c & 1];
                     wt[c] = inmap ? cw[c] : 0.f;
                     valid |= inmap ? (1u << c) : 0u;
                     // grad_value: a corner of bilinear weight exactly 0 (integer pixel coordinates, as the model's initial
                     // offsets produce) adds exactly 0 for finite gradients -- it is neither accumulated nor counted
                     const bool ok = inmap && (wt[c] != 0.f || !finite);
-                    const int wy = yy - w.cy0, wx = xx - w.cx0;
-                    const bool core = ok && finite && wy >= 0 && wy < TH && wx >= 0 && wx < TW;
-                    cell[c] = core ? static_cast<unsigned>(wy * w.tstride + wx) : 0xFFFFu;
+                    const bool core = ok && ky[c >> 1] && kx[c & 1];
+                    cell[c] = core ? static_cast<unsigned>(cell0 + (c >> 1) * w.tstride + (c & 1)) : 0xFFFFu;
                     anycore = anycore || core;
                     stray |= (ok && !core && owned) ? (1u << c) : 0u;
                 }
@@ -449,56 +547,50 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
             }
             wave_sync();
 
-            // ---- b1. own samples, 8 per group (8 lanes x 4 channels each), up to NG groups per batch: every load of the batch
-            //          is requested before the first group is consumed ----------------------------------------------------------
-            auto run_own = [&](bool on, int r, const float4 &g, const float4 &v0, const float4 &v1, const float4 &v2, const float4 &v3) {
-                float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f, a = 0.f, lh = 0.f, lw = 0.f;
-                float wt[4] = {0.f, 0.f, 0.f, 0.f};
-                unsigned flags = 0u;
-                int64_t pair = 0;
-                if (on) {
-                    const unsigned *rr = wrec + r * kRecDw;
-                    const uint4 r0 = *reinterpret_cast<const uint4 *>(rr);
-                    const uint4 r1 = *reinterpret_cast<const uint4 *>(rr + 4);
-                    const uint4 r2 = *reinterpret_cast<const uint4 *>(rr + 8);
-                    pair = pair0 + static_cast<int64_t>(r0.x) * M;
-                    wt[0] = __builtin_bit_cast(float, r1.x); wt[1] = __builtin_bit_cast(float, r1.y);
-                    wt[2] = __builtin_bit_cast(float, r1.z); wt[3] = __builtin_bit_cast(float, r1.w);
-                    a = __builtin_bit_cast(float, r2.x); lh = __builtin_bit_cast(float, r2.y); lw = __builtin_bit_cast(float, r2.z);
-                    flags = r2.w;
-                    if (finite) {
-                        const float as = a * scale;
-                        accumulate4(win, r0.z, r0.w, wt, make_float4(as * g.x, as * g.y, as * g.z, as * g.w), k, magic);
-                    }
-                    if ((flags & 0xF0u) && shift == 0) {      // corners nobody else will see: global fp32 atomics (.cuh:125-152)
-                        const float4 tg = make_float4(a * g.x, a * g.y, a * g.z, a * g.w);
-                        const unsigned pix = r0.y & 0xFFFFFFu;
+            // ---- b1. own samples, SPG per group (LPS lanes x CPL channels each), up to GMAX groups per batch: every load of the
+            //          batch is requested before the first group is consumed ---------------------------------------------------
+            auto run_own = [&](bool on, int r, const typename RG::T &graw, const typename RV::T (&vraw)[4]) __attribute__((always_inline)) {
+                // (lanes beyond the list hold the list's last record and its loads: everything is computed, only the side
+                // effects are masked)
+                const unsigned *rr = wrec + r * kRecDw;
+                const uint4 r0 = *reinterpret_cast<const uint4 *>(rr);
+                const uint4 r1 = *reinterpret_cast<const uint4 *>(rr + 4);
+                const uint4 r2 = *reinterpret_cast<const uint4 *>(rr + 8);
+                const float wt[4] = {__builtin_bit_cast(float, r1.x), __builtin_bit_cast(float, r1.y),
+                                     __builtin_bit_cast(float, r1.z), __builtin_bit_cast(float, r1.w)};
+                const float a = __builtin_bit_cast(float, r2.x), lh = __builtin_bit_cast(float, r2.y), lw = __builtin_bit_cast(float, r2.z);
+                const unsigned flags = r2.w;
+                float g[CPL];
+                RG::widen(graw, g);
+                if (on && finite) {
+                    const float as = a * scale;
+                    float ag[CPL];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            if (flags & (16u << c)) {
-                                float *p = far_lev + (static_cast<int64_t>(pix) + ((c & 1) && (r0.y >> 30 & 1u) ? 1 : 0) + ((c >> 1) && (r0.y >> 31) ? W : 0)) * (M * kCH);
-                                unsafeAtomicAdd(p + 0, wt[c] * tg.x);
-                                unsafeAtomicAdd(p + 1, wt[c] * tg.y);
-                                unsafeAtomicAdd(p + 2, wt[c] * tg.z);
-                                unsafeAtomicAdd(p + 3, wt[c] * tg.w);
-                            }
-                        }
-                        if (k == 0) hdr->far = 1u;
-                    }
-                    // four 4-channel dot products as packed pairs: (e0, e1) and (e2, e3) share their FMAs
-                    f32x2 p01 = mul2(make_f32x2(g.x, g.x), make_f32x2(v0.x, v1.x)), p23 = mul2(make_f32x2(g.x, g.x), make_f32x2(v2.x, v3.x));
-                    p01 = fma2(make_f32x2(g.y, g.y), make_f32x2(v0.y, v1.y), p01); p23 = fma2(make_f32x2(g.y, g.y), make_f32x2(v2.y, v3.y), p23);
-                    p01 = fma2(make_f32x2(g.z, g.z), make_f32x2(v0.z, v1.z), p01); p23 = fma2(make_f32x2(g.z, g.z), make_f32x2(v2.z, v3.z), p23);
-                    p01 = fma2(make_f32x2(g.w, g.w), make_f32x2(v0.w, v1.w), p01); p23 = fma2(make_f32x2(g.w, g.w), make_f32x2(v2.w, v3.w), p23);
-                    e0 = p01.x; e1 = p01.y; e2 = p23.x; e3 = p23.y;
+                    for (int i = 0; i < CPL; ++i) ag[i] = as * g[i];
+                    accumulate<CPL>(win, r0.z, r0.w, wt, ag, k, magic);
                 }
-                float d0 = sum8f(e0), d1 = sum8f(e1), d2 = sum8f(e2), d3 = sum8f(e3);    // over the 8 lanes of the sample, every lane takes part
+                if (on && (flags & 0xF0u) && shift == 0) {    // corners nobody else will see: global fp32 atomics (.cuh:125-152)
+                    const unsigned pix = r0.y & 0xFFFFFFu;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (flags & (16u << c)) {
+                            float *p = far_lev + (static_cast<int64_t>(pix) + ((c & 1) && (r0.y >> 30 & 1u) ? 1 : 0) + ((c >> 1) && (r0.y >> 31) ? W : 0)) * (M * kCH);
+#pragma unroll
+                            for (int i = 0; i < CPL; ++i) unsafeAtomicAdd(p + i, wt[c] * (a * g[i]));
+                        }
+                    }
+                    if (k == 0) hdr->far = 1u;
+                }
+                float e[4];
+                CornerDots<GT, VT, CPL>::run(graw, g, vraw, e);
+                // over the LPS lanes of the sample, every lane takes part
+                float d0 = sum_sample<LPS>(e[0]), d1 = sum_sample<LPS>(e[1]), d2 = sum_sample<LPS>(e[2]), d3 = sum_sample<LPS>(e[3]);
                 d0 = (flags & 1u) ? d0 : 0.f; d1 = (flags & 2u) ? d1 : 0.f;              // a corner outside the map reads nothing (.cuh:56-78)
                 d2 = (flags & 4u) ? d2 : 0.f; d3 = (flags & 8u) ? d3 : 0.f;
                 if (on && k == 0) {
                     const float hh = 1.f - lh, hw = 1.f - lw;
-                    const int p = (flags >> 8) & 15u;
-                    const int64_t o_ = pair * LP + l * P + p;
+                    const unsigned p = (flags >> 8) & 15u;
+                    const unsigned o_ = (pair0u + r0.x * static_cast<unsigned>(M)) * static_cast<unsigned>(LP) + static_cast<unsigned>(l * P) + p;   // < 2^28 (plan)
                     grad_attn[o_] = wt[0] * d0 + wt[1] * d1 + wt[2] * d2 + wt[3] * d3;                                     // .cuh:156
                     reinterpret_cast<float2 *>(grad_loc)[o_] = make_float2(static_cast<float>(W) * (a * (hh * (d1 - d0) + lh * (d3 - d2))),   // .cuh:157
                                                                             static_cast<float>(H) * (a * (hw * (d2 - d0) + lw * (d3 - d1))));  // .cuh:158
@@ -506,64 +598,64 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
             };
             // a batch of exactly NG groups (the last one possibly ragged): straight-line code, lanes beyond the list re-read its
             // last record and are masked at the use
-            auto own_batch = [&](auto ngc, int i0) {
+            auto own_batch = [&](auto ngc, int i0) __attribute__((always_inline)) {
                 constexpr int NG = decltype(ngc)::value;
-                typename Elem<GT>::Raw rg[NG];
-                typename Elem<VT>::Raw rv[NG][4];
+                typename RG::T rg[NG];
+                typename RV::T rv[NG][4];
 #pragma unroll
                 for (int t = 0; t < NG; ++t) {
-                    const int r = min(i0 + 8 * t + j, no - 1);
+                    const int r = min(i0 + SPG * t + j, no - 1);
                     const uint2 h = *reinterpret_cast<const uint2 *>(wrec + r * kRecDw);
-                    rg[t] = Elem<GT>::loadr(gbase + (pair0 + static_cast<int64_t>(h.x) * M) * (kCH * Elem<GT>::kBytes));
+                    rg[t] = RG::load(gbase + (pair0u + h.x * static_cast<unsigned>(M)) * static_cast<unsigned>(kCH * Elem<GT>::kBytes));
                     const int dxb = (h.y >> 30) & 1u ? rowb : 0, dyb = (h.y >> 31) ? W * rowb : 0;
-                    const char *vb = vlev + static_cast<int64_t>(h.y & 0xFFFFFFu) * rowb;
-                    rv[t][0] = Elem<VT>::loadr(vb); rv[t][1] = Elem<VT>::loadr(vb + dxb);
-                    rv[t][2] = Elem<VT>::loadr(vb + dyb); rv[t][3] = Elem<VT>::loadr(vb + dyb + dxb);
+                    const char *vb = vlev + (h.y & 0xFFFFFFu) * static_cast<unsigned>(rowb);
+                    rv[t][0] = RV::load(vb); rv[t][1] = RV::load(vb + dxb);
+                    rv[t][2] = RV::load(vb + dyb); rv[t][3] = RV::load(vb + dyb + dxb);
                 }
 #pragma unroll
                 for (int t = 0; t < NG; ++t) {
-                    const int r = i0 + 8 * t + j;
-                    run_own(r < no, min(r, no - 1), Elem<GT>::widen(rg[t]), Elem<VT>::widen(rv[t][0]), Elem<VT>::widen(rv[t][1]),
-                            Elem<VT>::widen(rv[t][2]), Elem<VT>::widen(rv[t][3]));
+                    const int r = i0 + SPG * t + j;
+                    run_own(r < no, min(r, no - 1), rg[t], rv[t]);
                 }
             };
-            for (int i0 = 0; i0 < no; i0 += 8 * GMAX) {
-                const int ng = min(GMAX, (no - i0 + 7) >> 3);                             // wave-uniform
+            for (int i0 = 0; i0 < no; i0 += SPG * GMAX) {
+                const int ng = min(GMAX, (no - i0 + SPG - 1) / SPG);                      // wave-uniform
                 if (ng == 1) own_batch(std::integral_constant<int, 1>(), i0);
-                else if (ng == 2) own_batch(std::integral_constant<int, 2>(), i0);
-                else if (ng == 3) own_batch(std::integral_constant<int, 3>(), i0);
-                else if (GMAX <= 4 || ng == 4) own_batch(std::integral_constant<int, 4>(), i0);
-                else if constexpr (GMAX > 4) {
-                    if (ng <= 6) { own_batch(std::integral_constant<int, 4>(), i0); own_batch(std::integral_constant<int, 2>(), i0 + 32); }
-                    else own_batch(std::integral_constant<int, GMAX>(), i0);
+                else if (GMAX == 2 || ng == 2) own_batch(std::integral_constant<int, 2>(), i0);
+                else if constexpr (GMAX >= 4) {
+                    if (ng == 3) own_batch(std::integral_constant<int, 3>(), i0);
+                    else own_batch(std::integral_constant<int, 4>(), i0);
                 }
             }
             // ---- b2. neighbours' samples that reach into this core: accumulate only ---------------------------------------
-            auto halo_batch = [&](auto ngc, int i0) {
+            auto halo_batch = [&](auto ngc, int i0) __attribute__((always_inline)) {
                 constexpr int NG = decltype(ngc)::value;
-                typename Elem<GT>::Raw rg[NG];
+                typename RG::T rg[NG];
                 const int h0 = 64 - nh;
 #pragma unroll
                 for (int t = 0; t < NG; ++t) {
-                    const int r = h0 + min(i0 + 8 * t + j, nh - 1);
-                    rg[t] = Elem<GT>::loadr(gbase + (pair0 + static_cast<int64_t>(wrec[r * kRecDw]) * M) * (kCH * Elem<GT>::kBytes));
+                    const int r = h0 + min(i0 + SPG * t + j, nh - 1);
+                    rg[t] = RG::load(gbase + (pair0u + wrec[r * kRecDw] * static_cast<unsigned>(M)) * static_cast<unsigned>(kCH * Elem<GT>::kBytes));
                 }
 #pragma unroll
                 for (int t = 0; t < NG; ++t) {
-                    if (i0 + 8 * t + j < nh) {
-                        const unsigned *rr = wrec + (h0 + i0 + 8 * t + j) * kRecDw;
+                    if (i0 + SPG * t + j < nh) {
+                        const unsigned *rr = wrec + (h0 + i0 + SPG * t + j) * kRecDw;
                         const uint4 r0 = *reinterpret_cast<const uint4 *>(rr);
                         const uint4 r1 = *reinterpret_cast<const uint4 *>(rr + 4);
                         const float wt[4] = {__builtin_bit_cast(float, r1.x), __builtin_bit_cast(float, r1.y),
                                              __builtin_bit_cast(float, r1.z), __builtin_bit_cast(float, r1.w)};
                         const float as = __builtin_bit_cast(float, rr[8]) * scale;
-                        const float4 g = Elem<GT>::widen(rg[t]);
-                        accumulate4(win, r0.z, r0.w, wt, make_float4(as * g.x, as * g.y, as * g.z, as * g.w), k, magic);
+                        float ag[CPL];
+                        RG::widen(rg[t], ag);
+#pragma unroll
+                        for (int i = 0; i < CPL; ++i) ag[i] *= as;
+                        accumulate<CPL>(win, r0.z, r0.w, wt, ag, k, magic);
                     }
                 }
             };
-            for (int i0 = 0; i0 < nh; i0 += 32) {
-                const int ng = min(4, (nh - i0 + 7) >> 3);
+            for (int i0 = 0; i0 < nh; i0 += 4 * SPG) {
+                const int ng = min(4, (nh - i0 + SPG - 1) / SPG);
                 if (ng == 1) halo_batch(std::integral_constant<int, 1>(), i0);
                 else if (ng == 2) halo_batch(std::integral_constant<int, 2>(), i0);
                 else if (ng == 3) halo_batch(std::integral_constant<int, 3>(), i0);
@@ -591,7 +683,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
             float *dst0 = grad_value + ((static_cast<int64_t>(b) * pl.S + pl.start[l]) * M + m) * kCH;
             for (int i = threadIdx.x; i < w.ncell * kCellU64; i += THREADS) {
                 const int cell = i / kCellU64, pr = i % kCellU64;
-                const unsigned long long s = win[i] - static_cast<unsigned long long>(cnt[cell]) * cbits;
+                const unsigned long long s = win[cell * kCellStride + pr] - static_cast<unsigned long long>(cnt[cell]) * cbits;
                 const int lo = static_cast<int>(static_cast<unsigned>(s));
                 const int hi = static_cast<int>((static_cast<long long>(s) - static_cast<long long>(lo)) >> 32);
                 const float2 out = make_float2(static_cast<float>(lo) * inv, static_cast<float>(hi) * inv);
@@ -674,6 +766,9 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
         total += static_cast<int64_t>(pl.H[l]) * pl.W[l];
     }
     if (total != S) return false;
+    // 32-bit index arithmetic in the kernel
+    if (static_cast<int64_t>(B) * Lq * M * L * P >= (1 << 28) || static_cast<int64_t>(B) * Lq * M * kCH * 4 >= (1LL << 31) ||
+        static_cast<int64_t>(S) * M * kCH * 4 >= (1LL << 31)) return false;
     const bool self = Lq == S;                               // queries = the pyramid's cells, in order
     if (!self && static_cast<int64_t>(Lq) * P > 16384) return false;   // every block scans every query: only for few queries
     // tuning knobs (read per call: a handful of getenv()s against a multi-microsecond launch sequence).  Defaults from the
@@ -782,27 +877,34 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
     profile_end(st);
     // 512 threads (8 waves) or 1024 (16 waves: twice the record buffers, more loads in flight per CU)
     int threads = env_int("MDETR_MSDA_THREADS", 1024);          // (bf16: 0.74 ms at 16 waves vs 0.96 at 8, same tile)
-    threads = (threads >= 1024 && elem_dtype == 2) ? 1024 : 512;   // (16 waves leave 128 VGPRs: the fp32 form's load batches do not fit)
-    size_t lds = static_cast<size_t>(pl.max_cells + kTrash) * kCellU64 * 8 + static_cast<size_t>(pl.max_cells) * 4 +
-                 static_cast<size_t>(threads / 64) * 64 * kRecDw * 4 + static_cast<size_t>(pl.max_tab) * 4 + 128 + 16;
-    if (lds > 160 * 1024 && threads == 1024) {
+    // (16 waves leave 128 VGPRs: the fp32 form's load batches do not fit; 768 = 12 waves with 170 VGPRs, bf16 only)
+    threads = (threads >= 1024 && elem_dtype == 2) ? 1024 : ((threads == 768 && elem_dtype == 2) ? 768 : 512);
+    auto lds_bytes = [&](int thr) {
+        return lds_win_bytes(pl.max_cells) + lds_cnt_bytes(pl.max_cells) + static_cast<size_t>(thr / 64) * 64 * kRecDw * 4 +
+               static_cast<size_t>(pl.max_tab) * 4 + 128 + 16;
+    };
+    size_t lds = lds_bytes(threads);
+    if (lds > 160 * 1024 && threads > 512) {
         threads = 512;
-        lds -= static_cast<size_t>(8) * 64 * kRecDw * 4;
+        lds = lds_bytes(threads);
     }
     if (lds > 160 * 1024) return hipErrorNotSupported;
     int dev = 0;
     if ((err = hipGetDevice(&dev)) != hipSuccess) return err;
-    // groups of 8 own samples whose loads are in flight together: 4 (<= 128 VGPRs: two 512-thread workgroups per CU when
-    // the LDS allows) or 8 (bf16 only, one workgroup per CU)
-    int groups = env_int("MDETR_MSDA_GROUPS", 4);
-    groups = (groups >= 8 && elem_dtype == 2 && threads == 512) ? 8 : 4;
+    // lanes per sample: 4 (bf16 at 16 waves: 8 channels per lane, two groups of 16 own samples in flight) or 8 (4 channels per
+    // lane, four groups of 8)
+    int lps = env_int("MDETR_MSDA_LPS", 4);
+    lps = (lps == 4 && elem_dtype == 2 && threads > 512) ? 4 : 8;
+    const int groups = env_int("MDETR_MSDA_GROUPS", 2);      // (12-wave form: 2 or 4 groups of 16 own samples in flight)
     static bool attr_set[6][64] = {};                        // per kernel instance and device
-    const int which = (elem_dtype == 2 ? 1 : 0) + (threads == 1024 ? 4 : (groups == 8 ? 2 : 0));
+    const int which = elem_dtype != 2 ? 0 : (threads == 512 ? 1 : (threads == 768 ? (groups >= 4 ? 5 : 4) : (lps == 8 ? 2 : 3)));
     typedef __hip_bfloat16 bf;
-    const void *kern = which == 0 ? reinterpret_cast<const void *>(msda_bwd_fused<float, float, 512, 4>)
-                     : which == 1 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 512, 4>)
-                     : which == 3 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 512, 8>)
-                                  : reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 1024, 4>);
+    const void *kern = which == 0 ? reinterpret_cast<const void *>(msda_bwd_fused<float, float, 512, 4, 8>)
+                     : which == 1 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 512, 4, 8>)
+                     : which == 2 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 1024, 4, 8>)
+                     : which == 3 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 1024, 2, 4>)
+                     : which == 4 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 768, 2, 4>)
+                                  : reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 768, 4, 4>);
     if (dev < 0 || dev >= 64 || !attr_set[which][dev]) {
         if ((err = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return err;
         if (dev >= 0 && dev < 64) attr_set[which][dev] = true;
@@ -814,10 +916,12 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
         hipLaunchKernelGGL(k, dim3(nblocks), dim3(threads), lds, st, pl, static_cast<const VT *>(value), loc, attn,
                            static_cast<const GT *>(grad_out), grad_value, grad_loc, grad_attn, hdr, scratch, far);
     };
-    if (which == 0) go(msda_bwd_fused<float, float, 512, 4>, float(), float());
-    else if (which == 1) go(msda_bwd_fused<bf, bf, 512, 4>, bf(), bf());
-    else if (which == 3) go(msda_bwd_fused<bf, bf, 512, 8>, bf(), bf());
-    else go(msda_bwd_fused<bf, bf, 1024, 4>, bf(), bf());
+    if (which == 0) go(msda_bwd_fused<float, float, 512, 4, 8>, float(), float());
+    else if (which == 1) go(msda_bwd_fused<bf, bf, 512, 4, 8>, bf(), bf());
+    else if (which == 2) go(msda_bwd_fused<bf, bf, 1024, 4, 8>, bf(), bf());
+    else if (which == 3) go(msda_bwd_fused<bf, bf, 1024, 2, 4>, bf(), bf());
+    else if (which == 4) go(msda_bwd_fused<bf, bf, 768, 2, 4>, bf(), bf());
+    else go(msda_bwd_fused<bf, bf, 768, 4, 4>, bf(), bf());
     profile_end(st);
     const int64_t nrows = static_cast<int64_t>(B) * S * M;
     profile_begin(8, Lq, st);

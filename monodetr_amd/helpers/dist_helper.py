@@ -6,8 +6,8 @@ parameters and drives its bucket logic from the autograd thread: measured +5 ms 
 iteration on a step that is launch-bound at 38 ms (bf16).  The model's gradients are small (150 MB
 fp32 / 75 MB bf16) next to xGMI bandwidth, so overlapping the all-reduce with the backward buys
 < 1 ms; what matters is launch count.  ``FlatGradSync`` therefore does the whole exchange after the
-backward in a handful of launches per dtype: one ``cat`` into a flat buffer, ONE all-reduce, one
-multi-tensor copy back.
+backward in a handful of launches per dtype: one ``cat`` into a flat buffer, ONE all-reduce, and the
+gradients re-pointed at slices of the reduced buffer (no copy back).
 
 Requirements (same as DDP's static-graph mode): every rank produces gradients for the same set of
 parameters in every iteration -- true for this model, whose unused parameters are unused on every
@@ -17,38 +17,116 @@ import torch
 import torch.distributed as dist
 
 
-def broadcast_parameters(module, src=0):
-    """Make every rank start from rank `src`'s parameters and buffers (what DDP does at wrap time)."""
-    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+def broadcast_parameters(module, src=0, extra=()):
+    """Make every rank start from rank `src`'s parameters and buffers (what DDP does at wrap time); `extra`: more tensors
+    to carry along (optimizer state)."""
+    tensors, seen = [], set()
+    for t in [p.data for p in module.parameters()] + [b.data for b in module.buffers()] + [t.data for t in extra]:
+        if t.data_ptr() not in seen and t.numel():                     # (flat optimizer buffers alias their per-parameter views)
+            seen.add(t.data_ptr())
+            tensors.append(t)
     by_dtype = {}
     for t in tensors:
         by_dtype.setdefault(t.dtype, []).append(t)
-    for group in by_dtype.values():
-        flat = torch.cat([t.reshape(-1) for t in group])
+    for dtype in sorted(by_dtype, key=str):
+        group = by_dtype[dtype]
+        flat = torch.cat([_flat(t) for t in group])
         dist.broadcast(flat, src)
-        torch._foreach_copy_(group, [c.view_as(t) for c, t in zip(flat.split([t.numel() for t in group]), group)])
+        torch._foreach_copy_(group, [_like(c, t) for c, t in zip(flat.split([t.numel() for t in group]), group)])
+
+
+def _flat(g):
+    """g as a 1-D tensor in MEMORY order -- a view for dense tensors (channels_last convolution weights included)."""
+    if g.is_contiguous():
+        return g.view(-1)
+    if g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last):
+        return g.permute(0, 2, 3, 1).reshape(-1)
+    return g.reshape(-1)                                              # a copy, in logical order
+
+
+def _like(c, g):
+    """The 1-D slice c (laid out by `_flat`) with g's shape AND strides."""
+    if g.dim() == 4 and not g.is_contiguous() and g.is_contiguous(memory_format=torch.channels_last):
+        n, ch, h, w = g.shape
+        return c.view(n, h, w, ch).permute(0, 3, 1, 2)
+    return c.view_as(g)
+
+
+def _avg_op(group=None):
+    """(reduce op, post-scale): RCCL averages inside the collective; gloo only sums."""
+    try:
+        if dist.get_backend(group) == "nccl":
+            return dist.ReduceOp.AVG, None
+    except Exception:                                                 # noqa: BLE001 -- older builds: fall through to SUM + scale
+        pass
+    return dist.ReduceOp.SUM, True
+
+
+def static_plan(params):
+    """[(parameters, their current gradient tensors, persistent flat buffer, views of its slices shaped like the gradients)]
+    per dtype -- no collective involved: usable before the process group exists."""
+    by_dtype = {}
+    for p in params:
+        if p.requires_grad and p.grad is not None:
+            by_dtype.setdefault(p.grad.dtype, []).append(p)
+    plan = []
+    for dtype in sorted(by_dtype, key=str):                           # same order on every rank
+        ps = by_dtype[dtype]
+        src = [p.grad for p in ps]
+        flat = torch.empty(sum(g.numel() for g in src), dtype=dtype, device=src[0].device)
+        plan.append((ps, src, flat, [_like(v, g) for v, g in zip(flat.split([g.numel() for g in src]), src)]))
+    return plan
 
 
 class FlatGradSync:
-    """``sync()`` after ``backward()``: p.grad <- mean over ranks of p.grad, for every parameter that has one."""
+    """``sync()`` after ``backward()``: p.grad <- mean over ranks of p.grad, for every parameter that has one.
+
+    Per dtype: one ``cat`` of the gradients into a flat buffer, ONE all-reduce (averaging inside RCCL), and the parameters'
+    ``.grad`` RE-POINTED at their slices of the reduced buffer -- no copy back (a multi-tensor copy of 313 gradients is 296
+    device-to-device memcpy launches, 1.3 ms on MI355X, profiles/r02l_syncbench.txt).
+
+    ``make_static()`` (graph replay, bench.py): remember the gradient tensors as they are NOW -- the fixed addresses a
+    captured backward writes to -- and reduce into persistent flat buffers; every later ``sync()`` gathers from those
+    remembered tensors, whatever ``.grad`` points at by then (the reduced views, which the captured optimizer step reads)."""
 
     def __init__(self, params, world_size=None, group=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = world_size if world_size is not None else dist.get_world_size(group)
+        self._static = None                       # dtype -> (params, source gradients, flat buffer, views)
 
-    @torch.no_grad()
-    def sync(self):
+    def _plan(self):
         by_dtype = {}
         for p in self.params:
             if p.grad is not None:
-                by_dtype.setdefault(p.grad.dtype, []).append(p.grad)
-        for dtype in sorted(by_dtype, key=str):                       # same order on every rank
-            grads = by_dtype[dtype]
-            flat = torch.cat([g.reshape(-1) for g in grads])
-            dist.all_reduce(flat, group=self.group)                   # SUM (gloo has no AVG); RCCL ring over xGMI on the GPU
-            flat.mul_(1.0 / self.world)
-            torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+                by_dtype.setdefault(p.grad.dtype, []).append(p)
+        return [(dtype, by_dtype[dtype]) for dtype in sorted(by_dtype, key=str)]      # same order on every rank
+
+    @torch.no_grad()
+    def make_static(self):
+        self._static = static_plan(self.params)
+        return self
+
+    @torch.no_grad()
+    def sync(self):
+        op, scale = _avg_op(self.group)
+        if self._static is not None:
+            for ps, src, flat, views in self._static:
+                torch.cat([_flat(g) for g in src], out=flat)
+                dist.all_reduce(flat, op=op, group=self.group)
+                if scale:
+                    flat.mul_(1.0 / self.world)
+                for p, v in zip(ps, views):
+                    p.grad = v
+            return
+        for dtype, ps in self._plan():
+            grads = [p.grad for p in ps]
+            flat = torch.cat([_flat(g) for g in grads])
+            dist.all_reduce(flat, op=op, group=self.group)                # RCCL ring over xGMI on the GPU
+            if scale:
+                flat.mul_(1.0 / self.world)
+            for p, c, g in zip(ps, flat.split([g.numel() for g in grads]), grads):
+                p.grad = _like(c, g)
 
 
 class BucketedGradSync:
@@ -92,7 +170,7 @@ class BucketedGradSync:
     @torch.no_grad()
     def _launch(self, b):
         grads = [p.grad for p in b["params"]]
-        b["flat"] = torch.cat([g.reshape(-1) for g in grads])
+        b["flat"] = torch.cat([_flat(g) for g in grads])
         b["work"] = dist.all_reduce(b["flat"], group=self.group, async_op=True)
 
     def _build(self):
@@ -127,6 +205,6 @@ class BucketedGradSync:
         for b in self.buckets:
             b["work"].wait()
             flat = b["flat"].mul_(1.0 / self.world)
-            grads = [p.grad for p in b["params"]]
-            torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+            for p, c in zip(b["params"], flat.split([p.grad.numel() for p in b["params"]])):
+                p.grad = _like(c, p.grad)                 # re-point instead of copying back
             b["work"], b["flat"], b["pending"] = None, None, len(b["params"])

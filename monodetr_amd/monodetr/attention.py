@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..attn_ext import fused_attention
-from .linear import token_linear
+from .linear import Linear, token_linear
 
 
 def _sdpa(q, k, v, num_heads, dropout_p, key_padding_mask):
@@ -65,7 +65,7 @@ class MultiheadAttention(nn.Module):
         self.head_dim = embed_dim // num_heads
         self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
         self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
-        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self.out_proj = Linear(embed_dim, embed_dim)
         nn.init.xavier_uniform_(self.in_proj_weight)
         nn.init.zeros_(self.out_proj.bias)
 

@@ -11,13 +11,14 @@ from torch import nn
 
 from ...utils.misc import at_least_fp32, no_padding
 from ...conv3x3_ext import Conv3x3
+from ...group_norm_ext import GroupNorm
 from ..linear import PointwiseConv2d
 from .transformer import TransformerEncoder, TransformerEncoderLayer
 
 
 def _conv_gn(cin, cout, k, stride=1):
     return nn.Sequential(PointwiseConv2d(cin, cout, kernel_size=(k, k), stride=(stride, stride), padding=k // 2),
-                         nn.GroupNorm(32, cout))
+                         GroupNorm(32, cout))
 
 
 _resize_cache = {}
@@ -72,8 +73,9 @@ class DepthPredictor(nn.Module):
         self.proj = _conv_gn(d, d, 1)
         self.upsample = _conv_gn(d, d, 1)
         self.depth_head = nn.Sequential(
-            Conv3x3(d, d, kernel_size=(3, 3), padding=1), nn.GroupNorm(32, num_channels=d), nn.ReLU(),
-            Conv3x3(d, d, kernel_size=(3, 3), padding=1), nn.GroupNorm(32, num_channels=d), nn.ReLU())
+            # (GroupNorm(relu=True) carries the ReLU; the Identity keeps the reference's Sequential indices -- state_dict keys)
+            Conv3x3(d, d, kernel_size=(3, 3), padding=1), GroupNorm(32, d, relu=True), nn.Identity(),
+            Conv3x3(d, d, kernel_size=(3, 3), padding=1), GroupNorm(32, d, relu=True), nn.Identity())
         self.depth_classifier = PointwiseConv2d(d, nbins + 1, kernel_size=(1, 1))
         self.depth_encoder = TransformerEncoder(TransformerEncoderLayer(d, nhead=8, dim_feedforward=256, dropout=0.1), 1)
         self.depth_pos_embed = nn.Embedding(int(dmax) + 1, 256)

@@ -9,7 +9,7 @@ from torch import nn
 
 from ...add_ln_ext import residual_layernorm
 from ..attention import MultiheadAttention
-from ..linear import ffn_hidden
+from ..linear import Linear, ffn_hidden
 
 
 def _get_clones(module, N):
@@ -27,9 +27,9 @@ class TransformerEncoderLayer(nn.Module):
     def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu"):
         super().__init__()
         self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
-        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear1 = Linear(d_model, dim_feedforward)
         self.dropout = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.linear2 = Linear(dim_feedforward, d_model)
         self.norm1 = nn.LayerNorm(d_model)
         self.norm2 = nn.LayerNorm(d_model)
         self.dropout1 = nn.Dropout(dropout)

@@ -27,7 +27,7 @@ from torch.nn.init import constant_, normal_, xavier_uniform_
 from ..add_ln_ext import residual_layernorm
 from ..utils.misc import inverse_sigmoid, no_padding
 from .attention import MultiheadAttention as FusedMultiheadAttention
-from .linear import ffn_hidden, token_linear
+from .linear import Linear, ffn_hidden, token_linear
 from .ops.modules import MSDeformAttn, MSDeformAttn_cross, MultiheadAttention  # noqa: F401  (reference :11)
 
 
@@ -38,7 +38,7 @@ class MLP(nn.Module):
         super().__init__()
         self.num_layers = num_layers
         dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
-        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.layers = nn.ModuleList(Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
 
     def forward(self, x):
         x = x.to(self.layers[0].weight.dtype)       # fp32 heads may sit behind a bf16 body
@@ -54,8 +54,14 @@ def fused_first_layers(x, heads):
     25-40 microsecond library launch three times over (forward, input gradient, weight gradient)."""
     firsts = [h.layers[0] if isinstance(h, MLP) else h for h in heads]
     x = x.to(firsts[0].weight.dtype)                # fp32 heads may sit behind a bf16 body: one cast for all of them
-    y = F.linear(x, torch.cat([l.weight for l in firsts], 0), torch.cat([l.bias for l in firsts], 0))
-    return y.split([l.out_features for l in firsts], -1)
+    widths = [l.out_features for l in firsts]
+    pad = -sum(widths) % 8                          # column sums (the bias gradient, csrc/colsum.hip) want whole 16-byte vectors
+    ws, bs = [l.weight for l in firsts], [l.bias for l in firsts]
+    if pad:
+        ws.append(ws[0].new_zeros(pad, ws[0].shape[1]))
+        bs.append(bs[0].new_zeros(pad))
+    y = token_linear(x, torch.cat(ws, 0), torch.cat(bs, 0))
+    return y.split(widths + ([pad] if pad else []), -1)[:len(widths)]
 
 
 def mlp_rest(mlp, h):
@@ -66,6 +72,35 @@ def mlp_rest(mlp, h):
     for layer in mlp.layers[1:-1]:
         x = F.relu(layer(x))
     return mlp.layers[-1](x)
+
+
+class _LevelPos(torch.autograd.Function):
+    """cat_l(flatten(pos_l) + level_embed[l]) along the token axis, as ``dtype`` (reference depthaware_transformer.py:215-218).
+    The sine embeddings are constants; the only gradient is level_embed's, a sum over the batch and the level's tokens.  As
+    the backward of four broadcast adds that is four generic reductions over [B, HW_l, C] slices of the concatenated
+    gradient (260 + 144 + ... microseconds at B = 8); here one streaming pass sums the batch (csrc/colsum.hip on the
+    [B, S * C] view) and four small column sums finish the levels."""
+
+    @staticmethod
+    def forward(ctx, level_embed, dtype, *pos):
+        ctx.counts = [p.shape[-2] * p.shape[-1] for p in pos]
+        ctx.embed_dtype = level_embed.dtype
+        return torch.cat([p.flatten(2).transpose(1, 2) + level_embed[l].view(1, 1, -1) for l, p in enumerate(pos)], 1).to(dtype)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from .. import colsum_ext
+        B, S, C = g.shape
+        g = g.contiguous()
+        flat = g.view(B, S * C)
+        over_batch = (colsum_ext.column_sum(flat) if colsum_ext.supported(flat) else flat.float().sum(0)).view(S, C)
+        rows, start = [], 0
+        for n in ctx.counts:
+            part = over_batch[start:start + n]
+            rows.append(colsum_ext.column_sum(part) if colsum_ext.supported(part) else part.sum(0))
+            start += n
+        return (torch.stack(rows).to(ctx.embed_dtype), None) + (None,) * len(ctx.counts)
 
 
 def _get_clones(module, N):
@@ -92,10 +127,10 @@ class VisualEncoderLayer(nn.Module):
         self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
-        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear1 = Linear(d_model, d_ffn)
         self.activation = _get_activation_fn(activation)
         self.dropout2 = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.linear2 = Linear(d_ffn, d_model)
         self.dropout3 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
 
@@ -173,18 +208,18 @@ class DepthAwareDecoderLayer(nn.Module):
         self.dropout2 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
         # ffn
-        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear1 = Linear(d_model, d_ffn)
         self.activation = _get_activation_fn(activation)
         self.dropout3 = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.linear2 = Linear(d_ffn, d_model)
         self.dropout4 = nn.Dropout(dropout)
         self.norm3 = nn.LayerNorm(d_model)
         self.group_num = group_num
         # content / position projections feeding the self attention
-        self.sa_qcontent_proj = nn.Linear(d_model, d_model)
-        self.sa_qpos_proj = nn.Linear(d_model, d_model)
-        self.sa_kcontent_proj = nn.Linear(d_model, d_model)
-        self.sa_kpos_proj = nn.Linear(d_model, d_model)
+        self.sa_qcontent_proj = Linear(d_model, d_model)
+        self.sa_qpos_proj = Linear(d_model, d_model)
+        self.sa_kcontent_proj = Linear(d_model, d_model)
+        self.sa_kpos_proj = Linear(d_model, d_model)
         self.sa_v_proj = nn.Linear(d_model, d_model)      # never contributes (reference :471 vs :477)
         self.nhead = n_heads
 
@@ -361,8 +396,7 @@ class DepthAwareTransformer(nn.Module):
         shapes = [tuple(s.shape[-2:]) for s in srcs]
         # flatten every level to [B, HW, C] and concatenate along the token axis
         src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
-        lvl_pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1)
-                             for l, p in enumerate(pos_embeds)], 1).to(src_flatten.dtype)
+        lvl_pos = _LevelPos.apply(self.level_embed, src_flatten.dtype, *pos_embeds)
         spatial_shapes, level_start_index = self._level_tensors(shapes, src_flatten.device)
         if unpadded:
             mask_flatten = valid_ratios = mask_depth = None

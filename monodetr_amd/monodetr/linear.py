@@ -172,6 +172,16 @@ def ffn_hidden(x, lin, dropout, activation=F.relu, tokenwise=True):
     return dropout(h) if dropout is not None else h
 
 
+class Linear(nn.Linear):
+    """nn.Linear (same parameters, same state_dict keys) whose forward is `token_linear`: from 4 096 token rows on -- the
+    decoder's B x 550 = 4 400 query rows, the depth encoder's B x 1 920 -- the weight gradient is the split-K batched product
+    and the bias gradient one `colsum` pass (the library's generic reduction takes 19 us for a [4 400, 256] matrix, its
+    single-tile NT GEMM 34 us); below that, or on the CPU, plain F.linear."""
+
+    def forward(self, x):
+        return token_linear(x, self.weight, self.bias)
+
+
 class PointwiseConv2d(nn.Conv2d):
     """nn.Conv2d (same parameters, same state_dict keys) whose forward takes `pointwise_conv` when the
     input qualifies and nn.Conv2d's otherwise."""

@@ -33,6 +33,7 @@ from .backbone import build_backbone
 from .depth_predictor import DepthPredictor
 from .depth_predictor.ddn_loss import DDNLoss
 from .depthaware_transformer import MLP, build_depthaware_transformer
+from ..group_norm_ext import GroupNorm
 from .linear import PointwiseConv2d
 from .matcher import build_matcher
 
@@ -76,7 +77,7 @@ class MonoDETR(nn.Module):
 
         def proj(cin, k, stride):
             return nn.Sequential(PointwiseConv2d(cin, hidden_dim, kernel_size=k, stride=stride, padding=k // 2),
-                                 nn.GroupNorm(32, hidden_dim))
+                                 GroupNorm(32, hidden_dim))
         if num_feature_levels > 1:
             projs = [proj(c, 1, 1) for c in backbone.num_channels]
             cin = backbone.num_channels[-1]

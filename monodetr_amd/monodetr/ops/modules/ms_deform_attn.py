@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..functions import MSDeformAttnFunction
-from ...linear import token_linear
+from ...linear import Linear, token_linear
 from .... import msda_prologue_ext
 
 
@@ -67,10 +67,10 @@ class MSDeformAttn(nn.Module):
         self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
         self.conditional = conditional
         d_value = d_model // 2 if conditional else d_model
-        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
-        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
-        self.value_proj = nn.Linear(d_value, d_value)
-        self.output_proj = nn.Linear(d_value, d_value)
+        self.sampling_offsets = Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = Linear(d_value, d_value)
+        self.output_proj = Linear(d_value, d_value)
         self._reset_parameters()
 
     def _reset_parameters(self):

@@ -26,6 +26,10 @@ def main():
     a = ap.parse_args()
     import bench
     from torch.profiler import ProfilerActivity, profile
+    # the profiler's shape recorder converts every integer argument to int64: keep the 64-bit dropout seeds below 2^63 here
+    from monodetr_amd import add_ln_ext
+    host_seed = add_ln_ext._host_seed
+    add_ln_ext._host_seed = lambda: host_seed() & (2 ** 63 - 1)
     step = bench.TrainStep(torch.device("cuda", 0), 8, a.precision, switches=bench.committed_switches(a.precision)[0])
     for _ in range(5):
         step._step()

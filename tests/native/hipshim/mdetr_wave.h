@@ -54,9 +54,16 @@ inline f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c)
 
 // two packed fp32 lanes (the real header: ext_vector_type(2) -> v_pk_fma_f32 / v_pk_mul_f32)
 struct f32x2 { float x, y; };
+struct alignas(16) f32x4 { float x, y, z, w; };
 inline f32x2 make_f32x2(float x, float y) { return {x, y}; }
 inline f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
 inline f32x2 mul2(f32x2 a, f32x2 b) { return {a.x * b.x, a.y * b.y}; }
+
+// v_dot2c_f32_bf16 (products of bf16 values are exact in fp32; the order of the two additions is the emulation's choice)
+inline float dot2_bf16(unsigned a, unsigned b, float c)
+{
+    return fmaf(__uint_as_float(a & 0xFFFF0000u), __uint_as_float(b & 0xFFFF0000u), fmaf(__uint_as_float(a << 16), __uint_as_float(b << 16), c));
+}
 
 inline void wave_sync() { hipshim::sync_wave(); }
 

@@ -697,3 +697,55 @@ def test_conv3x3_module_with_a_trainable_bias_matches_the_library(monkeypatch):
     for name, a, b in zip(("y", "dx", "dw", "db"), res[False], res[True]):
         lim = 2e-2 * max(1.0, a.float().abs().max().item()) * (4 if name in ("dw", "db") else 1)       # bf16 sums over 15 360 pixels
         assert (a.float() - b.float()).abs().max().item() <= lim, name
+
+
+# ---- GroupNorm (+ ReLU) on channels-last activations (csrc/group_norm.hip) --------------------------------------------------
+@pytest.mark.parametrize("shape,dtype,pdtype,relu", [
+    ((8, 256, 24, 80), torch.bfloat16, torch.bfloat16, True),          # depth head stage
+    ((8, 256, 48, 160), torch.bfloat16, torch.bfloat16, False),        # input projection, level 0: 32 row chunks of 240
+    ((8, 256, 6, 20), torch.bfloat16, torch.float32, False),           # coarsest level
+    ((2, 256, 24, 80), torch.float32, torch.float32, True),            # the fp32 path
+])
+def test_group_norm_kernel_matches_the_framework_operator(shape, dtype, pdtype, relu):
+    import torch.nn.functional as F
+    from monodetr_amd import group_norm_ext
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    N, C, H, W = shape
+    x = (torch.randn(shape, device="cuda", generator=g) * 1.7 + 0.3).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(C, device="cuda", generator=g) * 0.5 + 1.0).to(pdtype).requires_grad_(True)
+    b = (torch.randn(C, device="cuda", generator=g) * 0.5).to(pdtype).requires_grad_(True)
+    dy = torch.randn(shape, device="cuda", generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+    y = group_norm_ext.group_norm(x, w, b, 32, 1e-5, relu)
+    assert type(y.grad_fn).__name__ == "_GroupNormBackward" and y.is_contiguous(memory_format=torch.channels_last) and y.dtype == dtype
+    y.backward(dy)
+    got = (y.detach().float(), x.grad.float(), w.grad.float(), b.grad.float())
+    xr, wr, br = (t.detach().float().requires_grad_(True) for t in (x, w, b))
+    ref = F.group_norm(xr, 32, wr, br, 1e-5)
+    pre = ref.detach()
+    if relu:
+        ref = F.relu(ref)
+    ref.backward(dy.float())
+    out_tol = 2 ** -8 if dtype == torch.bfloat16 else 2e-5
+    for name, a, r in zip(("y", "dx", "dw", "db"), got, (ref.detach(), xr.grad, wr.grad, br.grad)):
+        tol = out_tol * (8 if name in ("dw", "db") else 1)            # sums over N * HW pixels, rounded once (bf16 parameters)
+        if relu and name == "dx":
+            near = pre.abs() < 1e-3                                    # elements whose mask may round the other way
+            a, r = a.masked_fill(near, 0.0), r.masked_fill(near, 0.0)
+            tol *= 4
+        assert (a - r).abs().max().item() <= tol * max(1.0, r.abs().max().item()), name
+
+
+def test_training_step_with_the_group_norm_kernel_matches_default():
+    import bench
+    from model_init import disable_dropout_
+    dev = torch.device("cuda", 0)
+    traj = {}
+    try:
+        for names in ((), ("MDETR_GROUP_NORM",)):
+            step = bench.TrainStep(dev, 2, "bf16", size=(96, 320), switches=names)
+            disable_dropout_(step.raw_model)
+            traj[names] = [float(step()) for _ in range(3)]
+    finally:
+        bench.apply_switches(set())
+    for a, b in zip(traj[()], traj[("MDETR_GROUP_NORM",)]):
+        assert abs(a - b) <= 2e-2 * abs(a), traj

@@ -1,0 +1,61 @@
+"""bench.py's default launch mode: the training iteration replayed from hipGraphs -- one graph on a single GPU, two (forward
++ backward | optimizer step) around the eager gradient all-reduce on the N > 1 path -- trains like the eagerly launched
+iteration: same kernels, same order, same static inputs, so the loss sequences agree step by step."""
+import os
+
+import pytest
+import torch
+
+import bench
+from model_init import disable_dropout_
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("sync", [None, "flat"])
+def test_graph_replay_trains_like_eager_launches(sync):
+    dev = torch.device("cuda", 0)
+    switches = bench.committed_switches("bf16")[0]
+
+    def process_group():                                 # the N > 1 code path with one rank: RCCL process group, flat all-reduce
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        seqs, finals = {}, {}
+        for mode in ("graph", "eager", "eager-again"):   # (one process group for all three: created after the capture)
+            step = bench.TrainStep(dev, 2, "bf16", switches=switches, graph=True, ddp=sync or False)   # (capturable optimizer in all)
+            disable_dropout_(step.raw_model)
+            if mode == "graph":
+                step.capture()                           # three eager iterations, then the capture -- BEFORE the process group exists
+                assert step.graph is not None and (step.graph_opt is not None) == bool(sync)
+                if sync:
+                    process_group()
+                    assert step.attach_process_group().startswith("two hipGraph replays") and step.grad_sync._static is not None
+            else:
+                assert (step.grad_sync is not None) == bool(sync)
+                for _ in range(3):
+                    step()
+            seqs[mode] = [float(step().clone()) for _ in range(6)]
+            torch.cuda.synchronize()
+            finals[mode] = {n: p.detach().float().clone() for n, p in step.raw_model.named_parameters()
+                            if n in ("class_embed.2.bias", "depthaware_transformer.encoder.layers.0.linear1.weight", "backbone.0.body.layer4.2.conv3.weight")}
+            del step
+            torch.cuda.empty_cache()
+        e, e2, g = seqs["eager"], seqs["eager-again"], seqs["graph"]
+        assert all(torch.isfinite(torch.tensor(g)))
+        # the yardstick: two eager runs of the same program (fp32 atomics in a few framework kernels, amplified by the first
+        # Adam steps, whose update is ~ sign(g)); the replayed graph must not be further from an eager run than a small
+        # multiple of that
+        spread = max(abs(a - b) / abs(a) for a, b in zip(e, e2))
+        dist = max(abs(a - b) / abs(a) for a, b in zip(e, g))
+        print("eager", e, "\neager again", e2, "\ngraph", g, "\nspread %.3g, graph-to-eager %.3g" % (spread, dist))
+        assert dist <= max(4.0 * spread, 5e-3), (e, e2, g)
+        assert g[-1] < g[0]                                              # and it does train
+        for n in finals["eager"]:
+            a, b, c = finals["eager"][n], finals["graph"][n], finals["eager-again"][n]
+            assert (a - b).norm() <= max(4.0 * (a - c).norm(), 1e-3 * a.norm()), n
+    finally:
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()

@@ -285,16 +285,59 @@ def test_fused_backward_non_finite_gradients_and_workspace_reuse(monkeypatch):
         assert close(gv, rv, 1e-5) and close(gl, rl, 1e-6) and close(ga, ra, 1e-6), (B, Lq)
 
 
-@pytest.mark.parametrize("threads,groups", [(512, 8), (1024, 4)])
-def test_fused_backward_kernel_variants(monkeypatch, threads, groups):
-    """The launch variants behind MDETR_MSDA_THREADS / MDETR_MSDA_GROUPS (16-wave workgroups; 8 sample groups in flight -- the
-    bf16 form only: the fp32 call below runs the 4-group kernel)."""
-    _fused_env(monkeypatch, 4, 8, 2, 30, 3)
+def _bwd_bf16(p, vb, gb):
+    L = native_emul.lib()
+    B, S, M, _ = p["value"].shape
+    Lq = p["loc"].shape[1]
+    gv, gl, ga = torch.full((B, S, M, 32), 9.0), torch.full_like(p["loc"], 7.0), torch.full_like(p["attn"], 5.0)
+    n = L.mdetr_msda_backward_workspace_bytes(0, p["shapes"].data_ptr(), p["level_start"].data_ptr(), B, S, M, 32, 4, Lq, 4)
+    assert n > 0
+    ws = torch.randint(0, 255, (n,), dtype=torch.uint8)
+    _check(L.mdetr_msda_backward_bf16(vb.data_ptr(), p["shapes"].data_ptr(), p["level_start"].data_ptr(), p["loc"].data_ptr(),
+                                      p["attn"].data_ptr(), gb.data_ptr(), gv.data_ptr(), gl.data_ptr(), ga.data_ptr(),
+                                      B, S, M, 32, 4, Lq, 4, p["shapes"].data_ptr(), p["level_start"].data_ptr(), ws.data_ptr(), n, 0, None))
+    return gv, gl, ga
+
+
+@pytest.mark.parametrize("threads,lps,groups", [(512, 8, 2), (1024, 8, 2), (1024, 4, 2), (768, 4, 2), (768, 4, 4)])
+@pytest.mark.parametrize("th,tw,reach,whole,chunks", [(4, 8, 2, 30, 3), (3, 5, 1, 0, 1)])
+def test_fused_backward_kernel_variants(monkeypatch, threads, lps, groups, th, tw, reach, whole, chunks):
+    """The launch variants behind MDETR_MSDA_THREADS / MDETR_MSDA_LPS / MDETR_MSDA_GROUPS (8-, 12- or 16-wave workgroups; 8 lanes x 4 channels or 4 lanes
+    x 8 channels per sample, the latter with the packed-bf16 dot products): the bf16 form against the fp32 form on the same
+    (widened) tensors and against the oracle, on plans that use tiles with candidates, whole-level chunks, scan-all tiles and
+    the `far` buffer (whose fp32 atomics make grad_value depend on the order of the waves: not bit-equal across variants here;
+    the integer-accumulated part is, see test_emulated_bf16_kernels_match_the_fp32_kernels_on_widened_tensors)."""
+    _fused_env(monkeypatch, th, tw, reach, whole, chunks)
     monkeypatch.setenv("MDETR_MSDA_THREADS", str(threads))
+    monkeypatch.setenv("MDETR_MSDA_LPS", str(lps))
     monkeypatch.setenv("MDETR_MSDA_GROUPS", str(groups))
     S = sum(h * w for h, w in SMALL)
     for Lq in (S, 50):
         p = make_problem(2, 2, 32, Lq, SMALL, 4, torch.float32, seed=3, lo=-0.2, hi=1.2)
-        gv, gl, ga = bwd(p, path="fused")
-        rv, rl, ra = _oracle_bwd(p)
+        vb, gb = (p["value"] * 100).to(torch.bfloat16), p["grad_out"].to(torch.bfloat16)
+        wide = dict(p, value=vb.float(), grad_out=gb.float())
+        gv, gl, ga = _bwd_bf16(p, vb, gb)
+        fv, fl, fa = bwd(wide, path="fused")
+        assert close(gv, fv, 1e-6) and close(gl, fl, 1e-6) and close(ga, fa, 1e-6)
+        rv, rl, ra = _oracle_bwd(wide)
         assert close(gv, rv, 1e-5) and close(gl, rl, 1e-6) and close(ga, ra, 1e-6)
+
+
+@pytest.mark.parametrize("lps", [4, 8])
+def test_fused_backward_bf16_lane_layouts_agree_bit_for_bit_on_near_samples(monkeypatch, lps):
+    """Near samples only (no fp32 atomics anywhere): tiles with candidate queries, bf16 operands, either lane layout and
+    16-wave workgroups -- grad_value equals the fp32 form's on the widened tensors bit for bit."""
+    S = sum(h * w for h, w in SMALL)
+    p = make_problem(2, 2, 32, S, SMALL, 4, torch.float32, seed=11)
+    ref = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij"), -1).reshape(-1, 2)
+                     for h, w in SMALL])[:, [1, 0]]
+    off = (torch.rand(2, S, 2, 4, 4, 2, generator=torch.Generator().manual_seed(2)) * 2 - 1) * 1.4
+    sizes = torch.tensor([[w, h] for h, w in SMALL], dtype=torch.float32).view(1, 1, 1, 4, 1, 2)
+    p["loc"] = (ref.view(1, S, 1, 1, 1, 2) + off / sizes).contiguous()
+    vb, gb = (p["value"] * 100).to(torch.bfloat16), p["grad_out"].to(torch.bfloat16)
+    wide = dict(p, value=vb.float(), grad_out=gb.float())
+    _fused_env(monkeypatch, 4, 8, 3, 30, 3)
+    monkeypatch.setenv("MDETR_MSDA_LPS", str(lps))
+    gv, gl, ga = _bwd_bf16(p, vb, gb)
+    fv, fl, fa = bwd(wide, path="fused")
+    assert torch.equal(gv, fv) and close(gl, fl, 1e-6) and close(ga, fa, 1e-6)

@@ -1,6 +1,7 @@
 """tools/switchprobe (the tool that times optional kernel families against each other; NOT part of bench.py's measured
 command any more) -- host logic only: candidate sets, the admissibility rule against the default path's deterministic
 losses, the choice, caching -- and bench.py's own bookkeeping: the committed switch list and the JSON line."""
+import contextlib
 import json
 import os
 import types
@@ -60,7 +61,7 @@ def test_autotune_runs_one_probe_caches_per_box_and_reports(tmp_path):
         return [{"switches": sorted(c), "losses": [30.0, 29.0, 28.0], "ms": 38.0 - 1.5 * len(c)} for c in configs]
     cache = str(tmp_path / "tune.json")
     chosen, report = sp.autotune(args(), 1, 0, runner=runner, cache_path=cache)
-    assert chosen == sorted(bench.AUTOTUNE_SWITCHES) and report["source"] == "probe" and len(report["candidates"]) == 11 and calls[0][0] == calls[0][-1] == []
+    assert chosen == sorted(bench.AUTOTUNE_SWITCHES) and report["source"] == "probe" and len(report["candidates"]) == len(bench.AUTOTUNE_SWITCHES) + 2 and calls[0][0] == calls[0][-1] == []
     chosen2, report2 = sp.autotune(args(), 1, 0, runner=runner, cache_path=cache)
     assert chosen2 == chosen and report2["source"] == "cache" and len(calls) == 1
     # N > 1: the N = 1 run's decision if it is there ...
@@ -197,12 +198,23 @@ def test_bench_main_composes_its_json_line(monkeypatch, capsys):
         def __call__(self):
             return torch.tensor(1.5)
 
+        _step = eager_iteration = __call__
+        graph = graph_opt = stream = None
+
+        def try_capture(self):
+            self.graph = object()
+            return "one hipGraph replay per iteration"
+
+        def attach_process_group(self):
+            return "two hipGraph replays per iteration (forward + backward | optimizer) around the eager RCCL gradient all-reduce"
+
     def no_topology(i):
         raise AttributeError
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a: None)
     monkeypatch.setattr(torch.cuda, "empty_cache", lambda: None)
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
     monkeypatch.setattr(torch.cuda, "get_device_properties", no_topology)
     monkeypatch.setattr(torch.distributed, "init_process_group", lambda *a, **k: None)
     monkeypatch.setattr(torch.distributed, "destroy_process_group", lambda *a, **k: None)
@@ -211,7 +223,7 @@ def test_bench_main_composes_its_json_line(monkeypatch, capsys):
     monkeypatch.setattr(_capi, "profile_read", lambda: [(0, 10200, 3, 0.7), (1, 10200, 3, 3.0), (2, 10200, 3, 2.1), (3, 10200, 3, 0.3),
                                                         (1, 550, 3, 0.6), (4, 1920 * 4096 + 1920, 3, 0.4)])
     monkeypatch.setattr(bench, "TrainStep", Step)
-    for env, argv in (({}, []), ({"MDETR_BENCH_DEFAULT_PATH": "1"}, []), ({}, ["--config", "2"]), ({}, ["--config", "5"])):
+    for env, argv in (({}, []), ({"MDETR_BENCH_DEFAULT_PATH": "1"}, []), ({}, ["--config", "2"]), ({}, ["--config", "5"]), ({}, ["--graph", "off"])):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         del built[:]
@@ -222,6 +234,11 @@ def test_bench_main_composes_its_json_line(monkeypatch, capsys):
         assert "autotune" not in line["config"] and line["vs_baseline"] is None
         roof = line["roofline"]
         assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / 8000.0) < 1e-3
+        if argv == ["--graph", "off"]:
+            assert line["config"]["launch"] == "eager" and "eager_path" not in line and not built[0][1]["graph"]
+            assert roof["timing"].endswith("of the timed steps") and line["fp32_path"]["launch"] == "eager"
+            continue
+        assert line["config"]["launch"].startswith("one hipGraph replay") and built[0][1]["graph"] and "right after the timed graph replays" in roof["timing"]
         if argv == ["--config", "2"]:
             assert line["dtype"] == "f32" and line["config"]["baseline_config"] == 2 and built[0][1]["part"] == "encoder"
             assert line["config"]["switches"] == sorted(bench.COMMITTED_SWITCHES["fp32"]) and "fp32_path" not in line
@@ -235,7 +252,9 @@ def test_bench_main_composes_its_json_line(monkeypatch, capsys):
             assert line["config"]["switches"] == sorted(bench.COMMITTED_SWITCHES["bf16"]) and line["config"]["switch_source"] == "bench.COMMITTED_SWITCHES"
             assert line["default_path"]["value"] > 0 and line["default_path"]["switches"] == [] and line["default_path"]["steps"] == 20
             assert line["fp32_path"]["precision"] == "fp32" and line["fp32_path"]["switches"] == sorted(bench.COMMITTED_SWITCHES["fp32"])
-            assert line["rccl_1rank"]["value"] > 0 and built[-1][1]["ddp"] == "flat"
+            assert line["rccl_1rank"]["value"] > 0 and built[-1][1]["ddp"] == "flat" and built[-1][1]["graph"] and line["rccl_1rank"]["launch"].startswith("two hipGraph")
+            assert line["eager_path"]["launch"] == "eager" and line["eager_path"]["switches"] == line["config"]["switches"]
+            assert line["fp32_path"]["launch"].startswith("one hipGraph") and line["default_path"]["launch"] == "eager"
             assert roof["algorithmic_bytes"] == 417800000         # bf16 value / out / grad_out
         for k in env:
             monkeypatch.delenv(k)
