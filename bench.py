@@ -104,7 +104,7 @@ def synthetic_batch(B, H, W, seed, device):
 # with the COMMITTED list below.  (MDETR_MSDA_BF16 changes the MSDA operator's element types; the roofline accounting
 # follows it: msda_algorithmic_bytes(mixed=True).)
 AUTOTUNE_SWITCHES = ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN", "MDETR_MSDA_BF16", "MDETR_TOKEN_GEMM",
-                     "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM")
+                     "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD")
 ALL_SWITCHES = AUTOTUNE_SWITCHES
 # The measured configuration.  family -> the GPU tests that hold it to the default path / the framework operators
 # (all in tests/test_fused_gpu.py unless a file is named); a family without green tests is not listed.
@@ -116,17 +116,19 @@ SWITCH_TESTS = {
     "MDETR_MSDA_BF16": "test_msda_bf16_kernels_*, test_msda_function_with_native_bf16_*, test_training_step_with_bf16_msda_*, test_msda_gpu.py::test_bf16_native_full_encoder_shape_vs_oracle",
     "MDETR_FUSED_EPILOGUE": "test_bias_act_kernel_*, test_training_step_with_fused_tails_*",
     "MDETR_GEMM_RELU": "test_library_gemm_relu_epilogue_*, test_training_step_with_fused_tails_*",
+    "MDETR_SMALL_WGRAD": "test_small_wgrad_kernel_*, test_training_step_with_the_small_wgrad_kernel_*",
     "MDETR_GROUP_NORM": "test_group_norm_kernel_*, test_training_step_with_the_group_norm_kernel_*",
     "MDETR_CONV3X3": "test_conv3x3_kernel_matches_the_library_convolution, test_training_step_with_the_conv3x3_kernel_*, test_conv3x3_module_with_a_trainable_bias_*",
 }
 COMMITTED_SWITCHES = {
     # (MDETR_CONV3X3: 1.6-3.5x MIOpen per kernel on the four ResNet stages, profiles/r02a_fusedbench.json; the step 249.3 vs
     # 234.6 img/s, profiles/r02b_bench_committed_plus_conv3x3.json.  MDETR_TOKEN_GEMM stays off: slower than hipBLASLt.
-    # MDETR_GROUP_NORM: 328.9 vs 308.7 img/s under graph replay, profiles/r02m_bench_with_gn.json.)
+    # MDETR_GROUP_NORM: 328.9 vs 308.7 img/s under graph replay, profiles/r02m_bench_with_gn.json.
+    # MDETR_SMALL_WGRAD: 340.2 vs 333.6 img/s, profiles/r02q_bench_{with_small_wgrad,committed}.json.)
     "bf16": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE", "MDETR_MSDA_BF16",
-             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM"),
+             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD"),
     "fp32": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE",
-             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_GROUP_NORM"),
+             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD"),
 }
 COMMITTED_SWITCHES["bf16-autocast"] = COMMITTED_SWITCHES["fp32"]
 
@@ -146,7 +148,7 @@ def env_switches():
 def apply_switches(names):
     """Runtime equivalent of the environment switches for the module-level ones (the criterion's and the optimizer's
     are applied by TrainStep)."""
-    from monodetr_amd import add_ln_ext, bias_act_ext, conv3x3_ext, group_norm_ext
+    from monodetr_amd import add_ln_ext, bias_act_ext, conv3x3_ext, group_norm_ext, small_wgrad_ext
     from monodetr_amd.monodetr import linear
     from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func
     from monodetr_amd.monodetr.ops.modules import ms_deform_attn
@@ -157,6 +159,7 @@ def apply_switches(names):
     bias_act_ext.ENABLED = "MDETR_FUSED_EPILOGUE" in names
     conv3x3_ext.ENABLED = "MDETR_CONV3X3" in names
     group_norm_ext.ENABLED = "MDETR_GROUP_NORM" in names
+    small_wgrad_ext.ENABLED = "MDETR_SMALL_WGRAD" in names
     ms_deform_attn_func._NATIVE_BF16 = "MDETR_MSDA_BF16" in names
 
 

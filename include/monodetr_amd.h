@@ -460,6 +460,19 @@ int mdetr_bias_act_backward(int io_dtype, const void *dy, const void *y, void *d
                             int device, void *stream);
 
 /*
+ * Weight and bias gradient of a linear layer y = x W^T + b over a few thousand token rows (the decoder's B x 550 query rows;
+ * reference depthaware_transformer.py:399-456, monodetr.py:222-262): dW[n, k] = sum_t dY[t, n] X[t, k], db[n] = sum_t dY[t, n]
+ * in one launch plus one chunk sum (deterministic, fp32 accumulation, one rounding into out_dtype).
+ *   dy [rows, n] (row stride ldy), x [rows, k] (row stride ldx): io_dtype MDETR_F32 / MDETR_BF16, 16-byte aligned, strides
+ *   multiples of 8 elements; rows <= 8 192; n, k multiples of 64 with n * k <= 131 072
+ *   out [n * k + n] in out_dtype: dW row-major, then db.  workspace: mdetr_small_wgrad_workspace_bytes(rows, n, k) bytes
+ *   (0 = shape not supported)
+ */
+int64_t mdetr_small_wgrad_workspace_bytes(int64_t rows, int n, int k);
+int mdetr_small_wgrad(int io_dtype, const void *dy, const void *x, void *out, int out_dtype, void *workspace, int64_t workspace_bytes,
+                      int64_t rows, int n, int k, int64_t ldy, int64_t ldx, int device, void *stream);
+
+/*
  * GroupNorm (+ ReLU) of a channels-last activation with 8 channels per group -- nn.GroupNorm(32, 256) after every input
  * projection (lib/models/monodetr/monodetr.py:77-99) and in the depth predictor's conv + GN (+ ReLU) stages
  * (depth_predictor/depth_predictor.py:30-56).  x, y, dy, dx: [n, hw, c] (NCHW tensors in channels_last memory format),

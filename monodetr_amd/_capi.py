@@ -50,6 +50,8 @@ SIGNATURES = {
     "mdetr_add_layernorm_partial_rows": (ctypes.c_int64, [ctypes.c_int64]),
     "mdetr_add_layernorm_backward": (_c_int, [_c_int, _c_int] + [_c_vp] * 7 + [ctypes.c_int64, _c_int, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),
     "mdetr_conv3x3_forward": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_int, _c_vp]),
+    "mdetr_small_wgrad_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, _c_int, _c_int]),
+    "mdetr_small_wgrad": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, ctypes.c_int64, ctypes.c_int64, _c_int, _c_int, ctypes.c_int64, ctypes.c_int64, _c_int, _c_vp]),
     "mdetr_group_norm_workspace_bytes": (ctypes.c_int64, [_c_int, ctypes.c_int64, _c_int, _c_int]),
     "mdetr_group_norm_forward": (_c_int, [_c_int, _c_int] + [_c_vp] * 6 + [ctypes.c_int64, _c_int, ctypes.c_int64, _c_int, _c_int, ctypes.c_float, _c_int, _c_int, _c_vp]),
     "mdetr_group_norm_backward": (_c_int, [_c_int, _c_int] + [_c_vp] * 8 + [ctypes.c_int64, _c_int, ctypes.c_int64, _c_int, _c_int, _c_int, _c_int, _c_vp]),

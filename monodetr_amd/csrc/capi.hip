@@ -17,6 +17,7 @@
 #include "bias_act.h"
 #include "colsum.h"
 #include "group_norm.h"
+#include "small_wgrad.h"
 #include "conv3x3.h"
 #include "ddn_loss.h"
 #include "kitti_prep.h"
@@ -539,6 +540,28 @@ int mdetr_bias_act_backward(int io_dtype, const void *dy, const void *y, void *d
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_bias_act_backward: set device %d: %s", device, hipGetErrorString(dev.err));
     const hipError_t e = mdetr::bias_act_backward_launch(io_dtype, dy, y, dx, rows, cols, scale, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_bias_act_backward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int64_t mdetr_small_wgrad_workspace_bytes(int64_t rows, int n, int k) { return mdetr::small_wgrad_workspace_bytes(rows, n, k); }
+
+int mdetr_small_wgrad(int io_dtype, const void *dy, const void *x, void *out, int out_dtype, void *workspace, int64_t workspace_bytes,
+                      int64_t rows, int n, int k, int64_t ldy, int64_t ldx, int device, void *stream)
+{
+    if (!mdetr::small_wgrad_supported(io_dtype, rows, n, k, ldy, ldx) || (out_dtype != MDETR_F32 && out_dtype != MDETR_BF16))
+        return fail(MDETR_E_ARG, "mdetr_small_wgrad: io_dtype %d / out_dtype %d / rows %lld / n %d / k %d / ldy %lld / ldx %lld (f32 or bf16; 1 <= rows <= 8192; "
+                                 "n, k multiples of 64 with n * k <= 131072; strides multiples of 8 elements)", io_dtype, out_dtype,
+                    static_cast<long long>(rows), n, k, static_cast<long long>(ldy), static_cast<long long>(ldx));
+    if (!dy || !x || !out || !workspace) return fail(MDETR_E_ARG, "mdetr_small_wgrad: null pointer");
+    if (workspace_bytes < mdetr::small_wgrad_workspace_bytes(rows, n, k))
+        return fail(MDETR_E_ARG, "mdetr_small_wgrad: workspace of %lld bytes, need %lld", static_cast<long long>(workspace_bytes),
+                    static_cast<long long>(mdetr::small_wgrad_workspace_bytes(rows, n, k)));
+    if (!aligned16(dy) || !aligned16(x) || !aligned16(out) || !aligned16(workspace))
+        return fail(MDETR_E_ALIGN, "mdetr_small_wgrad: dy, x, out, workspace must be 16-byte aligned");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_small_wgrad: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::small_wgrad_launch(io_dtype, dy, x, out, workspace, rows, n, k, ldy, ldx, out_dtype, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_small_wgrad: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

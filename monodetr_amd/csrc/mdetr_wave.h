@@ -21,6 +21,7 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c)
 // channels; the plain-float spelling compiles to two scalar FMAs)
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;      // 16 bytes as one register quad (arrays of it stay in registers)
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 __device__ __forceinline__ f32x2 make_f32x2(float x, float y) { f32x2 r; r.x = x; r.y = y; return r; }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 mul2(f32x2 a, f32x2 b) { return a * b; }

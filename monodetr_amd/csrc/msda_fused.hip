@@ -772,10 +772,11 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
     const bool self = Lq == S;                               // queries = the pyramid's cells, in order
     if (!self && static_cast<int64_t>(Lq) * P > 16384) return false;   // every block scans every query: only for few queries
     // tuning knobs (read per call: a handful of getenv()s against a multi-microsecond launch sequence).  Defaults from the
-    // sweep on MI355X at the encoder shape (profiles/r02f_opbench_*.json): 16 x 40 core tiles, reach 5 cells (the model's
-    // initial offsets reach 4 px on every level), whole-level windows up to 512 cells split into 12 query chunks.
-    // (the fp32 form runs 8 waves per workgroup and prefers bigger tiles: 24 x 40, 0.88 ms vs 0.95 at 16 x 32)
-    const int tile_h = env_int("MDETR_MSDA_TILE_H", elem_dtype == 2 ? 16 : 24), tile_w = env_int("MDETR_MSDA_TILE_W", 40);
+    // sweeps on MI355X at the encoder shape (profiles/r02f_opbench_*.json, r02o_): 24 x 32 core tiles (bf16, 16 waves: 0.545 ms
+    // vs 0.557 at 16 x 40, and 0.72 vs 0.82 for N(0, 4 px) offsets), reach 5 cells (the model's initial offsets reach 4 px on
+    // every level), whole-level windows up to 512 cells split into 12 query chunks.
+    // (the fp32 form runs 8 waves per workgroup: 24 x 40, 0.88 ms vs 0.95 at 16 x 32)
+    const int tile_h = env_int("MDETR_MSDA_TILE_H", 24), tile_w = env_int("MDETR_MSDA_TILE_W", elem_dtype == 2 ? 32 : 40);
     const int reach = env_int("MDETR_MSDA_REACH", 5), chunks_env = env_int("MDETR_MSDA_CHUNKS", 12);
     const int whole_max = env_int("MDETR_MSDA_WHOLE_LEVEL_CELLS", 512);
     if (tile_h < 1 || tile_w < 1 || tile_h * tile_w > kMaxCells || reach < 0 || chunks_env < 1) return false;

@@ -91,11 +91,13 @@ class DepthPredictor(nn.Module):
         weighted_depth = (F.softmax(at_least_fp32(depth_logits), dim=1) * at_least_fp32(self.depth_bin_values).reshape(1, -1, 1, 1)).sum(dim=1)
 
         B, C, H, W = src.shape
-        tokens = src.flatten(2).permute(2, 0, 1)
+        # the depth encoder batch-first: [B, HW, C] IS the channels-last map (a view), and so is its output -- the reference's
+        # sequence-first (HW, B, C) layout (depth_predictor.py:63-68) costs a layout copy per projection here
+        tokens = src.permute(0, 2, 3, 1).reshape(B, H * W, C)
         key_mask = None if no_padding(mask) else mask.flatten(1)
-        enc = self.depth_encoder(tokens, key_mask, pos.flatten(2).permute(2, 0, 1).to(tokens.dtype))
+        enc = self.depth_encoder.forward_batch_first(tokens, key_mask, pos.permute(0, 2, 3, 1).reshape(B, H * W, C).to(tokens.dtype))
         depth_pos_embed_ip = self.interpolate_depth_embed(weighted_depth).to(src.dtype)
-        depth_embed = enc.permute(1, 2, 0).reshape(B, C, H, W) + depth_pos_embed_ip
+        depth_embed = enc.view(B, H, W, C).permute(0, 3, 1, 2) + depth_pos_embed_ip
         return depth_logits, depth_embed, weighted_depth, depth_pos_embed_ip
 
     def interpolate_depth_embed(self, depth):

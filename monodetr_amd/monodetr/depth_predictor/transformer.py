@@ -43,6 +43,15 @@ class TransformerEncoderLayer(nn.Module):
         return residual_layernorm(src, ff, self.norm2, self.dropout2)
 
 
+    def forward_batch_first(self, src, src_key_padding_mask, pos):
+        """The same layer on [B, L, E] tensors (what a channels-last feature map is without any copy)."""
+        qk = src if pos is None else src + pos
+        attn = self.self_attn.forward_batch_first(qk, qk, src, key_padding_mask=src_key_padding_mask)
+        src = residual_layernorm(src, attn, self.norm1, self.dropout1)
+        ff = self.linear2(ffn_hidden(src, self.linear1, self.dropout, self.activation, tokenwise=False))
+        return residual_layernorm(src, ff, self.norm2, self.dropout2)
+
+
 class TransformerEncoder(nn.Module):
     def __init__(self, encoder_layer, num_layers, norm=None):
         super().__init__()
@@ -53,4 +62,9 @@ class TransformerEncoder(nn.Module):
     def forward(self, src, src_key_padding_mask, pos):
         for layer in self.layers:
             src = layer(src, src_key_padding_mask=src_key_padding_mask, pos=pos)
+        return src if self.norm is None else self.norm(src)
+
+    def forward_batch_first(self, src, src_key_padding_mask, pos):
+        for layer in self.layers:
+            src = layer.forward_batch_first(src, src_key_padding_mask, pos)
         return src if self.norm is None else self.norm(src)

@@ -238,7 +238,7 @@ class DepthAwareDecoderLayer(nn.Module):
         bq = self.sa_qcontent_proj.bias + self.sa_qpos_proj.bias
         wk = self.sa_kcontent_proj.weight + self.sa_kpos_proj.weight
         bk = self.sa_kcontent_proj.bias + self.sa_kpos_proj.bias
-        q, k = F.linear(x, torch.cat((wq, wk), 0), torch.cat((bq, bk), 0)).split(x.shape[-1], -1)
+        q, k = token_linear(x, torch.cat((wq, wk), 0), torch.cat((bq, bk), 0)).split(x.shape[-1], -1)
         return q, k
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,

@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .. import colsum_ext
+from .. import colsum_ext, small_wgrad_ext
 
 _MIN_TOKENS = 4096
 # MDETR_TOKEN_GEMM=1: forward and input-gradient products of K in {64, 128, 256, 512} bf16 layers through the
@@ -83,6 +83,11 @@ class _TokenLinear(torch.autograd.Function):
             if dx is None:
                 dx = (dy2 @ weight).view_as(x)
         T = x2.shape[0]
+        if small_wgrad_ext.ENABLED and ctx.needs_input_grad[1] and T <= small_wgrad_ext.MAX_ROWS \
+                and weight.dtype in (torch.float32, torch.bfloat16) and small_wgrad_ext.supported(dy2, x2):
+            # a few thousand rows (the decoder's 4 400): dW and db from one launch + one chunk sum (csrc/small_wgrad.hip)
+            dw, db = small_wgrad_ext.small_wgrad(dy2, x2, weight.dtype)
+            return dx, dw, (db if ctx.has_bias and ctx.needs_input_grad[2] else None), None
         C = _split_count(T)
         if ctx.needs_input_grad[1]:
             if C:

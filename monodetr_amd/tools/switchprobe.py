@@ -28,11 +28,11 @@ def probe_configs(precision):
     """Candidate switch sets, nested and growing by ONE kernel family per level, so that a family which faults or
     disagrees costs only itself and what is stacked on top of it: the default path; + the fused criterion; + the flat
     AdamW; + the residual LayerNorm kernel; + the MSDA prologue; + the bf16-native MSDA (bf16 body only); + the fused
-    convolution / FFN tails; + ReLU in the library GEMM's epilogue; + the channels-last GroupNorm; + the 3x3 convolution and the token GEMM (bf16 only; the
+    convolution / FFN tails; + ReLU in the library GEMM's epilogue; + the channels-last GroupNorm; + the small-T weight gradient; + the 3x3 convolution and the token GEMM (bf16 only; the
     candidates that replace tuned library kernels and may well be slower).  The fullest set runs last so that a crash in it
     loses nothing."""
     order = ["MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE", "MDETR_MSDA_BF16",
-             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_GROUP_NORM", "MDETR_CONV3X3", "MDETR_TOKEN_GEMM"]
+             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD", "MDETR_CONV3X3", "MDETR_TOKEN_GEMM"]
     if precision != "bf16":
         order = [k for k in order if k not in ("MDETR_MSDA_BF16", "MDETR_CONV3X3", "MDETR_TOKEN_GEMM")]
     return [order[:i] for i in range(len(order) + 1)]

@@ -55,6 +55,7 @@ inline f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c)
 // two packed fp32 lanes (the real header: ext_vector_type(2) -> v_pk_fma_f32 / v_pk_mul_f32)
 struct f32x2 { float x, y; };
 struct alignas(16) f32x4 { float x, y, z, w; };
+struct alignas(16) u32x4 { unsigned x, y, z, w; };
 inline f32x2 make_f32x2(float x, float y) { return {x, y}; }
 inline f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
 inline f32x2 mul2(f32x2 a, f32x2 b) { return {a.x * b.x, a.y * b.y}; }

@@ -749,3 +749,34 @@ def test_training_step_with_the_group_norm_kernel_matches_default():
         bench.apply_switches(set())
     for a, b in zip(traj[()], traj[("MDETR_GROUP_NORM",)]):
         assert abs(a - b) <= 2e-2 * abs(a), traj
+
+
+# ---- weight / bias gradient over a few thousand token rows (csrc/small_wgrad.hip) -------------------------------------------
+@pytest.mark.parametrize("T,N,K,dtype", [(4400, 256, 256, torch.bfloat16), (4400, 512, 256, torch.bfloat16), (4400, 128, 256, torch.bfloat16),
+                                         (4400, 256, 256, torch.float32), (8192, 256, 256, torch.bfloat16), (130, 64, 64, torch.bfloat16)])
+def test_small_wgrad_kernel_matches_the_library_products(T, N, K, dtype):
+    from monodetr_amd import small_wgrad_ext
+    g = torch.Generator(device="cuda").manual_seed(T + N + K)
+    dy, x = torch.randn(T, N, device="cuda", generator=g).to(dtype), torch.randn(T, K, device="cuda", generator=g).to(dtype)
+    dw, db = small_wgrad_ext.small_wgrad(dy, x, dtype)
+    rw, rb = dy.double().t() @ x.double(), dy.double().sum(0)
+    tol = 2 ** -8 if dtype == torch.bfloat16 else 1e-5
+    assert (dw.double() - rw).abs().max() <= tol * rw.abs().max() and (db.double() - rb).abs().max() <= tol * max(1.0, rb.abs().max().item())
+    dw2, db2 = small_wgrad_ext.small_wgrad(dy, x, dtype)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)                    # fixed summation order: deterministic
+
+
+def test_training_step_with_the_small_wgrad_kernel_matches_default():
+    import bench
+    from model_init import disable_dropout_
+    dev = torch.device("cuda", 0)
+    traj = {}
+    try:
+        for names in ((), ("MDETR_SMALL_WGRAD",)):
+            step = bench.TrainStep(dev, 8, "bf16", size=(96, 320), switches=names)      # B = 8: 4 400 decoder rows, the kernel's case
+            disable_dropout_(step.raw_model)
+            traj[names] = [float(step()) for _ in range(3)]
+    finally:
+        bench.apply_switches(set())
+    for a, b in zip(traj[()], traj[("MDETR_SMALL_WGRAD",)]):
+        assert abs(a - b) <= 2e-2 * abs(a), traj
