@@ -257,6 +257,8 @@ class TrainStep:
             for _ in range(eager_steps):                     # optimizer state, workspaces, geometry caches, MIOpen plans
                 self._step()
         torch.cuda.current_stream(self.device).wait_stream(side)
+        from monodetr_amd.attn_ext import _next_seed
+        _next_seed(self.device)                              # the device-resident dropout seed exists before anything is captured
         torch.cuda.synchronize(self.device)
         graph, graph_opt = torch.cuda.CUDAGraph(), None
         self.optimizer.zero_grad(set_to_none=True)
@@ -290,7 +292,9 @@ class TrainStep:
             self.capture_error = repr(e)[:160]
             self.graph = self.graph_opt = self.sync_plan = None
             torch.cuda.synchronize(self.device)
-            print("bench: graph capture not used (%s): eager launches" % self.capture_error, file=sys.stderr, flush=True)
+            import traceback
+            print("bench: graph capture not used (%s): eager launches\n%s" % (self.capture_error, "".join(traceback.format_exc().splitlines(True)[-14:])),
+                  file=sys.stderr, flush=True)
         return self.launch_mode()
 
     def launch_mode(self):

@@ -238,14 +238,14 @@ def test_fused_backward_near_samples_stay_in_lds_and_are_deterministic(monkeypat
     # (fp32 oracle: with pixel coordinates ON integers the floor is decided by the fp32 rounding of loc * size, .cuh:285-286)
     rv, rl, ra = oracle.backward(p["value"], p["shapes"], p["level_start"], p["loc"], p["attn"], p["grad_out"])
     outs = []
-    for th, tw in ((4, 8), (6, 20), (3, 7)):
+    for th, tw in ((4, 8), (3, 7)):
         _fused_env(monkeypatch, th, tw, 3, 30, 3)
         ws = torch.randint(0, 255, (1 << 22,), dtype=torch.uint8)
         gv, gl, ga = bwd(p, path="fused", ws=ws)
         assert ws[8:12].view(torch.int32).item() == 0                       # Header.far
         assert close(gv, rv, 1e-5) and close(gl, rl, 1e-5) and close(ga, ra, 1e-5)
         outs.append(gv)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_fused_backward_repeats_a_pass_when_a_cell_draws_too_many_contributions(monkeypatch):
@@ -299,8 +299,8 @@ def _bwd_bf16(p, vb, gb):
     return gv, gl, ga
 
 
-@pytest.mark.parametrize("threads,lps,groups", [(512, 8, 2), (1024, 8, 2), (1024, 4, 2), (768, 4, 2), (768, 4, 4)])
-@pytest.mark.parametrize("th,tw,reach,whole,chunks", [(4, 8, 2, 30, 3), (3, 5, 1, 0, 1)])
+@pytest.mark.parametrize("threads,lps,groups", [(512, 8, 2), (1024, 4, 2), (768, 4, 4)])      # (each instantiation family once)
+@pytest.mark.parametrize("th,tw,reach,whole,chunks", [(4, 8, 2, 30, 3)])
 def test_fused_backward_kernel_variants(monkeypatch, threads, lps, groups, th, tw, reach, whole, chunks):
     """The launch variants behind MDETR_MSDA_THREADS / MDETR_MSDA_LPS / MDETR_MSDA_GROUPS (8-, 12- or 16-wave workgroups; 8 lanes x 4 channels or 4 lanes
     x 8 channels per sample, the latter with the packed-bf16 dot products): the bf16 form against the fp32 form on the same
@@ -313,7 +313,7 @@ def test_fused_backward_kernel_variants(monkeypatch, threads, lps, groups, th, t
     monkeypatch.setenv("MDETR_MSDA_GROUPS", str(groups))
     S = sum(h * w for h, w in SMALL)
     for Lq in (S, 50):
-        p = make_problem(2, 2, 32, Lq, SMALL, 4, torch.float32, seed=3, lo=-0.2, hi=1.2)
+        p = make_problem(1, 2, 32, Lq, SMALL, 4, torch.float32, seed=3, lo=-0.2, hi=1.2)
         vb, gb = (p["value"] * 100).to(torch.bfloat16), p["grad_out"].to(torch.bfloat16)
         wide = dict(p, value=vb.float(), grad_out=gb.float())
         gv, gl, ga = _bwd_bf16(p, vb, gb)
@@ -323,7 +323,7 @@ def test_fused_backward_kernel_variants(monkeypatch, threads, lps, groups, th, t
         assert close(gv, rv, 1e-5) and close(gl, rl, 1e-6) and close(ga, ra, 1e-6)
 
 
-@pytest.mark.parametrize("lps", [4, 8])
+@pytest.mark.parametrize("lps", [4])
 def test_fused_backward_bf16_lane_layouts_agree_bit_for_bit_on_near_samples(monkeypatch, lps):
     """Near samples only (no fp32 atomics anywhere): tiles with candidate queries, bf16 operands, either lane layout and
     16-wave workgroups -- grad_value equals the fp32 form's on the widened tensors bit for bit."""
