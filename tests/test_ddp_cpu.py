@@ -25,7 +25,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, port2):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -109,6 +109,19 @@ def _worker(rank, world, port, out_dir):
         a.grad, b.grad = torch.full((5,), float(rank + 1)), torch.full((3, 2), float(2 * rank + 2), dtype=torch.bfloat16)
         FlatGradSync([a, b]).sync()
         mixed_ok = bool((a.grad == (1 + world) / 2).all()) and bool((b.grad.float() == (1 + world)).all())
+        # the graph-replay form (bench.py): gather from REMEMBERED gradient tensors (where a captured backward writes) into
+        # persistent flat buffers; .grad re-pointed at the reduced slices -- channels-last strides preserved
+        c = torch.nn.Parameter(torch.zeros(4, 3, 2, 2).contiguous(memory_format=torch.channels_last))
+        src_a, src_b, src_c = torch.zeros(5), torch.zeros(3, 2, dtype=torch.bfloat16), torch.zeros(4, 3, 2, 2).contiguous(memory_format=torch.channels_last)
+        a.grad, b.grad, c.grad = src_a, src_b, src_c
+        ssync = FlatGradSync([a, b, c]).make_static()
+        static_ok = True
+        for it in range(2):
+            src_a.fill_(float(rank + 1 + it)); src_b.fill_(float(2 * rank + 2)); src_c.copy_(torch.arange(48.).view(4, 3, 2, 2) * (rank + 1))
+            ssync.sync()
+            static_ok = static_ok and bool((a.grad == (1 + world) / 2 + it).all()) and bool((b.grad.float() == (1 + world)).all()) \
+                and torch.equal(c.grad, torch.arange(48.).view(4, 3, 2, 2) * (1 + world) / 2) and c.grad.stride() == c.stride() \
+                and a.grad.data_ptr() != src_a.data_ptr()
         # the overlapped form: discovery iteration (flat), then an iteration whose buckets are reduced from gradient hooks
         from monodetr_amd.helpers.dist_helper import BucketedGradSync
         model, criterion = fresh()
@@ -137,11 +150,26 @@ def _worker(rank, world, port, out_dir):
             gathered = [torch.empty_like(flat) for _ in range(world)]
             dist.all_gather(gathered, flat)
             same_bench[mode] = all(torch.equal(gathered[0], g) for g in gathered[1:])
+        # the step object built BEFORE the process group is attached (bench.py's order under graph replay): rank-dependent
+        # weights on purpose, repaired by attach_process_group's broadcast (parameters and optimizer state)
+        dist.destroy_process_group()
+        step = bench.TrainStep(torch.device("cpu"), 1, "fp32", ddp="flat", local_rank=rank, size=(96, 320), switches=(), seed=444 + rank)
+        deferred_pending = step.pending_sync == "flat" and step.grad_sync is None
+        step()                                                          # optimizer state exists before the broadcast
+        os.environ["MASTER_PORT"] = str(port2)                          # (a fresh port: the first one may still be in TIME_WAIT)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        mode_after = step.attach_process_group()
+        step()
+        flat = torch.cat([p.detach().reshape(-1) for p in step.raw_model.parameters()])
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        same_bench["deferred"] = deferred_pending and mode_after == "eager" and step.grad_sync is not None and \
+            all(torch.equal(gathered[0], g) for g in gathered[1:])
         lists = [None] * world
         dist.all_gather_object(lists, sorted(bench.committed_switches("bf16")[0]))
         same_switches = all(l == lists[0] for l in lists)
         torch.save(dict(worst=worst, same=same, unused=unused, n_grads=len(got), worst_flat=worst_flat, same_flat=same_flat,
-                        mixed_ok=mixed_ok, worst_bucketed=worst_bucketed, n_buckets=n_buckets, same_bench=same_bench,
+                        mixed_ok=mixed_ok, static_ok=static_ok, worst_bucketed=worst_bucketed, n_buckets=n_buckets, same_bench=same_bench,
                         same_switches=same_switches), os.path.join(out_dir, "r%d.pt" % rank))
     finally:
         dist.destroy_process_group()
@@ -149,15 +177,15 @@ def _worker(rank, world, port, out_dir):
 
 @pytest.mark.timeout(600)
 def test_two_rank_ddp_step_matches_manual_gradient_average(tmp_path):
-    world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    world, port, port2 = 2, _free_port(), _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), port2), nprocs=world, join=True)
     for r in range(world):
         res = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
         assert res["same"], "ranks diverged after the optimizer step"
         assert res["worst"] < 1e-4, res["worst"]
-        assert res["same_flat"] and res["worst_flat"] < 1e-4 and res["mixed_ok"], res
+        assert res["same_flat"] and res["worst_flat"] < 1e-4 and res["mixed_ok"] and res["static_ok"], res
         assert res["worst_bucketed"] < 1e-4 and res["n_buckets"] >= 3, res
-        assert res["same_bench"] == {"flat": True, "bucketed": True} and res["same_switches"], res
+        assert res["same_bench"] == {"flat": True, "bucketed": True, "deferred": True} and res["same_switches"], res
         assert res["n_grads"] > 300
         assert all(n.startswith("label_enc") or ".sa_v_proj." in n or "decoder.query_scale" in n or "decoder.ref_point_head" in n
                    for n in res["unused"]), res["unused"]
