@@ -140,6 +140,10 @@ hipError_t colsum_launch(int dtype, const void *x, void *out, void *workspace, i
         const int cvs = cols / vec;
         int CT = 1;
         while (CT * 2 <= cvs && CT * 2 <= kThreads) CT *= 2;
+        // few row blocks and many columns (the chunk sums of a split-K weight gradient: 16 - 69 rows x 65 536 columns, ONE row
+        // block): 256 column vectors per workgroup would leave 32 - 65 workgroups on 256 CUs, each lane walking all rows one
+        // load after the other.  Trade column vectors for row lanes until ~512 workgroups exist (every row lane keeps a row).
+        while (CT > 8 && nblk * ((cvs + CT - 1) / CT) < 512 && kThreads / (CT / 2) <= (rows < kRowsPerBlock ? rows : kRowsPerBlock)) CT /= 2;
         const dim3 grid(static_cast<unsigned>(nblk), static_cast<unsigned>((cvs + CT - 1) / CT));
         if (nblk == 1 && out_dtype == 2) {
             __hip_bfloat16 *o = static_cast<__hip_bfloat16 *>(out);

@@ -88,7 +88,9 @@ class _TokenLinear(torch.autograd.Function):
             # a few thousand rows (the decoder's 4 400): dW and db from one launch + one chunk sum (csrc/small_wgrad.hip)
             dw, db = small_wgrad_ext.small_wgrad(dy2, x2, weight.dtype)
             return dx, dw, (db if ctx.has_bias and ctx.needs_input_grad[2] else None), None
-        C = _split_count(T)
+        # the batched split rounds every chunk's partial product to the activation dtype: worth it from ~8 000 rows on (43 vs
+        # 110 us at 15 360), not for the decoder's 4 400 (29 + 12 vs 34 us, and 16 bf16 roundings instead of one)
+        C = _split_count(T) if T > small_wgrad_ext.MAX_ROWS else 0
         if ctx.needs_input_grad[1]:
             if C:
                 parts = torch.bmm(dy2.view(C, T // C, -1).transpose(1, 2), x2.view(C, T // C, -1))    # [C, N, K]
