@@ -503,7 +503,7 @@ int mdetr_group_norm_backward(int io_dtype, int param_dtype, const void *dy, con
  *   num_targets  [images] int32: valid targets of each image, <= kmax    (device)
  *   assign       [layers, images, groups, kmax] int32 (device): for problem (l, b, g) and target t <
  *                num_targets[b], the index in [g*n, (g+1)*n) of the query matched to it; -1 elsewhere
- *   n            queries per group (<= 64), kmax <= n
+ *   n            queries per group (<= 128: one or two columns per lane of the solving wave), kmax <= min(n, 64)
  * Each (l, b, g) is an independent min-cost matching of all targets of image b to distinct queries
  * of group g, solved exactly in float64 (shortest augmenting paths, one wave64 per problem).
  */

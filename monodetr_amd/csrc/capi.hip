@@ -298,8 +298,8 @@ int mdetr_lsa_forward(const float *cost, const int32_t *num_targets, int32_t *as
                       int layers, int images, int groups, int n, int kmax,
                       int64_t img_stride, int64_t q_stride, int64_t t_stride, int device, void *stream)
 {
-    if (layers < 0 || images < 0 || groups < 0 || n <= 0 || n > 64 || kmax < 0 || kmax > n)
-        return fail(MDETR_E_ARG, "mdetr_lsa_forward: need 0 < n <= 64 and 0 <= kmax <= n (n=%d kmax=%d)", n, kmax);
+    if (layers < 0 || images < 0 || groups < 0 || n <= 0 || n > 128 || kmax < 0 || kmax > n || kmax > 64)
+        return fail(MDETR_E_ARG, "mdetr_lsa_forward: need 0 < n <= 128 and 0 <= kmax <= min(n, 64) (n=%d kmax=%d)", n, kmax);
     if (layers == 0 || images == 0 || groups == 0 || kmax == 0) return MDETR_OK;
     if (!cost || !num_targets || !assign) return fail(MDETR_E_ARG, "mdetr_lsa_forward: null pointer");
     DeviceScope dev(device);
@@ -827,8 +827,8 @@ int mdetr_lsa_forward_fused(const float *logits, const float *boxes, const int64
                             int kmax, int num_classes, float w_class, float w_bbox, float w_center, float w_giou,
                             float focal_alpha, int device, void *stream)
 {
-    if (layers < 0 || images < 0 || groups < 0 || n <= 0 || n > 64 || kmax < 0 || kmax > n || num_classes <= 0)
-        return fail(MDETR_E_ARG, "mdetr_lsa_forward_fused: need 0 < n <= 64, 0 <= kmax <= n, num_classes > 0 (n=%d kmax=%d)", n, kmax);
+    if (layers < 0 || images < 0 || groups < 0 || n <= 0 || n > 128 || kmax < 0 || kmax > n || kmax > 64 || num_classes <= 0)
+        return fail(MDETR_E_ARG, "mdetr_lsa_forward_fused: need 0 < n <= 128, 0 <= kmax <= min(n, 64), num_classes > 0 (n=%d kmax=%d)", n, kmax);
     if (layers == 0 || images == 0 || groups == 0 || kmax == 0) return MDETR_OK;
     if (!logits || !boxes || !labels || !boxes3d || !num_targets || !assign)
         return fail(MDETR_E_ARG, "mdetr_lsa_forward_fused: null pointer");

@@ -11,7 +11,7 @@ def batched_assignment(cost, num_targets, groups):
     assert cost.is_cuda and cost.dtype == torch.float32 and cost.dim() == 4
     L, B, Q, K = cost.shape
     n = Q // groups
-    assert n * groups == Q and n <= 64 and K <= n, "need Q = groups * n with n <= 64 and Kmax <= n"
+    assert n * groups == Q and n <= 128 and K <= min(n, 64), "need Q = groups * n with n <= 128 and Kmax <= min(n, 64)"
     if cost.stride(0) != B * cost.stride(1):
         cost = cost.contiguous()
     num_targets = num_targets.to(device=cost.device, dtype=torch.int32).contiguous()
@@ -34,7 +34,7 @@ def batched_assignment_fused(logits, boxes, gt, groups, weights, focal_alpha=0.2
     L, B, Q, C = logits.shape
     K = gt["valid"].shape[1]
     n = Q // groups
-    assert n * groups == Q and n <= 64 and K <= n, "need Q = groups * n with n <= 64 and Kmax <= n"
+    assert n * groups == Q and n <= 128 and K <= min(n, 64), "need Q = groups * n with n <= 128 and Kmax <= min(n, 64)"
     dev = logits.device
     lg, bx = logits.float().contiguous(), boxes.float().contiguous()
     labels, b3d = gt["labels"].to(torch.int64).contiguous(), gt["boxes_3d"].float().contiguous()

@@ -123,13 +123,13 @@ class HungarianMatcher(nn.Module):
         L, B, Q, _ = logits.shape
         K = gt["valid"].shape[1]
         n = Q // group_num
-        if self.fused_cost and n <= 64 and K <= n and n * group_num == Q:
+        if self.fused_cost and n <= 128 and K <= min(n, 64) and n * group_num == Q:
             # the cost is evaluated inside the solver kernel: no cost matrix, one launch (lsa_ext)
             from ..lsa_ext import batched_assignment_fused
             return batched_assignment_fused(logits, boxes, gt, group_num, (self.cost_class, self.cost_bbox,
                                             self.cost_3dcenter, self.cost_giou)).long()
         C = self.cost_padded(logits, boxes, gt)
-        if C.is_cuda and n <= 64 and K <= n:
+        if C.is_cuda and n <= 128 and K <= min(n, 64):
             from ..lsa_ext import batched_assignment
             return batched_assignment(C.float(), gt["num"], group_num).long()
         Ch = C.double().cpu().numpy()

@@ -155,7 +155,10 @@ def test_fused_matching_cost_and_solver_match_scipy_on_the_pytorch_cost(backend)
     try:
         _, crit = build_monodetr(load_cfg())
         m = crit.matcher
-        for (L, B, Q, K, G, seed) in ((3, 4, 550, 50, 11, 0), (2, 3, 110, 7, 11, 1), (1, 2, 64, 64, 1, 2)):
+        sizes = ((3, 4, 550, 50, 11, 0), (2, 3, 110, 7, 11, 1), (1, 2, 64, 64, 1, 2))
+        if backend == "emul":
+            sizes += ((2, 2, 1100, 50, 11, 3),)                       # 100 queries per group (512 x 1760 configuration): two columns per lane
+        for (L, B, Q, K, G, seed) in sizes:
             preds, gt = _problem(L, B, Q, K, G, seed)
             cost = m.cost_padded(preds['pred_logits'], preds['pred_boxes'], gt).double().numpy()
             got = lsa_ext.batched_assignment_fused(preds['pred_logits'], preds['pred_boxes'], gt, G,

@@ -20,7 +20,8 @@ def solve(cost, num, groups, n):
     return assign
 
 
-@pytest.mark.parametrize("layers,images,groups,n,K,seed", [(3, 4, 11, 50, 50, 0), (1, 2, 1, 64, 64, 1), (2, 3, 5, 17, 9, 2)])
+@pytest.mark.parametrize("layers,images,groups,n,K,seed", [(3, 4, 11, 50, 50, 0), (1, 2, 1, 64, 64, 1), (2, 3, 5, 17, 9, 2),
+                                                          (2, 2, 11, 100, 50, 3), (1, 2, 2, 128, 64, 4), (1, 3, 3, 65, 7, 5)])    # two columns per lane
 def test_assignments_are_optimal(layers, images, groups, n, K, seed):
     g = torch.Generator().manual_seed(seed)
     cost = torch.rand(layers * images, groups * n, K, generator=g) * 4 - 1

@@ -24,7 +24,8 @@ def scipy_assign(cost, num_targets, groups):
     return out
 
 
-@pytest.mark.parametrize("L,B,G,n,K", [(3, 8, 11, 50, 50), (1, 4, 1, 50, 50), (2, 3, 5, 7, 7), (1, 2, 2, 64, 64), (1, 1, 1, 1, 1)])
+@pytest.mark.parametrize("L,B,G,n,K", [(3, 8, 11, 50, 50), (1, 4, 1, 50, 50), (2, 3, 5, 7, 7), (1, 2, 2, 64, 64), (1, 1, 1, 1, 1),
+                                       (3, 8, 11, 100, 50), (1, 2, 2, 128, 64)])       # > 64 queries per group: two columns per lane
 def test_matches_scipy(L, B, G, n, K):
     from monodetr_amd.lsa_ext import batched_assignment
     g = torch.Generator().manual_seed(L * 100 + n)
