@@ -1,0 +1,52 @@
+"""Host-side pieces added around the kernels: `_LevelPos` (level position embedding with a hand-written backward) and
+`linear.Linear` (nn.Linear routed through token_linear) against the plain framework expressions on the CPU."""
+import torch
+import torch.nn.functional as F
+
+from monodetr_amd.monodetr.depthaware_transformer import _LevelPos, fused_first_layers, mlp_rest, MLP
+from monodetr_amd.monodetr.linear import Linear
+
+
+def test_level_pos_matches_the_broadcast_adds():
+    g = torch.Generator().manual_seed(0)
+    shapes = [(6, 10), (3, 5), (2, 3), (1, 2)]
+    pos = [torch.randn(2, 16, h, w, generator=g) for h, w in shapes]
+    emb = torch.randn(4, 16, generator=g, requires_grad=True)
+    out = _LevelPos.apply(emb, torch.float32, *pos)
+    ref_emb = emb.detach().clone().requires_grad_(True)
+    ref = torch.cat([p.flatten(2).transpose(1, 2) + ref_emb[l].view(1, 1, -1) for l, p in enumerate(pos)], 1)
+    assert torch.equal(out, ref)
+    dy = torch.randn(ref.shape, generator=g)
+    out.backward(dy)
+    ref.backward(dy)
+    assert (emb.grad - ref_emb.grad).abs().max() <= 1e-5 * ref_emb.grad.abs().max()
+    # bf16 output, fp32 parameter: the gradient comes back in the parameter's dtype
+    emb2 = emb.detach().clone().requires_grad_(True)
+    _LevelPos.apply(emb2, torch.bfloat16, *pos).backward(dy.to(torch.bfloat16))
+    assert emb2.grad.dtype == torch.float32 and (emb2.grad - ref_emb.grad).abs().max() <= 2e-2 * ref_emb.grad.abs().max()
+
+
+def test_linear_keeps_nn_linear_semantics_and_keys():
+    torch.manual_seed(1)
+    a, b = Linear(8, 5), torch.nn.Linear(8, 5)
+    b.load_state_dict(a.state_dict())                                  # same parameter names
+    x = torch.randn(3, 7, 8, requires_grad=True)
+    ya, yb = a(x), b(x)
+    assert torch.equal(ya, yb)
+    ya.sum().backward()
+    assert a.weight.grad is not None and isinstance(a, torch.nn.Linear)
+
+
+def test_fused_first_layers_equal_the_separate_heads():
+    torch.manual_seed(2)
+    heads = [MLP(16, 16, 6, 3), MLP(16, 16, 3, 2), MLP(16, 16, 2, 2), torch.nn.Linear(16, 3)]
+    x = torch.randn(2, 5, 16)
+    parts = fused_first_layers(x, heads)
+    assert len(parts) == 4 and [p.shape[-1] for p in parts] == [16, 16, 16, 3]
+    for h, part in zip(heads, parts):
+        want = h(x)
+        got = mlp_rest(h, part) if isinstance(h, MLP) else part
+        assert (got - want).abs().max() < 1e-5
+    # a single-layer MLP: its first layer is its output
+    one = MLP(16, 16, 4, 1)
+    assert (mlp_rest(one, fused_first_layers(x, [one])[0]) - one(x)).abs().max() < 1e-5
