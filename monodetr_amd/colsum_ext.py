@@ -22,9 +22,10 @@ def column_sum(x, out_dtype=torch.float32):
     T, N = x.shape
     lib = _capi.lib()
     need = lib.mdetr_column_sum_workspace_bytes(T, N)
-    ws = _workspaces.get(x.device)
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)   # per stream: calls on different streams run concurrently
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < need:
-        ws = _workspaces[x.device] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
+        ws = _workspaces[key] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError("column_sum: out_dtype must be float32 or bfloat16")
     out = torch.empty(N, dtype=out_dtype, device=x.device)

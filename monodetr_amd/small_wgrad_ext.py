@@ -42,9 +42,10 @@ def small_wgrad(dy, x, out_dtype=None):
     K = x.shape[1]
     lib = _lib()
     need = lib.mdetr_small_wgrad_workspace_bytes(T, N, K)
-    ws = _workspaces.get(dy.device)
+    key = (dy.device, torch.cuda.current_stream(dy.device).cuda_stream if dy.is_cuda else 0)   # per stream: calls on different streams run concurrently
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < need:
-        ws = _workspaces[dy.device] = torch.empty(max(need, 8 << 20), dtype=torch.uint8, device=dy.device)
+        ws = _workspaces[key] = torch.empty(max(need, 8 << 20), dtype=torch.uint8, device=dy.device)
     out = torch.empty(N * K + N, dtype=out_dtype, device=dy.device)
     code = lambda dt: _capi.MDETR_BF16 if dt == torch.bfloat16 else _capi.MDETR_F32      # noqa: E731
     dev, stream = (dy.device.index, torch.cuda.current_stream(dy.device).cuda_stream) if dy.is_cuda else (-1, None)
