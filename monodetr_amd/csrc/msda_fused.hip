@@ -918,11 +918,14 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
     if ((err = zero_fill_launch(hdr, 16, st)) != hipSuccess) return err;
     const int64_t n_go = static_cast<int64_t>(B) * Lq * M * D, n_at = static_cast<int64_t>(B) * Lq * M * L * P;
     if ((L * P) % 4 != 0) return hipErrorNotSupported;       // the pre-pass reads attn in 16-byte pieces
+    // grid-stride over 16-byte pieces, four per lane and trip: no more workgroups than that gives work to (small calls)
+    const int64_t pre_items = (n_go + n_at) / 4 + nfar / 4 / 64;
+    const unsigned pre_blocks = static_cast<unsigned>(pre_items / (256 * 4) < 2048 ? (pre_items / (256 * 4) > 0 ? pre_items / (256 * 4) : 1) : 2048);
     profile_begin(7, Lq, st);
     if (elem_dtype == 2)
-        hipLaunchKernelGGL(msda_absmax_kernel<__hip_bfloat16>, dim3(2048), dim3(256), 0, st, static_cast<const __hip_bfloat16 *>(grad_out), n_go, attn, n_at, hdr, far, nfar);
+        hipLaunchKernelGGL(msda_absmax_kernel<__hip_bfloat16>, dim3(pre_blocks), dim3(256), 0, st, static_cast<const __hip_bfloat16 *>(grad_out), n_go, attn, n_at, hdr, far, nfar);
     else
-        hipLaunchKernelGGL(msda_absmax_kernel<float>, dim3(2048), dim3(256), 0, st, static_cast<const float *>(grad_out), n_go, attn, n_at, hdr, far, nfar);
+        hipLaunchKernelGGL(msda_absmax_kernel<float>, dim3(pre_blocks), dim3(256), 0, st, static_cast<const float *>(grad_out), n_go, attn, n_at, hdr, far, nfar);
     profile_end(st);
     // 512 threads (8 waves) or 1024 (16 waves: twice the record buffers, more loads in flight per CU)
     int threads = env_int("MDETR_MSDA_THREADS", 1024);          // (bf16: 0.74 ms at 16 waves vs 0.96 at 8, same tile)
