@@ -100,67 +100,11 @@ def synthetic_batch(B, H, W, seed, device):
 
 
 # ---- optional kernel families ------------------------------------------------------------------------------------------
-# Each can be forced with an environment variable of the same name (= "1").  Without any in the environment the step runs
-# with the COMMITTED list below.  (MDETR_MSDA_BF16 changes the MSDA operator's element types; the roofline accounting
-# follows it: msda_algorithmic_bytes(mixed=True).)
-AUTOTUNE_SWITCHES = ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN", "MDETR_MSDA_BF16", "MDETR_TOKEN_GEMM",
-                     "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD")
-ALL_SWITCHES = AUTOTUNE_SWITCHES
-# The measured configuration.  family -> the GPU tests that hold it to the default path / the framework operators
-# (all in tests/test_fused_gpu.py unless a file is named); a family without green tests is not listed.
-SWITCH_TESTS = {
-    "MDETR_FUSED_LOSSES": "test_fused_pair_losses_*, test_fused_ddn_loss_*, test_fused_cost_solver_*, test_training_step_with_fused_criterion_*",
-    "MDETR_FUSED_ADAMW": "test_fused_adamw_kernel_*, test_fused_adamw_vs_recorded_reference_steps, test_training_step_with_fused_adamw_*",
-    "MDETR_FUSED_LN": "test_fused_add_layernorm_*, test_training_step_with_fused_layernorm_*",
-    "MDETR_MSDA_PROLOGUE": "test_msda_prologue_kernel_*",
-    "MDETR_MSDA_BF16": "test_msda_bf16_kernels_*, test_msda_function_with_native_bf16_*, test_training_step_with_bf16_msda_*, test_msda_gpu.py::test_bf16_native_full_encoder_shape_vs_oracle",
-    "MDETR_FUSED_EPILOGUE": "test_bias_act_kernel_*, test_training_step_with_fused_tails_*",
-    "MDETR_GEMM_RELU": "test_library_gemm_relu_epilogue_*, test_training_step_with_fused_tails_*",
-    "MDETR_SMALL_WGRAD": "test_small_wgrad_kernel_*, test_training_step_with_the_small_wgrad_kernel_*",
-    "MDETR_GROUP_NORM": "test_group_norm_kernel_*, test_training_step_with_the_group_norm_kernel_*",
-    "MDETR_CONV3X3": "test_conv3x3_kernel_matches_the_library_convolution, test_training_step_with_the_conv3x3_kernel_*, test_conv3x3_module_with_a_trainable_bias_*",
-}
-COMMITTED_SWITCHES = {
-    # (MDETR_CONV3X3: 1.6-3.5x MIOpen per kernel on the four ResNet stages, profiles/r02a_fusedbench.json; the step 249.3 vs
-    # 234.6 img/s, profiles/r02b_bench_committed_plus_conv3x3.json.  MDETR_TOKEN_GEMM stays off: slower than hipBLASLt.
-    # MDETR_GROUP_NORM: 328.9 vs 308.7 img/s under graph replay, profiles/r02m_bench_with_gn.json.
-    # MDETR_SMALL_WGRAD: 340.2 vs 333.6 img/s, profiles/r02q_bench_{with_small_wgrad,committed}.json.)
-    "bf16": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE", "MDETR_MSDA_BF16",
-             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD"),
-    "fp32": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE",
-             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD"),
-}
-COMMITTED_SWITCHES["bf16-autocast"] = COMMITTED_SWITCHES["fp32"]
-
-
-def committed_switches(precision):
-    """(switch set, source): the environment's MDETR_* if any is set (A/B experiments), else the committed list."""
-    env = env_switches()
-    if env or os.environ.get("MDETR_BENCH_DEFAULT_PATH") == "1":
-        return env, "environment"
-    return set(COMMITTED_SWITCHES[precision]), "bench.COMMITTED_SWITCHES"
-
-
-def env_switches():
-    return {k for k in ALL_SWITCHES if os.environ.get(k) == "1"}
-
-
-def apply_switches(names):
-    """Runtime equivalent of the environment switches for the module-level ones (the criterion's and the optimizer's
-    are applied by TrainStep)."""
-    from monodetr_amd import add_ln_ext, bias_act_ext, conv3x3_ext, group_norm_ext, small_wgrad_ext
-    from monodetr_amd.monodetr import linear
-    from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func
-    from monodetr_amd.monodetr.ops.modules import ms_deform_attn
-    ms_deform_attn._FUSED_PROLOGUE = "MDETR_MSDA_PROLOGUE" in names
-    add_ln_ext.ENABLED = "MDETR_FUSED_LN" in names
-    linear._TOKEN_GEMM = "MDETR_TOKEN_GEMM" in names
-    linear._GEMM_RELU = "MDETR_GEMM_RELU" in names
-    bias_act_ext.ENABLED = "MDETR_FUSED_EPILOGUE" in names
-    conv3x3_ext.ENABLED = "MDETR_CONV3X3" in names
-    group_norm_ext.ENABLED = "MDETR_GROUP_NORM" in names
-    small_wgrad_ext.ENABLED = "MDETR_SMALL_WGRAD" in names
-    ms_deform_attn_func._NATIVE_BF16 = "MDETR_MSDA_BF16" in names
+# The lists live in the package (monodetr_amd/kernel_families.py): the benchmark measures the configuration the training
+# entry point runs.  (MDETR_MSDA_BF16 changes the MSDA operator's element types; the roofline accounting follows it:
+# msda_algorithmic_bytes(mixed=True).)
+from monodetr_amd.kernel_families import (ALL_SWITCHES, AUTOTUNE_SWITCHES, COMMITTED_SWITCHES, SWITCH_TESTS, apply_switches,  # noqa: E402,F401
+                                          committed_switches, env_switches)
 
 
 class TrainStep:

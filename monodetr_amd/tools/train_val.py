@@ -5,7 +5,8 @@
 
 One process per GPU (the reference wraps the model in ``nn.DataParallel`` when ``gpu_ids`` lists several): under
 torchrun every rank trains on its shard of each epoch (``DistributedSampler``), gradients are averaged over RCCL, and
-rank 0 alone writes checkpoints and evaluates.  Optional extra keys: ``trainer.precision: bf16`` (bf16 model body with
+rank 0 alone writes checkpoints and evaluates.  Optional extra keys: ``trainer.kernels: committed | default`` (the optional
+kernel families of monodetr_amd/kernel_families.py: on by default on a GPU), ``trainer.precision: bf16`` (bf16 model body with
 fp32 master weights -- the configuration ``bench.py`` measures) and ``model.backbone_weights`` (a local ResNet-50
 state_dict; the reference downloads one at construction).
 """
@@ -84,7 +85,14 @@ def main(argv=None):
         logger.info('###################  Evaluation Only  ##################')
         tester.test()
         return
-    optimizer = optimizer_helper.build_optimizer(cfg['optimizer'], model)
+    # the kernel families bench.py measures are what training runs with (trainer.kernels: default = none of them; any
+    # MDETR_<FAMILY>=1 in the environment replaces the list); they need the GPU
+    from monodetr_amd import kernel_families
+    optimizer_cfg, families = kernel_families.enable_for_training(
+        model, criterion, cfg['optimizer'], cfg['trainer'].get('precision', 'fp32'),
+        cfg['trainer'].get('kernels', 'committed' if proc.on_gpu else 'default'))
+    logger.info('Kernel families: %s' % (', '.join(families) or 'none'))
+    optimizer = optimizer_helper.build_optimizer(optimizer_cfg, model)
     schedule, warmup = scheduler_helper.build_lr_scheduler(cfg['lr_scheduler'], optimizer, last_epoch=-1)
     trainer = Trainer(cfg=cfg['trainer'], model=model, optimizer=optimizer, train_loader=train_loader, test_loader=test_loader,
                       lr_scheduler=schedule, warmup_lr_scheduler=warmup, logger=logger, loss=criterion, model_name=name)

@@ -505,7 +505,17 @@ def test_train_val_entry_point_end_to_end(tmp_path, monkeypatch):
     }
     path = str(tmp_path / 'cfg.yaml')
     yaml.safe_dump(cfg, open(path, 'w'))
-    train_val.main(['--config', path])
+    from monodetr_amd import group_norm_ext, kernel_families
+    try:
+        train_val.main(['--config', path])
+        assert group_norm_ext.ENABLED                                   # the entry point trains with the committed kernel families
+        _check_train_val_outputs(tmp_path, ids)
+        train_val.main(['--config', path, '-e'])                        # evaluation only, from checkpoint_epoch_2.pth
+    finally:
+        kernel_families.apply_switches(set())                           # module-level switches: leave the process as found
+
+
+def _check_train_val_outputs(tmp_path, ids):
     out = tmp_path / 'outputs' / 'monodetr'
     # (checkpoint_best.pth is written only when the validation AP rises above 0, trainer_helper.py:100-107 -- not after two
     # epochs from random weights: the run keeps every epoch and the tester is pointed at the last one)
@@ -514,7 +524,6 @@ def test_train_val_entry_point_end_to_end(tmp_path, monkeypatch):
     assert files == ['%s.txt' % i for i in ids]
     line = open(out / 'outputs' / 'data' / files[0]).readline().split(' ')
     assert len(line) == 16 and line[0] in ('Pedestrian', 'Car', 'Cyclist')
-    train_val.main(['--config', path, '-e'])                            # evaluation only, from checkpoint_epoch_2.pth
 
 
 # ---- fused residual + dropout + LayerNorm ----------------------------------------------------------------------------
