@@ -107,11 +107,15 @@ from monodetr_amd.kernel_families import (ALL_SWITCHES, AUTOTUNE_SWITCHES, COMMI
                                           committed_switches, env_switches)
 
 
-class TrainStep:
-    """model + criterion + optimizer on one device; __call__ runs one full training iteration."""
+from monodetr_amd.helpers.step_helper import TrainIteration  # noqa: E402
+
+
+class TrainStep(TrainIteration):
+    """The product's training iteration (monodetr_amd/helpers/step_helper.TrainIteration: the object ``Trainer.train_one_epoch``
+    drives) on a model built from the reference's yaml and ONE resident synthetic batch; __call__ runs one full iteration."""
 
     def __init__(self, device, batch, precision, seed=444, ddp=False, local_rank=0, size=(384, 1280), graph=False, switches=None,
-                 queries=50, part="full"):
+                 queries=50, part="full", capture_error_mode="global"):
         """queries: `num_queries` of the yaml (x 11 groups in training); part: "full" = the whole training iteration,
         "encoder" = BASELINE configs[1]: ResNet-50 + input projections + the MSDeformAttn encoder only (forward, a
         mean-square objective on the encoder memory, backward, optimizer step over the parameters involved)."""
@@ -126,40 +130,36 @@ class TrainStep:
             torch.backends.cudnn.benchmark = True
         cfg = dict(MODEL_CFG, device=str(device).split(':')[0], num_queries=queries)
         self.part = part
-        self.model, self.criterion = build_monodetr(cfg)
-        self.model.to(device)
+        model, criterion = build_monodetr(cfg)
+        model.to(device)
         if device.type == "cuda":
-            self.model.to(memory_format=torch.channels_last)
+            model.to(memory_format=torch.channels_last)
         if precision == "bf16":
             from monodetr_amd.helpers.precision import to_bf16_body
-            to_bf16_body(self.model)
-        self.model.train()
-        self.criterion.train()
+            to_bf16_body(model)
+        model.train()
+        criterion.train()
         if switches is not None:
-            self.criterion.fused_pair_losses = self.criterion.matcher.fused_cost = "MDETR_FUSED_LOSSES" in self.switches
-        self.raw_model = self.model
-        self.grad_sync = None
+            criterion.fused_pair_losses = criterion.matcher.fused_cost = "MDETR_FUSED_LOSSES" in self.switches
+        grad_sync, wrapped = None, model
         if ddp == "ddp":
             from torch.nn.parallel import DistributedDataParallel as DDP
             # static_graph: label_enc / sa_v_proj / decoder.query_scale / decoder.ref_point_head never
             # receive gradients on the default path; bucket views avoid a grad copy
-            self.model = DDP(self.model, device_ids=[local_rank], static_graph=True, gradient_as_bucket_view=True,
-                             bucket_cap_mb=64)
+            wrapped = DDP(model, device_ids=[local_rank], static_graph=True, gradient_as_bucket_view=True, bucket_cap_mb=64)
         elif ddp and torch.distributed.is_initialized():
             # default N > 1 path: one flat all-reduce per dtype after the backward; "bucketed": the same exchange in
             # ~32 MB buckets issued from gradient hooks while the backward is still running (helpers/dist_helper.py)
             from monodetr_amd.helpers.dist_helper import BucketedGradSync, FlatGradSync, broadcast_parameters
-            broadcast_parameters(self.raw_model)
-            self.grad_sync = (BucketedGradSync if ddp == "bucketed" else FlatGradSync)(self.raw_model.parameters())
-        self.pending_sync = ddp if (ddp and ddp != "ddp" and self.grad_sync is None) else None   # attach_process_group() later
-        # MDETR_FUSED_ADAMW=1: one-launch-per-group HIP AdamW (helpers/optimizer_helper.FusedAdamW); off until
-        # its kernel has had its first GPU validation (tests/test_fused_gpu.py)
-        self.optimizer = build_optimizer(dict(OPT_CFG, capturable=graph, fused="MDETR_FUSED_ADAMW" in self.switches),
-                                         self.raw_model)
-        self.graph = self.graph_opt = self.sync_plan = None
-        self.want_graph = graph
+            broadcast_parameters(model)
+            grad_sync = (BucketedGradSync if ddp == "bucketed" else FlatGradSync)(model.parameters())
+        pending = ddp if (ddp and ddp != "ddp" and grad_sync is None) else None   # attach_process_group() later
+        optimizer = build_optimizer(dict(OPT_CFG, capturable=graph, fused="MDETR_FUSED_ADAMW" in self.switches), model)
         self.precision = precision
-        self.device = device
+        super().__init__(model, criterion, optimizer, device, grad_sync=grad_sync, pending_sync=pending,
+                         compute=self._compute_encoder if part == "encoder" else None,
+                         graph="auto" if graph else "off", capture_error_mode=capture_error_mode)
+        self.model = wrapped
         H, W = size
         self.inputs = synthetic_batch(batch, H, W, seed + 1000 * (local_rank + 1), device)
         if device.type == "cuda":
@@ -176,140 +176,30 @@ class TrainStep:
                 padded["num_host"] = None                    # normaliser computed on the device: replays must not bake it in
             self.inputs = self.inputs[:3] + (padded,)
 
-    def capture(self, eager_steps=3):
-        """Record one whole training iteration (forward, criterion with on-device matching, backward,
-        optimizer) into a hipGraph; __call__ then replays it with one launch.  Warm-up and capture
-        share one side stream: autograd binds each parameter's AccumulateGrad node to the stream of
-        its first use, and a capture on any other stream would leave those nodes outside the graph.
+    def _compute_encoder(self, batch):
+        srcs, masks, pos = self.raw_model.pyramid(batch[0])
+        memory = self.raw_model.depthaware_transformer.encode(srcs, masks, pos)[0]
+        total = memory.float().square().mean()
+        return total, {"loss_encoder_memory": total}
 
-        With a gradient exchange (N > 1: ``FlatGradSync``) the iteration becomes TWO graphs with the exchange between them,
-        issued eagerly: [zero_grad, forward, criterion, backward] -> all-reduce of the flat gradient (RCCL, 8 launches) ->
-        [optimizer step].  The collectives stay outside any capture; the gradients live at fixed addresses in the graphs'
-        shared memory pool, so the eager exchange reads and rewrites them in place."""
-        if (self.grad_sync is not None and type(self.grad_sync).__name__ != "FlatGradSync") or self.pending_sync not in (None, "flat"):
-            raise RuntimeError("graph replay needs the flat gradient exchange (MDETR_BENCH_SYNC=flat)")
-        if self.grad_sync is not None:
-            # a live RCCL process group and stream capture do not mix on this stack: its watchdog thread polls events while
-            # the capture is under way and aborts the process ("operation not permitted on an event last recorded in a
-            # capturing stream", profiles/r02m).  Capture first, create the process group afterwards: attach_process_group().
-            raise RuntimeError("capture before the process group exists (TrainStep built before init_process_group)")
-        if self.model is not self.raw_model:
-            raise RuntimeError("graph replay is not available under the DistributedDataParallel wrapper")
-        side = self.stream = torch.cuda.Stream(self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):
-            for _ in range(eager_steps):                     # optimizer state, workspaces, geometry caches, MIOpen plans
-                self._step()
-        torch.cuda.current_stream(self.device).wait_stream(side)
-        from monodetr_amd.attn_ext import _next_seed
-        _next_seed(self.device)                              # the device-resident dropout seed exists before anything is captured
-        torch.cuda.synchronize(self.device)
-        graph, graph_opt = torch.cuda.CUDAGraph(), None
-        self.optimizer.zero_grad(set_to_none=True)
-        if self.pending_sync is None:
-            with torch.cuda.graph(graph, stream=side):       # same stream as the warm-up: autograd's AccumulateGrad nodes are bound to it
-                self.loss = self._step()
-        else:
-            from monodetr_amd.helpers.dist_helper import static_plan
-            with torch.cuda.graph(graph, stream=side):
-                self.loss = self._forward_backward()
-            # the gradients now sit at the addresses the captured backward writes to: every later exchange gathers from THOSE
-            # into persistent flat buffers, reduces there, and the captured optimizer reads the reduced slices
-            self.sync_plan = static_plan(self.raw_model.parameters())
-            for ps, src, flat, views in self.sync_plan:
-                for p_, v in zip(ps, views):
-                    p_.grad = v
-            graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_opt, stream=side, pool=graph.pool()):
-                self.optimizer.step()
-        torch.cuda.synchronize(self.device)
-        self.graph, self.graph_opt = graph, graph_opt
-        return self
+    def _compute_full(self, batch):
+        with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.precision == "bf16-autocast"):
+            return super()._compute_full(batch)
 
-    def try_capture(self):
-        """capture(), or the eager step if the capture fails.  With a pending gradient exchange the decision becomes final in
-        attach_process_group() (every rank must take the same one)."""
-        self.capture_error = ""
-        try:
-            self.capture()
-        except Exception as e:                               # noqa: BLE001 -- whatever the runtime objects to: measure eagerly instead
-            self.capture_error = repr(e)[:160]
-            self.graph = self.graph_opt = self.sync_plan = None
-            torch.cuda.synchronize(self.device)
-            import traceback
-            print("bench: graph capture not used (%s): eager launches\n%s" % (self.capture_error, "".join(traceback.format_exc().splitlines(True)[-14:])),
-                  file=sys.stderr, flush=True)
-        return self.launch_mode()
+    def capture(self, batch=None, in_place=True):
+        """Record the iteration on the resident synthetic batch (its tensors ARE the static buffers)."""
+        return super().capture(self.inputs if batch is None else batch, in_place)
 
-    def launch_mode(self):
-        if self.graph is None:
-            return "eager" + (" (graph capture failed: %s)" % self.capture_error if getattr(self, "capture_error", "") else "")
-        return ("one hipGraph replay per iteration" if self.graph_opt is None else
-                "two hipGraph replays per iteration (forward + backward | optimizer) around the eager RCCL gradient all-reduce")
-
-    def attach_process_group(self):
-        """The N > 1 half of the construction, once torch.distributed is up: rank 0's parameters and optimizer state to
-        everybody, the gradient exchange (gathering from the captured backward's gradient tensors if the step replays
-        graphs), and one decision for all ranks: graphs only if every rank captured them."""
-        from monodetr_amd.helpers.dist_helper import BucketedGradSync, FlatGradSync, broadcast_parameters
-        if self.pending_sync is None:
-            return self.launch_mode()
-        flag = torch.tensor([1 if self.graph is not None else 0], device=self.device, dtype=torch.int32)
-        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-        if int(flag) == 0 and self.graph is not None:
-            self.capture_error = "capture failed on another rank"
-            self.graph = self.graph_opt = self.sync_plan = None
-        broadcast_parameters(self.raw_model, extra=[t for st in self.optimizer.state.values() for t in st.values() if torch.is_tensor(t)] +
-                             [t for b in (getattr(self.optimizer, "_flat", None) or (None, []))[1] for t in b.values() if torch.is_tensor(t)])
-        self.grad_sync = (BucketedGradSync if self.pending_sync == "bucketed" else FlatGradSync)(self.raw_model.parameters())
-        if self.graph is not None:
-            self.grad_sync._static = self.sync_plan
-        self.pending_sync = None
-        return self.launch_mode()
+    def try_capture(self, batch=None, in_place=True):
+        return super().try_capture(self.inputs if batch is None else batch, in_place)
 
     def __call__(self):
         if self.graph is not None:
-            self.graph.replay()
-            if self.graph_opt is not None:
-                self.grad_sync.sync()
-                self.graph_opt.replay()
-            return self.loss
-        return self._step()
+            return self.replay()
+        return self._eager(self.inputs)
 
-    def eager_iteration(self):
-        """One eagerly launched iteration of a step that normally replays graphs (kernel timing after the timed region):
-        fresh gradient tensors, so the exchange must gather from them, not from the captured backward's."""
-        static = None
-        if self.grad_sync is not None and getattr(self.grad_sync, "_static", None) is not None:
-            static, self.grad_sync._static = self.grad_sync._static, None
-        try:
-            return self._step()
-        finally:
-            if static is not None:
-                self.grad_sync._static = static
-
-    def _forward_backward(self):
-        images, calibs, img_sizes, targets = self.inputs
-        self.optimizer.zero_grad(set_to_none=True)
-        if self.part == "encoder":
-            srcs, masks, pos = self.raw_model.pyramid(images)
-            memory = self.raw_model.depthaware_transformer.encode(srcs, masks, pos)[0]
-            total = memory.float().square().mean()
-            total.backward()
-            return total
-        with torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=self.precision == "bf16-autocast"):
-            out = self.model(images, calibs, targets, img_sizes, dn_args=None)
-            losses = self.criterion(out, targets, None)
-        total = self.criterion.weighted_total(losses)               # trainer_helper.py:141-143, one dot product
-        total.backward()
-        return total
-
-    def _step(self):
-        total = self._forward_backward()
-        if self.grad_sync is not None:
-            self.grad_sync.sync()
-        self.optimizer.step()
-        return total
+    def eager_iteration(self, batch=None):
+        return super().eager_iteration(self.inputs if batch is None else batch)
 
 
 def time_variant(device, args, precision, switches, prime=10, timed=20, pg_init=None, **kw):
@@ -456,7 +346,7 @@ def cpu_msda_op_baseline(warm=3, timed=10, leg_budget_s=10.0, emit=None):
     return rows
 
 
-def cpu_baseline_child(steps=1, batch=2):
+def cpu_baseline_child(steps=3, batch=2):
     """Runs in a child process of its own (fresh thread pools, no CPU pinning inherited from the GPU process): prints one
     `CPU-BASELINE {...}` line per finished part so that the parent can keep what was done if it has to cut the child off."""
     from oracle import msda_oracle                                   # checker, used only in this leg
@@ -481,7 +371,7 @@ def cpu_baseline_child(steps=1, batch=2):
     cpu_msda_op_baseline(emit=_emit)
 
 
-def cpu_baseline(steps=1, batch=2, timeout_s=150):
+def cpu_baseline(steps=3, batch=2, timeout_s=240):
     """The reported CPU baseline (kind "port": /root/reference cannot travel to the GPU box; its arithmetic is pinned to
     the reference's by tests/test_oracle_golden.py and tests/test_model_cpu.py).  Two parts, measured in a child process
     under a hard time limit: the whole training iteration at batch `batch` with PyTorch CPU ops and the C oracle as the
@@ -522,6 +412,63 @@ def cpu_baseline(steps=1, batch=2, timeout_s=150):
     return res
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: re-execute this command line under ``torch.distributed.run`` -- one
+    process per GPU, rendezvous on 127.0.0.1 (the container's hostname may not resolve), a free port -- and pass its output
+    and exit status through."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env, cwd=ROOT))
+
+
+def gpu_clocks(index=0):
+    """Current shader / memory clocks of the GPU (rocm-smi), for the record: the same tree measured 295-348 img/s across
+    boxes under graph replay (round 2)."""
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "-d", str(index), "--showclocks", "--showperflevel", "--showpower", "--json"],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=20, text=True).stdout
+        card = next(iter(json.loads(out).values()))
+        keep = {}
+        for k, v in card.items():
+            lk = k.lower()
+            if "sclk" in lk or "mclk" in lk or "fclk" in lk or "performance level" in lk or "power" in lk:
+                keep[k] = v
+        return keep or None
+    except Exception:                                                # noqa: BLE001 -- a record, never a reason to fail
+        return None
+
+
+def kernel_source_sha():
+    """sha256/16 of the MSDA backward's sources: ties ``roofline.traffic`` (a separate rocprofv3 --pmc pass) to the kernel
+    the benchmarked process runs."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("msda_fused.hip", "msda.hip", "msda.h"):
+        with open(os.path.join(ROOT, "monodetr_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(path=None):
+    """(record, note): the committed PMC record if it was taken on this tree's kernel source, else ({}, why not)."""
+    path = path or os.path.join(ROOT, "profiles", "msda_pmc_traffic.json")
+    if not os.path.exists(path):
+        return {}, "no PMC record"
+    rec = json.load(open(path))
+    if rec.get("kernel_source_sha") == kernel_source_sha():
+        return rec, rec.get("source", "profiles/msda_pmc_traffic.json")
+    return {}, "PMC record is of another kernel source (%s, this tree %s): not reported" % (rec.get("kernel_source_sha"), kernel_source_sha())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -542,7 +489,7 @@ def main():
                          "(~1 900 per iteration: the step time then depends on the host CPU, 224-261 img/s across boxes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the fp32_path / default_path / rccl_1rank side measurements")
-    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--config", type=int, default=3, choices=[2, 3, 5],
@@ -567,8 +514,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            return spawn_ranks(args.gpus)                           # plain `python bench.py --gpus N`: start the N ranks ourselves
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # (before the HIP runtime starts: RCCL's IPC handles need dmabuf mode)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
@@ -654,6 +601,7 @@ def main():
     if dist_on:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
+    clocks = gpu_clocks(local_rank) if rank == 0 else None          # right after the timed region (the GPU still warm)
     gc.enable()
     _capi.profile_enable(False)
     loss = loss.clone()
@@ -707,10 +655,9 @@ def main():
                         "dominant_kernel_ms": round(max(t for _, t in parts), 4), "ms": round(total, 4),
                         "algorithmic_MB": round(byts / 1e6, 1), "achieved_GBps": round(byts / total / 1e6, 1),
                         "frac": round(byts / total / 1e6 / 8000.0, 4)})
-    traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "msda_pmc_traffic.json")
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath))
+    # HBM traffic of the dominant operator: PMC counters cannot be read by the benchmarked process itself (rocprofv3 wraps a
+    # command), so the figure comes from the committed PMC passes -- and only if they were taken on THIS kernel source
+    traffic, traffic_note = pmc_traffic()
     dom = max(ops, key=lambda o: o["ms"]) if ops else None
 
     if rank == 0:
@@ -745,9 +692,11 @@ def main():
                                 "frac": dom["frac"], "traffic": traffic.get("msda_backward%s_Lq%d" % ("_bf16" if msda_mixed else "", dom["Lq"])),
                                 "avg_launch_ms": dom["ms"], "algorithmic_bytes": int(dom["algorithmic_MB"] * 1e6)}
             line["roofline"]["timing"] = kernel_timing
+            line["roofline"]["traffic_source"] = traffic_note
             line["ops"] = ops
             line["kernels"] = kernels
         line["config"]["cpu_affinity"] = "NUMA node %d of the GPU" % bound[0] if bound else "unbound"
+        line["config"]["gpu_clocks"] = clocks
         # optional kernel families in this run: the committed list, or the environment's for an A/B run
         line["config"]["switches"] = sorted(step.switches)
         line["config"]["switch_source"] = switch_source
@@ -774,6 +723,16 @@ def main():
                 line["default_path"] = time_variant(device, args, args.precision, (), size=size, queries=queries, part=part)
             except Exception as e:
                 line["default_path"] = {"value": None, "error": repr(e)[:200]}
+        if side and args.config == 3:
+            # the other single-GPU configurations of BASELINE.json on the same line, timed like `fp32_path`: configs[1]
+            # (ResNet-50 + input projections + MSDeformAttn encoder only, fp32) and configs[4]'s per-GPU work (512 x 1760,
+            # 100 queries, bf16); `python bench.py --config 2 | 5` are the full-length runs of the same
+            for tag, prec, kw in (("config2", "fp32", dict(part="encoder")), ("config5", "bf16", dict(size=(512, 1760), queries=100))):
+                try:
+                    line[tag] = time_variant(device, args, prec, committed_switches(prec)[0], graph=use_graph, **kw)
+                    line[tag]["baseline_config"] = int(tag[-1])
+                except Exception as e:
+                    line[tag] = {"value": None, "error": repr(e)[:200]}
         if side and args.config == 3:
             # the N > 1 code path with one rank: process group over RCCL, parameter broadcast, flat gradient all-reduce
             try:

@@ -5,7 +5,6 @@ import torch
 
 from . import _capi
 
-_workspaces = {}
 
 
 def supported(x):
@@ -22,10 +21,8 @@ def column_sum(x, out_dtype=torch.float32):
     T, N = x.shape
     lib = _capi.lib()
     need = lib.mdetr_column_sum_workspace_bytes(T, N)
-    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)   # per stream: calls on different streams run concurrently
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _workspaces[key] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
+    from . import _workspace as W
+    ws = W.get("colsum", x.device, need, floor=1 << 20)             # per stream: calls on different streams run concurrently
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError("column_sum: out_dtype must be float32 or bfloat16")
     out = torch.empty(N, dtype=out_dtype, device=x.device)

@@ -5,7 +5,6 @@ import torch
 
 from . import _capi
 
-_workspaces = {}
 _backend = None               # tests substitute the host build of the same arithmetic (tests/native)
 
 
@@ -14,10 +13,8 @@ def _lib():
 
 
 def _workspace(device):
-    ws = _workspaces.get(device)
-    if ws is None:
-        ws = _workspaces[device] = torch.zeros(16, dtype=torch.uint8, device=device)      # zero on first use
-    return ws
+    from . import _workspace as W
+    return W.get("ddn_loss", device, 16, zero=True)                 # zero on first use
 
 
 def _dense(t):

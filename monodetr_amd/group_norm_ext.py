@@ -13,7 +13,6 @@ from . import _capi
 _backend = None               # tests substitute the CPU emulation of the same kernel source (tests/native_emul.py)
 # MDETR_GROUP_NORM=1 routes GroupNorm modules through the kernel (bench.py's committed list after its GPU validation)
 ENABLED = os.environ.get("MDETR_GROUP_NORM") == "1"
-_workspaces = {}
 
 
 def _lib():
@@ -40,10 +39,8 @@ def _code(t):
 
 
 def _workspace(x, need):
-    ws = _workspaces.get(x.device)
-    if ws is None or ws.numel() < need:
-        ws = _workspaces[x.device] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=x.device)
-    return ws
+    from . import _workspace as W
+    return W.get("group_norm", x.device, need, floor=1 << 20)
 
 
 class _GroupNorm(torch.autograd.Function):

@@ -76,6 +76,40 @@ class AdamW(Optimizer):
                 if torch.is_tensor(v) and v.is_floating_point() and k != 'step':
                     self.state[p][k] = v.detach().clone().to(device=p.device)
 
+    # ---- graph replay (helpers/step_helper.TrainIteration): a replayed step advances the device counters only -------------
+    def note_replay(self):
+        """A captured ``step()`` was replayed: the host-side step counts (what ``state_dict()`` saves) are brought up to date
+        lazily by ``flush_replays``."""
+        self._pending_replays = getattr(self, "_pending_replays", 0) + 1
+
+    def uncount_step(self):
+        """The host bookkeeping of one ``step()`` whose kernels did not run (it was being captured) is taken back."""
+        self._advance_host_counts(-1)
+
+    def flush_replays(self):
+        n, self._pending_replays = getattr(self, "_pending_replays", 0), 0
+        if n:
+            self._advance_host_counts(n)
+
+    def _advance_host_counts(self, n):
+        for group in self.param_groups:
+            if 'calls' in group:
+                group['calls'] += n
+        for st in self.state.values():
+            if 'step' in st:
+                st['step'] += n
+
+    def state_dict(self):
+        """Device-only bookkeeping stays out of checkpoints (they remain interchangeable with the reference's): a
+        device-resident learning rate is saved as a float, the device step counters are rebuilt from the saved counts."""
+        self.flush_replays()
+        sd = super().state_dict()
+        for g in sd['param_groups']:
+            g.pop('step_dev', None)
+            if torch.is_tensor(g.get('lr')):
+                g['lr'] = float(g['lr'])
+        return sd
+
     def _device_step_size(self, group, device, first_step):
         """lr * sqrt(1 - b2^t) / (1 - b1^t) as a device scalar.  t lives on the device, one counter
         per cohort of parameters that started stepping together (``group['step_dev']``, keyed by the
@@ -98,6 +132,7 @@ class AdamW(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self.flush_replays()
         for group in self.param_groups:
             beta1, beta2 = group['betas']
             group['calls'] = group.get('calls', 0) + 1
@@ -183,6 +218,11 @@ class FusedAdamW(AdamW):
         super().load_state_dict(state_dict)      # AdamW.load_state_dict: keeps the saved dtypes
         self._flat = None                        # loaded state tensors are not views of the flat buffers: rebuild
 
+    def _advance_host_counts(self, n):
+        super()._advance_host_counts(n)
+        for buf in (self._flat[1] if self._flat is not None else ()):
+            buf['step'] += n
+
     def _eligible(self):
         for group in self.param_groups:
             if group['amsgrad']:
@@ -259,6 +299,7 @@ class FusedAdamW(AdamW):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self.flush_replays()
         if self._flat is None or self._flat[0] != self._signature():
             self._build_flat()
         from .. import _capi

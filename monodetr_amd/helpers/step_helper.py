@@ -1,0 +1,299 @@
+"""``TrainIteration`` -- the training iteration of ``Trainer.train_one_epoch`` (lib/helpers/trainer_helper.py:116-173:
+zero_grad -> model -> criterion -> weighted sum -> backward -> optimizer step) as ONE object that both the product's
+``Trainer`` and ``bench.py`` drive, so that what is measured is what a user of ``tools/train_val.py`` gets.
+
+Launched eagerly the iteration is ~1 700 kernel launches and its rate depends on the host CPU (224-278 img/s across boxes for
+the same 25 ms of GPU work).  On a GPU it is therefore REPLAYED from hipGraphs:
+
+* the inputs of a batch -- image tensor, calibration, image sizes, the loader's collated ``[B, 50, ...]`` target arrays --
+  are copied into STATIC device buffers (``load``); nothing about a batch lives in a Python object the graph baked in;
+* ``prepare`` (``pad_targets_from_batch``: the static-shape ground truth with its validity mask), the forward pass, the
+  criterion with the on-device Hungarian matching, the backward pass and the optimizer step are captured once, after a few
+  eagerly launched iterations on REAL batches (they are ordinary training steps: nothing is thrown away);
+* the learning rate is a device scalar per parameter group that torch's schedulers ``fill_`` in place, the Adam step
+  counts live on the device (``optimizer_helper.AdamW`` capturable mode), dropout seeds are device words
+  (``attn_ext`` / ``add_ln_ext`` / ``bias_act_ext``): a replay is a new training step, not a repetition;
+* a batch of another size (the last one of an epoch) runs eagerly on the same parameters and optimizer state.
+
+With a gradient exchange (one process per GPU) the iteration is TWO graphs -- [zero_grad, forward, criterion, backward] and
+[optimizer step] -- with the flat RCCL all-reduce issued eagerly between them (``dist_helper.FlatGradSync`` in its static
+form: it gathers from the addresses the captured backward writes and the captured optimizer reads the reduced slices).
+"""
+import sys
+
+import torch
+
+
+def _tree_map(fn, x):
+    if torch.is_tensor(x):
+        return fn(x)
+    if isinstance(x, dict):
+        return {k: _tree_map(fn, v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_tree_map(fn, v) for v in x)
+    return x
+
+
+def _tree_leaves(x, out=None):
+    out = [] if out is None else out
+    if torch.is_tensor(x):
+        out.append(x)
+    elif isinstance(x, dict):
+        for k in x:
+            _tree_leaves(x[k], out)
+    elif isinstance(x, (list, tuple)):
+        for v in x:
+            _tree_leaves(v, out)
+    return out
+
+
+def _signature(x):
+    return tuple((tuple(t.shape), t.dtype) for t in _tree_leaves(x))
+
+
+class TrainIteration:
+    """model + criterion + optimizer on one device; ``run(batch)`` is one full training iteration.
+
+    ``batch`` is any tree (tuple / dict) of tensors; ``compute(batch) -> (total, losses)`` defaults to the full MonoDETR
+    step on ``(images, calibs, img_sizes, targets)`` with ``prepare(targets)`` applied first.  ``graph``: "off" = eager
+    launches; "auto" = replay, eager if the capture fails; "on" = replay, errors propagate.  ``eager_steps`` iterations run
+    eagerly before the capture (optimizer state, workspaces, geometry caches, library plans)."""
+
+    def __init__(self, model, criterion, optimizer, device, grad_sync=None, pending_sync=None, prepare=None, compute=None,
+                 graph="off", eager_steps=3, capture_error_mode="global", log=None):
+        self.model = self.raw_model = model
+        self.criterion, self.optimizer, self.device = criterion, optimizer, torch.device(device)
+        self.grad_sync, self.pending_sync = grad_sync, pending_sync
+        self.prepare = prepare
+        self.compute = compute or self._compute_full
+        self.want_graph = graph in ("auto", "on", True) and self.device.type == "cuda"
+        self.strict = graph == "on"
+        self.eager_steps = eager_steps
+        self.capture_error_mode = capture_error_mode
+        self.graph = self.graph_opt = self.sync_plan = self.static = self.stream = None
+        self.loss = self.losses = None
+        self.capture_error = ""
+        self.eager_done = 0                                   # eagerly launched iterations so far
+        self.replays = 0
+        self._sig = None
+        self._log = log or (lambda msg: print(msg, file=sys.stderr, flush=True))
+        if self.want_graph:
+            self._device_lr()
+
+    # ---- the iteration itself -----------------------------------------------------------------------------------------
+    def _compute_full(self, batch):
+        images, calibs, img_sizes, targets = batch
+        if self.prepare is not None:
+            targets = self.prepare(targets)
+        out = self.model(images, calibs, targets, img_sizes, dn_args=None)
+        losses = self.criterion(out, targets, None)
+        if hasattr(self.criterion, "weighted_total"):
+            total = self.criterion.weighted_total(losses)           # trainer_helper.py:141-143 as one dot product
+        else:
+            w = self.criterion.weight_dict
+            total = sum(losses[k] * w[k] for k in losses if k in w)
+        return total, losses
+
+    def _forward_backward(self, batch):
+        self.optimizer.zero_grad(set_to_none=True)
+        total, losses = self.compute(batch)
+        total.backward()
+        self.losses = losses
+        return total
+
+    def _step(self, batch):
+        total = self._forward_backward(batch)
+        if self.grad_sync is not None:
+            self.grad_sync.sync()
+        self.optimizer.step()
+        return total
+
+    def _device_lr(self):
+        """Learning rates as device scalars: torch's schedulers update a tensor-valued ``group['lr']`` in place
+        (``LRScheduler._update_lr``), which is what lets a captured optimizer step follow the schedule."""
+        for g in self.optimizer.param_groups:
+            g["capturable"] = True
+            if not torch.is_tensor(g["lr"]):
+                g["lr"] = torch.tensor(float(g["lr"]), dtype=torch.float64, device=self.device)
+
+    # ---- launch modes -------------------------------------------------------------------------------------------------
+    def _eager(self, batch):
+        """One eagerly launched iteration.  When graphs are wanted every eager iteration runs on ONE side stream: autograd
+        binds each parameter's AccumulateGrad node to the stream of its first use, and a capture on any other stream would
+        leave those nodes outside the graph.  Host tensors of the batch (the loader's collated targets) are moved over."""
+        batch = _tree_map(lambda t: t if t.device == self.device else t.to(self.device, non_blocking=True), batch)
+        if self.want_graph:
+            if self.stream is None:
+                self.stream = torch.cuda.Stream(self.device)
+            cur = torch.cuda.current_stream(self.device)
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                for t in _tree_leaves(batch):
+                    if t.is_cuda:
+                        t.record_stream(self.stream)
+                if hasattr(self.optimizer, "flush_replays"):
+                    self.optimizer.flush_replays()
+                total = self._step(batch)
+            cur.wait_stream(self.stream)
+        else:
+            total = self._step(batch)
+        self.eager_done += 1
+        self.loss = total
+        return total
+
+    def load(self, batch):
+        """Copy a batch into the static buffers the graphs read (device-to-device or host-to-device, on the current stream)."""
+        for dst, src in zip(_tree_leaves(self.static), _tree_leaves(batch)):
+            if dst is not src:
+                dst.copy_(src, non_blocking=True)
+
+    def _static_like(self, batch):
+        def mk(t):
+            s = torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=self.device) if t.dim() == 4 and t.is_cuda \
+                else torch.empty(t.shape, dtype=t.dtype, device=self.device)
+            s.copy_(t)
+            return s
+        return _tree_map(mk, batch)
+
+    def capture(self, batch, in_place=False):
+        """Record the iteration on `batch`'s shapes.  in_place: `batch`'s own device tensors become the static buffers
+        (bench.py: one resident synthetic batch)."""
+        if (self.grad_sync is not None and type(self.grad_sync).__name__ != "FlatGradSync") or self.pending_sync not in (None, "flat"):
+            raise RuntimeError("graph replay needs the flat gradient exchange (MDETR_BENCH_SYNC=flat)")
+        if self.model is not self.raw_model:
+            raise RuntimeError("graph replay is not available under the DistributedDataParallel wrapper")
+        while self.eager_done < self.eager_steps:
+            self._eager(batch)
+        from ..attn_ext import _next_seed
+        _next_seed(self.device)                              # the device-resident dropout seed exists before anything is captured
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(self.device)
+        side = self.stream
+        self.static = batch if in_place else self._static_like(batch)
+        self._sig = _signature(self.static)
+        if hasattr(self.optimizer, "flush_replays"):
+            self.optimizer.flush_replays()
+        torch.cuda.synchronize(self.device)
+        graph, graph_opt = torch.cuda.CUDAGraph(), None
+        self.optimizer.zero_grad(set_to_none=True)
+        mode = dict(capture_error_mode=self.capture_error_mode)
+        two = self.grad_sync is not None or self.pending_sync is not None
+        if not two:
+            with torch.cuda.graph(graph, stream=side, **mode):  # same stream as the warm-up: the AccumulateGrad nodes are bound to it
+                self.loss = self._step_captured(self.static)
+        else:
+            from .dist_helper import static_plan
+            with torch.cuda.graph(graph, stream=side, **mode):
+                self.loss = self._forward_backward(self.static)
+            # the gradients now sit at the addresses the captured backward writes to: every later exchange gathers from THOSE
+            # into persistent flat buffers, reduces there, and the captured optimizer reads the reduced slices
+            self.sync_plan = static_plan(self.raw_model.parameters())
+            for ps, src, flat, views in self.sync_plan:
+                for p_, v in zip(ps, views):
+                    p_.grad = v
+            graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_opt, stream=side, pool=graph.pool(), **mode):
+                self.optimizer.step()
+            if self.grad_sync is not None:
+                self.grad_sync._static = self.sync_plan
+        if hasattr(self.optimizer, "uncount_step"):
+            self.optimizer.uncount_step()                    # the capture ran the host bookkeeping of a step no kernel executed
+        torch.cuda.synchronize(self.device)
+        self.graph, self.graph_opt = graph, graph_opt
+        return self
+
+    def _step_captured(self, batch):
+        total = self._forward_backward(batch)
+        self.optimizer.step()
+        return total
+
+    def try_capture(self, batch, in_place=False):
+        """capture(), or the eager step if the capture fails.  With a pending gradient exchange the decision becomes final in
+        attach_process_group() (every rank must take the same one)."""
+        self.capture_error = ""
+        try:
+            self.capture(batch, in_place)
+        except Exception as e:                               # noqa: BLE001 -- whatever the runtime objects to: launch eagerly instead
+            if self.strict:
+                raise
+            self.capture_error = repr(e)[:160]
+            self.graph = self.graph_opt = self.sync_plan = self.static = None
+            if self.grad_sync is not None:
+                self.grad_sync._static = None
+            self.want_graph = False
+            torch.cuda.synchronize(self.device)
+            import traceback
+            self._log("graph capture not used (%s): eager launches\n%s" % (self.capture_error, "".join(traceback.format_exc().splitlines(True)[-14:])))
+        return self.launch_mode()
+
+    def launch_mode(self):
+        if self.graph is None:
+            return "eager" + (" (graph capture failed: %s)" % self.capture_error if self.capture_error else "")
+        return ("one hipGraph replay per iteration" if self.graph_opt is None else
+                "two hipGraph replays per iteration (forward + backward | optimizer) around the eager RCCL gradient all-reduce")
+
+    def agree_on_launch_mode(self):
+        """One decision for all ranks: graphs only if every rank captured them."""
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return self.launch_mode()
+        flag = torch.tensor([1 if self.graph is not None else 0], device=self.device, dtype=torch.int32)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if int(flag) == 0 and self.graph is not None:
+            self.capture_error = "capture failed on another rank"
+            self.graph = self.graph_opt = self.sync_plan = self.static = None
+            self.want_graph = False
+            if self.grad_sync is not None:
+                self.grad_sync._static = None
+        return self.launch_mode()
+
+    def attach_process_group(self):
+        """The N > 1 half of a construction that captured BEFORE torch.distributed was up: rank 0's parameters and optimizer
+        state to everybody, the gradient exchange (gathering from the captured backward's gradient tensors if the step replays
+        graphs), and one decision for all ranks."""
+        from .dist_helper import BucketedGradSync, FlatGradSync, broadcast_parameters
+        if self.pending_sync is None:
+            return self.launch_mode()
+        self.agree_on_launch_mode()
+        broadcast_parameters(self.raw_model, extra=[t for st in self.optimizer.state.values() for t in st.values() if torch.is_tensor(t)] +
+                             [t for b in (getattr(self.optimizer, "_flat", None) or (None, []))[1] for t in b.values() if torch.is_tensor(t)])
+        self.grad_sync = (BucketedGradSync if self.pending_sync == "bucketed" else FlatGradSync)(self.raw_model.parameters())
+        if self.graph is not None:
+            self.grad_sync._static = self.sync_plan
+        self.pending_sync = None
+        return self.launch_mode()
+
+    def replay(self):
+        self.graph.replay()
+        if self.graph_opt is not None:
+            self.grad_sync.sync()
+            self.graph_opt.replay()
+        self.replays += 1
+        if hasattr(self.optimizer, "note_replay"):
+            self.optimizer.note_replay()
+        return self.loss
+
+    def run(self, batch):
+        """One training iteration on `batch`; returns the total loss (a device scalar; ``self.losses`` holds the dict)."""
+        if self.graph is None and self.want_graph and self.eager_done >= self.eager_steps:
+            self.try_capture(batch)
+            if self.graph_opt is not None or self.grad_sync is not None:
+                self.agree_on_launch_mode()
+        if self.graph is not None:
+            if _signature(batch) == self._sig:
+                self.load(batch)
+                return self.replay()
+            return self.eager_iteration(batch)               # another batch size: the same step, launched eagerly
+        return self._eager(batch)
+
+    def eager_iteration(self, batch=None):
+        """One eagerly launched iteration of a step that normally replays graphs (a ragged last batch; kernel timing after
+        bench.py's timed region): fresh gradient tensors, so the exchange must gather from them, not from the captured
+        backward's."""
+        static = None
+        if self.grad_sync is not None and getattr(self.grad_sync, "_static", None) is not None:
+            static, self.grad_sync._static = self.grad_sync._static, None
+        try:
+            return self._eager(self.static if batch is None else batch)
+        finally:
+            if static is not None:
+                self.grad_sync._static = static

@@ -8,7 +8,11 @@ What differs from the reference loop (trainer_helper.py:116-173), and why:
     ``.item()`` on each of the ~26 entries every iteration (26 synchronisations per step);
   * with more than one process (torchrun, one per GPU) gradients are averaged by one flat all-reduce per dtype
     (``dist_helper.FlatGradSync``) after the backward pass; the reference uses ``nn.DataParallel``
-    (tools/train_val.py:55).
+    (tools/train_val.py:55);
+  * on a GPU the iteration is REPLAYED from hipGraphs (``step_helper.TrainIteration``, the object ``bench.py`` times):
+    the first iterations of a run are launched eagerly on real batches, then the iteration is captured once and every
+    later batch is copied into static device buffers and replayed with one launch (two around the gradient exchange).
+    ``trainer.launch: eager`` in the yaml (or MDETR_TRAIN_LAUNCH=eager) keeps the ~1 700 eager launches per iteration.
 ``prepare_targets`` is kept for callers that want the reference's ragged lists.
 """
 import os
@@ -18,6 +22,10 @@ import torch
 
 from ..monodetr.monodetr import pad_targets_from_batch
 from .save_helper import get_checkpoint_state, load_checkpoint, save_checkpoint
+from .step_helper import TrainIteration
+
+# what ``pad_targets_from_batch`` reads of the loader's collated targets (kitti_dataset.py:299-312)
+TARGET_KEYS = ('labels', 'boxes', 'boxes_3d', 'depth', 'size_3d', 'heading_bin', 'heading_res', 'mask_2d')
 
 
 class Trainer(object):
@@ -33,6 +41,7 @@ class Trainer(object):
         self.tester = None
         self.log_every = log_every
         self.grad_sync = None
+        self.iteration = None
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             from .dist_helper import FlatGradSync, broadcast_parameters
             broadcast_parameters(self.model)
@@ -84,26 +93,33 @@ class Trainer(object):
         self.best_result, self.best_epoch = best_result, best_epoch
         return None
 
+    def _iteration(self):
+        """The step object, built on first use (after a resume / pretrain load, so that it sees the loaded optimizer)."""
+        if self.iteration is None:
+            launch = os.environ.get("MDETR_TRAIN_LAUNCH", self.cfg.get("launch", "graph" if self.device.type == "cuda" else "eager"))
+            if self.cfg.get("use_dn"):
+                raise NotImplementedError("denoising queries (use_dn) are off in configs/monodetr.yaml and not mirrored")
+            self.iteration = TrainIteration(
+                self.model, self.detr_loss, self.optimizer, self.device, grad_sync=self.grad_sync, prepare=pad_targets_from_batch,
+                graph="auto" if launch == "graph" else "off",
+                # a live RCCL process group's watchdog thread polls events while the capture is under way: only THIS thread's
+                # calls are checked against the capture
+                capture_error_mode="thread_local" if self.grad_sync is not None else "global",
+                log=lambda msg: self.logger.info(msg))
+        return self.iteration
+
     def train_step(self, inputs, calibs, targets, info=None):
         """One iteration on a collated batch; returns the dict of unweighted loss tensors (on the device)."""
         inputs, calibs = inputs.to(self.device, non_blocking=True), calibs.to(self.device, non_blocking=True)
         if inputs.is_cuda:
             inputs = inputs.contiguous(memory_format=torch.channels_last)
-        targets = {k: v.to(self.device, non_blocking=True) for k, v in targets.items()}
+        it = self._iteration()
+        # (host tensors: the graphs' static device buffers are filled straight from the collated arrays; an eagerly launched
+        # iteration moves them over itself)
+        gt = {k: targets[k] for k in TARGET_KEYS}
         img_sizes = targets['img_size']
-        if self.cfg.get("use_dn"):
-            raise NotImplementedError("denoising queries (use_dn) are off in configs/monodetr.yaml and not mirrored")
-        gt = pad_targets_from_batch(targets)
-        self.optimizer.zero_grad()
-        outputs = self.model(inputs, calibs, gt, img_sizes, dn_args=None)
-        losses = self.detr_loss(outputs, gt, None)
-        weights = self.detr_loss.weight_dict
-        total = sum(losses[k] * weights[k] for k in losses if k in weights)
-        total.backward()
-        if self.grad_sync is not None:
-            self.grad_sync.sync()
-        self.optimizer.step()
-        return losses
+        it.run((inputs, calibs, img_sizes, gt))
+        return it.losses
 
     def train_one_epoch(self, epoch):
         torch.set_grad_enabled(True)

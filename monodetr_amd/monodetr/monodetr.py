@@ -248,6 +248,16 @@ def pad_targets(targets, kmax=None):
     return gt
 
 
+_CONSTS = {}
+
+
+def _device_const(values, dtype, device):
+    key = (values, dtype, str(device))
+    if key not in _CONSTS:
+        _CONSTS[key] = torch.tensor(values, dtype=dtype, device=device)
+    return _CONSTS[key]
+
+
 def pad_targets_from_batch(targets):
     """The loader's collated targets (``[B, 50, ...]`` tensors + ``mask_2d``, kitti_dataset.py:299-312) -> the padded
     dict of ``pad_targets`` with K = 50, WITHOUT leaving the device: where the reference's trainer builds ragged
@@ -265,8 +275,12 @@ def pad_targets_from_batch(targets):
         t = targets[key]
         t = t.reshape(B, K, -1)
         t = torch.gather(t, 1, order[..., None].expand(-1, -1, t.shape[-1])).to(dtype)
-        pad = torch.as_tensor(fill, dtype=dtype, device=t.device).expand_as(t)
-        return torch.where(valid[..., None], t, pad)
+        if isinstance(fill, tuple) and len(set(fill)) == 1:
+            fill = fill[0]
+        if isinstance(fill, tuple):                                        # a per-column constant: cached on the device, so
+            pad = _device_const(fill, dtype, t.device).expand_as(t)        # that a captured graph holds no host-to-device copy
+            return torch.where(valid[..., None], t, pad)
+        return t.masked_fill(~valid[..., None], fill)
 
     return {
         "labels": take("labels", torch.int64, 0)[..., 0],

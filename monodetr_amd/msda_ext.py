@@ -78,7 +78,6 @@ def _stream(device):
 # once per resolution); a caller that builds fresh tensors every call pays one small synchronising copy per call.  (An
 # earlier version keyed a dict on data_ptr / _version: the caching allocator hands the address of a freed shapes tensor
 # to the next one, whose contents may differ.)  One scratch buffer per device for the workspace-based backward.
-_workspaces = {}
 
 
 def _geometry_on_host(spatial_shapes, level_start_index):
@@ -94,10 +93,10 @@ def _geometry_on_host(spatial_shapes, level_start_index):
 
 
 def _workspace(device, nbytes):
-    ws = _workspaces.get(device)
-    if ws is None or ws.numel() < nbytes:
-        ws = _workspaces[device] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    return ws
+    # per (device, stream); zero on (re)allocation: msda_fused keeps a cookie in the header saying that its `far` region is all
+    # zero between calls, and recycled pool memory could hold a stale one
+    from . import _workspace as W
+    return W.get("msda", device, nbytes, zero=True)
 
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):

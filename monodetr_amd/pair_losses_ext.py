@@ -12,7 +12,6 @@ from . import _capi
 ROWS = ("loss_ce", "loss_center", "loss_bbox", "loss_giou", "loss_depth", "loss_dim", "loss_angle",
         "class_error", "cardinality_error")
 
-_workspaces = {}
 _backend = None               # tests substitute the host build of the same arithmetic (tests/native)
 
 
@@ -21,10 +20,8 @@ def _lib():
 
 
 def _workspace(device, nbytes):
-    ws = _workspaces.get(device)
-    if ws is None or ws.numel() < nbytes:
-        ws = _workspaces[device] = torch.zeros(max(nbytes, 4096), dtype=torch.uint8, device=device)   # zero on first use
-    return ws
+    from . import _workspace as W
+    return W.get("pair_losses", device, nbytes, zero=True, floor=4096)   # zero on first use
 
 
 def _stream(device):

@@ -11,7 +11,6 @@ _backend = None               # tests substitute the CPU emulation of the same k
 # MDETR_SMALL_WGRAD=1 routes token_linear's backward through the kernel where the shape qualifies
 ENABLED = os.environ.get("MDETR_SMALL_WGRAD") == "1"
 MAX_ROWS = 8192
-_workspaces = {}
 
 
 def _lib():
@@ -42,10 +41,8 @@ def small_wgrad(dy, x, out_dtype=None):
     K = x.shape[1]
     lib = _lib()
     need = lib.mdetr_small_wgrad_workspace_bytes(T, N, K)
-    key = (dy.device, torch.cuda.current_stream(dy.device).cuda_stream if dy.is_cuda else 0)   # per stream: calls on different streams run concurrently
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _workspaces[key] = torch.empty(max(need, 8 << 20), dtype=torch.uint8, device=dy.device)
+    from . import _workspace as W
+    ws = W.get("small_wgrad", dy.device, need, floor=8 << 20)       # per stream: calls on different streams run concurrently
     out = torch.empty(N * K + N, dtype=out_dtype, device=dy.device)
     code = lambda dt: _capi.MDETR_BF16 if dt == torch.bfloat16 else _capi.MDETR_F32      # noqa: E731
     dev, stream = (dy.device.index, torch.cuda.current_stream(dy.device).cuda_stream) if dy.is_cuda else (-1, None)

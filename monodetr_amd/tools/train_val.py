@@ -84,7 +84,7 @@ def main(argv=None):
     if args.evaluate_only:
         logger.info('###################  Evaluation Only  ##################')
         tester.test()
-        return
+        return None
     # the kernel families bench.py measures are what training runs with (trainer.kernels: default = none of them; any
     # MDETR_<FAMILY>=1 in the environment replaces the list); they need the GPU
     from monodetr_amd import kernel_families
@@ -108,6 +108,7 @@ def main(argv=None):
         logger.info('Batch Size: %d' % cfg['dataset']['batch_size'])
         logger.info('Split: %s' % cfg['dataset']['test_split'])
         tester.test()
+    return trainer
 
 
 if __name__ == '__main__':

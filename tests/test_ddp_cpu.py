@@ -189,3 +189,50 @@ def test_two_rank_ddp_step_matches_manual_gradient_average(tmp_path):
         assert res["n_grads"] > 300
         assert all(n.startswith("label_enc") or ".sa_v_proj." in n or "decoder.query_scale" in n or "decoder.ref_point_head" in n
                    for n in res["unused"]), res["unused"]
+
+
+def _worker4(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func as F_
+        from oracle import msda_oracle
+        F_.MSDA = msda_oracle.OracleMSDA                     # test-only CPU backend
+        import bench
+        # the product's step object on four ranks, flat exchange, a different shard per rank
+        step = bench.TrainStep(torch.device("cpu"), 1, "fp32", ddp="flat", local_rank=rank, size=(64, 224), switches=())
+        step()
+        flat = torch.cat([p.detach().reshape(-1) for p in step.raw_model.parameters()])
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        same = all(torch.equal(gathered[0], g) for g in gathered[1:])
+        # the gradient every rank applied is the mean of the four local ones
+        g = next(p.grad for p in step.raw_model.parameters() if p.grad is not None).clone()
+        gs = [torch.empty_like(g) for _ in range(world)]
+        dist.all_gather(gs, g)
+        same_grad = all(torch.equal(gs[0], x) for x in gs[1:])
+        # a capture that failed on ONE rank: every rank launches eagerly (TrainIteration.agree_on_launch_mode)
+        step.graph = None if rank == 2 else object()
+        step.static = object()
+        mode = step.agree_on_launch_mode()
+        diverged_ok = step.graph is None and mode.startswith("eager") and (rank == 2 or "another rank" in mode)
+        # ... and one that succeeded everywhere stays
+        step.capture_error, step.graph = "", object()
+        kept = step.agree_on_launch_mode() == "one hipGraph replay per iteration" and step.graph is not None
+        step.graph = None
+        step()                                                  # the eager path still works afterwards
+        torch.save(dict(same=same, same_grad=same_grad, diverged_ok=diverged_ok, kept=kept), os.path.join(out_dir, "q%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_four_rank_flat_exchange_and_rank_divergent_capture_failure(tmp_path):
+    world, port = 4, _free_port()
+    mp.spawn(_worker4, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = torch.load(os.path.join(str(tmp_path), "q%d.pt" % r))
+        assert res == dict(same=True, same_grad=True, diverged_ok=True, kept=True), (r, res)

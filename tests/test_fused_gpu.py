@@ -490,7 +490,7 @@ def test_train_val_entry_point_end_to_end(tmp_path, monkeypatch):
     from monodetr_amd.tools import train_val
     monkeypatch.chdir(tmp_path)
     root = str(tmp_path / 'kitti')
-    ids = kitti_synth.make_tree(root, n_images=4, seed=5, occ_choices=[0, 0, 1])
+    ids = kitti_synth.make_tree(root, n_images=12, seed=5, occ_choices=[0, 0, 1])
     cfg = {
         'random_seed': 444, 'model_name': 'monodetr',
         'dataset': {'type': 'KITTI', 'root_dir': root, 'train_split': 'train', 'test_split': 'val', 'batch_size': 2, 'use_3d_center': True,
@@ -507,8 +507,12 @@ def test_train_val_entry_point_end_to_end(tmp_path, monkeypatch):
     yaml.safe_dump(cfg, open(path, 'w'))
     from monodetr_amd import group_norm_ext, kernel_families
     try:
-        train_val.main(['--config', path])
+        trainer = train_val.main(['--config', path])
         assert group_norm_ext.ENABLED                                   # the entry point trains with the committed kernel families
+        # ... and replays the iteration from a hipGraph (helpers/step_helper.TrainIteration, the object bench.py times): three
+        # eager iterations on real batches, the capture, then one launch per batch
+        n_iter = 2 * len(trainer.train_loader)
+        assert trainer.iteration.graph is not None and trainer.iteration.replays == n_iter - 3, (trainer.iteration.launch_mode(), trainer.iteration.replays)
         _check_train_val_outputs(tmp_path, ids)
         train_val.main(['--config', path, '-e'])                        # evaluation only, from checkpoint_epoch_2.pth
     finally:

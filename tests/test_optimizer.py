@@ -164,3 +164,32 @@ def test_fused_adamw_equals_foreach_adamw_on_mixed_layouts_and_dtypes(backend):
     ob.step(); oc.step()
     for y, z in zip(pb[:4], pc[:4]):
         assert torch.equal(y.detach(), z.detach())
+
+
+def test_replay_bookkeeping_and_checkpoint_sanitisation():
+    """helpers/step_helper.TrainIteration replays a captured ``step()``: the device counters advance by themselves, the host
+    counts (what a checkpoint saves) are brought up to date lazily; a device-resident learning rate is saved as a float and
+    the device counters stay out of the checkpoint."""
+    from monodetr_amd.helpers.optimizer_helper import AdamW
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(5, 3))
+    b = torch.nn.Parameter(torch.randn(3))
+    opt = AdamW([{'params': [b], 'weight_decay': 0}, {'params': [w], 'weight_decay': 1e-4}], lr=1e-3, capturable=True)
+    for g in opt.param_groups:
+        g['lr'] = torch.tensor(1e-3, dtype=torch.float64)
+    ref_w, ref_b = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    ref = AdamW([{'params': [ref_b], 'weight_decay': 0}, {'params': [ref_w], 'weight_decay': 1e-4}], lr=1e-3)
+    for i in range(6):
+        gw, gb = torch.randn(5, 3), torch.randn(3)
+        w.grad, b.grad, ref_w.grad, ref_b.grad = gw.clone(), gb.clone(), gw.clone(), gb.clone()
+        opt.step()
+        ref.step()
+        if i == 2:                         # a capture: the host bookkeeping of a step whose kernels do not run is taken back ...
+            opt.uncount_step()
+            opt.note_replay()              # ... and the replay that follows is counted lazily
+    assert torch.allclose(w, ref_w, atol=1e-7) and torch.allclose(b, ref_b, atol=1e-7)
+    opt.note_replay(); opt.note_replay()
+    sd = opt.state_dict()
+    assert {int(s['step']) for s in sd['state'].values()} == {8}
+    assert all(isinstance(g['lr'], float) and 'step_dev' not in g for g in sd['param_groups'])
+    assert all(torch.is_tensor(g['lr']) and 'step_dev' in g for g in opt.param_groups)      # the live groups keep theirs

@@ -1,0 +1,186 @@
+"""The product's launch mode on a GPU: ``helpers/step_helper.TrainIteration`` (what ``Trainer.train_one_epoch`` and ``bench.py``
+both drive) replays the training iteration from hipGraphs.  Held to the eagerly launched iteration on a DIFFERENT batch every
+step: different images, different object counts (0 ... 50 per image), a learning-rate change on the way, a ragged batch in
+the middle (launched eagerly, on the same state), garbage written over freed pool memory between replays."""
+import math
+import os
+
+import pytest
+import torch
+
+from model_init import MODEL_CFG, disable_dropout_, synthetic_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def collated_batch(B, seed, H=384, W=1280, kmax=50):
+    """What the loader hands to the trainer (kitti_dataset.py:299-312 collated): images on the device, [B, 50, ...] target
+    arrays + mask_2d on the host.  Objects sit in arbitrary slots of the 50; images may have none."""
+    images, calibs, img_sizes, targets = synthetic_batch(B, H, W, seed=seed, max_objs=12)
+    g = torch.Generator().manual_seed(seed + 77)
+    out = {'labels': torch.zeros(B, kmax, dtype=torch.int8), 'boxes': torch.zeros(B, kmax, 4), 'boxes_3d': torch.zeros(B, kmax, 6),
+           'depth': torch.zeros(B, kmax, 1), 'size_3d': torch.zeros(B, kmax, 3), 'heading_bin': torch.zeros(B, kmax, 1, dtype=torch.int64),
+           'heading_res': torch.zeros(B, kmax, 1), 'mask_2d': torch.zeros(B, kmax, dtype=torch.bool), 'img_size': img_sizes}
+    for b, t in enumerate(targets):
+        n = len(t['labels'])
+        if seed % 5 == 0 and b == 0:
+            continue                                                      # an image without objects
+        slots = torch.randperm(kmax, generator=g)[:n].sort().values
+        for k in ('labels', 'boxes', 'boxes_3d', 'depth', 'size_3d', 'heading_bin', 'heading_res'):
+            out[k][b, slots] = t[k].to(out[k].dtype)
+        out['mask_2d'][b, slots] = True
+    return images, calibs, out
+
+
+def build(dev, graph, switches):
+    import bench
+    from monodetr_amd.helpers.optimizer_helper import build_optimizer
+    from monodetr_amd.helpers.precision import to_bf16_body
+    from monodetr_amd.helpers.step_helper import TrainIteration
+    from monodetr_amd.monodetr import build_monodetr
+    from monodetr_amd.monodetr.monodetr import pad_targets_from_batch
+    bench.apply_switches(switches)
+    torch.manual_seed(444)
+    model, criterion = build_monodetr(dict(MODEL_CFG, device='cuda', dropout=0.0))
+    model.to(dev).to(memory_format=torch.channels_last)
+    to_bf16_body(model)
+    disable_dropout_(model).train()
+    criterion.train()
+    criterion.fused_pair_losses = criterion.matcher.fused_cost = "MDETR_FUSED_LOSSES" in switches
+    opt = build_optimizer({'type': 'adamw', 'lr': 2e-4, 'weight_decay': 1e-4, 'fused': "MDETR_FUSED_ADAMW" in switches}, model)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda e: 0.1 ** (e >= 1))
+    it = TrainIteration(model, criterion, opt, dev, prepare=pad_targets_from_batch, graph="on" if graph else "off")
+    return it, sched
+
+
+def run_sequence(dev, graph, switches, n_steps=24, poison=False):
+    from monodetr_amd.helpers.trainer_helper import TARGET_KEYS
+    it, sched = build(dev, graph, switches)
+    losses, modes = [], []
+    for i in range(n_steps):
+        B = 1 if i == 13 else 2                                           # one ragged batch: eager launches on the same state
+        images, calibs, t = collated_batch(B, seed=1000 + i)
+        images = images.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        if i == 16:
+            sched.step()                                                  # lr x 0.1: an in-place fill of the device scalar
+        before = it.replays
+        total = it.run((images, calibs.to(dev), t['img_size'], {k: t[k] for k in TARGET_KEYS}))
+        losses.append(float(total))
+        modes.append(it.replays > before)
+        if poison:
+            del images, calibs
+            junk = [torch.full((8 << 20,), float('nan'), device=dev) for _ in range(4)]     # recycled pool memory is garbage
+            del junk
+    torch.cuda.synchronize()
+    sd = it.optimizer.state_dict()
+    steps = {int(s['step']) for s in sd['state'].values()}
+    params = {n: p.detach().float().clone() for n, p in it.raw_model.named_parameters()
+              if n in ("class_embed.2.bias", "depthaware_transformer.encoder.layers.0.linear1.weight", "backbone.0.body.layer4.2.conv3.weight",
+                       "depthaware_transformer.decoder.layers.2.cross_attn.sampling_offsets.weight")}
+    lr = {float(g['lr']) for g in sd['param_groups']}
+    return losses, modes, steps, params, lr, it
+
+
+def test_replayed_training_iteration_follows_the_eager_one_on_changing_batches():
+    import bench
+    dev = torch.device("cuda", 0)
+    switches = bench.committed_switches("bf16")[0]
+    try:
+        e, me, se, pe, lre, _ = run_sequence(dev, False, switches)
+        e2, _, _, pe2, _, _ = run_sequence(dev, False, switches)
+        g, mg, sg, pg, lrg, it = run_sequence(dev, True, switches, poison=True)
+    finally:
+        bench.apply_switches(set())
+    assert not any(me) and it.graph is not None
+    # three eager iterations, the capture on the fourth batch, then replays -- except the ragged batch
+    assert mg == [False] * 3 + [True] * 10 + [False] + [True] * 10, mg
+    assert all(math.isfinite(x) for x in g)
+    # host-side step counts (what a checkpoint saves) follow the replays; the learning rate is saved as a float
+    assert se == sg == {24} and lre == lrg == {2e-5}, (se, sg, lre, lrg)
+    spread = max(abs(a - b) / abs(a) for a, b in zip(e, e2))
+    dist = max(abs(a - b) / abs(a) for a, b in zip(e, g))
+    print("eager", e, "\ngraph", g, "\nspread %.3g, graph-to-eager %.3g" % (spread, dist))
+    assert dist <= max(4.0 * spread, 4e-2), (e, e2, g)
+    for n in pe:
+        a, b, c = pe[n], pg[n], pe2[n]
+        assert (a - b).norm() <= max(4.0 * (a - c).norm(), 2e-2 * a.norm()), n
+
+
+def test_graph_sees_each_batch_not_the_captured_one():
+    """Same weights, optimizer frozen (lr = 0): the replayed iteration's loss on batch i equals the eager loss on batch i."""
+    import bench
+    from monodetr_amd.helpers.trainer_helper import TARGET_KEYS
+    dev = torch.device("cuda", 0)
+    switches = bench.committed_switches("bf16")[0]
+    try:
+        it, _ = build(dev, True, switches)
+        for g_ in it.optimizer.param_groups:
+            g_['lr'].fill_(0.0)
+            g_['weight_decay'] = 0.0
+        ref, _ = build(dev, False, switches)
+        ref.raw_model.load_state_dict(it.raw_model.state_dict())
+        for g_ in ref.optimizer.param_groups:
+            g_['lr'] = 0.0
+        worst = 0.0
+        for i in range(9):
+            images, calibs, t = collated_batch(2, seed=50 + i)
+            images = images.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            batch = (images, calibs.to(dev), t['img_size'], {k: t[k] for k in TARGET_KEYS})
+            a = float(it.run(batch))
+            d = {k: float(v) for k, v in it.losses.items()}
+            b = float(ref.run(batch))
+            d2 = {k: float(v) for k, v in ref.losses.items()}
+            worst = max(worst, abs(a - b) / abs(b))
+            assert abs(a - b) <= 2e-3 * abs(b), (i, a, b)
+            for k in d2:
+                assert abs(d[k] - d2[k]) <= 5e-3 * max(1.0, abs(d2[k])), (i, k, d[k], d2[k])
+        assert it.replays == 6
+        print("worst relative difference of the total loss, replay vs eager on the same batch: %.3g" % worst)
+    finally:
+        bench.apply_switches(set())
+
+
+def _pg_child():
+    import bench
+    from monodetr_amd.helpers.dist_helper import FlatGradSync
+    from monodetr_amd.helpers.trainer_helper import TARGET_KEYS
+    dev = torch.device("cuda", 0)
+    switches = bench.committed_switches("bf16")[0]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29547")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    it, _ = build(dev, True, switches)
+    it.grad_sync = FlatGradSync(it.raw_model.parameters())
+    it.capture_error_mode = os.environ.get("MDETR_TEST_CAPTURE_MODE", "thread_local")
+    it.strict = False
+    seq = []
+    for i in range(8):
+        images, calibs, t = collated_batch(2, seed=300 + i)
+        images = images.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        seq.append(float(it.run((images, calibs.to(dev), t['img_size'], {k: t[k] for k in TARGET_KEYS}))))
+    torch.cuda.synchronize()
+    print("PG-CHILD launch=%r replays=%d finite=%s" % (it.launch_mode(), it.replays, all(math.isfinite(x) for x in seq)), flush=True)
+    torch.distributed.destroy_process_group()
+
+
+def test_trainer_two_graph_form_with_a_live_process_group():
+    """One process per GPU: the Trainer's process group exists BEFORE the capture (bench.py captures first).  With the
+    capture checked per thread (capture_error_mode="thread_local") RCCL's watchdog thread does not abort it.  In a child
+    process: a watchdog abort takes the process down."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]))
+    done = subprocess.run([sys.executable, os.path.abspath(__file__), "--pg-child"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                          text=True, timeout=900)
+    tail = done.stdout[-3000:]
+    print(tail)
+    assert done.returncode == 0, tail
+    line = [ln for ln in done.stdout.splitlines() if ln.startswith("PG-CHILD")][-1]
+    assert "two hipGraph replays" in line and "replays=5" in line and "finite=True" in line, line
+
+
+if __name__ == "__main__":
+    import sys
+    if "--pg-child" in sys.argv:
+        _pg_child()
