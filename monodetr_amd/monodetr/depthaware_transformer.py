@@ -85,6 +85,7 @@ class _LevelPos(torch.autograd.Function):
     def forward(ctx, level_embed, dtype, *pos):
         ctx.counts = [p.shape[-2] * p.shape[-1] for p in pos]
         ctx.embed_dtype = level_embed.dtype
+        ctx.pos_meta = [(p.shape, p.dtype) for p in pos]
         return torch.cat([p.flatten(2).transpose(1, 2) + level_embed[l].view(1, 1, -1) for l, p in enumerate(pos)], 1).to(dtype)
 
     @staticmethod
@@ -94,13 +95,20 @@ class _LevelPos(torch.autograd.Function):
         B, S, C = g.shape
         g = g.contiguous()
         flat = g.view(B, S * C)
-        over_batch = (colsum_ext.column_sum(flat) if colsum_ext.supported(flat) else flat.float().sum(0)).view(S, C)
+        wide = torch.float64 if g.dtype == torch.float64 else torch.float32
+        over_batch = (colsum_ext.column_sum(flat) if colsum_ext.supported(flat) else flat.to(wide).sum(0)).view(S, C)
         rows, start = [], 0
         for n in ctx.counts:
             part = over_batch[start:start + n]
             rows.append(colsum_ext.column_sum(part) if colsum_ext.supported(part) else part.sum(0))
             start += n
-        return (torch.stack(rows).to(ctx.embed_dtype), None) + (None,) * len(ctx.counts)
+        # a LEARNED position embedding (position_embedding: learned / v3, position_encoding.py:58-84) needs its gradient too:
+        # the slice of g that belongs to the level, back in the map's layout (the sine embedding is a constant: None)
+        gpos, start = [], 0
+        for l, (n, (shape, dt)) in enumerate(zip(ctx.counts, ctx.pos_meta)):
+            gpos.append(g[:, start:start + n].transpose(1, 2).reshape(shape).to(dt) if ctx.needs_input_grad[2 + l] else None)
+            start += n
+        return (torch.stack(rows).to(ctx.embed_dtype), None) + tuple(gpos)
 
 
 def _get_clones(module, N):

@@ -26,6 +26,34 @@ def test_level_pos_matches_the_broadcast_adds():
     assert emb2.grad.dtype == torch.float32 and (emb2.grad - ref_emb.grad).abs().max() <= 2e-2 * ref_emb.grad.abs().max()
 
 
+def test_level_pos_back_propagates_into_a_learned_position_embedding():
+    """position_embedding: learned (position_encoding.py:58-84): row_embed / col_embed receive their gradient through
+    ``pos_l + level_embed[l]`` as in the reference (depthaware_transformer.py:215-218); float64 stays float64."""
+    from monodetr_amd.monodetr.position_encoding import PositionEmbeddingLearned
+    from monodetr_amd.utils.misc import NestedTensor
+    torch.manual_seed(4)
+    shapes = [(6, 10), (3, 5)]
+
+    def run(custom):
+        torch.manual_seed(5)
+        pe = PositionEmbeddingLearned(8).double()
+        emb = torch.randn(2, 16, dtype=torch.float64, requires_grad=True, generator=torch.Generator().manual_seed(6))
+        pos = [pe(NestedTensor(torch.zeros(2, 3, h, w, dtype=torch.float64), torch.zeros(2, h, w, dtype=torch.bool))) for h, w in shapes]
+        assert all(p.requires_grad for p in pos)
+        if custom:
+            out = _LevelPos.apply(emb, torch.float64, *pos)
+        else:
+            out = torch.cat([p.flatten(2).transpose(1, 2) + emb[l].view(1, 1, -1) for l, p in enumerate(pos)], 1)
+        dy = torch.randn(out.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(7))
+        out.backward(dy)
+        return out.detach(), emb.grad, pe.row_embed.weight.grad, pe.col_embed.weight.grad
+
+    got, want = run(True), run(False)
+    assert got[2] is not None and got[3] is not None
+    for a, b in zip(got, want):
+        assert a.dtype == torch.float64 and (a - b).abs().max() <= 1e-13 * max(1.0, b.abs().max().item())
+
+
 def test_linear_keeps_nn_linear_semantics_and_keys():
     torch.manual_seed(1)
     a, b = Linear(8, 5), torch.nn.Linear(8, 5)

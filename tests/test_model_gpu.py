@@ -230,3 +230,100 @@ def test_bf16_body_outputs_and_gradients_vs_fp32(switches):
         if nn >= 1e-1 * biggest:
             assert c >= 0.99, (c, n, nn / biggest)
     assert len(worst) > 250
+
+
+# ---- BASELINE configs[4]'s shape: 3 x 512 x 1760, num_queries 100 (1 100 training queries), S = 18 704 tokens ---------------
+def _hires_losses_on_reference_assignment(model, criterion, golden, x, calibs, targets, img_sizes):
+    out = model(x, calibs, targets, img_sizes)
+    layers = [{k: v for k, v in out.items() if k not in ("aux_outputs", "_levels")}] + list(out["aux_outputs"])
+    num_boxes = float(sum(len(t["labels"]) for t in targets) * 11)
+    losses = {}
+    for li, layer in enumerate(layers):
+        ref_idx = [(golden[f"f64/match{li}/0/src"], golden[f"f64/match{li}/0/tgt"])]
+        for name in criterion.losses:
+            if li > 0 and name == "depth_map":
+                continue
+            kw = {"log": False} if (li > 0 and name == "labels") else {}
+            ld = criterion.get_loss(name, layer, targets, ref_idx, num_boxes, **kw)
+            losses.update(ld if li == 0 else {"%s_%d" % (k, li - 1): v for k, v in ld.items()})
+    return out, losses
+
+
+def test_hires_100_query_model_matches_the_reference_classes():
+    """The fp32 model on the GPU (HIP MSDA / attention / matching in the loop) at 512 x 1760 with 100 queries per group against
+    tests/golden/model_hires_b1.npz, recorded from the reference's own classes with its two shape literals set to this
+    configuration (tests/golden/make_model_golden_hires.py): forward within 1e-3 (north_star), every loss within 1e-3, every
+    parameter's gradient norm within 2 % of the float64 fingerprints; the on-device matching finds the recorded assignment."""
+    from monodetr_amd.monodetr import build_monodetr
+    golden = load_golden("model_hires_b1")
+    cfg = load_cfg(device="cuda")
+    cfg["num_queries"] = 100
+    torch.manual_seed(0)
+    model, criterion = build_monodetr(cfg)
+    disable_dropout_(name_seeded_init_(model)).cuda().train()
+    criterion.train()
+    images, calibs, img_sizes, targets = synthetic_batch(1, 512, 1760, seed=11, device="cuda", max_objs=10)
+    out, losses = _hires_losses_on_reference_assignment(model, criterion, golden, images, calibs, targets, img_sizes)
+    assert out["pred_logits"].shape == (1, 1100, 3) and out["pred_depth_map_logits"].shape == (1, 81, 32, 110)
+    for k in ("pred_logits", "pred_boxes", "pred_3d_dim", "pred_depth", "pred_angle", "pred_depth_map_logits"):
+        for tag in ("f32", "f64"):
+            ref = golden[f"{tag}/{k}"]
+            err = (out[k].detach().cpu().double() - ref.double()).abs().max().item()
+            assert err < 1e-3 * max(1.0, ref.abs().max().item()), (tag, k, err)
+    for i, aux in enumerate(out["aux_outputs"]):
+        for k, v in aux.items():
+            ref = golden[f"f32/aux{i}/{k}"]
+            assert (v.detach().cpu() - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item()), (i, k)
+    for k, v in losses.items():
+        ref = float(golden["f64/loss/" + k])
+        assert abs(float(v) - ref) < 1e-3 * max(1.0, abs(ref)), (k, float(v), ref)
+    total = sum(losses[k] * criterion.weight_dict[k] for k in losses if k in criterion.weight_dict)
+    assert abs(float(total) - float(golden["f64/total_loss"])) < 1e-3 * float(golden["f64/total_loss"])
+    total.backward()
+    fp = grad_fingerprint(model)
+    names = [str(n) for n in golden["f64/grad_names"]]
+    assert sorted(fp) == sorted(names)
+    worst = 0.0
+    for n, (norm, proj) in zip(names, golden["f64/grad_fp"].tolist()):
+        if norm < 1e-6:
+            continue
+        worst = max(worst, abs(fp[n][0] - norm) / norm)
+        assert abs(fp[n][0] - norm) < 2e-2 * norm, (n, fp[n][0], norm)
+        assert abs(fp[n][1] - proj) < 2e-2 * norm, (n, fp[n][1], proj)
+    print("512x1760 / 100 queries: worst relative gradient-norm error", worst)
+    # the criterion's own matching on the device (csrc/lsa.hip: 100 queries per group = two columns per lane) finds the
+    # recorded assignment, or one of equal cost where costs tie
+    with torch.no_grad():
+        layers = [{k: v for k, v in out.items() if k not in ("aux_outputs", "_levels")}] + list(out["aux_outputs"])
+        mine = criterion.matcher.match_layers(layers, targets, group_num=11)
+        tgt_ids, tgt_boxes = targets[0]["labels"].long(), targets[0]["boxes_3d"]
+        for li, layer in enumerate(layers):
+            i1, j1 = (t.cpu() for t in mine[li][0])
+            i2, j2 = golden[f"f64/match{li}/0/src"], golden[f"f64/match{li}/0/tgt"]
+            assert len(i1) == len(i2) == 11 * len(tgt_ids)
+            if not (torch.equal(i1, i2) and torch.equal(j1, j2)):
+                C = criterion.matcher.cost_matrix(layer["pred_logits"].flatten(0, 1), layer["pred_boxes"].flatten(0, 1), tgt_ids, tgt_boxes).cpu()
+                c1, c2 = C[i1, j1].sum(), C[i2, j2].sum()
+                assert abs(c1 - c2) < 1e-4 * abs(c2), (li, float(c1), float(c2))
+
+
+def test_hires_100_query_committed_step_matches_the_fp32_model():
+    """The configuration bench.py --config 5 measures (bf16 body, committed kernel families, static-shape criterion) at
+    512 x 1760 / 100 queries: the total loss agrees with the fp32 model's on the same weights to bf16 accuracy, and the step
+    trains (three iterations, finite, loss decreasing)."""
+    import bench
+    dev = torch.device("cuda", 0)
+    totals = {}
+    try:
+        for prec in ("fp32", "bf16"):
+            step = bench.TrainStep(dev, 1, prec, switches=bench.committed_switches(prec)[0], size=(512, 1760), queries=100)
+            disable_dropout_(step.raw_model)
+            totals[prec] = [float(step()) for _ in range(3)]
+            del step
+            torch.cuda.empty_cache()
+    finally:
+        bench.apply_switches(set())
+    print(totals)
+    assert all(torch.isfinite(torch.tensor(v)).all() for v in totals.values())
+    assert abs(totals["bf16"][0] - totals["fp32"][0]) < 0.03 * abs(totals["fp32"][0]), totals
+    assert totals["bf16"][-1] < totals["bf16"][0] and totals["fp32"][-1] < totals["fp32"][0]
