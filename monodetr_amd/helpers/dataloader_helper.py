@@ -71,11 +71,11 @@ class DeviceLoader:
         return len(self.loader)
 
     def _upload(self, batch):
-        prep.self_check(self.device)                          # known-answer test of the image kernel, once per device
         packed, n = batch[0]
+        if self.device.type != 'cuda' and prep._backend is None:
+            raise RuntimeError("DeviceLoader needs a GPU: the image path has no CPU implementation")
+        prep.self_check(self.device)                          # known-answer test of the image kernel, once per device
         if self.device.type != 'cuda':
-            if prep._backend is None:
-                raise RuntimeError("DeviceLoader needs a GPU: the image path has no CPU implementation")
             inputs, ready = self._run(packed, n), None
         else:
             if self._stream is None:

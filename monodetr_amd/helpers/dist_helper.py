@@ -20,11 +20,18 @@ import torch.distributed as dist
 def broadcast_parameters(module, src=0, extra=()):
     """Make every rank start from rank `src`'s parameters and buffers (what DDP does at wrap time); `extra`: more tensors
     to carry along (optimizer state)."""
-    tensors, seen = [], set()
+    tensors, seen = [], []
     for t in [p.data for p in module.parameters()] + [b.data for b in module.buffers()] + [t.data for t in extra]:
-        if t.data_ptr() not in seen and t.numel():                     # (flat optimizer buffers alias their per-parameter views)
-            seen.add(t.data_ptr())
-            tensors.append(t)
+        if not t.numel():
+            continue
+        lo = t.data_ptr()
+        hi = lo + t.numel() * t.element_size()                         # (dense tensors: every caller's are)
+        # flat optimizer buffers alias their per-parameter views: skip a tensor only if an earlier one COVERS it (the same
+        # start address alone would drop a flat buffer listed after its first view)
+        if any(a <= lo and hi <= b for a, b in seen):
+            continue
+        seen.append((lo, hi))
+        tensors.append(t)
     by_dtype = {}
     for t in tensors:
         by_dtype.setdefault(t.dtype, []).append(t)

@@ -4,6 +4,8 @@ normalisation and HWC -> CHW of ``lib/datasets/kitti/kitti_dataset.py:127-163``,
 
 ``DESCRIPTOR`` is the numpy dtype of ``MdetrKittiImage`` (include/monodetr_amd.h); the host side of the pipeline
 (``monodetr_amd/datasets``) fills one record per image."""
+import os
+
 import numpy as np
 import torch
 
@@ -97,6 +99,12 @@ def self_check(device):
     out = preprocess_batch(px, ds, out_hw=(24, 40))
     got = hashlib.sha256(out.cpu().contiguous().numpy().tobytes()).hexdigest()
     if got != _SELF_CHECK_SHA256:
-        raise RuntimeError("mdetr_kitti_preprocess failed its known-answer check on %s (got %s): the device image path "
-                           "must not be trusted" % (device, got[:16]))
+        # MDETR_PREP_SELF_CHECK=warn: a new compiler / architecture may legitimately differ in a last bit (the bit-exact answer
+        # is pinned to the reference chain on gfx950 + ROCm 7.2); the operator of such a system decides, not a hard stop
+        msg = ("mdetr_kitti_preprocess failed its known-answer check on %s (got %s): the device image path must not be "
+               "trusted (MDETR_PREP_SELF_CHECK=warn continues)" % (device, got[:16]))
+        if os.environ.get("MDETR_PREP_SELF_CHECK", "strict") != "warn":
+            raise RuntimeError(msg)
+        import warnings
+        warnings.warn(msg)
     _self_checked.add(device)
