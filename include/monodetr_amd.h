@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDETR_ABI_VERSION 4
+#define MDETR_ABI_VERSION 5
 
 /* element types of the floating-point tensors */
 #define MDETR_F32 0
@@ -437,6 +437,34 @@ int mdetr_column_sum_to(int dtype, const void *x, void *out, int out_dtype, void
  */
 int mdetr_conv3x3_forward(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N,
                           int relu, int device, void *stream);
+
+/*
+ * The strided convolutions of the ResNet body, the fourth pyramid level and the depth predictor, and their input gradients, as
+ * one implicit-GEMM kernel over a rectangular set of taps (csrc/conv_taps.hip) -- torchvision Bottleneck.conv2 / downsample of
+ * each stage's first block behind lib/models/monodetr/backbone.py:93-106, monodetr.py:87-92, depth_predictor.py:29-31, which
+ * the reference hands to cuDNN:
+ *   y[b, r, c, n] = act(shift[n] + sum_{a < TR, e < TS, k < C} x[b, SI r + a - PT, SI c + e - PL, k]
+ *                                                              * w[n, ta0 + a ta_step, te0 + e te_step, k]),  r < OH, c < OW
+ *   x      bf16 [B, H, W, C], C % 64 == 0, 16-byte aligned; zero outside the map
+ *   w      bf16; element (n, tap row, tap column, k) at w + n w_sn + row w_sa + column w_se + k, 16-byte aligned rows
+ *   y      bf16; pixel (b, r, c) at y + y_off + b y_sb + r y_sr + c y_sc (elements, multiples of 4), N % 32 == 0 channels
+ *   dims   23 values: B H W C  OH OW N  SI TR TS PT PL  ta0 ta_step te0 te_step  y_off y_sb y_sr y_sc  w_sn w_sa w_se
+ * Supported tap sets: SI = 2 with 3x3 or 1x1 taps (forward of the stride-2 convolutions); SI = 1 with 1x1, 1x2, 2x1, 2x2 taps
+ * (the four pixel-parity classes of a stride-2 convolution's input gradient, written at y_sr = 2 W C, y_sc = 2 C).
+ */
+int mdetr_conv_taps(const void *x, const void *w, const float *shift, void *y, const int64_t *dims, int relu, int device, void *stream);
+
+/*
+ * Weight gradient of the 3x3 (stride 1 / 2, pad 1) and 1x1 (stride 2) convolutions on the matrix cores (csrc/conv_wgrad.hip):
+ *   dW[n, t, e, c] = sum_{b, r, q} dy[b, r, q, n] * x[b, SI r + t - P, SI q + e - P, c]        (P = 1 for K = 3, 0 for K = 1)
+ * -- autograd of the convolutions named above, cuDNN's in the reference.  Split-K over pixel tiles: the kernel writes
+ * mdetr_conv_wgrad_chunks(...) partial gradients, fp32 [chunks][N][K][K][C], into `partial`; the caller adds them (in a fixed
+ * order: mdetr_column_sum_to over the chunk axis) and rounds once.
+ *   x   bf16 [B, H, W, C], C % 64 == 0;  dy  bf16 [B, OH, OW, N], N % 32 == 0; both 16-byte aligned
+ */
+int mdetr_conv_wgrad_chunks(int B, int H, int W, int C, int OH, int OW, int N, int K, int SI);
+int mdetr_conv_wgrad(const void *x, const void *dy, float *partial, int64_t partial_floats, int B, int H, int W, int C, int OH, int OW, int N,
+                     int K, int SI, int device, void *stream);
 
 /*
  * y = dropout(relu(x + bias[col] + skip)) over a [rows, cols] channels-last activation in one pass, and its backward --

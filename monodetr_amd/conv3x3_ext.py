@@ -1,6 +1,6 @@
 """``conv3x3(x, weight, shift, relu)``: 3x3 / stride 1 / pad 1 convolution of a channels_last bf16 activation with the folded
 frozen-BN shift and the ReLU in its epilogue (csrc/conv3x3.hip through ``mdetr_conv3x3_forward``): forward and input gradient
-run on the kernel, the weight gradient stays with the library."""
+run on the kernel, the weight gradient on csrc/conv_wgrad.hip (conv_wgrad_ext)."""
 import os
 
 import torch
@@ -71,7 +71,11 @@ class _Conv3x3(torch.autograd.Function):
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (True, False, False))[0]
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
+            from . import conv_wgrad_ext
+            if conv_wgrad_ext.supported(x, dy, 3, 1):                    # csrc/conv_wgrad.hip: split-K over pixel tiles on the matrix cores
+                dw = conv_wgrad_ext.weight_gradient(x, dy, 3, 1, weight.dtype)
+            else:
+                dw = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
         ds = None
         if ctx.shift_dtype is not None and ctx.needs_input_grad[2]:
             # a trainable shift (a convolution bias): its gradient is the column sum of dY over the B*H*W pixels

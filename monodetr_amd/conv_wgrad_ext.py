@@ -1,0 +1,53 @@
+"""``weight_gradient(x, dy, k, stride, dtype)``: dW of a 3x3 (stride 1 / 2, pad 1) or 1x1 (stride 2) convolution from the
+channels_last bf16 activation and output gradient (csrc/conv_wgrad.hip through ``mdetr_conv_wgrad``: split-K over pixel tiles
+on the matrix cores; the per-chunk partial gradients are added in a fixed order by csrc/colsum.hip, one rounding)."""
+import os
+
+import torch
+
+from . import _capi
+
+_backend = None               # tests substitute the CPU emulation of the same kernel source (tests/native_emul.py)
+# MDETR_CONV_WGRAD=1: the hand-written convolutions (conv3x3_ext, conv_taps_ext) take their weight gradient from this kernel
+# instead of the library's (MIOpen igemm_wrw)
+ENABLED = os.environ.get("MDETR_CONV_WGRAD") == "1"
+
+
+def _lib():
+    return _backend if _backend is not None else _capi.lib()
+
+
+def supported(x, dy, k, stride):
+    return ((ENABLED or _backend is not None) and (x.is_cuda or _backend is not None) and x.dim() == 4 and dy.dim() == 4 and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
+            and ((k == 3 and stride in (1, 2)) or (k == 1 and stride == 2)) and x.shape[1] % 64 == 0 and dy.shape[1] % 32 == 0
+            and x.numel() > 0 and dy.numel() > 0 and x.is_contiguous(memory_format=torch.channels_last)
+            and dy.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0)
+
+
+def weight_gradient(x, dy, k, stride, dtype=torch.bfloat16):
+    """x [B, C, H, W], dy [B, N, OH, OW] (channels_last bf16) -> dW [N, C, k, k] in ``dtype`` (channels_last strides)."""
+    B, C, H, W = x.shape
+    _, N, OH, OW = dy.shape
+    lib = _lib()
+    chunks = lib.mdetr_conv_wgrad_chunks(B, H, W, C, OH, OW, N, k, stride)
+    if chunks <= 0:
+        raise RuntimeError("conv_wgrad: unsupported problem")
+    cols = N * k * k * C
+    cuda = x.is_cuda
+    if cuda and _backend is None:
+        from . import _workspace as W_
+        part = W_.get("conv_wgrad", x.device, chunks * cols * 4).view(torch.float32)[:chunks * cols]
+    else:
+        part = torch.empty(chunks * cols, dtype=torch.float32, device=x.device)
+    rc = lib.mdetr_conv_wgrad(x.data_ptr(), dy.data_ptr(), part.data_ptr(), part.numel(), B, H, W, C, OH, OW, N, k, stride,
+                              x.device.index if cuda else -1, torch.cuda.current_stream(x.device).cuda_stream if cuda else None)
+    if rc != 0:
+        _capi.check(rc, "mdetr_conv_wgrad")
+    part = part.view(chunks, cols)
+    if cuda and _backend is None:
+        from .colsum_ext import column_sum, supported as colsum_ok
+        out_dt = dtype if dtype in (torch.float32, torch.bfloat16) else torch.float32
+        dw = (column_sum(part, out_dtype=out_dt) if colsum_ok(part) else part.sum(0)).to(dtype)
+    else:
+        dw = part.sum(0).to(dtype)
+    return dw.view(N, k, k, C).permute(0, 3, 1, 2)                       # [N, C, k, k] with channels_last strides

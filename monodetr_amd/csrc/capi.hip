@@ -19,6 +19,8 @@
 #include "group_norm.h"
 #include "small_wgrad.h"
 #include "conv3x3.h"
+#include "conv_taps.h"
+#include "conv_wgrad.h"
 #include "ddn_loss.h"
 #include "kitti_prep.h"
 #include "lsa.h"
@@ -503,6 +505,66 @@ int mdetr_conv3x3_forward(const void *x, const void *w, const float *shift, void
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv3x3_forward: set device %d: %s", device, hipGetErrorString(dev.err));
     const hipError_t e = mdetr::conv3x3_launch(x, w, shift, y, B, H, W, C, N, relu != 0, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv3x3_forward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_conv_taps(const void *x, const void *w, const float *shift, void *y, const int64_t *dims, int relu, int device, void *stream)
+{
+    if (!dims) return fail(MDETR_E_ARG, "mdetr_conv_taps: null dims");
+    mdetr::ConvTapsDims d;
+    d.B = static_cast<int>(dims[0]); d.H = static_cast<int>(dims[1]); d.W = static_cast<int>(dims[2]); d.C = static_cast<int>(dims[3]);
+    d.OH = static_cast<int>(dims[4]); d.OW = static_cast<int>(dims[5]); d.N = static_cast<int>(dims[6]);
+    d.SI = static_cast<int>(dims[7]); d.TR = static_cast<int>(dims[8]); d.TS = static_cast<int>(dims[9]);
+    d.PT = static_cast<int>(dims[10]); d.PL = static_cast<int>(dims[11]);
+    d.ta0 = static_cast<int>(dims[12]); d.ta_step = static_cast<int>(dims[13]); d.te0 = static_cast<int>(dims[14]); d.te_step = static_cast<int>(dims[15]);
+    d.y_off = dims[16]; d.y_sb = dims[17]; d.y_sr = dims[18]; d.y_sc = dims[19];
+    d.w_sn = dims[20]; d.w_sa = dims[21]; d.w_se = dims[22];
+    for (int i = 0; i < 12; ++i)
+        if (dims[i] < 0 || dims[i] > (1ll << 30)) return fail(MDETR_E_ARG, "mdetr_conv_taps: bad size dims[%d] = %lld", i, static_cast<long long>(dims[i]));
+    if (d.B == 0 || d.OH == 0 || d.OW == 0) return MDETR_OK;
+    if (!x || !w || !y) return fail(MDETR_E_ARG, "mdetr_conv_taps: null pointer");
+    if (!mdetr::conv_taps_supported(d, x, w, y))
+        return fail(MDETR_E_ARG, "mdetr_conv_taps: unsupported problem (taps %dx%d stride %d, C=%d %% 64, N=%d %% 32, 16-byte aligned x / w, strides in whole "
+                                 "8-byte units)", d.TR, d.TS, d.SI, d.C, d.N);
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv_taps: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::conv_taps_launch(x, w, shift, y, d, relu != 0, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv_taps: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+static mdetr::ConvWgradDims wgrad_dims(int B, int H, int W, int C, int OH, int OW, int N, int K, int SI)
+{
+    mdetr::ConvWgradDims d;
+    d.B = B; d.H = H; d.W = W; d.C = C; d.OH = OH; d.OW = OW; d.N = N; d.K = K; d.SI = SI;
+    return d;
+}
+
+int mdetr_conv_wgrad_chunks(int B, int H, int W, int C, int OH, int OW, int N, int K, int SI)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || N <= 0) return 0;
+    return mdetr::conv_wgrad_chunks(wgrad_dims(B, H, W, C, OH, OW, N, K, SI));
+}
+
+int mdetr_conv_wgrad(const void *x, const void *dy, float *partial, int64_t partial_floats, int B, int H, int W, int C, int OH, int OW, int N,
+                     int K, int SI, int device, void *stream)
+{
+    if (B < 0 || H < 0 || W < 0 || C <= 0 || OH < 0 || OW < 0 || N <= 0)
+        return fail(MDETR_E_ARG, "mdetr_conv_wgrad: bad sizes B=%d H=%d W=%d C=%d OH=%d OW=%d N=%d", B, H, W, C, OH, OW, N);
+    if (B == 0 || OH == 0 || OW == 0) return fail(MDETR_E_ARG, "mdetr_conv_wgrad: empty problem (the caller zero-fills the gradient)");
+    if (!x || !dy || !partial) return fail(MDETR_E_ARG, "mdetr_conv_wgrad: null pointer");
+    const mdetr::ConvWgradDims d = wgrad_dims(B, H, W, C, OH, OW, N, K, SI);
+    if (OH != (H + 2 * (K == 3 ? 1 : 0) - K) / SI + 1 || OW != (W + 2 * (K == 3 ? 1 : 0) - K) / SI + 1)
+        return fail(MDETR_E_ARG, "mdetr_conv_wgrad: output map %dx%d does not belong to input %dx%d, %dx%d taps, stride %d", OH, OW, H, W, K, K, SI);
+    if (!mdetr::conv_wgrad_supported(d, x, dy))
+        return fail(MDETR_E_ARG, "mdetr_conv_wgrad: needs 3x3 (stride 1 / 2) or 1x1 (stride 2) taps, C %% 64 == 0, N %% 32 == 0, 16-byte aligned operands "
+                                 "(K=%d SI=%d C=%d N=%d)", K, SI, C, N);
+    const int64_t need = static_cast<int64_t>(mdetr::conv_wgrad_chunks(d)) * N * K * K * C;
+    if (partial_floats < need) return fail(MDETR_E_ARG, "mdetr_conv_wgrad: partial buffer holds %lld floats, %lld needed", static_cast<long long>(partial_floats), static_cast<long long>(need));
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv_wgrad: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::conv_wgrad_launch(x, dy, partial, d, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv_wgrad: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

@@ -1,0 +1,247 @@
+// monodetr_amd/csrc/conv_taps.hip -- the strided convolutions of the backbone and the feature pyramid, and the input gradients
+// of those, as implicit GEMMs on the matrix cores with the im2col in LDS: one kernel over a rectangular set of TAPS.
+//
+//   y[b, r, c, n] = act( shift[n] + sum_{a < TR, e < TS, k} x[b, SI r + a - PT, SI c + e - PL, k] * w[n, a, e, k] )
+//
+// with the output pixel (r, c) written at an arbitrary (row, column) stride and offset.  What the ResNet-50 body, the fourth
+// pyramid level and the depth predictor need of it (torchvision Bottleneck.conv2 / downsample of each stage's first block
+// behind lib/models/monodetr/backbone.py:93-106; monodetr.py:87-92; depth_predictor.py:29-31):
+//   * 3x3 / stride 2 / pad 1, forward:   TR = TS = 3, SI = 2, PT = PL = 1;
+//   * 1x1 / stride 2, forward:           TR = TS = 1, SI = 2, PT = PL = 0;
+//   * their INPUT GRADIENTS.  dX of a stride-2 convolution splits by the parity (pi, pj) of the input pixel: the pixels
+//     (2r + pi, 2c + pj) form a stride-1 problem over the dY map, dX[2r + pi, 2c + pj] = sum over the taps t = 2a' + 1 - pi ...
+//     i.e. one tap (t = 1) for an even coordinate and two (t = 2 reading dY[r], t = 0 reading dY[r + 1]) for an odd one:
+//     four launches with 1x1, 1x2, 2x1 and 2x2 taps, SI = 1, PT = PL = 0, writing every second pixel of every second row.
+//     (MIOpen's backward-data kernels for these take 48-64 us each in profiles/r02v; a zero-insertion form would do 4x the
+//     work.)  The weight is addressed through (tap offset, tap step) pairs, so the four classes read ONE transposed,
+//     tap-mirrored copy of it.
+// Geometry as conv3x3.hip (whose fragment conventions, staging scheme and epilogue this file follows): a workgroup = 4 waves
+// owns 4 output rows x 32 output columns x NB*32 output channels; wave i owns row i, lane & 31 a column; per 64-channel slab
+// the input halo -- (SI*3 + TR) x (SI*31 + TS) pixels, zero outside the image -- is staged in LDS once and serves every tap;
+// the weights of one tap row follow.  With SI = 2 the halo's columns are stored DE-INTERLEAVED (even columns, then odd): the
+// 32 lanes of a tap then read 32 consecutive LDS rows instead of every second one (a 2-way bank conflict on every operand).
+// Products transposed, Y^T[n][pixel], v_mfma_f32_32x32x16_bf16: shift, ReLU and the bf16 rounding in registers.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mdetr_wave.h>
+
+#include "conv_taps.h"
+
+namespace mdetr {
+namespace {
+
+constexpr int kWavesT = 4;               // = output rows per workgroup
+constexpr int kTileWT = 32;              // output columns per workgroup
+constexpr int kSlabT = 64;               // contraction channels per LDS slab
+constexpr int kPadT = kSlabT + 8;        // 72 bf16 per LDS row (conv3x3.hip: distinct bank quads for a b128 lane group)
+
+struct TapGeom {
+    ConvTapsDims d;
+    int tiles_x, tiles_y, tiles, ngroups, xcd_per;
+};
+
+template <int NB, bool RELU, int TR, int TS, int SI>
+__global__ __launch_bounds__(kWavesT * 64)
+void conv_taps_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, const float *__restrict__ shift,
+                      __bf16 *__restrict__ y, const TapGeom g)
+{
+    constexpr int HH = SI * (kWavesT - 1) + TR;                              // halo rows
+    constexpr int HWC = SI * (kTileWT - 1) + TS;                             // halo columns
+    constexpr int PLANE = (HWC + 1) / 2;                                     // SI = 2: even columns [0, PLANE), odd columns after
+    MDETR_DYNAMIC_LDS(unsigned char, taps_smem);
+    __bf16 *halo = reinterpret_cast<__bf16 *>(taps_smem);                    // [HH][HWC][kPadT]
+    __bf16 *wts = halo + HH * HWC * kPadT;                                   // [TS][NB*32][kPadT]
+    float *shift_s = reinterpret_cast<float *>(wts + TS * NB * 32 * kPadT);  // [NB*32]
+    const ConvTapsDims &d = g.d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+    int group, t;
+    if (g.xcd_per > 0) {                                                     // an XCD's L2 sees one output-channel group's weights
+        const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+        group = xcd % g.ngroups;
+        t = within * g.xcd_per + xcd / g.ngroups;
+    } else {
+        group = blockIdx.x % g.ngroups;
+        t = blockIdx.x / g.ngroups;
+    }
+    if (t >= g.tiles) return;
+    const int tx = t % g.tiles_x; t /= g.tiles_x;
+    const int ty = t % g.tiles_y; const int b = t / g.tiles_y;
+    const int r0 = ty * kWavesT, c0 = tx * kTileWT, n0 = group * NB * 32;
+    // (buffer-resource loads: a halo pixel outside the image -- the padding -- passes an offset beyond the tensor and reads zeros)
+    const mdetr_rsrc xr = make_rsrc(x, static_cast<unsigned>(static_cast<int64_t>(d.B) * d.H * d.W * d.C * 2));
+    const unsigned xb_off = static_cast<unsigned>(b * d.H * d.W) * static_cast<unsigned>(d.C * 2);
+
+    for (int i = threadIdx.x; i < NB * 32; i += kWavesT * 64) shift_s[i] = (shift && n0 + i < d.N) ? shift[n0 + i] : 0.f;
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+
+    constexpr int T = kWavesT * 64;
+    constexpr int WP = (TS * NB * 32 * (kSlabT / 8) + T - 1) / T;            // weight pieces per thread
+    constexpr int HP = (HH * HWC * (kSlabT / 8) + T - 1) / T;                // halo pieces per thread
+    bf16x8 wreg[WP];
+    auto zero8 = []() { bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = static_cast<__bf16>(0.f);
+        return v; };
+    auto fetch_w = [&](int k0, int a) {                                      // [e][n][64 k] <- w[n0 + n][tap a][tap e][k0 .. k0 + 64)
+#pragma unroll
+        for (int j = 0; j < WP; ++j) {
+            const int p = threadIdx.x + j * T, piece = p & 7, row = p >> 3;  // row = e * NB*32 + n
+            const int e = row / (NB * 32), n = row - e * (NB * 32);
+            bf16x8 v = zero8();
+            if (row < TS * NB * 32 && n0 + n < d.N)
+                v = *reinterpret_cast<const bf16x8 *>(w + static_cast<int64_t>(n0 + n) * d.w_sn + static_cast<int64_t>(d.ta0 + a * d.ta_step) * d.w_sa +
+                                                      static_cast<int64_t>(d.te0 + e * d.te_step) * d.w_se + k0 + piece * 8);
+            wreg[j] = v;
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int j = 0; j < WP; ++j) {
+            const int p = threadIdx.x + j * T;
+            if (p < TS * NB * 32 * (kSlabT / 8)) *reinterpret_cast<bf16x8 *>(wts + (p >> 3) * kPadT + (p & 7) * 8) = wreg[j];
+        }
+    };
+    // halo: global -> registers -> LDS in one go at each slab boundary (HP pieces per thread: up to 19 with SI = 2, too many to
+    // hold across a stage beside the accumulators); the weights of the next stage are what stays in flight during the products
+    auto load_halo = [&](int k0) {
+#pragma unroll
+        for (int j0 = 0; j0 < HP; j0 += 8) {
+            bf16x8 hreg[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = j0 + jj;
+                if (j >= HP) break;
+                const int p = threadIdx.x + j * T, piece = p & 7, pix = p >> 3;
+                const int hr = pix / HWC, hc = pix - hr * HWC;
+                const int r = SI * r0 + hr - d.PT, c = SI * c0 + hc - d.PL;
+                // (a single tap at stride 2 reads only the even rows / columns of its halo: the others are not fetched)
+                const bool used = !(SI == 2 && TS == 1 && (hc & 1)) && !(SI == 2 && TR == 1 && (hr & 1));
+                const bool in = used && pix < HH * HWC && r >= 0 && r < d.H && c >= 0 && c < d.W;
+                hreg[jj] = rsrc_load_bf16x8(xr, in ? static_cast<unsigned>(((r * d.W + c) * d.C + k0 + piece * 8) * 2) : kRsrcOob, xb_off);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = j0 + jj;
+                if (j >= HP) break;
+                const int p = threadIdx.x + j * T, piece = p & 7, pix = p >> 3;
+                const int hr = pix / HWC, hc = pix - hr * HWC;
+                const int slot = SI == 2 ? (hc & 1) * PLANE + (hc >> 1) : hc;
+                if (pix < HH * HWC) *reinterpret_cast<bf16x8 *>(halo + (hr * HWC + slot) * kPadT + piece * 8) = hreg[jj];
+            }
+        }
+    };
+
+    const int stages = d.C / kSlabT * TR;
+    fetch_w(0, 0);
+    for (int q = 0; q < stages; ++q) {
+        const int a = q % TR;
+        __syncthreads();                                                     // the previous stage's LDS reads are done
+        if (a == 0) load_halo(q / TR * kSlabT);
+        store_w();
+        if (q + 1 < stages) fetch_w((q + 1) / TR * kSlabT, (q + 1) % TR);    // in flight during the products below
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < TS; ++e) {
+            const int slot = SI == 2 ? (e & 1) * PLANE + col + (e >> 1) : col + e;       // halo column SI col + e of this lane's output pixel
+            const __bf16 *hp = halo + ((SI * wave + a) * HWC + slot) * kPadT;
+#pragma unroll
+            for (int ks = 0; ks < kSlabT / 16; ++ks) {
+                const bf16x8 xv = *reinterpret_cast<const bf16x8 *>(hp + ks * 16 + half * 8);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const bf16x8 wv = *reinterpret_cast<const bf16x8 *>(wts + (e * NB * 32 + nb * 32 + col) * kPadT + ks * 16 + half * 8);
+                    acc[nb] = mfma_bf16(wv, xv, acc[nb]);                    // Y^T[n][pixel]
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane = pixel; register quad q of block nb = channels 32 nb + 8 q + 4 half + 0..3 (conv3x3.hip)
+    const int r = r0 + wave, c = c0 + col;
+    if (r < d.OH && c < d.OW) {
+        __bf16 *yp = y + d.y_off + static_cast<int64_t>(b) * d.y_sb + static_cast<int64_t>(r) * d.y_sr + static_cast<int64_t>(c) * d.y_sc + n0 + 4 * half;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nn = nb * 32 + 8 * q + 4 * half;
+                if (n0 + nn < d.N) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[nb][4 * q + i] + shift_s[nn + i];
+                        if (RELU) v = v > 0.f ? v : 0.f;
+                        o[i] = static_cast<__bf16>(v);
+                    }
+                    *reinterpret_cast<bf16x4 *>(yp + nb * 32 + 8 * q) = o;
+                }
+            }
+    }
+}
+
+template <int NB, bool RELU, int TR, int TS, int SI>
+hipError_t launch(const void *x, const void *w, const float *shift, void *y, const ConvTapsDims &d, hipStream_t st)
+{
+    constexpr int HH = SI * (kWavesT - 1) + TR, HWC = SI * (kTileWT - 1) + TS;
+    constexpr size_t lds = static_cast<size_t>(HH) * HWC * kPadT * 2 + static_cast<size_t>(TS) * NB * 32 * kPadT * 2 + NB * 32 * 4;
+    static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
+    auto kern = conv_taps_kernel<NB, RELU, TR, TS, SI>;
+    static bool attr_set[64] = {};                           // per device
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess) dev_ = -1;
+    if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;
+    }
+    TapGeom g;
+    g.d = d;
+    g.tiles_x = (d.OW + kTileWT - 1) / kTileWT;
+    g.tiles_y = (d.OH + kWavesT - 1) / kWavesT;
+    g.tiles = d.B * g.tiles_x * g.tiles_y;
+    g.ngroups = (d.N + NB * 32 - 1) / (NB * 32);
+    g.xcd_per = (g.ngroups <= 8 && 8 % g.ngroups == 0) ? 8 / g.ngroups : 0;
+    const int64_t blocks = g.xcd_per ? 8ll * ((g.tiles + g.xcd_per - 1) / g.xcd_per) : static_cast<int64_t>(g.tiles) * g.ngroups;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kWavesT * 64), lds, st, static_cast<const __bf16 *>(x),
+                       static_cast<const __bf16 *>(w), shift, static_cast<__bf16 *>(y), g);
+    return hipGetLastError();
+}
+
+template <int TR, int TS, int SI>
+hipError_t by_width(const void *x, const void *w, const float *shift, void *y, const ConvTapsDims &d, bool relu, hipStream_t st)
+{
+    // 128 output channels per workgroup where the layer has them (the halo is then read once per 128 channels; 243 VGPRs for the
+    // 3x3 / stride-2 form, no spill)
+    if (d.N >= 128) return relu ? launch<4, true, TR, TS, SI>(x, w, shift, y, d, st) : launch<4, false, TR, TS, SI>(x, w, shift, y, d, st);
+    return relu ? launch<2, true, TR, TS, SI>(x, w, shift, y, d, st) : launch<2, false, TR, TS, SI>(x, w, shift, y, d, st);
+}
+
+}  // namespace
+
+bool conv_taps_supported(const ConvTapsDims &d, const void *x, const void *w, const void *y)
+{
+    const auto al = [](const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+    const bool shape = (d.SI == 2 && ((d.TR == 3 && d.TS == 3) || (d.TR == 1 && d.TS == 1))) ||
+                       (d.SI == 1 && d.TR >= 1 && d.TR <= 2 && d.TS >= 1 && d.TS <= 2);
+    return shape && d.B > 0 && d.H > 0 && d.W > 0 && d.OH > 0 && d.OW > 0 && d.C > 0 && d.C % 64 == 0 && d.N > 0 && d.N % 32 == 0 &&
+           al(x, 16) && al(w, 16) && al(y, 8) && d.w_sn % 8 == 0 && d.w_sa % 8 == 0 && d.w_se % 8 == 0 &&
+           d.y_off % 4 == 0 && d.y_sb % 4 == 0 && d.y_sr % 4 == 0 && d.y_sc % 4 == 0 && d.PT >= 0 && d.PL >= 0 &&
+           static_cast<int64_t>(d.B) * d.H * d.W * d.C < (1ll << 30) &&
+           static_cast<int64_t>(d.B) * ((d.OH + 3) / 4) * ((d.OW + 31) / 32) * ((d.N + 31) / 32) < (1ll << 30);
+}
+
+hipError_t conv_taps_launch(const void *x, const void *w, const float *shift, void *y, const ConvTapsDims &d, bool relu, hipStream_t st)
+{
+    if (d.SI == 2) return d.TR == 3 ? by_width<3, 3, 2>(x, w, shift, y, d, relu, st) : by_width<1, 1, 2>(x, w, shift, y, d, relu, st);
+    if (d.TR == 1) return d.TS == 1 ? by_width<1, 1, 1>(x, w, shift, y, d, relu, st) : by_width<1, 2, 1>(x, w, shift, y, d, relu, st);
+    return d.TS == 1 ? by_width<2, 1, 1>(x, w, shift, y, d, relu, st) : by_width<2, 2, 1>(x, w, shift, y, d, relu, st);
+}
+
+}  // namespace mdetr

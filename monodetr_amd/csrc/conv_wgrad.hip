@@ -1,0 +1,258 @@
+// monodetr_amd/csrc/conv_wgrad.hip -- weight gradient of the backbone's / pyramid's / depth head's 3x3 (stride 1 and 2) and
+// strided 1x1 convolutions on the matrix cores: split-K over pixel tiles, both operands transposed on their way into LDS.
+//
+//   dW[n, t, e, c] = sum_{b, r, q} dY[b, r, q, n] * X[b, SI r + t - P, SI q + e - P, c]        (P = 1 for 3x3, 0 for 1x1)
+//
+// Reference: autograd of torchvision Bottleneck.conv2 / downsample (lib/models/monodetr/backbone.py:93-106), the 3x3 / stride-2
+// pyramid level (monodetr.py:87-92) and the depth predictor's convolutions (depth_predictor.py:29-56), which the reference
+// leaves to cuDNN.  MIOpen's igemm_wrw kernels take 71 us per 18.1-GFLOP layer here (255 TFLOP/s, profiles/r02v).
+//
+// The contraction index is the PIXEL, the slow axis of both channels-last operands: an MFMA lane needs 8 consecutive
+// contraction values of one channel, so both operands are transposed -- in registers, an 8 x 8 bf16 block per thread (8 loads of
+// 16 bytes = 8 channels of 8 rows; 32 two-word permutes; 8 stores of 16 bytes = 8 rows of 8 channels) -- on their way into LDS:
+//   dYt[n][q][8 rows],   Xt[c][x column][8 rows]                       (a lane's operand = one aligned 16-byte read)
+// The group of 8 contraction values is 8 ROWS of one column: a tap's column shift e then moves the read by whole 16-byte
+// slots (8 consecutive columns would be shifted by 2 bytes: misaligned), and the tap's ROW shift t is taken out of the kernel's
+// inner structure altogether -- a workgroup owns ONE tap row t and loads its X rows already shifted.  With SI = 2 the X columns
+// are stored de-interleaved (even columns, then odd), as in conv_taps.hip.
+// Workgroup = 8 waves: (tap row t, 128 output channels n, 64 input channels c, a chunk of the pixel tiles); wave w owns
+// n-block w & 3 and c-block w >> 2: TS accumulator tiles D[n][c] (32 x 32) per wave, one per tap column.  A pixel tile is
+// 8 output rows x 32 output columns of one image = 16 MFMA k-steps (2 columns x 8 rows each).  The next tile's global loads are
+// issued before the current tile's products and transposed into the single LDS buffer after them.
+// Output: per-chunk partial gradients P[chunk][n][t][e][c] in fp32; colsum.hip adds the chunks in a fixed order and rounds once
+// into the parameter's dtype (deterministic, no atomics).
+// Algorithmic bytes = 2 B (H W C + OH OW N) + 4 TR TS N C;  flops = 2 B OH OW TR TS C N.  MFMA-bound by design.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mdetr_wave.h>
+
+#include "conv_wgrad.h"
+
+namespace mdetr {
+namespace {
+
+constexpr int kThreadsG = 512;
+constexpr int kNB = 128, kCB = 64;       // output / input channels per workgroup
+constexpr int kRows = 8, kCols = 32;     // output pixels of a tile
+constexpr int kDyStride = kCols + 1;     // 16-byte slots per n row of dYt: odd, so the 16 lanes of a b128 group fall on distinct slots
+
+struct WgradGeom {
+    ConvWgradDims d;
+    int bands, ctiles, units, chunks, nblocks, cblocks;
+};
+
+__device__ __forceinline__ void transpose8x8(const bf16x8 (&in)[8], bf16x8 (&out)[8])
+{
+    // in[i] = 8 channels of row i; out[q] = 8 rows of channel q.  Word m of out[q] = (in[2m][q], in[2m + 1][q]).
+    unsigned d[8][4], o[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) __builtin_memcpy(d[i], &in[i], 16);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const unsigned lo = d[2 * m][q >> 1], hi = d[2 * m + 1][q >> 1];
+            o[q][m] = (q & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+        }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) __builtin_memcpy(&out[q], o[q], 16);
+}
+
+template <int SI, int TS>
+__global__ __launch_bounds__(kThreadsG)
+void conv_wgrad_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy, float *__restrict__ part, const WgradGeom g)
+{
+    constexpr int P = TS == 3 ? 1 : 0;
+    // x columns of a tile in LDS: SI = 1: 32 + TS - 1 consecutive; SI = 2, 3 taps: 33 even + 32 odd; SI = 2, 1 tap: the 32 even ones
+    constexpr int XC = SI == 1 ? kCols + TS - 1 : (TS == 3 ? 2 * kCols + 1 : kCols);
+    constexpr int XSTRIDE = XC | 1;                                          // odd number of 16-byte slots per channel row
+    constexpr int EVEN = kCols + 1;                                          // SI = 2, 3 taps: slots [0, 33) even columns, [33, 65) odd
+    MDETR_DYNAMIC_LDS(unsigned char, wgrad_smem);
+    bf16x8 *dyt = reinterpret_cast<bf16x8 *>(wgrad_smem);                    // [kNB][kDyStride]
+    bf16x8 *xt = dyt + kNB * kDyStride;                                      // [kCB][XSTRIDE]
+    const ConvWgradDims &d = g.d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+    const int nsub = wave & 3, csub = wave >> 2;
+    int id = blockIdx.x;
+    const int chunk = id % g.chunks; id /= g.chunks;
+    const int t = id % TS; id /= TS;                                         // tap row (TR = TS)
+    const int cblk = id % g.cblocks; const int nblk = id / g.cblocks;
+    const int n0 = nblk * kNB, c0 = cblk * kCB;
+
+    f32x16 acc[TS];
+#pragma unroll
+    for (int e = 0; e < TS; ++e)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[e][i] = 0.f;
+
+    // ---- loading tasks: one 8 x 8 block each.  X: (slot, channel piece): XC * 8; dY: (column, channel piece): 32 * 16
+    constexpr int XT = XC * (kCB / 8), DT = kCols * (kNB / 8), TASKS = XT + DT;
+    constexpr int ROUNDS = (TASKS + kThreadsG - 1) / kThreadsG;
+    bf16x8 stage[ROUNDS][8];
+    // Loads go through buffer resources: a lane outside the image (the convolution's padding, a ragged tile) passes an offset
+    // beyond the tensor and receives zeros -- no branch, no zero fill.  Per-lane offset = the column part, scalar offset = the
+    // (image, row) part; the tensors are below 2^31 bytes (checked by the launcher).
+    const mdetr_rsrc xr = make_rsrc(x, static_cast<unsigned>(static_cast<int64_t>(d.B) * d.H * d.W * d.C * 2));
+    const mdetr_rsrc yr = make_rsrc(dy, static_cast<unsigned>(static_cast<int64_t>(d.B) * d.OH * d.OW * d.N * 2));
+    // what a thread's tasks are does not depend on the tile: (kind, slot / column, channel piece) per round
+    int t_rel[ROUNDS], t_ch[ROUNDS];
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int task = threadIdx.x + rd * kThreadsG;
+        if (task < XT) {
+            const int slot = task >> 3;
+            t_rel[rd] = SI == 1 ? slot : (TS == 3 ? (slot < EVEN ? 2 * slot : 2 * (slot - EVEN) + 1) : 2 * slot);
+            t_ch[rd] = (c0 + (task & 7) * 8) * 2;
+        } else {
+            const int k = task - XT;
+            t_rel[rd] = k >> 4;
+            t_ch[rd] = (n0 + (k & 15) * 8 < d.N && task < TASKS) ? (n0 + (k & 15) * 8) * 2 : -1;
+        }
+    }
+    auto fetch = [&](int u) {                                                // global loads of pixel tile u into `stage`
+        const int ct = u % g.ctiles; u /= g.ctiles;
+        const int band = u % g.bands; const int b = u / g.bands;
+        const int r0 = band * kRows, q0 = ct * kCols;
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const int task = threadIdx.x + rd * kThreadsG;
+            if (task < XT) {
+                const int col = SI * q0 + t_rel[rd] - P;
+                const unsigned lane_off = (col >= 0 && col < d.W) ? static_cast<unsigned>(col * d.C * 2 + t_ch[rd]) : kRsrcOob;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = SI * (r0 + i) + t - P;                   // uniform
+                    const bool ok = row >= 0 && row < d.H;
+                    stage[rd][i] = rsrc_load_bf16x8(xr, ok ? lane_off : kRsrcOob, ok ? static_cast<unsigned>((b * d.H + row) * d.W) * static_cast<unsigned>(d.C * 2) : 0u);
+                }
+            } else {
+                const int col = q0 + t_rel[rd];
+                const unsigned lane_off = (col < d.OW && t_ch[rd] >= 0) ? static_cast<unsigned>(col * d.N * 2 + t_ch[rd]) : kRsrcOob;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = r0 + i;
+                    const bool ok = row < d.OH;
+                    stage[rd][i] = rsrc_load_bf16x8(yr, ok ? lane_off : kRsrcOob, ok ? static_cast<unsigned>((b * d.OH + row) * d.OW) * static_cast<unsigned>(d.N * 2) : 0u);
+                }
+            }
+        }
+    };
+    auto commit = [&]() {                                                    // transpose `stage` into LDS
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd) {
+            const int task = threadIdx.x + rd * kThreadsG;
+            if (task >= TASKS) continue;
+            bf16x8 tr[8];
+            transpose8x8(stage[rd], tr);
+            if (task < XT) {
+                const int slot = task >> 3, piece = task & 7;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xt[(piece * 8 + q) * XSTRIDE + slot] = tr[q];
+            } else {
+                const int k = task - XT, col = k >> 4, piece = k & 15;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dyt[(piece * 8 + q) * kDyStride + col] = tr[q];
+            }
+        }
+    };
+
+    int u = chunk;
+    if (u < g.units) fetch(u);
+    while (u < g.units) {
+        __syncthreads();                                                     // the previous tile's LDS reads are done
+        commit();
+        const int nu = u + g.chunks;
+        if (nu < g.units) fetch(nu);                                         // in flight during the products below
+        __syncthreads();
+        const bf16x8 *ap = dyt + (nsub * 32 + l31) * kDyStride + half;
+        const bf16x8 *bp = xt + (csub * 32 + l31) * XSTRIDE;
+#pragma unroll 4
+        for (int ks = 0; ks < kCols / 2; ++ks) {
+            const int q = 2 * ks + half;                                     // this half-wave's column of the k-step
+            const bf16x8 a = ap[2 * ks];
+#pragma unroll
+            for (int e = 0; e < TS; ++e) {
+                int slot;
+                if (SI == 1) slot = q + e;
+                else if (TS == 3) slot = (e & 1) ? EVEN + q : q + (e >> 1);  // 2q + e: even -> q + e / 2, odd -> after the even ones
+                else slot = q;
+                acc[e] = mfma_bf16(a, bp[slot], acc[e]);                     // D[n][c] += dY^T[n][8 rows] X[8 rows][c]
+            }
+        }
+        u = nu;
+    }
+
+    // ---- epilogue: acc[e] register r of lane l = D[n = (r & 3) + 8 (r >> 2) + 4 half][c = l & 31]
+    const int c = c0 + csub * 32 + l31;
+    float *pp = part + static_cast<int64_t>(chunk) * d.N * TS * TS * d.C;
+#pragma unroll
+    for (int e = 0; e < TS; ++e)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + nsub * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (n < d.N) pp[((static_cast<int64_t>(n) * TS + t) * TS + e) * d.C + c] = acc[e][r];
+        }
+}
+
+template <int SI, int TS>
+hipError_t launch(const void *x, const void *dy, float *part, WgradGeom g, hipStream_t st)
+{
+    constexpr int XC = SI == 1 ? kCols + TS - 1 : (TS == 3 ? 2 * kCols + 1 : kCols);
+    constexpr size_t lds = (static_cast<size_t>(kNB) * kDyStride + static_cast<size_t>(kCB) * (XC | 1)) * 16;
+    static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
+    auto kern = conv_wgrad_kernel<SI, TS>;
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess) dev_ = -1;
+    if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;
+    }
+    const int64_t blocks = static_cast<int64_t>(g.chunks) * TS * g.cblocks * g.nblocks;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kThreadsG), lds, st, static_cast<const __bf16 *>(x),
+                       static_cast<const __bf16 *>(dy), part, g);
+    return hipGetLastError();
+}
+
+WgradGeom geometry(const ConvWgradDims &d)
+{
+    WgradGeom g;
+    g.d = d;
+    g.bands = (d.OH + kRows - 1) / kRows;
+    g.ctiles = (d.OW + kCols - 1) / kCols;
+    g.units = d.B * g.bands * g.ctiles;
+    g.nblocks = (d.N + kNB - 1) / kNB;
+    g.cblocks = d.C / kCB;
+    // one workgroup per CU (104-134 KB of LDS): about 256 workgroups, each with at least one pixel tile
+    const int base = d.K * g.nblocks * g.cblocks;
+    int chunks = 256 / (base > 0 ? base : 1);
+    if (chunks < 1) chunks = 1;
+    if (chunks > g.units) chunks = g.units;
+    g.chunks = chunks;
+    return g;
+}
+
+}  // namespace
+
+bool conv_wgrad_supported(const ConvWgradDims &d, const void *x, const void *dy)
+{
+    const auto al = [](const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+    const bool shape = (d.K == 3 && (d.SI == 1 || d.SI == 2)) || (d.K == 1 && d.SI == 2);
+    return shape && d.B > 0 && d.H > 0 && d.W > 0 && d.OH > 0 && d.OW > 0 && d.C > 0 && d.C % 64 == 0 && d.N > 0 && d.N % 32 == 0 &&
+           al(x, 16) && al(dy, 16) && static_cast<int64_t>(d.N) * d.K * d.K * d.C < (1ll << 28) &&
+           static_cast<int64_t>(d.B) * d.H * d.W * d.C < (1ll << 30) && static_cast<int64_t>(d.B) * d.OH * d.OW * d.N < (1ll << 30);
+}
+
+int conv_wgrad_chunks(const ConvWgradDims &d) { return geometry(d).chunks; }
+
+hipError_t conv_wgrad_launch(const void *x, const void *dy, float *part, const ConvWgradDims &d, hipStream_t st)
+{
+    const WgradGeom g = geometry(d);
+    if (d.K == 3) return d.SI == 1 ? launch<1, 3>(x, dy, part, g, st) : launch<2, 3>(x, dy, part, g, st);
+    return launch<2, 1>(x, dy, part, g, st);
+}
+
+}  // namespace mdetr

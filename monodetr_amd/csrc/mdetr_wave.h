@@ -41,4 +41,18 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Buffer-resource loads: a load whose per-lane offset lies beyond the resource's size returns ZERO instead of faulting -- the
+// image borders (convolution padding) and ragged tiles of the convolution kernels cost a select on the offset, not a branch.
+// The range check covers the per-lane offset only (the scalar offset is added afterwards): an invalid lane passes kRsrcOob.
+typedef __amdgpu_buffer_rsrc_t mdetr_rsrc;
+constexpr unsigned kRsrcOob = 0xfffffff0u;
+__device__ __forceinline__ mdetr_rsrc make_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);      // raw buffer, 32-bit data format
+}
+__device__ __forceinline__ bf16x8 rsrc_load_bf16x8(mdetr_rsrc r, unsigned lane_offset, unsigned scalar_offset)
+{
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, lane_offset, scalar_offset, 0));
+}
+
 #define MDETR_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]

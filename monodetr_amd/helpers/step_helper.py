@@ -71,7 +71,9 @@ class TrainIteration:
         self.eager_steps = eager_steps
         self.capture_error_mode = capture_error_mode
         self.graph = self.graph_opt = self.sync_plan = self.static = self.stream = None
-        self.loss = self.losses = None
+        self.loss = self.losses = self._captured = None
+        self._capturing = False
+        self.num_global = None                                # two-graph form: the rank-averaged object count, filled before each replay
         self.capture_error = ""
         self.eager_done = 0                                   # eagerly launched iterations so far
         self.replays = 0
@@ -85,6 +87,8 @@ class TrainIteration:
         images, calibs, img_sizes, targets = batch
         if self.prepare is not None:
             targets = self.prepare(targets)
+        if self._capturing and self.num_global is not None and isinstance(targets, dict):
+            targets = dict(targets, num_global=self.num_global, num_host=None)
         out = self.model(images, calibs, targets, img_sizes, dn_args=None)
         losses = self.criterion(out, targets, None)
         if hasattr(self.criterion, "weighted_total"):
@@ -178,29 +182,52 @@ class TrainIteration:
         self.optimizer.zero_grad(set_to_none=True)
         mode = dict(capture_error_mode=self.capture_error_mode)
         two = self.grad_sync is not None or self.pending_sync is not None
-        if not two:
-            with torch.cuda.graph(graph, stream=side, **mode):  # same stream as the warm-up: the AccumulateGrad nodes are bound to it
-                self.loss = self._step_captured(self.static)
-        else:
-            from .dist_helper import static_plan
-            with torch.cuda.graph(graph, stream=side, **mode):
-                self.loss = self._forward_backward(self.static)
-            # the gradients now sit at the addresses the captured backward writes to: every later exchange gathers from THOSE
-            # into persistent flat buffers, reduces there, and the captured optimizer reads the reduced slices
-            self.sync_plan = static_plan(self.raw_model.parameters())
-            for ps, src, flat, views in self.sync_plan:
-                for p_, v in zip(ps, views):
-                    p_.grad = v
-            graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_opt, stream=side, pool=graph.pool(), **mode):
-                self.optimizer.step()
-            if self.grad_sync is not None:
-                self.grad_sync._static = self.sync_plan
+        if two:
+            # the criterion's one collective -- the object count averaged over the ranks (monodetr.py:506-507) -- depends on the
+            # targets only: it is issued eagerly before each replay and handed to the captured criterion as a device scalar
+            self.num_global = torch.ones((), dtype=torch.float32, device=self.device)
+            self._fill_num_global()
+        self._capturing = True
+        try:
+            if not two:
+                with torch.cuda.graph(graph, stream=side, **mode):  # same stream as the warm-up: the AccumulateGrad nodes are bound to it
+                    self.loss = self._step_captured(self.static)
+            else:
+                from .dist_helper import static_plan
+                with torch.cuda.graph(graph, stream=side, **mode):
+                    self.loss = self._forward_backward(self.static)
+                # the gradients now sit at the addresses the captured backward writes to: every later exchange gathers from THOSE
+                # into persistent flat buffers, reduces there, and the captured optimizer reads the reduced slices
+                self.sync_plan = static_plan(self.raw_model.parameters())
+                for ps, src, flat, views in self.sync_plan:
+                    for p_, v in zip(ps, views):
+                        p_.grad = v
+                graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_opt, stream=side, pool=graph.pool(), **mode):
+                    self.optimizer.step()
+                if self.grad_sync is not None:
+                    self.grad_sync._static = self.sync_plan
+        finally:
+            self._capturing = False
         if hasattr(self.optimizer, "uncount_step"):
             self.optimizer.uncount_step()                    # the capture ran the host bookkeeping of a step no kernel executed
         torch.cuda.synchronize(self.device)
         self.graph, self.graph_opt = graph, graph_opt
+        self._captured = (self.loss, self.losses)
         return self
+
+    @staticmethod
+    def count_objects(batch):
+        """Ground-truth objects of a batch as a device scalar: the loader's collated form (``mask_2d``) or the padded form (``num``)."""
+        t = batch[3]
+        return t["mask_2d"].sum() if "mask_2d" in t else t["num"].sum()
+
+    def _fill_num_global(self):
+        n = self.count_objects(self.static).to(torch.float32)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(n)
+            n = n / torch.distributed.get_world_size()
+        self.num_global.copy_(n)
 
     def _step_captured(self, batch):
         total = self._forward_backward(batch)
@@ -217,7 +244,7 @@ class TrainIteration:
             if self.strict:
                 raise
             self.capture_error = repr(e)[:160]
-            self.graph = self.graph_opt = self.sync_plan = self.static = None
+            self.graph = self.graph_opt = self.sync_plan = self.static = self.num_global = None
             if self.grad_sync is not None:
                 self.grad_sync._static = None
             self.want_graph = False
@@ -240,7 +267,7 @@ class TrainIteration:
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
         if int(flag) == 0 and self.graph is not None:
             self.capture_error = "capture failed on another rank"
-            self.graph = self.graph_opt = self.sync_plan = self.static = None
+            self.graph = self.graph_opt = self.sync_plan = self.static = self.num_global = None
             self.want_graph = False
             if self.grad_sync is not None:
                 self.grad_sync._static = None
@@ -263,6 +290,9 @@ class TrainIteration:
         return self.launch_mode()
 
     def replay(self):
+        if self.num_global is not None:
+            self._fill_num_global()
+        self.loss, self.losses = self._captured               # (an eager iteration in between re-pointed them)
         self.graph.replay()
         if self.graph_opt is not None:
             self.grad_sync.sync()

@@ -11,7 +11,8 @@ import os
 # with the COMMITTED list below.  (MDETR_MSDA_BF16 changes the MSDA operator's element types; the roofline accounting
 # follows it: msda_algorithmic_bytes(mixed=True).)
 AUTOTUNE_SWITCHES = ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN", "MDETR_MSDA_BF16", "MDETR_TOKEN_GEMM",
-                     "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD")
+                     "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD",
+                     "MDETR_CONV_STRIDED", "MDETR_CONV_WGRAD")
 ALL_SWITCHES = AUTOTUNE_SWITCHES
 # The measured configuration.  family -> the GPU tests that hold it to the default path / the framework operators
 # (all in tests/test_fused_gpu.py unless a file is named); a family without green tests is not listed.
@@ -55,7 +56,7 @@ def env_switches():
 def apply_switches(names):
     """Runtime equivalent of the environment switches for the module-level ones (the criterion's and the optimizer's
     are applied by TrainStep)."""
-    from monodetr_amd import add_ln_ext, bias_act_ext, conv3x3_ext, group_norm_ext, small_wgrad_ext
+    from monodetr_amd import add_ln_ext, bias_act_ext, conv3x3_ext, conv_taps_ext, conv_wgrad_ext, group_norm_ext, small_wgrad_ext
     from monodetr_amd.monodetr import linear
     from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func
     from monodetr_amd.monodetr.ops.modules import ms_deform_attn
@@ -65,6 +66,8 @@ def apply_switches(names):
     linear._GEMM_RELU = "MDETR_GEMM_RELU" in names
     bias_act_ext.ENABLED = "MDETR_FUSED_EPILOGUE" in names
     conv3x3_ext.ENABLED = "MDETR_CONV3X3" in names
+    conv_taps_ext.ENABLED = "MDETR_CONV_STRIDED" in names
+    conv_wgrad_ext.ENABLED = "MDETR_CONV_WGRAD" in names
     group_norm_ext.ENABLED = "MDETR_GROUP_NORM" in names
     small_wgrad_ext.ENABLED = "MDETR_SMALL_WGRAD" in names
     ms_deform_attn_func._NATIVE_BF16 = "MDETR_MSDA_BF16" in names

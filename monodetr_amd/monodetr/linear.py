@@ -197,4 +197,9 @@ class PointwiseConv2d(nn.Conv2d):
         if pointwise_eligible(x, self.kernel_size, self.stride, self.padding, self.groups) \
                 and x.dtype == self.weight.dtype and not torch.is_autocast_enabled():
             return pointwise_conv(x, self.weight, self.bias)
+        from .. import conv_taps_ext
+        if conv_taps_ext.ENABLED and x.dtype == self.weight.dtype and not torch.is_autocast_enabled() and self.padding_mode == "zeros" \
+                and conv_taps_ext.supported(x, self.weight, self.stride, self.padding, self.dilation, self.groups):
+            # 3x3 / stride 2 (the fourth pyramid level, monodetr.py:87-92; the depth predictor's downsample, depth_predictor.py:29-31)
+            return conv_taps_ext.conv_strided(x, self.weight, self.bias, relu=False)
         return super().forward(x)

