@@ -455,6 +455,16 @@ int mdetr_conv3x3_forward(const void *x, const void *w, const float *shift, void
 int mdetr_conv_taps(const void *x, const void *w, const float *shift, void *y, const int64_t *dims, int relu, int device, void *stream);
 
 /*
+ * The ResNet stem (torchvision ResNet.conv1 -> bn1 -> relu behind lib/models/monodetr/backbone.py:93-106; frozen: forward only):
+ *   y[b, r, c, n] = relu(shift[n] + sum_{t, e < 7, ch < 3} x[b, 2r + t - 3, 2c + e - 3, ch] * w[n, ch, t, e])      (csrc/conv_stem.hip)
+ *   x         bf16 [B, H, W, 3] (a channels_last [B, 3, H, W] image batch)
+ *   w_packed  bf16 [64][176]: element t * 24 + e * 3 + ch of row n = w[n, ch, t, e], every other element zero; 16-byte aligned
+ *   shift     fp32 [64] or NULL
+ *   y         bf16 [B, (H - 1) / 2 + 1, (W - 1) / 2 + 1, 64], 8-byte aligned
+ */
+int mdetr_conv_stem(const void *x, const void *w_packed, const float *shift, void *y, int B, int H, int W, int device, void *stream);
+
+/*
  * Weight gradient of the 3x3 (stride 1 / 2, pad 1) and 1x1 (stride 2) convolutions on the matrix cores (csrc/conv_wgrad.hip):
  *   dW[n, t, e, c] = sum_{b, r, q} dy[b, r, q, n] * x[b, SI r + t - P, SI q + e - P, c]        (P = 1 for K = 3, 0 for K = 1)
  * -- autograd of the convolutions named above, cuDNN's in the reference.  Split-K over pixel tiles: the kernel writes

@@ -19,6 +19,7 @@
 #include "group_norm.h"
 #include "small_wgrad.h"
 #include "conv3x3.h"
+#include "conv_stem.h"
 #include "conv_taps.h"
 #include "conv_wgrad.h"
 #include "ddn_loss.h"
@@ -530,6 +531,20 @@ int mdetr_conv_taps(const void *x, const void *w, const float *shift, void *y, c
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv_taps: set device %d: %s", device, hipGetErrorString(dev.err));
     const hipError_t e = mdetr::conv_taps_launch(x, w, shift, y, d, relu != 0, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv_taps: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_conv_stem(const void *x, const void *w_packed, const float *shift, void *y, int B, int H, int W, int device, void *stream)
+{
+    if (B < 0 || H < 0 || W < 0) return fail(MDETR_E_ARG, "mdetr_conv_stem: bad sizes B=%d H=%d W=%d", B, H, W);
+    if (B == 0 || H == 0 || W == 0) return MDETR_OK;
+    if (!x || !w_packed || !y) return fail(MDETR_E_ARG, "mdetr_conv_stem: null pointer");
+    if (!mdetr::conv_stem_supported(B, H, W, x, w_packed, y))
+        return fail(MDETR_E_ARG, "mdetr_conv_stem: needs a 16-byte aligned packed weight, an 8-byte aligned output and an image batch below 2 GiB");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv_stem: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::conv_stem_launch(x, w_packed, shift, y, B, H, W, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv_stem: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

@@ -54,5 +54,9 @@ __device__ __forceinline__ bf16x8 rsrc_load_bf16x8(mdetr_rsrc r, unsigned lane_o
 {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, lane_offset, scalar_offset, 0));
 }
+__device__ __forceinline__ unsigned short rsrc_load_u16(mdetr_rsrc r, unsigned lane_offset, unsigned scalar_offset)
+{
+    return __builtin_amdgcn_raw_buffer_load_b16(r, lane_offset, scalar_offset, 0);
+}
 
 #define MDETR_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]

@@ -12,7 +12,7 @@ import os
 # follows it: msda_algorithmic_bytes(mixed=True).)
 AUTOTUNE_SWITCHES = ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN", "MDETR_MSDA_BF16", "MDETR_TOKEN_GEMM",
                      "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD",
-                     "MDETR_CONV_STRIDED", "MDETR_CONV_WGRAD")
+                     "MDETR_CONV_STRIDED", "MDETR_CONV_WGRAD", "MDETR_CONV_STEM")
 ALL_SWITCHES = AUTOTUNE_SWITCHES
 # The measured configuration.  family -> the GPU tests that hold it to the default path / the framework operators
 # (all in tests/test_fused_gpu.py unless a file is named); a family without green tests is not listed.
@@ -26,6 +26,9 @@ SWITCH_TESTS = {
     "MDETR_GEMM_RELU": "test_library_gemm_relu_epilogue_*, test_training_step_with_fused_tails_*",
     "MDETR_SMALL_WGRAD": "test_small_wgrad_kernel_*, test_training_step_with_the_small_wgrad_kernel_*",
     "MDETR_GROUP_NORM": "test_group_norm_kernel_*, test_training_step_with_the_group_norm_kernel_*",
+    "MDETR_CONV_STRIDED": "test_conv_strided_kernel_matches_the_library_convolution, test_training_step_with_the_convolution_kernels_*",
+    "MDETR_CONV_WGRAD": "test_conv_wgrad_kernel_matches_the_library_weight_gradient, test_conv_strided_kernel_*, test_training_step_with_the_convolution_kernels_*",
+    "MDETR_CONV_STEM": "test_conv_stem_kernel_matches_the_library_convolution, test_training_step_with_the_convolution_kernels_*",
     "MDETR_CONV3X3": "test_conv3x3_kernel_matches_the_library_convolution, test_training_step_with_the_conv3x3_kernel_*, test_conv3x3_module_with_a_trainable_bias_*",
 }
 COMMITTED_SWITCHES = {
@@ -56,7 +59,7 @@ def env_switches():
 def apply_switches(names):
     """Runtime equivalent of the environment switches for the module-level ones (the criterion's and the optimizer's
     are applied by TrainStep)."""
-    from monodetr_amd import add_ln_ext, bias_act_ext, conv3x3_ext, conv_taps_ext, conv_wgrad_ext, group_norm_ext, small_wgrad_ext
+    from monodetr_amd import add_ln_ext, bias_act_ext, conv3x3_ext, conv_stem_ext, conv_taps_ext, conv_wgrad_ext, group_norm_ext, small_wgrad_ext
     from monodetr_amd.monodetr import linear
     from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func
     from monodetr_amd.monodetr.ops.modules import ms_deform_attn
@@ -68,6 +71,7 @@ def apply_switches(names):
     conv3x3_ext.ENABLED = "MDETR_CONV3X3" in names
     conv_taps_ext.ENABLED = "MDETR_CONV_STRIDED" in names
     conv_wgrad_ext.ENABLED = "MDETR_CONV_WGRAD" in names
+    conv_stem_ext.ENABLED = "MDETR_CONV_STEM" in names
     group_norm_ext.ENABLED = "MDETR_GROUP_NORM" in names
     small_wgrad_ext.ENABLED = "MDETR_SMALL_WGRAD" in names
     ms_deform_attn_func._NATIVE_BF16 = "MDETR_MSDA_BF16" in names

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..utils.misc import NestedTensor, mark_no_padding
-from .. import bias_act_ext, conv3x3_ext, conv_taps_ext
+from .. import bias_act_ext, conv3x3_ext, conv_stem_ext, conv_taps_ext
 from .linear import pointwise_conv, pointwise_eligible, pointwise_relu_fusable
 from .position_encoding import build_position_encoding
 
@@ -144,6 +144,8 @@ def conv_bn(x, conv, bn, relu):
             if relu and pointwise_relu_fusable(x, w, b):
                 return pointwise_conv(x, w, b, relu=True)            # ReLU in the GEMM's epilogue
             x = pointwise_conv(x, w, b)
+        elif relu and conv_stem_ext.ENABLED and conv_stem_ext.supported(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
+            return conv_stem_ext.conv_stem(x, w, shift)              # the frozen 7x7 / stride-2 stem (csrc/conv_stem.hip), shift + ReLU inside
         elif conv_taps_ext.ENABLED and conv_taps_ext.supported(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
             # the stride-2 3x3 of a stage's first block and its 1x1 / stride-2 projection shortcut (csrc/conv_taps.hip), forward,
             # input gradient (four pixel-parity classes) and weight gradient (csrc/conv_wgrad.hip) by hand

@@ -83,6 +83,15 @@ inline bf16x8 rsrc_load_bf16x8(mdetr_rsrc r, unsigned lane_offset, unsigned scal
     return v;
 }
 
+inline unsigned short rsrc_load_u16(mdetr_rsrc r, unsigned lane_offset, unsigned scalar_offset)
+{
+    unsigned short v = 0;
+    if (static_cast<unsigned long long>(lane_offset) + 2 > r.bytes) return 0;
+    if (static_cast<unsigned long long>(lane_offset) + scalar_offset + 2 > r.bytes) abort();
+    memcpy(&v, r.base + lane_offset + scalar_offset, 2);
+    return v;
+}
+
 inline void wave_sync() { hipshim::sync_wave(); }
 
 #define MDETR_DYNAMIC_LDS(type, name) type *name = reinterpret_cast<type *>(hipshim::dynamic_lds())

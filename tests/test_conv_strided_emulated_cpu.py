@@ -107,3 +107,26 @@ def test_refusals(ext):
     assert lib.mdetr_conv_wgrad(x.data_ptr(), x.data_ptr(), buf.data_ptr(), 1 << 30, 1, 8, 8, 48, 8, 8, 64, 3, 1, -1, None) != 0   # C % 64
     d = torch.tensor([1, 8, 8, 64, 4, 4, 64, 3, 3, 3, 1, 1, 0, 1, 0, 1, 0, 1024, 256, 64, 576, 192, 64], dtype=torch.int64)
     assert lib.mdetr_conv_taps(x.data_ptr(), w.data_ptr(), None, x.data_ptr(), d.data_ptr(), 0, -1, None) != 0                   # 3x3 taps need stride 2
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 8, 64), (2, 13, 75), (1, 30, 200), (1, 5, 6)])
+def test_stem_matches_conv2d(B, H, W):
+    """csrc/conv_stem.hip: 7x7 / stride 2 / pad 3 on the 3-channel image, shift + ReLU: borders on every side, ragged tiles,
+    several column tiles per workgroup (W = 200: 100 output columns = 4 tiles)."""
+    from monodetr_amd import conv_stem_ext
+    conv_stem_ext._backend = native_emul.lib()
+    try:
+        g = torch.Generator().manual_seed(H * W + B)
+        x = torch.randn(B, 3, H, W, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(64, 3, 7, 7, generator=g) / 12).to(torch.bfloat16)
+        shift = torch.randn(64, generator=g) * 0.3
+        assert conv_stem_ext.supported(x, w)
+        y = conv_stem_ext.conv_stem(x, w, shift)
+        ref = F.relu(F.conv2d(x.float(), w.float(), shift, stride=2, padding=3))
+        assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+        close(y, ref, "stem")
+        # transposition-detecting: the packed weight is not symmetric in (t, e, ch)
+        p = conv_stem_ext.pack_weight(w)
+        assert p.shape == (64, 176) and float(p[5, 2 * 24 + 4 * 3 + 1]) == float(w[5, 1, 2, 4]) and float(p[:, 21:24].abs().max()) == 0 and float(p[:, 168:].abs().max()) == 0
+    finally:
+        conv_stem_ext._backend = None

@@ -714,6 +714,101 @@ def test_conv3x3_module_with_a_trainable_bias_matches_the_library(monkeypatch):
         assert (a.float() - b.float()).abs().max().item() <= lim, name
 
 
+# ---- strided convolutions (csrc/conv_taps.hip), convolution weight gradients (csrc/conv_wgrad.hip), the stem (csrc/conv_stem.hip) ----
+@pytest.mark.parametrize("B,H,W,C,N,k,relu", [
+    (8, 96, 320, 128, 128, 3, True),            # layer2.0.conv2
+    (8, 48, 160, 256, 256, 3, True),            # layer3.0.conv2 (and the depth predictor's downsample)
+    (8, 24, 80, 512, 512, 3, True),             # layer4.0.conv2
+    (8, 12, 40, 2048, 256, 3, False),           # the fourth pyramid level (monodetr.py:87-92)
+    (8, 96, 320, 256, 512, 1, False),           # layer2.0.downsample (1x1 / stride 2)
+    (8, 24, 80, 1024, 2048, 1, False),          # layer4.0.downsample
+    (2, 13, 45, 64, 192, 3, True),              # odd map, ragged tiles
+    (8, 32, 110, 256, 256, 3, False),           # 512 x 1760: the depth predictor's downsample / level shapes of BASELINE configs[4]
+])
+def test_conv_strided_kernel_matches_the_library_convolution(B, H, W, C, N, k, relu, monkeypatch):
+    from monodetr_amd import conv_taps_ext, conv_wgrad_ext
+    monkeypatch.setattr(conv_wgrad_ext, "ENABLED", True)
+    F = torch.nn.functional
+    g = torch.Generator(device="cuda").manual_seed(C + N + H + k)
+    pad = 1 if k == 3 else 0
+    x = torch.randn(B, C, H, W, generator=g, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(N, C, k, k, generator=g, device="cuda") / (k * C ** 0.5)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    shift = torch.randn(N, generator=g, device="cuda") * 0.5
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dy = torch.randn(B, N, OH, OW, generator=g, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = conv_taps_ext.conv_strided(x, w, shift, relu=relu)
+    assert y.shape == (B, N, OH, OW)
+    y.backward(dy)
+    got = (y.detach(), x.grad.clone(), w.grad.clone())
+    x.grad = w.grad = None
+    ref = F.conv2d(x.float(), w.float(), shift, stride=2, padding=pad)                  # fp32 on the same bf16 inputs
+    ref = torch.relu(ref) if relu else ref
+    mask = (y.detach() > 0) if relu else torch.ones_like(ref, dtype=torch.bool)
+    gx, gw = torch.autograd.grad(F.conv2d(x.float(), w.float(), None, stride=2, padding=pad), (x, w), dy.float() * mask)
+    for name, a, r in zip(("y", "dx", "dw"), got, (ref, gx, gw)):
+        lim = 1.2e-2 * max(1.0, r.abs().max().item())                                   # one bf16 rounding of an fp32 sum
+        assert (a.float() - r).abs().max().item() <= lim, name
+
+
+@pytest.mark.parametrize("B,H,W,C,N", [(8, 48, 160, 128, 128), (8, 24, 80, 256, 256), (8, 12, 40, 512, 512), (2, 9, 37, 64, 96), (8, 32, 110, 256, 256)])
+def test_conv_wgrad_kernel_matches_the_library_weight_gradient(B, H, W, C, N, monkeypatch):
+    """csrc/conv_wgrad.hip at the stride-1 shapes of layer2-4 / the depth head: fp32 partial sums, ONE rounding -- held to the fp32
+    autograd gradient on the same bf16 operands (tighter than the library's own bf16 split-K sums)."""
+    from monodetr_amd import conv_wgrad_ext
+    monkeypatch.setattr(conv_wgrad_ext, "ENABLED", True)
+    g = torch.Generator(device="cuda").manual_seed(C + H)
+    x = torch.randn(B, C, H, W, generator=g, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(B, N, H, W, generator=g, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert conv_wgrad_ext.supported(x, dy, 3, 1)
+    w = torch.zeros(N, C, 3, 3, device="cuda", requires_grad=True)
+    ref, = torch.autograd.grad(torch.nn.functional.conv2d(x.float(), w, None, padding=1), w, dy.float())
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 6e-3)):
+        dw = conv_wgrad_ext.weight_gradient(x, dy, 3, 1, dtype)
+        assert dw.shape == ref.shape and dw.dtype == dtype
+        assert (dw.float() - ref).abs().max().item() <= tol * ref.abs().max().item(), dtype
+    a, b = conv_wgrad_ext.weight_gradient(x, dy, 3, 1, torch.float32), conv_wgrad_ext.weight_gradient(x, dy, 3, 1, torch.float32)
+    assert torch.equal(a, b)                                                             # fixed-order sums: deterministic
+
+
+@pytest.mark.parametrize("B,H,W", [(8, 384, 1280), (2, 512, 1760), (1, 37, 75)])
+def test_conv_stem_kernel_matches_the_library_convolution(B, H, W):
+    from monodetr_amd import conv_stem_ext
+    g = torch.Generator(device="cuda").manual_seed(H)
+    x = torch.randn(B, 3, H, W, generator=g, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 3, 7, 7, generator=g, device="cuda") / 12).to(torch.bfloat16)
+    shift = torch.randn(64, generator=g, device="cuda") * 0.3
+    y = conv_stem_ext.conv_stem(x, w, shift)
+    ref = torch.relu(torch.nn.functional.conv2d(x.float(), w.float(), shift, stride=2, padding=3))
+    assert y.shape == ref.shape
+    assert (y.float() - ref).abs().max().item() <= 1.2e-2 * max(1.0, ref.abs().max().item())
+
+
+def test_training_step_with_the_convolution_kernels_matches_default():
+    """The backbone / pyramid / depth-head convolutions by hand (stem, stride-2 3x3 and 1x1, every weight gradient) against the
+    library path: loss trajectories of three iterations, and no MIOpen convolution is left in the step."""
+    import bench
+    from model_init import disable_dropout_
+    dev = torch.device("cuda", 0)
+    traj, families = {}, ("MDETR_CONV3X3", "MDETR_CONV_STRIDED", "MDETR_CONV_WGRAD", "MDETR_CONV_STEM")
+    try:
+        for names in ((), families):
+            step = bench.TrainStep(dev, 2, "bf16", size=(96, 320), switches=names)
+            disable_dropout_(step.raw_model)
+            traj[names] = [float(step()) for _ in range(3)]
+            if names:
+                with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+                    step()
+                    torch.cuda.synchronize()
+                kernels = [e.key for e in prof.key_averages()]
+                left = [k for k in kernels if "igemm" in k or "miopen" in k.lower() or "conv_bwd" in k or "grouped_conv" in k]
+                assert not left, left
+                assert any("conv_wgrad_kernel" in k for k in kernels) and any("conv_taps_kernel" in k for k in kernels) and any("conv_stem_kernel" in k for k in kernels)
+    finally:
+        bench.apply_switches(set())
+    for a, b in zip(traj[()], traj[families]):
+        assert abs(a - b) <= 2e-2 * abs(a), traj
+
+
 # ---- GroupNorm (+ ReLU) on channels-last activations (csrc/group_norm.hip) --------------------------------------------------
 @pytest.mark.parametrize("shape,dtype,pdtype,relu", [
     ((8, 256, 24, 80), torch.bfloat16, torch.bfloat16, True),          # depth head stage
