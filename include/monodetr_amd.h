@@ -455,6 +455,15 @@ int mdetr_conv3x3_forward(const void *x, const void *w, const float *shift, void
 int mdetr_conv_taps(const void *x, const void *w, const float *shift, void *y, const int64_t *dims, int relu, int device, void *stream);
 
 /*
+ * Input gradient of a stride-2 convolution (3x3 / pad 1 or 1x1 / pad 0), the four pixel-parity classes in ONE launch; every element
+ * of dx is written exactly once (the odd pixels of a 1x1 convolution's gradient as zeros):
+ *   dx[b, i, j, c] = sum_{t, s, n : (i + P - t) and (j + P - s) even} dy[b, (i + P - t) / 2, (j + P - s) / 2, n] * wt[c, t, s, n]
+ *   dy  bf16 [B, OH, OW, N], N % 64 == 0;  wt  bf16 [C, K, K, N] (the weight with its channel axes swapped, taps not mirrored);
+ *   dx  bf16 [B, H, W, C], C % 32 == 0;  OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1
+ */
+int mdetr_conv_dgrad_s2(const void *dy, const void *wt, void *dx, int B, int OH, int OW, int N, int H, int W, int C, int K, int device, void *stream);
+
+/*
  * The ResNet stem (torchvision ResNet.conv1 -> bn1 -> relu behind lib/models/monodetr/backbone.py:93-106; frozen: forward only):
  *   y[b, r, c, n] = relu(shift[n] + sum_{t, e < 7, ch < 3} x[b, 2r + t - 3, 2c + e - 3, ch] * w[n, ch, t, e])      (csrc/conv_stem.hip)
  *   x         bf16 [B, H, W, 3] (a channels_last [B, 3, H, W] image batch)

@@ -52,8 +52,11 @@ def conv_stem(x, weight, shift):
     """relu(conv2d(x, weight, stride=2, padding=3) + shift); the packed form of `weight` is cached per (storage, version)."""
     if not supported(x, weight):
         raise RuntimeError("conv_stem: needs a bf16 channels_last [B, 3, H, W] image batch and a frozen bf16 [64, 3, 7, 7] weight")
-    key = (weight.data_ptr(), weight._version, str(weight.device))
+    # keyed by the tensor OBJECT (a weak reference: a freed tensor's address and version may come back with another weight) and its
+    # version counter
     hit = _packed.get("w")
-    if hit is None or hit[0] != key:
-        hit = _packed["w"] = (key, pack_weight(weight), None if shift is None else shift.float().contiguous())
-    return _launch(x, hit[1], hit[2])
+    if hit is None or hit[0]() is not weight or hit[1] != weight._version or (hit[4]() is not shift if shift is not None else hit[4] is not None):
+        import weakref
+        hit = _packed["w"] = (weakref.ref(weight), weight._version, pack_weight(weight), None if shift is None else shift.float().contiguous(),
+                              None if shift is None else weakref.ref(shift))
+    return _launch(x, hit[2], hit[3])

@@ -54,28 +54,17 @@ def _forward(x, w_ohwi, shift, relu):
 
 
 def _input_gradient(dy, w_ohwi, H, W):
-    """dX [B, C, H, W] of the stride-2 convolution from dY [B, N, OH, OW] (channels_last): one launch per pixel-parity class."""
+    """dX [B, C, H, W] of the stride-2 convolution from dY [B, N, OH, OW] (channels_last): the four pixel-parity classes in one
+    launch (``mdetr_conv_dgrad_s2``); every element of dX is written by it."""
     B, N, OH, OW = dy.shape
     k, C = w_ohwi.shape[1], w_ohwi.shape[3]
-    wt = w_ohwi.flip(1, 2).permute(3, 1, 2, 0).contiguous()              # [C, k, k, N]: taps mirrored, channel axes swapped
-    if k == 1:
-        dx = torch.zeros((B, C, H, W), dtype=torch.bfloat16, device=dy.device).contiguous(memory_format=torch.channels_last)
-        classes = [(0, 0)]                                               # a 1x1 / stride-2 convolution reads the even pixels only
-    else:
-        dx = torch.empty((B, C, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
-        classes = [(0, 0), (0, 1), (1, 0), (1, 1)]
-    for pi, pj in classes:
-        oh, ow = (H - pi + 1) // 2, (W - pj + 1) // 2
-        if oh <= 0 or ow <= 0:
-            continue
-        if k == 1:
-            tr, ts, ta0, te0 = 1, 1, 0, 0
-        else:
-            # even coordinate 2r: the centre tap on dY[r]; odd coordinate 2r + 1: tap 2 on dY[r] and tap 0 on dY[r + 1] -- in the
-            # MIRRORED weight that is tap 0, then tap 2 (step 2)
-            tr, ts, ta0, te0 = 1 + pi, 1 + pj, 1 - pi, 1 - pj
-        _call(dy, wt, None, dx, [B, OH, OW, N, oh, ow, C, 1, tr, ts, 0, 0, ta0, 2, te0, 2,
-                                 (pi * W + pj) * C, H * W * C, 2 * W * C, 2 * C, k * k * N, k * N, N], False)
+    wt = w_ohwi.permute(3, 1, 2, 0).contiguous()                        # [C, k, k, N]: channel axes swapped (one small copy)
+    dx = torch.empty((B, C, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+    cuda = dy.is_cuda
+    rc = _lib().mdetr_conv_dgrad_s2(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), B, OH, OW, N, H, W, C, k, dy.device.index if cuda else -1,
+                                    torch.cuda.current_stream(dy.device).cuda_stream if cuda else None)
+    if rc != 0:
+        _capi.check(rc, "mdetr_conv_dgrad_s2")
     return dx
 
 

@@ -534,6 +534,21 @@ int mdetr_conv_taps(const void *x, const void *w, const float *shift, void *y, c
     return MDETR_OK;
 }
 
+int mdetr_conv_dgrad_s2(const void *dy, const void *wt, void *dx, int B, int OH, int OW, int N, int H, int W, int C, int K, int device, void *stream)
+{
+    if (B < 0 || OH < 0 || OW < 0 || H < 0 || W < 0 || N <= 0 || C <= 0) return fail(MDETR_E_ARG, "mdetr_conv_dgrad_s2: bad sizes");
+    if (B == 0 || H == 0 || W == 0) return MDETR_OK;
+    if (!dy || !wt || !dx) return fail(MDETR_E_ARG, "mdetr_conv_dgrad_s2: null pointer");
+    if (!mdetr::conv_dgrad_s2_supported(B, OH, OW, N, H, W, C, K, dy, wt, dx))
+        return fail(MDETR_E_ARG, "mdetr_conv_dgrad_s2: needs K in {1, 3}, N %% 64 == 0, C %% 32 == 0, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1, 16-byte aligned "
+                                 "dy / wt (K=%d N=%d C=%d %dx%d -> %dx%d)", K, N, C, H, W, OH, OW);
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv_dgrad_s2: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::conv_dgrad_s2_launch(dy, wt, dx, B, OH, OW, N, H, W, C, K, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv_dgrad_s2: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
 int mdetr_conv_stem(const void *x, const void *w_packed, const float *shift, void *y, int B, int H, int W, int device, void *stream)
 {
     if (B < 0 || H < 0 || W < 0) return fail(MDETR_E_ARG, "mdetr_conv_stem: bad sizes B=%d H=%d W=%d", B, H, W);

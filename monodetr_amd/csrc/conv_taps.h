@@ -18,6 +18,10 @@ struct ConvTapsDims {
 };
 
 bool conv_taps_supported(const ConvTapsDims &d, const void *x, const void *w, const void *y);
+// the input gradient of a 3x3 (pad 1) or 1x1 (pad 0) stride-2 convolution, all four pixel-parity classes in one launch:
+// dy [B, OH, OW, N] (N % 64 == 0), wt [C, K, K, N] (channel axes swapped, taps not mirrored), dx [B, H, W, C] (C % 32 == 0)
+bool conv_dgrad_s2_supported(int B, int OH, int OW, int N, int H, int W, int C, int K, const void *dy, const void *wt, const void *dx);
+hipError_t conv_dgrad_s2_launch(const void *dy, const void *wt, void *dx, int B, int OH, int OW, int N, int H, int W, int C, int K, hipStream_t st);
 hipError_t conv_taps_launch(const void *x, const void *w, const float *shift, void *y, const ConvTapsDims &d, bool relu, hipStream_t st);
 
 }  // namespace mdetr

@@ -23,6 +23,7 @@
 // Products transposed, Y^T[n][pixel], v_mfma_f32_32x32x16_bf16: shift, ReLU and the bf16 rounding in registers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <mdetr_wave.h>
 
@@ -42,9 +43,8 @@ struct TapGeom {
 };
 
 template <int NB, bool RELU, int TR, int TS, int SI>
-__global__ __launch_bounds__(kWavesT * 64)
-void conv_taps_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, const float *__restrict__ shift,
-                      __bf16 *__restrict__ y, const TapGeom g)
+__device__ __forceinline__ void conv_taps_body(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, const float *__restrict__ shift,
+                                               __bf16 *__restrict__ y, const TapGeom &g, const int bid)
 {
     constexpr int HH = SI * (kWavesT - 1) + TR;                              // halo rows
     constexpr int HWC = SI * (kTileWT - 1) + TS;                             // halo columns
@@ -57,12 +57,12 @@ void conv_taps_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
     int group, t;
     if (g.xcd_per > 0) {                                                     // an XCD's L2 sees one output-channel group's weights
-        const int xcd = blockIdx.x & 7, within = blockIdx.x >> 3;
+        const int xcd = bid & 7, within = bid >> 3;
         group = xcd % g.ngroups;
         t = within * g.xcd_per + xcd / g.ngroups;
     } else {
-        group = blockIdx.x % g.ngroups;
-        t = blockIdx.x / g.ngroups;
+        group = bid % g.ngroups;
+        t = bid / g.ngroups;
     }
     if (t >= g.tiles) return;
     const int tx = t % g.tiles_x; t /= g.tiles_x;
@@ -185,6 +185,99 @@ void conv_taps_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w
     }
 }
 
+inline TapGeom geometry(const ConvTapsDims &d, int nb, int64_t &blocks)
+{
+    TapGeom g;
+    g.d = d;
+    g.tiles_x = (d.OW + kTileWT - 1) / kTileWT;
+    g.tiles_y = (d.OH + kWavesT - 1) / kWavesT;
+    g.tiles = d.B * g.tiles_x * g.tiles_y;
+    g.ngroups = (d.N + nb * 32 - 1) / (nb * 32);
+    g.xcd_per = (g.ngroups <= 8 && 8 % g.ngroups == 0) ? 8 / g.ngroups : 0;
+    blocks = g.xcd_per ? 8ll * ((g.tiles + g.xcd_per - 1) / g.xcd_per) : static_cast<int64_t>(g.tiles) * g.ngroups;
+    return g;
+}
+
+// output channels per workgroup = 32 NB: as many as the layer has (the halo is then staged once for all of them) -- unless that
+// leaves most of the 256 CUs without a workgroup (the fourth pyramid level: 8 x 6 x 20 output pixels = 16 tiles)
+inline int pick_nb(const ConvTapsDims &d, int nb_min)
+{
+    const int64_t tiles = static_cast<int64_t>(d.B) * ((d.OH + kWavesT - 1) / kWavesT) * ((d.OW + kTileWT - 1) / kTileWT);
+    int nb = d.N >= 128 ? 4 : (d.N >= 64 ? 2 : 1);
+    if (const char *ev = getenv("MDETR_CONV_TAPS_NB")) {                     // tests / A-B runs: a fixed width (clamped to what exists)
+        const int f = atoi(ev);
+        if (f == 1 || f == 2 || f == 4) return f < nb_min ? nb_min : (f > nb ? nb : f);
+    }
+    while (nb > nb_min && tiles * ((d.N + nb * 32 - 1) / (nb * 32)) < 256) nb >>= 1;
+    return nb < nb_min ? nb_min : nb;
+}
+
+template <int NB, bool RELU, int TR, int TS, int SI>
+__global__ __launch_bounds__(kWavesT * 64)
+void conv_taps_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, const float *__restrict__ shift,
+                      __bf16 *__restrict__ y, const TapGeom g)
+{
+    conv_taps_body<NB, RELU, TR, TS, SI>(x, w, shift, y, g, static_cast<int>(blockIdx.x));
+}
+
+// ---- the input gradient of a stride-2 convolution in ONE launch: the four pixel-parity classes side by side ----------------
+// dX[2r + pi, 2c + pj] for (pi, pj) in {0, 1}^2; class (pi, pj) has (1 + pi) x (1 + pj) taps of a 3x3 kernel.  For a 1x1 kernel
+// only the even pixels receive anything: the other three classes store zeros (every element of dX is written exactly once: no
+// zero-fill pass).  Workgroups are numbered class by class, the four-tap class first (the longest workgroups start first).
+struct Dgrad4Geom {
+    TapGeom g[4];
+    int blk0[5];                         // first workgroup of each class (in launch order), and the total
+    int taps[4];                         // 0: store zeros, else (TR << 4) | TS
+};
+
+template <int NB>
+__device__ __forceinline__ void zero_tile(__bf16 *__restrict__ y, const TapGeom &g, const int bid)
+{
+    const ConvTapsDims &d = g.d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, col = lane & 31;
+    int group, t;
+    if (g.xcd_per > 0) {
+        const int xcd = bid & 7, within = bid >> 3;
+        group = xcd % g.ngroups;
+        t = within * g.xcd_per + xcd / g.ngroups;
+    } else {
+        group = bid % g.ngroups;
+        t = bid / g.ngroups;
+    }
+    if (t >= g.tiles) return;
+    const int tx = t % g.tiles_x; t /= g.tiles_x;
+    const int ty = t % g.tiles_y; const int b = t / g.tiles_y;
+    const int r = ty * kWavesT + wave, c = tx * kTileWT + col, n0 = group * NB * 32;
+    if (r < d.OH && c < d.OW) {
+        __bf16 *yp = y + d.y_off + static_cast<int64_t>(b) * d.y_sb + static_cast<int64_t>(r) * d.y_sr + static_cast<int64_t>(c) * d.y_sc + n0 + 4 * half;
+        bf16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = static_cast<__bf16>(0.f);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (n0 + nb * 32 + 8 * q + 4 * half < d.N) *reinterpret_cast<bf16x4 *>(yp + nb * 32 + 8 * q) = o;
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(kWavesT * 64)
+void conv_dgrad4_kernel(const __bf16 *__restrict__ dy, const __bf16 *__restrict__ wt, __bf16 *__restrict__ dx, const Dgrad4Geom q)
+{
+    const int bid = static_cast<int>(blockIdx.x);
+    const int cls = (bid >= q.blk0[1] ? 1 : 0) + (bid >= q.blk0[2] ? 1 : 0) + (bid >= q.blk0[3] ? 1 : 0);      // uniform
+    const TapGeom &g = q.g[cls];
+    const int local = bid - q.blk0[cls];
+    switch (q.taps[cls]) {
+    case 0x22: conv_taps_body<NB, false, 2, 2, 1>(dy, wt, nullptr, dx, g, local); break;
+    case 0x21: conv_taps_body<NB, false, 2, 1, 1>(dy, wt, nullptr, dx, g, local); break;
+    case 0x12: conv_taps_body<NB, false, 1, 2, 1>(dy, wt, nullptr, dx, g, local); break;
+    case 0x11: conv_taps_body<NB, false, 1, 1, 1>(dy, wt, nullptr, dx, g, local); break;
+    default: zero_tile<NB>(dx, g, local); break;
+    }
+}
+
 template <int NB, bool RELU, int TR, int TS, int SI>
 hipError_t launch(const void *x, const void *w, const float *shift, void *y, const ConvTapsDims &d, hipStream_t st)
 {
@@ -201,14 +294,8 @@ hipError_t launch(const void *x, const void *w, const float *shift, void *y, con
         if (e != hipSuccess) return e;
         if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;
     }
-    TapGeom g;
-    g.d = d;
-    g.tiles_x = (d.OW + kTileWT - 1) / kTileWT;
-    g.tiles_y = (d.OH + kWavesT - 1) / kWavesT;
-    g.tiles = d.B * g.tiles_x * g.tiles_y;
-    g.ngroups = (d.N + NB * 32 - 1) / (NB * 32);
-    g.xcd_per = (g.ngroups <= 8 && 8 % g.ngroups == 0) ? 8 / g.ngroups : 0;
-    const int64_t blocks = g.xcd_per ? 8ll * ((g.tiles + g.xcd_per - 1) / g.xcd_per) : static_cast<int64_t>(g.tiles) * g.ngroups;
+    int64_t blocks = 0;
+    const TapGeom g = geometry(d, NB, blocks);
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kWavesT * 64), lds, st, static_cast<const __bf16 *>(x),
                        static_cast<const __bf16 *>(w), shift, static_cast<__bf16 *>(y), g);
     return hipGetLastError();
@@ -217,10 +304,31 @@ hipError_t launch(const void *x, const void *w, const float *shift, void *y, con
 template <int TR, int TS, int SI>
 hipError_t by_width(const void *x, const void *w, const float *shift, void *y, const ConvTapsDims &d, bool relu, hipStream_t st)
 {
-    // 128 output channels per workgroup where the layer has them (the halo is then read once per 128 channels; 243 VGPRs for the
-    // 3x3 / stride-2 form, no spill)
-    if (d.N >= 128) return relu ? launch<4, true, TR, TS, SI>(x, w, shift, y, d, st) : launch<4, false, TR, TS, SI>(x, w, shift, y, d, st);
+    const int nb = pick_nb(d, SI == 2 && TR == 3 ? 1 : 2);
+    if (nb == 4) return relu ? launch<4, true, TR, TS, SI>(x, w, shift, y, d, st) : launch<4, false, TR, TS, SI>(x, w, shift, y, d, st);
+    if constexpr (SI == 2 && TR == 3) {
+        if (nb == 1) return relu ? launch<1, true, TR, TS, SI>(x, w, shift, y, d, st) : launch<1, false, TR, TS, SI>(x, w, shift, y, d, st);
+    }
     return relu ? launch<2, true, TR, TS, SI>(x, w, shift, y, d, st) : launch<2, false, TR, TS, SI>(x, w, shift, y, d, st);
+}
+
+template <int NB>
+hipError_t launch_dgrad4(const void *dy, const void *wt, void *dx, const Dgrad4Geom &q, hipStream_t st)
+{
+    constexpr int HH = kWavesT - 1 + 2, HWC = kTileWT - 1 + 2;                 // the 2x2 class needs the most
+    constexpr size_t lds = static_cast<size_t>(HH) * HWC * kPadT * 2 + static_cast<size_t>(2) * NB * 32 * kPadT * 2 + NB * 32 * 4;
+    auto kern = conv_dgrad4_kernel<NB>;
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess) dev_ = -1;
+    if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(q.blk0[4])), dim3(kWavesT * 64), lds, st, static_cast<const __bf16 *>(dy),
+                       static_cast<const __bf16 *>(wt), static_cast<__bf16 *>(dx), q);
+    return hipGetLastError();
 }
 
 }  // namespace
@@ -235,6 +343,52 @@ bool conv_taps_supported(const ConvTapsDims &d, const void *x, const void *w, co
            d.y_off % 4 == 0 && d.y_sb % 4 == 0 && d.y_sr % 4 == 0 && d.y_sc % 4 == 0 && d.PT >= 0 && d.PL >= 0 &&
            static_cast<int64_t>(d.B) * d.H * d.W * d.C < (1ll << 30) &&
            static_cast<int64_t>(d.B) * ((d.OH + 3) / 4) * ((d.OW + 31) / 32) * ((d.N + 31) / 32) < (1ll << 30);
+}
+
+bool conv_dgrad_s2_supported(int B, int OH, int OW, int N, int H, int W, int C, int K, const void *dy, const void *wt, const void *dx)
+{
+    const auto al = [](const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+    return B > 0 && OH > 0 && OW > 0 && H > 0 && W > 0 && (K == 3 || K == 1) && N > 0 && N % 64 == 0 && C > 0 && C % 32 == 0 &&
+           OH == (H - 1) / 2 + 1 && OW == (W - 1) / 2 + 1 && al(dy, 16) && al(wt, 16) && al(dx, 8) &&
+           static_cast<int64_t>(B) * OH * OW * N < (1ll << 30) && static_cast<int64_t>(B) * H * W * C < (1ll << 31);
+}
+
+// dy [B, OH, OW, N], wt [C, K, K, N] (the weight with its channel axes swapped; taps NOT mirrored), dx [B, H, W, C]
+hipError_t conv_dgrad_s2_launch(const void *dy, const void *wt, void *dx, int B, int OH, int OW, int N, int H, int W, int C, int K, hipStream_t st)
+{
+    Dgrad4Geom q;
+    ConvTapsDims probe;
+    probe.B = B; probe.OH = (H + 1) / 2; probe.OW = (W + 1) / 2; probe.N = C;
+    const int nb = pick_nb(probe, 2);
+    const int order[4] = {3, 2, 1, 0};                                        // class = 2 pi + pj; the four-tap class first
+    int blk = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int cls = order[k], pi = cls >> 1, pj = cls & 1;
+        ConvTapsDims d;
+        d.B = B; d.H = OH; d.W = OW; d.C = N;
+        d.OH = (H - pi + 1) / 2; d.OW = (W - pj + 1) / 2; d.N = C;
+        d.SI = 1; d.PT = 0; d.PL = 0;
+        d.y_off = (static_cast<int64_t>(pi) * W + pj) * C; d.y_sb = static_cast<int64_t>(H) * W * C; d.y_sr = 2ll * W * C; d.y_sc = 2ll * C;
+        d.w_sn = static_cast<int64_t>(K) * K * N; d.w_sa = static_cast<int64_t>(K) * N; d.w_se = N;
+        if (K == 3) {
+            // even coordinate 2r: the centre tap on dY[r]; odd coordinate 2r + 1: tap 2 on dY[r], then tap 0 on dY[r + 1]
+            d.TR = 1 + pi; d.TS = 1 + pj;
+            d.ta0 = pi ? 2 : 1; d.ta_step = pi ? -2 : 0;
+            d.te0 = pj ? 2 : 1; d.te_step = pj ? -2 : 0;
+            q.taps[k] = (d.TR << 4) | d.TS;
+        } else {
+            d.TR = d.TS = 1; d.ta0 = d.te0 = 0; d.ta_step = d.te_step = 0;
+            q.taps[k] = cls == 0 ? 0x11 : 0;                                  // a 1x1 / stride-2 convolution reads the even pixels only
+        }
+        int64_t blocks = 0;
+        q.g[k] = geometry(d, nb, blocks);
+        if (d.OH <= 0 || d.OW <= 0) blocks = 0;
+        q.blk0[k] = blk;
+        blk += static_cast<int>(blocks);
+    }
+    q.blk0[4] = blk;
+    if (blk == 0) return hipSuccess;
+    return nb == 4 ? launch_dgrad4<4>(dy, wt, dx, q, st) : launch_dgrad4<2>(dy, wt, dx, q, st);
 }
 
 hipError_t conv_taps_launch(const void *x, const void *w, const float *shift, void *y, const ConvTapsDims &d, bool relu, hipStream_t st)

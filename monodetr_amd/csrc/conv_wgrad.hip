@@ -86,85 +86,87 @@ void conv_wgrad_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[e][i] = 0.f;
 
-    // ---- loading tasks: one 8 x 8 block each.  X: (slot, channel piece): XC * 8; dY: (column, channel piece): 32 * 16
-    constexpr int XT = XC * (kCB / 8), DT = kCols * (kNB / 8), TASKS = XT + DT;
-    constexpr int ROUNDS = (TASKS + kThreadsG - 1) / kThreadsG;
-    bf16x8 stage[ROUNDS][8];
+    // ---- loading tasks: one 8 x 8 block (8 rows x 8 channels) per lane.  A WAVE takes 16 columns x 4 channel pieces of one operand
+    // (lane = 16 piece + column): the 16 lanes of a ds_write_b128 group then store 16 CONSECUTIVE slots of one channel row --
+    // conflict-free (8 lanes = the 8 pieces of one pixel, the coalescing-friendly order, put 4 lanes on each of two bank quads:
+    // 68 % of the LDS cycles were conflicts, profiles/r03b_pmc_conv.json) -- while a load instruction still covers 64 contiguous
+    // bytes of each of its 16 pixels.
+    constexpr int CGX = (XC + 15) / 16;                                      // column groups of the X window
+    constexpr int WTASKS = 2 * CGX + 8;                                      // X: CGX x 2 piece groups; dY: 2 x 4
+    constexpr int kWavesG = kThreadsG / 64;
+    constexpr int ROUNDS = (WTASKS + kWavesG - 1) / kWavesG;
+    constexpr int PF = ROUNDS <= 2 ? 2 : 1;                                  // tiles in flight ahead of the products (registers: 32 per round and tile)
+    bf16x8 stage[PF][ROUNDS][8];
     // Loads go through buffer resources: a lane outside the image (the convolution's padding, a ragged tile) passes an offset
     // beyond the tensor and receives zeros -- no branch, no zero fill.  Per-lane offset = the column part, scalar offset = the
     // (image, row) part; the tensors are below 2^31 bytes (checked by the launcher).
     const mdetr_rsrc xr = make_rsrc(x, static_cast<unsigned>(static_cast<int64_t>(d.B) * d.H * d.W * d.C * 2));
     const mdetr_rsrc yr = make_rsrc(dy, static_cast<unsigned>(static_cast<int64_t>(d.B) * d.OH * d.OW * d.N * 2));
-    // what a thread's tasks are does not depend on the tile: (kind, slot / column, channel piece) per round
-    int t_rel[ROUNDS], t_ch[ROUNDS];
+    const int ci = lane & 15, pi = lane >> 4;
+    // what a lane's tasks are does not depend on the tile: (column of the window / of the tile, channel byte offset) per round
+    int t_rel[ROUNDS], t_ch[ROUNDS], t_dst[ROUNDS];                          // t_dst: first LDS slot (row of its piece's channel 0)
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
-        const int task = threadIdx.x + rd * kThreadsG;
-        if (task < XT) {
-            const int slot = task >> 3;
-            t_rel[rd] = SI == 1 ? slot : (TS == 3 ? (slot < EVEN ? 2 * slot : 2 * (slot - EVEN) + 1) : 2 * slot);
-            t_ch[rd] = (c0 + (task & 7) * 8) * 2;
+        const int wt = wave + rd * kWavesG;                                  // wave-uniform
+        if (wt < 2 * CGX) {
+            const int slot = 16 * (wt >> 1) + ci, piece = 4 * (wt & 1) + pi;
+            t_rel[rd] = slot >= XC ? -1 : (SI == 1 ? slot : (TS == 3 ? (slot < EVEN ? 2 * slot : 2 * (slot - EVEN) + 1) : 2 * slot));
+            t_ch[rd] = (c0 + piece * 8) * 2;
+            t_dst[rd] = piece * 8 * XSTRIDE + slot;
         } else {
-            const int k = task - XT;
-            t_rel[rd] = k >> 4;
-            t_ch[rd] = (n0 + (k & 15) * 8 < d.N && task < TASKS) ? (n0 + (k & 15) * 8) * 2 : -1;
+            const int k = wt - 2 * CGX, col = 16 * (k >> 2) + ci, piece = 4 * (k & 3) + pi;
+            t_rel[rd] = col;
+            t_ch[rd] = (wt < WTASKS && n0 + piece * 8 < d.N) ? (n0 + piece * 8) * 2 : -1;
+            t_dst[rd] = piece * 8 * kDyStride + col;
         }
     }
-    auto fetch = [&](int u) {                                                // global loads of pixel tile u into `stage`
+    auto fetch = [&](int u, bf16x8 (&st)[ROUNDS][8]) {                       // global loads of pixel tile u
         const int ct = u % g.ctiles; u /= g.ctiles;
         const int band = u % g.bands; const int b = u / g.bands;
         const int r0 = band * kRows, q0 = ct * kCols;
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
-            const int task = threadIdx.x + rd * kThreadsG;
-            if (task < XT) {
+            const int wt = wave + rd * kWavesG;
+            if (wt < 2 * CGX) {
                 const int col = SI * q0 + t_rel[rd] - P;
-                const unsigned lane_off = (col >= 0 && col < d.W) ? static_cast<unsigned>(col * d.C * 2 + t_ch[rd]) : kRsrcOob;
+                const unsigned lane_off = (t_rel[rd] >= 0 && col >= 0 && col < d.W) ? static_cast<unsigned>(col * d.C * 2 + t_ch[rd]) : kRsrcOob;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int row = SI * (r0 + i) + t - P;                   // uniform
                     const bool ok = row >= 0 && row < d.H;
-                    stage[rd][i] = rsrc_load_bf16x8(xr, ok ? lane_off : kRsrcOob, ok ? static_cast<unsigned>((b * d.H + row) * d.W) * static_cast<unsigned>(d.C * 2) : 0u);
+                    st[rd][i] = rsrc_load_bf16x8(xr, ok ? lane_off : kRsrcOob, ok ? static_cast<unsigned>((b * d.H + row) * d.W) * static_cast<unsigned>(d.C * 2) : 0u);
                 }
-            } else {
+            } else if (wt < WTASKS) {
                 const int col = q0 + t_rel[rd];
                 const unsigned lane_off = (col < d.OW && t_ch[rd] >= 0) ? static_cast<unsigned>(col * d.N * 2 + t_ch[rd]) : kRsrcOob;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int row = r0 + i;
                     const bool ok = row < d.OH;
-                    stage[rd][i] = rsrc_load_bf16x8(yr, ok ? lane_off : kRsrcOob, ok ? static_cast<unsigned>((b * d.OH + row) * d.OW) * static_cast<unsigned>(d.N * 2) : 0u);
+                    st[rd][i] = rsrc_load_bf16x8(yr, ok ? lane_off : kRsrcOob, ok ? static_cast<unsigned>((b * d.OH + row) * d.OW) * static_cast<unsigned>(d.N * 2) : 0u);
                 }
             }
         }
     };
-    auto commit = [&]() {                                                    // transpose `stage` into LDS
+    auto commit = [&](const bf16x8 (&st)[ROUNDS][8]) {                       // transpose the staged blocks into LDS
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; ++rd) {
-            const int task = threadIdx.x + rd * kThreadsG;
-            if (task >= TASKS) continue;
+            const int wt = wave + rd * kWavesG;
+            if (wt >= WTASKS) continue;
             bf16x8 tr[8];
-            transpose8x8(stage[rd], tr);
-            if (task < XT) {
-                const int slot = task >> 3, piece = task & 7;
+            transpose8x8(st[rd], tr);
+            if (wt < 2 * CGX) {
+                if (16 * (wt >> 1) + ci < XC) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) xt[(piece * 8 + q) * XSTRIDE + slot] = tr[q];
+                    for (int q = 0; q < 8; ++q) xt[t_dst[rd] + q * XSTRIDE] = tr[q];
+                }
             } else {
-                const int k = task - XT, col = k >> 4, piece = k & 15;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) dyt[(piece * 8 + q) * kDyStride + col] = tr[q];
+                for (int q = 0; q < 8; ++q) dyt[t_dst[rd] + q * kDyStride] = tr[q];
             }
         }
     };
-
-    int u = chunk;
-    if (u < g.units) fetch(u);
-    while (u < g.units) {
-        __syncthreads();                                                     // the previous tile's LDS reads are done
-        commit();
-        const int nu = u + g.chunks;
-        if (nu < g.units) fetch(nu);                                         // in flight during the products below
-        __syncthreads();
+    auto products = [&]() {
         const bf16x8 *ap = dyt + (nsub * 32 + l31) * kDyStride + half;
         const bf16x8 *bp = xt + (csub * 32 + l31) * XSTRIDE;
 #pragma unroll 4
@@ -180,7 +182,24 @@ void conv_wgrad_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ 
                 acc[e] = mfma_bf16(a, bp[slot], acc[e]);                     // D[n][c] += dY^T[n][8 rows] X[8 rows][c]
             }
         }
-        u = nu;
+    };
+
+    // tile u's loads were issued PF steps before its products (registers: one set per tile in flight), one LDS buffer
+    int u = chunk;
+    if (u < g.units) fetch(u, stage[0]);
+    if (PF == 2 && u + g.chunks < g.units) fetch(u + g.chunks, stage[PF - 1]);
+    while (u < g.units) {
+#pragma unroll
+        for (int s_ = 0; s_ < PF; ++s_) {
+            if (u >= g.units) break;
+            __syncthreads();                                                 // the previous tile's LDS reads are done
+            commit(stage[s_]);
+            const int nu = u + PF * g.chunks;
+            if (nu < g.units) fetch(nu, stage[s_]);                          // in flight during the next PF tiles' products
+            __syncthreads();
+            products();
+            u += g.chunks;
+        }
     }
 
     // ---- epilogue: acc[e] register r of lane l = D[n = (r & 3) + 8 (r >> 2) + 4 half][c = l & 31]

@@ -31,7 +31,11 @@ def close(got, want, what, tol=1.2e-2):
     (1, 12, 40, 256, 64, 1, False, True),     # the projection shortcut: 1x1 / stride 2 (only even pixels are read)
     (1, 7, 9, 64, 128, 1, False, False),      # ... on an odd map
 ])
-def test_strided_convolution_matches_conv2d(ext, B, H, W, C, N, k, relu, use_shift):
+def test_strided_convolution_matches_conv2d(ext, B, H, W, C, N, k, relu, use_shift, monkeypatch):
+    # (the launcher narrows the workgroup's output-channel block for problems with few tiles -- every test here: pin it to the
+    # widest block the layer allows for half of the cases so that each instantiation runs)
+    if (H + W) % 2 == 0:
+        monkeypatch.setenv("MDETR_CONV_TAPS_NB", "4")
     g = torch.Generator().manual_seed(B * 1000 + H * W + C + N + k)
     x = torch.randn(B, C, H, W, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     w = (torch.randn(N, C, k, k, generator=g) / (k * C ** 0.5)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)

@@ -783,6 +783,22 @@ def test_conv_stem_kernel_matches_the_library_convolution(B, H, W):
     assert (y.float() - ref).abs().max().item() <= 1.2e-2 * max(1.0, ref.abs().max().item())
 
 
+def _library_convolutions(step):
+    """Which convolutions of one iteration still go to the library (shapes), for the failure message."""
+    seen, F = [], torch.nn.functional
+    real = F.conv2d
+
+    def spy(x, w, *a, **k):
+        seen.append((tuple(x.shape), tuple(w.shape), a[1:] if len(a) > 1 else k.get("stride")))
+        return real(x, w, *a, **k)
+    F.conv2d = spy
+    try:
+        step()
+    finally:
+        F.conv2d = real
+    return seen
+
+
 def test_training_step_with_the_convolution_kernels_matches_default():
     """The backbone / pyramid / depth-head convolutions by hand (stem, stride-2 3x3 and 1x1, every weight gradient) against the
     library path: loss trajectories of three iterations, and no MIOpen convolution is left in the step."""
@@ -801,7 +817,7 @@ def test_training_step_with_the_convolution_kernels_matches_default():
                     torch.cuda.synchronize()
                 kernels = [e.key for e in prof.key_averages()]
                 left = [k for k in kernels if "igemm" in k or "miopen" in k.lower() or "conv_bwd" in k or "grouped_conv" in k]
-                assert not left, left
+                assert not left, (left, _library_convolutions(step))
                 assert any("conv_wgrad_kernel" in k for k in kernels) and any("conv_taps_kernel" in k for k in kernels) and any("conv_stem_kernel" in k for k in kernels)
     finally:
         bench.apply_switches(set())
