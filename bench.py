@@ -52,7 +52,10 @@ import os
 import sys
 import time
 
-import torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import monodetr_amd._runtime_env  # noqa: E402,F401  -- runtime flags, BEFORE torch loads the HIP runtime
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

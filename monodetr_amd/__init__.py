@@ -11,6 +11,8 @@
 import importlib
 import sys
 
+from . import _runtime_env  # noqa: F401  (runtime flags: effective when this package is imported before torch)
+
 __all__ = ["install", "build_monodetr"]
 
 

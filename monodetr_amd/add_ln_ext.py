@@ -108,7 +108,8 @@ def fused_add_layernorm(a, b, gamma, beta, eps=1e-5, dropout_p=0.0, seed=None):
     seed_dev = None
     if dropout_p > 0.0 and seed is None:
         if a.is_cuda and torch.cuda.is_current_stream_capturing():
-            seed_dev = _next_seed(a.device)                 # a replayed graph needs a seed that lives on the device
+            from .attn_ext import site_seed
+            seed, seed_dev = site_seed(a.device)            # a replayed graph needs a seed that lives on the device
         else:
             seed = _host_seed()                             # eager: a host integer costs no launch
     return _AddLayerNorm.apply(a, b, gamma, beta, eps, dropout_p, seed or 0, seed_dev)

@@ -56,6 +56,39 @@ def _next_seed(device):
     return snap
 
 
+# ---- one device-side seed bump per training ITERATION instead of one snapshot + bump per dropout site -----------------------------
+# Inside an iteration scope (helpers/step_helper.TrainIteration opens one around forward + backward) every dropout site draws
+# (a host constant, the device-resident base): the kernels hash seed = constant + *base, the base advances ONCE per iteration
+# (one launch; captured, so every replay advances it), the constant is the site's ordinal times a 64-bit odd multiplier (flips
+# about half of the bits: see the caveat at `_next_seed`).  24 sites per step were 24 clones + 24 adds of an 8-byte tensor.
+# The backward of a site re-reads the base: valid as long as the iteration's backward runs before the next `begin_iteration`
+# (one forward + backward per scope, which is what TrainIteration does).
+_scope = {}
+_SITE = 0xD1B54A32D192ED03
+
+
+def begin_iteration(device):
+    device = torch.device(device)
+    st = _seed_state.get(device)
+    if st is None:
+        st = _seed_state[device] = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
+    st.add_(_WEYL)
+    _scope[device] = 0
+
+
+def end_iteration(device):
+    _scope.pop(torch.device(device), None)
+
+
+def site_seed(device):
+    """(host seed, device seed tensor) of the next dropout site on `device`."""
+    k = _scope.get(device)
+    if k is None:
+        return 0, _next_seed(device)
+    _scope[device] = k + 1
+    return ((k + 1) * _SITE) & 0x7FFFFFFFFFFFFFFF, _seed_state[device]
+
+
 class _FusedAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, num_heads, scale, dropout_p, seed, key_padding_mask, seed_dev=None):
@@ -114,5 +147,5 @@ def fused_attention(q, k, v, num_heads, dropout_p=0.0, key_padding_mask=None, sc
         scale = (q.shape[-1] // num_heads) ** -0.5
     seed_dev = None
     if dropout_p > 0.0 and seed is None:
-        seed_dev = _next_seed(q.device)          # explicit `seed` (tests) keeps the host-scalar path
+        seed, seed_dev = site_seed(q.device)     # explicit `seed` (tests) keeps the host-scalar path
     return _FusedAttention.apply(q, k, v, num_heads, scale, dropout_p, seed or 0, key_padding_mask, seed_dev)

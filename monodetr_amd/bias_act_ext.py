@@ -103,8 +103,8 @@ def bias_act(x, bias=None, skip=None, relu=True, dropout_p=0.0, seed=None):
     seed_dev = None
     if dropout_p > 0.0 and seed is None:
         if x.is_cuda and torch.cuda.is_current_stream_capturing():
-            from .attn_ext import _next_seed
-            seed_dev = _next_seed(x.device)                          # a replayed graph needs a seed that lives on the device
+            from .attn_ext import site_seed
+            seed, seed_dev = site_seed(x.device)                     # a replayed graph needs a seed that lives on the device
         else:
             from .add_ln_ext import _host_seed
             seed = _host_seed()

@@ -78,6 +78,9 @@ struct FusedPlan {
     int mode[kMaxLevels];             // 0: core tiles, candidates = queries within R cells (self-attention over the pyramid)
                                       // 1: whole level resident, queries split into chunks, partial windows -> scratch
                                       // 2: core tiles, every block scans all queries (cross-attention)
+                                      // 3: OWNER tiles (self-attention): a block looks at its own queries only and its LDS window
+                                      //    carries a halo of R cells; windows are flushed into grad_value with fp32 atomics
+    int owner;                        // self-attention in the owner scheme (modes 3 and 1, no candidates, no scratch, no finalize)
     int TH[kMaxLevels], TW[kMaxLevels], nty[kMaxLevels], ntx[kMaxLevels], R[kMaxLevels];
     int nchunk[kMaxLevels];
     // blocks of one (b, m): level l owns blk0[l] + i * bstride[l], i < nblk[l].  Whole-level (chunked) levels with the same
@@ -203,7 +206,7 @@ template <int CPL> struct CornerDots<__hip_bfloat16, __hip_bfloat16, CPL> {
 template <typename GT>
 __global__ __launch_bounds__(256)
 void msda_absmax_kernel(const GT *__restrict__ g, int64_t ng, const float *__restrict__ a, int64_t na,
-                        Header *__restrict__ hdr, float *__restrict__ far, int64_t nfar)
+                        Header *__restrict__ hdr, float *__restrict__ far, int64_t nfar, int zero_always)
 {
     // ng, na are multiples of 4; bases 16-byte aligned
     float mg = 0.f, ma = 0.f, poison = 0.f;
@@ -252,7 +255,8 @@ void msda_absmax_kernel(const GT *__restrict__ g, int64_t ng, const float *__res
         if (v > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, v);
     }
     // a workspace this library has not finalized yet (fresh allocation): its `far` buffer may hold anything
-    if (hdr->cookie != kCookie || hdr->far_elems != static_cast<unsigned long long>(nfar)) {
+    // (owner scheme: `far` IS grad_value, which every block of the main kernel adds into: zero-filled by this pass, every call)
+    if (zero_always || hdr->cookie != kCookie || hdr->far_elems != static_cast<unsigned long long>(nfar)) {
         float4 *f4 = reinterpret_cast<float4 *>(far);
         for (int64_t i = tid; i < nfar / 4; i += stride) f4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -306,6 +310,27 @@ __device__ __forceinline__ Work decode_block(const FusedPlan &pl, int k)
         w.cy0 = ty * pl.TH[l]; w.cx0 = tx * pl.TW[l]; w.tstride = pl.TW[l]; w.ncell = pl.TH[l] * pl.TW[l];
         if (w.mode == 2) {
             w.nq = pl.Lq;
+        } else if (w.mode == 3) {
+            // own queries only: on every query level the rectangle of cells whose centre falls into the CORE; the window adds R cells
+            const int R = pl.R[l], core_y = w.cy0, core_x = w.cx0;
+#pragma unroll
+            for (int lq = 0; lq < kMaxLevels; ++lq) {
+                if (lq < pl.L) {
+                    w.y0[lq] = first_at_or_after(core_y, pl.H[l], pl.H[lq]);
+                    w.rows[lq] = first_at_or_after(core_y + pl.TH[l], pl.H[l], pl.H[lq]) - w.y0[lq];
+                    w.x0[lq] = first_at_or_after(core_x, pl.W[l], pl.W[lq]);
+                    const int cols = first_at_or_after(core_x + pl.TW[l], pl.W[l], pl.W[lq]) - w.x0[lq];
+                    w.wx[lq] = cols > 0 ? cols : 1;
+                    w.inv_wx[lq] = 1.0f / static_cast<float>(w.wx[lq]);
+                    w.cum[lq + 1] = w.cum[lq] + (cols > 0 ? w.rows[lq] * cols : 0);
+                } else {
+                    w.cum[lq + 1] = w.cum[lq];
+                }
+            }
+            w.nq = w.cum[kMaxLevels];
+            w.cy0 = core_y - R; w.cx0 = core_x - R;          // from here on: the WINDOW's origin and extent
+            w.tstride = pl.TW[l] + 2 * R;
+            w.ncell = (pl.TH[l] + 2 * R) * w.tstride;
         } else {
             const int R = pl.R[l];
 #pragma unroll
@@ -357,7 +382,7 @@ __host__ __device__ inline size_t lds_cnt_bytes(int max_cells) { return (static_
 // LPS lanes per sample (each owning CPL = 32 / LPS channels), GMAX groups of 64 / LPS own samples with their loads in flight
 // together.  bf16: LPS = 4 -- 16 samples per wave pass instead of 8 halves every per-sample instruction (record reads, cell
 // addresses, the lane reduction, the d/d(loc) arithmetic) and the dot products run on the packed words.
-template <typename VT, typename GT, int THREADS, int GMAX, int LPS>
+template <typename VT, typename GT, int THREADS, int GMAX, int LPS, bool OWNER = false>
 __global__ __launch_bounds__(THREADS, (THREADS == 512 && GMAX <= 4 && sizeof(VT) == 2) ? 4 : 2)
 void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const float *__restrict__ loc,
                     const float *__restrict__ attn, const GT *__restrict__ grad_out,
@@ -379,7 +404,9 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
     const int bid = blockIdx.x;
     const int b = bid % pl.B, r_ = bid / pl.B, m = r_ % pl.M, kblk = r_ / pl.M;      // image -> XCD (bid % 8)
     const Work w = decode_block(pl, kblk);
-    const int l = w.l, H = pl.H[l], W = pl.W[l], TH = w.mode == 1 ? H : pl.TH[l], TW = w.mode == 1 ? W : pl.TW[l];
+    // TH x TW: the cells this block accumulates in LDS -- the core tile, the whole level (mode 1), or the core plus its halo (mode 3)
+    const int l = w.l, H = pl.H[l], W = pl.W[l];
+    const int TH = w.mode == 1 ? H : pl.TH[l] + (w.mode == 3 ? 2 * pl.R[l] : 0), TW = w.mode == 1 ? W : pl.TW[l] + (w.mode == 3 ? 2 * pl.R[l] : 0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int P = pl.P, LP = pl.L * P, M = pl.M, R = pl.R[l];
     const int j = lane / LPS, k = lane % LPS;
@@ -390,12 +417,14 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
     // index arithmetic in 32 bits (the plan guarantees B * Lq * M * L * P < 2^28 and byte offsets into grad_out / one image's
     // value below 2^31): pair index of query q = pair0u + q * M
     const unsigned pair0u = static_cast<unsigned>(b) * static_cast<unsigned>(pl.Lq) * M + m;
-    float *far_lev = far + ((static_cast<int64_t>(b) * pl.S + pl.start[l]) * M + m) * kCH + k * CPL;
+    // corners beyond the block's cells: global fp32 atomics -- into the side buffer the finalize pass folds in, or (owner scheme:
+    // grad_value is zero-filled by the pre-pass and every block adds into it) straight into grad_value
+    float *far_lev = (OWNER ? grad_value : far) + ((static_cast<int64_t>(b) * pl.S + pl.start[l]) * M + m) * kCH + k * CPL;
     unsigned *wrec = recs + wave * 64 * kRecDw;
 
     // centre cells of the candidate rectangles' rows and columns on level l (mode 0): two small tables instead of two
     // divisions per candidate
-    if (w.mode == 0) {
+    if (w.mode == 0 || w.mode == 3) {
         if (threadIdx.x < kMaxLevels) {
             const int lq = threadIdx.x;
 #define MDETR_SEL4(arr) (lq == 0 ? arr[0] : lq == 1 ? arr[1] : lq == 2 ? arr[2] : arr[3])
@@ -405,7 +434,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
             L8[7] = MDETR_SEL4(w.roff) | (MDETR_SEL4(w.coff) << 16);
 #undef MDETR_SEL4
         }
-        for (int t = threadIdx.x; t < w.ntab; t += THREADS) {
+        for (int t = threadIdx.x; w.mode == 0 && t < w.ntab; t += THREADS) {
             int v = 0;
 #pragma unroll
             for (int lq = 0; lq < kMaxLevels; ++lq) {
@@ -446,16 +475,20 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
             const int qi = P == 4 ? ia >> 2 : static_cast<int>((static_cast<float>(ia) + 0.5f) * inv_p);
             c.p = ia - qi * P;
             c.qcy = c.qcx = 0;
-            if (w.mode == 0) {
+            if (w.mode == 0 || w.mode == 3) {
                 const int lq = (qi >= w.cum[1] ? 1 : 0) + (qi >= w.cum[2] ? 1 : 0) + (qi >= w.cum[3] ? 1 : 0);
                 const int *L8 = lv + lq * 8;                  // this query level's rectangle (LDS; a step rarely straddles two levels)
                 const int rel = qi - L8[0], wxl = L8[1], y0l = L8[3], x0l = L8[4], Wq = L8[5], sq = L8[6], ro = L8[7] & 0xFFFF, co = L8[7] >> 16;
                 const float inv = __builtin_bit_cast(float, L8[2]);
                 const int row = static_cast<int>((static_cast<float>(rel) + 0.5f) * inv), col = rel - row * wxl;
                 c.q = sq + (y0l + row) * Wq + x0l + col;
-                c.qcy = tab[ro + row];
-                c.qcx = tab[co + col];
-                c.owned = static_cast<unsigned>(c.qcy - w.cy0) < static_cast<unsigned>(TH) && static_cast<unsigned>(c.qcx - w.cx0) < static_cast<unsigned>(TW);
+                if (!OWNER) {
+                    c.qcy = tab[ro + row];
+                    c.qcx = tab[co + col];
+                    c.owned = static_cast<unsigned>(c.qcy - w.cy0) < static_cast<unsigned>(TH) && static_cast<unsigned>(c.qcx - w.cx0) < static_cast<unsigned>(TW);
+                } else {
+                    c.owned = true;                           // the rectangles hold exactly the queries whose centre lies in the core
+                }
             } else {
                 c.q = w.q0 + qi;
                 c.owned = w.mode == 1;
@@ -516,9 +549,9 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 // this one's neighbour in the direction of the corner (a corner a whole tile further out is beyond anybody's
                 // reach: R <= TH, TW); it looks at queries whose centre lies within R cells of ITS core.  (Rare: skipped
                 // altogether when no lane of the wave has such a corner.)
-                unsigned farm = stray;
+                unsigned farm = stray;                        // (owner scheme: a corner beyond the window's halo goes out as a global atomic)
                 if (finite && w.mode == 2) farm = 0u;         // every other block scans every query
-                if (finite && w.mode == 0 && __any(stray != 0u)) {
+                if (!OWNER && finite && w.mode == 0 && __any(stray != 0u)) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const int wy = y + (c >> 1) - w.cy0, wx = x + (c & 1) - w.cx0;
@@ -541,11 +574,13 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 rec[11] = valid | (farm << 4) | (static_cast<unsigned>(p) << 8);
             }
             if (base + kWavesB * 64 < nsamp) decode(base + kWavesB * 64, cur);           // next step's loads go out now
-            const unsigned long long mo = __ballot(keep && owned), mh = __ballot(keep && !owned);
-            const int no = __popcll(mo), nh = __popcll(mh);
+            // own samples are listed from the front of the wave's record buffer, neighbours' from the back (owner scheme: every
+            // active lane is an own sample and the active lanes are a prefix of the wave: the list is the lanes themselves)
+            const unsigned long long mo = OWNER ? 0ull : __ballot(keep && owned), mh = OWNER ? 0ull : __ballot(keep && !owned);
+            const int no = OWNER ? min(64, nsamp - base) : __popcll(mo), nh = OWNER ? 0 : __popcll(mh);
             const unsigned long long below = (1ull << lane) - 1ull;
             if (keep) {
-                const int slot = owned ? __popcll(mo & below) : 63 - __popcll(mh & below);
+                const int slot = OWNER ? lane : (owned ? __popcll(mo & below) : 63 - __popcll(mh & below));
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {                 // this block's cells: count the contribution, other corners -> sink row
                     const unsigned cc = (c < 2 ? rec[2] >> (16 * c) : rec[3] >> (16 * (c - 2))) & 0xFFFFu;
@@ -594,7 +629,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                             for (int i = 0; i < CPL; ++i) unsafeAtomicAdd(p + i, wt[c] * (a * g[i]));
                         }
                     }
-                    if (k == 0) hdr->far = 1u;
+                    if (!OWNER && k == 0) hdr->far = 1u;
                 }
                 float e[4];
                 CornerDots<GT, VT, CPL>::run(graw, g, vraw, e);
@@ -702,7 +737,17 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 const int lo = static_cast<int>(static_cast<unsigned>(s));
                 const int hi = static_cast<int>((static_cast<long long>(s) - static_cast<long long>(lo)) >> 32);
                 const float2 out = make_float2(static_cast<float>(lo) * inv, static_cast<float>(hi) * inv);
-                if (w.mode == 1) {
+                if (OWNER) {
+                    // this block's share of the cell (its own samples only): added to the shares of the up to eight neighbours whose
+                    // halo covers it, and of the other query chunks (mode 1) -- fp32 atomics into the zero-filled grad_value, as the
+                    // reference accumulates (.cuh:125-152), but one per cell, channel and block instead of one per sample
+                    const int yy = w.cy0 + cell / w.tstride, xx = w.cx0 + cell % w.tstride;
+                    if (cnt[cell] != 0u && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                        float *dst = dst0 + static_cast<int64_t>(yy * W + xx) * (M * kCH) + 2 * pr;
+                        unsafeAtomicAdd(dst, out.x);
+                        unsafeAtomicAdd(dst + 1, out.y);
+                    }
+                } else if (w.mode == 1) {
                     *reinterpret_cast<float2 *>(dst1 + static_cast<int64_t>(cell) * kCH + 2 * pr) = out;
                 } else {
                     const int yy = w.cy0 + cell / w.tstride, xx = w.cx0 + cell % w.tstride;
@@ -828,6 +873,11 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
     const int reach = env_int("MDETR_MSDA_REACH", 5), chunks_env = env_int("MDETR_MSDA_CHUNKS", 12);
     const int whole_max = env_int("MDETR_MSDA_WHOLE_LEVEL_CELLS", 512);
     if (tile_h < 1 || tile_w < 1 || tile_h * tile_w > kMaxCells || reach < 0 || chunks_env < 1) return false;
+    // the owner scheme (self-attention; MDETR_MSDA_OWNER=0 restores the candidate scheme): 16 x 24 core tiles with a 4-cell halo
+    // = a 24 x 32 window (the model's initial offsets reach 4 px on every level)
+    pl.owner = (self && env_int("MDETR_MSDA_OWNER", 0) != 0) ? 1 : 0;
+    const int otile_h = env_int("MDETR_MSDA_OTILE_H", 16), otile_w = env_int("MDETR_MSDA_OTILE_W", 24), oreach = env_int("MDETR_MSDA_OREACH", 4);
+    if (pl.owner && (otile_h < 1 || otile_w < 1 || oreach < 0 || (otile_h + 2 * oreach) * (otile_w + 2 * oreach) > kMaxCells)) return false;
     int blk = 0;
     long long scr = 0;
     pl.max_cells = 0;
@@ -841,7 +891,16 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
             pl.nblk[l] = pl.nchunk[l];
             cells = H * W;
             pl.scr0[l] = scr;
-            scr += static_cast<long long>(pl.nchunk[l]) * cells * kCH;
+            if (!pl.owner) scr += static_cast<long long>(pl.nchunk[l]) * cells * kCH;
+        } else if (pl.owner) {
+            pl.mode[l] = 3;
+            const int TH = otile_h < H ? otile_h : H, TW = otile_w < W ? otile_w : W;
+            pl.TH[l] = TH; pl.TW[l] = TW; pl.R[l] = oreach;
+            pl.nty[l] = (H + TH - 1) / TH;
+            pl.ntx[l] = (W + TW - 1) / TW;
+            pl.nblk[l] = pl.nty[l] * pl.ntx[l];
+            cells = (TH + 2 * oreach) * (TW + 2 * oreach);
+            if (static_cast<long long>(Lq) * P >= (1 << 22)) return false;       // float index arithmetic of the query decode
         } else {
             pl.mode[l] = self ? 0 : 2;
             int TH = tile_h < H ? tile_h : H, TW = tile_w < W ? tile_w : W;
@@ -887,6 +946,7 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
 
 int64_t plan_workspace_bytes(const FusedPlan &pl)
 {
+    if (pl.owner) return 256;                                // the header only: no side buffer, no partial windows
     return 256 + (static_cast<int64_t>(pl.B) * pl.M * pl.scr_per_bm + static_cast<int64_t>(pl.B) * pl.S * pl.M * kCH) * 4;
 }
 
@@ -912,20 +972,21 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
     if (elem_dtype != 0 && elem_dtype != 2) return hipErrorNotSupported;
     Header *hdr = static_cast<Header *>(workspace);
     const int64_t nfar = static_cast<int64_t>(B) * S * M * kCH;
-    float *far = reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + 256);      // [256, 256 + 4 nfar): zero between calls
-    float *scratch = far + nfar;
+    // candidate scheme: [256, 256 + 4 nfar) = the side buffer, zero between calls, then the partial windows; owner scheme: neither
+    float *far = pl.owner ? grad_value : reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + 256);
+    float *scratch = pl.owner ? nullptr : far + nfar;
     hipError_t err;
     if ((err = zero_fill_launch(hdr, 16, st)) != hipSuccess) return err;
     const int64_t n_go = static_cast<int64_t>(B) * Lq * M * D, n_at = static_cast<int64_t>(B) * Lq * M * L * P;
     if ((L * P) % 4 != 0) return hipErrorNotSupported;       // the pre-pass reads attn in 16-byte pieces
     // grid-stride over 16-byte pieces, four per lane and trip: no more workgroups than that gives work to (small calls)
-    const int64_t pre_items = (n_go + n_at) / 4 + nfar / 4 / 64;
+    const int64_t pre_items = (n_go + n_at) / 4 + (pl.owner ? nfar / 4 : nfar / 4 / 64);
     const unsigned pre_blocks = static_cast<unsigned>(pre_items / (256 * 4) < 2048 ? (pre_items / (256 * 4) > 0 ? pre_items / (256 * 4) : 1) : 2048);
     profile_begin(7, Lq, st);
     if (elem_dtype == 2)
-        hipLaunchKernelGGL(msda_absmax_kernel<__hip_bfloat16>, dim3(pre_blocks), dim3(256), 0, st, static_cast<const __hip_bfloat16 *>(grad_out), n_go, attn, n_at, hdr, far, nfar);
+        hipLaunchKernelGGL(msda_absmax_kernel<__hip_bfloat16>, dim3(pre_blocks), dim3(256), 0, st, static_cast<const __hip_bfloat16 *>(grad_out), n_go, attn, n_at, hdr, far, nfar, pl.owner);
     else
-        hipLaunchKernelGGL(msda_absmax_kernel<float>, dim3(pre_blocks), dim3(256), 0, st, static_cast<const float *>(grad_out), n_go, attn, n_at, hdr, far, nfar);
+        hipLaunchKernelGGL(msda_absmax_kernel<float>, dim3(pre_blocks), dim3(256), 0, st, static_cast<const float *>(grad_out), n_go, attn, n_at, hdr, far, nfar, pl.owner);
     profile_end(st);
     // 512 threads (8 waves) or 1024 (16 waves: twice the record buffers, more loads in flight per CU)
     int threads = env_int("MDETR_MSDA_THREADS", 1024);          // (bf16: 0.74 ms at 16 waves vs 0.96 at 8, same tile)
@@ -948,18 +1009,28 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
     int lps = env_int("MDETR_MSDA_LPS", 4);
     lps = (lps == 4 && elem_dtype == 2 && threads > 512) ? 4 : 8;
     const int groups = env_int("MDETR_MSDA_GROUPS", 2);      // (12-wave form: 2 or 4 groups of 16 own samples in flight)
-    static bool attr_set[6][64] = {};                        // per kernel instance and device
-    const int which = elem_dtype != 2 ? 0 : (threads == 512 ? 1 : (threads == 768 ? (groups >= 4 ? 5 : 4) : (lps == 8 ? 2 : 3)));
+    static bool attr_set[9][64] = {};                        // per kernel instance and device
+    int which = elem_dtype != 2 ? 0 : (threads == 512 ? 1 : (threads == 768 ? (groups >= 4 ? 5 : 4) : (lps == 8 ? 2 : 3)));
+    if (pl.owner && which >= 2 && which != 3) {              // the owner scheme is instantiated for the default forms only
+        which = 3;
+        threads = 1024;
+        lds = lds_bytes(threads);
+        if (lds > 160 * 1024) return hipErrorNotSupported;
+    }
     typedef __hip_bfloat16 bf;
-    const void *kern = which == 0 ? reinterpret_cast<const void *>(msda_bwd_fused<float, float, 512, 4, 8>)
+    const void *kern = (pl.owner && which == 0) ? reinterpret_cast<const void *>(msda_bwd_fused<float, float, 512, 4, 8, true>)
+                     : (pl.owner && which == 1) ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 512, 4, 8, true>)
+                     : (pl.owner && which == 3) ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 1024, 2, 4, true>)
+                     : which == 0 ? reinterpret_cast<const void *>(msda_bwd_fused<float, float, 512, 4, 8>)
                      : which == 1 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 512, 4, 8>)
                      : which == 2 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 1024, 4, 8>)
                      : which == 3 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 1024, 2, 4>)
                      : which == 4 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 768, 2, 4>)
                                   : reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 768, 4, 4>);
-    if (dev < 0 || dev >= 64 || !attr_set[which][dev]) {
+    const int slot_ = pl.owner ? (which == 0 ? 6 : (which == 1 ? 7 : 8)) : which;
+    if (dev < 0 || dev >= 64 || !attr_set[slot_][dev]) {
         if ((err = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return err;
-        if (dev >= 0 && dev < 64) attr_set[which][dev] = true;
+        if (dev >= 0 && dev < 64) attr_set[slot_][dev] = true;
     }
     const unsigned nblocks = static_cast<unsigned>(B) * M * pl.nblocks;
     profile_begin(6, Lq, st);
@@ -968,13 +1039,17 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
         hipLaunchKernelGGL(k, dim3(nblocks), dim3(threads), lds, st, pl, static_cast<const VT *>(value), loc, attn,
                            static_cast<const GT *>(grad_out), grad_value, grad_loc, grad_attn, hdr, scratch, far);
     };
-    if (which == 0) go(msda_bwd_fused<float, float, 512, 4, 8>, float(), float());
+    if (pl.owner && which == 0) go(msda_bwd_fused<float, float, 512, 4, 8, true>, float(), float());
+    else if (pl.owner && which == 1) go(msda_bwd_fused<bf, bf, 512, 4, 8, true>, bf(), bf());
+    else if (pl.owner && which == 3) go(msda_bwd_fused<bf, bf, 1024, 2, 4, true>, bf(), bf());
+    else if (which == 0) go(msda_bwd_fused<float, float, 512, 4, 8>, float(), float());
     else if (which == 1) go(msda_bwd_fused<bf, bf, 512, 4, 8>, bf(), bf());
     else if (which == 2) go(msda_bwd_fused<bf, bf, 1024, 4, 8>, bf(), bf());
     else if (which == 3) go(msda_bwd_fused<bf, bf, 1024, 2, 4>, bf(), bf());
     else if (which == 4) go(msda_bwd_fused<bf, bf, 768, 2, 4>, bf(), bf());
     else go(msda_bwd_fused<bf, bf, 768, 4, 4>, bf(), bf());
     profile_end(st);
+    if (pl.owner) return hipGetLastError();                  // every block added its share into grad_value: nothing to finalize
     const int64_t nrows = static_cast<int64_t>(B) * S * M;
     profile_begin(8, Lq, st);
     const int64_t fin_blocks = (nrows * 8 + 255) / 256;      // grid-stride: at most 2 048 workgroups

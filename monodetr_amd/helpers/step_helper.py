@@ -19,6 +19,7 @@ With a gradient exchange (one process per GPU) the iteration is TWO graphs -- [z
 [optimizer step] -- with the flat RCCL all-reduce issued eagerly between them (``dist_helper.FlatGradSync`` in its static
 form: it gathers from the addresses the captured backward writes and the captured optimizer reads the reduced slices).
 """
+import os
 import sys
 
 import torch
@@ -100,8 +101,16 @@ class TrainIteration:
 
     def _forward_backward(self, batch):
         self.optimizer.zero_grad(set_to_none=True)
-        total, losses = self.compute(batch)
-        total.backward()
+        scoped = self.device.type == "cuda"
+        if scoped:                                            # one device-side dropout-seed bump for the whole iteration
+            from .. import attn_ext
+            attn_ext.begin_iteration(self.device)
+        try:
+            total, losses = self.compute(batch)
+            total.backward()
+        finally:
+            if scoped:
+                attn_ext.end_iteration(self.device)
         self.losses = losses
         return total
 
@@ -293,10 +302,21 @@ class TrainIteration:
         if self.num_global is not None:
             self._fill_num_global()
         self.loss, self.losses = self._captured               # (an eager iteration in between re-pointed them)
-        self.graph.replay()
-        if self.graph_opt is not None:
-            self.grad_sync.sync()
-            self.graph_opt.replay()
+        # The graphs are launched on the stream they were captured on, which carries nothing else: with eagerly launched KERNELS
+        # queued on the launching stream between two replays (an evaluation pass, logging reductions -- copies were harmless) the
+        # ROCm 7 runtime's pre-recorded graph packets produced non-finite gradients at fixed positions of a few tensors
+        # (profiles/r03_graph_replay_corruption.md).  MDETR_REPLAY_STREAM=current restores the launch on the caller's stream.
+        own = self.stream is not None and os.environ.get("MDETR_REPLAY_STREAM", "own") != "current"
+        cur = torch.cuda.current_stream(self.device)
+        if own:
+            self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream if own else cur):
+            self.graph.replay()
+            if self.graph_opt is not None:
+                self.grad_sync.sync()
+                self.graph_opt.replay()
+        if own:
+            cur.wait_stream(self.stream)
         self.replays += 1
         if hasattr(self.optimizer, "note_replay"):
             self.optimizer.note_replay()

@@ -14,7 +14,9 @@ import argparse
 import datetime
 import os
 
-import torch
+from monodetr_amd import _runtime_env  # noqa: F401  -- runtime flags, BEFORE torch loads the HIP runtime
+
+import torch  # noqa: E402
 import yaml
 
 from monodetr_amd.helpers import dataloader_helper, model_helper, optimizer_helper, scheduler_helper, utils_helper

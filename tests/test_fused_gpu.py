@@ -801,7 +801,9 @@ def _library_convolutions(step):
 
 def test_training_step_with_the_convolution_kernels_matches_default():
     """The backbone / pyramid / depth-head convolutions by hand (stem, stride-2 3x3 and 1x1, every weight gradient) against the
-    library path: loss trajectories of three iterations, and no MIOpen convolution is left in the step."""
+    library path: loss trajectories of three iterations; and at the training resolution no MIOpen convolution is left in the
+    iteration (at 96 x 320 the depth predictor's 6 x 20 maps fall below what the GroupNorm kernel takes, the framework's GroupNorm
+    hands NCHW-contiguous maps on, and the convolutions behind it rightly stay with the library)."""
     import bench
     from model_init import disable_dropout_
     dev = torch.device("cuda", 0)
@@ -811,14 +813,22 @@ def test_training_step_with_the_convolution_kernels_matches_default():
             step = bench.TrainStep(dev, 2, "bf16", size=(96, 320), switches=names)
             disable_dropout_(step.raw_model)
             traj[names] = [float(step()) for _ in range(3)]
-            if names:
-                with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
-                    step()
-                    torch.cuda.synchronize()
-                kernels = [e.key for e in prof.key_averages()]
-                left = [k for k in kernels if "igemm" in k or "miopen" in k.lower() or "conv_bwd" in k or "grouped_conv" in k]
-                assert not left, (left, _library_convolutions(step))
-                assert any("conv_wgrad_kernel" in k for k in kernels) and any("conv_taps_kernel" in k for k in kernels) and any("conv_stem_kernel" in k for k in kernels)
+            del step
+        step = bench.TrainStep(dev, 1, "bf16", size=(384, 1280), switches=set(bench.COMMITTED_SWITCHES["bf16"]) | set(families))
+        step()
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize()
+        kernels = [e.key for e in prof.key_averages()]
+        left = [k for k in kernels if "igemm" in k or "miopen" in k.lower() or "conv_bwd" in k or "grouped_conv" in k or "SubTensorOp" in k]
+        seen = _library_convolutions(step) if left else []
+        if left:
+            os.makedirs("gpurun_out", exist_ok=True)
+            with open("gpurun_out/library_convolutions.txt", "w") as f:
+                f.write("\n".join(map(str, left)) + "\n" + "\n".join(map(str, seen)) + "\n")
+        assert not left, (left, seen[:12])
+        assert any("conv_wgrad_kernel" in k for k in kernels) and any("conv_taps_kernel" in k for k in kernels) and any("conv_stem_kernel" in k for k in kernels)
+        assert any("conv_dgrad4_kernel" in k for k in kernels)
     finally:
         bench.apply_switches(set())
     for a, b in zip(traj[()], traj[families]):
