@@ -61,7 +61,7 @@ class TrainIteration:
     eagerly before the capture (optimizer state, workspaces, geometry caches, library plans)."""
 
     def __init__(self, model, criterion, optimizer, device, grad_sync=None, pending_sync=None, prepare=None, compute=None,
-                 graph="off", eager_steps=3, capture_error_mode="global", log=None):
+                 graph="off", eager_steps=3, capture_error_mode="global", log=None, on_captured=None):
         self.model = self.raw_model = model
         self.criterion, self.optimizer, self.device = criterion, optimizer, torch.device(device)
         self.grad_sync, self.pending_sync = grad_sync, pending_sync
@@ -80,6 +80,7 @@ class TrainIteration:
         self.replays = 0
         self._sig = None
         self._log = log or (lambda msg: print(msg, file=sys.stderr, flush=True))
+        self.on_captured = on_captured                        # called once after the capture attempt (creates a deferred process group)
         if self.want_graph:
             self._device_lr()
 
@@ -326,7 +327,10 @@ class TrainIteration:
         """One training iteration on `batch`; returns the total loss (a device scalar; ``self.losses`` holds the dict)."""
         if self.graph is None and self.want_graph and self.eager_done >= self.eager_steps:
             self.try_capture(batch)
-            if self.graph_opt is not None or self.grad_sync is not None:
+            if self.on_captured is not None:                  # a deferred process group: created now, after the capture
+                cb, self.on_captured = self.on_captured, None
+                cb(self)
+            elif self.graph_opt is not None or self.grad_sync is not None:
                 self.agree_on_launch_mode()
         if self.graph is not None:
             if _signature(batch) == self._sig:

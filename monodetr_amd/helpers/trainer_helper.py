@@ -30,7 +30,7 @@ TARGET_KEYS = ('labels', 'boxes', 'boxes_3d', 'depth', 'size_3d', 'heading_bin',
 
 class Trainer(object):
     def __init__(self, cfg, model, optimizer, train_loader, test_loader, lr_scheduler, warmup_lr_scheduler, logger, loss,
-                 model_name, log_every=30):
+                 model_name, log_every=30, process=None):
         self.cfg, self.model, self.optimizer = cfg, model, optimizer
         self.train_loader, self.test_loader = train_loader, test_loader
         self.lr_scheduler, self.warmup_lr_scheduler = lr_scheduler, warmup_lr_scheduler
@@ -42,6 +42,10 @@ class Trainer(object):
         self.log_every = log_every
         self.grad_sync = None
         self.iteration = None
+        # several processes whose group does not exist yet (tools/train_val.py under graph replay): the iteration is captured first,
+        # the first iterations run on each rank's own shard, then the group is created and rank 0's state goes to everybody
+        self.process = process
+        self.pending_sync = "flat" if (process is not None and process.world > 1 and not torch.distributed.is_initialized()) else None
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             from .dist_helper import FlatGradSync, broadcast_parameters
             broadcast_parameters(self.model)
@@ -99,14 +103,28 @@ class Trainer(object):
             launch = os.environ.get("MDETR_TRAIN_LAUNCH", self.cfg.get("launch", "graph" if self.device.type == "cuda" else "eager"))
             if self.cfg.get("use_dn"):
                 raise NotImplementedError("denoising queries (use_dn) are off in configs/monodetr.yaml and not mirrored")
+            pending = self.pending_sync if launch == "graph" else None
+            if self.pending_sync is not None and pending is None:        # eager launches after all: the group is needed now
+                self._attach_group(None)
             self.iteration = TrainIteration(
-                self.model, self.detr_loss, self.optimizer, self.device, grad_sync=self.grad_sync, prepare=pad_targets_from_batch,
-                graph="auto" if launch == "graph" else "off",
-                # a live RCCL process group's watchdog thread polls events while the capture is under way: only THIS thread's
-                # calls are checked against the capture
-                capture_error_mode="thread_local" if self.grad_sync is not None else "global",
-                log=lambda msg: self.logger.info(msg))
+                self.model, self.detr_loss, self.optimizer, self.device, grad_sync=self.grad_sync, pending_sync=pending,
+                prepare=pad_targets_from_batch, graph="auto" if launch == "graph" else "off",
+                on_captured=self._attach_group if pending is not None else None, log=lambda msg: self.logger.info(msg))
         return self.iteration
+
+    def _attach_group(self, iteration):
+        """Create the process group (after the capture, or at once when the iteration launches eagerly) and wire the gradient
+        exchange: rank 0's parameters and optimizer state go to every rank."""
+        from .dist_helper import FlatGradSync, broadcast_parameters
+        if self.process is not None:
+            self.process.init_group()
+        self.pending_sync = None
+        if iteration is not None:
+            self.logger.info("launch mode: %s" % iteration.attach_process_group())
+            self.grad_sync = iteration.grad_sync
+        elif torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            broadcast_parameters(self.model)
+            self.grad_sync = FlatGradSync(self.model.parameters())
 
     def train_step(self, inputs, calibs, targets, info=None):
         """One iteration on a collated batch; returns the dict of unweighted loss tensors (on the device)."""

@@ -36,8 +36,12 @@ COMMITTED_SWITCHES = {
     # 234.6 img/s, profiles/r02b_bench_committed_plus_conv3x3.json.  MDETR_TOKEN_GEMM stays off: slower than hipBLASLt.
     # MDETR_GROUP_NORM: 328.9 vs 308.7 img/s under graph replay, profiles/r02m_bench_with_gn.json.
     # MDETR_SMALL_WGRAD: 340.2 vs 333.6 img/s, profiles/r02q_bench_{with_small_wgrad,committed}.json.)
+    # MDETR_CONV_WGRAD / _STRIDED / _STEM (round 3): every convolution of the backbone, the pyramid and the depth head by hand --
+    # weight gradients 1.1-1.6x MIOpen's, the stem 2.9x, the stride-2 forms 0.4-2.8x (profiles/r03c_convbench.json); the step
+    # 354.2 vs 348.0 img/s (r03d_bench_{all,committed}.json), no MIOpen kernel left in the iteration.)
     "bf16": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE", "MDETR_MSDA_BF16",
-             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD"),
+             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD",
+             "MDETR_CONV_WGRAD", "MDETR_CONV_STRIDED", "MDETR_CONV_STEM"),
     "fp32": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE",
              "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD"),
 }

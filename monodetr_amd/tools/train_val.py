@@ -27,19 +27,27 @@ from monodetr_amd.helpers.trainer_helper import Trainer
 class Process:
     """Rank bookkeeping of one worker process (a single process when not launched by torchrun)."""
 
-    def __init__(self):
+    def __init__(self, defer_group=False):
+        """defer_group: create the process group later (``init_group``): with graph replay the training iteration is captured
+        BEFORE RCCL exists -- a live process group's watchdog thread polls events while a capture is under way and aborts the
+        process (profiles/r02m_rccl_watchdog_abort.txt; tests/test_trainer_gpu.py)."""
         self.world = int(os.environ.get('WORLD_SIZE', '1'))
         self.rank = int(os.environ.get('RANK', '0'))
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         self.on_gpu = torch.cuda.is_available()
         if self.on_gpu:
             torch.cuda.set_device(self.local_rank)
-        if self.world > 1:
+        self.device = torch.device("cuda", self.local_rank) if self.on_gpu else torch.device("cpu")
+        if self.world > 1 and not defer_group:
+            self.init_group()
+
+    def init_group(self):
+        if self.world > 1 and not torch.distributed.is_initialized():
             # only rank 0 runs the per-epoch inference + KITTI evaluation (3 769 frames) while the other ranks already wait in
             # the next epoch's first collective: the default watchdog time-out would abort the job
             import datetime
-            torch.distributed.init_process_group('nccl' if self.on_gpu else 'gloo', timeout=datetime.timedelta(minutes=60))
-        self.device = torch.device("cuda", self.local_rank) if self.on_gpu else torch.device("cpu")
+            kw = dict(device_id=self.device) if self.on_gpu else {}
+            torch.distributed.init_process_group('nccl' if self.on_gpu else 'gloo', timeout=datetime.timedelta(minutes=60), **kw)
 
     @property
     def is_main(self):
@@ -79,7 +87,9 @@ def build_run(cfg, proc):
 
 def main(argv=None):
     args, cfg = read_args(argv)
-    proc = Process()
+    # graph replay (the default on a GPU, trainer.launch: eager opts out): the process group is created after the capture
+    launch = os.environ.get("MDETR_TRAIN_LAUNCH", cfg['trainer'].get('launch', 'graph' if torch.cuda.is_available() else 'eager'))
+    proc = Process(defer_group=(launch == 'graph' and torch.cuda.is_available() and not args.evaluate_only))
     utils_helper.set_random_seed(cfg.get('random_seed', 444) + proc.rank)
     name, logger, (train_loader, test_loader), model, criterion = build_run(cfg, proc)
     tester = Tester(cfg=cfg['tester'], model=model, dataloader=test_loader, logger=logger, train_cfg=cfg['trainer'], model_name=name)
@@ -97,7 +107,8 @@ def main(argv=None):
     optimizer = optimizer_helper.build_optimizer(optimizer_cfg, model)
     schedule, warmup = scheduler_helper.build_lr_scheduler(cfg['lr_scheduler'], optimizer, last_epoch=-1)
     trainer = Trainer(cfg=cfg['trainer'], model=model, optimizer=optimizer, train_loader=train_loader, test_loader=test_loader,
-                      lr_scheduler=schedule, warmup_lr_scheduler=warmup, logger=logger, loss=criterion, model_name=name)
+                      lr_scheduler=schedule, warmup_lr_scheduler=warmup, logger=logger, loss=criterion, model_name=name,
+                      process=proc)
     held_out = cfg['dataset']['test_split'] == 'test'               # no labels: nothing to evaluate against
     if proc.is_main and not held_out:
         trainer.tester = tester

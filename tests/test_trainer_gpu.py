@@ -4,9 +4,13 @@ step: different images, different object counts (0 ... 50 per image), a learning
 the middle (launched eagerly, on the same state), garbage written over freed pool memory between replays."""
 import math
 import os
+import sys
 
-import pytest
-import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import monodetr_amd._runtime_env  # noqa: E402,F401  -- runtime flags, BEFORE torch loads the HIP runtime (the child process entry)
+
+import pytest  # noqa: E402
+import torch  # noqa: E402
 
 from model_init import MODEL_CFG, disable_dropout_, synthetic_batch
 
@@ -143,33 +147,42 @@ def test_graph_sees_each_batch_not_the_captured_one():
 
 
 def _pg_child():
+    """The multi-process form of the Trainer's iteration with ONE rank: local eager iterations, the two graphs captured before
+    RCCL exists, then the process group, the broadcast and the exchange between the two replays (tools/train_val.py's order)."""
     import bench
-    from monodetr_amd.helpers.dist_helper import FlatGradSync
     from monodetr_amd.helpers.trainer_helper import TARGET_KEYS
     dev = torch.device("cuda", 0)
     switches = bench.committed_switches("bf16")[0]
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29547")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     it, _ = build(dev, True, switches)
-    it.grad_sync = FlatGradSync(it.raw_model.parameters())
-    it.capture_error_mode = os.environ.get("MDETR_TEST_CAPTURE_MODE", "thread_local")
+    it.pending_sync = "flat"
     it.strict = False
+    modes = []
+
+    def attach(iteration):
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        modes.append(iteration.attach_process_group())
+    it.on_captured = attach
     seq = []
-    for i in range(8):
+    for i in range(10):
         images, calibs, t = collated_batch(2, seed=300 + i)
         images = images.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         seq.append(float(it.run((images, calibs.to(dev), t['img_size'], {k: t[k] for k in TARGET_KEYS}))))
+        # eager kernels on the launching stream between replays (what corrupted the runtime's packet path)
+        sum(float(p.detach().float().abs().max()) for p in list(it.raw_model.parameters())[:40])
     torch.cuda.synchronize()
-    print("PG-CHILD launch=%r replays=%d finite=%s" % (it.launch_mode(), it.replays, all(math.isfinite(x) for x in seq)), flush=True)
+    ok = all(math.isfinite(x) for x in seq) and all(bool(torch.isfinite(p).all()) for p in it.raw_model.parameters())
+    print("PG-CHILD launch=%r replays=%d finite=%s sync=%s %s" % (modes[-1] if modes else it.launch_mode(), it.replays, ok,
+                                                                 type(it.grad_sync).__name__, [round(x, 2) for x in seq]), flush=True)
     torch.distributed.destroy_process_group()
 
 
-def test_trainer_two_graph_form_with_a_live_process_group():
-    """One process per GPU: the Trainer's process group exists BEFORE the capture (bench.py captures first).  With the
-    capture checked per thread (capture_error_mode="thread_local") RCCL's watchdog thread does not abort it.  In a child
-    process: a watchdog abort takes the process down."""
+def test_two_graph_form_with_the_process_group_created_after_the_capture():
+    """One process per GPU (tools/train_val.py): the iteration is captured BEFORE the process group exists -- a live group's
+    watchdog thread polls events while a capture is under way and aborts the process -- then the group is created, rank 0's
+    state is broadcast, and every replay is [forward + backward] -> flat RCCL all-reduce -> [optimizer].  In a child process."""
     import subprocess
     import sys
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]))
@@ -179,7 +192,7 @@ def test_trainer_two_graph_form_with_a_live_process_group():
     print(tail)
     assert done.returncode == 0, tail
     line = [ln for ln in done.stdout.splitlines() if ln.startswith("PG-CHILD")][-1]
-    assert "two hipGraph replays" in line and "replays=5" in line and "finite=True" in line, line
+    assert "two hipGraph replays" in line and "replays=7" in line and "finite=True" in line and "sync=FlatGradSync" in line, line
 
 
 if __name__ == "__main__":
