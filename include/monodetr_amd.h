@@ -252,6 +252,19 @@ int mdetr_msda_prologue_backward(int io_dtype, int ref_dtype, const void *offset
                                  void *grad_offsets, void *grad_logits, float *grad_ref,
                                  int B, int Lq, int M, int L, int P, int R, int64_t ref_sb, int64_t ref_sq, int64_t ref_sl,
                                  int device, void *stream);
+/*
+ * The same pair on the output of ONE projection (the reference's two nn.Linear of the query, ms_deform_attn.py:138-139, with
+ * their weights stacked: sampling_offsets rows, then attention_weights rows): packed [B, Lq, M L P 3] of io_dtype holds per
+ * query the M L P 2 offsets followed by the M L P logits; grad_packed has the same layout.  L = P = 4 and 16-byte aligned
+ * pointers only (MDETR_E_ARG / MDETR_E_HIP otherwise).
+ */
+int mdetr_msda_prologue_forward_packed(int io_dtype, int ref_dtype, const void *packed, const void *ref, const int64_t *spatial_shapes,
+                                       float *sampling_loc, float *attn_weight, int B, int Lq, int M, int L, int P, int R,
+                                       int64_t ref_sb, int64_t ref_sq, int64_t ref_sl, int device, void *stream);
+int mdetr_msda_prologue_backward_packed(int io_dtype, int ref_dtype, const void *packed, const void *ref, const int64_t *spatial_shapes,
+                                        const float *attn_weight, const float *grad_loc, const float *grad_attn, void *grad_packed,
+                                        float *grad_ref, int B, int Lq, int M, int L, int P, int R,
+                                        int64_t ref_sb, int64_t ref_sq, int64_t ref_sl, int device, void *stream);
 
 /*
  * mdetr_lsa_forward with the matching cost evaluated inside the kernel (matcher.py:55-84) instead of read from a
@@ -302,6 +315,12 @@ int mdetr_ddn_loss_backward(const float *logits, const float *boxes, const float
 int mdetr_adamw_step(int param_dtype, void *param, float *master, const void *grad, float *exp_avg, float *exp_avg_sq,
                      int64_t n, int64_t n_no_decay, float beta1, float beta2, float eps, float weight_decay,
                      float step_size, const float *step_size_dev, int device, void *stream);
+/* The same update with the bias-corrected step size computed ON THE DEVICE: step = lr * sqrt(1 - beta2^t) / (1 - beta1^t) with the
+ * step count t read from `step_count_dev` (a double the caller has already advanced) and the learning rate from `lr_dev` (a
+ * double, or NULL: the host value `lr`) -- a captured optimizer step then needs no scalar launches of its own. */
+int mdetr_adamw_step_counted(int param_dtype, void *param, float *master, const void *grad, float *exp_avg, float *exp_avg_sq,
+                             int64_t n, int64_t n_no_decay, float beta1, float beta2, float eps, float weight_decay,
+                             const double *step_count_dev, float lr, const double *lr_dev, int device, void *stream);
 
 /*
  * y[T, N] = x[T, K] * weight[N, K]^T + bias (+ ReLU) for tall token matrices in bf16, with the weight held in
@@ -430,10 +449,10 @@ int mdetr_column_sum_to(int dtype, const void *x, void *out, int out_dtype, void
  * of the ResNet body (lib/models/monodetr/backbone.py:100-102 -> torchvision resnet), which the reference hands to cuDNN.
  *   x      bf16 [B, H, W, C], C % 64 == 0 (a channels_last [B, C, H, W] tensor), 16-byte aligned
  *   w      bf16 [N, 3, 3, C], N % 32 == 0 (a channels_last [N, C, 3, 3] weight), 16-byte aligned
- *   shift  fp32 [N] or NULL;  relu 0 / 1
+ *   shift  fp32 [N] or NULL;  relu: bit 0 = ReLU in the epilogue, bit 1 = taps read MIRRORED (w[n, 2 - t, 2 - s, :])
  *   y      bf16 [B, H, W, N], 8-byte aligned;  y = act(conv(x, w) + shift), fp32 accumulation, one rounding
- * The input gradient of the same convolution is this entry point on grad_y with the weight transformed to
- * w'[c, t, s, n] = w[n, 2 - t, 2 - s, c] (taps mirrored, channel axes swapped), shift = NULL, relu = 0.
+ * The input gradient of the same convolution is this entry point on grad_y with the weight's channel axes swapped,
+ * w'[c, t, s, n] = w[n, t, s, c], the taps mirrored by bit 1 of `relu`, shift = NULL.
  */
 int mdetr_conv3x3_forward(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N,
                           int relu, int device, void *stream);

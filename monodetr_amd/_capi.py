@@ -42,6 +42,7 @@ SIGNATURES = {
     "mdetr_pair_losses_forward": (_c_int, [_c_vp] * 14 + [_c_int] * 6 + [ctypes.c_float, ctypes.c_float] + [_c_vp] * 4 + [_c_int, _c_vp]),
     "mdetr_pair_losses_backward": (_c_int, [_c_vp] * 13 + [_c_int] * 6 + [ctypes.c_float, ctypes.c_float] + [_c_vp] * 8 + [_c_int, _c_vp]),
     "mdetr_adamw_step": (_c_int, [_c_int] + [_c_vp] * 5 + [ctypes.c_int64] * 2 + [ctypes.c_float] * 5 + [_c_vp, _c_int, _c_vp]),
+    "mdetr_adamw_step_counted": (_c_int, [_c_int] + [_c_vp] * 5 + [ctypes.c_int64] * 2 + [ctypes.c_float] * 4 + [_c_vp, ctypes.c_float, _c_vp, _c_int, _c_vp]),
     "mdetr_token_linear": (_c_int, [_c_vp] * 4 + [ctypes.c_int64, _c_int, _c_int, ctypes.c_int64, ctypes.c_int64, _c_int, _c_int, _c_vp]),
     "mdetr_column_sum_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, _c_int]),
     "mdetr_column_sum": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, ctypes.c_int64, ctypes.c_int64, _c_int, ctypes.c_int64, _c_int, _c_vp]),
@@ -69,6 +70,8 @@ SIGNATURES = {
     "mdetr_msda_forward_bf16": (_c_int, [_c_vp] * 6 + [_c_int] * 7 + [_c_int, _c_vp]),
     "mdetr_msda_backward_bf16": (_c_int, [_c_vp] * 9 + [_c_int] * 7 + [_c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_vp]),
     "mdetr_msda_prologue_forward": (_c_int, [_c_int, _c_int] + [_c_vp] * 6 + [_c_int] * 6 + [ctypes.c_int64] * 3 + [_c_int, _c_vp]),
+    "mdetr_msda_prologue_forward_packed": (_c_int, [_c_int, _c_int] + [_c_vp] * 5 + [_c_int] * 6 + [ctypes.c_int64] * 3 + [_c_int, _c_vp]),
+    "mdetr_msda_prologue_backward_packed": (_c_int, [_c_int, _c_int] + [_c_vp] * 8 + [_c_int] * 6 + [ctypes.c_int64] * 3 + [_c_int, _c_vp]),
     "mdetr_msda_prologue_backward": (_c_int, [_c_int, _c_int] + [_c_vp] * 9 + [_c_int] * 6 + [ctypes.c_int64] * 3 + [_c_int, _c_vp]),
     "mdetr_lsa_forward_fused": (_c_int, [_c_vp] * 6 + [_c_int] * 6 + [ctypes.c_float] * 5 + [_c_int, _c_vp]),
     "mdetr_profile_enable": (_c_int, [_c_int]),

@@ -31,14 +31,14 @@ def _ohwi(weight):
     return w if w.data_ptr() % 16 == 0 else w.clone()
 
 
-def _launch(x_cl, w_ohwi, shift, relu):
+def _launch(x_cl, w_ohwi, shift, relu, mirror=False):
     """x_cl [B, C, H, W] channels_last, w_ohwi [N, 3, 3, C] contiguous -> y [B, N, H, W] channels_last."""
     B, C, H, W = x_cl.shape
     N = w_ohwi.shape[0]
     y = torch.empty((B, N, H, W), dtype=torch.bfloat16, device=x_cl.device, memory_format=torch.channels_last)
     cuda = x_cl.is_cuda
     rc = _lib().mdetr_conv3x3_forward(x_cl.data_ptr(), w_ohwi.data_ptr(), shift.data_ptr() if shift is not None else None, y.data_ptr(),
-                                      B, H, W, C, N, 1 if relu else 0, x_cl.device.index if cuda else -1,
+                                      B, H, W, C, N, (1 if relu else 0) | (2 if mirror else 0), x_cl.device.index if cuda else -1,
                                       torch.cuda.current_stream(x_cl.device).cuda_stream if cuda else None)
     if rc != 0:
         _capi.check(rc, "mdetr_conv3x3_forward")
@@ -65,9 +65,10 @@ class _Conv3x3(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            # dX = conv(dY, w') with w'[c, t, s, n] = w[n, 2 - t, 2 - s, c]: the same kernel, taps mirrored, channel axes swapped
+            # dX = conv(dY, w') with w'[c, t, s, n] = w[n, 2 - t, 2 - s, c]: the same kernel on the weight with its channel axes
+            # swapped (one small copy), the taps mirrored by the kernel's addressing
             if dy.shape[1] % 64 == 0 and x.shape[1] % 32 == 0 and dy.data_ptr() % 16 == 0:
-                dx = _launch(dy, w.flip(1, 2).permute(3, 1, 2, 0).contiguous(), None, False)
+                dx = _launch(dy, w.permute(3, 1, 2, 0).contiguous(), None, False, mirror=True)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (True, False, False))[0]
         if ctx.needs_input_grad[1]:

@@ -49,9 +49,16 @@ template <typename P>
 __global__ __launch_bounds__(256)
 void adamw_kernel(P *__restrict__ param, float *__restrict__ master, const P *__restrict__ grad,
                   float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, int64_t n, int64_t n_no_decay,
-                  AdamWCoef c, float step_host, const float *__restrict__ step_dev)
+                  AdamWCoef c, float step_host, const float *__restrict__ step_dev, const double *__restrict__ count_dev,
+                  const double *__restrict__ lr_dev, float lr_host)
 {
-    const float step = step_dev ? *step_dev : step_host;
+    // the bias-corrected step size: a host scalar, a device scalar, or -- count_dev -- computed here from the device-resident step
+    // count and learning rate (a captured optimizer step: ten scalar launches per flat buffer otherwise)
+    float step = step_dev ? *step_dev : step_host;
+    if (count_dev) {
+        const double t = *count_dev, lr = lr_dev ? *lr_dev : static_cast<double>(lr_host);
+        step = static_cast<float>(lr * sqrt(1.0 - pow(static_cast<double>(c.beta2), t)) / (1.0 - pow(static_cast<double>(c.beta1), t)));
+    }
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x * 4;
     for (int64_t i0 = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4; i0 < n; i0 += stride) {
         if (i0 + 4 <= n) {
@@ -77,7 +84,8 @@ void adamw_kernel(P *__restrict__ param, float *__restrict__ master, const P *__
 
 hipError_t adamw_launch(int param_dtype, void *param, float *master, const void *grad, float *exp_avg,
                         float *exp_avg_sq, int64_t n, int64_t n_no_decay, float beta1, float beta2, float eps,
-                        float weight_decay, float step_host, const float *step_dev, hipStream_t st)
+                        float weight_decay, float step_host, const float *step_dev, hipStream_t st, const double *count_dev,
+                        const double *lr_dev, float lr_host)
 {
     if (n == 0) return hipSuccess;
     const AdamWCoef c{beta1, beta2, eps, weight_decay};
@@ -86,11 +94,11 @@ hipError_t adamw_launch(int param_dtype, void *param, float *master, const void 
     if (param_dtype == 2)
         hipLaunchKernelGGL(adamw_kernel<__hip_bfloat16>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st,
                            static_cast<__hip_bfloat16 *>(param), master, static_cast<const __hip_bfloat16 *>(grad),
-                           exp_avg, exp_avg_sq, n, n_no_decay, c, step_host, step_dev);
+                           exp_avg, exp_avg_sq, n, n_no_decay, c, step_host, step_dev, count_dev, lr_dev, lr_host);
     else
         hipLaunchKernelGGL(adamw_kernel<float>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st,
                            static_cast<float *>(param), master, static_cast<const float *>(grad),
-                           exp_avg, exp_avg_sq, n, n_no_decay, c, step_host, step_dev);
+                           exp_avg, exp_avg_sq, n, n_no_decay, c, step_host, step_dev, count_dev, lr_dev, lr_host);
     return hipGetLastError();
 }
 

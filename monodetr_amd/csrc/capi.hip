@@ -442,6 +442,27 @@ int mdetr_adamw_step(int param_dtype, void *param, float *master, const void *gr
     return MDETR_OK;
 }
 
+int mdetr_adamw_step_counted(int param_dtype, void *param, float *master, const void *grad, float *exp_avg, float *exp_avg_sq,
+                             int64_t n, int64_t n_no_decay, float beta1, float beta2, float eps, float weight_decay,
+                             const double *step_count_dev, float lr, const double *lr_dev, int device, void *stream)
+{
+    if (param_dtype != MDETR_F32 && param_dtype != MDETR_BF16)
+        return fail(MDETR_E_ARG, "mdetr_adamw_step_counted: parameter dtype must be f32 or bf16");
+    if (n < 0 || n_no_decay < 0 || n_no_decay > n) return fail(MDETR_E_ARG, "mdetr_adamw_step_counted: bad sizes");
+    if (n == 0) return MDETR_OK;
+    if (!param || !master || !grad || !exp_avg || !exp_avg_sq || !step_count_dev) return fail(MDETR_E_ARG, "mdetr_adamw_step_counted: null pointer");
+    if (param_dtype == MDETR_F32 && static_cast<void *>(master) != param)
+        return fail(MDETR_E_ARG, "mdetr_adamw_step_counted: an f32 parameter is its own master copy");
+    if (!aligned16(param) || !aligned16(master) || !aligned16(grad) || !aligned16(exp_avg) || !aligned16(exp_avg_sq))
+        return fail(MDETR_E_ALIGN, "mdetr_adamw_step_counted: buffers must be 16-byte aligned");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_adamw_step_counted: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::adamw_launch(param_dtype, param, master, grad, exp_avg, exp_avg_sq, n, n_no_decay, beta1, beta2, eps,
+                                             weight_decay, 0.f, nullptr, static_cast<hipStream_t>(stream), step_count_dev, lr_dev, lr);
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_adamw_step_counted: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
 int mdetr_token_linear(const void *x, const void *weight, const void *bias, void *y, int64_t T, int N, int K,
                        int64_t ldx, int64_t ldy, int relu, int device, void *stream)
 {
@@ -504,7 +525,7 @@ int mdetr_conv3x3_forward(const void *x, const void *w, const float *shift, void
         return fail(MDETR_E_ARG, "mdetr_conv3x3_forward: needs C %% 64 == 0, N %% 32 == 0, 16-byte aligned x / w, 8-byte aligned y (C=%d N=%d)", C, N);
     DeviceScope dev(device);
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv3x3_forward: set device %d: %s", device, hipGetErrorString(dev.err));
-    const hipError_t e = mdetr::conv3x3_launch(x, w, shift, y, B, H, W, C, N, relu != 0, static_cast<hipStream_t>(stream));
+    const hipError_t e = mdetr::conv3x3_launch(x, w, shift, y, B, H, W, C, N, (relu & 1) != 0, static_cast<hipStream_t>(stream), (relu & 2) != 0);
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv3x3_forward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
@@ -911,6 +932,54 @@ int mdetr_msda_prologue_backward(int io_dtype, int ref_dtype, const void *offset
         e = mdetr::msda_prologue_backward_launch(io_dtype, ref_dtype, d, offsets, ref, spatial_shapes, attn_weight, grad_loc, grad_attn,
                                                  grad_offsets, grad_logits, grad_ref, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_prologue_backward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+// the packed form: ONE projection output [B, Lq, M L P 3] holding, per query, the M L P 2 offsets and then the M L P logits
+int mdetr_msda_prologue_forward_packed(int io_dtype, int ref_dtype, const void *packed, const void *ref, const int64_t *spatial_shapes,
+                                       float *sampling_loc, float *attn_weight, int B, int Lq, int M, int L, int P, int R,
+                                       int64_t ref_sb, int64_t ref_sq, int64_t ref_sl, int device, void *stream)
+{
+    if (int rc = prologue_args("mdetr_msda_prologue_forward_packed", io_dtype, B, Lq, M, L, P, R)) return rc;
+    if (ref_dtype != MDETR_F32 && ref_dtype != MDETR_BF16) return fail(MDETR_E_ARG, "mdetr_msda_prologue_forward_packed: ref_dtype %d", ref_dtype);
+    if (B == 0 || Lq == 0) return MDETR_OK;
+    if (!packed || !ref || !spatial_shapes || !sampling_loc || !attn_weight) return fail(MDETR_E_ARG, "mdetr_msda_prologue_forward_packed: null pointer");
+    if (L != 4 || P != 4) return fail(MDETR_E_ARG, "mdetr_msda_prologue_forward_packed: the packed form needs L = P = 4 (L=%d P=%d)", L, P);
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_prologue_forward_packed: set device %d: %s", device, hipGetErrorString(dev.err));
+    mdetr::PrologueDims d{B, Lq, M, L, P, R, ref_sb, ref_sq, ref_sl};
+    d.po = d.pl = static_cast<int64_t>(M) * L * P * 3;
+    const size_t esz = io_dtype == MDETR_BF16 ? 2 : 4;
+    const void *logits = static_cast<const char *>(packed) + static_cast<size_t>(M) * L * P * 2 * esz;
+    const hipError_t e = mdetr::msda_prologue_forward_launch(io_dtype, ref_dtype, d, packed, logits, ref, spatial_shapes, sampling_loc,
+                                                             attn_weight, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_prologue_forward_packed: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_msda_prologue_backward_packed(int io_dtype, int ref_dtype, const void *packed, const void *ref, const int64_t *spatial_shapes,
+                                        const float *attn_weight, const float *grad_loc, const float *grad_attn, void *grad_packed,
+                                        float *grad_ref, int B, int Lq, int M, int L, int P, int R,
+                                        int64_t ref_sb, int64_t ref_sq, int64_t ref_sl, int device, void *stream)
+{
+    if (int rc = prologue_args("mdetr_msda_prologue_backward_packed", io_dtype, B, Lq, M, L, P, R)) return rc;
+    if (ref_dtype != MDETR_F32 && ref_dtype != MDETR_BF16) return fail(MDETR_E_ARG, "mdetr_msda_prologue_backward_packed: ref_dtype %d", ref_dtype);
+    if (B == 0 || Lq == 0) return MDETR_OK;
+    if (!packed || !ref || !spatial_shapes || !attn_weight || !grad_loc || !grad_attn || !grad_packed)
+        return fail(MDETR_E_ARG, "mdetr_msda_prologue_backward_packed: null pointer");
+    if (L != 4 || P != 4) return fail(MDETR_E_ARG, "mdetr_msda_prologue_backward_packed: the packed form needs L = P = 4 (L=%d P=%d)", L, P);
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_prologue_backward_packed: set device %d: %s", device, hipGetErrorString(dev.err));
+    mdetr::PrologueDims d{B, Lq, M, L, P, R, ref_sb, ref_sq, ref_sl};
+    d.po = d.pl = static_cast<int64_t>(M) * L * P * 3;
+    const size_t esz = io_dtype == MDETR_BF16 ? 2 : 4;
+    void *g_logits = static_cast<char *>(grad_packed) + static_cast<size_t>(M) * L * P * 2 * esz;
+    hipError_t e = hipSuccess;
+    if (grad_ref) e = mdetr::zero_fill_launch(grad_ref, static_cast<int64_t>(B) * Lq * L * R * 4, static_cast<hipStream_t>(stream));
+    if (e == hipSuccess)
+        e = mdetr::msda_prologue_backward_launch(io_dtype, ref_dtype, d, packed, ref, spatial_shapes, attn_weight, grad_loc, grad_attn,
+                                                 grad_packed, g_logits, grad_ref, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_msda_prologue_backward_packed: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

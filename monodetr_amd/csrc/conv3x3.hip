@@ -42,6 +42,7 @@ struct ConvDims {
     int tiles;                           // B * tiles_x * tiles_y
     int ngroups;                         // output-channel groups of NB*32
     int xcd_per;                         // 8 / ngroups when that is whole (XCD-aware numbering below), else 0
+    int mirror;                          // taps read mirrored: w[n][2 - t][2 - s][k] (the input gradient: no mirrored weight copy)
 };
 
 template <int NB, bool RELU>
@@ -95,7 +96,7 @@ void conv3x3_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, 
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = static_cast<__bf16>(0.f);
             if (n0 + n < d.N)
-                v = *reinterpret_cast<const bf16x8 *>(w + ((static_cast<int64_t>(n0 + n) * 3 + tr) * 3 + s) * d.C + k0 + piece * 8);
+                v = *reinterpret_cast<const bf16x8 *>(w + ((static_cast<int64_t>(n0 + n) * 3 + (d.mirror ? 2 - tr : tr)) * 3 + (d.mirror ? 2 - s : s)) * d.C + k0 + piece * 8);
             wreg[j] = v;
         }
     };
@@ -215,9 +216,9 @@ bool conv3x3_supported(int B, int H, int W, int C, int N, const void *x, const v
 }
 
 hipError_t conv3x3_launch(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N, bool relu,
-                          hipStream_t st)
+                          hipStream_t st, bool mirror)
 {
-    ConvDims d{B, H, W, C, N, (W + kTileW - 1) / kTileW, (H + kWavesC - 1) / kWavesC, 0, 0, 0};
+    ConvDims d{B, H, W, C, N, (W + kTileW - 1) / kTileW, (H + kWavesC - 1) / kWavesC, 0, 0, 0, mirror ? 1 : 0};
     // 128 output channels per workgroup where the layer has them (the halo is then read once per 128 channels); 64 for the
     // 64-channel stage
     if (N >= 128) return relu ? launch<4, true>(x, w, shift, y, d, st) : launch<4, false>(x, w, shift, y, d, st);

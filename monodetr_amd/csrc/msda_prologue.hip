@@ -149,8 +149,9 @@ void prologue_fwd_vec44(const PrologueDims d, const T *__restrict__ offsets, con
     const int64_t bq = u / d.M;
     const int b = static_cast<int>(bq / d.Lq), q = static_cast<int>(bq - static_cast<int64_t>(b) * d.Lq);
     float lg[16], at[16], off[32], lc[32];
-    load_vec<T, 16>(logits + u * 16, lg);
-    load_vec<T, 32>(offsets + u * 32, off);
+    const int mh = static_cast<int>(u - bq * d.M);                                         // head
+    load_vec<T, 16>(logits + (d.pl ? bq * d.pl + mh * 16 : u * 16), lg);
+    load_vec<T, 32>(offsets + (d.po ? bq * d.po + mh * 32 : u * 32), off);
     pro_softmax(lg, 16, at);
     store_vec<float, 16>(attn + u * 16, at);
 #pragma unroll
@@ -181,13 +182,14 @@ void prologue_bwd_vec44(const PrologueDims d, const T *__restrict__ offsets, con
     load_vec<float, 16>(attn + u * 16, at);
     load_vec<float, 16>(g_attn + u * 16, ga);
     load_vec<float, 32>(g_loc + u * 32, glc);
-    if (d.R != 2) load_vec<T, 32>(offsets + u * 32, off);          // the 2-component form does not read the offsets
+    const int mh = static_cast<int>(u - bq * d.M);                                         // head
+    if (d.R != 2) load_vec<T, 32>(offsets + (d.po ? bq * d.po + mh * 32 : u * 32), off);   // the 2-component form does not read the offsets
     else {
 #pragma unroll
         for (int i = 0; i < 32; ++i) off[i] = 0.f;
     }
     pro_softmax_backward(at, ga, 16, gl);
-    store_vec<T, 16>(g_logits + u * 16, gl);
+    store_vec<T, 16>(g_logits + (d.pl ? bq * d.pl + mh * 16 : u * 16), gl);
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
         float rl[6], gr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -207,7 +209,7 @@ void prologue_bwd_vec44(const PrologueDims d, const T *__restrict__ offsets, con
                 if (r < d.R) unsafeAtomicAdd(out + r, gr[r]);                             // summed over the M heads
         }
     }
-    store_vec<T, 32>(g_offsets + u * 32, go);
+    store_vec<T, 32>(g_offsets + (d.po ? bq * d.po + mh * 32 : u * 32), go);
 }
 
 bool aligned16_all(std::initializer_list<const void *> ps)
@@ -224,6 +226,9 @@ template <typename T, typename RT>
 hipError_t launch_fwd(const PrologueDims &d, const void *offsets, const void *logits, const void *ref, const int64_t *shapes,
                       float *loc, float *attn, dim3 grid, hipStream_t st)
 {
+    const bool pitched = d.po != 0 || d.pl != 0;
+    if (pitched && !(d.L == 4 && d.P == 4 && aligned16_all({offsets, logits, loc, attn}) && (d.po * sizeof(T)) % 16 == 0 && (d.pl * sizeof(T)) % 16 == 0))
+        return hipErrorNotSupported;                                 // a packed projection output: the 16-byte form only
     if (d.L == 4 && d.P == 4 && aligned16_all({offsets, logits, loc, attn}))
         hipLaunchKernelGGL((prologue_fwd_vec44<T, RT>), grid, dim3(256), 0, st, d, static_cast<const T *>(offsets),
                            static_cast<const T *>(logits), static_cast<const RT *>(ref), shapes, loc, attn);
@@ -240,6 +245,9 @@ template <typename T, typename RT>
 hipError_t launch_bwd(const PrologueDims &d, const void *offsets, const void *ref, const int64_t *shapes, const float *attn,
                       const float *g_loc, const float *g_attn, void *g_offsets, void *g_logits, float *g_ref, dim3 grid, hipStream_t st)
 {
+    const bool pitched = d.po != 0 || d.pl != 0;
+    if (pitched && !(d.L == 4 && d.P == 4 && aligned16_all({offsets, attn, g_loc, g_attn, g_offsets, g_logits}) && (d.po * sizeof(T)) % 16 == 0 && (d.pl * sizeof(T)) % 16 == 0))
+        return hipErrorNotSupported;
     if (d.L == 4 && d.P == 4 && aligned16_all({offsets, attn, g_loc, g_attn, g_offsets, g_logits}))
         hipLaunchKernelGGL((prologue_bwd_vec44<T, RT>), grid, dim3(256), 0, st, d, static_cast<const T *>(offsets),
                            static_cast<const RT *>(ref), shapes, attn, g_loc, g_attn, static_cast<T *>(g_offsets),

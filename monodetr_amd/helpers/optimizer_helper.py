@@ -317,11 +317,32 @@ class FusedAdamW(AdamW):
             for p in buf['params']:
                 self.state[p]['step'] = t
             step_dev = None
+            dev = buf['param'].device
             if group['capturable']:
                 group['calls'] = group.get('calls', 0)            # the device counters are keyed like the parent's
+                counted = getattr(lib, "mdetr_adamw_step_counted", None)
+                if counted is not None:
+                    # the step count advances on the device (one launch); the kernel derives the bias-corrected step size from it
+                    # and from the (device-resident) learning rate itself
+                    tdev = buf.get('step_dev')
+                    if tdev is None:
+                        tdev = buf['step_dev'] = torch.full((), float(t - 1), dtype=torch.float64, device=dev)
+                    tdev.add_(1.0)
+                    lr = group['lr']
+                    lr_dev = lr if torch.is_tensor(lr) and lr.dtype == torch.float64 and lr.device == dev else None
+                    rc = counted(
+                        _capi.MDETR_BF16 if buf['dtype'] == torch.bfloat16 else _capi.MDETR_F32,
+                        buf['param'].data_ptr(), buf['master'].data_ptr(), buf['grad'].data_ptr(),
+                        buf['exp_avg'].data_ptr(), buf['exp_avg_sq'].data_ptr(), buf['n'],
+                        buf['n'] if group['weight_decay'] == 0 else 0, beta1, beta2, group['eps'], group['weight_decay'],
+                        tdev.data_ptr(), 0.0 if lr_dev is not None else float(lr), lr_dev.data_ptr() if lr_dev is not None else None,
+                        dev.index if dev.type == "cuda" else -1,
+                        torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None)
+                    if rc != 0:
+                        _capi.check(rc, "mdetr_adamw_step_counted")
+                    continue
                 step_dev = self._fused_step_size(group, buf, t)
             step = float(group['lr']) * math.sqrt(1 - beta2 ** t) / (1 - beta1 ** t) if step_dev is None else 0.0
-            dev = buf['param'].device
             rc = lib.mdetr_adamw_step(
                 _capi.MDETR_BF16 if buf['dtype'] == torch.bfloat16 else _capi.MDETR_F32,
                 buf['param'].data_ptr(), buf['master'].data_ptr(), buf['grad'].data_ptr(),

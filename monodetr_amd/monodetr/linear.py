@@ -38,10 +38,21 @@ def _split_count(T):
 
 class _TokenLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, fused_relu=False):
-        """fused_relu: ReLU in the epilogue of the token-GEMM kernel or, failing that, of the library GEMM."""
+    def forward(ctx, x, weight, bias, fused_relu=False, wide_out=False):
+        """fused_relu: ReLU in the epilogue of the token-GEMM kernel or, failing that, of the library GEMM.
+        wide_out: bf16 operands, fp32 RESULT (the fp32 accumulator is written out unrounded) -- the decoder's deformable
+        cross-attention differences neighbouring value rows for d/d(location), and 8 mantissa bits on the values made those
+        gradients the least accurate of the bf16 model (cosine 0.86-0.98 against the fp32 model, round 2)."""
         ctx.has_bias = bias is not None
         ctx.fused_relu = False
+        ctx.wide_out = bool(wide_out)
+        if wide_out:
+            x2 = x.reshape(-1, x.shape[-1])
+            y = torch.mm(x2, weight.t(), out_dtype=torch.float32)
+            if bias is not None:
+                y += bias.float()
+            ctx.save_for_backward(x, weight)
+            return y.view(x.shape[:-1] + (weight.shape[0],))
         if _TOKEN_GEMM:
             from .. import token_gemm_ext
             x2 = x.reshape(-1, x.shape[-1])
@@ -70,6 +81,8 @@ class _TokenLinear(torch.autograd.Function):
             dy = torch.ops.aten.threshold_backward(dy, y, 0.0)       # ReLU of the epilogue: dy where y > 0, one launch
         else:
             x, weight = ctx.saved_tensors
+        if ctx.wide_out:
+            dy = dy.to(x.dtype)                                        # one rounding of the fp32 gradient, as the narrow form receives it
         dx = dw = db = None
         x2 = x.reshape(-1, x.shape[-1])
         dy2 = dy.reshape(-1, dy.shape[-1])
@@ -87,7 +100,7 @@ class _TokenLinear(torch.autograd.Function):
                 and weight.dtype in (torch.float32, torch.bfloat16) and small_wgrad_ext.supported(dy2, x2):
             # a few thousand rows (the decoder's 4 400): dW and db from one launch + one chunk sum (csrc/small_wgrad.hip)
             dw, db = small_wgrad_ext.small_wgrad(dy2, x2, weight.dtype)
-            return dx, dw, (db if ctx.has_bias and ctx.needs_input_grad[2] else None), None
+            return dx, dw, (db if ctx.has_bias and ctx.needs_input_grad[2] else None), None, None
         # the batched split rounds every chunk's partial product to the activation dtype: worth it from ~8 000 rows on (43 vs
         # 110 us at 15 360), not for the decoder's 4 400 (29 + 12 vs 34 us, and 16 bf16 roundings instead of one)
         C = _split_count(T) if T > small_wgrad_ext.MAX_ROWS else 0
@@ -107,7 +120,7 @@ class _TokenLinear(torch.autograd.Function):
                 db = colsum_ext.column_sum(dy2, weight.dtype)       # csrc/colsum.hip: one HBM pass, fp32 accumulation, one rounding
             else:
                 db = (dy2.view(C, T // C, -1).sum(1).sum(0) if C else dy2.sum(0)).to(weight.dtype)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 def _kernel_relu(x, weight, bias=None):
@@ -119,9 +132,12 @@ def _kernel_relu(x, weight, bias=None):
     return _GEMM_RELU and bias is not None and bias.dim() == 1 and bias.is_contiguous()
 
 
-def token_linear(x, weight, bias=None, relu=False):
+def token_linear(x, weight, bias=None, relu=False, wide_out=False):
     """F.linear (followed by ReLU if `relu`) with the split-K weight gradient for big token counts on the GPU;
-    plain F.linear otherwise.  With the token-GEMM kernel enabled the ReLU runs in its epilogue."""
+    plain F.linear otherwise.  With the token-GEMM kernel enabled the ReLU runs in its epilogue.
+    wide_out (bf16 operands on the GPU only): the result in fp32, see `_TokenLinear.forward`."""
+    if wide_out and not relu and x.is_cuda and x.dtype == weight.dtype == torch.bfloat16 and not torch.is_autocast_enabled():
+        return _TokenLinear.apply(x, weight, bias, False, True)
     if x.is_cuda and x.dtype == weight.dtype and x.numel() // x.shape[-1] >= _MIN_TOKENS and torch.is_grad_enabled() \
             and not torch.is_autocast_enabled():
         if relu and _kernel_relu(x, weight, bias):

@@ -23,6 +23,10 @@ from .... import msda_prologue_ext
 # MDETR_MSDA_PROLOGUE=1: fused softmax + sampling-location kernel (off until its first GPU validation,
 # tests/test_fused_gpu.py)
 _FUSED_PROLOGUE = os.environ.get("MDETR_MSDA_PROLOGUE") == "1"
+# with the prologue kernel: the sampling-offset and attention-weight projections as one GEMM (MDETR_MSDA_PACKED=0: two)
+_PACKED_PROJECTION = os.environ.get("MDETR_MSDA_PACKED", "1") != "0"
+# fp32 values for the decoder's deformable cross-attention in a bf16 model (MDETR_MSDA_WIDE_VALUE=0 restores bf16 values)
+_WIDE_CROSS_VALUE = os.environ.get("MDETR_MSDA_WIDE_VALUE", "1") != "0"
 
 
 
@@ -94,17 +98,34 @@ class MSDeformAttn(nn.Module):
         M, L, P = self.n_heads, self.n_levels, self.n_points
         _check_token_count(input_spatial_shapes, S)
 
-        value = token_linear(input_flatten, self.value_proj.weight, self.value_proj.bias)
+        # cross-attention of a few queries into the pyramid (the decoder: 550 queries, S = 10 200) in a bf16 model: fp32 values --
+        # the projection's fp32 accumulator written out unrounded -- through the fp32 operator.  Its d/d(location) differences
+        # neighbouring value rows; with bf16-rounded values those were the least accurate gradients of the bf16 model.
+        wide = _WIDE_CROSS_VALUE and input_flatten.is_cuda and input_flatten.dtype == torch.bfloat16 and Lq * 8 <= S
+        value = token_linear(input_flatten, self.value_proj.weight, self.value_proj.bias, wide_out=wide)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, S, M, -1)
 
-        offsets = token_linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias).view(N, Lq, M, L, P, 2)
-        logits = token_linear(query, self.attention_weights.weight, self.attention_weights.bias).view(N, Lq, M, L * P)
         if reference_points.shape[-1] not in (2, 6):
             raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
                 reference_points.shape[-1]))
-        if _FUSED_PROLOGUE and msda_prologue_ext.supported(offsets, logits, reference_points):
+        packed = None
+        if _FUSED_PROLOGUE and _PACKED_PROJECTION and not torch.is_autocast_enabled():
+            # the two projections of the query as ONE GEMM (384 = 256 offset + 128 logit columns): one read of the query forward,
+            # one input-gradient GEMM and one weight-gradient GEMM backward, and no sum of two query gradients
+            w = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
+            b = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
+            packed = token_linear(query, w, b)
+            if not msda_prologue_ext.packed_supported(packed, reference_points, L, P):
+                offsets, logits = packed[..., :M * L * P * 2].reshape(N, Lq, M, L, P, 2), packed[..., M * L * P * 2:].reshape(N, Lq, M, L * P)
+                packed = None
+        else:
+            offsets = token_linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias).view(N, Lq, M, L, P, 2)
+            logits = token_linear(query, self.attention_weights.weight, self.attention_weights.bias).view(N, Lq, M, L * P)
+        if packed is not None:
+            locations, weights = msda_prologue_ext.msda_prologue_packed(packed, reference_points, input_spatial_shapes, M, L, P)
+        elif _FUSED_PROLOGUE and msda_prologue_ext.supported(offsets, logits, reference_points):
             # softmax + sampling-location arithmetic in one fp32 launch (csrc/msda_prologue.hip)
             locations, weights = msda_prologue_ext.msda_prologue(offsets, logits, reference_points, input_spatial_shapes)
         else:
@@ -119,6 +140,8 @@ class MSDeformAttn(nn.Module):
 
         out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
                                          locations, weights, self.im2col_step)
+        if out.dtype != query.dtype and query.dtype == torch.bfloat16:
+            out = out.to(query.dtype)                                  # (the fp32 operator of the wide form)
         return token_linear(out, self.output_proj.weight, self.output_proj.bias)
 
 

@@ -72,6 +72,67 @@ class _Prologue(torch.autograd.Function):
         return g_off, g_lg.view(B, Lq, M, L * P), g_ref, None
 
 
+def packed_supported(packed, reference_points, L, P):
+    """The one-GEMM form: `packed` [B, Lq, M L P 3] = per query the M L P 2 offsets, then the M L P logits (L = P = 4)."""
+    return (L == 4 and P == 4 and (packed.is_cuda or _backend is not None) and packed.dtype in (torch.float32, torch.bfloat16)
+            and packed.is_contiguous() and packed.data_ptr() % 16 == 0
+            and reference_points.shape[-1] in (2, 6) and reference_points.stride(-1) == 1
+            and getattr(_lib(), "mdetr_msda_prologue_forward_packed", None) is not None)
+
+
+class _ProloguePacked(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, packed, ref, spatial_shapes, M, L, P):
+        B, Lq = packed.shape[:2]
+        R = ref.shape[-1]
+        io = packed.dtype
+        refc = ref if ref.dtype in (torch.float32, torch.bfloat16) else ref.float()
+        if refc.stride(-1) != 1:
+            refc = refc.contiguous()
+        rcode = _io_code(refc.dtype)
+        dev = packed.device
+        loc = torch.empty((B, Lq, M, L, P, 2), dtype=torch.float32, device=dev)
+        attn = torch.empty((B, Lq, M, L, P), dtype=torch.float32, device=dev)
+        geom = (B, Lq, M, L, P, R, refc.stride(0), refc.stride(1), refc.stride(2))
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
+        rc = _lib().mdetr_msda_prologue_forward_packed(_io_code(io), rcode, packed.data_ptr(), refc.data_ptr(), spatial_shapes.data_ptr(),
+                                                       loc.data_ptr(), attn.data_ptr(), *geom, dev.index if dev.type == "cuda" else -1, stream)
+        if rc != 0:
+            _capi.check(rc, "mdetr_msda_prologue_forward_packed")
+        ctx.save_for_backward(packed, refc, spatial_shapes, attn)
+        ctx.geom, ctx.io, ctx.ref_dtype, ctx.rcode = geom, io, ref.dtype, rcode
+        ctx.ref_shape = tuple(ref.shape)
+        return loc, attn
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_loc, g_attn):
+        packed, refc, shapes, attn = ctx.saved_tensors
+        B, Lq, M, L, P, R = ctx.geom[:6]
+        dev = packed.device
+        g_packed = torch.empty_like(packed)
+        g_ref = torch.empty((B, Lq, L, R), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
+        gl, ga = g_loc.contiguous().float(), g_attn.contiguous().float()
+        rc = _lib().mdetr_msda_prologue_backward_packed(
+            _io_code(ctx.io), ctx.rcode, packed.data_ptr(), refc.data_ptr(), shapes.data_ptr(), attn.data_ptr(),
+            gl.data_ptr(), ga.data_ptr(), g_packed.data_ptr(), g_ref.data_ptr() if g_ref is not None else None, *ctx.geom,
+            dev.index if dev.type == "cuda" else -1, stream)
+        if rc != 0:
+            _capi.check(rc, "mdetr_msda_prologue_backward_packed")
+        if g_ref is not None:
+            g_ref = g_ref.to(ctx.ref_dtype)
+            if ctx.ref_shape != tuple(g_ref.shape):
+                g_ref = g_ref.sum_to_size(ctx.ref_shape)
+        return g_packed, g_ref, None, None, None, None
+
+
+def msda_prologue_packed(packed, reference_points, spatial_shapes, M, L, P):
+    """packed [B, Lq, M L P 3] (offsets | logits per query: the output of ONE projection whose weight is the sampling-offset rows
+    followed by the attention-weight rows) -> the same pair as `msda_prologue`."""
+    return _ProloguePacked.apply(packed, reference_points, spatial_shapes, M, L, P)
+
+
 def msda_prologue(offsets, logits, reference_points, spatial_shapes):
     """offsets [B,Lq,M,L,P,2], logits [B,Lq,M,L*P] (f32 or bf16), reference_points [B,Lq,L,2|6] (may be an
     expanded view), spatial_shapes int64 [L,2] -> (sampling_locations fp32 [B,Lq,M,L,P,2], attention_weights

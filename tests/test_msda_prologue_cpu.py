@@ -69,6 +69,7 @@ def test_module_with_the_fused_prologue_matches_default(backend, oracle):
     from monodetr_amd.monodetr.ops.modules import ms_deform_attn as mod
     saved = F_.MSDA
     F_.MSDA = oracle.OracleMSDA
+    packed_was = mod._PACKED_PROJECTION
     try:
         torch.manual_seed(0)
         m = mod.MSDeformAttn(256, 4, 8, 4)
@@ -81,19 +82,22 @@ def test_module_with_the_fused_prologue_matches_default(backend, oracle):
         query = torch.randn(2, 9, 256)
         refp = torch.rand(2, 9, 6)[:, :, None].expand(-1, -1, 4, -1) * 0.5 + 0.1
         res = {}
-        for flag in (False, True):
-            mod._FUSED_PROLOGUE = flag
+        for flag in (False, True, "packed"):
+            mod._FUSED_PROLOGUE = bool(flag)
+            mod._PACKED_PROJECTION = flag == "packed"          # (the host stand-in has no packed entry point: the module splits the GEMM output)
             m.zero_grad(set_to_none=True)
             out = m(query, refp, src, shapes, start)
             out.square().sum().backward()
             res[flag] = (out.detach(), {n: p.grad.clone() for n, p in m.named_parameters()})
         mod._FUSED_PROLOGUE = False
-        assert (res[False][0] - res[True][0]).abs().max() < 1e-5
-        for n, gr in res[False][1].items():
-            assert (gr - res[True][1][n]).abs().max() <= 1e-4 * max(1.0, gr.abs().max().item()), n
+        for flag in (True, "packed"):
+            assert (res[False][0] - res[flag][0]).abs().max() < 1e-5
+            for n, gr in res[False][1].items():
+                assert (gr - res[flag][1][n]).abs().max() <= 1e-4 * max(1.0, gr.abs().max().item()), (flag, n)
     finally:
         F_.MSDA = saved
         mod._FUSED_PROLOGUE = False
+        mod._PACKED_PROJECTION = packed_was
 
 
 def test_fp32_reference_points_stay_fp32_with_bf16_projections(backend):
@@ -155,3 +159,32 @@ def test_vector_and_scalar_kernels_agree_bit_for_bit(dtype, R):
         assert torch.equal(a, b)
     # grad_ref is a float atomic sum over the M heads of a query: the same terms, in lane order
     assert (out[0][4] - out[1][4]).abs().max().item() <= 1e-5 * max(1.0, out[0][4].abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R", [2, 6])
+def test_packed_projection_output_gives_the_same_prologue(R, dtype):
+    """mdetr_msda_prologue_*_packed reads offsets | logits out of ONE [B, Lq, 384] projection output and writes the two
+    gradients back into one tensor of that layout: bit-identical to the two-tensor form (same kernels, pitched rows)."""
+    from monodetr_amd import msda_prologue_ext as ext
+    ext._backend = backends.get("emul")
+    try:
+        g = torch.Generator().manual_seed(R)
+        B, Lq, M, L, P = 2, 37, 8, 4, 4
+        shapes = torch.tensor([[48, 160], [24, 80], [12, 40], [6, 20]])
+        packed = (torch.randn(B, Lq, M * L * P * 3, generator=g) * 2).to(dtype).requires_grad_(True)
+        ref = (torch.rand(B, Lq, L, R, generator=g) * 0.8 + 0.1).requires_grad_(True)
+        g_loc = torch.randn(B, Lq, M, L, P, 2, generator=g)
+        g_att = torch.randn(B, Lq, M, L, P, generator=g)
+        assert ext.packed_supported(packed, ref, L, P)
+        loc, att = ext.msda_prologue_packed(packed, ref, shapes, M, L, P)
+        gp, gr = torch.autograd.grad([loc, att], [packed, ref], [g_loc, g_att])
+        off = packed[..., :M * L * P * 2].reshape(B, Lq, M, L, P, 2)
+        lg = packed[..., M * L * P * 2:].reshape(B, Lq, M, L * P)
+        loc2, att2 = ext.msda_prologue(off, lg, ref, shapes)
+        gp2, gr2 = torch.autograd.grad([loc2, att2], [packed, ref], [g_loc, g_att])
+        assert torch.equal(loc, loc2) and torch.equal(att, att2)
+        assert torch.equal(gp, gp2)
+        assert (gr - gr2).abs().max() <= 1e-5 * max(1.0, gr2.abs().max().item())            # atomics over the heads: order differs
+    finally:
+        ext._backend = None

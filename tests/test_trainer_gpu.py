@@ -80,7 +80,8 @@ def run_sequence(dev, graph, switches, n_steps=24, poison=False):
     steps = {int(s['step']) for s in sd['state'].values()}
     params = {n: p.detach().float().clone() for n, p in it.raw_model.named_parameters()
               if n in ("class_embed.2.bias", "depthaware_transformer.encoder.layers.0.linear1.weight", "backbone.0.body.layer4.2.conv3.weight",
-                       "depthaware_transformer.decoder.layers.2.cross_attn.sampling_offsets.weight")}
+                       "depthaware_transformer.decoder.layers.2.cross_attn.value_proj.weight")}       # (not the zero-initialised sampling_offsets weights:
+                       # six Adam steps of the noisiest gradient of the model, sign-sensitive)
     lr = {float(g['lr']) for g in sd['param_groups']}
     return losses, modes, steps, params, lr, it
 
