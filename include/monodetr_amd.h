@@ -529,10 +529,11 @@ int mdetr_bias_act_backward(int io_dtype, const void *dy, const void *y, void *d
  * Weight and bias gradient of a linear layer y = x W^T + b over a few thousand token rows (the decoder's B x 550 query rows;
  * reference depthaware_transformer.py:399-456, monodetr.py:222-262): dW[n, k] = sum_t dY[t, n] X[t, k], db[n] = sum_t dY[t, n]
  * in one launch plus one chunk sum (deterministic, fp32 accumulation, one rounding into out_dtype).
- *   dy [rows, n] (row stride ldy), x [rows, k] (row stride ldx): io_dtype MDETR_F32 / MDETR_BF16, 16-byte aligned, strides
- *   multiples of 8 elements; rows <= 8 192; n, k multiples of 64 with n * k <= 131 072
- *   out [n * k + n] in out_dtype: dW row-major, then db.  workspace: mdetr_small_wgrad_workspace_bytes(rows, n, k) bytes
- *   (0 = shape not supported)
+ *   dy [rows, n] (row stride ldy >= n), x [rows, k] (row stride ldx, a multiple of 8 elements, 16-byte aligned): io_dtype
+ *   MDETR_F32 / MDETR_BF16; rows <= 8 192 (65 536 for n <= 64); k a multiple of 64, any n >= 1, n * k <= 524 288.  n a multiple
+ *   of 64 with 16-byte aligned dy rows takes vector loads, anything else guarded scalar loads of dy.
+ *   out [round_up(n * k + n, 4)] in out_dtype: dW row-major, then db (then padding).  workspace:
+ *   mdetr_small_wgrad_workspace_bytes(rows, n, k) bytes (0 = shape not supported)
  */
 int64_t mdetr_small_wgrad_workspace_bytes(int64_t rows, int n, int k);
 int mdetr_small_wgrad(int io_dtype, const void *dy, const void *x, void *out, int out_dtype, void *workspace, int64_t workspace_bytes,

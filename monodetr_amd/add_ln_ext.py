@@ -23,7 +23,7 @@ def _host_seed():
     global _seed_counter
     if _seed_counter is None:
         _seed_counter = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64))
-    _seed_counter = (_seed_counter + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    _seed_counter = (_seed_counter + 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF      # 63 bits: autograd Function arguments must fit int64 (torch.profiler records them)
     return _seed_counter
 
 

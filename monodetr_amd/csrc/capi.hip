@@ -662,15 +662,15 @@ int mdetr_small_wgrad(int io_dtype, const void *dy, const void *x, void *out, in
                       int64_t rows, int n, int k, int64_t ldy, int64_t ldx, int device, void *stream)
 {
     if (!mdetr::small_wgrad_supported(io_dtype, rows, n, k, ldy, ldx) || (out_dtype != MDETR_F32 && out_dtype != MDETR_BF16))
-        return fail(MDETR_E_ARG, "mdetr_small_wgrad: io_dtype %d / out_dtype %d / rows %lld / n %d / k %d / ldy %lld / ldx %lld (f32 or bf16; 1 <= rows <= 8192; "
-                                 "n, k multiples of 64 with n * k <= 131072; strides multiples of 8 elements)", io_dtype, out_dtype,
+        return fail(MDETR_E_ARG, "mdetr_small_wgrad: io_dtype %d / out_dtype %d / rows %lld / n %d / k %d / ldy %lld / ldx %lld (f32 or bf16; 1 <= rows <= 8192, "
+                                 "65536 for n <= 64; k a multiple of 64 with n * k <= 524288; ldx a multiple of 8 elements)", io_dtype, out_dtype,
                     static_cast<long long>(rows), n, k, static_cast<long long>(ldy), static_cast<long long>(ldx));
     if (!dy || !x || !out || !workspace) return fail(MDETR_E_ARG, "mdetr_small_wgrad: null pointer");
     if (workspace_bytes < mdetr::small_wgrad_workspace_bytes(rows, n, k))
         return fail(MDETR_E_ARG, "mdetr_small_wgrad: workspace of %lld bytes, need %lld", static_cast<long long>(workspace_bytes),
                     static_cast<long long>(mdetr::small_wgrad_workspace_bytes(rows, n, k)));
-    if (!aligned16(dy) || !aligned16(x) || !aligned16(out) || !aligned16(workspace))
-        return fail(MDETR_E_ALIGN, "mdetr_small_wgrad: dy, x, out, workspace must be 16-byte aligned");
+    if (!aligned16(x) || !aligned16(out) || !aligned16(workspace))
+        return fail(MDETR_E_ALIGN, "mdetr_small_wgrad: x, out, workspace must be 16-byte aligned");
     DeviceScope dev(device);
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_small_wgrad: set device %d: %s", device, hipGetErrorString(dev.err));
     const hipError_t e = mdetr::small_wgrad_launch(io_dtype, dy, x, out, workspace, rows, n, k, ldy, ldx, out_dtype, static_cast<hipStream_t>(stream));

@@ -1,5 +1,8 @@
 // monodetr_amd/csrc/small_wgrad.hip -- weight and bias gradient of a linear layer over a FEW thousand token rows:
-//   dW[n, k] = sum_t dY[t, n] X[t, k],   db[n] = sum_t dY[t, n],   T <= 8 192, n and k multiples of 64, n k <= 131 072.
+//   dW[n, k] = sum_t dY[t, n] X[t, k],   db[n] = sum_t dY[t, n],   T <= 8 192, k a multiple of 64, n k <= 524 288.
+// Any n: widths that are not multiples of 64 (the prediction heads' last layers: 2, 3, 6, 24 outputs; their packed first
+// layers: 1 032) or dY rows that are not 16-byte aligned take guarded scalar loads of dY -- the library runs those weight
+// gradients as ONE 30-47 us single-tile GEMM each.
 //
 // The decoder's linear layers see B x 550 = 4 400 query rows (reference depthaware_transformer.py:399-456: projections of
 // both attentions, the deformable attention's offset / weight / output layers, the FFN; monodetr.py:222-262: the hidden
@@ -30,7 +33,8 @@ constexpr int kThreads = 256;
 constexpr int kTile = 64;            // output tile edge
 constexpr int kRows = 32;            // token rows staged per step
 constexpr int64_t kMaxRows = 8192;   // above: the library's batched split is faster (profiles/r02p_wgrad_timing.txt)
-constexpr int kMaxTileArea = 512 * 256;  // n * k: the chunk partials are chunks * n * k * 4 bytes
+constexpr int kMaxTileArea = 2048 * 256; // n * k: the chunk partials are chunks * n * k * 4 bytes (chunks shrink as tiles grow: ~19 MB at most)
+constexpr int64_t kMaxRowsNarrow = 65536;   // n <= 64: one tile row, the library has no good kernel at any height
 
 // 8 consecutive elements of a row as loaded (native register vectors: they stay in registers across the LDS pass)
 template <typename T> struct Row8;
@@ -58,8 +62,19 @@ template <> struct Row8<__hip_bfloat16> {
     }
 };
 
-// partial: [chunks][n * k + n] fp32
+__host__ __device__ inline int64_t partial_pitch(int n, int k) { return (static_cast<int64_t>(n) * k + n + 3) / 4 * 4; }
+
+// 8 consecutive dY elements of a row in the guarded form: columns >= n read as zero, no alignment assumed
 template <typename T>
+__device__ __forceinline__ void load_guarded(const T *row, int col0, int n, float (&v)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = col0 + i < n ? static_cast<float>(row[col0 + i]) : 0.f;
+}
+
+// partial: [chunks][partial_pitch(n, k)] fp32: n * k weight-gradient entries, then n bias-gradient entries
+// NGEN: any n / any dY row alignment (guarded scalar loads of dY, guarded stores)
+template <typename T, bool NGEN>
 __global__ __launch_bounds__(kThreads)
 void small_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, float *__restrict__ partial, int64_t rows, int n, int k,
                         int64_t ldy, int64_t ldx, int chunk_rows)
@@ -79,11 +94,22 @@ void small_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, float
     const T *px = x + static_cast<int64_t>(tile_k) * kTile + lv * 8;
     // the next step's rows are requested before the current step is consumed (registers carry them across the LDS pass)
     typename Row8<T>::Raw ry = Row8<T>::zero(), rx = Row8<T>::zero();
-    if (t0 + lr < t1) { ry = Row8<T>::load(py + (t0 + lr) * ldy); rx = Row8<T>::load(px + (t0 + lr) * ldx); }
+    float gy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // NGEN: the prefetched dY elements, already widened
+    const int col0 = tile_n * kTile + lv * 8;
+    if (t0 + lr < t1) {
+        if constexpr (NGEN) load_guarded<T>(dy + (t0 + lr) * ldy, col0, n, gy);
+        else ry = Row8<T>::load(py + (t0 + lr) * ldy);
+        rx = Row8<T>::load(px + (t0 + lr) * ldx);
+    }
     for (int64_t base = t0; base < t1; base += kRows) {
         {
             float vy[8], vx[8];
-            Row8<T>::widen(ry, vy);
+            if constexpr (NGEN) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) vy[i] = gy[i];
+            } else {
+                Row8<T>::widen(ry, vy);
+            }
             Row8<T>::widen(rx, vx);
             *reinterpret_cast<float4 *>(&sy[lr][lv * 8]) = make_float4(vy[0], vy[1], vy[2], vy[3]);
             *reinterpret_cast<float4 *>(&sy[lr][lv * 8 + 4]) = make_float4(vy[4], vy[5], vy[6], vy[7]);
@@ -94,7 +120,15 @@ void small_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, float
         {
             const int64_t r = base + kRows + lr;
             const bool more = r < t1;
-            ry = more ? Row8<T>::load(py + r * ldy) : Row8<T>::zero();
+            if constexpr (NGEN) {
+                if (more) load_guarded<T>(dy + r * ldy, col0, n, gy);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) gy[i] = 0.f;
+                }
+            } else {
+                ry = more ? Row8<T>::load(py + r * ldy) : Row8<T>::zero();
+            }
             rx = more ? Row8<T>::load(px + r * ldx) : Row8<T>::zero();
         }
 #pragma unroll 8
@@ -113,16 +147,28 @@ void small_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, float
         }
         __syncthreads();
     }
-    float *out = partial + static_cast<int64_t>(chunk) * (static_cast<int64_t>(n) * k + n);
+    float *out = partial + static_cast<int64_t>(chunk) * partial_pitch(n, k);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = tile_n * kTile + tn * 4 + i;
-        *reinterpret_cast<float4 *>(out + static_cast<int64_t>(row) * k + tile_k * kTile + tk * 4) =
-            make_float4(acc[i][0].x, acc[i][0].y, acc[i][1].x, acc[i][1].y);
+        if (!NGEN || row < n)
+            *reinterpret_cast<float4 *>(out + static_cast<int64_t>(row) * k + tile_k * kTile + tk * 4) =
+                make_float4(acc[i][0].x, acc[i][0].y, acc[i][1].x, acc[i][1].y);
     }
     if (tile_k == 0 && tk == 0) {                                   // the first k tile's blocks also own the bias gradient
         float *ob = out + static_cast<int64_t>(n) * k + tile_n * kTile + tn * 4;
-        *reinterpret_cast<float4 *>(ob) = make_float4(colsum[0], colsum[1], colsum[2], colsum[3]);
+        if constexpr (NGEN) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (tile_n * kTile + tn * 4 + i < n) ob[i] = colsum[i];
+        } else {
+            *reinterpret_cast<float4 *>(ob) = make_float4(colsum[0], colsum[1], colsum[2], colsum[3]);
+        }
+    }
+    if (NGEN && chunk == 0 && tile_k == 0 && tile_n == 0 && threadIdx.x < 4) {   // the pad of the row (summed along with the rest)
+        const int64_t at = static_cast<int64_t>(n) * k + n + threadIdx.x;
+        if (at < partial_pitch(n, k))
+            for (int c = 0; c < gridDim.z; ++c) partial[static_cast<int64_t>(c) * partial_pitch(n, k) + at] = 0.f;
     }
 }
 
@@ -130,15 +176,15 @@ void small_wgrad_kernel(const T *__restrict__ dy, const T *__restrict__ x, float
 
 bool small_wgrad_supported(int io_dtype, int64_t rows, int n, int k, int64_t ldy, int64_t ldx)
 {
-    return (io_dtype == 0 || io_dtype == 2) && rows > 0 && rows <= kMaxRows && n > 0 && k > 0 && n % kTile == 0 && k % kTile == 0 &&
-           static_cast<int64_t>(n) * k <= kMaxTileArea && ldy >= n && ldx >= k && ldy % 8 == 0 && ldx % 8 == 0;
+    return (io_dtype == 0 || io_dtype == 2) && rows > 0 && (rows <= kMaxRows || (n <= kTile && rows <= kMaxRowsNarrow)) && n > 0 && k > 0 &&
+           k % kTile == 0 && static_cast<int64_t>(n) * k <= kMaxTileArea && ldy >= n && ldx >= k && ldx % 8 == 0;
 }
 
 // chunks along the token axis: ~4 workgroups per CU (a workgroup waits on one global round trip per 32 rows; several per
 // CU keep the FMA pipes fed), at least 64 rows per chunk
 int small_wgrad_chunks(int64_t rows, int n, int k)
 {
-    const int tiles = (n / kTile) * (k / kTile);
+    const int tiles = ((n + kTile - 1) / kTile) * (k / kTile);
     int c = (1152 + tiles - 1) / tiles;
     const int64_t most = (rows + 63) / 64;
     if (c > most) c = static_cast<int>(most);
@@ -149,7 +195,7 @@ int small_wgrad_chunks(int64_t rows, int n, int k)
 int64_t small_wgrad_workspace_bytes(int64_t rows, int n, int k)
 {
     if (!small_wgrad_supported(0, rows, n, k, n, k)) return 0;
-    return static_cast<int64_t>(small_wgrad_chunks(rows, n, k)) * (static_cast<int64_t>(n) * k + n) * 4 + 64;
+    return static_cast<int64_t>(small_wgrad_chunks(rows, n, k)) * partial_pitch(n, k) * 4 + 64;
 }
 
 hipError_t small_wgrad_launch(int io_dtype, const void *dy, const void *x, void *out, void *workspace, int64_t rows, int n, int k,
@@ -159,16 +205,21 @@ hipError_t small_wgrad_launch(int io_dtype, const void *dy, const void *x, void 
     int chunk_rows = static_cast<int>((rows + chunks - 1) / chunks);
     chunk_rows = (chunk_rows + kRows - 1) / kRows * kRows;          // whole staging steps (the last chunk may be short or empty)
     float *partial = static_cast<float *>(workspace);
-    const dim3 grid(static_cast<unsigned>(k / kTile), static_cast<unsigned>(n / kTile), static_cast<unsigned>(chunks));
-    if (io_dtype == 2)
-        hipLaunchKernelGGL(small_wgrad_kernel<__hip_bfloat16>, grid, dim3(kThreads), 0, st, static_cast<const __hip_bfloat16 *>(dy),
-                           static_cast<const __hip_bfloat16 *>(x), partial, rows, n, k, ldy, ldx, chunk_rows);
-    else
-        hipLaunchKernelGGL(small_wgrad_kernel<float>, grid, dim3(kThreads), 0, st, static_cast<const float *>(dy),
-                           static_cast<const float *>(x), partial, rows, n, k, ldy, ldx, chunk_rows);
+    const dim3 grid(static_cast<unsigned>(k / kTile), static_cast<unsigned>((n + kTile - 1) / kTile), static_cast<unsigned>(chunks));
+    // the guarded form: a ragged last tile of n, or dY rows / base that 16-byte loads cannot take
+    const bool ngen = n % kTile != 0 || ldy % 8 != 0 || (reinterpret_cast<uintptr_t>(dy) & 15) != 0;
+    if (io_dtype == 2) {
+        const auto *a = static_cast<const __hip_bfloat16 *>(dy), *b = static_cast<const __hip_bfloat16 *>(x);
+        if (ngen) hipLaunchKernelGGL((small_wgrad_kernel<__hip_bfloat16, true>), grid, dim3(kThreads), 0, st, a, b, partial, rows, n, k, ldy, ldx, chunk_rows);
+        else hipLaunchKernelGGL((small_wgrad_kernel<__hip_bfloat16, false>), grid, dim3(kThreads), 0, st, a, b, partial, rows, n, k, ldy, ldx, chunk_rows);
+    } else {
+        const auto *a = static_cast<const float *>(dy), *b = static_cast<const float *>(x);
+        if (ngen) hipLaunchKernelGGL((small_wgrad_kernel<float, true>), grid, dim3(kThreads), 0, st, a, b, partial, rows, n, k, ldy, ldx, chunk_rows);
+        else hipLaunchKernelGGL((small_wgrad_kernel<float, false>), grid, dim3(kThreads), 0, st, a, b, partial, rows, n, k, ldy, ldx, chunk_rows);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const int cols = n * k + n;
+    const int cols = static_cast<int>(partial_pitch(n, k));          // `out` holds this many elements
     // <= 256 chunk rows: colsum's single-row-block form, one launch, result in out_dtype
     return colsum_launch(0, partial, out, nullptr, chunks, cols, cols, st, out_dtype);
 }

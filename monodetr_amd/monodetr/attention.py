@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..attn_ext import fused_attention
-from .linear import Linear, token_linear
+from .linear import Linear, split_rows, token_linear
 
 
 def _sdpa(q, k, v, num_heads, dropout_p, key_padding_mask):
@@ -75,15 +75,18 @@ class MultiheadAttention(nn.Module):
         W, b = self.in_proj_weight, self.in_proj_bias
         if query is key and key is value:
             return token_linear(query, W, b).split(E, -1)
+        # (row blocks through `split_rows`: one gradient assembly per parameter instead of a zero-fill, a copy and an add per block;
+        #  every product through `token_linear`: the 4 400-row weight gradients take csrc/small_wgrad.hip)
         if query is key:                                     # q = k = x + pos, v = x (encoder layers)
-            q, k = token_linear(query, W[:2 * E], b[:2 * E]).split(E, -1)
-            return q, k, token_linear(value, W[2 * E:], b[2 * E:])
-        q = F.linear(query, W[:E], b[:E])
+            (Wqk, Wv), (bqk, bv) = split_rows(W, 2 * E, E), split_rows(b, 2 * E, E)
+            q, k = token_linear(query, Wqk, bqk).split(E, -1)
+            return q, k, token_linear(value, Wv, bv)
         if key is value:
-            k, v = token_linear(key, W[E:], b[E:]).split(E, -1)
-        else:
-            k, v = F.linear(key, W[E:2 * E], b[E:2 * E]), F.linear(value, W[2 * E:], b[2 * E:])
-        return q, k, v
+            (Wq, Wkv), (bq, bkv) = split_rows(W, E, 2 * E), split_rows(b, E, 2 * E)
+            k, v = token_linear(key, Wkv, bkv).split(E, -1)
+            return token_linear(query, Wq, bq), k, v
+        (Wq, Wk, Wv), (bq, bk, bv) = split_rows(W, E, E, E), split_rows(b, E, E, E)
+        return token_linear(query, Wq, bq), token_linear(key, Wk, bk), token_linear(value, Wv, bv)
 
     def forward_batch_first(self, query, key, value, key_padding_mask=None):
         """[B, L, E] in, [B, Lq, E] out."""

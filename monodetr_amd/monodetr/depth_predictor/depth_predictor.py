@@ -56,6 +56,33 @@ def _bilinear_resize_matmul(x, size):
     return t.view(B, Ho, Wo, C).permute(0, 3, 1, 2)             # NCHW view with channels_last strides
 
 
+class _HatTimesTable(torch.autograd.Function):
+    """hat [..., n] @ table [n, C] whose table gradient hat^T dOut -- n = 61 rows contracted over B H W = 15 360 positions, which the
+    library runs as one single-tile GEMM (129 us) -- takes csrc/small_wgrad.hip (`hat` in the role of dY, dOut in the role of X)."""
+
+    @staticmethod
+    def forward(ctx, hat, table):
+        ctx.save_for_backward(hat, table)
+        return hat @ table
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        from ... import small_wgrad_ext
+        hat, table = ctx.saved_tensors
+        d_hat = dout @ table.t() if ctx.needs_input_grad[0] else None
+        d_table = None
+        if ctx.needs_input_grad[1]:
+            h2, d2 = hat.reshape(-1, hat.shape[-1]), dout.reshape(-1, dout.shape[-1])
+            if not d2.is_contiguous():
+                d2 = d2.contiguous()
+            if small_wgrad_ext.ENABLED and table.dtype in (torch.float32, torch.bfloat16) and small_wgrad_ext.supported(h2, d2):
+                d_table = small_wgrad_ext.small_wgrad(h2, d2, table.dtype)[0]
+            else:
+                d_table = (h2.t() @ d2).to(table.dtype)
+        return d_hat, d_table
+
+
 class DepthPredictor(nn.Module):
     def __init__(self, model_cfg):
         super().__init__()
@@ -114,4 +141,7 @@ class DepthPredictor(nn.Module):
         coord = coord.clamp(max=n - 1)
         grid = torch.arange(n, device=coord.device, dtype=coord.dtype)
         hat = (1 - (coord.unsqueeze(-1) - grid).abs()).clamp(min=0)               # [..., n]
-        return hat.to(embed.weight.dtype) @ embed.weight
+        hat = hat.to(embed.weight.dtype)
+        if hat.is_cuda and torch.is_grad_enabled() and embed.weight.requires_grad:
+            return _HatTimesTable.apply(hat, embed.weight)
+        return hat @ embed.weight

@@ -96,7 +96,7 @@ class _TokenLinear(torch.autograd.Function):
             if dx is None:
                 dx = (dy2 @ weight).view_as(x)
         T = x2.shape[0]
-        if small_wgrad_ext.ENABLED and ctx.needs_input_grad[1] and T <= small_wgrad_ext.MAX_ROWS \
+        if small_wgrad_ext.ENABLED and ctx.needs_input_grad[1] and (T <= small_wgrad_ext.MAX_ROWS or dy2.shape[1] <= 64) \
                 and weight.dtype in (torch.float32, torch.bfloat16) and small_wgrad_ext.supported(dy2, x2):
             # a few thousand rows (the decoder's 4 400): dW and db from one launch + one chunk sum (csrc/small_wgrad.hip)
             dw, db = small_wgrad_ext.small_wgrad(dy2, x2, weight.dtype)
@@ -121,6 +121,33 @@ class _TokenLinear(torch.autograd.Function):
             else:
                 db = (dy2.view(C, T // C, -1).sum(1).sum(0) if C else dy2.sum(0)).to(weight.dtype)
         return dx, dw, db, None, None
+
+
+class _SplitRows(torch.autograd.Function):
+    """Row blocks of a packed parameter (nn.MultiheadAttention's in_proj_weight / in_proj_bias: q | k | v) as views, with ONE
+    gradient assembly: the framework's slice backward builds a zero tensor of the whole parameter per block, copies the block's
+    gradient in and adds the results (3 fills + 3 copies + 2 adds per parameter and step); here the blocks' gradients are
+    concatenated once."""
+
+    @staticmethod
+    def forward(ctx, packed, *sizes):
+        ctx.sizes = sizes
+        ctx.meta = (packed.shape[1:], packed.dtype, packed.device)
+        return tuple(p.view_as(p) for p in packed.split(list(sizes), 0))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        tail, dtype, device = ctx.meta
+        parts = [g if g is not None else torch.zeros((n,) + tuple(tail), dtype=dtype, device=device) for g, n in zip(grads, ctx.sizes)]
+        return (torch.cat(parts, 0),) + (None,) * len(ctx.sizes)
+
+
+def split_rows(packed, *sizes):
+    """`packed.split(sizes, 0)` whose backward is a single concatenation (see `_SplitRows`)."""
+    if not (torch.is_grad_enabled() and packed.requires_grad):
+        return packed.split(list(sizes), 0)
+    return _SplitRows.apply(packed, *sizes)
 
 
 def _kernel_relu(x, weight, bias=None):

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--top", type=int, default=150)
     ap.add_argument("--out", default="")
     ap.add_argument("--match", default="", help="comma-separated substrings of operator names to keep (default: all)")
+    ap.add_argument("--stacks", default="", help="comma-separated operator names whose launches are also grouped by the repo's Python frames")
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--batch", type=int, default=8)
     a = ap.parse_args()
@@ -29,7 +30,8 @@ def main():
         step()
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    want_stacks = [m for m in a.stacks.split(",") if m]
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=bool(want_stacks)) as prof:
         step()
         torch.cuda.synchronize()
     keep = [m for m in a.match.split(",") if m]
@@ -46,6 +48,24 @@ def main():
     for dt, n, key, shp in rows[:a.top]:
         lines.append("%9.1f %6d  %-46s %s" % (dt, n, key[:46], shp))
     lines.append("total self device time of the listed groups: %.1f us, %d launches-or-more" % (sum(r[0] for r in rows), sum(r[1] for r in rows)))
+    if want_stacks:
+        import collections
+        groups = collections.defaultdict(lambda: [0, 0.0])
+        for e in prof.events():
+            if e.name not in want_stacks:
+                continue
+            dt = sum(k.duration for k in e.kernels) if getattr(e, "kernels", None) else 0.0
+            if dt <= 0:
+                continue
+            frames = [f for f in (e.stack or []) if "monodetr_amd" in f or "bench.py" in f][:3]
+            where = " <- ".join(f.split("monodetr_amd/")[-1] for f in frames) or "(autograd engine: no Python frame)"
+            key = (e.name, str(e.input_shapes)[:70], where)
+            groups[key][0] += 1
+            groups[key][1] += dt
+        lines.append("")
+        lines.append("%9s %6s  operator / shapes / innermost frames of this repo" % ("us", "calls"))
+        for (name, shp, where), (n, dt) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
+            lines.append("%9.1f %6d  %s %s  %s" % (dt, n, name, shp, where))
     text = "\n".join(lines)
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)

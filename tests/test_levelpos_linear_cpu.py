@@ -78,3 +78,29 @@ def test_fused_first_layers_equal_the_separate_heads():
     # a single-layer MLP: its first layer is its output
     one = MLP(16, 16, 4, 1)
     assert (mlp_rest(one, fused_first_layers(x, [one])[0]) - one(x)).abs().max() < 1e-5
+
+
+def test_split_rows_gradient_is_the_concatenation_and_mha_matches_torch():
+    """linear.split_rows == Tensor.split with one gradient assembly (absent block -> zeros); attention.MultiheadAttention through it
+    reproduces nn.MultiheadAttention's outputs and packed-parameter gradients in its three projection forms."""
+    from monodetr_amd.monodetr.attention import MultiheadAttention
+    from monodetr_amd.monodetr.linear import split_rows
+    torch.manual_seed(3)
+    w = torch.randn(12, 5, requires_grad=True)
+    a, b, c = split_rows(w, 4, 4, 4)
+    (a.sum() * 2 + c.square().sum()).backward()                                   # b unused
+    want = torch.cat((torch.full((4, 5), 2.0), torch.zeros(4, 5), 2 * w.detach()[8:]))
+    assert torch.equal(w.grad, want)
+
+    mine, ref = MultiheadAttention(64, 2), torch.nn.MultiheadAttention(64, 2, batch_first=True)
+    ref.load_state_dict(mine.state_dict())
+    x, y, z = (torch.randn(2, 7, 64) for _ in range(3))
+    for q, k, v in ((x, x, x), (x, x, y), (x, y, y), (x, y, z)):
+        mine.zero_grad(set_to_none=True); ref.zero_grad(set_to_none=True)
+        o1 = mine.forward_batch_first(q, k, v)
+        o2 = ref(q, k, v, need_weights=False)[0]
+        assert (o1 - o2).abs().max() < 1e-5
+        o1.square().sum().backward(); o2.square().sum().backward()
+        for n, p in mine.named_parameters():
+            g2 = dict(ref.named_parameters())[n].grad
+            assert (p.grad - g2).abs().max() <= 1e-4 * max(1.0, g2.abs().max().item()), n
