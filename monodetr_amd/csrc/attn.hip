@@ -105,7 +105,13 @@ __device__ __forceinline__ unsigned drop_qterm(uint64_t seed, int b, int h, int 
     return (static_cast<unsigned>(q) * 0x9E3779B1u) ^ static_cast<unsigned>(seed) ^
            (static_cast<unsigned>(seed >> 32) + static_cast<unsigned>(b * 131 + h) * 0xC2B2AE3Du);
 }
-__device__ __forceinline__ unsigned drop_kterm(int k) { return (static_cast<unsigned>(k) + 0x7F4A7C15u) * 0x85EBCA77u; }
+constexpr unsigned kDropQMul = 0x9E3779B1u, kDropKMul = 0x85EBCA77u;
+__device__ __forceinline__ unsigned drop_kterm(int k) { return (static_cast<unsigned>(k) + 0x7F4A7C15u) * kDropKMul; }
+// the part of drop_qterm that does not depend on the query: qterm(q) = q * kDropQMul ^ drop_qconst(seed, b, h)
+__device__ __forceinline__ unsigned drop_qconst(uint64_t seed, int b, int h)
+{
+    return static_cast<unsigned>(seed) ^ (static_cast<unsigned>(seed >> 32) + static_cast<unsigned>(b * 131 + h) * 0xC2B2AE3Du);
+}
 __device__ __forceinline__ bool keep_elem(unsigned qterm, unsigned kterm, unsigned thresh)
 {
     unsigned x = qterm ^ kterm;
@@ -287,7 +293,10 @@ __device__ __forceinline__ void own_row_frags(const T *rowp, bool valid, float m
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// DROP: dropout on the probabilities, a compile-time property of the kernel -- as a run-time flag it put a scalar branch
+// around every element's hash (16 per sub-tile), which kept the exponentials, the hash and the conversions of
+// neighbouring elements from being scheduled together.  The 1 / (1 - p) rescale is applied once to the output.
+template <typename T, bool DROP>
 __global__ __launch_bounds__(256)
 void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ lse2)
 {
@@ -305,11 +314,10 @@ void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ 
     Frag qf[2];
     own_row_frags<T, SP>(Q + static_cast<int64_t>(q) * a.q_rs, qv, a.scale * kLog2e, lane, qf);
 
-    const bool drop = a.dropout_p > 0.f;
     const uint64_t seed_eff = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
     const unsigned qterm = drop_qterm(seed_eff, b, h, q);        // this lane's query: constant over the key loop
-    const unsigned thresh = drop ? static_cast<unsigned>(a.dropout_p * 4294967296.0) : 0u;
-    const float rinv = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
+    const unsigned thresh = DROP ? static_cast<unsigned>(a.dropout_p * 4294967296.0) : 0u;
+    const float rinv = DROP ? 1.f / (1.f - a.dropout_p) : 1.f;
 
     float m = -__builtin_inff(), l = 0.f;
     f32x16 acc = zero16();
@@ -348,18 +356,22 @@ void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ 
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float msafe = mx == -__builtin_inff() ? 0.f : mx;
             const float alpha = fast_exp2(m - msafe);               // m = -inf -> 0
-            float psum = 0.f;
+            const f32x2 ms2 = make_f32x2(msafe, msafe);
+            f32x2 psum2 = make_f32x2(0.f, 0.f);
+            // kterm(key) is linear in the key: this lane's 16 keys are kbase + (a compile-time multiple of the multiplier)
+            const unsigned kbase = DROP ? drop_kterm(k0 + sub * 32 + 4 * half) : 0u;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = fast_exp2(p[r] - msafe);
-                psum += e;
-                p[r] = e;
-                if (drop) {
-                    const int key = k0 + sub * 32 + acc_row(r, half);
-                    p[r] = keep_elem(qterm, drop_kterm(key), thresh) ? e * rinv : 0.f;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 d = sub2(make_f32x2(p[r], p[r + 1]), ms2);      // packed subtract: two elements per instruction
+                f32x2 e = make_f32x2(fast_exp2(d.x), fast_exp2(d.y));
+                psum2 = add2(psum2, e);
+                if (DROP) {
+                    e.x = keep_elem(qterm, kbase + static_cast<unsigned>(acc_row(r, 0)) * kDropKMul, thresh) ? e.x : 0.f;
+                    e.y = keep_elem(qterm, kbase + static_cast<unsigned>(acc_row(r + 1, 0)) * kDropKMul, thresh) ? e.y : 0.f;
                 }
+                p[r] = e.x; p[r + 1] = e.y;
             }
-            l = l * alpha + psum;
+            l = l * alpha + (psum2.x + psum2.y);
             if (__any(mx != m)) {                                    // wave-uniform: the running maximum moved for some query
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] *= alpha;
@@ -371,7 +383,7 @@ void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ 
     }
     l += __shfl_xor(l, 32);
     if (qv) {
-        const float inv = l > 0.f ? 1.f / l : 0.f;               // fully masked row -> zeros
+        const float inv = l > 0.f ? rinv / l : 0.f;              // fully masked row -> zeros; dropout's 1 / (1 - p) once per row
         T *o = out + (static_cast<int64_t>(b) * a.Lq + q) * (a.H * kD) + h * kD + 4 * half;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -410,7 +422,7 @@ void attn_bwd_prep_kernel(const T *__restrict__ o, const T *__restrict__ d_o, fl
 // ------------------------------------------------------------------------------------------------
 // backward: dQ  (lane = query, loop over key tiles)
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool DROP>
 __global__ __launch_bounds__(256)
 void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float *__restrict__ lse2,
                         const float *__restrict__ dsum, T *__restrict__ dq)
@@ -432,13 +444,15 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
     own_row_frags<T, SP>(Q + static_cast<int64_t>(q) * a.q_rs, qv, a.scale * kLog2e, lane, qf);
     own_row_frags<T, SP>(d_o + orow, qv, 1.f, lane, dof);
     const int64_t stat = (static_cast<int64_t>(b) * a.H + h) * a.Lq + q;
-    const float L2 = qv ? lse2[stat] : 0.f, Dq = qv ? dsum[stat] : 0.f;
+    // a fully masked row has lse = -inf: read as +inf, exp2(s - inf) = 0 is its (zero) probability without a select per element
+    float L2 = qv ? lse2[stat] : 0.f;
+    if (L2 == -__builtin_inff()) L2 = __builtin_inff();
+    const float Dq = qv ? dsum[stat] : 0.f;
 
-    const bool drop = a.dropout_p > 0.f;
     const uint64_t seed_eff = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
     const unsigned qterm = drop_qterm(seed_eff, b, h, q);        // this lane's query: constant over the key loop
-    const unsigned thresh = drop ? static_cast<unsigned>(a.dropout_p * 4294967296.0) : 0u;
-    const float rinv = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
+    const unsigned thresh = DROP ? static_cast<unsigned>(a.dropout_p * 4294967296.0) : 0u;
+    const float rinv = DROP ? 1.f / (1.f - a.dropout_p) : 1.f;
     f32x16 acc = zero16();
 
     Raw8<T> rk = tile_load<T>(K, a.k_rs, 0, a.Lk), rv = tile_load<T>(V, a.v_rs, 0, a.Lk);
@@ -461,19 +475,29 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
             dp = mfmaX<SP>(frag_rows<SP>(Vs, sub, 1, lane), dof[1], dp);
             float ds[16];
             const bool plain = !a.kpm && k0 + sub * 32 + 32 <= a.Lk;   // block-uniform: whole sub-tile valid, no mask
-            const bool row_ok = L2 != -__builtin_inff();
+            const unsigned kbase = DROP ? drop_kterm(k0 + sub * 32 + 4 * half) : 0u;
+            const f32x2 l22 = make_f32x2(L2, L2);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + sub * 32 + acc_row(r, half);
-                bool ok = row_ok;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 d = sub2(make_f32x2(s[r], s[r + 1]), l22);
+                f32x2 p = make_f32x2(fast_exp2(d.x), fast_exp2(d.y));
                 if (!plain) {
-                    ok = ok && key < a.Lk;
-                    if (a.kpm) ok = ok && (a.kpm[static_cast<int64_t>(b) * a.Lk + (key < a.Lk ? key : 0)] == 0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int key = k0 + sub * 32 + acc_row(r + i, half);
+                        bool ok = key < a.Lk;
+                        if (a.kpm) ok = ok && (a.kpm[static_cast<int64_t>(b) * a.Lk + (ok ? key : 0)] == 0);
+                        if (i == 0) p.x = ok ? p.x : 0.f; else p.y = ok ? p.y : 0.f;
+                    }
                 }
-                const float p = ok ? fast_exp2(s[r] - L2) : 0.f;
-                float g = dp[r];
-                if (drop) g = keep_elem(qterm, drop_kterm(key), thresh) ? g * rinv : 0.f;
-                ds[r] = p * (g - Dq);
+                f32x2 g = make_f32x2(dp[r], dp[r + 1]);
+                if (DROP) {
+                    g.x = keep_elem(qterm, kbase + static_cast<unsigned>(acc_row(r, 0)) * kDropKMul, thresh) ? g.x : 0.f;
+                    g.y = keep_elem(qterm, kbase + static_cast<unsigned>(acc_row(r + 1, 0)) * kDropKMul, thresh) ? g.y : 0.f;
+                }
+                const f32x2 t = fma2(g, make_f32x2(rinv, rinv), make_f32x2(-Dq, -Dq));     // kept dP / (1 - p) - D
+                const f32x2 dsv = mul2(p, t);
+                ds[r] = dsv.x; ds[r + 1] = dsv.y;
             }
             acc = mfmaX<SP>(frag_cols<SP>(Kt, sub, 0, lane), frag_acc<SP>(ds, 0), acc);   // dQ^T[d][query]
             acc = mfmaX<SP>(frag_cols<SP>(Kt, sub, 1, lane), frag_acc<SP>(ds, 1), acc);
@@ -490,7 +514,7 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
 // ------------------------------------------------------------------------------------------------
 // backward: dK, dV  (lane = key, loop over query tiles)
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool DROP>
 __global__ __launch_bounds__(256)
 void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const float *__restrict__ lse2,
                          const float *__restrict__ dsum, T *__restrict__ dk, T *__restrict__ dv)
@@ -519,16 +543,20 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
     bool key_ok = kv;
     if (a.kpm && kv) key_ok = a.kpm[static_cast<int64_t>(b) * a.Lk + key] == 0;
 
-    const bool drop = a.dropout_p > 0.f;
     const uint64_t seed_eff = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
-    const unsigned kterm = drop_kterm(key);                      // this lane's key: constant over the query loop
-    const unsigned thresh = drop ? static_cast<unsigned>(a.dropout_p * 4294967296.0) : 0u;
-    const float rinv = drop ? 1.f / (1.f - a.dropout_p) : 1.f;
+    // this lane's key and the (b, h, seed) part of the query term: constant over the query loop
+    const unsigned kq = drop_kterm(key) ^ drop_qconst(seed_eff, b, h);
+    const unsigned thresh = DROP ? static_cast<unsigned>(a.dropout_p * 4294967296.0) : 0u;
+    const float rinv = DROP ? 1.f / (1.f - a.dropout_p) : 1.f;
     f32x16 acck = zero16(), accv = zero16();
 
     Raw8<T> rq = tile_load<T>(Q, a.q_rs, 0, a.Lq), ro = tile_load<T>(dO, a.H * kD, 0, a.Lq);
-    float rl = -__builtin_inff(), rd = 0.f;
-    if (threadIdx.x < kTile && threadIdx.x < a.Lq) { rl = L2b[threadIdx.x]; rd = Db[threadIdx.x]; }
+    // rows past Lq and fully masked rows (lse = -inf) carry lse = +inf: exp2(s - inf) = 0 without a select per element
+    float rl = __builtin_inff(), rd = 0.f;
+    if (threadIdx.x < kTile && threadIdx.x < a.Lq) {
+        rl = L2b[threadIdx.x]; rd = Db[threadIdx.x];
+        if (rl == -__builtin_inff()) rl = __builtin_inff();
+    }
     for (int q0 = 0; q0 < a.Lq; q0 += kTile) {
         __syncthreads();
         tile_store<T, true, true, SP>(rq, Qs, Qt);
@@ -540,7 +568,8 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
             ro = tile_load<T>(dO, a.H * kD, q0 + kTile, a.Lq);
             if (threadIdx.x < kTile) {
                 const int qq = q0 + kTile + threadIdx.x;
-                rl = qq < a.Lq ? L2b[qq] : -__builtin_inff();
+                rl = qq < a.Lq ? L2b[qq] : __builtin_inff();
+                if (rl == -__builtin_inff()) rl = __builtin_inff();
                 rd = qq < a.Lq ? Db[qq] : 0.f;
             }
         }
@@ -553,20 +582,26 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
             dp = mfmaX<SP>(frag_rows<SP>(Os, sub, 0, lane), vf[0], dp);   // dP[query][key] = dO V^T
             dp = mfmaX<SP>(frag_rows<SP>(Os, sub, 1, lane), vf[1], dp);
             float pd[16], ds[16];
+            // q * kDropQMul is linear in the query: this lane's 16 queries are qbase + (a compile-time multiple of the multiplier)
+            const unsigned qbase = DROP ? static_cast<unsigned>(q0 + sub * 32 + 4 * half) * kDropQMul : 0u;
+            const f32x2 ri2 = make_f32x2(rinv, rinv);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qi = sub * 32 + acc_row(r, half), qq = q0 + qi;
-                const float L2 = Ls[qi];
-                const bool ok = key_ok && L2 != -__builtin_inff();
-                const float p = ok ? fast_exp2(s[r] - L2) : 0.f;
-                float g = dp[r], pk = p;
-                if (drop) {
-                    const bool kp = keep_elem(drop_qterm(seed_eff, b, h, qq), kterm, thresh);
-                    g = kp ? g * rinv : 0.f;
-                    pk = kp ? p * rinv : 0.f;
+            for (int r = 0; r < 16; r += 2) {
+                const int qi = sub * 32 + acc_row(r, half);                      // (r even: qi + 1 is the row of register r + 1)
+                const f32x2 d = sub2(make_f32x2(s[r], s[r + 1]), make_f32x2(Ls[qi], Ls[qi + 1]));
+                f32x2 p = make_f32x2(fast_exp2(d.x), fast_exp2(d.y));
+                if (!key_ok) p = make_f32x2(0.f, 0.f);                           // a padded / masked key (its lane's whole column)
+                f32x2 g = make_f32x2(dp[r], dp[r + 1]), pk = p;
+                if (DROP) {
+                    const bool k0p = keep_elem(qbase + static_cast<unsigned>(acc_row(r, 0)) * kDropQMul, kq, thresh);
+                    const bool k1p = keep_elem(qbase + static_cast<unsigned>(acc_row(r + 1, 0)) * kDropQMul, kq, thresh);
+                    g.x = k0p ? g.x : 0.f; pk.x = k0p ? pk.x : 0.f;
+                    g.y = k1p ? g.y : 0.f; pk.y = k1p ? pk.y : 0.f;
                 }
-                pd[r] = pk;
-                ds[r] = p * (g - Ds[qi]);
+                pd[r] = pk.x; pd[r + 1] = pk.y;                                  // (1 / (1 - p) is applied to dV once, at the end)
+                const f32x2 t = sub2(mul2(g, ri2), make_f32x2(Ds[qi], Ds[qi + 1]));
+                const f32x2 dsv = mul2(p, t);
+                ds[r] = dsv.x; ds[r + 1] = dsv.y;
             }
             accv = mfmaX<SP>(frag_cols<SP>(Ot, sub, 0, lane), frag_acc<SP>(pd, 0), accv);   // dV^T[d][key] = dO^T P
             accv = mfmaX<SP>(frag_cols<SP>(Ot, sub, 1, lane), frag_acc<SP>(pd, 1), accv);
@@ -579,7 +614,7 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             store4<T>(dk + row + 8 * g, acck[4 * g] * a.scale, acck[4 * g + 1] * a.scale, acck[4 * g + 2] * a.scale, acck[4 * g + 3] * a.scale);
-            store4<T>(dv + row + 8 * g, accv[4 * g], accv[4 * g + 1], accv[4 * g + 2], accv[4 * g + 3]);
+            store4<T>(dv + row + 8 * g, accv[4 * g] * rinv, accv[4 * g + 1] * rinv, accv[4 * g + 2] * rinv, accv[4 * g + 3] * rinv);
         }
     }
 }
@@ -603,8 +638,14 @@ hipError_t attn_forward_launch(const AttnProblem &p, void *out, float *lse2, hip
     const AttnArgs a = make_args(p);
     const dim3 grid((p.Lq + 127) / 128, p.H, p.B), block(256);
     profile_begin(4, p.Lq * 4096 + (p.Lk < 4096 ? p.Lk : 4095), st);
-    if (p.dtype == 0) hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, block, 0, st, a, static_cast<float *>(out), lse2);
-    else hipLaunchKernelGGL(attn_fwd_kernel<__bf16>, grid, block, 0, st, a, static_cast<__bf16 *>(out), lse2);
+    const bool drop = p.dropout_p > 0.f;
+    if (p.dtype == 0) {
+        if (drop) hipLaunchKernelGGL((attn_fwd_kernel<float, true>), grid, block, 0, st, a, static_cast<float *>(out), lse2);
+        else hipLaunchKernelGGL((attn_fwd_kernel<float, false>), grid, block, 0, st, a, static_cast<float *>(out), lse2);
+    } else {
+        if (drop) hipLaunchKernelGGL((attn_fwd_kernel<__bf16, true>), grid, block, 0, st, a, static_cast<__bf16 *>(out), lse2);
+        else hipLaunchKernelGGL((attn_fwd_kernel<__bf16, false>), grid, block, 0, st, a, static_cast<__bf16 *>(out), lse2);
+    }
     profile_end(st);
     return hipGetLastError();
 }
@@ -616,20 +657,25 @@ hipError_t attn_backward_launch(const AttnProblem &p, const void *out, const voi
     const AttnArgs a = make_args(p);
     const int64_t items = static_cast<int64_t>(p.B) * p.Lq * p.H;
     const dim3 gq((p.Lq + 127) / 128, p.H, p.B), gk((p.Lk + 127) / 128, p.H, p.B), block(256);
+    const bool drop = p.dropout_p > 0.f;
     struct Scope { hipStream_t s; Scope(int key, hipStream_t s_) : s(s_) { profile_begin(5, key, s_); } ~Scope() { profile_end(s); } }
         scope(p.Lq * 4096 + (p.Lk < 4096 ? p.Lk : 4095), st);
     if (p.dtype == 0) {
         if (items) hipLaunchKernelGGL(attn_bwd_prep_kernel<float>, dim3(static_cast<unsigned>((items * 8 + 255) / 256)), block, 0, st,
                                       static_cast<const float *>(out), static_cast<const float *>(d_out), dsum, p.B, p.H, p.Lq);
-        if (p.Lq) hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, gq, block, 0, st, a, static_cast<const float *>(d_out), lse2, dsum, static_cast<float *>(dq));
-        if (p.Lk) hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, gk, block, 0, st, a, static_cast<const float *>(d_out), lse2, dsum,
-                                     static_cast<float *>(dk), static_cast<float *>(dv));
+        const float *go = static_cast<const float *>(d_out);
+        if (p.Lq && drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<float, true>), gq, block, 0, st, a, go, lse2, dsum, static_cast<float *>(dq));
+        if (p.Lq && !drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<float, false>), gq, block, 0, st, a, go, lse2, dsum, static_cast<float *>(dq));
+        if (p.Lk && drop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<float, true>), gk, block, 0, st, a, go, lse2, dsum, static_cast<float *>(dk), static_cast<float *>(dv));
+        if (p.Lk && !drop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<float, false>), gk, block, 0, st, a, go, lse2, dsum, static_cast<float *>(dk), static_cast<float *>(dv));
     } else {
         if (items) hipLaunchKernelGGL(attn_bwd_prep_kernel<__bf16>, dim3(static_cast<unsigned>((items * 8 + 255) / 256)), block, 0, st,
                                       static_cast<const __bf16 *>(out), static_cast<const __bf16 *>(d_out), dsum, p.B, p.H, p.Lq);
-        if (p.Lq) hipLaunchKernelGGL(attn_bwd_dq_kernel<__bf16>, gq, block, 0, st, a, static_cast<const __bf16 *>(d_out), lse2, dsum, static_cast<__bf16 *>(dq));
-        if (p.Lk) hipLaunchKernelGGL(attn_bwd_dkv_kernel<__bf16>, gk, block, 0, st, a, static_cast<const __bf16 *>(d_out), lse2, dsum,
-                                     static_cast<__bf16 *>(dk), static_cast<__bf16 *>(dv));
+        const __bf16 *go = static_cast<const __bf16 *>(d_out);
+        if (p.Lq && drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<__bf16, true>), gq, block, 0, st, a, go, lse2, dsum, static_cast<__bf16 *>(dq));
+        if (p.Lq && !drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<__bf16, false>), gq, block, 0, st, a, go, lse2, dsum, static_cast<__bf16 *>(dq));
+        if (p.Lk && drop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<__bf16, true>), gk, block, 0, st, a, go, lse2, dsum, static_cast<__bf16 *>(dk), static_cast<__bf16 *>(dv));
+        if (p.Lk && !drop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<__bf16, false>), gk, block, 0, st, a, go, lse2, dsum, static_cast<__bf16 *>(dk), static_cast<__bf16 *>(dv));
     }
     return hipGetLastError();
 }

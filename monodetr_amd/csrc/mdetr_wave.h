@@ -25,6 +25,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 __device__ __forceinline__ f32x2 make_f32x2(float x, float y) { f32x2 r; r.x = x; r.y = y; return r; }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 mul2(f32x2 a, f32x2 b) { return a * b; }
+__device__ __forceinline__ f32x2 add2(f32x2 a, f32x2 b) { return a + b; }
+__device__ __forceinline__ f32x2 sub2(f32x2 a, f32x2 b) { return a - b; }
 
 // c + a.lo * b.lo + a.hi * b.hi on two PACKED bf16 pairs (the 32-bit words as they sit in memory), fp32 accumulate:
 // v_dot2c_f32_bf16 -- a dot product over bf16 data without widening either operand first

@@ -147,13 +147,14 @@ class VisualEncoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, src):
-        h = ffn_hidden(src, self.linear1, self.dropout2, self.activation)       # ReLU (+ Dropout) fused behind the GEMM where possible
+        # (skip=True: the GEMM's input comes back as the tensor the residual continues from -- its two gradients meet inside
+        #  the input-gradient GEMM, linear.token_linear_skip)
+        h, src = ffn_hidden(src, self.linear1, self.dropout2, self.activation, skip=True)   # ReLU (+ Dropout) fused behind the GEMM where possible
         ff = token_linear(h, self.linear2.weight, self.linear2.bias)
         return residual_layernorm(src, ff, self.norm2, self.dropout3)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
-        attn = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
-                              level_start_index, padding_mask)
+        attn, src = self.self_attn.forward_self(src, pos, reference_points, spatial_shapes, level_start_index, padding_mask)
         return self.forward_ffn(residual_layernorm(src, attn, self.norm1, self.dropout1))
 
 

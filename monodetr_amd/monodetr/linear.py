@@ -21,6 +21,14 @@ _MIN_TOKENS = 4096
 # LDS-resident-weight kernel (csrc/token_gemm.hip).  Off until its first GPU validation
 # (tests/test_fused_gpu.py); the library GEMM is the default.
 _TOKEN_GEMM = os.environ.get("MDETR_TOKEN_GEMM") == "1"
+# ... except for NARROW outputs of very tall inputs (layer1's 256 -> 64 and 64 -> 64 convolutions over 245 760 pixels), where the
+# library picks a 64 x 64 macro-tile and runs at a quarter of the HBM rate (83 us vs 34 us, profiles/r02*): those take the kernel
+# unless MDETR_TOKEN_GEMM_NARROW=0
+_TOKEN_GEMM_NARROW = os.environ.get("MDETR_TOKEN_GEMM_NARROW", "1") != "0"
+
+
+def _wants_token_gemm(x2, weight):
+    return _TOKEN_GEMM or (_TOKEN_GEMM_NARROW and x2.is_cuda and weight.shape[0] <= 64 and x2.shape[0] >= 65536)
 # MDETR_GEMM_RELU=1: "linear -> ReLU" as one library GEMM with the RELU_BIAS epilogue (torch._addmm_activation ->
 # hipBLASLt) instead of a GEMM and an elementwise pass.  Off until timed on a GPU.
 _GEMM_RELU = os.environ.get("MDETR_GEMM_RELU") == "1"
@@ -34,6 +42,78 @@ def _split_count(T):
             best = c
             break
     return best
+
+
+def _weight_bias_grads(x2, dy2, weight, need_w, need_b):
+    """(dW, db) of y = x W^T + b from the [T, K] input and the [T, N] output gradient (either may be None when not needed)."""
+    dw = db = None
+    T = x2.shape[0]
+    if small_wgrad_ext.ENABLED and need_w and (T <= small_wgrad_ext.MAX_ROWS or dy2.shape[1] <= 64) \
+            and weight.dtype in (torch.float32, torch.bfloat16) and small_wgrad_ext.supported(dy2, x2):
+        # a few thousand rows (the decoder's 4 400): dW and db from one launch + one chunk sum (csrc/small_wgrad.hip)
+        dw, db = small_wgrad_ext.small_wgrad(dy2, x2, weight.dtype)
+        return dw, (db if need_b else None)
+    # the batched split rounds every chunk's partial product to the activation dtype: worth it from ~8 000 rows on (43 vs
+    # 110 us at 15 360), not for the decoder's 4 400 (29 + 12 vs 34 us, and 16 bf16 roundings instead of one)
+    C = _split_count(T) if T > small_wgrad_ext.MAX_ROWS else 0
+    if need_w:
+        if C:
+            parts = torch.bmm(dy2.view(C, T // C, -1).transpose(1, 2), x2.view(C, T // C, -1))    # [C, N, K]
+            flat = parts.view(C, -1)
+            if colsum_ext.supported(flat) and weight.dtype in (torch.float32, torch.bfloat16):
+                # sum over the C chunks in one streaming pass (csrc/colsum.hip), written in the parameter's dtype
+                dw = colsum_ext.column_sum(flat, weight.dtype).view(parts.shape[1], parts.shape[2])
+            else:
+                dw = parts.sum(0).to(weight.dtype)
+        else:
+            dw = (dy2.t() @ x2).to(weight.dtype)
+    if need_b:
+        if dy2.is_cuda and colsum_ext.supported(dy2) and weight.dtype in (torch.float32, torch.bfloat16):
+            db = colsum_ext.column_sum(dy2, weight.dtype)       # csrc/colsum.hip: one HBM pass, fp32 accumulation, one rounding
+        else:
+            db = (dy2.view(C, T // C, -1).sum(1).sum(0) if C else dy2.sum(0)).to(weight.dtype)
+    return dw, db
+
+
+class _TokenLinearSkip(torch.autograd.Function):
+    """(y, x') = ((x + pos) W^T + b, x): the linear layer of a residual branch together with the tensor the residual connection
+    continues from.  x has ONE consumer in the graph, so the gradient arriving through x' (the residual path) and the layer's own
+    input gradient dY W need no separate sum: backward issues the input-gradient GEMM with beta = 1 into the arriving gradient.
+    The encoder's 81 600-row layers read such a sum as three 42 MB tensors per residual site (reference
+    depthaware_transformer.py:318-345: `src` feeds with_pos_embed, value_proj and the residual; the FFN input feeds linear1 and
+    the residual).  `pos` is a constant here (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pos):
+        q = x if pos is None else x + pos
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(q, weight)
+        return F.linear(q, weight, bias), x.view_as(x)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy, dskip):
+        q, weight = ctx.saved_tensors
+        q2, dy2 = q.reshape(-1, q.shape[-1]), dy.reshape(-1, dy.shape[-1])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if dskip is None:
+                dx = (dy2 @ weight).view_as(q)
+            elif dskip.is_contiguous() and dskip.dtype == dy2.dtype:
+                dx = dskip.view(-1, q.shape[-1]).addmm_(dy2, weight).view_as(q)      # (the arriving gradient is this node's alone)
+            else:
+                dx = dskip + (dy2 @ weight).view_as(q)
+        dw, db = _weight_bias_grads(q2, dy2, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        return dx, dw, db, None
+
+
+def token_linear_skip(x, weight, bias=None, pos=None):
+    """-> (token_linear(x + pos, weight, bias), x'): use x' (== x) for everything that follows on the residual path; see
+    `_TokenLinearSkip`.  Plain tensors out of it when the fused form does not apply."""
+    if x.is_cuda and x.dtype == weight.dtype and x.numel() // x.shape[-1] >= _MIN_TOKENS and torch.is_grad_enabled() and x.requires_grad \
+            and not torch.is_autocast_enabled() and (pos is None or not pos.requires_grad) and not _TOKEN_GEMM:
+        return _TokenLinearSkip.apply(x, weight, bias, pos)
+    return token_linear(x if pos is None else x + pos, weight, bias), x
 
 
 class _TokenLinear(torch.autograd.Function):
@@ -53,7 +133,7 @@ class _TokenLinear(torch.autograd.Function):
                 y += bias.float()
             ctx.save_for_backward(x, weight)
             return y.view(x.shape[:-1] + (weight.shape[0],))
-        if _TOKEN_GEMM:
+        if _wants_token_gemm(x.reshape(-1, x.shape[-1]), weight):
             from .. import token_gemm_ext
             x2 = x.reshape(-1, x.shape[-1])
             if token_gemm_ext.supported(x2, weight):
@@ -95,31 +175,7 @@ class _TokenLinear(torch.autograd.Function):
                     dx = token_gemm_ext.token_gemm(dy2, wt).view_as(x)
             if dx is None:
                 dx = (dy2 @ weight).view_as(x)
-        T = x2.shape[0]
-        if small_wgrad_ext.ENABLED and ctx.needs_input_grad[1] and (T <= small_wgrad_ext.MAX_ROWS or dy2.shape[1] <= 64) \
-                and weight.dtype in (torch.float32, torch.bfloat16) and small_wgrad_ext.supported(dy2, x2):
-            # a few thousand rows (the decoder's 4 400): dW and db from one launch + one chunk sum (csrc/small_wgrad.hip)
-            dw, db = small_wgrad_ext.small_wgrad(dy2, x2, weight.dtype)
-            return dx, dw, (db if ctx.has_bias and ctx.needs_input_grad[2] else None), None, None
-        # the batched split rounds every chunk's partial product to the activation dtype: worth it from ~8 000 rows on (43 vs
-        # 110 us at 15 360), not for the decoder's 4 400 (29 + 12 vs 34 us, and 16 bf16 roundings instead of one)
-        C = _split_count(T) if T > small_wgrad_ext.MAX_ROWS else 0
-        if ctx.needs_input_grad[1]:
-            if C:
-                parts = torch.bmm(dy2.view(C, T // C, -1).transpose(1, 2), x2.view(C, T // C, -1))    # [C, N, K]
-                flat = parts.view(C, -1)
-                if colsum_ext.supported(flat) and weight.dtype in (torch.float32, torch.bfloat16):
-                    # sum over the C chunks in one streaming pass (csrc/colsum.hip), written in the parameter's dtype
-                    dw = colsum_ext.column_sum(flat, weight.dtype).view(parts.shape[1], parts.shape[2])
-                else:
-                    dw = parts.sum(0).to(weight.dtype)
-            else:
-                dw = (dy2.t() @ x2).to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            if dy2.is_cuda and colsum_ext.supported(dy2) and weight.dtype in (torch.float32, torch.bfloat16):
-                db = colsum_ext.column_sum(dy2, weight.dtype)       # csrc/colsum.hip: one HBM pass, fp32 accumulation, one rounding
-            else:
-                db = (dy2.view(C, T // C, -1).sum(1).sum(0) if C else dy2.sum(0)).to(weight.dtype)
+        dw, db = _weight_bias_grads(x2, dy2, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         return dx, dw, db, None, None
 
 
@@ -152,7 +208,7 @@ def split_rows(packed, *sizes):
 
 def _kernel_relu(x, weight, bias=None):
     """Can the ReLU ride in the GEMM's epilogue?  (the token-GEMM kernel, or the library's RELU_BIAS epilogue)"""
-    if _TOKEN_GEMM:
+    if _wants_token_gemm(x.reshape(-1, x.shape[-1]), weight):
         from .. import token_gemm_ext
         if token_gemm_ext.supported(x.reshape(-1, x.shape[-1]), weight):
             return True
@@ -201,13 +257,21 @@ def pointwise_relu_fusable(x, weight, bias):
             and _kernel_relu(x.permute(0, 2, 3, 1).reshape(-1, C), weight.reshape(weight.shape[0], C), bias))
 
 
-def ffn_hidden(x, lin, dropout, activation=F.relu, tokenwise=True):
+def ffn_hidden(x, lin, dropout, activation=F.relu, tokenwise=True, skip=False):
     """``dropout(activation(lin(x)))`` -- the first half of an FFN (depthaware_transformer.py:334-337, :431-435;
     depth_predictor/transformer.py:57-65).  ``tokenwise``: the GEMM through `token_linear` (the encoder's 81 600 token
     rows) instead of the module call.  With MDETR_FUSED_EPILOGUE=1 ReLU and Dropout are one pass behind the GEMM
     (csrc/bias_act.hip); otherwise the ReLU rides in the GEMM's epilogue when one of the GEMM switches allows it."""
     from .. import bias_act_ext
     p = dropout.p if (dropout is not None and dropout.training) else 0.0
+    if skip:
+        # -> (hidden, x'): x' == x, to be used by the residual connection that follows (`token_linear_skip`); the ReLU then
+        # rides with the Dropout pass (or is its own pass) instead of the GEMM's epilogue
+        h, x_out = token_linear_skip(x, lin.weight, lin.bias)
+        if activation is F.relu and bias_act_ext.ENABLED and p > 0.0 and torch.is_grad_enabled() and bias_act_ext.supported(h):
+            return bias_act_ext.bias_act(h, None, None, relu=True, dropout_p=p), x_out
+        h = activation(h)
+        return (dropout(h) if dropout is not None else h), x_out
     first = (lambda relu: token_linear(x, lin.weight, lin.bias, relu=relu)) if tokenwise else \
         (lambda relu: F.relu(lin(x)) if relu else lin(x))
     if activation is not F.relu:

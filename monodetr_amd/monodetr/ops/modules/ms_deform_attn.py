@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..functions import MSDeformAttnFunction
-from ...linear import Linear, token_linear
+from ...linear import Linear, token_linear, token_linear_skip
 from .... import msda_prologue_ext
 
 
@@ -110,19 +110,27 @@ class MSDeformAttn(nn.Module):
         if reference_points.shape[-1] not in (2, 6):
             raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead.".format(
                 reference_points.shape[-1]))
-        packed = None
+        packed = offsets = logits = None
         if _FUSED_PROLOGUE and _PACKED_PROJECTION and not torch.is_autocast_enabled():
-            # the two projections of the query as ONE GEMM (384 = 256 offset + 128 logit columns): one read of the query forward,
-            # one input-gradient GEMM and one weight-gradient GEMM backward, and no sum of two query gradients
-            w = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
-            b = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
-            packed = token_linear(query, w, b)
-            if not msda_prologue_ext.packed_supported(packed, reference_points, L, P):
-                offsets, logits = packed[..., :M * L * P * 2].reshape(N, Lq, M, L, P, 2), packed[..., M * L * P * 2:].reshape(N, Lq, M, L * P)
-                packed = None
+            packed = token_linear(query, *self._packed_projection())
         else:
             offsets = token_linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias).view(N, Lq, M, L, P, 2)
             logits = token_linear(query, self.attention_weights.weight, self.attention_weights.bias).view(N, Lq, M, L * P)
+        return self._attend(value, packed, offsets, logits, reference_points, input_spatial_shapes, input_level_start_index, query.dtype)
+
+    def _packed_projection(self):
+        """The two projections of the query as ONE GEMM (384 = 256 offset + 128 logit columns): one read of the query forward,
+        one input-gradient GEMM and one weight-gradient GEMM backward, and no sum of two query gradients."""
+        return (torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0),
+                torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0))
+
+    def _attend(self, value, packed, offsets, logits, reference_points, input_spatial_shapes, input_level_start_index, out_dtype):
+        N, S = value.shape[:2]
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        Lq = (packed if packed is not None else offsets).shape[1]
+        if packed is not None and not msda_prologue_ext.packed_supported(packed, reference_points, L, P):
+            offsets, logits = packed[..., :M * L * P * 2].reshape(N, Lq, M, L, P, 2), packed[..., M * L * P * 2:].reshape(N, Lq, M, L * P)
+            packed = None
         if packed is not None:
             locations, weights = msda_prologue_ext.msda_prologue_packed(packed, reference_points, input_spatial_shapes, M, L, P)
         elif _FUSED_PROLOGUE and msda_prologue_ext.supported(offsets, logits, reference_points):
@@ -140,9 +148,29 @@ class MSDeformAttn(nn.Module):
 
         out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
                                          locations, weights, self.im2col_step)
-        if out.dtype != query.dtype and query.dtype == torch.bfloat16:
-            out = out.to(query.dtype)                                  # (the fp32 operator of the wide form)
+        if out.dtype != out_dtype and out_dtype == torch.bfloat16:
+            out = out.to(out_dtype)                                    # (the fp32 operator of the wide form)
         return token_linear(out, self.output_proj.weight, self.output_proj.bias)
+
+    def forward_self(self, src, pos, reference_points, input_spatial_shapes, input_level_start_index, input_padding_mask=None):
+        """``forward(src + pos, reference_points, src, ...)`` -- self-attention over the pyramid, the encoder's call (reference
+        depthaware_transformer.py:339-341) -- together with the tensor the residual connection continues from:
+        -> (output, src').  `src` feeds the value projection, the query (after + pos) and the residual; with the packed
+        projection both GEMMs take `linear.token_linear_skip`, whose backward adds its input gradient into the gradient
+        arriving over the residual path inside the GEMM (two 126 MB elementwise sums per layer otherwise)."""
+        if not (_FUSED_PROLOGUE and _PACKED_PROJECTION and src.is_cuda and not torch.is_autocast_enabled()
+                and reference_points.shape[-1] in (2, 6)):
+            return self.forward(src if pos is None else src + pos, reference_points, src, input_spatial_shapes,
+                                input_level_start_index, input_padding_mask), src
+        N, S, _ = src.shape
+        _check_token_count(input_spatial_shapes, S)
+        value, src1 = token_linear_skip(src, self.value_proj.weight, self.value_proj.bias)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], 0.0)
+        packed, src2 = token_linear_skip(src1, *self._packed_projection(), pos=pos)
+        out = self._attend(value.view(N, S, self.n_heads, -1), packed, None, None, reference_points, input_spatial_shapes,
+                           input_level_start_index, src.dtype)
+        return out, src2
 
 
 class MSDeformAttn_cross(MSDeformAttn):

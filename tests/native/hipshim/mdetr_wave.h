@@ -59,6 +59,8 @@ struct alignas(16) u32x4 { unsigned x, y, z, w; };
 inline f32x2 make_f32x2(float x, float y) { return {x, y}; }
 inline f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
 inline f32x2 mul2(f32x2 a, f32x2 b) { return {a.x * b.x, a.y * b.y}; }
+inline f32x2 add2(f32x2 a, f32x2 b) { return {a.x + b.x, a.y + b.y}; }
+inline f32x2 sub2(f32x2 a, f32x2 b) { return {a.x - b.x, a.y - b.y}; }
 
 // v_dot2c_f32_bf16 (products of bf16 values are exact in fp32; the order of the two additions is the emulation's choice)
 inline float dot2_bf16(unsigned a, unsigned b, float c)

@@ -104,3 +104,34 @@ def test_split_rows_gradient_is_the_concatenation_and_mha_matches_torch():
         for n, p in mine.named_parameters():
             g2 = dict(ref.named_parameters())[n].grad
             assert (p.grad - g2).abs().max() <= 1e-4 * max(1.0, g2.abs().max().item()), n
+
+
+def test_token_linear_skip_chain_matches_plain_autograd():
+    """linear._TokenLinearSkip: (y, x') = ((x + pos) W^T + b, x); the gradient arriving over x' and the layer's own input gradient
+    are summed inside the input-gradient product.  A chain of two (the encoder layer's value / query projections) followed by a
+    residual use reproduces plain autograd's gradients for x, both weights and both biases."""
+    from monodetr_amd.monodetr.linear import _TokenLinearSkip
+    torch.manual_seed(5)
+    x = torch.randn(2, 9, 16, requires_grad=True)
+    pos = torch.randn(2, 9, 16)
+    w1, b1 = torch.randn(16, 16, requires_grad=True), torch.randn(16, requires_grad=True)
+    w2, b2 = torch.randn(24, 16, requires_grad=True), torch.randn(24, requires_grad=True)
+
+    def plain():
+        v = torch.nn.functional.linear(x, w1, b1)
+        p = torch.nn.functional.linear(x + pos, w2, b2)
+        return (v.sin().sum() + p.cos().sum() + (x * x).sum())
+
+    def chained():
+        v, x1 = _TokenLinearSkip.apply(x, w1, b1, None)
+        p, x2 = _TokenLinearSkip.apply(x1, w2, b2, pos)
+        return (v.sin().sum() + p.cos().sum() + (x2 * x2).sum())
+
+    want = torch.autograd.grad(plain(), [x, w1, b1, w2, b2])
+    got = torch.autograd.grad(chained(), [x, w1, b1, w2, b2])
+    for a, b in zip(want, got):
+        assert (a - b).abs().max() <= 1e-5 * max(1.0, a.abs().max().item())
+    # the residual branch unused: the skip output receives no gradient
+    v, x1 = _TokenLinearSkip.apply(x, w1, b1, None)
+    g = torch.autograd.grad(v.sum(), [x, w1])
+    assert torch.allclose(g[0], w1.sum(0).expand_as(x), atol=1e-5)
