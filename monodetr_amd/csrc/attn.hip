@@ -90,35 +90,34 @@ __device__ __forceinline__ f32x16 zero16()
 // row index (contraction / output row) of accumulator register r for this lane half
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-// Keep-probability test for dropout: a stateless hash of the element coordinates, split so that each
-// kernel hoists the part that is constant for a lane (its query in forward / dQ, its key in dK/dV)
-// and pays ONE 32-bit multiply per element: x = qterm ^ kterm; x ^= x >> 15; x *= C; keep = x >= thresh
-// (the comparison reads the high bits, which the multiply mixes from all lower ones).  Measured on
-// 33 M elements: drop rate 0.1000, neighbour correlations along q, k, head and batch < 3e-4 (noise
-// level), per-row / per-column counts binomial.  The previous two-multiply finaliser plus per-element
-// coordinate multiplies cost one third of the forward kernel's time at p = 0.1.
-// Caveat: the seed enters by XOR only, so two seeds that differ in just their lowest bits give correlated
-// masks (-0.11 for seed, seed + 1); callers must step seeds by a constant that flips many bits --
-// attn_ext._next_seed uses the 64-bit golden ratio (tests/test_dropout_hash_cpu.py).
-__device__ __forceinline__ unsigned drop_qterm(uint64_t seed, int b, int h, int q)
-{
-    return (static_cast<unsigned>(q) * 0x9E3779B1u) ^ static_cast<unsigned>(seed) ^
-           (static_cast<unsigned>(seed >> 32) + static_cast<unsigned>(b * 131 + h) * 0xC2B2AE3Du);
-}
+// Keep-probability test for dropout: stateless, a function of the element's coordinates, so that forward and both backward
+// kernels regenerate the same mask.  An element costs ONE full-rate multiply: keep(q, k) = mul_u24(Qs, Ks) >= thresh, where
+//   Qs = strong32(q * kDropQMul ^ f(seed, b, h)) | 1      per query  (its lane's constant in forward / dQ; a 64-entry LDS
+//   Ks = strong32((k + c) * kDropKMul)                    per key     table per staged tile in the kernel that loops over it)
+// are 32-bit finalised hashes (the murmur3 mixer: two 32-bit multiplies, paid once per row, not per element) and mul_u24 is the
+// low 32 bits of the product of their low 24 bits -- multiplication by an odd number permutes the residues, so the product is
+// uniform; it is non-linear in both terms, so no additive / xor relation ties the four elements of a (q, q', k, k') rectangle
+// together (xor of the two hashes alone would: three dropped corners made the fourth 8 x likelier).  Measured on 17 M elements
+// (tests/test_dropout_hash_cpu.py): drop rate 0.1000, correlations at 90 lags along q, k, head, image and the diagonals below
+// 3.6 sigma of the noise level, binomial row / column / tile counts.
+// Before (rounds 1-2) every element paid xor, shift, xor and a QUARTER-rate 32-bit multiply: 40 of the forward kernel's ~100
+// VALU cycles per element at p = 0.1; the compare + select that remain are 8, the multiply 4.
+// The seed enters Qs before the finaliser: masks of seeds that differ in one bit are independent (the one-multiply hash of
+// rounds 1-2 gave -0.11 for seed, seed + 1; callers still step seeds by the 64-bit golden ratio, attn_ext._next_seed).
 constexpr unsigned kDropQMul = 0x9E3779B1u, kDropKMul = 0x85EBCA77u;
-__device__ __forceinline__ unsigned drop_kterm(int k) { return (static_cast<unsigned>(k) + 0x7F4A7C15u) * kDropKMul; }
-// the part of drop_qterm that does not depend on the query: qterm(q) = q * kDropQMul ^ drop_qconst(seed, b, h)
+__device__ __forceinline__ unsigned strong32(unsigned v)
+{
+    v ^= v >> 16; v *= 0x85EBCA6Bu; v ^= v >> 13; v *= 0xC2B2AE35u; v ^= v >> 16;
+    return v;
+}
+// the part of the query term that does not depend on the query
 __device__ __forceinline__ unsigned drop_qconst(uint64_t seed, int b, int h)
 {
     return static_cast<unsigned>(seed) ^ (static_cast<unsigned>(seed >> 32) + static_cast<unsigned>(b * 131 + h) * 0xC2B2AE3Du);
 }
-__device__ __forceinline__ bool keep_elem(unsigned qterm, unsigned kterm, unsigned thresh)
-{
-    unsigned x = qterm ^ kterm;
-    x ^= x >> 15;
-    x *= 0x2C1B3C6Du;
-    return x >= thresh;
-}
+__device__ __forceinline__ unsigned drop_qs(unsigned qconst, int q) { return strong32((static_cast<unsigned>(q) * kDropQMul) ^ qconst) | 1u; }
+__device__ __forceinline__ unsigned drop_ks(int k) { return strong32((static_cast<unsigned>(k) + 0x7F4A7C15u) * kDropKMul); }
+__device__ __forceinline__ bool keep_elem(unsigned qs, unsigned ks, unsigned thresh) { return __umul24(qs, ks) >= thresh; }
 
 template <typename T> __device__ __forceinline__ void load8(const T *p, float (&o)[8]);
 template <> __device__ __forceinline__ void load8<float>(const float *p, float (&o)[8])
@@ -303,6 +302,7 @@ void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ 
     constexpr bool SP = sizeof(T) == 4;                  // fp32 I/O: hi/lo split operands
     __shared__ __attribute__((aligned(16))) __bf16 Ks[(SP ? 2 : 1) * kRmSize];
     __shared__ __attribute__((aligned(16))) __bf16 Vt[(SP ? 2 : 1) * kTrSize];
+    __shared__ __attribute__((aligned(16))) unsigned kh[kTile];           // dropout: the staged keys' hashed terms
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
@@ -315,7 +315,7 @@ void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ 
     own_row_frags<T, SP>(Q + static_cast<int64_t>(q) * a.q_rs, qv, a.scale * kLog2e, lane, qf);
 
     const uint64_t seed_eff = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
-    const unsigned qterm = drop_qterm(seed_eff, b, h, q);        // this lane's query: constant over the key loop
+    const unsigned qs = drop_qs(drop_qconst(seed_eff, b, h), q);   // this lane's query: constant over the key loop
     const unsigned thresh = DROP ? static_cast<unsigned>(a.dropout_p * 4294967296.0) : 0u;
     const float rinv = DROP ? 1.f / (1.f - a.dropout_p) : 1.f;
 
@@ -327,6 +327,7 @@ void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ 
         __syncthreads();                                         // everyone is done reading the previous tile
         tile_store<T, true, false, SP>(rk, Ks, nullptr);
         tile_store<T, false, true, SP>(rv, nullptr, Vt);
+        if (DROP && threadIdx.x < kTile) kh[threadIdx.x] = drop_ks(k0 + threadIdx.x);
         __syncthreads();
         if (k0 + kTile < a.Lk) {                                 // next tile's loads fly during this tile's math
             rk = tile_load<T>(K, a.k_rs, k0 + kTile, a.Lk);
@@ -358,16 +359,15 @@ void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ 
             const float alpha = fast_exp2(m - msafe);               // m = -inf -> 0
             const f32x2 ms2 = make_f32x2(msafe, msafe);
             f32x2 psum2 = make_f32x2(0.f, 0.f);
-            // kterm(key) is linear in the key: this lane's 16 keys are kbase + (a compile-time multiple of the multiplier)
-            const unsigned kbase = DROP ? drop_kterm(k0 + sub * 32 + 4 * half) : 0u;
+            const unsigned *khs = kh + sub * 32 + 4 * half;          // this lane's keys: rows acc_row(r, 0) from here (16-byte reads)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const f32x2 d = sub2(make_f32x2(p[r], p[r + 1]), ms2);      // packed subtract: two elements per instruction
                 f32x2 e = make_f32x2(fast_exp2(d.x), fast_exp2(d.y));
                 psum2 = add2(psum2, e);
                 if (DROP) {
-                    e.x = keep_elem(qterm, kbase + static_cast<unsigned>(acc_row(r, 0)) * kDropKMul, thresh) ? e.x : 0.f;
-                    e.y = keep_elem(qterm, kbase + static_cast<unsigned>(acc_row(r + 1, 0)) * kDropKMul, thresh) ? e.y : 0.f;
+                    e.x = keep_elem(qs, khs[acc_row(r, 0)], thresh) ? e.x : 0.f;
+                    e.y = keep_elem(qs, khs[acc_row(r + 1, 0)], thresh) ? e.y : 0.f;
                 }
                 p[r] = e.x; p[r + 1] = e.y;
             }
@@ -431,6 +431,7 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
     __shared__ __attribute__((aligned(16))) __bf16 Ks[(SP ? 2 : 1) * kRmSize];
     __shared__ __attribute__((aligned(16))) __bf16 Vs[(SP ? 2 : 1) * kRmSize];
     __shared__ __attribute__((aligned(16))) __bf16 Kt[(SP ? 2 : 1) * kTrSize];
+    __shared__ __attribute__((aligned(16))) unsigned kh[kTile];           // dropout: the staged keys' hashed terms
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
@@ -450,7 +451,7 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
     const float Dq = qv ? dsum[stat] : 0.f;
 
     const uint64_t seed_eff = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
-    const unsigned qterm = drop_qterm(seed_eff, b, h, q);        // this lane's query: constant over the key loop
+    const unsigned qs = drop_qs(drop_qconst(seed_eff, b, h), q);   // this lane's query: constant over the key loop
     const unsigned thresh = DROP ? static_cast<unsigned>(a.dropout_p * 4294967296.0) : 0u;
     const float rinv = DROP ? 1.f / (1.f - a.dropout_p) : 1.f;
     f32x16 acc = zero16();
@@ -460,6 +461,7 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
         __syncthreads();
         tile_store<T, true, true, SP>(rk, Ks, Kt);
         tile_store<T, true, false, SP>(rv, Vs, nullptr);
+        if (DROP && threadIdx.x < kTile) kh[threadIdx.x] = drop_ks(k0 + threadIdx.x);
         __syncthreads();
         if (k0 + kTile < a.Lk) {
             rk = tile_load<T>(K, a.k_rs, k0 + kTile, a.Lk);
@@ -475,7 +477,7 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
             dp = mfmaX<SP>(frag_rows<SP>(Vs, sub, 1, lane), dof[1], dp);
             float ds[16];
             const bool plain = !a.kpm && k0 + sub * 32 + 32 <= a.Lk;   // block-uniform: whole sub-tile valid, no mask
-            const unsigned kbase = DROP ? drop_kterm(k0 + sub * 32 + 4 * half) : 0u;
+            const unsigned *khs = kh + sub * 32 + 4 * half;
             const f32x2 l22 = make_f32x2(L2, L2);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
@@ -492,8 +494,8 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
                 }
                 f32x2 g = make_f32x2(dp[r], dp[r + 1]);
                 if (DROP) {
-                    g.x = keep_elem(qterm, kbase + static_cast<unsigned>(acc_row(r, 0)) * kDropKMul, thresh) ? g.x : 0.f;
-                    g.y = keep_elem(qterm, kbase + static_cast<unsigned>(acc_row(r + 1, 0)) * kDropKMul, thresh) ? g.y : 0.f;
+                    g.x = keep_elem(qs, khs[acc_row(r, 0)], thresh) ? g.x : 0.f;
+                    g.y = keep_elem(qs, khs[acc_row(r + 1, 0)], thresh) ? g.y : 0.f;
                 }
                 const f32x2 t = fma2(g, make_f32x2(rinv, rinv), make_f32x2(-Dq, -Dq));     // kept dP / (1 - p) - D
                 const f32x2 dsv = mul2(p, t);
@@ -526,6 +528,7 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
     __shared__ __attribute__((aligned(16))) __bf16 Ot[(SP ? 2 : 1) * kTrSize];
     __shared__ __attribute__((aligned(16))) float Ls[kTile];
     __shared__ __attribute__((aligned(16))) float Ds[kTile];
+    __shared__ __attribute__((aligned(16))) unsigned qh[kTile];           // dropout: the staged queries' hashed terms
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int key = blockIdx.x * 128 + wave * 32 + (lane & 31);
@@ -544,8 +547,8 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
     if (a.kpm && kv) key_ok = a.kpm[static_cast<int64_t>(b) * a.Lk + key] == 0;
 
     const uint64_t seed_eff = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
-    // this lane's key and the (b, h, seed) part of the query term: constant over the query loop
-    const unsigned kq = drop_kterm(key) ^ drop_qconst(seed_eff, b, h);
+    const unsigned ks = drop_ks(key);                             // this lane's key: constant over the query loop
+    const unsigned qconst = drop_qconst(seed_eff, b, h);
     const unsigned thresh = DROP ? static_cast<unsigned>(a.dropout_p * 4294967296.0) : 0u;
     const float rinv = DROP ? 1.f / (1.f - a.dropout_p) : 1.f;
     f32x16 acck = zero16(), accv = zero16();
@@ -561,7 +564,10 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
         __syncthreads();
         tile_store<T, true, true, SP>(rq, Qs, Qt);
         tile_store<T, true, true, SP>(ro, Os, Ot);
-        if (threadIdx.x < kTile) { Ls[threadIdx.x] = rl; Ds[threadIdx.x] = rd; }
+        if (threadIdx.x < kTile) {
+            Ls[threadIdx.x] = rl; Ds[threadIdx.x] = rd;
+            if (DROP) qh[threadIdx.x] = drop_qs(qconst, q0 + threadIdx.x);
+        }
         __syncthreads();
         if (q0 + kTile < a.Lq) {
             rq = tile_load<T>(Q, a.q_rs, q0 + kTile, a.Lq);
@@ -582,8 +588,6 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
             dp = mfmaX<SP>(frag_rows<SP>(Os, sub, 0, lane), vf[0], dp);   // dP[query][key] = dO V^T
             dp = mfmaX<SP>(frag_rows<SP>(Os, sub, 1, lane), vf[1], dp);
             float pd[16], ds[16];
-            // q * kDropQMul is linear in the query: this lane's 16 queries are qbase + (a compile-time multiple of the multiplier)
-            const unsigned qbase = DROP ? static_cast<unsigned>(q0 + sub * 32 + 4 * half) * kDropQMul : 0u;
             const f32x2 ri2 = make_f32x2(rinv, rinv);
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
@@ -593,8 +597,7 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
                 if (!key_ok) p = make_f32x2(0.f, 0.f);                           // a padded / masked key (its lane's whole column)
                 f32x2 g = make_f32x2(dp[r], dp[r + 1]), pk = p;
                 if (DROP) {
-                    const bool k0p = keep_elem(qbase + static_cast<unsigned>(acc_row(r, 0)) * kDropQMul, kq, thresh);
-                    const bool k1p = keep_elem(qbase + static_cast<unsigned>(acc_row(r + 1, 0)) * kDropQMul, kq, thresh);
+                    const bool k0p = keep_elem(qh[qi], ks, thresh), k1p = keep_elem(qh[qi + 1], ks, thresh);
                     g.x = k0p ? g.x : 0.f; pk.x = k0p ? pk.x : 0.f;
                     g.y = k1p ? g.y : 0.f; pk.y = k1p ? pk.y : 0.f;
                 }

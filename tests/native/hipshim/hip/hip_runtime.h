@@ -74,6 +74,7 @@ int live_lanes();                             // threads of this wave that exist
 }  // namespace hipshim
 
 inline void __syncthreads() { hipshim::sync_block(); }
+inline unsigned __umul24(unsigned a, unsigned b) { return static_cast<unsigned>(static_cast<unsigned long long>(a & 0xFFFFFFu) * (b & 0xFFFFFFu)); }   // v_mul_u32_u24
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 

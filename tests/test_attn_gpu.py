@@ -25,17 +25,22 @@ def reference(q, k, v, H, kpm=None, keep=None, p=0.0):
 
 
 def keep_mask(seed, B, H, Lq, Lk, p):
-    """The kernels' stateless dropout hash (attn.hip keep_elem), restated with int64 arithmetic."""
+    """The kernels' stateless dropout decision (attn.hip keep_elem: the low 32 bits of the product of the low 24 bits of two
+    finalised hashes, one of the query, one of the key), restated with int64 arithmetic."""
     M = 0xFFFFFFFF
+
+    def strong32(v):
+        v = v ^ (v >> 16); v = (v * 0x85EBCA6B) & M; v = v ^ (v >> 13); v = (v * 0xC2B2AE35) & M
+        return v ^ (v >> 16)
+
     b = torch.arange(B).view(B, 1, 1, 1)
     h = torch.arange(H).view(1, H, 1, 1)
     q = torch.arange(Lq).view(1, 1, Lq, 1)
     k = torch.arange(Lk).view(1, 1, 1, Lk)
-    qterm = ((q * 0x9E3779B1) & M) ^ (seed & M) ^ ((((seed >> 32) & M) + ((b * 131 + h) * 0xC2B2AE3D & M)) & M)
-    kterm = (((k + 0x7F4A7C15) & M) * 0x85EBCA77) & M
-    x = qterm ^ kterm
-    x = x ^ (x >> 15)
-    x = (x * 0x2C1B3C6D) & M
+    qconst = (seed & M) ^ ((((seed >> 32) & M) + ((b * 131 + h) * 0xC2B2AE3D & M)) & M)
+    qs = strong32(((q * 0x9E3779B1) & M) ^ qconst) | 1
+    ks = strong32((((k + 0x7F4A7C15) & M) * 0x85EBCA77) & M)
+    x = ((qs & 0xFFFFFF) * (ks & 0xFFFFFF)) & M
     return x >= int(p * 4294967296.0)
 
 
