@@ -526,6 +526,16 @@ int mdetr_bias_act_backward(int io_dtype, const void *dy, const void *y, void *d
                             int device, void *stream);
 
 /*
+ * Every second pixel of a channels-last activation, and the adjoint: a 1x1 convolution of stride 2 (the projection shortcut
+ * of a ResNet stage's first block, torchvision Bottleneck.downsample behind lib/models/monodetr/backbone.py:93-106) is a token
+ * GEMM over x[:, ::2, ::2].
+ *   backward = 0: src = x [B, H, W, C] -> dst = y [B, (H + 1) / 2, (W + 1) / 2, C]
+ *   backward = 1: src = dy [B, (H + 1) / 2, (W + 1) / 2, C] -> dst = dx [B, H, W, C], zero at the skipped pixels
+ * pixel_bytes = C * element size (any element type), a multiple of 16; pointers 16-byte aligned.
+ */
+int mdetr_decimate2(int backward, const void *src, void *dst, int B, int H, int W, int64_t pixel_bytes, int device, void *stream);
+
+/*
  * Weight and bias gradient of a linear layer y = x W^T + b over a few thousand token rows (the decoder's B x 550 query rows;
  * reference depthaware_transformer.py:399-456, monodetr.py:222-262): dW[n, k] = sum_t dY[t, n] X[t, k], db[n] = sum_t dY[t, n]
  * in one launch plus one chunk sum (deterministic, fp32 accumulation, one rounding into out_dtype).

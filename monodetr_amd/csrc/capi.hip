@@ -18,6 +18,7 @@
 #include "colsum.h"
 #include "group_norm.h"
 #include "small_wgrad.h"
+#include "decimate.h"
 #include "conv3x3.h"
 #include "conv_stem.h"
 #include "conv_taps.h"
@@ -653,6 +654,22 @@ int mdetr_bias_act_backward(int io_dtype, const void *dy, const void *y, void *d
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_bias_act_backward: set device %d: %s", device, hipGetErrorString(dev.err));
     const hipError_t e = mdetr::bias_act_backward_launch(io_dtype, dy, y, dx, rows, cols, scale, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_bias_act_backward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_decimate2(int backward, const void *src, void *dst, int B, int H, int W, int64_t pixel_bytes, int device, void *stream)
+{
+    const char *name = backward ? "mdetr_decimate2 (backward)" : "mdetr_decimate2";
+    if (B < 0 || H < 0 || W < 0) return fail(MDETR_E_ARG, "%s: negative extent (B=%d H=%d W=%d)", name, B, H, W);
+    if (B == 0 || H == 0 || W == 0) return MDETR_OK;
+    if (!src || !dst) return fail(MDETR_E_ARG, "%s: null pointer", name);
+    if (!mdetr::decimate2_supported(pixel_bytes, src, dst))
+        return fail(MDETR_E_ALIGN, "%s: %lld bytes per pixel / pointers: both need 16-byte granularity", name, static_cast<long long>(pixel_bytes));
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "%s: set device %d: %s", name, device, hipGetErrorString(dev.err));
+    const hipError_t e = backward ? mdetr::decimate2_backward_launch(src, dst, B, H, W, pixel_bytes, static_cast<hipStream_t>(stream))
+                                  : mdetr::decimate2_forward_launch(src, dst, B, H, W, pixel_bytes, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "%s: launch failed: %s", name, hipGetErrorString(e));
     return MDETR_OK;
 }
 

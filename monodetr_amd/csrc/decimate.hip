@@ -1,0 +1,93 @@
+// monodetr_amd/csrc/decimate.hip -- every second pixel of a channels-last activation, and the adjoint.
+//
+// The projection shortcut of a ResNet stage's first block is a 1x1 convolution of stride 2 (torchvision Bottleneck.downsample
+// behind lib/models/monodetr/backbone.py:93-106; layer2 / 3 / 4: 256 -> 512, 512 -> 1024, 1024 -> 2048 channels).  A 1x1
+// convolution reads only the pixels it keeps, so it IS a token GEMM over the decimated image:
+//     y = W x[:, ::2, ::2]          dx[:, ::2, ::2] = W^T dy (zero elsewhere)          dW = dy^T x[:, ::2, ::2]
+// The GEMMs go where the stride-1 1x1 convolutions go (hipBLASLt near the HBM rate, split-K weight gradient,
+// monodetr/linear.py); what is left for this file is the gather and its adjoint, two HBM streams:
+//   forward : reads the kept quarter of x, writes y                     -- bytes = 2 B OH OW C e
+//   backward: reads dy, writes ALL of dx (the zeros are part of the result) -- bytes = B (OH OW + H W) C e
+// 16 bytes per thread; consecutive threads cover a pixel's channels, then the next pixel of the row.
+// (round 3's conv_taps.hip ran these shapes as one-tap implicit GEMMs at 105 - 117 us forward, 74 - 84 us input gradient,
+// against 25 - 45 us for gather + GEMM.)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "decimate.h"
+
+namespace mdetr {
+namespace {
+
+struct DecDims {
+    int B, H, W, OH, OW;
+    int pieces;                 // 16-byte pieces per pixel
+};
+
+__global__ __launch_bounds__(256)
+void decimate2_fwd_kernel(const uint4 *__restrict__ x, uint4 *__restrict__ y, const DecDims d)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t total = static_cast<int64_t>(d.B) * d.OH * d.OW * d.pieces;
+    if (i >= total) return;
+    const int piece = static_cast<int>(i % d.pieces);
+    int64_t pix = i / d.pieces;
+    const int ow = static_cast<int>(pix % d.OW); pix /= d.OW;
+    const int oh = static_cast<int>(pix % d.OH);
+    const int b = static_cast<int>(pix / d.OH);
+    y[i] = x[((static_cast<int64_t>(b) * d.H + 2 * oh) * d.W + 2 * ow) * d.pieces + piece];
+}
+
+__global__ __launch_bounds__(256)
+void decimate2_bwd_kernel(const uint4 *__restrict__ dy, uint4 *__restrict__ dx, const DecDims d)
+{
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t total = static_cast<int64_t>(d.B) * d.H * d.W * d.pieces;
+    if (i >= total) return;
+    const int piece = static_cast<int>(i % d.pieces);
+    int64_t pix = i / d.pieces;
+    const int w = static_cast<int>(pix % d.W); pix /= d.W;
+    const int h = static_cast<int>(pix % d.H);
+    const int b = static_cast<int>(pix / d.H);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (!(h & 1) && !(w & 1)) v = dy[((static_cast<int64_t>(b) * d.OH + (h >> 1)) * d.OW + (w >> 1)) * d.pieces + piece];
+    dx[i] = v;
+}
+
+DecDims dims(int B, int H, int W, int64_t pixel_bytes)
+{
+    DecDims d;
+    d.B = B; d.H = H; d.W = W; d.OH = (H + 1) / 2; d.OW = (W + 1) / 2;
+    d.pieces = static_cast<int>(pixel_bytes / 16);
+    return d;
+}
+
+}  // namespace
+
+bool decimate2_supported(int64_t pixel_bytes, const void *x, const void *y)
+{
+    return pixel_bytes > 0 && pixel_bytes % 16 == 0 && pixel_bytes / 16 < (1 << 20) &&
+           (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+}
+
+hipError_t decimate2_forward_launch(const void *x, void *y, int B, int H, int W, int64_t pixel_bytes, hipStream_t st)
+{
+    const DecDims d = dims(B, H, W, pixel_bytes);
+    const int64_t total = static_cast<int64_t>(B) * d.OH * d.OW * d.pieces;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(decimate2_fwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st,
+                       static_cast<const uint4 *>(x), static_cast<uint4 *>(y), d);
+    return hipGetLastError();
+}
+
+hipError_t decimate2_backward_launch(const void *dy, void *dx, int B, int H, int W, int64_t pixel_bytes, hipStream_t st)
+{
+    const DecDims d = dims(B, H, W, pixel_bytes);
+    const int64_t total = static_cast<int64_t>(B) * H * W * d.pieces;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(decimate2_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st,
+                       static_cast<const uint4 *>(dy), static_cast<uint4 *>(dx), d);
+    return hipGetLastError();
+}
+
+}  // namespace mdetr

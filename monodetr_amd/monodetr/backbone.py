@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..utils.misc import NestedTensor, mark_no_padding
-from .. import bias_act_ext, conv3x3_ext, conv_stem_ext, conv_taps_ext
+from .. import bias_act_ext, conv3x3_ext, conv_stem_ext, conv_taps_ext, decimate_ext
 from .linear import pointwise_conv, pointwise_eligible, pointwise_relu_fusable
 from .position_encoding import build_position_encoding
 
@@ -140,7 +140,15 @@ def conv_bn(x, conv, bn, relu):
                                           scale.to(conv.weight.dtype).view(-1, 1, 1, 1), shift.to(dt))
             w = (conv.weight * cast[1]).to(dt)
             b = cast[2]
-        if pointwise_eligible(x, conv.kernel_size, conv.stride, conv.padding, conv.groups) and x.dtype == w.dtype:
+        if decimate_ext.ENABLED and tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (0, 0) \
+                and conv.groups == 1 and x.dtype == w.dtype and decimate_ext.supported(x) and not torch.is_autocast_enabled():
+            # the projection shortcut of a stage's first block: a 1x1 / stride-2 convolution reads only the pixels it keeps -- gather
+            # them (csrc/decimate.hip) and run the stride-1 token GEMM path below
+            x = decimate_ext.decimate2(x)
+            stride1 = True
+        else:
+            stride1 = tuple(conv.stride) == (1, 1)
+        if stride1 and pointwise_eligible(x, conv.kernel_size, (1, 1), conv.padding, conv.groups) and x.dtype == w.dtype:
             if relu and pointwise_relu_fusable(x, w, b):
                 return pointwise_conv(x, w, b, relu=True)            # ReLU in the GEMM's epilogue
             x = pointwise_conv(x, w, b)

@@ -1,0 +1,54 @@
+"""csrc/decimate.hip (every second pixel of a channels-last activation, and the adjoint) on the HIP-on-CPU shim, through
+monodetr_amd/decimate_ext.py: against tensor slicing and its autograd, even / odd extents, both element sizes; and the 1x1 /
+stride-2 convolution assembled from it against F.conv2d."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import native_emul
+
+
+@pytest.fixture()
+def ext():
+    from monodetr_amd import decimate_ext
+    decimate_ext._backend = native_emul.lib()
+    yield decimate_ext
+    decimate_ext._backend = None
+
+
+@pytest.mark.parametrize("B,C,H,W,dtype", [(2, 64, 12, 40, torch.bfloat16), (1, 8, 7, 9, torch.bfloat16), (3, 4, 5, 6, torch.float32),
+                                           (1, 256, 1, 1, torch.bfloat16), (2, 16, 2, 3, torch.float32)])
+def test_decimate_matches_slicing_and_its_adjoint(ext, B, C, H, W, dtype):
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+    x = torch.randn(B, C, H, W, generator=g).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert ext.supported(x)
+    y = ext.decimate2(x)
+    want = x.detach()[:, :, ::2, ::2]
+    assert y.shape == want.shape and y.is_contiguous(memory_format=torch.channels_last) and torch.equal(y, want)
+    gy = torch.randn(want.shape, generator=g).to(dtype)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    ref = torch.zeros_like(x.detach())
+    ref[:, :, ::2, ::2] = gy
+    assert gx.is_contiguous(memory_format=torch.channels_last) and torch.equal(gx, ref)
+
+
+def test_rejects_what_it_cannot_take(ext):
+    assert not ext.supported(torch.zeros(1, 4, 4, 4, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last))   # 8-byte pixels
+    assert not ext.supported(torch.zeros(1, 8, 4, 4, dtype=torch.bfloat16))                                                  # NCHW
+    with pytest.raises(RuntimeError):
+        ext.decimate2(torch.zeros(1, 8, 4, 4, dtype=torch.bfloat16))
+
+
+def test_projection_shortcut_as_gather_plus_token_gemm(ext):
+    """conv(1x1, stride 2)(x) == linear over the tokens of decimate2(x), values and all gradients (fp32)."""
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 16, 6, 10, generator=g).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(24, 16, 1, 1, generator=g) * 0.2).requires_grad_(True)
+    b = torch.randn(24, generator=g).requires_grad_(True)
+    want = F.conv2d(x, w, b, stride=2)
+    xd = ext.decimate2(x)
+    got = F.linear(xd.permute(0, 2, 3, 1), w.view(24, 16), b).permute(0, 3, 1, 2)
+    assert (want - got).abs().max() < 1e-5
+    gy = torch.randn(want.shape, generator=g)
+    for a, c in zip(torch.autograd.grad(want, [x, w, b], gy), torch.autograd.grad(got, [x, w, b], gy)):
+        assert (a - c).abs().max() < 1e-5

@@ -916,3 +916,30 @@ def test_training_step_with_the_small_wgrad_kernel_matches_default():
         bench.apply_switches(set())
     for a, b in zip(traj[()], traj[("MDETR_SMALL_WGRAD",)]):
         assert abs(a - b) <= 2e-2 * abs(a), traj
+
+
+@pytest.mark.parametrize("B,C,H,W,dtype", [(8, 256, 96, 320, torch.bfloat16), (2, 1024, 24, 80, torch.bfloat16), (1, 8, 7, 9, torch.float32)])
+def test_decimate_kernel_and_the_projection_shortcut_as_a_token_gemm(B, C, H, W, dtype):
+    """csrc/decimate.hip on the GPU: x[:, :, ::2, ::2] and its adjoint bit-exact against slicing; conv_bn's 1x1 / stride-2
+    route (gather + token GEMM) against the library convolution on the same bf16 operands."""
+    from monodetr_amd import decimate_ext
+    g = torch.Generator(device="cuda").manual_seed(C + H)
+    x = torch.randn(B, C, H, W, device="cuda", generator=g).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = decimate_ext.decimate2(x)
+    assert torch.equal(y, x.detach()[:, :, ::2, ::2])
+    gy = torch.randn(y.shape, device="cuda", generator=g).to(dtype)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    ref = torch.zeros_like(x.detach())
+    ref[:, :, ::2, ::2] = gy
+    assert torch.equal(gx, ref)
+    if dtype == torch.bfloat16:
+        N = 2 * C
+        w = (torch.randn(N, C, 1, 1, device="cuda", generator=g) / C ** 0.5).to(dtype).requires_grad_(True)
+        b = torch.randn(N, device="cuda", generator=g).to(dtype)
+        from monodetr_amd.monodetr.linear import pointwise_conv
+        got = pointwise_conv(decimate_ext.decimate2(x), w, b)
+        want = torch.nn.functional.conv2d(x.float(), w.float(), b.float(), stride=2)
+        assert (got.float() - want).abs().max() <= 2e-2 * want.abs().max()
+        go = torch.randn(got.shape, device="cuda", generator=g).to(dtype)
+        for a, c in zip(torch.autograd.grad(got, [x, w], go), torch.autograd.grad(want, [x, w], go.float())):
+            assert (a.float() - c.float()).abs().max() <= 2e-2 * c.float().abs().max()
