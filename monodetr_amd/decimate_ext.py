@@ -29,7 +29,7 @@ class _Decimate2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         B, C, H, W = x.shape
-        y = torch.empty((B, C, (H + 1) // 2, (W + 1) // 2), dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+        y = torch.empty((B, C, (H + 1) // 2, (W + 1) // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         _call(0, x, y, B, H, W, C)
         ctx.shape = (B, C, H, W)
         return y
@@ -39,7 +39,7 @@ class _Decimate2(torch.autograd.Function):
     def backward(ctx, dy):
         B, C, H, W = ctx.shape
         dy = dy.contiguous(memory_format=torch.channels_last)
-        dx = torch.empty(ctx.shape, dtype=dy.dtype, device=dy.device).contiguous(memory_format=torch.channels_last)
+        dx = torch.empty(ctx.shape, dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
         _call(1, dy, dx, B, H, W, C)
         return dx
 
