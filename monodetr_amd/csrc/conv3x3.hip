@@ -22,6 +22,7 @@
 // version: 5 ds_read_b128 per 4 MFMAs).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <mdetr_wave.h>
 
@@ -221,8 +222,20 @@ hipError_t conv3x3_launch(const void *x, const void *w, const float *shift, void
     ConvDims d{B, H, W, C, N, (W + kTileW - 1) / kTileW, (H + kWavesC - 1) / kWavesC, 0, 0, 0, mirror ? 1 : 0};
     // 128 output channels per workgroup where the layer has them (the halo is then read once per 128 channels); 64 for the
     // 64-channel stage
-    if (N >= 128) return relu ? launch<4, true>(x, w, shift, y, d, st) : launch<4, false>(x, w, shift, y, d, st);
-    if (N >= 64) return relu ? launch<2, true>(x, w, shift, y, d, st) : launch<2, false>(x, w, shift, y, d, st);
+    int nb = N >= 128 ? 4 : (N >= 64 ? 2 : 1);
+    // 85 KB of LDS at 128 channels = ONE workgroup (4 waves) per CU; 57 KB at 64 (two per CU), 43 KB at 32 (three).  A problem
+    // with few pixel tiles (layer3: 144, layer4: 48 at B = 8) is better served by narrow channel blocks -- more workgroups, more
+    // waves per SIMD to overlap the LDS reads with -- than by reading the halo once per 128 channels: measured at B = 8
+    // (profiles/r03o_conv3x3_nb*.json) layer3 61 / 42 / 36 us and layer4 58 / 47 / 41 us at 128 / 64 / 32 channels per
+    // workgroup, layer2 (480 tiles) 38 / 32 / 33 us.  Narrow until there are ~900 workgroups.
+    const int64_t tiles = static_cast<int64_t>(B) * d.tiles_x * d.tiles_y;
+    while (nb > 1 && tiles * ((N + nb * 32 - 1) / (nb * 32)) < 900) nb >>= 1;
+    if (const char *ev = getenv("MDETR_CONV3X3_NB")) {                        // A/B runs: a fixed width (clamped to what exists)
+        const int f = atoi(ev);
+        if ((f == 1 || f == 2 || f == 4) && f * 32 <= (N >= 128 ? 128 : (N >= 64 ? 64 : 32))) nb = f;
+    }
+    if (nb == 4) return relu ? launch<4, true>(x, w, shift, y, d, st) : launch<4, false>(x, w, shift, y, d, st);
+    if (nb == 2) return relu ? launch<2, true>(x, w, shift, y, d, st) : launch<2, false>(x, w, shift, y, d, st);
     return relu ? launch<1, true>(x, w, shift, y, d, st) : launch<1, false>(x, w, shift, y, d, st);
 }
 

@@ -24,6 +24,7 @@
 // Algorithmic bytes = 2 B (H W C + OH OW N) + 4 TR TS N C;  flops = 2 B OH OW TR TS C N.  MFMA-bound by design.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <mdetr_wave.h>
 
@@ -247,7 +248,12 @@ WgradGeom geometry(const ConvWgradDims &d)
     g.cblocks = d.C / kCB;
     // one workgroup per CU (104-134 KB of LDS): about 256 workgroups, each with at least one pixel tile
     const int base = d.K * g.nblocks * g.cblocks;
-    int chunks = 256 / (base > 0 ? base : 1);
+    int target = 256;
+    if (const char *ev = getenv("MDETR_CONV_WGRAD_WGS")) {                    // A/B runs: workgroups to aim for
+        const int f = atoi(ev);
+        if (f >= 64 && f <= 8192) target = f;
+    }
+    int chunks = target / (base > 0 ? base : 1);
     if (chunks < 1) chunks = 1;
     if (chunks > g.units) chunks = g.units;
     g.chunks = chunks;
