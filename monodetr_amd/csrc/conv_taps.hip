@@ -29,13 +29,22 @@
 
 #include "conv_taps.h"
 
+// Contraction channels per LDS slab.  32, not conv3x3.hip's 64: the stride-2 halo of a 4 x 32-pixel tile is 9 x 65 pixels -- 84 KB at
+// 64 channels + padding, which with the weights left ONE workgroup (four waves) per CU; at 32 channels the tile is 47 + 31 KB and
+// two workgroups fit.  Measured (profiles/r03q_strided_slab{64,32}.json): forward 3x3 / stride 2 of layer2 / 3 / 4 and the depth
+// head 49 / 71 / 86 / 70 us -> 39 / 54 / 68 / 52 us; the 2048-channel pyramid level loses (125 -> 146 us: twice the stages).
+#ifndef MDETR_CONV_TAPS_SLAB
+#define MDETR_CONV_TAPS_SLAB 32
+#endif
+
 namespace mdetr {
 namespace {
 
 constexpr int kWavesT = 4;               // = output rows per workgroup
 constexpr int kTileWT = 32;              // output columns per workgroup
-constexpr int kSlabT = 64;               // contraction channels per LDS slab
-constexpr int kPadT = kSlabT + 8;        // 72 bf16 per LDS row (conv3x3.hip: distinct bank quads for a b128 lane group)
+constexpr int kSlabT = MDETR_CONV_TAPS_SLAB;   // contraction channels per LDS slab
+constexpr int kPiecesT = kSlabT / 8;     // 16-byte pieces of a pixel's slab
+constexpr int kPadT = kSlabT + 8;        // 40 bf16 = 20 dwords per LDS row (72 at 64 channels): the 16 lanes of a b128 group fall on 16 distinct bank quads
 
 struct TapGeom {
     ConvTapsDims d;
@@ -91,7 +100,7 @@ __device__ __forceinline__ void conv_taps_body(const __bf16 *__restrict__ x, con
     auto fetch_w = [&](int k0, int a) {                                      // [e][n][64 k] <- w[n0 + n][tap a][tap e][k0 .. k0 + 64)
 #pragma unroll
         for (int j = 0; j < WP; ++j) {
-            const int p = threadIdx.x + j * T, piece = p & 7, row = p >> 3;  // row = e * NB*32 + n
+            const int p = threadIdx.x + j * T, piece = p % kPiecesT, row = p / kPiecesT;  // row = e * NB*32 + n
             const int e = row / (NB * 32), n = row - e * (NB * 32);
             bf16x8 v = zero8();
             if (row < TS * NB * 32 && n0 + n < d.N)
@@ -104,7 +113,7 @@ __device__ __forceinline__ void conv_taps_body(const __bf16 *__restrict__ x, con
 #pragma unroll
         for (int j = 0; j < WP; ++j) {
             const int p = threadIdx.x + j * T;
-            if (p < TS * NB * 32 * (kSlabT / 8)) *reinterpret_cast<bf16x8 *>(wts + (p >> 3) * kPadT + (p & 7) * 8) = wreg[j];
+            if (p < TS * NB * 32 * (kSlabT / 8)) *reinterpret_cast<bf16x8 *>(wts + (p / kPiecesT) * kPadT + (p % kPiecesT) * 8) = wreg[j];
         }
     };
     // halo: global -> registers -> LDS in one go at each slab boundary (HP pieces per thread: up to 19 with SI = 2, too many to
@@ -117,7 +126,7 @@ __device__ __forceinline__ void conv_taps_body(const __bf16 *__restrict__ x, con
             for (int jj = 0; jj < 8; ++jj) {
                 const int j = j0 + jj;
                 if (j >= HP) break;
-                const int p = threadIdx.x + j * T, piece = p & 7, pix = p >> 3;
+                const int p = threadIdx.x + j * T, piece = p % kPiecesT, pix = p / kPiecesT;
                 const int hr = pix / HWC, hc = pix - hr * HWC;
                 const int r = SI * r0 + hr - d.PT, c = SI * c0 + hc - d.PL;
                 // (a single tap at stride 2 reads only the even rows / columns of its halo: the others are not fetched)
@@ -129,7 +138,7 @@ __device__ __forceinline__ void conv_taps_body(const __bf16 *__restrict__ x, con
             for (int jj = 0; jj < 8; ++jj) {
                 const int j = j0 + jj;
                 if (j >= HP) break;
-                const int p = threadIdx.x + j * T, piece = p & 7, pix = p >> 3;
+                const int p = threadIdx.x + j * T, piece = p % kPiecesT, pix = p / kPiecesT;
                 const int hr = pix / HWC, hc = pix - hr * HWC;
                 const int slot = SI == 2 ? (hc & 1) * PLANE + (hc >> 1) : hc;
                 if (pix < HH * HWC) *reinterpret_cast<bf16x8 *>(halo + (hr * HWC + slot) * kPadT + piece * 8) = hreg[jj];
