@@ -17,7 +17,7 @@
 // are stored de-interleaved (even columns, then odd), as in conv_taps.hip.
 // Workgroup = 8 waves: (tap row t, 128 output channels n, 64 input channels c, a chunk of the pixel tiles); wave w owns
 // n-block w & 3 and c-block w >> 2: TS accumulator tiles D[n][c] (32 x 32) per wave, one per tap column.  A pixel tile is
-// 8 output rows x 32 output columns of one image = 16 MFMA k-steps (2 columns x 8 rows each).  The next tile's global loads are
+// 8 output rows x kCols (16) output columns of one image = kCols / 2 MFMA k-steps (2 columns x 8 rows each).  The next tile's global loads are
 // issued before the current tile's products and transposed into the single LDS buffer after them.
 // Output: per-chunk partial gradients P[chunk][n][t][e][c] in fp32; colsum.hip adds the chunks in a fixed order and rounds once
 // into the parameter's dtype (deterministic, no atomics).
@@ -35,7 +35,14 @@ namespace {
 
 constexpr int kThreadsG = 512;
 constexpr int kNB = 128, kCB = 64;       // output / input channels per workgroup
-constexpr int kRows = 8, kCols = 32;     // output pixels of a tile
+// Columns of a pixel tile: 16.  With 32 the two transposed operand tiles take 103 - 134 KB of LDS -- one workgroup (8 waves) per CU;
+// with 16 they take 54 - 70 KB and two workgroups fit.  Measured (profiles/r03s_wgrad_cols{32,16_wgs256}.json): 3x3 weight
+// gradient of layer2 / 3 / 4 46 / 51 / 82 us -> 43 / 42 / 63 us at the same ~256 workgroups (more workgroups = more fp32 chunk
+// partials to write and sum: 512 is slower again).
+#ifndef MDETR_CONV_WGRAD_COLS
+#define MDETR_CONV_WGRAD_COLS 16
+#endif
+constexpr int kRows = 8, kCols = MDETR_CONV_WGRAD_COLS;     // output pixels of a tile (columns: 16 or 32)
 constexpr int kDyStride = kCols + 1;     // 16-byte slots per n row of dYt: odd, so the 16 lanes of a b128 group fall on distinct slots
 
 struct WgradGeom {
@@ -93,7 +100,7 @@ void conv_wgrad_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ 
     // 68 % of the LDS cycles were conflicts, profiles/r03b_pmc_conv.json) -- while a load instruction still covers 64 contiguous
     // bytes of each of its 16 pixels.
     constexpr int CGX = (XC + 15) / 16;                                      // column groups of the X window
-    constexpr int WTASKS = 2 * CGX + 8;                                      // X: CGX x 2 piece groups; dY: 2 x 4
+    constexpr int WTASKS = 2 * CGX + 4 * (kCols / 16);                       // X: CGX x 2 piece groups; dY: (kCols / 16) x 4
     constexpr int kWavesG = kThreadsG / 64;
     constexpr int ROUNDS = (WTASKS + kWavesG - 1) / kWavesG;
     constexpr int PF = ROUNDS <= 2 ? 2 : 1;                                  // tiles in flight ahead of the products (registers: 32 per round and tile)

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <mdetr_wave.h>
 
@@ -180,12 +181,17 @@ bool small_wgrad_supported(int io_dtype, int64_t rows, int n, int k, int64_t ldy
            k % kTile == 0 && static_cast<int64_t>(n) * k <= kMaxTileArea && ldy >= n && ldx >= k && ldx % 8 == 0;
 }
 
-// chunks along the token axis: ~4 workgroups per CU (a workgroup waits on one global round trip per 32 rows; several per
+// chunks along the token axis: ~3 workgroups per CU (a workgroup waits on one global round trip per 32 rows; several per
 // CU keep the FMA pipes fed), at least 64 rows per chunk
 int small_wgrad_chunks(int64_t rows, int n, int k)
 {
     const int tiles = ((n + kTile - 1) / kTile) * (k / kTile);
-    int c = (1152 + tiles - 1) / tiles;
+    int target = 768;                                                        // (1152 until round 3: r03t sweep, 24.4 -> 21.3 us for the 256 x 256 layers)
+    if (const char *ev = getenv("MDETR_SMALL_WGRAD_WGS")) {                  // A/B runs: workgroups to aim for
+        const int f = atoi(ev);
+        if (f >= 64 && f <= 8192) target = f;
+    }
+    int c = (target + tiles - 1) / tiles;
     const int64_t most = (rows + 63) / 64;
     if (c > most) c = static_cast<int>(most);
     if (c > 256) c = 256;                                            // one colsum row block adds them in a single launch
