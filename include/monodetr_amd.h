@@ -533,6 +533,9 @@ int mdetr_bias_act_backward(int io_dtype, const void *dy, const void *y, void *d
  *   backward = 1: src = dy [B, (H + 1) / 2, (W + 1) / 2, C] -> dst = dx [B, H, W, C], zero at the skipped pixels
  * pixel_bytes = C * element size (any element type), a multiple of 16; pointers 16-byte aligned.
  */
+/* torchvision ResNet.maxpool (3x3 / stride 2 / pad 1) on a channels-last bf16 activation, forward only (the stem is frozen):
+ * x [B, H, W, C] -> y [B, (H - 1) / 2 + 1, (W - 1) / 2 + 1, C]; C a multiple of 8, 16-byte aligned pointers. */
+int mdetr_maxpool3x3s2_bf16(const void *x, void *y, int B, int H, int W, int C, int device, void *stream);
 int mdetr_decimate2(int backward, const void *src, void *dst, int B, int H, int W, int64_t pixel_bytes, int device, void *stream);
 
 /*

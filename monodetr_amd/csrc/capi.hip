@@ -673,6 +673,19 @@ int mdetr_decimate2(int backward, const void *src, void *dst, int B, int H, int 
     return MDETR_OK;
 }
 
+int mdetr_maxpool3x3s2_bf16(const void *x, void *y, int B, int H, int W, int C, int device, void *stream)
+{
+    if (B < 0 || H < 0 || W < 0 || C <= 0 || C % 8 != 0) return fail(MDETR_E_ARG, "mdetr_maxpool3x3s2_bf16: B=%d H=%d W=%d C=%d (C a positive multiple of 8)", B, H, W, C);
+    if (B == 0 || H == 0 || W == 0) return MDETR_OK;
+    if (!x || !y) return fail(MDETR_E_ARG, "mdetr_maxpool3x3s2_bf16: null pointer");
+    if (!aligned16(x) || !aligned16(y)) return fail(MDETR_E_ALIGN, "mdetr_maxpool3x3s2_bf16: x, y must be 16-byte aligned");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_maxpool3x3s2_bf16: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::maxpool3x3s2_bf16_launch(x, y, B, H, W, C, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_maxpool3x3s2_bf16: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
 int64_t mdetr_small_wgrad_workspace_bytes(int64_t rows, int n, int k) { return mdetr::small_wgrad_workspace_bytes(rows, n, k); }
 
 int mdetr_small_wgrad(int io_dtype, const void *dy, const void *x, void *out, int out_dtype, void *workspace, int64_t workspace_bytes,

@@ -44,6 +44,21 @@ class _Decimate2(torch.autograd.Function):
         return dx
 
 
+def maxpool_supported(x):
+    return ((x.is_cuda or _backend is not None) and x.dim() == 4 and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0
+            and x.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0 and x.numel() > 0
+            and not (torch.is_grad_enabled() and x.requires_grad))
+
+
+def maxpool3x3s2(x):
+    """nn.MaxPool2d(3, 2, 1) of a channels-last bf16 activation that needs no gradient (the frozen stem's output)."""
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    dev, stream = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream) if x.is_cuda else (-1, None)
+    _capi.check(_lib().mdetr_maxpool3x3s2_bf16(x.data_ptr(), y.data_ptr(), B, H, W, C, dev, stream), "mdetr_maxpool3x3s2_bf16")
+    return y
+
+
 def decimate2(x):
     """x [B, C, H, W] channels-last -> x[:, :, ::2, ::2] as a dense channels-last tensor; backward scatters into zeros."""
     if not supported(x):

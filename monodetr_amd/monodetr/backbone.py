@@ -270,7 +270,11 @@ class ResNetBody(nn.Module):
             pairs = self._trainable_pairs()
             if pairs:
                 prefold(pairs, dt if dt is not None else pairs[0][0].weight.dtype)
-        x = self.maxpool(conv_bn(x, self.conv1, self.bn1, True))
+        x = conv_bn(x, self.conv1, self.bn1, True)
+        if decimate_ext.ENABLED and decimate_ext.maxpool_supported(x):
+            x = decimate_ext.maxpool3x3s2(x)            # frozen stem: no gradient flows here (csrc/decimate.hip)
+        else:
+            x = self.maxpool(x)
         out = {}
         for name in ('layer1', 'layer2', 'layer3', 'layer4'):
             x = getattr(self, name)(x)

@@ -52,3 +52,14 @@ def test_projection_shortcut_as_gather_plus_token_gemm(ext):
     gy = torch.randn(want.shape, generator=g)
     for a, c in zip(torch.autograd.grad(want, [x, w, b], gy), torch.autograd.grad(got, [x, w, b], gy)):
         assert (a - c).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 12, 40), (1, 8, 7, 9), (1, 16, 1, 1), (2, 8, 2, 5)])
+def test_maxpool_matches_the_framework(ext, B, C, H, W):
+    g = torch.Generator().manual_seed(H * 100 + W)
+    x = torch.randn(B, C, H, W, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert ext.maxpool_supported(x)
+    y = ext.maxpool3x3s2(x)
+    want = F.max_pool2d(x.float(), 3, 2, 1).to(torch.bfloat16)
+    assert y.shape == want.shape and y.is_contiguous(memory_format=torch.channels_last) and torch.equal(y, want)
+    assert not ext.maxpool_supported(x.clone().requires_grad_(True))          # forward only: anything that needs a gradient stays with torch

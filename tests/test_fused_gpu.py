@@ -943,3 +943,15 @@ def test_decimate_kernel_and_the_projection_shortcut_as_a_token_gemm(B, C, H, W,
         go = torch.randn(got.shape, device="cuda", generator=g).to(dtype)
         for a, c in zip(torch.autograd.grad(got, [x, w], go), torch.autograd.grad(want, [x, w], go.float())):
             assert (a.float() - c.float()).abs().max() <= 2e-2 * c.float().abs().max()
+
+
+@pytest.mark.parametrize("B,C,H,W", [(8, 64, 192, 640), (1, 8, 7, 9), (2, 64, 5, 6)])
+def test_maxpool_kernel_matches_the_framework(B, C, H, W):
+    """csrc/decimate.hip maxpool3x3s2_bf16 (the frozen stem's pooling) == F.max_pool2d(x, 3, 2, 1), bit for bit."""
+    from monodetr_amd import decimate_ext
+    g = torch.Generator(device="cuda").manual_seed(H + W)
+    x = torch.randn(B, C, H, W, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert decimate_ext.maxpool_supported(x)
+    y = decimate_ext.maxpool3x3s2(x)
+    want = torch.nn.functional.max_pool2d(x, 3, 2, 1)
+    assert y.shape == want.shape and torch.equal(y, want)
