@@ -19,9 +19,31 @@ def _lib():
 
 def supported(x, dy, k, stride):
     return ((ENABLED or _backend is not None) and (x.is_cuda or _backend is not None) and x.dim() == 4 and dy.dim() == 4 and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
-            and ((k == 3 and stride in (1, 2)) or (k == 1 and stride == 2)) and x.shape[1] % 64 == 0 and dy.shape[1] % 32 == 0
+            and ((k == 3 and stride in (1, 2)) or (k == 1 and stride in (1, 2))) and x.shape[1] % 64 == 0 and dy.shape[1] % 32 == 0
             and x.numel() > 0 and dy.numel() > 0 and x.is_contiguous(memory_format=torch.channels_last)
             and dy.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0)
+
+
+# MDETR_TOKEN_WGRAD_CONV=1: weight gradients of token-wise linear layers over tens of thousands of rows (the encoder's 81 600, the
+# backbone's 1x1 convolutions) as the 1x1 case of this kernel instead of the library's batched split-K product
+TOKEN_ROUTE = os.environ.get("MDETR_TOKEN_WGRAD_CONV") == "1"
+
+
+def token_weight_gradient(x2, dy2, dtype):
+    """dW [N, K] = dy2^T x2 for token matrices x2 [T, K], dy2 [T, N] (bf16, contiguous rows, T a multiple of 8): the matrices
+    viewed as 1 x 8 x (T / 8) channels-last images, a 1x1 convolution's weight gradient."""
+    T, K = x2.shape
+    N = dy2.shape[1]
+    xi = x2.view(1, 8, T // 8, K).permute(0, 3, 1, 2)
+    di = dy2.view(1, 8, T // 8, N).permute(0, 3, 1, 2)
+    return weight_gradient(xi, di, 1, 1, dtype).reshape(N, K)
+
+
+def token_supported(x2, dy2):
+    T = x2.shape[0]
+    return (TOKEN_ROUTE and x2.dtype == torch.bfloat16 and dy2.dtype == torch.bfloat16 and x2.is_contiguous() and dy2.is_contiguous() and T % 8 == 0
+            and x2.shape[1] % 64 == 0 and dy2.shape[1] % 32 == 0 and (x2.is_cuda or _backend is not None)
+            and x2.data_ptr() % 16 == 0 and dy2.data_ptr() % 16 == 0 and T * max(x2.shape[1], dy2.shape[1]) * 2 < (1 << 31))
 
 
 def weight_gradient(x, dy, k, stride, dtype=torch.bfloat16):

@@ -272,7 +272,8 @@ WgradGeom geometry(const ConvWgradDims &d)
 bool conv_wgrad_supported(const ConvWgradDims &d, const void *x, const void *dy)
 {
     const auto al = [](const void *p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
-    const bool shape = (d.K == 3 && (d.SI == 1 || d.SI == 2)) || (d.K == 1 && d.SI == 2);
+    // (K = 1 / stride 1: the weight gradient of a token-wise linear layer, its [T, C] / [T, N] matrices viewed as a 1 x 8 x T / 8 image)
+    const bool shape = (d.K == 3 && (d.SI == 1 || d.SI == 2)) || (d.K == 1 && (d.SI == 2 || d.SI == 1));
     return shape && d.B > 0 && d.H > 0 && d.W > 0 && d.OH > 0 && d.OW > 0 && d.C > 0 && d.C % 64 == 0 && d.N > 0 && d.N % 32 == 0 &&
            al(x, 16) && al(dy, 16) && static_cast<int64_t>(d.N) * d.K * d.K * d.C < (1ll << 28) &&
            static_cast<int64_t>(d.B) * d.H * d.W * d.C < (1ll << 30) && static_cast<int64_t>(d.B) * d.OH * d.OW * d.N < (1ll << 30);
@@ -284,7 +285,7 @@ hipError_t conv_wgrad_launch(const void *x, const void *dy, float *part, const C
 {
     const WgradGeom g = geometry(d);
     if (d.K == 3) return d.SI == 1 ? launch<1, 3>(x, dy, part, g, st) : launch<2, 3>(x, dy, part, g, st);
-    return launch<2, 1>(x, dy, part, g, st);
+    return d.SI == 1 ? launch<1, 1>(x, dy, part, g, st) : launch<2, 1>(x, dy, part, g, st);
 }
 
 }  // namespace mdetr

@@ -57,7 +57,10 @@ def _weight_bias_grads(x2, dy2, weight, need_w, need_b):
     # 110 us at 15 360), not for the decoder's 4 400 (29 + 12 vs 34 us, and 16 bf16 roundings instead of one)
     C = _split_count(T) if T > small_wgrad_ext.MAX_ROWS else 0
     if need_w:
-        if C:
+        from .. import conv_wgrad_ext
+        if T > small_wgrad_ext.MAX_ROWS and conv_wgrad_ext.token_supported(x2, dy2) and weight.dtype in (torch.float32, torch.bfloat16):
+            dw = conv_wgrad_ext.token_weight_gradient(x2, dy2, weight.dtype)
+        elif C:
             parts = torch.bmm(dy2.view(C, T // C, -1).transpose(1, 2), x2.view(C, T // C, -1))    # [C, N, K]
             flat = parts.view(C, -1)
             if colsum_ext.supported(flat) and weight.dtype in (torch.float32, torch.bfloat16):
