@@ -23,6 +23,7 @@
 // Algorithmic bytes = 2 (T K + T N) + 2 N K; MFMA work is 4-5x below the memory time at these shapes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <mdetr_wave.h>
 
@@ -163,7 +164,9 @@ hipError_t launch(const void *x, const void *w, const void *bias, void *y, int64
     const int64_t tiles = (T + 31) / 32;
     int64_t gx = (tiles + kWavesG - 1) / kWavesG;
     const int ny = (N + NB * 32 - 1) / (NB * 32);
-    const int64_t cap = 256 / ny > 0 ? 256 / ny : 1;              // one workgroup per CU holds the weight: <= 256 in total
+    // as many workgroups as the CUs can hold at once (LDS decides: a 135 KB weight block = one per CU, a 34 KB one = three)
+    const int per_cu = static_cast<int>((160 * 1024) / lds) > 0 ? static_cast<int>((160 * 1024) / lds) : 1;
+    const int64_t cap = (256 * per_cu) / ny > 0 ? (256 * per_cu) / ny : 1;
     if (gx > cap) gx = cap;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(gx), static_cast<unsigned>(ny)), dim3(kWavesG * 64), lds, st,
                        static_cast<const __bf16 *>(x), static_cast<const __bf16 *>(w), static_cast<const __bf16 *>(bias),
@@ -186,7 +189,13 @@ hipError_t token_gemm_launch(const void *x, const void *w, const void *bias, voi
     if (K == 512)          // 128 output features per workgroup (133 KiB of weight); wider N re-reads x per block
         return relu ? launch<512, 4, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch<512, 4, false>(x, w, bias, y, T, N, ldx, ldy, st);
     if (K == 256) {
-        if (N <= 128) return relu ? launch<256, 4, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch<256, 4, false>(x, w, bias, y, T, N, ldx, ldy, st);
+        int nb = N <= 64 ? 2 : (N <= 128 ? 4 : 8);                            // (a 64-wide output fits two blocks: 34 KB of weight, three workgroups per CU)
+        if (const char *ev = getenv("MDETR_TOKEN_GEMM_NB")) {                 // A/B runs: output blocks of 32 per workgroup
+            const int f = atoi(ev);
+            if (f == 2 || f == 4 || f == 8) nb = f;
+        }
+        if (nb == 2) return relu ? launch<256, 2, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch<256, 2, false>(x, w, bias, y, T, N, ldx, ldy, st);
+        if (nb == 4) return relu ? launch<256, 4, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch<256, 4, false>(x, w, bias, y, T, N, ldx, ldy, st);
         return relu ? launch<256, 8, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch<256, 8, false>(x, w, bias, y, T, N, ldx, ldy, st);
     }
     if (K == 64)           // the backbone's 64 -> 256 expansions (245 760 tokens in layer1): one slab per tile
