@@ -27,6 +27,7 @@
 //     counter hash of (seed, b, h, q, k) so forward and backward regenerate the same mask.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <mdetr_wave.h>
 
@@ -189,9 +190,11 @@ template <typename T>
 __device__ __forceinline__ Raw8<T> tile_load(const T *base, int row_stride, int r0, int L)
 {
 #if MDETR_ATTN_STAGE_REMAP
-    const int row = (threadIdx.x & 15) + 16 * (threadIdx.x >> 6), dc = ((threadIdx.x >> 4) & 3) * 8;
+    const int t = threadIdx.x & 255;                             // (a workgroup may hold two 256-thread staging groups: key split)
+    const int row = (t & 15) + 16 * (t >> 6), dc = ((t >> 4) & 3) * 8;
 #else
-    const int row = threadIdx.x >> 2, dc = (threadIdx.x & 3) * 8;
+    const int t = threadIdx.x & 255;                             // (a workgroup may hold two 256-thread staging groups: key split)
+    const int row = t >> 2, dc = (t & 3) * 8;
 #endif
     Raw8<T> r;
     if (r0 + row < L) raw_load(r, base + static_cast<int64_t>(r0 + row) * row_stride + dc);
@@ -203,9 +206,9 @@ template <typename T, bool RM, bool TR, bool SP>
 __device__ __forceinline__ void tile_store(const Raw8<T> &raw, __bf16 *rm, __bf16 *tr)
 {
 #if MDETR_ATTN_STAGE_REMAP
-    const int t = threadIdx.x, row = (t & 15) + 16 * (t >> 6), dc = ((t >> 4) & 3) * 8;
+    const int t = threadIdx.x & 255, row = (t & 15) + 16 * (t >> 6), dc = ((t >> 4) & 3) * 8;
 #else
-    const int t = threadIdx.x, row = t >> 2, dc = (t & 3) * 8;
+    const int t = threadIdx.x & 255, row = t >> 2, dc = (t & 3) * 8;
 #endif
     float x[8];
     raw_floats(raw, x);
@@ -295,15 +298,24 @@ __device__ __forceinline__ void own_row_frags(const T *rowp, bool valid, float m
 // DROP: dropout on the probabilities, a compile-time property of the kernel -- as a run-time flag it put a scalar branch
 // around every element's hash (16 per sub-tile), which kept the exponentials, the hash and the conversions of
 // neighbouring elements from being scheduled together.  The 1 / (1 - p) rescale is applied once to the output.
-template <typename T, bool DROP>
-__global__ __launch_bounds__(256)
+// KS: key split.  With few queries (the decoder's 550: 5 query tiles x 8 heads x 8 images = 320 workgroups, 1 280 waves for 1 024
+// SIMDs) a wave per SIMD has nothing to overlap its exponentials with.  KS = 2 puts two 4-wave groups into a workgroup: both own
+// the SAME 128 queries, each walks half of the key tiles with its own staging buffers, and the two partial results
+// (running maximum, sum, accumulator) are merged through LDS at the end -- twice the waves, no second launch.
+template <typename T, bool DROP, int KS>
+__global__ __launch_bounds__(256 * KS)
 void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ lse2)
 {
     constexpr bool SP = sizeof(T) == 4;                  // fp32 I/O: hi/lo split operands
-    __shared__ __attribute__((aligned(16))) __bf16 Ks[(SP ? 2 : 1) * kRmSize];
-    __shared__ __attribute__((aligned(16))) __bf16 Vt[(SP ? 2 : 1) * kTrSize];
-    __shared__ __attribute__((aligned(16))) unsigned kh[kTile];           // dropout: the staged keys' hashed terms
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    constexpr int SPC = SP ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) __bf16 Ks_all[KS * SPC * kRmSize];
+    __shared__ __attribute__((aligned(16))) __bf16 Vt_all[KS * SPC * kTrSize];
+    __shared__ __attribute__((aligned(16))) unsigned kh_all[KS * kTile];  // dropout: the staged keys' hashed terms
+    __shared__ float merge[KS == 2 ? 4 * 64 * 18 : 1];                    // KS = 2: group 1's (acc[16], m, l) per lane
+    const int part = KS == 2 ? static_cast<int>(threadIdx.x >> 8) : 0, tl = threadIdx.x & 255;
+    __bf16 *Ks = Ks_all + part * SPC * kRmSize, *Vt = Vt_all + part * SPC * kTrSize;
+    unsigned *kh = kh_all + part * kTile;
+    const int lane = tl & 63, wave = tl >> 6, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
     const bool qv = q < a.Lq;
@@ -322,14 +334,18 @@ void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ 
     float m = -__builtin_inff(), l = 0.f;
     f32x16 acc = zero16();
 
-    Raw8<T> rk = tile_load<T>(K, a.k_rs, 0, a.Lk), rv = tile_load<T>(V, a.v_rs, 0, a.Lk);
-    for (int k0 = 0; k0 < a.Lk; k0 += kTile) {
+    // every group walks `trips` key tiles (the same count: the barriers are the workgroup's); a tile past the end is all padding
+    const int ntiles = (a.Lk + kTile - 1) / kTile, trips = (ntiles + KS - 1) / KS;
+    const int kfirst = part * trips * kTile;
+    Raw8<T> rk = tile_load<T>(K, a.k_rs, kfirst, a.Lk), rv = tile_load<T>(V, a.v_rs, kfirst, a.Lk);
+    for (int it = 0; it < trips; ++it) {
+        const int k0 = kfirst + it * kTile;
         __syncthreads();                                         // everyone is done reading the previous tile
         tile_store<T, true, false, SP>(rk, Ks, nullptr);
         tile_store<T, false, true, SP>(rv, nullptr, Vt);
-        if (DROP && threadIdx.x < kTile) kh[threadIdx.x] = drop_ks(k0 + threadIdx.x);
+        if (DROP && tl < kTile) kh[tl] = drop_ks(k0 + tl);
         __syncthreads();
-        if (k0 + kTile < a.Lk) {                                 // next tile's loads fly during this tile's math
+        if (it + 1 < trips) {                                    // next tile's loads fly during this tile's math
             rk = tile_load<T>(K, a.k_rs, k0 + kTile, a.Lk);
             rv = tile_load<T>(V, a.v_rs, k0 + kTile, a.Lk);
         }
@@ -382,6 +398,24 @@ void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ 
         }
     }
     l += __shfl_xor(l, 32);
+    if (KS == 2) {                                               // merge the two key ranges: group 1 hands over, group 0 finishes
+        float *mine = merge + (wave * 64 + lane) * 18;
+        __syncthreads();
+        if (part == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r] = acc[r];
+            mine[16] = m; mine[17] = l;
+        }
+        __syncthreads();
+        if (part == 1) return;
+        const float m1 = mine[16], l1 = mine[17];
+        const float mm = fmaxf(m, m1);
+        const float a0 = m == -__builtin_inff() ? 0.f : fast_exp2(m - mm), a1 = m1 == -__builtin_inff() ? 0.f : fast_exp2(m1 - mm);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = acc[r] * a0 + mine[r] * a1;
+        l = l * a0 + l1 * a1;
+        m = mm;
+    }
     if (qv) {
         const float inv = l > 0.f ? rinv / l : 0.f;              // fully masked row -> zeros; dropout's 1 / (1 - p) once per row
         T *o = out + (static_cast<int64_t>(b) * a.Lq + q) * (a.H * kD) + h * kD + 4 * half;
@@ -422,17 +456,22 @@ void attn_bwd_prep_kernel(const T *__restrict__ o, const T *__restrict__ d_o, fl
 // ------------------------------------------------------------------------------------------------
 // backward: dQ  (lane = query, loop over key tiles)
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool DROP>
-__global__ __launch_bounds__(256)
+template <typename T, bool DROP, int KS>
+__global__ __launch_bounds__(256 * KS)
 void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float *__restrict__ lse2,
                         const float *__restrict__ dsum, T *__restrict__ dq)
 {
     constexpr bool SP = sizeof(T) == 4;
-    __shared__ __attribute__((aligned(16))) __bf16 Ks[(SP ? 2 : 1) * kRmSize];
-    __shared__ __attribute__((aligned(16))) __bf16 Vs[(SP ? 2 : 1) * kRmSize];
-    __shared__ __attribute__((aligned(16))) __bf16 Kt[(SP ? 2 : 1) * kTrSize];
-    __shared__ __attribute__((aligned(16))) unsigned kh[kTile];           // dropout: the staged keys' hashed terms
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    constexpr int SPC = SP ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) __bf16 Ks_all[KS * SPC * kRmSize];
+    __shared__ __attribute__((aligned(16))) __bf16 Vs_all[KS * SPC * kRmSize];
+    __shared__ __attribute__((aligned(16))) __bf16 Kt_all[KS * SPC * kTrSize];
+    __shared__ __attribute__((aligned(16))) unsigned kh_all[KS * kTile];  // dropout: the staged keys' hashed terms
+    __shared__ float merge[KS == 2 ? 4 * 64 * 16 : 1];                    // KS = 2 (see attn_fwd_kernel): group 1's accumulator
+    const int part = KS == 2 ? static_cast<int>(threadIdx.x >> 8) : 0, tl = threadIdx.x & 255;
+    __bf16 *Ks = Ks_all + part * SPC * kRmSize, *Vs = Vs_all + part * SPC * kRmSize, *Kt = Kt_all + part * SPC * kTrSize;
+    unsigned *kh = kh_all + part * kTile;
+    const int lane = tl & 63, wave = tl >> 6, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
     const bool qv = q < a.Lq;
@@ -456,14 +495,17 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
     const float rinv = DROP ? 1.f / (1.f - a.dropout_p) : 1.f;
     f32x16 acc = zero16();
 
-    Raw8<T> rk = tile_load<T>(K, a.k_rs, 0, a.Lk), rv = tile_load<T>(V, a.v_rs, 0, a.Lk);
-    for (int k0 = 0; k0 < a.Lk; k0 += kTile) {
+    const int ntiles = (a.Lk + kTile - 1) / kTile, trips = (ntiles + KS - 1) / KS;
+    const int kfirst = part * trips * kTile;
+    Raw8<T> rk = tile_load<T>(K, a.k_rs, kfirst, a.Lk), rv = tile_load<T>(V, a.v_rs, kfirst, a.Lk);
+    for (int it = 0; it < trips; ++it) {
+        const int k0 = kfirst + it * kTile;
         __syncthreads();
         tile_store<T, true, true, SP>(rk, Ks, Kt);
         tile_store<T, true, false, SP>(rv, Vs, nullptr);
-        if (DROP && threadIdx.x < kTile) kh[threadIdx.x] = drop_ks(k0 + threadIdx.x);
+        if (DROP && tl < kTile) kh[tl] = drop_ks(k0 + tl);
         __syncthreads();
-        if (k0 + kTile < a.Lk) {
+        if (it + 1 < trips) {
             rk = tile_load<T>(K, a.k_rs, k0 + kTile, a.Lk);
             rv = tile_load<T>(V, a.v_rs, k0 + kTile, a.Lk);
         }
@@ -504,6 +546,18 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
             acc = mfmaX<SP>(frag_cols<SP>(Kt, sub, 0, lane), frag_acc<SP>(ds, 0), acc);   // dQ^T[d][query]
             acc = mfmaX<SP>(frag_cols<SP>(Kt, sub, 1, lane), frag_acc<SP>(ds, 1), acc);
         }
+    }
+    if (KS == 2) {
+        float *mine = merge + (wave * 64 + lane) * 16;
+        __syncthreads();
+        if (part == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[r] = acc[r];
+        }
+        __syncthreads();
+        if (part == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += mine[r];
     }
     if (qv) {
         T *o = dq + orow + 4 * half;
@@ -635,19 +689,33 @@ AttnArgs make_args(const AttnProblem &p)
 
 }  // namespace
 
+// two key ranges per workgroup (KS = 2) when the query tiles alone leave the chip under-occupied: bf16 only (the fp32 mode's
+// split operands double the staging buffers), several key tiles to share, fewer than 512 workgroups.  MDETR_ATTN_KSPLIT=0 / 1 forces.
+bool key_split(const AttnProblem &p)
+{
+    if (p.dtype == 0 || p.Lk < 4 * kTile) return false;
+    if (const char *ev = getenv("MDETR_ATTN_KSPLIT")) return ev[0] == '1';
+    return static_cast<int64_t>((p.Lq + 127) / 128) * p.H * p.B < 512;
+}
+
 hipError_t attn_forward_launch(const AttnProblem &p, void *out, float *lse2, hipStream_t st)
 {
     if (p.B == 0 || p.Lq == 0) return hipSuccess;
     const AttnArgs a = make_args(p);
-    const dim3 grid((p.Lq + 127) / 128, p.H, p.B), block(256);
+    const dim3 grid((p.Lq + 127) / 128, p.H, p.B);
+    const bool split = key_split(p);
+    const dim3 block(split ? 512 : 256);
     profile_begin(4, p.Lq * 4096 + (p.Lk < 4096 ? p.Lk : 4095), st);
     const bool drop = p.dropout_p > 0.f;
     if (p.dtype == 0) {
-        if (drop) hipLaunchKernelGGL((attn_fwd_kernel<float, true>), grid, block, 0, st, a, static_cast<float *>(out), lse2);
-        else hipLaunchKernelGGL((attn_fwd_kernel<float, false>), grid, block, 0, st, a, static_cast<float *>(out), lse2);
+        if (drop) hipLaunchKernelGGL((attn_fwd_kernel<float, true, 1>), grid, block, 0, st, a, static_cast<float *>(out), lse2);
+        else hipLaunchKernelGGL((attn_fwd_kernel<float, false, 1>), grid, block, 0, st, a, static_cast<float *>(out), lse2);
+    } else if (split) {
+        if (drop) hipLaunchKernelGGL((attn_fwd_kernel<__bf16, true, 2>), grid, block, 0, st, a, static_cast<__bf16 *>(out), lse2);
+        else hipLaunchKernelGGL((attn_fwd_kernel<__bf16, false, 2>), grid, block, 0, st, a, static_cast<__bf16 *>(out), lse2);
     } else {
-        if (drop) hipLaunchKernelGGL((attn_fwd_kernel<__bf16, true>), grid, block, 0, st, a, static_cast<__bf16 *>(out), lse2);
-        else hipLaunchKernelGGL((attn_fwd_kernel<__bf16, false>), grid, block, 0, st, a, static_cast<__bf16 *>(out), lse2);
+        if (drop) hipLaunchKernelGGL((attn_fwd_kernel<__bf16, true, 1>), grid, block, 0, st, a, static_cast<__bf16 *>(out), lse2);
+        else hipLaunchKernelGGL((attn_fwd_kernel<__bf16, false, 1>), grid, block, 0, st, a, static_cast<__bf16 *>(out), lse2);
     }
     profile_end(st);
     return hipGetLastError();
@@ -667,16 +735,20 @@ hipError_t attn_backward_launch(const AttnProblem &p, const void *out, const voi
         if (items) hipLaunchKernelGGL(attn_bwd_prep_kernel<float>, dim3(static_cast<unsigned>((items * 8 + 255) / 256)), block, 0, st,
                                       static_cast<const float *>(out), static_cast<const float *>(d_out), dsum, p.B, p.H, p.Lq);
         const float *go = static_cast<const float *>(d_out);
-        if (p.Lq && drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<float, true>), gq, block, 0, st, a, go, lse2, dsum, static_cast<float *>(dq));
-        if (p.Lq && !drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<float, false>), gq, block, 0, st, a, go, lse2, dsum, static_cast<float *>(dq));
+        if (p.Lq && drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<float, true, 1>), gq, block, 0, st, a, go, lse2, dsum, static_cast<float *>(dq));
+        if (p.Lq && !drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<float, false, 1>), gq, block, 0, st, a, go, lse2, dsum, static_cast<float *>(dq));
         if (p.Lk && drop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<float, true>), gk, block, 0, st, a, go, lse2, dsum, static_cast<float *>(dk), static_cast<float *>(dv));
         if (p.Lk && !drop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<float, false>), gk, block, 0, st, a, go, lse2, dsum, static_cast<float *>(dk), static_cast<float *>(dv));
     } else {
         if (items) hipLaunchKernelGGL(attn_bwd_prep_kernel<__bf16>, dim3(static_cast<unsigned>((items * 8 + 255) / 256)), block, 0, st,
                                       static_cast<const __bf16 *>(out), static_cast<const __bf16 *>(d_out), dsum, p.B, p.H, p.Lq);
         const __bf16 *go = static_cast<const __bf16 *>(d_out);
-        if (p.Lq && drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<__bf16, true>), gq, block, 0, st, a, go, lse2, dsum, static_cast<__bf16 *>(dq));
-        if (p.Lq && !drop) hipLaunchKernelGGL((attn_bwd_dq_kernel<__bf16, false>), gq, block, 0, st, a, go, lse2, dsum, static_cast<__bf16 *>(dq));
+        const bool split = key_split(p);
+        const dim3 bq(split ? 512 : 256);
+        if (p.Lq && drop && split) hipLaunchKernelGGL((attn_bwd_dq_kernel<__bf16, true, 2>), gq, bq, 0, st, a, go, lse2, dsum, static_cast<__bf16 *>(dq));
+        if (p.Lq && !drop && split) hipLaunchKernelGGL((attn_bwd_dq_kernel<__bf16, false, 2>), gq, bq, 0, st, a, go, lse2, dsum, static_cast<__bf16 *>(dq));
+        if (p.Lq && drop && !split) hipLaunchKernelGGL((attn_bwd_dq_kernel<__bf16, true, 1>), gq, bq, 0, st, a, go, lse2, dsum, static_cast<__bf16 *>(dq));
+        if (p.Lq && !drop && !split) hipLaunchKernelGGL((attn_bwd_dq_kernel<__bf16, false, 1>), gq, bq, 0, st, a, go, lse2, dsum, static_cast<__bf16 *>(dq));
         if (p.Lk && drop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<__bf16, true>), gk, block, 0, st, a, go, lse2, dsum, static_cast<__bf16 *>(dk), static_cast<__bf16 *>(dv));
         if (p.Lk && !drop) hipLaunchKernelGGL((attn_bwd_dkv_kernel<__bf16, false>), gk, block, 0, st, a, go, lse2, dsum, static_cast<__bf16 *>(dk), static_cast<__bf16 *>(dv));
     }

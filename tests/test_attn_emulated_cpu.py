@@ -53,3 +53,26 @@ def test_emulated_attention_dropout_uses_the_documented_hash(ext):
     assert (out.double() - ref).abs().max() < 2e-4 * max(1.0, ref.abs().max().item())
     for g, r in ((q.grad, qd.grad), (k.grad, kd.grad), (v.grad, vd.grad)):
         assert (g.double() - r).abs().max() < 5e-4 * max(1.0, r.abs().max().item())
+
+
+@pytest.mark.parametrize("masked,p", [(False, 0.0), (True, 0.1)])
+def test_emulated_attention_with_the_key_range_split_over_two_wave_groups(ext, masked, p):
+    """Few query tiles and several key tiles (the decoder's 550 x 1920 in small): the bf16 forward and dQ kernels put two 4-wave
+    groups into a workgroup, each walking half of the key tiles, and merge the partial softmax states through LDS -- against the
+    fp64 reference with the documented dropout mask, a ragged last tile (330 = 5 tiles + 10 keys: the second group's last tile is
+    all padding) and a key-padding mask."""
+    torch.manual_seed(11)
+    B, H, Lq, Lk, seed = 2, 2, 70, 330, 0x0FEDCBA987654321
+    E = H * 32
+    q, k, v = (torch.randn(B, L, E).to(torch.bfloat16).requires_grad_(True) for L in (Lq, Lk, Lk))
+    go = torch.randn(B, Lq, E).to(torch.bfloat16)
+    kpm = (torch.rand(B, Lk) < 0.3) if masked else None
+    out = ext.fused_attention(q, k, v, H, dropout_p=p, seed=seed if p > 0 else None, key_padding_mask=kpm)
+    out.backward(go)
+    keep = keep_mask(seed, B, H, Lq, Lk, p) if p > 0 else None
+    qd, kd, vd = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    ref = reference(qd, kd, vd, H, kpm, keep, p)
+    ref.backward(go.double())
+    assert (out.double() - ref).abs().max() < 2e-2 * max(1.0, ref.abs().max().item())
+    for g, r, name in ((q.grad, qd.grad, "dq"), (k.grad, kd.grad, "dk"), (v.grad, vd.grad, "dv")):
+        assert (g.double() - r).abs().max() < 3e-2 * max(1.0, r.abs().max().item()), name
