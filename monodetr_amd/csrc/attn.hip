@@ -298,8 +298,8 @@ __device__ __forceinline__ void own_row_frags(const T *rowp, bool valid, float m
 // DROP: dropout on the probabilities, a compile-time property of the kernel -- as a run-time flag it put a scalar branch
 // around every element's hash (16 per sub-tile), which kept the exponentials, the hash and the conversions of
 // neighbouring elements from being scheduled together.  The 1 / (1 - p) rescale is applied once to the output.
-// KS: key split.  With few queries (the decoder's 550: 5 query tiles x 8 heads x 8 images = 320 workgroups, 1 280 waves for 1 024
-// SIMDs) a wave per SIMD has nothing to overlap its exponentials with.  KS = 2 puts two 4-wave groups into a workgroup: both own
+// KS: key split (an experiment, off by default: see key_split()).  With few queries (the decoder's 550: 5 query tiles x 8 heads x
+// 8 images = 320 workgroups, 1 280 waves for 1 024 SIMDs) a SIMD holds about one wave.  KS = 2 puts two 4-wave groups into a workgroup: both own
 // the SAME 128 queries, each walks half of the key tiles with its own staging buffers, and the two partial results
 // (running maximum, sum, accumulator) are merged through LDS at the end -- twice the waves, no second launch.
 template <typename T, bool DROP, int KS>
@@ -689,13 +689,15 @@ AttnArgs make_args(const AttnProblem &p)
 
 }  // namespace
 
-// two key ranges per workgroup (KS = 2) when the query tiles alone leave the chip under-occupied: bf16 only (the fp32 mode's
-// split operands double the staging buffers), several key tiles to share, fewer than 512 workgroups.  MDETR_ATTN_KSPLIT=0 / 1 forces.
+// two key ranges per workgroup (KS = 2): bf16 only (the fp32 mode's split operands double the staging buffers), several key tiles
+// to share.  OFF unless MDETR_ATTN_KSPLIT=1: measured on the case it was written for (B = 8, 550 x 1920, dropout 0.1) the forward
+// went from 0.056 to 0.061 ms and the backward did not move (profiles/r03z_attnbench_ks{0,auto}.json) -- the 8-wave workgroup's
+// barriers and the merge cost more than the second wave per SIMD hides.
 bool key_split(const AttnProblem &p)
 {
     if (p.dtype == 0 || p.Lk < 4 * kTile) return false;
-    if (const char *ev = getenv("MDETR_ATTN_KSPLIT")) return ev[0] == '1';
-    return static_cast<int64_t>((p.Lq + 127) / 128) * p.H * p.B < 512;
+    const char *ev = getenv("MDETR_ATTN_KSPLIT");
+    return ev && ev[0] == '1';
 }
 
 hipError_t attn_forward_launch(const AttnProblem &p, void *out, float *lse2, hipStream_t st)

@@ -56,11 +56,12 @@ def test_emulated_attention_dropout_uses_the_documented_hash(ext):
 
 
 @pytest.mark.parametrize("masked,p", [(False, 0.0), (True, 0.1)])
-def test_emulated_attention_with_the_key_range_split_over_two_wave_groups(ext, masked, p):
+def test_emulated_attention_with_the_key_range_split_over_two_wave_groups(ext, masked, p, monkeypatch):
     """Few query tiles and several key tiles (the decoder's 550 x 1920 in small): the bf16 forward and dQ kernels put two 4-wave
     groups into a workgroup, each walking half of the key tiles, and merge the partial softmax states through LDS -- against the
     fp64 reference with the documented dropout mask, a ragged last tile (330 = 5 tiles + 10 keys: the second group's last tile is
     all padding) and a key-padding mask."""
+    monkeypatch.setenv("MDETR_ATTN_KSPLIT", "1")                 # (the launcher reads it per call; off by default: measured slower)
     torch.manual_seed(11)
     B, H, Lq, Lk, seed = 2, 2, 70, 330, 0x0FEDCBA987654321
     E = H * 32
