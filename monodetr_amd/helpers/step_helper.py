@@ -101,6 +101,8 @@ class TrainIteration:
         return total, losses
 
     def _forward_backward(self, batch):
+        # set_to_none (not zero-fill): the flat gradient exchanges re-point every parameter's .grad at slices of their reduced
+        # buffer (helpers/dist_helper.py); a kept-and-zeroed .grad would make the next backward ACCUMULATE into that slice
         self.optimizer.zero_grad(set_to_none=True)
         scoped = self.device.type == "cuda"
         if scoped:                                            # one device-side dropout-seed bump for the whole iteration
