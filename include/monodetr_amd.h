@@ -533,6 +533,16 @@ int mdetr_bias_act_backward(int io_dtype, const void *dy, const void *y, void *d
  *   backward = 1: src = dy [B, (H + 1) / 2, (W + 1) / 2, C] -> dst = dx [B, H, W, C], zero at the skipped pixels
  * pixel_bytes = C * element size (any element type), a multiple of 16; pointers 16-byte aligned.
  */
+/*
+ * Gather of many dense device tensors into one flat device buffer (the optimizer's flat gradient buffer; the reference's AdamW
+ * walks parameters one by one, lib/helpers/optimizer_helper.py:69-129).  HOST arrays: src_ptrs[ntensors] (device addresses; they
+ * travel as kernel arguments, 256 per launch) and tensor_block_begin[ntensors + 1] (first workgroup of each tensor).  DEVICE
+ * arrays: dst_offsets[i] / nbytes[i], the place and size of tensor i in bytes, and one entry per workgroup -- block_tensor[b],
+ * block_start[b]: workgroup b copies bytes [block_start[b], + chunk_bytes) of its tensor (clipped to the tensor's size).
+ */
+int mdetr_gather_flat(const void *const *src_ptrs, int ntensors, const int *tensor_block_begin, void *dst, const int64_t *dst_offsets,
+                      const int64_t *nbytes, const int *block_tensor, const int64_t *block_start, int chunk_bytes, int device, void *stream);
+
 /* torchvision ResNet.maxpool (3x3 / stride 2 / pad 1) on a channels-last bf16 activation, forward only (the stem is frozen):
  * x [B, H, W, C] -> y [B, (H - 1) / 2 + 1, (W - 1) / 2 + 1, C]; C a multiple of 8, 16-byte aligned pointers. */
 int mdetr_maxpool3x3s2_bf16(const void *x, void *y, int B, int H, int W, int C, int device, void *stream);

@@ -70,6 +70,7 @@ SIGNATURES = {
     "mdetr_msda_forward_bf16": (_c_int, [_c_vp] * 6 + [_c_int] * 7 + [_c_int, _c_vp]),
     "mdetr_msda_backward_bf16": (_c_int, [_c_vp] * 9 + [_c_int] * 7 + [_c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_vp]),
     "mdetr_msda_prologue_forward": (_c_int, [_c_int, _c_int] + [_c_vp] * 6 + [_c_int] * 6 + [ctypes.c_int64] * 3 + [_c_int, _c_vp]),
+    "mdetr_gather_flat": (_c_int, [_c_vp, _c_int] + [_c_vp] * 6 + [_c_int, _c_int, _c_vp]),
     "mdetr_maxpool3x3s2_bf16": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mdetr_decimate2": (_c_int, [_c_int, _c_vp, _c_vp, _c_int, _c_int, _c_int, ctypes.c_int64, _c_int, _c_vp]),
     "mdetr_msda_prologue_forward_packed": (_c_int, [_c_int, _c_int] + [_c_vp] * 5 + [_c_int] * 6 + [ctypes.c_int64] * 3 + [_c_int, _c_vp]),

@@ -673,6 +673,22 @@ int mdetr_decimate2(int backward, const void *src, void *dst, int B, int H, int 
     return MDETR_OK;
 }
 
+int mdetr_gather_flat(const void *const *src_ptrs, int ntensors, const int *tensor_block_begin, void *dst, const int64_t *dst_offsets,
+                      const int64_t *nbytes, const int *block_tensor, const int64_t *block_start, int chunk_bytes, int device, void *stream)
+{
+    if (ntensors < 0 || chunk_bytes <= 0 || chunk_bytes % 16 != 0) return fail(MDETR_E_ARG, "mdetr_gather_flat: ntensors %d / chunk_bytes %d (a positive multiple of 16)", ntensors, chunk_bytes);
+    if (ntensors == 0) return MDETR_OK;
+    if (!src_ptrs || !tensor_block_begin || !dst || !dst_offsets || !nbytes || !block_tensor || !block_start) return fail(MDETR_E_ARG, "mdetr_gather_flat: null pointer");
+    for (int i = 0; i < ntensors; ++i)
+        if (!src_ptrs[i] || tensor_block_begin[i + 1] < tensor_block_begin[i]) return fail(MDETR_E_ARG, "mdetr_gather_flat: tensor %d: null source or decreasing block table", i);
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_gather_flat: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::gather_flat_launch(src_ptrs, ntensors, tensor_block_begin, dst, dst_offsets, nbytes, block_tensor, block_start, chunk_bytes,
+                                                   static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_gather_flat: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
 int mdetr_maxpool3x3s2_bf16(const void *x, void *y, int B, int H, int W, int C, int device, void *stream)
 {
     if (B < 0 || H < 0 || W < 0 || C <= 0 || C % 8 != 0) return fail(MDETR_E_ARG, "mdetr_maxpool3x3s2_bf16: B=%d H=%d W=%d C=%d (C a positive multiple of 8)", B, H, W, C);

@@ -97,6 +97,37 @@ void maxpool3x3s2_bf16_kernel(const uint4 *__restrict__ x, uint4 *__restrict__ y
     y[i] = o;
 }
 
+// ---- gather of many dense tensors into one flat buffer (the optimizer's flat gradient buffer, helpers/optimizer_helper.FusedAdamW:
+// the reference's AdamW walks the parameters one by one, optimizer_helper.py:69-129).  The framework's multi-tensor copy moves the
+// 124 MB of gradients at 1.2 TB/s in six launches (0.21 ms per iteration); here a block owns one chunk of one tensor: table
+// blk_tensor / blk_start (built once, on the device); the per-tensor SOURCE pointers travel as a kernel argument (autograd allocates
+// gradients anew each iteration: no device table to refresh, nothing to race with, and a captured graph bakes them into its node),
+// kGatherPtrs tensors per launch.  16-byte vectors when source and destination of the chunk allow, elements otherwise.
+constexpr int kGatherPtrs = 256;
+struct GatherPtrs { const unsigned char *p[kGatherPtrs]; };
+
+__global__ __launch_bounds__(256)
+void gather_flat_kernel(const GatherPtrs src, int tensor0, int block0, unsigned char *__restrict__ dst, const int64_t *__restrict__ dst_off,
+                        const int64_t *__restrict__ nbytes, const int *__restrict__ blk_tensor, const int64_t *__restrict__ blk_start, int chunk_bytes)
+{
+    const int b = block0 + static_cast<int>(blockIdx.x);
+    const int i = blk_tensor[b];
+    const int64_t s0 = blk_start[b];
+    const int64_t left = nbytes[i] - s0;
+    const int cnt = static_cast<int>(left < chunk_bytes ? left : chunk_bytes);
+    const unsigned char *sp = src.p[i - tensor0] + s0;
+    unsigned char *dp = dst + dst_off[i] + s0;
+    if (((reinterpret_cast<uintptr_t>(sp) | reinterpret_cast<uintptr_t>(dp)) & 15) == 0) {
+        const int nv = cnt >> 4;
+        for (int k = threadIdx.x; k < nv; k += 256) reinterpret_cast<uint4 *>(dp)[k] = reinterpret_cast<const uint4 *>(sp)[k];
+        for (int k = (nv << 4) + threadIdx.x; k < cnt; k += 256) dp[k] = sp[k];
+    } else if (((reinterpret_cast<uintptr_t>(sp) | reinterpret_cast<uintptr_t>(dp) | cnt) & 1) == 0) {
+        for (int k = threadIdx.x; k < (cnt >> 1); k += 256) reinterpret_cast<unsigned short *>(dp)[k] = reinterpret_cast<const unsigned short *>(sp)[k];
+    } else {
+        for (int k = threadIdx.x; k < cnt; k += 256) dp[k] = sp[k];
+    }
+}
+
 DecDims dims(int B, int H, int W, int64_t pixel_bytes)
 {
     DecDims d;
@@ -131,6 +162,23 @@ hipError_t decimate2_backward_launch(const void *dy, void *dx, int B, int H, int
     hipLaunchKernelGGL(decimate2_bwd_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st,
                        static_cast<const uint4 *>(dy), static_cast<uint4 *>(dx), d);
     return hipGetLastError();
+}
+
+hipError_t gather_flat_launch(const void *const *src_host, int ntensors, const int *tensor_block_begin_host, void *dst, const int64_t *dst_off,
+                              const int64_t *nbytes, const int *blk_tensor, const int64_t *blk_start, int chunk_bytes, hipStream_t st)
+{
+    for (int t0 = 0; t0 < ntensors; t0 += kGatherPtrs) {
+        const int t1 = t0 + kGatherPtrs < ntensors ? t0 + kGatherPtrs : ntensors;
+        const int b0 = tensor_block_begin_host[t0], b1 = tensor_block_begin_host[t1];
+        if (b1 <= b0) continue;
+        GatherPtrs ptrs;
+        for (int i = 0; i < kGatherPtrs; ++i) ptrs.p[i] = t0 + i < t1 ? static_cast<const unsigned char *>(src_host[t0 + i]) : nullptr;
+        hipLaunchKernelGGL(gather_flat_kernel, dim3(static_cast<unsigned>(b1 - b0)), dim3(256), 0, st, ptrs, t0, b0,
+                           static_cast<unsigned char *>(dst), dst_off, nbytes, blk_tensor, blk_start, chunk_bytes);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t maxpool3x3s2_bf16_launch(const void *x, void *y, int B, int H, int W, int C, hipStream_t st)

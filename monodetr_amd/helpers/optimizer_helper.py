@@ -21,6 +21,7 @@ a hipGraph and replayed: a replay advances the count and applies the right bias 
 any host code running.
 """
 import math
+import os
 
 import torch
 import torch.optim as optim
@@ -206,6 +207,7 @@ class FusedAdamW(AdamW):
     multi-tensor copy and launches the update.  CUDA parameters only; amsgrad, sparse gradients and CPU
     parameters take the parent's path.  """
 
+    _GATHER_CHUNK = 32768        # bytes of one tensor a workgroup of the gradient gather copies
     _PAD = 64                                    # elements: 256 B for fp32 segments, 128 B for bf16
 
     def __init__(self, *args, **kwargs):
@@ -213,6 +215,9 @@ class FusedAdamW(AdamW):
         self._flat = None
         self._lib = None                         # tests substitute a host build of the same kernel arithmetic
         self._allow_cpu = False
+        # MDETR_ADAMW_GATHER=0: the flat gradient buffer is filled by the framework's multi-tensor copy (six launches, 0.21 ms per
+        # iteration of the bench model) instead of csrc/decimate.hip's gather (one launch per flat buffer over a block table)
+        self._gather = os.environ.get("MDETR_ADAMW_GATHER", "1") != "0"
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)      # AdamW.load_state_dict: keeps the saved dtypes
@@ -288,6 +293,25 @@ class FusedAdamW(AdamW):
                 if len(steps) != 1:
                     raise RuntimeError("FusedAdamW: the parameters of a flat group must have taken the same number of steps")
                 buf['grad_views'], buf['step'] = grad_views, steps.pop()
+                if dev.type == "cuda":
+                    # tables of the flat gradient gather (csrc/decimate.hip gather_flat_kernel): one 32 KB chunk of one tensor per workgroup
+                    esz = buf['grad'].element_size()
+                    chunk, bt, bs = self._GATHER_CHUNK, [], []
+                    for i, (p, off) in enumerate(zip(plist, offs)):
+                        for s0 in range(0, p.numel() * esz, chunk):
+                            bt.append(i)
+                            bs.append(s0)
+                    begin, nb = [], 0
+                    for i, p in enumerate(plist):
+                        begin.append(nb)
+                        nb += -(-(p.numel() * esz) // chunk)
+                    begin.append(nb)
+                    import ctypes
+                    buf['gather'] = dict(
+                        dst_off=torch.tensor([o * esz for o in offs], dtype=torch.int64, device=dev),
+                        nbytes=torch.tensor([p.numel() * esz for p in plist], dtype=torch.int64, device=dev),
+                        blk_tensor=torch.tensor(bt, dtype=torch.int32, device=dev), blk_start=torch.tensor(bs, dtype=torch.int64, device=dev),
+                        begin=(ctypes.c_int * len(begin))(*begin), ptrs=(ctypes.c_void_p * len(plist))())
                 flat.append(buf)
         self._flat = (self._signature(), flat)
 
@@ -311,7 +335,23 @@ class FusedAdamW(AdamW):
             for p in buf['params']:
                 g = p.grad
                 grads.append(g if g.stride() == p.stride() else torch.empty_like(p).copy_(g))
-            torch._foreach_copy_(buf['grad_views'], grads)
+            gather = buf.get('gather') if self._gather else None
+            gfn = getattr(lib, "mdetr_gather_flat", None) if gather is not None else None
+            if gfn is not None:
+                # the gradients' base addresses travel as kernel arguments (autograd allocates them anew each iteration; a captured
+                # graph bakes them into its node): nothing on the device to refresh
+                ptrs = gather['ptrs']
+                for i, g in enumerate(grads):
+                    ptrs[i] = g.data_ptr()
+                gdev = buf['grad'].device
+                rc = gfn(ptrs, len(grads), gather['begin'], buf['grad'].data_ptr(), gather['dst_off'].data_ptr(), gather['nbytes'].data_ptr(),
+                         gather['blk_tensor'].data_ptr(), gather['blk_start'].data_ptr(), self._GATHER_CHUNK,
+                         gdev.index, torch.cuda.current_stream(gdev).cuda_stream)
+                if rc != 0:
+                    _capi.check(rc, "mdetr_gather_flat")
+                buf['_keep'] = grads                              # the launch reads them: alive until the next step replaces the list
+            else:
+                torch._foreach_copy_(buf['grad_views'], grads)
             buf['step'] += 1
             t = buf['step']
             for p in buf['params']:

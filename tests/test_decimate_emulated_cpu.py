@@ -63,3 +63,36 @@ def test_maxpool_matches_the_framework(ext, B, C, H, W):
     want = F.max_pool2d(x.float(), 3, 2, 1).to(torch.bfloat16)
     assert y.shape == want.shape and y.is_contiguous(memory_format=torch.channels_last) and torch.equal(y, want)
     assert not ext.maxpool_supported(x.clone().requires_grad_(True))          # forward only: anything that needs a gradient stays with torch
+
+
+def test_flat_gather_of_many_tensors(ext):
+    """mdetr_gather_flat (the optimizer's flat gradient buffer): tensors of odd sizes and alignments, more than one launch's worth of
+    them (256 pointers per launch), several chunks per tensor -- every byte lands at its offset, the padding between stays."""
+    import ctypes
+    lib = native_emul.lib()
+    g = torch.Generator().manual_seed(3)
+    sizes = [1, 7, 64, 4097, 30000, 3] + [5 + (i * 37) % 211 for i in range(300)]
+    esz, chunk, pad = 2, 4096, 64
+    srcs, offs, total = [], [], 0
+    for i, n in enumerate(sizes):
+        base = torch.randn(n + 3, generator=g).to(torch.bfloat16)
+        srcs.append(base[(i % 3):(i % 3) + n])                                   # bases at 0, 2 and 4 bytes past an allocation
+        offs.append(total)
+        total += -(-n // pad) * pad
+    flat = torch.full((total,), 7.0, dtype=torch.bfloat16)
+    bt, bs, begin = [], [], []
+    for i, n in enumerate(sizes):
+        begin.append(len(bt))
+        for s0 in range(0, n * esz, chunk):
+            bt.append(i); bs.append(s0)
+    begin.append(len(bt))
+    dst_off = torch.tensor([o * esz for o in offs], dtype=torch.int64)
+    nbytes = torch.tensor([n * esz for n in sizes], dtype=torch.int64)
+    blk_t, blk_s = torch.tensor(bt, dtype=torch.int32), torch.tensor(bs, dtype=torch.int64)
+    ptrs = (ctypes.c_void_p * len(sizes))(*[t.data_ptr() for t in srcs])
+    rc = lib.mdetr_gather_flat(ptrs, len(sizes), (ctypes.c_int * len(begin))(*begin), flat.data_ptr(), dst_off.data_ptr(), nbytes.data_ptr(),
+                               blk_t.data_ptr(), blk_s.data_ptr(), chunk, -1, None)
+    assert rc == 0
+    for t, o, n in zip(srcs, offs, sizes):
+        assert torch.equal(flat[o:o + n], t)
+        assert bool((flat[o + n:o + -(-n // pad) * pad] == 7.0).all())
