@@ -215,9 +215,11 @@ class FusedAdamW(AdamW):
         self._flat = None
         self._lib = None                         # tests substitute a host build of the same kernel arithmetic
         self._allow_cpu = False
-        # MDETR_ADAMW_GATHER=0: the flat gradient buffer is filled by the framework's multi-tensor copy (six launches, 0.21 ms per
-        # iteration of the bench model) instead of csrc/decimate.hip's gather (one launch per flat buffer over a block table)
-        self._gather = os.environ.get("MDETR_ADAMW_GATHER", "1") != "0"
+        # MDETR_ADAMW_GATHER=1: the flat gradient buffer is filled by csrc/decimate.hip's gather (one launch per flat buffer over a
+        # block table) instead of the framework's multi-tensor copy.  Off: measured 388.2 vs 387.5 img/s under graph replay (noise)
+        # and 279.8 vs 286.3 launched eagerly -- filling 307 pointers from Python costs more than the copy kernels it saves
+        # (profiles/r03g2_bench_*.json)
+        self._gather = os.environ.get("MDETR_ADAMW_GATHER") == "1"
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)      # AdamW.load_state_dict: keeps the saved dtypes
