@@ -90,8 +90,15 @@ __device__ __forceinline__ void conv_taps_body(const __bf16 *__restrict__ x, con
         for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
 
     constexpr int T = kWavesT * 64;
-    constexpr int WP = (TS * NB * 32 * (kSlabT / 8) + T - 1) / T;            // weight pieces per thread
-    constexpr int HP = (HH * HWC * (kSlabT / 8) + T - 1) / T;                // halo pieces per thread
+    // staging tasks: a 16-lane group takes 16 CONSECUTIVE LDS rows (weight rows, halo pixels in slot order) at one 16-byte piece --
+    // rows are 20 dwords apart, so its ds_write_b128 lands on 16 distinct bank quads; the four groups of a wave take the four pieces
+    // of the same rows, so one global load instruction still covers 64 contiguous bytes of each of its 16 rows.  (Consecutive
+    // lanes = the pieces of one row put 4 rows on 16 lanes: rows 0 and 3 share banks; 27 - 38 % of the LDS cycles were conflicts,
+    // profiles/r03_pmc_conv_strided_after.json.)
+    constexpr int kGroup = 16 * kPiecesT;                                    // tasks per 16 rows
+    constexpr int WROWS = (TS * NB * 32 + 15) / 16 * 16, HROWS = (HH * HWC + 15) / 16 * 16;
+    constexpr int WP = (WROWS * kPiecesT + T - 1) / T;                       // weight pieces per thread
+    constexpr int HP = (HROWS * kPiecesT + T - 1) / T;                       // halo pieces per thread
     bf16x8 wreg[WP];
     auto zero8 = []() { bf16x8 v;
 #pragma unroll
@@ -100,7 +107,7 @@ __device__ __forceinline__ void conv_taps_body(const __bf16 *__restrict__ x, con
     auto fetch_w = [&](int k0, int a) {                                      // [e][n][64 k] <- w[n0 + n][tap a][tap e][k0 .. k0 + 64)
 #pragma unroll
         for (int j = 0; j < WP; ++j) {
-            const int p = threadIdx.x + j * T, piece = p % kPiecesT, row = p / kPiecesT;  // row = e * NB*32 + n
+            const int p = threadIdx.x + j * T, piece = (p / 16) % kPiecesT, row = p / kGroup * 16 + p % 16;  // row = e * NB*32 + n
             const int e = row / (NB * 32), n = row - e * (NB * 32);
             bf16x8 v = zero8();
             if (row < TS * NB * 32 && n0 + n < d.N)
@@ -112,8 +119,8 @@ __device__ __forceinline__ void conv_taps_body(const __bf16 *__restrict__ x, con
     auto store_w = [&]() {
 #pragma unroll
         for (int j = 0; j < WP; ++j) {
-            const int p = threadIdx.x + j * T;
-            if (p < TS * NB * 32 * (kSlabT / 8)) *reinterpret_cast<bf16x8 *>(wts + (p / kPiecesT) * kPadT + (p % kPiecesT) * 8) = wreg[j];
+            const int p = threadIdx.x + j * T, piece = (p / 16) % kPiecesT, row = p / kGroup * 16 + p % 16;
+            if (row < TS * NB * 32) *reinterpret_cast<bf16x8 *>(wts + row * kPadT + piece * 8) = wreg[j];
         }
     };
     // halo: global -> registers -> LDS in one go at each slab boundary (HP pieces per thread: up to 19 with SI = 2, too many to
@@ -126,8 +133,9 @@ __device__ __forceinline__ void conv_taps_body(const __bf16 *__restrict__ x, con
             for (int jj = 0; jj < 8; ++jj) {
                 const int j = j0 + jj;
                 if (j >= HP) break;
-                const int p = threadIdx.x + j * T, piece = p % kPiecesT, pix = p / kPiecesT;
-                const int hr = pix / HWC, hc = pix - hr * HWC;
+                const int p = threadIdx.x + j * T, piece = (p / 16) % kPiecesT, pix = p / kGroup * 16 + p % 16;   // pix = LDS row: hr * HWC + slot
+                const int hr = pix / HWC, slot_ = pix - hr * HWC;
+                const int hc = SI == 2 ? (slot_ < PLANE ? 2 * slot_ : 2 * (slot_ - PLANE) + 1) : slot_;
                 const int r = SI * r0 + hr - d.PT, c = SI * c0 + hc - d.PL;
                 // (a single tap at stride 2 reads only the even rows / columns of its halo: the others are not fetched)
                 const bool used = !(SI == 2 && TS == 1 && (hc & 1)) && !(SI == 2 && TR == 1 && (hr & 1));
@@ -138,10 +146,8 @@ __device__ __forceinline__ void conv_taps_body(const __bf16 *__restrict__ x, con
             for (int jj = 0; jj < 8; ++jj) {
                 const int j = j0 + jj;
                 if (j >= HP) break;
-                const int p = threadIdx.x + j * T, piece = p % kPiecesT, pix = p / kPiecesT;
-                const int hr = pix / HWC, hc = pix - hr * HWC;
-                const int slot = SI == 2 ? (hc & 1) * PLANE + (hc >> 1) : hc;
-                if (pix < HH * HWC) *reinterpret_cast<bf16x8 *>(halo + (hr * HWC + slot) * kPadT + piece * 8) = hreg[jj];
+                const int p = threadIdx.x + j * T, piece = (p / 16) % kPiecesT, pix = p / kGroup * 16 + p % 16;
+                if (pix < HH * HWC) *reinterpret_cast<bf16x8 *>(halo + pix * kPadT + piece * 8) = hreg[jj];
             }
         }
     };
