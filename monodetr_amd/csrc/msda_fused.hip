@@ -856,11 +856,13 @@ void msda_finalize_kernel(const FusedPlan pl, const float *__restrict__ scratch,
         if (pl.mode[l] != 1) continue;
         const int hw = pl.H[l] * pl.W[l];
         const int64_t n = static_cast<int64_t>(pl.B) * hw * pl.M * 8;
+        // rows in the order of the partial windows, [b][m][cell]: the 8 rows of a wave are 8 consecutive cells = 1 KB contiguous in
+        // every chunk (with the head fastest they were 8 windows apart: 128-byte reads, 52 us for 59 MB)
         for (int64_t i = gid; i < n; i += stride) {
             const int64_t row = i >> 3;
-            const int m = static_cast<int>(row % pl.M);
-            const int64_t bp = row / pl.M;
-            finalize_row(pl, scratch, far, grad_value, l, static_cast<int>(bp / hw), pl.start[l] + static_cast<int>(bp % hw), m,
+            const int cell = static_cast<int>(row % hw);
+            const int64_t bm = row / hw;
+            finalize_row(pl, scratch, far, grad_value, l, static_cast<int>(bm / pl.M), pl.start[l] + cell, static_cast<int>(bm % pl.M),
                          static_cast<int>(i & 7) * 4, false);
         }
     }
