@@ -64,16 +64,10 @@ constexpr int kMaxCells = 1024;       // (1024 + 8) * 128 B + 4 KB counts + 24 K
 constexpr unsigned long long kCookie = 0x6d64657472667573ull;
 
 // workspace header (first 256 bytes)
-constexpr int kMaxSlots = 8;
 struct Header {
-    unsigned absmax_g, absmax_a;      // (unused since the slots below; kept: tests/diag read the word after them)
+    unsigned absmax_g, absmax_a;      // bit patterns of max|grad_out|, max|attn| (inf: something non-finite)
     unsigned far;                     // some block added into the `far` buffer during this call
     unsigned pad;
-    // bit patterns of max|grad_out| (first kMaxSlots) and max|attn| (next kMaxSlots; inf: something non-finite): the pre-pass's
-    // workgroups publish into slot (block & 7).  One word each serialised 2 x 2 048 same-address atomics in L2 -- ~12 ns apiece,
-    // 25 of the pre-pass's 36 us (the blocks finish together, so the "only if larger" test rarely spares one); eight words take
-    // an eighth of that each, in parallel.  Everything up to here is zeroed per call.
-    unsigned slots[2 * kMaxSlots];
     unsigned long long cookie;        // kCookie once the `far` buffer is known to be all zero between calls ...
     unsigned long long far_elems;     // ... over this many floats (a call of another size lays the workspace out differently)
 };
@@ -285,7 +279,7 @@ void msda_absmax_kernel(const GT *__restrict__ g, int64_t ng, const float *__res
     }
     __syncthreads();
     if (threadIdx.x < 2) {
-        unsigned *dst = &hdr->slots[threadIdx.x * kMaxSlots + (blockIdx.x & (kMaxSlots - 1))];
+        unsigned *dst = threadIdx.x == 0 ? &hdr->absmax_g : &hdr->absmax_a;
         const unsigned v = s_max[threadIdx.x];
         if (v > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, v);
     }
@@ -483,14 +477,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
     }
 
     // one power-of-two scale per call: |w * attn * g| <= max|attn| * max|g| = mx < 2^e
-    unsigned bg = 0u, ba = 0u;                                // non-negative floats order like their bit patterns
-#pragma unroll
-    for (int i = 0; i < kMaxSlots; ++i) {
-        const unsigned sg = hdr->slots[i], sa = hdr->slots[kMaxSlots + i];
-        bg = sg > bg ? sg : bg;
-        ba = sa > ba ? sa : ba;
-    }
-    const float mx = __builtin_bit_cast(float, bg) * __builtin_bit_cast(float, ba);
+    const float mx = __builtin_bit_cast(float, hdr->absmax_g) * __builtin_bit_cast(float, hdr->absmax_a);
     const bool finite = mx <= 3.0e38f;                        // inf / NaN somewhere: every corner goes to the `far` buffer
     int e = 0;
     if (finite && mx > 0.f) (void)frexpf(mx, &e);
@@ -1020,7 +1007,7 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
     float *far = pl.owner ? grad_value : reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + 256);
     float *scratch = pl.owner ? nullptr : far + nfar;
     hipError_t err;
-    if ((err = zero_fill_launch(hdr, 16 + 2 * kMaxSlots * 4, st)) != hipSuccess) return err;   // maxima, far flag, the slots (not the cookie behind them)
+    if ((err = zero_fill_launch(hdr, 16, st)) != hipSuccess) return err;
     const int64_t n_go = static_cast<int64_t>(B) * Lq * M * D, n_at = static_cast<int64_t>(B) * Lq * M * L * P;
     if ((L * P) % 4 != 0) return hipErrorNotSupported;       // the pre-pass reads attn in 16-byte pieces
     // grid-stride over 16-byte pieces, four per lane and trip: no more workgroups than that gives work to (small calls)
