@@ -78,3 +78,24 @@ def test_staging_stores_with_and_without_the_remap(remap, expect_tr, expect_rm):
 def test_remap_is_a_permutation_of_the_tile():
     for remap in (False, True):
         assert sorted(staging(t, remap) for t in range(256)) == sorted((r, c) for r in range(64) for c in range(4))
+
+
+@pytest.mark.parametrize("remap,expect", [(False, 2), (True, 1)])
+def test_conv_taps_staging_stores(remap, expect):
+    """csrc/conv_taps.hip: 16-byte staging stores into LDS rows of 40 bf16 (32-channel slab + 8 pad = 80 bytes).  Round 3's first
+    mapping gave consecutive lanes the four pieces of one row (two rows per 8-lane store group: row 1's last piece wraps onto
+    row 0's first banks) -- rocprofv3 counted 27 - 38 % of the kernels' LDS cycles as bank conflicts
+    (profiles/r03_pmc_conv_strided_after.json); the remap gives a 16-lane group 16 consecutive rows at one piece: none
+    (profiles/r03_pmc_conv_strided_remap.json)."""
+    def task(p):
+        if remap:
+            return (p // 16) % 4, p // 64 * 16 + p % 16            # (piece, row)
+        return p % 4, p // 4
+    worst = 1
+    for wave in range(4):
+        def addr(l, wave=wave):
+            piece, row = task(64 * wave + l)
+            return 2 * (row * 40 + piece * 8)
+        worst = max(worst, worst_conflict(addr, 16, OCTETS, 32))
+    assert worst == expect
+    assert sorted(task(p) for p in range(256)) == sorted((c, r) for r in range(64) for c in range(4))    # both cover 64 rows x 4 pieces
