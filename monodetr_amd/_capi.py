@@ -12,7 +12,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmonodetr_amd.so")
+# (MDETR_LIB_PATH: developer switch for timing two builds of the library in one GPU call; the product never sets it)
+LIB_PATH = os.environ.get("MDETR_LIB_PATH") or os.path.join(_HERE, "libmonodetr_amd.so")
 
 MDETR_F32, MDETR_F64, MDETR_BF16 = 0, 1, 2
 ABI_VERSION = 5

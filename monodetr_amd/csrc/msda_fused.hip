@@ -50,6 +50,12 @@
 
 #include "msda.h"
 
+// developer ablations (timing only, results wrong): -DMDETR_ABL=<bits>  1: no LDS accumulation  2: no value gather / gradients of
+// loc, attn  4: candidate pass only  8: no per-cell counts
+#ifndef MDETR_ABL
+#define MDETR_ABL 0
+#endif
+
 namespace mdetr {
 namespace {
 
@@ -63,9 +69,11 @@ constexpr int kTrash = 8;             // sink rows for corners that are not this
 constexpr int kMaxCells = 1024;       // (1024 + 8) * 128 B + 4 KB counts + 24 KB records + tables < 160 KB
 constexpr unsigned long long kCookie = 0x6d64657472667573ull;
 
-// workspace header (first 256 bytes)
+// workspace header (first 256 bytes), followed by the pre-pass's per-workgroup maxima (kMaxPre x 2 words): kHdrBytes in all
+constexpr int kMaxPre = 1024;
+constexpr int kHdrBytes = 256 + kMaxPre * 2 * 4;
 struct Header {
-    unsigned absmax_g, absmax_a;      // bit patterns of max|grad_out|, max|attn| (inf: something non-finite)
+    unsigned npre, pad0;              // workgroups of the pre-pass = valid entries of the maxima array behind the header
     unsigned far;                     // some block added into the `far` buffer during this call
     unsigned pad;
     unsigned long long cookie;        // kCookie once the `far` buffer is known to be all zero between calls ...
@@ -91,6 +99,7 @@ struct FusedPlan {
     long long scr_per_bm;
     int max_cells;
     int max_tab;                      // ints of the centre-cell tables a mode-0 block may need
+    int small;                        // every extent < 2^13: the rectangle bounds and chunk limits fit 32-bit arithmetic
 };
 
 // ---- tiny helpers ---------------------------------------------------------------------------------
@@ -109,6 +118,16 @@ __host__ __device__ inline int centre_cell(int y, int n_l, int n_q)
 __host__ __device__ inline int first_at_or_after(int t, int n_l, int n_q)
 {
     const int y = ceil_div_ll(2LL * t * n_q - n_l, 2LL * n_l);
+    return y < 0 ? 0 : (y > n_q ? n_q : y);
+}
+
+// the same in 32 bits (FusedPlan::small: |t| < 2^15, extents < 2^13): one unsigned division instead of a 64-bit one (~150
+// instructions, 33 of them quarter-rate multiplies, per call and per WAVE -- 16 calls per mode-0 block were 10-20 us of its ~35)
+__host__ __device__ inline int first_at_or_after_small(int t, int n_l, int n_q)
+{
+    const int a = 2 * t * n_q - n_l, b = 2 * n_l;
+    const int y = a >= 0 ? static_cast<int>((static_cast<unsigned>(a) + static_cast<unsigned>(b) - 1u) / static_cast<unsigned>(b))
+                         : -static_cast<int>(static_cast<unsigned>(-a) / static_cast<unsigned>(b));
     return y < 0 ? 0 : (y > n_q ? n_q : y);
 }
 
@@ -133,7 +152,12 @@ __device__ __forceinline__ float sum4f(float v)            // over the 4 lanes o
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
     return v;
 }
-template <int LPS> __device__ __forceinline__ float sum_sample(float v) { return LPS == 8 ? sum8f(v) : sum4f(v); }
+__device__ __forceinline__ float sum2f(float v)            // over a lane pair
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    return v;
+}
+template <int LPS> __device__ __forceinline__ float sum_sample(float v) { return LPS == 8 ? sum8f(v) : (LPS == 4 ? sum4f(v) : sum2f(v)); }
 
 // The CPL = 32 / LPS channels ONE lane owns of a 32-channel row (LPS lanes per sample), as they sit in memory: loaded with one
 // 16-byte (or 8-byte) request, widened only where fp32 values are needed.
@@ -161,6 +185,30 @@ template <> struct LaneRaw<__hip_bfloat16, 8> {
     {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            const unsigned u = word(r, i);
+            f[2 * i] = __uint_as_float(u << 16);
+            f[2 * i + 1] = __uint_as_float(u & 0xFFFF0000u);
+        }
+    }
+};
+
+template <> struct LaneRaw<__hip_bfloat16, 16> {             // half a row per lane (LPS = 2): two 16-byte requests
+    struct T { uint4 a, b; };
+    static __device__ __forceinline__ T load(const char *p)
+    {
+        T r;
+        r.a = *reinterpret_cast<const uint4 *>(p);
+        r.b = *reinterpret_cast<const uint4 *>(p + 16);
+        return r;
+    }
+    static __device__ __forceinline__ unsigned word(const T &r, int i)
+    {
+        return i == 0 ? r.a.x : i == 1 ? r.a.y : i == 2 ? r.a.z : i == 3 ? r.a.w : i == 4 ? r.b.x : i == 5 ? r.b.y : i == 6 ? r.b.z : r.b.w;
+    }
+    static __device__ __forceinline__ void widen(const T &r, float (&f)[16])
+    {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
             const unsigned u = word(r, i);
             f[2 * i] = __uint_as_float(u << 16);
             f[2 * i + 1] = __uint_as_float(u & 0xFFFF0000u);
@@ -268,8 +316,9 @@ void msda_absmax_kernel(const GT *__restrict__ g, int64_t ng, const float *__res
     }
     if (!(poison == 0.f)) mg = __builtin_inff();
     for (int o = 32; o > 0; o >>= 1) { mg = fmaxf(mg, __shfl_xor(mg, o)); ma = fmaxf(ma, __shfl_xor(ma, o)); }
-    // one atomic per WORKGROUP and only if it raises the maximum: same-address atomics serialise in L2 (~12 ns each; one
-    // per wave made this 25-microsecond pass take 110)
+    // one pair of words per WORKGROUP behind the header, reduced by every block of the main kernel (1 024 x 2 words from L2): no
+    // atomics at all.  (Same-address atomicMax serialises in L2, ~12 ns each: one per workgroup made this 20-microsecond pass
+    // take 35, one per wave 110; and the words needed a zero-fill launch of their own in front of the pass.)
     __shared__ unsigned s_max[2];
     if (threadIdx.x < 2) s_max[threadIdx.x] = 0u;
     __syncthreads();
@@ -278,10 +327,11 @@ void msda_absmax_kernel(const GT *__restrict__ g, int64_t ng, const float *__res
         atomicMax(&s_max[1], __builtin_bit_cast(unsigned, ma));
     }
     __syncthreads();
-    if (threadIdx.x < 2) {
-        unsigned *dst = threadIdx.x == 0 ? &hdr->absmax_g : &hdr->absmax_a;
-        const unsigned v = s_max[threadIdx.x];
-        if (v > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, v);
+    unsigned *maxima = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(hdr) + 256);
+    if (threadIdx.x < 2) maxima[2 * blockIdx.x + threadIdx.x] = s_max[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hdr->npre = gridDim.x;
+        hdr->far = 0u;                                        // (set by the main kernel, read by the finalize pass: stream order)
     }
     // a workspace this library has not finalized yet (fresh allocation): its `far` buffer may hold anything
     // (owner scheme: `far` IS grad_value, which every block of the main kernel adds into: zero-filled by this pass, every call)
@@ -305,20 +355,25 @@ struct Work {
     int slot;                          // tile / chunk index within the level
 };
 
-__device__ __forceinline__ Work decode_block(const FusedPlan &pl, int k)
+// `bounds` = 16 ints of LDS scratch (tiled levels of self-attention): the 4 x 4 rectangle bounds of the block are computed ONCE,
+// one per lane of the first 16 threads, and read back by everyone -- not 16 serial divisions on each of the block's waves.
+// Called by every thread of the block (two barriers inside, the branch is block-uniform).
+__device__ __forceinline__ Work decode_block(const FusedPlan &pl, int k, int *bounds)
 {
     Work w;
     int l = 0;
 #pragma unroll
     for (int i = 0; i < kMaxLevels; ++i) {
         if (i < pl.L && k >= pl.blk0[i]) {
-            const int d = k - pl.blk0[i], st = pl.bstride[i];
-            if (d % st == 0 && d / st < pl.nblk[i]) l = i;
+            const unsigned d = static_cast<unsigned>(k - pl.blk0[i]), st = static_cast<unsigned>(pl.bstride[i]);
+            const unsigned qd = st == 1u ? d : d / st;
+            if (qd * st == d && qd < static_cast<unsigned>(pl.nblk[i])) l = i;
         }
     }
     w.l = l;
     w.mode = pl.mode[l];
-    const int t = (k - pl.blk0[l]) / pl.bstride[l];
+    const unsigned dk = static_cast<unsigned>(k - pl.blk0[l]), stl = static_cast<unsigned>(pl.bstride[l]);
+    const int t = static_cast<int>(stl == 1u ? dk : dk / stl);
     w.slot = t;
     w.q0 = 0;
     w.nq = 0;
@@ -332,53 +387,70 @@ __device__ __forceinline__ Work decode_block(const FusedPlan &pl, int k)
     if (w.mode == 1) {
         w.cy0 = 0; w.cx0 = 0; w.tstride = pl.W[l]; w.ncell = pl.H[l] * pl.W[l];
         const int nch = pl.nchunk[l];
-        w.q0 = static_cast<int>(static_cast<long long>(pl.Lq) * t / nch);
-        w.nq = static_cast<int>(static_cast<long long>(pl.Lq) * (t + 1) / nch) - w.q0;
+        if (static_cast<long long>(pl.Lq) * (nch + 1) < (1LL << 31)) {          // (uniform) the chunk limits in 32 bits
+            const unsigned un = static_cast<unsigned>(nch), lq_ = static_cast<unsigned>(pl.Lq);
+            w.q0 = static_cast<int>(lq_ * static_cast<unsigned>(t) / un);
+            w.nq = static_cast<int>(lq_ * static_cast<unsigned>(t + 1) / un) - w.q0;
+        } else {
+            w.q0 = static_cast<int>(static_cast<long long>(pl.Lq) * t / nch);
+            w.nq = static_cast<int>(static_cast<long long>(pl.Lq) * (t + 1) / nch) - w.q0;
+        }
     } else {
-        const int ty = t / pl.ntx[l], tx = t % pl.ntx[l];
+        const unsigned ntx = static_cast<unsigned>(pl.ntx[l]);
+        const int ty = static_cast<int>(static_cast<unsigned>(t) / ntx), tx = t - ty * static_cast<int>(ntx);
         w.cy0 = ty * pl.TH[l]; w.cx0 = tx * pl.TW[l]; w.tstride = pl.TW[l]; w.ncell = pl.TH[l] * pl.TW[l];
         if (w.mode == 2) {
             w.nq = pl.Lq;
-        } else if (w.mode == 3) {
-            // own queries only: on every query level the rectangle of cells whose centre falls into the CORE; the window adds R cells
-            const int R = pl.R[l], core_y = w.cy0, core_x = w.cx0;
-#pragma unroll
-            for (int lq = 0; lq < kMaxLevels; ++lq) {
-                if (lq < pl.L) {
-                    w.y0[lq] = first_at_or_after(core_y, pl.H[l], pl.H[lq]);
-                    w.rows[lq] = first_at_or_after(core_y + pl.TH[l], pl.H[l], pl.H[lq]) - w.y0[lq];
-                    w.x0[lq] = first_at_or_after(core_x, pl.W[l], pl.W[lq]);
-                    const int cols = first_at_or_after(core_x + pl.TW[l], pl.W[l], pl.W[lq]) - w.x0[lq];
-                    w.wx[lq] = cols > 0 ? cols : 1;
-                    w.inv_wx[lq] = 1.0f / static_cast<float>(w.wx[lq]);
-                    w.cum[lq + 1] = w.cum[lq] + (cols > 0 ? w.rows[lq] * cols : 0);
-                } else {
-                    w.cum[lq + 1] = w.cum[lq];
-                }
-            }
-            w.nq = w.cum[kMaxLevels];
-            w.cy0 = core_y - R; w.cx0 = core_x - R;          // from here on: the WINDOW's origin and extent
-            w.tstride = pl.TW[l] + 2 * R;
-            w.ncell = (pl.TH[l] + 2 * R) * w.tstride;
         } else {
-            const int R = pl.R[l];
+            // mode 3 (owner): own queries only -- on every query level the rectangle of cells whose centre falls into the CORE
+            // (the window adds R cells); mode 0: the queries whose centre lies within R cells of the core
+            const int R = pl.R[l], margin = w.mode == 3 ? 0 : R;
+            if (threadIdx.x < 4 * kMaxLevels) {
+                const int lq = static_cast<int>(threadIdx.x) >> 2, which = static_cast<int>(threadIdx.x) & 3;
+                int v = 0;
+                if (lq < pl.L) {
+                    const bool xs = (which & 2) != 0, hi = (which & 1) != 0;
+                    const int t0 = (xs ? w.cx0 : w.cy0) + (hi ? (xs ? pl.TW[l] : pl.TH[l]) + margin : -margin);
+                    const int n_l = xs ? pl.W[l] : pl.H[l];
+                    // (pl.H[lq] / pl.W[lq] with a lane-dependent index: selected, not indexed -- the plan sits in SGPRs)
+                    const int hq = lq == 0 ? pl.H[0] : lq == 1 ? pl.H[1] : lq == 2 ? pl.H[2] : pl.H[3];
+                    const int wq = lq == 0 ? pl.W[0] : lq == 1 ? pl.W[1] : lq == 2 ? pl.W[2] : pl.W[3];
+                    const int n_q = xs ? wq : hq;
+                    v = pl.small ? first_at_or_after_small(t0, n_l, n_q) : first_at_or_after(t0, n_l, n_q);
+                }
+                bounds[threadIdx.x] = v;                      // [lq][y lo, y hi, x lo, x hi]
+            }
+            __syncthreads();
+            int bnd[4 * kMaxLevels];
+#pragma unroll
+            for (int i = 0; i < 4 * kMaxLevels; ++i) bnd[i] = __builtin_amdgcn_readfirstlane(bounds[i]);
+            __syncthreads();                                  // the scratch is reused by the caller
 #pragma unroll
             for (int lq = 0; lq < kMaxLevels; ++lq) {
                 if (lq < pl.L) {
-                    w.y0[lq] = first_at_or_after(w.cy0 - R, pl.H[l], pl.H[lq]);
-                    w.rows[lq] = first_at_or_after(w.cy0 + pl.TH[l] + R, pl.H[l], pl.H[lq]) - w.y0[lq];
-                    w.x0[lq] = first_at_or_after(w.cx0 - R, pl.W[l], pl.W[lq]);
-                    const int cols = first_at_or_after(w.cx0 + pl.TW[l] + R, pl.W[l], pl.W[lq]) - w.x0[lq];
+                    w.y0[lq] = bnd[4 * lq];
+                    w.rows[lq] = bnd[4 * lq + 1] - bnd[4 * lq];
+                    w.x0[lq] = bnd[4 * lq + 2];
+                    const int cols = bnd[4 * lq + 3] - bnd[4 * lq + 2];
                     w.wx[lq] = cols > 0 ? cols : 1;
                     w.inv_wx[lq] = 1.0f / static_cast<float>(w.wx[lq]);
-                    w.roff[lq] = w.ntab; w.ntab += w.rows[lq];
-                    w.coff[lq] = w.ntab; w.ntab += cols;
-                    w.cum[lq + 1] = w.cum[lq] + w.rows[lq] * cols;
+                    if (w.mode == 3) {
+                        w.cum[lq + 1] = w.cum[lq] + (cols > 0 ? w.rows[lq] * cols : 0);
+                    } else {
+                        w.roff[lq] = w.ntab; w.ntab += w.rows[lq];
+                        w.coff[lq] = w.ntab; w.ntab += cols;
+                        w.cum[lq + 1] = w.cum[lq] + w.rows[lq] * cols;
+                    }
                 } else {
                     w.cum[lq + 1] = w.cum[lq];
                 }
             }
             w.nq = w.cum[kMaxLevels];
+            if (w.mode == 3) {
+                w.cy0 -= R; w.cx0 -= R;                       // from here on: the WINDOW's origin and extent
+                w.tstride = pl.TW[l] + 2 * R;
+                w.ncell = (pl.TH[l] + 2 * R) * w.tstride;
+            }
         }
     }
     return w;
@@ -432,7 +504,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
 
     const int bid = blockIdx.x;
     const int b = bid % pl.B, r_ = bid / pl.B, m = r_ % pl.M, kblk = r_ / pl.M;      // image -> XCD (bid % 8)
-    const Work w = decode_block(pl, kblk);
+    const Work w = decode_block(pl, kblk, lv);
     // TH x TW: the cells this block accumulates in LDS -- the core tile, the whole level (mode 1), or the core plus its halo (mode 3)
     const int l = w.l, H = pl.H[l], W = pl.W[l];
     const int TH = w.mode == 1 ? H : pl.TH[l] + (w.mode == 3 ? 2 * pl.R[l] : 0), TW = w.mode == 1 ? W : pl.TW[l] + (w.mode == 3 ? 2 * pl.R[l] : 0);
@@ -476,8 +548,35 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
         }
     }
 
-    // one power-of-two scale per call: |w * attn * g| <= max|attn| * max|g| = mx < 2^e
-    const float mx = __builtin_bit_cast(float, hdr->absmax_g) * __builtin_bit_cast(float, hdr->absmax_a);
+    // one power-of-two scale per call: |w * attn * g| <= max|attn| * max|g| = mx < 2^e.  The pre-pass left one pair of maxima per
+    // workgroup behind the header: every block reduces them (one 8-byte load per thread, a wave reduction, 2 x waves words of LDS)
+    float mx;
+    {
+        const uint2 *maxima = reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned char *>(hdr) + 256);
+        const int npre = static_cast<int>(hdr->npre);
+        unsigned mg = 0u, ma = 0u;
+        for (int i = threadIdx.x; i < npre; i += THREADS) {
+            const uint2 v = maxima[i];
+            mg = v.x > mg ? v.x : mg;
+            ma = v.y > ma ? v.y : ma;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned og = __shfl_xor(mg, o), oa = __shfl_xor(ma, o);
+            mg = og > mg ? og : mg;
+            ma = oa > ma ? oa : ma;
+        }
+        if (lane == 0) { recs[2 * wave] = mg; recs[2 * wave + 1] = ma; }    // (the record buffers are idle until the pass starts)
+        __syncthreads();
+        mg = 0u; ma = 0u;
+#pragma unroll
+        for (int i = 0; i < kWavesB; ++i) {
+            const unsigned vg = recs[2 * i], va = recs[2 * i + 1];
+            mg = vg > mg ? vg : mg;
+            ma = va > ma ? va : ma;
+        }
+        mx = __builtin_bit_cast(float, mg) * __builtin_bit_cast(float, ma);
+        // (no barrier needed before the records are written: every wave passes the barrier behind the window's zero fill first)
+    }
     const bool finite = mx <= 3.0e38f;                        // inf / NaN somewhere: every corner goes to the `far` buffer
     int e = 0;
     if (finite && mx > 0.f) (void)frexpf(mx, &e);
@@ -613,7 +712,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {                 // this block's cells: count the contribution, other corners -> sink row
                     const unsigned cc = (c < 2 ? rec[2] >> (16 * c) : rec[3] >> (16 * (c - 2))) & 0xFFFFu;
-                    if (cc != 0xFFFFu) atomicAdd(cnt + cc, 1u);
+                    if (cc != 0xFFFFu && !(MDETR_ABL & 8)) atomicAdd(cnt + cc, 1u);
                 }
                 const unsigned sink = static_cast<unsigned>(w.ncell + (slot & 7));
                 const unsigned c0 = rec[2] & 0xFFFFu, c1 = rec[2] >> 16, c2 = rec[3] & 0xFFFFu, c3 = rec[3] >> 16;
@@ -641,7 +740,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 const unsigned flags = r2.w;
                 float g[CPL];
                 RG::widen(graw, g);
-                if (on && finite) {
+                if (on && finite && !(MDETR_ABL & 1)) {
                     const float as = a * scale;
                     float ag[CPL];
 #pragma unroll
@@ -660,13 +759,13 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                     }
                     if (!OWNER && k == 0) hdr->far = 1u;
                 }
-                float e[4];
-                CornerDots<GT, VT, CPL>::run(graw, g, vraw, e);
+                float e[4] = {0.f, 0.f, 0.f, 0.f};
+                if (!(MDETR_ABL & 2)) CornerDots<GT, VT, CPL>::run(graw, g, vraw, e);
                 // over the LPS lanes of the sample, every lane takes part
                 float d0 = sum_sample<LPS>(e[0]), d1 = sum_sample<LPS>(e[1]), d2 = sum_sample<LPS>(e[2]), d3 = sum_sample<LPS>(e[3]);
                 d0 = (flags & 1u) ? d0 : 0.f; d1 = (flags & 2u) ? d1 : 0.f;              // a corner outside the map reads nothing (.cuh:56-78)
                 d2 = (flags & 4u) ? d2 : 0.f; d3 = (flags & 8u) ? d3 : 0.f;
-                if (on && k == 0) {
+                if (on && k == 0 && !(MDETR_ABL & 2)) {
                     const float hh = 1.f - lh, hw = 1.f - lw;
                     const unsigned p = (flags >> 8) & 15u;
                     const unsigned o_ = (pair0u + r0.x * static_cast<unsigned>(M)) * static_cast<unsigned>(LP) + static_cast<unsigned>(l * P) + p;   // < 2^28 (plan)
@@ -688,8 +787,10 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                     rg[t] = RG::load(gbase + (pair0u + h.x * static_cast<unsigned>(M)) * static_cast<unsigned>(kCH * Elem<GT>::kBytes));
                     const int dxb = (h.y >> 30) & 1u ? rowb : 0, dyb = (h.y >> 31) ? W * rowb : 0;
                     const char *vb = vlev + (h.y & 0xFFFFFFu) * static_cast<unsigned>(rowb);
-                    rv[t][0] = RV::load(vb); rv[t][1] = RV::load(vb + dxb);
-                    rv[t][2] = RV::load(vb + dyb); rv[t][3] = RV::load(vb + dyb + dxb);
+                    if (!(MDETR_ABL & 2)) {
+                        rv[t][0] = RV::load(vb); rv[t][1] = RV::load(vb + dxb);
+                        rv[t][2] = RV::load(vb + dyb); rv[t][3] = RV::load(vb + dyb + dxb);
+                    }
                 }
 #pragma unroll
                 for (int t = 0; t < NG; ++t) {
@@ -697,13 +798,17 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                     run_own(r < no, min(r, no - 1), rg[t], rv[t]);
                 }
             };
-            for (int i0 = 0; i0 < no; i0 += SPG * GMAX) {
+            for (int i0 = 0; i0 < no && !(MDETR_ABL & 4); i0 += SPG * GMAX) {
                 const int ng = min(GMAX, (no - i0 + SPG - 1) / SPG);                      // wave-uniform
-                if (ng == 1) own_batch(std::integral_constant<int, 1>(), i0);
-                else if (GMAX == 2 || ng == 2) own_batch(std::integral_constant<int, 2>(), i0);
-                else if constexpr (GMAX >= 4) {
-                    if (ng == 3) own_batch(std::integral_constant<int, 3>(), i0);
-                    else own_batch(std::integral_constant<int, 4>(), i0);
+                if constexpr (GMAX == 1) {
+                    own_batch(std::integral_constant<int, 1>(), i0);
+                } else {
+                    if (ng == 1) own_batch(std::integral_constant<int, 1>(), i0);
+                    else if (GMAX == 2 || ng == 2) own_batch(std::integral_constant<int, 2>(), i0);
+                    else if constexpr (GMAX >= 4) {
+                        if (ng == 3) own_batch(std::integral_constant<int, 3>(), i0);
+                        else own_batch(std::integral_constant<int, 4>(), i0);
+                    }
                 }
             }
             // ---- b2. neighbours' samples that reach into this core: accumulate only ---------------------------------------
@@ -729,16 +834,19 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                         RG::widen(rg[t], ag);
 #pragma unroll
                         for (int i = 0; i < CPL; ++i) ag[i] *= as;
-                        accumulate<CPL>(win, r0.z, r0.w, wt, ag, k, magic);
+                        if (!(MDETR_ABL & 1)) accumulate<CPL>(win, r0.z, r0.w, wt, ag, k, magic);
                     }
                 }
             };
-            for (int i0 = 0; i0 < nh; i0 += 4 * SPG) {
-                const int ng = min(4, (nh - i0 + SPG - 1) / SPG);
+            constexpr int HG = LPS == 2 ? 2 : 4;              // (a neighbour list is at most 64 samples = 2 groups of 32)
+            for (int i0 = 0; i0 < nh && !(MDETR_ABL & 4); i0 += HG * SPG) {
+                const int ng = min(HG, (nh - i0 + SPG - 1) / SPG);
                 if (ng == 1) halo_batch(std::integral_constant<int, 1>(), i0);
-                else if (ng == 2) halo_batch(std::integral_constant<int, 2>(), i0);
-                else if (ng == 3) halo_batch(std::integral_constant<int, 3>(), i0);
-                else halo_batch(std::integral_constant<int, 4>(), i0);
+                else if (HG == 2 || ng == 2) halo_batch(std::integral_constant<int, 2>(), i0);
+                else if constexpr (HG >= 4) {
+                    if (ng == 3) halo_batch(std::integral_constant<int, 3>(), i0);
+                    else halo_batch(std::integral_constant<int, 4>(), i0);
+                }
             }
             wave_sync();
         }
@@ -804,16 +912,17 @@ __device__ __forceinline__ void finalize_row(const FusedPlan &pl, const float *_
                             static_cast<int64_t>(pix - pl.start[l]) * kCH + c4;
         const int64_t cs = static_cast<int64_t>(ncell) * kCH;
         const int nch = pl.nchunk[l];
-        int t = 0;
-        for (; t + 3 < nch; t += 4) {                         // fixed order: deterministic; four requests in flight
-            const float4 v0 = *reinterpret_cast<const float4 *>(base + t * cs), v1 = *reinterpret_cast<const float4 *>(base + (t + 1) * cs);
-            const float4 v2 = *reinterpret_cast<const float4 *>(base + (t + 2) * cs), v3 = *reinterpret_cast<const float4 *>(base + (t + 3) * cs);
-            acc.x = (((acc.x + v0.x) + v1.x) + v2.x) + v3.x; acc.y = (((acc.y + v0.y) + v1.y) + v2.y) + v3.y;
-            acc.z = (((acc.z + v0.z) + v1.z) + v2.z) + v3.z; acc.w = (((acc.w + v0.w) + v1.w) + v2.w) + v3.w;
-        }
-        for (; t < nch; ++t) {
-            const float4 v = *reinterpret_cast<const float4 *>(base + t * cs);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        // fixed order (deterministic); up to 12 requests in flight -- the default plan's 12 chunks in ONE round trip (the pass moves
+        // 59 MB with ~300 k threads: what it waits for is round trips, with four requests at a time there were three)
+        constexpr int kFlight = 12;
+        for (int t0 = 0; t0 < nch; t0 += kFlight) {
+            float4 v[kFlight];
+#pragma unroll
+            for (int u = 0; u < kFlight; ++u)
+                if (t0 + u < nch) v[u] = *reinterpret_cast<const float4 *>(base + (t0 + u) * cs);
+#pragma unroll
+            for (int u = 0; u < kFlight; ++u)
+                if (t0 + u < nch) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
         }
     } else {
         acc = *reinterpret_cast<const float4 *>(grad_value + row * kCH + c4);
@@ -841,30 +950,53 @@ void msda_finalize_kernel(const FusedPlan pl, const float *__restrict__ scratch,
     const bool use_far = hdr->far != 0u;
     if (use_far) {                                           // every row (the chunked levels' included)
         const int64_t n = static_cast<int64_t>(pl.B) * pl.S * pl.M * 8;
+        const bool narrow = n < (1LL << 34);                 // (uniform) row numbers fit 32 bits: no 64-bit divisions (~150 instructions each)
         for (int64_t i = gid; i < n; i += stride) {
             const int64_t row = i >> 3;
-            const int m = static_cast<int>(row % pl.M);
-            const int64_t bp = row / pl.M;
-            const int pix = static_cast<int>(bp % pl.S), b = static_cast<int>(bp / pl.S);
+            int m, pix, b;
+            if (narrow) {
+                const unsigned r = static_cast<unsigned>(row), bp = r / static_cast<unsigned>(pl.M);
+                m = static_cast<int>(r - bp * static_cast<unsigned>(pl.M));
+                b = static_cast<int>(bp / static_cast<unsigned>(pl.S));
+                pix = static_cast<int>(bp - static_cast<unsigned>(b) * static_cast<unsigned>(pl.S));
+            } else {
+                m = static_cast<int>(row % pl.M);
+                const int64_t bp = row / pl.M;
+                pix = static_cast<int>(bp % pl.S); b = static_cast<int>(bp / pl.S);
+            }
             int l = 0;
             while (l + 1 < pl.L && pix >= pl.start[l + 1]) ++l;
             finalize_row(pl, scratch, far, grad_value, l, b, pix, m, static_cast<int>(i & 7) * 4, true);
         }
         return;
     }
-    for (int l = 0; l < pl.L; ++l) {
-        if (pl.mode[l] != 1) continue;
+    // the chunked levels' rows, all levels in ONE index space (level after level; a thread rarely sees more than one row): rows in
+    // the order of the partial windows, [b][m][cell] -- the 8 rows of a wave are 8 consecutive cells = 1 KB contiguous in every
+    // chunk (with the head fastest they were 8 windows apart: 128-byte reads, 52 us for 59 MB)
+    int64_t cum[kMaxLevels + 1];
+    cum[0] = 0;
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; ++l)
+        cum[l + 1] = cum[l] + ((l < pl.L && pl.mode[l] == 1) ? static_cast<int64_t>(pl.B) * pl.H[l] * pl.W[l] * pl.M * 8 : 0);
+    const bool narrow = cum[kMaxLevels] < (1LL << 34);
+    for (int64_t i = gid; i < cum[kMaxLevels]; i += stride) {
+        int l = 0;
+#pragma unroll
+        for (int t = 1; t < kMaxLevels; ++t) l += i >= cum[t] ? 1 : 0;
         const int hw = pl.H[l] * pl.W[l];
-        const int64_t n = static_cast<int64_t>(pl.B) * hw * pl.M * 8;
-        // rows in the order of the partial windows, [b][m][cell]: the 8 rows of a wave are 8 consecutive cells = 1 KB contiguous in
-        // every chunk (with the head fastest they were 8 windows apart: 128-byte reads, 52 us for 59 MB)
-        for (int64_t i = gid; i < n; i += stride) {
-            const int64_t row = i >> 3;
-            const int cell = static_cast<int>(row % hw);
+        const int64_t row = (i - cum[l]) >> 3;
+        int cell, b, m;
+        if (narrow) {
+            const unsigned r = static_cast<unsigned>(row), bm = r / static_cast<unsigned>(hw);
+            cell = static_cast<int>(r - bm * static_cast<unsigned>(hw));
+            b = static_cast<int>(bm / static_cast<unsigned>(pl.M));
+            m = static_cast<int>(bm - static_cast<unsigned>(b) * static_cast<unsigned>(pl.M));
+        } else {
+            cell = static_cast<int>(row % hw);
             const int64_t bm = row / hw;
-            finalize_row(pl, scratch, far, grad_value, l, static_cast<int>(bm / pl.M), pl.start[l] + cell, static_cast<int>(bm % pl.M),
-                         static_cast<int>(i & 7) * 4, false);
+            b = static_cast<int>(bm / pl.M); m = static_cast<int>(bm % pl.M);
         }
+        finalize_row(pl, scratch, far, grad_value, l, b, pl.start[l] + cell, m, static_cast<int>(i & 7) * 4, false);
     }
 }
 
@@ -909,6 +1041,9 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
     pl.owner = (self && env_int("MDETR_MSDA_OWNER", 0) != 0) ? 1 : 0;
     const int otile_h = env_int("MDETR_MSDA_OTILE_H", 16), otile_w = env_int("MDETR_MSDA_OTILE_W", 24), oreach = env_int("MDETR_MSDA_OREACH", 4);
     if (pl.owner && (otile_h < 1 || otile_w < 1 || oreach < 0 || (otile_h + 2 * oreach) * (otile_w + 2 * oreach) > kMaxCells)) return false;
+    pl.small = (reach < (1 << 13) && oreach < (1 << 13)) ? 1 : 0;
+    for (int l = 0; l < L; ++l)
+        if (pl.H[l] >= (1 << 13) || pl.W[l] >= (1 << 13)) pl.small = 0;
     int blk = 0;
     long long scr = 0;
     pl.max_cells = 0;
@@ -977,8 +1112,8 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
 
 int64_t plan_workspace_bytes(const FusedPlan &pl)
 {
-    if (pl.owner) return 256;                                // the header only: no side buffer, no partial windows
-    return 256 + (static_cast<int64_t>(pl.B) * pl.M * pl.scr_per_bm + static_cast<int64_t>(pl.B) * pl.S * pl.M * kCH) * 4;
+    if (pl.owner) return kHdrBytes;                          // the header only: no side buffer, no partial windows
+    return kHdrBytes + (static_cast<int64_t>(pl.B) * pl.M * pl.scr_per_bm + static_cast<int64_t>(pl.B) * pl.S * pl.M * kCH) * 4;
 }
 
 }  // namespace
@@ -1003,16 +1138,15 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
     if (elem_dtype != 0 && elem_dtype != 2) return hipErrorNotSupported;
     Header *hdr = static_cast<Header *>(workspace);
     const int64_t nfar = static_cast<int64_t>(B) * S * M * kCH;
-    // candidate scheme: [256, 256 + 4 nfar) = the side buffer, zero between calls, then the partial windows; owner scheme: neither
-    float *far = pl.owner ? grad_value : reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + 256);
+    // candidate scheme: [kHdrBytes, kHdrBytes + 4 nfar) = the side buffer, zero between calls, then the partial windows; owner scheme: neither
+    float *far = pl.owner ? grad_value : reinterpret_cast<float *>(static_cast<unsigned char *>(workspace) + kHdrBytes);
     float *scratch = pl.owner ? nullptr : far + nfar;
     hipError_t err;
-    if ((err = zero_fill_launch(hdr, 16, st)) != hipSuccess) return err;
     const int64_t n_go = static_cast<int64_t>(B) * Lq * M * D, n_at = static_cast<int64_t>(B) * Lq * M * L * P;
     if ((L * P) % 4 != 0) return hipErrorNotSupported;       // the pre-pass reads attn in 16-byte pieces
     // grid-stride over 16-byte pieces, four per lane and trip: no more workgroups than that gives work to (small calls)
     const int64_t pre_items = (n_go + n_at) / 4 + (pl.owner ? nfar / 4 : nfar / 4 / 64);
-    const unsigned pre_blocks = static_cast<unsigned>(pre_items / (256 * 4) < 2048 ? (pre_items / (256 * 4) > 0 ? pre_items / (256 * 4) : 1) : 2048);
+    const unsigned pre_blocks = static_cast<unsigned>(pre_items / (256 * 4) < kMaxPre ? (pre_items / (256 * 4) > 0 ? pre_items / (256 * 4) : 1) : kMaxPre);
     profile_begin(7, Lq, st);
     if (elem_dtype == 2)
         hipLaunchKernelGGL(msda_absmax_kernel<__hip_bfloat16>, dim3(pre_blocks), dim3(256), 0, st, static_cast<const __hip_bfloat16 *>(grad_out), n_go, attn, n_at, hdr, far, nfar, pl.owner);
@@ -1038,10 +1172,12 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
     // lanes per sample: 4 (bf16 at 16 waves: 8 channels per lane, two groups of 16 own samples in flight) or 8 (4 channels per
     // lane, four groups of 8)
     int lps = env_int("MDETR_MSDA_LPS", 4);
-    lps = (lps == 4 && elem_dtype == 2 && threads > 512) ? 4 : 8;
+    // (2: half a row per lane, one group of 32 own samples in flight -- the per-sample instructions halve again; 16 waves, bf16)
+    lps = ((lps == 4 || lps == 2) && elem_dtype == 2 && threads > 512) ? lps : 8;
+    if (lps == 2 && threads != 1024) lps = 4;
     const int groups = env_int("MDETR_MSDA_GROUPS", 2);      // (12-wave form: 2 or 4 groups of 16 own samples in flight)
-    static bool attr_set[9][64] = {};                        // per kernel instance and device
-    int which = elem_dtype != 2 ? 0 : (threads == 512 ? 1 : (threads == 768 ? (groups >= 4 ? 5 : 4) : (lps == 8 ? 2 : 3)));
+    static bool attr_set[10][64] = {};                        // per kernel instance and device
+    int which = elem_dtype != 2 ? 0 : (threads == 512 ? 1 : (threads == 768 ? (groups >= 4 ? 5 : 4) : (lps == 8 ? 2 : (lps == 2 ? 9 : 3))));
     if (pl.owner && which >= 2 && which != 3) {              // the owner scheme is instantiated for the default forms only
         which = 3;
         threads = 1024;
@@ -1057,6 +1193,7 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
                      : which == 2 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 1024, 4, 8>)
                      : which == 3 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 1024, 2, 4>)
                      : which == 4 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 768, 2, 4>)
+                     : which == 9 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 1024, 1, 2>)
                                   : reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 768, 4, 4>);
     const int slot_ = pl.owner ? (which == 0 ? 6 : (which == 1 ? 7 : 8)) : which;
     if (dev < 0 || dev >= 64 || !attr_set[slot_][dev]) {
@@ -1078,6 +1215,7 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
     else if (which == 2) go(msda_bwd_fused<bf, bf, 1024, 4, 8>, bf(), bf());
     else if (which == 3) go(msda_bwd_fused<bf, bf, 1024, 2, 4>, bf(), bf());
     else if (which == 4) go(msda_bwd_fused<bf, bf, 768, 2, 4>, bf(), bf());
+    else if (which == 9) go(msda_bwd_fused<bf, bf, 1024, 1, 2>, bf(), bf());
     else go(msda_bwd_fused<bf, bf, 768, 4, 4>, bf(), bf());
     profile_end(st);
     if (pl.owner) return hipGetLastError();                  // every block added its share into grad_value: nothing to finalize

@@ -145,6 +145,177 @@ void token_gemm_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ 
     }
 }
 
+// ---- the "direct" form (MDETR_TOKEN_GEMM_DIRECT=1) ------------------------------------------------------------------------------
+// What the listing of the kernel above shows (tools/isa_blocks.py): (1) its weight prologue is ONE 16-byte load per loop trip,
+// waited for and stored -- 32 dependent round trips to L2 before the first product; (2) with 256 VGPRs taken (8 accumulators +
+// a tile of staged inputs) the compiler reuses one register quad for every weight fragment: ds_read -> s_waitcnt 0 -> MFMA, 128
+// times per tile at one wave per SIMD, i.e. an LDS latency per product; (3) the inputs take a round trip through LDS only to
+// change which lane holds which 16 bytes.  Here instead:
+//   * the B operand of v_mfma_f32_32x32x16_bf16 for lane (token = lane & 31, half = lane >> 5) at k-step ks is the 8
+//     CONTIGUOUS values x[token][16 ks + 8 half ...]: the lane loads them itself, 16 bytes, straight from global memory.  The
+//     four loads of a 64-value slab are issued back to back (they touch the same 32 cache lines), a slab's registers are
+//     refilled for the wave's NEXT tile as soon as its four k-steps are consumed: a whole tile (16 KiB per wave) stays in flight.
+//   * the weight fragments of k-step ks + 1 are read from LDS while the products of k-step ks issue (two register sets);
+//   * NB = 4 output blocks per workgroup at K = 256: 68 KB of LDS and <= 256 registers, so TWO workgroups = two waves per SIMD
+//     share a CU (the column halves of N = 256 walk the same token tiles at the same time: the second reader of x hits L2);
+//   * the weight prologue keeps 16 loads in flight per lane (and the first tile's operands are requested ahead of it).
+template <int K, int NB, bool RELU>
+__global__ __launch_bounds__(kWavesG * 64, (NB * 32 * (K + 8) * 2 + NB * 32 * 4 <= 80 * 1024) ? 2 : 1)     // two workgroups per CU where the LDS allows
+void token_gemm_direct_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, const __bf16 *__restrict__ bias,
+                              __bf16 *__restrict__ y, int64_t T, int N, int64_t ldx, int64_t ldy, int gx, int ny)
+{
+    constexpr int KP = K + 8;                                    // padded weight row (see above)
+    constexpr int NS = K / kSlabK, KS = K / 16;                  // slabs, k-steps per tile
+    constexpr int kChunks = NB * 32 * (K / 8), kPer = kChunks / (kWavesG * 64);
+    static_assert(kChunks % (kWavesG * 64) == 0, "weight chunks divide over the workgroup");
+    MDETR_DYNAMIC_LDS(unsigned char, smem_raw);
+    __bf16 *Ws = reinterpret_cast<__bf16 *>(smem_raw);           // [NB*32][KP]
+    float *bias_s = reinterpret_cast<float *>(Ws + NB * 32 * KP);   // [NB*32]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    // 1-D grid of gx * ny workgroups, gx a multiple of 8.  Workgroup ids go round-robin over the 8 XCDs (id % 8), each with its own
+    // L2: the ny column blocks of one token range are ids 8 apart -- the same XCD, neighbouring dispatch slots -- so that the
+    // second reader of an x tile finds it in that L2 instead of fetching it from memory again.
+    const int id = blockIdx.x, grp = id >> 3;
+    const int col = grp % ny, bx = (grp / ny) * 8 + (id & 7);    // column block, token-range index (< gx)
+    const int n0 = col * NB * 32;
+    const int64_t tiles = (T + 31) / 32;
+    if (static_cast<int64_t>(bx) * kWavesG >= tiles) return;     // (gx was rounded up to a multiple of 8)
+
+    const int64_t wave_id = static_cast<int64_t>(bx) * kWavesG + wave, wave_n = static_cast<int64_t>(gx) * kWavesG;
+    // the first tile's operands are requested BEFORE the weight is staged: their latency hides behind the prologue
+    bf16x8 xb[KS];                                               // the lane's B operands of one tile
+    auto request = [&](int64_t tile_, int s) __attribute__((always_inline)) {
+        // (rows beyond T read row T - 1: their products are computed and never stored -- no branch, no zero fill)
+        const int64_t t = tile_ * 32 + (lane & 31), tc = t < T ? t : T - 1;
+        const __bf16 *p = x + tc * ldx + s * kSlabK + half * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xb[s * 4 + q] = *reinterpret_cast<const bf16x8 *>(p + q * 16);
+    };
+
+    int64_t tile = wave_id;
+    if (tile < tiles) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) request(tile, s);
+    }
+
+    // ---- weight (and bias) into LDS, once: batches of kBatch independent 16-byte loads per lane
+    constexpr int kBatch = 16;
+#pragma unroll
+    for (int c0 = 0; c0 < kPer; c0 += kBatch) {
+        bf16x8 v[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            if (c0 + u < kPer) {                                  // (compile time)
+                const int c = (c0 + u) * (kWavesG * 64) + static_cast<int>(threadIdx.x);
+                const int row = c / (K / 8), kc = (c - row * (K / 8)) * 8;
+                // rows beyond N read row N - 1 and are zeroed at the store: unconditional loads, nothing between them
+                const int rc = n0 + row < N ? n0 + row : N - 1;
+                v[u] = *reinterpret_cast<const bf16x8 *>(w + static_cast<int64_t>(rc) * K + kc);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            if (c0 + u < kPer) {
+                const int c = (c0 + u) * (kWavesG * 64) + static_cast<int>(threadIdx.x);
+                const int row = c / (K / 8), kc = (c - row * (K / 8)) * 8;
+                if (n0 + row >= N) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[u][i] = static_cast<__bf16>(0.f);
+                }
+                *reinterpret_cast<bf16x8 *>(Ws + row * KP + kc) = v[u];
+            }
+        }
+    }
+    for (int c = threadIdx.x; c < NB * 32; c += kWavesG * 64)
+        bias_s[c] = (bias && n0 + c < N) ? static_cast<float>(bias[n0 + c]) : 0.f;
+    __syncthreads();
+
+    const __bf16 *wl = Ws + (lane & 31) * KP + half * 8;         // this lane's fragment of block b, k-step ks: + b * 32 * KP + 16 ks
+
+    for (; tile < tiles; tile += wave_n) {
+        f32x16 acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+        const int64_t next = tile + wave_n;
+        bf16x8 wa[2][NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) wa[0][b] = *reinterpret_cast<const bf16x8 *>(wl + b * 32 * KP);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) wa[(ks + 1) & 1][b] = *reinterpret_cast<const bf16x8 *>(wl + b * 32 * KP + (ks + 1) * 16);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] = mfma_bf16(wa[ks & 1][b], xb[ks], acc[b]);       // Y^T[n][token]
+            if ((ks & 3) == 3 && next < tiles) request(next, ks >> 2);                           // this slab's registers are free again
+            // (a fence for the COMPILER only: left alone it hoists all NB x KS fragment reads -- they do not depend on the tile --
+            // to the top of the tile and spills them: 644 bytes of scratch per lane)
+            __asm__ volatile("" ::: "memory");
+            // ... and the order within the step: one fragment read of step ks + 1 ahead of each product of step ks
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // one LDS read
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // one MFMA
+            }
+        }
+        // ---- epilogue: lane = token (lane & 31); register quad g holds features 32 b + 8 g + 4 half + 0..3
+        const int64_t t = tile * 32 + (lane & 31);
+        if (t < T) {
+            __bf16 *yr = y + t * ldy + n0 + 4 * half;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nn = b * 32 + 8 * g + 4 * half;
+                    if (n0 + nn < N) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float v = acc[b][4 * g + i] + bias_s[nn + i];
+                            if (RELU) v = v > 0.f ? v : 0.f;
+                            o[i] = static_cast<__bf16>(v);
+                        }
+                        *reinterpret_cast<bf16x4 *>(yr + b * 32 + 8 * g) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int K, int NB, bool RELU>
+hipError_t launch_direct(const void *x, const void *w, const void *bias, void *y, int64_t T, int N, int64_t ldx, int64_t ldy,
+                         hipStream_t st)
+{
+    constexpr size_t lds = static_cast<size_t>(NB) * 32 * (K + 8) * 2 + NB * 32 * 4;
+    static_assert(lds <= 160 * 1024, "weight block does not fit the LDS");
+    auto kern = token_gemm_direct_kernel<K, NB, RELU>;
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess) dev_ = -1;
+    if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;
+    }
+    const int64_t tiles = (T + 31) / 32;
+    int64_t gx = (tiles + kWavesG - 1) / kWavesG;
+    const int ny = (N + NB * 32 - 1) / (NB * 32);
+    int per_cu = static_cast<int>((160 * 1024) / lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);         // (two waves per SIMD is what the register budget allows)
+    const int64_t cap = (256 * per_cu) / ny > 0 ? (256 * per_cu) / ny : 1;
+    if (gx > cap) gx = cap;
+    gx = (gx + 7) / 8 * 8;                                       // whole rounds over the XCDs (idle workgroups leave at once)
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(gx * ny)), dim3(kWavesG * 64), lds, st,
+                       static_cast<const __bf16 *>(x), static_cast<const __bf16 *>(w), static_cast<const __bf16 *>(bias),
+                       static_cast<__bf16 *>(y), T, N, ldx, ldy, static_cast<int>(gx), ny);
+    return hipGetLastError();
+}
+
 template <int K, int NB, bool RELU>
 hipError_t launch(const void *x, const void *w, const void *bias, void *y, int64_t T, int N, int64_t ldx, int64_t ldy,
                   hipStream_t st)
@@ -186,9 +357,21 @@ bool token_gemm_supported(int64_t T, int N, int K, int64_t ldx, int64_t ldy, con
 hipError_t token_gemm_launch(const void *x, const void *w, const void *bias, void *y, int64_t T, int N, int K,
                              int64_t ldx, int64_t ldy, bool relu, hipStream_t st)
 {
+    const char *dv_ = getenv("MDETR_TOKEN_GEMM_DIRECT");
+    const bool direct = dv_ && atoi(dv_) != 0;
+    if (direct && K == 512) return relu ? launch_direct<512, 4, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch_direct<512, 4, false>(x, w, bias, y, T, N, ldx, ldy, st);
+    if (direct && K == 128) return relu ? launch_direct<128, 8, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch_direct<128, 8, false>(x, w, bias, y, T, N, ldx, ldy, st);
+    if (direct && K == 64) {
+        if (N <= 64) return relu ? launch_direct<64, 2, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch_direct<64, 2, false>(x, w, bias, y, T, N, ldx, ldy, st);
+        return relu ? launch_direct<64, 8, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch_direct<64, 8, false>(x, w, bias, y, T, N, ldx, ldy, st);
+    }
     if (K == 512)          // 128 output features per workgroup (133 KiB of weight); wider N re-reads x per block
         return relu ? launch<512, 4, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch<512, 4, false>(x, w, bias, y, T, N, ldx, ldy, st);
     if (K == 256) {
+        if (direct) {                                                        // the direct form: 64 or 128 output features per workgroup
+            if (N <= 64) return relu ? launch_direct<256, 2, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch_direct<256, 2, false>(x, w, bias, y, T, N, ldx, ldy, st);
+            return relu ? launch_direct<256, 4, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch_direct<256, 4, false>(x, w, bias, y, T, N, ldx, ldy, st);
+        }
         int nb = N <= 64 ? 2 : (N <= 128 ? 4 : 8);                            // (a 64-wide output fits two blocks: 34 KB of weight, three workgroups per CU)
         if (const char *ev = getenv("MDETR_TOKEN_GEMM_NB")) {                 // A/B runs: output blocks of 32 per workgroup
             const int f = atoi(ev);

@@ -314,7 +314,7 @@ def _bwd_bf16(p, vb, gb):
     return gv, gl, ga
 
 
-@pytest.mark.parametrize("threads,lps,groups", [(512, 8, 2), (1024, 4, 2), (768, 4, 4)])      # (each instantiation family once)
+@pytest.mark.parametrize("threads,lps,groups", [(512, 8, 2), (1024, 4, 2), (768, 4, 4), (1024, 2, 2)])      # (each instantiation family once)
 @pytest.mark.parametrize("th,tw,reach,whole,chunks", [(4, 8, 2, 30, 3)])
 def test_fused_backward_kernel_variants(monkeypatch, threads, lps, groups, th, tw, reach, whole, chunks):
     """The launch variants behind MDETR_MSDA_THREADS / MDETR_MSDA_LPS / MDETR_MSDA_GROUPS (8-, 12- or 16-wave workgroups; 8 lanes x 4 channels or 4 lanes
@@ -338,7 +338,7 @@ def test_fused_backward_kernel_variants(monkeypatch, threads, lps, groups, th, t
         assert close(gv, rv, 1e-5) and close(gl, rl, 1e-6) and close(ga, ra, 1e-6)
 
 
-@pytest.mark.parametrize("lps", [4])
+@pytest.mark.parametrize("lps", [4, 2])
 def test_fused_backward_bf16_lane_layouts_agree_bit_for_bit_on_near_samples(monkeypatch, lps):
     """Near samples only (no fp32 atomics anywhere): tiles with candidate queries, bf16 operands, either lane layout and
     16-wave workgroups -- grad_value equals the fp32 form's on the widened tensors bit for bit."""

@@ -47,6 +47,59 @@ def test_token_gemm_source_on_the_cpu_shim_matches_linear(T, K, N, relu, use_bia
     assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err          # bf16 output rounding
 
 
+@pytest.mark.parametrize("T,N,relu,use_bias", [
+    (300, 256, False, True),        # two column blocks of 128 features, ragged last tile
+    (64, 128, True, True),
+    (1, 8, False, True),            # one token, one quad pair: the other rows of the tile re-read row 0
+    (2100, 256, True, True),        # 66 tiles
+    (97, 264, False, False),        # three column blocks, the last with 8 live features
+    (33000, 16, True, True),        # NB = 2 form (N <= 64); more tiles than waves in flight: the refill of a slab's registers across tiles
+    (130, 64, False, True),
+])
+def test_token_gemm_direct_form_on_the_cpu_shim_matches_linear(monkeypatch, T, N, relu, use_bias):
+    """MDETR_TOKEN_GEMM_DIRECT=1 (K = 256): the lane loads its own MFMA operand from global memory, weight fragments are read one
+    k-step ahead, rows beyond T re-read row T - 1 and are not stored."""
+    monkeypatch.setenv("MDETR_TOKEN_GEMM_DIRECT", "1")
+    K = 256
+    g = torch.Generator().manual_seed(T + N)
+    x = (torch.randn(T, K, generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16) if use_bias else None
+    y = run(x, w, b, relu)
+    monkeypatch.setenv("MDETR_TOKEN_GEMM_DIRECT", "0")
+    y0 = run(x, w, b, relu)
+    ref = x.double() @ w.double().t() + (b.double() if use_bias else 0)
+    if relu:
+        ref = ref.clamp(min=0)
+    assert (y.double() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    assert torch.equal(y, y0)                                # same products in the same order as the LDS-staged form
+
+
+@pytest.mark.parametrize("T,K,N,relu", [(33, 512, 136, True), (97, 128, 264, False), (170, 64, 256, True), (70, 64, 72, False), (33000, 64, 64, True)])
+def test_token_gemm_direct_form_other_contraction_lengths(monkeypatch, T, K, N, relu):
+    g = torch.Generator().manual_seed(T + K + N)
+    x = (torch.randn(T, K, generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16)
+    monkeypatch.setenv("MDETR_TOKEN_GEMM_DIRECT", "1")
+    y = run(x, w, b, relu)
+    monkeypatch.setenv("MDETR_TOKEN_GEMM_DIRECT", "0")
+    assert torch.equal(y, run(x, w, b, relu))
+
+
+def test_token_gemm_direct_form_respects_row_strides(monkeypatch):
+    monkeypatch.setenv("MDETR_TOKEN_GEMM_DIRECT", "1")
+    g = torch.Generator().manual_seed(1)
+    T, K, N = 70, 256, 40
+    big = (torch.randn(T, K + 64, generator=g)).to(torch.bfloat16)
+    x = big[:, 32:32 + K]
+    w = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16)
+    y = run(x, w, None, False, ldy=N + 12)
+    ref = (x.double() @ w.double().t())
+    assert (y[:, :N].double() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    assert torch.all(y[:, N:] == 7.0)
+
+
 def test_token_gemm_respects_row_strides_and_leaves_padding_untouched():
     g = torch.Generator().manual_seed(0)
     T, K, N = 70, 128, 40
