@@ -56,6 +56,22 @@
 #define MDETR_ABL 0
 #endif
 
+// developer timing: -DMDETR_PHASES accumulates shader-clock cycles per phase (thread 0 of every block; wave 0 for the sections of
+// the main loop) into 16 x 2 64-bit words at byte 64 of the workspace header's maxima area end (read by tools/opbench --phases)
+#ifdef MDETR_PHASES
+#define MDETR_PH_DECL long long ph_t = clock64(); long long ph_acc[3] = {0, 0, 0}; long long ph_w = 0;
+#define MDETR_PH_MARK(idx) do { if (threadIdx.x == 0) { const long long n_ = clock64(); atomicAdd(reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(hdr) + 64) + ((w.mode == 1 ? 12 : 0) + (idx)), static_cast<unsigned long long>(n_ - ph_t)); ph_t = n_; } } while (0)
+#define MDETR_PH_W0() do { if (threadIdx.x == 0) ph_w = clock64(); } while (0)
+#define MDETR_PH_W(i) do { if (threadIdx.x == 0) { const long long n_ = clock64(); ph_acc[i] += n_ - ph_w; ph_w = n_; } } while (0)
+#define MDETR_PH_WFLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 3; ++i_) atomicAdd(reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(hdr) + 64) + ((w.mode == 1 ? 12 : 0) + 8 + i_), static_cast<unsigned long long>(ph_acc[i_])); } while (0)
+#else
+#define MDETR_PH_DECL
+#define MDETR_PH_MARK(idx) do { } while (0)
+#define MDETR_PH_W0() do { } while (0)
+#define MDETR_PH_W(i) do { } while (0)
+#define MDETR_PH_WFLUSH() do { } while (0)
+#endif
+
 namespace mdetr {
 namespace {
 
@@ -99,6 +115,7 @@ struct FusedPlan {
     long long scr_per_bm;
     int max_cells;
     int max_tab;                      // ints of the centre-cell tables a mode-0 block may need
+    int npre;                         // workgroups of the pre-pass = pairs of maxima behind the workspace header
     int small;                        // every extent < 2^13: the rectangle bounds and chunk limits fit 32-bit arithmetic
 };
 
@@ -504,6 +521,18 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
 
     const int bid = blockIdx.x;
     const int b = bid % pl.B, r_ = bid / pl.B, m = r_ % pl.M, kblk = r_ / pl.M;      // image -> XCD (bid % 8)
+    MDETR_PH_DECL
+    unsigned *wmax = blk + 4;                                                // 2 words per wave: the pre-pass's maxima, reduced
+    // the pre-pass left one pair of maxima per workgroup behind the header: requested first, consumed after the block's bounds
+    unsigned mg_ = 0u, ma_ = 0u;
+    {
+        const uint2 *maxima = reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned char *>(hdr) + 256);
+        for (int i = threadIdx.x; i < pl.npre; i += THREADS) {
+            const uint2 v = maxima[i];
+            mg_ = v.x > mg_ ? v.x : mg_;
+            ma_ = v.y > ma_ ? v.y : ma_;
+        }
+    }
     const Work w = decode_block(pl, kblk, lv);
     // TH x TW: the cells this block accumulates in LDS -- the core tile, the whole level (mode 1), or the core plus its halo (mode 3)
     const int l = w.l, H = pl.H[l], W = pl.W[l];
@@ -548,34 +577,29 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
         }
     }
 
-    // one power-of-two scale per call: |w * attn * g| <= max|attn| * max|g| = mx < 2^e.  The pre-pass left one pair of maxima per
-    // workgroup behind the header: every block reduces them (one 8-byte load per thread, a wave reduction, 2 x waves words of LDS)
+    // one power-of-two scale per call: |w * attn * g| <= max|attn| * max|g| = mx < 2^e (every block reduces the pre-pass's per-
+    // workgroup maxima: one 8-byte load per thread above, a wave reduction, 2 words of LDS per wave).  The same barrier covers the
+    // first zero fill of the window.
+    for (int i = threadIdx.x; i < (w.ncell + kTrash) * kCellStride; i += THREADS) win[i] = 0ull;
+    for (int i = threadIdx.x; i < w.ncell; i += THREADS) cnt[i] = 0u;
+    if (threadIdx.x == 0) { blk[0] = 0u; blk[1] = kWavesB * 64u; blk[2] = 0u; blk[3] = 0u; }
     float mx;
     {
-        const uint2 *maxima = reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned char *>(hdr) + 256);
-        const int npre = static_cast<int>(hdr->npre);
-        unsigned mg = 0u, ma = 0u;
-        for (int i = threadIdx.x; i < npre; i += THREADS) {
-            const uint2 v = maxima[i];
-            mg = v.x > mg ? v.x : mg;
-            ma = v.y > ma ? v.y : ma;
-        }
         for (int o = 32; o > 0; o >>= 1) {
-            const unsigned og = __shfl_xor(mg, o), oa = __shfl_xor(ma, o);
-            mg = og > mg ? og : mg;
-            ma = oa > ma ? oa : ma;
+            const unsigned og = __shfl_xor(mg_, o), oa = __shfl_xor(ma_, o);
+            mg_ = og > mg_ ? og : mg_;
+            ma_ = oa > ma_ ? oa : ma_;
         }
-        if (lane == 0) { recs[2 * wave] = mg; recs[2 * wave + 1] = ma; }    // (the record buffers are idle until the pass starts)
+        if (lane == 0) { wmax[2 * wave] = mg_; wmax[2 * wave + 1] = ma_; }
         __syncthreads();
-        mg = 0u; ma = 0u;
+        unsigned mg = 0u, ma = 0u;
 #pragma unroll
         for (int i = 0; i < kWavesB; ++i) {
-            const unsigned vg = recs[2 * i], va = recs[2 * i + 1];
+            const unsigned vg = wmax[2 * i], va = wmax[2 * i + 1];
             mg = vg > mg ? vg : mg;
             ma = va > ma ? va : ma;
         }
         mx = __builtin_bit_cast(float, mg) * __builtin_bit_cast(float, ma);
-        // (no barrier needed before the records are written: every wave passes the barrier behind the window's zero fill first)
     }
     const bool finite = mx <= 3.0e38f;                        // inf / NaN somewhere: every corner goes to the `far` buffer
     int e = 0;
@@ -583,14 +607,18 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
     const int nsamp = w.nq * P;
     const float inv_p = 1.0f / static_cast<float>(P);
 
+    MDETR_PH_MARK(0);
     for (int shift = 0;; ++shift) {
         // contributions are rounded to multiples of 2^-(22 - shift - e): |x| * scale < 2^(22 - shift), up to 2^(9 + shift) - 1 per cell
         const float scale = ldexpf(1.0f, 22 - shift - e);
         const float magic = ldexpf(1.0f, 23) + ldexpf(1.0f, 22 - shift);
-        for (int i = threadIdx.x; i < (w.ncell + kTrash) * kCellStride; i += THREADS) win[i] = 0ull;
-        for (int i = threadIdx.x; i < w.ncell; i += THREADS) cnt[i] = 0u;
-        if (threadIdx.x == 0) blk[0] = 0u;
-        __syncthreads();
+        if (shift > 0) {                                      // (the first pass's zero fill shares the prologue's barrier)
+            for (int i = threadIdx.x; i < (w.ncell + kTrash) * kCellStride; i += THREADS) win[i] = 0ull;
+            for (int i = threadIdx.x; i < w.ncell; i += THREADS) cnt[i] = 0u;
+            if (threadIdx.x == 0) { blk[0] = 0u; blk[1] = kWavesB * 64u; blk[2 + (shift & 1)] = 0u; }
+            __syncthreads();
+        }
+        MDETR_PH_MARK(1);
 
         // candidate decode + the loads of its location / weight, issued one step AHEAD of their use (the loop is bound by
         // memory round trips, not by arithmetic: everything that can be in flight early is)
@@ -626,9 +654,16 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
             c.a = c.act ? attn[srec] : 0.f;
         };
 
+        // steps of 64 candidates: the first one per wave by position, the following ones from a counter in LDS -- the steps differ
+        // (a row of the candidate rectangle inside the core is all own samples, a row of its margin none), and with a fixed
+        // stride the waves of a block finished up to a third apart (the barrier behind the loop was 17 % of a block's time)
         Cand cur;
         if (wave * 64 < nsamp) decode(wave * 64, cur);
-        for (int base = wave * 64; base < nsamp; base += kWavesB * 64) {
+        for (int base = wave * 64; base < nsamp;) {
+            MDETR_PH_W0();
+            unsigned nxt_ = 0u;
+            if (lane == 0) nxt_ = atomicAdd(blk + 1, 64u);
+            const int next_base = __builtin_amdgcn_readfirstlane(static_cast<int>(nxt_));
             // ---- a. one candidate sample per lane: footprint, ownership, record ----------------------------------------
             bool keep = false, owned = false;
             unsigned rec[kRecDw];
@@ -701,7 +736,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 rec[10] = __builtin_bit_cast(unsigned, lw);
                 rec[11] = valid | (farm << 4) | (static_cast<unsigned>(p) << 8);
             }
-            if (base + kWavesB * 64 < nsamp) decode(base + kWavesB * 64, cur);           // next step's loads go out now
+            if (next_base < nsamp) decode(next_base, cur);                              // next step's loads go out now
             // own samples are listed from the front of the wave's record buffer, neighbours' from the back (owner scheme: every
             // active lane is an own sample and the active lanes are a prefix of the wave: the list is the lanes themselves)
             const unsigned long long mo = OWNER ? 0ull : __ballot(keep && owned), mh = OWNER ? 0ull : __ballot(keep && !owned);
@@ -724,6 +759,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 *reinterpret_cast<uint4 *>(dst + 8) = make_uint4(rec[8], rec[9], rec[10], rec[11]);
             }
             wave_sync();
+            MDETR_PH_W(0);
 
             // ---- b1. own samples, SPG per group (LPS lanes x CPL channels each), up to GMAX groups per batch: every load of the
             //          batch is requested before the first group is consumed ---------------------------------------------------
@@ -811,6 +847,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                     }
                 }
             }
+            MDETR_PH_W(1);
             // ---- b2. neighbours' samples that reach into this core: accumulate only ---------------------------------------
             auto halo_batch = [&](auto ngc, int i0) __attribute__((always_inline)) {
                 constexpr int NG = decltype(ngc)::value;
@@ -849,28 +886,39 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 }
             }
             wave_sync();
+            MDETR_PH_W(2);
+            base = next_base;
         }
+        MDETR_PH_MARK(2);
         __syncthreads();
+        MDETR_PH_MARK(3);
+        MDETR_PH_WFLUSH();
 
-        // ---- c. did any cell draw more contributions than a 32-bit field holds at this scale? ---------------------------
-        {
+        // ---- c. read-out: strip the n * (magic bits) the atomics added along, store.  Did any cell draw more contributions than a
+        //         32-bit field holds at this scale?  The maximum count is taken along; the (rare) repeat overwrites what this pass stored.
+        //         (Owner scheme: the read-out ADDS into grad_value, so its counts are checked first.)
+        if (OWNER) {
             unsigned mc = 0u;
             for (int i = threadIdx.x; i < w.ncell; i += THREADS) mc = max(mc, cnt[i]);
             for (int o = 32; o > 0; o >>= 1) mc = max(mc, __shfl_xor(mc, o));
             if (lane == 0) atomicMax(blk, mc);
+            __syncthreads();
+            const unsigned maxcnt0 = blk[0];
+            __syncthreads();
+            if (finite && maxcnt0 >= (512u << shift) && shift < 12) continue;
         }
-        __syncthreads();
-        const unsigned maxcnt = blk[0];
-        __syncthreads();
-        if (!finite || maxcnt < (512u << shift) || shift >= 12) {
-            // ---- d. read-out: strip the n * (magic bits) the atomics added along, store ----------------------------------
+        MDETR_PH_MARK(4);
+        {
             const unsigned long long cbits = static_cast<unsigned long long>(__builtin_bit_cast(unsigned, magic)) * 0x100000001ull;
             const float inv = finite ? ldexpf(1.0f, -(22 - shift - e)) : 0.f;
             float *dst1 = scratch + (static_cast<int64_t>(b) * M + m) * pl.scr_per_bm + pl.scr0[l] + static_cast<int64_t>(w.slot) * w.ncell * kCH;
             float *dst0 = grad_value + ((static_cast<int64_t>(b) * pl.S + pl.start[l]) * M + m) * kCH;
+            unsigned mc = 0u;
             for (int i = threadIdx.x; i < w.ncell * kCellU64; i += THREADS) {
                 const int cell = i / kCellU64, pr = i % kCellU64;
-                const unsigned long long s = win[cell * kCellStride + pr] - static_cast<unsigned long long>(cnt[cell]) * cbits;
+                const unsigned n = cnt[cell];
+                mc = max(mc, n);
+                const unsigned long long s = win[cell * kCellStride + pr] - static_cast<unsigned long long>(n) * cbits;
                 const int lo = static_cast<int>(static_cast<unsigned>(s));
                 const int hi = static_cast<int>((static_cast<long long>(s) - static_cast<long long>(lo)) >> 32);
                 const float2 out = make_float2(static_cast<float>(lo) * inv, static_cast<float>(hi) * inv);
@@ -879,7 +927,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                     // halo covers it, and of the other query chunks (mode 1) -- fp32 atomics into the zero-filled grad_value, as the
                     // reference accumulates (.cuh:125-152), but one per cell, channel and block instead of one per sample
                     const int yy = w.cy0 + cell / w.tstride, xx = w.cx0 + cell % w.tstride;
-                    if (cnt[cell] != 0u && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    if (n != 0u && yy >= 0 && yy < H && xx >= 0 && xx < W) {
                         float *dst = dst0 + static_cast<int64_t>(yy * W + xx) * (M * kCH) + 2 * pr;
                         unsafeAtomicAdd(dst, out.x);
                         unsafeAtomicAdd(dst + 1, out.y);
@@ -892,7 +940,18 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                         *reinterpret_cast<float2 *>(dst0 + static_cast<int64_t>(yy * W + xx) * (M * kCH) + 2 * pr) = out;
                 }
             }
-            break;
+            if (OWNER) break;
+            for (int o = 32; o > 0; o >>= 1) mc = max(mc, __shfl_xor(mc, o));
+            // (one vote word per pass parity: the word of pass `shift` is zeroed again at the start of pass shift + 2, behind a barrier
+            // of pass shift + 1 -- a wave still reading it cannot meet the reset.  No __syncthreads_or: its library form takes
+            // static LDS on top of the 160 KB this kernel asks for, and the launch fails.)
+            if (lane == 0) atomicMax(blk + 2 + (shift & 1), mc);
+            __syncthreads();
+            const unsigned maxcnt = blk[2 + (shift & 1)];
+            if (!(finite && maxcnt >= (512u << shift) && shift < 12)) {
+                MDETR_PH_MARK(5);
+                break;
+            }
         }
     }
 }
@@ -1090,8 +1149,19 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
         pl.max_cells = cells > pl.max_cells ? cells : pl.max_cells;
         pl.bstride[l] = 1;
     }
-    // block numbering: the chunked levels first (their blocks are the longest), interleaved chunk by chunk; then the tiled
-    // levels, coarsest first
+    // block numbering = dispatch order: the longest blocks first, so that the launch's tail is made of short ones.  Measured per
+    // block at the encoder shape (cycles per phase, -DMDETR_PHASES): a 24 x 32 core tile 85 us, a 1/12 query chunk of a whole level
+    // 42 us -- with the chunked levels in front (rounds 2 and 3) the last quarter-round of tiles ran on a quarter of the CUs.
+    // MDETR_MSDA_ORDER=0 restores that order.  Chunked levels with the same chunk count stay interleaved chunk by chunk.
+    const bool tiles_first = env_int("MDETR_MSDA_ORDER", 1) != 0;
+    auto number_tiled = [&]() {
+        for (int l = 0; l < L; ++l) {                        // finest level first: its tiles are full-sized
+            if (pl.mode[l] == 1) continue;
+            pl.blk0[l] = blk;
+            blk += pl.nblk[l];
+        }
+    };
+    if (tiles_first) number_tiled();
     int n1 = 0, first_chunks = 0;
     for (int l = L - 1; l >= 0; --l)
         if (pl.mode[l] == 1) { if (!n1) first_chunks = pl.nchunk[l]; if (pl.nchunk[l] == first_chunks) ++n1; }
@@ -1101,9 +1171,16 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
     }
     blk += n1 * first_chunks;
     for (int l = L - 1; l >= 0; --l) {
-        if (pl.mode[l] == 1 && pl.nchunk[l] == first_chunks) continue;
+        if (pl.mode[l] != 1 || pl.nchunk[l] == first_chunks) continue;
         pl.blk0[l] = blk;
         blk += pl.nblk[l];
+    }
+    if (!tiles_first) {
+        for (int l = L - 1; l >= 0; --l) {
+            if (pl.mode[l] == 1) continue;
+            pl.blk0[l] = blk;
+            blk += pl.nblk[l];
+        }
     }
     pl.nblocks = blk;
     pl.scr_per_bm = scr;
@@ -1147,6 +1224,7 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
     // grid-stride over 16-byte pieces, four per lane and trip: no more workgroups than that gives work to (small calls)
     const int64_t pre_items = (n_go + n_at) / 4 + (pl.owner ? nfar / 4 : nfar / 4 / 64);
     const unsigned pre_blocks = static_cast<unsigned>(pre_items / (256 * 4) < kMaxPre ? (pre_items / (256 * 4) > 0 ? pre_items / (256 * 4) : 1) : kMaxPre);
+    pl.npre = static_cast<int>(pre_blocks);
     profile_begin(7, Lq, st);
     if (elem_dtype == 2)
         hipLaunchKernelGGL(msda_absmax_kernel<__hip_bfloat16>, dim3(pre_blocks), dim3(256), 0, st, static_cast<const __hip_bfloat16 *>(grad_out), n_go, attn, n_at, hdr, far, nfar, pl.owner);
@@ -1159,7 +1237,7 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
     threads = (threads >= 1024 && elem_dtype == 2) ? 1024 : ((threads == 768 && elem_dtype == 2) ? 768 : 512);
     auto lds_bytes = [&](int thr) {
         return lds_win_bytes(pl.max_cells) + lds_cnt_bytes(pl.max_cells) + static_cast<size_t>(thr / 64) * 64 * kRecDw * 4 +
-               static_cast<size_t>(pl.max_tab) * 4 + 128 + 16;
+               static_cast<size_t>(pl.max_tab) * 4 + 128 + 16 + 128;
     };
     size_t lds = lds_bytes(threads);
     if (lds > 160 * 1024 && threads > 512) {

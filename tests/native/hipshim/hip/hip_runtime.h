@@ -125,6 +125,16 @@ inline unsigned long long __ballot(int pred)
     hipshim::sync_wave();
     return r;
 }
+// block-wide vote with a barrier on both sides
+inline int __syncthreads_or(int pred)
+{
+    hipshim::exchange[threadIdx.x] = pred != 0;
+    hipshim::sync_block();
+    int r = 0;
+    for (unsigned t = 0; t < blockDim.x * blockDim.y * blockDim.z; ++t) r |= static_cast<int>(hipshim::exchange[t]);
+    hipshim::sync_block();
+    return r;
+}
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 
 template <typename T, typename U> inline T atomicAdd(T *p, U v) { const T old = *p; *p = old + static_cast<T>(v); return old; }
@@ -142,7 +152,17 @@ inline void __builtin_amdgcn_fence(int, const char *) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}               // a hint to the instruction scheduler: nothing to emulate
 inline void __builtin_amdgcn_wave_barrier() { hipshim::sync_wave(); }        // lanes run one after another here: a real rendezvous
 inline void __builtin_amdgcn_s_barrier() { hipshim::sync_block(); }
-inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+// value of the wave's first live lane (every live lane of the wave takes part)
+inline int __builtin_amdgcn_readfirstlane(int v)
+{
+    const int me = threadIdx.x, base = hipshim::lane_base();
+    memcpy(&hipshim::exchange[me], &v, sizeof(int));
+    hipshim::sync_wave();
+    int r;
+    memcpy(&r, &hipshim::exchange[base], sizeof(int));
+    hipshim::sync_wave();
+    return r;
+}
 inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }                // only used on wave-uniform values
 // v_mov_b32 with a DPP modifier, all rows / banks enabled, bound_ctrl: quad_perm, row_shl / row_shr, row_mirror,
 // row_half_mirror (the controls the sources use); a row is 16 lanes.  Invalid source lanes read 0 (bound_ctrl).
