@@ -55,6 +55,9 @@
 #ifndef MDETR_ABL
 #define MDETR_ABL 0
 #endif
+#ifndef MDETR_ROLL
+#define MDETR_ROLL 0
+#endif
 
 // developer timing: -DMDETR_PHASES accumulates shader-clock cycles per phase (thread 0 of every block; wave 0 for the sections of
 // the main loop) into 16 x 2 64-bit words at byte 64 of the workspace header's maxima area end (read by tools/opbench --phases)
@@ -124,6 +127,11 @@ __host__ __device__ inline int ceil_div_ll(long long a, long long b)   // b > 0,
 {
     return static_cast<int>(a >= 0 ? (a + b - 1) / b : -((-a) / b));
 }
+
+#ifndef MDETR_NOPAD
+#define MDETR_NOPAD 0
+#endif
+__host__ __device__ inline int row_pad(int tw) { return (!MDETR_NOPAD && tw % 16 == 0) ? 1 : 0; }      // tiled windows: see decode_block
 
 // cell of level l (extent n_l) that holds the centre of cell y of a level with extent n_q
 __host__ __device__ inline int centre_cell(int y, int n_l, int n_q)
@@ -415,7 +423,10 @@ __device__ __forceinline__ Work decode_block(const FusedPlan &pl, int k, int *bo
     } else {
         const unsigned ntx = static_cast<unsigned>(pl.ntx[l]);
         const int ty = static_cast<int>(static_cast<unsigned>(t) / ntx), tx = t - ty * static_cast<int>(ntx);
-        w.cy0 = ty * pl.TH[l]; w.cx0 = tx * pl.TW[l]; w.tstride = pl.TW[l]; w.ncell = pl.TH[l] * pl.TW[l];
+        // (a window row of a multiple of 16 cells gets one cell of padding: with 136-byte cells, rows 32 cells apart start on the
+        // same LDS bank -- the four points of a query of a head whose offsets run along y then collide 4-way in every ds_add_u64;
+        // that was the 37 % bank-conflict share of the LDS cycles in rounds 2 and 3)
+        w.cy0 = ty * pl.TH[l]; w.cx0 = tx * pl.TW[l]; w.tstride = pl.TW[l] + row_pad(pl.TW[l]); w.ncell = pl.TH[l] * w.tstride;
         if (w.mode == 2) {
             w.nq = pl.Lq;
         } else {
@@ -479,7 +490,13 @@ template <int CPL>
 __device__ __forceinline__ void accumulate(unsigned long long *win, unsigned o01, unsigned o23, const float (&wt)[4],
                                            const float (&ag)[CPL], int k, float magic)
 {
-    const unsigned cell[4] = {o01 & 0xFFFFu, o01 >> 16, o23 & 0xFFFFu, o23 >> 16};
+    unsigned cell[4] = {o01 & 0xFFFFu, o01 >> 16, o23 & 0xFFFFu, o23 >> 16};
+    if (MDETR_ABL & 32) {                                     // timing only: the 8 samples of a half-wave on disjoint banks
+        const unsigned s8 = (threadIdx.x / (2 * CPL > 8 ? 4 : 8)) & 7u;
+        const unsigned tb[8] = {0u, 17u, 2u, 19u, 16u, 1u, 18u, 3u};
+        const unsigned cc = s8 == 0 ? tb[0] : s8 == 1 ? tb[1] : s8 == 2 ? tb[2] : s8 == 3 ? tb[3] : s8 == 4 ? tb[4] : s8 == 5 ? tb[5] : s8 == 6 ? tb[6] : tb[7];
+        cell[0] = cc; cell[1] = cc + 32u; cell[2] = cc + 64u; cell[3] = cc + 96u;
+    }
     const f32x2 mg = make_f32x2(magic, magic);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -820,7 +837,8 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 for (int t = 0; t < NG; ++t) {
                     const int r = min(i0 + SPG * t + j, no - 1);
                     const uint2 h = *reinterpret_cast<const uint2 *>(wrec + r * kRecDw);
-                    rg[t] = RG::load(gbase + (pair0u + h.x * static_cast<unsigned>(M)) * static_cast<unsigned>(kCH * Elem<GT>::kBytes));
+                    if (MDETR_ABL & 16) rg[t] = RG::load(reinterpret_cast<const char *>(wrec + (r & 31) * kRecDw));
+                    else rg[t] = RG::load(gbase + (pair0u + h.x * static_cast<unsigned>(M)) * static_cast<unsigned>(kCH * Elem<GT>::kBytes));
                     const int dxb = (h.y >> 30) & 1u ? rowb : 0, dyb = (h.y >> 31) ? W * rowb : 0;
                     const char *vb = vlev + (h.y & 0xFFFFFFu) * static_cast<unsigned>(rowb);
                     if (!(MDETR_ABL & 2)) {
@@ -834,8 +852,39 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                     run_own(r < no, min(r, no - 1), rg[t], rv[t]);
                 }
             };
+#if MDETR_ROLL
+            // rolling form: group t + 1's loads are requested BEFORE group t is consumed, two register sets alternating -- one
+            // exposed round trip per step instead of one per batch of GMAX groups (the ablations say the own pass waits: without
+            // the gather AND without the accumulation it costs nothing, with either one nearly everything)
+            if (no > 0 && !(MDETR_ABL & 4)) {
+                auto load_group = [&](int gi, typename RG::T &rg, typename RV::T (&rv)[4]) __attribute__((always_inline)) {
+                    const int r = min(gi * SPG + j, no - 1);
+                    const uint2 h = *reinterpret_cast<const uint2 *>(wrec + r * kRecDw);
+                    rg = RG::load(gbase + (pair0u + h.x * static_cast<unsigned>(M)) * static_cast<unsigned>(kCH * Elem<GT>::kBytes));
+                    const int dxb = (h.y >> 30) & 1u ? rowb : 0, dyb = (h.y >> 31) ? W * rowb : 0;
+                    const char *vb = vlev + (h.y & 0xFFFFFFu) * static_cast<unsigned>(rowb);
+                    rv[0] = RV::load(vb); rv[1] = RV::load(vb + dxb);
+                    rv[2] = RV::load(vb + dyb); rv[3] = RV::load(vb + dyb + dxb);
+                };
+                const int G = (no + SPG - 1) / SPG;                                      // wave-uniform
+                typename RG::T gA, gB;
+                typename RV::T vA[4], vB[4];
+                load_group(0, gA, vA);
+                for (int t = 0; t < G; t += 2) {
+                    if (t + 1 < G) load_group(t + 1, gB, vB);
+                    { const int r = t * SPG + j; run_own(r < no, min(r, no - 1), gA, vA); }
+                    if (t + 1 < G) {
+                        if (t + 2 < G) load_group(t + 2, gA, vA);
+                        { const int r = (t + 1) * SPG + j; run_own(r < no, min(r, no - 1), gB, vB); }
+                    }
+                }
+            }
+            for (int i0 = 0; false; ) {
+                const int ng = 0;
+#else
             for (int i0 = 0; i0 < no && !(MDETR_ABL & 4); i0 += SPG * GMAX) {
                 const int ng = min(GMAX, (no - i0 + SPG - 1) / SPG);                      // wave-uniform
+#endif
                 if constexpr (GMAX == 1) {
                     own_batch(std::integral_constant<int, 1>(), i0);
                 } else {
@@ -935,8 +984,9 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 } else if (w.mode == 1) {
                     *reinterpret_cast<float2 *>(dst1 + static_cast<int64_t>(cell) * kCH + 2 * pr) = out;
                 } else {
-                    const int yy = w.cy0 + cell / w.tstride, xx = w.cx0 + cell % w.tstride;
-                    if (yy < H && xx < W)                     // cores partition the level: exclusive owner, plain store
+                    const int wxx = cell % w.tstride;
+                    const int yy = w.cy0 + cell / w.tstride, xx = w.cx0 + wxx;
+                    if (yy < H && xx < W && wxx < pl.TW[l])   // cores partition the level: exclusive owner, plain store (not the padding column)
                         *reinterpret_cast<float2 *>(dst0 + static_cast<int64_t>(yy * W + xx) * (M * kCH) + 2 * pr) = out;
                 }
             }
@@ -1136,7 +1186,7 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
             // the owner's "does a neighbour see this query" test looks one tile out: the reach must not exceed a tile
             if (self && ((pl.nty[l] > 1 && reach > TH) || (pl.ntx[l] > 1 && reach > TW))) return false;
             pl.nblk[l] = pl.nty[l] * pl.ntx[l];
-            cells = TH * TW;
+            cells = TH * (TW + row_pad(TW));
             if (self) {                                      // centre-cell tables: rows + columns of the candidate rectangle on every query level
                 int tab = 0;
                 for (int lq = 0; lq < L; ++lq)
