@@ -862,6 +862,11 @@ hipError_t msda_forward_bf16_launch(const void *value, const int64_t *shapes, co
     if (D != 32 || L != 4 || P != 4) return hipErrorNotSupported;
     if (static_cast<int64_t>(B) * Lq * M == 0) return hipSuccess;
     struct Scope { hipStream_t s; Scope(int Lq_, hipStream_t s_) : s(s_) { profile_begin(0, Lq_, s_); } ~Scope() { profile_end(s); } } scope(Lq, st);
+    // (Round 4 measured a head-blocked form -- one head of one image per workgroup, levels 2 / 3 resident in LDS, four lanes
+    // per query with 16-byte requests: 0.191-0.201 ms against this kernel's 0.193-0.196 at the encoder shape, 0.223 vs 0.202 for
+    // N(0, 4 px) offsets, profiles/r04m_msda_fwd_head_blocked_vs_record.log.  Halving the rows gathered through memory bought
+    // nothing: with one head per workgroup a 128-byte line carries one useful 64-byte row instead of two, so the number of L1
+    // line look-ups per (query, head) pair is the same 32.  Not kept.)
     const int npairs = Lq * M, iters = rounds_per_block(B, npairs);
     const int chunks = (npairs + 32 * iters - 1) / (32 * iters);
     hipLaunchKernelGGL((msda_fwd_rec<4, 4, __hip_bfloat16, __hip_bfloat16>), dim3(static_cast<unsigned>(B) * chunks), dim3(kWaves * 64), 0, st,

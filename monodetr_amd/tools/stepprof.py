@@ -32,11 +32,11 @@ def main():
     add_ln_ext._host_seed = lambda: host_seed() & (2 ** 63 - 1)
     step = bench.TrainStep(torch.device("cuda", 0), 8, a.precision, switches=bench.committed_switches(a.precision)[0])
     for _ in range(5):
-        step._step()
+        step.eager_iteration()
     torch.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
         for _ in range(a.steps):
-            step._step()
+            step.eager_iteration()
         torch.cuda.synchronize()
     rows = collections.defaultdict(lambda: [0, 0.0])
     for e in prof.key_averages(group_by_input_shape=True):
