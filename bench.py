@@ -297,13 +297,14 @@ def _emit(tag, obj):
     print("CPU-BASELINE " + json.dumps({tag: obj}), flush=True)
 
 
-def cpu_msda_op_baseline(warm=3, timed=10, leg_budget_s=10.0, emit=None):
+def cpu_msda_op_baseline(warm=3, timed=10, leg_budget_s=25.0, emit=None, min_timed=5):
     """BASELINE.md section 3.  The reference's CPU path for the operator is `ms_deform_attn_core_pytorch`
     (ops/functions/ms_deform_attn_func.py:41-61: one F.grid_sample per level + weighted sum); /root/reference does not
     exist on the GPU box, so its port oracle/msda_torch_ref.msda_grid_sample is timed: fp32, every host core, inputs as
     ops/test.py:33-36 (seed 3, value = rand * 0.01, loc = rand, attn = rand + 1e-5 normalised), 3 warm-up + 10 timed calls,
     forward alone and forward + backward (autograd), decoder-train (Lq = 550) and encoder (Lq = S = 10 200) shapes at B = 8.
-    GB/s on the ALGORITHMIC bytes of SURVEY.md 8d.  A leg whose calls are too slow for `leg_budget_s` runs fewer of them
+    GB/s on the ALGORITHMIC bytes of SURVEY.md 8d.  Every leg times at least `min_timed` calls (the encoder's forward + backward
+    takes ~3.5 s per call on 128 cores: 5 calls); a leg whose single call exceeds a third of `leg_budget_s` is sampled once
     (the counts actually used are in the record)."""
     from oracle.msda_torch_ref import msda_grid_sample                # checker, used only in this leg
     B, M, D, P = 8, 8, 32, 4
@@ -336,7 +337,7 @@ def cpu_msda_op_baseline(warm=3, timed=10, leg_budget_s=10.0, emit=None):
                 n_warm = min(warm - 1, max(0, int(leg_budget_s / 4 / first)))
                 for _ in range(n_warm):
                     fn()
-                n_timed = max(2, min(timed, int((leg_budget_s - first * (1 + n_warm)) / first)))
+                n_timed = max(min_timed, min(timed, int((leg_budget_s - first * (1 + n_warm)) / first)))
                 t0 = time.perf_counter()
                 for _ in range(n_timed):
                     fn()
@@ -374,7 +375,7 @@ def cpu_baseline_child(steps=3, batch=2):
     cpu_msda_op_baseline(emit=_emit)
 
 
-def cpu_baseline(steps=3, batch=2, timeout_s=240):
+def cpu_baseline(steps=3, batch=2, timeout_s=300):
     """The reported CPU baseline (kind "port": /root/reference cannot travel to the GPU box; its arithmetic is pinned to
     the reference's by tests/test_oracle_golden.py and tests/test_model_cpu.py).  Two parts, measured in a child process
     under a hard time limit: the whole training iteration at batch `batch` with PyTorch CPU ops and the C oracle as the
@@ -408,7 +409,7 @@ def cpu_baseline(steps=3, batch=2, timeout_s=240):
            "kind": "port", "cpu": host.get("cpu", "unknown"),
            "sample": "%d training iteration(s) at batch %d (3x384x1280, fp32) after 1 warm-up: PyTorch CPU ops + the C oracle as the MSDA "
                      "operator; msda_op = BASELINE.md section 3 protocol on oracle/msda_torch_ref (port of ms_deform_attn_core_pytorch), "
-                     "B=8, up to 3 warm-up + 10 timed calls within 10 s per leg" % (steps, batch),
+                     "B=8, up to 3 warm-up + 5-10 timed calls (about 25 s) per leg" % (steps, batch),
            "s_per_iter": stepr.get("s_per_iter"), "msda_op": parts.get("msda_op", {})}
     if note:
         res["note"] = note
@@ -627,16 +628,24 @@ def main():
 
     # ---- per-kernel timings from the HIP events recorded by the C ABI during the timed steps --------
     names = {0: "msda_fwd_rec", 1: "msda_bwd_d32", 2: "msda_scatter_tiles", 3: "msda_reduce_tiles",
-             4: "attn_fwd_kernel", 5: "attn_bwd(prep+dq+dkv)", 6: "msda_bwd_fused", 7: "msda_absmax", 8: "msda_finalize"}
+             4: "attn_fwd_kernel", 5: "attn_bwd(prep+dq+dkv)", 6: "msda_bwd_fused", 7: "msda_absmax", 8: "msda_finalize", 9: "convolution"}
     kernels, by_key = [], {}
     msda_mixed = "MDETR_MSDA_BF16" in step.switches               # bf16-native operator: 2-byte value / out / grad_out
+    MFMA_PEAK_TF = 2500.0                                            # dense bf16 (MI355X_MICROARCH.md; the headline 5 PF includes 2:1 sparsity)
+    mfma_groups = {"attention_forward": [0.0, 0.0, 0], "attention_backward": [0.0, 0.0, 0], "convolutions": [0.0, 0.0, 0]}   # flop, ms, launches
     for kind, key, launches, total_ms in _capi.profile_read():
         avg = total_ms / max(launches, 1)
+        if kind == 9:                                                # hand-written convolutions: key = MFLOP of the launch
+            g = mfma_groups["convolutions"]
+            g[0] += key * 1e6 * launches; g[1] += total_ms; g[2] += launches
+            continue
         row = {"kernel": names.get(kind, str(kind)), "launches": launches, "avg_ms": round(avg, 4)}
         if kind in (4, 5):
             Lq, Lk = key // 4096, key % 4096
             flops = 4.0 * args.batch * 8 * Lq * Lk * 32 * (1.0 if kind == 4 else 2.5)
-            row.update(Lq=Lq, Lk=Lk, TFLOPs=round(flops / avg / 1e9, 1))
+            row.update(Lq=Lq, Lk=Lk, TFLOPs=round(flops / avg / 1e9, 1), mfma_utilisation=round(flops / avg / 1e9 / MFMA_PEAK_TF, 4))
+            g = mfma_groups["attention_forward" if kind == 4 else "attention_backward"]
+            g[0] += flops * launches; g[1] += total_ms; g[2] += launches
         else:
             row["Lq"] = key
             if kind == 0:
@@ -698,6 +707,14 @@ def main():
             line["roofline"]["traffic_source"] = traffic_note
             line["ops"] = ops
             line["kernels"] = kernels
+        # the MFMA kernels of the step (north_star: "MFMA-utilisation ... against gfx950 peak"): useful FLOP of every launch of a
+        # family / the HIP-event time of those launches, against the dense bf16 peak.  utilisation = achieved / peak (what the
+        # MFMA-busy counter of profiles/*pmc_attn.json gives when divided by 1 024 SIMDs x kernel cycles)
+        line["mfma"] = {"peak_TFLOPs": MFMA_PEAK_TF, "dtype": "bf16", "timing": kernel_timing,
+                        **{k: {"TFLOPs": round(g[0] / g[1] / 1e9, 1), "utilisation": round(g[0] / g[1] / 1e9 / MFMA_PEAK_TF, 4),
+                               "launches_per_step": round(g[2] / (3 if use_graph else args.steps), 1),
+                               "ms_per_step": round(g[1] / (3 if use_graph else args.steps), 3)}
+                           for k, g in mfma_groups.items() if g[1] > 0}}
         line["config"]["cpu_affinity"] = "NUMA node %d of the GPU" % bound[0] if bound else "unbound"
         line["config"]["gpu_clocks"] = clocks
         # optional kernel families in this run: the committed list, or the environment's for an A/B run

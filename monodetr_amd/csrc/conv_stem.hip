@@ -20,6 +20,7 @@
 #include <mdetr_wave.h>
 
 #include "conv_stem.h"
+#include "msda.h"       // profile scopes
 
 namespace mdetr {
 namespace {
@@ -131,6 +132,7 @@ hipError_t conv_stem_launch(const void *x, const void *wp, const float *shift, v
     d.groups_x = (d.tiles_x + kTilesPerWg - 1) / kTilesPerWg;
     d.tiles_y = (d.OH + kWavesS - 1) / kWavesS;
     const int64_t blocks = static_cast<int64_t>(B) * d.tiles_y * d.groups_x;
+    ProfileScope prof(9, conv_mflop(static_cast<int64_t>(B) * d.OH * d.OW, 64 * 3 * 49), st);
     hipLaunchKernelGGL(conv_stem_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kWavesS * 64), 0, st, static_cast<const __bf16 *>(x),
                        static_cast<const __bf16 *>(wp), shift, static_cast<__bf16 *>(y), d);
     return hipGetLastError();

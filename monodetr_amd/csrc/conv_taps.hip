@@ -28,6 +28,7 @@
 #include <mdetr_wave.h>
 
 #include "conv_taps.h"
+#include "msda.h"       // profile scopes
 
 // Contraction channels per LDS slab.  32, not conv3x3.hip's 64: the stride-2 halo of a 4 x 32-pixel tile is 9 x 65 pixels -- 84 KB at
 // 64 channels + padding, which with the weights left ONE workgroup (four waves) per CU; at 32 channels the tile is 47 + 31 KB and
@@ -403,11 +404,14 @@ hipError_t conv_dgrad_s2_launch(const void *dy, const void *wt, void *dx, int B,
     }
     q.blk0[4] = blk;
     if (blk == 0) return hipSuccess;
+    // every output pixel of dY meets every (tap, channel pair) once: the four parity classes together are the dense product
+    ProfileScope prof(9, conv_mflop(static_cast<int64_t>(B) * OH * OW, static_cast<int64_t>(C) * N * K * K), st);
     return nb == 4 ? launch_dgrad4<4>(dy, wt, dx, q, st) : launch_dgrad4<2>(dy, wt, dx, q, st);
 }
 
 hipError_t conv_taps_launch(const void *x, const void *w, const float *shift, void *y, const ConvTapsDims &d, bool relu, hipStream_t st)
 {
+    ProfileScope prof(9, conv_mflop(static_cast<int64_t>(d.B) * d.OH * d.OW, static_cast<int64_t>(d.C) * d.N * d.TR * d.TS), st);
     if (d.SI == 2) return d.TR == 3 ? by_width<3, 3, 2>(x, w, shift, y, d, relu, st) : by_width<1, 1, 2>(x, w, shift, y, d, relu, st);
     if (d.TR == 1) return d.TS == 1 ? by_width<1, 1, 1>(x, w, shift, y, d, relu, st) : by_width<1, 2, 1>(x, w, shift, y, d, relu, st);
     return d.TS == 1 ? by_width<2, 1, 1>(x, w, shift, y, d, relu, st) : by_width<2, 2, 1>(x, w, shift, y, d, relu, st);

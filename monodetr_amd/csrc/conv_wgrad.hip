@@ -29,6 +29,7 @@
 #include <mdetr_wave.h>
 
 #include "conv_wgrad.h"
+#include "msda.h"       // profile scopes
 
 namespace mdetr {
 namespace {
@@ -284,6 +285,7 @@ int conv_wgrad_chunks(const ConvWgradDims &d) { return geometry(d).chunks; }
 hipError_t conv_wgrad_launch(const void *x, const void *dy, float *part, const ConvWgradDims &d, hipStream_t st)
 {
     const WgradGeom g = geometry(d);
+    ProfileScope prof(9, conv_mflop(static_cast<int64_t>(d.B) * d.OH * d.OW, static_cast<int64_t>(d.C) * d.N * d.K * d.K), st);
     if (d.K == 3) return d.SI == 1 ? launch<1, 3>(x, dy, part, g, st) : launch<2, 3>(x, dy, part, g, st);
     return d.SI == 1 ? launch<1, 1>(x, dy, part, g, st) : launch<2, 1>(x, dy, part, g, st);
 }

@@ -110,5 +110,13 @@ hipError_t zero_fill_launch(void *p, int64_t bytes, hipStream_t st);
 // event-pair profiling of kernel launches (capi.hip owns the storage)
 void profile_begin(int kind, int Lq, hipStream_t st);
 void profile_end(hipStream_t st);
+// one event pair around the launches of a scope.  kind 9 = a hand-written convolution, key = its MFLOP (2 x MACs / 1e6): what
+// bench.py's `mfma` object sums into TFLOP/s against the dense bf16 MFMA peak
+struct ProfileScope {
+    hipStream_t s;
+    ProfileScope(int kind, int64_t key, hipStream_t st) : s(st) { profile_begin(kind, static_cast<int>(key > 0x7fffffff ? 0x7fffffff : key), st); }
+    ~ProfileScope() { profile_end(s); }
+};
+inline int64_t conv_mflop(int64_t out_pixels, int64_t macs_per_pixel) { return (2 * out_pixels * macs_per_pixel + 500000) / 1000000; }
 
 }  // namespace mdetr

@@ -52,6 +52,16 @@ def _signature(x):
     return tuple((tuple(t.shape), t.dtype) for t in _tree_leaves(x))
 
 
+def _rccl_group_is_up():
+    """A process group whose backend runs a watchdog thread over HIP events (nccl = RCCL) exists in this process."""
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return False
+    try:
+        return "nccl" in str(torch.distributed.get_backend()).lower()
+    except Exception:                                        # noqa: BLE001 -- an exotic backend: assume the worst
+        return True
+
+
 class TrainIteration:
     """model + criterion + optimizer on one device; ``run(batch)`` is one full training iteration.
 
@@ -64,6 +74,10 @@ class TrainIteration:
                  graph="off", eager_steps=3, capture_error_mode="global", log=None, on_captured=None):
         self.model = self.raw_model = model
         self.criterion, self.optimizer, self.device = criterion, optimizer, torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            # device('cuda') and device('cuda:0') neither compare nor hash equal: the per-iteration dropout seed scope
+            # (attn_ext.begin_iteration) is keyed on the device the kernels see, which always carries its index
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.grad_sync, self.pending_sync = grad_sync, pending_sync
         self.prepare = prepare
         self.compute = compute or self._compute_full
@@ -81,6 +95,19 @@ class TrainIteration:
         self._sig = None
         self._log = log or (lambda msg: print(msg, file=sys.stderr, flush=True))
         self.on_captured = on_captured                        # called once after the capture attempt (creates a deferred process group)
+        if self.want_graph:
+            from .. import _runtime_env
+            if not _runtime_env.graph_packets_off():
+                # torch was imported before this package: the runtime flag that keeps ROCm 7's pre-recorded graph packets from
+                # corrupting a replay that follows eager launches (profiles/r03_graph_replay_corruption.md) is NOT in effect
+                if self.strict:
+                    self._log("WARNING: %s=0 was not set before the HIP runtime loaded (import monodetr_amd before torch, or export "
+                              "it): graph replay was asked for explicitly and stays on, guarded only by its own launch stream"
+                              % _runtime_env.GRAPH_PACKET_ENV)
+                else:
+                    self._log("graph replay not used: %s=0 was not set before the HIP runtime loaded (import monodetr_amd before "
+                              "torch, or export it); eager launches" % _runtime_env.GRAPH_PACKET_ENV)
+                    self.want_graph = False
         if self.want_graph:
             self._device_lr()
 
@@ -178,6 +205,14 @@ class TrainIteration:
             raise RuntimeError("graph replay needs the flat gradient exchange (MDETR_BENCH_SYNC=flat)")
         if self.model is not self.raw_model:
             raise RuntimeError("graph replay is not available under the DistributedDataParallel wrapper")
+        # RCCL's watchdog polls its streams' events; during a stream capture that query fails with hipErrorCapturedEvent and the
+        # watchdog ABORTS the process (profiles/r02m_rccl_watchdog_abort.txt) -- an abort, not an exception, so graph="auto"
+        # could not fall back.  The supported order is capture first, process group afterwards (pending_sync +
+        # attach_process_group(); tools/train_val.py and bench.py defer the group): with a live NCCL / RCCL group, or a gradient
+        # exchange already attached, raise here and let try_capture() take the eager path.
+        if self.device.type == "cuda" and (self.grad_sync is not None or _rccl_group_is_up()):
+            raise RuntimeError("capture before the process group exists: a live RCCL group aborts the process during a stream "
+                               "capture (build the trainer first, call attach_process_group() afterwards)")
         while self.eager_done < self.eager_steps:
             self._eager(batch)
         from ..attn_ext import _next_seed

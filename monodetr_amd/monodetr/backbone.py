@@ -140,8 +140,11 @@ def conv_bn(x, conv, bn, relu):
                                           scale.to(conv.weight.dtype).view(-1, 1, 1, 1), shift.to(dt))
             w = (conv.weight * cast[1]).to(dt)
             b = cast[2]
+        # (decimate only when the decimated tensor WILL take the stride-1 token path: the fall-backs below still apply the
+        # convolution's own stride and would stride the gathered pixels a second time)
         if decimate_ext.ENABLED and tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (0, 0) \
-                and conv.groups == 1 and x.dtype == w.dtype and decimate_ext.supported(x) and not torch.is_autocast_enabled():
+                and conv.groups == 1 and x.dtype == w.dtype and decimate_ext.supported(x) and not torch.is_autocast_enabled() \
+                and pointwise_eligible(x, conv.kernel_size, (1, 1), conv.padding, conv.groups):
             # the projection shortcut of a stage's first block: a 1x1 / stride-2 convolution reads only the pixels it keeps -- gather
             # them (csrc/decimate.hip) and run the stride-1 token GEMM path below
             x = decimate_ext.decimate2(x)

@@ -103,7 +103,9 @@ class _TokenLinearSkip(torch.autograd.Function):
             if dskip is None:
                 dx = (dy2 @ weight).view_as(q)
             elif dskip.is_contiguous() and dskip.dtype == dy2.dtype:
-                dx = dskip.view(-1, q.shape[-1]).addmm_(dy2, weight).view_as(q)      # (the arriving gradient is this node's alone)
+                # beta = 1 GEMM reading the arriving gradient, writing a NEW tensor: the same traffic as the in-place form (the
+                # library reads C and writes D either way), and a tensor hook / retain_grad() holder of `dskip` keeps its values
+                dx = torch.addmm(dskip.view(-1, q.shape[-1]), dy2, weight).view_as(q)
             else:
                 dx = dskip + (dy2 @ weight).view_as(q)
         dw, db = _weight_bias_grads(q2, dy2, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])

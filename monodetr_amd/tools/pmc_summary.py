@@ -58,10 +58,12 @@ def main():
                           ("SQ_ACTIVE_INST_ANY", "frac_issuing")):
                 if k in c:
                     row[nm] = round(c[k] / c["SQ_WAVE_CYCLES"], 4)
-        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CYCLES" in c and c["SQ_BUSY_CYCLES"] > 0:
-            # MFMA_BUSY counts cycles summed over SIMDs; SQ_BUSY_CYCLES per SQ (per CU/SE instance, quad-cycle units differ):
-            # the ratio is only an index -- the absolute MFMA utilisation is computed from the MFMA count in DESIGN.md
-            row["mfma_busy_over_sq_busy"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CYCLES"], 4)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE", 0) > 0:
+            # MFMA utilisation = cycles the matrix pipes were busy, summed over the 1 024 SIMDs (256 CUs x 4), over SIMDs x the
+            # kernel's duration in cycles.  GRBM_GUI_ACTIVE comes summed over the 8 XCDs (0.49 ms of MSDA backward reads 9.4 M
+            # at 2.4 GHz), so the kernel ran GRBM_GUI_ACTIVE / 8 cycles: busy / (1024 x GRBM / 8).  (Rounds 1-3 printed
+            # busy / SQ_BUSY_CYCLES -- a per-SE counter under a per-SIMD sum, values 1.5-11 -- which is not a utilisation.)
+            row["mfma_utilisation"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (128.0 * c["GRBM_GUI_ACTIVE"]), 4)
         if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
             row["lds_conflict_frac"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 4)
         rows.append(row)

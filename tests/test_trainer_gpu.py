@@ -180,6 +180,47 @@ def _pg_child():
     torch.distributed.destroy_process_group()
 
 
+def _pg_first_child():
+    """The WRONG order -- the RCCL group exists before the iteration object is built (a user script that calls
+    init_process_group first): graph="auto" must notice, launch eagerly and keep training; it must not start a capture (the
+    group's watchdog would abort the process, profiles/r02m_rccl_watchdog_abort.txt)."""
+    import bench
+    from monodetr_amd.helpers.dist_helper import FlatGradSync
+    from monodetr_amd.helpers.trainer_helper import TARGET_KEYS
+    dev = torch.device("cuda", 0)
+    switches = bench.committed_switches("bf16")[0]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29549")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    it, _ = build(dev, True, switches)
+    it.strict = False                                                     # graph="auto"
+    it.grad_sync = FlatGradSync(it.raw_model.parameters())
+    seq = []
+    for i in range(6):
+        images, calibs, t = collated_batch(2, seed=300 + i)
+        images = images.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        seq.append(float(it.run((images, calibs.to(dev), t['img_size'], {k: t[k] for k in TARGET_KEYS}))))
+    torch.cuda.synchronize()
+    ok = all(math.isfinite(x) for x in seq)
+    print("PG-FIRST launch=%r replays=%d finite=%s %s" % (it.launch_mode(), it.replays, ok, [round(x, 2) for x in seq]), flush=True)
+    torch.distributed.destroy_process_group()
+
+
+def test_a_live_process_group_makes_the_iteration_launch_eagerly_instead_of_capturing():
+    import subprocess
+    import sys
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]))
+    done = subprocess.run([sys.executable, os.path.abspath(__file__), "--pg-first-child"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                          text=True, timeout=900)
+    tail = done.stdout[-3000:]
+    print(tail)
+    assert done.returncode == 0, tail
+    line = [ln for ln in done.stdout.splitlines() if ln.startswith("PG-FIRST")][-1]
+    assert "launch='eager (graph capture failed" in line and "capture before the process group exists" in line, line
+    assert "replays=0" in line and "finite=True" in line, line
+
+
 def test_two_graph_form_with_the_process_group_created_after_the_capture():
     """One process per GPU (tools/train_val.py): the iteration is captured BEFORE the process group exists -- a live group's
     watchdog thread polls events while a capture is under way and aborts the process -- then the group is created, rank 0's
@@ -200,3 +241,5 @@ if __name__ == "__main__":
     import sys
     if "--pg-child" in sys.argv:
         _pg_child()
+    if "--pg-first-child" in sys.argv:
+        _pg_first_child()
