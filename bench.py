@@ -153,9 +153,9 @@ class TrainStep(TrainIteration):
         elif ddp and torch.distributed.is_initialized():
             # default N > 1 path: one flat all-reduce per dtype after the backward; "bucketed": the same exchange in
             # ~32 MB buckets issued from gradient hooks while the backward is still running (helpers/dist_helper.py)
-            from monodetr_amd.helpers.dist_helper import BucketedGradSync, FlatGradSync, broadcast_parameters
+            from monodetr_amd.helpers.dist_helper import BucketedGradSync, FlatGradSync, SplitGradSync, broadcast_parameters
             broadcast_parameters(model)
-            grad_sync = (BucketedGradSync if ddp == "bucketed" else FlatGradSync)(model.parameters())
+            grad_sync = {"bucketed": BucketedGradSync, "overlap": SplitGradSync}.get(ddp, FlatGradSync)(model.parameters())
         pending = ddp if (ddp and ddp != "ddp" and grad_sync is None) else None   # attach_process_group() later
         optimizer = build_optimizer(dict(OPT_CFG, capturable=graph, fused="MDETR_FUSED_ADAMW" in self.switches), model)
         self.precision = precision
@@ -534,10 +534,12 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
     dist_on = world > 1 or force_ddp
-    sync_mode = os.environ.get("MDETR_BENCH_SYNC", "flat") if dist_on else False
-    want_graph = args.graph != "off" and sync_mode in (False, "flat")
+    # N > 1: "overlap" (default) = the backward pass cut at the backbone's outputs, the upper gradients' all-reduce running beside
+    # the backbone's backward (three graph replays per iteration); "flat" = one exchange after the whole backward (two replays)
+    sync_mode = os.environ.get("MDETR_BENCH_SYNC", "overlap") if dist_on else False
+    want_graph = args.graph != "off" and sync_mode in (False, "flat", "overlap")
     if args.graph == "on" and not want_graph:
-        raise SystemExit("--graph on needs the flat gradient exchange (MDETR_BENCH_SYNC=flat), not %r" % (sync_mode,))
+        raise SystemExit("--graph on needs the flat or overlapped gradient exchange (MDETR_BENCH_SYNC=flat | overlap), not %r" % (sync_mode,))
 
     def init_process_group():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -560,8 +562,7 @@ def main():
     if want_graph:                                                  # untimed: part of start-up, like model build
         if args.graph == "on":
             step.capture()
-            launch_mode = ("one hipGraph replay per iteration" if step.graph_opt is None else
-                           "two hipGraph replays per iteration (forward + backward | optimizer) around the eager RCCL gradient all-reduce")
+            launch_mode = step.launch_mode()
         else:
             launch_mode = step.try_capture()
         if dist_on:
@@ -692,7 +693,7 @@ def main():
             "config": {"workload": workload, "baseline_config": args.config,
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "image": img, "queries": queries,
                        "precision": args.precision, "parallelism": "dp%d" % world,
-                       "grad_sync": (os.environ.get("MDETR_BENCH_SYNC", "flat") if dist_on else "none"), "prime_steps": args.prime,
+                       "grad_sync": (sync_mode if dist_on else "none"), "prime_steps": args.prime,
                        "launch": launch_mode,
                        **({"gemm_selection": "TunableOp during start-up"} if tunable else {})},
             "final_loss": round(float(loss), 4),
@@ -762,7 +763,7 @@ def main():
                 import datetime
                 one_rank = lambda: torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=device,   # noqa: E731
                                                                         timeout=datetime.timedelta(minutes=5))
-                line["rccl_1rank"] = time_variant(device, args, args.precision, chosen, ddp="flat", graph=use_graph, pg_init=one_rank)
+                line["rccl_1rank"] = time_variant(device, args, args.precision, chosen, ddp="overlap", graph=use_graph, pg_init=one_rank)
                 torch.distributed.destroy_process_group()
             except Exception as e:
                 line["rccl_1rank"] = {"value": None, "error": repr(e)[:200]}

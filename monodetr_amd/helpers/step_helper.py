@@ -85,7 +85,8 @@ class TrainIteration:
         self.strict = graph == "on"
         self.eager_steps = eager_steps
         self.capture_error_mode = capture_error_mode
-        self.graph = self.graph_opt = self.sync_plan = self.static = self.stream = None
+        self.graph = self.graph_opt = self.graph_bb = self.sync_plan = self.static = self.stream = None
+        self._boundary = None
         self.loss = self.losses = self._captured = None
         self._capturing = False
         self.num_global = None                                # two-graph form: the rank-averaged object count, filled before each replay
@@ -127,7 +128,13 @@ class TrainIteration:
             total = sum(losses[k] * w[k] for k in losses if k in w)
         return total, losses
 
-    def _forward_backward(self, batch):
+    def _overlap(self):
+        """Is the gradient exchange the two-part, overlapped one (dist_helper.SplitGradSync) -- now or once the group exists?"""
+        return (type(self.grad_sync).__name__ == "SplitGradSync" or self.pending_sync == "overlap") and hasattr(self.raw_model, "pyramid")
+
+    def _forward_backward(self, batch, cut=False):
+        """Forward, criterion and backward pass.  cut: the backward pass stops at the backbone's outputs (MonoDETR.pyramid cuts
+        the pyramid levels out of the graph); `_backward_backbone()` continues from there."""
         # set_to_none (not zero-fill): the flat gradient exchanges re-point every parameter's .grad at slices of their reduced
         # buffer (helpers/dist_helper.py); a kept-and-zeroed .grad would make the next backward ACCUMULATE into that slice
         self.optimizer.zero_grad(set_to_none=True)
@@ -135,16 +142,41 @@ class TrainIteration:
         if scoped:                                            # one device-side dropout-seed bump for the whole iteration
             from .. import attn_ext
             attn_ext.begin_iteration(self.device)
+        self._boundary = [] if cut else None
+        if cut:
+            self.raw_model.__dict__["_grad_boundary"] = self._boundary
         try:
             total, losses = self.compute(batch)
             total.backward()
         finally:
+            self.raw_model.__dict__.pop("_grad_boundary", None)
             if scoped:
                 attn_ext.end_iteration(self.device)
         self.losses = losses
         return total
 
+    def _backward_backbone(self):
+        """The second part of a cut backward pass: from the gradients that arrived at the pyramid levels down through the backbone."""
+        pairs = [(t, td.grad) for t, td in (self._boundary or ()) if td.grad is not None]
+        self._boundary = None
+        if pairs:
+            torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
+
+    def _with_grad(self, exclude=()):
+        seen = {id(p) for p in exclude}
+        return [p for p in self.raw_model.parameters() if p.requires_grad and p.grad is not None and id(p) not in seen]
+
     def _step(self, batch):
+        if self.grad_sync is not None and self._overlap():
+            # [forward + upper backward] -> exchange of the upper gradients starts -> [backbone backward] -> its exchange -> wait
+            total = self._forward_backward(batch, cut=True)
+            upper = self._with_grad()
+            self.grad_sync.start(upper)
+            self._backward_backbone()
+            self.grad_sync.start(self._with_grad(exclude=upper))
+            self.grad_sync.finish()
+            self.optimizer.step()
+            return total
         total = self._forward_backward(batch)
         if self.grad_sync is not None:
             self.grad_sync.sync()
@@ -201,8 +233,9 @@ class TrainIteration:
     def capture(self, batch, in_place=False):
         """Record the iteration on `batch`'s shapes.  in_place: `batch`'s own device tensors become the static buffers
         (bench.py: one resident synthetic batch)."""
-        if (self.grad_sync is not None and type(self.grad_sync).__name__ != "FlatGradSync") or self.pending_sync not in (None, "flat"):
-            raise RuntimeError("graph replay needs the flat gradient exchange (MDETR_BENCH_SYNC=flat)")
+        if (self.grad_sync is not None and type(self.grad_sync).__name__ not in ("FlatGradSync", "SplitGradSync")) \
+                or self.pending_sync not in (None, "flat", "overlap"):
+            raise RuntimeError("graph replay needs the flat or the two-part gradient exchange (MDETR_BENCH_SYNC=flat | overlap)")
         if self.model is not self.raw_model:
             raise RuntimeError("graph replay is not available under the DistributedDataParallel wrapper")
         # RCCL's watchdog polls its streams' events; during a stream capture that query fails with hipErrorCapturedEvent and the
@@ -225,7 +258,7 @@ class TrainIteration:
         if hasattr(self.optimizer, "flush_replays"):
             self.optimizer.flush_replays()
         torch.cuda.synchronize(self.device)
-        graph, graph_opt = torch.cuda.CUDAGraph(), None
+        graph, graph_opt, graph_bb = torch.cuda.CUDAGraph(), None, None
         self.optimizer.zero_grad(set_to_none=True)
         mode = dict(capture_error_mode=self.capture_error_mode)
         two = self.grad_sync is not None or self.pending_sync is not None
@@ -241,12 +274,22 @@ class TrainIteration:
                     self.loss = self._step_captured(self.static)
             else:
                 from .dist_helper import static_plan
+                cut = self._overlap()
                 with torch.cuda.graph(graph, stream=side, **mode):
-                    self.loss = self._forward_backward(self.static)
+                    self.loss = self._forward_backward(self.static, cut=cut)
                 # the gradients now sit at the addresses the captured backward writes to: every later exchange gathers from THOSE
                 # into persistent flat buffers, reduces there, and the captured optimizer reads the reduced slices
-                self.sync_plan = static_plan(self.raw_model.parameters())
-                for ps, src, flat, views in self.sync_plan:
+                if cut:
+                    upper = self._with_grad()
+                    graph_bb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph_bb, stream=side, pool=graph.pool(), **mode):
+                        self._backward_backbone()
+                    self.sync_plan = {"upper": static_plan(upper), "backbone": static_plan(self._with_grad(exclude=upper))}
+                    plans = [e for part in self.sync_plan.values() for e in part]
+                else:
+                    self.sync_plan = static_plan(self.raw_model.parameters())
+                    plans = self.sync_plan
+                for ps, src, flat, views in plans:
                     for p_, v in zip(ps, views):
                         p_.grad = v
                 graph_opt = torch.cuda.CUDAGraph()
@@ -259,7 +302,7 @@ class TrainIteration:
         if hasattr(self.optimizer, "uncount_step"):
             self.optimizer.uncount_step()                    # the capture ran the host bookkeeping of a step no kernel executed
         torch.cuda.synchronize(self.device)
-        self.graph, self.graph_opt = graph, graph_opt
+        self.graph, self.graph_opt, self.graph_bb = graph, graph_opt, graph_bb
         self._captured = (self.loss, self.losses)
         return self
 
@@ -291,7 +334,7 @@ class TrainIteration:
             if self.strict:
                 raise
             self.capture_error = repr(e)[:160]
-            self.graph = self.graph_opt = self.sync_plan = self.static = self.num_global = None
+            self.graph = self.graph_opt = self.graph_bb = self.sync_plan = self.static = self.num_global = None
             if self.grad_sync is not None:
                 self.grad_sync._static = None
             self.want_graph = False
@@ -303,6 +346,9 @@ class TrainIteration:
     def launch_mode(self):
         if self.graph is None:
             return "eager" + (" (graph capture failed: %s)" % self.capture_error if self.capture_error else "")
+        if self.graph_bb is not None:
+            return ("three hipGraph replays per iteration (forward + upper backward | backbone backward | optimizer): the RCCL "
+                    "all-reduce of the upper gradients runs beside the backbone's backward")
         return ("one hipGraph replay per iteration" if self.graph_opt is None else
                 "two hipGraph replays per iteration (forward + backward | optimizer) around the eager RCCL gradient all-reduce")
 
@@ -314,7 +360,7 @@ class TrainIteration:
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
         if int(flag) == 0 and self.graph is not None:
             self.capture_error = "capture failed on another rank"
-            self.graph = self.graph_opt = self.sync_plan = self.static = self.num_global = None
+            self.graph = self.graph_opt = self.graph_bb = self.sync_plan = self.static = self.num_global = None
             self.want_graph = False
             if self.grad_sync is not None:
                 self.grad_sync._static = None
@@ -324,13 +370,14 @@ class TrainIteration:
         """The N > 1 half of a construction that captured BEFORE torch.distributed was up: rank 0's parameters and optimizer
         state to everybody, the gradient exchange (gathering from the captured backward's gradient tensors if the step replays
         graphs), and one decision for all ranks."""
-        from .dist_helper import BucketedGradSync, FlatGradSync, broadcast_parameters
+        from .dist_helper import BucketedGradSync, FlatGradSync, SplitGradSync, broadcast_parameters
         if self.pending_sync is None:
             return self.launch_mode()
         self.agree_on_launch_mode()
         broadcast_parameters(self.raw_model, extra=[t for st in self.optimizer.state.values() for t in st.values() if torch.is_tensor(t)] +
                              [t for b in (getattr(self.optimizer, "_flat", None) or (None, []))[1] for t in b.values() if torch.is_tensor(t)])
-        self.grad_sync = (BucketedGradSync if self.pending_sync == "bucketed" else FlatGradSync)(self.raw_model.parameters())
+        kinds = {"bucketed": BucketedGradSync, "overlap": SplitGradSync}
+        self.grad_sync = kinds.get(self.pending_sync, FlatGradSync)(self.raw_model.parameters())
         if self.graph is not None:
             self.grad_sync._static = self.sync_plan
         self.pending_sync = None
@@ -350,7 +397,13 @@ class TrainIteration:
             self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream if own else cur):
             self.graph.replay()
-            if self.graph_opt is not None:
+            if self.graph_bb is not None:                    # the upper gradients travel while the backbone's backward replays
+                self.grad_sync.start(part="upper")
+                self.graph_bb.replay()
+                self.grad_sync.start(part="backbone")
+                self.grad_sync.finish()
+                self.graph_opt.replay()
+            elif self.graph_opt is not None:
                 self.grad_sync.sync()
                 self.graph_opt.replay()
         if own:

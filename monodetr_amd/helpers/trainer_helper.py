@@ -45,11 +45,14 @@ class Trainer(object):
         # several processes whose group does not exist yet (tools/train_val.py under graph replay): the iteration is captured first,
         # the first iterations run on each rank's own shard, then the group is created and rank 0's state goes to everybody
         self.process = process
-        self.pending_sync = "flat" if (process is not None and process.world > 1 and not torch.distributed.is_initialized()) else None
+        # ("overlap": the backward pass cut at the backbone's outputs, the upper gradients exchanged beside the backbone's backward
+        # -- dist_helper.SplitGradSync; trainer.grad_sync: flat restores the single exchange after the whole backward)
+        kind = str(cfg.get("grad_sync", "overlap"))
+        self.pending_sync = kind if (process is not None and process.world > 1 and not torch.distributed.is_initialized()) else None
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            from .dist_helper import FlatGradSync, broadcast_parameters
+            from .dist_helper import FlatGradSync, SplitGradSync, broadcast_parameters
             broadcast_parameters(self.model)
-            self.grad_sync = FlatGradSync(self.model.parameters())
+            self.grad_sync = (SplitGradSync if kind == "overlap" else FlatGradSync)(self.model.parameters())
 
         if cfg.get('pretrain_model'):
             assert os.path.exists(cfg['pretrain_model'])
@@ -115,16 +118,16 @@ class Trainer(object):
     def _attach_group(self, iteration):
         """Create the process group (after the capture, or at once when the iteration launches eagerly) and wire the gradient
         exchange: rank 0's parameters and optimizer state go to every rank."""
-        from .dist_helper import FlatGradSync, broadcast_parameters
+        from .dist_helper import FlatGradSync, SplitGradSync, broadcast_parameters
         if self.process is not None:
             self.process.init_group()
-        self.pending_sync = None
+        kind, self.pending_sync = self.pending_sync, None
         if iteration is not None:
             self.logger.info("launch mode: %s" % iteration.attach_process_group())
             self.grad_sync = iteration.grad_sync
         elif torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             broadcast_parameters(self.model)
-            self.grad_sync = FlatGradSync(self.model.parameters())
+            self.grad_sync = (SplitGradSync if kind == "overlap" else FlatGradSync)(self.model.parameters())
 
     def train_step(self, inputs, calibs, targets, info=None):
         """One iteration on a collated batch; returns the dict of unweighted loss tensors (on the device)."""

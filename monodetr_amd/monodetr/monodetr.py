@@ -121,6 +121,20 @@ class MonoDETR(nn.Module):
         """Backbone + input projections (monodetr.py:156-178 of the reference): (srcs, masks, pos), one entry per
         feature level."""
         features, pos = self.backbone(images)
+        boundary = self.__dict__.get("_grad_boundary")
+        if boundary is not None and torch.is_grad_enabled():
+            # a two-part backward pass (helpers/step_helper.TrainIteration, N > 1 ranks): the pyramid levels are cut out of the
+            # autograd graph here -- everything above runs on detached copies, whose .grad the second part (the backbone's
+            # backward) starts from, while the gradients of the part above are already being exchanged
+            cut = []
+            for f in features:
+                t = f.tensors
+                if t.requires_grad:
+                    td = t.detach().requires_grad_(True)
+                    boundary.append((t, td))
+                    f = NestedTensor(td, f.mask)
+                cut.append(f)
+            features = cut
         srcs, masks = [], []
         for l, feat in enumerate(features):
             src, mask = feat.decompose()

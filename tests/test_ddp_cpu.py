@@ -141,8 +141,8 @@ def _worker(rank, world, port, out_dir, port2):
         # bench.py's own step object on the N > 1 path (gloo here, RCCL on the GPUs), both exchanges: ranks hold identical
         # parameters after two iterations, and every rank runs the same committed switch list
         import bench
-        same_bench = {}
-        for mode in ("flat", "bucketed"):
+        same_bench, after = {}, {}
+        for mode in ("flat", "bucketed", "overlap"):
             step = bench.TrainStep(torch.device("cpu"), 1, "fp32", ddp=mode, local_rank=rank, size=(96, 320), switches=())
             for _ in range(2):
                 step()
@@ -150,6 +150,11 @@ def _worker(rank, world, port, out_dir, port2):
             gathered = [torch.empty_like(flat) for _ in range(world)]
             dist.all_gather(gathered, flat)
             same_bench[mode] = all(torch.equal(gathered[0], g) for g in gathered[1:])
+            after[mode] = flat.clone()
+        # the two-part exchange (backward pass cut at the backbone's outputs, upper gradients reduced while the backbone's backward
+        # runs -- helpers/dist_helper.SplitGradSync) leaves the parameters the flat exchange leaves: same gradients, same averages
+        overlap_vs_flat = ((after["overlap"] - after["flat"]).abs().max() / (after["flat"].abs().max() + 1e-12)).item()
+        split_kind = type(step.grad_sync).__name__
         # the step object built BEFORE the process group is attached (bench.py's order under graph replay): rank-dependent
         # weights on purpose, repaired by attach_process_group's broadcast (parameters and optimizer state)
         dist.destroy_process_group()
@@ -170,7 +175,7 @@ def _worker(rank, world, port, out_dir, port2):
         same_switches = all(l == lists[0] for l in lists)
         torch.save(dict(worst=worst, same=same, unused=unused, n_grads=len(got), worst_flat=worst_flat, same_flat=same_flat,
                         mixed_ok=mixed_ok, static_ok=static_ok, worst_bucketed=worst_bucketed, n_buckets=n_buckets, same_bench=same_bench,
-                        same_switches=same_switches), os.path.join(out_dir, "r%d.pt" % rank))
+                        same_switches=same_switches, overlap_vs_flat=overlap_vs_flat, split_kind=split_kind), os.path.join(out_dir, "r%d.pt" % rank))
     finally:
         dist.destroy_process_group()
 
@@ -185,7 +190,8 @@ def test_two_rank_ddp_step_matches_manual_gradient_average(tmp_path):
         assert res["worst"] < 1e-4, res["worst"]
         assert res["same_flat"] and res["worst_flat"] < 1e-4 and res["mixed_ok"] and res["static_ok"], res
         assert res["worst_bucketed"] < 1e-4 and res["n_buckets"] >= 3, res
-        assert res["same_bench"] == {"flat": True, "bucketed": True, "deferred": True} and res["same_switches"], res
+        assert res["same_bench"] == {"flat": True, "bucketed": True, "overlap": True, "deferred": True} and res["same_switches"], res
+        assert res["split_kind"] == "SplitGradSync" and res["overlap_vs_flat"] < 1e-6, res
         assert res["n_grads"] > 300
         assert all(n.startswith("label_enc") or ".sa_v_proj." in n or "decoder.query_scale" in n or "decoder.ref_point_head" in n
                    for n in res["unused"]), res["unused"]

@@ -147,7 +147,7 @@ def test_graph_sees_each_batch_not_the_captured_one():
         bench.apply_switches(set())
 
 
-def _pg_child():
+def _pg_child(kind="flat"):
     """The multi-process form of the Trainer's iteration with ONE rank: local eager iterations, the two graphs captured before
     RCCL exists, then the process group, the broadcast and the exchange between the two replays (tools/train_val.py's order)."""
     import bench
@@ -158,7 +158,7 @@ def _pg_child():
     os.environ.setdefault("MASTER_PORT", "29547")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     it, _ = build(dev, True, switches)
-    it.pending_sync = "flat"
+    it.pending_sync = kind
     it.strict = False
     modes = []
 
@@ -217,29 +217,39 @@ def test_a_live_process_group_makes_the_iteration_launch_eagerly_instead_of_capt
     print(tail)
     assert done.returncode == 0, tail
     line = [ln for ln in done.stdout.splitlines() if ln.startswith("PG-FIRST")][-1]
-    assert "launch='eager (graph capture failed" in line and "capture before the process group exists" in line, line
+    assert "eager (graph capture failed" in line and "capture before the process group exists" in line, line
     assert "replays=0" in line and "finite=True" in line, line
 
 
-def test_two_graph_form_with_the_process_group_created_after_the_capture():
+@pytest.mark.parametrize("kind,replays,sync", [("flat", "two hipGraph replays", "FlatGradSync"), ("overlap", "three hipGraph replays", "SplitGradSync")])
+def test_multi_graph_forms_with_the_process_group_created_after_the_capture(kind, replays, sync):
     """One process per GPU (tools/train_val.py): the iteration is captured BEFORE the process group exists -- a live group's
     watchdog thread polls events while a capture is under way and aborts the process -- then the group is created, rank 0's
-    state is broadcast, and every replay is [forward + backward] -> flat RCCL all-reduce -> [optimizer].  In a child process."""
+    state is broadcast, and every replay is [forward + backward] -> flat RCCL all-reduce -> [optimizer], or, with the overlapped
+    exchange, [forward + upper backward] -> all-reduce of the upper gradients beside [backbone backward] -> its all-reduce ->
+    [optimizer].  Both reach the same losses (the exchange of one rank is the identity).  In a child process."""
     import subprocess
     import sys
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]))
-    done = subprocess.run([sys.executable, os.path.abspath(__file__), "--pg-child"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+    done = subprocess.run([sys.executable, os.path.abspath(__file__), "--pg-child", kind], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                           text=True, timeout=900)
     tail = done.stdout[-3000:]
     print(tail)
     assert done.returncode == 0, tail
     line = [ln for ln in done.stdout.splitlines() if ln.startswith("PG-CHILD")][-1]
-    assert "two hipGraph replays" in line and "replays=7" in line and "finite=True" in line and "sync=FlatGradSync" in line, line
+    assert replays in line and "replays=7" in line and "finite=True" in line and "sync=%s" % sync in line, line
+    _PG_LOSSES[kind] = line[line.index("["):]
+    if len(_PG_LOSSES) == 2:                                              # same data, same weights: the cut changes nothing
+        a, b = (eval(_PG_LOSSES[k]) for k in ("flat", "overlap"))
+        assert max(abs(x - y) for x, y in zip(a, b)) <= 0.02 * max(abs(x) for x in a), (a, b)
+
+
+_PG_LOSSES = {}
 
 
 if __name__ == "__main__":
     import sys
     if "--pg-child" in sys.argv:
-        _pg_child()
+        _pg_child(sys.argv[sys.argv.index("--pg-child") + 1] if len(sys.argv) > sys.argv.index("--pg-child") + 1 else "flat")
     if "--pg-first-child" in sys.argv:
         _pg_first_child()
