@@ -163,21 +163,26 @@ class TrainStep(TrainIteration):
                          compute=self._compute_encoder if part == "encoder" else None,
                          graph="auto" if graph else "off", capture_error_mode=capture_error_mode)
         self.model = wrapped
-        H, W = size
-        self.inputs = synthetic_batch(batch, H, W, seed + 1000 * (local_rank + 1), device)
-        if device.type == "cuda":
-            self.inputs = (self.inputs[0].contiguous(memory_format=torch.channels_last),) + self.inputs[1:]
-        if precision == "bf16":
-            self.inputs = (self.inputs[0].to(torch.bfloat16),) + self.inputs[1:]
+        self._input_spec = (batch, size, precision, graph)
+        self.inputs = self.make_inputs(seed + 1000 * (local_rank + 1))
 
+    def make_inputs(self, seed):
+        """A synthetic batch in the form the step consumes (channels-last / bf16 images on the GPU, targets padded to KITTI's
+        max_objs = 50 once, outside the step -- the data loader's job, lib/datasets/kitti/kitti_dataset.py pads the same way)."""
+        batch, (H, W), precision, graph = self._input_spec
+        device = self.device
+        inputs = synthetic_batch(batch, H, W, seed, device)
         if device.type == "cuda":
-            # the ragged per-image target lists are padded to KITTI's max_objs = 50 once, outside the step
-            # (the data loader's job: lib/datasets/kitti/kitti_dataset.py pads to max_objs the same way)
+            inputs = (inputs[0].contiguous(memory_format=torch.channels_last),) + inputs[1:]
+        if precision == "bf16":
+            inputs = (inputs[0].to(torch.bfloat16),) + inputs[1:]
+        if device.type == "cuda":
             from monodetr_amd.monodetr.monodetr import pad_targets
-            padded = pad_targets(self.inputs[3], kmax=50)
+            padded = pad_targets(inputs[3], kmax=50)
             if graph:
                 padded["num_host"] = None                    # normaliser computed on the device: replays must not bake it in
-            self.inputs = self.inputs[:3] + (padded,)
+            inputs = inputs[:3] + (padded,)
+        return inputs
 
     def _compute_encoder(self, batch):
         srcs, masks, pos = self.raw_model.pyramid(batch[0])
