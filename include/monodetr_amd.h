@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDETR_ABI_VERSION 5
+#define MDETR_ABI_VERSION 6
 
 /* element types of the floating-point tensors */
 #define MDETR_F32 0
@@ -503,6 +503,19 @@ int mdetr_conv_stem(const void *x, const void *w_packed, const float *shift, voi
 int mdetr_conv_wgrad_chunks(int B, int H, int W, int C, int OH, int OW, int N, int K, int SI);
 int mdetr_conv_wgrad(const void *x, const void *dy, float *partial, int64_t partial_floats, int B, int H, int W, int C, int OH, int OW, int N,
                      int K, int SI, int device, void *stream);
+
+/*
+ * Weight AND bias gradient of a token-wise linear layer y = x W^T + b over T token rows (autograd of the nn.Linear / 1x1
+ * convolutions of lib/models/monodetr/depthaware_transformer.py:328-331, 409-423, ops/modules/ms_deform_attn.py:94-102,
+ * backbone.py:100-102), the 1x1 case of the kernel above with the column sums of dy riding along on the same operand:
+ *   dW[n, c] = sum_t dy[t, n] x[t, c],    db[n] = sum_t dy[t, n]
+ * The kernel writes mdetr_token_wgrad_chunks(T, C, N) partials, fp32 [chunks][N * C + (with_bias ? N : 0)] (a chunk's dW block,
+ * then its db); the caller adds the chunks in a fixed order (mdetr_column_sum_to) and rounds once.
+ *   x   bf16 [T, C] contiguous, C % 64 == 0;  dy  bf16 [T, N] contiguous, N % 32 == 0;  T % 8 == 0;  both 16-byte aligned
+ */
+int mdetr_token_wgrad_chunks(int64_t T, int C, int N);
+int mdetr_token_wgrad(const void *x, const void *dy, float *partial, int64_t partial_floats, int64_t T, int C, int N, int with_bias,
+                      int device, void *stream);
 
 /*
  * y = dropout(relu(x + bias[col] + skip)) over a [rows, cols] channels-last activation in one pass, and its backward --

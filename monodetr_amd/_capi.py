@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDETR_LIB_PATH") or os.path.join(_HERE, "libmonodetr_amd.so")
 
 MDETR_F32, MDETR_F64, MDETR_BF16 = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -57,6 +57,8 @@ SIGNATURES = {
     "mdetr_conv_stem": (_c_int, [_c_vp] * 4 + [_c_int] * 3 + [_c_int, _c_vp]),
     "mdetr_conv_wgrad_chunks": (_c_int, [_c_int] * 9),
     "mdetr_conv_wgrad": (_c_int, [_c_vp] * 3 + [ctypes.c_int64] + [_c_int] * 9 + [_c_int, _c_vp]),
+    "mdetr_token_wgrad_chunks": (_c_int, [ctypes.c_int64, _c_int, _c_int]),
+    "mdetr_token_wgrad": (_c_int, [_c_vp, _c_vp, _c_vp, ctypes.c_int64, ctypes.c_int64, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mdetr_small_wgrad_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, _c_int, _c_int]),
     "mdetr_small_wgrad": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_int, _c_vp, ctypes.c_int64, ctypes.c_int64, _c_int, _c_int, ctypes.c_int64, ctypes.c_int64, _c_int, _c_vp]),
     "mdetr_group_norm_workspace_bytes": (ctypes.c_int64, [_c_int, ctypes.c_int64, _c_int, _c_int]),

@@ -24,23 +24,51 @@ def supported(x, dy, k, stride):
             and dy.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0)
 
 
-# MDETR_TOKEN_WGRAD_CONV=1: weight gradients of token-wise linear layers over tens of thousands of rows (the encoder's 81 600, the
-# backbone's 1x1 convolutions) as the 1x1 case of this kernel instead of the library's batched split-K product
-TOKEN_ROUTE = os.environ.get("MDETR_TOKEN_WGRAD_CONV") == "1"
+# Weight AND bias gradients of token-wise linear layers over tens of thousands of rows (the encoder's 81 600, the backbone's 1x1
+# convolutions) as the 1x1 case of this kernel, the bias gradient riding along (mdetr_token_wgrad), instead of the library's batched
+# split-K product + chunk sum + two-launch column sum: 53 -> 43 us at [81 600, 256] x [81 600, 256], 49 -> 28-36 us on the backbone's
+# and the depth head's shapes (profiles/r04q_wgradbench.json).  MDETR_TOKEN_WGRAD_CONV=0 restores the library route.
+TOKEN_ROUTE = os.environ.get("MDETR_TOKEN_WGRAD_CONV", "1") != "0"
 
 
-def token_weight_gradient(x2, dy2, dtype):
-    """dW [N, K] = dy2^T x2 for token matrices x2 [T, K], dy2 [T, N] (bf16, contiguous rows, T a multiple of 8): the matrices
-    viewed as 1 x 8 x (T / 8) channels-last images, a 1x1 convolution's weight gradient."""
+def token_weight_gradient(x2, dy2, dtype, bias=False):
+    """(dW [N, K], db [N] or None) = (dy2^T x2, column sums of dy2) for token matrices x2 [T, K], dy2 [T, N] (bf16, contiguous rows, T a
+    multiple of 8): the 1x1 case of the convolution weight-gradient kernel, the bias gradient riding along on the dy operand that
+    is already in LDS -- one kernel + one sum over its chunks for both gradients (the library route: a batched split-K product, a
+    chunk sum, and a two-launch column sum that reads dy a second time)."""
     T, K = x2.shape
     N = dy2.shape[1]
-    xi = x2.view(1, 8, T // 8, K).permute(0, 3, 1, 2)
-    di = dy2.view(1, 8, T // 8, N).permute(0, 3, 1, 2)
-    return weight_gradient(xi, di, 1, 1, dtype).reshape(N, K)
+    lib = _lib()
+    chunks = lib.mdetr_token_wgrad_chunks(T, K, N)
+    if chunks <= 0:
+        raise RuntimeError("token_wgrad: unsupported problem")
+    cols = N * K + (N if bias else 0)
+    cuda = x2.is_cuda
+    if cuda and _backend is None:
+        from . import _workspace as W_
+        part = W_.get("conv_wgrad", x2.device, chunks * cols * 4).view(torch.float32)[:chunks * cols]
+    else:
+        part = torch.empty(chunks * cols, dtype=torch.float32, device=x2.device)
+    rc = lib.mdetr_token_wgrad(x2.data_ptr(), dy2.data_ptr(), part.data_ptr(), part.numel(), T, K, N, 1 if bias else 0,
+                               x2.device.index if cuda else -1, torch.cuda.current_stream(x2.device).cuda_stream if cuda else None)
+    if rc != 0:
+        _capi.check(rc, "mdetr_token_wgrad")
+    part = part.view(chunks, cols)
+    if cuda and _backend is None:
+        from .colsum_ext import column_sum, supported as colsum_ok
+        out_dt = dtype if dtype in (torch.float32, torch.bfloat16) else torch.float32
+        both = (column_sum(part, out_dtype=out_dt) if colsum_ok(part) else part.sum(0)).to(dtype)
+    else:
+        both = part.sum(0).to(dtype)
+    return both[:N * K].view(N, K), (both[N * K:] if bias else None)
 
 
 def token_supported(x2, dy2):
     T = x2.shape[0]
+    # (narrow outputs waste the kernel's 128-row dy block: 58 vs 49 us at N = 64; a weight of more than 64 (128 x 64) blocks leaves
+    # fewer than four chunks of tokens per block column: the library's split is better there)
+    if dy2.shape[1] < 128 or ((dy2.shape[1] + 127) // 128) * (x2.shape[1] // 64) > 64:
+        return False
     return (TOKEN_ROUTE and x2.dtype == torch.bfloat16 and dy2.dtype == torch.bfloat16 and x2.is_contiguous() and dy2.is_contiguous() and T % 8 == 0
             and x2.shape[1] % 64 == 0 and dy2.shape[1] % 32 == 0 and (x2.is_cuda or _backend is not None)
             and x2.data_ptr() % 16 == 0 and dy2.data_ptr() % 16 == 0 and T * max(x2.shape[1], dy2.shape[1]) * 2 < (1 << 31))

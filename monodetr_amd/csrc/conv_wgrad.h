@@ -11,6 +11,8 @@ struct ConvWgradDims {
     int B, H, W, C;
     int OH, OW, N;
     int K, SI;
+    int DB = 0;       // 1 (K = 1, SI = 1 only): every chunk also carries the column sums of dy -- the bias gradient of a token-wise linear
+                      // layer -- as N more floats behind its [N][C] block: part is [chunks][N * C + N]
 };
 
 bool conv_wgrad_supported(const ConvWgradDims &d, const void *x, const void *dy);

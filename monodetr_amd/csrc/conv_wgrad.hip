@@ -94,6 +94,16 @@ void conv_wgrad_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ 
     for (int e = 0; e < TS; ++e)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[e][i] = 0.f;
+    // the bias gradient of a token-wise linear layer rides along (d.DB): db[n] = sum over pixels of dY[.][n] is the product of the
+    // dY^T operand already in LDS with a matrix of ones -- one more MFMA per k-step on the waves of the first input-channel block,
+    // no second pass over dY (a separate column sum: two launches and 42 MB per 81 600-row layer)
+    const bool want_db = TS == 1 && d.DB != 0 && cblk == 0 && csub == 0;       // wave-uniform
+    f32x16 accb;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accb[i] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = static_cast<__bf16>(1.0f);
 
     // ---- loading tasks: one 8 x 8 block (8 rows x 8 channels) per lane.  A WAVE takes 16 columns x 4 channel pieces of one operand
     // (lane = 16 piece + column): the 16 lanes of a ds_write_b128 group then store 16 CONSECUTIVE slots of one channel row --
@@ -190,6 +200,7 @@ void conv_wgrad_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ 
                 else slot = q;
                 acc[e] = mfma_bf16(a, bp[slot], acc[e]);                     // D[n][c] += dY^T[n][8 rows] X[8 rows][c]
             }
+            if (want_db) accb = mfma_bf16(a, ones, accb);                    // every column: sum over the 16 pixels of the k-step
         }
     };
 
@@ -213,7 +224,14 @@ void conv_wgrad_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ 
 
     // ---- epilogue: acc[e] register r of lane l = D[n = (r & 3) + 8 (r >> 2) + 4 half][c = l & 31]
     const int c = c0 + csub * 32 + l31;
-    float *pp = part + static_cast<int64_t>(chunk) * d.N * TS * TS * d.C;
+    float *pp = part + static_cast<int64_t>(chunk) * (static_cast<int64_t>(d.N) * TS * TS * d.C + (d.DB ? d.N : 0));
+    if (want_db && l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + nsub * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (n < d.N) pp[static_cast<int64_t>(d.N) * d.C + n] = accb[r];
+        }
+    }
 #pragma unroll
     for (int e = 0; e < TS; ++e)
 #pragma unroll

@@ -59,7 +59,8 @@ def _weight_bias_grads(x2, dy2, weight, need_w, need_b):
     if need_w:
         from .. import conv_wgrad_ext
         if T > small_wgrad_ext.MAX_ROWS and conv_wgrad_ext.token_supported(x2, dy2) and weight.dtype in (torch.float32, torch.bfloat16):
-            dw = conv_wgrad_ext.token_weight_gradient(x2, dy2, weight.dtype)
+            # dW and db from ONE kernel + one chunk sum (csrc/conv_wgrad.hip, the 1x1 case with the bias gradient riding along)
+            return conv_wgrad_ext.token_weight_gradient(x2, dy2, weight.dtype, bias=need_b)
         elif C:
             parts = torch.bmm(dy2.view(C, T // C, -1).transpose(1, 2), x2.view(C, T // C, -1))    # [C, N, K]
             flat = parts.view(C, -1)

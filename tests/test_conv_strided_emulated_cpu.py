@@ -83,6 +83,23 @@ def test_weight_gradient_matches_autograd(ext, B, H, W, C, N, k, stride):
         close(dw, ref, "dw", tol=1e-2 if dtype == torch.bfloat16 else 1e-5)
 
 
+@pytest.mark.parametrize("T,K,N", [(136, 64, 32), (1000, 128, 160), (264, 64, 256)])
+def test_token_weight_and_bias_gradient_from_one_kernel(ext, T, K, N):
+    """mdetr_token_wgrad: dW = dy^T x and db = column sums of dy for a token-wise linear layer, the bias gradient riding on the dy
+    operand of the 1x1 weight-gradient kernel (ragged last tile, several chunks, N beyond one 128-channel block)."""
+    from monodetr_amd import conv_wgrad_ext
+    g = torch.Generator().manual_seed(T + K + N)
+    x = torch.randn(T, K, generator=g).to(torch.bfloat16)
+    dy = torch.randn(T, N, generator=g).to(torch.bfloat16)
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
+        dw, db = conv_wgrad_ext.token_weight_gradient(x, dy, dtype, bias=True)
+        assert dw.shape == (N, K) and db.shape == (N,) and dw.dtype == db.dtype == dtype
+        close(dw, dy.float().t() @ x.float(), "dw", tol=tol)
+        close(db, dy.float().sum(0), "db", tol=tol)
+        dw2, none = conv_wgrad_ext.token_weight_gradient(x, dy, dtype, bias=False)
+        assert none is None and torch.equal(dw2, dw)
+
+
 def test_stride1_convolution_takes_the_weight_gradient_kernel(ext):
     """conv3x3_ext (stride 1): forward + input gradient on conv3x3.hip, weight gradient now on conv_wgrad.hip."""
     from monodetr_amd import conv3x3_ext

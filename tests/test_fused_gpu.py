@@ -770,6 +770,25 @@ def test_conv_wgrad_kernel_matches_the_library_weight_gradient(B, H, W, C, N, mo
     assert torch.equal(a, b)                                                             # fixed-order sums: deterministic
 
 
+@pytest.mark.parametrize("T,K,N", [(81600, 256, 256), (81600, 256, 384), (61440, 128, 512), (15360, 1024, 256), (245760, 64, 256), (4408, 256, 256)])
+def test_token_wgrad_kernel_gives_weight_and_bias_gradient(T, K, N):
+    """mdetr_token_wgrad (csrc/conv_wgrad.hip, 1x1 case, bias gradient riding along) at the step's token shapes -- the encoder's
+    81 600 rows, the packed offsets / weights projection, the backbone's 1x1 convolutions: held to fp32 products of the same bf16
+    operands, tighter than the library's bf16 split-K partials it replaces; deterministic."""
+    from monodetr_amd import conv_wgrad_ext
+    g = torch.Generator(device="cuda").manual_seed(T + N)
+    x = (torch.randn(T, K, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    dy = (torch.randn(T, N, generator=g, device="cuda") * 0.1).to(torch.bfloat16)
+    rw, rb = dy.float().t() @ x.float(), dy.float().sum(0)
+    for dtype, tol in ((torch.float32, 3e-5), (torch.bfloat16, 6e-3)):
+        dw, db = conv_wgrad_ext.token_weight_gradient(x, dy, dtype, bias=True)
+        assert dw.shape == rw.shape and db.shape == rb.shape and dw.dtype == db.dtype == dtype
+        assert (dw.float() - rw).abs().max().item() <= tol * rw.abs().max().item(), dtype
+        assert (db.float() - rb).abs().max().item() <= tol * max(rb.abs().max().item(), 1.0), dtype
+    a, b = conv_wgrad_ext.token_weight_gradient(x, dy, torch.float32, bias=True), conv_wgrad_ext.token_weight_gradient(x, dy, torch.float32, bias=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 @pytest.mark.parametrize("B,H,W", [(8, 384, 1280), (2, 512, 1760), (1, 37, 75)])
 def test_conv_stem_kernel_matches_the_library_convolution(B, H, W):
     from monodetr_amd import conv_stem_ext
