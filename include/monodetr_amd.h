@@ -474,6 +474,16 @@ int mdetr_conv3x3_forward(const void *x, const void *w, const float *shift, void
 int mdetr_conv_taps(const void *x, const void *w, const float *shift, void *y, const int64_t *dims, int relu, int device, void *stream);
 
 /*
+ * The 3x3 / stride-2 / pad-1 case of mdetr_conv_taps with the CONTRACTION split over ksplit groups of input channels -- for layers
+ * with few output pixels against a long contraction (the fourth pyramid level, lib/models/monodetr/monodetr.py:87-92: 2048 channels
+ * x 9 taps into 8 x 6 x 20 pixels).  Writes fp32 partials [ksplit][B][OH][OW][N] (split 0 carries the shift, no activation); the
+ * caller adds the splits in a fixed order (mdetr_column_sum_to over the split axis) and rounds once.  dims as mdetr_conv_taps (the
+ * output strides dims[16..19] are ignored); C % (32 ksplit) == 0.
+ */
+int mdetr_conv_taps_split(const void *x, const void *w, const float *shift, float *partial, int64_t partial_floats, const int64_t *dims,
+                          int ksplit, int device, void *stream);
+
+/*
  * Input gradient of a stride-2 convolution (3x3 / pad 1 or 1x1 / pad 0), the four pixel-parity classes in ONE launch; every element
  * of dx is written exactly once (the odd pixels of a 1x1 convolution's gradient as zeros):
  *   dx[b, i, j, c] = sum_{t, s, n : (i + P - t) and (j + P - s) even} dy[b, (i + P - t) / 2, (j + P - s) / 2, n] * wt[c, t, s, n]

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mdetr_add_layernorm_backward": (_c_int, [_c_int, _c_int] + [_c_vp] * 7 + [ctypes.c_int64, _c_int, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),
     "mdetr_conv3x3_forward": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_int, _c_vp]),
     "mdetr_conv_taps": (_c_int, [_c_vp] * 5 + [_c_int, _c_int, _c_vp]),
+    "mdetr_conv_taps_split": (_c_int, [_c_vp] * 4 + [ctypes.c_int64, _c_vp, _c_int, _c_int, _c_vp]),
     "mdetr_conv_dgrad_s2": (_c_int, [_c_vp] * 3 + [_c_int] * 8 + [_c_int, _c_vp]),
     "mdetr_conv_stem": (_c_int, [_c_vp] * 4 + [_c_int] * 3 + [_c_int, _c_vp]),
     "mdetr_conv_wgrad_chunks": (_c_int, [_c_int] * 9),

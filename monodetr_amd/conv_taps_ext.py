@@ -42,11 +42,54 @@ def _call(x, w, shift, y, dims, relu):
         _capi.check(rc, "mdetr_conv_taps")
 
 
+def _split_count(B, OH, OW, N, C, k, relu):
+    """Contraction splits for the forward pass, 0 = none: few output tiles (4 x 32 pixels x 32 channels each) against many channel
+    slabs -- split until ~1 000 workgroups exist, at least 4 slabs of 32 channels per split."""
+    if relu or k != 3 or os.environ.get("MDETR_CONV_TAPS_SPLIT", "1") == "0":
+        return 0
+    blocks = B * ((OH + 3) // 4) * ((OW + 31) // 32) * (N // 32)
+    slabs = C // 32
+    if blocks >= 256 or slabs < 16:
+        return 0
+    ks = 1
+    while ks * 2 <= 64 and blocks * ks * 2 <= 1024 and slabs % (ks * 2) == 0 and slabs // (ks * 2) >= 4:
+        ks *= 2
+    return ks if ks >= 2 else 0
+
+
+def _forward_split(x, w_ohwi, shift, ks, dims):
+    """The forward pass with the contraction split ks ways (mdetr_conv_taps_split) + one sum over the splits (csrc/colsum.hip)."""
+    B, OH, OW, N = dims[0], dims[4], dims[5], dims[6]
+    cuda = x.is_cuda
+    cols = B * OH * OW * N
+    if cuda and _backend is None:
+        from . import _workspace as W_
+        part = W_.get("conv_taps_split", x.device, ks * cols * 4).view(torch.float32)[:ks * cols]
+    else:
+        part = torch.empty(ks * cols, dtype=torch.float32, device=x.device)
+    d = torch.tensor(dims, dtype=torch.int64)
+    rc = _lib().mdetr_conv_taps_split(x.data_ptr(), w_ohwi.data_ptr(), shift.data_ptr() if shift is not None else None, part.data_ptr(),
+                                      part.numel(), d.data_ptr(), ks, x.device.index if cuda else -1,
+                                      torch.cuda.current_stream(x.device).cuda_stream if cuda else None)
+    if rc != 0:
+        _capi.check(rc, "mdetr_conv_taps_split")
+    part = part.view(ks, cols)
+    if cuda and _backend is None:
+        from .colsum_ext import column_sum, supported as colsum_ok
+        y = column_sum(part, out_dtype=torch.bfloat16) if colsum_ok(part) else part.sum(0).to(torch.bfloat16)
+    else:
+        y = part.sum(0).to(torch.bfloat16)
+    return y.view(B, OH, OW, N).permute(0, 3, 1, 2)                     # [B, N, OH, OW] with channels_last strides
+
+
 def _forward(x, w_ohwi, shift, relu):
     """x [B, C, H, W] channels_last, w_ohwi [N, k, k, C] -> y [B, N, OH, OW] channels_last."""
     B, C, H, W = x.shape
     N, k = w_ohwi.shape[0], w_ohwi.shape[1]
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    ks = _split_count(B, OH, OW, N, C, k, relu)
+    if ks:
+        return _forward_split(x, w_ohwi, shift, ks, [B, H, W, C, OH, OW, N, 2, k, k, 1, 1, 0, 1, 0, 1, 0, OH * OW * N, OW * N, N, k * k * C, k * C, C])
     y = torch.empty((B, N, OH, OW), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
     pad = 1 if k == 3 else 0
     _call(x, w_ohwi, shift, y, [B, H, W, C, OH, OW, N, 2, k, k, pad, pad, 0, 1, 0, 1, 0, OH * OW * N, OW * N, N, k * k * C, k * C, C], relu)

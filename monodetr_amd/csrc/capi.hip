@@ -556,6 +556,33 @@ int mdetr_conv_taps(const void *x, const void *w, const float *shift, void *y, c
     return MDETR_OK;
 }
 
+int mdetr_conv_taps_split(const void *x, const void *w, const float *shift, float *partial, int64_t partial_floats, const int64_t *dims,
+                          int ksplit, int device, void *stream)
+{
+    if (!dims) return fail(MDETR_E_ARG, "mdetr_conv_taps_split: null dims");
+    mdetr::ConvTapsDims d;
+    d.B = static_cast<int>(dims[0]); d.H = static_cast<int>(dims[1]); d.W = static_cast<int>(dims[2]); d.C = static_cast<int>(dims[3]);
+    d.OH = static_cast<int>(dims[4]); d.OW = static_cast<int>(dims[5]); d.N = static_cast<int>(dims[6]);
+    d.SI = static_cast<int>(dims[7]); d.TR = static_cast<int>(dims[8]); d.TS = static_cast<int>(dims[9]);
+    d.PT = static_cast<int>(dims[10]); d.PL = static_cast<int>(dims[11]);
+    d.ta0 = static_cast<int>(dims[12]); d.ta_step = static_cast<int>(dims[13]); d.te0 = static_cast<int>(dims[14]); d.te_step = static_cast<int>(dims[15]);
+    d.y_off = 0; d.y_sb = static_cast<int64_t>(d.OH) * d.OW * d.N; d.y_sr = static_cast<int64_t>(d.OW) * d.N; d.y_sc = d.N;
+    d.w_sn = dims[20]; d.w_sa = dims[21]; d.w_se = dims[22];
+    for (int i = 0; i < 12; ++i)
+        if (dims[i] < 0 || dims[i] > (1ll << 30)) return fail(MDETR_E_ARG, "mdetr_conv_taps_split: bad size dims[%d] = %lld", i, static_cast<long long>(dims[i]));
+    if (d.B == 0 || d.OH == 0 || d.OW == 0) return MDETR_OK;
+    if (!x || !w || !partial) return fail(MDETR_E_ARG, "mdetr_conv_taps_split: null pointer");
+    if (!mdetr::conv_taps_supported(d, x, w, partial) || !mdetr::conv_taps_split_supported(d, ksplit))
+        return fail(MDETR_E_ARG, "mdetr_conv_taps_split: needs the 3x3 / stride-2 form, C a multiple of 32 x ksplit (C=%d ksplit=%d), 2 <= ksplit <= 64", d.C, ksplit);
+    const int64_t need = static_cast<int64_t>(ksplit) * d.B * d.OH * d.OW * d.N;
+    if (partial_floats < need) return fail(MDETR_E_ARG, "mdetr_conv_taps_split: partial buffer holds %lld floats, %lld needed", static_cast<long long>(partial_floats), static_cast<long long>(need));
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv_taps_split: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::conv_taps_split_launch(x, w, shift, partial, d, ksplit, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv_taps_split: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
 int mdetr_conv_dgrad_s2(const void *dy, const void *wt, void *dx, int B, int OH, int OW, int N, int H, int W, int C, int K, int device, void *stream)
 {
     if (B < 0 || OH < 0 || OW < 0 || H < 0 || W < 0 || N <= 0 || C <= 0) return fail(MDETR_E_ARG, "mdetr_conv_dgrad_s2: bad sizes");

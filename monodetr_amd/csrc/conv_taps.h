@@ -22,6 +22,9 @@ bool conv_taps_supported(const ConvTapsDims &d, const void *x, const void *w, co
 // dy [B, OH, OW, N] (N % 64 == 0), wt [C, K, K, N] (channel axes swapped, taps not mirrored), dx [B, H, W, C] (C % 32 == 0)
 bool conv_dgrad_s2_supported(int B, int OH, int OW, int N, int H, int W, int C, int K, const void *dy, const void *wt, const void *dx);
 hipError_t conv_dgrad_s2_launch(const void *dy, const void *wt, void *dx, int B, int OH, int OW, int N, int H, int W, int C, int K, hipStream_t st);
+// split over the contraction channels: fp32 partials [ksplit][B][OH][OW][N] (split 0 carries the shift), summed by the caller
+bool conv_taps_split_supported(const ConvTapsDims &d, int ksplit);
+hipError_t conv_taps_split_launch(const void *x, const void *w, const float *shift, float *part, const ConvTapsDims &d, int ksplit, hipStream_t st);
 hipError_t conv_taps_launch(const void *x, const void *w, const float *shift, void *y, const ConvTapsDims &d, bool relu, hipStream_t st);
 
 }  // namespace mdetr

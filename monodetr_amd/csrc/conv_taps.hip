@@ -50,12 +50,19 @@ constexpr int kPadT = kSlabT + 8;        // 40 bf16 = 20 dwords per LDS row (72 
 struct TapGeom {
     ConvTapsDims d;
     int tiles_x, tiles_y, tiles, ngroups, xcd_per;
+    // split over the contraction channels (few output pixels against a long contraction: the fourth pyramid level, 2048 channels
+    // x 9 taps into 8 x 6 x 20 pixels, kept 128 workgroups busy for 191 us): workgroup (split s, tile, group) contracts channel slabs
+    // [s, s + 1) * C / ksplit and writes an fp32 partial [ksplit][B][OH][OW][N] (split 0 adds the shift); the caller sums the splits
+    int ksplit = 1, inner_blocks = 0;
+    float *part = nullptr;
 };
 
 template <int NB, bool RELU, int TR, int TS, int SI>
 __device__ __forceinline__ void conv_taps_body(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, const float *__restrict__ shift,
-                                               __bf16 *__restrict__ y, const TapGeom &g, const int bid)
+                                               __bf16 *__restrict__ y, const TapGeom &g, const int bid_)
 {
+    const int split = g.ksplit > 1 ? bid_ / g.inner_blocks : 0;               // uniform
+    const int bid = g.ksplit > 1 ? bid_ - split * g.inner_blocks : bid_;
     constexpr int HH = SI * (kWavesT - 1) + TR;                              // halo rows
     constexpr int HWC = SI * (kTileWT - 1) + TS;                             // halo columns
     constexpr int PLANE = (HWC + 1) / 2;                                     // SI = 2: even columns [0, PLANE), odd columns after
@@ -153,14 +160,15 @@ __device__ __forceinline__ void conv_taps_body(const __bf16 *__restrict__ x, con
         }
     };
 
-    const int stages = d.C / kSlabT * TR;
-    fetch_w(0, 0);
+    const int slabs = d.C / kSlabT / g.ksplit, kbase = split * slabs * kSlabT;     // this workgroup's channel range
+    const int stages = slabs * TR;
+    fetch_w(kbase, 0);
     for (int q = 0; q < stages; ++q) {
         const int a = q % TR;
         __syncthreads();                                                     // the previous stage's LDS reads are done
-        if (a == 0) load_halo(q / TR * kSlabT);
+        if (a == 0) load_halo(kbase + q / TR * kSlabT);
         store_w();
-        if (q + 1 < stages) fetch_w((q + 1) / TR * kSlabT, (q + 1) % TR);    // in flight during the products below
+        if (q + 1 < stages) fetch_w(kbase + (q + 1) / TR * kSlabT, (q + 1) % TR);    // in flight during the products below
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < TS; ++e) {
@@ -180,6 +188,24 @@ __device__ __forceinline__ void conv_taps_body(const __bf16 *__restrict__ x, con
 
     // ---- epilogue: lane = pixel; register quad q of block nb = channels 32 nb + 8 q + 4 half + 0..3 (conv3x3.hip)
     const int r = r0 + wave, c = c0 + col;
+    if (g.part != nullptr) {                                                 // a split of the contraction: fp32 partial, no activation
+        if (r < d.OH && c < d.OW) {
+            float *pp = g.part + (((static_cast<int64_t>(split) * d.B + b) * d.OH + r) * d.OW + c) * d.N + n0 + 4 * half;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nn = nb * 32 + 8 * q + 4 * half;
+                    if (n0 + nn < d.N) {
+                        float o[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = acc[nb][4 * q + i] + (split == 0 ? shift_s[nn + i] : 0.f);
+                        *reinterpret_cast<float4 *>(pp + nb * 32 + 8 * q) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                }
+        }
+        return;
+    }
     if (r < d.OH && c < d.OW) {
         __bf16 *yp = y + d.y_off + static_cast<int64_t>(b) * d.y_sb + static_cast<int64_t>(r) * d.y_sr + static_cast<int64_t>(c) * d.y_sc + n0 + 4 * half;
 #pragma unroll
@@ -317,6 +343,33 @@ hipError_t launch(const void *x, const void *w, const float *shift, void *y, con
     return hipGetLastError();
 }
 
+// the split form (see TapGeom): 32 output channels per workgroup, ksplit workgroups per (tile, channel group)
+template <int TR, int TS, int SI>
+hipError_t launch_split(const void *x, const void *w, const float *shift, float *part, const ConvTapsDims &d, int ksplit, hipStream_t st)
+{
+    constexpr int NB = 1;
+    constexpr int HH = SI * (kWavesT - 1) + TR, HWC = SI * (kTileWT - 1) + TS;
+    constexpr size_t lds = static_cast<size_t>(HH) * HWC * kPadT * 2 + static_cast<size_t>(TS) * NB * 32 * kPadT * 2 + NB * 32 * 4;
+    auto kern = conv_taps_kernel<NB, false, TR, TS, SI>;
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess) dev_ = -1;
+    if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;
+    }
+    int64_t blocks = 0;
+    TapGeom g = geometry(d, NB, blocks);
+    g.ksplit = ksplit;
+    g.inner_blocks = static_cast<int>(blocks);
+    g.part = part;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks * ksplit)), dim3(kWavesT * 64), lds, st, static_cast<const __bf16 *>(x),
+                       static_cast<const __bf16 *>(w), shift, static_cast<__bf16 *>(nullptr), g);
+    return hipGetLastError();
+}
+
 template <int TR, int TS, int SI>
 hipError_t by_width(const void *x, const void *w, const float *shift, void *y, const ConvTapsDims &d, bool relu, hipStream_t st)
 {
@@ -407,6 +460,18 @@ hipError_t conv_dgrad_s2_launch(const void *dy, const void *wt, void *dx, int B,
     // every output pixel of dY meets every (tap, channel pair) once: the four parity classes together are the dense product
     ProfileScope prof(9, conv_mflop(static_cast<int64_t>(B) * OH * OW, static_cast<int64_t>(C) * N * K * K), st);
     return nb == 4 ? launch_dgrad4<4>(dy, wt, dx, q, st) : launch_dgrad4<2>(dy, wt, dx, q, st);
+}
+
+bool conv_taps_split_supported(const ConvTapsDims &d, int ksplit)
+{
+    // the 3x3 / stride-2 forward form only (the one the fourth pyramid level needs); whole slabs per split
+    return d.SI == 2 && d.TR == 3 && d.TS == 3 && ksplit >= 2 && ksplit <= 64 && d.C % (kSlabT * ksplit) == 0 && d.N % 4 == 0;
+}
+
+hipError_t conv_taps_split_launch(const void *x, const void *w, const float *shift, float *part, const ConvTapsDims &d, int ksplit, hipStream_t st)
+{
+    ProfileScope prof(9, conv_mflop(static_cast<int64_t>(d.B) * d.OH * d.OW, static_cast<int64_t>(d.C) * d.N * d.TR * d.TS), st);
+    return launch_split<3, 3, 2>(x, w, shift, part, d, ksplit, st);
 }
 
 hipError_t conv_taps_launch(const void *x, const void *w, const float *shift, void *y, const ConvTapsDims &d, bool relu, hipStream_t st)

@@ -30,6 +30,7 @@ def close(got, want, what, tol=1.2e-2):
     (2, 6, 6, 64, 64, 3, False, False),       # a map smaller than the tile
     (1, 12, 40, 256, 64, 1, False, True),     # the projection shortcut: 1x1 / stride 2 (only even pixels are read)
     (1, 7, 9, 64, 128, 1, False, False),      # ... on an odd map
+    (1, 12, 40, 512, 64, 3, False, True),     # few output tiles, 16 channel slabs: the contraction is split 4 ways (fp32 partials + sum)
 ])
 def test_strided_convolution_matches_conv2d(ext, B, H, W, C, N, k, relu, use_shift, monkeypatch):
     # (the launcher narrows the workgroup's output-channel block for problems with few tiles -- every test here: pin it to the
@@ -44,6 +45,7 @@ def test_strided_convolution_matches_conv2d(ext, B, H, W, C, N, k, relu, use_shi
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     dy = torch.randn(B, N, OH, OW, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     assert ext.supported(x, w, padding=(pad, pad))
+    assert (ext._split_count(B, OH, OW, N, C, k, relu) == 4) == (C == 512)
     y = ext.conv_strided(x, w, shift, relu=relu)
     assert y.shape == (B, N, OH, OW) and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
     y.backward(dy)
