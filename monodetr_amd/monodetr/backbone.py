@@ -13,6 +13,7 @@ MI355X notes: every BatchNorm is frozen, i.e. an affine map per channel.  ``forw
 the preceding convolution (conv(x, W*s) + t  ==  conv(x, W)*s + t), which removes one full
 read+write pass over every activation of the backbone; gradients still reach W through W*s.
 """
+import os
 from typing import Dict, List
 
 import torch
@@ -21,7 +22,7 @@ from torch import nn
 
 from ..utils.misc import NestedTensor, mark_no_padding
 from .. import bias_act_ext, conv3x3_ext, conv_stem_ext, conv_taps_ext, decimate_ext
-from .linear import pointwise_conv, pointwise_eligible, pointwise_relu_fusable
+from .linear import pointwise_conv, pointwise_conv_skip, pointwise_eligible, pointwise_relu_fusable, skip_relu_fusable
 from .position_encoding import build_position_encoding
 
 
@@ -114,9 +115,21 @@ def prefold(pairs, dt):
         conv.__dict__["_prefolded"] = (w, b)
 
 
-def conv_bn(x, conv, bn, relu):
+def conv_bn(x, conv, bn, relu, skip_out=False):
     """conv -> frozen BN (-> ReLU), with the BN folded into the convolution's weight and bias.
-    For frozen convolutions (stem, layer1) the folded weight itself is cached."""
+    For frozen convolutions (stem, layer1) the folded weight itself is cached.
+    skip_out: -> (result, x') with x' == x for the identity connection that follows (linear.pointwise_conv_skip: its gradient is
+    folded into this convolution's input-gradient GEMM); (result, x) where that form does not apply."""
+    if skip_out:
+        if isinstance(bn, FrozenBatchNorm2d) and conv.bias is None and conv.weight.requires_grad and x.requires_grad \
+                and tuple(conv.stride) == (1, 1) and torch.is_grad_enabled() \
+                and pointwise_eligible(x, conv.kernel_size, (1, 1), conv.padding, conv.groups):
+            pre = conv.__dict__.get("_prefolded", None)
+            dt = x.dtype if x.dtype in (torch.bfloat16, torch.float16) and not torch.is_autocast_enabled() else conv.weight.dtype
+            if pre is not None and pre[0].dtype == dt == x.dtype and (not relu or skip_relu_fusable(pre[1])):
+                conv.__dict__.pop("_prefolded", None)
+                return pointwise_conv_skip(x, pre[0], pre[1], relu=relu)
+        return conv_bn(x, conv, bn, relu), x
     if isinstance(bn, FrozenBatchNorm2d) and conv.bias is None:
         scale, shift = bn.affine()
         dt = x.dtype if x.dtype in (torch.bfloat16, torch.float16) and not torch.is_autocast_enabled() else conv.weight.dtype
@@ -179,6 +192,10 @@ def conv_bn(x, conv, bn, relu):
     return F.relu(x, inplace=True) if relu else x
 
 
+# (A/B switch of the identity-gradient fusion in Bottleneck.forward; MDETR_BOTTLENECK_SKIP=0 = the separate elementwise add)
+_SKIP_FUSE = os.environ.get("MDETR_BOTTLENECK_SKIP", "1") != "0"
+
+
 class Bottleneck(nn.Module):
     """1x1 reduce -> 3x3 (carries the stride) -> 1x1 expand (x4), residual add, ReLU."""
     expansion = 4
@@ -196,8 +213,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        skip = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], False)
-        y = conv_bn(x, self.conv1, self.bn1, True)
+        if self.downsample is None and _SKIP_FUSE:
+            y, skip = conv_bn(x, self.conv1, self.bn1, True, skip_out=True)     # (the identity's gradient meets conv1's inside its dgrad GEMM)
+        else:
+            skip = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], False)
+            y = conv_bn(x, self.conv1, self.bn1, True)
         y = conv_bn(y, self.conv2, self.bn2, True)
         y = conv_bn(y, self.conv3, self.bn3, False)
         if bias_act_ext.ENABLED and bias_act_ext.supported(y, None, skip):

@@ -88,16 +88,24 @@ class _TokenLinearSkip(torch.autograd.Function):
     the residual).  `pos` is a constant here (no gradient)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pos):
+    def forward(ctx, x, weight, bias, pos, relu=False):
         q = x if pos is None else x + pos
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(q, weight)
-        return F.linear(q, weight, bias), x.view_as(x)
+        ctx.relu = bool(relu)
+        if relu:                                                     # library GEMM with the RELU_BIAS epilogue (as _TokenLinear)
+            y = torch._addmm_activation(bias, q.reshape(-1, q.shape[-1]), weight.t()).view(q.shape[:-1] + (weight.shape[0],))
+            ctx.save_for_backward(q, weight, y)
+        else:
+            y = F.linear(q, weight, bias)
+            ctx.save_for_backward(q, weight)
+        return y, x.view_as(x)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy, dskip):
-        q, weight = ctx.saved_tensors
+        q, weight = ctx.saved_tensors[:2]
+        if ctx.relu:
+            dy = torch.ops.aten.threshold_backward(dy, ctx.saved_tensors[2], 0.0)
         q2, dy2 = q.reshape(-1, q.shape[-1]), dy.reshape(-1, dy.shape[-1])
         dx = None
         if ctx.needs_input_grad[0]:
@@ -110,16 +118,22 @@ class _TokenLinearSkip(torch.autograd.Function):
             else:
                 dx = dskip + (dy2 @ weight).view_as(q)
         dw, db = _weight_bias_grads(q2, dy2, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
-def token_linear_skip(x, weight, bias=None, pos=None):
-    """-> (token_linear(x + pos, weight, bias), x'): use x' (== x) for everything that follows on the residual path; see
-    `_TokenLinearSkip`.  Plain tensors out of it when the fused form does not apply."""
+def token_linear_skip(x, weight, bias=None, pos=None, relu=False):
+    """-> (token_linear(x + pos, weight, bias[, relu]), x'): use x' (== x) for everything that follows on the residual path; see
+    `_TokenLinearSkip`.  Plain tensors out of it when the fused form does not apply.  relu: only with the library's RELU_BIAS
+    epilogue available (MDETR_GEMM_RELU and a 1-D bias); the caller asks `skip_relu_fusable` first."""
     if x.is_cuda and x.dtype == weight.dtype and x.numel() // x.shape[-1] >= _MIN_TOKENS and torch.is_grad_enabled() and x.requires_grad \
-            and not torch.is_autocast_enabled() and (pos is None or not pos.requires_grad) and not _TOKEN_GEMM:
-        return _TokenLinearSkip.apply(x, weight, bias, pos)
-    return token_linear(x if pos is None else x + pos, weight, bias), x
+            and not torch.is_autocast_enabled() and (pos is None or not pos.requires_grad) and not _TOKEN_GEMM \
+            and (not relu or skip_relu_fusable(bias)):
+        return _TokenLinearSkip.apply(x, weight, bias, pos, relu)
+    return token_linear(x if pos is None else x + pos, weight, bias, relu=relu), x
+
+
+def skip_relu_fusable(bias):
+    return _GEMM_RELU and not _TOKEN_GEMM and bias is not None and bias.dim() == 1 and bias.is_contiguous()
 
 
 class _TokenLinear(torch.autograd.Function):
@@ -251,6 +265,16 @@ def pointwise_conv(x, weight, bias=None, relu=False):
     B, C, H, W = x.shape
     y = token_linear(x.permute(0, 2, 3, 1).reshape(B * H * W, C), weight.reshape(weight.shape[0], C), bias, relu=relu)
     return y.view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def pointwise_conv_skip(x, weight, bias=None, relu=False):
+    """-> (pointwise_conv(x, weight, bias, relu), x'): the 1x1 convolution that opens a residual block together with the tensor the
+    identity connection continues from (x' == x) -- the gradient arriving through the identity path is folded into the
+    convolution's input-gradient GEMM (beta = 1) instead of a separate 30-60 MB elementwise add per bottleneck
+    (`_TokenLinearSkip`; reference torchvision Bottleneck.forward behind lib/models/monodetr/backbone.py:93-106)."""
+    B, C, H, W = x.shape
+    y, xs = token_linear_skip(x.permute(0, 2, 3, 1).reshape(B * H * W, C), weight.reshape(weight.shape[0], C), bias, relu=relu)
+    return y.view(B, H, W, -1).permute(0, 3, 1, 2), xs.view(B, H, W, C).permute(0, 3, 1, 2)
 
 
 def pointwise_relu_fusable(x, weight, bias):

@@ -23,6 +23,12 @@ SHAPES = [  # (name, T, K, N, relu)
     ("layer1_64to64_relu", 245760, 64, 64, True),
     ("layer2_128to512", 61440, 128, 512, False),
     ("layer2_512to128_relu", 61440, 512, 128, True),
+    ("decoder_256to256", 4400, 256, 256, False),
+    ("decoder_256to256_relu", 4400, 256, 256, True),
+    ("decoder_256to128", 4400, 256, 128, False),
+    ("depth_tokens_256to256", 15360, 256, 256, False),
+    ("layer3_256to1024", 15360, 256, 1024, False),
+    ("layer3_512to256_relu", 15360, 512, 256, True),
 ]
 
 

@@ -206,7 +206,7 @@ def test_bench_main_composes_its_json_line(monkeypatch, capsys):
             return "one hipGraph replay per iteration"
 
         def attach_process_group(self):
-            return "two hipGraph replays per iteration (forward + backward | optimizer) around the eager RCCL gradient all-reduce"
+            return "three hipGraph replays per iteration (forward + upper backward | backbone backward | optimizer)"
 
     def no_topology(i):
         raise AttributeError
@@ -252,7 +252,7 @@ def test_bench_main_composes_its_json_line(monkeypatch, capsys):
             assert line["config"]["switches"] == sorted(bench.COMMITTED_SWITCHES["bf16"]) and line["config"]["switch_source"] == "bench.COMMITTED_SWITCHES"
             assert line["default_path"]["value"] > 0 and line["default_path"]["switches"] == [] and line["default_path"]["steps"] == 20
             assert line["fp32_path"]["precision"] == "fp32" and line["fp32_path"]["switches"] == sorted(bench.COMMITTED_SWITCHES["fp32"])
-            assert line["rccl_1rank"]["value"] > 0 and built[-1][1]["ddp"] == "flat" and built[-1][1]["graph"] and line["rccl_1rank"]["launch"].startswith("two hipGraph")
+            assert line["rccl_1rank"]["value"] > 0 and built[-1][1]["ddp"] == "overlap" and built[-1][1]["graph"] and line["rccl_1rank"]["launch"].startswith("three hipGraph")
             assert line["eager_path"]["launch"] == "eager" and line["eager_path"]["switches"] == line["config"]["switches"]
             assert line["fp32_path"]["launch"].startswith("one hipGraph") and line["default_path"]["launch"] == "eager"
             assert roof["algorithmic_bytes"] == 417800000         # bf16 value / out / grad_out
