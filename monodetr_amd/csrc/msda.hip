@@ -866,7 +866,11 @@ hipError_t msda_forward_bf16_launch(const void *value, const int64_t *shapes, co
     // per query with 16-byte requests: 0.191-0.201 ms against this kernel's 0.193-0.196 at the encoder shape, 0.223 vs 0.202 for
     // N(0, 4 px) offsets, profiles/r04m_msda_fwd_head_blocked_vs_record.log.  Halving the rows gathered through memory bought
     // nothing: with one head per workgroup a 128-byte line carries one useful 64-byte row instead of two, so the number of L1
-    // line look-ups per (query, head) pair is the same 32.  Not kept.)
+    // line look-ups per (query, head) pair is the same 32.  Not kept.  A second form blocked like the backward pass -- one head, one
+    // region of 16 x 24 level-0 cells' queries per workgroup, EVERY level's reachable window of value rows staged in LDS (134 KB),
+    // DPP quad broadcasts instead of LDS records -- measured 0.232-0.256 ms against 0.189 (0.274 vs 0.195 at N(0, 4 px)),
+    // profiles/r04fw_msda_fwd_lds_windows_vs_record.log: one 16-wave workgroup per CU with two passes of 16 queries per wave behind a
+    // 134 KB staging phase, 160 VGPRs wanted at a cap of 128.  Not kept either: this kernel stays the forward path.)
     const int npairs = Lq * M, iters = rounds_per_block(B, npairs);
     const int chunks = (npairs + 32 * iters - 1) / (32 * iters);
     hipLaunchKernelGGL((msda_fwd_rec<4, 4, __hip_bfloat16, __hip_bfloat16>), dim3(static_cast<unsigned>(B) * chunks), dim3(kWaves * 64), 0, st,
