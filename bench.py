@@ -605,8 +605,11 @@ def main():
     torch.cuda.synchronize()
     _capi.profile_enable(not use_graph)
     t0 = time.perf_counter()
+    step_sync = os.environ.get("MDETR_BENCH_STEP_SYNC") == "1"       # experiment (scripts/r04_gaps.sh): the host never runs ahead
     for _ in range(args.steps):
         loss = step()
+        if step_sync:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     if dist_on:
         torch.distributed.barrier()
@@ -700,6 +703,7 @@ def main():
                        "precision": args.precision, "parallelism": "dp%d" % world,
                        "grad_sync": (sync_mode if dist_on else "none"), "prime_steps": args.prime,
                        "launch": launch_mode,
+                       **({"step_sync": "a device synchronisation after every step (experiment, not the metric)"} if step_sync else {}),
                        **({"gemm_selection": "TunableOp during start-up"} if tunable else {})},
             "final_loss": round(float(loss), 4),
         }

@@ -69,6 +69,14 @@ def _avg_op(group=None):
     return dist.ReduceOp.SUM, True
 
 
+def _point(ps, views):
+    """p.grad <- its slice of the reduced buffer (skipped when already so: every replay after the first)."""
+    if ps and ps[0].grad is views[0] and ps[-1].grad is views[-1]:
+        return
+    for p, v in zip(ps, views):
+        p.grad = v
+
+
 def static_plan(params):
     """[(parameters, their current gradient tensors, persistent flat buffer, views of its slices shaped like the gradients)]
     per dtype -- no collective involved: usable before the process group exists."""
@@ -82,6 +90,17 @@ def static_plan(params):
         src = [p.grad for p in ps]
         flat = torch.empty(sum(g.numel() for g in src), dtype=dtype, device=src[0].device)
         plan.append((ps, src, flat, [_like(v, g) for v, g in zip(flat.split([g.numel() for g in src]), src)]))
+    return plan
+
+
+@torch.no_grad()
+def gather(plan):
+    """One ``cat`` per dtype of a static plan's gradient tensors into its flat buffer.  TrainIteration.capture() records these
+    INSIDE the graph that produced the gradients (``_gathered``): between two replays the host then only issues the all-reduce
+    -- the 150-tensor ``cat`` call costs the host ~0.3 ms, which a replayed iteration does not hide (the graph launch returns
+    only a queue's depth ahead of the GPU; profiles/r04gap_ddp.txt)."""
+    for ps, src, flat, views in plan:
+        torch.cat([_flat(g) for g in src], out=flat)
     return plan
 
 
@@ -101,6 +120,7 @@ class FlatGradSync:
         self.group = group
         self.world = world_size if world_size is not None else dist.get_world_size(group)
         self._static = None                       # dtype -> (params, source gradients, flat buffer, views)
+        self._gathered = False                    # the static plan's flat buffers are filled by the captured backward itself
 
     def _plan(self):
         by_dtype = {}
@@ -119,12 +139,12 @@ class FlatGradSync:
         op, scale = _avg_op(self.group)
         if self._static is not None:
             for ps, src, flat, views in self._static:
-                torch.cat([_flat(g) for g in src], out=flat)
+                if not self._gathered:
+                    torch.cat([_flat(g) for g in src], out=flat)
                 dist.all_reduce(flat, op=op, group=self.group)
                 if scale:
                     flat.mul_(1.0 / self.world)
-                for p, v in zip(ps, views):
-                    p.grad = v
+                _point(ps, views)
             return
         for dtype, ps in self._plan():
             grads = [p.grad for p in ps]
@@ -159,8 +179,10 @@ class SplitGradSync(FlatGradSync):
             plan = self._static[part]
         else:
             plan = static_plan(self.params if params is None else params)
+        pre = self._gathered and self._static is not None and part is not None
         for ps, src, flat, views in plan:
-            torch.cat([_flat(g) for g in src], out=flat)
+            if not pre:
+                torch.cat([_flat(g) for g in src], out=flat)
             work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
             self._pending.append((work, ps, flat, views, scale))
 
@@ -170,8 +192,7 @@ class SplitGradSync(FlatGradSync):
             work.wait()
             if scale:
                 flat.mul_(1.0 / self.world)
-            for p, v in zip(ps, views):
-                p.grad = v
+            _point(ps, views)
         self._pending = []
 
     @torch.no_grad()

@@ -52,6 +52,11 @@ def _signature(x):
     return tuple((tuple(t.shape), t.dtype) for t in _tree_leaves(x))
 
 
+def _graph_parts():
+    """MDETR_GRAPH_PARTS: into how many executable graphs the single-process iteration is recorded (1 | 2)."""
+    return 2 if os.environ.get("MDETR_GRAPH_PARTS", "1") == "2" else 1
+
+
 def _rccl_group_is_up():
     """A process group whose backend runs a watchdog thread over HIP events (nccl = RCCL) exists in this process."""
     if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -85,7 +90,7 @@ class TrainIteration:
         self.strict = graph == "on"
         self.eager_steps = eager_steps
         self.capture_error_mode = capture_error_mode
-        self.graph = self.graph_opt = self.graph_bb = self.sync_plan = self.static = self.stream = None
+        self.graph = self.graph_opt = self.graph_bb = self.graph_tail = self.sync_plan = self.static = self.stream = None
         self._boundary = None
         self.loss = self.losses = self._captured = None
         self._capturing = False
@@ -132,9 +137,9 @@ class TrainIteration:
         """Is the gradient exchange the two-part, overlapped one (dist_helper.SplitGradSync) -- now or once the group exists?"""
         return (type(self.grad_sync).__name__ == "SplitGradSync" or self.pending_sync == "overlap") and hasattr(self.raw_model, "pyramid")
 
-    def _forward_backward(self, batch, cut=False):
-        """Forward, criterion and backward pass.  cut: the backward pass stops at the backbone's outputs (MonoDETR.pyramid cuts
-        the pyramid levels out of the graph); `_backward_backbone()` continues from there."""
+    def _forward(self, batch, cut=False):
+        """Forward pass and criterion -> the total loss.  cut: MonoDETR.pyramid cuts the pyramid levels out of the autograd graph
+        (the backward pass then stops at the backbone's outputs; `_backward_backbone()` continues from there)."""
         # set_to_none (not zero-fill): the flat gradient exchanges re-point every parameter's .grad at slices of their reduced
         # buffer (helpers/dist_helper.py); a kept-and-zeroed .grad would make the next backward ACCUMULATE into that slice
         self.optimizer.zero_grad(set_to_none=True)
@@ -147,12 +152,17 @@ class TrainIteration:
             self.raw_model.__dict__["_grad_boundary"] = self._boundary
         try:
             total, losses = self.compute(batch)
-            total.backward()
         finally:
             self.raw_model.__dict__.pop("_grad_boundary", None)
             if scoped:
                 attn_ext.end_iteration(self.device)
         self.losses = losses
+        return total
+
+    def _forward_backward(self, batch, cut=False):
+        """Forward, criterion and backward pass (cut: see `_forward`)."""
+        total = self._forward(batch, cut)
+        total.backward()
         return total
 
     def _backward_backbone(self):
@@ -258,7 +268,7 @@ class TrainIteration:
         if hasattr(self.optimizer, "flush_replays"):
             self.optimizer.flush_replays()
         torch.cuda.synchronize(self.device)
-        graph, graph_opt, graph_bb = torch.cuda.CUDAGraph(), None, None
+        graph, graph_opt, graph_bb, graph_tail = torch.cuda.CUDAGraph(), None, None, None
         self.optimizer.zero_grad(set_to_none=True)
         mode = dict(capture_error_mode=self.capture_error_mode)
         two = self.grad_sync is not None or self.pending_sync is not None
@@ -269,26 +279,36 @@ class TrainIteration:
             self._fill_num_global()
         self._capturing = True
         try:
-            if not two:
+            if not two and _graph_parts() > 1:
+                # forward + criterion | backward + optimizer: two executable graphs of < 1000 nodes each (see `_graph_parts`)
+                with torch.cuda.graph(graph, stream=side, **mode):
+                    self.loss = self._forward(self.static)
+                graph_tail = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_tail, stream=side, pool=graph.pool(), **mode):
+                    self.loss.backward()
+                    self.optimizer.step()
+            elif not two:
                 with torch.cuda.graph(graph, stream=side, **mode):  # same stream as the warm-up: the AccumulateGrad nodes are bound to it
                     self.loss = self._step_captured(self.static)
             else:
-                from .dist_helper import static_plan
+                from .dist_helper import gather, static_plan
                 cut = self._overlap()
+                # the gradients sit at the addresses the captured backward writes to; the graph that produced them also gathers
+                # them into persistent flat buffers (one cat per dtype, recorded), every later exchange reduces there, and the
+                # captured optimizer reads the reduced slices
                 with torch.cuda.graph(graph, stream=side, **mode):
                     self.loss = self._forward_backward(self.static, cut=cut)
-                # the gradients now sit at the addresses the captured backward writes to: every later exchange gathers from THOSE
-                # into persistent flat buffers, reduces there, and the captured optimizer reads the reduced slices
+                    upper = self._with_grad() if cut else list(self.raw_model.parameters())
+                    first = gather(static_plan(upper))
                 if cut:
-                    upper = self._with_grad()
                     graph_bb = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph_bb, stream=side, pool=graph.pool(), **mode):
                         self._backward_backbone()
-                    self.sync_plan = {"upper": static_plan(upper), "backbone": static_plan(self._with_grad(exclude=upper))}
+                        second = gather(static_plan(self._with_grad(exclude=upper)))
+                    self.sync_plan = {"upper": first, "backbone": second}
                     plans = [e for part in self.sync_plan.values() for e in part]
                 else:
-                    self.sync_plan = static_plan(self.raw_model.parameters())
-                    plans = self.sync_plan
+                    self.sync_plan = plans = first
                 for ps, src, flat, views in plans:
                     for p_, v in zip(ps, views):
                         p_.grad = v
@@ -296,13 +316,13 @@ class TrainIteration:
                 with torch.cuda.graph(graph_opt, stream=side, pool=graph.pool(), **mode):
                     self.optimizer.step()
                 if self.grad_sync is not None:
-                    self.grad_sync._static = self.sync_plan
+                    self.grad_sync._static, self.grad_sync._gathered = self.sync_plan, True
         finally:
             self._capturing = False
         if hasattr(self.optimizer, "uncount_step"):
             self.optimizer.uncount_step()                    # the capture ran the host bookkeeping of a step no kernel executed
         torch.cuda.synchronize(self.device)
-        self.graph, self.graph_opt, self.graph_bb = graph, graph_opt, graph_bb
+        self.graph, self.graph_opt, self.graph_bb, self.graph_tail = graph, graph_opt, graph_bb, graph_tail
         self._captured = (self.loss, self.losses)
         return self
 
@@ -334,7 +354,7 @@ class TrainIteration:
             if self.strict:
                 raise
             self.capture_error = repr(e)[:160]
-            self.graph = self.graph_opt = self.graph_bb = self.sync_plan = self.static = self.num_global = None
+            self.graph = self.graph_opt = self.graph_bb = self.graph_tail = self.sync_plan = self.static = self.num_global = None
             if self.grad_sync is not None:
                 self.grad_sync._static = None
             self.want_graph = False
@@ -349,6 +369,8 @@ class TrainIteration:
         if self.graph_bb is not None:
             return ("three hipGraph replays per iteration (forward + upper backward | backbone backward | optimizer): the RCCL "
                     "all-reduce of the upper gradients runs beside the backbone's backward")
+        if self.graph_tail is not None:
+            return "two hipGraph replays per iteration (forward + criterion | backward + optimizer)"
         return ("one hipGraph replay per iteration" if self.graph_opt is None else
                 "two hipGraph replays per iteration (forward + backward | optimizer) around the eager RCCL gradient all-reduce")
 
@@ -360,7 +382,7 @@ class TrainIteration:
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
         if int(flag) == 0 and self.graph is not None:
             self.capture_error = "capture failed on another rank"
-            self.graph = self.graph_opt = self.graph_bb = self.sync_plan = self.static = self.num_global = None
+            self.graph = self.graph_opt = self.graph_bb = self.graph_tail = self.sync_plan = self.static = self.num_global = None
             self.want_graph = False
             if self.grad_sync is not None:
                 self.grad_sync._static = None
@@ -379,7 +401,7 @@ class TrainIteration:
         kinds = {"bucketed": BucketedGradSync, "overlap": SplitGradSync}
         self.grad_sync = kinds.get(self.pending_sync, FlatGradSync)(self.raw_model.parameters())
         if self.graph is not None:
-            self.grad_sync._static = self.sync_plan
+            self.grad_sync._static, self.grad_sync._gathered = self.sync_plan, True
         self.pending_sync = None
         return self.launch_mode()
 
@@ -397,6 +419,8 @@ class TrainIteration:
             self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream if own else cur):
             self.graph.replay()
+            if self.graph_tail is not None:
+                self.graph_tail.replay()
             if self.graph_bb is not None:                    # the upper gradients travel while the backbone's backward replays
                 self.grad_sync.start(part="upper")
                 self.graph_bb.replay()

@@ -197,7 +197,7 @@ def test_two_rank_ddp_step_matches_manual_gradient_average(tmp_path):
                    for n in res["unused"]), res["unused"]
 
 
-def _worker4(rank, world, port, out_dir):
+def _worker4(rank, world, port, out_dir, mode):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -208,8 +208,9 @@ def _worker4(rank, world, port, out_dir):
         from oracle import msda_oracle
         F_.MSDA = msda_oracle.OracleMSDA                     # test-only CPU backend
         import bench
-        # the product's step object on four ranks, flat exchange, a different shard per rank
-        step = bench.TrainStep(torch.device("cpu"), 1, "fp32", ddp="flat", local_rank=rank, size=(64, 224), switches=())
+        # the product's step object on four ranks, a different shard per rank; flat = one exchange after the backward pass,
+        # overlap = the backward pass cut at the backbone's outputs with the upper part's exchange started at the cut
+        step = bench.TrainStep(torch.device("cpu"), 1, "fp32", ddp=mode, local_rank=rank, size=(64, 224), switches=())
         step()
         flat = torch.cat([p.detach().reshape(-1) for p in step.raw_model.parameters()])
         gathered = [torch.empty_like(flat) for _ in range(world)]
@@ -236,9 +237,10 @@ def _worker4(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(600)
-def test_four_rank_flat_exchange_and_rank_divergent_capture_failure(tmp_path):
+@pytest.mark.parametrize("mode", ["flat", "overlap"])
+def test_four_rank_exchange_and_rank_divergent_capture_failure(tmp_path, mode):
     world, port = 4, _free_port()
-    mp.spawn(_worker4, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker4, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     for r in range(world):
         res = torch.load(os.path.join(str(tmp_path), "q%d.pt" % r))
         assert res == dict(same=True, same_grad=True, diverged_ok=True, kept=True), (r, res)

@@ -111,9 +111,12 @@ def test_replayed_training_iteration_follows_the_eager_one_on_changing_batches()
         assert (a - b).norm() <= max(4.0 * (a - c).norm(), 2e-2 * a.norm()), n
 
 
-def test_graph_sees_each_batch_not_the_captured_one():
-    """Same weights, optimizer frozen (lr = 0): the replayed iteration's loss on batch i equals the eager loss on batch i."""
+@pytest.mark.parametrize("parts", ["1", "2"])
+def test_graph_sees_each_batch_not_the_captured_one(parts, monkeypatch):
+    """Same weights, optimizer frozen (lr = 0): the replayed iteration's loss on batch i equals the eager loss on batch i.
+    parts = 2: the iteration recorded as two executable graphs (forward + criterion | backward + optimizer, MDETR_GRAPH_PARTS)."""
     import bench
+    monkeypatch.setenv("MDETR_GRAPH_PARTS", parts)
     from monodetr_amd.helpers.trainer_helper import TARGET_KEYS
     dev = torch.device("cuda", 0)
     switches = bench.committed_switches("bf16")[0]
@@ -141,7 +144,7 @@ def test_graph_sees_each_batch_not_the_captured_one():
                 if k.startswith(("class_error", "cardinality_error")):     # logged counts: one query at a threshold moves them by a whole step
                     continue
                 assert abs(d[k] - d2[k]) <= 5e-3 * max(1.0, abs(d2[k])), (i, k, d[k], d2[k])
-        assert it.replays == 6
+        assert it.replays == 6 and (it.graph_tail is not None) == (parts == "2")
         print("worst relative difference of the total loss, replay vs eager on the same batch: %.3g" % worst)
     finally:
         bench.apply_switches(set())
