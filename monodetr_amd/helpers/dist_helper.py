@@ -95,10 +95,10 @@ def static_plan(params):
 
 @torch.no_grad()
 def gather(plan):
-    """One ``cat`` per dtype of a static plan's gradient tensors into its flat buffer.  TrainIteration.capture() records these
-    INSIDE the graph that produced the gradients (``_gathered``): between two replays the host then only issues the all-reduce
-    -- the 150-tensor ``cat`` call costs the host ~0.3 ms, which a replayed iteration does not hide (the graph launch returns
-    only a queue's depth ahead of the GPU; profiles/r04gap_ddp.txt)."""
+    """One ``cat`` per dtype of a static plan's gradient tensors into its flat buffer.  With MDETR_GATHER_IN_GRAPH=1
+    TrainIteration.capture() records these INSIDE the graph that produced the gradients (``_gathered``) and the host only
+    issues the all-reduce between two replays; measured with one rank that form is 0.4 % slower than the host issuing the cat
+    (profiles/r04ddpab.log), so it is a switch, not the default."""
     for ps, src, flat, views in plan:
         torch.cat([_flat(g) for g in src], out=flat)
     return plan
