@@ -9,6 +9,7 @@ GPU item.  Here the token axis is split into C chunks evaluated as one batched G
 Pure library plumbing (torch.bmm -> hipBLASLt); numerics are those of a split-K GEMM.
 """
 import os
+import sys
 
 import torch
 import torch.nn.functional as F
@@ -32,6 +33,8 @@ def _wants_token_gemm(x2, weight):
 # MDETR_GEMM_RELU=1: "linear -> ReLU" as one library GEMM with the RELU_BIAS epilogue (torch._addmm_activation ->
 # hipBLASLt) instead of a GEMM and an elementwise pass.  Off until timed on a GPU.
 _GEMM_RELU = os.environ.get("MDETR_GEMM_RELU") == "1"
+# the residual-path gradient of `_TokenLinearSkip` is accumulated INTO the arriving gradient tensor when nobody else holds it
+_SKIP_INPLACE = os.environ.get("MDETR_SKIP_INPLACE", "1") != "0"
 
 
 def _split_count(T):
@@ -79,6 +82,70 @@ def _weight_bias_grads(x2, dy2, weight, need_w, need_b):
     return dw, db
 
 
+def _holders(t):
+    """(C++ references to the tensor object, Python references to its wrapper, the same two for the base of a view, tensor
+    objects + wrappers on the storage).  A view keeps its base alive; Python variables share ONE wrapper object, which holds one
+    C++ reference however many of them there are -- hence both kinds of count."""
+    base = t._base
+    return (t._use_count(), sys.getrefcount(t),
+            0 if base is None else base._use_count(), 0 if base is None else sys.getrefcount(base),
+            torch._C._storage_Use_Count(t.untyped_storage()._cdata))
+
+
+_BASELINE = {}              # is-a-view -> _holders() of a gradient that provably nobody else holds (calibrated once, see below)
+SKIP_STATS = None           # tools / tests: a list collects (shape, counts, decision) of every site
+
+
+def _exclusive(t):
+    """Can nobody but the running backward function reach `t`'s memory?  Compared with `_holders()` of a gradient that is known
+    to be exclusively ours (`_calibrate`: the same call path on a toy problem): another node still waiting for the same gradient
+    holds it in its input buffer, retain_grad() and saved-for-backward lists hold the tensor object, a hook that kept it holds
+    the Python wrapper, any further view or detach() alias holds the storage -- each raises one of the counts, and then the
+    caller must not write into `t`.  (MDETR_SKIP_INPLACE=0, or a failed calibration: never.)"""
+    if not _SKIP_INPLACE:
+        return False
+    try:
+        want = _BASELINE.get(t._base is not None)
+        got = _holders(t)
+    except (AttributeError, RuntimeError, TypeError):
+        return False
+    if _BASELINE.get("calibrating"):
+        _BASELINE.setdefault("seen", []).append(got)
+        return False
+    ok = want is not None and all(g <= w for g, w in zip(got, want))
+    if SKIP_STATS is not None:
+        SKIP_STATS.append((tuple(t.shape), got, ok))
+    return ok
+
+
+def _calibrate():
+    """Holder counts of a residual-path gradient that nobody else holds, through the very call path `_TokenLinearSkip.backward`
+    uses: a fresh tensor (the gradient of `x' * 2`) and a view of a fresh tensor (the gradient arriving through a reshape of x').
+    Anything unexpected (other counts on a second pass, an exception) leaves the baseline empty = never in place."""
+    _BASELINE["calibrating"] = True
+    try:
+        found = {}
+        for _ in range(2):
+            for view in (False, True):
+                _BASELINE["seen"] = []
+                with torch.enable_grad():                            # (called from a Function's forward: grad mode is off there)
+                    x = torch.zeros(4, 3, 8, requires_grad=True)
+                    w = torch.zeros(2, 8, requires_grad=True)
+                    y, xs = _TokenLinearSkip.apply(x, w, None, None)
+                    tail = (xs.view(12, 8) if view else xs) * 2.0
+                    (y.sum() + tail.sum()).backward()
+                seen = _BASELINE["seen"]
+                if len(seen) != 1 or (seen[0][2] > 0) != view or found.setdefault(view, seen[0]) != seen[0]:
+                    found = None
+                    break
+            if found is None:
+                break
+    except Exception:                                                # noqa: BLE001 -- no baseline, no in-place writes
+        found = None
+    _BASELINE.clear()
+    _BASELINE.update(found or {"failed": True})
+
+
 class _TokenLinearSkip(torch.autograd.Function):
     """(y, x') = ((x + pos) W^T + b, x): the linear layer of a residual branch together with the tensor the residual connection
     continues from.  x has ONE consumer in the graph, so the gradient arriving through x' (the residual path) and the layer's own
@@ -89,6 +156,9 @@ class _TokenLinearSkip(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, pos, relu=False):
+        if _SKIP_INPLACE and not _BASELINE:
+            _calibrate()                                             # (here, not in backward: a backward pass inside a backward pass
+                                                                     # runs on another call path)
         q = x if pos is None else x + pos
         ctx.has_bias = bias is not None
         ctx.relu = bool(relu)
@@ -111,9 +181,14 @@ class _TokenLinearSkip(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if dskip is None:
                 dx = (dy2 @ weight).view_as(q)
+            elif dskip.is_contiguous() and dskip.dtype == dy2.dtype and _exclusive(dskip):
+                # beta = 1 GEMM INTO the arriving gradient: nobody else can reach that tensor (see `_exclusive`).  The
+                # out-of-place form below first copies it (torch.addmm = a 42 MB device-to-device copy, then the same GEMM): 14
+                # such copies per training step, 0.3 ms (the MEMCPY nodes of profiles/r04_graph_structure.txt)
+                dx = dskip.view(-1, q.shape[-1]).addmm_(dy2, weight).view_as(q)
             elif dskip.is_contiguous() and dskip.dtype == dy2.dtype:
-                # beta = 1 GEMM reading the arriving gradient, writing a NEW tensor: the same traffic as the in-place form (the
-                # library reads C and writes D either way), and a tensor hook / retain_grad() holder of `dskip` keeps its values
+                # somebody else holds the arriving gradient (a second consumer still waiting for it, retain_grad(), a hook that
+                # kept it): a NEW tensor
                 dx = torch.addmm(dskip.view(-1, q.shape[-1]), dy2, weight).view_as(q)
             else:
                 dx = dskip + (dy2 @ weight).view_as(q)
