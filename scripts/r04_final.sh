@@ -40,6 +40,7 @@ cd $R; f=$(find /tmp/trace_step -name "*kernel_trace.csv" | head -1); st=$(find 
 python -m monodetr_amd.tools.trace_stats $f --steps 8 --skip-last 14 --gaps 8 --out $O/${T}_bench_bf16_steady_kernel_stats.csv --top 14 > $O/trace_stats.txt 2>&1; grep -v " us/step " $O/trace_stats.txt | head -34 | cut -c1-170
 grep -E "mdetr|Name" $st | head -90 > $O/${T}_rocprofv3_stats_mdetr_kernels.csv
 tail -1 $O/bench_traced.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('traced', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_ms'], d['roofline'].get('traffic'))"
+[ "${SKIP_SIDE:-0}" = "1" ] && exit 0                    # (the operator benches below: unchanged kernels, measured in r04f)
 for p in 0.1 0.0; do timeout 300 python -m monodetr_amd.tools.attnbench --dropout $p 2>/dev/null | tail -1 > $O/attnbench_p$p.json; done
 timeout 300 python -m monodetr_amd.tools.convbench --iters 20 2>/dev/null | tail -1 > $O/convbench.json
 timeout 300 python -m monodetr_amd.tools.convbench --only conv3x3 --iters 20 2>/dev/null | tail -1 > $O/convbench_conv3x3.json
