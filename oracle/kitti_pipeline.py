@@ -19,8 +19,11 @@ reference's requirements.txt) is restated from OpenCV's published algorithms:
 PARITY STATUS.  Pinned: everything computed by numpy / PIL / the reference's own Python -- tests/golden/
 kitti_pipeline.npz is recorded by running the reference's KITTI_Dataset class itself on a synthetic KITTI tree
 (tests/golden/make_kitti_golden.py), with cv2 / numba / skimage / torchvision stubbed because they are absent here.
-UNPINNED: the two cv2 functions above -- the golden run routes them through this file's restatements, so the HSV
-round trip and the last bits of the affine matrix are checked only against OpenCV's documented formulas.
+UNPINNED against OpenCV itself: the two cv2 functions above -- the golden run routes them through this file's restatements.
+What holds them instead (tests/test_kitti_pipeline_cpu.py): both HSV directions against the standard library's `colorsys` (an
+independent implementation of the same hexcone model; float32 rounding), and the affine matrix by uniqueness -- three
+non-collinear point pairs have exactly one affine map, the test checks that the matrix maps them (and a least-squares route
+to the same matrix).  The last bits of OpenCV's own float evaluation order remain unchecked.
 
 Everything is a function of (decoded image, label lines, calibration, the draws of numpy's global RNG); the draws are
 made in the reference's order, so `np.random.seed(s)` reproduces the reference sample for sample.

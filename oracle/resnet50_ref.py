@@ -9,6 +9,12 @@ projection on the first block of each stage -- as a pure FUNCTION of a state_dic
 nothing but ``F.conv2d``, the frozen-BN affine of backbone.py:54-64 (``w * rsqrt(running_var + 1e-5)``), ``F.max_pool2d``
 and ``F.relu``.  It shares no code with monodetr_amd/monodetr/backbone.py (no folding, no GEMM forms, no module classes),
 so agreement between the two pins the product's backbone values to something other than itself.
+
+Pinning of THIS file: torchvision is installed nowhere in the build container, so its code cannot be run.  The restatement is
+held instead to an independent public implementation of the same network that IS present -- Hugging Face transformers 5.15.0,
+``transformers.models.resnet.modeling_resnet`` (what the ``microsoft/resnet-50`` checkpoint, converted from the torchvision /
+timm weights, runs on): tests/test_backbone_parity_hf_cpu.py loads one state_dict into both and compares the three feature maps
+and the gradients of the input and of all 53 convolutions (1e-10 / 1e-9 in fp64).  torchvision's own code path stays unpinned.
 """
 import torch
 import torch.nn.functional as F

@@ -90,6 +90,47 @@ def test_hsv_round_trip_restatement_properties():
     assert np.allclose(okp.bgr2hsv_f32(pure)[0, :, 0], [240.0, 120.0, 0.0], atol=1e-3)
 
 
+def test_hsv_restatements_against_the_standard_library_colorsys():
+    """cv2 is absent, so the float HSV conversions are restated from OpenCV's documented formulas; Python's `colorsys` is an
+    independent implementation of the same hexcone model (hue as a fraction of a turn instead of degrees, no epsilon in the
+    denominators): both directions agree to float32 rounding on random colours, greys, ties and pure colours."""
+    import colorsys
+    rs = np.random.RandomState(3)
+    bgr = rs.uniform(0, 255, size=(400, 3)).astype(np.float32)
+    bgr[:20] = bgr[:20, :1]                                            # greys
+    bgr[20:40, 1] = bgr[20:40, 2]                                      # ties between two channels
+    bgr[40:43] = np.array([[255, 0, 0], [0, 255, 0], [0, 0, 255]], dtype=np.float32)
+    hsv = okp.bgr2hsv_f32(bgr[None])[0]
+    for (b, g, r), (h, s_, v) in zip(bgr.astype(np.float64), hsv.astype(np.float64)):
+        hc, sc, vc = colorsys.rgb_to_hsv(r, g, b)
+        dh = abs(h - hc * 360.0)
+        assert min(dh, 360.0 - dh) <= 2e-3 and abs(s_ - sc) <= 2e-6 and v == vc, ((b, g, r), (h, s_, v), (hc * 360, sc, vc))
+    # the other direction on arbitrary (hue, saturation, value) triples, hue outside [0, 360) included
+    hsv_in = np.stack([rs.uniform(-300, 700, 400), rs.uniform(0, 1, 400), rs.uniform(0, 255, 400)], -1).astype(np.float32)
+    back = okp.hsv2bgr_f32(hsv_in[None])[0]
+    for (h, s_, v), (b, g, r) in zip(hsv_in.astype(np.float64), back.astype(np.float64)):
+        rc, gc, bc = colorsys.hsv_to_rgb((h / 360.0) % 1.0, s_, v)
+        assert max(abs(r - rc), abs(g - gc), abs(b - bc)) <= 2e-3 * max(1.0, v), ((h, s_, v), (b, g, r), (bc, gc, rc))
+
+
+def test_affine_matrix_restatement_is_the_unique_map_of_its_three_points():
+    """cv2.getAffineTransform, restated: three non-collinear point pairs determine ONE affine map, so mapping the points is the
+    whole specification (the inputs are float32, as cv2 requires; the solve is float64, as the library's)."""
+    rs = np.random.RandomState(5)
+    for _ in range(50):
+        src = rs.uniform(-500, 1500, size=(3, 2)).astype(np.float32)
+        dst = rs.uniform(-500, 1500, size=(3, 2)).astype(np.float32)
+        if abs(np.linalg.det(np.c_[src.astype(np.float64), np.ones(3)])) < 1.0:
+            continue
+        m = okp.get_affine_matrix(src, dst)
+        assert m.shape == (2, 3) and m.dtype == np.float64
+        mapped = src.astype(np.float64) @ m[:, :2].T + m[:, 2]
+        assert np.abs(mapped - dst.astype(np.float64)).max() <= 1e-8
+        # ... and an independent route to the same matrix: least squares on homogeneous coordinates
+        ls = np.linalg.lstsq(np.c_[src.astype(np.float64), np.ones(3)], dst.astype(np.float64), rcond=None)[0].T
+        assert np.abs(ls - m).max() <= 1e-8 * max(1.0, np.abs(m).max())
+
+
 def test_uint8_cast_is_the_wrapping_c_cast_the_reference_relies_on():
     x = np.array([300.7, -3.2, 255.9, 256.0, -0.5, 511.9], dtype=np.float32)
     with np.errstate(invalid='ignore'):
