@@ -294,12 +294,11 @@ class TrainIteration:
             else:
                 from .dist_helper import gather, static_plan
                 cut = self._overlap()
-                # the gradients sit at the addresses the captured backward writes to; the graph that produced them also gathers
-                # them into persistent flat buffers (one cat per dtype, recorded), every later exchange reduces there, and the
-                # captured optimizer reads the reduced slices
-                # MDETR_GATHER_IN_GRAPH=1: the cat of the gradients into the flat buffers is recorded in the graph that produced
-                # them (the host then only issues the all-reduce between two replays).  Measured on one box with one rank
-                # (profiles/r04ddpab.log): 376.1 img/s against 377.9 with the host issuing the cat -- not the default.
+                # the gradients sit at the addresses the captured backward writes to: every later exchange gathers from THOSE into
+                # persistent flat buffers (one cat per dtype), reduces there, and the captured optimizer reads the reduced slices.
+                # MDETR_GATHER_IN_GRAPH=1: the cat is recorded in the graph that produced the gradients (the host then only issues
+                # the all-reduce between two replays).  Measured on one box with one rank (profiles/r04ddpab.log): 376.1 img/s
+                # against 377.9 with the host issuing the cat -- not the default.
                 inside = os.environ.get("MDETR_GATHER_IN_GRAPH", "0") == "1"
                 fill = gather if inside else (lambda plan: plan)
                 with torch.cuda.graph(graph, stream=side, **mode):
