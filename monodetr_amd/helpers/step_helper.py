@@ -53,8 +53,11 @@ def _signature(x):
 
 
 def _graph_parts():
-    """MDETR_GRAPH_PARTS: into how many executable graphs the single-process iteration is recorded (1 | 2)."""
-    return 2 if os.environ.get("MDETR_GRAPH_PARTS", "1") == "2" else 1
+    """MDETR_GRAPH_PARTS: how the single-process iteration is recorded -- "1": one executable graph; "2": forward + criterion |
+    backward + optimizer; "msda": forward + the backward pass down to the encoder's last layer | from that layer's MSDA backward
+    launch on + optimizer (monodetr/_cut.py: the second graph starts with a 0.45 ms kernel)."""
+    v = os.environ.get("MDETR_GRAPH_PARTS", "1")
+    return v if v in ("2", "msda") else "1"
 
 
 def _rccl_group_is_up():
@@ -149,12 +152,17 @@ class TrainIteration:
             from .. import attn_ext
             attn_ext.begin_iteration(self.device)
         self._boundary = [] if cut else None
-        if cut:
+        if cut == "msda":
+            from ..monodetr import _cut
+            _cut.begin(self._boundary, "msda")
+        elif cut:
             self.raw_model.__dict__["_grad_boundary"] = self._boundary
         try:
             total, losses = self.compute(batch)
         finally:
             self.raw_model.__dict__.pop("_grad_boundary", None)
+            if cut == "msda":
+                _cut.end()
             if scoped:
                 attn_ext.end_iteration(self.device)
         self.losses = losses
@@ -280,7 +288,17 @@ class TrainIteration:
             self._fill_num_global()
         self._capturing = True
         try:
-            if not two and _graph_parts() > 1:
+            if not two and _graph_parts() == "msda":
+                # forward + criterion + the backward pass above the encoder's last MSDA launch | the rest + optimizer
+                with torch.cuda.graph(graph, stream=side, **mode):
+                    self.loss = self._forward_backward(self.static, cut="msda")
+                if not self._boundary:
+                    raise RuntimeError("MDETR_GRAPH_PARTS=msda: the forward pass crossed no cut point (monodetr/_cut.py)")
+                graph_tail = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_tail, stream=side, pool=graph.pool(), **mode):
+                    self._backward_backbone()
+                    self.optimizer.step()
+            elif not two and _graph_parts() == "2":
                 # forward + criterion | backward + optimizer: two executable graphs of < 1000 nodes each (see `_graph_parts`)
                 with torch.cuda.graph(graph, stream=side, **mode):
                     self.loss = self._forward(self.static)
@@ -380,7 +398,9 @@ class TrainIteration:
             return ("three hipGraph replays per iteration (forward + upper backward | backbone backward | optimizer): the RCCL "
                     "all-reduce of the upper gradients runs beside the backbone's backward")
         if self.graph_tail is not None:
-            return "two hipGraph replays per iteration (forward + criterion | backward + optimizer)"
+            return "two hipGraph replays per iteration (%s)" % (
+                "forward + upper backward | from the encoder's last MSDA backward on + optimizer" if _graph_parts() == "msda"
+                else "forward + criterion | backward + optimizer")
         return ("one hipGraph replay per iteration" if self.graph_opt is None else
                 "two hipGraph replays per iteration (forward + backward | optimizer) around the eager RCCL gradient all-reduce")
 

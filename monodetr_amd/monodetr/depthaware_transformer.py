@@ -25,6 +25,7 @@ from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
 from ..add_ln_ext import residual_layernorm
+from . import _cut
 from ..utils.misc import inverse_sigmoid, no_padding
 from .attention import MultiheadAttention as FusedMultiheadAttention
 from .linear import Linear, ffn_hidden, token_linear
@@ -195,8 +196,9 @@ class VisualEncoder(nn.Module):
         else:
             reference_points = self.get_reference_points(shapes, valid_ratios, src.device)
         out = src
-        for layer in self.layers:
-            out = layer(out, pos, reference_points, spatial_shapes, level_start_index, padding_mask)
+        for i, layer in enumerate(self.layers):
+            with _cut.armed(i == len(self.layers) - 1):               # (_cut: the last layer's operator may head a second graph)
+                out = layer(out, pos, reference_points, spatial_shapes, level_start_index, padding_mask)
         return out
 
 

@@ -29,6 +29,7 @@ from ..losses.focal_loss import sigmoid_focal_loss
 from ..utils import box_ops
 from ..utils.misc import (NestedTensor, get_world_size, inverse_sigmoid,
                           is_dist_avail_and_initialized, mark_no_padding)
+from . import _cut
 from .backbone import build_backbone
 from .depth_predictor import DepthPredictor
 from .depth_predictor.ddn_loss import DDNLoss
@@ -156,7 +157,8 @@ class MonoDETR(nn.Module):
 
         query_embeds = self.query_embed.weight if self.training else self.query_embed.weight[:self.num_queries]
 
-        depth_logits, depth_pos_embed, weighted_depth, depth_pos_embed_ip = self.depth_predictor(srcs, masks[1], pos[1])
+        dp_srcs = [_cut.at("msda", s) for s in srcs] if _cut.active("msda") else srcs
+        depth_logits, depth_pos_embed, weighted_depth, depth_pos_embed_ip = self.depth_predictor(dp_srcs, masks[1], pos[1])
         # the decoder evaluates the five heads that read a level's output together (first layers as one GEMM).  The head
         # lists are handed over per forward, through the decoder's __dict__: not registered sub-modules (the state_dict
         # keeps the reference's key names), and THIS replica's modules when a DataParallel wrapper has replicated the model

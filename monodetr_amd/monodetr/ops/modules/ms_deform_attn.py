@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..functions import MSDeformAttnFunction
+from ... import _cut
 from ...linear import Linear, token_linear, token_linear_skip
 from .... import msda_prologue_ext
 
@@ -148,6 +149,7 @@ class MSDeformAttn(nn.Module):
 
         out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
                                          locations, weights, self.im2col_step)
+        out = _cut.at("msda", out, when_armed=True)                   # (a two-graph iteration may start its second graph here)
         if out.dtype != out_dtype and out_dtype == torch.bfloat16:
             out = out.to(out_dtype)                                    # (the fp32 operator of the wide form)
         return token_linear(out, self.output_proj.weight, self.output_proj.bias)
@@ -161,7 +163,7 @@ class MSDeformAttn(nn.Module):
         if not (_FUSED_PROLOGUE and _PACKED_PROJECTION and src.is_cuda and not torch.is_autocast_enabled()
                 and reference_points.shape[-1] in (2, 6)):
             return self.forward(src if pos is None else src + pos, reference_points, src, input_spatial_shapes,
-                                input_level_start_index, input_padding_mask), src
+                                input_level_start_index, input_padding_mask), _cut.at("msda", src, when_armed=True)
         N, S, _ = src.shape
         _check_token_count(input_spatial_shapes, S)
         value, src1 = token_linear_skip(src, self.value_proj.weight, self.value_proj.bias)
@@ -170,7 +172,7 @@ class MSDeformAttn(nn.Module):
         packed, src2 = token_linear_skip(src1, *self._packed_projection(), pos=pos)
         out = self._attend(value.view(N, S, self.n_heads, -1), packed, None, None, reference_points, input_spatial_shapes,
                            input_level_start_index, src.dtype)
-        return out, src2
+        return out, _cut.at("msda", src2, when_armed=True)
 
 
 class MSDeformAttn_cross(MSDeformAttn):

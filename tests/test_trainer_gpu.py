@@ -111,7 +111,40 @@ def test_replayed_training_iteration_follows_the_eager_one_on_changing_batches()
         assert (a - b).norm() <= max(4.0 * (a - c).norm(), 2e-2 * a.norm()), n
 
 
-@pytest.mark.parametrize("parts", ["1", "2"])
+def test_backward_pass_cut_at_the_encoders_last_msda_launch_gives_the_same_gradients():
+    """monodetr/_cut.py, site "msda": the backward pass in two calls -- down to the cut set {the last encoder layer's MSDA output,
+    the residual stream next to it, the pyramid levels the depth predictor reads}, then from there -- leaves every parameter
+    with the gradient of the uncut pass, and the second call's autograd roots include the operator's output."""
+    import bench
+    from monodetr_amd.helpers.trainer_helper import TARGET_KEYS
+    dev = torch.device("cuda", 0)
+    switches = bench.committed_switches("bf16")[0]
+    try:
+        it, _ = build(dev, False, switches)
+        images, calibs, t = collated_batch(2, seed=77)
+        images = images.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        batch = (images, calibs.to(dev), t['img_size'].to(dev), {k: t[k].to(dev) for k in TARGET_KEYS})      # (`run()` moves them)
+        it._forward_backward(batch)
+        want = {n: p.grad.detach().float().clone() for n, p in it.raw_model.named_parameters() if p.grad is not None}
+        total = it._forward_backward(batch, cut="msda")
+        cuts = [tuple(td.shape) for _, td in it._boundary]
+        first = {n for n, p in it.raw_model.named_parameters() if p.grad is not None}
+        it._backward_backbone()
+        got = {n: p.grad.detach().float() for n, p in it.raw_model.named_parameters() if p.grad is not None}
+        assert torch.isfinite(total) and set(got) == set(want)
+        # two cuts in the encoder's last layer ([B, S, 256] each) + the pyramid levels the depth predictor was handed
+        assert cuts.count((2, 10200, 256)) == 2 and len(cuts) >= 4, cuts
+        # the first call stopped above the cut: nothing of the backbone, of the input projections or of the first encoder layers
+        assert not any(n.startswith(("backbone.", "input_proj.", "depthaware_transformer.encoder.layers.0.")) for n in first), sorted(first)[:8]
+        assert any(n.startswith("depthaware_transformer.decoder.") for n in first)
+        worst = max(((got[n] - want[n]).norm() / want[n].norm().clamp_min(1e-20)).item() for n in want)
+        print("worst relative difference of a parameter gradient, cut vs uncut backward pass: %.3g" % worst)
+        assert worst <= 1e-6, worst
+    finally:
+        bench.apply_switches(set())
+
+
+@pytest.mark.parametrize("parts", ["1", "2", "msda"])
 def test_graph_sees_each_batch_not_the_captured_one(parts, monkeypatch):
     """Same weights, optimizer frozen (lr = 0): the replayed iteration's loss on batch i equals the eager loss on batch i.
     parts = 2: the iteration recorded as two executable graphs (forward + criterion | backward + optimizer, MDETR_GRAPH_PARTS)."""
@@ -144,7 +177,7 @@ def test_graph_sees_each_batch_not_the_captured_one(parts, monkeypatch):
                 if k.startswith(("class_error", "cardinality_error")):     # logged counts: one query at a threshold moves them by a whole step
                     continue
                 assert abs(d[k] - d2[k]) <= 5e-3 * max(1.0, abs(d2[k])), (i, k, d[k], d2[k])
-        assert it.replays == 6 and (it.graph_tail is not None) == (parts == "2")
+        assert it.replays == 6 and (it.graph_tail is not None) == (parts != "1")
         print("worst relative difference of the total loss, replay vs eager on the same batch: %.3g" % worst)
     finally:
         bench.apply_switches(set())
