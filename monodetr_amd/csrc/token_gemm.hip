@@ -286,6 +286,183 @@ void token_gemm_direct_kernel(const __bf16 *__restrict__ x, const __bf16 *__rest
     }
 }
 
+// ---- the "weight in registers" form (MDETR_TOKEN_GEMM_DIRECT=2) -------------------------------------------------------------
+// The two forms above hold the weight in LDS and give every wave its own tokens: each product reads a 1 KB weight fragment from
+// LDS, the 135 KB weight block allows one workgroup of four waves per CU (one wave per SIMD: nothing hides a wait), and the
+// direct form fetches x in 16-byte pieces of a row per instruction.  Here the roles are swapped:
+//   * a workgroup = 8 waves owns up to 256 output features, wave v the 32 features n0 + 32 v ...: its weight slice [32][K] is 16 KB
+//     at K = 256 -- K / 16 register quads per lane (the A operands of v_mfma_f32_32x32x16_bf16), loaded ONCE;
+//   * the workgroup walks tiles of TT = 64 (or 32) tokens: the tile's [TT][K] inputs come in with full-row coalesced 16-byte
+//     loads (a wave covers two whole 512-byte rows per instruction), go through registers into one of two LDS buffers
+//     (rows padded by 8 bf16: conflict-free ds_read_b128), and ALL eight waves read their B operands from there -- x is
+//     fetched from memory once per 256 output features, 32 KB per tile and workgroup;
+//   * two register stages: the loads of tile i + 2 are issued before the products of tile i, the stage holding tile i + 1 is
+//     written to LDS after them -- one barrier per tile, 1.5 - 2 tiles (48 - 64 KB per CU) in flight;
+//   * 1 275 tiles of 64 tokens at T = 81 600 = 4.98 per CU: five rounds with no tail (256-token tiles: 319 over 256 CUs = two
+//     rounds for 1.25 rounds of work).
+// LDS 68 KB, ~170 registers at two waves per SIMD.  Same products in the same order per output element as the other forms.
+constexpr int kWavesW = 8;
+
+template <int K, int TT, bool RELU>
+__global__ __launch_bounds__(kWavesW * 64, 2)
+void token_gemm_ws_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, const __bf16 *__restrict__ bias,
+                          __bf16 *__restrict__ y, int64_t T, int N, int64_t ldx, int64_t ldy, int gx, int ny)
+{
+    constexpr int KP = K + 8, KS = K / 16, TB = TT / 32;
+    constexpr int kChunks = TT * (K / 8), kPer = (kChunks + kWavesW * 64 - 1) / (kWavesW * 64);      // 16-byte pieces of a tile, per thread
+    MDETR_DYNAMIC_LDS(unsigned char, smem_raw);
+    __bf16 *Xs = reinterpret_cast<__bf16 *>(smem_raw);           // [2][TT][KP]
+    float *bias_s = reinterpret_cast<float *>(Xs + 2 * TT * KP);  // [256]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+    // 1-D grid of gx * ny workgroups, gx a multiple of 8: the ny column blocks of one token range share an XCD (see the direct form)
+    const int id = blockIdx.x, grp = id >> 3;
+    const int col = grp % ny, bx = (grp / ny) * 8 + (id & 7);
+    const int n0 = col * kWavesW * 32;
+    const int64_t tiles = (T + TT - 1) / TT;
+    if (bx >= tiles) return;
+
+    // one tile's inputs: piece c = thread + 512 p -> row c / (K / 8), 16-byte piece c % (K / 8); rows beyond T re-read row T - 1
+    // (their products are never stored)
+    auto request = [&](bf16x8 (&st_)[kPer], int64_t tile_) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p_ = 0; p_ < kPer; ++p_) {
+            const int c = static_cast<int>(threadIdx.x) + kWavesW * 64 * p_;
+            if (kChunks % (kWavesW * 64) == 0 || c < kChunks) {
+                const int row = c / (K / 8), piece = c - row * (K / 8);
+                const int64_t t = tile_ * TT + row, tc = t < T ? t : T - 1;
+                st_[p_] = *reinterpret_cast<const bf16x8 *>(x + tc * ldx + piece * 8);
+            }
+        }
+    };
+    auto deposit = [&](const bf16x8 (&st_)[kPer], int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p_ = 0; p_ < kPer; ++p_) {
+            const int c = static_cast<int>(threadIdx.x) + kWavesW * 64 * p_;
+            if (kChunks % (kWavesW * 64) == 0 || c < kChunks) {
+                const int row = c / (K / 8), piece = c - row * (K / 8);
+                *reinterpret_cast<bf16x8 *>(Xs + (buf * TT + row) * KP + piece * 8) = st_[p_];
+            }
+        }
+    };
+
+    bf16x8 st0[kPer], st1[kPer];
+    int64_t tile = bx;
+    request(st0, tile);                                          // tile 0 of this workgroup: requested ahead of the weight
+    if (tile + gx < tiles) request(st1, tile + gx);
+
+    // ---- this wave's weight slice into registers: fragment ks = W[n0 + 32 wave + (lane & 31)][16 ks + 8 half ...]
+    const int nrow = n0 + wave * 32 + (lane & 31);
+    const bool live = nrow < N;
+    const __bf16 *wr = w + static_cast<int64_t>(live ? nrow : N - 1) * K + half * 8;
+    bf16x8 wa[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        wa[ks] = *reinterpret_cast<const bf16x8 *>(wr + ks * 16);
+        if (!live) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wa[ks][i] = static_cast<__bf16>(0.f);
+        }
+    }
+    for (int c = threadIdx.x; c < kWavesW * 32; c += kWavesW * 64)
+        bias_s[c] = (bias && n0 + c < N) ? static_cast<float>(bias[n0 + c]) : 0.f;
+
+    deposit(st0, 0);
+    if (tile + 2 * static_cast<int64_t>(gx) < tiles) request(st0, tile + 2 * static_cast<int64_t>(gx));
+    __syncthreads();
+
+    // products and epilogue of the tile in LDS buffer `buf`
+    auto compute = [&](int64_t tile_, int buf) __attribute__((always_inline)) {
+        f32x16 acc[TB];
+#pragma unroll
+        for (int b = 0; b < TB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
+        const __bf16 *xl = Xs + (buf * TT + (lane & 31)) * KP + half * 8;      // this lane's token of block b: + b * 32 * KP; k-step: + 16 ks
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                const bf16x8 xb = *reinterpret_cast<const bf16x8 *>(xl + b * 32 * KP + ks * 16);
+                acc[b] = mfma_bf16(wa[ks], xb, acc[b]);          // Y^T[n][token]
+            }
+        }
+        // lane = token (lane & 31) of block b; register quad g holds features 32 wave + 8 g + 4 half + 0..3
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+            const int64_t t = tile_ * TT + b * 32 + (lane & 31);
+            if (t < T) {
+                __bf16 *yr = y + t * ldy + n0 + wave * 32 + 4 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nn = wave * 32 + 8 * g + 4 * half;
+                    if (n0 + nn < N) {                            // N is a multiple of 4: a quad is in or out as a whole
+                        bf16x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float v = acc[b][4 * g + i] + bias_s[nn + i];
+                            if (RELU) v = v > 0.f ? v : 0.f;
+                            o[i] = static_cast<__bf16>(v);
+                        }
+                        *reinterpret_cast<bf16x4 *>(yr + 8 * g) = o;
+                    }
+                }
+            }
+        }
+    };
+
+    // two tiles per trip: stage st1 holds tile i + 1 and st0 tile i + 2 on entry (whichever exist)
+    const int64_t step = gx;
+    for (;; tile += 2 * step) {
+        compute(tile, 0);
+        if (tile + step >= tiles) break;
+        deposit(st1, 1);                                         // tile i + 1 (buffer 1 was last read before the previous barrier)
+        if (tile + 3 * step < tiles) request(st1, tile + 3 * step);
+        __syncthreads();
+        compute(tile + step, 1);
+        if (tile + 2 * step >= tiles) break;
+        deposit(st0, 0);                                         // tile i + 2
+        if (tile + 4 * step < tiles) request(st0, tile + 4 * step);
+        __syncthreads();
+    }
+}
+
+template <int K, int TT, bool RELU>
+hipError_t launch_ws(const void *x, const void *w, const void *bias, void *y, int64_t T, int N, int64_t ldx, int64_t ldy,
+                     hipStream_t st)
+{
+    constexpr size_t lds = static_cast<size_t>(2) * TT * (K + 8) * 2 + kWavesW * 32 * 4;
+    auto kern = token_gemm_ws_kernel<K, TT, RELU>;
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    if (hipGetDevice(&dev_) != hipSuccess) dev_ = -1;
+    if (dev_ < 0 || dev_ >= 64 || !attr_set[dev_]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;
+    }
+    const int64_t tiles = (T + TT - 1) / TT;
+    const int ny = (N + kWavesW * 32 - 1) / (kWavesW * 32);
+    int64_t gx = tiles;
+    const int64_t cap = 256 / ny > 0 ? 256 / ny : 1;             // one workgroup per CU (two waves per SIMD)
+    if (gx > cap) gx = cap;
+    gx = (gx + 7) / 8 * 8;                                       // whole rounds over the XCDs (idle workgroups leave at once)
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(gx * ny)), dim3(kWavesW * 64), lds, st,
+                       static_cast<const __bf16 *>(x), static_cast<const __bf16 *>(w), static_cast<const __bf16 *>(bias),
+                       static_cast<__bf16 *>(y), T, N, ldx, ldy, static_cast<int>(gx), ny);
+    return hipGetLastError();
+}
+
+// token tiles of 64 when they fill the chip, of 32 for the few-thousand-row products
+template <int K, bool RELU>
+hipError_t launch_ws_any(const void *x, const void *w, const void *bias, void *y, int64_t T, int N, int64_t ldx, int64_t ldy,
+                         hipStream_t st)
+{
+    const int ny = (N + kWavesW * 32 - 1) / (kWavesW * 32);
+    if ((T + 63) / 64 * ny >= 256) return launch_ws<K, 64, RELU>(x, w, bias, y, T, N, ldx, ldy, st);
+    return launch_ws<K, 32, RELU>(x, w, bias, y, T, N, ldx, ldy, st);
+}
+
 template <int K, int NB, bool RELU>
 hipError_t launch_direct(const void *x, const void *w, const void *bias, void *y, int64_t T, int N, int64_t ldx, int64_t ldy,
                          hipStream_t st)
@@ -359,6 +536,11 @@ hipError_t token_gemm_launch(const void *x, const void *w, const void *bias, voi
 {
     const char *dv_ = getenv("MDETR_TOKEN_GEMM_DIRECT");
     const bool direct = dv_ && atoi(dv_) != 0;
+    if (dv_ && atoi(dv_) == 2 && (K == 256 || K == 128 || K == 64)) {                 // the weight-in-registers form
+        if (K == 256) return relu ? launch_ws_any<256, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch_ws_any<256, false>(x, w, bias, y, T, N, ldx, ldy, st);
+        if (K == 128) return relu ? launch_ws_any<128, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch_ws_any<128, false>(x, w, bias, y, T, N, ldx, ldy, st);
+        return relu ? launch_ws_any<64, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch_ws_any<64, false>(x, w, bias, y, T, N, ldx, ldy, st);
+    }
     if (direct && K == 512) return relu ? launch_direct<512, 4, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch_direct<512, 4, false>(x, w, bias, y, T, N, ldx, ldy, st);
     if (direct && K == 128) return relu ? launch_direct<128, 8, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch_direct<128, 8, false>(x, w, bias, y, T, N, ldx, ldy, st);
     if (direct && K == 64) {

@@ -1,5 +1,6 @@
-"""Token-shaped products y[T, N] = x[T, K] W^T + b (bf16) three ways in one process: the library GEMM, csrc/token_gemm.hip with the
-inputs staged through LDS, and its direct form (MDETR_TOKEN_GEMM_DIRECT=1: the switch is read at every launch) -- milliseconds,
+"""Token-shaped products y[T, N] = x[T, K] W^T + b (bf16) four ways in one process: the library GEMM, csrc/token_gemm.hip with the
+inputs staged through LDS, its direct form (MDETR_TOKEN_GEMM_DIRECT=1: the switch is read at every launch) and the
+weight-in-registers form (= 2) -- milliseconds,
 algorithmic bytes / time as a fraction of the 8 TB/s HBM roofline, and whether the two kernel forms agree bit for bit.
 
     python -m monodetr_amd.tools.tokenbench [--iters 50] [--out gpurun_out/tokenbench.json]
@@ -48,11 +49,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--out", default="")
+    ap.add_argument("--only", default="", help="comma-separated substrings: only the shapes whose name contains one of them")
     a = ap.parse_args()
     from monodetr_amd import token_gemm_ext
     dev = torch.device("cuda", 0)
     res = {}
     for name, T, K, N, relu in SHAPES:
+        if a.only and not any(k in name for k in a.only.split(",")):
+            continue
         g = torch.Generator(device="cpu").manual_seed(T + K + N)
         x = (torch.randn(T, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
         w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(dev)
@@ -62,7 +66,7 @@ def main():
         lib = (lambda: F.relu_(F.linear(x, w, b))) if relu else (lambda: F.linear(x, w, b))
         row["library_ms"] = round(timeit(lib, a.iters), 4)
         outs = {}
-        for tag, flag in (("staged", "0"), ("direct", "1")):
+        for tag, flag in (("staged", "0"), ("direct", "1"), ("regs", "2")):      # (2: the weight-in-registers form, K <= 256)
             os.environ["MDETR_TOKEN_GEMM_DIRECT"] = flag
             if not token_gemm_ext.supported(x, w):
                 continue
@@ -70,8 +74,8 @@ def main():
             outs[tag] = f()
             row[tag + "_ms"] = round(timeit(f, a.iters), 4)
             row[tag + "_frac"] = round(byts / (row[tag + "_ms"] * 1e-3) / HBM, 4)
-        if len(outs) == 2:
-            row["forms_bit_equal"] = bool(torch.equal(outs["staged"], outs["direct"]))
+        if len(outs) >= 2:
+            row["forms_bit_equal"] = all(bool(torch.equal(outs["staged"], o)) for o in outs.values())
         if outs:
             ref = lib().float()
             row["max_err_vs_library"] = float((next(iter(outs.values())).float() - ref).abs().max())

@@ -144,3 +144,45 @@ def test_token_linear_autograd_function_with_the_emulated_kernel(relu, monkeypat
     for name, a, r in zip(("y", "dx", "dw", "db"), got, (ref.detach(), x.grad, w.grad, b.grad)):
         assert a.dtype == torch.bfloat16
         assert (a.float() - r.float()).abs().max() <= 3e-2 * max(1.0, r.float().abs().max().item()), name
+
+
+@pytest.mark.parametrize("T,K,N,relu,use_bias", [
+    (300, 256, 256, False, True),       # five 64-token tiles over five workgroups, ragged last tile (300 = 4 * 64 + 44)
+    (64, 256, 128, True, True),         # half of the waves own no live feature
+    (1, 256, 8, False, True),           # one token, one quad pair: 32-token tiles, the other rows re-read row 0
+    (97, 128, 264, False, False),       # two column blocks (the second with 8 live features) sharing the token ranges
+    (170, 64, 256, True, True),         # K = 64: a tile's pieces do not fill the workgroup's threads
+    (70, 64, 72, False, False),
+    (2100, 256, 256, True, True),       # 66 tiles of 32 tokens over 66 workgroups
+    (20000, 256, 24, True, True),       # 313 tiles of 64 over 256 workgroups: a second tile per workgroup through the other buffer
+    (70000, 128, 16, False, True),      # 1 094 tiles over 256 workgroups: four to five tiles each -- both stages refilled, both breaks
+])
+def test_token_gemm_weight_in_registers_form_on_the_cpu_shim(monkeypatch, T, K, N, relu, use_bias):
+    """MDETR_TOKEN_GEMM_DIRECT=2: the weight slice of a wave in registers, the tokens of a tile shared by the workgroup's eight
+    waves through LDS, two register stages ahead.  Same products in the same order as the LDS-weight form: identical bits."""
+    g = torch.Generator().manual_seed(T + K + N)
+    x = (torch.randn(T, K, generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16) if use_bias else None
+    monkeypatch.setenv("MDETR_TOKEN_GEMM_DIRECT", "2")
+    y = run(x, w, b, relu)
+    monkeypatch.setenv("MDETR_TOKEN_GEMM_DIRECT", "0")
+    y0 = run(x, w, b, relu)
+    ref = x.double() @ w.double().t() + (b.double() if use_bias else 0)
+    if relu:
+        ref = ref.clamp(min=0)
+    assert (y.double() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    assert torch.equal(y, y0)
+
+
+def test_token_gemm_weight_in_registers_form_with_strided_rows(monkeypatch):
+    """Row strides larger than the row (a column slice of a wider matrix in, a wider matrix out): untouched columns keep their values."""
+    monkeypatch.setenv("MDETR_TOKEN_GEMM_DIRECT", "2")
+    g = torch.Generator().manual_seed(9)
+    wide = (torch.randn(150, 320, generator=g) * 0.5).to(torch.bfloat16)
+    x = wide[:, 64:320]                                                  # [150, 256], ldx = 320
+    w = (torch.randn(40, 256, generator=g) * 0.1).to(torch.bfloat16)
+    y = run(x, w, None, False, ldy=48)
+    ref = x.double() @ w.double().t()
+    assert (y[:, :40].double() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    assert torch.all(y[:, 40:] == 7.0)
