@@ -303,16 +303,20 @@ void token_gemm_direct_kernel(const __bf16 *__restrict__ x, const __bf16 *__rest
 // LDS 68 KB, ~170 registers at two waves per SIMD.  Same products in the same order per output element as the other forms.
 constexpr int kWavesW = 8;
 
-template <int K, int TT, bool RELU>
+template <int K, int TT, bool RELU, bool YS>
 __global__ __launch_bounds__(kWavesW * 64, 2)
 void token_gemm_ws_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, const __bf16 *__restrict__ bias,
-                          __bf16 *__restrict__ y, int64_t T, int N, int64_t ldx, int64_t ldy, int gx, int ny)
+                          __bf16 *__restrict__ y, int64_t T, int N, int64_t ldx, int64_t ldy, int gx, int ny, int ablate, int wide)
 {
+    // ablate (MDETR_TOKEN_GEMM_ABLATE, developer timing runs only -- the results are then wrong): bit 0 = no output stores,
+    // bit 1 = every tile re-reads the workgroup's first tile (inputs from L2 instead of memory), bit 2 = no products
     constexpr int KP = K + 8, KS = K / 16, TB = TT / 32;
     constexpr int kChunks = TT * (K / 8), kPer = (kChunks + kWavesW * 64 - 1) / (kWavesW * 64);      // 16-byte pieces of a tile, per thread
     MDETR_DYNAMIC_LDS(unsigned char, smem_raw);
+    constexpr int YP = kWavesW * 32 + 8;                          // padded row of the output tile
     __bf16 *Xs = reinterpret_cast<__bf16 *>(smem_raw);           // [2][TT][KP]
-    float *bias_s = reinterpret_cast<float *>(Xs + 2 * TT * KP);  // [256]
+    __bf16 *Ysm = Xs + 2 * TT * KP;                              // YS: [2][TT][YP] -- the output tile, written back in whole rows
+    float *bias_s = reinterpret_cast<float *>(Ysm + (YS ? 2 * TT * YP : 0));  // [256]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
     // 1-D grid of gx * ny workgroups, gx a multiple of 8: the ny column blocks of one token range share an XCD (see the direct form)
     const int id = blockIdx.x, grp = id >> 3;
@@ -329,7 +333,7 @@ void token_gemm_ws_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict
             const int c = static_cast<int>(threadIdx.x) + kWavesW * 64 * p_;
             if (kChunks % (kWavesW * 64) == 0 || c < kChunks) {
                 const int row = c / (K / 8), piece = c - row * (K / 8);
-                const int64_t t = tile_ * TT + row, tc = t < T ? t : T - 1;
+                const int64_t t = ((ablate & 2) ? static_cast<int64_t>(bx) : tile_) * TT + row, tc = t < T ? t : T - 1;
                 st_[p_] = *reinterpret_cast<const bf16x8 *>(x + tc * ldx + piece * 8);
             }
         }
@@ -371,26 +375,48 @@ void token_gemm_ws_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict
     __syncthreads();
 
     // products and epilogue of the tile in LDS buffer `buf`
-    auto compute = [&](int64_t tile_, int buf) __attribute__((always_inline)) {
+    auto compute = [&](int64_t tile_, int buf, int ybuf) __attribute__((always_inline)) {
         f32x16 acc[TB];
 #pragma unroll
         for (int b = 0; b < TB; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
         const __bf16 *xl = Xs + (buf * TT + (lane & 31)) * KP + half * 8;      // this lane's token of block b: + b * 32 * KP; k-step: + 16 ks
+        if (!(ablate & 4)) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+            for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-            for (int b = 0; b < TB; ++b) {
-                const bf16x8 xb = *reinterpret_cast<const bf16x8 *>(xl + b * 32 * KP + ks * 16);
-                acc[b] = mfma_bf16(wa[ks], xb, acc[b]);          // Y^T[n][token]
+                for (int b = 0; b < TB; ++b) {
+                    const bf16x8 xb = *reinterpret_cast<const bf16x8 *>(xl + b * 32 * KP + ks * 16);
+                    acc[b] = mfma_bf16(wa[ks], xb, acc[b]);      // Y^T[n][token]
+                }
             }
         }
         // lane = token (lane & 31) of block b; register quad g holds features 32 wave + 8 g + 4 half + 0..3
+        if (YS) {
+            // through LDS: the tile leaves in whole 512-byte rows after the barrier (store_tile); 8-byte pieces of 32 rows per store
+            // instruction cost 11 of the form's 28 us at [81 600, 256] x [256, 256] (profiles/r04tga_tokenbench_ablate.json)
+#pragma unroll
+            for (int b = 0; b < TB; ++b) {
+                __bf16 *yl = Ysm + (ybuf * TT + b * 32 + (lane & 31)) * YP + wave * 32 + 4 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[b][4 * g + i] + bias_s[wave * 32 + 8 * g + 4 * half + i];
+                        if (RELU) v = v > 0.f ? v : 0.f;
+                        o[i] = static_cast<__bf16>(v);
+                    }
+                    *reinterpret_cast<bf16x4 *>(yl + 8 * g) = o;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int b = 0; b < TB; ++b) {
             const int64_t t = tile_ * TT + b * 32 + (lane & 31);
-            if (t < T) {
+            if (t < T && !(ablate & 1)) {
                 __bf16 *yr = y + t * ldy + n0 + wave * 32 + 4 * half;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -410,28 +436,62 @@ void token_gemm_ws_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict
         }
     };
 
-    // two tiles per trip: stage st1 holds tile i + 1 and st0 tile i + 2 on entry (whichever exist)
+    // the output tile of LDS buffer `ybuf`: piece c = thread + 512 p -> row c / 32, 16 bytes at feature 8 (c % 32)
+    auto store_tile = [&](int64_t tile_, int ybuf) __attribute__((always_inline)) {
+        if (!YS || (ablate & 1)) return;
+#pragma unroll
+        for (int p_ = 0; p_ < TT * 32 / (kWavesW * 64); ++p_) {
+            const int c = static_cast<int>(threadIdx.x) + kWavesW * 64 * p_;
+            const int row = c >> 5, piece = c & 31;
+            const int64_t t = tile_ * TT + row;
+            const int n = n0 + piece * 8;
+            if (t < T && n < N) {                                 // N is a multiple of 8: a piece is in or out as a whole
+                const __bf16 *src = Ysm + (ybuf * TT + row) * YP + piece * 8;
+                __bf16 *dst = y + t * ldy + n;
+                if (wide) {
+                    *reinterpret_cast<bf16x8 *>(dst) = *reinterpret_cast<const bf16x8 *>(src);
+                } else {                                          // rows that are only 8-byte aligned
+                    *reinterpret_cast<bf16x4 *>(dst) = *reinterpret_cast<const bf16x4 *>(src);
+                    *reinterpret_cast<bf16x4 *>(dst + 4) = *reinterpret_cast<const bf16x4 *>(src + 4);
+                }
+            }
+        }
+    };
+
+    // two tiles per trip: stage st1 holds tile i + 1 and st0 tile i + 2 on entry (whichever exist).  One barrier per tile: it
+    // publishes the next tile's inputs AND this tile's outputs; the output buffers alternate, so a wave can only overwrite one
+    // after the barrier that follows the row stores out of it.
     const int64_t step = gx;
     for (;; tile += 2 * step) {
-        compute(tile, 0);
-        if (tile + step >= tiles) break;
-        deposit(st1, 1);                                         // tile i + 1 (buffer 1 was last read before the previous barrier)
-        if (tile + 3 * step < tiles) request(st1, tile + 3 * step);
-        __syncthreads();
-        compute(tile + step, 1);
-        if (tile + 2 * step >= tiles) break;
-        deposit(st0, 0);                                         // tile i + 2
-        if (tile + 4 * step < tiles) request(st0, tile + 4 * step);
-        __syncthreads();
+        compute(tile, 0, 0);
+        const bool more = tile + step < tiles;
+        if (more) {
+            deposit(st1, 1);                                     // tile i + 1 (buffer 1 was last read before the previous barrier)
+            if (tile + 3 * step < tiles) request(st1, tile + 3 * step);
+        }
+        if (YS || more) __syncthreads();
+        store_tile(tile, 0);
+        if (!more) break;
+        compute(tile + step, 1, 1);
+        const bool more2 = tile + 2 * step < tiles;
+        if (more2) {
+            deposit(st0, 0);                                     // tile i + 2
+            if (tile + 4 * step < tiles) request(st0, tile + 4 * step);
+        }
+        if (YS || more2) __syncthreads();
+        store_tile(tile + step, 1);
+        if (!more2) break;
     }
 }
 
-template <int K, int TT, bool RELU>
+template <int K, int TT, bool RELU, bool YS>
 hipError_t launch_ws(const void *x, const void *w, const void *bias, void *y, int64_t T, int N, int64_t ldx, int64_t ldy,
                      hipStream_t st)
 {
-    constexpr size_t lds = static_cast<size_t>(2) * TT * (K + 8) * 2 + kWavesW * 32 * 4;
-    auto kern = token_gemm_ws_kernel<K, TT, RELU>;
+    constexpr size_t lds = static_cast<size_t>(2) * TT * (K + 8) * 2 + (YS ? static_cast<size_t>(2) * TT * (kWavesW * 32 + 8) * 2 : 0) +
+                           kWavesW * 32 * 4;
+    static_assert(lds <= 160 * 1024, "the tiles do not fit the LDS");
+    auto kern = token_gemm_ws_kernel<K, TT, RELU, YS>;
     static bool attr_set[64] = {};
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess) dev_ = -1;
@@ -447,9 +507,11 @@ hipError_t launch_ws(const void *x, const void *w, const void *bias, void *y, in
     const int64_t cap = 256 / ny > 0 ? 256 / ny : 1;             // one workgroup per CU (two waves per SIMD)
     if (gx > cap) gx = cap;
     gx = (gx + 7) / 8 * 8;                                       // whole rounds over the XCDs (idle workgroups leave at once)
+    const char *ab = getenv("MDETR_TOKEN_GEMM_ABLATE");
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(gx * ny)), dim3(kWavesW * 64), lds, st,
                        static_cast<const __bf16 *>(x), static_cast<const __bf16 *>(w), static_cast<const __bf16 *>(bias),
-                       static_cast<__bf16 *>(y), T, N, ldx, ldy, static_cast<int>(gx), ny);
+                       static_cast<__bf16 *>(y), T, N, ldx, ldy, static_cast<int>(gx), ny, ab ? atoi(ab) : 0,
+                       ((reinterpret_cast<uintptr_t>(y) & 15) == 0 && ldy % 8 == 0) ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -459,8 +521,13 @@ hipError_t launch_ws_any(const void *x, const void *w, const void *bias, void *y
                          hipStream_t st)
 {
     const int ny = (N + kWavesW * 32 - 1) / (kWavesW * 32);
-    if ((T + 63) / 64 * ny >= 256) return launch_ws<K, 64, RELU>(x, w, bias, y, T, N, ldx, ldy, st);
-    return launch_ws<K, 32, RELU>(x, w, bias, y, T, N, ldx, ldy, st);
+    const char *ys = getenv("MDETR_TOKEN_GEMM_YSTAGE");          // 0: 8-byte pieces straight from the accumulators (A/B runs)
+    if (ys && atoi(ys) == 0) {
+        if ((T + 63) / 64 * ny >= 256) return launch_ws<K, 64, RELU, false>(x, w, bias, y, T, N, ldx, ldy, st);
+        return launch_ws<K, 32, RELU, false>(x, w, bias, y, T, N, ldx, ldy, st);
+    }
+    if ((T + 63) / 64 * ny >= 256) return launch_ws<K, 64, RELU, true>(x, w, bias, y, T, N, ldx, ldy, st);
+    return launch_ws<K, 32, RELU, true>(x, w, bias, y, T, N, ldx, ldy, st);
 }
 
 template <int K, int NB, bool RELU>

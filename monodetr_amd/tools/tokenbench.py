@@ -49,6 +49,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--out", default="")
+    ap.add_argument("--ablate", action="store_true", help="time the weight-in-registers form with MDETR_TOKEN_GEMM_ABLATE = 1..7 "
+                    "(bit 0 no stores, bit 1 inputs from L2, bit 2 no products)")
     ap.add_argument("--only", default="", help="comma-separated substrings: only the shapes whose name contains one of them")
     a = ap.parse_args()
     from monodetr_amd import token_gemm_ext
@@ -74,6 +76,12 @@ def main():
             outs[tag] = f()
             row[tag + "_ms"] = round(timeit(f, a.iters), 4)
             row[tag + "_frac"] = round(byts / (row[tag + "_ms"] * 1e-3) / HBM, 4)
+        if a.ablate and "regs_ms" in row:                          # developer timing of the weight-in-registers form with parts removed
+            os.environ["MDETR_TOKEN_GEMM_DIRECT"] = "2"
+            for bits in (1, 2, 3, 4, 5, 6, 7):
+                os.environ["MDETR_TOKEN_GEMM_ABLATE"] = str(bits)
+                row["regs_ablate%d_ms" % bits] = round(timeit(lambda: token_gemm_ext.token_gemm(x, w, b, relu=relu), a.iters), 4)
+            os.environ.pop("MDETR_TOKEN_GEMM_ABLATE", None)
         if len(outs) >= 2:
             row["forms_bit_equal"] = all(bool(torch.equal(outs["staged"], o)) for o in outs.values())
         if outs:

@@ -240,6 +240,30 @@ def test_token_gemm_matches_the_library_gemm(T, K, N, relu, bias):
     assert ((y.float() - ref).norm() / ref.norm()).item() < 4e-3
 
 
+@pytest.mark.parametrize("T,K,N,relu", [(81600, 256, 256, False), (81600, 256, 384, True), (4400, 256, 256, True), (33, 256, 8, False),
+                                        (245760, 64, 256, False), (61440, 128, 512, True), (1000, 256, 264, False)])
+def test_token_gemm_forms_agree_bit_for_bit(T, K, N, relu, monkeypatch):
+    """MDETR_TOKEN_GEMM_DIRECT = 0 (inputs staged through LDS), 1 (operands straight from global memory), 2 (weight slices in
+    registers, the tokens of a tile shared through LDS, the output tile written in whole rows; also with MDETR_TOKEN_GEMM_YSTAGE=0):
+    the same products in the same order -- identical bits; strided input rows, ragged tile tails, a partial last column block."""
+    from monodetr_amd.token_gemm_ext import token_gemm
+    torch.manual_seed(T + N)
+    x = torch.randn(T, K + 64, device="cuda").to(torch.bfloat16)[:, :K]
+    w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda").to(torch.bfloat16)
+    outs = {}
+    for form, ystage in (("0", "1"), ("1", "1"), ("2", "1"), ("2", "0")):
+        monkeypatch.setenv("MDETR_TOKEN_GEMM_DIRECT", form)
+        monkeypatch.setenv("MDETR_TOKEN_GEMM_YSTAGE", ystage)
+        outs[form + ystage] = token_gemm(x, w, b, relu)
+    ref = torch.nn.functional.linear(x.float(), w.float(), b.float())
+    if relu:
+        ref = ref.relu()
+    assert (outs["01"].float() - ref).abs().max() <= 1e-2 * max(1.0, ref.abs().max().item())
+    for k, v in outs.items():
+        assert torch.equal(v, outs["01"]), k
+
+
 def test_token_linear_layer_with_the_token_gemm_matches_default():
     """token_linear forward + input gradient through the kernel (MDETR_TOKEN_GEMM) against the library path."""
     import importlib

@@ -157,9 +157,12 @@ def test_token_linear_autograd_function_with_the_emulated_kernel(relu, monkeypat
     (20000, 256, 24, True, True),       # 313 tiles of 64 over 256 workgroups: a second tile per workgroup through the other buffer
     (70000, 128, 16, False, True),      # 1 094 tiles over 256 workgroups: four to five tiles each -- both stages refilled, both breaks
 ])
-def test_token_gemm_weight_in_registers_form_on_the_cpu_shim(monkeypatch, T, K, N, relu, use_bias):
+@pytest.mark.parametrize("ystage", ["1", "0"])
+def test_token_gemm_weight_in_registers_form_on_the_cpu_shim(monkeypatch, T, K, N, relu, use_bias, ystage):
     """MDETR_TOKEN_GEMM_DIRECT=2: the weight slice of a wave in registers, the tokens of a tile shared by the workgroup's eight
-    waves through LDS, two register stages ahead.  Same products in the same order as the LDS-weight form: identical bits."""
+    waves through LDS, two register stages ahead; the output tile leaves through LDS in whole rows (ystage 1, the default) or in
+    8-byte pieces straight from the accumulators (0).  Same products in the same order as the LDS-weight form: identical bits."""
+    monkeypatch.setenv("MDETR_TOKEN_GEMM_YSTAGE", ystage)
     g = torch.Generator().manual_seed(T + K + N)
     x = (torch.randn(T, K, generator=g) * 0.5).to(torch.bfloat16)
     w = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16)
@@ -182,7 +185,8 @@ def test_token_gemm_weight_in_registers_form_with_strided_rows(monkeypatch):
     wide = (torch.randn(150, 320, generator=g) * 0.5).to(torch.bfloat16)
     x = wide[:, 64:320]                                                  # [150, 256], ldx = 320
     w = (torch.randn(40, 256, generator=g) * 0.1).to(torch.bfloat16)
-    y = run(x, w, None, False, ldy=48)
     ref = x.double() @ w.double().t()
-    assert (y[:, :40].double() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
-    assert torch.all(y[:, 40:] == 7.0)
+    for ldy in (48, 44):                                                 # 44: rows only 8-byte aligned -> the two-piece row stores
+        y = run(x, w, None, False, ldy=ldy)
+        assert (y[:, :40].double() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+        assert torch.all(y[:, 40:] == 7.0)
