@@ -504,7 +504,11 @@ hipError_t launch_ws(const void *x, const void *w, const void *bias, void *y, in
     const int64_t tiles = (T + TT - 1) / TT;
     const int ny = (N + kWavesW * 32 - 1) / (kWavesW * 32);
     int64_t gx = tiles;
-    const int64_t cap = 256 / ny > 0 ? 256 / ny : 1;             // one workgroup per CU (two waves per SIMD)
+    // one workgroup per CU (two waves per SIMD); MDETR_TOKEN_GEMM_WS_PER_CU=2 (A/B runs): two, where the 32-token form's 69 KB of
+    // LDS and <= 128 registers allow it -- the products and stores of one workgroup beside the loads of the other
+    int per_cu = 1;
+    if (const char *pc = getenv("MDETR_TOKEN_GEMM_WS_PER_CU")) per_cu = (atoi(pc) == 2 && lds <= 80 * 1024) ? 2 : 1;
+    const int64_t cap = (256 * per_cu) / ny > 0 ? (256 * per_cu) / ny : 1;
     if (gx > cap) gx = cap;
     gx = (gx + 7) / 8 * 8;                                       // whole rounds over the XCDs (idle workgroups leave at once)
     const char *ab = getenv("MDETR_TOKEN_GEMM_ABLATE");
@@ -522,11 +526,13 @@ hipError_t launch_ws_any(const void *x, const void *w, const void *bias, void *y
 {
     const int ny = (N + kWavesW * 32 - 1) / (kWavesW * 32);
     const char *ys = getenv("MDETR_TOKEN_GEMM_YSTAGE");          // 0: 8-byte pieces straight from the accumulators (A/B runs)
+    const char *tt = getenv("MDETR_TOKEN_GEMM_WS_TT");           // 32 | 64: force the token tile (A/B runs)
+    const bool big = tt ? atoi(tt) == 64 : (T + 63) / 64 * ny >= 256;
     if (ys && atoi(ys) == 0) {
-        if ((T + 63) / 64 * ny >= 256) return launch_ws<K, 64, RELU, false>(x, w, bias, y, T, N, ldx, ldy, st);
+        if (big) return launch_ws<K, 64, RELU, false>(x, w, bias, y, T, N, ldx, ldy, st);
         return launch_ws<K, 32, RELU, false>(x, w, bias, y, T, N, ldx, ldy, st);
     }
-    if ((T + 63) / 64 * ny >= 256) return launch_ws<K, 64, RELU, true>(x, w, bias, y, T, N, ldx, ldy, st);
+    if (big) return launch_ws<K, 64, RELU, true>(x, w, bias, y, T, N, ldx, ldy, st);
     return launch_ws<K, 32, RELU, true>(x, w, bias, y, T, N, ldx, ldy, st);
 }
 

@@ -190,3 +190,19 @@ def test_token_gemm_weight_in_registers_form_with_strided_rows(monkeypatch):
         y = run(x, w, None, False, ldy=ldy)
         assert (y[:, :40].double() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
         assert torch.all(y[:, 40:] == 7.0)
+
+
+@pytest.mark.parametrize("tt,per_cu", [("32", "2"), ("64", "1"), ("32", "1")])
+def test_token_gemm_weight_in_registers_form_launch_knobs(monkeypatch, tt, per_cu):
+    """MDETR_TOKEN_GEMM_WS_TT / _PER_CU (A/B runs): the forced token tile and the two-workgroups-per-CU launch cap change the
+    schedule -- 40 000 rows = 1 250 tiles of 32 over 512 workgroups, or 625 of 64 over 256 -- not a bit of the result."""
+    g = torch.Generator().manual_seed(77)
+    x = (torch.randn(40000, 128, generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(24, 128, generator=g) * 0.1).to(torch.bfloat16)
+    b = torch.randn(24, generator=g).to(torch.bfloat16)
+    monkeypatch.setenv("MDETR_TOKEN_GEMM_DIRECT", "0")
+    y0 = run(x, w, b, True)
+    monkeypatch.setenv("MDETR_TOKEN_GEMM_DIRECT", "2")
+    monkeypatch.setenv("MDETR_TOKEN_GEMM_WS_TT", tt)
+    monkeypatch.setenv("MDETR_TOKEN_GEMM_WS_PER_CU", per_cu)
+    assert torch.equal(run(x, w, b, True), y0)
