@@ -609,6 +609,8 @@ hipError_t token_gemm_launch(const void *x, const void *w, const void *bias, voi
 {
     const char *dv_ = getenv("MDETR_TOKEN_GEMM_DIRECT");
     const bool direct = dv_ && atoi(dv_) != 0;
+    if (dv_ && atoi(dv_) == 2 && K == 512)                      // 32 KB of weight per wave: 32-token tiles only (100 KB of LDS)
+        return relu ? launch_ws<512, 32, true, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch_ws<512, 32, false, true>(x, w, bias, y, T, N, ldx, ldy, st);
     if (dv_ && atoi(dv_) == 2 && (K == 256 || K == 128 || K == 64)) {                 // the weight-in-registers form
         if (K == 256) return relu ? launch_ws_any<256, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch_ws_any<256, false>(x, w, bias, y, T, N, ldx, ldy, st);
         if (K == 128) return relu ? launch_ws_any<128, true>(x, w, bias, y, T, N, ldx, ldy, st) : launch_ws_any<128, false>(x, w, bias, y, T, N, ldx, ldy, st);

@@ -241,7 +241,7 @@ def test_token_gemm_matches_the_library_gemm(T, K, N, relu, bias):
 
 
 @pytest.mark.parametrize("T,K,N,relu", [(81600, 256, 256, False), (81600, 256, 384, True), (4400, 256, 256, True), (33, 256, 8, False),
-                                        (245760, 64, 256, False), (61440, 128, 512, True), (1000, 256, 264, False)])
+                                        (245760, 64, 256, False), (61440, 128, 512, True), (1000, 256, 264, False), (61440, 512, 128, True)])
 def test_token_gemm_forms_agree_bit_for_bit(T, K, N, relu, monkeypatch):
     """MDETR_TOKEN_GEMM_DIRECT = 0 (inputs staged through LDS), 1 (operands straight from global memory), 2 (weight slices in
     registers, the tokens of a tile shared through LDS, the output tile written in whole rows; also with MDETR_TOKEN_GEMM_YSTAGE=0):

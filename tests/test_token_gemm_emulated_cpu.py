@@ -156,6 +156,8 @@ def test_token_linear_autograd_function_with_the_emulated_kernel(relu, monkeypat
     (2100, 256, 256, True, True),       # 66 tiles of 32 tokens over 66 workgroups
     (20000, 256, 24, True, True),       # 313 tiles of 64 over 256 workgroups: a second tile per workgroup through the other buffer
     (70000, 128, 16, False, True),      # 1 094 tiles over 256 workgroups: four to five tiles each -- both stages refilled, both breaks
+    (33, 512, 136, True, True),         # K = 512: 32 KB of weight per wave, 32-token tiles only
+    (9000, 512, 16, False, True),       # ... 282 tiles over 256 workgroups
 ])
 @pytest.mark.parametrize("ystage", ["1", "0"])
 def test_token_gemm_weight_in_registers_form_on_the_cpu_shim(monkeypatch, T, K, N, relu, use_bias, ystage):
