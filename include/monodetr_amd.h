@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDETR_ABI_VERSION 6
+#define MDETR_ABI_VERSION 7
 
 /* element types of the floating-point tensors */
 #define MDETR_F32 0
@@ -333,6 +333,31 @@ int mdetr_adamw_step_counted(int param_dtype, void *param, float *master, const 
  */
 int mdetr_token_linear(const void *x, const void *weight, const void *bias, void *y, int64_t T, int N, int K,
                        int64_t ldx, int64_t ldy, int relu, int device, void *stream);
+
+/*
+ * y[T, N] = dropout(relu(a[T, K] op(w) + bias + res)) in bf16 on the matrix cores, every part of the tail optional: the general
+ * token-wise product of the training iteration with its elementwise tail inside (csrc/tgemm.hip).  Replaces, per call site, the
+ * library GEMM + separate passes of the reference: torchvision Bottleneck.conv1 / conv3 (+ identity + ReLU) / downsample behind
+ * lib/models/monodetr/backbone.py:93-106, the input projections monodetr.py:77-99, nn.Linear in ops/modules/ms_deform_attn.py:94-102
+ * and depthaware_transformer.py:328-353 (linear1 + ReLU + Dropout), and their input gradients.
+ *   a      bf16 [T, K], row stride lda (elements; % 8 == 0), 16-byte aligned
+ *   w      bf16, 16-byte aligned: [N, K] with row stride ldw (y = a w^T: the forward of a linear layer / 1x1 convolution), or with
+ *          MDETR_TGEMM_NN [K, N] with row stride ldw (y = a w: the input gradient dX = dY W with the parameter as it lies in memory)
+ *   bias   [N] bf16 (fp32 with MDETR_TGEMM_BIAS_F32) or NULL
+ *   res    bf16 [T, N] with row stride ldr, added in fp32 before the ReLU, or NULL.  res == y is allowed: y += a op(w) (the gradient
+ *          arriving over a residual connection summed inside the input-gradient product)
+ *   y      bf16 [T, N] (fp32 with MDETR_TGEMM_OUT_F32), row stride ldy (% 8 == 0; % 4 for fp32), 16-byte aligned
+ *   dropout_p > 0: inverted dropout behind the ReLU, kept iff ln_hash(seed [+ *seed_dev], t * N + n) >= p * 2^32 (csrc/add_ln_math.h: the
+ *          decision mdetr_bias_act_forward makes for the same element, so mdetr_bias_act_backward serves as its backward)
+ * K % 8 == 0, N % 8 == 0; fp32 accumulation, ONE rounding at the store.
+ */
+#define MDETR_TGEMM_RELU 1
+#define MDETR_TGEMM_NN 2
+#define MDETR_TGEMM_BIAS_F32 4
+#define MDETR_TGEMM_OUT_F32 8
+int mdetr_tgemm(const void *a, const void *w, const void *bias, const void *res, void *y, int64_t T, int N, int K,
+                int64_t lda, int64_t ldw, int64_t ldr, int64_t ldy, int flags, float dropout_p, uint64_t seed,
+                const void *seed_dev, int device, void *stream);
 
 /*
  * Training image path of the input pipeline on the device: what

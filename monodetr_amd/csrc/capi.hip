@@ -29,6 +29,7 @@
 #include "pair_losses.h"
 #include "rotate_iou.h"
 #include "token_gemm.h"
+#include "tgemm.h"
 #include "msda.h"
 #include "msda_prologue.h"
 #include "msda_prologue_math.h"
@@ -476,6 +477,27 @@ int mdetr_token_linear(const void *x, const void *weight, const void *bias, void
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_token_linear: set device %d: %s", device, hipGetErrorString(dev.err));
     const hipError_t e = mdetr::token_gemm_launch(x, weight, bias, y, T, N, K, ldx, ldy, relu != 0, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_token_linear: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_tgemm(const void *a, const void *w, const void *bias, const void *res, void *y, int64_t T, int N, int K,
+                int64_t lda, int64_t ldw, int64_t ldr, int64_t ldy, int flags, float dropout_p, uint64_t seed,
+                const void *seed_dev, int device, void *stream)
+{
+    if (T < 0 || N <= 0 || K <= 0) return fail(MDETR_E_ARG, "mdetr_tgemm: bad shape T=%lld N=%d K=%d", static_cast<long long>(T), N, K);
+    if (T == 0) return MDETR_OK;
+    if (!a || !w || !y) return fail(MDETR_E_ARG, "mdetr_tgemm: null pointer");
+    if (flags & ~(MDETR_TGEMM_RELU | MDETR_TGEMM_NN | MDETR_TGEMM_BIAS_F32 | MDETR_TGEMM_OUT_F32)) return fail(MDETR_E_ARG, "mdetr_tgemm: unknown flag bits 0x%x", flags);
+    if (dropout_p > 0.f && !(flags & MDETR_TGEMM_RELU)) return fail(MDETR_E_ARG, "mdetr_tgemm: dropout is only fused behind the ReLU");
+    mdetr::TgemmProblem p{a, w, bias, res, y, T, N, K, lda, ldw, res ? ldr : 0, ldy, flags, dropout_p, seed, static_cast<const uint64_t *>(seed_dev)};
+    if (!mdetr::tgemm_supported(p))
+        return fail(MDETR_E_ARG, "mdetr_tgemm: needs bf16 operands, K %% 8 == 0, N %% 8 == 0, row strides %% 8 == 0 and >= the row length, 16-byte aligned "
+                    "pointers, 0 <= dropout_p < 1 (T=%lld N=%d K=%d lda=%lld ldw=%lld ldr=%lld ldy=%lld flags=0x%x)", static_cast<long long>(T), N, K,
+                    static_cast<long long>(lda), static_cast<long long>(ldw), static_cast<long long>(ldr), static_cast<long long>(ldy), flags);
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_tgemm: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::tgemm_launch(p, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_tgemm: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

@@ -1,0 +1,95 @@
+"""csrc/tgemm.hip on the GPU: every token-wise product shape of the training iteration (forward NT and input-gradient NN forms, the
+tails each call site fuses) held ELEMENT BY ELEMENT to the fp64 product of the same bf16 operands (tests/gemm_bounds.py: output
+rounding + fp32 accumulation; no absolute-of-max bound), each tile shape and pipeline depth on one awkward shape, determinism, and
+the C ABI's argument checks."""
+import pytest
+import torch
+
+from gemm_bounds import assert_product_close
+
+pytestmark = pytest.mark.gpu
+
+T1, T2, T3, T4, TE, TD = 245760, 61440, 15360, 3840, 81600, 4400
+STEP_SHAPES = [
+    # T, K, N, nn, tail
+    (TE, 256, 256, False, "bias"), (TE, 256, 256, False, "relu_bias"), (TE, 256, 384, False, "bias"),
+    (TE, 256, 256, True, "accum"), (TE, 384, 256, True, ""),
+    (T1, 256, 64, False, "relu_bias"), (T1, 64, 256, False, "res_relu"),
+    (T2, 512, 128, False, "relu_bias"), (T2, 128, 512, False, "res_relu"), (T2, 128, 512, True, "accum"), (T2, 512, 128, True, ""),
+    (T3, 1024, 256, False, "relu_bias"), (T3, 256, 1024, False, "res_relu"), (T3, 256, 1024, True, "accum"), (T3, 1024, 256, True, ""),
+    (T4, 2048, 512, False, "relu_bias"), (T4, 512, 2048, False, "res_relu"), (T4, 512, 2048, True, "accum"), (T4, 2048, 512, True, ""),
+    (T4, 2048, 256, False, "bias"),
+    (TD, 256, 1032, False, "bias"), (TD, 1032, 256, True, ""), (TD, 256, 256, False, "relu_bias"),
+]
+
+
+def _operands(T, K, N, nn, seed, dev):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    a = (torch.randn(T, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
+    w = ((torch.randn(K, N, generator=g) if nn else torch.randn(N, K, generator=g)) * 0.1).to(torch.bfloat16).to(dev)
+    b = torch.randn(N, generator=g).to(torch.bfloat16).to(dev)
+    r = torch.randn(T, N, generator=g).to(torch.bfloat16).to(dev)
+    return a, w, b, r
+
+
+def _reference(a, w, nn, bias, res, relu):
+    wd = w.double() if nn else w.double().t()
+    ref = a.double() @ wd
+    mag = a.double().abs() @ wd.abs()
+    if bias is not None:
+        ref += bias.double()
+        mag += bias.double().abs()
+    if res is not None:
+        ref += res.double()
+        mag += res.double().abs()
+    return (ref.clamp_(min=0) if relu else ref), mag
+
+
+@pytest.mark.parametrize("T,K,N,nn,tail", STEP_SHAPES)
+def test_tgemm_step_shapes_element_wise_against_fp64(T, K, N, nn, tail):
+    from monodetr_amd import tgemm_ext
+    dev = torch.device("cuda", 0)
+    a, w, b, r = _operands(T, K, N, nn, T + 3 * K + N, dev)
+    bias = b if "bias" in tail else None
+    res = r.clone() if tail in ("res_relu", "accum") else None
+    relu = "relu" in tail
+    assert tgemm_ext.supported(a, w, nn=nn, res=res, bias=bias)
+    out = res if tail == "accum" else None
+    keep = res.clone() if res is not None else None
+    y = tgemm_ext.tgemm(a, w, bias, res, relu=relu, nn=nn, out=out)
+    torch.cuda.synchronize()
+    ref, mag = _reference(a, w, nn, bias, keep, relu)
+    assert_product_close(y, ref, mag, K, "T=%d K=%d N=%d nn=%s %s" % (T, K, N, nn, tail))
+    y2 = tgemm_ext.tgemm(a, w, bias, keep, relu=relu, nn=nn)        # (out of place, also where y was accumulated into its residual)
+    assert torch.equal(y, y2)                                        # deterministic
+
+
+@pytest.mark.parametrize("tile", ["128x128", "128x64", "64x128", "64x64"])
+@pytest.mark.parametrize("pf", ["1", "2"])
+@pytest.mark.parametrize("nn", [False, True])
+def test_tgemm_every_tile_shape_and_pipeline_depth(monkeypatch, tile, pf, nn):
+    from monodetr_amd import tgemm_ext
+    monkeypatch.setenv("MDETR_TGEMM_TILE", tile)
+    monkeypatch.setenv("MDETR_TGEMM_PF", pf)
+    dev = torch.device("cuda", 0)
+    for T, K, N in ((4133, 456, 264), (300, 64, 72), (9000, 1032, 136)):
+        a, w, b, r = _operands(T, K, N, nn, T + K, dev)
+        y = tgemm_ext.tgemm(a, w, b.float(), r, relu=True, nn=nn)
+        ref, mag = _reference(a, w, nn, b, r, True)
+        assert_product_close(y, ref, mag, K, "%s pf%s nn=%s T=%d" % (tile, pf, nn, T))
+        y32 = tgemm_ext.tgemm(a, w, None, None, nn=nn, out_dtype=torch.float32)
+        ref, mag = _reference(a, w, nn, None, None, False)
+        assert_product_close(y32, ref, mag, K, "fp32 out")
+
+
+def test_tgemm_dropout_tail_is_the_bias_act_decision():
+    from monodetr_amd import bias_act_ext, tgemm_ext
+    dev = torch.device("cuda", 0)
+    T, K, N = 81600, 256, 256
+    a, w, b, _ = _operands(T, K, N, False, 9, dev)
+    y = tgemm_ext.tgemm(a, w, b, None, relu=True, dropout_p=0.1, seed=77)
+    pre = tgemm_ext.tgemm(a, w, b, None, out_dtype=torch.float32)
+    want = bias_act_ext.bias_act(pre, None, None, relu=True, dropout_p=0.1, seed=77).to(torch.bfloat16)
+    assert torch.equal(y, want)
+    frac = (y == 0).float().mean().item()
+    assert 0.5 < frac < 0.6                                          # half negative + a tenth of the rest dropped
