@@ -61,4 +61,14 @@ __device__ __forceinline__ unsigned short rsrc_load_u16(mdetr_rsrc r, unsigned l
     return __builtin_amdgcn_raw_buffer_load_b16(r, lane_offset, scalar_offset, 0);
 }
 
+// ... and stores: a lane whose offset lies beyond the resource's size stores nothing (ragged tiles without a branch)
+__device__ __forceinline__ void rsrc_store_bf16x8(mdetr_rsrc r, bf16x8 v, unsigned lane_offset, unsigned scalar_offset)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_offset, scalar_offset, 0);
+}
+__device__ __forceinline__ void rsrc_store_f32x4(mdetr_rsrc r, f32x4 v, unsigned lane_offset, unsigned scalar_offset)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, lane_offset, scalar_offset, 0);
+}
+
 #define MDETR_DYNAMIC_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]

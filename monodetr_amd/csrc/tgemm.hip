@@ -61,84 +61,116 @@ constexpr size_t tgemm_lds()
     return slabs > tile ? slabs : tile;
 }
 
-// PF = slabs of global loads in flight beyond the one being written to LDS (register sets)
-template <int BM, int BN, bool NN, int PF>
+// 4 k-rows x 8 columns of bf16 (in[i] = 8 consecutive n of k-row i) -> out[q] = the 4 k values of column q (8 bytes)
+__device__ __forceinline__ void transpose4x8(const bf16x8 (&in)[4], unsigned (&out)[8][2])
+{
+    unsigned d[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_memcpy(d[i], &in[i], 16);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const unsigned lo = d[2 * m][q >> 1], hi = d[2 * m + 1][q >> 1];
+            out[q][m] = (q & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+        }
+}
+
+// PF = slabs of global loads in flight beyond the one being written to LDS (register sets).
+// PERSISTENT workgroups: workgroup w walks the output tiles w, w + G, w + 2 G, ... (G = gridDim.x, a multiple of 8: a tile keeps
+// its XCD) as ONE sequence of contraction slabs -- the loads of the next tile's first slabs are in flight while this tile's last
+// products issue and its output leaves, so only a workgroup's very first slab pays an exposed memory latency.
+// TAIL: 0 = bias (bf16) + ReLU, bf16 output;  1 = the same + a residual tile;  2 = everything (fp32 bias / output, dropout, residual)
+template <int BM, int BN, bool NN, int PF, int TAIL>
 __global__ __launch_bounds__(kThreadsT, 2)
 void tgemm_kernel(const TgemmArgs g)
 {
     constexpr int TM = BM / 64, TN = BN / 64;                    // 32 x 32 blocks of a wave along tokens / features
     constexpr int XCH = BM * 8 / kThreadsT;                      // 16-byte pieces of an input slab per thread
-    constexpr int WCH = NN ? 8 : BN * 8 / kThreadsT;             // weight slab: pieces per thread (NT) / the 8 rows of one 8 x 8 block (NN)
+    constexpr int WCH = NN ? 4 : BN * 8 / kThreadsT;             // weight slab: pieces per thread (NT) / the 4 k-rows of one 4 x 8 block (NN)
+    constexpr int WTHR = NN ? 2 * BN : kThreadsT;                // threads that stage the weight slab (NN: 16 k-groups x BN / 8 column blocks)
     MDETR_DYNAMIC_LDS(unsigned char, tg_smem);
     __bf16 *Xs = reinterpret_cast<__bf16 *>(tg_smem);            // [2][BM][kLd]
     __bf16 *Ws = Xs + 2 * BM * kLd;                              // [2][BN][kLd]
-    float *Cs = reinterpret_cast<float *>(tg_smem);              // [BM][BN + kCPad], after the last slab
+    float *Cs = reinterpret_cast<float *>(tg_smem);              // [BM][BN + kCPad], after a tile's last slab
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int wm = wave & 1, wn = wave >> 1;
-    const int id = blockIdx.x, grp = id >> 3;
-    const int col = grp % g.ny, bx = (grp / g.ny) * 8 + (id & 7);
-    const int64_t m0 = static_cast<int64_t>(bx) * BM;
-    if (m0 >= g.T) return;                                       // (gx was rounded up to a multiple of 8)
-    const int n0 = col * BN;
     const int KT = (g.K + kBK - 1) / kBK;
+    const int G = gridDim.x, vtiles = g.gx * g.ny;               // virtual tile ids (gx: row tiles rounded up to a multiple of 8)
+    const int64_t tiles_m = (g.T + BM - 1) / BM;
+    // virtual id v -> (column tile, row tile): the ny column tiles of one token range are ids 8 apart (same XCD, adjacent slots)
+    auto tile_of = [&](int v, int &col, int64_t &m0) __attribute__((always_inline)) {
+        const int grp = v >> 3;
+        col = grp % g.ny;
+        m0 = (static_cast<int64_t>(grp / g.ny) * 8 + (v & 7)) * BM;
+    };
+    auto next_tile = [&](int v) __attribute__((always_inline)) {  // the next virtual id >= v with a live row tile (or >= vtiles)
+        for (; v < vtiles; v += G) {
+            if (static_cast<int64_t>((v >> 3) / g.ny) * 8 + (v & 7) < tiles_m) break;
+        }
+        return v;
+    };
 
-    bf16x8 zero8;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) zero8[i] = static_cast<__bf16>(0.f);
-
-    // ---- staging maps.  Input slab: piece c = tid + 256 j -> row c / 8, 16 bytes at k = 8 (c % 8): 8 lanes cover one 128-byte
-    // row segment.  Rows beyond T re-read row T - 1 (their outputs are never stored); pieces beyond K are zero.
-    const __bf16 *xsrc[XCH];
-    int xdst[XCH];
+    // Loads go through buffer resources: a lane whose offset lies beyond the tensor (rows past T or N, pieces past K) receives
+    // zeros -- no branch, no select on the data.  Per-lane offset = (row, piece) of the tile, scalar offset = the slab.
+    const unsigned a_bytes = static_cast<unsigned>(((g.T - 1) * g.lda + g.K) * 2);
+    const unsigned w_bytes = static_cast<unsigned>(NN ? ((static_cast<int64_t>(g.K) - 1) * g.ldw + g.N) * 2 : ((static_cast<int64_t>(g.N) - 1) * g.ldw + g.K) * 2);
+    const mdetr_rsrc ar = make_rsrc(g.a, a_bytes), wr_ = make_rsrc(g.w, w_bytes);
+    const int xk = (tid & 7) * 8;                                // NT maps: this thread's k offset inside a slab (the same for all its pieces)
+    const int wkg = tid & 15, wnb = tid >> 4;                    // NN map: k-group (4 rows) and column block (8 columns) of this thread
+    unsigned xoff[XCH], woff[NN ? 1 : WCH];                      // per-lane byte offsets of the FETCH cursor's tile
+    int xdst[XCH], wdst[NN ? 1 : WCH];
 #pragma unroll
     for (int j = 0; j < XCH; ++j) {
-        const int c = tid + kThreadsT * j, row = c >> 3, piece = c & 7;
-        const int64_t t = m0 + row, tc = t < g.T ? t : g.T - 1;
-        xsrc[j] = g.a + tc * g.lda + piece * 8;
-        xdst[j] = row * kLd + piece * 8;
+        const int c = tid + kThreadsT * j;
+        xdst[j] = (c >> 3) * kLd + (c & 7) * 8;
     }
-    const int xk = (tid & 7) * 8;                                // this thread's k offset inside a slab (the same for all its pieces)
-    // Weight slab, NT (w = W[N][K]): the same map over BN rows; rows beyond N re-read row N - 1 (columns never stored).
-    // NN (w = W[K][N]): thread b < BN owns the 8 x 8 block (k-block b & 7, n-block b >> 3): 8 loads of 16 bytes (8 k-rows, 8
-    // consecutive n), transposed in registers into 8 LDS rows (n) of 8 k -- the 8 lanes of a ds_write_b128 group hold the 8
-    // k-blocks of one n-row: 128 contiguous bytes, conflict-free.
-    const __bf16 *wsrc[NN ? 1 : WCH];
-    int wdst[NN ? 1 : WCH];
-    bool wlive = true;
-    int wkb = 0;
     if (NN) {
-        const int kb = tid & 7, nb = tid >> 3;
-        wlive = tid < BN && n0 + nb * 8 < g.N;                   // (N % 8 == 0: a block's 8 columns are in or out together)
-        wkb = kb * 8;
-        wsrc[0] = g.w + static_cast<int64_t>(kb * 8) * g.ldw + (wlive ? n0 + nb * 8 : 0);
-        wdst[0] = nb * 8 * kLd + kb * 8;
+        wdst[0] = wnb * 8 * kLd + wkg * 4;
     } else {
 #pragma unroll
         for (int j = 0; j < (NN ? 1 : WCH); ++j) {
-            const int c = tid + kThreadsT * j, row = c >> 3, piece = c & 7;
-            const int n = n0 + row < g.N ? n0 + row : g.N - 1;
-            wsrc[j] = g.w + static_cast<int64_t>(n) * g.ldw + piece * 8;
-            wdst[j] = row * kLd + piece * 8;
+            const int c = tid + kThreadsT * j;
+            wdst[j] = (c >> 3) * kLd + (c & 7) * 8;
         }
     }
+    auto aim = [&](int v) __attribute__((always_inline)) {       // the fetch cursor moves to tile v
+        int col; int64_t m0;
+        tile_of(v, col, m0);
+        const int n0 = col * BN;
+#pragma unroll
+        for (int j = 0; j < XCH; ++j) {
+            const int c = tid + kThreadsT * j;
+            const int64_t t = m0 + (c >> 3);
+            xoff[j] = t < g.T ? static_cast<unsigned>((t * g.lda + (c & 7) * 8) * 2) : kRsrcOob;
+        }
+        if (NN) {
+            woff[0] = (tid < WTHR && n0 + wnb * 8 < g.N) ? static_cast<unsigned>((static_cast<int64_t>(wkg * 4) * g.ldw + n0 + wnb * 8) * 2) : kRsrcOob;
+        } else {
+#pragma unroll
+            for (int j = 0; j < (NN ? 1 : WCH); ++j) {
+                const int c = tid + kThreadsT * j, row = n0 + (c >> 3);
+                woff[j] = row < g.N ? static_cast<unsigned>((static_cast<int64_t>(row) * g.ldw + (c & 7) * 8) * 2) : kRsrcOob;
+            }
+        }
+    };
 
     bf16x8 xr[PF][XCH], wr[PF][WCH];
     auto fetch = [&](int kt, bf16x8 (&xs_)[XCH], bf16x8 (&ws_)[WCH]) __attribute__((always_inline)) {
         const int k0 = kt * kBK;
-        const bool xin = k0 + xk < g.K;
+        const bool xin = k0 + xk < g.K;                          // (only a ragged last slab has dead pieces)
 #pragma unroll
-        for (int j = 0; j < XCH; ++j) xs_[j] = xin ? *reinterpret_cast<const bf16x8 *>(xsrc[j] + k0) : zero8;
+        for (int j = 0; j < XCH; ++j) xs_[j] = rsrc_load_bf16x8(ar, xin ? xoff[j] : kRsrcOob, static_cast<unsigned>(k0 * 2));
         if (NN) {
-            if (tid < BN) {
+            if (tid < WTHR) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const bool in = wlive && k0 + wkb + i < g.K;
-                    ws_[i] = in ? *reinterpret_cast<const bf16x8 *>(wsrc[0] + static_cast<int64_t>(k0 + i) * g.ldw) : zero8;
-                }
+                for (int i = 0; i < 4; ++i)
+                    ws_[i] = rsrc_load_bf16x8(wr_, k0 + wkg * 4 + i < g.K ? woff[0] : kRsrcOob,
+                                              static_cast<unsigned>((static_cast<int64_t>(k0 + i) * g.ldw) * 2));
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < WCH; ++j) ws_[j] = xin ? *reinterpret_cast<const bf16x8 *>(wsrc[NN ? 0 : j] + k0) : zero8;
+            for (int j = 0; j < WCH; ++j) ws_[j] = rsrc_load_bf16x8(wr_, xin ? woff[NN ? 0 : j] : kRsrcOob, static_cast<unsigned>(k0 * 2));
         }
     };
     auto deposit = [&](int buf, const bf16x8 (&xs_)[XCH], const bf16x8 (&ws_)[WCH]) __attribute__((always_inline)) {
@@ -146,13 +178,14 @@ void tgemm_kernel(const TgemmArgs g)
 #pragma unroll
         for (int j = 0; j < XCH; ++j) *reinterpret_cast<bf16x8 *>(xb + xdst[j]) = xs_[j];
         if (NN) {
-            if (tid < BN) {
-                bf16x8 in[8], tr[8];
+            if (tid < WTHR) {
+                bf16x8 in[4];
+                unsigned tr[8][2];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) in[i] = ws_[i];
-                transpose8x8(in, tr);
+                for (int i = 0; i < 4; ++i) in[i] = ws_[i];
+                transpose4x8(in, tr);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) *reinterpret_cast<bf16x8 *>(wb + wdst[0] + q * kLd) = tr[q];
+                for (int q = 0; q < 8; ++q) __builtin_memcpy(wb + wdst[0] + q * kLd, tr[q], 8);
             }
         } else {
 #pragma unroll
@@ -161,13 +194,14 @@ void tgemm_kernel(const TgemmArgs g)
     };
 
     f32x16 acc[TN][TM];
+    auto clear = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int a_ = 0; a_ < TN; ++a_)
+        for (int a_ = 0; a_ < TN; ++a_)
 #pragma unroll
-        for (int b_ = 0; b_ < TM; ++b_)
+            for (int b_ = 0; b_ < TM; ++b_)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a_][b_][i] = 0.f;
-
+                for (int i = 0; i < 16; ++i) acc[a_][b_][i] = 0.f;
+    };
     auto products = [&](int buf) __attribute__((always_inline)) {
         const __bf16 *xl = Xs + (buf * BM + wm * (BM / 2) + l31) * kLd + half * 8;     // + 32 tm rows, + 16 ks
         const __bf16 *wl = Ws + (buf * BN + wn * (BN / 2) + l31) * kLd + half * 8;
@@ -185,107 +219,162 @@ void tgemm_kernel(const TgemmArgs g)
         }
     };
 
-    // ---- slab pipeline: slab s + 1 is written to LDS after the barrier that freed its buffer, slabs s + 2 .. s + 1 + PF are in
-    // flight in registers while slab s's products issue
+    // ---- a tile's tail.  piece c = tid + 256 j of the output tile: row c / (BN / 8), 8 features at 8 (c % (BN / 8)); 256 % (BN / 8)
+    // == 0, so a thread's feature group -- its bias -- is the same for all its pieces.  Straight-line code: rows beyond T and
+    // feature groups beyond N carry an out-of-range buffer offset (loads give zero, stores are dropped).
+    constexpr int PR = BN / 8, NP = BM * PR / kThreadsT;
+    constexpr bool RES = TAIL != 0;
+    const int pc = tid % PR;
+    const float lo = (g.flags & kTgemmRelu) ? 0.f : -__builtin_inff();
+    const bool out32 = TAIL == 2 && (g.flags & kTgemmOutF32) != 0;
+    const bool has_res = TAIL == 1 || (TAIL == 2 && g.res != nullptr);
+    const uint64_t sd = (TAIL == 2 && g.thresh) ? g.seed + (g.seed_dev ? *g.seed_dev : 0ull) : 0ull;
+    const mdetr_rsrc yr = make_rsrc(g.y, static_cast<unsigned>(((g.T - 1) * g.ldy + g.N) * (out32 ? 4 : 2)));
+    const mdetr_rsrc rr_ = make_rsrc(has_res ? static_cast<const void *>(g.res) : static_cast<const void *>(g.a),
+                                     has_res ? static_cast<unsigned>(((g.T - 1) * g.ldr + g.N) * 2) : 0u);
+    constexpr int NPB = NP < 4 ? NP : 4;                         // pieces per batch of the tail (registers: 8 floats each)
+    bf16x8 rq[RES ? NP : 1];
+    float bv[8];
+    unsigned yoff[NP];                                           // element offsets of the pieces (kRsrcOob: not stored)
+    int64_t tail_m0 = 0;
+    int tail_n = 0;
+    auto aim_tail = [&](int v) __attribute__((always_inline)) { // where the tile goes; its residual tile and bias are requested
+        int col;
+        tile_of(v, col, tail_m0);
+        tail_n = col * BN + pc * 8;
+        const bool ncol = tail_n < g.N;                          // N % 8 == 0
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int64_t t = tail_m0 + (tid + kThreadsT * j) / PR;
+            yoff[j] = (ncol && t < g.T) ? static_cast<unsigned>(t * g.ldy + tail_n) : kRsrcOob;
+            if (RES) rq[j] = rsrc_load_bf16x8(rr_, (has_res && ncol && t < g.T) ? static_cast<unsigned>((t * g.ldr + tail_n) * 2) : kRsrcOob, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bv[i] = 0.f;
+        if (g.bias && ncol) {
+            if (TAIL == 2 && (g.flags & kTgemmBiasF32)) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bv[i] = static_cast<const float *>(g.bias)[tail_n + i];
+            } else {
+                const bf16x8 b8 = *reinterpret_cast<const bf16x8 *>(static_cast<const __bf16 *>(g.bias) + tail_n);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bv[i] = static_cast<float>(b8[i]);
+            }
+        }
+    };
+    auto park = [&]() __attribute__((always_inline)) {          // accumulators -> LDS
+        // accumulator register 4 q + i of lane l: feature 8 q + 4 (l >> 5) + i, token l & 31 of its 32 x 32 block
+#pragma unroll
+        for (int a_ = 0; a_ < TN; ++a_)
+#pragma unroll
+            for (int b_ = 0; b_ < TM; ++b_) {
+                float *cr = Cs + (wm * (BM / 2) + b_ * 32 + l31) * (BN + kCPad) + wn * (BN / 2) + a_ * 32 + 4 * half;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 o;
+                    o.x = acc[a_][b_][4 * q]; o.y = acc[a_][b_][4 * q + 1]; o.z = acc[a_][b_][4 * q + 2]; o.w = acc[a_][b_][4 * q + 3];
+                    *reinterpret_cast<f32x4 *>(cr + 8 * q) = o;
+                }
+            }
+    };
+    auto drain = [&]() __attribute__((always_inline)) {         // (behind the barrier that follows park) the tile leaves row by row:
+        // bias, residual, ReLU, dropout, ONE rounding, 16-byte stores
+#pragma unroll
+        for (int j0 = 0; j0 < NP; j0 += NPB) {
+            f32x4 cq[NPB][2];
+#pragma unroll
+            for (int u = 0; u < NPB; ++u) {
+                const float *cr = Cs + ((tid + kThreadsT * (j0 + u)) / PR) * (BN + kCPad) + pc * 8;
+                cq[u][0] = *reinterpret_cast<const f32x4 *>(cr);
+                cq[u][1] = *reinterpret_cast<const f32x4 *>(cr + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < NPB; ++u) {
+                const int j = j0 + u;
+                float o[8] = {cq[u][0].x, cq[u][0].y, cq[u][0].z, cq[u][0].w, cq[u][1].x, cq[u][1].y, cq[u][1].z, cq[u][1].w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float f = o[i] + bv[i];
+                    if (RES) f += static_cast<float>(rq[j][i]);
+                    f = f < lo ? lo : f;                         // ReLU (NaN passes through, as clamp_min does)
+                    if (TAIL == 2 && g.thresh) {
+                        const uint64_t t = static_cast<uint64_t>(tail_m0 + (tid + kThreadsT * j) / PR);
+                        f = ln_hash(sd, t * static_cast<uint64_t>(g.N) + static_cast<uint64_t>(tail_n + i)) >= g.thresh ? f * g.keep_scale : 0.f;
+                    }
+                    o[i] = f;
+                }
+                if (out32) {
+                    f32x4 o0, o1;
+                    o0.x = o[0]; o0.y = o[1]; o0.z = o[2]; o0.w = o[3]; o1.x = o[4]; o1.y = o[5]; o1.z = o[6]; o1.w = o[7];
+                    const unsigned off = yoff[j] == kRsrcOob ? kRsrcOob : yoff[j] * 4u;
+                    rsrc_store_f32x4(yr, o0, off, 0u);
+                    rsrc_store_f32x4(yr, o1, off, 16u);
+                } else {
+                    bf16x8 ob;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ob[i] = static_cast<__bf16>(o[i]);
+                    rsrc_store_bf16x8(yr, ob, yoff[j] == kRsrcOob ? kRsrcOob : yoff[j] * 2u, 0u);
+                }
+            }
+        }
+    };
+
+    // ---- the slab sequence.  Compute cursor (cv, ck), fetch cursor (fv, fk) up to 1 + PF slabs ahead; slab s of the sequence lives
+    // in LDS buffer s & 1 and, before that, in register set (s - 1) % PF.
+    int cv = next_tile(static_cast<int>(blockIdx.x));
+    if (cv >= vtiles) return;
+    int ck = 0, fv = cv, fk = 0;
+    auto advance = [&]() __attribute__((always_inline)) {        // the fetch cursor moves one slab on
+        if (++fk == KT) {
+            fk = 0;
+            fv = next_tile(fv + G);
+            if (fv < vtiles) aim(fv);
+        }
+    };
+    aim(fv);
     fetch(0, xr[0], wr[0]);
+    advance();
     deposit(0, xr[0], wr[0]);
 #pragma unroll
     for (int p = 0; p < PF; ++p)
-        if (1 + p < KT) fetch(1 + p, xr[p], wr[p]);
+        if (fv < vtiles) { fetch(fk, xr[p], wr[p]); advance(); }
+    clear();
     __syncthreads();
-    for (int kt = 0; kt < KT; kt += PF) {
+    for (int s = 0;; s += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            const int s = kt + p;
-            if (s < KT) {                                        // (uniform)
-                if (s + 1 < KT) deposit((s + 1) & 1, xr[p], wr[p]);
-                if (s + 1 + PF < KT) fetch(s + 1 + PF, xr[p], wr[p]);
-                products(s & 1);
+            const bool last = ck == KT - 1;                      // (uniform) this tile's last slab
+            if (!last) {
+                deposit((s + p + 1) & 1, xr[p], wr[p]);          // slab s + p + 1 (the barrier behind the previous slab freed that buffer)
+                if (fv < vtiles) { fetch(fk, xr[p], wr[p]); advance(); }
+            }
+            products((s + p) & 1);
+            __syncthreads();
+            ++ck;
+            if (last) {                                          // every wave is done with the slab buffers: the tile is parked there
+                aim_tail(cv);
+                park();
+                __syncthreads();
+                drain();                                         // the tile leaves
+                cv = next_tile(cv + G);
+                if (cv >= vtiles) return;
+                __syncthreads();                                 // the buffers are free again
+                deposit((s + p + 1) & 1, xr[p], wr[p]);          // the next tile's first slab (in flight since this tile's last slabs)
+                if (fv < vtiles) { fetch(fk, xr[p], wr[p]); advance(); }
+                clear();
+                ck = 0;
                 __syncthreads();
             }
         }
     }
-
-    // ---- epilogue.  piece c = tid + 256 j of the output tile: row c / (BN / 8), 8 features at 8 (c % (BN / 8)); 256 % (BN / 8) == 0,
-    // so a thread's feature group -- its bias -- is the same for all its pieces.
-    constexpr int PR = BN / 8, NP = BM * PR / kThreadsT;
-    const int pc = tid % PR, n = n0 + pc * 8;
-    const bool ncol = n < g.N;                                   // N % 8 == 0
-    bf16x8 rr[NP];
-    if (g.res) {                                                 // the residual tile: requested before the accumulators are parked
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int row = (tid + kThreadsT * j) / PR;
-            const int64_t t = m0 + row;
-            rr[j] = (ncol && t < g.T) ? *reinterpret_cast<const bf16x8 *>(g.res + t * g.ldr + n) : zero8;
-        }
-    }
-    float bv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) bv[i] = 0.f;
-    if (g.bias && ncol) {
-        if (g.flags & kTgemmBiasF32) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) bv[i] = static_cast<const float *>(g.bias)[n + i];
-        } else {
-            const bf16x8 b8 = *reinterpret_cast<const bf16x8 *>(static_cast<const __bf16 *>(g.bias) + n);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) bv[i] = static_cast<float>(b8[i]);
-        }
-    }
-    // accumulator register 4 q + i of lane l: feature 8 q + 4 (l >> 5) + i, token l & 31 of its 32 x 32 block
-#pragma unroll
-    for (int a_ = 0; a_ < TN; ++a_)
-#pragma unroll
-        for (int b_ = 0; b_ < TM; ++b_) {
-            float *cr = Cs + (wm * (BM / 2) + b_ * 32 + l31) * (BN + kCPad) + wn * (BN / 2) + a_ * 32 + 4 * half;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 v;
-                v.x = acc[a_][b_][4 * q]; v.y = acc[a_][b_][4 * q + 1]; v.z = acc[a_][b_][4 * q + 2]; v.w = acc[a_][b_][4 * q + 3];
-                *reinterpret_cast<f32x4 *>(cr + 8 * q) = v;
-            }
-        }
-    __syncthreads();
-    const bool relu = (g.flags & kTgemmRelu) != 0;
-    const uint64_t sd = g.thresh ? g.seed + (g.seed_dev ? *g.seed_dev : 0ull) : 0ull;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const int row = (tid + kThreadsT * j) / PR;
-        const int64_t t = m0 + row;
-        if (!ncol || t >= g.T) continue;
-        const float *cr = Cs + row * (BN + kCPad) + pc * 8;
-        const f32x4 c0 = *reinterpret_cast<const f32x4 *>(cr), c1 = *reinterpret_cast<const f32x4 *>(cr + 4);
-        float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float f = v[i] + bv[i];
-            if (g.res) f += static_cast<float>(rr[j][i]);
-            if (relu) f = f < 0.f ? 0.f : f;                     // (NaN passes through, as clamp_min does)
-            if (g.thresh) f = ln_hash(sd, static_cast<uint64_t>(t) * static_cast<uint64_t>(g.N) + static_cast<uint64_t>(n + i)) >= g.thresh ? f * g.keep_scale : 0.f;
-            v[i] = f;
-        }
-        if (g.flags & kTgemmOutF32) {
-            float *yp = static_cast<float *>(g.y) + t * g.ldy + n;
-            f32x4 o0, o1;
-            o0.x = v[0]; o0.y = v[1]; o0.z = v[2]; o0.w = v[3]; o1.x = v[4]; o1.y = v[5]; o1.z = v[6]; o1.w = v[7];
-            *reinterpret_cast<f32x4 *>(yp) = o0;
-            *reinterpret_cast<f32x4 *>(yp + 4) = o1;
-        } else {
-            bf16x8 o;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = static_cast<__bf16>(v[i]);
-            *reinterpret_cast<bf16x8 *>(static_cast<__bf16 *>(g.y) + t * g.ldy + n) = o;
-        }
-    }
 }
 
-template <int BM, int BN, bool NN, int PF>
+template <int BM, int BN, bool NN, int PF, int TAIL>
 hipError_t launch_tile(TgemmArgs g, hipStream_t st)
 {
     constexpr size_t lds = tgemm_lds<BM, BN>();
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
-    auto kern = tgemm_kernel<BM, BN, NN, PF>;
+    auto kern = tgemm_kernel<BM, BN, NN, PF, TAIL>;
     static bool attr_set[64] = {};                               // the attribute is per device: one process may drive several GPUs
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess) dev_ = -1;
@@ -297,18 +386,34 @@ hipError_t launch_tile(TgemmArgs g, hipStream_t st)
     }
     const int64_t tiles_m = (g.T + BM - 1) / BM;
     g.ny = (g.N + BN - 1) / BN;
-    g.gx = static_cast<int>((tiles_m + 7) / 8 * 8);              // whole rounds over the XCDs (idle workgroups leave at once)
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(static_cast<int64_t>(g.gx) * g.ny)), dim3(kThreadsT), lds, st, g);
+    g.gx = static_cast<int>((tiles_m + 7) / 8 * 8);              // whole rounds over the XCDs (dead row tiles are skipped)
+    const int64_t vtiles = static_cast<int64_t>(g.gx) * g.ny;
+    // persistent: as many workgroups as the chip holds at once (LDS: 160 KB per CU), a multiple of 8
+    int per_cu = static_cast<int>((160 * 1024) / lds);
+    per_cu = per_cu > 4 ? 4 : per_cu;
+    if (const char *ev = getenv("MDETR_TGEMM_PER_CU")) { const int f = atoi(ev); if (f >= 1 && f <= 8) per_cu = f; }       // A/B runs
+    int64_t grid = static_cast<int64_t>(256) * per_cu;
+    if (const char *ev = getenv("MDETR_TGEMM_PERSIST")) { if (atoi(ev) == 0) grid = vtiles; }       // A/B runs: one tile per workgroup
+    if (const char *ev = getenv("MDETR_TGEMM_GRID")) { const int f = atoi(ev); if (f >= 8 && f % 8 == 0) grid = f; }       // tests: few workgroups, many tiles each
+    if (grid > vtiles) grid = vtiles;
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(kThreadsT), lds, st, g);
     return hipGetLastError();
 }
 
-template <bool NN, int PF>
+template <bool NN, int PF, int TAIL>
 hipError_t launch_any(const TgemmArgs &g, int bm, int bn, hipStream_t st)
 {
-    if (bm == 128 && bn == 128) return launch_tile<128, 128, NN, PF>(g, st);
-    if (bm == 128) return launch_tile<128, 64, NN, PF>(g, st);
-    if (bn == 128) return launch_tile<64, 128, NN, PF>(g, st);
-    return launch_tile<64, 64, NN, PF>(g, st);
+    if (bm == 128 && bn == 128) return launch_tile<128, 128, NN, PF, TAIL>(g, st);
+    if (bm == 128) return launch_tile<128, 64, NN, PF, TAIL>(g, st);
+    if (bn == 128) return launch_tile<64, 128, NN, PF, TAIL>(g, st);
+    return launch_tile<64, 64, NN, PF, TAIL>(g, st);
+}
+
+template <bool NN, int PF>
+hipError_t launch_tail(const TgemmArgs &g, int bm, int bn, hipStream_t st)
+{
+    if ((g.flags & (kTgemmBiasF32 | kTgemmOutF32)) || g.thresh) return launch_any<NN, PF, 2>(g, bm, bn, st);
+    return g.res ? launch_any<NN, PF, 1>(g, bm, bn, st) : launch_any<NN, PF, 0>(g, bm, bn, st);
 }
 
 }  // namespace
@@ -320,7 +425,9 @@ bool tgemm_supported(const TgemmProblem &p)
     return p.T > 0 && p.T < (1ll << 31) - 256 && p.N > 0 && p.N % 8 == 0 && p.K > 0 && p.K % 8 == 0 && p.a && p.w && p.y && al(p.a) && al(p.w) &&
            al(p.y) && p.lda % 8 == 0 && p.lda >= p.K && p.ldw % 8 == 0 && p.ldw >= (nn ? p.N : p.K) &&
            p.ldy % ((p.flags & kTgemmOutF32) ? 4 : 8) == 0 && p.ldy >= p.N &&
-           (!p.res || (al(p.res) && p.ldr % 8 == 0 && p.ldr >= p.N)) && (!p.bias || al(p.bias)) && p.dropout_p >= 0.f && p.dropout_p < 1.f;
+           (!p.res || (al(p.res) && p.ldr % 8 == 0 && p.ldr >= p.N)) && (!p.bias || al(p.bias)) && p.dropout_p >= 0.f && p.dropout_p < 1.f &&
+           // buffer-resource addressing: every tensor below 2^31 bytes
+           p.T * p.lda < (1ll << 30) && p.T * p.ldy < (1ll << 29) && p.T * p.ldr < (1ll << 30) && static_cast<int64_t>(nn ? p.K : p.N) * p.ldw < (1ll << 30);
 }
 
 hipError_t tgemm_launch(const TgemmProblem &p, hipStream_t st)
@@ -333,20 +440,26 @@ hipError_t tgemm_launch(const TgemmProblem &p, hipStream_t st)
     g.thresh = p.dropout_p > 0.f ? ln_threshold(p.dropout_p) : 0u;
     g.keep_scale = p.dropout_p > 0.f ? 1.f / (1.f - p.dropout_p) : 1.f;
     g.seed = p.seed; g.seed_dev = p.seed_dev;
-    // the largest tile that still gives every CU two workgroups (512); narrow outputs take 64-wide feature tiles
-    int bm = 128, bn = p.N <= 64 ? 64 : 128;
+    // Tile choice (profiles/r05e_gemmbench.json: every product of the step x every tile): 128 x 128 wherever it still gives the
+    // chip ~1.5 workgroups per CU, 128 x 64 when only that does, 64 x 64 for narrow outputs, the decoder's few thousand rows and
+    // the everything-tail (whose 128 x 128 form runs out of registers)
+    const bool generic_tail = (p.flags & (kTgemmBiasF32 | kTgemmOutF32)) != 0 || p.dropout_p > 0.f;
     const auto wgs = [&](int m, int n) { return ((p.T + m - 1) / m) * ((p.N + n - 1) / n); };
-    if (wgs(bm, bn) < 512) bm = 64;
-    if (wgs(bm, bn) < 512 && bn == 128) bn = 64;
+    int bm = 64, bn = 64;
+    if (p.N > 64 && !generic_tail && !(p.T < 8192 && p.K <= 256)) {
+        if (wgs(128, 128) >= 400) { bm = 128; bn = 128; }
+        else if (wgs(128, 64) >= 400) { bm = 128; bn = 64; }
+    }
     if (const char *ev = getenv("MDETR_TGEMM_TILE")) {           // A/B runs: "128x64"
         int m = 0, n = 0;
         if (sscanf(ev, "%dx%d", &m, &n) == 2 && (m == 64 || m == 128) && (n == 64 || n == 128)) { bm = m; bn = n; }
     }
     int pf = 2;
+    if (bm == 128 && bn == 128 && (p.res || (p.flags & (kTgemmBiasF32 | kTgemmOutF32)) || p.dropout_p > 0.f)) pf = 1;       // (the big tile's tails: registers)
     if (const char *ev = getenv("MDETR_TGEMM_PF")) pf = atoi(ev) == 1 ? 1 : 2;       // A/B runs: register sets in flight
     ProfileScope prof(10, conv_mflop(p.T, static_cast<int64_t>(p.N) * p.K), st);
-    if (p.flags & kTgemmNN) return pf == 1 ? launch_any<true, 1>(g, bm, bn, st) : launch_any<true, 2>(g, bm, bn, st);
-    return pf == 1 ? launch_any<false, 1>(g, bm, bn, st) : launch_any<false, 2>(g, bm, bn, st);
+    if (p.flags & kTgemmNN) return pf == 1 ? launch_tail<true, 1>(g, bm, bn, st) : launch_tail<true, 2>(g, bm, bn, st);
+    return pf == 1 ? launch_tail<false, 1>(g, bm, bn, st) : launch_tail<false, 2>(g, bm, bn, st);
 }
 
 }  // namespace mdetr

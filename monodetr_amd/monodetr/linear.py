@@ -33,8 +33,35 @@ def _wants_token_gemm(x2, weight):
 # MDETR_GEMM_RELU=1: "linear -> ReLU" as one library GEMM with the RELU_BIAS epilogue (torch._addmm_activation ->
 # hipBLASLt) instead of a GEMM and an elementwise pass.  Off until timed on a GPU.
 _GEMM_RELU = os.environ.get("MDETR_GEMM_RELU") == "1"
-# the residual-path gradient of `_TokenLinearSkip` is accumulated INTO the arriving gradient tensor when nobody else holds it
-_SKIP_INPLACE = os.environ.get("MDETR_SKIP_INPLACE", "1") != "0"
+# MDETR_TGEMM=1: forward and input-gradient products of bf16 layers through csrc/tgemm.hip, their elementwise tails (bias, ReLU,
+# Dropout, "+ identity", the residual-path gradient's accumulation) inside its epilogue.  kernel_families decides (committed for bf16).
+_TGEMM = os.environ.get("MDETR_TGEMM") == "1"
+
+
+def _tgemm_ok(x2, weight, bias=None, res2=None, nn=False):
+    if not _TGEMM:
+        return False
+    from .. import tgemm_ext
+    return tgemm_ext.supported(x2, weight, nn=nn, res=res2, bias=bias)
+
+
+def _drop_seed(x, p):
+    """(seed, device-resident seed or None) of one dropout site: a replayed graph needs a seed that lives on the device."""
+    if p <= 0.0:
+        return 0, None
+    if x.is_cuda and torch.cuda.is_current_stream_capturing():
+        from ..attn_ext import site_seed
+        return site_seed(x.device)
+    from ..add_ln_ext import _host_seed
+    return _host_seed(), None
+
+
+def _act_backward(dy, y, scale=1.0):
+    """Backward of y = dropout(relu(.)) from the saved output: dy * scale where y > 0 (kept and positive), else 0."""
+    if scale == 1.0:
+        return torch.ops.aten.threshold_backward(dy, y, 0.0)
+    from .. import bias_act_ext
+    return bias_act_ext.act_backward(dy, y, scale)
 
 
 def _split_count(T):
@@ -82,91 +109,54 @@ def _weight_bias_grads(x2, dy2, weight, need_w, need_b):
     return dw, db
 
 
-def _holders(t):
-    """(C++ references to the tensor object, Python references to its wrapper, the same two for the base of a view, tensor
-    objects + wrappers on the storage).  A view keeps its base alive; Python variables share ONE wrapper object, which holds one
-    C++ reference however many of them there are -- hence both kinds of count."""
-    base = t._base
-    return (t._use_count(), sys.getrefcount(t),
-            0 if base is None else base._use_count(), 0 if base is None else sys.getrefcount(base),
-            torch._C._storage_Use_Count(t.untyped_storage()._cdata))
+def _fwd_product(x2, weight, bias, relu=False, res2=None, dropout_p=0.0, seed=0, seed_dev=None, out_dtype=torch.bfloat16):
+    """x2 W^T + bias (+ res2, ReLU, Dropout) through csrc/tgemm.hip (the caller has asked `_tgemm_ok`)."""
+    from .. import tgemm_ext
+    return tgemm_ext.tgemm(x2, weight, bias, res2, relu=relu, out_dtype=out_dtype, dropout_p=dropout_p, seed=seed, seed_dev=seed_dev)
 
 
-_BASELINE = {}              # is-a-view -> _holders() of a gradient that provably nobody else holds (calibrated once, see below)
-SKIP_STATS = None           # tools / tests: a list collects (shape, counts, decision) of every site
-
-
-def _exclusive(t):
-    """Can nobody but the running backward function reach `t`'s memory?  Compared with `_holders()` of a gradient that is known
-    to be exclusively ours (`_calibrate`: the same call path on a toy problem): another node still waiting for the same gradient
-    holds it in its input buffer, retain_grad() and saved-for-backward lists hold the tensor object, a hook that kept it holds
-    the Python wrapper, any further view or detach() alias holds the storage -- each raises one of the counts, and then the
-    caller must not write into `t`.  (MDETR_SKIP_INPLACE=0, or a failed calibration: never.)"""
-    if not _SKIP_INPLACE:
-        return False
-    try:
-        want = _BASELINE.get(t._base is not None)
-        got = _holders(t)
-    except (AttributeError, RuntimeError, TypeError):
-        return False
-    if _BASELINE.get("calibrating"):
-        _BASELINE.setdefault("seen", []).append(got)
-        return False
-    ok = want is not None and all(g <= w for g, w in zip(got, want))
-    if SKIP_STATS is not None:
-        SKIP_STATS.append((tuple(t.shape), got, ok))
-    return ok
-
-
-def _calibrate():
-    """Holder counts of a residual-path gradient that nobody else holds, through the very call path `_TokenLinearSkip.backward`
-    uses: a fresh tensor (the gradient of `x' * 2`) and a view of a fresh tensor (the gradient arriving through a reshape of x').
-    Anything unexpected (other counts on a second pass, an exception) leaves the baseline empty = never in place."""
-    _BASELINE["calibrating"] = True
-    try:
-        found = {}
-        for _ in range(2):
-            for view in (False, True):
-                _BASELINE["seen"] = []
-                with torch.enable_grad():                            # (called from a Function's forward: grad mode is off there)
-                    x = torch.zeros(4, 3, 8, requires_grad=True)
-                    w = torch.zeros(2, 8, requires_grad=True)
-                    y, xs = _TokenLinearSkip.apply(x, w, None, None)
-                    tail = (xs.view(12, 8) if view else xs) * 2.0
-                    (y.sum() + tail.sum()).backward()
-                seen = _BASELINE["seen"]
-                if len(seen) != 1 or (seen[0][2] > 0) != view or found.setdefault(view, seen[0]) != seen[0]:
-                    found = None
-                    break
-            if found is None:
-                break
-    except Exception:                                                # noqa: BLE001 -- no baseline, no in-place writes
-        found = None
-    _BASELINE.clear()
-    _BASELINE.update(found or {"failed": True})
+def _input_gradient(dy2, weight, dskip2=None):
+    """dY W (+ the gradient arriving over a residual path): csrc/tgemm.hip's NN form reads the parameter as it lies in memory and
+    adds `dskip2` where the product's tile leaves the chip -- into a NEW tensor: nothing is written into the arriving gradient,
+    whoever else may hold it.  The library route is a copy of the residual gradient followed by a beta = 1 GEMM."""
+    if dy2.is_contiguous() and _tgemm_ok(dy2, weight, res2=dskip2, nn=True):
+        from .. import tgemm_ext
+        return tgemm_ext.tgemm(dy2, weight, None, dskip2, nn=True)
+    if dskip2 is None:
+        return dy2 @ weight
+    if dskip2.dtype == dy2.dtype:
+        return torch.addmm(dskip2, dy2, weight)
+    return dskip2 + dy2 @ weight
 
 
 class _TokenLinearSkip(torch.autograd.Function):
-    """(y, x') = ((x + pos) W^T + b, x): the linear layer of a residual branch together with the tensor the residual connection
-    continues from.  x has ONE consumer in the graph, so the gradient arriving through x' (the residual path) and the layer's own
-    input gradient dY W need no separate sum: backward issues the input-gradient GEMM with beta = 1 into the arriving gradient.
-    The encoder's 81 600-row layers read such a sum as three 42 MB tensors per residual site (reference
+    """(y, x') = (tail((x + pos) W^T + b), x): the linear layer of a residual branch together with the tensor the residual
+    connection continues from.  x has ONE consumer in the graph, so the gradient arriving through x' (the residual path) and the
+    layer's own input gradient dY W need no separate sum: backward adds the arriving gradient inside the input-gradient product
+    (`_input_gradient`).  The encoder's 81 600-row layers read such a sum as three 42 MB tensors per residual site (reference
     depthaware_transformer.py:318-345: `src` feeds with_pos_embed, value_proj and the residual; the FFN input feeds linear1 and
-    the residual).  `pos` is a constant here (no gradient)."""
+    the residual); the bottleneck's conv1 shares its input with the identity connection (torchvision Bottleneck.forward behind
+    backbone.py:93-106).  tail: ReLU (relu) followed by Dropout (dropout_p, csrc/tgemm.hip only).  `pos` is a constant (no gradient)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pos, relu=False):
-        if _SKIP_INPLACE and not _BASELINE:
-            _calibrate()                                             # (here, not in backward: a backward pass inside a backward pass
-                                                                     # runs on another call path)
+    def forward(ctx, x, weight, bias, pos, relu=False, dropout_p=0.0):
         q = x if pos is None else x + pos
+        q2 = q.reshape(-1, q.shape[-1])
         ctx.has_bias = bias is not None
         ctx.relu = bool(relu)
-        if relu:                                                     # library GEMM with the RELU_BIAS epilogue (as _TokenLinear)
-            y = torch._addmm_activation(bias, q.reshape(-1, q.shape[-1]), weight.t()).view(q.shape[:-1] + (weight.shape[0],))
-            ctx.save_for_backward(q, weight, y)
+        ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
+        if _tgemm_ok(q2, weight, bias):
+            seed, seed_dev = _drop_seed(q, dropout_p)
+            y = _fwd_product(q2, weight, bias, relu, None, dropout_p, seed, seed_dev).view(q.shape[:-1] + (weight.shape[0],))
+        elif dropout_p > 0.0:
+            raise RuntimeError("token_linear_skip: dropout is only fused into csrc/tgemm.hip's epilogue")
+        elif relu:                                                   # library GEMM with the RELU_BIAS epilogue (as _TokenLinear)
+            y = torch._addmm_activation(bias, q2, weight.t()).view(q.shape[:-1] + (weight.shape[0],))
         else:
             y = F.linear(q, weight, bias)
+        if relu:
+            ctx.save_for_backward(q, weight, y)
+        else:
             ctx.save_for_backward(q, weight)
         return y, x.view_as(x)
 
@@ -175,62 +165,69 @@ class _TokenLinearSkip(torch.autograd.Function):
     def backward(ctx, dy, dskip):
         q, weight = ctx.saved_tensors[:2]
         if ctx.relu:
-            dy = torch.ops.aten.threshold_backward(dy, ctx.saved_tensors[2], 0.0)
+            dy = _act_backward(dy.contiguous(), ctx.saved_tensors[2], ctx.scale)
         q2, dy2 = q.reshape(-1, q.shape[-1]), dy.reshape(-1, dy.shape[-1])
         dx = None
         if ctx.needs_input_grad[0]:
-            if dskip is None:
-                dx = (dy2 @ weight).view_as(q)
-            elif dskip.is_contiguous() and dskip.dtype == dy2.dtype and _exclusive(dskip):
-                # beta = 1 GEMM INTO the arriving gradient: nobody else can reach that tensor (see `_exclusive`).  The
-                # out-of-place form below first copies it (torch.addmm = a 42 MB device-to-device copy, then the same GEMM): 14
-                # such copies per training step, 0.3 ms (the MEMCPY nodes of profiles/r04_graph_structure.txt)
-                dx = dskip.view(-1, q.shape[-1]).addmm_(dy2, weight).view_as(q)
-            elif dskip.is_contiguous() and dskip.dtype == dy2.dtype:
-                # somebody else holds the arriving gradient (a second consumer still waiting for it, retain_grad(), a hook that
-                # kept it): a NEW tensor
-                dx = torch.addmm(dskip.view(-1, q.shape[-1]), dy2, weight).view_as(q)
-            else:
-                dx = dskip + (dy2 @ weight).view_as(q)
+            ds2 = dskip.reshape(-1, q.shape[-1]) if dskip is not None else None
+            dx = _input_gradient(dy2, weight, ds2).view_as(q)
         dw, db = _weight_bias_grads(q2, dy2, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def token_linear_skip(x, weight, bias=None, pos=None, relu=False):
-    """-> (token_linear(x + pos, weight, bias[, relu]), x'): use x' (== x) for everything that follows on the residual path; see
-    `_TokenLinearSkip`.  Plain tensors out of it when the fused form does not apply.  relu: only with the library's RELU_BIAS
-    epilogue available (MDETR_GEMM_RELU and a 1-D bias); the caller asks `skip_relu_fusable` first."""
+def token_linear_skip(x, weight, bias=None, pos=None, relu=False, dropout_p=0.0):
+    """-> (token_linear(x + pos, weight, bias[, relu, dropout]), x'): use x' (== x) for everything that follows on the residual path;
+    see `_TokenLinearSkip`.  Plain tensors out of it when the fused form does not apply.  relu / dropout_p: the caller asks
+    `skip_relu_fusable` / `skip_dropout_fusable` first."""
     if x.is_cuda and x.dtype == weight.dtype and x.numel() // x.shape[-1] >= _MIN_TOKENS and torch.is_grad_enabled() and x.requires_grad \
             and not torch.is_autocast_enabled() and (pos is None or not pos.requires_grad) and not _TOKEN_GEMM \
-            and (not relu or skip_relu_fusable(bias)):
-        return _TokenLinearSkip.apply(x, weight, bias, pos, relu)
+            and (not relu or skip_relu_fusable(bias, x, weight)) and (dropout_p <= 0.0 or skip_dropout_fusable(x, weight, bias)):
+        return _TokenLinearSkip.apply(x, weight, bias, pos, relu, dropout_p)
+    if dropout_p > 0.0:
+        raise RuntimeError("token_linear_skip: ask skip_dropout_fusable before passing dropout_p")
     return token_linear(x if pos is None else x + pos, weight, bias, relu=relu), x
 
 
-def skip_relu_fusable(bias):
-    return _GEMM_RELU and not _TOKEN_GEMM and bias is not None and bias.dim() == 1 and bias.is_contiguous()
+def skip_relu_fusable(bias, x=None, weight=None):
+    if _TOKEN_GEMM:
+        return False
+    if x is not None and weight is not None and _tgemm_ok(x.reshape(-1, x.shape[-1]), weight, bias):
+        return True
+    return _GEMM_RELU and bias is not None and bias.dim() == 1 and bias.is_contiguous()
+
+
+def skip_dropout_fusable(x, weight, bias):
+    return x.is_cuda and not _TOKEN_GEMM and _tgemm_ok(x.reshape(-1, x.shape[-1]), weight, bias)
 
 
 class _TokenLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, fused_relu=False, wide_out=False):
-        """fused_relu: ReLU in the epilogue of the token-GEMM kernel or, failing that, of the library GEMM.
+        """fused_relu: ReLU in the epilogue of the GEMM kernel or, failing that, of the library GEMM.
         wide_out: bf16 operands, fp32 RESULT (the fp32 accumulator is written out unrounded) -- the decoder's deformable
         cross-attention differences neighbouring value rows for d/d(location), and 8 mantissa bits on the values made those
         gradients the least accurate of the bf16 model (cosine 0.86-0.98 against the fp32 model, round 2)."""
         ctx.has_bias = bias is not None
         ctx.fused_relu = False
         ctx.wide_out = bool(wide_out)
+        x2 = x.reshape(-1, x.shape[-1])
+        if _tgemm_ok(x2, weight, bias):
+            y = _fwd_product(x2, weight, bias, fused_relu, out_dtype=torch.float32 if wide_out else torch.bfloat16)
+            y = y.view(x.shape[:-1] + (weight.shape[0],))
+            ctx.fused_relu = bool(fused_relu)
+            if fused_relu:
+                ctx.save_for_backward(x, weight, y)
+            else:
+                ctx.save_for_backward(x, weight)
+            return y
         if wide_out:
-            x2 = x.reshape(-1, x.shape[-1])
             y = torch.mm(x2, weight.t(), out_dtype=torch.float32)
             if bias is not None:
                 y += bias.float()
             ctx.save_for_backward(x, weight)
             return y.view(x.shape[:-1] + (weight.shape[0],))
-        if _wants_token_gemm(x.reshape(-1, x.shape[-1]), weight):
+        if _wants_token_gemm(x2, weight):
             from .. import token_gemm_ext
-            x2 = x.reshape(-1, x.shape[-1])
             if token_gemm_ext.supported(x2, weight):
                 y = token_gemm_ext.token_gemm(x2, weight, bias, relu=fused_relu).view(x.shape[:-1] + (weight.shape[0],))
                 if fused_relu:
@@ -240,7 +237,6 @@ class _TokenLinear(torch.autograd.Function):
                     ctx.save_for_backward(x, weight)
                 return y
         if fused_relu:                                               # library GEMM, RELU_BIAS epilogue
-            x2 = x.reshape(-1, x.shape[-1])
             y = torch._addmm_activation(bias, x2, weight.t()).view(x.shape[:-1] + (weight.shape[0],))
             ctx.fused_relu = True
             ctx.save_for_backward(x, weight, y)
@@ -269,9 +265,32 @@ class _TokenLinear(torch.autograd.Function):
                 if dy2.is_contiguous() and token_gemm_ext.supported(dy2, wt):
                     dx = token_gemm_ext.token_gemm(dy2, wt).view_as(x)
             if dx is None:
-                dx = (dy2 @ weight).view_as(x)
+                dx = _input_gradient(dy2, weight).view_as(x)
         dw, db = _weight_bias_grads(x2, dy2, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
         return dx, dw, db, None, None
+
+
+class _TokenLinearResidualRelu(torch.autograd.Function):
+    """out = relu(x W^T + b + res) from ONE kernel (csrc/tgemm.hip, residual epilogue): the tail of a bottleneck block -- the 1x1
+    expansion with the frozen BN folded in, "+ identity" and the ReLU (torchvision Bottleneck.forward behind
+    lib/models/monodetr/backbone.py:93-106) -- without the elementwise pass that read the product back (csrc/bias_act.hip: 0.47 ms
+    per iteration forward).  Backward: the ReLU mask from the saved output; the masked gradient IS the identity's gradient."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias, res2):
+        out = _fwd_product(x2, weight, bias, True, res2)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x2, weight, out)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        x2, weight, out = ctx.saved_tensors
+        g = torch.ops.aten.threshold_backward(dout.contiguous(), out, 0.0)
+        dx = _input_gradient(g, weight) if ctx.needs_input_grad[0] else None
+        dw, db = _weight_bias_grads(x2, g, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        return dx, dw, db, (g if ctx.needs_input_grad[3] else None)
 
 
 class _SplitRows(torch.autograd.Function):
@@ -350,6 +369,33 @@ def pointwise_conv_skip(x, weight, bias=None, relu=False):
     B, C, H, W = x.shape
     y, xs = token_linear_skip(x.permute(0, 2, 3, 1).reshape(B * H * W, C), weight.reshape(weight.shape[0], C), bias, relu=relu)
     return y.view(B, H, W, -1).permute(0, 3, 1, 2), xs.view(B, H, W, C).permute(0, 3, 1, 2)
+
+
+def pointwise_residual_relu_eligible(x, weight, bias, identity):
+    """Can `pointwise_conv_residual_relu` take relu(conv1x1(x) + identity)?  channels-last bf16 activations whose token views are
+    views, a bf16 weight, csrc/tgemm.hip's shape rules."""
+    if not (_TGEMM and x.dim() == 4 and identity.dim() == 4 and x.dtype == torch.bfloat16 and identity.dtype == torch.bfloat16
+            and weight.dtype == torch.bfloat16 and not torch.is_autocast_enabled()
+            and x.is_contiguous(memory_format=torch.channels_last) and identity.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    B, C, H, W = x.shape
+    N = weight.shape[0]
+    if identity.shape != (B, N, H, W):
+        return False
+    return _tgemm_ok(x.permute(0, 2, 3, 1).reshape(B * H * W, C), weight.reshape(N, C), bias,
+                     identity.permute(0, 2, 3, 1).reshape(B * H * W, N))
+
+
+def pointwise_conv_residual_relu(x, weight, bias, identity):
+    """relu(conv1x1(x, weight, bias) + identity) for channels-last activations (ask `pointwise_residual_relu_eligible` first)."""
+    B, C, H, W = x.shape
+    N = weight.shape[0]
+    x2, r2 = x.permute(0, 2, 3, 1).reshape(B * H * W, C), identity.permute(0, 2, 3, 1).reshape(B * H * W, N)
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or identity.requires_grad):
+        out = _TokenLinearResidualRelu.apply(x2, weight.reshape(N, C), bias, r2)
+    else:
+        out = _fwd_product(x2, weight.reshape(N, C), bias, True, r2)
+    return out.view(B, H, W, N).permute(0, 3, 1, 2)
 
 
 def pointwise_relu_fusable(x, weight, bias):

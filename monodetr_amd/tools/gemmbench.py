@@ -38,8 +38,21 @@ FORWARD = [
 ]
 
 
+EAGER = False                 # --eager (counter passes under rocprofv3): plain launches, HIP-event timed
+
+
 def graph_time(fn_of_set, nsets, reps):
     """us per launch of fn_of_set(i) over `reps` launches replayed from one graph."""
+    if EAGER:
+        for i in range(nsets):
+            fn_of_set(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for r in range(reps):
+            fn_of_set(r % nsets)
+        e1.record()
+        e1.synchronize()
+        return round(e0.elapsed_time(e1) * 1e3 / reps, 2)
     for i in range(nsets):
         fn_of_set(i)                                                # warm-up (lazy library initialisation outside the capture)
     torch.cuda.synchronize()
@@ -70,7 +83,11 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--no-backward", action="store_true")
     ap.add_argument("--out", default="")
+    ap.add_argument("--env", default="", help="extra tgemm variants, e.g. 'MDETR_TGEMM_PERSIST=0;MDETR_TGEMM_PER_CU=1'")
+    ap.add_argument("--eager", action="store_true", help="plain launches instead of graph replays (counter passes)")
     a = ap.parse_args()
+    global EAGER
+    EAGER = a.eager
     from monodetr_amd import bias_act_ext, tgemm_ext, token_gemm_ext
     dev = torch.device("cuda", 0)
     res = {}
@@ -127,6 +144,13 @@ def main():
                     os.environ["MDETR_TGEMM_TILE"], os.environ["MDETR_TGEMM_PF"] = tile, pf
                     row["tgemm_%s_pf%s_us" % (tile, pf)] = graph_time(ours, nsets, a.reps)
             for k in ("MDETR_TGEMM_TILE", "MDETR_TGEMM_PF"):
+                os.environ.pop(k, None)
+        for var in [v for v in a.env.split(";") if v]:                # extra variants: "NAME=VAL,NAME2=VAL2;..." (each group timed once)
+            pairs = [kv.split("=") for kv in var.split(",")]
+            for k, v in pairs:
+                os.environ[k] = v
+            row["tgemm[%s]_us" % var] = graph_time(ours, nsets, a.reps)
+            for k, _ in pairs:
                 os.environ.pop(k, None)
         best = min(v for k, v in row.items() if k.startswith("tgemm") and k.endswith("_us"))
         row["tgemm_best_us"], row["tgemm_frac_of_bound"] = best, round(row["bound_us"] / best, 3)

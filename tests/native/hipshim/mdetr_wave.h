@@ -94,6 +94,17 @@ inline unsigned short rsrc_load_u16(mdetr_rsrc r, unsigned lane_offset, unsigned
     return v;
 }
 
+// buffer-resource stores: a lane whose offset lies beyond the resource's size stores nothing
+template <typename V> inline void rsrc_store16(mdetr_rsrc r, const V &v, unsigned lane_offset, unsigned scalar_offset)
+{
+    static_assert(sizeof(V) == 16, "16-byte store");
+    if (static_cast<unsigned long long>(lane_offset) + 16 > r.bytes) return;
+    if (static_cast<unsigned long long>(lane_offset) + scalar_offset + 16 > r.bytes) abort();      // a valid lane must address the tensor
+    memcpy(const_cast<unsigned char *>(r.base) + lane_offset + scalar_offset, &v, 16);
+}
+inline void rsrc_store_bf16x8(mdetr_rsrc r, bf16x8 v, unsigned lane_offset, unsigned scalar_offset) { rsrc_store16(r, v, lane_offset, scalar_offset); }
+inline void rsrc_store_f32x4(mdetr_rsrc r, f32x4 v, unsigned lane_offset, unsigned scalar_offset) { rsrc_store16(r, v, lane_offset, scalar_offset); }
+
 inline void wave_sync() { hipshim::sync_wave(); }
 
 #define MDETR_DYNAMIC_LDS(type, name) type *name = reinterpret_cast<type *>(hipshim::dynamic_lds())

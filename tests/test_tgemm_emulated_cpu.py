@@ -130,3 +130,24 @@ def test_tgemm_rejects_what_it_cannot_run():
     for bad in (dict(K=60), dict(N=12), dict(lda=60), dict(flags=64), dict(p=0.5), dict(a=a.data_ptr() + 2), dict(T=-1)):
         assert L.mdetr_tgemm(*args(**bad)) < 0, bad
         assert b"mdetr_tgemm" in ctypes.string_at(L.mdetr_last_error())
+
+
+@pytest.mark.parametrize("grid", ["8", "16"])
+@pytest.mark.parametrize("pf", ["1", "2"])
+@pytest.mark.parametrize("nn", [False, True])
+def test_tgemm_persistent_workgroups_walk_several_tiles(monkeypatch, grid, pf, nn):
+    """Few workgroups, many tiles each: the slab sequence runs across tile boundaries (the next tile's first slabs are fetched during
+    this tile's last products and parked tail), dead row tiles of the rounded-up grid are skipped, column tiles alternate."""
+    monkeypatch.setenv("MDETR_TGEMM_GRID", grid)
+    monkeypatch.setenv("MDETR_TGEMM_PF", pf)
+    monkeypatch.setenv("MDETR_TGEMM_TILE", "64x64")
+    for T, K, N in ((700, 192, 136), (1500, 64, 72), (330, 328, 200)):        # 11 / 24 / 6 row tiles x 3 / 2 / 4 column tiles
+        a, w, b, r = problem(T, K, N, nn, T + K + N + 1)
+        y = run(a, w, bias=b, res=r, relu=True, nn=nn)
+        ref, mag = reference(a, w, nn, b, r, True)
+        assert_product_close(y, ref, mag, K, "grid=%s T=%d K=%d N=%d" % (grid, T, K, N))
+    monkeypatch.setenv("MDETR_TGEMM_TILE", "128x128")
+    a, w, b, r = problem(2100, 320, 264, nn, 99)
+    y = run(a, w, bias=b, nn=nn)
+    ref, mag = reference(a, w, nn, b)
+    assert_product_close(y, ref, mag, 320, "128x128 persistent")
