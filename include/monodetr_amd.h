@@ -323,18 +323,6 @@ int mdetr_adamw_step_counted(int param_dtype, void *param, float *master, const 
                              const double *step_count_dev, float lr, const double *lr_dev, int device, void *stream);
 
 /*
- * y[T, N] = x[T, K] * weight[N, K]^T + bias (+ ReLU) for tall token matrices in bf16, with the weight held in
- * LDS (the GEMM behind every nn.Linear applied to the flattened feature pyramid: ops/modules/ms_deform_attn.py:
- * 80-83, depthaware_transformer.py:331-333; the input gradient is the same product with weight^T).
- *   x      bf16 [T, K], row stride ldx elements (ldx % 8 == 0, 16-byte aligned base)
- *   weight bf16 [N, K] row-major, 16-byte aligned;  bias bf16 [N] or NULL
- *   y      bf16 [T, N], row stride ldy elements (ldy % 4 == 0, 8-byte aligned base)
- *   K in {64, 128, 256, 512}, N % 8 == 0, fp32 accumulation on the matrix cores
- */
-int mdetr_token_linear(const void *x, const void *weight, const void *bias, void *y, int64_t T, int N, int K,
-                       int64_t ldx, int64_t ldy, int relu, int device, void *stream);
-
-/*
  * y[T, N] = dropout(relu(a[T, K] op(w) + bias + res)) in bf16 on the matrix cores, every part of the tail optional: the general
  * token-wise product of the training iteration with its elementwise tail inside (csrc/tgemm.hip).  Replaces, per call site, the
  * library GEMM + separate passes of the reference: torchvision Bottleneck.conv1 / conv3 (+ identity + ReLU) / downsample behind

@@ -91,6 +91,20 @@ class _BiasAct(torch.autograd.Function):
         return dx, None, (dx if ctx.has_skip else None), None, None, None, None
 
 
+def act_backward(dy, y, scale=1.0):
+    """dx = dy * scale where y > 0, else 0: the backward of y = dropout(relu(.)) from the saved output alone (the same launch
+    `_BiasAct.backward` makes; also serves csrc/tgemm.hip's ReLU + Dropout epilogue, which makes bias_act's keep decisions)."""
+    if dy.stride() != y.stride() or dy.data_ptr() % 16 != 0:
+        dy = torch.empty_like(y).copy_(dy)
+    dx = torch.empty_like(y)
+    C = _cols(y)
+    dev, stream = _dev(y)
+    rc = _lib().mdetr_bias_act_backward(_io(y), dy.data_ptr(), y.data_ptr(), dx.data_ptr(), y.numel() // C, C, float(scale), dev, stream)
+    if rc != 0:
+        _capi.check(rc, "mdetr_bias_act_backward")
+    return dx
+
+
 def bias_act(x, bias=None, skip=None, relu=True, dropout_p=0.0, seed=None):
     """dropout(relu(x + bias + skip)).  ``x`` [B, C, H, W] channels_last or [..., C] contiguous (f32 / bf16); ``bias`` [C]
     without gradient (a frozen-BN shift); ``skip`` like ``x``.  Dropout needs ``relu`` (the backward recovers the mask from

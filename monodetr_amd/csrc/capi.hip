@@ -28,7 +28,6 @@
 #include "lsa.h"
 #include "pair_losses.h"
 #include "rotate_iou.h"
-#include "token_gemm.h"
 #include "tgemm.h"
 #include "msda.h"
 #include "msda_prologue.h"
@@ -462,21 +461,6 @@ int mdetr_adamw_step_counted(int param_dtype, void *param, float *master, const 
     const hipError_t e = mdetr::adamw_launch(param_dtype, param, master, grad, exp_avg, exp_avg_sq, n, n_no_decay, beta1, beta2, eps,
                                              weight_decay, 0.f, nullptr, static_cast<hipStream_t>(stream), step_count_dev, lr_dev, lr);
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_adamw_step_counted: launch failed: %s", hipGetErrorString(e));
-    return MDETR_OK;
-}
-
-int mdetr_token_linear(const void *x, const void *weight, const void *bias, void *y, int64_t T, int N, int K,
-                       int64_t ldx, int64_t ldy, int relu, int device, void *stream)
-{
-    if (T < 0 || N <= 0 || K <= 0) return fail(MDETR_E_ARG, "mdetr_token_linear: bad shape T=%lld N=%d K=%d", static_cast<long long>(T), N, K);
-    if (T == 0) return MDETR_OK;
-    if (!x || !weight || !y) return fail(MDETR_E_ARG, "mdetr_token_linear: null pointer");
-    if (!mdetr::token_gemm_supported(T, N, K, ldx, ldy, x, weight, y))
-        return fail(MDETR_E_ARG, "mdetr_token_linear: needs bf16, K in {64, 128, 256, 512}, N %% 8 == 0, 16-byte aligned x / weight rows");
-    DeviceScope dev(device);
-    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_token_linear: set device %d: %s", device, hipGetErrorString(dev.err));
-    const hipError_t e = mdetr::token_gemm_launch(x, weight, bias, y, T, N, K, ldx, ldy, relu != 0, static_cast<hipStream_t>(stream));
-    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_token_linear: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

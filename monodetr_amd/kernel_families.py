@@ -10,9 +10,9 @@ import os
 # Each can be forced with an environment variable of the same name (= "1").  Without any in the environment the step runs
 # with the COMMITTED list below.  (MDETR_MSDA_BF16 changes the MSDA operator's element types; the roofline accounting
 # follows it: msda_algorithmic_bytes(mixed=True).)
-AUTOTUNE_SWITCHES = ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN", "MDETR_MSDA_BF16", "MDETR_TOKEN_GEMM",
+AUTOTUNE_SWITCHES = ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN", "MDETR_MSDA_BF16",
                      "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD",
-                     "MDETR_CONV_STRIDED", "MDETR_CONV_WGRAD", "MDETR_CONV_STEM")
+                     "MDETR_CONV_STRIDED", "MDETR_CONV_WGRAD", "MDETR_CONV_STEM", "MDETR_TGEMM")
 ALL_SWITCHES = AUTOTUNE_SWITCHES
 # The measured configuration.  family -> the GPU tests that hold it to the default path / the framework operators
 # (all in tests/test_fused_gpu.py unless a file is named); a family without green tests is not listed.
@@ -29,19 +29,22 @@ SWITCH_TESTS = {
     "MDETR_CONV_STRIDED": "test_conv_strided_kernel_matches_the_library_convolution, test_training_step_with_the_convolution_kernels_*",
     "MDETR_CONV_WGRAD": "test_conv_wgrad_kernel_matches_the_library_weight_gradient, test_conv_strided_kernel_*, test_training_step_with_the_convolution_kernels_*",
     "MDETR_CONV_STEM": "test_conv_stem_kernel_matches_the_library_convolution, test_training_step_with_the_convolution_kernels_*",
+    "MDETR_TGEMM": "test_tgemm_gpu.py::test_tgemm_*, test_training_step_with_the_token_gemm_kernel_*, test_bottleneck_with_fused_tails_*",
     "MDETR_CONV3X3": "test_conv3x3_kernel_matches_the_library_convolution, test_training_step_with_the_conv3x3_kernel_*, test_conv3x3_module_with_a_trainable_bias_*",
 }
 COMMITTED_SWITCHES = {
     # (MDETR_CONV3X3: 1.6-3.5x MIOpen per kernel on the four ResNet stages, profiles/r02a_fusedbench.json; the step 249.3 vs
-    # 234.6 img/s, profiles/r02b_bench_committed_plus_conv3x3.json.  MDETR_TOKEN_GEMM stays off: slower than hipBLASLt.
+    # 234.6 img/s, profiles/r02b_bench_committed_plus_conv3x3.json.
     # MDETR_GROUP_NORM: 328.9 vs 308.7 img/s under graph replay, profiles/r02m_bench_with_gn.json.
     # MDETR_SMALL_WGRAD: 340.2 vs 333.6 img/s, profiles/r02q_bench_{with_small_wgrad,committed}.json.)
     # MDETR_CONV_WGRAD / _STRIDED / _STEM (round 3): every convolution of the backbone, the pyramid and the depth head by hand --
     # weight gradients 1.1-1.6x MIOpen's, the stem 2.9x, the stride-2 forms 0.4-2.8x (profiles/r03c_convbench.json); the step
     # 354.2 vs 348.0 img/s (r03d_bench_{all,committed}.json), no MIOpen kernel left in the iteration.)
+    # MDETR_TGEMM (round 5): every token-wise product of the bf16 step (1x1 convolutions, linear layers; forward and input gradient)
+    # through csrc/tgemm.hip with the tails in its epilogue: 396.6 -> 418.5 img/s in one call (profiles/r05f_step_ab.log).
     "bf16": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE", "MDETR_MSDA_BF16",
              "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD",
-             "MDETR_CONV_WGRAD", "MDETR_CONV_STRIDED", "MDETR_CONV_STEM"),
+             "MDETR_CONV_WGRAD", "MDETR_CONV_STRIDED", "MDETR_CONV_STEM", "MDETR_TGEMM"),
     "fp32": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE",
              "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD"),
 }
@@ -69,7 +72,7 @@ def apply_switches(names):
     from monodetr_amd.monodetr.ops.modules import ms_deform_attn
     ms_deform_attn._FUSED_PROLOGUE = "MDETR_MSDA_PROLOGUE" in names
     add_ln_ext.ENABLED = "MDETR_FUSED_LN" in names
-    linear._TOKEN_GEMM = "MDETR_TOKEN_GEMM" in names
+    linear._TGEMM = "MDETR_TGEMM" in names
     linear._GEMM_RELU = "MDETR_GEMM_RELU" in names
     bias_act_ext.ENABLED = "MDETR_FUSED_EPILOGUE" in names
     conv3x3_ext.ENABLED = "MDETR_CONV3X3" in names

@@ -22,7 +22,8 @@ from torch import nn
 
 from ..utils.misc import NestedTensor, mark_no_padding
 from .. import bias_act_ext, conv3x3_ext, conv_stem_ext, conv_taps_ext, decimate_ext
-from .linear import pointwise_conv, pointwise_conv_skip, pointwise_eligible, pointwise_relu_fusable, skip_relu_fusable
+from .linear import (pointwise_conv, pointwise_conv_residual_relu, pointwise_conv_skip, pointwise_eligible, pointwise_relu_fusable,
+                     pointwise_residual_relu_eligible, skip_relu_fusable)
 from .position_encoding import build_position_encoding
 
 
@@ -115,6 +116,19 @@ def prefold(pairs, dt):
         conv.__dict__["_prefolded"] = (w, b)
 
 
+def frozen_fold(conv, bn, dt):
+    """(W * scale, shift) of a FROZEN convolution + frozen BN pair in dtype `dt`, cached on the module until a buffer or the weight
+    changes."""
+    scale, shift = bn.affine()
+    key = (conv.weight.data_ptr(), conv.weight._version, bn._affine_key, dt)
+    if getattr(conv, "_folded_key", None) != key:
+        with torch.no_grad():
+            conv._folded = ((conv.weight * scale.view(-1, 1, 1, 1)).to(dt).contiguous(memory_format=torch.channels_last),
+                            shift.to(dt))
+        conv._folded_key = key
+    return conv._folded
+
+
 def conv_bn(x, conv, bn, relu, skip_out=False):
     """conv -> frozen BN (-> ReLU), with the BN folded into the convolution's weight and bias.
     For frozen convolutions (stem, layer1) the folded weight itself is cached.
@@ -126,7 +140,8 @@ def conv_bn(x, conv, bn, relu, skip_out=False):
                 and pointwise_eligible(x, conv.kernel_size, (1, 1), conv.padding, conv.groups):
             pre = conv.__dict__.get("_prefolded", None)
             dt = x.dtype if x.dtype in (torch.bfloat16, torch.float16) and not torch.is_autocast_enabled() else conv.weight.dtype
-            if pre is not None and pre[0].dtype == dt == x.dtype and (not relu or skip_relu_fusable(pre[1])):
+            if pre is not None and pre[0].dtype == dt == x.dtype and (not relu or skip_relu_fusable(
+                    pre[1], x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]), pre[0].reshape(pre[0].shape[0], -1))):
                 conv.__dict__.pop("_prefolded", None)
                 return pointwise_conv_skip(x, pre[0], pre[1], relu=relu)
         return conv_bn(x, conv, bn, relu), x
@@ -137,13 +152,7 @@ def conv_bn(x, conv, bn, relu, skip_out=False):
         if pre is not None and pre[0].dtype == dt:
             w, b = pre
         elif not conv.weight.requires_grad:
-            key = (conv.weight.data_ptr(), conv.weight._version, bn._affine_key, dt)
-            if getattr(conv, "_folded_key", None) != key:
-                with torch.no_grad():
-                    conv._folded = ((conv.weight * scale.view(-1, 1, 1, 1)).to(dt).contiguous(memory_format=torch.channels_last),
-                                    shift.to(dt))
-                conv._folded_key = key
-            w, b = conv._folded
+            w, b = frozen_fold(conv, bn, dt)
         else:
             # trainable convolution: the fold is part of the autograd graph (dW = dW_folded * scale); the
             # casts of the frozen (scale, shift) pair are cached per dtype
@@ -219,6 +228,15 @@ class Bottleneck(nn.Module):
             skip = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], False)
             y = conv_bn(x, self.conv1, self.bn1, True)
         y = conv_bn(y, self.conv2, self.bn2, True)
+        pre = self.conv3.__dict__.get("_prefolded")
+        if pre is None and not self.conv3.weight.requires_grad and isinstance(self.bn3, FrozenBatchNorm2d) and self.conv3.bias is None \
+                and y.dtype in (torch.bfloat16, torch.float16) and not torch.is_autocast_enabled():
+            pre = frozen_fold(self.conv3, self.bn3, y.dtype)     # (layer1: frozen, the folded weight is cached)
+        if pre is not None and pre[0].dtype == y.dtype and pointwise_residual_relu_eligible(y, pre[0], pre[1], skip):
+            # expansion + folded BN + "+ identity" + ReLU from ONE kernel (csrc/tgemm.hip's residual epilogue): the product is not
+            # read back by an elementwise pass
+            self.conv3.__dict__.pop("_prefolded", None)
+            return pointwise_conv_residual_relu(y, pre[0], pre[1], skip)
         y = conv_bn(y, self.conv3, self.bn3, False)
         if bias_act_ext.ENABLED and bias_act_ext.supported(y, None, skip):
             return bias_act_ext.bias_act(y, None, skip, relu=True)   # "+ identity" and the ReLU in one pass

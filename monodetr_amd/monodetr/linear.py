@@ -9,7 +9,6 @@ GPU item.  Here the token axis is split into C chunks evaluated as one batched G
 Pure library plumbing (torch.bmm -> hipBLASLt); numerics are those of a split-K GEMM.
 """
 import os
-import sys
 
 import torch
 import torch.nn.functional as F
@@ -18,18 +17,6 @@ from torch import nn
 from .. import colsum_ext, small_wgrad_ext
 
 _MIN_TOKENS = 4096
-# MDETR_TOKEN_GEMM=1: forward and input-gradient products of K in {64, 128, 256, 512} bf16 layers through the
-# LDS-resident-weight kernel (csrc/token_gemm.hip).  Off until its first GPU validation
-# (tests/test_fused_gpu.py); the library GEMM is the default.
-_TOKEN_GEMM = os.environ.get("MDETR_TOKEN_GEMM") == "1"
-# ... except for NARROW outputs of very tall inputs (layer1's 256 -> 64 and 64 -> 64 convolutions over 245 760 pixels), where the
-# library picks a 64 x 64 macro-tile and runs at a quarter of the HBM rate (83 us vs 34 us, profiles/r02*): those take the kernel
-# unless MDETR_TOKEN_GEMM_NARROW=0
-_TOKEN_GEMM_NARROW = os.environ.get("MDETR_TOKEN_GEMM_NARROW", "1") != "0"
-
-
-def _wants_token_gemm(x2, weight):
-    return _TOKEN_GEMM or (_TOKEN_GEMM_NARROW and x2.is_cuda and weight.shape[0] <= 64 and x2.shape[0] >= 65536)
 # MDETR_GEMM_RELU=1: "linear -> ReLU" as one library GEMM with the RELU_BIAS epilogue (torch._addmm_activation ->
 # hipBLASLt) instead of a GEMM and an elementwise pass.  Off until timed on a GPU.
 _GEMM_RELU = os.environ.get("MDETR_GEMM_RELU") == "1"
@@ -61,7 +48,9 @@ def _act_backward(dy, y, scale=1.0):
     if scale == 1.0:
         return torch.ops.aten.threshold_backward(dy, y, 0.0)
     from .. import bias_act_ext
-    return bias_act_ext.act_backward(dy, y, scale)
+    if bias_act_ext.supported(y):
+        return bias_act_ext.act_backward(dy, y, scale)
+    return torch.where(y > 0, dy * scale, torch.zeros_like(dy))
 
 
 def _split_count(T):
@@ -179,8 +168,8 @@ def token_linear_skip(x, weight, bias=None, pos=None, relu=False, dropout_p=0.0)
     """-> (token_linear(x + pos, weight, bias[, relu, dropout]), x'): use x' (== x) for everything that follows on the residual path;
     see `_TokenLinearSkip`.  Plain tensors out of it when the fused form does not apply.  relu / dropout_p: the caller asks
     `skip_relu_fusable` / `skip_dropout_fusable` first."""
-    if x.is_cuda and x.dtype == weight.dtype and x.numel() // x.shape[-1] >= _MIN_TOKENS and torch.is_grad_enabled() and x.requires_grad \
-            and not torch.is_autocast_enabled() and (pos is None or not pos.requires_grad) and not _TOKEN_GEMM \
+    if (x.is_cuda or _tgemm_backend()) and x.dtype == weight.dtype and x.numel() // x.shape[-1] >= _MIN_TOKENS and torch.is_grad_enabled() and x.requires_grad \
+            and not torch.is_autocast_enabled() and (pos is None or not pos.requires_grad) \
             and (not relu or skip_relu_fusable(bias, x, weight)) and (dropout_p <= 0.0 or skip_dropout_fusable(x, weight, bias)):
         return _TokenLinearSkip.apply(x, weight, bias, pos, relu, dropout_p)
     if dropout_p > 0.0:
@@ -189,30 +178,32 @@ def token_linear_skip(x, weight, bias=None, pos=None, relu=False, dropout_p=0.0)
 
 
 def skip_relu_fusable(bias, x=None, weight=None):
-    if _TOKEN_GEMM:
-        return False
     if x is not None and weight is not None and _tgemm_ok(x.reshape(-1, x.shape[-1]), weight, bias):
         return True
     return _GEMM_RELU and bias is not None and bias.dim() == 1 and bias.is_contiguous()
 
 
 def skip_dropout_fusable(x, weight, bias):
-    return x.is_cuda and not _TOKEN_GEMM and _tgemm_ok(x.reshape(-1, x.shape[-1]), weight, bias)
+    return (x.is_cuda or _tgemm_backend()) and x.dtype == weight.dtype and x.numel() // x.shape[-1] >= _MIN_TOKENS \
+        and not torch.is_autocast_enabled() and _tgemm_ok(x.reshape(-1, x.shape[-1]), weight, bias)
 
 
 class _TokenLinear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, fused_relu=False, wide_out=False):
+    def forward(ctx, x, weight, bias, fused_relu=False, wide_out=False, dropout_p=0.0):
         """fused_relu: ReLU in the epilogue of the GEMM kernel or, failing that, of the library GEMM.
+        dropout_p (csrc/tgemm.hip only, behind the ReLU): Dropout in the same epilogue.
         wide_out: bf16 operands, fp32 RESULT (the fp32 accumulator is written out unrounded) -- the decoder's deformable
         cross-attention differences neighbouring value rows for d/d(location), and 8 mantissa bits on the values made those
         gradients the least accurate of the bf16 model (cosine 0.86-0.98 against the fp32 model, round 2)."""
         ctx.has_bias = bias is not None
         ctx.fused_relu = False
         ctx.wide_out = bool(wide_out)
+        ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
         x2 = x.reshape(-1, x.shape[-1])
         if _tgemm_ok(x2, weight, bias):
-            y = _fwd_product(x2, weight, bias, fused_relu, out_dtype=torch.float32 if wide_out else torch.bfloat16)
+            seed, seed_dev = _drop_seed(x, dropout_p)
+            y = _fwd_product(x2, weight, bias, fused_relu, None, dropout_p, seed, seed_dev, torch.float32 if wide_out else torch.bfloat16)
             y = y.view(x.shape[:-1] + (weight.shape[0],))
             ctx.fused_relu = bool(fused_relu)
             if fused_relu:
@@ -220,22 +211,14 @@ class _TokenLinear(torch.autograd.Function):
             else:
                 ctx.save_for_backward(x, weight)
             return y
+        if dropout_p > 0.0:
+            raise RuntimeError("token_linear: dropout is only fused into csrc/tgemm.hip's epilogue")
         if wide_out:
             y = torch.mm(x2, weight.t(), out_dtype=torch.float32)
             if bias is not None:
                 y += bias.float()
             ctx.save_for_backward(x, weight)
             return y.view(x.shape[:-1] + (weight.shape[0],))
-        if _wants_token_gemm(x2, weight):
-            from .. import token_gemm_ext
-            if token_gemm_ext.supported(x2, weight):
-                y = token_gemm_ext.token_gemm(x2, weight, bias, relu=fused_relu).view(x.shape[:-1] + (weight.shape[0],))
-                if fused_relu:
-                    ctx.fused_relu = True
-                    ctx.save_for_backward(x, weight, y)
-                else:
-                    ctx.save_for_backward(x, weight)
-                return y
         if fused_relu:                                               # library GEMM, RELU_BIAS epilogue
             y = torch._addmm_activation(bias, x2, weight.t()).view(x.shape[:-1] + (weight.shape[0],))
             ctx.fused_relu = True
@@ -249,7 +232,7 @@ class _TokenLinear(torch.autograd.Function):
     def backward(ctx, dy):
         if ctx.fused_relu:
             x, weight, y = ctx.saved_tensors
-            dy = torch.ops.aten.threshold_backward(dy, y, 0.0)       # ReLU of the epilogue: dy where y > 0, one launch
+            dy = _act_backward(dy.contiguous(), y, ctx.scale)        # ReLU (+ Dropout) of the epilogue: dy where y > 0, one launch
         else:
             x, weight = ctx.saved_tensors
         if ctx.wide_out:
@@ -258,16 +241,9 @@ class _TokenLinear(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         dy2 = dy.reshape(-1, dy.shape[-1])
         if ctx.needs_input_grad[0]:
-            dx = None
-            if _TOKEN_GEMM:
-                from .. import token_gemm_ext
-                wt = weight.t().contiguous()                        # [K_in, N]: dX = dY (W^T)^T, contraction over N
-                if dy2.is_contiguous() and token_gemm_ext.supported(dy2, wt):
-                    dx = token_gemm_ext.token_gemm(dy2, wt).view_as(x)
-            if dx is None:
-                dx = _input_gradient(dy2, weight).view_as(x)
+            dx = _input_gradient(dy2, weight).view_as(x)
         dw, db = _weight_bias_grads(x2, dy2, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class _TokenLinearResidualRelu(torch.autograd.Function):
@@ -321,21 +297,35 @@ def split_rows(packed, *sizes):
 
 
 def _kernel_relu(x, weight, bias=None):
-    """Can the ReLU ride in the GEMM's epilogue?  (the token-GEMM kernel, or the library's RELU_BIAS epilogue)"""
-    if _wants_token_gemm(x.reshape(-1, x.shape[-1]), weight):
-        from .. import token_gemm_ext
-        if token_gemm_ext.supported(x.reshape(-1, x.shape[-1]), weight):
-            return True
+    """Can the ReLU ride in the GEMM's epilogue?  (csrc/tgemm.hip, or the library's RELU_BIAS epilogue)"""
+    if _tgemm_ok(x.reshape(-1, x.shape[-1]), weight, bias):
+        return True
     return _GEMM_RELU and bias is not None and bias.dim() == 1 and bias.is_contiguous()
 
 
-def token_linear(x, weight, bias=None, relu=False, wide_out=False):
+def dropout_fusable(x, weight, bias):
+    """Can `token_linear(..., relu=True, dropout_p=p)` run ReLU and Dropout inside the GEMM's epilogue?  (csrc/tgemm.hip)"""
+    return (x.is_cuda or _tgemm_backend()) and x.dtype == weight.dtype and x.numel() // x.shape[-1] >= _MIN_TOKENS and torch.is_grad_enabled() \
+        and not torch.is_autocast_enabled() and _tgemm_ok(x.reshape(-1, x.shape[-1]), weight, bias)
+
+
+def _tgemm_backend():
+    from .. import tgemm_ext
+    return tgemm_ext._backend is not None
+
+
+def token_linear(x, weight, bias=None, relu=False, wide_out=False, dropout_p=0.0):
     """F.linear (followed by ReLU if `relu`) with the split-K weight gradient for big token counts on the GPU;
-    plain F.linear otherwise.  With the token-GEMM kernel enabled the ReLU runs in its epilogue.
-    wide_out (bf16 operands on the GPU only): the result in fp32, see `_TokenLinear.forward`."""
+    plain F.linear otherwise.  With a GEMM kernel of this repository enabled the ReLU runs in its epilogue.
+    wide_out (bf16 operands on the GPU only): the result in fp32, see `_TokenLinear.forward`.
+    dropout_p: Dropout behind the ReLU in the same epilogue (ask `dropout_fusable` first)."""
+    if dropout_p > 0.0:
+        if not (relu and dropout_fusable(x, weight, bias)):
+            raise RuntimeError("token_linear: ask dropout_fusable before passing dropout_p (ReLU + Dropout ride in csrc/tgemm.hip's epilogue only)")
+        return _TokenLinear.apply(x, weight, bias, True, False, dropout_p)
     if wide_out and not relu and x.is_cuda and x.dtype == weight.dtype == torch.bfloat16 and not torch.is_autocast_enabled():
         return _TokenLinear.apply(x, weight, bias, False, True)
-    if x.is_cuda and x.dtype == weight.dtype and x.numel() // x.shape[-1] >= _MIN_TOKENS and torch.is_grad_enabled() \
+    if (x.is_cuda or _tgemm_backend()) and x.dtype == weight.dtype and x.numel() // x.shape[-1] >= _MIN_TOKENS and torch.is_grad_enabled() \
             and not torch.is_autocast_enabled():
         if relu and _kernel_relu(x, weight, bias):
             return _TokenLinear.apply(x, weight, bias, True)
@@ -346,7 +336,7 @@ def token_linear(x, weight, bias=None, relu=False, wide_out=False):
 
 
 def pointwise_eligible(x, kernel_size, stride, padding, groups):
-    return (x.is_cuda and tuple(kernel_size) == (1, 1) and tuple(stride) == (1, 1) and tuple(padding) == (0, 0)
+    return ((x.is_cuda or _tgemm_backend()) and tuple(kernel_size) == (1, 1) and tuple(stride) == (1, 1) and tuple(padding) == (0, 0)
             and groups == 1 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))
 
 
@@ -401,7 +391,7 @@ def pointwise_conv_residual_relu(x, weight, bias, identity):
 def pointwise_relu_fusable(x, weight, bias):
     """Would `pointwise_conv(..., relu=True)` run the ReLU inside the GEMM?  (callers that apply an in-place ReLU
     themselves otherwise)"""
-    if not (_TOKEN_GEMM or _GEMM_RELU):                              # the default path pays nothing for the question
+    if not (_GEMM_RELU or _TGEMM):                    # the default path pays nothing for the question
         return False
     C = x.shape[1]
     return (x.numel() // C >= _MIN_TOKENS and torch.is_grad_enabled() and not torch.is_autocast_enabled()
@@ -411,18 +401,22 @@ def pointwise_relu_fusable(x, weight, bias):
 def ffn_hidden(x, lin, dropout, activation=F.relu, tokenwise=True, skip=False):
     """``dropout(activation(lin(x)))`` -- the first half of an FFN (depthaware_transformer.py:334-337, :431-435;
     depth_predictor/transformer.py:57-65).  ``tokenwise``: the GEMM through `token_linear` (the encoder's 81 600 token
-    rows) instead of the module call.  With MDETR_FUSED_EPILOGUE=1 ReLU and Dropout are one pass behind the GEMM
-    (csrc/bias_act.hip); otherwise the ReLU rides in the GEMM's epilogue when one of the GEMM switches allows it."""
+    rows) instead of the module call.  With csrc/tgemm.hip (MDETR_TGEMM) bias, ReLU and Dropout are the product's epilogue;
+    otherwise, with MDETR_FUSED_EPILOGUE=1, ReLU and Dropout are one pass behind the GEMM (csrc/bias_act.hip), or the ReLU
+    rides in the library GEMM's epilogue when a GEMM switch allows it."""
     from .. import bias_act_ext
     p = dropout.p if (dropout is not None and dropout.training) else 0.0
     if skip:
-        # -> (hidden, x'): x' == x, to be used by the residual connection that follows (`token_linear_skip`); the ReLU then
-        # rides with the Dropout pass (or is its own pass) instead of the GEMM's epilogue
+        # -> (hidden, x'): x' == x, to be used by the residual connection that follows (`token_linear_skip`)
+        if activation is F.relu and tokenwise and torch.is_grad_enabled() and x.requires_grad and skip_dropout_fusable(x, lin.weight, lin.bias):
+            return token_linear_skip(x, lin.weight, lin.bias, relu=True, dropout_p=p)
         h, x_out = token_linear_skip(x, lin.weight, lin.bias)
         if activation is F.relu and bias_act_ext.ENABLED and p > 0.0 and torch.is_grad_enabled() and bias_act_ext.supported(h):
             return bias_act_ext.bias_act(h, None, None, relu=True, dropout_p=p), x_out
         h = activation(h)
         return (dropout(h) if dropout is not None else h), x_out
+    if activation is F.relu and tokenwise and p > 0.0 and dropout_fusable(x, lin.weight, lin.bias):
+        return token_linear(x, lin.weight, lin.bias, relu=True, dropout_p=p)
     first = (lambda relu: token_linear(x, lin.weight, lin.bias, relu=relu)) if tokenwise else \
         (lambda relu: F.relu(lin(x)) if relu else lin(x))
     if activation is not F.relu:

@@ -52,14 +52,14 @@ def main():
         res["add_ln_bwd_" + tag] = row(timeit(bwd, a.iters), 4 * T * C * e)
 
     # ---- token GEMM ------------------------------------------------------------------------------------------------
-    from monodetr_amd import token_gemm_ext
+    from monodetr_amd import tgemm_ext
     w = (torch.randn(C, C, device=dev) * 0.05).to(torch.bfloat16)
     b = torch.randn(C, device=dev).to(torch.bfloat16)
     xt = x.detach()
     byts = e * (T * C + T * C + C * C)
-    res["token_gemm_256x256"] = row(timeit(lambda: token_gemm_ext.token_gemm(xt, w, b), a.iters), byts, TFLOPs=None)
+    res["token_gemm_256x256"] = row(timeit(lambda: tgemm_ext.tgemm(xt, w, b), a.iters), byts, TFLOPs=None)
     res["library_gemm_256x256"] = row(timeit(lambda: F.linear(xt, w, b), a.iters), byts)
-    res["token_gemm_256x256_relu"] = row(timeit(lambda: token_gemm_ext.token_gemm(xt, w, b, relu=True), a.iters), byts)
+    res["token_gemm_256x256_relu"] = row(timeit(lambda: tgemm_ext.tgemm(xt, w, b, relu=True), a.iters), byts)
     res["library_gemm_256x256_relu"] = row(timeit(lambda: F.relu(F.linear(xt, w, b)), a.iters), byts)
     res["library_gemm_256x256_relu_epilogue"] = row(timeit(lambda: torch._addmm_activation(b, xt, w.t()), a.iters), byts)   # MDETR_GEMM_RELU
 
@@ -82,7 +82,7 @@ def main():
         res["ffn_relu_dropout_bwd_" + tag] = row(timeit(lambda: torch.autograd.grad(y, (h,), dy, retain_graph=True), a.iters), 3 * T * C * e)
     w128 = (torch.randn(128, C, device=dev) * 0.05).to(torch.bfloat16)
     byts = e * (T * C + T * 128 + 128 * C)
-    res["token_gemm_256x128"] = row(timeit(lambda: token_gemm_ext.token_gemm(xt, w128), a.iters), byts)
+    res["token_gemm_256x128"] = row(timeit(lambda: tgemm_ext.tgemm(xt, w128), a.iters), byts)
     res["library_gemm_256x128"] = row(timeit(lambda: F.linear(xt, w128), a.iters), byts)
 
     # the backbone's layer1 expansions / reductions as token GEMMs (245 760 tokens)
@@ -91,9 +91,9 @@ def main():
     w_up, w_dn = (torch.randn(256, 64, device=dev) * 0.1).to(torch.bfloat16), (torch.randn(64, 256, device=dev) * 0.05).to(torch.bfloat16)
     b_up, b_dn = torch.randn(256, device=dev).to(torch.bfloat16), torch.randn(64, device=dev).to(torch.bfloat16)
     byts = e * (T1 * 64 + T1 * 256 + 64 * 256)
-    res["token_gemm_layer1_64to256"] = row(timeit(lambda: token_gemm_ext.token_gemm(x64, w_up, b_up), a.iters), byts)
+    res["token_gemm_layer1_64to256"] = row(timeit(lambda: tgemm_ext.tgemm(x64, w_up, b_up), a.iters), byts)
     res["library_gemm_layer1_64to256"] = row(timeit(lambda: F.linear(x64, w_up, b_up), a.iters), byts)
-    res["token_gemm_layer1_256to64_relu"] = row(timeit(lambda: token_gemm_ext.token_gemm(x256, w_dn, b_dn, relu=True), a.iters), byts)
+    res["token_gemm_layer1_256to64_relu"] = row(timeit(lambda: tgemm_ext.tgemm(x256, w_dn, b_dn, relu=True), a.iters), byts)
     res["library_gemm_layer1_256to64_relu"] = row(timeit(lambda: F.relu_(F.linear(x256, w_dn, b_dn)), a.iters), byts)
 
     # ---- 3x3 convolutions of the backbone: csrc/conv3x3.hip (shift + ReLU inside) vs the library convolution + its tail ----

@@ -1,6 +1,6 @@
-"""The token-wise products of one training iteration (B = 8, 384 x 1280), each timed three ways in one process: the library GEMM
-(+ its separate elementwise tail where the call site has one), csrc/tgemm.hip with the tail in its epilogue (default tile, and with
---sweep every tile shape / pipeline depth), and the weight-in-registers form of csrc/token_gemm.hip where it applies.
+"""The token-wise products of one training iteration (B = 8, 384 x 1280), each timed two ways in one process: the library GEMM
+(+ its separate elementwise tail where the call site has one) and csrc/tgemm.hip with the tail in its epilogue (default tile, and
+with --sweep every tile shape / pipeline depth).
 
 Timing: `reps` launches captured into one hipGraph and replayed (no host launch gaps between kernels), operands rotating over enough
 buffer sets to exceed the 256 MB Infinity Cache (a product never finds its own previous input there); microseconds per launch,
@@ -88,7 +88,7 @@ def main():
     a = ap.parse_args()
     global EAGER
     EAGER = a.eager
-    from monodetr_amd import bias_act_ext, tgemm_ext, token_gemm_ext
+    from monodetr_amd import bias_act_ext, tgemm_ext
     dev = torch.device("cuda", 0)
     res = {}
     cases = []
@@ -154,11 +154,6 @@ def main():
                 os.environ.pop(k, None)
         best = min(v for k, v in row.items() if k.startswith("tgemm") and k.endswith("_us"))
         row["tgemm_best_us"], row["tgemm_frac_of_bound"] = best, round(row["bound_us"] / best, 3)
-        # ---- the weight-in-registers form (plain products, K <= 512, forward only)
-        if not nn and tail in ("", "relu") and token_gemm_ext.supported(xs[0], w):
-            os.environ["MDETR_TOKEN_GEMM_DIRECT"] = "2"
-            row["regs_us"] = graph_time(lambda i: token_gemm_ext.token_gemm(xs[i], w, b, relu=tail == "relu"), nsets, a.reps)
-            os.environ.pop("MDETR_TOKEN_GEMM_DIRECT", None)
         # ---- agreement (one set): element-wise against the fp64 product is the tests' job; here the two paths side by side
         if tail != "accum" and tail != "relu_drop":
             y_l = lib(0).float().clone()

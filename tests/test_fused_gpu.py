@@ -216,56 +216,8 @@ def test_training_step_with_fused_criterion_matches_default():
         assert abs(a - b) <= 2e-2 * abs(a), traj
 
 
-@pytest.mark.parametrize("T,K,N,relu,bias", [(81600, 256, 256, False, True), (81600, 256, 1024, True, True),
-                                             (81600, 256, 128, False, True), (4400, 256, 256, False, False),
-                                             (61440, 128, 512, False, True), (61440, 512, 128, True, True), (1000, 256, 384, False, True),
-                                             (33, 256, 8, False, True), (245760, 64, 256, False, True), (245760, 256, 64, True, True)])
-def test_token_gemm_matches_the_library_gemm(T, K, N, relu, bias):
-    """csrc/token_gemm.hip (weight resident in LDS, MFMA 32x32x16 bf16) against F.linear evaluated in fp32 on the
-    same bf16 inputs; ragged T (tile tail), N below / above one weight block, strided x."""
-    from monodetr_amd.token_gemm_ext import supported, token_gemm
-    torch.manual_seed(T + N)
-    big = torch.randn(T, K + 64, device="cuda").to(torch.bfloat16)
-    x = big[:, :K]                                              # row stride K + 64: ldx != K
-    w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
-    b = torch.randn(N, device="cuda").to(torch.bfloat16) if bias else None
-    assert supported(x, w)
-    y = token_gemm(x, w, b, relu)
-    ref = torch.nn.functional.linear(x.float(), w.float(), b.float() if bias else None)
-    if relu:
-        ref = ref.relu()
-    assert y.shape == ref.shape and y.dtype == torch.bfloat16
-    # bf16 output rounding (2^-9 relative) on top of fp32 accumulation
-    assert (y.float() - ref).abs().max() <= 1e-2 * max(1.0, ref.abs().max().item())
-    assert ((y.float() - ref).norm() / ref.norm()).item() < 4e-3
-
-
-@pytest.mark.parametrize("T,K,N,relu", [(81600, 256, 256, False), (81600, 256, 384, True), (4400, 256, 256, True), (33, 256, 8, False),
-                                        (245760, 64, 256, False), (61440, 128, 512, True), (1000, 256, 264, False), (61440, 512, 128, True)])
-def test_token_gemm_forms_agree_bit_for_bit(T, K, N, relu, monkeypatch):
-    """MDETR_TOKEN_GEMM_DIRECT = 0 (inputs staged through LDS), 1 (operands straight from global memory), 2 (weight slices in
-    registers, the tokens of a tile shared through LDS, the output tile written in whole rows; also with MDETR_TOKEN_GEMM_YSTAGE=0):
-    the same products in the same order -- identical bits; strided input rows, ragged tile tails, a partial last column block."""
-    from monodetr_amd.token_gemm_ext import token_gemm
-    torch.manual_seed(T + N)
-    x = torch.randn(T, K + 64, device="cuda").to(torch.bfloat16)[:, :K]
-    w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
-    b = torch.randn(N, device="cuda").to(torch.bfloat16)
-    outs = {}
-    for form, ystage in (("0", "1"), ("1", "1"), ("2", "1"), ("2", "0")):
-        monkeypatch.setenv("MDETR_TOKEN_GEMM_DIRECT", form)
-        monkeypatch.setenv("MDETR_TOKEN_GEMM_YSTAGE", ystage)
-        outs[form + ystage] = token_gemm(x, w, b, relu)
-    ref = torch.nn.functional.linear(x.float(), w.float(), b.float())
-    if relu:
-        ref = ref.relu()
-    assert (outs["01"].float() - ref).abs().max() <= 1e-2 * max(1.0, ref.abs().max().item())
-    for k, v in outs.items():
-        assert torch.equal(v, outs["01"]), k
-
-
 def test_token_linear_layer_with_the_token_gemm_matches_default():
-    """token_linear forward + input gradient through the kernel (MDETR_TOKEN_GEMM) against the library path."""
+    """token_linear forward + input gradient through csrc/tgemm.hip (MDETR_TGEMM) against the library path."""
     import importlib
     from monodetr_amd.monodetr import linear
     torch.manual_seed(9)
@@ -276,12 +228,12 @@ def test_token_linear_layer_with_the_token_gemm_matches_default():
     for relu in (False, True):                                      # relu=True: ReLU in the kernel's epilogue
         res = {}
         for flag in (False, True):
-            linear._TOKEN_GEMM = flag
+            linear._TGEMM = flag
             try:
                 y = linear.token_linear(x, w, b, relu=relu)
                 res[flag] = (y.detach().float(),) + tuple(t.float() for t in torch.autograd.grad(y, (x, w, b), g))
             finally:
-                linear._TOKEN_GEMM = False
+                linear._TGEMM = False
         for a, c in zip(res[False], res[True]):
             assert ((a - c).norm() / a.norm()).item() < 6e-3
 

@@ -27,7 +27,7 @@ def clean_env(monkeypatch):
 def test_candidate_sets():
     bf = sp.probe_configs("bf16")
     assert bf[0] == [] and set(bf[-1]) == set(bench.AUTOTUNE_SWITCHES) and all(set(a) < set(b) for a, b in zip(bf, bf[1:]))   # nested
-    assert not {"MDETR_TOKEN_GEMM", "MDETR_MSDA_BF16", "MDETR_CONV3X3"} & set(sum(sp.probe_configs("fp32"), []))                          # bf16-body kernels
+    assert not {"MDETR_TGEMM", "MDETR_MSDA_BF16", "MDETR_CONV3X3"} & set(sum(sp.probe_configs("fp32"), []))                          # bf16-body kernels
     # the roofline accounting follows the operator's element types
     f32, mixed = bench.msda_algorithmic_bytes(8, 10200, True), bench.msda_algorithmic_bytes(8, 10200, True, mixed=True)
     assert f32 - mixed == 2 * 8 * 10200 * 8 * 32 * 2                                        # value and grad_out at half width
@@ -37,7 +37,7 @@ def test_choice_takes_the_fastest_admissible_candidate():
     base = {"switches": [], "losses": [30.0, 29.0, 28.5], "ms": 38.0}
     good = {"switches": ["MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW"], "losses": [30.1, 29.2, 28.4], "ms": 34.0}
     better_but_wrong = {"switches": ["MDETR_FUSED_LN"], "losses": [30.0, 35.0, 28.5], "ms": 30.0}
-    nan = {"switches": ["MDETR_TOKEN_GEMM"], "losses": [float("nan"), 1.0, 1.0], "ms": 20.0}
+    nan = {"switches": ["MDETR_TGEMM"], "losses": [float("nan"), 1.0, 1.0], "ms": 20.0}
     slower = {"switches": ["MDETR_MSDA_PROLOGUE"], "losses": [30.0, 29.0, 28.5], "ms": 39.0}
     chosen, why = sp.choose_config([base, good, better_but_wrong, nan, slower])
     assert chosen == sorted(good["switches"]) and "admissible" in why
@@ -115,9 +115,9 @@ def test_apply_switches_sets_and_clears_the_module_flags():
     from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func
     from monodetr_amd.monodetr.ops.modules import ms_deform_attn
     bench.apply_switches({"MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE"})
-    assert add_ln_ext.ENABLED and ms_deform_attn._FUSED_PROLOGUE and not linear._TOKEN_GEMM and not ms_deform_attn_func._NATIVE_BF16
+    assert add_ln_ext.ENABLED and ms_deform_attn._FUSED_PROLOGUE and not linear._TGEMM and not ms_deform_attn_func._NATIVE_BF16
     bench.apply_switches(set())
-    assert not (add_ln_ext.ENABLED or ms_deform_attn._FUSED_PROLOGUE or linear._TOKEN_GEMM or ms_deform_attn_func._NATIVE_BF16)
+    assert not (add_ln_ext.ENABLED or ms_deform_attn._FUSED_PROLOGUE or linear._TGEMM or ms_deform_attn_func._NATIVE_BF16)
     bench.apply_switches({"MDETR_MSDA_BF16"})
     assert ms_deform_attn_func._NATIVE_BF16
     bench.apply_switches(set())

@@ -93,3 +93,65 @@ def test_tgemm_dropout_tail_is_the_bias_act_decision():
     assert torch.equal(y, want)
     frac = (y == 0).float().mean().item()
     assert 0.5 < frac < 0.6                                          # half negative + a tenth of the rest dropped
+
+
+def test_training_step_with_the_token_gemm_kernel_matches_default():
+    """The whole bf16 training iteration with MDETR_TGEMM on top of the other committed families against the same list without it:
+    loss trajectories of three optimizer steps (dropout off: the two routes draw their masks at different sites)."""
+    import bench
+    from model_init import disable_dropout_
+    dev = torch.device("cuda", 0)
+    base = tuple(sorted(set(bench.COMMITTED_SWITCHES["bf16"]) - {"MDETR_TGEMM"}))
+    traj = {}
+    try:
+        for names in (base, base + ("MDETR_TGEMM",)):
+            step = bench.TrainStep(dev, 8, "bf16", size=(192, 640), switches=names)
+            disable_dropout_(step.raw_model)
+            traj[names] = [float(step()) for _ in range(3)]
+    finally:
+        bench.apply_switches(set())
+    for a, b in zip(traj[base], traj[base + ("MDETR_TGEMM",)]):
+        assert abs(a - b) <= 2e-2 * abs(a), traj
+
+
+def test_bottleneck_with_fused_tails_on_the_gpu_is_as_close_to_fp32_as_the_default_route(monkeypatch):
+    """ResNet bottlenecks at layer2's shape (B = 8, 48 x 160) with the conv1 / conv3 tails in csrc/tgemm.hip's epilogue: outputs and
+    every gradient against the block evaluated in fp32 on the same bf16-valued parameters, no worse than the default bf16 route."""
+    import copy
+    from monodetr_amd.monodetr import backbone, linear
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(2)
+
+    def rel(a, b):
+        return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item()
+
+    for down in (False, True):
+        inpl, planes = (512, 128) if not down else (256, 128)
+        ds = torch.nn.Sequential(torch.nn.Conv2d(inpl, planes * 4, 1, 1, bias=False), backbone.FrozenBatchNorm2d(planes * 4)) if down else None
+        blk = backbone.Bottleneck(inpl, planes, 1, ds).to(dev)
+        for m in blk.modules():
+            if isinstance(m, backbone.FrozenBatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2); m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+        x = (torch.randn(8, inpl, 48, 160, device=dev) * 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        for p in blk.parameters():                                     # bf16-valued fp32 parameters (the backbone keeps fp32 masters)
+            p.data = p.data.to(torch.bfloat16).float()
+        res = {}
+        for on in (False, True):
+            monkeypatch.setattr(linear, "_TGEMM", on)
+            for p in blk.parameters():
+                p.grad = None
+            x.grad = None
+            pairs = [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)] + ([(ds[0], ds[1])] if down else [])
+            backbone.prefold(pairs, torch.bfloat16)
+            y = blk(x)
+            (y.float() * 0.01).sum().backward()
+            res[on] = (y.detach().float(), x.grad.float().clone(), {n: p.grad.float().clone() for n, p in blk.named_parameters()})
+        monkeypatch.setattr(linear, "_TGEMM", False)
+        ref = copy.deepcopy(blk).double()
+        x64 = x.detach().double().requires_grad_(True)
+        y64 = ref(x64)
+        (y64 * 0.01).sum().backward()
+        assert rel(res[True][0], y64.detach()) <= max(1.2 * rel(res[False][0], y64.detach()), 6e-3)
+        assert rel(res[True][1], x64.grad) <= max(1.3 * rel(res[False][1], x64.grad), 2e-2)
+        for n, p in ref.named_parameters():
+            assert rel(res[True][2][n], p.grad) <= max(1.3 * rel(res[False][2][n], p.grad), 2e-2), n

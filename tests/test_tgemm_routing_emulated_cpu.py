@@ -1,0 +1,129 @@
+"""MDETR_TGEMM routing (monodetr/linear.py, monodetr/backbone.py) with csrc/tgemm.hip running on the CPU shim: every token-wise
+product of a module goes through the kernel (forward, input gradient, fused tails) and the module's outputs and gradients stay
+those of the default route on the same bf16 parameters."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import native_emul
+
+
+@pytest.fixture
+def tgemm_on(monkeypatch):
+    from monodetr_amd import bias_act_ext, small_wgrad_ext, tgemm_ext
+    from monodetr_amd.monodetr import linear
+    L = native_emul.lib()
+    monkeypatch.setattr(tgemm_ext, "_backend", L)
+    monkeypatch.setattr(bias_act_ext, "_backend", L)
+    monkeypatch.setattr(small_wgrad_ext, "ENABLED", False)            # (weight gradients through the plain products here)
+    monkeypatch.setattr(linear, "_TGEMM", True)
+    calls = []
+    real = tgemm_ext.tgemm
+    monkeypatch.setattr(tgemm_ext, "tgemm", lambda *a, **k: (calls.append((tuple(a[0].shape), k.get("nn", False), a[3] is not None if len(a) > 3 else False,
+                                                                          k.get("relu", False), k.get("dropout_p", 0.0))), real(*a, **k))[1])
+    return calls
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item()
+
+
+def test_token_linear_forms_take_the_kernel_and_match_autograd(tgemm_on):
+    from monodetr_amd.monodetr import linear
+    g = torch.Generator().manual_seed(3)
+    T, K, N = 4200, 64, 72
+    x = (torch.randn(3, T // 3, K, generator=g) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(torch.bfloat16).requires_grad_(True)
+    proj = torch.randn(3, T // 3, N, generator=g).to(torch.bfloat16)
+
+    def ref(relu, skip):
+        x2, w2, b2 = (t.detach().float().requires_grad_(True) for t in (x, w, b))
+        y = F.linear(x2, w2, b2)
+        y = F.relu(y) if relu else y
+        ((y * proj.float()).sum() + ((x2 * 2.0).sum() if skip else 0.0)).backward()
+        return y, x2.grad, w2.grad, b2.grad
+
+    for relu in (False, True):
+        for skip in (False, True):
+            for t in (x, w, b):
+                t.grad = None
+            tgemm_on.clear()
+            if skip:
+                y, xs = linear.token_linear_skip(x, w, b, relu=relu)
+                ((y * proj).float().sum() + (xs.float() * 2.0).sum()).backward()
+            else:
+                y = linear.token_linear(x, w, b, relu=relu)
+                (y * proj).float().sum().backward()
+            want = ref(relu, skip)
+            assert _rel(y, want[0]) <= 4e-3
+            assert _rel(x.grad, want[1]) <= 6e-3 and _rel(w.grad, want[2]) <= 1e-2 and _rel(b.grad, want[3]) <= 1e-2
+            kinds = [(c[1], c[2]) for c in tgemm_on]
+            assert (False, False) in kinds                             # forward through the kernel ...
+            assert (True, skip) in kinds                               # ... and the input gradient, the residual gradient summed inside
+
+
+def test_ffn_first_half_runs_relu_and_dropout_in_the_epilogue(tgemm_on):
+    from monodetr_amd.monodetr import linear
+    torch.manual_seed(0)
+    lin = linear.Linear(64, 72).to(torch.bfloat16)
+    drop = torch.nn.Dropout(0.25)
+    x = (torch.randn(2, 2100, 64) * 0.5).to(torch.bfloat16).requires_grad_(True)
+    for skip in (False, True):
+        tgemm_on.clear()
+        out = linear.ffn_hidden(x, lin, drop, skip=skip)
+        h = out[0] if skip else out
+        assert [c for c in tgemm_on if c[3] and c[4] == 0.25], tgemm_on          # one launch: bias + ReLU + Dropout
+        pre = F.linear(x.float(), lin.weight.float(), lin.bias.float())
+        kept = h != 0
+        # kept elements are relu(pre) / 0.75; dropped or negative ones are zero
+        assert _rel(h[kept], (pre.clamp(min=0) / 0.75)[kept]) <= 5e-3
+        frac = kept.float().mean().item()
+        assert 0.3 < frac < 0.45                                       # ~ half positive x three quarters kept
+        gsum = torch.autograd.grad(h.float().sum(), x, retain_graph=False)[0]
+        want = (kept.float() / 0.75) @ lin.weight.float()
+        assert _rel(gsum, want) <= 1e-2
+
+
+def test_bottleneck_with_fused_tails_matches_the_default_block(tgemm_on, monkeypatch):
+    """conv1 (shift + ReLU in the epilogue, the identity's gradient summed inside its input-gradient product) and conv3 (shift +
+    identity + ReLU in the epilogue) of a bottleneck against the default route, with and without a projection shortcut."""
+    from monodetr_amd.monodetr import backbone, linear
+    torch.manual_seed(1)
+    for down in (False, True):
+        inpl, planes = (64, 16) if not down else (32, 16)
+        ds = torch.nn.Sequential(torch.nn.Conv2d(inpl, planes * 4, 1, 1, bias=False), backbone.FrozenBatchNorm2d(planes * 4)) if down else None
+        blk = backbone.Bottleneck(inpl, planes, 1, ds)
+        for m in blk.modules():
+            if isinstance(m, backbone.FrozenBatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2); m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+        x = (torch.randn(2, inpl, 48, 48) * 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        res = {}
+        for on in (False, True):
+            monkeypatch.setattr(linear, "_TGEMM", on)
+            for p in blk.parameters():
+                p.grad = None
+            x.grad = None
+            tgemm_on.clear()
+            pairs = [(c, b) for c, b in ((blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)) + (((ds[0], ds[1]),) if down else ())]
+            backbone.prefold(pairs, torch.bfloat16)
+            y = blk(x)
+            (y.float() * 0.01).sum().backward()
+            res[on] = (y.detach().float(), x.grad.float().clone(), {n: p.grad.float().clone() for n, p in blk.named_parameters()})
+            if on:
+                assert [c for c in tgemm_on if c[2] and c[3] and not c[1]], tgemm_on      # conv3: residual + ReLU epilogue
+        # both routes against the block in fp32 on the same (bf16-valued) parameters: the fused route must be as close as the default
+        import copy
+        ref = copy.deepcopy(blk).float()
+        x32 = x.detach().float().requires_grad_(True)
+        monkeypatch.setattr(linear, "_TGEMM", False)
+        y32 = ref(x32)
+        (y32 * 0.01).sum().backward()
+        want = (y32.detach(), x32.grad, {n: p.grad for n, p in ref.named_parameters()})
+        for on in (False, True):
+            assert _rel(res[on][0], want[0]) <= 8e-3
+        e_def, e_fused = _rel(res[False][1], want[1]), _rel(res[True][1], want[1])
+        assert e_fused <= max(1.3 * e_def, 3e-2), (e_def, e_fused)
+        for n, gd in want[2].items():
+            e_def, e_fused = _rel(res[False][2][n], gd), _rel(res[True][2][n], gd)
+            assert e_fused <= max(1.3 * e_def, 3e-2), (n, e_def, e_fused)
