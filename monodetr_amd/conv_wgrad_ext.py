@@ -64,14 +64,17 @@ def token_weight_gradient(x2, dy2, dtype, bias=False):
 
 
 def token_supported(x2, dy2):
+    """bf16 token matrices with contiguous rows whose widths are multiples of 8 (csrc/twgrad.hip).  With MDETR_TWGRAD=0 (A/B runs: the
+    1x1 case of csrc/conv_wgrad.hip behind the same entry point) that kernel's narrower rules apply."""
     T = x2.shape[0]
-    # (narrow outputs waste the kernel's 128-row dy block: 58 vs 49 us at N = 64; a weight of more than 64 (128 x 64) blocks leaves
-    # fewer than four chunks of tokens per block column: the library's split is better there)
-    if dy2.shape[1] < 128 or ((dy2.shape[1] + 127) // 128) * (x2.shape[1] // 64) > 64:
-        return False
-    return (TOKEN_ROUTE and x2.dtype == torch.bfloat16 and dy2.dtype == torch.bfloat16 and x2.is_contiguous() and dy2.is_contiguous() and T % 8 == 0
-            and x2.shape[1] % 64 == 0 and dy2.shape[1] % 32 == 0 and (x2.is_cuda or _backend is not None)
-            and x2.data_ptr() % 16 == 0 and dy2.data_ptr() % 16 == 0 and T * max(x2.shape[1], dy2.shape[1]) * 2 < (1 << 31))
+    ok = (TOKEN_ROUTE and (ENABLED or _backend is not None) and x2.dtype == torch.bfloat16 and dy2.dtype == torch.bfloat16 and x2.is_contiguous()
+          and dy2.is_contiguous() and (x2.is_cuda or _backend is not None) and x2.data_ptr() % 16 == 0 and dy2.data_ptr() % 16 == 0
+          and T * max(x2.shape[1], dy2.shape[1]) * 2 < (1 << 31))
+    if os.environ.get("MDETR_TWGRAD") == "0":
+        # (narrow outputs waste that kernel's 128-row dy block; a weight of more than 64 (128 x 64) blocks leaves too few chunks)
+        return ok and T % 8 == 0 and x2.shape[1] % 64 == 0 and dy2.shape[1] % 32 == 0 and dy2.shape[1] >= 128 \
+            and ((dy2.shape[1] + 127) // 128) * (x2.shape[1] // 64) <= 64
+    return ok and x2.shape[1] % 8 == 0 and dy2.shape[1] % 8 == 0
 
 
 def weight_gradient(x, dy, k, stride, dtype=torch.bfloat16):

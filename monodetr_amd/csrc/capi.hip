@@ -29,6 +29,7 @@
 #include "pair_losses.h"
 #include "rotate_iou.h"
 #include "tgemm.h"
+#include "twgrad.h"
 #include "msda.h"
 #include "msda_prologue.h"
 #include "msda_prologue_math.h"
@@ -653,8 +654,16 @@ int mdetr_conv_wgrad(const void *x, const void *dy, float *partial, int64_t part
     return MDETR_OK;
 }
 
+// csrc/twgrad.hip (transposing LDS reads) unless MDETR_TWGRAD=0 asks for the 1x1 case of csrc/conv_wgrad.hip (A/B runs)
+static bool twgrad_wanted(int64_t T, int C, int N)
+{
+    const char *ev = getenv("MDETR_TWGRAD");
+    return !(ev && atoi(ev) == 0) && T > 0 && C > 0 && N > 0 && C % 8 == 0 && N % 8 == 0;
+}
+
 int mdetr_token_wgrad_chunks(int64_t T, int C, int N)
 {
+    if (twgrad_wanted(T, C, N)) return mdetr::twgrad_chunks(T, C, N);
     if (T <= 0 || T % 8 != 0 || T / 8 >= (1ll << 30) || C <= 0 || N <= 0) return 0;
     return mdetr::conv_wgrad_chunks(wgrad_dims(1, 8, static_cast<int>(T / 8), C, 8, static_cast<int>(T / 8), N, 1, 1));
 }
@@ -662,9 +671,21 @@ int mdetr_token_wgrad_chunks(int64_t T, int C, int N)
 int mdetr_token_wgrad(const void *x, const void *dy, float *partial, int64_t partial_floats, int64_t T, int C, int N, int with_bias,
                       int device, void *stream)
 {
+    if (!x || !dy || !partial) return fail(MDETR_E_ARG, "mdetr_token_wgrad: null pointer");
+    if (twgrad_wanted(T, C, N)) {
+        if (!mdetr::twgrad_supported(T, C, N, C, N, x, dy))
+            return fail(MDETR_E_ARG, "mdetr_token_wgrad: needs C %% 8 == 0, N %% 8 == 0, 16-byte aligned operands below 2^31 bytes (T=%lld C=%d N=%d)",
+                        static_cast<long long>(T), C, N);
+        const int64_t need = static_cast<int64_t>(mdetr::twgrad_chunks(T, C, N)) * (static_cast<int64_t>(N) * C + (with_bias ? N : 0));
+        if (partial_floats < need) return fail(MDETR_E_ARG, "mdetr_token_wgrad: partial buffer holds %lld floats, %lld needed", static_cast<long long>(partial_floats), static_cast<long long>(need));
+        DeviceScope dev(device);
+        if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_token_wgrad: set device %d: %s", device, hipGetErrorString(dev.err));
+        const hipError_t e = mdetr::twgrad_launch(x, dy, partial, T, C, N, C, N, with_bias != 0, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_token_wgrad: launch failed: %s", hipGetErrorString(e));
+        return MDETR_OK;
+    }
     if (T <= 0 || T % 8 != 0 || T / 8 >= (1ll << 30) || C <= 0 || N <= 0)
         return fail(MDETR_E_ARG, "mdetr_token_wgrad: bad sizes T=%lld (a positive multiple of 8) C=%d N=%d", static_cast<long long>(T), C, N);
-    if (!x || !dy || !partial) return fail(MDETR_E_ARG, "mdetr_token_wgrad: null pointer");
     // the [T, C] / [T, N] matrices as 1 x 8 x (T / 8) channels-last images: a 1x1 convolution's weight gradient
     mdetr::ConvWgradDims d = wgrad_dims(1, 8, static_cast<int>(T / 8), C, 8, static_cast<int>(T / 8), N, 1, 1);
     d.DB = with_bias ? 1 : 0;

@@ -36,6 +36,16 @@ __device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float c)
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
 }
 
+// ds_read_b64_tr_b16: the transposing LDS read.  Every lane passes the (8-byte aligned) address of 4 consecutive bf16; within a
+// 16-lane group, lane i receives element i & 3 of the vectors that lanes (i >> 2), 4 + (i >> 2), 8 + (i >> 2), 12 + (i >> 2) point at
+// (measured: scripts/exp/ds_read_tr16_probe.hip).  With lane s pointing at row s >> 2, columns 4 (s & 3) .. + 3 of a row-major tile,
+// lane i gets column i of rows 0 .. 3: four consecutive CONTRACTION values of its own column -- half an MFMA operand.
+__device__ __forceinline__ bf16x4 lds_read_tr4(const __bf16 *p)
+{
+    typedef bf16x4 __attribute__((address_space(3))) lds_bf16x4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(p));
+}
+
 // orders a wave's LDS writes before its subsequent LDS reads (wave-private buffers: no workgroup barrier needed)
 __device__ __forceinline__ void wave_sync()
 {

@@ -1,38 +1,34 @@
-"""Weight + bias gradient of the step's token-wise linear layers two ways in one process (developer tool):
-the library route (batched split-K product + chunk sum + a two-launch column sum of dy) and csrc/conv_wgrad.hip's 1x1 case with the
-bias gradient riding along (one kernel + one chunk sum).
+"""Weight + bias gradient of the step's token-wise layers in one process (developer tool): csrc/twgrad.hip (transposing LDS reads)
+against the 1x1 case of csrc/conv_wgrad.hip (MDETR_TWGRAD=0) and, with --library, the library's batched split-K route -- each
+INCLUDING its chunk sum, timed as graph replays over rotating operand sets (tools/gemmbench.graph_time).
 
-    python -m monodetr_amd.tools.wgradbench [--iters 50] [--out gpurun_out/wgradbench.json]
+    python -m monodetr_amd.tools.wgradbench [--reps 20] [--env "MDETR_TWGRAD_WGS=512;..."] [--out gpurun_out/wgradbench.json]
 """
 import argparse
 import json
+import os
 
 import monodetr_amd._runtime_env  # noqa: F401  (before torch)
 import torch
 
+from monodetr_amd.tools.gemmbench import graph_time
+
+HBM, MFMA = 8.0e12, 2.5e15
 SHAPES = [  # (name, T, K, N)
-    ("encoder_256x256", 81600, 256, 256), ("encoder_packed_384", 81600, 256, 384), ("layer1_64to256", 245760, 64, 256),
-    ("layer1_256to64", 245760, 256, 64), ("layer2_128to512", 61440, 128, 512), ("layer2_512to128", 61440, 512, 128),
-    ("layer3_256to1024", 15360, 256, 1024), ("layer3_1024to256", 15360, 1024, 256), ("layer4_512to2048", 3840, 512, 2048),
-    ("layer4_2048to512", 3840, 2048, 512), ("depth_tokens_256x256", 15360, 256, 256),
+    ("encoder_256x256", 81600, 256, 256), ("encoder_packed_384", 81600, 256, 384), ("layer2b0_256to128", 245760, 256, 128),
+    ("layer2_128to512", 61440, 128, 512), ("layer2_512to128", 61440, 512, 128), ("layer2_down_256to512", 61440, 256, 512),
+    ("layer3_256to1024", 15360, 256, 1024), ("layer3_1024to256", 15360, 1024, 256), ("layer3_down_512to1024", 15360, 512, 1024),
+    ("layer4_512to2048", 3840, 512, 2048), ("layer4_2048to512", 3840, 2048, 512), ("layer4_down_1024to2048", 3840, 1024, 2048),
+    ("proj0_512to256", 61440, 512, 256), ("proj2_2048to256", 3840, 2048, 256), ("depth_tokens_256x256", 15360, 256, 256),
 ]
-
-
-def timeit(fn, iters):
-    for _ in range(5):
-        fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    e1.synchronize()
-    return e0.elapsed_time(e1) / iters
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--env", default="", help="extra variants of the new kernel, e.g. 'MDETR_TWGRAD_WGS=512;MDETR_TWGRAD_WGS=1024'")
+    ap.add_argument("--library", action="store_true")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     from monodetr_amd import conv_wgrad_ext
@@ -40,20 +36,41 @@ def main():
     dev = torch.device("cuda", 0)
     res = {}
     for name, T, K, N in SHAPES:
+        if a.only and not any(k in name for k in a.only.split(",")):
+            continue
+        nsets = max(1, min(6, int(300e6 // (2 * T * (K + N))) + 1))
         g = torch.Generator(device="cpu").manual_seed(T + K + N)
-        x = (torch.randn(T, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
-        dy = (torch.randn(T, N, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+        xs = [(torch.randn(T, K, generator=g) * 0.5).to(torch.bfloat16).to(dev) for _ in range(nsets)]
+        dys = [(torch.randn(T, N, generator=g) * 0.1).to(torch.bfloat16).to(dev) for _ in range(nsets)]
         w = torch.zeros(N, K, dtype=torch.bfloat16, device=dev)
-        row = {"T": T, "K": K, "N": N}
-        for tag, on in (("library_ms", False), ("kernel_ms", True)):
-            conv_wgrad_ext.TOKEN_ROUTE = on
-            if on and not conv_wgrad_ext.token_supported(x, dy):
-                row[tag] = None
-                continue
-            row[tag] = round(timeit(lambda: linear._weight_bias_grads(x, dy, w, True, True), a.iters), 4)
+        byts, flops = 2 * T * (K + N) + 2 * N * K, 2.0 * T * N * K
+        row = {"T": T, "K": K, "N": N, "bound_us": round(max(byts / HBM, flops / MFMA) * 1e6, 2)}
+        f = lambda i: linear._weight_bias_grads(xs[i], dys[i], w, True, True)
+        conv_wgrad_ext.TOKEN_ROUTE = conv_wgrad_ext.ENABLED = True
+        os.environ.pop("MDETR_TWGRAD", None)
+        row["twgrad_us"] = graph_time(f, nsets, a.reps) if conv_wgrad_ext.token_supported(xs[0], dys[0]) else None
+        for var in [v for v in a.env.split(";") if v]:
+            pairs = [kv.split("=") for kv in var.split(",")]
+            for k, v in pairs:
+                os.environ[k] = v
+            row["twgrad[%s]_us" % var] = graph_time(f, nsets, a.reps)
+            for k, _ in pairs:
+                os.environ.pop(k, None)
+        os.environ["MDETR_TWGRAD"] = "0"
+        row["conv1x1_us"] = graph_time(f, nsets, a.reps) if conv_wgrad_ext.token_supported(xs[0], dys[0]) else None
+        os.environ.pop("MDETR_TWGRAD", None)
+        if a.library:
+            conv_wgrad_ext.TOKEN_ROUTE = False
+            row["library_us"] = graph_time(f, nsets, a.reps)
+            conv_wgrad_ext.TOKEN_ROUTE = True
+        if row["twgrad_us"]:
+            row["frac_of_bound"] = round(row["bound_us"] / row["twgrad_us"], 3)
         res[name] = row
-        print(name, row, flush=True)
+        print(name, json.dumps(row), flush=True)
+        del xs, dys
+        torch.cuda.empty_cache()
     if a.out:
+        os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
         json.dump(res, open(a.out, "w"), indent=1)
 
 

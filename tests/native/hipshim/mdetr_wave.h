@@ -105,6 +105,26 @@ template <typename V> inline void rsrc_store16(mdetr_rsrc r, const V &v, unsigne
 inline void rsrc_store_bf16x8(mdetr_rsrc r, bf16x8 v, unsigned lane_offset, unsigned scalar_offset) { rsrc_store16(r, v, lane_offset, scalar_offset); }
 inline void rsrc_store_f32x4(mdetr_rsrc r, f32x4 v, unsigned lane_offset, unsigned scalar_offset) { rsrc_store16(r, v, lane_offset, scalar_offset); }
 
+// ds_read_b64_tr_b16 (the real header: the transposing LDS read, semantics measured on gfx950 with scripts/exp/ds_read_tr16_probe.hip):
+// within a 16-lane group, lane i receives element i & 3 of the 4-element vectors that lanes (i >> 2) + 4 j, j = 0 .. 3, point at
+inline bf16x4 lds_read_tr4(const __bf16 *p)
+{
+    const int me = threadIdx.x, base = hipshim::lane_base(), lane = me - base;
+    static_assert(sizeof(bf16x4) == 8, "one exchange slot");
+    if ((reinterpret_cast<uintptr_t>(p) & 7) != 0) abort();       // (misaligned: the hardware would read the aligned address's data)
+    memcpy(&hipshim::exchange[me], p, 8);
+    hipshim::sync_wave();
+    bf16x4 r;
+    const int grp = base + (lane & ~15), i = lane & 15;
+    for (int j = 0; j < 4; ++j) {
+        bf16x4 src;
+        memcpy(&src, &hipshim::exchange[grp + 4 * j + (i >> 2)], 8);
+        r[j] = src[i & 3];
+    }
+    hipshim::sync_wave();
+    return r;
+}
+
 inline void wave_sync() { hipshim::sync_wave(); }
 
 #define MDETR_DYNAMIC_LDS(type, name) type *name = reinterpret_cast<type *>(hipshim::dynamic_lds())

@@ -746,21 +746,29 @@ def test_conv_wgrad_kernel_matches_the_library_weight_gradient(B, H, W, C, N, mo
     assert torch.equal(a, b)                                                             # fixed-order sums: deterministic
 
 
-@pytest.mark.parametrize("T,K,N", [(81600, 256, 256), (81600, 256, 384), (61440, 128, 512), (15360, 1024, 256), (245760, 64, 256), (4408, 256, 256)])
-def test_token_wgrad_kernel_gives_weight_and_bias_gradient(T, K, N):
-    """mdetr_token_wgrad (csrc/conv_wgrad.hip, 1x1 case, bias gradient riding along) at the step's token shapes -- the encoder's
-    81 600 rows, the packed offsets / weights projection, the backbone's 1x1 convolutions: held to fp32 products of the same bf16
-    operands, tighter than the library's bf16 split-K partials it replaces; deterministic."""
+@pytest.mark.parametrize("form", ["1", "0"])
+@pytest.mark.parametrize("T,K,N", [(81600, 256, 256), (81600, 256, 384), (61440, 128, 512), (15360, 1024, 256), (245760, 64, 256), (4408, 256, 256),
+                                   (3840, 2048, 512), (245760, 256, 64), (4403, 264, 72)])
+def test_token_wgrad_kernel_gives_weight_and_bias_gradient(T, K, N, form, monkeypatch):
+    """mdetr_token_wgrad at the step's token shapes -- the encoder's 81 600 rows, the packed offsets / weights projection, the
+    backbone's 1x1 convolutions -- as csrc/twgrad.hip (form 1: transposing LDS reads) and as the 1x1 case of csrc/conv_wgrad.hip
+    (form 0), the bias gradient riding along: ELEMENT BY ELEMENT against the fp64 products of the same bf16 operands (fp32
+    accumulation of exact products; bf16 results: one more rounding); deterministic."""
     from monodetr_amd import conv_wgrad_ext
+    monkeypatch.setenv("MDETR_TWGRAD", form)
+    monkeypatch.setattr(conv_wgrad_ext, "ENABLED", True)
     g = torch.Generator(device="cuda").manual_seed(T + N)
     x = (torch.randn(T, K, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
     dy = (torch.randn(T, N, generator=g, device="cuda") * 0.1).to(torch.bfloat16)
-    rw, rb = dy.float().t() @ x.float(), dy.float().sum(0)
-    for dtype, tol in ((torch.float32, 3e-5), (torch.bfloat16, 6e-3)):
+    if not conv_wgrad_ext.token_supported(x, dy):
+        pytest.skip("this form does not take the shape")
+    rw, rb = dy.double().t() @ x.double(), dy.double().sum(0)
+    mw, mb = dy.double().abs().t() @ x.double().abs(), dy.double().abs().sum(0)
+    for dtype, ulp in ((torch.float32, 0.0), (torch.bfloat16, 2.0 ** -8)):
         dw, db = conv_wgrad_ext.token_weight_gradient(x, dy, dtype, bias=True)
         assert dw.shape == rw.shape and db.shape == rb.shape and dw.dtype == db.dtype == dtype
-        assert (dw.float() - rw).abs().max().item() <= tol * rw.abs().max().item(), dtype
-        assert (db.float() - rb).abs().max().item() <= tol * max(rb.abs().max().item(), 1.0), dtype
+        assert bool(((dw.double() - rw).abs() <= ulp * rw.abs() + 4 * T ** 0.5 * 2.0 ** -23 * mw + 1e-30).all()), dtype
+        assert bool(((db.double() - rb).abs() <= ulp * rb.abs() + 4 * T ** 0.5 * 2.0 ** -23 * mb + 1e-30).all()), dtype
     a, b = conv_wgrad_ext.token_weight_gradient(x, dy, torch.float32, bias=True), conv_wgrad_ext.token_weight_gradient(x, dy, torch.float32, bias=True)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 

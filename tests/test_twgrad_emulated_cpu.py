@@ -1,0 +1,61 @@
+"""csrc/twgrad.hip -- the REAL kernel source, launcher and C-ABI entry (mdetr_token_wgrad) -- on the HIP-on-CPU shim: transposing-read
+fragments (the shim restates ds_read_b64_tr_b16 as measured on the chip), the four tile shapes, ragged T / N / C, several chunks
+per tile, the bias gradient riding on the dY fragments; against fp64 products of the same bf16 operands."""
+import ctypes
+
+import pytest
+import torch
+
+import native_emul
+
+
+def run(x, dy, with_bias, form="1"):
+    L = native_emul.lib()
+    T, C = x.shape
+    N = dy.shape[1]
+    chunks = L.mdetr_token_wgrad_chunks(T, C, N)
+    assert chunks >= 1
+    cols = N * C + (N if with_bias else 0)
+    part = torch.full((chunks, cols), float("nan"))
+    rc = L.mdetr_token_wgrad(x.data_ptr(), dy.data_ptr(), part.data_ptr(), part.numel(), T, C, N, 1 if with_bias else 0, -1, None)
+    assert rc == 0, ctypes.string_at(L.mdetr_last_error())
+    assert not torch.isnan(part).any()                                 # every chunk wrote every element
+    tot = part.double().sum(0)
+    return tot[:N * C].view(N, C), (tot[N * C:] if with_bias else None), chunks
+
+
+@pytest.mark.parametrize("T,C,N", [
+    (136, 64, 32),          # 64 x 64 tiles, 5 slabs (ragged last), one chunk
+    (1000, 128, 160),       # 128 x 128 tiles, N = 160: a ragged second row tile
+    (264, 64, 256),         # 128 (n) x 64 (c)
+    (300, 264, 72),         # C = 264: three column tiles, the last with 8 live columns; N = 72
+    (4101, 256, 256),       # many slabs: several chunks per tile; T % 8 != 0
+    (33, 8, 8),             # two slabs, everything ragged
+])
+def test_twgrad_source_on_the_cpu_shim(monkeypatch, T, C, N):
+    monkeypatch.delenv("MDETR_TWGRAD", raising=False)
+    g = torch.Generator().manual_seed(T + C + N)
+    x = (torch.randn(T, C, generator=g) * 0.5).to(torch.bfloat16)
+    dy = (torch.randn(T, N, generator=g) * 0.2).to(torch.bfloat16)
+    dw, db, chunks = run(x, dy, True)
+    rw, rb = dy.double().t() @ x.double(), dy.double().sum(0)
+    mag = dy.double().abs().t() @ x.double().abs()
+    assert bool(((dw - rw).abs() <= 4 * (T ** 0.5) * 2.0 ** -23 * mag + 1e-30).all())      # fp32 accumulation of exact products
+    assert bool(((db - rb).abs() <= 4 * (T ** 0.5) * 2.0 ** -23 * dy.double().abs().sum(0) + 1e-30).all())
+    dw2, none, _ = run(x, dy, False)
+    assert none is None and torch.equal(dw2, dw)
+
+
+def test_twgrad_chunking_is_a_partition(monkeypatch):
+    """More workgroups asked for than slabs allow: every chunk keeps at least one slab, the sum over chunks is the whole product."""
+    monkeypatch.setenv("MDETR_TWGRAD_WGS", "8192")
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(700, 64, generator=g)).to(torch.bfloat16)
+    dy = (torch.randn(700, 64, generator=g)).to(torch.bfloat16)
+    dw, db, chunks = run(x, dy, True)
+    assert chunks == 5                                                 # 22 slabs, at least four per chunk
+    assert (dw - dy.double().t() @ x.double()).abs().max() <= 1e-3
+    monkeypatch.setenv("MDETR_TWGRAD", "0")                            # the 1x1 case of csrc/conv_wgrad.hip answers the same entry point
+    x8, dy8 = x[:696].contiguous(), dy[:696].contiguous()
+    dw0, db0, _ = run(x8, dy8, True)
+    assert (dw0 - dy8.double().t() @ x8.double()).abs().max() <= 1e-3
