@@ -1,6 +1,6 @@
 """Build libmonodetr_amd.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
 
-    python -m monodetr_amd.build [--force] [--save-temps]
+    python -m monodetr_amd.build [--force] [--save-temps]      (--save-temps: recompile everything with register / LDS usage remarks)
 
 The .so lands next to this file (monodetr_amd/libmonodetr_amd.so): git-ignored, but it travels to
 the GPU box with the repo snapshot.  hipcc cross-compiles without a GPU.
@@ -54,28 +54,39 @@ def _compile_one(args):
     return obj
 
 
+def _stamp():
+    """What an object file depends on besides its source: compiler, architecture, flags (a change of any rebuilds everything)."""
+    import hashlib
+    return hashlib.sha256("\0".join([hipcc(), ARCH] + _flags()).encode()).hexdigest()[:16]
+
+
 def build(force=False, save_temps=False, verbose=False):
-    """One object per translation unit (kept under build_obj/, rebuilt when the source or any header is newer), compiled in
-    parallel, then one link: a kernel edit costs one file's compile time instead of the whole library's."""
-    if not force and not _stale():
-        return LIB
+    """One object per translation unit (kept under build_obj/, rebuilt when the source, any header, the compiler or a flag
+    changed), compiled in parallel, then one link of EXACTLY the objects of sources(): a kernel edit costs one file's compile
+    time; objects of deleted or renamed sources are removed."""
     objdir = os.path.join(HERE, "build_obj")
     os.makedirs(objdir, exist_ok=True)
+    stamp_file = os.path.join(objdir, "flags.stamp")
+    stamp = _stamp()
+    same_flags = os.path.exists(stamp_file) and open(stamp_file).read().strip() == stamp
+    if not force and same_flags and not _stale():
+        return LIB
     hdr_t = max(os.path.getmtime(d) for d in glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h")) + [os.path.abspath(__file__)])
-    extra = []
-    if save_temps:
-        os.makedirs(os.path.join(HERE, "build_tmp"), exist_ok=True)
-        extra = ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+    extra = ["-Rpass-analysis=kernel-resource-usage"] if save_temps else []
     jobs, objs = [], []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or save_temps or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+        if force or save_temps or not same_flags or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
             jobs.append((src, obj, extra, verbose))
+    for stale in set(glob.glob(os.path.join(objdir, "*.o"))) - set(objs):     # a deleted / renamed source's object must not be linked
+        os.remove(stale)
     if jobs:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(_compile_one, jobs))
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
     cmd = [hipcc(), "--offload-arch=" + ARCH, "-fPIC", "-shared", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))

@@ -175,11 +175,21 @@ class SplitGradSync(FlatGradSync):
     @torch.no_grad()
     def start(self, params=None, part=None):
         op, scale = _avg_op(self.group)
-        if self._static is not None and part is not None:
-            plan = self._static[part]
+        static = self._static_parts()
+        if static is not None and (part is not None or params is None):
+            # under graph replay the gradients live at the CAPTURED addresses and the captured optimizer reads the persistent flat
+            # buffers: always the remembered plan, never a fresh one built from whatever .grad points at by now
+            plan = static[part if part is not None else "all"]
+            pre = self._gathered
         else:
-            plan = static_plan(self.params if params is None else params)
-        pre = self._gathered and self._static is not None and part is not None
+            if params is not None:
+                # (the eager cut path) a parameter may appear in ONE part only: a second start() for it would reduce a gradient
+                # whose first contribution is already travelling
+                seen = {id(p) for _, ps, _, _, _ in self._pending for p in ps}
+                twice = [p for p in params if id(p) in seen]
+                if twice:
+                    raise RuntimeError("SplitGradSync: %d parameter(s) received gradient in both parts of the cut backward pass" % len(twice))
+            plan, pre = static_plan(self.params if params is None else params), False
         for ps, src, flat, views in plan:
             if not pre:
                 torch.cat([_flat(g) for g in src], out=flat)
@@ -195,11 +205,19 @@ class SplitGradSync(FlatGradSync):
             _point(ps, views)
         self._pending = []
 
+    def _static_parts(self):
+        """{part name: plan} of the remembered (graph replay) plan; a plan that was remembered as ONE list -- `make_static()`, or a
+        capture of a model without a pyramid cut -- is the single part "all"."""
+        if self._static is None:
+            return None
+        return self._static if isinstance(self._static, dict) else {"all": self._static}
+
     @torch.no_grad()
     def sync(self):
         """Every part at once (= the flat exchange): what an iteration without the cut calls."""
-        if isinstance(self._static, dict):
-            for part in self._static:
+        static = self._static_parts()
+        if static is not None:
+            for part in static:
                 self.start(part=part)
         else:
             self.start()

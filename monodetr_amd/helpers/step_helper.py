@@ -476,6 +476,11 @@ class TrainIteration:
                 cb(self)
             elif self.graph_opt is not None or self.grad_sync is not None:
                 self.agree_on_launch_mode()
+        elif not self.want_graph and self.on_captured is not None:
+            # graphs are off (asked for, or the runtime-flag gate of __init__ tripped): there will be no capture to wait for, and
+            # the deferred process group must exist before the first gradient exchange -- without it every rank would train alone
+            cb, self.on_captured = self.on_captured, None
+            cb(self)
         if self.graph is not None:
             if _signature(batch) == self._sig:
                 self.load(batch)

@@ -63,38 +63,44 @@ def _split_count(T):
     return best
 
 
-def _weight_bias_grads(x2, dy2, weight, need_w, need_b):
-    """(dW, db) of y = x W^T + b from the [T, K] input and the [T, N] output gradient (either may be None when not needed)."""
+def _weight_bias_grads(x2, dy2, weight, need_w, need_b, bias_dtype=None, out_dtype=None):
+    """(dW, db) of y = x W^T + b from the [T, K] input and the [T, N] output gradient (either may be None when not needed), in the
+    weight's dtype (or `out_dtype`).  bias_dtype: the bias parameter's dtype where it differs from the weight's -- an fp32 bias
+    beside a bf16 weight gets its gradient from the fp32 sums, not through a bf16 rounding."""
+    dt = out_dtype if out_dtype is not None else weight.dtype
+    if need_b and bias_dtype is not None and bias_dtype != dt:
+        dw, db = _weight_bias_grads(x2, dy2, weight, need_w, True, out_dtype=torch.float32)
+        return (dw.to(dt) if dw is not None else None), db.to(bias_dtype)
     dw = db = None
     T = x2.shape[0]
     if small_wgrad_ext.ENABLED and need_w and (T <= small_wgrad_ext.MAX_ROWS or dy2.shape[1] <= 64) \
-            and weight.dtype in (torch.float32, torch.bfloat16) and small_wgrad_ext.supported(dy2, x2):
+            and dt in (torch.float32, torch.bfloat16) and small_wgrad_ext.supported(dy2, x2):
         # a few thousand rows (the decoder's 4 400): dW and db from one launch + one chunk sum (csrc/small_wgrad.hip)
-        dw, db = small_wgrad_ext.small_wgrad(dy2, x2, weight.dtype)
+        dw, db = small_wgrad_ext.small_wgrad(dy2, x2, dt)
         return dw, (db if need_b else None)
     # the batched split rounds every chunk's partial product to the activation dtype: worth it from ~8 000 rows on (43 vs
     # 110 us at 15 360), not for the decoder's 4 400 (29 + 12 vs 34 us, and 16 bf16 roundings instead of one)
     C = _split_count(T) if T > small_wgrad_ext.MAX_ROWS else 0
     if need_w:
         from .. import conv_wgrad_ext
-        if T > small_wgrad_ext.MAX_ROWS and conv_wgrad_ext.token_supported(x2, dy2) and weight.dtype in (torch.float32, torch.bfloat16):
-            # dW and db from ONE kernel + one chunk sum (csrc/conv_wgrad.hip, the 1x1 case with the bias gradient riding along)
-            return conv_wgrad_ext.token_weight_gradient(x2, dy2, weight.dtype, bias=need_b)
+        if T > small_wgrad_ext.MAX_ROWS and conv_wgrad_ext.token_supported(x2, dy2) and dt in (torch.float32, torch.bfloat16):
+            # dW and db from ONE kernel + one chunk sum (csrc/twgrad.hip, the bias gradient riding along)
+            return conv_wgrad_ext.token_weight_gradient(x2, dy2, dt, bias=need_b)
         elif C:
             parts = torch.bmm(dy2.view(C, T // C, -1).transpose(1, 2), x2.view(C, T // C, -1))    # [C, N, K]
             flat = parts.view(C, -1)
-            if colsum_ext.supported(flat) and weight.dtype in (torch.float32, torch.bfloat16):
+            if colsum_ext.supported(flat) and dt in (torch.float32, torch.bfloat16):
                 # sum over the C chunks in one streaming pass (csrc/colsum.hip), written in the parameter's dtype
-                dw = colsum_ext.column_sum(flat, weight.dtype).view(parts.shape[1], parts.shape[2])
+                dw = colsum_ext.column_sum(flat, dt).view(parts.shape[1], parts.shape[2])
             else:
-                dw = parts.sum(0).to(weight.dtype)
+                dw = parts.sum(0).to(dt)
         else:
-            dw = (dy2.t() @ x2).to(weight.dtype)
+            dw = (dy2.t() @ x2).to(dt)
     if need_b:
-        if dy2.is_cuda and colsum_ext.supported(dy2) and weight.dtype in (torch.float32, torch.bfloat16):
-            db = colsum_ext.column_sum(dy2, weight.dtype)       # csrc/colsum.hip: one HBM pass, fp32 accumulation, one rounding
+        if dy2.is_cuda and colsum_ext.supported(dy2) and dt in (torch.float32, torch.bfloat16):
+            db = colsum_ext.column_sum(dy2, dt)       # csrc/colsum.hip: one HBM pass, fp32 accumulation, one rounding
         else:
-            db = (dy2.view(C, T // C, -1).sum(1).sum(0) if C else dy2.sum(0)).to(weight.dtype)
+            db = (dy2.view(C, T // C, -1).sum(1).sum(0) if C else dy2.sum(0)).to(dt)
     return dw, db
 
 
@@ -132,6 +138,7 @@ class _TokenLinearSkip(torch.autograd.Function):
         q = x if pos is None else x + pos
         q2 = q.reshape(-1, q.shape[-1])
         ctx.has_bias = bias is not None
+        ctx.bias_dtype = bias.dtype if bias is not None else None
         ctx.relu = bool(relu)
         ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
         if _tgemm_ok(q2, weight, bias):
@@ -160,7 +167,7 @@ class _TokenLinearSkip(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             ds2 = dskip.reshape(-1, q.shape[-1]) if dskip is not None else None
             dx = _input_gradient(dy2, weight, ds2).view_as(q)
-        dw, db = _weight_bias_grads(q2, dy2, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        dw, db = _weight_bias_grads(q2, dy2, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], ctx.bias_dtype)
         return dx, dw, db, None, None, None
 
 
@@ -197,6 +204,7 @@ class _TokenLinear(torch.autograd.Function):
         cross-attention differences neighbouring value rows for d/d(location), and 8 mantissa bits on the values made those
         gradients the least accurate of the bf16 model (cosine 0.86-0.98 against the fp32 model, round 2)."""
         ctx.has_bias = bias is not None
+        ctx.bias_dtype = bias.dtype if bias is not None else None
         ctx.fused_relu = False
         ctx.wide_out = bool(wide_out)
         ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
@@ -242,7 +250,7 @@ class _TokenLinear(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         if ctx.needs_input_grad[0]:
             dx = _input_gradient(dy2, weight).view_as(x)
-        dw, db = _weight_bias_grads(x2, dy2, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        dw, db = _weight_bias_grads(x2, dy2, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], ctx.bias_dtype)
         return dx, dw, db, None, None, None
 
 
@@ -256,6 +264,7 @@ class _TokenLinearResidualRelu(torch.autograd.Function):
     def forward(ctx, x2, weight, bias, res2):
         out = _fwd_product(x2, weight, bias, True, res2)
         ctx.has_bias = bias is not None
+        ctx.bias_dtype = bias.dtype if bias is not None else None
         ctx.save_for_backward(x2, weight, out)
         return out
 
@@ -265,7 +274,7 @@ class _TokenLinearResidualRelu(torch.autograd.Function):
         x2, weight, out = ctx.saved_tensors
         g = torch.ops.aten.threshold_backward(dout.contiguous(), out, 0.0)
         dx = _input_gradient(g, weight) if ctx.needs_input_grad[0] else None
-        dw, db = _weight_bias_grads(x2, g, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2])
+        dw, db = _weight_bias_grads(x2, g, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], ctx.bias_dtype)
         return dx, dw, db, (g if ctx.needs_input_grad[3] else None)
 
 
