@@ -653,6 +653,9 @@ int mdetr_lsa_forward(const float *cost, const int32_t *num_targets, int32_t *as
  */
 int mdetr_profile_enable(int on);
 int mdetr_profile_read(double *rows, int cap);
+/* The same rows with the useful work the launches declared: (kind, key, launches, total_ms, MFLOP, algorithmic KB), 6 doubles per row
+ * (0 where a kind leaves the accounting to the caller: MSDA and attention, whose bytes / flops follow from the key). */
+int mdetr_profile_read_work(double *rows, int cap);
 
 #ifdef __cplusplus
 }

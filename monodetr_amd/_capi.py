@@ -83,6 +83,7 @@ SIGNATURES = {
     "mdetr_lsa_forward_fused": (_c_int, [_c_vp] * 6 + [_c_int] * 6 + [ctypes.c_float] * 5 + [_c_int, _c_vp]),
     "mdetr_profile_enable": (_c_int, [_c_int]),
     "mdetr_profile_read": (_c_int, [_c_vp, _c_int]),
+    "mdetr_profile_read_work": (_c_int, [_c_vp, _c_int]),
 }
 
 _lib = None
@@ -138,3 +139,12 @@ def profile_read(cap=64):
     if n < 0:
         check(n, "mdetr_profile_read")
     return [(int(buf[4 * i]), int(buf[4 * i + 1]), int(buf[4 * i + 2]), float(buf[4 * i + 3])) for i in range(n)]
+
+
+def profile_read_work(cap=256):
+    """[(kind, key, launches, total_ms, mflop, kbytes)]: `profile_read` plus the useful work the launches declared."""
+    buf = (ctypes.c_double * (6 * cap))()
+    n = lib().mdetr_profile_read_work(ctypes.cast(buf, ctypes.c_void_p), cap)
+    if n < 0:
+        check(n, "mdetr_profile_read_work")
+    return [(int(buf[6 * i]), int(buf[6 * i + 1]), int(buf[6 * i + 2]), float(buf[6 * i + 3]), float(buf[6 * i + 4]), float(buf[6 * i + 5])) for i in range(n)]

@@ -78,7 +78,7 @@ int check_common(const char *who, int dtype, int B, int S, int M, int D, int L, 
 // ---- optional kernel timing ------------------------------------------------------------------
 namespace mdetr {
 namespace {
-struct Rec { int kind, Lq; hipEvent_t a, b; };
+struct Rec { int kind, Lq; hipEvent_t a, b; double mflop, kbytes; };
 std::atomic<int> g_prof_on{0};
 std::mutex g_prof_mu;
 std::vector<Rec> g_recs;
@@ -89,10 +89,17 @@ thread_local Rec t_cur;
 void profile_begin(int kind, int Lq, hipStream_t st)
 {
     if (!g_prof_on.load(std::memory_order_relaxed)) return;
-    t_cur = Rec{kind, Lq, nullptr, nullptr};
+    t_cur = Rec{kind, Lq, nullptr, nullptr, 0.0, 0.0};
     if (hipEventCreate(&t_cur.a) != hipSuccess || hipEventCreate(&t_cur.b) != hipSuccess) return;
     (void)hipEventRecord(t_cur.a, st);
     t_open = &t_cur;
+}
+
+void profile_work(double mflop, double kbytes)
+{
+    if (!t_open) return;
+    t_cur.mflop += mflop;
+    t_cur.kbytes += kbytes;
 }
 
 void profile_end(hipStream_t st)
@@ -118,30 +125,36 @@ int mdetr_profile_enable(int on)
     return MDETR_OK;
 }
 
-int mdetr_profile_read(double *rows, int cap)
+static int profile_read_impl(double *rows, int cap, int width)
 {
     if (!rows || cap < 0) return fail(MDETR_E_ARG, "mdetr_profile_read: bad arguments");
     std::lock_guard<std::mutex> lk(mdetr::g_prof_mu);
-    std::map<std::pair<int, int>, std::pair<double, double>> agg;     // (kind, Lq) -> (launches, ms)
+    struct Agg { double launches = 0, ms = 0, mflop = 0, kbytes = 0; };
+    std::map<std::pair<int, int>, Agg> agg;                           // (kind, key)
     for (auto &r : mdetr::g_recs) {
         float ms = 0.f;
         if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess)
             return fail(MDETR_E_HIP, "mdetr_profile_read: event query failed");
         auto &e = agg[{r.kind, r.Lq}];
-        e.first += 1.0;
-        e.second += ms;
+        e.launches += 1.0;
+        e.ms += ms;
+        e.mflop += r.mflop;
+        e.kbytes += r.kbytes;
     }
     int n = 0;
     for (auto &kv : agg) {
         if (n >= cap) break;
-        rows[4 * n + 0] = kv.first.first;
-        rows[4 * n + 1] = kv.first.second;
-        rows[4 * n + 2] = kv.second.first;
-        rows[4 * n + 3] = kv.second.second;
+        double *o = rows + static_cast<size_t>(width) * n;
+        o[0] = kv.first.first; o[1] = kv.first.second; o[2] = kv.second.launches; o[3] = kv.second.ms;
+        if (width == 6) { o[4] = kv.second.mflop; o[5] = kv.second.kbytes; }
         ++n;
     }
     return n;
 }
+
+int mdetr_profile_read(double *rows, int cap) { return profile_read_impl(rows, cap, 4); }
+
+int mdetr_profile_read_work(double *rows, int cap) { return profile_read_impl(rows, cap, 6); }
 
 int mdetr_abi_version(void) { return MDETR_ABI_VERSION; }
 
@@ -506,6 +519,7 @@ static int column_sum_impl(const char *who, int dtype, const void *x, void *out,
         return fail(MDETR_E_ARG, "%s: workspace too small", who);
     DeviceScope dev(device);
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "%s: set device %d: %s", who, device, hipGetErrorString(dev.err));
+    mdetr::ProfileScope prof(12, cols, static_cast<hipStream_t>(stream), 0.0, static_cast<double>(rows) * cols * (dtype == MDETR_BF16 ? 2.0 : 4.0) / 1e3);
     const hipError_t e = mdetr::colsum_launch(dtype, x, out, workspace, rows, cols, ld, static_cast<hipStream_t>(stream), out_dtype);
     if (e != hipSuccess) return fail(MDETR_E_HIP, "%s: launch failed: %s", who, hipGetErrorString(e));
     return MDETR_OK;
@@ -717,6 +731,7 @@ int mdetr_bias_act_forward(int io_dtype, int bias_dtype, const void *x, const vo
     DeviceScope dev(device);
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_bias_act_forward: set device %d: %s", device, hipGetErrorString(dev.err));
     const mdetr::BiasActProblem p{io_dtype, bias ? bias_dtype : MDETR_F32, rows, cols, relu ? 1 : 0, dropout_p, seed, seed_dev};
+    mdetr::ProfileScope prof(14, cols, static_cast<hipStream_t>(stream), 0.0, static_cast<double>(rows) * cols * (io_dtype == MDETR_BF16 ? 2.0 : 4.0) * (skip ? 3.0 : 2.0) / 1e3);
     const hipError_t e = mdetr::bias_act_forward_launch(p, x, bias, skip, y, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_bias_act_forward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
@@ -733,6 +748,7 @@ int mdetr_bias_act_backward(int io_dtype, const void *dy, const void *y, void *d
     if (!aligned16(dy) || !aligned16(y) || !aligned16(dx)) return fail(MDETR_E_ALIGN, "mdetr_bias_act_backward: dy, y, dx must be 16-byte aligned");
     DeviceScope dev(device);
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_bias_act_backward: set device %d: %s", device, hipGetErrorString(dev.err));
+    mdetr::ProfileScope prof(14, cols, static_cast<hipStream_t>(stream), 0.0, static_cast<double>(rows) * cols * (io_dtype == MDETR_BF16 ? 2.0 : 4.0) * 3.0 / 1e3);
     const hipError_t e = mdetr::bias_act_backward_launch(io_dtype, dy, y, dx, rows, cols, scale, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_bias_act_backward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
@@ -800,6 +816,7 @@ int mdetr_small_wgrad(int io_dtype, const void *dy, const void *x, void *out, in
         return fail(MDETR_E_ALIGN, "mdetr_small_wgrad: x, out, workspace must be 16-byte aligned");
     DeviceScope dev(device);
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_small_wgrad: set device %d: %s", device, hipGetErrorString(dev.err));
+    mdetr::ProfileScope prof(16, n, static_cast<hipStream_t>(stream), 2.0 * rows * n * k / 1e6, (static_cast<double>(rows) * (n + k) * (io_dtype == MDETR_BF16 ? 2.0 : 4.0) + 4.0 * n * k) / 1e3);
     const hipError_t e = mdetr::small_wgrad_launch(io_dtype, dy, x, out, workspace, rows, n, k, ldy, ldx, out_dtype, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_small_wgrad: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
@@ -834,6 +851,7 @@ int mdetr_group_norm_forward(int io_dtype, int param_dtype, const void *x, const
     DeviceScope dev(device);
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_group_norm_forward: set device %d: %s", device, hipGetErrorString(dev.err));
     const mdetr::GroupNormProblem p{io_dtype, param_dtype, n, hw, c, groups, eps, relu ? 1 : 0};
+    mdetr::ProfileScope prof(15, c, static_cast<hipStream_t>(stream), 0.0, 2.0 * n * hw * c * (io_dtype == MDETR_BF16 ? 2.0 : 4.0) / 1e3);
     const hipError_t e = mdetr::group_norm_forward_launch(p, x, gamma, beta, y, stats, workspace, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_group_norm_forward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
@@ -855,6 +873,7 @@ int mdetr_group_norm_backward(int io_dtype, int param_dtype, const void *dy, con
     if (!aligned16(dy) || !aligned16(x) || !aligned16(dx) || !aligned16(gamma) || !aligned16(beta) || !aligned16(dparams) || !aligned16(workspace))
         return fail(MDETR_E_ALIGN, "mdetr_group_norm_backward: dy, x, dx, gamma, beta, dparams, workspace must be 16-byte aligned");
     const mdetr::GroupNormProblem p{io_dtype, param_dtype, n, hw, c, groups, 0.f, relu ? 1 : 0};
+    mdetr::ProfileScope prof(15, c, static_cast<hipStream_t>(stream), 0.0, 3.0 * n * hw * c * (io_dtype == MDETR_BF16 ? 2.0 : 4.0) / 1e3);
     const hipError_t e = mdetr::group_norm_backward_launch(p, dy, x, gamma, beta, stats, dx, dparams, workspace, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_group_norm_backward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
@@ -882,6 +901,7 @@ int mdetr_add_layernorm_forward(int io_dtype, int param_dtype, const void *a, co
     DeviceScope dev(device);
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_add_layernorm_forward: set device %d: %s", device, hipGetErrorString(dev.err));
     const mdetr::AddLnProblem p{io_dtype, param_dtype, rows, cols, eps, dropout_p, seed, seed_dev};
+    mdetr::ProfileScope prof(13, cols, static_cast<hipStream_t>(stream), 0.0, 4.0 * rows * cols * (io_dtype == MDETR_BF16 ? 2.0 : 4.0) / 1e3);
     const hipError_t e = mdetr::add_ln_forward_launch(p, a, b, gamma, beta, y, s, stats, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_add_layernorm_forward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
@@ -902,8 +922,12 @@ int mdetr_add_layernorm_backward(int io_dtype, int param_dtype, const void *dy, 
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_add_layernorm_backward: set device %d: %s", device, hipGetErrorString(dev.err));
     const mdetr::AddLnProblem p{io_dtype, param_dtype, rows, cols, 0.f, dropout_p, seed, seed_dev};
     hipError_t e = hipSuccess;
-    if (rows == 0) e = mdetr::zero_fill_launch(partial, static_cast<int64_t>(2) * cols * 4, static_cast<hipStream_t>(stream));
-    else e = mdetr::add_ln_backward_launch(p, dy, s, gamma, stats, da, db, partial, static_cast<hipStream_t>(stream));
+    if (rows == 0) {
+        e = mdetr::zero_fill_launch(partial, static_cast<int64_t>(2) * cols * 4, static_cast<hipStream_t>(stream));
+    } else {
+        mdetr::ProfileScope prof(13, cols, static_cast<hipStream_t>(stream), 0.0, 4.0 * rows * cols * (io_dtype == MDETR_BF16 ? 2.0 : 4.0) / 1e3);
+        e = mdetr::add_ln_backward_launch(p, dy, s, gamma, stats, da, db, partial, static_cast<hipStream_t>(stream));
+    }
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_add_layernorm_backward: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }

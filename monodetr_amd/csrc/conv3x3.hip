@@ -221,7 +221,8 @@ hipError_t conv3x3_launch(const void *x, const void *w, const float *shift, void
                           hipStream_t st, bool mirror)
 {
     ConvDims d{B, H, W, C, N, (W + kTileW - 1) / kTileW, (H + kWavesC - 1) / kWavesC, 0, 0, 0, mirror ? 1 : 0};
-    ProfileScope prof(9, conv_mflop(static_cast<int64_t>(B) * H * W, static_cast<int64_t>(C) * N * 9), st);
+    ProfileScope prof(9, conv_mflop(static_cast<int64_t>(B) * H * W, static_cast<int64_t>(C) * N * 9), st, 18.0 * B * H * W * C * N / 1e6,
+                      (2.0 * B * H * W * (C + N) + 18.0 * N * C) / 1e3);
     // 128 output channels per workgroup where the layer has them (the halo is then read once per 128 channels); 64 for the
     // 64-channel stage
     int nb = N >= 128 ? 4 : (N >= 64 ? 2 : 1);

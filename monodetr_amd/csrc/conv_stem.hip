@@ -132,7 +132,8 @@ hipError_t conv_stem_launch(const void *x, const void *wp, const float *shift, v
     d.groups_x = (d.tiles_x + kTilesPerWg - 1) / kTilesPerWg;
     d.tiles_y = (d.OH + kWavesS - 1) / kWavesS;
     const int64_t blocks = static_cast<int64_t>(B) * d.tiles_y * d.groups_x;
-    ProfileScope prof(9, conv_mflop(static_cast<int64_t>(B) * d.OH * d.OW, 64 * 3 * 49), st);
+    ProfileScope prof(9, conv_mflop(static_cast<int64_t>(B) * d.OH * d.OW, 64 * 3 * 49), st, 2.0 * B * d.OH * d.OW * 64 * 147 / 1e6,
+                      (2.0 * B * (static_cast<double>(d.H) * d.W * 3 + static_cast<double>(d.OH) * d.OW * 64)) / 1e3);
     hipLaunchKernelGGL(conv_stem_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kWavesS * 64), 0, st, static_cast<const __bf16 *>(x),
                        static_cast<const __bf16 *>(wp), shift, static_cast<__bf16 *>(y), d);
     return hipGetLastError();

@@ -458,7 +458,8 @@ hipError_t conv_dgrad_s2_launch(const void *dy, const void *wt, void *dx, int B,
     q.blk0[4] = blk;
     if (blk == 0) return hipSuccess;
     // every output pixel of dY meets every (tap, channel pair) once: the four parity classes together are the dense product
-    ProfileScope prof(9, conv_mflop(static_cast<int64_t>(B) * OH * OW, static_cast<int64_t>(C) * N * K * K), st);
+    ProfileScope prof(9, conv_mflop(static_cast<int64_t>(B) * OH * OW, static_cast<int64_t>(C) * N * K * K), st, 2.0 * B * OH * OW * C * N * K * K / 1e6,
+                      (2.0 * B * (static_cast<double>(OH) * OW * N + 4.0 * OH * OW * C) + 2.0 * K * K * N * C) / 1e3);
     return nb == 4 ? launch_dgrad4<4>(dy, wt, dx, q, st) : launch_dgrad4<2>(dy, wt, dx, q, st);
 }
 
@@ -470,13 +471,17 @@ bool conv_taps_split_supported(const ConvTapsDims &d, int ksplit)
 
 hipError_t conv_taps_split_launch(const void *x, const void *w, const float *shift, float *part, const ConvTapsDims &d, int ksplit, hipStream_t st)
 {
-    ProfileScope prof(9, conv_mflop(static_cast<int64_t>(d.B) * d.OH * d.OW, static_cast<int64_t>(d.C) * d.N * d.TR * d.TS), st);
+    ProfileScope prof(9, conv_mflop(static_cast<int64_t>(d.B) * d.OH * d.OW, static_cast<int64_t>(d.C) * d.N * d.TR * d.TS), st,
+                      2.0 * d.B * d.OH * d.OW * d.C * d.N * d.TR * d.TS / 1e6,
+                      (2.0 * d.B * (static_cast<double>(d.H) * d.W * d.C) + 4.0 * ksplit * d.B * d.OH * d.OW * d.N + 2.0 * d.TR * d.TS * d.N * d.C) / 1e3);
     return launch_split<3, 3, 2>(x, w, shift, part, d, ksplit, st);
 }
 
 hipError_t conv_taps_launch(const void *x, const void *w, const float *shift, void *y, const ConvTapsDims &d, bool relu, hipStream_t st)
 {
-    ProfileScope prof(9, conv_mflop(static_cast<int64_t>(d.B) * d.OH * d.OW, static_cast<int64_t>(d.C) * d.N * d.TR * d.TS), st);
+    ProfileScope prof(9, conv_mflop(static_cast<int64_t>(d.B) * d.OH * d.OW, static_cast<int64_t>(d.C) * d.N * d.TR * d.TS), st,
+                      2.0 * d.B * d.OH * d.OW * d.C * d.N * d.TR * d.TS / 1e6,
+                      (2.0 * d.B * (static_cast<double>(d.H) * d.W * d.C + static_cast<double>(d.OH) * d.OW * d.N) + 2.0 * d.TR * d.TS * d.N * d.C) / 1e3);
     if (d.SI == 2) return d.TR == 3 ? by_width<3, 3, 2>(x, w, shift, y, d, relu, st) : by_width<1, 1, 2>(x, w, shift, y, d, relu, st);
     if (d.TR == 1) return d.TS == 1 ? by_width<1, 1, 1>(x, w, shift, y, d, relu, st) : by_width<1, 2, 1>(x, w, shift, y, d, relu, st);
     return d.TS == 1 ? by_width<2, 1, 1>(x, w, shift, y, d, relu, st) : by_width<2, 2, 1>(x, w, shift, y, d, relu, st);

@@ -287,7 +287,9 @@ int conv_wgrad_chunks(const ConvWgradDims &d) { return geometry(d).chunks; }
 hipError_t conv_wgrad_launch(const void *x, const void *dy, float *part, const ConvWgradDims &d, hipStream_t st)
 {
     const WgradGeom g = geometry(d);
-    ProfileScope prof(9, conv_mflop(static_cast<int64_t>(d.B) * d.OH * d.OW, static_cast<int64_t>(d.C) * d.N * d.K * d.K), st);
+    ProfileScope prof(d.K == 1 && d.SI == 1 ? 11 : 9, conv_mflop(static_cast<int64_t>(d.B) * d.OH * d.OW, static_cast<int64_t>(d.C) * d.N * d.K * d.K), st,
+                      2.0 * d.B * d.OH * d.OW * d.C * d.N * d.K * d.K / 1e6,
+                      (2.0 * d.B * (static_cast<double>(d.H) * d.W * d.C + static_cast<double>(d.OH) * d.OW * d.N) + 4.0 * g.chunks * d.K * d.K * d.N * d.C) / 1e3);
     if (d.K == 3) return d.SI == 1 ? launch<1, 3>(x, dy, part, g, st) : launch<2, 3>(x, dy, part, g, st);
     return d.SI == 1 ? launch<1, 1>(x, dy, part, g, st) : launch<2, 1>(x, dy, part, g, st);
 }

@@ -112,9 +112,18 @@ void profile_begin(int kind, int Lq, hipStream_t st);
 void profile_end(hipStream_t st);
 // one event pair around the launches of a scope.  kind 9 = a hand-written convolution, key = its MFLOP (2 x MACs / 1e6): what
 // bench.py's `mfma` object sums into TFLOP/s against the dense bf16 MFMA peak
+// ... and the useful work of the launches inside the scope (MFLOP, algorithmic KB): what bench.py's `families` divide by the
+// families' kernel times.  kinds: 10 token GEMM, 11 token weight gradient, 12 column sum, 13 residual LayerNorm, 14 bias / activation
+// tails, 15 GroupNorm, 16 small-T weight gradient, 17 MSDA prologue, 18 AdamW, 19 gathers / pooling
+void profile_work(double mflop, double kbytes);
 struct ProfileScope {
     hipStream_t s;
     ProfileScope(int kind, int64_t key, hipStream_t st) : s(st) { profile_begin(kind, static_cast<int>(key > 0x7fffffff ? 0x7fffffff : key), st); }
+    ProfileScope(int kind, int64_t key, hipStream_t st, double mflop, double kbytes) : s(st)
+    {
+        profile_begin(kind, static_cast<int>(key > 0x7fffffff ? 0x7fffffff : key), st);
+        profile_work(mflop, kbytes);
+    }
     ~ProfileScope() { profile_end(s); }
 };
 inline int64_t conv_mflop(int64_t out_pixels, int64_t macs_per_pixel) { return (2 * out_pixels * macs_per_pixel + 500000) / 1000000; }

@@ -457,7 +457,8 @@ hipError_t tgemm_launch(const TgemmProblem &p, hipStream_t st)
     int pf = 2;
     if (bm == 128 && bn == 128 && (p.res || (p.flags & (kTgemmBiasF32 | kTgemmOutF32)) || p.dropout_p > 0.f)) pf = 1;       // (the big tile's tails: registers)
     if (const char *ev = getenv("MDETR_TGEMM_PF")) pf = atoi(ev) == 1 ? 1 : 2;       // A/B runs: register sets in flight
-    ProfileScope prof(10, conv_mflop(p.T, static_cast<int64_t>(p.N) * p.K), st);
+    ProfileScope prof(10, conv_mflop(p.T, static_cast<int64_t>(p.N) * p.K), st, 2.0 * p.T * p.N * p.K / 1e6,
+                      (2.0 * p.T * p.K + ((p.flags & kTgemmOutF32) ? 4.0 : 2.0) * p.T * p.N + (p.res ? 2.0 * p.T * p.N : 0.0) + 2.0 * p.N * p.K) / 1e3);
     if (p.flags & kTgemmNN) return pf == 1 ? launch_tail<true, 1>(g, bm, bn, st) : launch_tail<true, 2>(g, bm, bn, st);
     return pf == 1 ? launch_tail<false, 1>(g, bm, bn, st) : launch_tail<false, 2>(g, bm, bn, st);
 }

@@ -256,7 +256,8 @@ hipError_t twgrad_launch(const void *x, const void *dy, float *part, int64_t T, 
     g.T = T; g.ldx = ldx; g.ldy = ldy; g.part_stride = static_cast<int64_t>(N) * C + (with_db ? N : 0);
     g.C = C; g.N = N; g.tiles_n = p.tiles_n; g.tiles_c = p.tiles_c; g.chunks = p.chunks; g.slabs = p.slabs; g.slabs_per_chunk = p.slabs_per_chunk;
     g.with_db = with_db ? 1 : 0;
-    ProfileScope prof(9, conv_mflop(T, static_cast<int64_t>(C) * N), st);
+    ProfileScope prof(11, conv_mflop(T, static_cast<int64_t>(C) * N), st, 2.0 * T * N * C / 1e6,
+                      (2.0 * T * (N + C) + 4.0 * p.chunks * (static_cast<double>(N) * C + (with_db ? N : 0))) / 1e3);       // (+ the fp32 partials it writes)
     if (p.bn == 128 && p.bc == 128) return launch_tile<128, 128>(g, st);
     if (p.bn == 128) return launch_tile<128, 64>(g, st);
     if (p.bc == 128) return launch_tile<64, 128>(g, st);

@@ -644,13 +644,24 @@ def test_conv3x3_kernel_matches_the_library_convolution(B, H, W, C, N, relu):
     y.backward(dy)
     got = (y.detach(), x.grad.clone(), w.grad.clone())
     x.grad = w.grad = None
-    ref = torch.nn.functional.conv2d(x.float(), w.float(), shift, padding=1)            # fp32 on the same bf16 inputs
-    ref = torch.relu(ref) if relu else ref
+    from gemm_bounds import assert_product_close, conv2d_f64
+    # fp64 on the same bf16 operands, ELEMENT-WISE: one bf16 rounding of the value + fp32 accumulation noise, the latter scaled by
+    # the SAME operator applied to absolute values (round 4: 1.2e-2 / 4.8e-2 of the tensor's maximum)
+    x64, w64 = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    pre = conv2d_f64(x64, w64, shift.double(), padding=1)
+    ref = torch.relu(pre) if relu else pre
     mask = (y.detach() > 0) if relu else torch.ones_like(ref, dtype=torch.bool)
-    gx, gw = torch.autograd.grad(torch.nn.functional.conv2d(x.float(), w.float(), None, padding=1), (x, w), dy.float() * mask)
-    for name, a, r in zip(("y", "dx", "dw"), got, (ref, gx, gw)):
-        lim = 1.2e-2 * max(1.0, r.abs().max().item()) * (4 if name == "dw" else 1)      # dw: the library's bf16 split-K sums
-        assert (a.float() - r).abs().max().item() <= lim, name
+    gx, gw = torch.autograd.grad(pre, (x64, w64), dy.double() * mask)
+    xa, wa = x.detach().double().abs().requires_grad_(True), w.detach().double().abs().requires_grad_(True)
+    my = conv2d_f64(xa, wa, shift.double().abs(), padding=1)
+    mx, mw = torch.autograd.grad(my, (xa, wa), dy.double().abs() * mask)
+    for name, a, r, m, K in zip(("y", "dx", "dw"), got, (ref.detach(), gx, gw), (my.detach(), mx, mw), (9 * C, 9 * N, B * H * W)):
+        if name == "dx" and N % 64 != 0:
+            # (the input gradient's contraction runs over N: 96 channels are not whole slabs and go to the library, whose bf16 kernel
+            # is not this repository's to hold to an ulp bound)
+            assert ((a.double() - r).norm() / r.norm()).item() <= 1e-2
+            continue
+        assert_product_close(a, r, m, K, name)
 
 
 def test_training_step_with_the_conv3x3_kernel_matches_default():
@@ -717,13 +728,17 @@ def test_conv_strided_kernel_matches_the_library_convolution(B, H, W, C, N, k, r
     y.backward(dy)
     got = (y.detach(), x.grad.clone(), w.grad.clone())
     x.grad = w.grad = None
-    ref = F.conv2d(x.float(), w.float(), shift, stride=2, padding=pad)                  # fp32 on the same bf16 inputs
-    ref = torch.relu(ref) if relu else ref
+    from gemm_bounds import assert_product_close, conv2d_f64
+    x64, w64 = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    pre = conv2d_f64(x64, w64, shift.double(), stride=2, padding=pad)                     # fp64 on the same bf16 operands
+    ref = torch.relu(pre) if relu else pre
     mask = (y.detach() > 0) if relu else torch.ones_like(ref, dtype=torch.bool)
-    gx, gw = torch.autograd.grad(F.conv2d(x.float(), w.float(), None, stride=2, padding=pad), (x, w), dy.float() * mask)
-    for name, a, r in zip(("y", "dx", "dw"), got, (ref, gx, gw)):
-        lim = 1.2e-2 * max(1.0, r.abs().max().item())                                   # one bf16 rounding of an fp32 sum
-        assert (a.float() - r).abs().max().item() <= lim, name
+    gx, gw = torch.autograd.grad(pre, (x64, w64), dy.double() * mask)
+    xa, wa = x.detach().double().abs().requires_grad_(True), w.detach().double().abs().requires_grad_(True)
+    my = conv2d_f64(xa, wa, shift.double().abs(), stride=2, padding=pad)
+    mx, mw = torch.autograd.grad(my, (xa, wa), dy.double().abs() * mask)
+    for name, a, r, m, K in zip(("y", "dx", "dw"), got, (ref.detach(), gx, gw), (my.detach(), mx, mw), (k * k * C, k * k * N, B * OH * OW)):
+        assert_product_close(a, r, m, K, name)                                            # element-wise (round 4: 1.2e-2 of the tensor's maximum)
 
 
 @pytest.mark.parametrize("B,H,W,C,N", [(8, 48, 160, 128, 128), (8, 24, 80, 256, 256), (8, 12, 40, 512, 512), (2, 9, 37, 64, 96), (8, 32, 110, 256, 256)])
@@ -736,12 +751,14 @@ def test_conv_wgrad_kernel_matches_the_library_weight_gradient(B, H, W, C, N, mo
     x = torch.randn(B, C, H, W, generator=g, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     dy = torch.randn(B, N, H, W, generator=g, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     assert conv_wgrad_ext.supported(x, dy, 3, 1)
-    w = torch.zeros(N, C, 3, 3, device="cuda", requires_grad=True)
-    ref, = torch.autograd.grad(torch.nn.functional.conv2d(x.float(), w, None, padding=1), w, dy.float())
-    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 6e-3)):
+    from gemm_bounds import assert_product_close, conv2d_f64
+    w = torch.zeros(N, C, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    ref, = torch.autograd.grad(conv2d_f64(x.double(), w, None, padding=1), w, dy.double())
+    mag, = torch.autograd.grad(conv2d_f64(x.double().abs(), w, None, padding=1), w, dy.double().abs())
+    for dtype in (torch.float32, torch.bfloat16):
         dw = conv_wgrad_ext.weight_gradient(x, dy, 3, 1, dtype)
         assert dw.shape == ref.shape and dw.dtype == dtype
-        assert (dw.float() - ref).abs().max().item() <= tol * ref.abs().max().item(), dtype
+        assert_product_close(dw, ref, mag, B * H * W, str(dtype))                        # element-wise against fp64
     a, b = conv_wgrad_ext.weight_gradient(x, dy, 3, 1, torch.float32), conv_wgrad_ext.weight_gradient(x, dy, 3, 1, torch.float32)
     assert torch.equal(a, b)                                                             # fixed-order sums: deterministic
 
