@@ -46,6 +46,7 @@ kernels themselves.
                 ops and the C oracle as the operator (`value`, images/sec).  kind "port".  N = 1, rank 0 only.
 """
 import argparse
+import contextlib
 import gc
 import json
 import os
@@ -478,6 +479,81 @@ def pmc_traffic(path=None):
     return {}, "PMC record is of another kernel source (%s, this tree %s): not reported" % (rec.get("kernel_source_sha"), kernel_source_sha())
 
 
+FAMILY_PATTERNS = (      # (family, substrings of the kernel name, profile kinds whose declared work belongs to it)
+    ("token_gemm", ("tgemm_kernel",), (10,)),
+    ("token_weight_gradient", ("twgrad_kernel", "conv_wgrad_kernel<1, 1>"), (11,)),
+    ("convolutions", ("conv3x3_kernel", "conv_taps", "conv_dgrad4", "conv_stem", "conv_wgrad_kernel", "maxpool3x3s2", "decimate"), (9,)),
+    ("small_weight_gradient", ("small_wgrad",), (16,)),
+    ("column_sums", ("colsum",), (12,)),
+    ("residual_layernorm", ("add_ln",), (13,)),
+    ("bias_activation_tails", ("bias_act",), (14,)),
+    ("group_norm", ("gn_fwd", "gn_bwd"), (15,)),
+    ("msda", ("msda", "prologue_fwd", "prologue_bwd"), ()),
+    ("attention", ("attn_",), ()),
+    ("losses_matching_optimizer", ("pair_losses", "ddn_", "lsa_kernel", "adamw_kernel", "multi_tensor_apply"), ()),
+    ("library_gemm", ("Cijk_",), ()),
+    ("framework_elementwise", ("elementwise", "vectorized", "CatArray", "reduce_kernel", "rocclr", "index", "gather", "scatter", "softmax", "copy"), ()),
+)
+STEP_FLOP = 2.95e12          # one B = 8 training iteration at 384 x 1280
+
+
+def family_of(kernel_name):
+    for fam, pats, _ in FAMILY_PATTERNS:
+        if any(p in kernel_name for p in pats):
+            return fam
+    return "other"
+
+
+def families_table(kernel_times, work, msda_bytes=0.0, attn_flop=0.0, iterations=1):
+    """kernel_times: [(kernel name, launches, total microseconds)] of `iterations` eager iterations (torch.profiler);
+    work: {profile kind: (MFLOP, KB)} declared by the C ABI's launchers over the same number of iterations.  -> the `families` list
+    of the driver line: launches and time per step, algorithmic bytes and flops per step, the bound they imply (HBM 8 TB/s vs dense
+    bf16 MFMA 2.5 PFLOP/s, whichever takes longer) and the fraction of it reached.  Families without declared work (library GEMMs,
+    framework elementwise) carry their time only."""
+    acc = {}
+    for name, launches, us in kernel_times:
+        a = acc.setdefault(family_of(name), [0, 0.0])
+        a[0] += launches
+        a[1] += us
+    out = []
+    for fam, (launches, us) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+        row = {"name": fam, "launches": round(launches / iterations, 1), "ms_per_step": round(us / iterations / 1e3, 3)}
+        kinds = next((k for f, _, k in FAMILY_PATTERNS if f == fam), ())
+        flops = sum(work.get(k, (0.0, 0.0))[0] for k in kinds) * 1e6 / iterations
+        byts = sum(work.get(k, (0.0, 0.0))[1] for k in kinds) * 1e3 / iterations
+        if fam == "msda":
+            byts = msda_bytes
+        if fam == "attention":
+            flops = attn_flop
+        if flops > 0 or byts > 0:
+            t_hbm, t_mfma = byts / 8.0e12, flops / 2.5e15
+            row.update(algorithmic_bytes=int(byts), flops=int(flops), bound="hbm" if t_hbm >= t_mfma else "mfma",
+                       frac=round(max(t_hbm, t_mfma) / (us / iterations * 1e-6), 4) if us > 0 else None)
+        else:
+            row.update(algorithmic_bytes=None, flops=None, bound=None, frac=None)
+        out.append(row)
+    return out
+
+
+def profile_kernels(step, iterations=1):
+    """[(kernel name, launches, total device microseconds)] of `iterations` eagerly launched iterations under torch.profiler
+    (roctracer): every kernel of the step, the libraries' and the framework's included."""
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        with torch.cuda.stream(step.stream) if getattr(step, "stream", None) is not None else contextlib.nullcontext():
+            for _ in range(iterations):
+                step.eager_iteration()
+        torch.cuda.synchronize()
+    rows = []
+    for e in prof.key_averages():
+        us = getattr(e, "device_time_total", None)
+        if us is None:
+            us = getattr(e, "cuda_time_total", 0.0)
+        if us and us > 0:
+            rows.append((e.key, int(e.count), float(us)))
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -629,6 +705,14 @@ def main():
         torch.cuda.synchronize()
         _capi.profile_enable(False)
         kernel_timing = "HIP events around every launch of 3 eager iterations run right after the timed graph replays"
+    work_rows = _capi.profile_read_work()                       # (kind, key, launches, ms, MFLOP, KB) of those iterations
+    work_iters = 3 if use_graph else args.steps
+    family_kernels, family_error = None, None
+    if rank == 0 and hasattr(step, "eager_iteration") and os.environ.get("MDETR_BENCH_FAMILIES", "1") != "0":
+        try:                                                    # one more eager iteration under torch.profiler: every kernel's time
+            family_kernels = profile_kernels(step, 1)
+        except Exception as e:                                  # noqa: BLE001 -- a reported breakdown must not cost the measured line
+            family_error = repr(e)[:200]
     if dist_on:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -725,6 +809,22 @@ def main():
                                "launches_per_step": round(g[2] / (3 if use_graph else args.steps), 1),
                                "ms_per_step": round(g[1] / (3 if use_graph else args.steps), 3)}
                            for k, g in mfma_groups.items() if g[1] > 0}}
+        # where the step's GPU time goes, family by family, against the bound each family's declared work implies
+        if family_kernels is not None:
+            work = {}
+            for kind, key, launches, total_ms, mflop, kb in work_rows:
+                w = work.setdefault(kind, [0.0, 0.0])
+                w[0] += mflop; w[1] += kb
+            msda_b = sum(msda_algorithmic_bytes(args.batch, key, kind != 0, S=S_tokens, mixed=msda_mixed) * launches
+                         for kind, key, launches, _, _, _ in work_rows if kind in (0, 6)) / work_iters
+            attn_f = sum(g[0] for k, g in mfma_groups.items() if k.startswith("attention")) / work_iters
+            line["families"] = families_table(family_kernels, {k: (v[0] / work_iters, v[1] / work_iters) for k, v in work.items()}, msda_b, attn_f, 1)
+            line["families_timing"] = "torch.profiler over one eager iteration after the timed region (same kernels as the replayed graph)"
+            line["kernels_per_step"] = int(sum(n for _, n, _ in family_kernels))
+        elif family_error:
+            line["families"] = {"error": family_error}
+        if args.config == 3:
+            line["step_mfma_frac"] = round(STEP_FLOP / (ms * 1e-3) / 2.5e15, 4)      # 2.95 TFLOP per iteration / step time / dense bf16 peak
         line["config"]["cpu_affinity"] = "NUMA node %d of the GPU" % bound[0] if bound else "unbound"
         line["config"]["gpu_clocks"] = clocks
         # optional kernel families in this run: the committed list, or the environment's for an A/B run
