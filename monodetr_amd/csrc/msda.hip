@@ -725,13 +725,11 @@ hipError_t msda_forward_launch(int dtype, const void *value, const int64_t *shap
                                static_cast<const float *>(loc), static_cast<const float *>(attn),
                                static_cast<float *>(out), B, S, M, L, P, npairs, iters);
         };
-        static const bool legacy = [] { const char *ev = getenv("MDETR_MSDA_FWD_LEGACY"); return ev && atoi(ev) != 0; }();
-        if (L == 4 && P == 4 && !legacy)
+        if (L == 4 && P == 4)
             hipLaunchKernelGGL((msda_fwd_rec<4, 4>), grid, block, 0, st, static_cast<const float *>(value), shapes, lstart,
                                static_cast<const float *>(loc), static_cast<const float *>(attn),
                                static_cast<float *>(out), B, S, M, npairs, iters);
-        else if (L == 4 && P == 4) a(msda_fwd_d32<4, 4>);
-        else a(msda_fwd_d32<0, 0>);
+        else a(msda_fwd_d32<0, 0>);                            // other (L, P) of the D = 32 fast path: the slab kernel with run-time L, P
     } else if (dtype == 0) {
         hipLaunchKernelGGL(msda_fwd_generic<float>, dim3(grid_for(n, 256)), dim3(256), 0, st,
                            static_cast<const float *>(value), shapes, lstart, static_cast<const float *>(loc),

@@ -1145,10 +1145,10 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
     const int reach = env_int("MDETR_MSDA_REACH", 5), chunks_env = env_int("MDETR_MSDA_CHUNKS", 12);
     const int whole_max = env_int("MDETR_MSDA_WHOLE_LEVEL_CELLS", 512);
     if (tile_h < 1 || tile_w < 1 || tile_h * tile_w > kMaxCells || reach < 0 || chunks_env < 1) return false;
-    // the owner scheme (self-attention; MDETR_MSDA_OWNER=0 restores the candidate scheme): 16 x 24 core tiles with a 4-cell halo
-    // = a 24 x 32 window (the model's initial offsets reach 4 px on every level)
-    pl.owner = (self && env_int("MDETR_MSDA_OWNER", 0) != 0) ? 1 : 0;
-    const int otile_h = env_int("MDETR_MSDA_OTILE_H", 16), otile_w = env_int("MDETR_MSDA_OTILE_W", 24), oreach = env_int("MDETR_MSDA_OREACH", 4);
+    // (the owner scheme -- a block looks at its own queries only, 16 x 24 core tiles with a 4-cell halo -- lost its A/B in round 3 and
+    // is no longer instantiated: the OWNER = true branches of the kernel are compiled out, its switch and launch forms are gone)
+    pl.owner = 0;
+    const int otile_h = 16, otile_w = 24, oreach = 4;
     if (pl.owner && (otile_h < 1 || otile_w < 1 || oreach < 0 || (otile_h + 2 * oreach) * (otile_w + 2 * oreach) > kMaxCells)) return false;
     pl.small = (reach < (1 << 13) && oreach < (1 << 13)) ? 1 : 0;
     for (int l = 0; l < L; ++l)
@@ -1306,24 +1306,15 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
     const int groups = env_int("MDETR_MSDA_GROUPS", 2);      // (12-wave form: 2 or 4 groups of 16 own samples in flight)
     static bool attr_set[10][64] = {};                        // per kernel instance and device
     int which = elem_dtype != 2 ? 0 : (threads == 512 ? 1 : (threads == 768 ? (groups >= 4 ? 5 : 4) : (lps == 8 ? 2 : (lps == 2 ? 9 : 3))));
-    if (pl.owner && which >= 2 && which != 3) {              // the owner scheme is instantiated for the default forms only
-        which = 3;
-        threads = 1024;
-        lds = lds_bytes(threads);
-        if (lds > 160 * 1024) return hipErrorNotSupported;
-    }
     typedef __hip_bfloat16 bf;
-    const void *kern = (pl.owner && which == 0) ? reinterpret_cast<const void *>(msda_bwd_fused<float, float, 512, 4, 8, true>)
-                     : (pl.owner && which == 1) ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 512, 4, 8, true>)
-                     : (pl.owner && which == 3) ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 1024, 2, 4, true>)
-                     : which == 0 ? reinterpret_cast<const void *>(msda_bwd_fused<float, float, 512, 4, 8>)
+    const void *kern = which == 0 ? reinterpret_cast<const void *>(msda_bwd_fused<float, float, 512, 4, 8>)
                      : which == 1 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 512, 4, 8>)
                      : which == 2 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 1024, 4, 8>)
                      : which == 3 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 1024, 2, 4>)
                      : which == 4 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 768, 2, 4>)
                      : which == 9 ? reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 1024, 1, 2>)
                                   : reinterpret_cast<const void *>(msda_bwd_fused<bf, bf, 768, 4, 4>);
-    const int slot_ = pl.owner ? (which == 0 ? 6 : (which == 1 ? 7 : 8)) : which;
+    const int slot_ = which;
     if (dev < 0 || dev >= 64 || !attr_set[slot_][dev]) {
         if ((err = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return err;
         if (dev >= 0 && dev < 64) attr_set[slot_][dev] = true;
@@ -1335,10 +1326,7 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
         hipLaunchKernelGGL(k, dim3(nblocks), dim3(threads), lds, st, pl, static_cast<const VT *>(value), loc, attn,
                            static_cast<const GT *>(grad_out), grad_value, grad_loc, grad_attn, hdr, scratch, far);
     };
-    if (pl.owner && which == 0) go(msda_bwd_fused<float, float, 512, 4, 8, true>, float(), float());
-    else if (pl.owner && which == 1) go(msda_bwd_fused<bf, bf, 512, 4, 8, true>, bf(), bf());
-    else if (pl.owner && which == 3) go(msda_bwd_fused<bf, bf, 1024, 2, 4, true>, bf(), bf());
-    else if (which == 0) go(msda_bwd_fused<float, float, 512, 4, 8>, float(), float());
+    if (which == 0) go(msda_bwd_fused<float, float, 512, 4, 8>, float(), float());
     else if (which == 1) go(msda_bwd_fused<bf, bf, 512, 4, 8>, bf(), bf());
     else if (which == 2) go(msda_bwd_fused<bf, bf, 1024, 4, 8>, bf(), bf());
     else if (which == 3) go(msda_bwd_fused<bf, bf, 1024, 2, 4>, bf(), bf());

@@ -25,6 +25,11 @@ _GEMM_RELU = os.environ.get("MDETR_GEMM_RELU") == "1"
 _TGEMM = os.environ.get("MDETR_TGEMM") == "1"
 
 
+# rows from which a bf16 weight gradient takes csrc/twgrad.hip instead of csrc/small_wgrad.hip: the decoder's 4 400 and layer4's 3 840
+# rows included (421.7 -> 426.9 img/s, profiles/r05n_step_ab_twgrad_small_rows.log; MDETR_TWGRAD_MIN_ROWS=1000000000 restores round 4's split)
+_TWGRAD_MIN_ROWS = int(os.environ.get("MDETR_TWGRAD_MIN_ROWS", "1024"))
+
+
 def _tgemm_ok(x2, weight, bias=None, res2=None, nn=False):
     if not _TGEMM:
         return False
@@ -73,6 +78,11 @@ def _weight_bias_grads(x2, dy2, weight, need_w, need_b, bias_dtype=None, out_dty
         return (dw.to(dt) if dw is not None else None), db.to(bias_dtype)
     dw = db = None
     T = x2.shape[0]
+    if need_w and _TWGRAD_MIN_ROWS <= T <= small_wgrad_ext.MAX_ROWS and dt in (torch.float32, torch.bfloat16):
+        # a few thousand rows of bf16 operands (the decoder's 4 400, layer4's 3 840): csrc/twgrad.hip as well (MDETR_TWGRAD_MIN_ROWS)
+        from .. import conv_wgrad_ext
+        if conv_wgrad_ext.token_supported(x2, dy2):
+            return conv_wgrad_ext.token_weight_gradient(x2, dy2, dt, bias=need_b)
     if small_wgrad_ext.ENABLED and need_w and (T <= small_wgrad_ext.MAX_ROWS or dy2.shape[1] <= 64) \
             and dt in (torch.float32, torch.bfloat16) and small_wgrad_ext.supported(dy2, x2):
         # a few thousand rows (the decoder's 4 400): dW and db from one launch + one chunk sum (csrc/small_wgrad.hip)

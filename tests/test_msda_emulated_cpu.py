@@ -222,21 +222,6 @@ def test_fused_backward_matches_the_oracle_for_every_plan(monkeypatch, th, tw, r
     assert close(gv, rv, 1e-5) and close(gl, rl, 1e-6) and close(ga, ra, 1e-6)
 
 
-@pytest.mark.parametrize("oth,otw,oreach", [(4, 6, 2), (3, 5, 1)])
-@pytest.mark.parametrize("shapes,lo,hi", [(TINY, 0.0, 1.0), (SMALL, -0.3, 1.3)])
-def test_fused_backward_owner_scheme_matches_the_oracle(monkeypatch, oth, otw, oreach, shapes, lo, hi):
-    """MDETR_MSDA_OWNER=1 (mode 3: a block looks at its own queries only, its window carries a halo, the rest goes out as global
-    atomics): the rectangles of own queries come from the same 16 bounds the candidate scheme uses, with no margin."""
-    _fused_env(monkeypatch, 4, 8, 2, 30, 3)
-    for k, v in (("MDETR_MSDA_OWNER", 1), ("MDETR_MSDA_OTILE_H", oth), ("MDETR_MSDA_OTILE_W", otw), ("MDETR_MSDA_OREACH", oreach)):
-        monkeypatch.setenv(k, str(v))
-    S = sum(h * w for h, w in shapes)
-    p = make_problem(2, 2, 32, S, shapes, 4, torch.float32, seed=5, lo=lo, hi=hi)
-    gv, gl, ga = bwd(p, path="fused")
-    rv, rl, ra = _oracle_bwd(p)
-    assert close(gv, rv, 1e-5) and close(gl, rl, 1e-6) and close(ga, ra, 1e-6)
-
-
 def test_fused_backward_near_samples_stay_in_lds_and_are_deterministic(monkeypatch):
     """Offsets of at most `reach` cells (the model's initial star pattern, ops/modules/ms_deform_attn.py:107-114): nothing
     takes the global-atomic route (the `far` flag in the workspace header stays 0), and the result is independent of the
