@@ -81,20 +81,24 @@ __device__ __forceinline__ void transpose4x8(const bf16x8 (&in)[4], unsigned (&o
 // its XCD) as ONE sequence of contraction slabs -- the loads of the next tile's first slabs are in flight while this tile's last
 // products issue and its output leaves, so only a workgroup's very first slab pays an exposed memory latency.
 // TAIL: 0 = bias (bf16) + ReLU, bf16 output;  1 = the same + a residual tile;  2 = everything (fp32 bias / output, dropout, residual)
-template <int BM, int BN, bool NN, int PF, int TAIL>
-__global__ __launch_bounds__(kThreadsT, 2)
+// NTH: threads of the workgroup -- 256 (waves 2 x 2) or 512 (2 x 4: the big tile with twice the waves in flight per CU)
+template <int BM, int BN, bool NN, int PF, int TAIL, int NTH = 256>
+__global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2)
 void tgemm_kernel(const TgemmArgs g)
 {
-    constexpr int TM = BM / 64, TN = BN / 64;                    // 32 x 32 blocks of a wave along tokens / features
+    constexpr int kThreadsT = NTH;                               // (shadows the file-level default inside this kernel)
+    constexpr int WNW = NTH / 128;                               // waves along the features (2 along the tokens)
+    constexpr int TM = BM / 64, TN = BN / (32 * WNW);            // 32 x 32 blocks of a wave along tokens / features
     constexpr int XCH = BM * 8 / kThreadsT;                      // 16-byte pieces of an input slab per thread
     constexpr int WCH = NN ? 4 : BN * 8 / kThreadsT;             // weight slab: pieces per thread (NT) / the 4 k-rows of one 4 x 8 block (NN)
     constexpr int WTHR = NN ? 2 * BN : kThreadsT;                // threads that stage the weight slab (NN: 16 k-groups x BN / 8 column blocks)
+    static_assert(TM >= 1 && TN >= 1 && XCH >= 1 && WCH >= 1 && WTHR <= kThreadsT, "tile / workgroup shape");
     MDETR_DYNAMIC_LDS(unsigned char, tg_smem);
     __bf16 *Xs = reinterpret_cast<__bf16 *>(tg_smem);            // [2][BM][kLd]
     __bf16 *Ws = Xs + 2 * BM * kLd;                              // [2][BN][kLd]
     float *Cs = reinterpret_cast<float *>(tg_smem);              // [BM][BN + kCPad], after a tile's last slab
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave & 1, wn = wave >> 1;                    // wave's place: 2 along the tokens, WNW along the features
     const int KT = (g.K + kBK - 1) / kBK;
     const int G = gridDim.x, vtiles = g.gx * g.ny;               // virtual tile ids (gx: row tiles rounded up to a multiple of 8)
     const int64_t tiles_m = (g.T + BM - 1) / BM;
@@ -204,7 +208,7 @@ void tgemm_kernel(const TgemmArgs g)
     };
     auto products = [&](int buf) __attribute__((always_inline)) {
         const __bf16 *xl = Xs + (buf * BM + wm * (BM / 2) + l31) * kLd + half * 8;     // + 32 tm rows, + 16 ks
-        const __bf16 *wl = Ws + (buf * BN + wn * (BN / 2) + l31) * kLd + half * 8;
+        const __bf16 *wl = Ws + (buf * BN + wn * (BN / WNW) + l31) * kLd + half * 8;
 #pragma unroll
         for (int ks = 0; ks < kBK / 16; ++ks) {
             bf16x8 xf[TM], wf[TN];
@@ -268,7 +272,7 @@ void tgemm_kernel(const TgemmArgs g)
         for (int a_ = 0; a_ < TN; ++a_)
 #pragma unroll
             for (int b_ = 0; b_ < TM; ++b_) {
-                float *cr = Cs + (wm * (BM / 2) + b_ * 32 + l31) * (BN + kCPad) + wn * (BN / 2) + a_ * 32 + 4 * half;
+                float *cr = Cs + (wm * (BM / 2) + b_ * 32 + l31) * (BN + kCPad) + wn * (BN / WNW) + a_ * 32 + 4 * half;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     f32x4 o;
@@ -369,12 +373,13 @@ void tgemm_kernel(const TgemmArgs g)
     }
 }
 
-template <int BM, int BN, bool NN, int PF, int TAIL>
+template <int BM, int BN, bool NN, int PF, int TAIL, int NTH = 256>
 hipError_t launch_tile(TgemmArgs g, hipStream_t st)
 {
     constexpr size_t lds = tgemm_lds<BM, BN>();
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
-    auto kern = tgemm_kernel<BM, BN, NN, PF, TAIL>;
+    constexpr int kThreadsT = NTH;
+    auto kern = tgemm_kernel<BM, BN, NN, PF, TAIL, NTH>;
     static bool attr_set[64] = {};                               // the attribute is per device: one process may drive several GPUs
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess) dev_ = -1;
@@ -403,7 +408,17 @@ hipError_t launch_tile(TgemmArgs g, hipStream_t st)
 template <bool NN, int PF, int TAIL>
 hipError_t launch_any(const TgemmArgs &g, int bm, int bn, hipStream_t st)
 {
-    if (bm == 128 && bn == 128) return launch_tile<128, 128, NN, PF, TAIL>(g, st);
+    if (bm == 128 && bn == 128) {
+        // the plain forward product takes the big tile with EIGHT waves (2 x 4) and one register set: 120 registers, twice the waves
+        // in flight per CU at the same LDS -- 24.3 -> 22.4 us at the encoder shape, 34.7 -> 32.1 at the packed projection
+        // (profiles/r05o_gemmbench_eight_waves.json); every other form would spill at the 128-register ceiling that costs.
+        // MDETR_TGEMM_WAVES=4 (A/B runs, read at every launch) restores four waves.
+        if constexpr (!NN && PF == 1 && TAIL == 0) {
+            const char *ev = getenv("MDETR_TGEMM_WAVES");
+            if (!(ev && atoi(ev) == 4)) return launch_tile<128, 128, NN, PF, TAIL, 512>(g, st);
+        }
+        return launch_tile<128, 128, NN, PF, TAIL>(g, st);
+    }
     if (bm == 128) return launch_tile<128, 64, NN, PF, TAIL>(g, st);
     if (bn == 128) return launch_tile<64, 128, NN, PF, TAIL>(g, st);
     return launch_tile<64, 64, NN, PF, TAIL>(g, st);
@@ -456,6 +471,7 @@ hipError_t tgemm_launch(const TgemmProblem &p, hipStream_t st)
     }
     int pf = 2;
     if (bm == 128 && bn == 128 && (p.res || (p.flags & (kTgemmBiasF32 | kTgemmOutF32)) || p.dropout_p > 0.f)) pf = 1;       // (the big tile's tails: registers)
+    if (bm == 128 && bn == 128 && !(p.flags & kTgemmNN) && !p.res && !generic_tail) pf = 1;                                  // (... and its eight-wave plain form)
     if (const char *ev = getenv("MDETR_TGEMM_PF")) pf = atoi(ev) == 1 ? 1 : 2;       // A/B runs: register sets in flight
     ProfileScope prof(10, conv_mflop(p.T, static_cast<int64_t>(p.N) * p.K), st, 2.0 * p.T * p.N * p.K / 1e6,
                       (2.0 * p.T * p.K + ((p.flags & kTgemmOutF32) ? 4.0 : 2.0) * p.T * p.N + (p.res ? 2.0 * p.T * p.N : 0.0) + 2.0 * p.N * p.K) / 1e3);

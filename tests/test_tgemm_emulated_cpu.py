@@ -151,3 +151,18 @@ def test_tgemm_persistent_workgroups_walk_several_tiles(monkeypatch, grid, pf, n
     y = run(a, w, bias=b, nn=nn)
     ref, mag = reference(a, w, nn, b)
     assert_product_close(y, ref, mag, 320, "128x128 persistent")
+
+
+def test_tgemm_eight_wave_form_of_the_big_tile(monkeypatch):
+    """The plain forward product on the 128 x 128 tile runs with 512 threads (waves 2 x 4) and one register set; MDETR_TGEMM_WAVES=4
+    restores four waves -- the same values bit for bit (same products in the same order per element)."""
+    monkeypatch.setenv("MDETR_TGEMM_TILE", "128x128")
+    monkeypatch.setenv("MDETR_TGEMM_GRID", "8")
+    for T, K, N in ((700, 192, 264), (130, 1032, 72)):
+        a, w, b, r = problem(T, K, N, False, T + K)
+        monkeypatch.delenv("MDETR_TGEMM_WAVES", raising=False)
+        y8 = run(a, w, bias=b, relu=True)
+        ref, mag = reference(a, w, False, b, None, True)
+        assert_product_close(y8, ref, mag, K, "8 waves T=%d" % T)
+        monkeypatch.setenv("MDETR_TGEMM_WAVES", "4")
+        assert torch.equal(run(a, w, bias=b, relu=True), y8)
