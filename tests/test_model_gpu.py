@@ -127,12 +127,16 @@ def test_fp32_gradients_per_tensor_against_the_float64_model(built, oracle):
     for n, (norm, proj) in zip(names, golden["f64/grad_fp"].tolist()):
         assert abs(fp[n][0] - norm) < 1e-7 * norm + 1e-10 and abs(fp[n][1] - proj) < 1e-7 * norm + 1e-10, n
     g64 = {n: p.grad for n, p in m64.named_parameters() if p.grad is not None}
-    # ---- fp32 on the GPU
+    # ---- fp32 on the GPU.  The measured pass is the SECOND one of this process: the fp32 model's convolutions are the library's,
+    # and its first call per shape runs whatever algorithm the immediate-mode heuristic names (some of them transform-based, good to
+    # ~1e-3) before the searched choice takes over -- with that first pass measured, the encoder's sampling-offset gradients sat at
+    # 1.8e-2 and the backbone's at 1.8e-3 (profiles/r05k_fp32_gradient_errors_per_tensor.txt), with a warm process at < 1e-3.
     model.train(); criterion.train()
-    model.zero_grad(set_to_none=True)
     dev = lambda t: t.cuda() if torch.is_tensor(t) else t
     tg = [{k: dev(v) for k, v in t.items()} for t in targets]
-    total_on_recorded_matching(model, criterion, model(images.cuda(), calibs.cuda(), tg, img_sizes.cuda() if torch.is_tensor(img_sizes) else img_sizes), tg).backward()
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        total_on_recorded_matching(model, criterion, model(images.cuda(), calibs.cuda(), tg, img_sizes.cuda() if torch.is_tensor(img_sizes) else img_sizes), tg).backward()
     worst = []
     for n, p in model.named_parameters():
         if n not in g64:
@@ -147,26 +151,17 @@ def test_fp32_gradients_per_tensor_against_the_float64_model(built, oracle):
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "fp32_gradient_errors_per_tensor.txt"), "w") as f:
             f.write("\n".join("%.3e %s" % w for w in worst) + "\n")
-    # Where fp32 can NOT meet 1e-3 against float64, and why (measured over several runs, profiles/r05k_fp32_gradient_errors_per_tensor.txt):
-    #  * sampling_offsets (and what feeds only them: level_embed, query position projections) -- d/d(location) of bilinear sampling is
-    #    DISCONTINUOUS at cell boundaries: `loc * W - 0.5` floors differently in fp32 and fp64 for the handful of samples within
-    #    rounding of an integer, and each such sample moves its whole contribution (the reference's fp32 CUDA kernel has the same
-    #    property; tests/test_msda_gpu.py holds the operator itself to the fp32 oracle there).  Run-to-run they vary with the order of
-    #    the fp32 atomics.  Bar: 3e-2 (round 4 held EVERY tensor to 2e-2 of two scalars).
-    #  * the decoder's grouped self-attention q / k projections -- the softmax Jacobian differences nearly equal terms and the fp32
-    #    attention core evaluates products as three bf16 x bf16 MFMA terms (csrc/attn.hip: ~2^-16 per product).  Bar: 6e-3.
-    #  Everything else -- backbone, value / output projections, FFNs, heads, norms: 80 % of ALL tensors are within north_star's 1e-3;
-    #  the backbone's (1.2 - 1.8e-3, the same value in every run) inherit the encoder's flipped samples through the gradient that
-    #  arrives at the pyramid.  Bar: 2.5e-3, and at least 75 % of the 307 tensors within 1e-3.
-    loc_path = ("sampling_offsets", "level_embed", "query_embed", "ca_qpos", "reference_points", "attention_weights")
+    # Where fp32 does NOT meet 1e-3 against float64, and why (profiles/r05q_fp32_gradient_errors_per_tensor.txt): the decoder's grouped
+    # self-attention takes its q / k projections' gradients through the softmax Jacobian -- differences of nearly equal terms -- and
+    # the fp32 attention core evaluates its products as three bf16 x bf16 MFMA terms (csrc/attn.hip: ~2^-16 per product, not 2^-24):
+    # those four tensors per decoder layer carry up to 3.6e-3 and are held to 6e-3.  Everything else -- backbone, deformable attention
+    # (sampling offsets included), FFNs, heads, norms: north_star's 1e-3 (measured worst 5.9e-4).
     soft = ("sa_qcontent_proj", "sa_qpos_proj", "sa_kcontent_proj", "sa_kpos_proj")
-    rest = [w for w in worst if not any(k in w[1] for k in loc_path + soft)]
-    print("largest per-tensor relative gradient errors:", worst[:4], "| outside the two documented classes:", rest[:4],
+    rest = [w for w in worst if not any(k in w[1] for k in soft)]
+    print("largest per-tensor relative gradient errors:", worst[:4], "| outside the self-attention q / k projections:", rest[:4],
           "| tensors within 1e-3: %d of %d" % (sum(1 for w in worst if w[0] <= 1e-3), len(worst)))
-    assert rest[0][0] <= 2.5e-3, rest[:8]
-    assert max(w[0] for w in worst if any(k in w[1] for k in soft)) <= 6e-3
-    assert worst[0][0] <= 3e-2, worst[:8]
-    assert sum(1 for w in worst if w[0] <= 1e-3) >= 0.75 * len(worst)
+    assert rest[0][0] <= 1e-3, rest[:8]
+    assert worst[0][0] <= 6e-3, worst[:8]
 
 
 def test_bf16_autocast_step_runs_and_is_close(built):
