@@ -10,7 +10,7 @@ from . import _capi
 from .attn_ext import _next_seed
 
 _backend = None               # tests substitute the CPU emulation of the same kernel source (tests/native_emul.py)
-# MDETR_FUSED_LN=1 routes the residual sites through the kernel; off until it has run on a GPU
+# MDETR_FUSED_LN=1 routes the residual sites through the kernel; on the committed list of kernel_families.py
 ENABLED = os.environ.get("MDETR_FUSED_LN") == "1"
 
 

@@ -6,7 +6,7 @@ copy that requires grad and appends ``(t, copy)`` to ``boundary``; the first bac
 starts from ``torch.autograd.backward([t ...], [copy.grad ...])``.
 
 Site "msda" -- the single-process iteration in two graphs, the second one STARTING with the encoder's last MSDA backward
-launch (0.45 ms: the runtime's slow first launches of a graph arrive while it runs).  Its cut set: the operator's
+launch (0.45 ms: the runtime's slow first launches of a graph arrive while it runs, round 4: profiles/r04gap_msda_parts.txt).  Its cut set: the operator's
 output and the residual stream next to it in the encoder's LAST layer (``armed``), and the pyramid levels the depth predictor
 reads (the only other way from the loss to the backbone)."""
 import contextlib

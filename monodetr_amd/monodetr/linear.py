@@ -18,7 +18,7 @@ from .. import colsum_ext, small_wgrad_ext
 
 _MIN_TOKENS = 4096
 # MDETR_GEMM_RELU=1: "linear -> ReLU" as one library GEMM with the RELU_BIAS epilogue (torch._addmm_activation ->
-# hipBLASLt) instead of a GEMM and an elementwise pass.  Off until timed on a GPU.
+# hipBLASLt) instead of a GEMM and an elementwise pass.  On the committed list (kernel_families.py); the bf16 step takes csrc/tgemm.hip's epilogue instead.
 _GEMM_RELU = os.environ.get("MDETR_GEMM_RELU") == "1"
 # MDETR_TGEMM=1: forward and input-gradient products of bf16 layers through csrc/tgemm.hip, their elementwise tails (bias, ReLU,
 # Dropout, "+ identity", the residual-path gradient's accumulation) inside its epilogue.  kernel_families decides (committed for bf16).

@@ -1,4 +1,4 @@
-"""Op-level timing of the kernels written after round 1's GPU budget against the framework operators
+"""Op-level timing of the kernels written after round 1's GPU budget (the optional families of kernel_families.py) against the framework operators
 they replace, at the encoder's token count (81 600 x 256, bf16), with algorithmic bytes -> fraction of the 8 TB/s HBM
 roofline.
 

@@ -9,7 +9,7 @@ for several (cell stride, window row stride, lane layout, record order) combinat
 group serialise -- also when they hit the SAME address (atomics do not broadcast).  Result (profiles/r04_lds_atomic_model.txt):
 1.8 - 1.9 for every combination -- the +-1-cell randomness of floor() puts neighbouring queries' corners on the same cell, which no
 layout removes; only the rows-32-cells-apart case of heads 2 / 6 (2.56 -> 1.93) responds to padding the window rows, which is
-what DESIGN.md 3.2's row padding does.  `SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE` = 0.36 on the GPU agrees."""
+what msda_fused.hip's row padding does.  `SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE` = 0.36 on the GPU agrees."""
 import math
 
 import numpy as np

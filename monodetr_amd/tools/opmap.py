@@ -31,7 +31,9 @@ def main():
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
     want_stacks = [m for m in a.stacks.split(",") if m]
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=bool(want_stacks)) as prof:
+    xc = torch._C._profiler._ExperimentalConfig(verbose=True) if want_stacks else None       # (Python frames need the verbose collector)
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=bool(want_stacks),
+                 experimental_config=xc) as prof:
         step()
         torch.cuda.synchronize()
     keep = [m for m in a.match.split(",") if m]
@@ -51,20 +53,41 @@ def main():
     if want_stacks:
         import collections
         groups = collections.defaultdict(lambda: [0, 0.0])
-        for e in prof.events():
-            if e.name not in want_stacks:
+        evs = list(prof.events())
+
+        def frames_of(e):
+            fr = [f for f in (e.stack or []) if "monodetr_amd" in f or "bench.py" in f][:3]
+            return " <- ".join(f.split("monodetr_amd/")[-1] for f in fr)
+        # a backward node carries the sequence number of the forward operator that recorded it: its launches go to that operator's frames
+        fwd = {}
+        for e in evs:
+            if getattr(e, "sequence_nr", -1) >= 0 and e.stack and not e.name.startswith("autograd::engine"):
+                w = frames_of(e)
+                if w:
+                    fwd.setdefault(e.sequence_nr, w)
+        for e in evs:
+            if "all" not in want_stacks and e.name not in want_stacks:
                 continue
             dt = sum(k.duration for k in e.kernels) if getattr(e, "kernels", None) else 0.0
             if dt <= 0:
                 continue
-            frames = [f for f in (e.stack or []) if "monodetr_amd" in f or "bench.py" in f][:3]
-            where = " <- ".join(f.split("monodetr_amd/")[-1] for f in frames) or "(autograd engine: no Python frame)"
+            where = frames_of(e)
+            if not where:
+                up, node = e, None
+                while up is not None:
+                    if up.name.startswith("autograd::engine::evaluate_function"):
+                        node = up
+                    up = up.cpu_parent
+                if node is not None:
+                    where = "backward (%s) of: %s" % (node.name.split(": ")[-1], fwd.get(node.sequence_nr, "?"))
+                else:
+                    where = "(no Python frame)"
             key = (e.name, str(e.input_shapes)[:70], where)
-            groups[key][0] += 1
+            groups[key][0] += len(e.kernels)
             groups[key][1] += dt
         lines.append("")
         lines.append("%9s %6s  operator / shapes / innermost frames of this repo" % ("us", "calls"))
-        for (name, shp, where), (n, dt) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
+        for (name, shp, where), (n, dt) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
             lines.append("%9.1f %6d  %s %s  %s" % (dt, n, name, shp, where))
     text = "\n".join(lines)
     if a.out:

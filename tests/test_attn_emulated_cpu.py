@@ -10,7 +10,7 @@ import native_emul
 from test_attn_gpu import keep_mask, reference
 
 
-# default build, and the build with the conflict-free staging map of DESIGN.md 7.1 item 6 (-DMDETR_ATTN_STAGE_REMAP=1)
+# default build, and the build with the conflict-free staging map (-DMDETR_ATTN_STAGE_REMAP=1)
 @pytest.fixture(params=[(), ("MDETR_ATTN_STAGE_REMAP=1",)], ids=["default", "stage_remap"])
 def ext(request):
     from monodetr_amd import attn_ext

@@ -2,7 +2,7 @@
 to the access patterns of csrc/attn.hip and csrc/tgemm.hip.  Documents, and guards against regressions of,
 the padding choices: transposed tile 68 bf16 per row (72 was 2-way on reads: measured 52 % conflict cycles),
 row-major tile 40 per row, token-GEMM weight rows K + 8 and slab rows 72; and evaluates the staging-thread
-remap proposed in DESIGN.md 7.1 (compile-time MDETR_ATTN_STAGE_REMAP in attn.hip, off until validated)."""
+remap (compile-time MDETR_ATTN_STAGE_REMAP in attn.hip, off until validated)."""
 import pytest
 
 B128_READ_GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],

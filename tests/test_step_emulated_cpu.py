@@ -3,7 +3,7 @@ in-solver matching cost), MSDA prologue, fused residual LayerNorm, fused AdamW -
 sources on the HIP-on-CPU shim (tests/native_emul.py), against the default path of the same model with the oracle as
 the operator (the configuration tests/test_model_cpu.py pins to the reference's classes).
 
-This is the CPU stand-in for `bench.py` with the switches of DESIGN.md 7.0 on: losses, every parameter gradient and
+This is the CPU stand-in for `bench.py` with the optional kernel families on: losses, every parameter gradient and
 the parameters after the optimizer step must agree.  Small images (64 x 192: the pyramid of the emulated MSDA tests)
 keep the fiber emulation to seconds."""
 import ctypes
