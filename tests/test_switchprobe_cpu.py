@@ -222,6 +222,7 @@ def test_bench_main_composes_its_json_line(monkeypatch, capsys):
     monkeypatch.setattr(_capi, "profile_enable", lambda on: None)
     monkeypatch.setattr(_capi, "profile_read", lambda: [(0, 10200, 3, 0.7), (1, 10200, 3, 3.0), (2, 10200, 3, 2.1), (3, 10200, 3, 0.3),
                                                         (1, 550, 3, 0.6), (4, 1920 * 4096 + 1920, 3, 0.4)])
+    monkeypatch.setattr(_capi, "profile_read_work", lambda: [(10, 81600, 3, 0.07, 32000.0, 125000.0), (11, 81600, 3, 0.1, 10700.0, 117000.0)])
     monkeypatch.setattr(bench, "TrainStep", Step)
     for env, argv in (({}, []), ({"MDETR_BENCH_DEFAULT_PATH": "1"}, []), ({}, ["--config", "2"]), ({}, ["--config", "5"]), ({}, ["--graph", "off"])):
         for k, v in env.items():
