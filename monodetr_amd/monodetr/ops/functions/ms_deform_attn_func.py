@@ -41,7 +41,7 @@ class MSDeformAttnFunction(Function):
                 attention_weights, im2col_step):
         ctx.im2col_step = im2col_step
         ctx.in_dtypes = (value.dtype, sampling_locations.dtype, attention_weights.dtype)
-        ctx.native_bf16 = _NATIVE_BF16 and MSDA.bf16_supported(value, sampling_locations)
+        ctx.native_bf16 = _NATIVE_BF16 and value.dtype == torch.bfloat16 and MSDA.bf16_supported(value, sampling_locations)
         if ctx.native_bf16:
             value, sampling_locations, attention_weights = value.contiguous(), sampling_locations.float(), attention_weights.float()
             out = MSDA.ms_deform_attn_forward_bf16(value, value_spatial_shapes, value_level_start_index,
