@@ -130,8 +130,6 @@ class TrainStep(TrainIteration):
         if switches is not None:
             apply_switches(self.switches)
         torch.manual_seed(seed)                               # same initial weights on every rank
-        if os.environ.get("MDETR_BENCH_MIOPEN_FIND") == "1":       # experiment: let MIOpen time its solvers per convolution shape
-            torch.backends.cudnn.benchmark = True
         cfg = dict(MODEL_CFG, device=str(device).split(':')[0], num_queries=queries)
         self.part = part
         model, criterion = build_monodetr(cfg)
@@ -651,23 +649,8 @@ def main():
             launch_mode = step.attach_process_group()
     use_graph = step.graph is not None
 
-    # experiment: let PyTorch's TunableOp time the library's GEMM solutions per shape during
-    # the start-up iterations and freeze the choice before anything is measured -- the decoder-sized products
-    # ([4 400, 256] x [256, 256] and smaller) take 10-26 us each in `r01h` with the heuristic's macro-tiles
-    tunable = os.environ.get("MDETR_BENCH_TUNABLEOP") == "1" and hasattr(torch.cuda, "tunable")
-    if tunable:
-        torch.cuda.tunable.enable(True)
-        torch.cuda.tunable.tuning_enable(True)
-        torch.cuda.tunable.set_max_tuning_duration(int(os.environ.get("MDETR_BENCH_TUNABLEOP_MS", "3")))
-        torch.cuda.tunable.set_max_tuning_iterations(10)
-        if hasattr(torch.cuda.tunable, "write_file_on_exit"):
-            torch.cuda.tunable.write_file_on_exit(False)
-        else:                                                        # this build always writes its results file at exit: keep it out of the tree
-            torch.cuda.tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), "mdetr_tunableop_results.csv"))
-    for i in range(args.prime):                                     # process start-up, like the model build
+    for _ in range(args.prime):                                     # process start-up, like the model build
         step()
-        if tunable and i == 1:
-            torch.cuda.tunable.tuning_enable(False)                 # two iterations have seen every shape: keep the choices, stop timing
     # cyclic garbage collection off for the measured loop (objects are freed by reference counting; a
     # generation-0 sweep every ~700 allocations costs the launch-bound step ~1 ms): what production
     # training loops do with gc.freeze() / scheduled gc.collect()
@@ -681,11 +664,8 @@ def main():
     torch.cuda.synchronize()
     _capi.profile_enable(not use_graph)
     t0 = time.perf_counter()
-    step_sync = os.environ.get("MDETR_BENCH_STEP_SYNC") == "1"       # experiment (scripts/r04_gaps.sh): the host never runs ahead
     for _ in range(args.steps):
         loss = step()
-        if step_sync:
-            torch.cuda.synchronize()
     torch.cuda.synchronize()
     if dist_on:
         torch.distributed.barrier()
@@ -787,8 +767,7 @@ def main():
                        "precision": args.precision, "parallelism": "dp%d" % world,
                        "grad_sync": (sync_mode if dist_on else "none"), "prime_steps": args.prime,
                        "launch": launch_mode,
-                       **({"step_sync": "a device synchronisation after every step (experiment, not the metric)"} if step_sync else {}),
-                       **({"gemm_selection": "TunableOp during start-up"} if tunable else {})},
+                       },
             "final_loss": round(float(loss), 4),
         }
         if dom is not None:

@@ -1202,16 +1202,12 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
     // block numbering = dispatch order: the longest blocks first, so that the launch's tail is made of short ones.  Measured per
     // block at the encoder shape (cycles per phase, -DMDETR_PHASES): a 24 x 32 core tile 85 us, a 1/12 query chunk of a whole level
     // 42 us -- with the chunked levels in front (rounds 2 and 3) the last quarter-round of tiles ran on a quarter of the CUs.
-    // MDETR_MSDA_ORDER=0 restores that order.  Chunked levels with the same chunk count stay interleaved chunk by chunk.
-    const bool tiles_first = env_int("MDETR_MSDA_ORDER", 1) != 0;
-    auto number_tiled = [&]() {
-        for (int l = 0; l < L; ++l) {                        // finest level first: its tiles are full-sized
-            if (pl.mode[l] == 1) continue;
-            pl.blk0[l] = blk;
-            blk += pl.nblk[l];
-        }
-    };
-    if (tiles_first) number_tiled();
+    // Chunked levels with the same chunk count stay interleaved chunk by chunk.
+    for (int l = 0; l < L; ++l) {                            // finest level first: its tiles are full-sized
+        if (pl.mode[l] == 1) continue;
+        pl.blk0[l] = blk;
+        blk += pl.nblk[l];
+    }
     int n1 = 0, first_chunks = 0;
     for (int l = L - 1; l >= 0; --l)
         if (pl.mode[l] == 1) { if (!n1) first_chunks = pl.nchunk[l]; if (pl.nchunk[l] == first_chunks) ++n1; }
@@ -1224,13 +1220,6 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
         if (pl.mode[l] != 1 || pl.nchunk[l] == first_chunks) continue;
         pl.blk0[l] = blk;
         blk += pl.nblk[l];
-    }
-    if (!tiles_first) {
-        for (int l = L - 1; l >= 0; --l) {
-            if (pl.mode[l] == 1) continue;
-            pl.blk0[l] = blk;
-            blk += pl.nblk[l];
-        }
     }
     pl.nblocks = blk;
     pl.scr_per_bm = scr;
