@@ -1,12 +1,12 @@
-"""``token_linear``: y = x W^T + b for activations with tens of thousands of token rows.
+"""``token_linear`` and its relatives: every token-wise product y = x W^T + b of the model (linear layers, 1x1 convolutions of
+channels-last maps) with its autograd structure, and the router that decides which kernel runs it.
 
-Forward and the input gradient are ordinary GEMMs (hipBLASLt reaches the memory roofline there:
-~26 us for 81 600 x 256 x 256 bf16).  The WEIGHT gradient dW = dY^T X contracts over the 81 600
-tokens into a 256 x 256 result; the library's NT kernel for that shape runs 16 workgroups deep and
-takes 205-228 us (123 us after TunableOp) -- 27 such GEMMs per training step were the largest single
-GPU item.  Here the token axis is split into C chunks evaluated as one batched GEMM
-([C, N, T/C] x [C, T/C, K], thousands of independent tiles) followed by a sum over C: 35 us.
-Pure library plumbing (torch.bmm -> hipBLASLt); numerics are those of a split-K GEMM.
+bf16 operands on the GPU with MDETR_TGEMM (the committed bf16 list): forward and input gradient through csrc/tgemm.hip -- bias,
+ReLU, Dropout, "+ identity" and the residual-path gradient in the product's epilogue -- and the weight + bias gradient through
+csrc/twgrad.hip (>= 1 024 rows) or csrc/small_wgrad.hip, chunk partials summed by csrc/colsum.hip.  Everything else (fp32, autocast,
+CPU tensors, operands the kernels' alignment rules refuse) takes the library GEMMs with the SAME autograd functions: a batched
+split-K product for tall weight gradients (the library's single NT GEMM runs 16 workgroups deep at [81 600, 256]^T x [81 600, 256]:
+205 us against 35), `colsum` for the bias.  Rules, not probing: nothing is timed at run time.
 """
 import os
 
@@ -452,9 +452,8 @@ def ffn_hidden(x, lin, dropout, activation=F.relu, tokenwise=True, skip=False):
 
 class Linear(nn.Linear):
     """nn.Linear (same parameters, same state_dict keys) whose forward is `token_linear`: from 4 096 token rows on -- the
-    decoder's B x 550 = 4 400 query rows, the depth encoder's B x 1 920 -- the weight gradient is the split-K batched product
-    and the bias gradient one `colsum` pass (the library's generic reduction takes 19 us for a [4 400, 256] matrix, its
-    single-tile NT GEMM 34 us); below that, or on the CPU, plain F.linear."""
+    decoder's B x 550 = 4 400 query rows, the depth encoder's B x 1 920, the encoder's 81 600 -- the kernels / split forms of this
+    module's header; below that, or on the CPU, plain F.linear."""
 
     def forward(self, x):
         return token_linear(x, self.weight, self.bias)
