@@ -486,6 +486,7 @@ FAMILY_PATTERNS = (      # (family, substrings of the kernel name, profile kinds
     ("residual_layernorm", ("add_ln",), (13,)),
     ("bias_activation_tails", ("bias_act",), (14,)),
     ("group_norm", ("gn_fwd", "gn_bwd"), (15,)),
+    ("weight_fold", ("fold_kernel",), (20,)),
     ("msda", ("msda", "prologue_fwd", "prologue_bwd"), ()),
     ("attention", ("attn_",), ()),
     ("losses_matching_optimizer", ("pair_losses", "ddn_", "lsa_kernel", "adamw_kernel", "multi_tensor_apply"), ()),

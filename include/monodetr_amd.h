@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDETR_ABI_VERSION 7
+#define MDETR_ABI_VERSION 8
 
 /* element types of the floating-point tensors */
 #define MDETR_F32 0
@@ -569,6 +569,21 @@ int mdetr_bias_act_backward(int io_dtype, const void *dy, const void *y, void *d
  *   backward = 1: src = dy [B, (H + 1) / 2, (W + 1) / 2, C] -> dst = dx [B, H, W, C], zero at the skipped pixels
  * pixel_bytes = C * element size (any element type), a multiple of 16; pointers 16-byte aligned.
  */
+/*
+ * The frozen-BatchNorm fold of many trainable convolution weights in one launch each way (ABI 8; csrc/wfold.hip).  The reference
+ * applies FrozenBatchNorm2d (lib/models/monodetr/backbone.py:27-64, y = x * scale + shift) as a pass over every activation behind
+ * each convolution; here conv(x, W * scale) + shift, so with trainable weights every iteration folds
+ *     folded_i[o][t][c] = bf16(w_i[o][t][c] * scale_i[o])        (fp32 [O][taps][C]: a channels-last weight as it lies in memory)
+ * and, where folded_t[i] != NULL, writes the same values as folded_t_i[c][t][o] (the input-gradient kernels' operand), and unfolds
+ *     dw_i[o][t][c] = float(dfolded_i[o][t][c]) * scale_i[o]     (bf16 in, fp32 out).
+ * HOST arrays of n entries each: device pointers (they travel as kernel arguments, 48 tensors per launch) and the dimensions.
+ * O_i and C_i multiples of 8, pointers 16-byte aligned.  folded_t itself may be NULL (no transposed copies at all).
+ */
+int mdetr_fold_weights(int n, const void *const *w, const void *const *scale, void *const *folded, void *const *folded_t,
+                       const int *O, const int *C, const int *taps, int device, void *stream);
+int mdetr_unfold_grads(int n, const void *const *dfolded, const void *const *scale, void *const *dw,
+                       const int *O, const int *C, const int *taps, int device, void *stream);
+
 /*
  * Gather of many dense device tensors into one flat device buffer (the optimizer's flat gradient buffer; the reference's AdamW
  * walks parameters one by one, lib/helpers/optimizer_helper.py:69-129).  HOST arrays: src_ptrs[ntensors] (device addresses; they

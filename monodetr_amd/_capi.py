@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDETR_LIB_PATH") or os.path.join(_HERE, "libmonodetr_amd.so")
 
 MDETR_F32, MDETR_F64, MDETR_BF16 = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -75,6 +75,8 @@ SIGNATURES = {
     "mdetr_msda_backward_bf16": (_c_int, [_c_vp] * 9 + [_c_int] * 7 + [_c_vp, _c_vp, _c_vp, ctypes.c_int64, _c_int, _c_vp]),
     "mdetr_msda_prologue_forward": (_c_int, [_c_int, _c_int] + [_c_vp] * 6 + [_c_int] * 6 + [ctypes.c_int64] * 3 + [_c_int, _c_vp]),
     "mdetr_gather_flat": (_c_int, [_c_vp, _c_int] + [_c_vp] * 6 + [_c_int, _c_int, _c_vp]),
+    "mdetr_fold_weights": (_c_int, [_c_int] + [_c_vp] * 7 + [_c_int, _c_vp]),
+    "mdetr_unfold_grads": (_c_int, [_c_int] + [_c_vp] * 6 + [_c_int, _c_vp]),
     "mdetr_maxpool3x3s2_bf16": (_c_int, [_c_vp, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_vp]),
     "mdetr_decimate2": (_c_int, [_c_int, _c_vp, _c_vp, _c_int, _c_int, _c_int, ctypes.c_int64, _c_int, _c_vp]),
     "mdetr_msda_prologue_forward_packed": (_c_int, [_c_int, _c_int] + [_c_vp] * 5 + [_c_int] * 6 + [ctypes.c_int64] * 3 + [_c_int, _c_vp]),

@@ -53,6 +53,7 @@ class _Conv3x3(torch.autograd.Function):
         y = _launch(x, w, sh, relu)
         ctx.relu = bool(relu)
         ctx.shift_dtype = None if shift is None else shift.dtype
+        ctx.w_ihwo = getattr(weight, "_mdetr_ihwo", None)              # [C, 3, 3, N] copy made with the weight (csrc/wfold.hip), if any
         ctx.save_for_backward(x, weight, w, *((y,) if relu else ()))
         return y
 
@@ -68,7 +69,10 @@ class _Conv3x3(torch.autograd.Function):
             # dX = conv(dY, w') with w'[c, t, s, n] = w[n, 2 - t, 2 - s, c]: the same kernel on the weight with its channel axes
             # swapped (one small copy), the taps mirrored by the kernel's addressing
             if dy.shape[1] % 64 == 0 and x.shape[1] % 32 == 0 and dy.data_ptr() % 16 == 0:
-                dx = _launch(dy, w.permute(3, 1, 2, 0).contiguous(), None, False, mirror=True)
+                wt = ctx.w_ihwo
+                if wt is None or wt.shape != (w.shape[3], 3, 3, w.shape[0]) or not wt.is_contiguous() or wt.dtype != w.dtype:
+                    wt = w.permute(3, 1, 2, 0).contiguous()
+                dx = _launch(dy, wt, None, False, mirror=True)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (True, False, False))[0]
         if ctx.needs_input_grad[1]:

@@ -96,12 +96,14 @@ def _forward(x, w_ohwi, shift, relu):
     return y
 
 
-def _input_gradient(dy, w_ohwi, H, W):
+def _input_gradient(dy, w_ohwi, H, W, w_ihwo=None):
     """dX [B, C, H, W] of the stride-2 convolution from dY [B, N, OH, OW] (channels_last): the four pixel-parity classes in one
     launch (``mdetr_conv_dgrad_s2``); every element of dX is written by it."""
     B, N, OH, OW = dy.shape
     k, C = w_ohwi.shape[1], w_ohwi.shape[3]
-    wt = w_ohwi.permute(3, 1, 2, 0).contiguous()                        # [C, k, k, N]: channel axes swapped (one small copy)
+    wt = w_ihwo                                                         # [C, k, k, N]: made with the weight (csrc/wfold.hip) ...
+    if wt is None or wt.shape != (C, k, k, N) or not wt.is_contiguous() or wt.dtype != w_ohwi.dtype:
+        wt = w_ohwi.permute(3, 1, 2, 0).contiguous()                    # ... or one small copy here
     dx = torch.empty((B, C, H, W), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
     cuda = dy.is_cuda
     rc = _lib().mdetr_conv_dgrad_s2(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), B, OH, OW, N, H, W, C, k, dy.device.index if cuda else -1,
@@ -119,6 +121,7 @@ class _ConvStrided(torch.autograd.Function):
         y = _forward(x, w, sh, relu)
         ctx.relu = bool(relu)
         ctx.shift_dtype = None if shift is None else shift.dtype
+        ctx.w_ihwo = getattr(weight, "_mdetr_ihwo", None)
         ctx.save_for_backward(x, weight, w, *((y,) if relu else ()))
         return y
 
@@ -133,7 +136,7 @@ class _ConvStrided(torch.autograd.Function):
         pad = (1, 1) if k == 3 else (0, 0)
         dx = dw = ds = None
         if ctx.needs_input_grad[0]:
-            dx = _input_gradient(dy, w, x.shape[2], x.shape[3])
+            dx = _input_gradient(dy, w, x.shape[2], x.shape[3], ctx.w_ihwo)
         if ctx.needs_input_grad[1]:
             from . import conv_wgrad_ext
             if conv_wgrad_ext.supported(x, dy, k, 2):

@@ -19,6 +19,7 @@
 #include "group_norm.h"
 #include "small_wgrad.h"
 #include "decimate.h"
+#include "wfold.h"
 #include "conv3x3.h"
 #include "conv_stem.h"
 #include "conv_taps.h"
@@ -783,6 +784,47 @@ int mdetr_gather_flat(const void *const *src_ptrs, int ntensors, const int *tens
     const hipError_t e = mdetr::gather_flat_launch(src_ptrs, ntensors, tensor_block_begin, dst, dst_offsets, nbytes, block_tensor, block_start, chunk_bytes,
                                                    static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_gather_flat: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+static int fold_args_ok(const char *who, int n, const void *const *a, const void *const *b, void *const *c, const int *O, const int *C, const int *taps)
+{
+    if (n < 0) return fail(MDETR_E_ARG, "%s: n = %d", who, n);
+    if (n == 0) return MDETR_OK;
+    if (!a || !b || !c || !O || !C || !taps) return fail(MDETR_E_ARG, "%s: null array", who);
+    for (int i = 0; i < n; ++i) {
+        if (!a[i] || !b[i] || !c[i]) return fail(MDETR_E_ARG, "%s: tensor %d: null pointer", who, i);
+        if (!mdetr::fold_shape_supported(O[i], C[i], taps[i]))
+            return fail(MDETR_E_ARG, "%s: tensor %d: O=%d C=%d taps=%d (O, C positive multiples of 8)", who, i, O[i], C[i], taps[i]);
+        if (!aligned16(a[i]) || !aligned16(c[i]) || (reinterpret_cast<uintptr_t>(b[i]) & 3)) return fail(MDETR_E_ALIGN, "%s: tensor %d: 16-byte aligned tensors", who, i);
+    }
+    return MDETR_OK;
+}
+
+int mdetr_fold_weights(int n, const void *const *w, const void *const *scale, void *const *folded, void *const *folded_t,
+                       const int *O, const int *C, const int *taps, int device, void *stream)
+{
+    const int rc = fold_args_ok("mdetr_fold_weights", n, w, scale, folded, O, C, taps);
+    if (rc != MDETR_OK || n == 0) return rc;
+    if (folded_t)
+        for (int i = 0; i < n; ++i)
+            if (folded_t[i] && !aligned16(folded_t[i])) return fail(MDETR_E_ALIGN, "mdetr_fold_weights: tensor %d: 16-byte aligned tensors", i);
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_fold_weights: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::fold_weights_launch(n, w, scale, folded, folded_t, O, C, taps, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_fold_weights: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_unfold_grads(int n, const void *const *dfolded, const void *const *scale, void *const *dw,
+                       const int *O, const int *C, const int *taps, int device, void *stream)
+{
+    const int rc = fold_args_ok("mdetr_unfold_grads", n, dfolded, scale, dw, O, C, taps);
+    if (rc != MDETR_OK || n == 0) return rc;
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_unfold_grads: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::unfold_grads_launch(n, dfolded, scale, dw, O, C, taps, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_unfold_grads: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

@@ -114,7 +114,7 @@ void profile_end(hipStream_t st);
 // bench.py's `mfma` object sums into TFLOP/s against the dense bf16 MFMA peak
 // ... and the useful work of the launches inside the scope (MFLOP, algorithmic KB): what bench.py's `families` divide by the
 // families' kernel times.  kinds: 10 token GEMM, 11 token weight gradient, 12 column sum, 13 residual LayerNorm, 14 bias / activation
-// tails, 15 GroupNorm, 16 small-T weight gradient, 17 MSDA prologue, 18 AdamW, 19 gathers / pooling
+// tails, 15 GroupNorm, 16 small-T weight gradient, 17 MSDA prologue, 18 AdamW, 19 gathers / pooling, 20 frozen-BN weight fold
 void profile_work(double mflop, double kbytes);
 struct ProfileScope {
     hipStream_t s;

@@ -12,7 +12,7 @@ import os
 # follows it: msda_algorithmic_bytes(mixed=True).)
 AUTOTUNE_SWITCHES = ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN", "MDETR_MSDA_BF16",
                      "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD",
-                     "MDETR_CONV_STRIDED", "MDETR_CONV_WGRAD", "MDETR_CONV_STEM", "MDETR_TGEMM")
+                     "MDETR_CONV_STRIDED", "MDETR_CONV_WGRAD", "MDETR_CONV_STEM", "MDETR_TGEMM", "MDETR_WFOLD")
 ALL_SWITCHES = AUTOTUNE_SWITCHES
 # The measured configuration.  family -> the GPU tests that hold it to the default path / the framework operators
 # (all in tests/test_fused_gpu.py unless a file is named); a family without green tests is not listed.
@@ -30,6 +30,7 @@ SWITCH_TESTS = {
     "MDETR_CONV_WGRAD": "test_conv_wgrad_kernel_matches_the_library_weight_gradient, test_conv_strided_kernel_*, test_training_step_with_the_convolution_kernels_*",
     "MDETR_CONV_STEM": "test_conv_stem_kernel_matches_the_library_convolution, test_training_step_with_the_convolution_kernels_*",
     "MDETR_TGEMM": "test_tgemm_gpu.py::test_tgemm_*, test_training_step_with_the_token_gemm_kernel_*, test_bottleneck_with_fused_tails_*",
+    "MDETR_WFOLD": "test_fold_kernel_*, test_training_step_with_the_fold_kernel_*",
     "MDETR_CONV3X3": "test_conv3x3_kernel_matches_the_library_convolution, test_training_step_with_the_conv3x3_kernel_*, test_conv3x3_module_with_a_trainable_bias_*",
 }
 COMMITTED_SWITCHES = {
@@ -42,9 +43,11 @@ COMMITTED_SWITCHES = {
     # 354.2 vs 348.0 img/s (r03d_bench_{all,committed}.json), no MIOpen kernel left in the iteration.)
     # MDETR_TGEMM (round 5): every token-wise product of the bf16 step (1x1 convolutions, linear layers; forward and input gradient)
     # through csrc/tgemm.hip with the tails in its epilogue: 396.6 -> 418.5 img/s in one call (profiles/r05f_step_ab.log).
+    # MDETR_WFOLD (round 5): the frozen-BN fold of the 42 trainable backbone weights, their [C][tap][O] copies and the unfolding of
+    # their gradients as one launch each way (csrc/wfold.hip): 426.3 -> 432.4 img/s in one call (profiles/r05z1_step_ab_wfold.log).
     "bf16": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE", "MDETR_MSDA_BF16",
              "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD",
-             "MDETR_CONV_WGRAD", "MDETR_CONV_STRIDED", "MDETR_CONV_STEM", "MDETR_TGEMM"),
+             "MDETR_CONV_WGRAD", "MDETR_CONV_STRIDED", "MDETR_CONV_STEM", "MDETR_TGEMM", "MDETR_WFOLD"),
     "fp32": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE",
              "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD"),
 }
@@ -66,13 +69,14 @@ def env_switches():
 def apply_switches(names):
     """Runtime equivalent of the environment switches for the module-level ones (the criterion's and the optimizer's
     are applied by TrainStep)."""
-    from monodetr_amd import add_ln_ext, bias_act_ext, conv3x3_ext, conv_stem_ext, conv_taps_ext, conv_wgrad_ext, group_norm_ext, small_wgrad_ext
+    from monodetr_amd import add_ln_ext, bias_act_ext, conv3x3_ext, conv_stem_ext, conv_taps_ext, conv_wgrad_ext, group_norm_ext, small_wgrad_ext, wfold_ext
     from monodetr_amd.monodetr import linear
     from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func
     from monodetr_amd.monodetr.ops.modules import ms_deform_attn
     ms_deform_attn._FUSED_PROLOGUE = "MDETR_MSDA_PROLOGUE" in names
     add_ln_ext.ENABLED = "MDETR_FUSED_LN" in names
     linear._TGEMM = "MDETR_TGEMM" in names
+    wfold_ext.ENABLED = "MDETR_WFOLD" in names
     linear._GEMM_RELU = "MDETR_GEMM_RELU" in names
     bias_act_ext.ENABLED = "MDETR_FUSED_EPILOGUE" in names
     conv3x3_ext.ENABLED = "MDETR_CONV3X3" in names

@@ -94,6 +94,33 @@ class _FoldAll(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+class _FoldKernel(torch.autograd.Function):
+    """`_FoldAll` as ONE launch each way (csrc/wfold.hip): folded_i = bf16(W_i * scale_i) straight from the fp32 channels-last
+    parameters and the per-channel scales, the 3x3 weights' [C][tap][O] copies for the input-gradient kernels from the same
+    launch (handed out as non-differentiable outputs), dW_i = float(dfolded_i) * scale_i in the backward.  Same bits as `_FoldAll`."""
+
+    @staticmethod
+    def forward(ctx, svecs, want_t, *weights):
+        from .. import wfold_ext
+        folded, folded_t = wfold_ext.fold_weights(weights, svecs, want_t)
+        ctx.svecs, ctx.like = svecs, weights
+        extra = [t for t in folded_t if t is not None]
+        ctx.mark_non_differentiable(*extra)
+        return tuple(folded) + tuple(extra)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        from .. import wfold_ext
+        like = ctx.like
+        grads = [g if g is not None else torch.zeros_like(w, dtype=torch.bfloat16) for g, w in zip(grads[:len(like)], like)]
+        if wfold_ext.grads_supported(grads, like):
+            out = wfold_ext.unfold_grads(grads, ctx.svecs, like)
+        else:                                        # a gradient that is not a dense bf16 channels-last tensor (a library fall-back upstream)
+            out = [g.to(w.dtype) * s.view(-1, 1, 1, 1) for g, w, s in zip(grads, like, ctx.svecs)]
+        return (None, None) + tuple(out)
+
+
 def prefold(pairs, dt):
     """Fold the frozen BN of every trainable (conv, bn) pair into its weight for THIS forward pass and
     park the result on the conv module (`conv_bn` consumes it)."""
@@ -102,7 +129,7 @@ def prefold(pairs, dt):
     key = tuple(bn.affine()[0].data_ptr() for _, bn in pairs) + tuple(c.weight.data_ptr() for c, _ in pairs) + (dt,)
     cache = pairs[0][0].__dict__.get("_prefold_cache")
     if cache is None or cache[0] != key:
-        scales, shifts = [], []
+        scales, shifts, svecs = [], [], []
         with torch.no_grad():
             for conv, bn in pairs:
                 scale, shift = bn.affine()
@@ -110,8 +137,21 @@ def prefold(pairs, dt):
                 full.copy_(scale.to(conv.weight.dtype).view(-1, 1, 1, 1).expand_as(conv.weight))
                 scales.append(full)
                 shifts.append(shift.to(dt))
-        cache = pairs[0][0].__dict__["_prefold_cache"] = (key, scales, shifts)
-    folded = _FoldAll.apply(cache[1], dt, *[conv.weight for conv, _ in pairs])
+                svecs.append(scale.to(conv.weight.dtype).contiguous())
+        cache = pairs[0][0].__dict__["_prefold_cache"] = (key, scales, shifts, svecs)
+    from .. import wfold_ext
+    weights = [conv.weight for conv, _ in pairs]
+    if wfold_ext.ENABLED and wfold_ext.supported(weights, cache[3], dt):
+        # one launch (csrc/wfold.hip); a 3x3 weight's [C][tap][O] copy rides on the folded tensor for the input-gradient kernels
+        # (conv3x3_ext / conv_taps_ext look for it: `_mdetr_ihwo`)
+        want_t = [tuple(conv.kernel_size) == (3, 3) for conv, _ in pairs]
+        out = _FoldKernel.apply(cache[3], want_t, *weights)
+        folded, extra = out[:len(pairs)], iter(out[len(pairs):])
+        for w, t in zip(folded, want_t):
+            if t:
+                w._mdetr_ihwo = next(extra)
+    else:
+        folded = _FoldAll.apply(cache[1], dt, *weights)
     for (conv, _), w, b in zip(pairs, folded, cache[2]):
         conv.__dict__["_prefolded"] = (w, b)
 

@@ -6,7 +6,7 @@
 #      barrier runs first and the result changes.
 #   ./scripts/asan_emulated.sh            (~8 min on 8 vCPUs)
 cd "$(dirname "$0")/.."
-T="tests/test_msda_emulated_cpu.py tests/test_attn_emulated_cpu.py tests/test_add_ln_emulated_cpu.py tests/test_tgemm_emulated_cpu.py
+T="tests/test_msda_emulated_cpu.py tests/test_attn_emulated_cpu.py tests/test_add_ln_emulated_cpu.py tests/test_tgemm_emulated_cpu.py tests/test_twgrad_emulated_cpu.py tests/test_wfold_emulated_cpu.py
    tests/test_kitti_eval_cpu.py tests/test_msda_prologue_cpu.py tests/test_bias_act_emulated_cpu.py tests/test_conv3x3_emulated_cpu.py tests/test_lsa_emulated_cpu.py tests/test_fused_losses_cpu.py tests/test_optimizer.py tests/test_kitti_pipeline_cpu.py"
 set -e
 for order in reverse shuffle; do

@@ -975,3 +975,51 @@ def test_maxpool_kernel_matches_the_framework(B, C, H, W):
     y = decimate_ext.maxpool3x3s2(x)
     want = torch.nn.functional.max_pool2d(x, 3, 2, 1)
     assert y.shape == want.shape and torch.equal(y, want)
+
+
+# ---- the frozen-BN fold of the trainable backbone weights in one launch each way (csrc/wfold.hip) ------------------------------------
+def test_fold_kernel_matches_the_multi_tensor_fold():
+    """Every trainable convolution of a ResNet-50 body at once: folded weights, [C][tap][O] copies and unfolded gradients, bit for
+    bit the framework expressions they replace."""
+    from monodetr_amd import wfold_ext
+    g = torch.Generator(device="cuda").manual_seed(5)
+    shapes = []
+    for planes, blocks in ((128, 4), (256, 6), (512, 3)):
+        for b in range(blocks):
+            cin = planes * 2 if b == 0 else planes * 4
+            shapes += [(planes, cin, 1, 1), (planes, planes, 3, 3), (planes * 4, planes, 1, 1)]
+        shapes.append((planes * 4, planes * 2, 1, 1))
+    ws = [(torch.randn(*s, device="cuda", generator=g) * 0.05).contiguous(memory_format=torch.channels_last) for s in shapes]
+    ss = [torch.rand(s[0], device="cuda", generator=g) + 0.5 for s in shapes]
+    want_t = [s[2] == 3 for s in shapes]
+    assert len(ws) == 42 and wfold_ext.supported(ws, ss, torch.bfloat16)
+    folded, folded_t = wfold_ext.fold_weights(ws, ss, want_t)
+    for w, s, f, ft in zip(ws, ss, folded, folded_t):
+        ref = (w * s.view(-1, 1, 1, 1)).to(torch.bfloat16)
+        assert torch.equal(f, ref) and f.shape == w.shape
+        assert (ft is None) == (w.shape[2] == 1)
+        if ft is not None:
+            assert ft.is_contiguous() and torch.equal(ft, ref.permute(1, 2, 3, 0))
+    grads = [torch.randn(*s, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for s in shapes]
+    assert wfold_ext.grads_supported(grads, ws)
+    for w, s, gr, o in zip(ws, ss, grads, wfold_ext.unfold_grads(grads, ss, ws)):
+        assert o.dtype == torch.float32 and torch.equal(o, gr.float() * s.view(-1, 1, 1, 1))
+
+
+def test_training_step_with_the_fold_kernel_matches_default():
+    """The committed bf16 list with and without MDETR_WFOLD: the same folded weights and the same unfolded gradients, so the
+    loss trajectories coincide to the last bit that deterministic kernels leave (dropout off)."""
+    import bench
+    from model_init import disable_dropout_
+    dev = torch.device("cuda", 0)
+    base = tuple(sorted(set(bench.COMMITTED_SWITCHES["bf16"]) - {"MDETR_WFOLD"}))
+    traj = {}
+    try:
+        for names in (base, base + ("MDETR_WFOLD",)):
+            step = bench.TrainStep(dev, 2, "bf16", size=(96, 320), switches=names)
+            disable_dropout_(step.raw_model)
+            traj[names] = [float(step()) for _ in range(3)]
+    finally:
+        bench.apply_switches(set())
+    for a, b in zip(traj[base], traj[base + ("MDETR_WFOLD",)]):
+        assert abs(a - b) <= 1e-3 * abs(a), traj

@@ -1,0 +1,103 @@
+"""csrc/wfold.hip -- the REAL kernel sources, launchers and C-ABI entries (mdetr_fold_weights / mdetr_unfold_grads) -- on the HIP-on-CPU
+shim: many tensors per launch, 1x1 and 3x3 weights, tiles that are not whole (O % 32, C % 64), the transposed copies, and the route
+through monodetr/backbone.prefold; against the framework expressions they replace, bit for bit."""
+import pytest
+import torch
+
+import native_emul
+from monodetr_amd import wfold_ext
+
+
+@pytest.fixture()
+def emulated(monkeypatch):
+    monkeypatch.setattr(wfold_ext, "_backend", native_emul.lib())
+    monkeypatch.setattr(wfold_ext, "ENABLED", True)
+
+
+def weights_and_scales(shapes, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    ws = [(torch.randn(*s, generator=g) * 0.1).contiguous(memory_format=torch.channels_last) for s in shapes]
+    ss = [torch.rand(s[0], generator=g) + 0.5 for s in shapes]
+    return ws, ss
+
+
+SHAPES = [(128, 256, 1, 1), (128, 128, 3, 3), (40, 72, 3, 3), (512, 128, 1, 1), (8, 8, 1, 1), (64, 200, 3, 3), (256, 64, 3, 3)]
+
+
+def test_fold_and_unfold_match_the_framework_expressions(emulated):
+    ws, ss = weights_and_scales(SHAPES)
+    want_t = [w.shape[2] == 3 for w in ws]
+    assert wfold_ext.supported(ws, ss, torch.bfloat16)
+    folded, folded_t = wfold_ext.fold_weights(ws, ss, want_t)
+    for w, s, f, ft, t in zip(ws, ss, folded, folded_t, want_t):
+        ref = (w * s.view(-1, 1, 1, 1)).to(torch.bfloat16)
+        assert f.shape == w.shape and f.is_contiguous(memory_format=torch.channels_last) or w.shape[2] == 1
+        assert torch.equal(f, ref)                                   # one fp32 product, one rounding
+        if t:
+            assert ft.is_contiguous() and torch.equal(ft, ref.permute(1, 2, 3, 0))      # [C, kh, kw, O]
+        else:
+            assert ft is None
+    g = torch.Generator().manual_seed(1)
+    grads = [torch.randn(*w.shape, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for w in ws]
+    assert wfold_ext.grads_supported(grads, ws)
+    out = wfold_ext.unfold_grads(grads, ss, ws)
+    for w, s, gr, o in zip(ws, ss, grads, out):
+        assert o.dtype == torch.float32 and o.stride() == w.stride() or w.shape[2] == 1
+        assert torch.equal(o, gr.float() * s.view(-1, 1, 1, 1))
+
+
+def test_more_tensors_than_one_launch_carries(emulated):
+    shapes = [(16, 8 * (1 + i % 5), 1, 1) for i in range(60)] + [(8, 16, 3, 3)]
+    ws, ss = weights_and_scales(shapes, seed=3)
+    folded, folded_t = wfold_ext.fold_weights(ws, ss, [w.shape[2] == 3 for w in ws])
+    for w, s, f in zip(ws, ss, folded):
+        assert torch.equal(f, (w * s.view(-1, 1, 1, 1)).to(torch.bfloat16))
+    assert torch.equal(folded_t[-1], folded[-1].permute(1, 2, 3, 0))
+
+
+def test_what_the_kernel_refuses(emulated):
+    ws, ss = weights_and_scales([(16, 16, 1, 1)])
+    assert not wfold_ext.supported(ws, ss, torch.float32)                               # bf16 results only
+    assert not wfold_ext.supported([ws[0].double()], ss, torch.bfloat16)
+    assert not wfold_ext.supported([torch.randn(16, 16, 3, 3)], ss, torch.bfloat16)     # NCHW-contiguous 3x3: not OHWI in memory
+    assert not wfold_ext.supported([torch.randn(12, 16, 1, 1)], [torch.rand(12)], torch.bfloat16)
+    g = torch.randn(16, 16, 3, 3).to(torch.bfloat16)
+    assert not wfold_ext.grads_supported([g], [torch.randn(16, 16, 3, 3).contiguous(memory_format=torch.channels_last)])
+
+
+def test_prefold_route_gives_the_same_folded_weights_and_gradients(emulated, monkeypatch):
+    """monodetr/backbone.prefold with the kernel against the multi-tensor form: folded weights, the [C][tap][O] hint, and the
+    parameters' gradients after a backward through both."""
+    from monodetr_amd.monodetr import backbone as bb
+    torch.manual_seed(0)
+
+    def pairs():
+        out = []
+        for cin, cout, k in ((64, 32, 1), (32, 32, 3), (32, 128, 1)):
+            conv = torch.nn.Conv2d(cin, cout, k, padding=k // 2, bias=False).to(memory_format=torch.channels_last)
+            bn = bb.FrozenBatchNorm2d(cout)
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+            out.append((conv, bn))
+        return out
+    a = pairs()
+    b = pairs()
+    for (ca, na), (cb, nb) in zip(a, b):
+        cb.load_state_dict(ca.state_dict()); nb.load_state_dict(na.state_dict())
+    bb.prefold(a, torch.bfloat16)
+    monkeypatch.setattr(wfold_ext, "ENABLED", False)
+    bb.prefold(b, torch.bfloat16)
+    loss_a = loss_b = 0.0
+    for (ca, _), (cb, _) in zip(a, b):
+        wa, sa = ca.__dict__.pop("_prefolded")
+        wb, sb = cb.__dict__.pop("_prefolded")
+        assert wa.dtype == torch.bfloat16 and torch.equal(wa, wb) and torch.equal(sa, sb)
+        hint = getattr(wa, "_mdetr_ihwo", None)
+        assert (hint is not None) == (ca.kernel_size == (3, 3)) and getattr(wb, "_mdetr_ihwo", None) is None
+        if hint is not None:
+            assert torch.equal(hint, wa.detach().permute(1, 2, 3, 0))
+        coef = torch.linspace(-1, 1, wa.numel()).view_as(wa).to(torch.bfloat16)
+        loss_a = loss_a + (wa.float() * coef.float()).sum()
+        loss_b = loss_b + (wb.float() * coef.float()).sum()
+    loss_a.backward(); loss_b.backward()
+    for (ca, _), (cb, _) in zip(a, b):
+        assert ca.weight.grad is not None and torch.equal(ca.weight.grad, cb.weight.grad)
