@@ -195,6 +195,12 @@ class AdamW(Optimizer):
         return loss
 
 
+def _same_layout(g, p):
+    """Do g and p place their elements in the same memory order?  Strides of size-1 axes say nothing (a [256, 512, 1, 1] weight
+    is the same bytes with contiguous and with channels-last strides)."""
+    return g.shape == p.shape and all(a == b for n, a, b in zip(p.shape, g.stride(), p.stride()) if n != 1)
+
+
 class FusedAdamW(AdamW):
     """The same update as :class:`AdamW` with ONE kernel launch per (parameter group, dtype)
     (csrc/adamw.hip through ``mdetr_adamw_step``) instead of ~40 multi-tensor launches per group.
@@ -336,7 +342,9 @@ class FusedAdamW(AdamW):
             grads = []
             for p in buf['params']:
                 g = p.grad
-                grads.append(g if g.stride() == p.stride() else torch.empty_like(p).copy_(g))
+                if g.stride() != p.stride():          # (the multi-tensor copy leaves its fused path on any stride mismatch)
+                    g = g.as_strided(p.shape, p.stride(), g.storage_offset()) if _same_layout(g, p) else torch.empty_like(p).copy_(g)
+                grads.append(g)
             gather = buf.get('gather') if self._gather else None
             gfn = getattr(lib, "mdetr_gather_flat", None) if gather is not None else None
             if gfn is not None:

@@ -106,6 +106,7 @@ class _FoldKernel(torch.autograd.Function):
         ctx.svecs, ctx.like = svecs, weights
         extra = [t for t in folded_t if t is not None]
         ctx.mark_non_differentiable(*extra)
+        ctx.set_materialize_grads(False)             # (no zero tensors for the copies' absent gradients: 13 fill launches)
         return tuple(folded) + tuple(extra)
 
     @staticmethod
