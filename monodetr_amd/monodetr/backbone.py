@@ -414,10 +414,23 @@ class Joiner(nn.Sequential):
         self.strides = backbone.strides
         self.num_channels = backbone.num_channels
 
+    def _as(self, level, p, dt):
+        """p in dtype dt.  A constant (sine) encoding comes out of its per-shape cache as the SAME tensor every iteration: its cast is
+        kept per level while that holds (three casts of up to 31 MB per iteration otherwise)."""
+        if p.dtype == dt:
+            return p
+        if p.requires_grad or p.grad_fn is not None:
+            return p.to(dt)
+        last = self.__dict__.setdefault("_pos_cast", {})
+        hit = last.get(level)
+        if hit is None or hit[0] is not p or hit[1] != p._version or hit[2].dtype != dt:
+            hit = last[level] = (p, p._version, p.to(dt))
+        return hit[2]
+
     def forward(self, images):
         feats = self[0](images)
         out: List[NestedTensor] = [feats[k] for k in sorted(feats)]
-        pos = [self[1](x).to(x.tensors.dtype) for x in out]
+        pos = [self._as(i, self[1](x), x.tensors.dtype) for i, x in enumerate(out)]
         return out, pos
 
 

@@ -59,10 +59,24 @@ def fused_first_layers(x, heads):
     pad = -sum(widths) % 8                          # column sums (the bias gradient, csrc/colsum.hip) want whole 16-byte vectors
     ws, bs = [l.weight for l in firsts], [l.bias for l in firsts]
     if pad:
-        ws.append(ws[0].new_zeros(pad, ws[0].shape[1]))
-        bs.append(bs[0].new_zeros(pad))
+        zw, zb = _zero_rows(ws[0], pad)
+        ws.append(zw)
+        bs.append(zb)
     y = token_linear(x, torch.cat(ws, 0), torch.cat(bs, 0))
     return y.split(widths + ([pad] if pad else []), -1)[:len(widths)]
+
+
+_ZERO_ROWS = {}
+
+
+def _zero_rows(like, rows):
+    """(zeros [rows, like.shape[1]], zeros [rows]) in like's dtype on its device: constants, made once (two fill launches per call
+    otherwise)."""
+    key = (like.device, like.dtype, rows, like.shape[1])
+    hit = _ZERO_ROWS.get(key)
+    if hit is None:
+        hit = _ZERO_ROWS[key] = (like.new_zeros(rows, like.shape[1]), like.new_zeros(rows))
+    return hit
 
 
 def mlp_rest(mlp, h):
