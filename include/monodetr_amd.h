@@ -346,6 +346,17 @@ int mdetr_adamw_step_counted(int param_dtype, void *param, float *master, const 
 int mdetr_tgemm(const void *a, const void *w, const void *bias, const void *res, void *y, int64_t T, int N, int K,
                 int64_t lda, int64_t ldw, int64_t ldr, int64_t ldy, int flags, float dropout_p, uint64_t seed,
                 const void *seed_dev, int device, void *stream);
+/*
+ * The input gradient of a layer whose INPUT is the output of a ReLU, with that ReLU's backward inside (ABI 8):
+ *     y[T, N] = mask[T, N] <= 0 ? 0 : a[T, K] w[K, N] + res[T, N]       (bf16; w as with MDETR_TGEMM_NN; res may be NULL)
+ * mask is the layer's forward input (= the ReLU's output: positive exactly where the ReLU passed its input).  Replaces the
+ * input-gradient GEMM followed by autograd's threshold_backward of the preceding nn.ReLU (torchvision Bottleneck.forward behind
+ * lib/models/monodetr/backbone.py:93-106: relu -> conv1 of the next block, relu -> conv3).  Applying the mask here is safe whatever
+ * else consumes the ReLU's output: mask (g1 + g2) = mask g1 + mask g2, and mask mask = mask.  Alignment rules as mdetr_tgemm; ldm = the
+ * mask's row stride.
+ */
+int mdetr_tgemm_masked(const void *a, const void *w, const void *res, const void *mask, void *y, int64_t T, int N, int K,
+                       int64_t lda, int64_t ldw, int64_t ldr, int64_t ldm, int64_t ldy, int device, void *stream);
 
 /*
  * Training image path of the input pipeline on the device: what

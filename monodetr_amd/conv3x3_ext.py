@@ -47,13 +47,17 @@ def _launch(x_cl, w_ohwi, shift, relu, mirror=False):
 
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, shift, relu):
+    def forward(ctx, x, weight, shift, relu, hand_out_token=False):
         w = _ohwi(weight)
         sh = None if shift is None else shift.float().contiguous()
         y = _launch(x, w, sh, relu)
         ctx.relu = bool(relu)
         ctx.shift_dtype = None if shift is None else shift.dtype
         ctx.w_ihwo = getattr(weight, "_mdetr_ihwo", None)              # [C, 3, 3, N] copy made with the weight (csrc/wfold.hip), if any
+        ctx.relu_token = None
+        if relu and hand_out_token:
+            from .monodetr.linear import ReluToken
+            ctx.relu_token = y._mdetr_relu_token = ReluToken()         # the one consumer of y may take over this ReLU's backward mask
         ctx.save_for_backward(x, weight, w, *((y,) if relu else ()))
         return y
 
@@ -61,7 +65,7 @@ class _Conv3x3(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, weight, w = ctx.saved_tensors[:3]
-        if ctx.relu:
+        if ctx.relu and not (ctx.relu_token is not None and ctx.relu_token.premasked):      # (premasked: the consumer's input gradient came masked)
             dy = torch.ops.aten.threshold_backward(dy, ctx.saved_tensors[3], 0.0)
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = dw = None
@@ -91,14 +95,14 @@ class _Conv3x3(torch.autograd.Function):
             else:
                 ds = dy2.float().sum(0)
             ds = ds.to(ctx.shift_dtype)
-        return dx, dw, ds, None
+        return dx, dw, ds, None, None
 
 
-def conv3x3(x, weight, shift=None, relu=False):
+def conv3x3(x, weight, shift=None, relu=False, hand_out_token=False):
     """act(conv2d(x, weight, padding=1) + shift[None, :, None, None]); ``shift`` [N]: a frozen-BN shift or a trainable bias."""
     if not supported(x, weight):
         raise RuntimeError("conv3x3: needs a CUDA bf16 channels_last activation with C % 64 == 0 and a bf16 [N, C, 3, 3] weight with N % 32 == 0")
-    return _Conv3x3.apply(x, weight, shift, relu)
+    return _Conv3x3.apply(x, weight, shift, relu, hand_out_token)
 
 
 class Conv3x3(torch.nn.Conv2d):

@@ -115,13 +115,17 @@ def _input_gradient(dy, w_ohwi, H, W, w_ihwo=None):
 
 class _ConvStrided(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, shift, relu):
+    def forward(ctx, x, weight, shift, relu, hand_out_token=False):
         w = _ohwi(weight)
         sh = None if shift is None else shift.float().contiguous()
         y = _forward(x, w, sh, relu)
         ctx.relu = bool(relu)
         ctx.shift_dtype = None if shift is None else shift.dtype
         ctx.w_ihwo = getattr(weight, "_mdetr_ihwo", None)
+        ctx.relu_token = None
+        if relu and hand_out_token:
+            from .monodetr.linear import ReluToken
+            ctx.relu_token = y._mdetr_relu_token = ReluToken()         # the one consumer of y may take over this ReLU's backward mask
         ctx.save_for_backward(x, weight, w, *((y,) if relu else ()))
         return y
 
@@ -129,7 +133,7 @@ class _ConvStrided(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, weight, w = ctx.saved_tensors[:3]
-        if ctx.relu:
+        if ctx.relu and not (ctx.relu_token is not None and ctx.relu_token.premasked):
             dy = torch.ops.aten.threshold_backward(dy, ctx.saved_tensors[3], 0.0)
         dy = dy.contiguous(memory_format=torch.channels_last)
         k = weight.shape[2]
@@ -151,14 +155,14 @@ class _ConvStrided(torch.autograd.Function):
             else:
                 ds = dy2.float().sum(0)
             ds = ds.to(ctx.shift_dtype)
-        return dx, dw, ds, None
+        return dx, dw, ds, None, None
 
 
-def conv_strided(x, weight, shift=None, relu=False):
+def conv_strided(x, weight, shift=None, relu=False, hand_out_token=False):
     """act(conv2d(x, weight, stride=2, padding=1 (3x3) / 0 (1x1)) + shift[None, :, None, None])."""
     if not supported(x, weight, padding=(1, 1) if weight.shape[2] == 3 else (0, 0)):
         raise RuntimeError("conv_strided: needs a bf16 channels_last activation with C % 64 == 0 and a bf16 [N, C, 3, 3] / [N, C, 1, 1] weight with N % 64 == 0")
-    return _ConvStrided.apply(x, weight, shift, relu)
+    return _ConvStrided.apply(x, weight, shift, relu, hand_out_token)
 
 
 class ConvStrided(torch.nn.Conv2d):

@@ -500,6 +500,25 @@ int mdetr_tgemm(const void *a, const void *w, const void *bias, const void *res,
     return MDETR_OK;
 }
 
+int mdetr_tgemm_masked(const void *a, const void *w, const void *res, const void *mask, void *y, int64_t T, int N, int K,
+                       int64_t lda, int64_t ldw, int64_t ldr, int64_t ldm, int64_t ldy, int device, void *stream)
+{
+    if (T < 0 || N <= 0 || K <= 0) return fail(MDETR_E_ARG, "mdetr_tgemm_masked: bad shape T=%lld N=%d K=%d", static_cast<long long>(T), N, K);
+    if (T == 0) return MDETR_OK;
+    if (!a || !w || !y || !mask) return fail(MDETR_E_ARG, "mdetr_tgemm_masked: null pointer");
+    mdetr::TgemmProblem p{a, w, nullptr, res, y, T, N, K, lda, ldw, res ? ldr : 0, ldy, MDETR_TGEMM_NN, 0.f, 0, nullptr};
+    p.mask = mask; p.ldm = ldm;
+    if (!mdetr::tgemm_supported(p))
+        return fail(MDETR_E_ARG, "mdetr_tgemm_masked: needs bf16 operands, K %% 8 == 0, N %% 8 == 0, row strides %% 8 == 0 and >= the row length, 16-byte "
+                    "aligned pointers (T=%lld N=%d K=%d lda=%lld ldw=%lld ldr=%lld ldm=%lld ldy=%lld)", static_cast<long long>(T), N, K,
+                    static_cast<long long>(lda), static_cast<long long>(ldw), static_cast<long long>(ldr), static_cast<long long>(ldm), static_cast<long long>(ldy));
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_tgemm_masked: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::tgemm_launch(p, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_tgemm_masked: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
 int64_t mdetr_column_sum_workspace_bytes(int64_t rows, int cols)
 {
     if (rows < 0 || cols < 0) return -1;

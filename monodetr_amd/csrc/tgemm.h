@@ -21,6 +21,8 @@ struct TgemmProblem {
     float dropout_p;          // > 0: y = dropout(relu(.)) with the stateless hash of add_ln_math.h on the element index t * N + n
     uint64_t seed;
     const uint64_t *seed_dev; // added to seed when not null (a replayed graph's seed lives on the device)
+    const void *mask = nullptr;   // bf16 [T, N] (row stride ldm) or null: y = mask <= 0 ? 0 : a w + res (NN form, bf16 output, no other tail)
+    int64_t ldm = 0;
 };
 
 bool tgemm_supported(const TgemmProblem &p);

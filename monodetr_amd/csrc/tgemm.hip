@@ -43,10 +43,10 @@ constexpr int kLd = kBK + 8;               // LDS row of a slab: 72 bf16 = 36 dw
 constexpr int kCPad = 4;                   // fp32 output tile: rows of BN + 4 floats (8 consecutive rows x 16 bytes: 8 distinct bank quads)
 
 struct TgemmArgs {
-    const __bf16 *a, *w, *res;
+    const __bf16 *a, *w, *res, *mask;
     const void *bias;
     void *y;
-    int64_t T, lda, ldw, ldr, ldy;
+    int64_t T, lda, ldw, ldr, ldy, ldm;
     int N, K, gx, ny, flags;
     uint32_t thresh;
     float keep_scale;
@@ -80,7 +80,9 @@ __device__ __forceinline__ void transpose4x8(const bf16x8 (&in)[4], unsigned (&o
 // PERSISTENT workgroups: workgroup w walks the output tiles w, w + G, w + 2 G, ... (G = gridDim.x, a multiple of 8: a tile keeps
 // its XCD) as ONE sequence of contraction slabs -- the loads of the next tile's first slabs are in flight while this tile's last
 // products issue and its output leaves, so only a workgroup's very first slab pays an exposed memory latency.
-// TAIL: 0 = bias (bf16) + ReLU, bf16 output;  1 = the same + a residual tile;  2 = everything (fp32 bias / output, dropout, residual)
+// TAIL: 0 = bias (bf16) + ReLU, bf16 output;  1 = the same + a residual tile;  2 = everything (fp32 bias / output, dropout, residual);
+//       3 = tail 1 (residual optional) times the sign mask of a second [T, N] tensor: y = mask > 0 ? acc + res : 0 -- the ReLU backward of
+//           the layer's INPUT applied where the input gradient leaves the chip (the mask tile is requested once the accumulators are parked)
 // NTH: threads of the workgroup -- 256 (waves 2 x 2) or 512 (2 x 4: the big tile with twice the waves in flight per CU)
 template <int BM, int BN, bool NN, int PF, int TAIL, int NTH = 256>
 __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2)
@@ -228,16 +230,20 @@ void tgemm_kernel(const TgemmArgs g)
     // feature groups beyond N carry an out-of-range buffer offset (loads give zero, stores are dropped).
     constexpr int PR = BN / 8, NP = BM * PR / kThreadsT;
     constexpr bool RES = TAIL != 0;
+    constexpr bool MASK = TAIL == 3;
     const int pc = tid % PR;
     const float lo = (g.flags & kTgemmRelu) ? 0.f : -__builtin_inff();
     const bool out32 = TAIL == 2 && (g.flags & kTgemmOutF32) != 0;
-    const bool has_res = TAIL == 1 || (TAIL == 2 && g.res != nullptr);
+    const bool has_res = TAIL == 1 || ((TAIL == 2 || TAIL == 3) && g.res != nullptr);
     const uint64_t sd = (TAIL == 2 && g.thresh) ? g.seed + (g.seed_dev ? *g.seed_dev : 0ull) : 0ull;
     const mdetr_rsrc yr = make_rsrc(g.y, static_cast<unsigned>(((g.T - 1) * g.ldy + g.N) * (out32 ? 4 : 2)));
     const mdetr_rsrc rr_ = make_rsrc(has_res ? static_cast<const void *>(g.res) : static_cast<const void *>(g.a),
                                      has_res ? static_cast<unsigned>(((g.T - 1) * g.ldr + g.N) * 2) : 0u);
+    const mdetr_rsrc mr_ = make_rsrc(MASK ? static_cast<const void *>(g.mask) : static_cast<const void *>(g.a),
+                                     MASK ? static_cast<unsigned>(((g.T - 1) * g.ldm + g.N) * 2) : 0u);
     constexpr int NPB = NP < 4 ? NP : 4;                         // pieces per batch of the tail (registers: 8 floats each)
     bf16x8 rq[RES ? NP : 1];
+    bf16x8 mq[MASK ? NP : 1];
     float bv[8];
     unsigned yoff[NP];                                           // element offsets of the pieces (kRsrcOob: not stored)
     int64_t tail_m0 = 0;
@@ -251,7 +257,7 @@ void tgemm_kernel(const TgemmArgs g)
         for (int j = 0; j < NP; ++j) {
             const int64_t t = tail_m0 + (tid + kThreadsT * j) / PR;
             yoff[j] = (ncol && t < g.T) ? static_cast<unsigned>(t * g.ldy + tail_n) : kRsrcOob;
-            if (RES) rq[j] = rsrc_load_bf16x8(rr_, (has_res && ncol && t < g.T) ? static_cast<unsigned>((t * g.ldr + tail_n) * 2) : kRsrcOob, 0u);
+            if (RES && !MASK) rq[j] = rsrc_load_bf16x8(rr_, (has_res && ncol && t < g.T) ? static_cast<unsigned>((t * g.ldr + tail_n) * 2) : kRsrcOob, 0u);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) bv[i] = 0.f;
@@ -281,6 +287,16 @@ void tgemm_kernel(const TgemmArgs g)
                 }
             }
     };
+    auto aim_mask = [&]() __attribute__((always_inline)) {      // (after park: the accumulators' registers are free) the mask tile and, in
+        const bool ncol = tail_n < g.N;                          // this tail, the residual tile are requested
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int64_t t = tail_m0 + (tid + kThreadsT * j) / PR;
+            const bool in = ncol && t < g.T;
+            mq[MASK ? j : 0] = rsrc_load_bf16x8(mr_, in ? static_cast<unsigned>((t * g.ldm + tail_n) * 2) : kRsrcOob, 0u);
+            rq[RES ? j : 0] = rsrc_load_bf16x8(rr_, (has_res && in) ? static_cast<unsigned>((t * g.ldr + tail_n) * 2) : kRsrcOob, 0u);
+        }
+    };
     auto drain = [&]() __attribute__((always_inline)) {         // (behind the barrier that follows park) the tile leaves row by row:
         // bias, residual, ReLU, dropout, ONE rounding, 16-byte stores
 #pragma unroll
@@ -300,6 +316,7 @@ void tgemm_kernel(const TgemmArgs g)
                 for (int i = 0; i < 8; ++i) {
                     float f = o[i] + bv[i];
                     if (RES) f += static_cast<float>(rq[j][i]);
+                    if (MASK) f = static_cast<float>(mq[j][i]) <= 0.f ? 0.f : f;       // (threshold_backward's test: a NaN in the mask lets the gradient pass)
                     f = f < lo ? lo : f;                         // ReLU (NaN passes through, as clamp_min does)
                     if (TAIL == 2 && g.thresh) {
                         const uint64_t t = static_cast<uint64_t>(tail_m0 + (tid + kThreadsT * j) / PR);
@@ -358,6 +375,10 @@ void tgemm_kernel(const TgemmArgs g)
             if (last) {                                          // every wave is done with the slab buffers: the tile is parked there
                 aim_tail(cv);
                 park();
+                if (MASK) {
+                    __builtin_amdgcn_sched_barrier(0);           // (the requests stay behind the accumulators' last reads: their registers are the room)
+                    aim_mask();
+                }
                 __syncthreads();
                 drain();                                         // the tile leaves
                 cv = next_tile(cv + G);
@@ -428,6 +449,9 @@ template <bool NN, int PF>
 hipError_t launch_tail(const TgemmArgs &g, int bm, int bn, hipStream_t st)
 {
     if ((g.flags & (kTgemmBiasF32 | kTgemmOutF32)) || g.thresh) return launch_any<NN, PF, 2>(g, bm, bn, st);
+    if constexpr (NN) {
+        if (g.mask) return launch_any<NN, PF, 3>(g, bm, bn, st);
+    }
     return g.res ? launch_any<NN, PF, 1>(g, bm, bn, st) : launch_any<NN, PF, 0>(g, bm, bn, st);
 }
 
@@ -441,6 +465,9 @@ bool tgemm_supported(const TgemmProblem &p)
            al(p.y) && p.lda % 8 == 0 && p.lda >= p.K && p.ldw % 8 == 0 && p.ldw >= (nn ? p.N : p.K) &&
            p.ldy % ((p.flags & kTgemmOutF32) ? 4 : 8) == 0 && p.ldy >= p.N &&
            (!p.res || (al(p.res) && p.ldr % 8 == 0 && p.ldr >= p.N)) && (!p.bias || al(p.bias)) && p.dropout_p >= 0.f && p.dropout_p < 1.f &&
+           // the masked tail: input gradients only (NN), bf16 in and out, no bias / ReLU / dropout of its own
+           (!p.mask || (nn && al(p.mask) && p.ldm % 8 == 0 && p.ldm >= p.N && p.T * p.ldm < (1ll << 30) && !p.bias && p.dropout_p == 0.f &&
+                        !(p.flags & (kTgemmRelu | kTgemmBiasF32 | kTgemmOutF32)))) &&
            // buffer-resource addressing: every tensor below 2^31 bytes
            p.T * p.lda < (1ll << 30) && p.T * p.ldy < (1ll << 29) && p.T * p.ldr < (1ll << 30) && static_cast<int64_t>(nn ? p.K : p.N) * p.ldw < (1ll << 30);
 }
@@ -449,6 +476,7 @@ hipError_t tgemm_launch(const TgemmProblem &p, hipStream_t st)
 {
     TgemmArgs g;
     g.a = static_cast<const __bf16 *>(p.a); g.w = static_cast<const __bf16 *>(p.w); g.res = static_cast<const __bf16 *>(p.res);
+    g.mask = static_cast<const __bf16 *>(p.mask); g.ldm = p.ldm;
     g.bias = p.bias; g.y = p.y;
     g.T = p.T; g.lda = p.lda; g.ldw = p.ldw; g.ldr = p.ldr; g.ldy = p.ldy;
     g.N = p.N; g.K = p.K; g.gx = g.ny = 0; g.flags = p.flags;
@@ -470,11 +498,11 @@ hipError_t tgemm_launch(const TgemmProblem &p, hipStream_t st)
         if (sscanf(ev, "%dx%d", &m, &n) == 2 && (m == 64 || m == 128) && (n == 64 || n == 128)) { bm = m; bn = n; }
     }
     int pf = 2;
-    if (bm == 128 && bn == 128 && (p.res || (p.flags & (kTgemmBiasF32 | kTgemmOutF32)) || p.dropout_p > 0.f)) pf = 1;       // (the big tile's tails: registers)
+    if (bm == 128 && bn == 128 && (p.res || p.mask || (p.flags & (kTgemmBiasF32 | kTgemmOutF32)) || p.dropout_p > 0.f)) pf = 1;       // (the big tile's tails: registers)
     if (bm == 128 && bn == 128 && !(p.flags & kTgemmNN) && !p.res && !generic_tail) pf = 1;                                  // (... and its eight-wave plain form)
     if (const char *ev = getenv("MDETR_TGEMM_PF")) pf = atoi(ev) == 1 ? 1 : 2;       // A/B runs: register sets in flight
     ProfileScope prof(10, conv_mflop(p.T, static_cast<int64_t>(p.N) * p.K), st, 2.0 * p.T * p.N * p.K / 1e6,
-                      (2.0 * p.T * p.K + ((p.flags & kTgemmOutF32) ? 4.0 : 2.0) * p.T * p.N + (p.res ? 2.0 * p.T * p.N : 0.0) + 2.0 * p.N * p.K) / 1e3);
+                      (2.0 * p.T * p.K + ((p.flags & kTgemmOutF32) ? 4.0 : 2.0) * p.T * p.N + (p.res ? 2.0 * p.T * p.N : 0.0) + (p.mask ? 2.0 * p.T * p.N : 0.0) + 2.0 * p.N * p.K) / 1e3);
     if (p.flags & kTgemmNN) return pf == 1 ? launch_tail<true, 1>(g, bm, bn, st) : launch_tail<true, 2>(g, bm, bn, st);
     return pf == 1 ? launch_tail<false, 1>(g, bm, bn, st) : launch_tail<false, 2>(g, bm, bn, st);
 }

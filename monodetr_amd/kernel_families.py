@@ -12,7 +12,7 @@ import os
 # follows it: msda_algorithmic_bytes(mixed=True).)
 AUTOTUNE_SWITCHES = ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN", "MDETR_MSDA_BF16",
                      "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD",
-                     "MDETR_CONV_STRIDED", "MDETR_CONV_WGRAD", "MDETR_CONV_STEM", "MDETR_TGEMM", "MDETR_WFOLD")
+                     "MDETR_CONV_STRIDED", "MDETR_CONV_WGRAD", "MDETR_CONV_STEM", "MDETR_TGEMM", "MDETR_WFOLD", "MDETR_RELU_PREMASK")
 ALL_SWITCHES = AUTOTUNE_SWITCHES
 # The measured configuration.  family -> the GPU tests that hold it to the default path / the framework operators
 # (all in tests/test_fused_gpu.py unless a file is named); a family without green tests is not listed.
@@ -31,6 +31,7 @@ SWITCH_TESTS = {
     "MDETR_CONV_STEM": "test_conv_stem_kernel_matches_the_library_convolution, test_training_step_with_the_convolution_kernels_*",
     "MDETR_TGEMM": "test_tgemm_gpu.py::test_tgemm_*, test_training_step_with_the_token_gemm_kernel_*, test_bottleneck_with_fused_tails_*",
     "MDETR_WFOLD": "test_fold_kernel_*, test_training_step_with_the_fold_kernel_*",
+    "MDETR_RELU_PREMASK": "test_tgemm_gpu.py::test_masked_input_gradient_*, test_tgemm_gpu.py::test_bottleneck_stage_with_premasked_relu_*",
     "MDETR_CONV3X3": "test_conv3x3_kernel_matches_the_library_convolution, test_training_step_with_the_conv3x3_kernel_*, test_conv3x3_module_with_a_trainable_bias_*",
 }
 COMMITTED_SWITCHES = {
@@ -45,9 +46,12 @@ COMMITTED_SWITCHES = {
     # through csrc/tgemm.hip with the tails in its epilogue: 396.6 -> 418.5 img/s in one call (profiles/r05f_step_ab.log).
     # MDETR_WFOLD (round 5): the frozen-BN fold of the 42 trainable backbone weights, their [C][tap][O] copies and the unfolding of
     # their gradients as one launch each way (csrc/wfold.hip): 426.3 -> 432.4 img/s in one call (profiles/r05z1_step_ab_wfold.log).
+    # MDETR_RELU_PREMASK (round 5): the ReLU backward masks inside the bottlenecks (conv2 -> conv3) and between consecutive blocks of a
+    # stage applied in the consumers' input-gradient products (mdetr_tgemm_masked), 23 elementwise passes less: 436.2 -> 441.4 img/s in
+    # one call, bit-identical gradients (profiles/r05z2_step_ab_premask.log).
     "bf16": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE", "MDETR_MSDA_BF16",
              "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD",
-             "MDETR_CONV_WGRAD", "MDETR_CONV_STRIDED", "MDETR_CONV_STEM", "MDETR_TGEMM", "MDETR_WFOLD"),
+             "MDETR_CONV_WGRAD", "MDETR_CONV_STRIDED", "MDETR_CONV_STEM", "MDETR_TGEMM", "MDETR_WFOLD", "MDETR_RELU_PREMASK"),
     "fp32": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE",
              "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD"),
 }
@@ -77,6 +81,7 @@ def apply_switches(names):
     add_ln_ext.ENABLED = "MDETR_FUSED_LN" in names
     linear._TGEMM = "MDETR_TGEMM" in names
     wfold_ext.ENABLED = "MDETR_WFOLD" in names
+    linear._PREMASK = "MDETR_RELU_PREMASK" in names
     linear._GEMM_RELU = "MDETR_GEMM_RELU" in names
     bias_act_ext.ENABLED = "MDETR_FUSED_EPILOGUE" in names
     conv3x3_ext.ENABLED = "MDETR_CONV3X3" in names

@@ -170,11 +170,14 @@ def frozen_fold(conv, bn, dt):
     return conv._folded
 
 
-def conv_bn(x, conv, bn, relu, skip_out=False):
+def conv_bn(x, conv, bn, relu, skip_out=False, relu_token=None, hand_out_token=False):
     """conv -> frozen BN (-> ReLU), with the BN folded into the convolution's weight and bias.
     For frozen convolutions (stem, layer1) the folded weight itself is cached.
     skip_out: -> (result, x') with x' == x for the identity connection that follows (linear.pointwise_conv_skip: its gradient is
-    folded into this convolution's input-gradient GEMM); (result, x) where that form does not apply."""
+    folded into this convolution's input-gradient GEMM); (result, x) where that form does not apply.
+    relu_token (with skip_out): x is a ReLU output that only this call consumes -- its backward mask moves into this convolution's
+    input gradient where the kernel takes it (linear.ReluToken).  hand_out_token: the result (with relu) goes to exactly one consumer
+    inside the caller's module, which may do the same for THIS ReLU."""
     if skip_out:
         if isinstance(bn, FrozenBatchNorm2d) and conv.bias is None and conv.weight.requires_grad and x.requires_grad \
                 and tuple(conv.stride) == (1, 1) and torch.is_grad_enabled() \
@@ -184,7 +187,7 @@ def conv_bn(x, conv, bn, relu, skip_out=False):
             if pre is not None and pre[0].dtype == dt == x.dtype and (not relu or skip_relu_fusable(
                     pre[1], x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]), pre[0].reshape(pre[0].shape[0], -1))):
                 conv.__dict__.pop("_prefolded", None)
-                return pointwise_conv_skip(x, pre[0], pre[1], relu=relu)
+                return pointwise_conv_skip(x, pre[0], pre[1], relu=relu, relu_token=relu_token)
         return conv_bn(x, conv, bn, relu), x
     if isinstance(bn, FrozenBatchNorm2d) and conv.bias is None:
         scale, shift = bn.affine()
@@ -223,11 +226,11 @@ def conv_bn(x, conv, bn, relu, skip_out=False):
         elif conv_taps_ext.ENABLED and conv_taps_ext.supported(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
             # the stride-2 3x3 of a stage's first block and its 1x1 / stride-2 projection shortcut (csrc/conv_taps.hip), forward,
             # input gradient (four pixel-parity classes) and weight gradient (csrc/conv_wgrad.hip) by hand
-            return conv_taps_ext.conv_strided(x, w, shift, relu=relu)
+            return conv_taps_ext.conv_strided(x, w, shift, relu=relu, hand_out_token=hand_out_token and relu)
         elif conv3x3_ext.ENABLED and conv3x3_ext.supported(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
             # stride-1 3x3: implicit GEMM with LDS im2col, shift and ReLU in its epilogue (csrc/conv3x3.hip); forward and
             # input gradient on the kernel, weight gradient with the library
-            return conv3x3_ext.conv3x3(x, w, shift, relu=relu)
+            return conv3x3_ext.conv3x3(x, w, shift, relu=relu, hand_out_token=hand_out_token and relu)
         elif relu and bias_act_ext.ENABLED and (x.is_cuda or bias_act_ext._backend is not None):
             # the shift and the ReLU in one pass behind the library convolution (csrc/bias_act.hip) instead of the
             # library's own bias kernel plus a clamp
@@ -263,12 +266,17 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        from . import linear
+        # ReLU masks of the backward pass applied by the consuming kernel (linear.ReluToken): only where this module sees every
+        # consumer of the tensor -- no hook may have been handed it
+        premask = linear._PREMASK and torch.is_grad_enabled() and not (self._forward_hooks or self._forward_pre_hooks)
         if self.downsample is None and _SKIP_FUSE:
-            y, skip = conv_bn(x, self.conv1, self.bn1, True, skip_out=True)     # (the identity's gradient meets conv1's inside its dgrad GEMM)
+            # (the identity's gradient meets conv1's inside its dgrad GEMM; so does, with a token from the previous block, its ReLU mask)
+            y, skip = conv_bn(x, self.conv1, self.bn1, True, skip_out=True, relu_token=linear.relu_token_of(x) if premask else None)
         else:
             skip = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], False)
             y = conv_bn(x, self.conv1, self.bn1, True)
-        y = conv_bn(y, self.conv2, self.bn2, True)
+        y = conv_bn(y, self.conv2, self.bn2, True, hand_out_token=premask)
         pre = self.conv3.__dict__.get("_prefolded")
         if pre is None and not self.conv3.weight.requires_grad and isinstance(self.bn3, FrozenBatchNorm2d) and self.conv3.bias is None \
                 and y.dtype in (torch.bfloat16, torch.float16) and not torch.is_autocast_enabled():
@@ -277,7 +285,8 @@ class Bottleneck(nn.Module):
             # expansion + folded BN + "+ identity" + ReLU from ONE kernel (csrc/tgemm.hip's residual epilogue): the product is not
             # read back by an elementwise pass
             self.conv3.__dict__.pop("_prefolded", None)
-            return pointwise_conv_residual_relu(y, pre[0], pre[1], skip)
+            return pointwise_conv_residual_relu(y, pre[0], pre[1], skip, in_token=linear.relu_token_of(y) if premask else None,
+                                                hand_out_token=premask and self.__dict__.get("feeds_next_block", False))
         y = conv_bn(y, self.conv3, self.bn3, False)
         if bias_act_ext.ENABLED and bias_act_ext.supported(y, None, skip):
             return bias_act_ext.bias_act(y, None, skip, relu=True)   # "+ identity" and the ReLU in one pass
@@ -321,6 +330,8 @@ class ResNetBody(nn.Module):
         layers = [Bottleneck(self.inplanes, planes, stride, down, prev_dilation, norm_layer)]
         self.inplanes = planes * 4
         layers += [Bottleneck(self.inplanes, planes, dilation=self.dilation, norm_layer=norm_layer) for _ in range(1, blocks)]
+        for blk in layers[:-1]:
+            blk.__dict__["feeds_next_block"] = True      # its output has ONE consumer: the next block of this Sequential (linear.ReluToken)
         return nn.Sequential(*layers)
 
     def _trainable_pairs(self):

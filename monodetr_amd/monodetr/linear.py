@@ -30,6 +30,30 @@ _TGEMM = os.environ.get("MDETR_TGEMM") == "1"
 _TWGRAD_MIN_ROWS = int(os.environ.get("MDETR_TWGRAD_MIN_ROWS", "1024"))
 
 
+# MDETR_RELU_PREMASK=1: the ReLU backward between two kernels of this repository is applied where the CONSUMER's input gradient leaves
+# the chip (csrc/tgemm.hip's masked tail) and the producer skips its own pass -- see `ReluToken`.  kernel_families decides.
+_PREMASK = os.environ.get("MDETR_RELU_PREMASK") == "1"
+
+
+class ReluToken:
+    """The contract between the producer of a ReLU output y and its ONE consumer.  The producer hangs a token on y
+    (`y._mdetr_relu_token`) and keeps it; a consumer whose backward applies the ReLU's mask to the input gradient it returns (y <= 0 ->
+    0: `mdetr_tgemm_masked`) sets `premasked`; the producer's backward then takes the arriving gradient as it is instead of running
+    threshold_backward over it.  Masking is idempotent and linear, so a consumer may always mask its own contribution; the producer
+    may only SKIP its pass when every consumer masks -- which is why tokens are only handed out where the graph is closed by
+    construction: inside a Bottleneck (conv2 -> conv3) and between consecutive blocks of a stage (monodetr/backbone.py), never on a
+    tensor that leaves the module."""
+    __slots__ = ("premasked",)
+
+    def __init__(self):
+        self.premasked = False
+
+
+def relu_token_of(t):
+    """The token a producer hung on `t`, if the switch is on."""
+    return getattr(t, "_mdetr_relu_token", None) if _PREMASK else None
+
+
 def _tgemm_ok(x2, weight, bias=None, res2=None, nn=False):
     if not _TGEMM:
         return False
@@ -120,18 +144,23 @@ def _fwd_product(x2, weight, bias, relu=False, res2=None, dropout_p=0.0, seed=0,
     return tgemm_ext.tgemm(x2, weight, bias, res2, relu=relu, out_dtype=out_dtype, dropout_p=dropout_p, seed=seed, seed_dev=seed_dev)
 
 
-def _input_gradient(dy2, weight, dskip2=None):
+def _input_gradient(dy2, weight, dskip2=None, mask2=None):
     """dY W (+ the gradient arriving over a residual path): csrc/tgemm.hip's NN form reads the parameter as it lies in memory and
     adds `dskip2` where the product's tile leaves the chip -- into a NEW tensor: nothing is written into the arriving gradient,
-    whoever else may hold it.  The library route is a copy of the residual gradient followed by a beta = 1 GEMM."""
+    whoever else may hold it.  The library route is a copy of the residual gradient followed by a beta = 1 GEMM.
+    mask2 (the layer's input, a ReLU output): the result is zeroed where mask2 <= 0, inside the product where the kernel takes it."""
     if dy2.is_contiguous() and _tgemm_ok(dy2, weight, res2=dskip2, nn=True):
         from .. import tgemm_ext
-        return tgemm_ext.tgemm(dy2, weight, None, dskip2, nn=True)
-    if dskip2 is None:
-        return dy2 @ weight
-    if dskip2.dtype == dy2.dtype:
-        return torch.addmm(dskip2, dy2, weight)
-    return dskip2 + dy2 @ weight
+        if mask2 is not None and tgemm_ext.masked_supported(dy2, weight, mask2, dskip2):
+            return tgemm_ext.tgemm_masked(dy2, weight, mask2, dskip2)
+        dx = tgemm_ext.tgemm(dy2, weight, None, dskip2, nn=True)
+    elif dskip2 is None:
+        dx = dy2 @ weight
+    elif dskip2.dtype == dy2.dtype:
+        dx = torch.addmm(dskip2, dy2, weight)
+    else:
+        dx = dskip2 + dy2 @ weight
+    return dx if mask2 is None else torch.ops.aten.threshold_backward(dx, mask2, 0.0)
 
 
 class _TokenLinearSkip(torch.autograd.Function):
@@ -144,7 +173,8 @@ class _TokenLinearSkip(torch.autograd.Function):
     backbone.py:93-106).  tail: ReLU (relu) followed by Dropout (dropout_p, csrc/tgemm.hip only).  `pos` is a constant (no gradient)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pos, relu=False, dropout_p=0.0):
+    def forward(ctx, x, weight, bias, pos, relu=False, dropout_p=0.0, premask=False):
+        ctx.premask = bool(premask) and pos is None                 # x is a ReLU output whose producer leaves the mask to this backward
         q = x if pos is None else x + pos
         q2 = q.reshape(-1, q.shape[-1])
         ctx.has_bias = bias is not None
@@ -176,19 +206,23 @@ class _TokenLinearSkip(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             ds2 = dskip.reshape(-1, q.shape[-1]) if dskip is not None else None
-            dx = _input_gradient(dy2, weight, ds2).view_as(q)
+            dx = _input_gradient(dy2, weight, ds2, q2 if ctx.premask else None).view_as(q)
         dw, db = _weight_bias_grads(q2, dy2, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], ctx.bias_dtype)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def token_linear_skip(x, weight, bias=None, pos=None, relu=False, dropout_p=0.0):
+def token_linear_skip(x, weight, bias=None, pos=None, relu=False, dropout_p=0.0, relu_token=None):
     """-> (token_linear(x + pos, weight, bias[, relu, dropout]), x'): use x' (== x) for everything that follows on the residual path;
     see `_TokenLinearSkip`.  Plain tensors out of it when the fused form does not apply.  relu / dropout_p: the caller asks
     `skip_relu_fusable` / `skip_dropout_fusable` first."""
     if (x.is_cuda or _tgemm_backend()) and x.dtype == weight.dtype and x.numel() // x.shape[-1] >= _MIN_TOKENS and torch.is_grad_enabled() and x.requires_grad \
             and not torch.is_autocast_enabled() and (pos is None or not pos.requires_grad) \
             and (not relu or skip_relu_fusable(bias, x, weight)) and (dropout_p <= 0.0 or skip_dropout_fusable(x, weight, bias)):
-        return _TokenLinearSkip.apply(x, weight, bias, pos, relu, dropout_p)
+        # relu_token: x is a ReLU output with this call as its only consumer (`ReluToken`): the mask goes into the input gradient here
+        premask = relu_token is not None and pos is None and x.dtype == torch.bfloat16 and _tgemm_ok(x.reshape(-1, x.shape[-1]), weight, bias)
+        if premask:
+            relu_token.premasked = True
+        return _TokenLinearSkip.apply(x, weight, bias, pos, relu, dropout_p, premask)
     if dropout_p > 0.0:
         raise RuntimeError("token_linear_skip: ask skip_dropout_fusable before passing dropout_p")
     return token_linear(x if pos is None else x + pos, weight, bias, relu=relu), x
@@ -271,10 +305,12 @@ class _TokenLinearResidualRelu(torch.autograd.Function):
     per iteration forward).  Backward: the ReLU mask from the saved output; the masked gradient IS the identity's gradient."""
 
     @staticmethod
-    def forward(ctx, x2, weight, bias, res2):
+    def forward(ctx, x2, weight, bias, res2, out_token=None, in_premask=False):
         out = _fwd_product(x2, weight, bias, True, res2)
         ctx.has_bias = bias is not None
         ctx.bias_dtype = bias.dtype if bias is not None else None
+        ctx.out_token = out_token                    # set by the consumer of `out` if IT applies this ReLU's mask (`ReluToken`)
+        ctx.in_premask = bool(in_premask)            # x2 is a ReLU output whose producer leaves its mask to this backward
         ctx.save_for_backward(x2, weight, out)
         return out
 
@@ -282,10 +318,13 @@ class _TokenLinearResidualRelu(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dout):
         x2, weight, out = ctx.saved_tensors
-        g = torch.ops.aten.threshold_backward(dout.contiguous(), out, 0.0)
-        dx = _input_gradient(g, weight) if ctx.needs_input_grad[0] else None
+        if ctx.out_token is not None and ctx.out_token.premasked:
+            g = dout.contiguous()                    # already zero where out <= 0
+        else:
+            g = torch.ops.aten.threshold_backward(dout.contiguous(), out, 0.0)
+        dx = _input_gradient(g, weight, None, x2 if ctx.in_premask else None) if ctx.needs_input_grad[0] else None
         dw, db = _weight_bias_grads(x2, g, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], ctx.bias_dtype)
-        return dx, dw, db, (g if ctx.needs_input_grad[3] else None)
+        return dx, dw, db, (g if ctx.needs_input_grad[3] else None), None, None
 
 
 class _SplitRows(torch.autograd.Function):
@@ -370,13 +409,13 @@ def pointwise_conv(x, weight, bias=None, relu=False):
     return y.view(B, H, W, -1).permute(0, 3, 1, 2)
 
 
-def pointwise_conv_skip(x, weight, bias=None, relu=False):
+def pointwise_conv_skip(x, weight, bias=None, relu=False, relu_token=None):
     """-> (pointwise_conv(x, weight, bias, relu), x'): the 1x1 convolution that opens a residual block together with the tensor the
     identity connection continues from (x' == x) -- the gradient arriving through the identity path is folded into the
     convolution's input-gradient GEMM (beta = 1) instead of a separate 30-60 MB elementwise add per bottleneck
     (`_TokenLinearSkip`; reference torchvision Bottleneck.forward behind lib/models/monodetr/backbone.py:93-106)."""
     B, C, H, W = x.shape
-    y, xs = token_linear_skip(x.permute(0, 2, 3, 1).reshape(B * H * W, C), weight.reshape(weight.shape[0], C), bias, relu=relu)
+    y, xs = token_linear_skip(x.permute(0, 2, 3, 1).reshape(B * H * W, C), weight.reshape(weight.shape[0], C), bias, relu=relu, relu_token=relu_token)
     return y.view(B, H, W, -1).permute(0, 3, 1, 2), xs.view(B, H, W, C).permute(0, 3, 1, 2)
 
 
@@ -395,16 +434,26 @@ def pointwise_residual_relu_eligible(x, weight, bias, identity):
                      identity.permute(0, 2, 3, 1).reshape(B * H * W, N))
 
 
-def pointwise_conv_residual_relu(x, weight, bias, identity):
-    """relu(conv1x1(x, weight, bias) + identity) for channels-last activations (ask `pointwise_residual_relu_eligible` first)."""
+def pointwise_conv_residual_relu(x, weight, bias, identity, in_token=None, hand_out_token=False):
+    """relu(conv1x1(x, weight, bias) + identity) for channels-last activations (ask `pointwise_residual_relu_eligible` first).
+    in_token: x is a ReLU output whose producer agreed to leave its mask to this call's backward (`ReluToken`).
+    hand_out_token: the result goes to exactly one consumer inside the caller's module: a token rides on it."""
     B, C, H, W = x.shape
     N = weight.shape[0]
     x2, r2 = x.permute(0, 2, 3, 1).reshape(B * H * W, C), identity.permute(0, 2, 3, 1).reshape(B * H * W, N)
+    token = None
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or identity.requires_grad):
-        out = _TokenLinearResidualRelu.apply(x2, weight.reshape(N, C), bias, r2)
+        token = ReluToken() if (_PREMASK and hand_out_token) else None
+        in_premask = in_token is not None and x.requires_grad
+        if in_premask:
+            in_token.premasked = True
+        out = _TokenLinearResidualRelu.apply(x2, weight.reshape(N, C), bias, r2, token, in_premask)
     else:
         out = _fwd_product(x2, weight.reshape(N, C), bias, True, r2)
-    return out.view(B, H, W, N).permute(0, 3, 1, 2)
+    out = out.view(B, H, W, N).permute(0, 3, 1, 2)
+    if token is not None:
+        out._mdetr_relu_token = token
+    return out
 
 
 def pointwise_relu_fusable(x, weight, bias):

@@ -53,3 +53,25 @@ def tgemm(a2, w, bias=None, res=None, relu=False, nn=False, out=None, out_dtype=
     if rc != 0:
         _capi.check(rc, "mdetr_tgemm")
     return out
+
+
+def masked_supported(a2, w, mask, res=None):
+    """`tgemm_masked`'s operands: the NN rules of `supported` plus a bf16 mask [T, N] with 16-byte aligned rows."""
+    if not supported(a2, w, nn=True, res=res):
+        return False
+    return mask.dtype == torch.bfloat16 and tuple(mask.shape) == (a2.shape[0], w.shape[1]) and _rows_ok(mask, w.shape[1])
+
+
+def tgemm_masked(a2, w, mask, res=None):
+    """-> out [T, N] = where(mask <= 0, 0, a2 @ w + res): an input gradient with the ReLU backward of the layer's input inside
+    (``mdetr_tgemm_masked``; w = the parameter [K, N] as it lies in memory)."""
+    T, K = a2.shape
+    N = w.shape[1]
+    out = torch.empty((T, N), dtype=torch.bfloat16, device=a2.device)
+    rc = _lib().mdetr_tgemm_masked(
+        a2.data_ptr(), w.data_ptr(), res.data_ptr() if res is not None else None, mask.data_ptr(), out.data_ptr(), T, N, K,
+        a2.stride(0), w.stride(0), res.stride(0) if res is not None else 0, mask.stride(0), out.stride(0),
+        a2.device.index if a2.is_cuda else -1, torch.cuda.current_stream(a2.device).cuda_stream if a2.is_cuda else None)
+    if rc != 0:
+        _capi.check(rc, "mdetr_tgemm_masked")
+    return out

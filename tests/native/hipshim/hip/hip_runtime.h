@@ -150,6 +150,7 @@ using std::min;
 // ---- AMDGCN builtins used by the covered sources ------------------------------------------------------------------
 inline void __builtin_amdgcn_fence(int, const char *) {}
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}               // a hint to the instruction scheduler: nothing to emulate
+inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_wave_barrier() { hipshim::sync_wave(); }        // lanes run one after another here: a real rendezvous
 inline void __builtin_amdgcn_s_barrier() { hipshim::sync_block(); }
 // value of the wave's first live lane (every live lane of the wave takes part)

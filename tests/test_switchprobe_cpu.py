@@ -27,7 +27,7 @@ def clean_env(monkeypatch):
 def test_candidate_sets():
     bf = sp.probe_configs("bf16")
     assert bf[0] == [] and set(bf[-1]) == set(bench.AUTOTUNE_SWITCHES) and all(set(a) < set(b) for a, b in zip(bf, bf[1:]))   # nested
-    assert not {"MDETR_TGEMM", "MDETR_WFOLD", "MDETR_MSDA_BF16", "MDETR_CONV3X3"} & set(sum(sp.probe_configs("fp32"), []))                          # bf16-body kernels
+    assert not {"MDETR_TGEMM", "MDETR_WFOLD", "MDETR_RELU_PREMASK", "MDETR_MSDA_BF16", "MDETR_CONV3X3"} & set(sum(sp.probe_configs("fp32"), []))                          # bf16-body kernels
     # the roofline accounting follows the operator's element types
     f32, mixed = bench.msda_algorithmic_bytes(8, 10200, True), bench.msda_algorithmic_bytes(8, 10200, True, mixed=True)
     assert f32 - mixed == 2 * 8 * 10200 * 8 * 32 * 2                                        # value and grad_out at half width

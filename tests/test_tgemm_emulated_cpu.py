@@ -166,3 +166,25 @@ def test_tgemm_eight_wave_form_of_the_big_tile(monkeypatch):
         assert_product_close(y8, ref, mag, K, "8 waves T=%d" % T)
         monkeypatch.setenv("MDETR_TGEMM_WAVES", "4")
         assert torch.equal(run(a, w, bias=b, relu=True), y8)
+
+
+@pytest.mark.parametrize("T,K,N", [(300, 256, 256), (97, 128, 264), (1, 8, 8), (2100, 64, 128), (130, 72, 1032)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_masked_input_gradient(T, K, N, with_res, monkeypatch):
+    """mdetr_tgemm_masked: y = mask > 0 ? a w + res : 0 -- the ReLU backward of the layer's input where the input gradient leaves."""
+    from monodetr_amd import tgemm_ext
+    monkeypatch.setattr(tgemm_ext, "_backend", native_emul.lib())
+    a, w, _, r = problem(T, K, N, True, T + K + N)
+    g = torch.Generator().manual_seed(7)
+    mask = torch.randn(T, N, generator=g).clamp(min=0).to(torch.bfloat16)          # a ReLU output: zeros and positives
+    mask[0, 0] = float("nan") if T * N > 1 else mask[0, 0]                         # (NaN <= 0 is false: the gradient passes, as in threshold_backward)
+    res = r if with_res else None
+    assert tgemm_ext.masked_supported(a, w, mask, res)
+    y = tgemm_ext.tgemm_masked(a, w, mask, res)
+    ref, mag = reference(a, w, True, None, res)
+    keep = ~(mask.double() <= 0)
+    assert bool((y[~keep] == 0).all())
+    assert_product_close(torch.where(keep, y.double(), torch.zeros_like(ref)).to(y.dtype), torch.where(keep, ref, torch.zeros_like(ref)), mag, K)
+    for tile in ("64x64", "128x64", "64x128", "128x128"):
+        monkeypatch.setenv("MDETR_TGEMM_TILE", tile)
+        assert torch.equal(tgemm_ext.tgemm_masked(a, w, mask, res), y)

@@ -155,3 +155,67 @@ def test_bottleneck_with_fused_tails_on_the_gpu_is_as_close_to_fp32_as_the_defau
         assert rel(res[True][1], x64.grad) <= max(1.3 * rel(res[False][1], x64.grad), 2e-2)
         for n, p in ref.named_parameters():
             assert rel(res[True][2][n], p.grad) <= max(1.3 * rel(res[False][2][n], p.grad), 2e-2), n
+
+
+# ---- the ReLU backward inside the consumer's input gradient (mdetr_tgemm_masked, linear.ReluToken) ---------------------------------
+@pytest.mark.parametrize("T,K,N,with_res", [(61440, 128, 512, True), (15360, 256, 1024, True), (3840, 512, 2048, True),
+                                            (61440, 512, 128, False), (15360, 1024, 256, False), (4403, 72, 264, True)])
+def test_masked_input_gradient_equals_the_product_followed_by_threshold_backward(T, K, N, with_res):
+    from monodetr_amd import tgemm_ext
+    g = torch.Generator(device="cuda").manual_seed(T + K + N)
+    dy = torch.randn(T, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(K, N, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    x = torch.randn(T, N, device="cuda", generator=g).clamp(min=0).to(torch.bfloat16)         # a ReLU output
+    r = torch.randn(T, N, device="cuda", generator=g).to(torch.bfloat16) if with_res else None
+    assert tgemm_ext.masked_supported(dy, w, x, r)
+    want = torch.ops.aten.threshold_backward(tgemm_ext.tgemm(dy, w, None, r, nn=True), x, 0.0)
+    got = tgemm_ext.tgemm_masked(dy, w, x, r)
+    assert torch.equal(got, want)                                        # one rounding of the same fp32 sum, then the same zeros
+    ref = dy.double() @ w.double() + (r.double() if with_res else 0.0)
+    mag = dy.double().abs() @ w.double().abs() + (r.double().abs() if with_res else 0.0)
+    keep = x > 0
+    from gemm_bounds import assert_product_close
+    assert_product_close(got, torch.where(keep, ref, torch.zeros_like(ref)), mag, K)
+
+
+def test_bottleneck_stage_with_premasked_relu_backward_is_bit_identical(monkeypatch):
+    """A ResNet stage at layer3's shape on the GPU kernels (tgemm, conv3x3, twgrad, conv_wgrad) with and without MDETR_RELU_PREMASK:
+    the masks moved into the consumers' input-gradient products change no bit of any output or gradient."""
+    from monodetr_amd import conv3x3_ext, conv_wgrad_ext, tgemm_ext
+    from monodetr_amd.monodetr import backbone, linear
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(4)
+    for mod, on in ((conv3x3_ext, True), (conv_wgrad_ext, True)):
+        monkeypatch.setattr(mod, "ENABLED", on)
+    monkeypatch.setattr(linear, "_TGEMM", True)
+    down = torch.nn.Sequential(torch.nn.Conv2d(512, 1024, 1, 1, bias=False), backbone.FrozenBatchNorm2d(1024))
+    blocks = [backbone.Bottleneck(512, 256, 1, down), backbone.Bottleneck(1024, 256), backbone.Bottleneck(1024, 256)]
+    for blk in blocks[:-1]:
+        blk.__dict__["feeds_next_block"] = True
+    stage = torch.nn.Sequential(*blocks).to(dev).to(memory_format=torch.channels_last)
+    for m in stage.modules():
+        if isinstance(m, backbone.FrozenBatchNorm2d):
+            m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2); m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+    x = (torch.randn(8, 512, 24, 80, device=dev) * 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    calls = []
+    real = tgemm_ext.tgemm_masked
+    monkeypatch.setattr(tgemm_ext, "tgemm_masked", lambda a, w, m, r=None: (calls.append(r is not None), real(a, w, m, r))[1])
+    proj = torch.linspace(-1, 1, 8 * 1024 * 24 * 80, device=dev).view(8, 24, 80, 1024).permute(0, 3, 1, 2)
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(linear, "_PREMASK", on)
+        for p in stage.parameters():
+            p.grad = None
+        x.grad = None
+        calls.clear()
+        pairs = []
+        for blk in blocks:
+            pairs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)] + ([(blk.downsample[0], blk.downsample[1])] if blk.downsample is not None else [])
+        backbone.prefold(pairs, torch.bfloat16)
+        y = stage(x)
+        (y.float() * proj).sum().backward()
+        res[on] = (y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in stage.named_parameters()}, sorted(calls))
+    assert res[False][3] == [] and res[True][3] == [False, False, False, True, True], res[True][3]
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for n, gr in res[False][2].items():
+        assert torch.equal(res[True][2][n], gr), n

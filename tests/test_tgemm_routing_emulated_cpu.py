@@ -127,3 +127,50 @@ def test_bottleneck_with_fused_tails_matches_the_default_block(tgemm_on, monkeyp
         for n, gd in want[2].items():
             e_def, e_fused = _rel(res[False][2][n], gd), _rel(res[True][2][n], gd)
             assert e_fused <= max(1.3 * e_def, 3e-2), (n, e_def, e_fused)
+
+
+def test_stage_with_premasked_relu_backward_is_bit_identical(tgemm_on, monkeypatch):
+    """linear.ReluToken: with MDETR_RELU_PREMASK the ReLU masks between conv2 -> conv3 and between consecutive blocks of a stage are
+    applied inside the consumers' input-gradient products (mdetr_tgemm_masked) and the producers skip their passes.  Same bits:
+    one rounding of the same fp32 sum, then the same zeros."""
+    from monodetr_amd import conv3x3_ext, conv_wgrad_ext, tgemm_ext
+    from monodetr_amd.monodetr import backbone, linear
+    L = native_emul.lib()
+    monkeypatch.setattr(conv3x3_ext, "_backend", L)
+    monkeypatch.setattr(conv3x3_ext, "ENABLED", True)
+    monkeypatch.setattr(conv_wgrad_ext, "ENABLED", False)
+    torch.manual_seed(2)
+    down = torch.nn.Sequential(torch.nn.Conv2d(128, 256, 1, 1, bias=False), backbone.FrozenBatchNorm2d(256))
+    blocks = [backbone.Bottleneck(128, 64, 1, down), backbone.Bottleneck(256, 64), backbone.Bottleneck(256, 64)]
+    for blk in blocks[:-1]:
+        blk.__dict__["feeds_next_block"] = True
+    stage = torch.nn.Sequential(*blocks).to(memory_format=torch.channels_last)
+    for m in stage.modules():
+        if isinstance(m, backbone.FrozenBatchNorm2d):
+            m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2); m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+    x = (torch.randn(2, 128, 48, 48) * 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    masked_calls = []
+    real = tgemm_ext.tgemm_masked
+    monkeypatch.setattr(tgemm_ext, "tgemm_masked", lambda a, w, m, r=None: (masked_calls.append((tuple(a.shape), r is not None)), real(a, w, m, r))[1])
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(linear, "_PREMASK", on)
+        for p in stage.parameters():
+            p.grad = None
+        x.grad = None
+        masked_calls.clear()
+        pairs = []
+        for blk in blocks:
+            pairs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)] + ([(blk.downsample[0], blk.downsample[1])] if blk.downsample is not None else [])
+        backbone.prefold(pairs, torch.bfloat16)
+        y = stage(x)
+        assert (getattr(y, "_mdetr_relu_token", None) is None)          # the stage's output leaves the module: no token on it
+        (y.float() * torch.linspace(-1, 1, y.numel()).view_as(y)).sum().backward()
+        res[on] = (y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in stage.named_parameters()}, list(masked_calls))
+    assert res[False][3] == []
+    # three conv3 input gradients masked by conv2's output (no residual), two conv1 input gradients of the identity blocks masked by
+    # the previous block's output with the identity's gradient summed inside
+    assert sorted(r for _, r in res[True][3]) == [False, False, False, True, True], res[True][3]
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for n, g in res[False][2].items():
+        assert torch.equal(res[True][2][n], g), n
