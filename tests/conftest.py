@@ -5,11 +5,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 import monodetr_amd._runtime_env  # noqa: E402,F401  -- runtime flags, BEFORE torch loads the HIP runtime
-# The fp32 LIBRARY convolutions serve as references here (and run the fp32 model of the parity tests): MIOpen's Winograd solvers are
-# good to ~1e-3 per convolution, which the ill-conditioned gradients amplify (two encoder tensors at 1.8e-2 of the float64 model with
-# them, 5e-4 without: profiles/r05x_fp32_gradient_errors_winograd.txt).  The test processes run the library without them; the
-# product's fp32 configurations keep the library's default choice.  (Read once by MIOpen: must be set before the first convolution.)
-os.environ.setdefault("MIOPEN_DEBUG_CONV_WINOGRAD", "0")
 
 import numpy as np  # noqa: E402
 import pytest  # noqa: E402
