@@ -425,23 +425,27 @@ class Joiner(nn.Sequential):
         self.strides = backbone.strides
         self.num_channels = backbone.num_channels
 
-    def _as(self, level, p, dt):
-        """p in dtype dt.  A constant (sine) encoding comes out of its per-shape cache as the SAME tensor every iteration: its cast is
-        kept per level while that holds (three casts of up to 31 MB per iteration otherwise)."""
+    def _as(self, x, p, dt):
+        """p in dtype dt.  A constant (sine) encoding of an unpadded map comes out of its per-shape cache as the same tensor every
+        iteration: its cast is kept beside it, per shape and for good (three casts of up to 31 MB per iteration otherwise).  Never
+        evicted: a captured hipGraph that has read an entry reads that address in every replay (an eager iteration on another
+        batch shape in between must not free it -- tests/test_trainer_gpu.py poisons freed memory to show exactly this)."""
         if p.dtype == dt:
             return p
-        if p.requires_grad or p.grad_fn is not None:
+        from ..utils.misc import no_padding
+        if p.requires_grad or p.grad_fn is not None or not no_padding(x.mask):
             return p.to(dt)
-        last = self.__dict__.setdefault("_pos_cast", {})
-        hit = last.get(level)
-        if hit is None or hit[0] is not p or hit[1] != p._version or hit[2].dtype != dt:
-            hit = last[level] = (p, p._version, p.to(dt))
+        casts = self.__dict__.setdefault("_pos_cast", {})
+        key = (tuple(p.shape), p.device, p.dtype, dt)
+        hit = casts.get(key)
+        if hit is None or hit[0] is not p or hit[1] != p._version:
+            hit = casts[key] = (p, p._version, p.to(dt), hit)          # (a superseded entry stays referenced: see above)
         return hit[2]
 
     def forward(self, images):
         feats = self[0](images)
         out: List[NestedTensor] = [feats[k] for k in sorted(feats)]
-        pos = [self._as(i, self[1](x), x.tensors.dtype) for i, x in enumerate(out)]
+        pos = [self._as(x, self[1](x), x.tensors.dtype) for x in out]
         return out, pos
 
 
