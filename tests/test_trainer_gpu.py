@@ -137,12 +137,16 @@ def test_backward_pass_cut_at_the_encoders_last_msda_launch_gives_the_same_gradi
         # the first call stopped above the cut: nothing of the backbone, of the input projections or of the first encoder layers
         assert not any(n.startswith(("backbone.", "input_proj.", "depthaware_transformer.encoder.layers.0.")) for n in first), sorted(first)[:8]
         assert any(n.startswith("depthaware_transformer.decoder.") for n in first)
-        worst = max(((got[n] - want[n]).norm() / want[n].norm().clamp_min(1e-20)).item() for n in want)
-        print("worst relative difference of a parameter gradient, cut vs uncut backward pass: %.3g" % worst)
+        # (against the tensor's own norm, but not below 1e-4 of the largest gradient norm: the key-projection BIASES of the decoder's
+        #  self-attention have gradients that cancel to ~0 -- softmax is invariant to a constant added to every key's logit -- and two
+        #  bf16 evaluations of a zero differ by 10 % of nothing)
+        floor = 1e-4 * max(w.norm().item() for w in want.values())
+        worst, worst_name = max((((got[n] - want[n]).norm() / want[n].norm().clamp_min(floor)).item(), n) for n in want)
+        print("worst relative difference of a parameter gradient, cut vs uncut backward pass: %.3g (%s)" % (worst, worst_name))
         # bf16 gradients: the cut changes the ORDER in which a pyramid level's gradients (depth predictor | encoder) and the residual
         # stream's meet -- (a + b) + c against a + (b + c) in bf16 -- so parameter gradients agree to bf16 rounding (2^-8), measured
         # 2.1e-3; the exact statement (fp64, bit for bit) is tests/test_graph_cut_cpu.py
-        assert worst <= 2.0 ** -8, worst
+        assert worst <= 2.0 ** -8, (worst, worst_name)
     finally:
         bench.apply_switches(set())
 
