@@ -101,3 +101,41 @@ def test_prefold_route_gives_the_same_folded_weights_and_gradients(emulated, mon
     loss_a.backward(); loss_b.backward()
     for (ca, _), (cb, _) in zip(a, b):
         assert ca.weight.grad is not None and torch.equal(ca.weight.grad, cb.weight.grad)
+
+
+def test_c_abi_argument_checks():
+    """mdetr_fold_weights / mdetr_unfold_grads refuse what the kernels cannot take, with a message, before any launch."""
+    import ctypes
+    L = native_emul.lib()
+    w = torch.randn(16, 1, 1, 16).contiguous()                          # [O][taps][C] fp32
+    s = torch.rand(16)
+    f = torch.empty(16 * 16, dtype=torch.bfloat16)
+    arr = lambda *ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() if t is not None else None for t in ts])
+    ints = lambda *v: (ctypes.c_int * len(v))(*v)
+    assert L.mdetr_fold_weights(0, None, None, None, None, None, None, None, -1, None) == 0           # nothing to do
+    assert L.mdetr_fold_weights(1, arr(w), arr(s), arr(f), None, ints(16), ints(16), ints(1), -1, None) == 0
+    assert torch.equal(f.view(16, 16), (w.view(16, 16) * s.view(-1, 1)).to(torch.bfloat16))
+    for bad in (ints(12), ints(0)):                                     # O not a multiple of 8 / empty
+        rc = L.mdetr_fold_weights(1, arr(w), arr(s), arr(f), None, bad, ints(16), ints(1), -1, None)
+        assert rc != 0 and b"mdetr_fold_weights" in ctypes.string_at(L.mdetr_last_error())
+    assert L.mdetr_fold_weights(1, arr(None), arr(s), arr(f), None, ints(16), ints(16), ints(1), -1, None) != 0      # null tensor
+    assert L.mdetr_fold_weights(-1, arr(w), arr(s), arr(f), None, ints(16), ints(16), ints(1), -1, None) != 0
+    g = torch.randn(16, 16).to(torch.bfloat16)
+    out = torch.empty(16, 16)
+    assert L.mdetr_unfold_grads(1, arr(g), arr(s), arr(out), ints(16), ints(16), ints(1), -1, None) == 0
+    assert torch.equal(out, g.float() * s.view(-1, 1))
+    rc = L.mdetr_unfold_grads(1, arr(g), arr(s), arr(out), ints(16), ints(20), ints(1), -1, None)
+    assert rc != 0 and b"mdetr_unfold_grads" in ctypes.string_at(L.mdetr_last_error())
+
+
+def test_masked_gemm_c_abi_argument_checks():
+    import ctypes
+    L = native_emul.lib()
+    a = torch.randn(8, 8).to(torch.bfloat16); w = torch.randn(8, 8).to(torch.bfloat16); m = torch.ones(8, 8).to(torch.bfloat16)
+    y = torch.empty(8, 8, dtype=torch.bfloat16)
+    ok = L.mdetr_tgemm_masked(a.data_ptr(), w.data_ptr(), None, m.data_ptr(), y.data_ptr(), 8, 8, 8, 8, 8, 0, 8, 8, -1, None)
+    assert ok == 0 and (y.float() - (a.float() @ w.float())).abs().max() < 0.1
+    assert L.mdetr_tgemm_masked(a.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), 8, 8, 8, 8, 8, 0, 8, 8, -1, None) != 0     # a mask is what it is for
+    rc = L.mdetr_tgemm_masked(a.data_ptr(), w.data_ptr(), None, m.data_ptr(), y.data_ptr(), 8, 8, 8, 8, 8, 0, 4, 8, -1, None)    # mask rows shorter than N
+    assert rc != 0 and b"mdetr_tgemm_masked" in ctypes.string_at(L.mdetr_last_error())
+    assert L.mdetr_tgemm_masked(a.data_ptr(), w.data_ptr(), None, m.data_ptr(), y.data_ptr(), 0, 8, 8, 8, 8, 0, 8, 8, -1, None) == 0         # no rows: nothing to do
