@@ -127,7 +127,8 @@ def test_fp32_gradients_per_tensor_against_the_float64_model(built, oracle):
     for n, (norm, proj) in zip(names, golden["f64/grad_fp"].tolist()):
         assert abs(fp[n][0] - norm) < 1e-7 * norm + 1e-10 and abs(fp[n][1] - proj) < 1e-7 * norm + 1e-10, n
     g64 = {n: p.grad for n, p in m64.named_parameters() if p.grad is not None}
-    # ---- fp32 on the GPU (two passes, the second is measured: first-call library algorithms differ from the steady ones)
+    # ---- fp32 on the GPU (two passes, the second is measured: the steady state of the process, after every one-time choice of the
+    # libraries; the difference once attributed to that turned out to be (1) below)
     model.train(); criterion.train()
     dev = lambda t: t.cuda() if torch.is_tensor(t) else t
     tg = [{k: dev(v) for k, v in t.items()} for t in targets]
