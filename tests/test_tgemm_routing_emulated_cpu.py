@@ -174,3 +174,29 @@ def test_stage_with_premasked_relu_backward_is_bit_identical(tgemm_on, monkeypat
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
     for n, g in res[False][2].items():
         assert torch.equal(res[True][2][n], g), n
+
+
+def test_no_relu_token_is_handed_out_when_a_hook_can_see_the_tensor(tgemm_on, monkeypatch):
+    """linear.ReluToken: a forward hook on a block is a second party that may consume its output -- the block then keeps its own mask
+    pass (no token rides on its result) and the next block does not premask."""
+    from monodetr_amd import tgemm_ext
+    from monodetr_amd.monodetr import backbone, linear
+    monkeypatch.setattr(linear, "_PREMASK", True)
+    torch.manual_seed(5)
+    blocks = [backbone.Bottleneck(64, 16), backbone.Bottleneck(64, 16)]
+    blocks[0].__dict__["feeds_next_block"] = True
+    seen = []
+    blocks[0].register_forward_hook(lambda m, i, o: seen.append(getattr(o, "_mdetr_relu_token", None)))
+    stage = torch.nn.Sequential(*blocks).to(memory_format=torch.channels_last)
+    masked = []
+    real = tgemm_ext.tgemm_masked
+    monkeypatch.setattr(tgemm_ext, "tgemm_masked", lambda a, w, m, r=None: (masked.append(1), real(a, w, m, r))[1])
+    x = (torch.randn(2, 64, 48, 48) * 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    pairs = []
+    for blk in blocks:
+        pairs += [(blk.conv1, blk.bn1), (blk.conv2, blk.bn2), (blk.conv3, blk.bn3)]
+    backbone.prefold(pairs, torch.bfloat16)
+    y = stage(x)
+    y.float().sum().backward()
+    assert seen == [None] and masked == []                            # block 0: hooked -> no token; block 1's conv2 is the library's here -> nothing premasked
+    assert x.grad is not None and torch.isfinite(x.grad.float()).all()

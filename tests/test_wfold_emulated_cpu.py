@@ -139,3 +139,32 @@ def test_masked_gemm_c_abi_argument_checks():
     rc = L.mdetr_tgemm_masked(a.data_ptr(), w.data_ptr(), None, m.data_ptr(), y.data_ptr(), 8, 8, 8, 8, 8, 0, 4, 8, -1, None)    # mask rows shorter than N
     assert rc != 0 and b"mdetr_tgemm_masked" in ctypes.string_at(L.mdetr_last_error())
     assert L.mdetr_tgemm_masked(a.data_ptr(), w.data_ptr(), None, m.data_ptr(), y.data_ptr(), 0, 8, 8, 8, 8, 0, 8, 8, -1, None) == 0         # no rows: nothing to do
+
+
+def test_fold_kernel_gradients_accumulate_and_survive_odd_gradient_layouts(emulated):
+    """Two backward passes without zero_grad add up (the unfolded gradients are fresh tensors, nothing aliases p.grad); a gradient that
+    arrives NCHW-contiguous (a library fall-back upstream) takes the framework expression and gives the same numbers."""
+    from monodetr_amd.monodetr import backbone as bb
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(16, 24, 3, padding=1, bias=False).to(memory_format=torch.channels_last)
+    bn = bb.FrozenBatchNorm2d(24)
+    bn.weight.uniform_(0.5, 1.5); bn.running_var.uniform_(0.5, 2.0)
+    coef = torch.randn(24, 16, 3, 3)
+
+    def one_pass(contiguous_grad):
+        bb.prefold([(conv, bn)], torch.bfloat16)
+        w, _ = conv.__dict__.pop("_prefolded")
+        if contiguous_grad:                                          # route the gradient through an NCHW-contiguous tensor
+            (w.contiguous().float() * coef).sum().backward()
+        else:
+            (w.float() * coef.contiguous(memory_format=torch.channels_last)).sum().backward()
+
+    one_pass(False)
+    g1 = conv.weight.grad.clone()
+    scale = bn.affine()[0]
+    assert torch.equal(g1, (coef.to(torch.bfloat16).float() * scale.view(-1, 1, 1, 1)))
+    one_pass(False)
+    assert torch.equal(conv.weight.grad, 2 * g1)
+    conv.weight.grad = None
+    one_pass(True)
+    assert torch.equal(conv.weight.grad, g1)
