@@ -249,6 +249,12 @@ def conv_bn(x, conv, bn, relu, skip_out=False, relu_token=None, hand_out_token=F
 _SKIP_FUSE = os.environ.get("MDETR_BOTTLENECK_SKIP", "1") != "0"
 
 
+def _global_hooks():
+    """Is a process-wide forward (pre-)hook registered?  (torch.nn.modules.module.register_module_forward_hook: it sees every block's tensors)"""
+    m = torch.nn.modules.module
+    return bool(getattr(m, "_global_forward_hooks", None)) or bool(getattr(m, "_global_forward_pre_hooks", None))
+
+
 class Bottleneck(nn.Module):
     """1x1 reduce -> 3x3 (carries the stride) -> 1x1 expand (x4), residual add, ReLU."""
     expansion = 4
@@ -269,7 +275,7 @@ class Bottleneck(nn.Module):
         from . import linear
         # ReLU masks of the backward pass applied by the consuming kernel (linear.ReluToken): only where this module sees every
         # consumer of the tensor -- no hook may have been handed it
-        premask = linear._PREMASK and torch.is_grad_enabled() and not (self._forward_hooks or self._forward_pre_hooks)
+        premask = linear._PREMASK and torch.is_grad_enabled() and not (self._forward_hooks or self._forward_pre_hooks or _global_hooks())
         if self.downsample is None and _SKIP_FUSE:
             # (the identity's gradient meets conv1's inside its dgrad GEMM; so does, with a token from the previous block, its ReLU mask)
             y, skip = conv_bn(x, self.conv1, self.bn1, True, skip_out=True, relu_token=linear.relu_token_of(x) if premask else None)
