@@ -144,9 +144,9 @@ def test_backward_pass_cut_at_the_encoders_last_msda_launch_gives_the_same_gradi
         worst, worst_name = max((((got[n] - want[n]).norm() / want[n].norm().clamp_min(floor)).item(), n) for n in want)
         print("worst relative difference of a parameter gradient, cut vs uncut backward pass: %.3g (%s)" % (worst, worst_name))
         # bf16 gradients: the cut changes the ORDER in which a pyramid level's gradients (depth predictor | encoder) and the residual
-        # stream's meet -- (a + b) + c against a + (b + c) in bf16 -- so parameter gradients agree to bf16 rounding (2^-8), measured
-        # 2.1e-3; the exact statement (fp64, bit for bit) is tests/test_graph_cut_cpu.py
-        assert worst <= 2.0 ** -8, (worst, worst_name)
+        # stream's meet -- (a + b) + c against a + (b + c) in bf16 -- so parameter gradients agree to bf16 rounding, measured
+        # 0 .. 2.3e-3 (bar: two roundings, 2^-7); the exact statement (fp64, bit for bit) is tests/test_graph_cut_cpu.py
+        assert worst <= 2.0 ** -7, (worst, worst_name)
     finally:
         bench.apply_switches(set())
 
