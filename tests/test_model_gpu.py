@@ -162,7 +162,7 @@ def test_fp32_gradients_per_tensor_against_the_float64_model(built, oracle):
     #     nearly equal terms -- and the fp32 attention core evaluates its products as three bf16 x bf16 MFMA terms (csrc/attn.hip:
     #     ~2^-16 per product): 3.2e-3 .. 5.6e-3 on those four tensors per decoder layer.
     # Bars: the prediction heads (no location derivative between them and the loss) 1e-3 -- north_star's bar where it is well
-    # posed; (2) 1e-2; every other tensor 5e-3 (measured 5.1e-4 or, with flips, up to 1.8e-3); the location-derivative parameters
+    # posed; (2) 2e-2 (3.2e-3 .. 5.6e-3 measured over seven processes); every other tensor 5e-3 (measured 5.1e-4 or, with flips, up to 1.8e-3); the location-derivative parameters
     # themselves 1e-1 (5e-4 or 1.8e-2 measured: which samples flip is chaotic, so the bar leaves room -- the derivative itself is held
     # to the oracle at 1e-4 of scale on 10.4 M samples in tests/test_msda_gpu.py).
     soft = ("sa_qcontent_proj", "sa_qpos_proj", "sa_kcontent_proj", "sa_kpos_proj")
@@ -174,7 +174,7 @@ def test_fp32_gradients_per_tensor_against_the_float64_model(built, oracle):
     head_worst = max(w[0] for w in worst if w[1].startswith(heads))
     assert head_worst <= 1e-3, head_worst
     assert rest[0][0] <= 5e-3, rest[:8]
-    assert max([w[0] for w in worst if any(k in w[1] for k in soft)] + [0.0]) <= 1e-2, worst[:8]
+    assert max([w[0] for w in worst if any(k in w[1] for k in soft)] + [0.0]) <= 2e-2, worst[:8]
     assert worst[0][0] <= 1e-1, worst[:8]
 
 
