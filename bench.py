@@ -689,11 +689,16 @@ def main():
     work_rows = _capi.profile_read_work()                       # (kind, key, launches, ms, MFLOP, KB) of those iterations
     work_iters = 3 if use_graph else args.steps
     family_kernels, family_error = None, None
-    if rank == 0 and hasattr(step, "eager_iteration") and os.environ.get("MDETR_BENCH_FAMILIES", "1") != "0":
-        try:                                                    # one more eager iteration under torch.profiler: every kernel's time
+    if hasattr(step, "eager_iteration") and os.environ.get("MDETR_BENCH_FAMILIES", "1") != "0":
+        # one more eager iteration under torch.profiler: every kernel's time.  EVERY rank runs it -- the iteration holds the
+        # gradient exchange's collectives, which one rank alone would enter unmatched (a hang no try/except catches); rank 0's
+        # table is the one reported
+        try:
             family_kernels = profile_kernels(step, 1)
         except Exception as e:                                  # noqa: BLE001 -- a reported breakdown must not cost the measured line
             family_error = repr(e)[:200]
+        if rank != 0:
+            family_kernels = None
     if dist_on:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

@@ -18,11 +18,15 @@
 //     lane&31 -- is fed straight back as the B operand of the next product: the contraction index
 //     is then visited in a permuted ("virtual") order, and the A operand is read from a TRANSPOSED
 //     LDS copy with the same permutation (two 8-byte reads per lane), so no register shuffles.
-//   * bf16 inputs: one bf16 MFMA per product step.  fp32 inputs: every operand x is split into
-//     bf16 hi + bf16 lo (lo = bf16(x - hi)) and each product is evaluated as hi*hi + hi*lo + lo*hi
-//     (three MFMAs, the dropped lo*lo term is ~2^-16 relative): fp32-level accuracy at 3/16 of the
-//     cost of the f32-input MFMA, which is what the fp32 model needs to stay within 1e-3 of the
-//     reference.  fp32 accumulation in both modes; exp2-domain online
+//   * bf16 inputs: one bf16 MFMA per product step.  fp32 inputs: every operand x is split into THREE
+//     bf16 parts hi + mid + lo (mid = bf16(x - hi), lo = bf16(x - hi - mid): 3 x 8 significand bits =
+//     the 24 of an fp32 number, the split is exact) and each product is evaluated as
+//     hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid (six MFMAs; the dropped mid*lo, lo*mid and
+//     lo*lo terms are <= 2^-23 relative to |a||b|, the size of one fp32 rounding) -- products with
+//     fp32 accuracy at 6/16 of the cost of the f32-input MFMA.  Round 5's two-part split carried 16
+//     significand bits (2^-16 per product): the self-attention q / k projection gradients, which pass
+//     through the ill-conditioned softmax Jacobian, came out at 3e-3 .. 6e-3 of float64, above the
+//     1e-3 bar of the fp32 path.  fp32 accumulation in both modes; exp2-domain online
 //     softmax with the scale folded into Q (or K), dropout on the probabilities from a stateless
 //     counter hash of (seed, b, h, q, k) so forward and backward regenerate the same mask.
 #include <hip/hip_runtime.h>
@@ -57,22 +61,27 @@ struct AttnArgs {
 
 __device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return mfma_bf16(a, b, c); }      // mdetr_wave.h
 
-struct Frag { bf16x8 h, l; };       // operand fragment: hi part (+ lo part in split mode)
+struct Frag { bf16x8 h, m, l; };    // operand fragment: hi part (+ mid and lo parts in split mode)
 
 template <bool SP>
 __device__ __forceinline__ f32x16 mfmaX(const Frag &a, const Frag &b, f32x16 c)
 {
     c = mfma(a.h, b.h, c);
-    if (SP) { c = mfma(a.h, b.l, c); c = mfma(a.l, b.h, c); }
+    if (SP) {                        // smallest terms first would be more accurate still; the order costs nothing either way
+        c = mfma(a.h, b.m, c); c = mfma(a.m, b.h, c);
+        c = mfma(a.h, b.l, c); c = mfma(a.l, b.h, c); c = mfma(a.m, b.m, c);
+    }
     return c;
 }
 
-struct HiLo { __bf16 h, l; };
+struct HiLo { __bf16 h, m, l; };
 __device__ __forceinline__ HiLo split_bf16(float x)
 {
     HiLo r;
     r.h = static_cast<__bf16>(x);
-    r.l = static_cast<__bf16>(x - static_cast<float>(r.h));
+    const float r1 = x - static_cast<float>(r.h);                 // exact (Sterbenz-like: hi is x rounded to 8 bits)
+    r.m = static_cast<__bf16>(r1);
+    r.l = static_cast<__bf16>(r1 - static_cast<float>(r.m));      // exact again; what is left has <= 8 significant bits
     return r;
 }
 
@@ -147,7 +156,7 @@ template <> __device__ __forceinline__ void store4<__bf16>(__bf16 *p, float a, f
 
 // Stage rows [r0, r0+64) x 32 of a [L, row_stride] matrix into LDS: row-major bf16 copy `rm`
 // ([64][kRowPad]) and/or transposed copy `tr` ([32][kTPad]); rows >= L are zero.  In split mode the
-// lo parts go to rm + kRmSize / tr + kTrSize.  256 threads.
+// mid / lo parts go to rm + {1, 2} * kRmSize / tr + {1, 2} * kTrSize.  256 threads.
 constexpr int kRmSize = kTile * kRowPad, kTrSize = kD * kTPad;
 
 // 8 consecutive elements exactly as loaded (conversion is deferred to the LDS store so that the
@@ -212,18 +221,24 @@ __device__ __forceinline__ void tile_store(const Raw8<T> &raw, __bf16 *rm, __bf1
 #endif
     float x[8];
     raw_floats(raw, x);
-    bf16x8 vh, vl;
+    bf16x8 vh, vm, vl;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { const HiLo s2 = split_bf16(x[i]); vh[i] = s2.h; vl[i] = s2.l; }
+    for (int i = 0; i < 8; ++i) {
+        if (SP) { const HiLo s2 = split_bf16(x[i]); vh[i] = s2.h; vm[i] = s2.m; vl[i] = s2.l; }
+        else vh[i] = static_cast<__bf16>(x[i]);
+    }
     if (RM) {
         *reinterpret_cast<bf16x8 *>(rm + row * kRowPad + dc) = vh;
-        if (SP) *reinterpret_cast<bf16x8 *>(rm + kRmSize + row * kRowPad + dc) = vl;
+        if (SP) {
+            *reinterpret_cast<bf16x8 *>(rm + kRmSize + row * kRowPad + dc) = vm;
+            *reinterpret_cast<bf16x8 *>(rm + 2 * kRmSize + row * kRowPad + dc) = vl;
+        }
     }
     if (TR) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             tr[(dc + i) * kTPad + row] = vh[i];
-            if (SP) tr[kTrSize + (dc + i) * kTPad + row] = vl[i];
+            if (SP) { tr[kTrSize + (dc + i) * kTPad + row] = vm[i]; tr[2 * kTrSize + (dc + i) * kTPad + row] = vl[i]; }
         }
     }
 }
@@ -235,7 +250,7 @@ __device__ __forceinline__ Frag frag_rows(const __bf16 *rm, int sub, int kstep, 
     const int off = (sub * 32 + (lane & 31)) * kRowPad + kstep * 16 + (lane >> 5) * 8;
     Frag f;
     f.h = *reinterpret_cast<const bf16x8 *>(rm + off);
-    if (SP) f.l = *reinterpret_cast<const bf16x8 *>(rm + kRmSize + off);
+    if (SP) { f.m = *reinterpret_cast<const bf16x8 *>(rm + kRmSize + off); f.l = *reinterpret_cast<const bf16x8 *>(rm + 2 * kRmSize + off); }
     return f;
 }
 
@@ -255,7 +270,7 @@ __device__ __forceinline__ Frag frag_cols(const __bf16 *tr, int sub, int kstep, 
     const int off = (lane & 31) * kTPad + sub * 32 + kstep * 16 + (lane >> 5) * 4;
     Frag f;
     f.h = read_cols(tr + off);
-    if (SP) f.l = read_cols(tr + kTrSize + off);
+    if (SP) { f.m = read_cols(tr + kTrSize + off); f.l = read_cols(tr + 2 * kTrSize + off); }
     return f;
 }
 
@@ -266,7 +281,7 @@ __device__ __forceinline__ Frag frag_acc(const float (&p)[16], int kstep)
     Frag f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        if (SP) { const HiLo s2 = split_bf16(p[8 * kstep + i]); f.h[i] = s2.h; f.l[i] = s2.l; }
+        if (SP) { const HiLo s2 = split_bf16(p[8 * kstep + i]); f.h[i] = s2.h; f.m[i] = s2.m; f.l[i] = s2.l; }
         else f.h[i] = static_cast<__bf16>(p[8 * kstep + i]);
     }
     return f;
@@ -286,7 +301,7 @@ __device__ __forceinline__ void own_row_frags(const T *rowp, bool valid, float m
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if (SP) { const HiLo s2 = split_bf16(x[i] * mul); f[ks].h[i] = s2.h; f[ks].l[i] = s2.l; }
+            if (SP) { const HiLo s2 = split_bf16(x[i] * mul); f[ks].h[i] = s2.h; f[ks].m[i] = s2.m; f[ks].l[i] = s2.l; }
             else f[ks].h[i] = static_cast<__bf16>(x[i] * mul);
         }
     }
@@ -306,8 +321,8 @@ template <typename T, bool DROP, int KS>
 __global__ __launch_bounds__(256 * KS)
 void attn_fwd_kernel(const AttnArgs a, T *__restrict__ out, float *__restrict__ lse2)
 {
-    constexpr bool SP = sizeof(T) == 4;                  // fp32 I/O: hi/lo split operands
-    constexpr int SPC = SP ? 2 : 1;
+    constexpr bool SP = sizeof(T) == 4;                  // fp32 I/O: hi / mid / lo split operands
+    constexpr int SPC = SP ? 3 : 1;
     __shared__ __attribute__((aligned(16))) __bf16 Ks_all[KS * SPC * kRmSize];
     __shared__ __attribute__((aligned(16))) __bf16 Vt_all[KS * SPC * kTrSize];
     __shared__ __attribute__((aligned(16))) unsigned kh_all[KS * kTile];  // dropout: the staged keys' hashed terms
@@ -462,7 +477,7 @@ void attn_bwd_dq_kernel(const AttnArgs a, const T *__restrict__ d_o, const float
                         const float *__restrict__ dsum, T *__restrict__ dq)
 {
     constexpr bool SP = sizeof(T) == 4;
-    constexpr int SPC = SP ? 2 : 1;
+    constexpr int SPC = SP ? 3 : 1;
     __shared__ __attribute__((aligned(16))) __bf16 Ks_all[KS * SPC * kRmSize];
     __shared__ __attribute__((aligned(16))) __bf16 Vs_all[KS * SPC * kRmSize];
     __shared__ __attribute__((aligned(16))) __bf16 Kt_all[KS * SPC * kTrSize];
@@ -576,10 +591,10 @@ void attn_bwd_dkv_kernel(const AttnArgs a, const T *__restrict__ d_o, const floa
                          const float *__restrict__ dsum, T *__restrict__ dk, T *__restrict__ dv)
 {
     constexpr bool SP = sizeof(T) == 4;
-    __shared__ __attribute__((aligned(16))) __bf16 Qs[(SP ? 2 : 1) * kRmSize];
-    __shared__ __attribute__((aligned(16))) __bf16 Os[(SP ? 2 : 1) * kRmSize];
-    __shared__ __attribute__((aligned(16))) __bf16 Qt[(SP ? 2 : 1) * kTrSize];
-    __shared__ __attribute__((aligned(16))) __bf16 Ot[(SP ? 2 : 1) * kTrSize];
+    __shared__ __attribute__((aligned(16))) __bf16 Qs[(SP ? 3 : 1) * kRmSize];
+    __shared__ __attribute__((aligned(16))) __bf16 Os[(SP ? 3 : 1) * kRmSize];
+    __shared__ __attribute__((aligned(16))) __bf16 Qt[(SP ? 3 : 1) * kTrSize];
+    __shared__ __attribute__((aligned(16))) __bf16 Ot[(SP ? 3 : 1) * kTrSize];
     __shared__ __attribute__((aligned(16))) float Ls[kTile];
     __shared__ __attribute__((aligned(16))) float Ds[kTile];
     __shared__ __attribute__((aligned(16))) unsigned qh[kTile];           // dropout: the staged queries' hashed terms

@@ -179,7 +179,13 @@ class SplitGradSync(FlatGradSync):
         if static is not None and (part is not None or params is None):
             # under graph replay the gradients live at the CAPTURED addresses and the captured optimizer reads the persistent flat
             # buffers: always the remembered plan, never a fresh one built from whatever .grad points at by now
-            plan = static[part if part is not None else "all"]
+            if part is None and "all" not in static:
+                # every remembered part, in order (start() without a name on a plan remembered in parts = the flat exchange)
+                plan = [entry for name in static for entry in static[name]]
+            elif (part if part is not None else "all") not in static:
+                raise RuntimeError("SplitGradSync.start(part=%r): the remembered plan has the parts %s" % (part, sorted(static)))
+            else:
+                plan = static[part if part is not None else "all"]
             pre = self._gathered
         else:
             if params is not None:

@@ -439,7 +439,10 @@ class Joiner(nn.Sequential):
         if p.dtype == dt:
             return p
         from ..utils.misc import no_padding
-        if p.requires_grad or p.grad_fn is not None or not no_padding(x.mask):
+        from .position_encoding import PositionEmbeddingSine
+        if p.requires_grad or p.grad_fn is not None or not no_padding(x.mask) or not isinstance(self[1], PositionEmbeddingSine):
+            # (a learned embedding returns a fresh tensor per call -- under no_grad nothing above tells it from a constant, and
+            #  a chain of superseded casts would grow by one map per level and evaluation iteration)
             return p.to(dt)
         casts = self.__dict__.setdefault("_pos_cast", {})
         key = (tuple(p.shape), p.device, p.dtype, dt)

@@ -42,7 +42,13 @@ class ReluToken:
     threshold_backward over it.  Masking is idempotent and linear, so a consumer may always mask its own contribution; the producer
     may only SKIP its pass when every consumer masks -- which is why tokens are only handed out where the graph is closed by
     construction: inside a Bottleneck (conv2 -> conv3) and between consecutive blocks of a stage (monodetr/backbone.py), never on a
-    tensor that leaves the module."""
+    tensor that leaves the module.
+
+    Limitation (what "closed by construction" does not see): an observer attached to the INTERMEDIATE tensor itself --
+    `y.retain_grad()`, `y.register_hook(...)`, `torch.autograd.grad(loss, y)` -- receives the consumer-masked gradient (zero where
+    y <= 0) instead of d loss / d y.  Parameter gradients and every gradient outside the module are unaffected (the mask would have
+    been applied one node later anyway).  Module-level forward hooks switch the tokens off (backbone.py checks `_forward_hooks`);
+    to observe intermediate gradients inside a bottleneck run with MDETR_RELU_PREMASK unset."""
     __slots__ = ("premasked",)
 
     def __init__(self):

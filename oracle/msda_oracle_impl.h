@@ -40,10 +40,14 @@ static inline int FN(in_window)(REAL h_im, REAL w_im, int H, int W)
     return h_im > (REAL)-1 && w_im > (REAL)-1 && h_im < (REAL)H && w_im < (REAL)W;
 }
 
-static inline void FN(make_footprint)(REAL h, REAL w, int H, int W, FN(footprint) *f)
+/* cell: NULL = the sample's own cell (floor, .cuh:38-39); otherwise (h_low, w_low) GIVEN by the caller -- the "forced cell"
+ * evaluation used by tests/test_model_gpu.py: the float64 model is evaluated on the bilinear patch the fp32 run chose for each
+ * sample (the output is continuous across a cell boundary, its location derivative is not; a sample within fp32 resolution of a
+ * boundary may floor differently in the two precisions).  The weights lh / lw are then the same polynomial extended past [0, 1]. */
+static inline void FN(make_footprint)(REAL h, REAL w, int H, int W, FN(footprint) *f, const int32_t *cell)
 {
-    f->h_low = (int)FLOOR(h);
-    f->w_low = (int)FLOOR(w);
+    f->h_low = cell ? (int)cell[0] : (int)FLOOR(h);
+    f->w_low = cell ? (int)cell[1] : (int)FLOOR(w);
     const int h_high = f->h_low + 1, w_high = f->w_low + 1;
     f->lh = h - (REAL)f->h_low;
     f->lw = w - (REAL)f->w_low;
@@ -59,9 +63,11 @@ static inline void FN(make_footprint)(REAL h, REAL w, int H, int W, FN(footprint
 
 /* value [B,S,M,D]; shapes [L,2] (H,W); level_start [L]; loc [B,Lq,M,L,P,2] (x,y);
  * attn [B,Lq,M,L,P]; out [B,Lq,M*D].  Returns 0. */
-int FN(msda_oracle_forward)(const REAL *value, const int64_t *shapes, const int64_t *level_start,
+/* forced: NULL, or int32 [B,Lq,M,L,P,4] = (in_window, h_low, w_low, -) as msda_oracle_indices writes it: window test and cell
+ * of every sample taken from there instead of from this precision's own arithmetic. */
+static int FN(msda_forward_impl)(const REAL *value, const int64_t *shapes, const int64_t *level_start,
                             const REAL *loc, const REAL *attn, REAL *out,
-                            int B, int S, int M, int D, int L, int Lq, int P)
+                            int B, int S, int M, int D, int L, int Lq, int P, const int32_t *forced)
 {
     const int64_t qid_stride = (int64_t)M * D;
 #pragma omp parallel for collapse(2) schedule(static)
@@ -82,9 +88,10 @@ int FN(msda_oracle_forward)(const REAL *value, const int64_t *shapes, const int6
                         const REAL weight = attp[l * P + p];
                         const REAL h_im = loc_h * (REAL)H - (REAL)0.5;   /* .cuh:285 */
                         const REAL w_im = loc_w * (REAL)W - (REAL)0.5;   /* .cuh:286 */
-                        if (!FN(in_window)(h_im, w_im, H, W)) continue;
+                        const int32_t *fc = forced ? forced + ((samp * L + l) * P + p) * 4 : NULL;
+                        if (fc ? !fc[0] : !FN(in_window)(h_im, w_im, H, W)) continue;
                         FN(footprint) f;
-                        FN(make_footprint)(h_im, w_im, H, W, &f);
+                        FN(make_footprint)(h_im, w_im, H, W, &f, fc ? fc + 1 : NULL);
                         const int64_t o_ll = ((int64_t)f.h_low * W + f.w_low) * qid_stride + (int64_t)m * D;
                         const int64_t dx = qid_stride, dy = (int64_t)W * qid_stride;
                         for (int c = 0; c < D; ++c) {
@@ -103,16 +110,30 @@ int FN(msda_oracle_forward)(const REAL *value, const int64_t *shapes, const int6
     return 0;
 }
 
+int FN(msda_oracle_forward)(const REAL *value, const int64_t *shapes, const int64_t *level_start,
+                            const REAL *loc, const REAL *attn, REAL *out,
+                            int B, int S, int M, int D, int L, int Lq, int P)
+{
+    return FN(msda_forward_impl)(value, shapes, level_start, loc, attn, out, B, S, M, D, L, Lq, P, NULL);
+}
+
+int FN(msda_oracle_forward_forced)(const REAL *value, const int64_t *shapes, const int64_t *level_start,
+                                   const REAL *loc, const REAL *attn, REAL *out, const int32_t *forced,
+                                   int B, int S, int M, int D, int L, int Lq, int P)
+{
+    return FN(msda_forward_impl)(value, shapes, level_start, loc, attn, out, B, S, M, D, L, Lq, P, forced);
+}
+
 /* grad_out [B,Lq,M*D] -> grad_value [B,S,M,D], grad_loc (shape of loc), grad_attn (shape of attn).
  * All three outputs are fully (re)written; no pre-zeroing needed.  Parallel over (image, head):
  * heads write disjoint channels of grad_value, and inside one (image, head) the scatter stays
  * sequential in (q,l,p,c) order -- every address sees its contributions in the same order as a
  * fully serial (q,m,l,p,c) loop, so the oracle is deterministic and thread-count independent
  * (the reference's atomics are not). */
-int FN(msda_oracle_backward)(const REAL *value, const int64_t *shapes, const int64_t *level_start,
+static int FN(msda_backward_impl)(const REAL *value, const int64_t *shapes, const int64_t *level_start,
                              const REAL *loc, const REAL *attn, const REAL *grad_out,
                              REAL *grad_value, REAL *grad_loc, REAL *grad_attn,
-                             int B, int S, int M, int D, int L, int Lq, int P)
+                             int B, int S, int M, int D, int L, int Lq, int P, const int32_t *forced)
 {
     const int64_t qid_stride = (int64_t)M * D;
     memset(grad_value, 0, sizeof(REAL) * (size_t)B * S * M * D);
@@ -138,9 +159,10 @@ int FN(msda_oracle_backward)(const REAL *value, const int64_t *shapes, const int
                         const REAL h_im = loc_h * (REAL)H - (REAL)0.5;
                         const REAL w_im = loc_w * (REAL)W - (REAL)0.5;
                         REAL acc_w = (REAL)0, acc_h = (REAL)0, acc_a = (REAL)0;  /* .cuh:365-367 */
-                        if (FN(in_window)(h_im, w_im, H, W)) {
+                        const int32_t *fc = forced ? forced + ((samp * L + l) * P + p) * 4 : NULL;
+                        if (fc ? fc[0] : FN(in_window)(h_im, w_im, H, W)) {
                             FN(footprint) f;
-                            FN(make_footprint)(h_im, w_im, H, W, &f);
+                            FN(make_footprint)(h_im, w_im, H, W, &f, fc ? fc + 1 : NULL);
                             const int64_t o_ll = ((int64_t)f.h_low * W + f.w_low) * qid_stride + (int64_t)m * D;
                             const int64_t dx = qid_stride, dy = (int64_t)W * qid_stride;
                             for (int c = 0; c < D; ++c) {
@@ -169,6 +191,24 @@ int FN(msda_oracle_backward)(const REAL *value, const int64_t *shapes, const int
     return 0;
 }
 
+int FN(msda_oracle_backward)(const REAL *value, const int64_t *shapes, const int64_t *level_start,
+                             const REAL *loc, const REAL *attn, const REAL *grad_out,
+                             REAL *grad_value, REAL *grad_loc, REAL *grad_attn,
+                             int B, int S, int M, int D, int L, int Lq, int P)
+{
+    return FN(msda_backward_impl)(value, shapes, level_start, loc, attn, grad_out, grad_value, grad_loc, grad_attn,
+                                  B, S, M, D, L, Lq, P, NULL);
+}
+
+int FN(msda_oracle_backward_forced)(const REAL *value, const int64_t *shapes, const int64_t *level_start,
+                                    const REAL *loc, const REAL *attn, const REAL *grad_out,
+                                    REAL *grad_value, REAL *grad_loc, REAL *grad_attn, const int32_t *forced,
+                                    int B, int S, int M, int D, int L, int Lq, int P)
+{
+    return FN(msda_backward_impl)(value, shapes, level_start, loc, attn, grad_out, grad_value, grad_loc, grad_attn,
+                                  B, S, M, D, L, Lq, P, forced);
+}
+
 /* Gather indices per sample, for the "bit-exact index" parity check.
  * idx [B,Lq,M,L,P,4] int32 = (in_window, h_low, w_low, corner_mask); h_low/w_low/corner_mask
  * are 0 when the sample is outside the window (.cuh:288). corner_mask bit k = ok(k+1). */
@@ -187,7 +227,7 @@ int FN(msda_oracle_indices)(const int64_t *shapes, const REAL *loc, int32_t *idx
                 o[0] = o[1] = o[2] = o[3] = 0;
                 if (FN(in_window)(h_im, w_im, H, W)) {
                     FN(footprint) f;
-                    FN(make_footprint)(h_im, w_im, H, W, &f);
+                    FN(make_footprint)(h_im, w_im, H, W, &f, NULL);
                     o[0] = 1; o[1] = f.h_low; o[2] = f.w_low;
                     o[3] = f.ok1 | (f.ok2 << 1) | (f.ok3 << 2) | (f.ok4 << 3);
                 }

@@ -65,8 +65,9 @@ def test_forward_backward_vs_fp64(B, H, Lq, Lk, dtype):
     ref = reference(qd, kd, vd, H)
     ref.backward(go.double())
     assert out.dtype == dtype and out.shape == (B, Lq, E)
-    # fp32 I/O uses hi/lo split operands (near-fp32 products); bf16 I/O is bf16-level
-    tol, gtol, ftol = (2e-4, 5e-4, 1e-4) if dtype == torch.float32 else (2e-2, 3e-2, 1e-2)
+    # fp32 I/O uses three-part split operands (hi + mid + lo = all 24 significand bits, six MFMA terms: fp32 products; measured
+    # 0.7 - 2.7e-6 of scale on the shim); bf16 I/O is bf16-level.  Round 5's two-part split stood at 2e-4 / 5e-4 / 1e-4 here.
+    tol, gtol, ftol = (2e-5, 2e-5, 1e-5) if dtype == torch.float32 else (2e-2, 3e-2, 1e-2)
     assert (out.double() - ref).abs().max() < tol * max(1.0, ref.abs().max().item())
     for g, r, name in ((q.grad, qd.grad, "dq"), (k.grad, kd.grad, "dk"), (v.grad, vd.grad, "dv")):
         assert (g.double() - r).abs().max() < gtol * max(1.0, r.abs().max().item()), name
