@@ -481,6 +481,7 @@ FAMILY_PATTERNS = (      # (family, substrings of the kernel name, profile kinds
     ("token_gemm", ("tgemm_kernel",), (10,)),
     ("token_weight_gradient", ("twgrad_kernel", "conv_wgrad_kernel<1, 1>"), (11,)),
     ("convolutions", ("conv3x3_kernel", "conv_taps", "conv_dgrad4", "conv_stem", "conv_wgrad_kernel", "maxpool3x3s2", "decimate"), (9,)),
+    ("fp32_matrix_products", ("sgemm_",), (21,)),        # the fp32 prediction heads (csrc/sgemm.hip): priced against the f32-input MFMA peak
     ("small_weight_gradient", ("small_wgrad",), (16,)),
     ("column_sums", ("colsum",), (12,)),
     ("residual_layernorm", ("add_ln",), (13,)),
@@ -525,7 +526,7 @@ def families_table(kernel_times, work, msda_bytes=0.0, attn_flop=0.0, iterations
         if fam == "attention":
             flops = attn_flop
         if flops > 0 or byts > 0:
-            t_hbm, t_mfma = byts / 8.0e12, flops / 2.5e15
+            t_hbm, t_mfma = byts / 8.0e12, flops / (157.3e12 if fam == "fp32_matrix_products" else 2.5e15)
             row.update(algorithmic_bytes=int(byts), flops=int(flops), bound="hbm" if t_hbm >= t_mfma else "mfma",
                        frac=round(max(t_hbm, t_mfma) / (us / iterations * 1e-6), 4) if us > 0 else None)
         else:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDETR_ABI_VERSION 8
+#define MDETR_ABI_VERSION 9
 
 /* element types of the floating-point tensors */
 #define MDETR_F32 0
@@ -357,6 +357,50 @@ int mdetr_tgemm(const void *a, const void *w, const void *bias, const void *res,
  */
 int mdetr_tgemm_masked(const void *a, const void *w, const void *res, const void *mask, void *y, int64_t T, int N, int K,
                        int64_t lda, int64_t ldw, int64_t ldr, int64_t ldm, int64_t ldy, int device, void *stream);
+
+/*
+ * Grouped fp32 products on the f32-input matrix instruction (ABI 9; csrc/sgemm.hip): up to MDETR_SGEMM_MAX_PROBLEMS independent
+ * products per launch, each
+ *     C[m, n] = mask( relu( sum_t A_t op(B_t) + bias + res ) )
+ * in exact fp32 arithmetic (v_mfma_f32_32x32x2_f32: the k-ordered fmaf chain -- no reduced-precision path exists on gfx950 and none
+ * is used).  Replaces, for the prediction heads of lib/models/monodetr/monodetr.py:222-262 (class_embed, bbox_embed, dim_embed_3d,
+ * angle_embed, depth_embed: nn.Linear / MLP on the [B x queries, 256] decoder output of every level -> ATen addmm / mm -> rocBLAS /
+ * hipBLASLt sgemm, one launch per layer and direction) the 20 library launches per decoder level by 7 grouped ones.
+ *   mode MDETR_SGEMM_NT   C[M, N] = A[M, K] B[N, K]^T     forward of a linear layer (B = the weight as it lies in memory)
+ *        MDETR_SGEMM_NN   C[M, N] = A[M, K] B[K, N]       input gradient dX = dY W
+ *        MDETR_SGEMM_TN   C[M, N] = A[K, M]^T B[K, N]     weight gradient dW = dY^T X (k = the token count); colsum[m] = sum_k A[k, m]
+ *                                                          (the bias gradient) rides along; one term, no bias / relu / mask / res
+ *   term   A_t, B_t with their row strides (elements), contraction length k, element types MDETR_F32 or MDETR_BF16 (widened on load).
+ *          Several terms = one product over a contraction axis that is split over several tensors (dX of a packed first layer:
+ *          the per-head gradient slices against the per-head weights -- no concatenated copy of either exists).
+ *   bias   [N] fp32 or NULL;  relu_cols: columns [0, relu_cols) pass through max(., 0) (0 = none);
+ *   mask   fp32 [M, N] (row stride ldm) or NULL: the result is zeroed where mask <= 0 (the backward of the ReLU whose OUTPUT is mask);
+ *   res    [M, N] (row stride ldr, res_dtype) or NULL: added before relu / mask (a gradient arriving over another path);
+ *   c      [M, N] (row stride ldc), c_dtype MDETR_F32 or MDETR_BF16 (one rounding at the store).
+ * Any shape: ragged edges are guarded element-wise; rows whose stride and base allow it are read with 16-byte loads.  Deterministic
+ * (fixed summation order, no atomics).
+ */
+#define MDETR_SGEMM_NT 0
+#define MDETR_SGEMM_NN 1
+#define MDETR_SGEMM_TN 2
+#define MDETR_SGEMM_MAX_PROBLEMS 10
+#define MDETR_SGEMM_MAX_TERMS 5
+typedef struct {
+    const void *a, *b;
+    int64_t lda, ldb;
+    int32_t k, a_dtype, b_dtype, pad_;
+} mdetr_sgemm_term;
+typedef struct {
+    mdetr_sgemm_term term[MDETR_SGEMM_MAX_TERMS];
+    void *c;
+    const float *bias;
+    float *colsum;
+    const float *mask;
+    const void *res;
+    int64_t ldc, ldm, ldr;
+    int32_t nterm, m, n, relu_cols, c_dtype, res_dtype;
+} mdetr_sgemm_problem;
+int mdetr_sgemm_grouped(int mode, const mdetr_sgemm_problem *problems, int nprob, int device, void *stream);
 
 /*
  * Training image path of the input pipeline on the device: what

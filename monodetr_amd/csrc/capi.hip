@@ -30,6 +30,7 @@
 #include "pair_losses.h"
 #include "rotate_iou.h"
 #include "tgemm.h"
+#include "sgemm.h"
 #include "twgrad.h"
 #include "msda.h"
 #include "msda_prologue.h"
@@ -497,6 +498,17 @@ int mdetr_tgemm(const void *a, const void *w, const void *bias, const void *res,
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_tgemm: set device %d: %s", device, hipGetErrorString(dev.err));
     const hipError_t e = mdetr::tgemm_launch(p, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_tgemm: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_sgemm_grouped(int mode, const mdetr_sgemm_problem *problems, int nprob, int device, void *stream)
+{
+    const char *why = mdetr::sgemm_check(mode, problems, nprob);
+    if (why) return fail(MDETR_E_ARG, "mdetr_sgemm_grouped: %s (mode %d, %d problems)", why, mode, nprob);
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_sgemm_grouped: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::sgemm_launch(mode, problems, nprob, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_sgemm_grouped: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }
 

@@ -17,6 +17,14 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// D = A B + C on one wave with fp32 operands (v_mfma_f32_32x32x2_f32): lane l supplies A[l & 31][l >> 5] and B[l >> 5][l & 31] -- ONE
+// value each, a contraction of depth 2 per instruction; the accumulator layout is mfma_bf16's.  Exact fp32: the result is the
+// k-ordered fmaf chain (MI355X_MICROARCH.md, "Matrix cores"), at the fp32 vector rate (1/16 of the bf16 instruction).
+__device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
 // two packed fp32 lanes: element-wise fma / mul on this type select v_pk_fma_f32 / v_pk_mul_f32 (one issue slot for two
 // channels; the plain-float spelling compiles to two scalar FMAs)
 typedef __attribute__((ext_vector_type(2))) float f32x2;

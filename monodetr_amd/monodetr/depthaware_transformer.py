@@ -28,6 +28,7 @@ from ..add_ln_ext import residual_layernorm
 from . import _cut
 from ..utils.misc import inverse_sigmoid, no_padding
 from .attention import MultiheadAttention as FusedMultiheadAttention
+from .heads import heads_level
 from .linear import Linear, ffn_hidden, token_linear
 from .ops.modules import MSDeformAttn, MSDeformAttn_cross, MultiheadAttention  # noqa: F401  (reference :11)
 
@@ -338,10 +339,17 @@ class DepthAwareDecoder(nn.Module):
                 # finished here (the refinement needs them), the rest is handed to MonoDETR.forward -- which would
                 # otherwise evaluate bbox_embed a second time on the same tensor (reference monodetr.py:226-236)
                 cls, dep, ang = (f[lid] for f in fused)
-                parts = fused_first_layers(output, [self.bbox_embed[lid], self.dim_embed[lid], dep, ang, cls])
-                delta = mlp_rest(self.bbox_embed[lid], parts[0])
-                head_out.append((delta, mlp_rest(dep, parts[2]), mlp_rest(ang, parts[3]),
-                                 mlp_rest(cls, parts[4]) if isinstance(cls, MLP) else parts[4]))
+                grouped = heads_level(output, self.bbox_embed[lid], self.dim_embed[lid], dep, ang, cls)
+                if grouped is not None:
+                    # the five heads as grouped fp32 launches (heads.py); `output` continues as the tensor handed back, so that
+                    # the next layer's gradient is summed inside the heads' input-gradient launch
+                    delta, grouped_dims, dep_out, ang_out, cls_out, output = grouped
+                    head_out.append((delta, dep_out, ang_out, cls_out))
+                else:
+                    parts = fused_first_layers(output, [self.bbox_embed[lid], self.dim_embed[lid], dep, ang, cls])
+                    delta = mlp_rest(self.bbox_embed[lid], parts[0])
+                    head_out.append((delta, mlp_rest(dep, parts[2]), mlp_rest(ang, parts[3]),
+                                     mlp_rest(cls, parts[4]) if isinstance(cls, MLP) else parts[4]))
             elif self.bbox_embed is not None:
                 delta = self.bbox_embed[lid](output)
             if self.bbox_embed is not None:             # iterative refinement (:602-613)
@@ -351,7 +359,7 @@ class DepthAwareDecoder(nn.Module):
                     new_ref = torch.cat((delta[..., :2] + inverse_sigmoid(reference_points), delta[..., 2:]), -1).sigmoid()
                 reference_points = new_ref.detach()
             if fused is not None and self.bbox_embed is not None and self.dim_embed is not None:
-                reference_dims = mlp_rest(self.dim_embed[lid], parts[1])
+                reference_dims = grouped_dims if grouped is not None else mlp_rest(self.dim_embed[lid], parts[1])
             elif self.dim_embed is not None:
                 reference_dims = self.dim_embed[lid](output)
             if self.return_intermediate:

@@ -52,6 +52,25 @@ inline f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c)
     return c;
 }
 
+// v_mfma_f32_32x32x2_f32: lane l supplies A[l & 31][l >> 5] and B[l >> 5][l & 31]; D = the k-ordered fmaf chain (exact fp32)
+inline f32x16 mfma_f32(float a, float b, f32x16 c)
+{
+    const int me = threadIdx.x, base = hipshim::lane_base(), lane = me - base;
+    hipshim::mfma_a[me][0] = a;
+    hipshim::mfma_b[me][0] = b;
+    hipshim::sync_wave();
+    const int col = lane & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k)
+            acc = fmaf(hipshim::mfma_a[base + row + 32 * k][0], hipshim::mfma_b[base + col + 32 * k][0], acc);
+        c[r] = acc;
+    }
+    hipshim::sync_wave();
+    return c;
+}
+
 // two packed fp32 lanes (the real header: ext_vector_type(2) -> v_pk_fma_f32 / v_pk_mul_f32)
 struct f32x2 { float x, y; };
 struct alignas(16) f32x4 { float x, y, z, w; };

@@ -1,0 +1,114 @@
+"""csrc/sgemm.hip on the GPU: the grouped fp32 products at the shapes of the prediction heads (B x 550 = 4 400 rows), against
+float64; a decoder level's heads (monodetr/heads.py) against the modules; the training step with and without the family."""
+import copy
+
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, absref, K):
+    """|got - ref| <= 2 K 2^-24 sum|a||b| + one output rounding (fp32 accumulation, nothing narrower)."""
+    bound = 2.0 * K * 2.0 ** -24 * absref + (2.0 ** -8 * ref.abs() if got.dtype == torch.bfloat16 else 2.0 ** -23 * ref.abs()) + 1e-30
+    bad = (got.double() - ref).abs() > bound
+    assert not bad.any(), (int(bad.sum()), float(((got.double() - ref).abs() / bound).max()))
+
+
+def test_sgemm_nt_nn_tn_at_the_heads_shapes_vs_float64():
+    from monodetr_amd import sgemm_ext as ext
+    torch.manual_seed(0)
+    dev = "cuda"
+    T = 4400
+    x = torch.randn(T, 256, device=dev).to(torch.bfloat16)
+    w1 = [torch.randn(256, 256, device=dev) * 0.06 for _ in range(4)]
+    b1 = [torch.randn(256, device=dev) for _ in range(4)]
+    wc, bc = torch.randn(3, 256, device=dev), torch.randn(3, device=dev)
+    h1 = torch.empty(T, 1024, device=dev)
+    logits = torch.empty(T, 3, device=dev)
+    ext.grouped(ext.NT, [ext.Problem([(x, w)], h1[:, 256 * i:256 * (i + 1)], bias=b, relu_cols=True) for i, (w, b) in enumerate(zip(w1, b1))]
+                + [ext.Problem([(x, wc)], logits, bias=bc)])
+    xd = x.double()
+    for i in range(4):
+        ref = (xd @ w1[i].double().t() + b1[i].double()).clamp(min=0)
+        _close(h1[:, 256 * i:256 * (i + 1)], ref, xd.abs() @ w1[i].double().abs().t() + b1[i].double().abs(), 256)
+    _close(logits, xd @ wc.double().t() + bc.double(), xd.abs() @ wc.double().abs().t() + bc.double().abs(), 256)
+    # input gradient over a contraction split across five tensors, the residual-path gradient and the bf16 rounding inside
+    dh1 = torch.randn(T, 1024, device=dev)
+    dcls = torch.randn(T, 3, device=dev)
+    skip = torch.randn(T, 256, device=dev).to(torch.bfloat16)
+    dx = torch.empty(T, 256, device=dev, dtype=torch.bfloat16)
+    ext.grouped(ext.NN, [ext.Problem([(dh1[:, 256 * i:256 * (i + 1)], w1[i]) for i in range(4)] + [(dcls, wc)], dx, res=skip)])
+    ref = sum(dh1[:, 256 * i:256 * (i + 1)].double() @ w1[i].double() for i in range(4)) + dcls.double() @ wc.double() + skip.double()
+    absref = sum(dh1[:, 256 * i:256 * (i + 1)].double().abs() @ w1[i].double().abs() for i in range(4)) + dcls.double().abs() @ wc.double().abs() + skip.double().abs()
+    _close(dx, ref, absref, 1027)
+    # masked input gradient with a 6-long contraction
+    g6, w6, saved = torch.randn(T, 6, device=dev), torch.randn(6, 256, device=dev), torch.randn(T, 256, device=dev)
+    dh2 = torch.empty(T, 256, device=dev)
+    ext.grouped(ext.NN, [ext.Problem([(g6, w6)], dh2, mask=saved)])
+    _close(dh2, (g6.double() @ w6.double()) * (saved > 0), g6.double().abs() @ w6.double().abs(), 6)
+    # weight gradients over 4 400 rows with their column sums
+    dws = [torch.empty(256, 256, device=dev) for _ in range(4)] + [torch.empty(3, 256, device=dev), torch.empty(6, 256, device=dev)]
+    dbs = [torch.empty(256, device=dev) for _ in range(4)] + [torch.empty(3, device=dev), torch.empty(6, device=dev)]
+    ops = [(dh1[:, 256 * i:256 * (i + 1)], x) for i in range(4)] + [(dcls, x), (g6, saved)]
+    ext.grouped(ext.TN, [ext.Problem([op], dw, colsum=db) for op, dw, db in zip(ops, dws, dbs)])
+    for (a, b), dw, db in zip(ops, dws, dbs):
+        _close(dw, a.double().t() @ b.double(), a.double().abs().t() @ b.double().abs(), T)
+        _close(db, a.double().sum(0), a.double().abs().sum(0), T)
+    # twice the same launch: bit-identical (fixed summation order, no atomics)
+    again = [torch.empty_like(d) for d in dws]
+    ext.grouped(ext.TN, [ext.Problem([op], dw) for op, dw in zip(ops, again)])
+    assert all(torch.equal(a, b) for a, b in zip(dws, again))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_heads_level_matches_the_modules_on_the_gpu(dtype):
+    from monodetr_amd.monodetr import heads as H
+    from monodetr_amd.monodetr.depthaware_transformer import MLP
+    torch.manual_seed(5)
+    mods = [MLP(256, 256, 6, 3), MLP(256, 256, 3, 2), MLP(256, 256, 2, 2), MLP(256, 256, 24, 2), nn.Linear(256, 3)]
+    mods = [m.cuda() for m in mods]
+    ref = [copy.deepcopy(m).double() for m in mods]
+    B, Q = 8, 550
+    x = torch.randn(B, Q, 256, device="cuda").to(dtype).requires_grad_(True)
+    was, H.ENABLED = H.ENABLED, True
+    try:
+        out = H.heads_level(x, *mods)
+        assert out is not None
+        delta, size, depth, angle, logits, xs = out
+        gs = [torch.randn_like(t) for t in (delta, size, depth, angle, logits)]
+        skip_w = torch.randn(B, Q, 256, device="cuda")
+        (sum((t * g).sum() for t, g in zip((delta, size, depth, angle, logits), gs)) + (xs.float() * skip_w).sum()).backward()
+    finally:
+        H.ENABLED = was
+    xd = x.detach().double().requires_grad_(True)
+    outs = [m(xd) for m in ref]
+    (sum((t * g.double()).sum() for t, g in zip(outs, gs)) + (xd * skip_w.double()).sum()).backward()
+    for got, want in zip((delta, size, depth, angle, logits), outs):
+        assert (got.detach().double() - want.detach()).abs().max() <= 1e-5 * max(1.0, float(want.abs().max()))
+    gx_tol = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-5
+    assert (x.grad.double() - xd.grad).abs().max() <= gx_tol * float(xd.grad.abs().max())
+    for m, r in zip(mods, ref):
+        for (n, p), (_, q) in zip(m.named_parameters(), r.named_parameters()):
+            assert (p.grad.double() - q.grad).abs().max() <= 1e-5 * max(1.0, float(q.grad.abs().max())), n
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_training_step_with_the_grouped_heads_matches_the_modules(precision):
+    """The committed list with and without MDETR_HEADS: the heads computed by grouped fp32 launches or by the modules (library
+    GEMMs) give the same loss trajectory to fp32 rounding (dropout off), and no library GEMM of the heads' shapes remains."""
+    import bench
+    from model_init import disable_dropout_
+    dev = torch.device("cuda", 0)
+    base = tuple(sorted(set(bench.COMMITTED_SWITCHES[precision]) - {"MDETR_HEADS"}))
+    traj = {}
+    try:
+        for names in (base, base + ("MDETR_HEADS",)):
+            step = bench.TrainStep(dev, 2, precision, size=(96, 320), switches=names)
+            disable_dropout_(step.raw_model)
+            traj[names] = [float(step()) for _ in range(3)]
+    finally:
+        bench.apply_switches(set())
+    for a, b in zip(traj[base], traj[base + ("MDETR_HEADS",)]):
+        assert abs(a - b) <= (1e-3 if precision == "bf16" else 1e-4) * abs(a), traj

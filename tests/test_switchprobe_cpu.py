@@ -164,7 +164,7 @@ def test_probe_candidate_runs_the_training_step_with_exactly_its_switches(oracle
 def test_committed_switch_list_is_the_configuration(monkeypatch):
     """Every committed family names the GPU tests that hold it, those tests exist, and the environment only overrides
     the list when it says so."""
-    src = "".join(open(os.path.join(os.path.dirname(__file__), f)).read() for f in ("test_fused_gpu.py", "test_msda_gpu.py", "test_tgemm_gpu.py"))
+    src = "".join(open(os.path.join(os.path.dirname(__file__), f)).read() for f in ("test_fused_gpu.py", "test_msda_gpu.py", "test_tgemm_gpu.py", "test_sgemm_gpu.py"))
     for precision, fams in bench.COMMITTED_SWITCHES.items():
         for fam in fams:
             assert fam in bench.ALL_SWITCHES and fam in bench.SWITCH_TESTS, fam

@@ -129,6 +129,8 @@ def test_backward_pass_cut_at_the_encoders_last_msda_launch_gives_the_same_gradi
         images = images.to(dev).to(torch.bfloat16 if precision == "bf16" else torch.float32).contiguous(memory_format=torch.channels_last)
         batch = (images, calibs.to(dev), t['img_size'].to(dev), {k: t[k].to(dev) for k in TARGET_KEYS})      # (`run()` moves them)
         it._forward_backward(batch)
+        again = {n: p.grad.detach().float().clone() for n, p in it.raw_model.named_parameters() if p.grad is not None}
+        it._forward_backward(batch)
         want = {n: p.grad.detach().float().clone() for n, p in it.raw_model.named_parameters() if p.grad is not None}
         total = it._forward_backward(batch, cut="msda")
         cuts = [tuple(td.shape) for _, td in it._boundary]
@@ -146,12 +148,15 @@ def test_backward_pass_cut_at_the_encoders_last_msda_launch_gives_the_same_gradi
         #  bf16 evaluations of a zero differ by 10 % of nothing)
         floor = 1e-4 * max(w.norm().item() for w in want.values())
         worst, worst_name = max((((got[n] - want[n]).norm() / want[n].norm().clamp_min(floor)).item(), n) for n in want)
-        print("worst relative difference of a parameter gradient, cut vs uncut backward pass: %.3g (%s)" % (worst, worst_name))
+        # (the uncut pass against ITSELF: what the libraries' atomically accumulated fp32 kernels leave undetermined from run to run)
+        spread, spread_name = max((((again[n] - want[n]).norm() / want[n].norm().clamp_min(floor)).item(), n) for n in want)
+        print("worst relative difference of a parameter gradient, cut vs uncut backward pass: %.3g (%s); uncut vs uncut: %.3g (%s)"
+              % (worst, worst_name, spread, spread_name))
         # the cut changes the ORDER in which a pyramid level's gradients (depth predictor | encoder) and the residual stream's
         # meet -- (a + b) + c against a + (b + c).  fp32: rounding-level agreement (bar 1e-5).  bf16: parameter gradients agree
         # to bf16 rounding, measured 0 .. 2.3e-3 (bar: two roundings, 2^-7).  The exact statement (fp64, bit for bit) is
         # tests/test_graph_cut_cpu.py
-        assert worst <= (1e-5 if precision == "fp32" else 2.0 ** -7), (worst, worst_name)
+        assert worst <= (max(1e-5, 4.0 * spread) if precision == "fp32" else 2.0 ** -7), (worst, worst_name, spread, spread_name)
     finally:
         bench.apply_switches(set())
 
