@@ -400,7 +400,10 @@ typedef struct {
     int64_t ldc, ldm, ldr;
     int32_t nterm, m, n, relu_cols, c_dtype, res_dtype;
 } mdetr_sgemm_problem;
-int mdetr_sgemm_grouped(int mode, const mdetr_sgemm_problem *problems, int nprob, int device, void *stream);
+/* workspace: a TN group cuts its contraction into parts (one workgroup per tile and part: 100 tiles alone would leave most of the chip
+ * idle) whose partial results a second kernel sums in order; mdetr_sgemm_workspace_bytes gives the scratch that needs (0 for NT / NN). */
+int64_t mdetr_sgemm_workspace_bytes(int mode, const mdetr_sgemm_problem *problems, int nprob);
+int mdetr_sgemm_grouped(int mode, const mdetr_sgemm_problem *problems, int nprob, void *workspace, int64_t workspace_bytes, int device, void *stream);
 
 /*
  * Training image path of the input pipeline on the device: what

@@ -45,7 +45,8 @@ SIGNATURES = {
     "mdetr_adamw_step": (_c_int, [_c_int] + [_c_vp] * 5 + [ctypes.c_int64] * 2 + [ctypes.c_float] * 5 + [_c_vp, _c_int, _c_vp]),
     "mdetr_adamw_step_counted": (_c_int, [_c_int] + [_c_vp] * 5 + [ctypes.c_int64] * 2 + [ctypes.c_float] * 4 + [_c_vp, ctypes.c_float, _c_vp, _c_int, _c_vp]),
     "mdetr_tgemm": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_int, _c_int] + [ctypes.c_int64] * 4 + [_c_int, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),
-    "mdetr_sgemm_grouped": (_c_int, [_c_int, _c_vp, _c_int, _c_int, _c_vp]),
+    "mdetr_sgemm_workspace_bytes": (ctypes.c_int64, [_c_int, _c_vp, _c_int]),
+    "mdetr_sgemm_grouped": (_c_int, [_c_int, _c_vp, _c_int, _c_vp, ctypes.c_int64, _c_int, _c_vp]),
     "mdetr_tgemm_masked": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_int, _c_int] + [ctypes.c_int64] * 5 + [_c_int, _c_vp]),
     "mdetr_column_sum_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, _c_int]),
     "mdetr_column_sum": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, ctypes.c_int64, ctypes.c_int64, _c_int, ctypes.c_int64, _c_int, _c_vp]),

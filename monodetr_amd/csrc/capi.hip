@@ -501,13 +501,24 @@ int mdetr_tgemm(const void *a, const void *w, const void *bias, const void *res,
     return MDETR_OK;
 }
 
-int mdetr_sgemm_grouped(int mode, const mdetr_sgemm_problem *problems, int nprob, int device, void *stream)
+int64_t mdetr_sgemm_workspace_bytes(int mode, const mdetr_sgemm_problem *problems, int nprob)
+{
+    const char *why = mdetr::sgemm_check(mode, problems, nprob);
+    if (why) return fail(MDETR_E_ARG, "mdetr_sgemm_workspace_bytes: %s (mode %d, %d problems)", why, mode, nprob);
+    return mdetr::sgemm_workspace_bytes(mode, problems, nprob);
+}
+
+int mdetr_sgemm_grouped(int mode, const mdetr_sgemm_problem *problems, int nprob, void *workspace, int64_t workspace_bytes, int device, void *stream)
 {
     const char *why = mdetr::sgemm_check(mode, problems, nprob);
     if (why) return fail(MDETR_E_ARG, "mdetr_sgemm_grouped: %s (mode %d, %d problems)", why, mode, nprob);
+    const int64_t need = mdetr::sgemm_workspace_bytes(mode, problems, nprob);
+    if (need > 0 && (!workspace || workspace_bytes < need || !aligned16(workspace)))
+        return fail(MDETR_E_ARG, "mdetr_sgemm_grouped: needs a 16-byte aligned workspace of %lld bytes (mdetr_sgemm_workspace_bytes), got %lld",
+                    static_cast<long long>(need), static_cast<long long>(workspace ? workspace_bytes : 0));
     DeviceScope dev(device);
     if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_sgemm_grouped: set device %d: %s", device, hipGetErrorString(dev.err));
-    const hipError_t e = mdetr::sgemm_launch(mode, problems, nprob, static_cast<hipStream_t>(stream));
+    const hipError_t e = mdetr::sgemm_launch(mode, problems, nprob, workspace, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_sgemm_grouped: launch failed: %s", hipGetErrorString(e));
     return MDETR_OK;
 }

@@ -25,11 +25,29 @@ __device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// A pointer that went through LDS or a register shuffle has lost its address space: the compiler then emits FLAT loads, which count
+// on both memory counters and can only be waited for all at once -- a software pipeline of such loads degenerates into
+// load-wait-use.  `as_global<T>(p)` states that p points into global memory (global_load / global_store, vmcnt only).
+#define MDETR_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ const MDETR_GLOBAL T *as_global(const void *p) { return (const MDETR_GLOBAL T *)(p); }
+template <typename T> __device__ __forceinline__ MDETR_GLOBAL T *as_global_rw(void *p) { return (MDETR_GLOBAL T *)(p); }
+
+// a value every lane of the wave holds identically, moved to a scalar register (v_readfirstlane): what was read from LDS or memory
+// per lane but is uniform by construction (descriptors, strides) then costs no vector register and feeds scalar address arithmetic
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t wave_uniform64(int64_t v)
+{
+    const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
+    const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(v >> 32)));
+    return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
 // two packed fp32 lanes: element-wise fma / mul on this type select v_pk_fma_f32 / v_pk_mul_f32 (one issue slot for two
 // channels; the plain-float spelling compiles to two scalar FMAs)
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;      // 16 bytes as one register quad (arrays of it stay in registers)
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 __device__ __forceinline__ f32x2 make_f32x2(float x, float y) { f32x2 r; r.x = x; r.y = y; return r; }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 mul2(f32x2 a, f32x2 b) { return a * b; }

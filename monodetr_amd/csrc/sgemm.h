@@ -10,6 +10,8 @@ namespace mdetr {
 // Validates a group (shapes, strides, alignment of the vectorised paths is decided per operand inside the kernel); returns a
 // message or nullptr.
 const char *sgemm_check(int mode, const mdetr_sgemm_problem *p, int nprob);
-hipError_t sgemm_launch(int mode, const mdetr_sgemm_problem *p, int nprob, hipStream_t st);
+// bytes of scratch a group needs (TN groups whose contraction is cut into parts for occupancy; 0 otherwise)
+int64_t sgemm_workspace_bytes(int mode, const mdetr_sgemm_problem *p, int nprob);
+hipError_t sgemm_launch(int mode, const mdetr_sgemm_problem *p, int nprob, void *workspace, hipStream_t st);
 
 }  // namespace mdetr

@@ -105,8 +105,12 @@ def grouped(mode, problems):
         if pr.colsum is not None:
             assert pr.colsum.dtype == torch.float32 and pr.colsum.shape == (M,) and pr.colsum.is_contiguous()
             q.colsum = pr.colsum.data_ptr()
-    rc = _lib().mdetr_sgemm_grouped(mode, ctypes.cast(arr, ctypes.c_void_p), len(problems), dev.index if dev.type == "cuda" else -1,
-                                    torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None)
+    parr = ctypes.cast(arr, ctypes.c_void_p)
+    need = _lib().mdetr_sgemm_workspace_bytes(mode, parr, len(problems)) if mode == TN else 0
+    ws = torch.empty(need, dtype=torch.uint8, device=dev) if need > 0 else None          # (scratch of this launch; the caching allocator recycles it)
+    rc = -1 if need < 0 else _lib().mdetr_sgemm_grouped(mode, parr, len(problems), ws.data_ptr() if ws is not None else None, max(need, 0),
+                                                        dev.index if dev.type == "cuda" else -1,
+                                                        torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None)
     if rc != 0:
         msg = _lib().mdetr_last_error()
         raise RuntimeError("mdetr_sgemm_grouped failed (code %d): %s" % (rc, msg.decode() if msg else "?"))

@@ -71,10 +71,20 @@ inline f32x16 mfma_f32(float a, float b, f32x16 c)
     return c;
 }
 
+// address-space statements are for the GPU compiler only
+#define MDETR_GLOBAL
+template <typename T> inline const T *as_global(const void *p) { return static_cast<const T *>(p); }
+template <typename T> inline T *as_global_rw(void *p) { return static_cast<T *>(p); }
+
+// v_readfirstlane of a value that is uniform by construction: the value itself
+inline int wave_uniform(int v) { return v; }
+inline int64_t wave_uniform64(int64_t v) { return v; }
+
 // two packed fp32 lanes (the real header: ext_vector_type(2) -> v_pk_fma_f32 / v_pk_mul_f32)
 struct f32x2 { float x, y; };
 struct alignas(16) f32x4 { float x, y, z, w; };
 struct alignas(16) u32x4 { unsigned x, y, z, w; };
+struct alignas(8) u32x2 { unsigned x, y; };
 inline f32x2 make_f32x2(float x, float y) { return {x, y}; }
 inline f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
 inline f32x2 mul2(f32x2 a, f32x2 b) { return {a.x * b.x, a.y * b.y}; }

@@ -72,12 +72,21 @@ def test_heads_level_matches_the_modules_on_the_gpu(dtype):
     ref = [copy.deepcopy(m).double() for m in mods]
     B, Q = 8, 550
     x = torch.randn(B, Q, 256, device="cuda").to(dtype).requires_grad_(True)
+    # Rows with a hidden pre-activation within 2e-5 of zero get NO upstream gradient: the ReLU's derivative jumps there, an fp32
+    # evaluation may sit on the other side of the jump than float64 (4.5 M decisions per level: a handful do), and the comparison
+    # would measure that coin toss instead of the kernels (~2 % of the rows; the forward outputs are compared on every row)
+    with torch.no_grad():
+        xd0 = x.detach().double()
+        pre = [m.layers[0](xd0) for m in ref[:4]]
+        near = torch.stack([p.abs().amin(-1) for p in pre] + [ref[0].layers[1](pre[0].clamp(min=0)).abs().amin(-1)]).amin(0) < 2e-5
+        keep = (~near).float().unsqueeze(-1)
+    assert 0.0 < float(near.float().mean()) < 0.2
     was, H.ENABLED = H.ENABLED, True
     try:
         out = H.heads_level(x, *mods)
         assert out is not None
         delta, size, depth, angle, logits, xs = out
-        gs = [torch.randn_like(t) for t in (delta, size, depth, angle, logits)]
+        gs = [torch.randn_like(t) * keep for t in (delta, size, depth, angle, logits)]
         skip_w = torch.randn(B, Q, 256, device="cuda")
         (sum((t * g).sum() for t, g in zip((delta, size, depth, angle, logits), gs)) + (xs.float() * skip_w).sum()).backward()
     finally:
