@@ -511,6 +511,17 @@ int mdetr_column_sum(int dtype, const void *x, float *out, void *workspace, int6
                      int64_t rows, int cols, int64_t ld, int device, void *stream);
 /* The same reduction with the result written in `out_dtype` (MDETR_F32, or MDETR_BF16: the fp32 sum rounded once) -- the
  * gradient of a bf16 parameter then needs no separate cast launch. */
+/* Several chunk sums in ONE launch (ABI 9): out_i[cols_i] = sum over the chunks of part_i[chunks_i][cols_i] (fp32 partials of the
+ * split weight-gradient kernels), added in chunk order, rounded once to out_dtype -- what mdetr_column_sum_to computes for one such
+ * matrix, for any number of them (159 launches of the round-5 step become 4).  cols % 4 == 0, part 16-byte aligned, out 16-byte (fp32)
+ * / 8-byte (bf16) aligned. */
+typedef struct {
+    const float *part;
+    void *out;
+    int64_t cols;
+    int32_t chunks, out_dtype;
+} mdetr_chunk_job;
+int mdetr_chunk_sums(const mdetr_chunk_job *jobs, int njobs, int device, void *stream);
 int mdetr_column_sum_to(int dtype, const void *x, void *out, int out_dtype, void *workspace, int64_t workspace_bytes,
                         int64_t rows, int cols, int64_t ld, int device, void *stream);
 

@@ -44,17 +44,21 @@ def token_weight_gradient(x2, dy2, dtype, bias=False):
         raise RuntimeError("token_wgrad: unsupported problem")
     cols = N * K + (N if bias else 0)
     cuda = x2.is_cuda
-    if cuda and _backend is None:
+    from . import chunk_sums
+    batched = chunk_sums.deferring() and cols % 4 == 0 and dtype in (torch.float32, torch.bfloat16) and (cuda or chunk_sums._backend is not None)
+    if cuda and _backend is None and not batched:
         from . import _workspace as W_
         part = W_.get("conv_wgrad", x2.device, chunks * cols * 4).view(torch.float32)[:chunks * cols]
-    else:
+    else:                                            # (a deferred sum reads its partials later: they get a buffer of their own)
         part = torch.empty(chunks * cols, dtype=torch.float32, device=x2.device)
     rc = lib.mdetr_token_wgrad(x2.data_ptr(), dy2.data_ptr(), part.data_ptr(), part.numel(), T, K, N, 1 if bias else 0,
                                x2.device.index if cuda else -1, torch.cuda.current_stream(x2.device).cuda_stream if cuda else None)
     if rc != 0:
         _capi.check(rc, "mdetr_token_wgrad")
     part = part.view(chunks, cols)
-    if cuda and _backend is None:
+    if batched:
+        both = chunk_sums.chunk_sum(part, dtype)     # one launch for all the iteration's weight gradients (chunk_sums.flush)
+    elif cuda and _backend is None:
         from .colsum_ext import column_sum, supported as colsum_ok
         out_dt = dtype if dtype in (torch.float32, torch.bfloat16) else torch.float32
         both = (column_sum(part, out_dtype=out_dt) if colsum_ok(part) else part.sum(0)).to(dtype)
@@ -87,7 +91,9 @@ def weight_gradient(x, dy, k, stride, dtype=torch.bfloat16):
         raise RuntimeError("conv_wgrad: unsupported problem")
     cols = N * k * k * C
     cuda = x.is_cuda
-    if cuda and _backend is None:
+    from . import chunk_sums
+    batched = chunk_sums.deferring() and dtype in (torch.float32, torch.bfloat16) and (cuda or chunk_sums._backend is not None)
+    if cuda and _backend is None and not batched:
         from . import _workspace as W_
         part = W_.get("conv_wgrad", x.device, chunks * cols * 4).view(torch.float32)[:chunks * cols]
     else:
@@ -97,7 +103,9 @@ def weight_gradient(x, dy, k, stride, dtype=torch.bfloat16):
     if rc != 0:
         _capi.check(rc, "mdetr_conv_wgrad")
     part = part.view(chunks, cols)
-    if cuda and _backend is None:
+    if batched:
+        dw = chunk_sums.chunk_sum(part, dtype)
+    elif cuda and _backend is None:
         from .colsum_ext import column_sum, supported as colsum_ok
         out_dt = dtype if dtype in (torch.float32, torch.bfloat16) else torch.float32
         dw = (column_sum(part, out_dtype=out_dt) if colsum_ok(part) else part.sum(0)).to(dtype)

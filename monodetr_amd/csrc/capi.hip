@@ -580,6 +580,21 @@ int mdetr_column_sum_to(int dtype, const void *x, void *out, int out_dtype, void
     return column_sum_impl("mdetr_column_sum_to", dtype, x, out, out_dtype, workspace, workspace_bytes, rows, cols, ld, device, stream);
 }
 
+int mdetr_chunk_sums(const mdetr_chunk_job *jobs, int njobs, int device, void *stream)
+{
+    if (njobs == 0) return MDETR_OK;
+    const char *why = mdetr::chunk_sums_check(jobs, njobs);
+    if (why) return fail(MDETR_E_ARG, "mdetr_chunk_sums: %s (%d jobs)", why, njobs);
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_chunk_sums: set device %d: %s", device, hipGetErrorString(dev.err));
+    double kb = 0.0;
+    for (int i = 0; i < njobs; ++i) kb += (static_cast<double>(jobs[i].chunks) * jobs[i].cols * 4.0 + jobs[i].cols * (jobs[i].out_dtype == 2 ? 2.0 : 4.0)) / 1e3;
+    mdetr::ProfileScope prof(12, njobs, static_cast<hipStream_t>(stream), 0.0, kb);
+    const hipError_t e = mdetr::chunk_sums_launch(jobs, njobs, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_chunk_sums: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
 int mdetr_conv3x3_forward(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N,
                           int relu, int device, void *stream)
 {

@@ -113,7 +113,100 @@ void colsum_final_kernel(const float *__restrict__ partial, OT *__restrict__ out
     }
 }
 
+// ---- grouped chunk sums ------------------------------------------------------------------------------------------------------
+// Every split weight-gradient kernel (twgrad.hip, conv_wgrad.hip) leaves fp32 partials [chunks][cols] that have to be added in
+// a fixed order.  One launch of colsum_partial_kernel per weight gradient was 159 launches of ~6 us in the round-5 step, nearly
+// all of it fill and drain.  Here ONE launch adds the partials of up to kChunkJobs gradients: the jobs' tables travel as the
+// kernel's argument (copied to LDS once per workgroup), a workgroup owns 1 024 consecutive columns of one job, a thread four
+// of them; the chunks are added in order with four loads in flight.  Same sums, same order, same single rounding.
+constexpr int kChunkJobs = 48, kChunkCols = 4 * kThreads;
+struct ChunkJob {
+    const float *part;
+    void *out;
+    int64_t cols;
+    int chunks, out_bf16;
+    int block0, pad_;
+};
+struct ChunkArgs {
+    ChunkJob j[kChunkJobs];
+    int njobs, pad_;
+};
+
+__global__ __launch_bounds__(kThreads)
+void chunk_sums_kernel(const ChunkArgs a)
+{
+    __shared__ __attribute__((aligned(16))) ChunkArgs la;
+    {
+        const unsigned *src = reinterpret_cast<const unsigned *>(&a);
+        unsigned *dst = reinterpret_cast<unsigned *>(&la);
+        for (unsigned i = threadIdx.x; i < sizeof(ChunkArgs) / 4; i += kThreads) dst[i] = src[i];
+        __syncthreads();
+    }
+    int ji = 0;
+    for (int i = 1; i < la.njobs; ++i)
+        if (static_cast<int>(blockIdx.x) >= la.j[i].block0) ji = i;
+    const ChunkJob &J = la.j[ji];
+    const int64_t cols = J.cols, c = static_cast<int64_t>(static_cast<int>(blockIdx.x) - J.block0) * kChunkCols + 4 * threadIdx.x;
+    if (c >= cols) return;
+    const float *p = J.part + c;
+    const int chunks = J.chunks;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 3 < chunks; k += 4) {
+        const float4 v0 = *reinterpret_cast<const float4 *>(p + static_cast<int64_t>(k) * cols);
+        const float4 v1 = *reinterpret_cast<const float4 *>(p + static_cast<int64_t>(k + 1) * cols);
+        const float4 v2 = *reinterpret_cast<const float4 *>(p + static_cast<int64_t>(k + 2) * cols);
+        const float4 v3 = *reinterpret_cast<const float4 *>(p + static_cast<int64_t>(k + 3) * cols);
+        s.x = (((s.x + v0.x) + v1.x) + v2.x) + v3.x; s.y = (((s.y + v0.y) + v1.y) + v2.y) + v3.y;
+        s.z = (((s.z + v0.z) + v1.z) + v2.z) + v3.z; s.w = (((s.w + v0.w) + v1.w) + v2.w) + v3.w;
+    }
+    for (; k < chunks; ++k) {
+        const float4 v = *reinterpret_cast<const float4 *>(p + static_cast<int64_t>(k) * cols);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (J.out_bf16) {
+        __hip_bfloat16 *o = static_cast<__hip_bfloat16 *>(J.out) + c;
+        o[0] = __float2bfloat16(s.x); o[1] = __float2bfloat16(s.y); o[2] = __float2bfloat16(s.z); o[3] = __float2bfloat16(s.w);
+    } else {
+        *reinterpret_cast<float4 *>(static_cast<float *>(J.out) + c) = s;
+    }
+}
+
 }  // namespace
+
+const char *chunk_sums_check(const mdetr_chunk_job *jobs, int njobs)
+{
+    if (!jobs || njobs <= 0) return "no jobs";
+    for (int i = 0; i < njobs; ++i) {
+        const mdetr_chunk_job &q = jobs[i];
+        if (!q.part || !q.out || q.cols <= 0 || q.chunks <= 0) return "null pointer or empty job";
+        if (q.cols % 4 != 0 || (reinterpret_cast<uintptr_t>(q.part) & 15) != 0) return "cols must be a multiple of 4 and the partials 16-byte aligned";
+        if (q.out_dtype != 0 && q.out_dtype != 2) return "out_dtype must be MDETR_F32 or MDETR_BF16";
+        if ((reinterpret_cast<uintptr_t>(q.out) & (q.out_dtype == 2 ? 7 : 15)) != 0) return "result not aligned (16 bytes fp32, 8 bytes bf16)";
+        if ((q.cols + kChunkCols - 1) / kChunkCols > (1 << 24)) return "job too wide";
+    }
+    return nullptr;
+}
+
+hipError_t chunk_sums_launch(const mdetr_chunk_job *jobs, int njobs, hipStream_t st)
+{
+    for (int first = 0; first < njobs; first += kChunkJobs) {
+        ChunkArgs a;
+        const int n = njobs - first < kChunkJobs ? njobs - first : kChunkJobs;
+        int blocks = 0;
+        for (int i = 0; i < n; ++i) {
+            const mdetr_chunk_job &q = jobs[first + i];
+            ChunkJob &J = a.j[i];
+            J.part = q.part; J.out = q.out; J.cols = q.cols; J.chunks = q.chunks; J.out_bf16 = q.out_dtype == 2; J.block0 = blocks; J.pad_ = 0;
+            blocks += static_cast<int>((q.cols + kChunkCols - 1) / kChunkCols);
+        }
+        a.njobs = n; a.pad_ = 0;
+        hipLaunchKernelGGL(chunk_sums_kernel, dim3(blocks), dim3(kThreads), 0, st, a);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 
 int64_t colsum_workspace_bytes(int64_t rows, int cols)
 {

@@ -171,15 +171,24 @@ class TrainIteration:
     def _forward_backward(self, batch, cut=False):
         """Forward, criterion and backward pass (cut: see `_forward`)."""
         total = self._forward(batch, cut)
-        total.backward()
+        self._backward(total)
         return total
+
+    @staticmethod
+    def _backward(total):
+        """loss.backward() with the chunk sums of the split weight-gradient kernels batched into one launch (chunk_sums.py)."""
+        from .. import chunk_sums
+        with chunk_sums.deferred():
+            total.backward()
 
     def _backward_backbone(self):
         """The second part of a cut backward pass: from the gradients that arrived at the pyramid levels down through the backbone."""
         pairs = [(t, td.grad) for t, td in (self._boundary or ()) if td.grad is not None]
         self._boundary = None
         if pairs:
-            torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
+            from .. import chunk_sums
+            with chunk_sums.deferred():
+                torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
 
     def _with_grad(self, exclude=()):
         seen = {id(p) for p in exclude}
@@ -304,7 +313,7 @@ class TrainIteration:
                     self.loss = self._forward(self.static)
                 graph_tail = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph_tail, stream=side, pool=graph.pool(), **mode):
-                    self.loss.backward()
+                    self._backward(self.loss)
                     self.optimizer.step()
             elif not two:
                 with torch.cuda.graph(graph, stream=side, **mode):  # same stream as the warm-up: the AccumulateGrad nodes are bound to it

@@ -83,6 +83,8 @@ class _FoldAll(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
+        from .. import chunk_sums
+        chunk_sums.flush()                           # (see _FoldKernel.backward)
         grads = [g if g is not None else torch.zeros_like(w, dtype=ctx.wdtype) for g, w in zip(grads, ctx.like)]
         if grads[0].dtype != ctx.wdtype or any(g.dtype != ctx.wdtype for g in grads):
             wide = [torch.empty_like(w) for w in ctx.like]
@@ -112,7 +114,8 @@ class _FoldKernel(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
-        from .. import wfold_ext
+        from .. import chunk_sums, wfold_ext
+        chunk_sums.flush()                           # the folded weights' gradients may be registered chunk sums: they are READ here
         like = ctx.like
         grads = [g if g is not None else torch.zeros_like(w, dtype=torch.bfloat16) for g, w in zip(grads[:len(like)], like)]
         if wfold_ext.grads_supported(grads, like):

@@ -16,7 +16,7 @@ from torch import nn
 
 from .. import colsum_ext, small_wgrad_ext
 
-_MIN_TOKENS = 4096
+_MIN_TOKENS = 4096        # (2 048, which would hand layer4 to csrc/tgemm.hip too, measured no different: profiles/r06k_)
 # MDETR_GEMM_RELU=1: "linear -> ReLU" as one library GEMM with the RELU_BIAS epilogue (torch._addmm_activation ->
 # hipBLASLt) instead of a GEMM and an elementwise pass.  On the committed list (kernel_families.py); the bf16 step takes csrc/tgemm.hip's epilogue instead.
 _GEMM_RELU = os.environ.get("MDETR_GEMM_RELU") == "1"
@@ -105,6 +105,8 @@ def _weight_bias_grads(x2, dy2, weight, need_w, need_b, bias_dtype=None, out_dty
     dt = out_dtype if out_dtype is not None else weight.dtype
     if need_b and bias_dtype is not None and bias_dtype != dt:
         dw, db = _weight_bias_grads(x2, dy2, weight, need_w, True, out_dtype=torch.float32)
+        from .. import chunk_sums
+        chunk_sums.flush()                           # (the conversions below READ what may be a registered, not yet computed chunk sum)
         return (dw.to(dt) if dw is not None else None), db.to(bias_dtype)
     dw = db = None
     T = x2.shape[0]
@@ -349,6 +351,8 @@ class _SplitRows(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
         tail, dtype, device = ctx.meta
+        from .. import chunk_sums
+        chunk_sums.flush()                           # the blocks' gradients are read by the concatenation: registered chunk sums first
         parts = [g if g is not None else torch.zeros((n,) + tuple(tail), dtype=dtype, device=device) for g, n in zip(grads, ctx.sizes)]
         return (torch.cat(parts, 0),) + (None,) * len(ctx.sizes)
 

@@ -50,3 +50,49 @@ def test_column_sum_written_as_bf16_is_the_rounded_fp32_sum(dtype, shape):
     f32 = column_sum(x)
     b16 = column_sum(x, torch.bfloat16)
     assert b16.dtype == torch.bfloat16 and torch.equal(b16, f32.to(torch.bfloat16))
+
+
+def test_chunk_sums_grouped_launch_equals_the_single_launches():
+    """mdetr_chunk_sums vs mdetr_column_sum_to on the partials' shapes of the step (chunks x (N C + N) fp32): same order, same bits."""
+    from monodetr_amd import chunk_sums
+    from monodetr_amd.colsum_ext import column_sum
+    torch.manual_seed(3)
+    shapes = [(128, 65792), (64, 147456), (32, 1024 * 256 + 1024), (8, 2048 * 512), (1, 1028)] + [(16 + i, 256 * 64 + 64) for i in range(60)]
+    parts = [torch.randn(c, n, device="cuda") for c, n in shapes]
+    was, chunk_sums.ENABLED = chunk_sums.ENABLED, True
+    try:
+        with chunk_sums.deferred():
+            outs = [chunk_sums.chunk_sum(p, torch.bfloat16 if i % 2 else torch.float32) for i, p in enumerate(parts)]
+        for i, (o, p) in enumerate(zip(outs, parts)):
+            ref = p[0].clone()
+            for k in range(1, p.shape[0]):
+                ref += p[k]
+            assert torch.equal(o, ref.to(o.dtype)), i
+            assert (o.double() - p.double().sum(0)).abs().max() <= (2.0 ** -7 if o.dtype == torch.bfloat16 else 1e-4) * p.double().sum(0).abs().max()
+    finally:
+        chunk_sums.ENABLED = was
+
+
+def test_deferred_chunk_sums_give_the_same_gradients_as_immediate_ones():
+    """One backward pass of the whole model (bf16 committed kernels, dropout off) with the chunk sums batched (MDETR_CHUNK_SUMS) and
+    with every sum launched on the spot: EVERY parameter gradient bit-identical.  A consumer inside the backward pass that read a
+    registered sum before its flush would show up here as garbage in that parameter (and everything upstream of it)."""
+    import bench
+    from model_init import disable_dropout_
+    dev = torch.device("cuda", 0)
+    base = tuple(sorted(set(bench.COMMITTED_SWITCHES["bf16"]) - {"MDETR_CHUNK_SUMS"}))
+    grads = {}
+    try:
+        for names in (base, base + ("MDETR_CHUNK_SUMS",)):
+            step = bench.TrainStep(dev, 2, "bf16", size=(192, 640), switches=names)
+            disable_dropout_(step.raw_model)
+            step._forward_backward(step.inputs)
+            torch.cuda.synchronize()
+            grads[names] = {n: p.grad.detach().clone() for n, p in step.raw_model.named_parameters() if p.grad is not None}
+            del step
+    finally:
+        bench.apply_switches(set())
+    a, b = grads[base], grads[base + ("MDETR_CHUNK_SUMS",)]
+    assert set(a) == set(b) and len(a) > 300
+    bad = [n for n in a if not torch.equal(a[n], b[n])]
+    assert not bad, bad[:8]

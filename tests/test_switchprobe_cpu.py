@@ -27,7 +27,7 @@ def clean_env(monkeypatch):
 def test_candidate_sets():
     bf = sp.probe_configs("bf16")
     assert bf[0] == [] and set(bf[-1]) == set(bench.AUTOTUNE_SWITCHES) and all(set(a) < set(b) for a, b in zip(bf, bf[1:]))   # nested
-    assert not {"MDETR_TGEMM", "MDETR_WFOLD", "MDETR_RELU_PREMASK", "MDETR_MSDA_BF16", "MDETR_CONV3X3"} & set(sum(sp.probe_configs("fp32"), []))                          # bf16-body kernels
+    assert not {"MDETR_TGEMM", "MDETR_WFOLD", "MDETR_RELU_PREMASK", "MDETR_MSDA_BF16", "MDETR_CONV3X3", "MDETR_CHUNK_SUMS"} & set(sum(sp.probe_configs("fp32"), []))                          # bf16-body kernels
     # the roofline accounting follows the operator's element types
     f32, mixed = bench.msda_algorithmic_bytes(8, 10200, True), bench.msda_algorithmic_bytes(8, 10200, True, mixed=True)
     assert f32 - mixed == 2 * 8 * 10200 * 8 * 32 * 2                                        # value and grad_out at half width
@@ -164,7 +164,7 @@ def test_probe_candidate_runs_the_training_step_with_exactly_its_switches(oracle
 def test_committed_switch_list_is_the_configuration(monkeypatch):
     """Every committed family names the GPU tests that hold it, those tests exist, and the environment only overrides
     the list when it says so."""
-    src = "".join(open(os.path.join(os.path.dirname(__file__), f)).read() for f in ("test_fused_gpu.py", "test_msda_gpu.py", "test_tgemm_gpu.py", "test_sgemm_gpu.py"))
+    src = "".join(open(os.path.join(os.path.dirname(__file__), f)).read() for f in ("test_fused_gpu.py", "test_msda_gpu.py", "test_tgemm_gpu.py", "test_sgemm_gpu.py", "test_colsum_gpu.py"))
     for precision, fams in bench.COMMITTED_SWITCHES.items():
         for fam in fams:
             assert fam in bench.ALL_SWITCHES and fam in bench.SWITCH_TESTS, fam
