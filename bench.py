@@ -483,7 +483,7 @@ FAMILY_PATTERNS = (      # (family, substrings of the kernel name, profile kinds
     ("convolutions", ("conv3x3_kernel", "conv_taps", "conv_dgrad4", "conv_stem", "conv_wgrad_kernel", "maxpool3x3s2", "decimate"), (9,)),
     ("fp32_matrix_products", ("sgemm_",), (21,)),        # the fp32 prediction heads (csrc/sgemm.hip): priced against the f32-input MFMA peak
     ("small_weight_gradient", ("small_wgrad",), (16,)),
-    ("column_sums", ("colsum",), (12,)),
+    ("column_sums", ("colsum", "chunk_sums"), (12,)),
     ("residual_layernorm", ("add_ln",), (13,)),
     ("bias_activation_tails", ("bias_act",), (14,)),
     ("group_norm", ("gn_fwd", "gn_bwd"), (15,)),

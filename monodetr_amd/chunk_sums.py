@@ -21,6 +21,11 @@ from . import _capi
 
 # MDETR_CHUNK_SUMS=1 (kernel_families decides): batch the sums; off = every sum its own launch, as in round 5
 ENABLED = os.environ.get("MDETR_CHUNK_SUMS") == "1"
+# tests: a registered result is filled with NaN until its flush, so that anything reading it too early shows (a recycled buffer
+# otherwise tends to hold last iteration's -- plausible -- values)
+POISON = False
+# tests: every sum at once, through the same kernel (the reference the batched results must equal bit for bit)
+IMMEDIATE = False
 _backend = None               # tests substitute the CPU emulation of the same kernel source (tests/native_emul.py)
 _lock = threading.RLock()     # (registrations come from autograd's device thread, flush() from either)
 _depth = 0
@@ -60,7 +65,9 @@ def chunk_sum(part, out_dtype=torch.float32):
         raise RuntimeError("chunk_sum: needs contiguous fp32 partials [chunks, cols], cols a multiple of 4, 16-byte aligned")
     out = torch.empty(part.shape[1], dtype=out_dtype, device=part.device)
     with _lock:
-        if ENABLED and _depth > 0:
+        if ENABLED and _depth > 0 and not IMMEDIATE:
+            if POISON:
+                out.fill_(float("nan"))
             _pending.append((part, out))
             return out
     _launch([(part, out)])

@@ -90,6 +90,26 @@ def mlp_rest(mlp, h):
     return mlp.layers[-1](x)
 
 
+class _SummedPair(torch.autograd.Function):
+    """([W1 + W2; W3 + W4], [b1 + b2; b3 + b4]): two pairs of projections that act on the same input, summed in weight space and
+    packed for one GEMM.  Backward: the packed gradient's two halves, each handed to BOTH members of its pair -- views, nothing is
+    computed.  (As plain `+` / `cat` the same gradient tensor reaches two AccumulateGrad nodes, the first of which has to clone it;
+    `chunk_sums.flush()` makes sure the values exist before anything downstream may read them.)"""
+
+    @staticmethod
+    def forward(ctx, w1, w2, w3, w4, b1, b2, b3, b4):
+        ctx.rows = w1.shape[0]
+        return torch.cat((w1 + w2, w3 + w4), 0), torch.cat((b1 + b2, b3 + b4), 0)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gw, gb):
+        from .. import chunk_sums
+        chunk_sums.flush()
+        n = ctx.rows
+        return gw[:n], gw[:n], gw[n:], gw[n:], gb[:n], gb[:n], gb[n:], gb[n:]
+
+
 class _LevelPos(torch.autograd.Function):
     """cat_l(flatten(pos_l) + level_embed[l]) along the token axis, as ``dtype`` (reference depthaware_transformer.py:215-218).
     The sine embeddings are constants; the only gradient is level_embed's, a sum over the batch and the level's tokens.  As
@@ -259,12 +279,10 @@ class DepthAwareDecoderLayer(nn.Module):
 
     def _self_attention_inputs(self, x):
         """q = (Wqc + Wqp) x + b, k = (Wkc + Wkp) x + b : the four projections of the reference
-        (:467-474) act on the same input, so they are summed in weight space -- 2 GEMMs, not 4."""
-        wq = self.sa_qcontent_proj.weight + self.sa_qpos_proj.weight
-        bq = self.sa_qcontent_proj.bias + self.sa_qpos_proj.bias
-        wk = self.sa_kcontent_proj.weight + self.sa_kpos_proj.weight
-        bk = self.sa_kcontent_proj.bias + self.sa_kpos_proj.bias
-        q, k = token_linear(x, torch.cat((wq, wk), 0), torch.cat((bq, bk), 0)).split(x.shape[-1], -1)
+        (:467-474) act on the same input, so they are summed in weight space -- ONE GEMM, not 4."""
+        w, b = _SummedPair.apply(self.sa_qcontent_proj.weight, self.sa_qpos_proj.weight, self.sa_kcontent_proj.weight, self.sa_kpos_proj.weight,
+                                 self.sa_qcontent_proj.bias, self.sa_qpos_proj.bias, self.sa_kcontent_proj.bias, self.sa_kpos_proj.bias)
+        q, k = token_linear(x, w, b).split(x.shape[-1], -1)
         return q, k
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,

@@ -74,25 +74,37 @@ def test_chunk_sums_grouped_launch_equals_the_single_launches():
 
 
 def test_deferred_chunk_sums_give_the_same_gradients_as_immediate_ones():
-    """One backward pass of the whole model (bf16 committed kernels, dropout off) with the chunk sums batched (MDETR_CHUNK_SUMS) and
-    with every sum launched on the spot: EVERY parameter gradient bit-identical.  A consumer inside the backward pass that read a
-    registered sum before its flush would show up here as garbage in that parameter (and everything upstream of it)."""
+    """One backward pass of the whole model (bf16 committed kernels, dropout off, the training shape, launched the way the product
+    launches its eager iterations: on the side stream) with the chunk sums batched, against every sum computed on the spot by the
+    same kernel.  In the batched run every registered result is filled with NaN until its flush (chunk_sums.POISON): a consumer
+    inside the backward pass that read a registered sum too early -- AccumulateGrad cloning a gradient that two parameters share,
+    a concatenation, a cast -- leaves NaN in that parameter.  (Not bit-for-bit: two runs of the bf16 step differ by a bf16 rounding
+    here and there, test_trainer_gpu.py measures that spread.)"""
     import bench
     from model_init import disable_dropout_
+    from monodetr_amd import chunk_sums
     dev = torch.device("cuda", 0)
-    base = tuple(sorted(set(bench.COMMITTED_SWITCHES["bf16"]) - {"MDETR_CHUNK_SUMS"}))
+    names = tuple(sorted(bench.COMMITTED_SWITCHES["bf16"]))
+    assert "MDETR_CHUNK_SUMS" in names
     grads = {}
     try:
-        for names in (base, base + ("MDETR_CHUNK_SUMS",)):
-            step = bench.TrainStep(dev, 2, "bf16", size=(192, 640), switches=names)
+        for mode in ("immediate", "deferred"):
+            chunk_sums.IMMEDIATE, chunk_sums.POISON = mode == "immediate", mode == "deferred"
+            step = bench.TrainStep(dev, 8, "bf16", size=(384, 1280), switches=names, graph=True)
             disable_dropout_(step.raw_model)
-            step._forward_backward(step.inputs)
+            step.optimizer.step = lambda *a, **k: None                   # gradients only
+            step._eager(step.inputs)
             torch.cuda.synchronize()
-            grads[names] = {n: p.grad.detach().clone() for n, p in step.raw_model.named_parameters() if p.grad is not None}
+            grads[mode] = {n: p.grad.detach().float().clone() for n, p in step.raw_model.named_parameters() if p.grad is not None}
             del step
     finally:
+        chunk_sums.IMMEDIATE = chunk_sums.POISON = False
         bench.apply_switches(set())
-    a, b = grads[base], grads[base + ("MDETR_CHUNK_SUMS",)]
+    a, b = grads["immediate"], grads["deferred"]
     assert set(a) == set(b) and len(a) > 300
-    bad = [n for n in a if not torch.equal(a[n], b[n])]
-    assert not bad, bad[:8]
+    assert not [n for n in b if not torch.isfinite(b[n]).all()], [n for n in b if not torch.isfinite(b[n]).all()][:8]
+    # (against the tensor's own size, but not below 1e-3 of the largest gradient: the key-projection biases of the decoder's self-
+    #  attention have gradients that cancel to ~0 -- softmax ignores a constant added to every key's logit)
+    floor = 1e-3 * max(float(t.abs().max()) for t in a.values())
+    worst = max((float((a[n] - b[n]).abs().max() / a[n].abs().max().clamp_min(floor)), n) for n in a)
+    assert worst[0] <= 2.0 ** -5, worst
