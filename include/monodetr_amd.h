@@ -511,6 +511,27 @@ int mdetr_column_sum(int dtype, const void *x, float *out, void *workspace, int6
                      int64_t rows, int cols, int64_t ld, int device, void *stream);
 /* The same reduction with the result written in `out_dtype` (MDETR_F32, or MDETR_BF16: the fp32 sum rounded once) -- the
  * gradient of a bf16 parameter then needs no separate cast launch. */
+/*
+ * What follows the prediction heads, per (decoder level, image, query), in one launch each way (ABI 9; csrc/head_tail.hip).  Replaces
+ * the elementwise chain of lib/models/monodetr/monodetr.py:226-253 -- inverse_sigmoid of the references, box = sigmoid(delta +
+ * reference), the geometric depth f H3d / h2d with its clamp, F.grid_sample of the weighted depth map at the (detached) 3-D centre, the
+ * three-way depth average -- and its backward nodes (~100 framework launches per iteration on [3, 8, 550, <= 6] tensors).
+ *   delta [L,B,Q,6], init_ref [B,Q,nd0] (nd0 = 2 or 6: refines the first nd0 components of level 0), inter_refs [L-1,B,Q,6] (levels >= 1),
+ *   size3d [L,B,Q,3] (component 0 = height), depth_reg [L,B,Q,2], depth_map [B,H,W], img_h [B], focal [B]   -- all fp32, dense
+ *   -> coord [L,B,Q,6], depth_ave [L,B,Q,2]
+ * backward: g_coord / g_depth (either may be NULL = zeros) -> g_delta, g_init_ref, g_size3d, g_depth_reg, g_map (NULL = not wanted).
+ * The map's gradient is computed per cell in a fixed order (no atomics).  mdetr_box_refine is the decoder's reference update between
+ * layers (depthaware_transformer.py:602-613, no gradient): out [rows,6] = sigmoid(delta [rows,6] + inverse_sigmoid(ref [rows,nd]) on
+ * the first nd components).
+ */
+int mdetr_box_refine(const float *delta, const float *ref, float *out, int64_t rows, int nd, int device, void *stream);
+int mdetr_head_tail_forward(const float *delta, const float *init_ref, const float *inter_refs, const float *size3d, const float *depth_reg,
+                            const float *depth_map, const float *img_h, const float *focal, float *coord, float *depth_ave,
+                            int L, int B, int Q, int nd0, int H, int W, int device, void *stream);
+int mdetr_head_tail_backward(const float *init_ref, const float *size3d, const float *depth_reg, const float *img_h, const float *focal,
+                             const float *coord, const float *g_coord, const float *g_depth, float *g_delta, float *g_init_ref,
+                             float *g_size3d, float *g_depth_reg, float *g_map, int L, int B, int Q, int nd0, int H, int W, int device, void *stream);
+
 /* Several chunk sums in ONE launch (ABI 9): out_i[cols_i] = sum over the chunks of part_i[chunks_i][cols_i] (fp32 partials of the
  * split weight-gradient kernels), added in chunk order, rounded once to out_dtype -- what mdetr_column_sum_to computes for one such
  * matrix, for any number of them (159 launches of the round-5 step become 4).  cols % 4 == 0, part 16-byte aligned, out 16-byte (fp32)

@@ -50,6 +50,9 @@ SIGNATURES = {
     "mdetr_tgemm_masked": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_int, _c_int] + [ctypes.c_int64] * 5 + [_c_int, _c_vp]),
     "mdetr_column_sum_workspace_bytes": (ctypes.c_int64, [ctypes.c_int64, _c_int]),
     "mdetr_column_sum": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, ctypes.c_int64, ctypes.c_int64, _c_int, ctypes.c_int64, _c_int, _c_vp]),
+    "mdetr_box_refine": (_c_int, [_c_vp] * 3 + [ctypes.c_int64, _c_int, _c_int, _c_vp]),
+    "mdetr_head_tail_forward": (_c_int, [_c_vp] * 10 + [_c_int] * 6 + [_c_int, _c_vp]),
+    "mdetr_head_tail_backward": (_c_int, [_c_vp] * 13 + [_c_int] * 6 + [_c_int, _c_vp]),
     "mdetr_chunk_sums": (_c_int, [_c_vp, _c_int, _c_int, _c_vp]),
     "mdetr_column_sum_to": (_c_int, [_c_int, _c_vp, _c_vp, _c_int, _c_vp, ctypes.c_int64, ctypes.c_int64, _c_int, ctypes.c_int64, _c_int, _c_vp]),
     "mdetr_add_layernorm_forward": (_c_int, [_c_int, _c_int] + [_c_vp] * 7 + [ctypes.c_int64, _c_int, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),

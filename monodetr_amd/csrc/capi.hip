@@ -31,6 +31,7 @@
 #include "rotate_iou.h"
 #include "tgemm.h"
 #include "sgemm.h"
+#include "head_tail.h"
 #include "twgrad.h"
 #include "msda.h"
 #include "msda_prologue.h"
@@ -578,6 +579,58 @@ int mdetr_column_sum_to(int dtype, const void *x, void *out, int out_dtype, void
                         int64_t rows, int cols, int64_t ld, int device, void *stream)
 {
     return column_sum_impl("mdetr_column_sum_to", dtype, x, out, out_dtype, workspace, workspace_bytes, rows, cols, ld, device, stream);
+}
+
+int mdetr_box_refine(const float *delta, const float *ref, float *out, int64_t rows, int nd, int device, void *stream)
+{
+    if (rows < 0 || (nd != 2 && nd != 6)) return fail(MDETR_E_ARG, "mdetr_box_refine: bad sizes rows=%lld nd=%d (2 or 6)", static_cast<long long>(rows), nd);
+    if (rows == 0) return MDETR_OK;
+    if (!delta || !ref || !out) return fail(MDETR_E_ARG, "mdetr_box_refine: null pointer");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_box_refine: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::box_refine_launch(delta, ref, out, rows, nd, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_box_refine: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+static int head_tail_dims(const char *who, int L, int B, int Q, int nd0, int H, int W, mdetr::HeadTailDims *d)
+{
+    if (L <= 0 || B <= 0 || Q <= 0 || H <= 0 || W <= 0 || (nd0 != 2 && nd0 != 6) || static_cast<int64_t>(L) * B * Q * 6 >= (1ll << 31))
+        return fail(MDETR_E_ARG, "%s: bad sizes L=%d B=%d Q=%d nd0=%d H=%d W=%d", who, L, B, Q, nd0, H, W);
+    d->L = L; d->B = B; d->Q = Q; d->nd0 = nd0; d->H = H; d->W = W;
+    return MDETR_OK;
+}
+
+int mdetr_head_tail_forward(const float *delta, const float *init_ref, const float *inter_refs, const float *size3d, const float *depth_reg,
+                            const float *depth_map, const float *img_h, const float *focal, float *coord, float *depth_ave,
+                            int L, int B, int Q, int nd0, int H, int W, int device, void *stream)
+{
+    mdetr::HeadTailDims d;
+    if (int rc = head_tail_dims("mdetr_head_tail_forward", L, B, Q, nd0, H, W, &d)) return rc;
+    if (!delta || !init_ref || (L > 1 && !inter_refs) || !size3d || !depth_reg || !depth_map || !img_h || !focal || !coord || !depth_ave)
+        return fail(MDETR_E_ARG, "mdetr_head_tail_forward: null pointer");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_head_tail_forward: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::head_tail_forward_launch(d, delta, init_ref, inter_refs, size3d, depth_reg, depth_map, img_h, focal, coord, depth_ave,
+                                                         static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_head_tail_forward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
+int mdetr_head_tail_backward(const float *init_ref, const float *size3d, const float *depth_reg, const float *img_h, const float *focal,
+                             const float *coord, const float *g_coord, const float *g_depth, float *g_delta, float *g_init_ref,
+                             float *g_size3d, float *g_depth_reg, float *g_map, int L, int B, int Q, int nd0, int H, int W, int device, void *stream)
+{
+    mdetr::HeadTailDims d;
+    if (int rc = head_tail_dims("mdetr_head_tail_backward", L, B, Q, nd0, H, W, &d)) return rc;
+    if (!init_ref || !size3d || !depth_reg || !img_h || !focal || !coord || !g_delta || !g_init_ref || !g_size3d || !g_depth_reg)
+        return fail(MDETR_E_ARG, "mdetr_head_tail_backward: null pointer");
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_head_tail_backward: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::head_tail_backward_launch(d, init_ref, size3d, depth_reg, img_h, focal, coord, g_coord, g_depth, g_delta, g_init_ref,
+                                                          g_size3d, g_depth_reg, g_map, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_head_tail_backward: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
 }
 
 int mdetr_chunk_sums(const mdetr_chunk_job *jobs, int njobs, int device, void *stream)

@@ -13,7 +13,7 @@ import os
 AUTOTUNE_SWITCHES = ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_MSDA_PROLOGUE", "MDETR_FUSED_LN", "MDETR_MSDA_BF16",
                      "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD",
                      "MDETR_CONV_STRIDED", "MDETR_CONV_WGRAD", "MDETR_CONV_STEM", "MDETR_TGEMM", "MDETR_WFOLD", "MDETR_RELU_PREMASK",
-                     "MDETR_HEADS", "MDETR_CHUNK_SUMS")
+                     "MDETR_HEADS", "MDETR_CHUNK_SUMS", "MDETR_HEAD_TAIL")
 ALL_SWITCHES = AUTOTUNE_SWITCHES
 # The measured configuration.  family -> the GPU tests that hold it to the default path / the framework operators
 # (all in tests/test_fused_gpu.py unless a file is named); a family without green tests is not listed.
@@ -34,6 +34,7 @@ SWITCH_TESTS = {
     "MDETR_WFOLD": "test_fold_kernel_*, test_training_step_with_the_fold_kernel_*",
     "MDETR_RELU_PREMASK": "test_tgemm_gpu.py::test_masked_input_gradient_*, test_tgemm_gpu.py::test_bottleneck_stage_with_premasked_relu_*",
     "MDETR_HEADS": "test_sgemm_gpu.py::test_sgemm_*, test_sgemm_gpu.py::test_heads_level_*, test_training_step_with_the_grouped_heads_*",
+    "MDETR_HEAD_TAIL": "test_sgemm_gpu.py::test_head_tail_*, test_sgemm_gpu.py::test_training_step_with_the_head_tail_*",
     "MDETR_CHUNK_SUMS": "test_colsum_gpu.py::test_chunk_sums_*, test_colsum_gpu.py::test_deferred_chunk_sums_*",
     "MDETR_CONV3X3": "test_conv3x3_kernel_matches_the_library_convolution, test_training_step_with_the_conv3x3_kernel_*, test_conv3x3_module_with_a_trainable_bias_*",
 }
@@ -55,9 +56,10 @@ COMMITTED_SWITCHES = {
     "bf16": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE", "MDETR_MSDA_BF16",
              "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_CONV3X3", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD",
              "MDETR_CONV_WGRAD", "MDETR_CONV_STRIDED", "MDETR_CONV_STEM", "MDETR_TGEMM", "MDETR_WFOLD", "MDETR_RELU_PREMASK", "MDETR_HEADS",
-             "MDETR_CHUNK_SUMS"),
+             "MDETR_CHUNK_SUMS", "MDETR_HEAD_TAIL"),
     "fp32": ("MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE",
-             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD", "MDETR_HEADS"),
+             "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD", "MDETR_HEADS",
+             "MDETR_HEAD_TAIL"),
 }
 COMMITTED_SWITCHES["bf16-autocast"] = COMMITTED_SWITCHES["fp32"]
 
@@ -77,8 +79,9 @@ def env_switches():
 def apply_switches(names):
     """Runtime equivalent of the environment switches for the module-level ones (the criterion's and the optimizer's
     are applied by TrainStep)."""
-    from monodetr_amd import chunk_sums
+    from monodetr_amd import chunk_sums, head_tail_ext
     chunk_sums.ENABLED = "MDETR_CHUNK_SUMS" in names
+    head_tail_ext.ENABLED = "MDETR_HEAD_TAIL" in names
     from monodetr_amd import add_ln_ext, bias_act_ext, conv3x3_ext, conv_stem_ext, conv_taps_ext, conv_wgrad_ext, group_norm_ext, small_wgrad_ext, wfold_ext
     from monodetr_amd.monodetr import heads, linear
     from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func

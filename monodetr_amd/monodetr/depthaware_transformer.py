@@ -24,6 +24,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
+from .. import head_tail_ext
 from ..add_ln_ext import residual_layernorm
 from . import _cut
 from ..utils.misc import inverse_sigmoid, no_padding
@@ -370,7 +371,10 @@ class DepthAwareDecoder(nn.Module):
                                      mlp_rest(cls, parts[4]) if isinstance(cls, MLP) else parts[4]))
             elif self.bbox_embed is not None:
                 delta = self.bbox_embed[lid](output)
-            if self.bbox_embed is not None:             # iterative refinement (:602-613)
+            if self.bbox_embed is not None and head_tail_ext.usable(delta, reference_points) and delta.shape[-1] == 6:
+                # iterative refinement (:602-613) as one launch: sigmoid(delta + inverse_sigmoid(reference)), no gradient
+                reference_points = head_tail_ext.box_refine(delta, reference_points)
+            elif self.bbox_embed is not None:           # iterative refinement (:602-613)
                 if nd == 6:
                     new_ref = (delta + inverse_sigmoid(reference_points)).sigmoid()
                 else:

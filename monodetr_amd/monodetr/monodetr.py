@@ -170,7 +170,6 @@ class MonoDETR(nn.Module):
         # Prediction heads (:222-262).  The per-level MLPs have their own weights; everything after them
         # is evaluated once on level-stacked [L, B, Q, .] tensors instead of once per decoder level.
         head_dtype = self.class_embed[0].weight.dtype          # heads stay fp32 even behind a bf16 body
-        hs = hs.to(head_dtype)
         L = hs.shape[0]
         weighted_depth = weighted_depth.to(head_dtype)
         calibs, img_sizes = calibs.to(head_dtype), img_sizes.to(head_dtype)
@@ -178,6 +177,21 @@ class MonoDETR(nn.Module):
         img_h = img_sizes[:, 1].view(1, -1, 1)
         # level 0 refines the initial reference, level l > 0 the reference left by level l-1 (:226-236).  A
         # 2-component reference only shifts (cx, cy): padded with zeros it adds nothing to (l, r, t, b)
+        head_out = self.depthaware_transformer.decoder.__dict__.get("head_outputs") or []
+        fused = len(head_out) == L                             # the decoder already evaluated the heads (fused first layers)
+        from .. import head_tail_ext
+        if fused and inter_references.shape[-1] == 6 and head_dtype == torch.float32 and \
+                head_tail_ext.usable(head_out[0][0], weighted_depth, calibs, img_sizes, inter_references_dim):
+            # everything between the heads' raw outputs and the predictions in one launch each way (csrc/head_tail.hip)
+            coord, depth_ave = head_tail_ext.head_tail(
+                torch.stack([head_out[lvl][0] for lvl in range(L)]), init_reference.to(head_dtype), inter_references[:L - 1],
+                inter_references_dim[:L], torch.stack([head_out[lvl][1] for lvl in range(L)]), weighted_depth, img_sizes[:, 1], calibs[:, 0, 0])
+            size3d = inter_references_dim[:L].to(head_dtype)
+            classes = torch.stack([head_out[lvl][3] for lvl in range(L)])
+            angles = torch.stack([head_out[lvl][2] for lvl in range(L)])
+            self.depthaware_transformer.decoder.__dict__["head_outputs"] = []
+            return self._outputs(classes, coord, size3d, angles, depth_ave, depth_logits)
+        hs = hs.to(head_dtype)
         first = inverse_sigmoid(init_reference.to(head_dtype))
         if first.shape[-1] == 2:
             first = F.pad(first, (0, 4))
@@ -185,8 +199,6 @@ class MonoDETR(nn.Module):
         if later.shape[-1] == 2:
             later = F.pad(later, (0, 4))
         reference = torch.cat((first[None], later), 0)
-        head_out = self.depthaware_transformer.decoder.__dict__.get("head_outputs") or []
-        fused = len(head_out) == L                             # the decoder already evaluated the heads (fused first layers)
         box = torch.stack([head_out[lvl][0] if fused else self.bbox_embed[lvl](hs[lvl]) for lvl in range(L)]) + reference
         coord = box.sigmoid()                                      # (cx, cy, l, r, t, b) of the 3D centre / 2D box
         size3d = inter_references_dim[:L].to(head_dtype)
@@ -206,6 +218,9 @@ class MonoDETR(nn.Module):
         angles = torch.stack([head_out[lvl][2] if fused else self.angle_embed[lvl](hs[lvl]) for lvl in range(L)])
         self.depthaware_transformer.decoder.__dict__["head_outputs"] = []     # do not keep the graph alive past this forward
 
+        return self._outputs(classes, coord, size3d, angles, depth_ave, depth_logits)
+
+    def _outputs(self, classes, coord, size3d, angles, depth_ave, depth_logits):
         out = {'pred_logits': classes[-1], 'pred_boxes': coord[-1], 'pred_3d_dim': size3d[-1],
                'pred_depth': depth_ave[-1], 'pred_angle': angles[-1], 'pred_depth_map_logits': depth_logits}
         if self.aux_loss:

@@ -33,7 +33,7 @@ def probe_configs(precision):
     loses nothing."""
     order = ["MDETR_FUSED_LOSSES", "MDETR_FUSED_ADAMW", "MDETR_FUSED_LN", "MDETR_MSDA_PROLOGUE", "MDETR_MSDA_BF16",
              "MDETR_FUSED_EPILOGUE", "MDETR_GEMM_RELU", "MDETR_GROUP_NORM", "MDETR_SMALL_WGRAD", "MDETR_CONV3X3", "MDETR_CONV_STRIDED", "MDETR_CONV_WGRAD",
-             "MDETR_CONV_STEM", "MDETR_TGEMM", "MDETR_WFOLD", "MDETR_RELU_PREMASK", "MDETR_HEADS", "MDETR_CHUNK_SUMS"]
+             "MDETR_CONV_STEM", "MDETR_TGEMM", "MDETR_WFOLD", "MDETR_RELU_PREMASK", "MDETR_HEADS", "MDETR_CHUNK_SUMS", "MDETR_HEAD_TAIL"]
     if precision != "bf16":
         order = [k for k in order if k not in ("MDETR_MSDA_BF16", "MDETR_CONV3X3", "MDETR_CONV_STRIDED", "MDETR_CONV_WGRAD", "MDETR_CONV_STEM", "MDETR_TGEMM", "MDETR_WFOLD", "MDETR_RELU_PREMASK", "MDETR_CHUNK_SUMS")]
     return [order[:i] for i in range(len(order) + 1)]

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(ROOT, "monodetr_amd", "csrc")
 SHIM = os.path.join(HERE, "native", "hipshim")
 OUT = os.path.join(HERE, "native", "_build", "libemul_asan.so" if os.environ.get("MDETR_EMUL_ASAN") == "1" else "libemul.so")
-KERNELS = ["capi", "bias_act", "decimate", "conv3x3", "conv_taps", "conv_stem", "conv_wgrad", "pair_losses", "ddn_loss", "adamw", "msda_prologue", "kitti_prep", "colsum", "group_norm", "small_wgrad", "tgemm", "sgemm", "twgrad", "wfold", "msda", "msda_tiled", "msda_fused", "msda_cpu", "lsa", "rotate_iou", "kitti_stats", "add_ln", "attn"]
+KERNELS = ["capi", "bias_act", "decimate", "conv3x3", "conv_taps", "conv_stem", "conv_wgrad", "pair_losses", "ddn_loss", "adamw", "msda_prologue", "kitti_prep", "colsum", "group_norm", "small_wgrad", "tgemm", "sgemm", "head_tail", "twgrad", "wfold", "msda", "msda_tiled", "msda_fused", "msda_cpu", "lsa", "rotate_iou", "kitti_stats", "add_ln", "attn"]
 
 _libs = {}
 

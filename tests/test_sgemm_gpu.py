@@ -121,3 +121,54 @@ def test_training_step_with_the_grouped_heads_matches_the_modules(precision):
         bench.apply_switches(set())
     for a, b in zip(traj[base], traj[base + ("MDETR_HEADS",)]):
         assert abs(a - b) <= (1e-3 if precision == "bf16" else 1e-4) * abs(a), traj
+
+
+def test_head_tail_kernels_match_the_framework_expression_on_the_gpu():
+    """csrc/head_tail.hip at the training shape (3 levels x 8 images x 550 queries, the 24 x 80 depth map) against
+    monodetr.py:226-253 written with the framework's operators in float64: values and all five gradients."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_head_tail_emulated_cpu import reference
+    from monodetr_amd import head_tail_ext as ext
+    torch.manual_seed(0)
+    L, B, Q, H, W = 3, 8, 550, 24, 80
+    dev = "cuda"
+    delta, init_ref, inter = torch.randn(L, B, Q, 6, device=dev), torch.rand(B, Q, 2, device=dev), torch.rand(L - 1, B, Q, 6, device=dev)
+    size3d, depth_reg, depth_map = torch.rand(L, B, Q, 3, device=dev) + 0.5, torch.randn(L, B, Q, 2, device=dev), torch.rand(B, H, W, device=dev) * 50
+    img_h, focal = torch.full((B,), 375.0, device=dev), torch.full((B,), 721.5, device=dev)
+    was, ext.ENABLED = ext.ENABLED, True
+    try:
+        leaves = [t.clone().requires_grad_(True) for t in (delta, init_ref, size3d, depth_reg, depth_map)]
+        coord, ave = ext.head_tail(leaves[0], leaves[1], inter, leaves[2], leaves[3], leaves[4], img_h, focal)
+        gc, ga = torch.randn_like(coord), torch.randn_like(ave)
+        ((coord * gc).sum() + (ave * ga).sum()).backward()
+        again = ext.head_tail(delta, init_ref, inter, size3d, depth_reg, depth_map, img_h, focal)
+        assert torch.equal(again[0], coord.detach()) and torch.equal(again[1], ave.detach())
+    finally:
+        ext.ENABLED = was
+    ref_leaves = [t.double().clone().requires_grad_(True) for t in (delta, init_ref, size3d, depth_reg, depth_map)]
+    rc, ra = reference(ref_leaves[0], ref_leaves[1], inter.double(), ref_leaves[2], ref_leaves[3], ref_leaves[4], img_h.double(), focal.double())
+    ((rc * gc.double()).sum() + (ra * ga.double()).sum()).backward()
+    assert (coord.double() - rc).abs().max() < 1e-6
+    assert ((ave.double() - ra).abs() / (1 + ra.abs())).max() < 1e-5
+    for name, a, b in zip(("delta", "init_ref", "size3d", "depth_reg", "depth_map"), leaves, ref_leaves):
+        assert ((a.grad.double() - b.grad).abs() / (1e-3 * b.grad.abs().max() + b.grad.abs())).max() < 2e-3, name
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_training_step_with_the_head_tail_kernels_matches_the_framework_operators(precision):
+    """The committed list with and without MDETR_HEAD_TAIL: the same loss trajectory to fp32 rounding (dropout off)."""
+    import bench
+    from model_init import disable_dropout_
+    dev = torch.device("cuda", 0)
+    base = tuple(sorted(set(bench.COMMITTED_SWITCHES[precision]) - {"MDETR_HEAD_TAIL"}))
+    traj = {}
+    try:
+        for names in (base, base + ("MDETR_HEAD_TAIL",)):
+            step = bench.TrainStep(dev, 2, precision, size=(96, 320), switches=names)
+            disable_dropout_(step.raw_model)
+            traj[names] = [float(step()) for _ in range(3)]
+    finally:
+        bench.apply_switches(set())
+    for a, b in zip(traj[base], traj[base + ("MDETR_HEAD_TAIL",)]):
+        assert abs(a - b) <= (1e-3 if precision == "bf16" else 1e-4) * abs(a), traj
