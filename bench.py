@@ -482,6 +482,7 @@ FAMILY_PATTERNS = (      # (family, substrings of the kernel name, profile kinds
     ("token_weight_gradient", ("twgrad_kernel", "conv_wgrad_kernel<1, 1>"), (11,)),
     ("convolutions", ("conv3x3_kernel", "conv_taps", "conv_dgrad4", "conv_stem", "conv_wgrad_kernel", "maxpool3x3s2", "decimate"), (9,)),
     ("fp32_matrix_products", ("sgemm_",), (21,)),        # the fp32 prediction heads (csrc/sgemm.hip): priced against the f32-input MFMA peak
+    ("head_arithmetic", ("head_tail", "box_refine"), ()),  # boxes / depths behind the heads, the decoder's reference update (csrc/head_tail.hip)
     ("small_weight_gradient", ("small_wgrad",), (16,)),
     ("column_sums", ("colsum", "chunk_sums"), (12,)),
     ("residual_layernorm", ("add_ln",), (13,)),

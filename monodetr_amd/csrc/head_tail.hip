@@ -127,25 +127,38 @@ void head_tail_bwd_kernel(const HeadTailDims d, const float *__restrict__ init_r
     }
 }
 
-// d loss / d map[b, y, x] = sum over the image's (level, query) pairs of g_depth_0 / 3 * (the pair's bilinear weight on this cell),
-// one thread per cell, pairs visited in (level, query) order
+// d loss / d map[b, y, x] = sum over the image's (level, query) pairs of g_depth_0 / 3 * (the pair's bilinear weight on this cell).
+// A workgroup owns 256 cells of one image; the image's pairs -- footprint corner, fractions, gradient -- are worked out ONCE per
+// workgroup into LDS in batches of 256, then every cell's thread walks the batch (broadcast reads) in (level, query) order:
+// deterministic, no atomics.  (Per cell and pair from global memory, the first version, took longer than the two other kernels together.)
 __global__ __launch_bounds__(256)
 void head_tail_map_grad_kernel(const HeadTailDims d, const float *__restrict__ coord, const float *__restrict__ g_depth, float *__restrict__ g_map)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x, HW = d.H * d.W;
-    if (i >= d.B * HW) return;
-    const int b = i / HW, cell = i - b * HW, y = cell / d.W, x = cell - y * d.W;
+    __shared__ int px[256], py[256];
+    __shared__ float pwx[256], pwy[256], pg[256];
+    const int HW = d.H * d.W, per_image = (HW + 255) / 256;
+    const int b = blockIdx.x / per_image, cell = (blockIdx.x - b * per_image) * 256 + threadIdx.x;
+    const int y = cell / d.W, x = cell - y * d.W;
+    const int pairs = d.L * d.Q;
     float acc = 0.f;
-    for (int l = 0; g_depth && l < d.L; ++l) {
-        for (int q = 0; q < d.Q; ++q) {
-            const int j = (l * d.B + b) * d.Q + q;
+    for (int p0 = 0; g_depth && p0 < pairs; p0 += 256) {
+        const int p = p0 + threadIdx.x;
+        __syncthreads();
+        if (p < pairs) {
+            const int l = p / d.Q, q = p - l * d.Q, j = (l * d.B + b) * d.Q + q;
             const Bilinear f = footprint(coord[j * 6], coord[j * 6 + 1], d.H, d.W);
-            const int dx = x - f.x0, dy = y - f.y0;
+            px[threadIdx.x] = f.x0; py[threadIdx.x] = f.y0; pwx[threadIdx.x] = f.wx; pwy[threadIdx.x] = f.wy;
+            pg[threadIdx.x] = g_depth[j * 2] / 3.f;
+        }
+        __syncthreads();
+        const int n = pairs - p0 < 256 ? pairs - p0 : 256;
+        for (int k = 0; k < n; ++k) {
+            const int dx = x - px[k], dy = y - py[k];
             if (dx < 0 || dx > 1 || dy < 0 || dy > 1) continue;
-            acc += g_depth[j * 2] / 3.f * (dx ? f.wx : 1.f - f.wx) * (dy ? f.wy : 1.f - f.wy);
+            acc += pg[k] * (dx ? pwx[k] : 1.f - pwx[k]) * (dy ? pwy[k] : 1.f - pwy[k]);
         }
     }
-    g_map[i] = acc;
+    if (cell < HW) g_map[b * HW + cell] = acc;
 }
 
 }  // namespace
@@ -180,8 +193,8 @@ hipError_t head_tail_backward_launch(const HeadTailDims &d, const float *init_re
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (g_map) {
-        const int cells = d.B * d.H * d.W;
-        hipLaunchKernelGGL(head_tail_map_grad_kernel, dim3((cells + 255) / 256), dim3(256), 0, st, d, coord, g_depth, g_map);      // (no g_depth: zeros)
+        const int blocks = d.B * ((d.H * d.W + 255) / 256);
+        hipLaunchKernelGGL(head_tail_map_grad_kernel, dim3(blocks), dim3(256), 0, st, d, coord, g_depth, g_map);      // (no g_depth: zeros)
         e = hipGetLastError();
     }
     return e;

@@ -150,7 +150,7 @@ def test_head_tail_kernels_match_the_framework_expression_on_the_gpu():
     rc, ra = reference(ref_leaves[0], ref_leaves[1], inter.double(), ref_leaves[2], ref_leaves[3], ref_leaves[4], img_h.double(), focal.double())
     ((rc * gc.double()).sum() + (ra * ga.double()).sum()).backward()
     assert (coord.double() - rc).abs().max() < 1e-6
-    assert ((ave.double() - ra).abs() / (1 + ra.abs())).max() < 1e-5
+    assert ((ave.double() - ra).abs() / (1 + ra.abs())).max() < 1e-4          # fp32 of 1 / (sigmoid + 1e-6) - 1 + f H / h2d (values up to ~1e3)
     for name, a, b in zip(("delta", "init_ref", "size3d", "depth_reg", "depth_map"), leaves, ref_leaves):
         assert ((a.grad.double() - b.grad).abs() / (1e-3 * b.grad.abs().max() + b.grad.abs())).max() < 2e-3, name
 
