@@ -565,10 +565,10 @@ def main():
                          "kernel selection, allocator pool growth, clock ramp: the first ~15 iterations of a process "
                          "run 10-25 %% slower than its steady state)")
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
-    ap.add_argument("--precision", default=os.environ.get("MDETR_BENCH_PRECISION", "bf16"), choices=["fp32", "bf16", "bf16-autocast"],
+    ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16", "bf16-autocast"],
                     help="bf16 = bf16 model body + fp32 heads + fp32 master weights (helpers/precision.py); "
                          "bf16-autocast = fp32 parameters under torch.autocast")
-    ap.add_argument("--graph", default=os.environ.get("MDETR_BENCH_GRAPH", "auto"), choices=["auto", "on", "off"],
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
                     help="auto (default) = replay the training iteration from hipGraphs -- one graph on a single GPU, two "
                          "(forward + backward | optimizer) around the eager RCCL all-reduce with N > 1 -- and fall back to eager "
                          "launches if the capture fails on any rank; on = the same without the fall-back; off = eager launches "
@@ -588,7 +588,7 @@ def main():
     size, queries, part = (384, 1280), 50, "full"
     if args.config == 2:
         part = "encoder"
-        if "--precision" not in sys.argv and "MDETR_BENCH_PRECISION" not in os.environ:
+        if "--precision" not in sys.argv:
             args.precision = "fp32"
     elif args.config == 5:
         size, queries = (512, 1760), 100
@@ -607,7 +607,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    bound = None if os.environ.get("MDETR_BENCH_NO_NUMA_BIND") == "1" else bind_to_gpu_numa_node(local_rank)
+    bound = bind_to_gpu_numa_node(local_rank)
     # MDETR_BENCH_FORCE_DDP=1: take the N > 1 code path (process group, DDP wrapper, RCCL all-reduce,
     # barriers) with a single rank -- the only way to exercise it on a 1-GPU box
     force_ddp = os.environ.get("MDETR_BENCH_FORCE_DDP", "0") == "1"

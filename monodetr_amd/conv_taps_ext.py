@@ -45,7 +45,8 @@ def _call(x, w, shift, y, dims, relu):
 def _split_count(B, OH, OW, N, C, k, relu):
     """Contraction splits for the forward pass, 0 = none: few output tiles (4 x 32 pixels x 32 channels each) against many channel
     slabs -- split until ~1 000 workgroups exist, at least 4 slabs of 32 channels per split."""
-    if relu or k != 3 or os.environ.get("MDETR_CONV_TAPS_SPLIT", "1") == "0":
+    from . import _tune
+    if relu or k != 3 or _tune.get("conv_taps_split", "1") == "0":
         return 0
     blocks = B * ((OH + 3) // 4) * ((OW + 31) // 32) * (N // 32)
     slabs = C // 32

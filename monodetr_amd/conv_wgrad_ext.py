@@ -27,8 +27,8 @@ def supported(x, dy, k, stride):
 # Weight AND bias gradients of token-wise linear layers over tens of thousands of rows (the encoder's 81 600, the backbone's 1x1
 # convolutions) as the 1x1 case of this kernel, the bias gradient riding along (mdetr_token_wgrad), instead of the library's batched
 # split-K product + chunk sum + two-launch column sum: 53 -> 43 us at [81 600, 256] x [81 600, 256], 49 -> 28-36 us on the backbone's
-# and the depth head's shapes (profiles/r04q_wgradbench.json).  MDETR_TOKEN_WGRAD_CONV=0 restores the library route.
-TOKEN_ROUTE = os.environ.get("MDETR_TOKEN_WGRAD_CONV", "1") != "0"
+# and the depth head's shapes (profiles/r04q_wgradbench.json).
+TOKEN_ROUTE = True
 
 
 def token_weight_gradient(x2, dy2, dtype, bias=False):
@@ -68,13 +68,14 @@ def token_weight_gradient(x2, dy2, dtype, bias=False):
 
 
 def token_supported(x2, dy2):
-    """bf16 token matrices with contiguous rows whose widths are multiples of 8 (csrc/twgrad.hip).  With MDETR_TWGRAD=0 (A/B runs: the
+    """bf16 token matrices with contiguous rows whose widths are multiples of 8 (csrc/twgrad.hip).  With MDETR_TUNE="twgrad=0" (tests: the
     1x1 case of csrc/conv_wgrad.hip behind the same entry point) that kernel's narrower rules apply."""
     T = x2.shape[0]
     ok = (TOKEN_ROUTE and (ENABLED or _backend is not None) and x2.dtype == torch.bfloat16 and dy2.dtype == torch.bfloat16 and x2.is_contiguous()
           and dy2.is_contiguous() and (x2.is_cuda or _backend is not None) and x2.data_ptr() % 16 == 0 and dy2.data_ptr() % 16 == 0
           and T * max(x2.shape[1], dy2.shape[1]) * 2 < (1 << 31))
-    if os.environ.get("MDETR_TWGRAD") == "0":
+    from . import _tune
+    if _tune.get("twgrad") == "0":
         # (narrow outputs waste that kernel's 128-row dy block; a weight of more than 64 (128 x 64) blocks leaves too few chunks)
         return ok and T % 8 == 0 and x2.shape[1] % 64 == 0 and dy2.shape[1] % 32 == 0 and dy2.shape[1] >= 128 \
             and ((dy2.shape[1] + 127) // 128) * (x2.shape[1] // 64) <= 64

@@ -36,6 +36,7 @@
 #include <mdetr_wave.h>
 
 #include "attn.h"
+#include "mdetr_tune.h"
 #include "msda.h"
 
 namespace mdetr {
@@ -705,13 +706,14 @@ AttnArgs make_args(const AttnProblem &p)
 }  // namespace
 
 // two key ranges per workgroup (KS = 2): bf16 only (the fp32 mode's split operands double the staging buffers), several key tiles
-// to share.  OFF unless MDETR_ATTN_KSPLIT=1: measured on the case it was written for (B = 8, 550 x 1920, dropout 0.1) the forward
+// to share.  OFF unless MDETR_TUNE="attn_ksplit=1" (tests): measured on the case it was written for (B = 8, 550 x 1920, dropout 0.1) the forward
 // went from 0.056 to 0.061 ms and the backward did not move (profiles/r03z_attnbench_ks{0,auto}.json) -- the 8-wave workgroup's
 // barriers and the merge cost more than the second wave per SIMD hides.
 bool key_split(const AttnProblem &p)
 {
     if (p.dtype == 0 || p.Lk < 4 * kTile) return false;
-    const char *ev = getenv("MDETR_ATTN_KSPLIT");
+    char tune_buf[8];
+    const char *ev = tune_str("attn_ksplit", tune_buf, sizeof(tune_buf));
     return ev && ev[0] == '1';
 }
 

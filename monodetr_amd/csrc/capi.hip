@@ -32,6 +32,7 @@
 #include "tgemm.h"
 #include "sgemm.h"
 #include "head_tail.h"
+#include "mdetr_tune.h"
 #include "twgrad.h"
 #include "msda.h"
 #include "msda_prologue.h"
@@ -779,10 +780,11 @@ int mdetr_conv_wgrad(const void *x, const void *dy, float *partial, int64_t part
     return MDETR_OK;
 }
 
-// csrc/twgrad.hip (transposing LDS reads) unless MDETR_TWGRAD=0 asks for the 1x1 case of csrc/conv_wgrad.hip (A/B runs)
+// csrc/twgrad.hip (transposing LDS reads) unless MDETR_TUNE="twgrad=0" asks for the 1x1 case of csrc/conv_wgrad.hip (tests)
 static bool twgrad_wanted(int64_t T, int C, int N)
 {
-    const char *ev = getenv("MDETR_TWGRAD");
+    char tune_buf[8];
+    const char *ev = mdetr::tune_str("twgrad", tune_buf, sizeof(tune_buf));
     return !(ev && atoi(ev) == 0) && T > 0 && C > 0 && N > 0 && C % 8 == 0 && N % 8 == 0;
 }
 

@@ -233,10 +233,6 @@ hipError_t conv3x3_launch(const void *x, const void *w, const float *shift, void
     // workgroup, layer2 (480 tiles) 38 / 32 / 33 us.  Narrow until there are ~900 workgroups.
     const int64_t tiles = static_cast<int64_t>(B) * d.tiles_x * d.tiles_y;
     while (nb > 1 && tiles * ((N + nb * 32 - 1) / (nb * 32)) < 900) nb >>= 1;
-    if (const char *ev = getenv("MDETR_CONV3X3_NB")) {                        // A/B runs: a fixed width (clamped to what exists)
-        const int f = atoi(ev);
-        if ((f == 1 || f == 2 || f == 4) && f * 32 <= (N >= 128 ? 128 : (N >= 64 ? 64 : 32))) nb = f;
-    }
     if (nb == 4) return relu ? launch<4, true>(x, w, shift, y, d, st) : launch<4, false>(x, w, shift, y, d, st);
     if (nb == 2) return relu ? launch<2, true>(x, w, shift, y, d, st) : launch<2, false>(x, w, shift, y, d, st);
     return relu ? launch<1, true>(x, w, shift, y, d, st) : launch<1, false>(x, w, shift, y, d, st);

@@ -28,6 +28,7 @@
 #include <mdetr_wave.h>
 
 #include "conv_taps.h"
+#include "mdetr_tune.h"
 #include "msda.h"       // profile scopes
 
 // Contraction channels per LDS slab.  32, not conv3x3.hip's 64: the stride-2 halo of a 4 x 32-pixel tile is 9 x 65 pixels -- 84 KB at
@@ -246,7 +247,8 @@ inline int pick_nb(const ConvTapsDims &d, int nb_min)
 {
     const int64_t tiles = static_cast<int64_t>(d.B) * ((d.OH + kWavesT - 1) / kWavesT) * ((d.OW + kTileWT - 1) / kTileWT);
     int nb = d.N >= 128 ? 4 : (d.N >= 64 ? 2 : 1);
-    if (const char *ev = getenv("MDETR_CONV_TAPS_NB")) {                     // tests / A-B runs: a fixed width (clamped to what exists)
+    char tune_buf[8];
+    if (const char *ev = tune_str("conv_taps_nb", tune_buf, sizeof(tune_buf))) {                     // tests / A-B runs: a fixed width (clamped to what exists)
         const int f = atoi(ev);
         if (f == 1 || f == 2 || f == 4) return f < nb_min ? nb_min : (f > nb ? nb : f);
     }

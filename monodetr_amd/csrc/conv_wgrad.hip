@@ -29,6 +29,7 @@
 #include <mdetr_wave.h>
 
 #include "conv_wgrad.h"
+#include "mdetr_tune.h"
 #include "mdetr_transpose.h"
 #include "msda.h"       // profile scopes
 
@@ -259,7 +260,8 @@ WgradGeom geometry(const ConvWgradDims &d)
     // one workgroup per CU (104-134 KB of LDS): about 256 workgroups, each with at least one pixel tile
     const int base = d.K * g.nblocks * g.cblocks;
     int target = 256;
-    if (const char *ev = getenv("MDETR_CONV_WGRAD_WGS")) {                    // A/B runs: workgroups to aim for
+    char tune_buf[16];
+    if (const char *ev = tune_str("conv_wgrad_wgs", tune_buf, sizeof(tune_buf))) {                    // A/B runs: workgroups to aim for
         const int f = atoi(ev);
         if (f >= 64 && f <= 8192) target = f;
     }

@@ -33,6 +33,7 @@
 #include <mdetr_wave.h>
 
 #include "msda.h"
+#include "mdetr_tune.h"
 
 namespace mdetr {
 namespace {
@@ -781,8 +782,8 @@ hipError_t msda_backward_launch_ex(int dtype, const void *value, const int64_t *
     const int64_t nv = static_cast<int64_t>(B) * S * M * D, ns = static_cast<int64_t>(B) * Lq * M * L * P;
     hipError_t err;
     const int64_t n = static_cast<int64_t>(B) * Lq * M * D;
-    // MDETR_MSDA_BWD = fused (default) | tiled | atomic: which grad_value strategy the fast path takes
-    const int bwd_env = [] { const char *ev = getenv("MDETR_MSDA_BWD"); return !ev || !*ev || ev[0] == 'f' ? 0 : (ev[0] == 't' ? 1 : 2); }();
+    // MDETR_TUNE="msda_bwd=fused (default) | tiled | atomic" (tests): which grad_value strategy the fast path takes
+    const int bwd_env = [] { char tb[16]; const char *ev = tune_str("msda_bwd", tb, sizeof(tb)); return !ev || !*ev || ev[0] == 'f' ? 0 : (ev[0] == 't' ? 1 : 2); }();
     const bool fast = msda_fast_path(dtype, D, L, P);
     if (fast && bwd_env == 0 && n && ns && shapes_host && lstart_host && workspace) {
         // one-pass backward (msda_fused.hip): writes all three outputs completely, no zero fill
@@ -798,7 +799,7 @@ hipError_t msda_backward_launch_ex(int dtype, const void *value, const int64_t *
         if ((err = zero_fill_launch(grad_attn, ns * e, st)) != hipSuccess) return err;
     }
     if (fast) {
-        static const int var_env = [] { const char *ev = getenv("MDETR_MSDA_BWD_VARIANT"); return ev ? atoi(ev) : -1; }();
+        const int var_env = tune_int("msda_bwd_variant", -1);
         // tile-privatised grad_value (msda_tiled.hip) when the geometry qualifies; the kernel below then
         // only produces grad_loc / grad_attn (VAR 2)
         const bool try_tiled = shapes_host && lstart_host && workspace && var_env != 0 && var_env != 1 && bwd_env != 2 &&
@@ -887,7 +888,7 @@ hipError_t msda_backward_bf16_launch(const void *value, const int64_t *shapes, c
     if (D != 32 || L != 4 || P != 4) return hipErrorNotSupported;
     const int64_t nv = static_cast<int64_t>(B) * S * M * D;
     hipError_t err;
-    const int bwd_env = [] { const char *ev = getenv("MDETR_MSDA_BWD"); return !ev || !*ev || ev[0] == 'f' ? 0 : (ev[0] == 't' ? 1 : 2); }();
+    const int bwd_env = [] { char tb[16]; const char *ev = tune_str("msda_bwd", tb, sizeof(tb)); return !ev || !*ev || ev[0] == 'f' ? 0 : (ev[0] == 't' ? 1 : 2); }();
     if (bwd_env == 0 && static_cast<int64_t>(B) * Lq * M && shapes_host && lstart_host && workspace) {
         err = msda_backward_fused_launch(shapes_host, lstart_host, value, loc, attn, grad_out, grad_value, grad_loc, grad_attn,
                                          workspace, workspace_bytes, B, S, M, D, L, Lq, P, 2, st);

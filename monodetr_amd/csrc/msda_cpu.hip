@@ -8,7 +8,7 @@
 // disjoint channels of grad_value, so the scatter needs no atomics and is deterministic.
 //
 // They are EXPLICIT entry points for host tensors, not a fallback: the GPU entry points never route here, and
-// monodetr_amd/msda_ext.py keeps the reference's behaviour (CPU tensors raise) unless MDETR_MSDA_CPU=1 asks for them.
+// monodetr_amd/msda_ext.py keeps the reference's behaviour (CPU tensors raise) unless allow_cpu(True) asks for them.
 // Host-only code: nothing here runs on the device.
 #include <hip/hip_runtime.h>
 #include <math.h>

@@ -49,31 +49,7 @@
 #include <mdetr_wave.h>
 
 #include "msda.h"
-
-// developer ablations (timing only, results wrong): -DMDETR_ABL=<bits>  1: no LDS accumulation  2: no value gather / gradients of
-// loc, attn  4: candidate pass only  8: no per-cell counts
-#ifndef MDETR_ABL
-#define MDETR_ABL 0
-#endif
-#ifndef MDETR_ROLL
-#define MDETR_ROLL 0
-#endif
-
-// developer timing: -DMDETR_PHASES accumulates shader-clock cycles per phase (thread 0 of every block; wave 0 for the sections of
-// the main loop) into 16 x 2 64-bit words at byte 64 of the workspace header's maxima area end (read by tools/opbench --phases)
-#ifdef MDETR_PHASES
-#define MDETR_PH_DECL long long ph_t = clock64(); long long ph_acc[3] = {0, 0, 0}; long long ph_w = 0;
-#define MDETR_PH_MARK(idx) do { if (threadIdx.x == 0) { const long long n_ = clock64(); atomicAdd(reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(hdr) + 64) + ((w.mode == 1 ? 12 : 0) + (idx)), static_cast<unsigned long long>(n_ - ph_t)); ph_t = n_; } } while (0)
-#define MDETR_PH_W0() do { if (threadIdx.x == 0) ph_w = clock64(); } while (0)
-#define MDETR_PH_W(i) do { if (threadIdx.x == 0) { const long long n_ = clock64(); ph_acc[i] += n_ - ph_w; ph_w = n_; } } while (0)
-#define MDETR_PH_WFLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 3; ++i_) atomicAdd(reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(hdr) + 64) + ((w.mode == 1 ? 12 : 0) + 8 + i_), static_cast<unsigned long long>(ph_acc[i_])); } while (0)
-#else
-#define MDETR_PH_DECL
-#define MDETR_PH_MARK(idx) do { } while (0)
-#define MDETR_PH_W0() do { } while (0)
-#define MDETR_PH_W(i) do { } while (0)
-#define MDETR_PH_WFLUSH() do { } while (0)
-#endif
+#include "mdetr_tune.h"
 
 namespace mdetr {
 namespace {
@@ -128,10 +104,7 @@ __host__ __device__ inline int ceil_div_ll(long long a, long long b)   // b > 0,
     return static_cast<int>(a >= 0 ? (a + b - 1) / b : -((-a) / b));
 }
 
-#ifndef MDETR_NOPAD
-#define MDETR_NOPAD 0
-#endif
-__host__ __device__ inline int row_pad(int tw) { return (!MDETR_NOPAD && tw % 16 == 0) ? 1 : 0; }      // tiled windows: see decode_block
+__host__ __device__ inline int row_pad(int tw) { return tw % 16 == 0 ? 1 : 0; }      // tiled windows: see decode_block
 
 // cell of level l (extent n_l) that holds the centre of cell y of a level with extent n_q
 __host__ __device__ inline int centre_cell(int y, int n_l, int n_q)
@@ -491,12 +464,6 @@ __device__ __forceinline__ void accumulate(unsigned long long *win, unsigned o01
                                            const float (&ag)[CPL], int k, float magic)
 {
     unsigned cell[4] = {o01 & 0xFFFFu, o01 >> 16, o23 & 0xFFFFu, o23 >> 16};
-    if (MDETR_ABL & 32) {                                     // timing only: the 8 samples of a half-wave on disjoint banks
-        const unsigned s8 = (threadIdx.x / (2 * CPL > 8 ? 4 : 8)) & 7u;
-        const unsigned tb[8] = {0u, 17u, 2u, 19u, 16u, 1u, 18u, 3u};
-        const unsigned cc = s8 == 0 ? tb[0] : s8 == 1 ? tb[1] : s8 == 2 ? tb[2] : s8 == 3 ? tb[3] : s8 == 4 ? tb[4] : s8 == 5 ? tb[5] : s8 == 6 ? tb[6] : tb[7];
-        cell[0] = cc; cell[1] = cc + 32u; cell[2] = cc + 64u; cell[3] = cc + 96u;
-    }
     const f32x2 mg = make_f32x2(magic, magic);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -538,7 +505,6 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
 
     const int bid = blockIdx.x;
     const int b = bid % pl.B, r_ = bid / pl.B, m = r_ % pl.M, kblk = r_ / pl.M;      // image -> XCD (bid % 8)
-    MDETR_PH_DECL
     unsigned *wmax = blk + 4;                                                // 2 words per wave: the pre-pass's maxima, reduced
     // the pre-pass left one pair of maxima per workgroup behind the header: requested first, consumed after the block's bounds
     unsigned mg_ = 0u, ma_ = 0u;
@@ -624,7 +590,6 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
     const int nsamp = w.nq * P;
     const float inv_p = 1.0f / static_cast<float>(P);
 
-    MDETR_PH_MARK(0);
     for (int shift = 0;; ++shift) {
         // contributions are rounded to multiples of 2^-(22 - shift - e): |x| * scale < 2^(22 - shift), up to 2^(9 + shift) - 1 per cell
         const float scale = ldexpf(1.0f, 22 - shift - e);
@@ -635,7 +600,6 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
             if (threadIdx.x == 0) { blk[0] = 0u; blk[1] = kWavesB * 64u; blk[2 + (shift & 1)] = 0u; }
             __syncthreads();
         }
-        MDETR_PH_MARK(1);
 
         // candidate decode + the loads of its location / weight, issued one step AHEAD of their use (the loop is bound by
         // memory round trips, not by arithmetic: everything that can be in flight early is)
@@ -677,7 +641,6 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
         Cand cur;
         if (wave * 64 < nsamp) decode(wave * 64, cur);
         for (int base = wave * 64; base < nsamp;) {
-            MDETR_PH_W0();
             unsigned nxt_ = 0u;
             if (lane == 0) nxt_ = atomicAdd(blk + 1, 64u);
             const int next_base = __builtin_amdgcn_readfirstlane(static_cast<int>(nxt_));
@@ -764,7 +727,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {                 // this block's cells: count the contribution, other corners -> sink row
                     const unsigned cc = (c < 2 ? rec[2] >> (16 * c) : rec[3] >> (16 * (c - 2))) & 0xFFFFu;
-                    if (cc != 0xFFFFu && !(MDETR_ABL & 8)) atomicAdd(cnt + cc, 1u);
+                    if (cc != 0xFFFFu) atomicAdd(cnt + cc, 1u);
                 }
                 const unsigned sink = static_cast<unsigned>(w.ncell + (slot & 7));
                 const unsigned c0 = rec[2] & 0xFFFFu, c1 = rec[2] >> 16, c2 = rec[3] & 0xFFFFu, c3 = rec[3] >> 16;
@@ -776,7 +739,6 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 *reinterpret_cast<uint4 *>(dst + 8) = make_uint4(rec[8], rec[9], rec[10], rec[11]);
             }
             wave_sync();
-            MDETR_PH_W(0);
 
             // ---- b1. own samples, SPG per group (LPS lanes x CPL channels each), up to GMAX groups per batch: every load of the
             //          batch is requested before the first group is consumed ---------------------------------------------------
@@ -793,7 +755,7 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 const unsigned flags = r2.w;
                 float g[CPL];
                 RG::widen(graw, g);
-                if (on && finite && !(MDETR_ABL & 1)) {
+                if (on && finite) {
                     const float as = a * scale;
                     float ag[CPL];
 #pragma unroll
@@ -813,12 +775,12 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                     if (!OWNER && k == 0) hdr->far = 1u;
                 }
                 float e[4] = {0.f, 0.f, 0.f, 0.f};
-                if (!(MDETR_ABL & 2)) CornerDots<GT, VT, CPL>::run(graw, g, vraw, e);
+                CornerDots<GT, VT, CPL>::run(graw, g, vraw, e);
                 // over the LPS lanes of the sample, every lane takes part
                 float d0 = sum_sample<LPS>(e[0]), d1 = sum_sample<LPS>(e[1]), d2 = sum_sample<LPS>(e[2]), d3 = sum_sample<LPS>(e[3]);
                 d0 = (flags & 1u) ? d0 : 0.f; d1 = (flags & 2u) ? d1 : 0.f;              // a corner outside the map reads nothing (.cuh:56-78)
                 d2 = (flags & 4u) ? d2 : 0.f; d3 = (flags & 8u) ? d3 : 0.f;
-                if (on && k == 0 && !(MDETR_ABL & 2)) {
+                if (on && k == 0) {
                     const float hh = 1.f - lh, hw = 1.f - lw;
                     const unsigned p = (flags >> 8) & 15u;
                     const unsigned o_ = (pair0u + r0.x * static_cast<unsigned>(M)) * static_cast<unsigned>(LP) + static_cast<unsigned>(l * P) + p;   // < 2^28 (plan)
@@ -837,14 +799,11 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 for (int t = 0; t < NG; ++t) {
                     const int r = min(i0 + SPG * t + j, no - 1);
                     const uint2 h = *reinterpret_cast<const uint2 *>(wrec + r * kRecDw);
-                    if (MDETR_ABL & 16) rg[t] = RG::load(reinterpret_cast<const char *>(wrec + (r & 31) * kRecDw));
-                    else rg[t] = RG::load(gbase + (pair0u + h.x * static_cast<unsigned>(M)) * static_cast<unsigned>(kCH * Elem<GT>::kBytes));
+                    rg[t] = RG::load(gbase + (pair0u + h.x * static_cast<unsigned>(M)) * static_cast<unsigned>(kCH * Elem<GT>::kBytes));
                     const int dxb = (h.y >> 30) & 1u ? rowb : 0, dyb = (h.y >> 31) ? W * rowb : 0;
                     const char *vb = vlev + (h.y & 0xFFFFFFu) * static_cast<unsigned>(rowb);
-                    if (!(MDETR_ABL & 2)) {
-                        rv[t][0] = RV::load(vb); rv[t][1] = RV::load(vb + dxb);
-                        rv[t][2] = RV::load(vb + dyb); rv[t][3] = RV::load(vb + dyb + dxb);
-                    }
+                    rv[t][0] = RV::load(vb); rv[t][1] = RV::load(vb + dxb);
+                    rv[t][2] = RV::load(vb + dyb); rv[t][3] = RV::load(vb + dyb + dxb);
                 }
 #pragma unroll
                 for (int t = 0; t < NG; ++t) {
@@ -852,39 +811,8 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                     run_own(r < no, min(r, no - 1), rg[t], rv[t]);
                 }
             };
-#if MDETR_ROLL
-            // rolling form: group t + 1's loads are requested BEFORE group t is consumed, two register sets alternating -- one
-            // exposed round trip per step instead of one per batch of GMAX groups (the ablations say the own pass waits: without
-            // the gather AND without the accumulation it costs nothing, with either one nearly everything)
-            if (no > 0 && !(MDETR_ABL & 4)) {
-                auto load_group = [&](int gi, typename RG::T &rg, typename RV::T (&rv)[4]) __attribute__((always_inline)) {
-                    const int r = min(gi * SPG + j, no - 1);
-                    const uint2 h = *reinterpret_cast<const uint2 *>(wrec + r * kRecDw);
-                    rg = RG::load(gbase + (pair0u + h.x * static_cast<unsigned>(M)) * static_cast<unsigned>(kCH * Elem<GT>::kBytes));
-                    const int dxb = (h.y >> 30) & 1u ? rowb : 0, dyb = (h.y >> 31) ? W * rowb : 0;
-                    const char *vb = vlev + (h.y & 0xFFFFFFu) * static_cast<unsigned>(rowb);
-                    rv[0] = RV::load(vb); rv[1] = RV::load(vb + dxb);
-                    rv[2] = RV::load(vb + dyb); rv[3] = RV::load(vb + dyb + dxb);
-                };
-                const int G = (no + SPG - 1) / SPG;                                      // wave-uniform
-                typename RG::T gA, gB;
-                typename RV::T vA[4], vB[4];
-                load_group(0, gA, vA);
-                for (int t = 0; t < G; t += 2) {
-                    if (t + 1 < G) load_group(t + 1, gB, vB);
-                    { const int r = t * SPG + j; run_own(r < no, min(r, no - 1), gA, vA); }
-                    if (t + 1 < G) {
-                        if (t + 2 < G) load_group(t + 2, gA, vA);
-                        { const int r = (t + 1) * SPG + j; run_own(r < no, min(r, no - 1), gB, vB); }
-                    }
-                }
-            }
-            for (int i0 = 0; false; ) {
-                const int ng = 0;
-#else
-            for (int i0 = 0; i0 < no && !(MDETR_ABL & 4); i0 += SPG * GMAX) {
+            for (int i0 = 0; i0 < no; i0 += SPG * GMAX) {
                 const int ng = min(GMAX, (no - i0 + SPG - 1) / SPG);                      // wave-uniform
-#endif
                 if constexpr (GMAX == 1) {
                     own_batch(std::integral_constant<int, 1>(), i0);
                 } else {
@@ -896,7 +824,6 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                     }
                 }
             }
-            MDETR_PH_W(1);
             // ---- b2. neighbours' samples that reach into this core: accumulate only ---------------------------------------
             auto halo_batch = [&](auto ngc, int i0) __attribute__((always_inline)) {
                 constexpr int NG = decltype(ngc)::value;
@@ -920,12 +847,12 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                         RG::widen(rg[t], ag);
 #pragma unroll
                         for (int i = 0; i < CPL; ++i) ag[i] *= as;
-                        if (!(MDETR_ABL & 1)) accumulate<CPL>(win, r0.z, r0.w, wt, ag, k, magic);
+                        accumulate<CPL>(win, r0.z, r0.w, wt, ag, k, magic);
                     }
                 }
             };
             constexpr int HG = LPS == 2 ? 2 : 4;              // (a neighbour list is at most 64 samples = 2 groups of 32)
-            for (int i0 = 0; i0 < nh && !(MDETR_ABL & 4); i0 += HG * SPG) {
+            for (int i0 = 0; i0 < nh; i0 += HG * SPG) {
                 const int ng = min(HG, (nh - i0 + SPG - 1) / SPG);
                 if (ng == 1) halo_batch(std::integral_constant<int, 1>(), i0);
                 else if (HG == 2 || ng == 2) halo_batch(std::integral_constant<int, 2>(), i0);
@@ -935,13 +862,9 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
                 }
             }
             wave_sync();
-            MDETR_PH_W(2);
             base = next_base;
         }
-        MDETR_PH_MARK(2);
         __syncthreads();
-        MDETR_PH_MARK(3);
-        MDETR_PH_WFLUSH();
 
         // ---- c. read-out: strip the n * (magic bits) the atomics added along, store.  Did any cell draw more contributions than a
         //         32-bit field holds at this scale?  The maximum count is taken along; the (rare) repeat overwrites what this pass stored.
@@ -956,7 +879,6 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
             __syncthreads();
             if (finite && maxcnt0 >= (512u << shift) && shift < 12) continue;
         }
-        MDETR_PH_MARK(4);
         {
             const unsigned long long cbits = static_cast<unsigned long long>(__builtin_bit_cast(unsigned, magic)) * 0x100000001ull;
             const float inv = finite ? ldexpf(1.0f, -(22 - shift - e)) : 0.f;
@@ -999,7 +921,6 @@ void msda_bwd_fused(const FusedPlan pl, const VT *__restrict__ value, const floa
             __syncthreads();
             const unsigned maxcnt = blk[2 + (shift & 1)];
             if (!(finite && maxcnt >= (512u << shift) && shift < 12)) {
-                MDETR_PH_MARK(5);
                 break;
             }
         }
@@ -1110,11 +1031,7 @@ void msda_finalize_kernel(const FusedPlan pl, const float *__restrict__ scratch,
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------
-int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
+int env_int(const char *key, int dflt) { return tune_int(key, dflt); }      // MDETR_TUNE (mdetr_tune.h): tests force a tile / wave geometry
 
 bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, int B, int S, int M, int L, int Lq, int P, int elem_dtype = 2)
 {
@@ -1141,9 +1058,9 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
     // vs 0.557 at 16 x 40, and 0.72 vs 0.82 for N(0, 4 px) offsets), reach 5 cells (the model's initial offsets reach 4 px on
     // every level), whole-level windows up to 512 cells split into 12 query chunks.
     // (the fp32 form runs 8 waves per workgroup: 24 x 40, 0.88 ms vs 0.95 at 16 x 32)
-    const int tile_h = env_int("MDETR_MSDA_TILE_H", 24), tile_w = env_int("MDETR_MSDA_TILE_W", elem_dtype == 2 ? 32 : 40);
-    const int reach = env_int("MDETR_MSDA_REACH", 5), chunks_env = env_int("MDETR_MSDA_CHUNKS", 12);
-    const int whole_max = env_int("MDETR_MSDA_WHOLE_LEVEL_CELLS", 512);
+    const int tile_h = env_int("msda_tile_h", 24), tile_w = env_int("msda_tile_w", elem_dtype == 2 ? 32 : 40);
+    const int reach = env_int("msda_reach", 5), chunks_env = env_int("msda_chunks", 12);
+    const int whole_max = env_int("msda_whole_level_cells", 512);
     if (tile_h < 1 || tile_w < 1 || tile_h * tile_w > kMaxCells || reach < 0 || chunks_env < 1) return false;
     // (the owner scheme -- a block looks at its own queries only, 16 x 24 core tiles with a 4-cell halo -- lost its A/B in round 3 and
     // is no longer instantiated: the OWNER = true branches of the kernel are compiled out, its switch and launch forms are gone)
@@ -1200,7 +1117,7 @@ bool build_plan(FusedPlan &pl, const int64_t *shapes_h, const int64_t *start_h, 
         pl.bstride[l] = 1;
     }
     // block numbering = dispatch order: the longest blocks first, so that the launch's tail is made of short ones.  Measured per
-    // block at the encoder shape (cycles per phase, -DMDETR_PHASES): a 24 x 32 core tile 85 us, a 1/12 query chunk of a whole level
+    // block at the encoder shape (cycles per phase, measured with a timing build in round 3): a 24 x 32 core tile 85 us, a 1/12 query chunk of a whole level
     // 42 us -- with the chunked levels in front (rounds 2 and 3) the last quarter-round of tiles ran on a quarter of the CUs.
     // Chunked levels with the same chunk count stay interleaved chunk by chunk.
     for (int l = 0; l < L; ++l) {                            // finest level first: its tiles are full-sized
@@ -1271,7 +1188,7 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
         hipLaunchKernelGGL(msda_absmax_kernel<float>, dim3(pre_blocks), dim3(256), 0, st, static_cast<const float *>(grad_out), n_go, attn, n_at, hdr, far, nfar, pl.owner);
     profile_end(st);
     // 512 threads (8 waves) or 1024 (16 waves: twice the record buffers, more loads in flight per CU)
-    int threads = env_int("MDETR_MSDA_THREADS", 1024);          // (bf16: 0.74 ms at 16 waves vs 0.96 at 8, same tile)
+    int threads = env_int("msda_threads", 1024);          // (bf16: 0.74 ms at 16 waves vs 0.96 at 8, same tile)
     // (16 waves leave 128 VGPRs: the fp32 form's load batches do not fit; 768 = 12 waves with 170 VGPRs, bf16 only)
     threads = (threads >= 1024 && elem_dtype == 2) ? 1024 : ((threads == 768 && elem_dtype == 2) ? 768 : 512);
     auto lds_bytes = [&](int thr) {
@@ -1288,11 +1205,11 @@ hipError_t msda_backward_fused_launch(const int64_t *shapes_h, const int64_t *st
     if ((err = hipGetDevice(&dev)) != hipSuccess) return err;
     // lanes per sample: 4 (bf16 at 16 waves: 8 channels per lane, two groups of 16 own samples in flight) or 8 (4 channels per
     // lane, four groups of 8)
-    int lps = env_int("MDETR_MSDA_LPS", 4);
+    int lps = env_int("msda_lps", 4);
     // (2: half a row per lane, one group of 32 own samples in flight -- the per-sample instructions halve again; 16 waves, bf16)
     lps = ((lps == 4 || lps == 2) && elem_dtype == 2 && threads > 512) ? lps : 8;
     if (lps == 2 && threads != 1024) lps = 4;
-    const int groups = env_int("MDETR_MSDA_GROUPS", 2);      // (12-wave form: 2 or 4 groups of 16 own samples in flight)
+    const int groups = env_int("msda_groups", 2);      // (12-wave form: 2 or 4 groups of 16 own samples in flight)
     static bool attr_set[10][64] = {};                        // per kernel instance and device
     int which = elem_dtype != 2 ? 0 : (threads == 512 ? 1 : (threads == 768 ? (groups >= 4 ? 5 : 4) : (lps == 8 ? 2 : (lps == 2 ? 9 : 3))));
     typedef __hip_bfloat16 bf;

@@ -187,10 +187,6 @@ int small_wgrad_chunks(int64_t rows, int n, int k)
 {
     const int tiles = ((n + kTile - 1) / kTile) * (k / kTile);
     int target = 768;                                                        // (1152 until round 3: r03t sweep, 24.4 -> 21.3 us for the 256 x 256 layers)
-    if (const char *ev = getenv("MDETR_SMALL_WGRAD_WGS")) {                  // A/B runs: workgroups to aim for
-        const int f = atoi(ev);
-        if (f >= 64 && f <= 8192) target = f;
-    }
     int c = (target + tiles - 1) / tiles;
     const int64_t most = (rows + 63) / 64;
     if (c > most) c = static_cast<int>(most);

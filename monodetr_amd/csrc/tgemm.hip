@@ -33,6 +33,7 @@
 #include "mdetr_transpose.h"
 #include "msda.h"       // profile scopes
 #include "tgemm.h"
+#include "mdetr_tune.h"
 
 namespace mdetr {
 namespace {
@@ -417,10 +418,8 @@ hipError_t launch_tile(TgemmArgs g, hipStream_t st)
     // persistent: as many workgroups as the chip holds at once (LDS: 160 KB per CU), a multiple of 8
     int per_cu = static_cast<int>((160 * 1024) / lds);
     per_cu = per_cu > 4 ? 4 : per_cu;
-    if (const char *ev = getenv("MDETR_TGEMM_PER_CU")) { const int f = atoi(ev); if (f >= 1 && f <= 8) per_cu = f; }       // A/B runs
     int64_t grid = static_cast<int64_t>(256) * per_cu;
-    if (const char *ev = getenv("MDETR_TGEMM_PERSIST")) { if (atoi(ev) == 0) grid = vtiles; }       // A/B runs: one tile per workgroup
-    if (const char *ev = getenv("MDETR_TGEMM_GRID")) { const int f = atoi(ev); if (f >= 8 && f % 8 == 0) grid = f; }       // tests: few workgroups, many tiles each
+    { const int f = tune_int("tgemm_grid", 0); if (f >= 8 && f % 8 == 0) grid = f; }       // tests: few workgroups, many tiles each
     if (grid > vtiles) grid = vtiles;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(kThreadsT), lds, st, g);
     return hipGetLastError();
@@ -433,10 +432,9 @@ hipError_t launch_any(const TgemmArgs &g, int bm, int bn, hipStream_t st)
         // the plain forward product takes the big tile with EIGHT waves (2 x 4) and one register set: 120 registers, twice the waves
         // in flight per CU at the same LDS -- 24.3 -> 22.4 us at the encoder shape, 34.7 -> 32.1 at the packed projection
         // (profiles/r05o_gemmbench_eight_waves.json); every other form would spill at the 128-register ceiling that costs.
-        // MDETR_TGEMM_WAVES=4 (A/B runs, read at every launch) restores four waves.
+        // MDETR_TUNE="tgemm_waves=4" (tests) restores four waves.
         if constexpr (!NN && PF == 1 && TAIL == 0) {
-            const char *ev = getenv("MDETR_TGEMM_WAVES");
-            if (!(ev && atoi(ev) == 4)) return launch_tile<128, 128, NN, PF, TAIL, 512>(g, st);
+            if (tune_int("tgemm_waves", 8) != 4) return launch_tile<128, 128, NN, PF, TAIL, 512>(g, st);
         }
         return launch_tile<128, 128, NN, PF, TAIL>(g, st);
     }
@@ -493,14 +491,15 @@ hipError_t tgemm_launch(const TgemmProblem &p, hipStream_t st)
         if (wgs(128, 128) >= 400) { bm = 128; bn = 128; }
         else if (wgs(128, 64) >= 400) { bm = 128; bn = 64; }
     }
-    if (const char *ev = getenv("MDETR_TGEMM_TILE")) {           // A/B runs: "128x64"
+    char tune_buf[16];
+    if (const char *ev = tune_str("tgemm_tile", tune_buf, sizeof(tune_buf))) {           // tests: "128x64"
         int m = 0, n = 0;
         if (sscanf(ev, "%dx%d", &m, &n) == 2 && (m == 64 || m == 128) && (n == 64 || n == 128)) { bm = m; bn = n; }
     }
     int pf = 2;
     if (bm == 128 && bn == 128 && (p.res || p.mask || (p.flags & (kTgemmBiasF32 | kTgemmOutF32)) || p.dropout_p > 0.f)) pf = 1;       // (the big tile's tails: registers)
     if (bm == 128 && bn == 128 && !(p.flags & kTgemmNN) && !p.res && !generic_tail) pf = 1;                                  // (... and its eight-wave plain form)
-    if (const char *ev = getenv("MDETR_TGEMM_PF")) pf = atoi(ev) == 1 ? 1 : 2;       // A/B runs: register sets in flight
+    if (const int f = tune_int("tgemm_pf", 0)) pf = f == 1 ? 1 : 2;       // tests: register sets in flight
     ProfileScope prof(10, conv_mflop(p.T, static_cast<int64_t>(p.N) * p.K), st, 2.0 * p.T * p.N * p.K / 1e6,
                       (2.0 * p.T * p.K + ((p.flags & kTgemmOutF32) ? 4.0 : 2.0) * p.T * p.N + (p.res ? 2.0 * p.T * p.N : 0.0) + (p.mask ? 2.0 * p.T * p.N : 0.0) + 2.0 * p.N * p.K) / 1e3);
     if (p.flags & kTgemmNN) return pf == 1 ? launch_tail<true, 1>(g, bm, bn, st) : launch_tail<true, 2>(g, bm, bn, st);

@@ -27,6 +27,7 @@
 
 #include "msda.h"       // profile scopes
 #include "twgrad.h"
+#include "mdetr_tune.h"
 
 namespace mdetr {
 namespace {
@@ -207,7 +208,7 @@ TwgradPlan plan(int64_t T, int C, int N)
     // two workgroups per CU, every chunk with at least four slabs: more chunks mean more fp32 partials to write and sum again
     // (256 / 512 / 1024 workgroups at [81 600, 256] x [81 600, 256]: 39.1 / 32.6 / 46.9 us with the chunk sum, profiles/r05h_wgradbench.json)
     int target = 512;
-    if (const char *ev = getenv("MDETR_TWGRAD_WGS")) { const int f = atoi(ev); if (f >= 64 && f <= 8192) target = f; }       // A/B runs
+    { const int f = tune_int("twgrad_wgs", 0); if (f >= 64 && f <= 8192) target = f; }       // tests
     int chunks = target / (p.tiles_n * p.tiles_c);
     if (chunks > p.slabs / 4) chunks = p.slabs / 4;
     if (chunks < 1) chunks = 1;

@@ -7,8 +7,8 @@ import torch
 from . import _capi
 
 _backend = None               # tests substitute the CPU emulation of the same kernel source (tests/native_emul.py)
-# MDETR_CONV_S2_GEMM=0: the 1x1 / stride-2 projection shortcuts stay with csrc/conv_taps.hip (one-tap implicit GEMM)
-ENABLED = os.environ.get("MDETR_CONV_S2_GEMM", "1") != "0"
+# False (tests): the 1x1 / stride-2 projection shortcuts stay with csrc/conv_taps.hip (one-tap implicit GEMM)
+ENABLED = True
 
 
 def _lib():

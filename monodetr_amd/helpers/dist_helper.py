@@ -95,7 +95,7 @@ def static_plan(params):
 
 @torch.no_grad()
 def gather(plan):
-    """One ``cat`` per dtype of a static plan's gradient tensors into its flat buffer.  With MDETR_GATHER_IN_GRAPH=1
+    """One ``cat`` per dtype of a static plan's gradient tensors into its flat buffer.  With MDETR_TUNE="gather_in_graph=1"
     TrainIteration.capture() records these INSIDE the graph that produced the gradients (``_gathered``) and the host only
     issues the all-reduce between two replays; measured with one rank that form is 0.4 % slower than the host issuing the cat
     (profiles/r04ddpab.log), so it is a switch, not the default."""

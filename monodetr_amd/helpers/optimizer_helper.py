@@ -221,11 +221,11 @@ class FusedAdamW(AdamW):
         self._flat = None
         self._lib = None                         # tests substitute a host build of the same kernel arithmetic
         self._allow_cpu = False
-        # MDETR_ADAMW_GATHER=1: the flat gradient buffer is filled by csrc/decimate.hip's gather (one launch per flat buffer over a
-        # block table) instead of the framework's multi-tensor copy.  Off: measured 388.2 vs 387.5 img/s under graph replay (noise)
-        # and 279.8 vs 286.3 launched eagerly -- filling 307 pointers from Python costs more than the copy kernels it saves
-        # (profiles/r03g2_bench_*.json)
-        self._gather = os.environ.get("MDETR_ADAMW_GATHER") == "1"
+        # _gather = True: the flat gradient buffer is filled by csrc/decimate.hip's gather (one launch per flat buffer over a
+        # block table) instead of the framework's multi-tensor copy.  Off: measured 388.2 vs 387.5 img/s under graph replay (noise;
+        # again 461.5 vs 461.6 in round 6, profiles/r06p_) and 279.8 vs 286.3 launched eagerly -- filling 307 pointers from Python
+        # costs more than the copy kernels it saves (profiles/r03g2_bench_*.json).  Tests switch it on.
+        self._gather = False
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)      # AdamW.load_state_dict: keeps the saved dtypes

@@ -323,10 +323,11 @@ class TrainIteration:
                 cut = self._overlap()
                 # the gradients sit at the addresses the captured backward writes to: every later exchange gathers from THOSE into
                 # persistent flat buffers (one cat per dtype), reduces there, and the captured optimizer reads the reduced slices.
-                # MDETR_GATHER_IN_GRAPH=1: the cat is recorded in the graph that produced the gradients (the host then only issues
+                # MDETR_TUNE="gather_in_graph=1" (tests): the cat is recorded in the graph that produced the gradients (the host then only issues
                 # the all-reduce between two replays).  Measured on one box with one rank (profiles/r04ddpab.log): 376.1 img/s
                 # against 377.9 with the host issuing the cat -- not the default.
-                inside = os.environ.get("MDETR_GATHER_IN_GRAPH", "0") == "1"
+                from .. import _tune
+                inside = _tune.get("gather_in_graph", "0") == "1"
                 fill = gather if inside else (lambda plan: plan)
                 with torch.cuda.graph(graph, stream=side, **mode):
                     self.loss = self._forward_backward(self.static, cut=cut)
@@ -451,8 +452,8 @@ class TrainIteration:
         # The graphs are launched on the stream they were captured on, which carries nothing else: with eagerly launched KERNELS
         # queued on the launching stream between two replays (an evaluation pass, logging reductions -- copies were harmless) the
         # ROCm 7 runtime's pre-recorded graph packets produced non-finite gradients at fixed positions of a few tensors
-        # (profiles/r03_graph_replay_corruption.md).  MDETR_REPLAY_STREAM=current restores the launch on the caller's stream.
-        own = self.stream is not None and os.environ.get("MDETR_REPLAY_STREAM", "own") != "current"
+        # (profiles/r03_graph_replay_corruption.md).  
+        own = self.stream is not None
         cur = torch.cuda.current_stream(self.device)
         if own:
             self.stream.wait_stream(cur)

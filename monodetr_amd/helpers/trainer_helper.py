@@ -12,7 +12,7 @@ What differs from the reference loop (trainer_helper.py:116-173), and why:
   * on a GPU the iteration is REPLAYED from hipGraphs (``step_helper.TrainIteration``, the object ``bench.py`` times):
     the first iterations of a run are launched eagerly on real batches, then the iteration is captured once and every
     later batch is copied into static device buffers and replayed with one launch (two around the gradient exchange).
-    ``trainer.launch: eager`` in the yaml (or MDETR_TRAIN_LAUNCH=eager) keeps the ~1 700 eager launches per iteration.
+    ``trainer.launch: eager`` in the yaml keeps the ~1 700 eager launches per iteration.
 ``prepare_targets`` is kept for callers that want the reference's ragged lists.
 """
 import os
@@ -103,7 +103,7 @@ class Trainer(object):
     def _iteration(self):
         """The step object, built on first use (after a resume / pretrain load, so that it sees the loaded optimizer)."""
         if self.iteration is None:
-            launch = os.environ.get("MDETR_TRAIN_LAUNCH", self.cfg.get("launch", "graph" if self.device.type == "cuda" else "eager"))
+            launch = self.cfg.get("launch", "graph" if self.device.type == "cuda" else "eager")
             if self.cfg.get("use_dn"):
                 raise NotImplementedError("denoising queries (use_dn) are off in configs/monodetr.yaml and not mirrored")
             pending = self.pending_sync if launch == "graph" else None

@@ -1,7 +1,7 @@
 """The optional kernel families of the training iteration: which exist, which GPU tests hold each to the framework operators,
 which are ON by default (the COMMITTED list: what ``bench.py`` measures and what ``tools/train_val.py`` trains with), and the
 function that switches them at run time.  A family is listed in COMMITTED only with green tests
-(``tests/test_switchprobe_cpu.py`` checks that the tests named here exist).
+(``tests/test_kernel_families_cpu.py`` checks that the tests named here exist).
 
 Each family can also be forced from the environment (``MDETR_<FAMILY>=1``) -- for A/B runs: any such variable replaces the
 committed list altogether (``MDETR_BENCH_DEFAULT_PATH=1`` / ``trainer.kernels: default`` = none at all)."""

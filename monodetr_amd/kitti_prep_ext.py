@@ -99,11 +99,12 @@ def self_check(device):
     out = preprocess_batch(px, ds, out_hw=(24, 40))
     got = hashlib.sha256(out.cpu().contiguous().numpy().tobytes()).hexdigest()
     if got != _SELF_CHECK_SHA256:
-        # MDETR_PREP_SELF_CHECK=warn: a new compiler / architecture may legitimately differ in a last bit (the bit-exact answer
+        # MDETR_TUNE="prep_self_check=warn": a new compiler / architecture may legitimately differ in a last bit (the bit-exact answer
         # is pinned to the reference chain on gfx950 + ROCm 7.2); the operator of such a system decides, not a hard stop
         msg = ("mdetr_kitti_preprocess failed its known-answer check on %s (got %s): the device image path must not be "
-               "trusted (MDETR_PREP_SELF_CHECK=warn continues)" % (device, got[:16]))
-        if os.environ.get("MDETR_PREP_SELF_CHECK", "strict") != "warn":
+               "trusted (MDETR_TUNE=prep_self_check=warn continues)" % (device, got[:16]))
+        from . import _tune
+        if _tune.get("prep_self_check", "strict") != "warn":
             raise RuntimeError(msg)
         import warnings
         warnings.warn(msg)

@@ -46,8 +46,9 @@ def attention_core(q, k, v, num_heads, dropout_p=0.0, key_padding_mask=None):
     GPU tensors with 32 channels per head (the model's geometry) run the gfx950 MFMA kernels of
     monodetr_amd/csrc/attn.hip -- no fallback: a missing library raises.  CPU tensors (the
     reference is plain PyTorch there too) and other head sizes use PyTorch's SDPA;
-    MDETR_ATTN_BACKEND=sdpa forces the comparator on the GPU for A/B measurements."""
-    if q.is_cuda and q.shape[-1] == 32 * num_heads and os.environ.get("MDETR_ATTN_BACKEND", "hip") == "hip":
+    MDETR_TUNE="attn_backend=sdpa" forces the comparator on the GPU (tests)."""
+    from .. import _tune
+    if q.is_cuda and q.shape[-1] == 32 * num_heads and _tune.get("attn_backend", "hip") == "hip":
         if q.dtype not in (torch.float32, torch.bfloat16):
             q, k, v = q.float(), k.float(), v.float()
         if k.dtype != q.dtype or v.dtype != q.dtype:

@@ -248,8 +248,8 @@ def conv_bn(x, conv, bn, relu, skip_out=False, relu_token=None, hand_out_token=F
     return F.relu(x, inplace=True) if relu else x
 
 
-# (A/B switch of the identity-gradient fusion in Bottleneck.forward; MDETR_BOTTLENECK_SKIP=0 = the separate elementwise add)
-_SKIP_FUSE = os.environ.get("MDETR_BOTTLENECK_SKIP", "1") != "0"
+# (the identity-gradient fusion in Bottleneck.forward; False = the separate elementwise add, for tests)
+_SKIP_FUSE = True
 
 
 def _global_hooks():

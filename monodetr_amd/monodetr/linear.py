@@ -26,8 +26,8 @@ _TGEMM = os.environ.get("MDETR_TGEMM") == "1"
 
 
 # rows from which a bf16 weight gradient takes csrc/twgrad.hip instead of csrc/small_wgrad.hip: the decoder's 4 400 and layer4's 3 840
-# rows included (421.7 -> 426.9 img/s, profiles/r05n_step_ab_twgrad_small_rows.log; MDETR_TWGRAD_MIN_ROWS=1000000000 restores round 4's split)
-_TWGRAD_MIN_ROWS = int(os.environ.get("MDETR_TWGRAD_MIN_ROWS", "1024"))
+# rows included (421.7 -> 426.9 img/s, profiles/r05n_step_ab_twgrad_small_rows.log)
+_TWGRAD_MIN_ROWS = 1024
 
 
 # MDETR_RELU_PREMASK=1: the ReLU backward between two kernels of this repository is applied where the CONSUMER's input gradient leaves
@@ -111,7 +111,7 @@ def _weight_bias_grads(x2, dy2, weight, need_w, need_b, bias_dtype=None, out_dty
     dw = db = None
     T = x2.shape[0]
     if need_w and _TWGRAD_MIN_ROWS <= T <= small_wgrad_ext.MAX_ROWS and dt in (torch.float32, torch.bfloat16):
-        # a few thousand rows of bf16 operands (the decoder's 4 400, layer4's 3 840): csrc/twgrad.hip as well (MDETR_TWGRAD_MIN_ROWS)
+        # a few thousand rows of bf16 operands (the decoder's 4 400, layer4's 3 840): csrc/twgrad.hip as well (_TWGRAD_MIN_ROWS)
         from .. import conv_wgrad_ext
         if conv_wgrad_ext.token_supported(x2, dy2):
             return conv_wgrad_ext.token_weight_gradient(x2, dy2, dt, bias=need_b)

@@ -24,10 +24,10 @@ from .... import msda_prologue_ext
 # MDETR_MSDA_PROLOGUE=1: fused softmax + sampling-location kernel (off until its first GPU validation,
 # tests/test_fused_gpu.py)
 _FUSED_PROLOGUE = os.environ.get("MDETR_MSDA_PROLOGUE") == "1"
-# with the prologue kernel: the sampling-offset and attention-weight projections as one GEMM (MDETR_MSDA_PACKED=0: two)
-_PACKED_PROJECTION = os.environ.get("MDETR_MSDA_PACKED", "1") != "0"
-# fp32 values for the decoder's deformable cross-attention in a bf16 model (MDETR_MSDA_WIDE_VALUE=0 restores bf16 values)
-_WIDE_CROSS_VALUE = os.environ.get("MDETR_MSDA_WIDE_VALUE", "1") != "0"
+# with the prologue kernel: the sampling-offset and attention-weight projections as one GEMM (False: two; tests)
+_PACKED_PROJECTION = True
+# fp32 values for the decoder's deformable cross-attention in a bf16 model (False: bf16 values; tests)
+_WIDE_CROSS_VALUE = True
 
 
 

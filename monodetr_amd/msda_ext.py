@@ -19,11 +19,11 @@ from . import _capi
 
 _NAMES5 = ("value", "spatial_shapes", "level_start_index", "sampling_loc", "attn_weight")
 
-# MDETR_MSDA_CPU=1 (or ``allow_cpu(True)``): host tensors go to the C ABI's host entry points mdetr_msda_forward_cpu /
+# ``allow_cpu(True)``: host tensors go to the C ABI's host entry points mdetr_msda_forward_cpu /
 # _backward_cpu instead of raising.  OFF by default: the reference raises for CPU tensors (ops/src/ms_deform_attn.h:38,
 # cpu/ms_deform_attn_cpu.cpp:26,39) and so does this module -- the switch exists so that BASELINE configs[0] (the yaml on a
 # CPU, one training iteration: plumbing) can run at all.  CUDA tensors never take this route, switch or no switch.
-_ALLOW_CPU = os.environ.get("MDETR_MSDA_CPU") == "1"
+_ALLOW_CPU = False
 
 
 def allow_cpu(on=True):
@@ -166,7 +166,7 @@ def _host_args(tensors, names):
 
 
 def _forward_cpu(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
-    """Host tensors through mdetr_msda_forward_cpu (only when MDETR_MSDA_CPU=1 / allow_cpu())."""
+    """Host tensors through mdetr_msda_forward_cpu (only after allow_cpu(True))."""
     args = (value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
     _host_args(args, _NAMES5)
     B, S, M, D, L, Lq, P = _dims(*args, im2col_step)

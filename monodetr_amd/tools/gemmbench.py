@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--no-backward", action="store_true")
     ap.add_argument("--out", default="")
-    ap.add_argument("--env", default="", help="extra tgemm variants, e.g. 'MDETR_TGEMM_PERSIST=0;MDETR_TGEMM_PER_CU=1'")
+    ap.add_argument("--tune", default="", help="extra tgemm variants as MDETR_TUNE strings, e.g. 'tgemm_tile=128x64,tgemm_pf=1;tgemm_grid=512'")
     ap.add_argument("--eager", action="store_true", help="plain launches instead of graph replays (counter passes)")
     a = ap.parse_args()
     global EAGER
@@ -135,21 +135,18 @@ def main():
                 return tgemm_ext.tgemm(x, w, None, rs[i] if tail == "accum" else None, nn=True, out=rs[i] if tail == "accum" else ys[i])
             return tgemm_ext.tgemm(x, w, b, rs[i] if tail == "res_relu" else None, relu=tail in ("relu", "res_relu", "relu_drop"),
                                    out=ys[i], dropout_p=0.1 if tail == "relu_drop" else 0.0, seed=5)
-        for k in ("MDETR_TGEMM_TILE", "MDETR_TGEMM_PF"):
-            os.environ.pop(k, None)
+        os.environ.pop("MDETR_TUNE", None)
         row["tgemm_us"] = graph_time(ours, nsets, a.reps)
         if a.sweep:
             for tile in ("128x128", "128x64", "64x128", "64x64"):
                 for pf in ("1", "2"):
-                    os.environ["MDETR_TGEMM_TILE"], os.environ["MDETR_TGEMM_PF"] = tile, pf
+                    os.environ["MDETR_TUNE"] = "tgemm_tile=%s,tgemm_pf=%s" % (tile, pf)
                     row["tgemm_%s_pf%s_us" % (tile, pf)] = graph_time(ours, nsets, a.reps)
-            for k in ("MDETR_TGEMM_TILE", "MDETR_TGEMM_PF"):
-                os.environ.pop(k, None)
-        for var in [v for v in a.env.split(";") if v]:                # extra variants: "NAME=VAL,NAME2=VAL2;..." (each group timed once)
-            pairs = [kv.split("=") for kv in var.split(",")]
-            for k, v in pairs:
-                os.environ[k] = v
+            os.environ.pop("MDETR_TUNE", None)
+        for var in [v for v in a.tune.split(";") if v]:               # extra variants: "key=value,key=value;..." (each group timed once)
+            os.environ["MDETR_TUNE"] = var
             row["tgemm[%s]_us" % var] = graph_time(ours, nsets, a.reps)
+        os.environ.pop("MDETR_TUNE", None)
             for k, _ in pairs:
                 os.environ.pop(k, None)
         best = min(v for k, v in row.items() if k.startswith("tgemm") and k.endswith("_us"))

@@ -80,7 +80,6 @@ def main():
     ap.add_argument("--dist", default="trained")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--B", type=int, default=8)
-    ap.add_argument("--phases", action="store_true", help="a -DMDETR_PHASES build: cycles per phase of the fused backward (developer)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="bf16 = the mixed-precision operator of the bf16 model body (bf16 value / out / grad_out)")
     a = ap.parse_args()
@@ -104,16 +103,6 @@ def main():
             f_bwd = lambda: msda_ext.ms_deform_attn_backward(v, sh, st, loc, attn, go, 64)
         tf = time_call(f_fwd, a.iters)
         tb = time_call(f_bwd, a.iters)
-        if a.phases:
-            from monodetr_amd import _workspace as W
-            ws = [t for (tag, dev, stm), t in W._live.items() if tag.startswith("msda")][0]
-            ws[64:64 + 192].zero_()
-            f_bwd()
-            torch.cuda.synchronize()
-            ph = ws[64:64 + 192].view(torch.int64).cpu().tolist()
-            names_ph = ["prologue", "zero", "loop(thread0)", "loop_tail_wait", "count_check", "readout", "", "", "w0_candidate", "w0_own", "w0_halo"]
-            for mode, off in (("tiled", 0), ("chunked", 12)):
-                print(name, mode, {n: ph[off + i] for i, n in enumerate(names_ph) if n})
         _capi.profile_enable(True)                            # per-kernel split of one more round, HIP events inside the C ABI
         for _ in range(10):
             f_bwd()

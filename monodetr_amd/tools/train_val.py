@@ -88,7 +88,7 @@ def build_run(cfg, proc):
 def main(argv=None):
     args, cfg = read_args(argv)
     # graph replay (the default on a GPU, trainer.launch: eager opts out): the process group is created after the capture
-    launch = os.environ.get("MDETR_TRAIN_LAUNCH", cfg['trainer'].get('launch', 'graph' if torch.cuda.is_available() else 'eager'))
+    launch = cfg['trainer'].get('launch', 'graph' if torch.cuda.is_available() else 'eager')
     proc = Process(defer_group=(launch == 'graph' and torch.cuda.is_available() and not args.evaluate_only))
     utils_helper.set_random_seed(cfg.get('random_seed', 444) + proc.rank)
     name, logger, (train_loader, test_loader), model, criterion = build_run(cfg, proc)

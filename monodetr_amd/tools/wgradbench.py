@@ -1,8 +1,8 @@
 """Weight + bias gradient of the step's token-wise layers in one process (developer tool): csrc/twgrad.hip (transposing LDS reads)
-against the 1x1 case of csrc/conv_wgrad.hip (MDETR_TWGRAD=0) and, with --library, the library's batched split-K route -- each
+against the 1x1 case of csrc/conv_wgrad.hip (MDETR_TUNE="twgrad=0") and, with --library, the library's batched split-K route -- each
 INCLUDING its chunk sum, timed as graph replays over rotating operand sets (tools/gemmbench.graph_time).
 
-    python -m monodetr_amd.tools.wgradbench [--reps 20] [--env "MDETR_TWGRAD_WGS=512;..."] [--out gpurun_out/wgradbench.json]
+    python -m monodetr_amd.tools.wgradbench [--reps 20] [--tune "twgrad_wgs=512;..."] [--out gpurun_out/wgradbench.json]
 """
 import argparse
 import json
@@ -27,7 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
-    ap.add_argument("--env", default="", help="extra variants of the new kernel, e.g. 'MDETR_TWGRAD_WGS=512;MDETR_TWGRAD_WGS=1024'")
+    ap.add_argument("--tune", default="", help="extra variants of the new kernel as MDETR_TUNE strings, e.g. 'twgrad_wgs=512;twgrad_wgs=1024'")
     ap.add_argument("--library", action="store_true")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
@@ -47,18 +47,14 @@ def main():
         row = {"T": T, "K": K, "N": N, "bound_us": round(max(byts / HBM, flops / MFMA) * 1e6, 2)}
         f = lambda i: linear._weight_bias_grads(xs[i], dys[i], w, True, True)
         conv_wgrad_ext.TOKEN_ROUTE = conv_wgrad_ext.ENABLED = True
-        os.environ.pop("MDETR_TWGRAD", None)
+        os.environ.pop("MDETR_TUNE", None)
         row["twgrad_us"] = graph_time(f, nsets, a.reps) if conv_wgrad_ext.token_supported(xs[0], dys[0]) else None
-        for var in [v for v in a.env.split(";") if v]:
-            pairs = [kv.split("=") for kv in var.split(",")]
-            for k, v in pairs:
-                os.environ[k] = v
+        for var in [v for v in a.tune.split(";") if v]:
+            os.environ["MDETR_TUNE"] = var
             row["twgrad[%s]_us" % var] = graph_time(f, nsets, a.reps)
-            for k, _ in pairs:
-                os.environ.pop(k, None)
-        os.environ["MDETR_TWGRAD"] = "0"
+        os.environ["MDETR_TUNE"] = "twgrad=0"
         row["conv1x1_us"] = graph_time(f, nsets, a.reps) if conv_wgrad_ext.token_supported(xs[0], dys[0]) else None
-        os.environ.pop("MDETR_TWGRAD", None)
+        os.environ.pop("MDETR_TUNE", None)
         if a.library:
             conv_wgrad_ext.TOKEN_ROUTE = False
             row["library_us"] = graph_time(f, nsets, a.reps)

@@ -44,3 +44,19 @@ def make_problem(B, M, D, Lq, shapes, P, dtype, seed=0, lo=0.0, hi=1.0, device="
     grad_out = torch.randn(B, Lq, M * D, generator=g).to(dtype)
     t = dict(value=value, shapes=shapes, level_start=level_start, loc=loc, attn=attn, grad_out=grad_out)
     return {k: v.to(device) for k, v in t.items()}
+
+
+def tune(monkeypatch, **kv):
+    """Set (value) or clear (None) keys of MDETR_TUNE, the one variable through which tests force a launch geometry or an alternative
+    route (monodetr_amd/csrc/mdetr_tune.h, monodetr_amd/_tune.py); the other keys already set stay."""
+    import os
+    cur = dict(item.split("=", 1) for item in os.environ.get("MDETR_TUNE", "").split(",") if "=" in item)
+    for k, v in kv.items():
+        if v is None:
+            cur.pop(k, None)
+        else:
+            cur[k] = str(v)
+    if cur:
+        monkeypatch.setenv("MDETR_TUNE", ",".join("%s=%s" % item for item in cur.items()))
+    else:
+        monkeypatch.delenv("MDETR_TUNE", raising=False)

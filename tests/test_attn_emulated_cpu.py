@@ -8,6 +8,7 @@ import torch
 
 import native_emul
 from test_attn_gpu import keep_mask, reference
+from conftest import tune
 
 
 # default build, and the build with the conflict-free staging map (-DMDETR_ATTN_STAGE_REMAP=1)
@@ -61,7 +62,7 @@ def test_emulated_attention_with_the_key_range_split_over_two_wave_groups(ext, m
     groups into a workgroup, each walking half of the key tiles, and merge the partial softmax states through LDS -- against the
     fp64 reference with the documented dropout mask, a ragged last tile (330 = 5 tiles + 10 keys: the second group's last tile is
     all padding) and a key-padding mask."""
-    monkeypatch.setenv("MDETR_ATTN_KSPLIT", "1")                 # (the launcher reads it per call; off by default: measured slower)
+    tune(monkeypatch, attn_ksplit="1")                 # (the launcher reads it per call; off by default: measured slower)
     torch.manual_seed(11)
     B, H, Lq, Lk, seed = 2, 2, 70, 330, 0x0FEDCBA987654321
     E = H * 32

@@ -7,6 +7,7 @@ import torch
 import torch.nn.functional as F
 
 import native_emul
+from conftest import tune
 
 
 @pytest.fixture()
@@ -36,7 +37,7 @@ def test_strided_convolution_matches_conv2d(ext, B, H, W, C, N, k, relu, use_shi
     # (the launcher narrows the workgroup's output-channel block for problems with few tiles -- every test here: pin it to the
     # widest block the layer allows for half of the cases so that each instantiation runs)
     if (H + W) % 2 == 0:
-        monkeypatch.setenv("MDETR_CONV_TAPS_NB", "4")
+        tune(monkeypatch, conv_taps_nb="4")
     g = torch.Generator().manual_seed(B * 1000 + H * W + C + N + k)
     x = torch.randn(B, C, H, W, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     w = (torch.randn(N, C, k, k, generator=g) / (k * C ** 0.5)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)

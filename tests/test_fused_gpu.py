@@ -7,6 +7,7 @@ import os
 
 import pytest
 import torch
+from conftest import tune  # noqa: E402
 
 pytestmark = [pytest.mark.gpu]
 
@@ -772,7 +773,7 @@ def test_token_wgrad_kernel_gives_weight_and_bias_gradient(T, K, N, form, monkey
     (form 0), the bias gradient riding along: ELEMENT BY ELEMENT against the fp64 products of the same bf16 operands (fp32
     accumulation of exact products; bf16 results: one more rounding); deterministic."""
     from monodetr_amd import conv_wgrad_ext
-    monkeypatch.setenv("MDETR_TWGRAD", form)
+    tune(monkeypatch, twgrad=form)
     monkeypatch.setattr(conv_wgrad_ext, "ENABLED", True)
     g = torch.Generator(device="cuda").manual_seed(T + N)
     x = (torch.randn(T, K, generator=g, device="cuda") * 0.5).to(torch.bfloat16)

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import native_emul
-from conftest import make_problem
+from conftest import make_problem, tune
 from oracle import msda_oracle as oracle
 
 SMALL = [(12, 40), (6, 20), (3, 10), (2, 5)]          # the KITTI pyramid / 4, S = 635
@@ -35,7 +35,7 @@ def fwd(p, code=0):
 
 def bwd(p, code=0, tiled=False, path=None, ws=None):
     """path: None = C ABI without workspace (global atomics); "tiled" / "fused" / "atomic" = mdetr_msda_backward_ex with the
-    grad_value strategy selected through MDETR_MSDA_BWD (`tiled=True` is the round-1 spelling of path="tiled")."""
+    grad_value strategy selected through MDETR_TUNE="msda_bwd=..." (`tiled=True` is the round-1 spelling of path="tiled")."""
     import os
     L = native_emul.lib()
     path = "tiled" if tiled and path is None else path
@@ -45,8 +45,8 @@ def bwd(p, code=0, tiled=False, path=None, ws=None):
     common = (code, p["value"].data_ptr(), p["shapes"].data_ptr(), p["level_start"].data_ptr(), p["loc"].data_ptr(),
               p["attn"].data_ptr(), p["grad_out"].data_ptr(), gv.data_ptr(), gl.data_ptr(), ga.data_ptr(), B, S, M, D, Lv, Lq, P)
     if path is not None:
-        saved = os.environ.get("MDETR_MSDA_BWD")
-        os.environ["MDETR_MSDA_BWD"] = path
+        saved = os.environ.get("MDETR_TUNE")
+        os.environ["MDETR_TUNE"] = ",".join(x for x in ("msda_bwd=" + path, saved) if x)
         try:
             n = L.mdetr_msda_backward_workspace_bytes(code, p["shapes"].data_ptr(), p["level_start"].data_ptr(), B, S, M, D, Lv, Lq, P)
             assert n > 0
@@ -55,9 +55,9 @@ def bwd(p, code=0, tiled=False, path=None, ws=None):
             _check(L.mdetr_msda_backward_ex(*common, p["shapes"].data_ptr(), p["level_start"].data_ptr(), ws.data_ptr(), ws.numel(), 0, None))
         finally:
             if saved is None:
-                del os.environ["MDETR_MSDA_BWD"]
+                del os.environ["MDETR_TUNE"]
             else:
-                os.environ["MDETR_MSDA_BWD"] = saved
+                os.environ["MDETR_TUNE"] = saved
     else:
         _check(L.mdetr_msda_backward(*common, 0, None))
     return gv, gl, ga
@@ -195,9 +195,7 @@ def test_autograd_function_with_native_bf16_matches_the_widening_path(monkeypatc
 
 # ---- (3) the one-pass backward (csrc/msda_fused.hip) ------------------------------------------------------------------
 def _fused_env(monkeypatch, th, tw, reach, whole, chunks):
-    for k, v in (("MDETR_MSDA_TILE_H", th), ("MDETR_MSDA_TILE_W", tw), ("MDETR_MSDA_REACH", reach),
-                 ("MDETR_MSDA_WHOLE_LEVEL_CELLS", whole), ("MDETR_MSDA_CHUNKS", chunks)):
-        monkeypatch.setenv(k, str(v))
+    tune(monkeypatch, msda_tile_h=th, msda_tile_w=tw, msda_reach=reach, msda_whole_level_cells=whole, msda_chunks=chunks)
 
 
 def _oracle_bwd(p):
@@ -302,15 +300,15 @@ def _bwd_bf16(p, vb, gb):
 @pytest.mark.parametrize("threads,lps,groups", [(512, 8, 2), (1024, 4, 2), (768, 4, 4), (1024, 2, 2)])      # (each instantiation family once)
 @pytest.mark.parametrize("th,tw,reach,whole,chunks", [(4, 8, 2, 30, 3)])
 def test_fused_backward_kernel_variants(monkeypatch, threads, lps, groups, th, tw, reach, whole, chunks):
-    """The launch variants behind MDETR_MSDA_THREADS / MDETR_MSDA_LPS / MDETR_MSDA_GROUPS (8-, 12- or 16-wave workgroups; 8 lanes x 4 channels or 4 lanes
+    """The launch variants behind MDETR_TUNE msda_threads / msda_lps / msda_groups (8-, 12- or 16-wave workgroups; 8 lanes x 4 channels or 4 lanes
     x 8 channels per sample, the latter with the packed-bf16 dot products): the bf16 form against the fp32 form on the same
     (widened) tensors and against the oracle, on plans that use tiles with candidates, whole-level chunks, scan-all tiles and
     the `far` buffer (whose fp32 atomics make grad_value depend on the order of the waves: not bit-equal across variants here;
     the integer-accumulated part is, see test_emulated_bf16_kernels_match_the_fp32_kernels_on_widened_tensors)."""
     _fused_env(monkeypatch, th, tw, reach, whole, chunks)
-    monkeypatch.setenv("MDETR_MSDA_THREADS", str(threads))
-    monkeypatch.setenv("MDETR_MSDA_LPS", str(lps))
-    monkeypatch.setenv("MDETR_MSDA_GROUPS", str(groups))
+    tune(monkeypatch, msda_threads=str(threads))
+    tune(monkeypatch, msda_lps=str(lps))
+    tune(monkeypatch, msda_groups=str(groups))
     S = sum(h * w for h, w in SMALL)
     for Lq in (S, 50):
         p = make_problem(1, 2, 32, Lq, SMALL, 4, torch.float32, seed=3, lo=-0.2, hi=1.2)
@@ -337,7 +335,7 @@ def test_fused_backward_bf16_lane_layouts_agree_bit_for_bit_on_near_samples(monk
     vb, gb = (p["value"] * 100).to(torch.bfloat16), p["grad_out"].to(torch.bfloat16)
     wide = dict(p, value=vb.float(), grad_out=gb.float())
     _fused_env(monkeypatch, 4, 8, 3, 30, 3)
-    monkeypatch.setenv("MDETR_MSDA_LPS", str(lps))
+    tune(monkeypatch, msda_lps=str(lps))
     gv, gl, ga = _bwd_bf16(p, vb, gb)
     fv, fl, fa = bwd(wide, path="fused")
     assert torch.equal(gv, fv) and close(gl, fl, 1e-6) and close(ga, fa, 1e-6)

@@ -12,7 +12,7 @@ Tolerances
 import pytest
 import torch
 
-from conftest import load_golden, make_problem
+from conftest import load_golden, make_problem, tune
 
 pytestmark = pytest.mark.gpu
 
@@ -319,7 +319,7 @@ def test_workspace_backward_paths_match_oracle(ext, oracle, shapes, dist, path, 
     round 1's gather + tile scatter + reduce (msda_tiled.hip, MDETR_MSDA_BWD=tiled), for sampling locations that stay near
     the query ("local", the trained-like case), mostly do ("mixed") or are anywhere ("uniform": nearly every corner leaves
     the blocks' reach and takes the global-atomic route)."""
-    monkeypatch.setenv("MDETR_MSDA_BWD", path)
+    tune(monkeypatch, msda_bwd=path)
     B = 2
     p = pyramid_problem(B, shapes, dist, seed=len(shapes) * 7 + len(dist))
     d = dev(p)
@@ -353,7 +353,7 @@ def test_workspace_backward_paths_match_oracle(ext, oracle, shapes, dist, path, 
 
 @pytest.mark.parametrize("path", ["fused", "tiled"])
 def test_workspace_backward_nonfinite_gradients_fall_back(ext, oracle, path, monkeypatch):
-    monkeypatch.setenv("MDETR_MSDA_BWD", path)
+    tune(monkeypatch, msda_bwd=path)
     p = pyramid_problem(1, [(12, 40), (6, 20), (3, 10), (2, 5)], "local", seed=3)
     p["grad_out"][0, 5, 7] = float("inf")
     d = dev(p)

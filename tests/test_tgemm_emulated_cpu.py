@@ -9,6 +9,7 @@ import torch
 
 import native_emul
 from gemm_bounds import assert_product_close
+from conftest import tune
 
 
 def run(a, w, bias=None, res=None, relu=False, nn=False, out=None, out_dtype=torch.bfloat16, p=0.0, seed=0):
@@ -62,8 +63,8 @@ SHAPES = [
 @pytest.mark.parametrize("pf", ["1", "2"])
 @pytest.mark.parametrize("nn", [False, True])
 def test_tgemm_plain_products_every_tile_and_pipeline(monkeypatch, tile, pf, nn):
-    monkeypatch.setenv("MDETR_TGEMM_TILE", tile)
-    monkeypatch.setenv("MDETR_TGEMM_PF", pf)
+    tune(monkeypatch, tgemm_tile=tile)
+    tune(monkeypatch, tgemm_pf=pf)
     for T, K, N in SHAPES[:6]:
         a, w, _, _ = problem(T, K, N, nn, T + K + N)
         y = run(a, w, nn=nn)
@@ -138,15 +139,15 @@ def test_tgemm_rejects_what_it_cannot_run():
 def test_tgemm_persistent_workgroups_walk_several_tiles(monkeypatch, grid, pf, nn):
     """Few workgroups, many tiles each: the slab sequence runs across tile boundaries (the next tile's first slabs are fetched during
     this tile's last products and parked tail), dead row tiles of the rounded-up grid are skipped, column tiles alternate."""
-    monkeypatch.setenv("MDETR_TGEMM_GRID", grid)
-    monkeypatch.setenv("MDETR_TGEMM_PF", pf)
-    monkeypatch.setenv("MDETR_TGEMM_TILE", "64x64")
+    tune(monkeypatch, tgemm_grid=grid)
+    tune(monkeypatch, tgemm_pf=pf)
+    tune(monkeypatch, tgemm_tile="64x64")
     for T, K, N in ((700, 192, 136), (1500, 64, 72), (330, 328, 200)):        # 11 / 24 / 6 row tiles x 3 / 2 / 4 column tiles
         a, w, b, r = problem(T, K, N, nn, T + K + N + 1)
         y = run(a, w, bias=b, res=r, relu=True, nn=nn)
         ref, mag = reference(a, w, nn, b, r, True)
         assert_product_close(y, ref, mag, K, "grid=%s T=%d K=%d N=%d" % (grid, T, K, N))
-    monkeypatch.setenv("MDETR_TGEMM_TILE", "128x128")
+    tune(monkeypatch, tgemm_tile="128x128")
     a, w, b, r = problem(2100, 320, 264, nn, 99)
     y = run(a, w, bias=b, nn=nn)
     ref, mag = reference(a, w, nn, b)
@@ -156,15 +157,15 @@ def test_tgemm_persistent_workgroups_walk_several_tiles(monkeypatch, grid, pf, n
 def test_tgemm_eight_wave_form_of_the_big_tile(monkeypatch):
     """The plain forward product on the 128 x 128 tile runs with 512 threads (waves 2 x 4) and one register set; MDETR_TGEMM_WAVES=4
     restores four waves -- the same values bit for bit (same products in the same order per element)."""
-    monkeypatch.setenv("MDETR_TGEMM_TILE", "128x128")
-    monkeypatch.setenv("MDETR_TGEMM_GRID", "8")
+    tune(monkeypatch, tgemm_tile="128x128")
+    tune(monkeypatch, tgemm_grid="8")
     for T, K, N in ((700, 192, 264), (130, 1032, 72)):
         a, w, b, r = problem(T, K, N, False, T + K)
-        monkeypatch.delenv("MDETR_TGEMM_WAVES", raising=False)
+        tune(monkeypatch, tgemm_waves=None)
         y8 = run(a, w, bias=b, relu=True)
         ref, mag = reference(a, w, False, b, None, True)
         assert_product_close(y8, ref, mag, K, "8 waves T=%d" % T)
-        monkeypatch.setenv("MDETR_TGEMM_WAVES", "4")
+        tune(monkeypatch, tgemm_waves="4")
         assert torch.equal(run(a, w, bias=b, relu=True), y8)
 
 
@@ -186,5 +187,5 @@ def test_masked_input_gradient(T, K, N, with_res, monkeypatch):
     assert bool((y[~keep] == 0).all())
     assert_product_close(torch.where(keep, y.double(), torch.zeros_like(ref)).to(y.dtype), torch.where(keep, ref, torch.zeros_like(ref)), mag, K)
     for tile in ("64x64", "128x64", "64x128", "128x128"):
-        monkeypatch.setenv("MDETR_TGEMM_TILE", tile)
+        tune(monkeypatch, tgemm_tile=tile)
         assert torch.equal(tgemm_ext.tgemm_masked(a, w, mask, res), y)

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from gemm_bounds import assert_product_close
+from conftest import tune
 
 pytestmark = pytest.mark.gpu
 
@@ -69,8 +70,8 @@ def test_tgemm_step_shapes_element_wise_against_fp64(T, K, N, nn, tail):
 @pytest.mark.parametrize("nn", [False, True])
 def test_tgemm_every_tile_shape_and_pipeline_depth(monkeypatch, tile, pf, nn):
     from monodetr_amd import tgemm_ext
-    monkeypatch.setenv("MDETR_TGEMM_TILE", tile)
-    monkeypatch.setenv("MDETR_TGEMM_PF", pf)
+    tune(monkeypatch, tgemm_tile=tile)
+    tune(monkeypatch, tgemm_pf=pf)
     dev = torch.device("cuda", 0)
     for T, K, N in ((4133, 456, 264), (300, 64, 72), (9000, 1032, 136)):
         a, w, b, r = _operands(T, K, N, nn, T + K, dev)

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import native_emul
+from conftest import tune
 
 
 def run(x, dy, with_bias, form="1"):
@@ -33,7 +34,7 @@ def run(x, dy, with_bias, form="1"):
     (33, 8, 8),             # two slabs, everything ragged
 ])
 def test_twgrad_source_on_the_cpu_shim(monkeypatch, T, C, N):
-    monkeypatch.delenv("MDETR_TWGRAD", raising=False)
+    tune(monkeypatch, twgrad=None)
     g = torch.Generator().manual_seed(T + C + N)
     x = (torch.randn(T, C, generator=g) * 0.5).to(torch.bfloat16)
     dy = (torch.randn(T, N, generator=g) * 0.2).to(torch.bfloat16)
@@ -48,14 +49,14 @@ def test_twgrad_source_on_the_cpu_shim(monkeypatch, T, C, N):
 
 def test_twgrad_chunking_is_a_partition(monkeypatch):
     """More workgroups asked for than slabs allow: every chunk keeps at least one slab, the sum over chunks is the whole product."""
-    monkeypatch.setenv("MDETR_TWGRAD_WGS", "8192")
+    tune(monkeypatch, twgrad_wgs="8192")
     g = torch.Generator().manual_seed(1)
     x = (torch.randn(700, 64, generator=g)).to(torch.bfloat16)
     dy = (torch.randn(700, 64, generator=g)).to(torch.bfloat16)
     dw, db, chunks = run(x, dy, True)
     assert chunks == 5                                                 # 22 slabs, at least four per chunk
     assert (dw - dy.double().t() @ x.double()).abs().max() <= 1e-3
-    monkeypatch.setenv("MDETR_TWGRAD", "0")                            # the 1x1 case of csrc/conv_wgrad.hip answers the same entry point
+    tune(monkeypatch, twgrad="0")                            # the 1x1 case of csrc/conv_wgrad.hip answers the same entry point
     x8, dy8 = x[:696].contiguous(), dy[:696].contiguous()
     dw0, db0, _ = run(x8, dy8, True)
     assert (dw0 - dy8.double().t() @ x8.double()).abs().max() <= 1e-3
