@@ -356,35 +356,40 @@ def cpu_msda_op_baseline(warm=3, timed=10, leg_budget_s=25.0, emit=None, min_tim
 
 def cpu_baseline_child(steps=3, batch=2):
     """Runs in a child process of its own (fresh thread pools, no CPU pinning inherited from the GPU process): prints one
-    `CPU-BASELINE {...}` line per finished part so that the parent can keep what was done if it has to cut the child off."""
-    from oracle import msda_oracle                                   # checker, used only in this leg
+    `CPU-BASELINE {...}` line per finished part so that the parent can keep what was done if it has to cut the child off.
+    Two timings of the whole training iteration on the host: with the reference's CPU path as the MSDA operator (the port of
+    `ms_deform_attn_core_pytorch` + autograd: BASELINE.md section 3 -- the headline `value`), and with the C oracle (OpenMP over
+    images and heads) as the operator -- faster than anything the reference could run there, reported beside it."""
+    from oracle import msda_oracle                                   # checkers, used only in this leg
+    from oracle.msda_torch_ref import GridSampleMSDA
     from monodetr_amd.monodetr.ops.functions import ms_deform_attn_func as F_
     cores, logical = _physical_cores()
     torch.set_num_threads(cores)
     _emit("host", {"cores": torch.get_num_threads(), "logical_cpus": logical, "cpu": _cpu_model_name()})
     msda_oracle.build()
     saved = F_.MSDA
-    F_.MSDA = msda_oracle.OracleMSDA
-    try:
-        step = TrainStep(torch.device("cpu"), batch, "fp32", switches=())   # the optional GPU kernels have no business here
-        step()                                                       # warm-up (allocations, oneDNN primitives)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        dt = (time.perf_counter() - t0) / steps
-        del step
-    finally:
-        F_.MSDA = saved
-    _emit("step", {"value": round(batch / dt, 4), "s_per_iter": round(dt, 3), "batch": batch, "steps": steps})
+    for tag, operator, n in (("step", GridSampleMSDA(), max(1, steps - 1)), ("step_oracle_operator", msda_oracle.OracleMSDA, steps)):
+        F_.MSDA = operator
+        try:
+            step = TrainStep(torch.device("cpu"), batch, "fp32", switches=())   # the optional GPU kernels have no business here
+            step()                                                   # warm-up (allocations, oneDNN primitives)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                step()
+            dt = (time.perf_counter() - t0) / n
+            del step
+        finally:
+            F_.MSDA = saved
+        _emit(tag, {"value": round(batch / dt, 4), "s_per_iter": round(dt, 3), "batch": batch, "steps": n})
     cpu_msda_op_baseline(emit=_emit)
 
 
-def cpu_baseline(steps=3, batch=2, timeout_s=300):
+def cpu_baseline(steps=3, batch=2, timeout_s=360):
     """The reported CPU baseline (kind "port": /root/reference cannot travel to the GPU box; its arithmetic is pinned to
-    the reference's by tests/test_oracle_golden.py and tests/test_model_cpu.py).  Two parts, measured in a child process
-    under a hard time limit: the whole training iteration at batch `batch` with PyTorch CPU ops and the C oracle as the
-    MSDA operator (OpenMP over (image, head)) -> `value` in the metric's unit; and the operator-level protocol of
-    BASELINE.md section 3 (`msda_op`)."""
+    the reference's by tests/test_oracle_golden.py and tests/test_model_cpu.py).  Measured in a child process under a hard time
+    limit: the whole training iteration at batch `batch` with PyTorch CPU ops and the port of the reference's CPU path as the MSDA
+    operator -> `value` in the metric's unit; the same with the C oracle as the operator
+    (`oracle_operator`); and section 3's operator-level protocol (`msda_op`)."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")
            and not k.startswith("OMP_") and not k.startswith("MDETR_")}
@@ -411,10 +416,12 @@ def cpu_baseline(steps=3, batch=2, timeout_s=300):
     host, stepr = parts.get("host", {}), parts.get("step", {})
     res = {"value": stepr.get("value"), "unit": "images/sec", "cores": host.get("cores", 0), "logical_cpus": host.get("logical_cpus"),
            "kind": "port", "cpu": host.get("cpu", "unknown"),
-           "sample": "%d training iteration(s) at batch %d (3x384x1280, fp32) after 1 warm-up: PyTorch CPU ops + the C oracle as the MSDA "
-                     "operator; msda_op = BASELINE.md section 3 protocol on oracle/msda_torch_ref (port of ms_deform_attn_core_pytorch), "
-                     "B=8, up to 3 warm-up + 5-10 timed calls (about 25 s) per leg" % (steps, batch),
-           "s_per_iter": stepr.get("s_per_iter"), "msda_op": parts.get("msda_op", {})}
+           "sample": "%s training iteration(s) at batch %d (3x384x1280, fp32) after 1 warm-up: PyTorch CPU ops with the reference's CPU path "
+                     "as the MSDA operator (oracle/msda_torch_ref: the port of ms_deform_attn_core_pytorch, one grid_sample per level, "
+                     "autograd backward) = BASELINE.md section 3's whole-iteration figure; oracle_operator = the same iteration with the C "
+                     "oracle (OpenMP) as the operator; msda_op = section 3's operator protocol on the port, B=8, up to 3 warm-up + 5-10 "
+                     "timed calls (about 25 s) per leg" % (stepr.get("steps", "?"), batch),
+           "s_per_iter": stepr.get("s_per_iter"), "oracle_operator": parts.get("step_oracle_operator", {}), "msda_op": parts.get("msda_op", {})}
     if note:
         res["note"] = note
     return res

@@ -28,3 +28,24 @@ def msda_grid_sample(value, spatial_shapes, sampling_locations, attention_weight
     w = attention_weights.permute(0, 2, 1, 3, 4).reshape(B * M, 1, Lq, L * P)
     out = (sampled * w).sum(-1)                              # [B*M, D, Lq]
     return out.reshape(B, M * D, Lq).transpose(1, 2).contiguous()
+
+
+class GridSampleMSDA:
+    """Stand-in for the extension module object (``MultiScaleDeformableAttention``, ops/src/vision.cpp:13-16) that runs the
+    reference's CPU path -- `msda_grid_sample` forward, its autograd backward -- behind the extension's two functions, so that the
+    whole model can be timed on the host the way the reference would run there (bench.py's ``cpu_baseline`` leg; test
+    infrastructure, never on the product path).  The forward keeps its autograd graph until the matching backward call."""
+
+    def __init__(self):
+        self._graphs = {}
+
+    def ms_deform_attn_forward(self, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+        leaves = [t.detach().requires_grad_(True) for t in (value, sampling_loc, attn_weight)]
+        with torch.enable_grad():
+            out = msda_grid_sample(leaves[0], spatial_shapes.tolist(), leaves[1], leaves[2])
+        self._graphs[(value.data_ptr(), sampling_loc.data_ptr())] = (out, leaves)
+        return out.detach()
+
+    def ms_deform_attn_backward(self, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step):
+        out, leaves = self._graphs.pop((value.data_ptr(), sampling_loc.data_ptr()))
+        return list(torch.autograd.grad(out, leaves, grad_output.to(out.dtype)))
