@@ -133,3 +133,23 @@ def test_conv_module_with_a_trainable_bias_as_in_the_depth_head(ext):
         assert type(conv(x.contiguous()).grad_fn).__name__ != "_Conv3x3Backward"              # NCHW-contiguous input
     finally:
         ext.ENABLED = False
+
+
+@pytest.mark.parametrize("tile", [321, 161, 162, 84, 82])
+@pytest.mark.parametrize("nb", [1, 2, 4])
+def test_every_block_shape_and_width_gives_the_same_convolution(ext, monkeypatch, tile, nb):
+    """The 32 pixels of a wave as 1 x 32, 2 x 16 (second row's columns rotated) or 4 x 8, at 32 / 64 / 128 output channels per workgroup,
+    on a ragged image (H % 4, W % 8 != 0) with two slabs: idle waves, the three-stage load ring running dry, mirrored taps."""
+    from conftest import tune
+    tune(monkeypatch, conv3x3_tile=tile, conv3x3_nb=nb)
+    g = torch.Generator().manual_seed(tile * 10 + nb)
+    x = torch.randn(2, 128, 7, 43, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(128, 128, 3, 3, generator=g) / (3.0 * 128 ** 0.5)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    shift = torch.randn(128, generator=g) * 0.5
+    dy = torch.randn(2, 128, 7, 43, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = ext.conv3x3(x, w, shift, relu=False)
+    y.backward(dy)
+    ref = F.conv2d(x.float(), w.float(), shift, padding=1)
+    gx, = torch.autograd.grad(ref, x, dy.float())
+    close(y.detach(), ref, "y")
+    close(x.grad, gx, "dx")
