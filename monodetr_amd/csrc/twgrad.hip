@@ -55,8 +55,12 @@ __device__ __forceinline__ bf16x8 tr_fragment(const __bf16 *rows, int pitch, int
     return f;
 }
 
-template <int BN, int BC, int TS, int PF>
-__global__ __launch_bounds__(kThreadsW)
+// KG = 2: TWO groups of four waves per workgroup, each with the pipeline and the LDS buffers of a four-wave workgroup, on the even /
+// odd slabs of the chunk; their accumulators are added through LDS at the end.  Same waves per CU as two workgroups of four -- and
+// HALF the fp32 partials to write and to sum again (a partial costs 4 BN BC bytes per workgroup whatever the tile: at [81 600, 256] x
+// [81 600, 256] 128 chunks x 256 KB = 33 MB written and read back, against 84 MB of operands).
+template <int BN, int BC, int TS, int PF, int KG>
+__global__ __launch_bounds__(kThreadsW * KG)
 void twgrad_kernel(const TwgradArgs g)
 {
     constexpr int PN = BN + kRowPad, PC = BC + kRowPad;          // row pitches of the two slab images
@@ -64,9 +68,10 @@ void twgrad_kernel(const TwgradArgs g)
     constexpr int YCH = TS * BN / 8 / kThreadsW, XCH = TS * BC / 8 / kThreadsW;      // 16-byte pieces per thread and slab
     static_assert(YCH >= 1 && XCH >= 1, "a slab gives every thread at least one piece of each operand");
     MDETR_DYNAMIC_LDS(unsigned char, tw_smem);
-    __bf16 *Ys = reinterpret_cast<__bf16 *>(tw_smem);            // [2][TS][PN]
+    const int kg = KG == 1 ? 0 : wave_uniform(static_cast<int>(threadIdx.x) >> 8);      // this wave's group
+    __bf16 *Ys = reinterpret_cast<__bf16 *>(tw_smem) + kg * 2 * TS * (PN + PC);          // [2][TS][PN] of the group
     __bf16 *Xs = Ys + 2 * TS * PN;                               // [2][TS][PC]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int tid = threadIdx.x & (kThreadsW - 1), lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int wn = wave & 1, wc = wave >> 1;
     const int tiles = g.tiles_n * g.tiles_c;
     const int id = blockIdx.x, grp = id >> 3;
@@ -96,17 +101,21 @@ void twgrad_kernel(const TwgradArgs g)
         xdst[j] = row * PC + pc * 8;
     }
     bf16x8 yst[PF][YCH], xst[PF][XCH];
-    auto fetch = [&](int s, bf16x8 (&ys_)[YCH], bf16x8 (&xs_)[XCH]) __attribute__((always_inline)) {
+    // (slab index i of this GROUP: the chunk's slab s_begin + KG i + kg; one beyond the chunk -- the groups run the same number of
+    // iterations, they share the barriers -- reads zeros)
+    auto fetch = [&](int i, bf16x8 (&ys_)[YCH], bf16x8 (&xs_)[XCH]) __attribute__((always_inline)) {
+        const int s = s_begin + KG * i + kg;
         const int64_t t0 = static_cast<int64_t>(s) * TS;
+        const bool live = s < s_end;
 #pragma unroll
         for (int j = 0; j < YCH; ++j) {
             const int64_t t = t0 + yrow[j];
-            ys_[j] = rsrc_load_bf16x8(yr, (t < g.T && ycol[j] != kRsrcOob) ? static_cast<unsigned>(t * g.ldy * 2) + ycol[j] : kRsrcOob, 0u);
+            ys_[j] = rsrc_load_bf16x8(yr, (live && t < g.T && ycol[j] != kRsrcOob) ? static_cast<unsigned>(t * g.ldy * 2) + ycol[j] : kRsrcOob, 0u);
         }
 #pragma unroll
         for (int j = 0; j < XCH; ++j) {
             const int64_t t = t0 + xrow[j];
-            xs_[j] = rsrc_load_bf16x8(xr, (t < g.T && xcol[j] != kRsrcOob) ? static_cast<unsigned>(t * g.ldx * 2) + xcol[j] : kRsrcOob, 0u);
+            xs_[j] = rsrc_load_bf16x8(xr, (live && t < g.T && xcol[j] != kRsrcOob) ? static_cast<unsigned>(t * g.ldx * 2) + xcol[j] : kRsrcOob, 0u);
         }
     };
     auto deposit = [&](int buf, const bf16x8 (&ys_)[YCH], const bf16x8 (&xs_)[XCH]) __attribute__((always_inline)) {
@@ -151,13 +160,13 @@ void twgrad_kernel(const TwgradArgs g)
     };
 
     // ---- slab pipeline (tgemm.hip's): slab s + 1 is written to LDS after the barrier that freed its buffer, PF more are in flight
-    const int ns = s_end - s_begin;
+    const int ns = (s_end - s_begin + KG - 1) / KG;              // iterations of a group
     if (ns > 0) {
-        fetch(s_begin, yst[0], xst[0]);
+        fetch(0, yst[0], xst[0]);
         deposit(0, yst[0], xst[0]);
 #pragma unroll
         for (int p = 0; p < PF; ++p)
-            if (1 + p < ns) fetch(s_begin + 1 + p, yst[p], xst[p]);
+            if (1 + p < ns) fetch(1 + p, yst[p], xst[p]);
         __syncthreads();
         for (int k = 0; k < ns; k += PF) {
 #pragma unroll
@@ -165,11 +174,42 @@ void twgrad_kernel(const TwgradArgs g)
                 const int s = k + p;
                 if (s < ns) {                                    // (uniform)
                     if (s + 1 < ns) deposit((s + 1) & 1, yst[p], xst[p]);
-                    if (s + 1 + PF < ns) fetch(s_begin + s + 1 + PF, yst[p], xst[p]);
+                    if (s + 1 + PF < ns) fetch(s + 1 + PF, yst[p], xst[p]);
                     products(s & 1);
                     __syncthreads();
                 }
             }
+        }
+    }
+    if (KG == 2) {
+        // the second group's accumulators through LDS (register-major: lane-contiguous 256-byte rows, 64 KB for 128 x 128), added by the
+        // first group's wave of the same quadrant: one partial per workgroup
+        float *red = reinterpret_cast<float *>(tw_smem);
+        constexpr int kPerWave = TN * TC * 16 * 64 + TN * 32;     // (the bias sums are the same in all 32 columns: one lane per half stores them)
+        float *mine = red + wave * kPerWave;
+        if (kg == 1) {
+#pragma unroll
+            for (int a_ = 0; a_ < TN; ++a_) {
+#pragma unroll
+                for (int b_ = 0; b_ < TC; ++b_)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mine[((a_ * TC + b_) * 16 + r) * 64 + lane] = acc[a_][b_][r];
+                if (l31 == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mine[TN * TC * 16 * 64 + (a_ * 16 + r) * 2 + half] = accb[a_][r];
+                }
+            }
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int a_ = 0; a_ < TN; ++a_) {
+#pragma unroll
+            for (int b_ = 0; b_ < TC; ++b_)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a_][b_][r] += mine[((a_ * TC + b_) * 16 + r) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accb[a_][r] += mine[TN * TC * 16 * 64 + (a_ * 16 + r) * 2 + half];
         }
     }
 
@@ -192,7 +232,7 @@ void twgrad_kernel(const TwgradArgs g)
 }
 
 struct TwgradPlan {
-    int bn, bc, tiles_n, tiles_c, chunks, slabs, slabs_per_chunk;
+    int bn, bc, tiles_n, tiles_c, chunks, slabs, slabs_per_chunk, kg;
 };
 
 constexpr int kSlab = 32;
@@ -207,22 +247,31 @@ TwgradPlan plan(int64_t T, int C, int N)
     p.slabs = static_cast<int>((T + kSlab - 1) / kSlab);
     // two workgroups per CU, every chunk with at least four slabs: more chunks mean more fp32 partials to write and sum again
     // (256 / 512 / 1024 workgroups at [81 600, 256] x [81 600, 256]: 39.1 / 32.6 / 46.9 us with the chunk sum, profiles/r05h_wgradbench.json)
-    int target = 512;
+    // Two wave groups per workgroup (see the kernel) for the full tile on long token axes: half the workgroups, half the partials
+    // (profiles/r06_wgradbench_kg.json).
+    p.kg = (p.bn == 128 && p.bc == 128 && p.slabs >= 256) ? 2 : 1;
+    { const int f = tune_int("twgrad_kg", 0); if (f == 1 || (f == 2 && p.bn == 128 && p.bc == 128)) p.kg = f; }      // tests / A-B runs
+    int target = 512 / p.kg;
     { const int f = tune_int("twgrad_wgs", 0); if (f >= 64 && f <= 8192) target = f; }       // tests
     int chunks = target / (p.tiles_n * p.tiles_c);
-    if (chunks > p.slabs / 4) chunks = p.slabs / 4;
+    // chunk c runs on XCD c % 8 (all its tiles: the second reader of a slab finds it in that L2), so the chunks come in whole
+    // eights -- 42 chunks of 6 tiles put 36 workgroups on the 32 CUs of two XCDs and 30 on the others: a second round on two
+    if (chunks >= 8) chunks = chunks / 8 * 8;
+    if (chunks > p.slabs / (4 * p.kg)) chunks = p.slabs / (4 * p.kg);
     if (chunks < 1) chunks = 1;
     p.slabs_per_chunk = (p.slabs + chunks - 1) / chunks;
     p.chunks = (p.slabs + p.slabs_per_chunk - 1) / p.slabs_per_chunk;          // every chunk has at least one slab
     return p;
 }
 
-template <int BN, int BC>
+template <int BN, int BC, int KG>
 hipError_t launch_tile(TwgradArgs g, hipStream_t st)
 {
     constexpr int TS = kSlab, PF = 2;
-    constexpr size_t lds = static_cast<size_t>(2) * TS * ((BN + kRowPad) + (BC + kRowPad)) * 2;
-    auto kern = twgrad_kernel<BN, BC, TS, PF>;
+    constexpr size_t slabs_b = static_cast<size_t>(KG) * 2 * TS * ((BN + kRowPad) + (BC + kRowPad)) * 2;
+    constexpr size_t red_b = KG == 2 ? static_cast<size_t>(4) * ((BN / 64) * (BC / 64) * 16 * 64 + (BN / 64) * 32) * 4 : 0;
+    constexpr size_t lds = slabs_b > red_b ? slabs_b : red_b;
+    auto kern = twgrad_kernel<BN, BC, TS, PF, KG>;
     static bool attr_set[64] = {};
     int dev_ = 0;
     if (hipGetDevice(&dev_) != hipSuccess) dev_ = -1;
@@ -233,7 +282,7 @@ hipError_t launch_tile(TwgradArgs g, hipStream_t st)
         if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;
     }
     const int64_t grid = static_cast<int64_t>((g.chunks + 7) / 8 * 8) * g.tiles_n * g.tiles_c;
-    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(kThreadsW), lds, st, g);
+    hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(grid)), dim3(kThreadsW * KG), lds, st, g);
     return hipGetLastError();
 }
 
@@ -259,10 +308,10 @@ hipError_t twgrad_launch(const void *x, const void *dy, float *part, int64_t T, 
     g.with_db = with_db ? 1 : 0;
     ProfileScope prof(11, conv_mflop(T, static_cast<int64_t>(C) * N), st, 2.0 * T * N * C / 1e6,
                       (2.0 * T * (N + C) + 4.0 * p.chunks * (static_cast<double>(N) * C + (with_db ? N : 0))) / 1e3);       // (+ the fp32 partials it writes)
-    if (p.bn == 128 && p.bc == 128) return launch_tile<128, 128>(g, st);
-    if (p.bn == 128) return launch_tile<128, 64>(g, st);
-    if (p.bc == 128) return launch_tile<64, 128>(g, st);
-    return launch_tile<64, 64>(g, st);
+    if (p.bn == 128 && p.bc == 128) return p.kg == 2 ? launch_tile<128, 128, 2>(g, st) : launch_tile<128, 128, 1>(g, st);
+    if (p.bn == 128) return launch_tile<128, 64, 1>(g, st);
+    if (p.bc == 128) return launch_tile<64, 128, 1>(g, st);
+    return launch_tile<64, 64, 1>(g, st);
 }
 
 }  // namespace mdetr

@@ -147,8 +147,6 @@ def main():
             os.environ["MDETR_TUNE"] = var
             row["tgemm[%s]_us" % var] = graph_time(ours, nsets, a.reps)
         os.environ.pop("MDETR_TUNE", None)
-            for k, _ in pairs:
-                os.environ.pop(k, None)
         best = min(v for k, v in row.items() if k.startswith("tgemm") and k.endswith("_us"))
         row["tgemm_best_us"], row["tgemm_frac_of_bound"] = best, round(row["bound_us"] / best, 3)
         # ---- agreement (one set): element-wise against the fp64 product is the tests' job; here the two paths side by side

@@ -60,3 +60,26 @@ def test_twgrad_chunking_is_a_partition(monkeypatch):
     x8, dy8 = x[:696].contiguous(), dy[:696].contiguous()
     dw0, db0, _ = run(x8, dy8, True)
     assert (dw0 - dy8.double().t() @ x8.double()).abs().max() <= 1e-3
+
+
+@pytest.mark.parametrize("T,C,N", [
+    (4101, 256, 256),       # four tiles; an odd number of slabs in the last chunk: one group's last slab is beyond it
+    (1000, 160, 136),       # ragged tiles in both directions
+    (40, 128, 128),         # two slabs in all: one per group
+])
+def test_two_wave_groups_per_workgroup_give_the_same_sums(monkeypatch, T, C, N):
+    """twgrad_kg=2: eight waves, the even / odd slabs of a chunk on two groups with their own LDS buffers, accumulators (and the bias
+    sums) added through LDS -- half the partials; against the one-group kernel on the same operands."""
+    g = torch.Generator().manual_seed(T * 3 + C + N)
+    x = (torch.randn(T, C, generator=g) * 0.5).to(torch.bfloat16)
+    dy = (torch.randn(T, N, generator=g) * 0.2).to(torch.bfloat16)
+    tune(monkeypatch, twgrad_kg="1", twgrad_wgs="64")
+    dw1, db1, chunks1 = run(x, dy, True)
+    tune(monkeypatch, twgrad_kg="2", twgrad_wgs="64")
+    dw2, db2, chunks2 = run(x, dy, True)
+    assert chunks2 <= chunks1
+    rw, rb = dy.double().t() @ x.double(), dy.double().sum(0)
+    mag = dy.double().abs().t() @ x.double().abs()
+    for dw, db in ((dw1, db1), (dw2, db2)):
+        assert bool(((dw - rw).abs() <= 4 * (T ** 0.5) * 2.0 ** -23 * mag + 1e-30).all())
+        assert bool(((db - rb).abs() <= 4 * (T ** 0.5) * 2.0 ** -23 * dy.double().abs().sum(0) + 1e-30).all())
