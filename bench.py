@@ -498,7 +498,7 @@ FAMILY_PATTERNS = (      # (family, substrings of the kernel name, profile kinds
     ("weight_fold", ("fold_kernel",), (20,)),
     ("msda", ("msda", "prologue_fwd", "prologue_bwd"), ()),
     ("attention", ("attn_",), ()),
-    ("losses_matching_optimizer", ("pair_losses", "ddn_", "lsa_kernel", "adamw_kernel", "multi_tensor_apply"), ()),
+    ("losses_matching_optimizer", ("pair_losses", "ddn_", "lsa_kernel", "adamw_", "multi_tensor_apply"), ()),
     ("library_gemm", ("Cijk_",), ()),
     ("framework_elementwise", ("elementwise", "vectorized", "CatArray", "reduce_kernel", "rocclr", "index", "gather", "scatter", "softmax", "copy"), ()),
 )

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDETR_ABI_VERSION 9
+#define MDETR_ABI_VERSION 10
 
 /* element types of the floating-point tensors */
 #define MDETR_F32 0
@@ -321,6 +321,18 @@ int mdetr_adamw_step(int param_dtype, void *param, float *master, const void *gr
 int mdetr_adamw_step_counted(int param_dtype, void *param, float *master, const void *grad, float *exp_avg, float *exp_avg_sq,
                              int64_t n, int64_t n_no_decay, float beta1, float beta2, float eps, float weight_decay,
                              const double *step_count_dev, float lr, const double *lr_dev, int device, void *stream);
+/* The same update with the gradients WHERE AUTOGRAD LEFT THEM -- no flat gradient buffer, no copy into one (the reference's loop reads
+ * p.grad tensor by tensor, lib/helpers/optimizer_helper.py:96-129; so does this).  grad_ptrs[i] (host array) = base address of the
+ * gradient of tensor i, same dtype and memory layout as its parameter; flat_offsets[i] / nbytes[i] (device, int64) = byte offset of
+ * tensor i in `param` (x 2 in the fp32 arrays of a bf16 group: they are indexed by ELEMENT) and its size in bytes; a workgroup
+ * takes up to chunk_bytes of one tensor: block_tensor / block_start (device) name tensor and byte start per workgroup,
+ * tensor_block_begin (host, ntensors + 1) the first workgroup of every tensor -- the tables of mdetr_gather_flat.  Step size:
+ * step_count_dev (as mdetr_adamw_step_counted) if not NULL, else step_size_dev if not NULL, else step_size. */
+int mdetr_adamw_step_gathered(int param_dtype, void *param, float *master, const void *const *grad_ptrs, int ntensors,
+                              const int *tensor_block_begin, const int64_t *flat_offsets, const int64_t *nbytes, const int *block_tensor,
+                              const int64_t *block_start, int chunk_bytes, float *exp_avg, float *exp_avg_sq, int64_t n_no_decay,
+                              float beta1, float beta2, float eps, float weight_decay, float step_size, const float *step_size_dev,
+                              const double *step_count_dev, float lr, const double *lr_dev, int device, void *stream);
 
 /*
  * y[T, N] = dropout(relu(a[T, K] op(w) + bias + res)) in bf16 on the matrix cores, every part of the tail optional: the general

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDETR_LIB_PATH") or os.path.join(_HERE, "libmonodetr_amd.so")
 
 MDETR_F32, MDETR_F64, MDETR_BF16 = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -43,6 +43,8 @@ SIGNATURES = {
     "mdetr_pair_losses_forward": (_c_int, [_c_vp] * 14 + [_c_int] * 6 + [ctypes.c_float, ctypes.c_float] + [_c_vp] * 4 + [_c_int, _c_vp]),
     "mdetr_pair_losses_backward": (_c_int, [_c_vp] * 13 + [_c_int] * 6 + [ctypes.c_float, ctypes.c_float] + [_c_vp] * 8 + [_c_int, _c_vp]),
     "mdetr_adamw_step": (_c_int, [_c_int] + [_c_vp] * 5 + [ctypes.c_int64] * 2 + [ctypes.c_float] * 5 + [_c_vp, _c_int, _c_vp]),
+    "mdetr_adamw_step_gathered": (_c_int, [_c_int, _c_vp, _c_vp, _c_vp, _c_int] + [_c_vp] * 5 + [_c_int, _c_vp, _c_vp, ctypes.c_int64] + [ctypes.c_float] * 5
+                                  + [_c_vp, _c_vp, ctypes.c_float, _c_vp, _c_int, _c_vp]),
     "mdetr_adamw_step_counted": (_c_int, [_c_int] + [_c_vp] * 5 + [ctypes.c_int64] * 2 + [ctypes.c_float] * 4 + [_c_vp, ctypes.c_float, _c_vp, _c_int, _c_vp]),
     "mdetr_tgemm": (_c_int, [_c_vp] * 5 + [ctypes.c_int64, _c_int, _c_int] + [ctypes.c_int64] * 4 + [_c_int, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),
     "mdetr_sgemm_workspace_bytes": (ctypes.c_int64, [_c_int, _c_vp, _c_int]),

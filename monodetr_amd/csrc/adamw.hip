@@ -80,7 +80,81 @@ void adamw_kernel(P *__restrict__ param, float *__restrict__ master, const P *__
     }
 }
 
+// The same update with the gradients where autograd left them: no flat gradient buffer and no copy into one (the multi-tensor copy
+// of ~300 gradients was 7 launches and 0.12 ms per iteration, profiles/r06z7_opmap.txt).  A workgroup owns up to `chunk_bytes` of ONE
+// parameter tensor (the tables of csrc/decimate.hip's gather_flat_kernel: tensor and byte offset per workgroup); the gradients' base
+// addresses travel as kernel arguments, kAdamPtrs per launch (a captured graph bakes them into its node, like any other argument).
+constexpr int kAdamPtrs = 256;
+struct GradPtrs { const unsigned char *p[kAdamPtrs]; };
+
+template <typename P>
+__global__ __launch_bounds__(256)
+void adamw_gathered_kernel(const GradPtrs grads, int tensor0, int block0, P *__restrict__ param, float *__restrict__ master,
+                           float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, const int64_t *__restrict__ dst_off,
+                           const int64_t *__restrict__ nbytes, const int *__restrict__ blk_tensor, const int64_t *__restrict__ blk_start,
+                           int chunk_bytes, int64_t n_no_decay, AdamWCoef c, float step_host, const float *__restrict__ step_dev,
+                           const double *__restrict__ count_dev, const double *__restrict__ lr_dev, float lr_host)
+{
+    float step = step_dev ? *step_dev : step_host;
+    if (count_dev) {
+        const double t = *count_dev, lr = lr_dev ? *lr_dev : static_cast<double>(lr_host);
+        step = static_cast<float>(lr * sqrt(1.0 - pow(static_cast<double>(c.beta2), t)) / (1.0 - pow(static_cast<double>(c.beta1), t)));
+    }
+    const int b = block0 + static_cast<int>(blockIdx.x);
+    const int ti = blk_tensor[b];
+    const int64_t s0 = blk_start[b], left = nbytes[ti] - s0;
+    const int ne = static_cast<int>((left < chunk_bytes ? left : chunk_bytes) / static_cast<int64_t>(sizeof(P)));     // elements of this workgroup
+    const P *gp = reinterpret_cast<const P *>(grads.p[ti - tensor0] + s0);
+    const int64_t e0 = (dst_off[ti] + s0) / static_cast<int64_t>(sizeof(P));                                        // first element in the flat arrays
+    const bool vec = ((reinterpret_cast<uintptr_t>(gp) | static_cast<uintptr_t>(e0 * sizeof(P))) & (4 * sizeof(P) - 1)) == 0;      // (uniform)
+    const int nv = vec ? ne & ~3 : 0;
+    for (int k = threadIdx.x * 4; k < nv; k += 256 * 4) {
+        const int64_t i0 = e0 + k;
+        float g[4], m[4], v[4], q[4];
+        load4(gp + k, g); load4(exp_avg + i0, m); load4(exp_avg_sq + i0, v); load4(master + i0, q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            q[j] = adamw_element(q[j], g[j], m[j], v[j], c, i0 + j < n_no_decay ? 0.f : c.weight_decay, step);
+        store4(exp_avg + i0, m); store4(exp_avg_sq + i0, v); store4(master + i0, q);
+        if (sizeof(P) == 2) store4(param + i0, q);
+    }
+    for (int k = nv + threadIdx.x; k < ne; k += 256) {
+        const int64_t i = e0 + k;
+        float m = exp_avg[i], v = exp_avg_sq[i];
+        const float q = adamw_element(master[i], to_f32<P>(gp[k]), m, v, c, i < n_no_decay ? 0.f : c.weight_decay, step);
+        exp_avg[i] = m; exp_avg_sq[i] = v; master[i] = q;
+        if (sizeof(P) == 2) param[i] = static_cast<P>(q);
+    }
+}
+
 }  // namespace
+
+hipError_t adamw_gathered_launch(int param_dtype, void *param, float *master, const void *const *grads_host, int ntensors,
+                                 const int *tensor_block_begin_host, const int64_t *dst_off, const int64_t *nbytes, const int *blk_tensor,
+                                 const int64_t *blk_start, int chunk_bytes, float *exp_avg, float *exp_avg_sq, int64_t n_no_decay,
+                                 float beta1, float beta2, float eps, float weight_decay, float step_host, const float *step_dev,
+                                 hipStream_t st, const double *count_dev, const double *lr_dev, float lr_host)
+{
+    const AdamWCoef c{beta1, beta2, eps, weight_decay};
+    for (int t0 = 0; t0 < ntensors; t0 += kAdamPtrs) {
+        const int t1 = t0 + kAdamPtrs < ntensors ? t0 + kAdamPtrs : ntensors;
+        const int b0 = tensor_block_begin_host[t0], b1 = tensor_block_begin_host[t1];
+        if (b1 <= b0) continue;
+        GradPtrs ptrs;
+        for (int i = 0; i < kAdamPtrs; ++i) ptrs.p[i] = t0 + i < t1 ? static_cast<const unsigned char *>(grads_host[t0 + i]) : nullptr;
+        if (param_dtype == 2)
+            hipLaunchKernelGGL(adamw_gathered_kernel<__hip_bfloat16>, dim3(static_cast<unsigned>(b1 - b0)), dim3(256), 0, st, ptrs, t0, b0,
+                               static_cast<__hip_bfloat16 *>(param), master, exp_avg, exp_avg_sq, dst_off, nbytes, blk_tensor, blk_start,
+                               chunk_bytes, n_no_decay, c, step_host, step_dev, count_dev, lr_dev, lr_host);
+        else
+            hipLaunchKernelGGL(adamw_gathered_kernel<float>, dim3(static_cast<unsigned>(b1 - b0)), dim3(256), 0, st, ptrs, t0, b0,
+                               static_cast<float *>(param), master, exp_avg, exp_avg_sq, dst_off, nbytes, blk_tensor, blk_start,
+                               chunk_bytes, n_no_decay, c, step_host, step_dev, count_dev, lr_dev, lr_host);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 
 hipError_t adamw_launch(int param_dtype, void *param, float *master, const void *grad, float *exp_avg,
                         float *exp_avg_sq, int64_t n, int64_t n_no_decay, float beta1, float beta2, float eps,

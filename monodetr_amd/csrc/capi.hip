@@ -482,6 +482,36 @@ int mdetr_adamw_step_counted(int param_dtype, void *param, float *master, const 
     return MDETR_OK;
 }
 
+int mdetr_adamw_step_gathered(int param_dtype, void *param, float *master, const void *const *grad_ptrs, int ntensors,
+                              const int *tensor_block_begin, const int64_t *flat_offsets, const int64_t *nbytes, const int *block_tensor,
+                              const int64_t *block_start, int chunk_bytes, float *exp_avg, float *exp_avg_sq, int64_t n_no_decay,
+                              float beta1, float beta2, float eps, float weight_decay, float step_size, const float *step_size_dev,
+                              const double *step_count_dev, float lr, const double *lr_dev, int device, void *stream)
+{
+    if (param_dtype != MDETR_F32 && param_dtype != MDETR_BF16)
+        return fail(MDETR_E_ARG, "mdetr_adamw_step_gathered: parameter dtype must be f32 or bf16");
+    const int esz = param_dtype == MDETR_F32 ? 4 : 2;
+    if (ntensors < 0 || n_no_decay < 0 || chunk_bytes <= 0 || chunk_bytes % 16 != 0)
+        return fail(MDETR_E_ARG, "mdetr_adamw_step_gathered: ntensors %d / chunk_bytes %d (a positive multiple of 16)", ntensors, chunk_bytes);
+    if (ntensors == 0) return MDETR_OK;
+    if (!param || !master || !grad_ptrs || !tensor_block_begin || !flat_offsets || !nbytes || !block_tensor || !block_start || !exp_avg || !exp_avg_sq)
+        return fail(MDETR_E_ARG, "mdetr_adamw_step_gathered: null pointer");
+    if (param_dtype == MDETR_F32 && static_cast<void *>(master) != param)
+        return fail(MDETR_E_ARG, "mdetr_adamw_step_gathered: an f32 parameter is its own master copy");
+    if (!aligned16(param) || !aligned16(master) || !aligned16(exp_avg) || !aligned16(exp_avg_sq))
+        return fail(MDETR_E_ALIGN, "mdetr_adamw_step_gathered: buffers must be 16-byte aligned");
+    for (int i = 0; i < ntensors; ++i)
+        if (!grad_ptrs[i] || tensor_block_begin[i + 1] < tensor_block_begin[i] || (reinterpret_cast<uintptr_t>(grad_ptrs[i]) & (esz - 1)))
+            return fail(MDETR_E_ARG, "mdetr_adamw_step_gathered: tensor %d: null / misaligned gradient or decreasing block table", i);
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_adamw_step_gathered: set device %d: %s", device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::adamw_gathered_launch(param_dtype, param, master, grad_ptrs, ntensors, tensor_block_begin, flat_offsets, nbytes, block_tensor,
+                                                      block_start, chunk_bytes, exp_avg, exp_avg_sq, n_no_decay, beta1, beta2, eps, weight_decay,
+                                                      step_size, step_size_dev, static_cast<hipStream_t>(stream), step_count_dev, lr_dev, lr);
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_adamw_step_gathered: launch failed: %s", hipGetErrorString(e));
+    return MDETR_OK;
+}
+
 int mdetr_tgemm(const void *a, const void *w, const void *bias, const void *res, void *y, int64_t T, int N, int K,
                 int64_t lda, int64_t ldw, int64_t ldr, int64_t ldy, int flags, float dropout_p, uint64_t seed,
                 const void *seed_dev, int device, void *stream)

@@ -24,6 +24,8 @@ import math
 import os
 
 import torch
+
+from .. import _tune
 import torch.optim as optim
 from torch.optim.optimizer import Optimizer
 
@@ -221,11 +223,11 @@ class FusedAdamW(AdamW):
         self._flat = None
         self._lib = None                         # tests substitute a host build of the same kernel arithmetic
         self._allow_cpu = False
-        # _gather = True: the flat gradient buffer is filled by csrc/decimate.hip's gather (one launch per flat buffer over a
-        # block table) instead of the framework's multi-tensor copy.  Off: measured 388.2 vs 387.5 img/s under graph replay (noise;
-        # again 461.5 vs 461.6 in round 6, profiles/r06p_) and 279.8 vs 286.3 launched eagerly -- filling 307 pointers from Python
-        # costs more than the copy kernels it saves (profiles/r03g2_bench_*.json).  Tests switch it on.
-        self._gather = False
+        # _gather = True: the update reads every gradient where autograd left it (csrc/adamw.hip adamw_gathered_kernel over a block
+        # table, base addresses as kernel arguments) -- no flat gradient buffer and no multi-tensor copy into one (7 launches, 0.12 ms
+        # per iteration).  Off = the flat form.  (Round 3's gather INTO the flat buffer ahead of the flat update moved the same bytes
+        # as the copy it replaced and measured the same: profiles/r03g2_bench_*.json, r06p_.)
+        self._gather = _tune.get("adamw_gather", "1") != "0"           # (MDETR_TUNE=adamw_gather=0: A-B runs)
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)      # AdamW.load_state_dict: keeps the saved dtypes
@@ -301,8 +303,8 @@ class FusedAdamW(AdamW):
                 if len(steps) != 1:
                     raise RuntimeError("FusedAdamW: the parameters of a flat group must have taken the same number of steps")
                 buf['grad_views'], buf['step'] = grad_views, steps.pop()
-                if dev.type == "cuda":
-                    # tables of the flat gradient gather (csrc/decimate.hip gather_flat_kernel): one 32 KB chunk of one tensor per workgroup
+                if True:
+                    # tables of the gathered update (csrc/adamw.hip adamw_gathered_kernel): one 32 KB chunk of one tensor per workgroup
                     esz = buf['grad'].element_size()
                     chunk, bt, bs = self._GATHER_CHUNK, [], []
                     for i, (p, off) in enumerate(zip(plist, offs)):
@@ -345,62 +347,62 @@ class FusedAdamW(AdamW):
                 if g.stride() != p.stride():          # (the multi-tensor copy leaves its fused path on any stride mismatch)
                     g = g.as_strided(p.shape, p.stride(), g.storage_offset()) if _same_layout(g, p) else torch.empty_like(p).copy_(g)
                 grads.append(g)
-            gather = buf.get('gather') if self._gather else None
-            gfn = getattr(lib, "mdetr_gather_flat", None) if gather is not None else None
-            if gfn is not None:
-                # the gradients' base addresses travel as kernel arguments (autograd allocates them anew each iteration; a captured
-                # graph bakes them into its node): nothing on the device to refresh
-                ptrs = gather['ptrs']
-                for i, g in enumerate(grads):
-                    ptrs[i] = g.data_ptr()
-                gdev = buf['grad'].device
-                rc = gfn(ptrs, len(grads), gather['begin'], buf['grad'].data_ptr(), gather['dst_off'].data_ptr(), gather['nbytes'].data_ptr(),
-                         gather['blk_tensor'].data_ptr(), gather['blk_start'].data_ptr(), self._GATHER_CHUNK,
-                         gdev.index, torch.cuda.current_stream(gdev).cuda_stream)
-                if rc != 0:
-                    _capi.check(rc, "mdetr_gather_flat")
-                buf['_keep'] = grads                              # the launch reads them: alive until the next step replaces the list
-            else:
-                torch._foreach_copy_(buf['grad_views'], grads)
             buf['step'] += 1
             t = buf['step']
             for p in buf['params']:
                 self.state[p]['step'] = t
-            step_dev = None
             dev = buf['param'].device
+            dtype_code = _capi.MDETR_BF16 if buf['dtype'] == torch.bfloat16 else _capi.MDETR_F32
+            dev_index = dev.index if dev.type == "cuda" else -1
+            stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None
+            n_no_decay = buf['n'] if group['weight_decay'] == 0 else 0
+            # where the step size comes from: a device-resident step count (capturable: one launch, nothing else), a device scalar,
+            # or the host
+            tdev = step_dev = None
+            lr = group['lr']
+            lr_dev = lr if torch.is_tensor(lr) and lr.dtype == torch.float64 and lr.device == dev else None
+            counted = getattr(lib, "mdetr_adamw_step_counted", None)
             if group['capturable']:
                 group['calls'] = group.get('calls', 0)            # the device counters are keyed like the parent's
-                counted = getattr(lib, "mdetr_adamw_step_counted", None)
                 if counted is not None:
-                    # the step count advances on the device (one launch); the kernel derives the bias-corrected step size from it
-                    # and from the (device-resident) learning rate itself
                     tdev = buf.get('step_dev')
                     if tdev is None:
                         tdev = buf['step_dev'] = torch.full((), float(t - 1), dtype=torch.float64, device=dev)
                     tdev.add_(1.0)
-                    lr = group['lr']
-                    lr_dev = lr if torch.is_tensor(lr) and lr.dtype == torch.float64 and lr.device == dev else None
-                    rc = counted(
-                        _capi.MDETR_BF16 if buf['dtype'] == torch.bfloat16 else _capi.MDETR_F32,
-                        buf['param'].data_ptr(), buf['master'].data_ptr(), buf['grad'].data_ptr(),
-                        buf['exp_avg'].data_ptr(), buf['exp_avg_sq'].data_ptr(), buf['n'],
-                        buf['n'] if group['weight_decay'] == 0 else 0, beta1, beta2, group['eps'], group['weight_decay'],
-                        tdev.data_ptr(), 0.0 if lr_dev is not None else float(lr), lr_dev.data_ptr() if lr_dev is not None else None,
-                        dev.index if dev.type == "cuda" else -1,
-                        torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None)
-                    if rc != 0:
-                        _capi.check(rc, "mdetr_adamw_step_counted")
-                    continue
-                step_dev = self._fused_step_size(group, buf, t)
-            step = float(group['lr']) * math.sqrt(1 - beta2 ** t) / (1 - beta1 ** t) if step_dev is None else 0.0
-            rc = lib.mdetr_adamw_step(
-                _capi.MDETR_BF16 if buf['dtype'] == torch.bfloat16 else _capi.MDETR_F32,
-                buf['param'].data_ptr(), buf['master'].data_ptr(), buf['grad'].data_ptr(),
-                buf['exp_avg'].data_ptr(), buf['exp_avg_sq'].data_ptr(), buf['n'],
-                buf['n'] if group['weight_decay'] == 0 else 0, beta1, beta2, group['eps'], group['weight_decay'],
-                step, step_dev.data_ptr() if step_dev is not None else None,
-                dev.index if dev.type == "cuda" else -1,
-                torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else None)
+                else:
+                    step_dev = self._fused_step_size(group, buf, t)
+            step = float(lr) * math.sqrt(1 - beta2 ** t) / (1 - beta1 ** t) if (tdev is None and step_dev is None) else 0.0
+            lr_host = 0.0 if (lr_dev is not None or tdev is None) else float(lr)
+            gather = buf.get('gather') if self._gather else None
+            gathered = getattr(lib, "mdetr_adamw_step_gathered", None) if gather is not None else None
+            if gathered is not None:
+                # the kernel reads every gradient where autograd left it (base addresses as kernel arguments: autograd allocates them anew
+                # each iteration, a captured graph bakes them into its node): no flat gradient buffer, no copy into one
+                ptrs = gather['ptrs']
+                for i, g in enumerate(grads):
+                    ptrs[i] = g.data_ptr()
+                rc = gathered(dtype_code, buf['param'].data_ptr(), buf['master'].data_ptr(), ptrs, len(grads), gather['begin'],
+                              gather['dst_off'].data_ptr(), gather['nbytes'].data_ptr(), gather['blk_tensor'].data_ptr(), gather['blk_start'].data_ptr(),
+                              self._GATHER_CHUNK, buf['exp_avg'].data_ptr(), buf['exp_avg_sq'].data_ptr(), n_no_decay,
+                              beta1, beta2, group['eps'], group['weight_decay'], step, step_dev.data_ptr() if step_dev is not None else None,
+                              tdev.data_ptr() if tdev is not None else None, lr_host, lr_dev.data_ptr() if (lr_dev is not None and tdev is not None) else None,
+                              dev_index, stream)
+                if rc != 0:
+                    _capi.check(rc, "mdetr_adamw_step_gathered")
+                buf['_keep'] = grads                              # the launch reads them: alive until the next step replaces the list
+                continue
+            torch._foreach_copy_(buf['grad_views'], grads)
+            if tdev is not None:
+                rc = counted(dtype_code, buf['param'].data_ptr(), buf['master'].data_ptr(), buf['grad'].data_ptr(),
+                             buf['exp_avg'].data_ptr(), buf['exp_avg_sq'].data_ptr(), buf['n'], n_no_decay, beta1, beta2, group['eps'],
+                             group['weight_decay'], tdev.data_ptr(), lr_host, lr_dev.data_ptr() if lr_dev is not None else None, dev_index, stream)
+                if rc != 0:
+                    _capi.check(rc, "mdetr_adamw_step_counted")
+                continue
+            rc = lib.mdetr_adamw_step(dtype_code, buf['param'].data_ptr(), buf['master'].data_ptr(), buf['grad'].data_ptr(),
+                                      buf['exp_avg'].data_ptr(), buf['exp_avg_sq'].data_ptr(), buf['n'], n_no_decay, beta1, beta2,
+                                      group['eps'], group['weight_decay'], step, step_dev.data_ptr() if step_dev is not None else None,
+                                      dev_index, stream)
             if rc != 0:
                 _capi.check(rc, "mdetr_adamw_step")
         return loss
