@@ -30,6 +30,10 @@ from . import _cut
 from ..utils.misc import inverse_sigmoid, no_padding
 from .attention import MultiheadAttention as FusedMultiheadAttention
 from .heads import heads_level
+from .. import _tune
+
+# the decoder's layers read the encoder's memory in a chain (MSDeformAttn.forward, chain_input); MDETR_TUNE=decoder_chain=0: A-B runs
+_CHAIN_MEMORY = _tune.get("decoder_chain", "1") != "0"
 from .linear import Linear, ffn_hidden, token_linear
 from .ops.modules import MSDeformAttn, MSDeformAttn_cross, MultiheadAttention  # noqa: F401  (reference :11)
 
@@ -288,9 +292,10 @@ class DepthAwareDecoderLayer(nn.Module):
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes, level_start_index,
                 src_padding_mask, depth_pos_embed, mask_depth, bs, query_sine_embed=None, is_first=None,
-                depth_pos_embed_ip=None, pos_embeds=None, self_attn_mask=None, query_pos_un=None):
+                depth_pos_embed_ip=None, pos_embeds=None, self_attn_mask=None, query_pos_un=None, chain_src=False):
         """tgt, query_pos [B, Nq, C]; depth_pos_embed [HW/256, B, C] (sequence-first, as the reference
-        passes it); mask_depth [B, HW/256] or None."""
+        passes it); mask_depth [B, HW/256] or None.  chain_src: -> (tgt, src') with src' == src for the next layer
+        (`MSDeformAttn.forward`, chain_input)."""
         B, Nq, C = tgt.shape
         depth_tokens = depth_pos_embed.transpose(0, 1)
         # depth cross attention
@@ -308,9 +313,11 @@ class DepthAwareDecoderLayer(nn.Module):
         tgt = residual_layernorm(tgt, s, self.norm2, self.dropout2)
         # deformable cross attention into the visual memory
         c = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
-                            level_start_index, src_padding_mask)
+                            level_start_index, src_padding_mask, chain_input=chain_src)
+        if chain_src:
+            c, src = c
         tgt = residual_layernorm(tgt, c, self.norm1, self.dropout1)
-        return self.forward_ffn(tgt)
+        return (self.forward_ffn(tgt), src) if chain_src else self.forward_ffn(tgt)
 
 
 class DepthAwareDecoder(nn.Module):
@@ -348,10 +355,13 @@ class DepthAwareDecoder(nn.Module):
                 ref_in = reference_points[:, :, None].expand(-1, -1, L, -1)
             else:
                 ref_in = reference_points[:, :, None] * src_valid_ratios.repeat(1, 1, nd // 2)[:, None]
+            # (the layers read the memory one after the other: `src` continues from the previous reader)
             output = layer(output, query_pos, ref_in, src, src_spatial_shapes, src_level_start_index,
                            src_padding_mask, depth_pos_embed, mask_depth, bs, query_sine_embed=None,
                            is_first=(lid == 0), depth_pos_embed_ip=depth_pos_embed_ip, pos_embeds=pos_embeds,
-                           self_attn_mask=attn_mask, query_pos_un=None)
+                           self_attn_mask=attn_mask, query_pos_un=None, chain_src=_CHAIN_MEMORY)
+            if _CHAIN_MEMORY:
+                output, src = output
             fused = self.__dict__.get("fused_heads")      # (class_embed, depth_embed, angle_embed) lists, set by MonoDETR
             if fused is not None and self.bbox_embed is not None and self.dim_embed is not None:
                 # every head that reads this level's output, first layers as one GEMM; the box and size heads are

@@ -181,8 +181,9 @@ class _TokenLinearSkip(torch.autograd.Function):
     backbone.py:93-106).  tail: ReLU (relu) followed by Dropout (dropout_p, csrc/tgemm.hip only).  `pos` is a constant (no gradient)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pos, relu=False, dropout_p=0.0, premask=False):
+    def forward(ctx, x, weight, bias, pos, relu=False, dropout_p=0.0, premask=False, wide_out=False):
         ctx.premask = bool(premask) and pos is None                 # x is a ReLU output whose producer leaves the mask to this backward
+        ctx.wide_out = bool(wide_out)                               # fp32 result of bf16 operands (`_TokenLinear.forward`)
         q = x if pos is None else x + pos
         q2 = q.reshape(-1, q.shape[-1])
         ctx.has_bias = bias is not None
@@ -191,9 +192,10 @@ class _TokenLinearSkip(torch.autograd.Function):
         ctx.scale = 1.0 / (1.0 - dropout_p) if dropout_p > 0.0 else 1.0
         if _tgemm_ok(q2, weight, bias):
             seed, seed_dev = _drop_seed(q, dropout_p)
-            y = _fwd_product(q2, weight, bias, relu, None, dropout_p, seed, seed_dev).view(q.shape[:-1] + (weight.shape[0],))
-        elif dropout_p > 0.0:
-            raise RuntimeError("token_linear_skip: dropout is only fused into csrc/tgemm.hip's epilogue")
+            y = _fwd_product(q2, weight, bias, relu, None, dropout_p, seed, seed_dev,
+                             torch.float32 if wide_out else torch.bfloat16).view(q.shape[:-1] + (weight.shape[0],))
+        elif dropout_p > 0.0 or wide_out:
+            raise RuntimeError("token_linear_skip: dropout and the fp32 result exist in csrc/tgemm.hip's epilogue only")
         elif relu:                                                   # library GEMM with the RELU_BIAS epilogue (as _TokenLinear)
             y = torch._addmm_activation(bias, q2, weight.t()).view(q.shape[:-1] + (weight.shape[0],))
         else:
@@ -210,30 +212,33 @@ class _TokenLinearSkip(torch.autograd.Function):
         q, weight = ctx.saved_tensors[:2]
         if ctx.relu:
             dy = _act_backward(dy.contiguous(), ctx.saved_tensors[2], ctx.scale)
+        if ctx.wide_out:
+            dy = dy.to(q.dtype)                                        # one rounding of the fp32 gradient, as the narrow form receives it
         q2, dy2 = q.reshape(-1, q.shape[-1]), dy.reshape(-1, dy.shape[-1])
         dx = None
         if ctx.needs_input_grad[0]:
             ds2 = dskip.reshape(-1, q.shape[-1]) if dskip is not None else None
             dx = _input_gradient(dy2, weight, ds2, q2 if ctx.premask else None).view_as(q)
         dw, db = _weight_bias_grads(q2, dy2, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], ctx.bias_dtype)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def token_linear_skip(x, weight, bias=None, pos=None, relu=False, dropout_p=0.0, relu_token=None):
+def token_linear_skip(x, weight, bias=None, pos=None, relu=False, dropout_p=0.0, relu_token=None, wide_out=False):
     """-> (token_linear(x + pos, weight, bias[, relu, dropout]), x'): use x' (== x) for everything that follows on the residual path;
     see `_TokenLinearSkip`.  Plain tensors out of it when the fused form does not apply.  relu / dropout_p: the caller asks
     `skip_relu_fusable` / `skip_dropout_fusable` first."""
     if (x.is_cuda or _tgemm_backend()) and x.dtype == weight.dtype and x.numel() // x.shape[-1] >= _MIN_TOKENS and torch.is_grad_enabled() and x.requires_grad \
             and not torch.is_autocast_enabled() and (pos is None or not pos.requires_grad) \
-            and (not relu or skip_relu_fusable(bias, x, weight)) and (dropout_p <= 0.0 or skip_dropout_fusable(x, weight, bias)):
+            and (not relu or skip_relu_fusable(bias, x, weight)) and (dropout_p <= 0.0 or skip_dropout_fusable(x, weight, bias)) \
+            and (not wide_out or (not relu and x.is_cuda and x.dtype == torch.bfloat16 and _tgemm_ok(x.reshape(-1, x.shape[-1]), weight, bias))):
         # relu_token: x is a ReLU output with this call as its only consumer (`ReluToken`): the mask goes into the input gradient here
         premask = relu_token is not None and pos is None and x.dtype == torch.bfloat16 and _tgemm_ok(x.reshape(-1, x.shape[-1]), weight, bias)
         if premask:
             relu_token.premasked = True
-        return _TokenLinearSkip.apply(x, weight, bias, pos, relu, dropout_p, premask)
+        return _TokenLinearSkip.apply(x, weight, bias, pos, relu, dropout_p, premask, wide_out)
     if dropout_p > 0.0:
         raise RuntimeError("token_linear_skip: ask skip_dropout_fusable before passing dropout_p")
-    return token_linear(x if pos is None else x + pos, weight, bias, relu=relu), x
+    return token_linear(x if pos is None else x + pos, weight, bias, relu=relu, wide_out=wide_out), x
 
 
 def skip_relu_fusable(bias, x=None, weight=None):

@@ -90,10 +90,14 @@ class MSDeformAttn(nn.Module):
             self.output_proj.bias.zero_()
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
-                input_level_start_index, input_padding_mask=None):
+                input_level_start_index, input_padding_mask=None, chain_input=False):
         """query [N,Lq,C]; reference_points [N,Lq,L,2] or [N,Lq,L,6] (cx,cy,l,r,t,b);
         input_flatten [N,S,C]; input_spatial_shapes [L,2] (H,W) int64; input_level_start_index [L];
-        input_padding_mask [N,S] bool (True = padding).  Returns [N,Lq,C]."""
+        input_padding_mask [N,S] bool (True = padding).  Returns [N,Lq,C].
+        chain_input (not in the reference's signature): -> (output, input_flatten'), the second == input_flatten, for the NEXT reader
+        of the same tensor -- the decoder's layers all read the encoder's memory, and three readers in parallel mean two 42 MB
+        sums of their gradients; read in a chain, each value projection adds the gradient arriving from the readers behind it
+        inside its input-gradient product (`linear.token_linear_skip`)."""
         N, Lq, _ = query.shape
         S = input_flatten.shape[1]
         M, L, P = self.n_heads, self.n_levels, self.n_points
@@ -103,7 +107,10 @@ class MSDeformAttn(nn.Module):
         # the projection's fp32 accumulator written out unrounded -- through the fp32 operator.  Its d/d(location) differences
         # neighbouring value rows; with bf16-rounded values those were the least accurate gradients of the bf16 model.
         wide = _WIDE_CROSS_VALUE and input_flatten.is_cuda and input_flatten.dtype == torch.bfloat16 and Lq * 8 <= S
-        value = token_linear(input_flatten, self.value_proj.weight, self.value_proj.bias, wide_out=wide)
+        if chain_input:
+            value, input_next = token_linear_skip(input_flatten, self.value_proj.weight, self.value_proj.bias, wide_out=wide)
+        else:
+            value, input_next = token_linear(input_flatten, self.value_proj.weight, self.value_proj.bias, wide_out=wide), input_flatten
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, S, M, -1)
@@ -117,7 +124,8 @@ class MSDeformAttn(nn.Module):
         else:
             offsets = token_linear(query, self.sampling_offsets.weight, self.sampling_offsets.bias).view(N, Lq, M, L, P, 2)
             logits = token_linear(query, self.attention_weights.weight, self.attention_weights.bias).view(N, Lq, M, L * P)
-        return self._attend(value, packed, offsets, logits, reference_points, input_spatial_shapes, input_level_start_index, query.dtype)
+        out = self._attend(value, packed, offsets, logits, reference_points, input_spatial_shapes, input_level_start_index, query.dtype)
+        return (out, input_next) if chain_input else out
 
     def _packed_projection(self):
         """The two projections of the query as ONE GEMM (384 = 256 offset + 128 logit columns): one read of the query forward,
