@@ -26,6 +26,9 @@ done
 cd $R
 bash scripts/r06_headspmc.sh ${T}_pmc_sgemm > $O/pmc_sgemm.txt 2>&1; cp $O/../${T}_pmc_sgemm/${T}_pmc_sgemm.json $O/ 2>/dev/null; tail -8 $O/pmc_sgemm.txt | cut -c1-260
 bash scripts/r06_headstrace.sh > $O/${T}_heads_launch_times.txt 2>&1; cat $O/${T}_heads_launch_times.txt
+bash scripts/r06_convpmc.sh ${T}_pmc_conv > $O/pmc_conv.txt 2>&1; cp $O/../${T}_pmc_conv/${T}_pmc_conv_pmc_conv.json $O/${T}_pmc_conv.json 2>/dev/null; tail -8 $O/pmc_conv.txt | cut -c1-200
+python -m monodetr_amd.tools.convbench --only conv3x3 --iters 50 > $O/${T}_convbench_conv3x3.json 2>/dev/null; python -c "
+import json; j=json.load(open('$O/${T}_convbench_conv3x3.json')); print('  '.join('%s %.1fus %.3f' % (k, v['ms']*1e3, v['frac_mfma']) for k, v in j.items()))"
 python -m monodetr_amd.tools.pmc_summary /tmp/pmc_msda_* --match msda --out $O/${T}_pmc_msda.json > /dev/null 2>$O/summary_msda.err
 python -m monodetr_amd.tools.pmc_summary /tmp/pmc_gemm_* --match tgemm --out $O/${T}_pmc_tgemm.json > /dev/null 2>$O/summary_gemm.err
 python -m monodetr_amd.tools.pmc_summary /tmp/pmc_wgrad_* --match twgrad --out $O/${T}_pmc_twgrad.json > /dev/null 2>$O/summary_wgrad.err
@@ -57,3 +60,4 @@ cd $R; f=$(find /tmp/trace_step -name "*kernel_trace.csv" | head -1); st=$(find 
 python -m monodetr_amd.tools.trace_stats $f --steps 8 --skip-last 14 --gaps 8 --out $O/${T}_bench_bf16_steady_kernel_stats.csv --top 14 > $O/trace_stats.txt 2>&1; grep -v " us/step " $O/trace_stats.txt | head -34 | cut -c1-170
 grep -E "mdetr|Name" $st | head -90 > $O/${T}_rocprofv3_stats_mdetr_kernels.csv
 tail -1 $O/bench_traced.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('traced', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_ms'], d['roofline'].get('traffic'))"
+python -m monodetr_amd.tools.rounds $f --steps 8 --top 60 > $O/${T}_workgroup_rounds.txt 2>&1
