@@ -106,12 +106,21 @@ void adamw_gathered_kernel(const GradPtrs grads, int tensor0, int block0, P *__r
     const int ne = static_cast<int>((left < chunk_bytes ? left : chunk_bytes) / static_cast<int64_t>(sizeof(P)));     // elements of this workgroup
     const P *gp = reinterpret_cast<const P *>(grads.p[ti - tensor0] + s0);
     const int64_t e0 = (dst_off[ti] + s0) / static_cast<int64_t>(sizeof(P));                                        // first element in the flat arrays
-    const bool vec = ((reinterpret_cast<uintptr_t>(gp) | static_cast<uintptr_t>(e0 * sizeof(P))) & (4 * sizeof(P) - 1)) == 0;      // (uniform)
+    // the flat side is aligned by construction (tensors start at multiples of 64 elements, chunks at multiples of 16 bytes); a
+    // gradient may be a slice of an exchange buffer at any element offset: its four elements then come as four loads
+    const bool vec = (static_cast<uintptr_t>(e0 * sizeof(P)) & (4 * sizeof(P) - 1)) == 0;                            // (uniform)
+    const bool gvec = (reinterpret_cast<uintptr_t>(gp) & (4 * sizeof(P) - 1)) == 0;                                  // (uniform)
     const int nv = vec ? ne & ~3 : 0;
     for (int k = threadIdx.x * 4; k < nv; k += 256 * 4) {
         const int64_t i0 = e0 + k;
         float g[4], m[4], v[4], q[4];
-        load4(gp + k, g); load4(exp_avg + i0, m); load4(exp_avg_sq + i0, v); load4(master + i0, q);
+        if (gvec) {
+            load4(gp + k, g);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = to_f32<P>(gp[k + j]);
+        }
+        load4(exp_avg + i0, m); load4(exp_avg_sq + i0, v); load4(master + i0, q);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             q[j] = adamw_element(q[j], g[j], m[j], v[j], c, i0 + j < n_no_decay ? 0.f : c.weight_decay, step);

@@ -193,3 +193,35 @@ def test_replay_bookkeeping_and_checkpoint_sanitisation():
     assert {int(s['step']) for s in sd['state'].values()} == {8}
     assert all(isinstance(g['lr'], float) and 'step_dev' not in g for g in sd['param_groups'])
     assert all(torch.is_tensor(g['lr']) and 'step_dev' in g for g in opt.param_groups)      # the live groups keep theirs
+
+
+def test_gathered_update_reads_gradient_slices_at_any_offset():
+    """The gathered AdamW (csrc/adamw.hip on the CPU shim) with gradients that are slices of ONE exchange buffer at odd element
+    offsets -- what `dist_helper`'s flat all-reduce leaves in `.grad` -- against the multi-tensor AdamW."""
+    from monodetr_amd.helpers.optimizer_helper import AdamW
+
+    def make():
+        torch.manual_seed(11)
+        ps = [torch.nn.Parameter(torch.randn(n)) for n in (5, 64, 3, 130, 7)] + [torch.nn.Parameter(torch.randn(9, 6).to(torch.bfloat16)),
+                                                                                 torch.nn.Parameter(torch.randn(33).to(torch.bfloat16))]
+        return ps, [{'params': ps, 'weight_decay': 1e-2}]
+
+    pa, ga = make()
+    pb, gb = make()
+    oa, ob = AdamW(ga, lr=1e-3), _fused(gb, "emul", lr=1e-3)
+    assert ob._gather
+    for step in range(3):
+        gen = torch.Generator().manual_seed(50 + step)
+        flat32 = torch.randn(1 + sum(p.numel() for p in pb[:5]), generator=gen)
+        flat16 = torch.randn(1 + sum(p.numel() for p in pb[5:]), generator=gen).to(torch.bfloat16)
+        o32, o16 = 1, 1                                   # the first slice starts at element 1: no 16-byte alignment anywhere
+        for x, y in zip(pa, pb):
+            if y.dtype == torch.float32:
+                y.grad = flat32[o32:o32 + y.numel()].view_as(y); o32 += y.numel()
+            else:
+                y.grad = flat16[o16:o16 + y.numel()].view_as(y); o16 += y.numel()
+            x.grad = y.grad.clone()
+        oa.step(); ob.step()
+    for x, y in zip(pa, pb):
+        tol = 1e-6 if x.dtype == torch.float32 else 1e-2
+        assert (x.detach().float() - y.detach().float()).abs().max() <= tol * max(1.0, x.detach().float().abs().max().item())
