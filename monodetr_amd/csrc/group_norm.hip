@@ -87,6 +87,11 @@ struct Dims { int n; int64_t hw; int c, gl, rl, chunk_rows, nchunks; float eps; 
     const int64_t r1 = r0 + d.chunk_rows < d.hw ? r0 + d.chunk_rows : d.hw; \
     const int64_t img_off = static_cast<int64_t>(img) * d.hw * d.c + gl * 8
 
+// Rows of a chunk in batches of kBatch per thread: all loads of a batch are issued before the first is used (a row beyond the chunk
+// re-reads the chunk's last row instead of branching around the load -- a branch per load makes every load wait for itself).
+// One row per iteration was a chain of 8 dependent ~1.5 us round trips per thread at 240 workgroups of 4 waves: 16 us for 7.8 MB.
+constexpr int kBatch = 4;
+
 template <typename T>
 __global__ __launch_bounds__(kThreads)
 void gn_fwd_moments(const Dims d, const T *__restrict__ x, float *__restrict__ partial)
@@ -94,14 +99,23 @@ void gn_fwd_moments(const Dims d, const T *__restrict__ x, float *__restrict__ p
     __shared__ float red[3][kThreads];
     MDETR_GN_LANES();
     Moments m = {0.f, 0.f, 0.f};
-    for (int64_t r = r0 + rl; r < r1; r += d.rl) {
-        float v[8];
-        Vec8<T>::load(x + img_off + r * d.c, v);
-        const float rm = ((v[0] + v[1]) + (v[2] + v[3]) + ((v[4] + v[5]) + (v[6] + v[7]))) * 0.125f;
-        float q = 0.f;
+    for (int64_t rb = r0 + rl; rb < r1; rb += kBatch * d.rl) {
+        float vv[kBatch][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) q += (v[i] - rm) * (v[i] - rm);
-        m = combine(m, Moments{8.f, rm, q});
+        for (int u = 0; u < kBatch; ++u) {
+            const int64_t r = rb + u * d.rl;
+            Vec8<T>::load(x + img_off + (r < r1 ? r : r1 - 1) * d.c, vv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            if (rb + u * d.rl >= r1) break;
+            const float (&v)[8] = vv[u];
+            const float rm = ((v[0] + v[1]) + (v[2] + v[3]) + ((v[4] + v[5]) + (v[6] + v[7]))) * 0.125f;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q += (v[i] - rm) * (v[i] - rm);
+            m = combine(m, Moments{8.f, rm, q});
+        }
     }
     red[0][threadIdx.x] = m.n; red[1][threadIdx.x] = m.mean; red[2][threadIdx.x] = m.m2;
     __syncthreads();
@@ -120,11 +134,21 @@ __global__ __launch_bounds__(kThreads)
 void gn_fwd_apply(const Dims d, const T *__restrict__ x, const float *__restrict__ partial, const PT *__restrict__ gamma,
                   const PT *__restrict__ beta, T *__restrict__ y, float *__restrict__ stats)
 {
+    __shared__ float red[3][kThreads];
     MDETR_GN_LANES();
+    // the image's moments from the chunks' partials: every row lane combines its share (a few independent loads), the row lanes'
+    // results through LDS in fixed order -- not one thread walking all chunks (30 dependent round trips ahead of the first row)
     Moments m = {0.f, 0.f, 0.f};
-    for (int k = 0; k < d.nchunks; ++k) {
+    for (int k = rl; k < d.nchunks; k += d.rl) {
         const float *p = partial + ((static_cast<int64_t>(img) * d.nchunks + k) * d.gl + gl) * 3;
         m = combine(m, Moments{p[0], p[1], p[2]});
+    }
+    red[0][threadIdx.x] = m.n; red[1][threadIdx.x] = m.mean; red[2][threadIdx.x] = m.m2;
+    __syncthreads();
+    m = Moments{red[0][gl], red[1][gl], red[2][gl]};
+    for (int l = 1; l < d.rl; ++l) {
+        const int t = l * d.gl + gl;
+        m = combine(m, Moments{red[0][t], red[1][t], red[2][t]});
     }
     const float mean = m.mean, rstd = 1.0f / sqrtf(m.m2 / m.n + d.eps);
     if (chunk == 0 && rl == 0) {
@@ -136,15 +160,24 @@ void gn_fwd_apply(const Dims d, const T *__restrict__ x, const float *__restrict
     Vec8<PT>::load(beta + gl * 8, b);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { g[i] *= rstd; b[i] -= mean * g[i]; }      // y = x * (gamma rstd) + (beta - mean gamma rstd)
-    for (int64_t r = r0 + rl; r < r1; r += d.rl) {
-        float v[8];
-        Vec8<T>::load(x + img_off + r * d.c, v);
+    for (int64_t rb = r0 + rl; rb < r1; rb += kBatch * d.rl) {
+        float vv[kBatch][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            v[i] = v[i] * g[i] + b[i];
-            if (RELU) v[i] = v[i] > 0.f ? v[i] : 0.f;
+        for (int u = 0; u < kBatch; ++u) {
+            const int64_t r = rb + u * d.rl;
+            Vec8<T>::load(x + img_off + (r < r1 ? r : r1 - 1) * d.c, vv[u]);
         }
-        Vec8<T>::store(y + img_off + r * d.c, v);
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int64_t r = rb + u * d.rl;
+            if (r >= r1) break;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                vv[u][i] = vv[u][i] * g[i] + b[i];
+                if (RELU) vv[u][i] = vv[u][i] > 0.f ? vv[u][i] : 0.f;
+            }
+            Vec8<T>::store(y + img_off + r * d.c, vv[u]);
+        }
     }
 }
 
@@ -168,16 +201,24 @@ void gn_bwd_sums(const Dims d, const T *__restrict__ dy, const T *__restrict__ x
     float dg[8], db[8], a = 0.f, b = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) dg[i] = db[i] = 0.f;
-    for (int64_t r = r0 + rl; r < r1; r += d.rl) {
-        float v[8], e[8];
-        Vec8<T>::load(x + img_off + r * d.c, v);
-        Vec8<T>::load(dy + img_off + r * d.c, e);
+    for (int64_t rb = r0 + rl; rb < r1; rb += kBatch * d.rl) {
+        float vv[kBatch][8], ee[kBatch][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float dd = gn_active<RELU>(v[i], gs[i], bs[i]) ? e[i] : 0.f;
-            const float xh = (v[i] - mean) * rstd;
-            dg[i] += dd * xh; db[i] += dd;
-            a += dd * g[i]; b += dd * g[i] * xh;
+        for (int u = 0; u < kBatch; ++u) {
+            const int64_t r = rb + u * d.rl, rc = r < r1 ? r : r1 - 1;
+            Vec8<T>::load(x + img_off + rc * d.c, vv[u]);
+            Vec8<T>::load(dy + img_off + rc * d.c, ee[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            if (rb + u * d.rl >= r1) break;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float dd = gn_active<RELU>(vv[u][i], gs[i], bs[i]) ? ee[u][i] : 0.f;
+                const float xh = (vv[u][i] - mean) * rstd;
+                dg[i] += dd * xh; db[i] += dd;
+                a += dd * g[i]; b += dd * g[i] * xh;
+            }
         }
     }
 #pragma unroll
@@ -206,11 +247,16 @@ void gn_bwd_apply(const Dims d, const T *__restrict__ dy, const T *__restrict__ 
 {
     MDETR_GN_LANES();
     const float mean = stats[(static_cast<int64_t>(img) * d.gl + gl) * 2], rstd = stats[(static_cast<int64_t>(img) * d.gl + gl) * 2 + 1];
+    __shared__ float red[2][kThreads];
     float a = 0.f, b = 0.f;
-    for (int k = 0; k < d.nchunks; ++k) {
+    for (int k = rl; k < d.nchunks; k += d.rl) {                            // (as gn_fwd_apply: the row lanes share the chunks)
         const float *p = ab + ((static_cast<int64_t>(img) * d.nchunks + k) * d.gl + gl) * 2;
         a += p[0]; b += p[1];
     }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    a = red[0][gl]; b = red[1][gl];
+    for (int l = 1; l < d.rl; ++l) { a += red[0][l * d.gl + gl]; b += red[1][l * d.gl + gl]; }
     const float inv_m = 1.0f / (static_cast<float>(d.hw) * 8.f);
     a *= inv_m; b *= inv_m;
     float g[8], gs[8], bs[8];
@@ -218,17 +264,26 @@ void gn_bwd_apply(const Dims d, const T *__restrict__ dy, const T *__restrict__ 
     Vec8<PT>::load(beta + gl * 8, bs);
 #pragma unroll
     for (int i = 0; i < 8; ++i) { gs[i] = g[i] * rstd; bs[i] -= mean * gs[i]; }
-    for (int64_t r = r0 + rl; r < r1; r += d.rl) {
-        float v[8], e[8];
-        Vec8<T>::load(x + img_off + r * d.c, v);
-        Vec8<T>::load(dy + img_off + r * d.c, e);
+    for (int64_t rb = r0 + rl; rb < r1; rb += kBatch * d.rl) {
+        float vv[kBatch][8], ee[kBatch][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float dd = gn_active<RELU>(v[i], gs[i], bs[i]) ? e[i] : 0.f;
-            const float xh = (v[i] - mean) * rstd;
-            e[i] = rstd * (dd * g[i] - (a + xh * b));
+        for (int u = 0; u < kBatch; ++u) {
+            const int64_t r = rb + u * d.rl, rc = r < r1 ? r : r1 - 1;
+            Vec8<T>::load(x + img_off + rc * d.c, vv[u]);
+            Vec8<T>::load(dy + img_off + rc * d.c, ee[u]);
         }
-        Vec8<T>::store(dx + img_off + r * d.c, e);
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int64_t r = rb + u * d.rl;
+            if (r >= r1) break;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float dd = gn_active<RELU>(vv[u][i], gs[i], bs[i]) ? ee[u][i] : 0.f;
+                const float xh = (vv[u][i] - mean) * rstd;
+                ee[u][i] = rstd * (dd * g[i] - (a + xh * b));
+            }
+            Vec8<T>::store(dx + img_off + r * d.c, ee[u]);
+        }
     }
 }
 
