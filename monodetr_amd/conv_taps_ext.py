@@ -152,7 +152,8 @@ class _ConvStrided(torch.autograd.Function):
             dy2 = dy.permute(0, 2, 3, 1).reshape(-1, dy.shape[1])
             if dy2.is_cuda and _backend is None:
                 from .colsum_ext import column_sum, supported as colsum_ok
-                ds = column_sum(dy2) if colsum_ok(dy2) else dy2.float().sum(0)
+                od = ctx.shift_dtype if ctx.shift_dtype in (torch.float32, torch.bfloat16) else torch.float32       # (one rounding, no cast launch)
+                ds = column_sum(dy2, out_dtype=od) if colsum_ok(dy2) else dy2.float().sum(0)
             else:
                 ds = dy2.float().sum(0)
             ds = ds.to(ctx.shift_dtype)

@@ -95,11 +95,21 @@ MDETR_HD int ddn_target(const DdnDims &d, const float *boxes_b, const float *dep
 {
     float nearest = 0.f;
     bool any = false;
-    for (int k = 0; k < d.K; ++k) {
-        if (!valid_b[k]) continue;
-        if (ddn_covers(boxes_b + 4 * k, x, y, d.H, d.W)) {
-            nearest = any ? (depth_b[k] < nearest ? depth_b[k] : nearest) : depth_b[k];
-            any = true;
+    // (batches of 5 boxes, every load of a batch before its first use and no branch between them: one box per iteration behind
+    // `if (!valid) continue` was K dependent round trips per pixel)
+    for (int k0 = 0; k0 < d.K; k0 += 5) {
+        float bx[5][4], dp[5];
+        unsigned char vl[5];
+        for (int u = 0; u < 5; ++u) {
+            const int k = k0 + u < d.K ? k0 + u : d.K - 1;
+            vl[u] = valid_b[k];
+            dp[u] = depth_b[k];
+            for (int i = 0; i < 4; ++i) bx[u][i] = boxes_b[4 * k + i];
+        }
+        for (int u = 0; u < 5; ++u) {
+            const bool hit = (k0 + u < d.K) & (vl[u] != 0) & ddn_covers(bx[u], x, y, d.H, d.W);
+            nearest = hit ? (any ? (dp[u] < nearest ? dp[u] : nearest) : dp[u]) : nearest;
+            any = any | hit;
         }
     }
     fg = any;
@@ -113,16 +123,19 @@ MDETR_HD int ddn_target(const DdnDims &d, const float *boxes_b, const float *dep
 // focal loss of one pixel (focalloss.py:58-129, gamma = 2): value, and (if g != nullptr) d loss / d logit_c
 // scaled by `scale`, written with stride sc.
 //   focal_c = -alpha (1 - p_c)^2 log p_c ;  loss = focal_t + 1e-6 sum_c focal_c
-MDETR_HD float ddn_pixel(const DdnDims &d, const float *z, int t, float scale, float *g)
+constexpr int kDdnRegs = 96;              // classes (depth bins + 1) a pixel keeps in registers: 81 in the reference's configuration
+
+template <typename Z>
+MDETR_HD float ddn_pixel_body(const DdnDims &d, const Z &zc, int t, float scale, float *g)
 {
-    float mx = z[0];
-    for (int c = 1; c < d.C; ++c) mx = z[c * d.sc] > mx ? z[c * d.sc] : mx;
+    float mx = zc(0);
+    for (int c = 1; c < d.C; ++c) mx = zc(c) > mx ? zc(c) : mx;
     float se = 0.f;
-    for (int c = 0; c < d.C; ++c) se += ddn_exp(z[c * d.sc] - mx);
+    for (int c = 0; c < d.C; ++c) se += ddn_exp(zc(c) - mx);
     const float lse = mx + ddn_log(se);
     float loss = 0.f, sum_a = 0.f, a_t = 0.f;
     for (int c = 0; c < d.C; ++c) {
-        const float logp = z[c * d.sc] - lse, p = ddn_exp(logp), om = 1.f - p;
+        const float logp = zc(c) - lse, p = ddn_exp(logp), om = 1.f - p;
         const float focal = -d.alpha * om * om * logp;
         loss += (c == t ? 1.f : 0.f) * focal + 1e-6f * focal;
         const float a = d.alpha * (2.f * om * p * logp - om * om);        // d focal_c / d p_c * p_c
@@ -132,12 +145,64 @@ MDETR_HD float ddn_pixel(const DdnDims &d, const float *z, int t, float scale, f
     if (g) {
         const float tail = a_t + 1e-6f * sum_a;
         for (int c = 0; c < d.C; ++c) {
-            const float logp = z[c * d.sc] - lse, p = ddn_exp(logp), om = 1.f - p;
+            const float logp = zc(c) - lse, p = ddn_exp(logp), om = 1.f - p;
             const float a = d.alpha * (2.f * om * p * logp - om * om);
             g[c * d.sc] = scale * ((c == t ? a_t : 0.f) + 1e-6f * a - p * tail);
         }
     }
     return loss;
+}
+
+MDETR_HD float ddn_pixel(const DdnDims &d, const float *z, int t, float scale, float *g)
+{
+    if (d.C <= kDdnRegs) {
+        // the pixel's logits ONCE into registers, 16 loads at a time before their first use (a class beyond C re-reads the last one: no
+        // branch around a load): the three passes below then run on registers -- from memory they were 3 x 81 loads in a chain of
+        // short batches per pixel
+        float zz[kDdnRegs];
+#pragma unroll
+        for (int c0 = 0; c0 < kDdnRegs; c0 += 16) {
+            if (c0 >= d.C) break;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = c0 + u < d.C ? c0 + u : d.C - 1;
+                zz[c0 + u] = z[c * d.sc];
+            }
+        }
+        // (static register indices: the loops over c are unrolled to kDdnRegs and cut at C)
+        float mx = zz[0];
+#pragma unroll
+        for (int c = 1; c < kDdnRegs; ++c) if (c < d.C) mx = zz[c] > mx ? zz[c] : mx;
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < kDdnRegs; ++c) if (c < d.C) se += ddn_exp(zz[c] - mx);
+        const float lse = mx + ddn_log(se);
+        float loss = 0.f, sum_a = 0.f, a_t = 0.f;
+#pragma unroll
+        for (int c = 0; c < kDdnRegs; ++c) {
+            if (c < d.C) {
+                const float logp = zz[c] - lse, p = ddn_exp(logp), om = 1.f - p;
+                const float focal = -d.alpha * om * om * logp;
+                loss += (c == t ? 1.f : 0.f) * focal + 1e-6f * focal;
+                const float a = d.alpha * (2.f * om * p * logp - om * om);
+                sum_a += a;
+                if (c == t) a_t = a;
+            }
+        }
+        if (g) {
+            const float tail = a_t + 1e-6f * sum_a;
+#pragma unroll
+            for (int c = 0; c < kDdnRegs; ++c) {
+                if (c < d.C) {
+                    const float logp = zz[c] - lse, p = ddn_exp(logp), om = 1.f - p;
+                    const float a = d.alpha * (2.f * om * p * logp - om * om);
+                    g[c * d.sc] = scale * ((c == t ? a_t : 0.f) + 1e-6f * a - p * tail);
+                }
+            }
+        }
+        return loss;
+    }
+    return ddn_pixel_body(d, [&](int c) { return z[c * d.sc]; }, t, scale, g);
 }
 
 }  // namespace mdetr

@@ -128,37 +128,45 @@ void head_tail_bwd_kernel(const HeadTailDims d, const float *__restrict__ init_r
 }
 
 // d loss / d map[b, y, x] = sum over the image's (level, query) pairs of g_depth_0 / 3 * (the pair's bilinear weight on this cell).
-// A workgroup owns 256 cells of one image; the image's pairs -- footprint corner, fractions, gradient -- are worked out ONCE per
-// workgroup into LDS in batches of 256, then every cell's thread walks the batch (broadcast reads) in (level, query) order:
-// deterministic, no atomics.  (Per cell and pair from global memory, the first version, took longer than the two other kernels together.)
+// Deterministic, no atomics: 16 lanes share a cell -- lane i walks the pairs i, i + 16, ... of a batch in order, the 16 partial sums
+// are added in lane order at the end -- and a workgroup owns 16 cells of one image; the image's pairs (footprint corner, fractions,
+// gradient) are worked out once per workgroup into LDS in batches of 2 048.  (One thread per cell walking all 1 650 pairs, 64
+// workgroups: 117 us, the longest kernel of the step after the two MSDA kernels -- a chain of dependent LDS reads.)
+constexpr int kMapLanes = 16, kMapBatch = 2048;
+
 __global__ __launch_bounds__(256)
 void head_tail_map_grad_kernel(const HeadTailDims d, const float *__restrict__ coord, const float *__restrict__ g_depth, float *__restrict__ g_map)
 {
-    __shared__ int px[256], py[256];
-    __shared__ float pwx[256], pwy[256], pg[256];
-    const int HW = d.H * d.W, per_image = (HW + 255) / 256;
-    const int b = blockIdx.x / per_image, cell = (blockIdx.x - b * per_image) * 256 + threadIdx.x;
+    __shared__ short px[kMapBatch], py[kMapBatch];
+    __shared__ float pwx[kMapBatch], pwy[kMapBatch], pg[kMapBatch];
+    const int HW = d.H * d.W, cells_per_wg = 256 / kMapLanes, per_image = (HW + cells_per_wg - 1) / cells_per_wg;
+    const int b = blockIdx.x / per_image, lane = threadIdx.x % kMapLanes;
+    const int cell = (blockIdx.x - b * per_image) * cells_per_wg + threadIdx.x / kMapLanes;
     const int y = cell / d.W, x = cell - y * d.W;
     const int pairs = d.L * d.Q;
     float acc = 0.f;
-    for (int p0 = 0; g_depth && p0 < pairs; p0 += 256) {
-        const int p = p0 + threadIdx.x;
+    for (int p0 = 0; g_depth && p0 < pairs; p0 += kMapBatch) {
+        const int n = pairs - p0 < kMapBatch ? pairs - p0 : kMapBatch;
         __syncthreads();
-        if (p < pairs) {
-            const int l = p / d.Q, q = p - l * d.Q, j = (l * d.B + b) * d.Q + q;
+        for (int k = threadIdx.x; k < n; k += 256) {
+            const int p = p0 + k, l = p / d.Q, q = p - l * d.Q, j = (l * d.B + b) * d.Q + q;
             const Bilinear f = footprint(coord[j * 6], coord[j * 6 + 1], d.H, d.W);
-            px[threadIdx.x] = f.x0; py[threadIdx.x] = f.y0; pwx[threadIdx.x] = f.wx; pwy[threadIdx.x] = f.wy;
-            pg[threadIdx.x] = g_depth[j * 2] / 3.f;
+            px[k] = static_cast<short>(f.x0 < -2 ? -2 : (f.x0 > 32000 ? 32000 : f.x0)); py[k] = static_cast<short>(f.y0 < -2 ? -2 : (f.y0 > 32000 ? 32000 : f.y0)); pwx[k] = f.wx; pwy[k] = f.wy;
+            pg[k] = g_depth[j * 2] / 3.f;
         }
         __syncthreads();
-        const int n = pairs - p0 < 256 ? pairs - p0 : 256;
-        for (int k = 0; k < n; ++k) {
+        for (int k = lane; k < n; k += kMapLanes) {
             const int dx = x - px[k], dy = y - py[k];
             if (dx < 0 || dx > 1 || dy < 0 || dy > 1) continue;
             acc += pg[k] * (dx ? pwx[k] : 1.f - pwx[k]) * (dy ? pwy[k] : 1.f - pwy[k]);
         }
     }
-    if (cell < HW) g_map[b * HW + cell] = acc;
+    // the 16 lanes of the cell, in lane order (the same on every run)
+    float sum = 0.f;
+    const int base = (threadIdx.x & 63) & ~(kMapLanes - 1);
+#pragma unroll
+    for (int i = 0; i < kMapLanes; ++i) sum += __shfl(acc, base + i);
+    if (lane == 0 && cell < HW) g_map[b * HW + cell] = sum;
 }
 
 }  // namespace
@@ -193,7 +201,7 @@ hipError_t head_tail_backward_launch(const HeadTailDims &d, const float *init_re
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (g_map) {
-        const int blocks = d.B * ((d.H * d.W + 255) / 256);
+        const int blocks = d.B * ((d.H * d.W + 256 / kMapLanes - 1) / (256 / kMapLanes));
         hipLaunchKernelGGL(head_tail_map_grad_kernel, dim3(blocks), dim3(256), 0, st, d, coord, g_depth, g_map);      // (no g_depth: zeros)
         e = hipGetLastError();
     }

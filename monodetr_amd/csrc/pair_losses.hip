@@ -54,9 +54,21 @@ void pair_losses_fwd_kernel(const PairLossDims d, const PairLossIn in, const int
     float acc[kAcc];
 #pragma unroll
     for (int i = 0; i < kAcc; ++i) acc[i] = 0.f;
+    // the cardinality count: one atomic per (wave, image) instead of one per row -- 13 200 atomics on 24 addresses queue up behind
+    // each other at the L2 (they were most of this kernel's 100 us); a wave's 64 consecutive rows belong to at most two images
+    bool counted = false;
+    int my_b = -1;
     if (r < rows_per_level) {
         const int b = r / d.Q, q = r - b * d.Q;
-        if (pl_row_forward(d, in, l, b, q, acc)) atomicAdd(&w.card[l * d.B + b], 1);
+        counted = pl_row_forward(d, in, l, b, q, acc);
+        my_b = b;
+    }
+    for (unsigned long long rest = __ballot(counted); rest != 0ull;) {
+        const int first = __builtin_ctzll(rest);
+        const int bb = __shfl(my_b, first);
+        const unsigned long long same = __ballot(counted && my_b == bb);
+        if (static_cast<int>(threadIdx.x & 63) == first) atomicAdd(&w.card[l * d.B + bb], __popcll(same));
+        rest &= ~same;
     }
     // wave reduction (64 lanes), then the 4 waves through LDS
 #pragma unroll

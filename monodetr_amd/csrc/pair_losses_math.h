@@ -58,9 +58,20 @@ MDETR_HD float pl_log1p(float x)
 // slot matched to query q: k in [0, K) or -1.  `assign_g` = assign[l, b, q / n, :], `valid_b` = valid[b, :]
 MDETR_HD int pl_find_match(const int *assign_g, const unsigned char *valid_b, int q, int K)
 {
+    // (batches of 8 slots, every load of a batch before its first use and no branch between them: one slot per iteration with a
+    // short-circuit `&&` was 50 dependent round trips ahead of everything else a row does)
     int hit = -1;
-    for (int k = 0; k < K; ++k)
-        if (assign_g[k] == q && valid_b[k]) hit = k;
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        int a[8];
+        unsigned char v[8];
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u < K ? k0 + u : K - 1;
+            a[u] = assign_g[k];
+            v[u] = valid_b[k];
+        }
+        for (int u = 0; u < 8; ++u)
+            hit = (k0 + u < K) & (a[u] == q) & (v[u] != 0) ? k0 + u : hit;
+    }
     return hit;
 }
 
