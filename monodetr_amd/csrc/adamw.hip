@@ -111,21 +111,35 @@ void adamw_gathered_kernel(const GradPtrs grads, int tensor0, int block0, P *__r
     const bool vec = (static_cast<uintptr_t>(e0 * sizeof(P)) & (4 * sizeof(P) - 1)) == 0;                            // (uniform)
     const bool gvec = (reinterpret_cast<uintptr_t>(gp) & (4 * sizeof(P) - 1)) == 0;                                  // (uniform)
     const int nv = vec ? ne & ~3 : 0;
-    for (int k = threadIdx.x * 4; k < nv; k += 256 * 4) {
-        const int64_t i0 = e0 + k;
-        float g[4], m[4], v[4], q[4];
-        if (gvec) {
-            load4(gp + k, g);
-        } else {
+    // two steps of the thread per iteration, the eight loads of both first (the second step of a ragged end re-reads the first's
+    // elements and stores nothing)
+    for (int ka = threadIdx.x * 4; ka < nv; ka += 2 * 256 * 4) {
+        const int kb_ = ka + 256 * 4;
+        const bool two = kb_ < nv;
+        const int kb = two ? kb_ : ka;
+        float g[2][4], m[2][4], v[2][4], q[2][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) g[j] = to_f32<P>(gp[k + j]);
+        for (int u = 0; u < 2; ++u) {
+            const int k = u ? kb : ka;
+            const int64_t i0 = e0 + k;
+            if (gvec) {
+                load4(gp + k, g[u]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[u][j] = to_f32<P>(gp[k + j]);
+            }
+            load4(exp_avg + i0, m[u]); load4(exp_avg_sq + i0, v[u]); load4(master + i0, q[u]);
         }
-        load4(exp_avg + i0, m); load4(exp_avg_sq + i0, v); load4(master + i0, q);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            q[j] = adamw_element(q[j], g[j], m[j], v[j], c, i0 + j < n_no_decay ? 0.f : c.weight_decay, step);
-        store4(exp_avg + i0, m); store4(exp_avg_sq + i0, v); store4(master + i0, q);
-        if (sizeof(P) == 2) store4(param + i0, q);
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            const int64_t i0 = e0 + (u ? kb : ka);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                q[u][j] = adamw_element(q[u][j], g[u][j], m[u][j], v[u][j], c, i0 + j < n_no_decay ? 0.f : c.weight_decay, step);
+            store4(exp_avg + i0, m[u]); store4(exp_avg_sq + i0, v[u]); store4(master + i0, q[u]);
+            if (sizeof(P) == 2) store4(param + i0, q[u]);
+        }
     }
     for (int k = nv + threadIdx.x; k < ne; k += 256) {
         const int64_t i = e0 + k;

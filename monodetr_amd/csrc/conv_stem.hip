@@ -58,19 +58,36 @@ void conv_stem_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w
     if (threadIdx.x < 64) shift_s[threadIdx.x] = shift ? shift[threadIdx.x] : 0.f;
 
     const mdetr_rsrc xr = make_rsrc(x, static_cast<unsigned>(static_cast<int64_t>(d.B) * d.H * d.W * 6));
+    // The window of the NEXT column tile is requested while this tile's products run and stored behind the barrier: one 2-byte load
+    // per thread and loop iteration straight into LDS -- the first version -- was 11 dependent round trips per tile ahead of the
+    // first matrix instruction.  (A tile beyond the row reads nothing: offsets beyond the resource.)
+    constexpr int kWinLoads = (kWinRows * kWinEl + kWavesS * 64 - 1) / (kWavesS * 64);
+    unsigned short wreg[kWinLoads];
+    auto fetch_window = [&](int tx) {
+        const int c0n = tx * kTileWS;
+#pragma unroll
+        for (int j = 0; j < kWinLoads; ++j) {
+            const int i = threadIdx.x + j * kWavesS * 64;
+            const int wr = i / kWinEl, el = i - wr * kWinEl;
+            const int row = 2 * r0 + wr - 3, gel = (2 * c0n - 3) * 3 + el;   // element of the image row
+            const bool in = tx < d.tiles_x && i < kWinRows * kWinEl && row >= 0 && row < d.H && gel >= 0 && gel < d.W * 3;
+            wreg[j] = rsrc_load_u16(xr, in ? static_cast<unsigned>((row * d.W * 3 + gel) * 2) : kRsrcOob,
+                                    static_cast<unsigned>(b) * static_cast<unsigned>(d.H * d.W * 6));
+        }
+    };
+    fetch_window(gx * kTilesPerWg);
     for (int tt = 0; tt < kTilesPerWg; ++tt) {
         const int tx = gx * kTilesPerWg + tt;
         if (tx >= d.tiles_x) break;                                          // uniform
         const int c0 = tx * kTileWS;
         __syncthreads();                                                     // the previous tile's window reads are done (and, first time, nothing)
         // window: rows 2 r0 - 3 .. + 12, elements (2 c0 - 3) * 3 .. + 209 of each
-        for (int i = threadIdx.x; i < kWinRows * kWinEl; i += kWavesS * 64) {
-            const int wr = i / kWinEl, el = i - wr * kWinEl;
-            const int row = 2 * r0 + wr - 3, gel = (2 * c0 - 3) * 3 + el;    // element of the image row
-            const bool in = row >= 0 && row < d.H && gel >= 0 && gel < d.W * 3;
-            win[wr * kWinRow + el] = rsrc_load_u16(xr, in ? static_cast<unsigned>((row * d.W * 3 + gel) * 2) : kRsrcOob,
-                                                   static_cast<unsigned>(b) * static_cast<unsigned>(d.H * d.W * 6));
+#pragma unroll
+        for (int j = 0; j < kWinLoads; ++j) {
+            const int i = threadIdx.x + j * kWavesS * 64;
+            if (i < kWinRows * kWinEl) win[(i / kWinEl) * kWinRow + (i % kWinEl)] = wreg[j];
         }
+        if (tt + 1 < kTilesPerWg) fetch_window(tx + 1);                      // in flight during the products below
         __syncthreads();
 
         f32x16 acc[2];
