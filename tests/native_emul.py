@@ -34,17 +34,33 @@ _SAN = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g"] if SANITIZE else 
 
 def _compile(job):
     src, obj, defines = job
+    tmp = "%s.%d.tmp" % (obj, os.getpid())
     cmd = ["g++", "-std=c++17", "-O1", "-fPIC", "-ffp-contract=off"] + _SAN + [ "-I", SHIM, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           "-c", "-o", obj] + ["-D" + d for d in defines] + (["-x", "c++"] if src.endswith(".hip") else []) + [src]
+           "-c", "-o", tmp] + ["-D" + d for d in defines] + (["-x", "c++"] if src.endswith(".hip") else []) + [src]
     subprocess.check_call(cmd)
+    os.replace(tmp, obj)                                   # (a reader never sees a half-written object)
 
 
 def _build(OUT, defines):
     """One object per source (compiled in parallel, cached by modification time), then one link.  A compile-time
     variant recompiles only the sources that mention one of its macros."""
     from concurrent.futures import ThreadPoolExecutor
+    import fcntl
     bdir = os.path.dirname(OUT)
     os.makedirs(bdir, exist_ok=True)
+    # several test processes (pytest -n) may find the library stale at the same moment: one builds, the others wait for the lock
+    # and then find everything up to date ("file too short" from a half-written libemul.so otherwise)
+    lock = open(os.path.join(bdir, ".build.lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        return _build_locked(OUT, defines, bdir)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(OUT, defines, bdir):
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, k + ".hip") for k in KERNELS] + [os.path.join(SHIM, "runtime.cpp")]
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
         [os.path.join(SHIM, "hip", f) for f in os.listdir(os.path.join(SHIM, "hip"))] + [os.path.join(SHIM, "mdetr_wave.h"),
@@ -62,8 +78,10 @@ def _build(OUT, defines):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as pool:
             list(pool.map(_compile, jobs))
-    if jobs or not os.path.exists(OUT):
-        subprocess.check_call(["g++", "-shared", "-o", OUT] + _SAN + objs)
+    if jobs or not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(o) for o in objs):
+        tmp = "%s.%d.tmp" % (OUT, os.getpid())
+        subprocess.check_call(["g++", "-shared", "-o", tmp] + _SAN + objs)
+        os.replace(tmp, OUT)
     from monodetr_amd import _capi
     L = ctypes.CDLL(OUT)
     for name, (res, args) in _capi.SIGNATURES.items():
