@@ -353,13 +353,16 @@ void tgemm_kernel(const TgemmArgs g)
             if (fv < vtiles) aim(fv);
         }
     };
+    // prologue: slab 0 goes through the LAST register set, so that slabs 1 .. PF - 1 (sets 0 .. PF - 2, where the loop expects them)
+    // are requested before the first wait -- with slab 0 in set 0 the kernel's first two round trips were one after the other
     aim(fv);
-    fetch(0, xr[0], wr[0]);
+    fetch(0, xr[PF - 1], wr[PF - 1]);
     advance();
-    deposit(0, xr[0], wr[0]);
 #pragma unroll
-    for (int p = 0; p < PF; ++p)
+    for (int p = 0; p < PF - 1; ++p)
         if (fv < vtiles) { fetch(fk, xr[p], wr[p]); advance(); }
+    deposit(0, xr[PF - 1], wr[PF - 1]);
+    if (fv < vtiles) { fetch(fk, xr[PF - 1], wr[PF - 1]); advance(); }
     clear();
     __syncthreads();
     for (int s = 0;; s += PF) {

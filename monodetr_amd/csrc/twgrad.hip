@@ -162,11 +162,13 @@ void twgrad_kernel(const TwgradArgs g)
     // ---- slab pipeline (tgemm.hip's): slab s + 1 is written to LDS after the barrier that freed its buffer, PF more are in flight
     const int ns = (s_end - s_begin + KG - 1) / KG;              // iterations of a group
     if (ns > 0) {
-        fetch(0, yst[0], xst[0]);
-        deposit(0, yst[0], xst[0]);
+        // (slab 0 through the last register set: slabs 1 .. PF - 1 are requested before the first wait, as in tgemm.hip)
+        fetch(0, yst[PF - 1], xst[PF - 1]);
 #pragma unroll
-        for (int p = 0; p < PF; ++p)
+        for (int p = 0; p < PF - 1; ++p)
             if (1 + p < ns) fetch(1 + p, yst[p], xst[p]);
+        deposit(0, yst[PF - 1], xst[PF - 1]);
+        if (PF < ns) fetch(PF, yst[PF - 1], xst[PF - 1]);
         __syncthreads();
         for (int k = 0; k < ns; k += PF) {
 #pragma unroll

@@ -20,6 +20,7 @@ SHAPES = [  # (name, T, K, N)
     ("layer3_256to1024", 15360, 256, 1024), ("layer3_1024to256", 15360, 1024, 256), ("layer3_down_512to1024", 15360, 512, 1024),
     ("layer4_512to2048", 3840, 512, 2048), ("layer4_2048to512", 3840, 2048, 512), ("layer4_down_1024to2048", 3840, 1024, 2048),
     ("proj0_512to256", 61440, 512, 256), ("proj2_2048to256", 3840, 2048, 256), ("depth_tokens_256x256", 15360, 256, 256),
+    ("decoder_256x256", 4400, 256, 256), ("decoder_ffn_256x1024", 4400, 256, 1024),
 ]
 
 
