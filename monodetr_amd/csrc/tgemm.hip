@@ -48,7 +48,7 @@ struct TgemmArgs {
     const void *bias;
     void *y;
     int64_t T, lda, ldw, ldr, ldy, ldm;
-    int N, K, gx, ny, flags;
+    int N, K, gx, ny, flags, tiles_m;                       // tiles_m: row tiles (the host divides: a 64-bit division in the kernel's first microsecond otherwise)
     uint32_t thresh;
     float keep_scale;
     uint64_t seed;
@@ -85,10 +85,19 @@ __device__ __forceinline__ void transpose4x8(const bf16x8 (&in)[4], unsigned (&o
 //       3 = tail 1 (residual optional) times the sign mask of a second [T, N] tensor: y = mask > 0 ? acc + res : 0 -- the ReLU backward of
 //           the layer's INPUT applied where the input gradient leaves the chip (the mask tile is requested once the accumulators are parked)
 // NTH: threads of the workgroup -- 256 (waves 2 x 2) or 512 (2 x 4: the big tile with twice the waves in flight per CU)
+// scripts/exp/tgemm_timeline.hip compiles this file with the macro set: clock marks of workgroup 0's first wave
+#ifdef MDETR_TGEMM_TIMELINE
+__device__ long long tgemm_tl[64];
+#define TG_MARK(i) do { if (blockIdx.x == 3 && threadIdx.x == 0 && (i) < 64) tgemm_tl[(i)] = clock64(); } while (0)
+#else
+#define TG_MARK(i) do { } while (0)
+#endif
+
 template <int BM, int BN, bool NN, int PF, int TAIL, int NTH = 256>
 __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : 2)
 void tgemm_kernel(const TgemmArgs g)
 {
+    TG_MARK(0);
     constexpr int kThreadsT = NTH;                               // (shadows the file-level default inside this kernel)
     constexpr int WNW = NTH / 128;                               // waves along the features (2 along the tokens)
     constexpr int TM = BM / 64, TN = BN / (32 * WNW);            // 32 x 32 blocks of a wave along tokens / features
@@ -104,7 +113,7 @@ void tgemm_kernel(const TgemmArgs g)
     const int wm = wave & 1, wn = wave >> 1;                    // wave's place: 2 along the tokens, WNW along the features
     const int KT = (g.K + kBK - 1) / kBK;
     const int G = gridDim.x, vtiles = g.gx * g.ny;               // virtual tile ids (gx: row tiles rounded up to a multiple of 8)
-    const int64_t tiles_m = (g.T + BM - 1) / BM;
+    const int tiles_m = g.tiles_m;
     // virtual id v -> (column tile, row tile): the ny column tiles of one token range are ids 8 apart (same XCD, adjacent slots)
     auto tile_of = [&](int v, int &col, int64_t &m0) __attribute__((always_inline)) {
         const int grp = v >> 3;
@@ -113,7 +122,7 @@ void tgemm_kernel(const TgemmArgs g)
     };
     auto next_tile = [&](int v) __attribute__((always_inline)) {  // the next virtual id >= v with a live row tile (or >= vtiles)
         for (; v < vtiles; v += G) {
-            if (static_cast<int64_t>((v >> 3) / g.ny) * 8 + (v & 7) < tiles_m) break;
+            if ((v >> 3) / g.ny * 8 + (v & 7) < tiles_m) break;
         }
         return v;
     };
@@ -149,7 +158,7 @@ void tgemm_kernel(const TgemmArgs g)
         for (int j = 0; j < XCH; ++j) {
             const int c = tid + kThreadsT * j;
             const int64_t t = m0 + (c >> 3);
-            xoff[j] = t < g.T ? static_cast<unsigned>((t * g.lda + (c & 7) * 8) * 2) : kRsrcOob;
+            xoff[j] = t < g.T ? (static_cast<unsigned>(t) * static_cast<unsigned>(g.lda) + (c & 7) * 8) * 2u : kRsrcOob;      // (T lda < 2^30: tgemm_supported)
         }
         if (NN) {
             woff[0] = (tid < WTHR && n0 + wnb * 8 < g.N) ? static_cast<unsigned>((static_cast<int64_t>(wkg * 4) * g.ldw + n0 + wnb * 8) * 2) : kRsrcOob;
@@ -157,7 +166,7 @@ void tgemm_kernel(const TgemmArgs g)
 #pragma unroll
             for (int j = 0; j < (NN ? 1 : WCH); ++j) {
                 const int c = tid + kThreadsT * j, row = n0 + (c >> 3);
-                woff[j] = row < g.N ? static_cast<unsigned>((static_cast<int64_t>(row) * g.ldw + (c & 7) * 8) * 2) : kRsrcOob;
+                woff[j] = row < g.N ? (static_cast<unsigned>(row) * static_cast<unsigned>(g.ldw) + (c & 7) * 8) * 2u : kRsrcOob;
             }
         }
     };
@@ -355,16 +364,20 @@ void tgemm_kernel(const TgemmArgs g)
     };
     // prologue: slab 0 goes through the LAST register set, so that slabs 1 .. PF - 1 (sets 0 .. PF - 2, where the loop expects them)
     // are requested before the first wait -- with slab 0 in set 0 the kernel's first two round trips were one after the other
+    TG_MARK(1);
     aim(fv);
     fetch(0, xr[PF - 1], wr[PF - 1]);
     advance();
 #pragma unroll
     for (int p = 0; p < PF - 1; ++p)
         if (fv < vtiles) { fetch(fk, xr[p], wr[p]); advance(); }
+    TG_MARK(2);
     deposit(0, xr[PF - 1], wr[PF - 1]);
+    TG_MARK(3);
     if (fv < vtiles) { fetch(fk, xr[PF - 1], wr[PF - 1]); advance(); }
     clear();
     __syncthreads();
+    TG_MARK(4);
     for (int s = 0;; s += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
@@ -373,18 +386,24 @@ void tgemm_kernel(const TgemmArgs g)
                 deposit((s + p + 1) & 1, xr[p], wr[p]);          // slab s + p + 1 (the barrier behind the previous slab freed that buffer)
                 if (fv < vtiles) { fetch(fk, xr[p], wr[p]); advance(); }
             }
+            TG_MARK(5 + 3 * (s + p));
             products((s + p) & 1);
+            TG_MARK(6 + 3 * (s + p));
             __syncthreads();
+            TG_MARK(7 + 3 * (s + p));
             ++ck;
             if (last) {                                          // every wave is done with the slab buffers: the tile is parked there
                 aim_tail(cv);
                 park();
+                TG_MARK(40);
                 if (MASK) {
                     __builtin_amdgcn_sched_barrier(0);           // (the requests stay behind the accumulators' last reads: their registers are the room)
                     aim_mask();
                 }
                 __syncthreads();
+                TG_MARK(41);
                 drain();                                         // the tile leaves
+                TG_MARK(42);
                 cv = next_tile(cv + G);
                 if (cv >= vtiles) return;
                 __syncthreads();                                 // the buffers are free again
@@ -415,6 +434,7 @@ hipError_t launch_tile(TgemmArgs g, hipStream_t st)
         if (dev_ >= 0 && dev_ < 64) attr_set[dev_] = true;
     }
     const int64_t tiles_m = (g.T + BM - 1) / BM;
+    g.tiles_m = static_cast<int>(tiles_m);
     g.ny = (g.N + BN - 1) / BN;
     g.gx = static_cast<int>((tiles_m + 7) / 8 * 8);              // whole rounds over the XCDs (dead row tiles are skipped)
     const int64_t vtiles = static_cast<int64_t>(g.gx) * g.ny;
