@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDETR_ABI_VERSION 10
+#define MDETR_ABI_VERSION 11
 
 /* element types of the floating-point tensors */
 #define MDETR_F32 0
@@ -571,6 +571,11 @@ int mdetr_column_sum_to(int dtype, const void *x, void *out, int out_dtype, void
  */
 int mdetr_conv3x3_forward(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N,
                           int relu, int device, void *stream);
+/* The same with a MASK (bf16 [B, H, W, N], 8-byte aligned): y = mask <= 0 ? 0 : act(conv(x, w) + shift).  The input gradient of
+ * Bottleneck.conv2 with autograd's threshold_backward of the ReLU behind conv1 -> bn1 (torchvision Bottleneck.forward, `out =
+ * self.relu(out)` between conv1 and conv2) applied where the gradient leaves the chip: mask = conv2's input. */
+int mdetr_conv3x3_masked(const void *x, const void *w, const float *shift, const void *mask, void *y, int B, int H, int W, int C, int N,
+                         int relu, int device, void *stream);
 
 /*
  * The strided convolutions of the ResNet body, the fourth pyramid level and the depth predictor, and their input gradients, as

@@ -31,23 +31,36 @@ def _ohwi(weight):
     return w if w.data_ptr() % 16 == 0 else w.clone()
 
 
-def _launch(x_cl, w_ohwi, shift, relu, mirror=False):
-    """x_cl [B, C, H, W] channels_last, w_ohwi [N, 3, 3, C] contiguous -> y [B, N, H, W] channels_last."""
+def _launch(x_cl, w_ohwi, shift, relu, mirror=False, mask=None):
+    """x_cl [B, C, H, W] channels_last, w_ohwi [N, 3, 3, C] contiguous -> y [B, N, H, W] channels_last.
+    mask [B, N, H, W] channels_last bf16: the result is zeroed where mask <= 0 (``mdetr_conv3x3_masked``)."""
     B, C, H, W = x_cl.shape
     N = w_ohwi.shape[0]
     y = torch.empty((B, N, H, W), dtype=torch.bfloat16, device=x_cl.device, memory_format=torch.channels_last)
     cuda = x_cl.is_cuda
-    rc = _lib().mdetr_conv3x3_forward(x_cl.data_ptr(), w_ohwi.data_ptr(), shift.data_ptr() if shift is not None else None, y.data_ptr(),
-                                      B, H, W, C, N, (1 if relu else 0) | (2 if mirror else 0), x_cl.device.index if cuda else -1,
-                                      torch.cuda.current_stream(x_cl.device).cuda_stream if cuda else None)
+    flags = (1 if relu else 0) | (2 if mirror else 0)
+    dev_i, stream = x_cl.device.index if cuda else -1, torch.cuda.current_stream(x_cl.device).cuda_stream if cuda else None
+    if mask is not None:
+        assert mask.shape == y.shape and mask.dtype == torch.bfloat16 and mask.is_contiguous(memory_format=torch.channels_last)
+        rc = _lib().mdetr_conv3x3_masked(x_cl.data_ptr(), w_ohwi.data_ptr(), shift.data_ptr() if shift is not None else None, mask.data_ptr(),
+                                         y.data_ptr(), B, H, W, C, N, flags, dev_i, stream)
+    else:
+        rc = _lib().mdetr_conv3x3_forward(x_cl.data_ptr(), w_ohwi.data_ptr(), shift.data_ptr() if shift is not None else None, y.data_ptr(),
+                                          B, H, W, C, N, flags, dev_i, stream)
     if rc != 0:
-        _capi.check(rc, "mdetr_conv3x3_forward")
+        _capi.check(rc, "mdetr_conv3x3_masked" if mask is not None else "mdetr_conv3x3_forward")
     return y
 
 
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, shift, relu, hand_out_token=False):
+    def forward(ctx, x, weight, shift, relu, hand_out_token=False, in_token=None):
+        # in_token (linear.ReluToken): x is a ReLU output that only this convolution consumes; its producer leaves the ReLU's backward
+        # mask to THIS backward, which applies it where the input gradient leaves the kernel (mdetr_conv3x3_masked) -- or, on the
+        # library route, by one threshold_backward of its own
+        ctx.in_token = in_token
+        if in_token is not None:
+            in_token.premasked = True
         w = _ohwi(weight)
         sh = None if shift is None else shift.float().contiguous()
         y = _launch(x, w, sh, relu)
@@ -76,9 +89,14 @@ class _Conv3x3(torch.autograd.Function):
                 wt = ctx.w_ihwo
                 if wt is None or wt.shape != (w.shape[3], 3, 3, w.shape[0]) or not wt.is_contiguous() or wt.dtype != w.dtype:
                     wt = w.permute(3, 1, 2, 0).contiguous()
-                dx = _launch(dy, wt, None, False, mirror=True)
+                masked = ctx.in_token is not None and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last)
+                dx = _launch(dy, wt, None, False, mirror=True, mask=x if masked else None)
+                if ctx.in_token is not None and not masked:
+                    dx = torch.ops.aten.threshold_backward(dx, x, 0.0)
             else:
                 dx = torch.ops.aten.convolution_backward(dy, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (True, False, False))[0]
+                if ctx.in_token is not None:
+                    dx = torch.ops.aten.threshold_backward(dx, x, 0.0)
         if ctx.needs_input_grad[1]:
             from . import conv_wgrad_ext
             if conv_wgrad_ext.supported(x, dy, 3, 1):                    # csrc/conv_wgrad.hip: split-K over pixel tiles on the matrix cores
@@ -96,14 +114,14 @@ class _Conv3x3(torch.autograd.Function):
             else:
                 ds = dy2.float().sum(0)
             ds = ds.to(ctx.shift_dtype)
-        return dx, dw, ds, None, None
+        return dx, dw, ds, None, None, None
 
 
-def conv3x3(x, weight, shift=None, relu=False, hand_out_token=False):
+def conv3x3(x, weight, shift=None, relu=False, hand_out_token=False, in_token=None):
     """act(conv2d(x, weight, padding=1) + shift[None, :, None, None]); ``shift`` [N]: a frozen-BN shift or a trainable bias."""
     if not supported(x, weight):
         raise RuntimeError("conv3x3: needs a CUDA bf16 channels_last activation with C % 64 == 0 and a bf16 [N, C, 3, 3] weight with N % 32 == 0")
-    return _Conv3x3.apply(x, weight, shift, relu, hand_out_token)
+    return _Conv3x3.apply(x, weight, shift, relu, hand_out_token, in_token if x.requires_grad else None)
 
 
 class Conv3x3(torch.nn.Conv2d):

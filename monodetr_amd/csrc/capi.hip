@@ -679,19 +679,32 @@ int mdetr_chunk_sums(const mdetr_chunk_job *jobs, int njobs, int device, void *s
     return MDETR_OK;
 }
 
+static int conv3x3_any(const char *who, const void *x, const void *w, const float *shift, const void *mask, void *y, int B, int H, int W, int C, int N,
+                       int relu, int device, void *stream)
+{
+    if (B < 0 || H < 0 || W < 0 || C <= 0 || N <= 0) return fail(MDETR_E_ARG, "%s: bad sizes B=%d H=%d W=%d C=%d N=%d", who, B, H, W, C, N);
+    if (B == 0 || H == 0 || W == 0) return MDETR_OK;
+    if (!x || !w || !y) return fail(MDETR_E_ARG, "%s: null pointer", who);
+    if (!mdetr::conv3x3_supported(B, H, W, C, N, x, w, y) || (reinterpret_cast<uintptr_t>(mask) & 7) != 0)
+        return fail(MDETR_E_ARG, "%s: needs C %% 64 == 0, N %% 32 == 0, 16-byte aligned x / w, 8-byte aligned y / mask (C=%d N=%d)", who, C, N);
+    DeviceScope dev(device);
+    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "%s: set device %d: %s", who, device, hipGetErrorString(dev.err));
+    const hipError_t e = mdetr::conv3x3_launch(x, w, shift, y, B, H, W, C, N, (relu & 1) != 0, static_cast<hipStream_t>(stream), (relu & 2) != 0, mask);
+    if (e != hipSuccess) return fail(MDETR_E_HIP, "%s: launch failed: %s", who, hipGetErrorString(e));
+    return MDETR_OK;
+}
+
 int mdetr_conv3x3_forward(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N,
                           int relu, int device, void *stream)
 {
-    if (B < 0 || H < 0 || W < 0 || C <= 0 || N <= 0) return fail(MDETR_E_ARG, "mdetr_conv3x3_forward: bad sizes B=%d H=%d W=%d C=%d N=%d", B, H, W, C, N);
-    if (B == 0 || H == 0 || W == 0) return MDETR_OK;
-    if (!x || !w || !y) return fail(MDETR_E_ARG, "mdetr_conv3x3_forward: null pointer");
-    if (!mdetr::conv3x3_supported(B, H, W, C, N, x, w, y))
-        return fail(MDETR_E_ARG, "mdetr_conv3x3_forward: needs C %% 64 == 0, N %% 32 == 0, 16-byte aligned x / w, 8-byte aligned y (C=%d N=%d)", C, N);
-    DeviceScope dev(device);
-    if (dev.err != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv3x3_forward: set device %d: %s", device, hipGetErrorString(dev.err));
-    const hipError_t e = mdetr::conv3x3_launch(x, w, shift, y, B, H, W, C, N, (relu & 1) != 0, static_cast<hipStream_t>(stream), (relu & 2) != 0);
-    if (e != hipSuccess) return fail(MDETR_E_HIP, "mdetr_conv3x3_forward: launch failed: %s", hipGetErrorString(e));
-    return MDETR_OK;
+    return conv3x3_any("mdetr_conv3x3_forward", x, w, shift, nullptr, y, B, H, W, C, N, relu, device, stream);
+}
+
+int mdetr_conv3x3_masked(const void *x, const void *w, const float *shift, const void *mask, void *y, int B, int H, int W, int C, int N,
+                         int relu, int device, void *stream)
+{
+    if (!mask) return fail(MDETR_E_ARG, "mdetr_conv3x3_masked: null mask");
+    return conv3x3_any("mdetr_conv3x3_masked", x, w, shift, mask, y, B, H, W, C, N, relu, device, stream);
 }
 
 int mdetr_conv_taps(const void *x, const void *w, const float *shift, void *y, const int64_t *dims, int relu, int device, void *stream)

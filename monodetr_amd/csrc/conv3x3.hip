@@ -89,7 +89,7 @@ __device__ long long conv_span[4096][4];                  // per workgroup: star
 template <int NB, int WC, int GC>
 __global__ __launch_bounds__(kThreads)
 void conv3x3_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, const float *__restrict__ shift,
-                    __bf16 *__restrict__ y, const ConvDims d)
+                    __bf16 *__restrict__ y, const ConvDims d, const __bf16 *__restrict__ mask)
 {
     using TL = Tile<WC, GC>;
     constexpr int WR = TL::WR, HWL = TL::pitch, kHaloH = TL::halo_h, kHaloW = TL::halo_w;
@@ -269,7 +269,18 @@ void conv3x3_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, 
     // ---- epilogue: lane = pixel; register quad g of block nb = channels 32 nb + 8 g + 4 half + 0..3
     const int r = r0 + prow, c = c0 + pcol;
     if (r < d.H && c < d.W) {
-        __bf16 *yp = y + ((static_cast<int64_t>(b) * d.H + r) * d.W + c) * d.N + n0 + 4 * half;
+        const int64_t at = ((static_cast<int64_t>(b) * d.H + r) * d.W + c) * d.N + n0 + 4 * half;
+        __bf16 *yp = y + at;
+        // mask (the input gradient of a convolution whose INPUT is a ReLU output): the result is zeroed where mask <= 0 -- that
+        // ReLU's backward, applied where its gradient leaves the chip (linear.ReluToken)
+        bf16x4 mk[NB][4];
+        if (mask) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (n0 + nb * 32 + 8 * g + 4 * half < d.N) mk[nb][g] = *reinterpret_cast<const bf16x4 *>(mask + at + nb * 32 + 8 * g);
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -281,6 +292,7 @@ void conv3x3_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, 
                     for (int i = 0; i < 4; ++i) {
                         float v = acc[nb][4 * g + i] + shift_s[nn + i];
                         if (d.relu) v = v > 0.f ? v : 0.f;
+                        if (mask && !(static_cast<float>(mk[nb][g][i]) > 0.f)) v = 0.f;
                         o[i] = static_cast<__bf16>(v);
                     }
                     *reinterpret_cast<bf16x4 *>(yp + nb * 32 + 8 * g) = o;
@@ -290,7 +302,7 @@ void conv3x3_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ w, 
 }
 
 template <int NB, int WC, int GC>
-hipError_t launch(const void *x, const void *w, const float *shift, void *y, const ConvDims &d, hipStream_t st)
+hipError_t launch(const void *x, const void *w, const float *shift, void *y, const ConvDims &d, hipStream_t st, const void *mask)
 {
     using TL = Tile<WC, GC>;
     constexpr size_t lds = TL::lds(NB);
@@ -313,16 +325,16 @@ hipError_t launch(const void *x, const void *w, const float *shift, void *y, con
     g.xcd_per = (g.ngroups <= 8 && 8 % g.ngroups == 0) ? 8 / g.ngroups : 0;
     const int64_t blocks = g.xcd_per ? 8ll * ((g.tiles + g.xcd_per - 1) / g.xcd_per) : static_cast<int64_t>(g.tiles) * g.ngroups;
     hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), lds, st, static_cast<const __bf16 *>(x),
-                       static_cast<const __bf16 *>(w), shift, static_cast<__bf16 *>(y), g);
+                       static_cast<const __bf16 *>(w), shift, static_cast<__bf16 *>(y), g, static_cast<const __bf16 *>(mask));
     return hipGetLastError();
 }
 
 template <int WC, int GC>
-hipError_t by_width(int nb, const void *x, const void *w, const float *shift, void *y, const ConvDims &d, hipStream_t st)
+hipError_t by_width(int nb, const void *x, const void *w, const float *shift, void *y, const ConvDims &d, hipStream_t st, const void *mask)
 {
-    if (nb == 4) return launch<4, WC, GC>(x, w, shift, y, d, st);
-    if (nb == 2) return launch<2, WC, GC>(x, w, shift, y, d, st);
-    return launch<1, WC, GC>(x, w, shift, y, d, st);
+    if (nb == 4) return launch<4, WC, GC>(x, w, shift, y, d, st, mask);
+    if (nb == 2) return launch<2, WC, GC>(x, w, shift, y, d, st, mask);
+    return launch<1, WC, GC>(x, w, shift, y, d, st, mask);
 }
 
 // The tile shapes built, and what a choice costs.  A workgroup's duration hardly depends on what shares its CU (one alone at 64
@@ -371,18 +383,18 @@ bool conv3x3_supported(int B, int H, int W, int C, int N, const void *x, const v
 }
 
 hipError_t conv3x3_launch(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N, bool relu,
-                          hipStream_t st, bool mirror)
+                          hipStream_t st, bool mirror, const void *mask)
 {
     ConvDims d{B, H, W, C, N, 0, 0, 0, 0, 0, mirror ? 1 : 0, relu ? 1 : 0};
     ProfileScope prof(9, conv_mflop(static_cast<int64_t>(B) * H * W, static_cast<int64_t>(C) * N * 9), st, 18.0 * B * H * W * C * N / 1e6,
                       (2.0 * B * H * W * (C + N) + 18.0 * N * C) / 1e3);
     const Choice c = choose(B, H, W, N);
     switch (c.shape) {
-    case 1: return by_width<16, 1>(c.nb, x, w, shift, y, d, st);
-    case 2: return by_width<16, 2>(c.nb, x, w, shift, y, d, st);
-    case 3: return by_width<8, 4>(c.nb, x, w, shift, y, d, st);
-    case 4: return by_width<8, 2>(c.nb, x, w, shift, y, d, st);
-    default: return by_width<32, 1>(c.nb, x, w, shift, y, d, st);
+    case 1: return by_width<16, 1>(c.nb, x, w, shift, y, d, st, mask);
+    case 2: return by_width<16, 2>(c.nb, x, w, shift, y, d, st, mask);
+    case 3: return by_width<8, 4>(c.nb, x, w, shift, y, d, st, mask);
+    case 4: return by_width<8, 2>(c.nb, x, w, shift, y, d, st, mask);
+    default: return by_width<32, 1>(c.nb, x, w, shift, y, d, st, mask);
     }
 }
 

@@ -17,6 +17,8 @@ import os
 from typing import Dict, List
 
 import torch
+
+from .. import _tune
 import torch.nn.functional as F
 from torch import nn
 
@@ -190,7 +192,7 @@ def conv_bn(x, conv, bn, relu, skip_out=False, relu_token=None, hand_out_token=F
             if pre is not None and pre[0].dtype == dt == x.dtype and (not relu or skip_relu_fusable(
                     pre[1], x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]), pre[0].reshape(pre[0].shape[0], -1))):
                 conv.__dict__.pop("_prefolded", None)
-                return pointwise_conv_skip(x, pre[0], pre[1], relu=relu, relu_token=relu_token)
+                return pointwise_conv_skip(x, pre[0], pre[1], relu=relu, relu_token=relu_token, hand_out_token=hand_out_token)
         return conv_bn(x, conv, bn, relu), x
     if isinstance(bn, FrozenBatchNorm2d) and conv.bias is None:
         scale, shift = bn.affine()
@@ -233,7 +235,7 @@ def conv_bn(x, conv, bn, relu, skip_out=False, relu_token=None, hand_out_token=F
         elif conv3x3_ext.ENABLED and conv3x3_ext.supported(x, w, conv.stride, conv.padding, conv.dilation, conv.groups):
             # stride-1 3x3: implicit GEMM with LDS im2col, shift and ReLU in its epilogue (csrc/conv3x3.hip); forward and
             # input gradient on the kernel, weight gradient with the library
-            return conv3x3_ext.conv3x3(x, w, shift, relu=relu, hand_out_token=hand_out_token and relu)
+            return conv3x3_ext.conv3x3(x, w, shift, relu=relu, hand_out_token=hand_out_token and relu, in_token=relu_token)
         elif relu and bias_act_ext.ENABLED and (x.is_cuda or bias_act_ext._backend is not None):
             # the shift and the ReLU in one pass behind the library convolution (csrc/bias_act.hip) instead of the
             # library's own bias kernel plus a clamp
@@ -250,6 +252,8 @@ def conv_bn(x, conv, bn, relu, skip_out=False, relu_token=None, hand_out_token=F
 
 # (the identity-gradient fusion in Bottleneck.forward; False = the separate elementwise add, for tests)
 _SKIP_FUSE = True
+# conv2's input gradient applies the mask of the ReLU behind conv1 (mdetr_conv3x3_masked); MDETR_TUNE=conv2_mask=0: A-B runs
+_CONV2_TAKES_MASK = _tune.get("conv2_mask", "1") != "0"
 
 
 def _global_hooks():
@@ -281,11 +285,12 @@ class Bottleneck(nn.Module):
         premask = linear._PREMASK and torch.is_grad_enabled() and not (self._forward_hooks or self._forward_pre_hooks or _global_hooks())
         if self.downsample is None and _SKIP_FUSE:
             # (the identity's gradient meets conv1's inside its dgrad GEMM; so does, with a token from the previous block, its ReLU mask)
-            y, skip = conv_bn(x, self.conv1, self.bn1, True, skip_out=True, relu_token=linear.relu_token_of(x) if premask else None)
+            y, skip = conv_bn(x, self.conv1, self.bn1, True, skip_out=True, relu_token=linear.relu_token_of(x) if premask else None,
+                              hand_out_token=premask)             # (conv2 below is the one consumer of conv1's ReLU output)
         else:
             skip = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], False)
             y = conv_bn(x, self.conv1, self.bn1, True)
-        y = conv_bn(y, self.conv2, self.bn2, True, hand_out_token=premask)
+        y = conv_bn(y, self.conv2, self.bn2, True, hand_out_token=premask, relu_token=linear.relu_token_of(y) if (premask and _CONV2_TAKES_MASK) else None)
         pre = self.conv3.__dict__.get("_prefolded")
         if pre is None and not self.conv3.weight.requires_grad and isinstance(self.bn3, FrozenBatchNorm2d) and self.conv3.bias is None \
                 and y.dtype in (torch.bfloat16, torch.float16) and not torch.is_autocast_enabled():

@@ -181,8 +181,9 @@ class _TokenLinearSkip(torch.autograd.Function):
     backbone.py:93-106).  tail: ReLU (relu) followed by Dropout (dropout_p, csrc/tgemm.hip only).  `pos` is a constant (no gradient)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, pos, relu=False, dropout_p=0.0, premask=False, wide_out=False):
+    def forward(ctx, x, weight, bias, pos, relu=False, dropout_p=0.0, premask=False, wide_out=False, out_token=None):
         ctx.premask = bool(premask) and pos is None                 # x is a ReLU output whose producer leaves the mask to this backward
+        ctx.out_token = out_token                                   # (ReluToken) the consumer of y may take over THIS ReLU's backward mask
         ctx.wide_out = bool(wide_out)                               # fp32 result of bf16 operands (`_TokenLinear.forward`)
         q = x if pos is None else x + pos
         q2 = q.reshape(-1, q.shape[-1])
@@ -210,8 +211,8 @@ class _TokenLinearSkip(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy, dskip):
         q, weight = ctx.saved_tensors[:2]
-        if ctx.relu:
-            dy = _act_backward(dy.contiguous(), ctx.saved_tensors[2], ctx.scale)
+        if ctx.relu and not (ctx.out_token is not None and ctx.out_token.premasked and ctx.scale == 1.0):
+            dy = _act_backward(dy.contiguous(), ctx.saved_tensors[2], ctx.scale)       # (premasked: the gradient arrived masked)
         if ctx.wide_out:
             dy = dy.to(q.dtype)                                        # one rounding of the fp32 gradient, as the narrow form receives it
         q2, dy2 = q.reshape(-1, q.shape[-1]), dy.reshape(-1, dy.shape[-1])
@@ -220,10 +221,10 @@ class _TokenLinearSkip(torch.autograd.Function):
             ds2 = dskip.reshape(-1, q.shape[-1]) if dskip is not None else None
             dx = _input_gradient(dy2, weight, ds2, q2 if ctx.premask else None).view_as(q)
         dw, db = _weight_bias_grads(q2, dy2, weight, ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2], ctx.bias_dtype)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def token_linear_skip(x, weight, bias=None, pos=None, relu=False, dropout_p=0.0, relu_token=None, wide_out=False):
+def token_linear_skip(x, weight, bias=None, pos=None, relu=False, dropout_p=0.0, relu_token=None, wide_out=False, out_token=None):
     """-> (token_linear(x + pos, weight, bias[, relu, dropout]), x'): use x' (== x) for everything that follows on the residual path;
     see `_TokenLinearSkip`.  Plain tensors out of it when the fused form does not apply.  relu / dropout_p: the caller asks
     `skip_relu_fusable` / `skip_dropout_fusable` first."""
@@ -235,7 +236,7 @@ def token_linear_skip(x, weight, bias=None, pos=None, relu=False, dropout_p=0.0,
         premask = relu_token is not None and pos is None and x.dtype == torch.bfloat16 and _tgemm_ok(x.reshape(-1, x.shape[-1]), weight, bias)
         if premask:
             relu_token.premasked = True
-        return _TokenLinearSkip.apply(x, weight, bias, pos, relu, dropout_p, premask, wide_out)
+        return _TokenLinearSkip.apply(x, weight, bias, pos, relu, dropout_p, premask, wide_out, out_token if relu else None)
     if dropout_p > 0.0:
         raise RuntimeError("token_linear_skip: ask skip_dropout_fusable before passing dropout_p")
     return token_linear(x if pos is None else x + pos, weight, bias, relu=relu, wide_out=wide_out), x
@@ -424,14 +425,20 @@ def pointwise_conv(x, weight, bias=None, relu=False):
     return y.view(B, H, W, -1).permute(0, 3, 1, 2)
 
 
-def pointwise_conv_skip(x, weight, bias=None, relu=False, relu_token=None):
+def pointwise_conv_skip(x, weight, bias=None, relu=False, relu_token=None, hand_out_token=False):
     """-> (pointwise_conv(x, weight, bias, relu), x'): the 1x1 convolution that opens a residual block together with the tensor the
     identity connection continues from (x' == x) -- the gradient arriving through the identity path is folded into the
     convolution's input-gradient GEMM (beta = 1) instead of a separate 30-60 MB elementwise add per bottleneck
     (`_TokenLinearSkip`; reference torchvision Bottleneck.forward behind lib/models/monodetr/backbone.py:93-106)."""
     B, C, H, W = x.shape
-    y, xs = token_linear_skip(x.permute(0, 2, 3, 1).reshape(B * H * W, C), weight.reshape(weight.shape[0], C), bias, relu=relu, relu_token=relu_token)
-    return y.view(B, H, W, -1).permute(0, 3, 1, 2), xs.view(B, H, W, C).permute(0, 3, 1, 2)
+    # hand_out_token: the (ReLU) result has exactly one consumer, which may apply this ReLU's backward mask itself (`ReluToken`)
+    token = ReluToken() if (_PREMASK and hand_out_token and relu) else None
+    y, xs = token_linear_skip(x.permute(0, 2, 3, 1).reshape(B * H * W, C), weight.reshape(weight.shape[0], C), bias, relu=relu, relu_token=relu_token,
+                              out_token=token)
+    y = y.view(B, H, W, -1).permute(0, 3, 1, 2)
+    if token is not None:
+        y._mdetr_relu_token = token                                 # (a producer on the library route ignores it and masks itself: masking twice is masking once)
+    return y, xs.view(B, H, W, C).permute(0, 3, 1, 2)
 
 
 def pointwise_residual_relu_eligible(x, weight, bias, identity):

@@ -153,3 +153,24 @@ def test_every_block_shape_and_width_gives_the_same_convolution(ext, monkeypatch
     gx, = torch.autograd.grad(ref, x, dy.float())
     close(y.detach(), ref, "y")
     close(x.grad, gx, "dx")
+
+
+def test_input_gradient_takes_over_the_relu_mask_of_its_input(ext):
+    """in_token (linear.ReluToken): the convolution's input is a ReLU output with this convolution as its only consumer -- the input
+    gradient leaves the kernel zeroed where the input is <= 0 (mdetr_conv3x3_masked) and the token tells the producer so."""
+    from monodetr_amd.monodetr.linear import ReluToken
+    g = torch.Generator().manual_seed(77)
+    pre = torch.randn(2, 64, 6, 21, generator=g)
+    x0 = F.relu(pre).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)              # ~half of it zeros
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(2, 64, 6, 21, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    grads = []
+    for token in (None, ReluToken()):
+        x = x0.clone().requires_grad_(True)
+        y = ext.conv3x3(x, w, None, relu=False, in_token=token)
+        y.backward(dy)
+        grads.append(x.grad.clone())
+        assert token is None or token.premasked
+    plain, masked = grads
+    assert torch.equal(masked, torch.where(x0 > 0, plain, torch.zeros_like(plain)))
+    assert (masked != plain).any()
