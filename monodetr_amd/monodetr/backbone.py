@@ -287,6 +287,11 @@ class Bottleneck(nn.Module):
             # (the identity's gradient meets conv1's inside its dgrad GEMM; so does, with a token from the previous block, its ReLU mask)
             y, skip = conv_bn(x, self.conv1, self.bn1, True, skip_out=True, relu_token=linear.relu_token_of(x) if premask else None,
                               hand_out_token=premask)             # (conv2 below is the one consumer of conv1's ReLU output)
+        elif self.downsample is not None and _SKIP_FUSE and x.requires_grad and torch.is_grad_enabled():
+            # a stage's first block: x feeds conv1 and the projection shortcut.  Read in a chain -- the shortcut continues from the x'
+            # conv1 hands back -- the shortcut's input gradient is added inside conv1's input-gradient GEMM (one 30 - 60 MB sum less)
+            y, x2 = conv_bn(x, self.conv1, self.bn1, True, skip_out=True)
+            skip = conv_bn(x2, self.downsample[0], self.downsample[1], False)
         else:
             skip = x if self.downsample is None else conv_bn(x, self.downsample[0], self.downsample[1], False)
             y = conv_bn(x, self.conv1, self.bn1, True)
