@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDETR_ABI_VERSION 11
+#define MDETR_ABI_VERSION 12
 
 /* element types of the floating-point tensors */
 #define MDETR_F32 0
@@ -571,6 +571,10 @@ int mdetr_column_sum_to(int dtype, const void *x, void *out, int out_dtype, void
  */
 int mdetr_conv3x3_forward(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N,
                           int relu, int device, void *stream);
+/* The launch geometry mdetr_conv3x3_forward takes for a shape (host only, no device work): 100 x WC + 10 x GC + NB -- a wave's 32 pixels
+ * are a (32 / WC) x WC block, GC blocks side by side and 4 / GC one below the other form the workgroup's tile, NB x 32 output channels per
+ * workgroup.  Chosen for the fewest ROUNDS of workgroups on 256 CUs, then the cheapest round, then the fewest blocks on empty columns. */
+int mdetr_conv3x3_plan(int B, int H, int W, int N);
 /* The same with a MASK (bf16 [B, H, W, N], 8-byte aligned): y = mask <= 0 ? 0 : act(conv(x, w) + shift).  The input gradient of
  * Bottleneck.conv2 with autograd's threshold_backward of the ReLU behind conv1 -> bn1 (torchvision Bottleneck.forward, `out =
  * self.relu(out)` between conv1 and conv2) applied where the gradient leaves the chip: mask = conv2's input. */

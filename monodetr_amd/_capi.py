@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDETR_LIB_PATH") or os.path.join(_HERE, "libmonodetr_amd.so")
 
 MDETR_F32, MDETR_F64, MDETR_BF16 = 0, 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _c_int, _c_vp = ctypes.c_int, ctypes.c_void_p
 
@@ -61,6 +61,7 @@ SIGNATURES = {
     "mdetr_add_layernorm_partial_rows": (ctypes.c_int64, [ctypes.c_int64]),
     "mdetr_add_layernorm_backward": (_c_int, [_c_int, _c_int] + [_c_vp] * 7 + [ctypes.c_int64, _c_int, ctypes.c_float, ctypes.c_uint64, _c_vp, _c_int, _c_vp]),
     "mdetr_conv3x3_forward": (_c_int, [_c_vp] * 4 + [_c_int] * 6 + [_c_int, _c_vp]),
+    "mdetr_conv3x3_plan": (_c_int, [_c_int] * 4),
     "mdetr_conv3x3_masked": (_c_int, [_c_vp] * 5 + [_c_int] * 6 + [_c_int, _c_vp]),
     "mdetr_conv_taps": (_c_int, [_c_vp] * 5 + [_c_int, _c_int, _c_vp]),
     "mdetr_conv_taps_split": (_c_int, [_c_vp] * 4 + [ctypes.c_int64, _c_vp, _c_int, _c_int, _c_vp]),

@@ -694,6 +694,12 @@ static int conv3x3_any(const char *who, const void *x, const void *w, const floa
     return MDETR_OK;
 }
 
+int mdetr_conv3x3_plan(int B, int H, int W, int N)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || N <= 0) return fail(MDETR_E_ARG, "mdetr_conv3x3_plan: bad sizes");
+    return mdetr::conv3x3_plan(B, H, W, N);
+}
+
 int mdetr_conv3x3_forward(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N,
                           int relu, int device, void *stream)
 {

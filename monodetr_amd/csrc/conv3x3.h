@@ -12,4 +12,7 @@ bool conv3x3_supported(int B, int H, int W, int C, int N, const void *x, const v
 hipError_t conv3x3_launch(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N, bool relu,
                           hipStream_t st, bool mirror = false, const void *mask = nullptr);
 
+// the launcher's choice for a shape: 100 x (columns of a wave's pixel block) + 10 x (blocks side by side) + output-channel blocks of 32
+int conv3x3_plan(int B, int H, int W, int N);
+
 }  // namespace mdetr

@@ -382,6 +382,12 @@ bool conv3x3_supported(int B, int H, int W, int C, int N, const void *x, const v
            static_cast<int64_t>(H) * W * C < (1ll << 30) && static_cast<int64_t>(N) * 9 * C < (1ll << 30);      // (32-bit byte offsets of one image / the weight)
 }
 
+int conv3x3_plan(int B, int H, int W, int N)
+{
+    const Choice c = choose(B, H, W, N);
+    return kShapes[c.shape].wc * 100 + kShapes[c.shape].gc * 10 + c.nb;
+}
+
 hipError_t conv3x3_launch(const void *x, const void *w, const float *shift, void *y, int B, int H, int W, int C, int N, bool relu,
                           hipStream_t st, bool mirror, const void *mask)
 {

@@ -191,3 +191,16 @@ def test_baseline_config_1_runs_on_the_cpu_through_the_c_abi(built_lib):
     for n, p in step.raw_model.named_parameters():
         if p.requires_grad and not any(u in n for u in unused):
             assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+def test_conv3x3_launch_geometry_for_the_resnet_stages(built_lib):
+    """mdetr_conv3x3_plan (host only): the tile shape / channel width csrc/conv3x3.hip takes at B = 8, 384 x 1280 -- chosen for ONE round of
+    workgroups where the stage allows it (layer3: 8 x 16 tiles of 2 x 16 blocks at 64 channels = 480 workgroups on 512 places, no empty
+    block at W = 80) and for no matrix instructions on empty columns (layer4, W = 40: 8-wide blocks).  100 WC + 10 GC + NB."""
+    from monodetr_amd import _capi
+    lib = _capi.lib()
+    plan = lambda H, W, N, B=8: lib.mdetr_conv3x3_plan(B, H, W, N)          # noqa: E731
+    assert plan(96, 320, 64) == 3212 and plan(48, 160, 128) == 3212          # exact fits: 1 x 32 blocks, 4 x 32 tiles, 64 channels
+    assert plan(24, 80, 256) == 1612                                         # layer3 and the depth head
+    assert plan(12, 40, 512) // 100 == 8 and plan(12, 40, 512) % 10 == 1     # layer4: 8-wide blocks, 32 channels (768 workgroups, one round)
+    assert plan(0, 1, 32) < 0
